@@ -97,6 +97,15 @@ int zo_compress_data(const uint8_t *in, uint64_t n, int method,
                      uint8_t *out, uint64_t cap, uint64_t *out_len,
                      uint32_t *crc_out, uint16_t *zip_type);
 
+/* Archive writer either side of the hot path (zada_oracle_zip.c): Zip.Create.Create_Archive /
+ * Add_Stream / Finish on a memory stream, Zip_32 archives only. */
+typedef struct zoz_archive zoz_archive;
+zoz_archive *zo_zip_create(int method);
+int zo_zip_add(zoz_archive *a, const char *entry_name, const uint8_t *data, uint64_t n,
+               uint32_t file_time, int unicode_name);
+int zo_zip_finish(zoz_archive *a, const uint8_t **bytes, uint64_t *len);
+void zo_zip_free(zoz_archive *a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,104 @@
+// hostcheck.cpp -- TEST library (not product code): compiles the host/device logic of
+// zip-ada_amd/csrc/zada_logic.h with g++ so that the arithmetic the GPU kernels run per lane can
+// be checked against the oracle on a machine without a GPU.  Nothing in the product loads this.
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "../../zip-ada_amd/csrc/zada_logic.h"
+using namespace zada;
+
+extern "C" {
+
+void hc_llhc(const uint32_t *freq, int n, int max_bits, uint8_t *bl) {
+  static LlhcScratch S;
+  llhc_serial(freq, n, max_bits, bl, &S);
+}
+void hc_tweak(uint32_t *counts, int n) { uint8_t good[320]; tweak_for_better_rle(counts, n, good); }
+void hc_patch_dist(uint32_t *sd) { patch_dist_stats(sd); }
+uint32_t hc_header_bits(const uint8_t *ll, const uint8_t *dd, uint8_t *truc_bl20) {
+  static LlhcScratch S; HeaderPlan hp;
+  header_plan(ll, dd, &hp, &S);
+  for (int i = 0; i < 19; i++) truc_bl20[i] = hp.truc_bl[i];
+  truc_bl20[19] = hp.a_non_zero;
+  return hp.bits;
+}
+void hc_canonical(const uint8_t *bl, int n, uint16_t *codes) { canonical_codes(bl, n, codes); }
+int hc_len_symbol(int len) { return len_symbol(len); }
+int hc_len_extra_bits(int len) { return len_extra_bits(len); }
+uint32_t hc_len_extra_val(int len) { return len_extra_val(len); }
+int hc_dist_symbol(int d) { return dist_symbol(d); }
+int hc_dist_extra_bits(int d) { return dist_extra_bits(d); }
+uint32_t hc_dist_extra_val(int d) { return dist_extra_val(d); }
+
+// Match tables by a deliberately simple sequential model (independent of the GPU kernel):
+// absolute positions, head/prev as in INSERT_STRING, bytes beyond n never match.
+static void match_tables(const uint8_t *in, uint64_t n, const LzConfig &cfg, std::vector<uint32_t> &MF, std::vector<uint32_t> &MQ) {
+  std::vector<int64_t> prev(n, -1), head(32768, -1);
+  MF.assign(n, 0); MQ.assign(n, 0);
+  for (uint64_t p = 0; p + 2 < n; p++) {
+    uint32_t h = (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFF;
+    prev[p] = head[h]; head[h] = (int64_t)p;
+    int la = (n - p) < 258 ? (int)(n - p) : 258;
+    int nice = cfg.nice < la ? cfg.nice : la;
+    int best = 2; uint32_t bd = 0; int steps = 0; bool haveq = false; uint32_t rq = 0;
+    int64_t c = prev[p];
+    while (c > 0) {
+      uint64_t dist = p - (uint64_t)c;
+      if (dist > (uint64_t)(steps == 0 ? MAX_DIST : MAX_DIST - 1)) break;
+      steps++;
+      int len = 0;
+      while (len < la && in[c + len] == in[p + len]) len++;
+      if (len > best) { best = len; bd = (uint32_t)dist; if (len >= nice) break; }
+      if (steps == cfg.chain / 4) { haveq = true; rq = best >= 3 ? ((uint32_t)best << 16) | bd : 0; }
+      if (steps == cfg.chain) break;
+      c = prev[c];
+    }
+    MF[p] = best >= 3 ? ((uint32_t)best << 16) | bd : 0;
+    MQ[p] = haveq ? rq : MF[p];
+  }
+}
+
+// Emulates k_parse_spec / k_parse_fix (to the fixpoint) / k_tok_compact sequentially.
+uint64_t hc_chunked_tokens(const uint8_t *in, uint64_t n, int level, uint32_t chunk, uint32_t *tokens, uint64_t cap, int *rounds_out) {
+  if (n == 0) return 0;
+  LzConfig cfg = lz_config(level);
+  std::vector<uint32_t> MF, MQ;
+  match_tables(in, n, cfg, MF, MQ);
+  ParseIO io{in, n, MF.data(), MQ.data(), cfg};
+  const uint32_t nch = (uint32_t)((n + chunk - 1) / chunk), stride = chunk + 1024;
+  std::vector<uint32_t> spec((size_t)nch * stride), fix((size_t)nch * stride), scnt(nch), fcnt(nch), take(nch), u0(nch);
+  std::vector<uint32_t> Fb(n / 32 + 2, 0xDEADBEEF), Lb(n / 32 + 2, 0xDEADBEEF);
+  std::vector<ExitState> sex(nch), tex(nch);
+  for (uint32_t k = 0; k < nch; k++) { uint32_t nt = 0; parse_spec_chunk(io, k, chunk, &spec[(size_t)k * stride], nt, Fb.data(), Lb.data(), sex[k]); scnt[k] = nt; }
+  tex = sex;
+  std::vector<uint8_t> dirty(nch, 1), nd(nch, 0);
+  int rounds = 0;
+  for (;;) {
+    std::fill(nd.begin(), nd.end(), 0);
+    uint32_t changed = 0;
+    std::vector<ExitState> snapshot = tex;      // a launch sees the previous round's exits (or newer)
+    for (uint32_t k = 0; k < nch; k++) {
+      if (!dirty[k]) continue;
+      ExitState entry{0, SYNC_F};
+      if (k > 0) entry = snapshot[k - 1];
+      ExitState ne; uint32_t nt = 0, tk = 0, uu = 0;
+      parse_fix_chunk(io, k, chunk, entry, &spec[(size_t)k * stride], scnt[k], Fb.data(), Lb.data(), sex[k], &fix[(size_t)k * stride], nt, tk, uu, ne);
+      fcnt[k] = nt; take[k] = tk; u0[k] = uu;
+      ExitState old = tex[k];
+      tex[k] = ne;
+      if (k + 1 < nch && (ne.pos != old.pos || ne.kind != old.kind)) { nd[k + 1] = 1; changed++; }
+    }
+    rounds++;
+    if (!changed) break;
+    dirty = nd;
+  }
+  if (rounds_out) *rounds_out = rounds;
+  uint64_t T = 0;
+  for (uint32_t k = 0; k < nch; k++) {
+    for (uint32_t i = 0; i < fcnt[k]; i++) { if (T < cap) tokens[T] = fix[(size_t)k * stride + i]; T++; }
+    for (uint32_t i = take[k]; i < scnt[k]; i++) { if (T < cap) tokens[T] = spec[(size_t)k * stride + i]; T++; }
+  }
+  return T;
+}
+
+}  // extern "C"

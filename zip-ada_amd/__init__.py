@@ -1,0 +1,225 @@
+"""zip-ada_amd -- MI355X-native Deflate encoder behind the Zip-Ada `Zip.Compress` interface.
+
+Host-side mirror of the reference's interface for the hot path (the reference is Ada; no Ada
+toolchain exists in the build image, so the host side above the C ABI is written here and in
+`csrc/`; see INTEGRATION.md for the Ada shim a maintainer would add):
+
+    Compression_Method        zip_lib/zip-compress.ads:59-122   -> `Method`
+    Zip.Compress.Deflate      zip_lib/zip-compress-deflate.ads:36-46 -> `Encoder.deflate`
+    Zip.Compress.Compress_Data zip_lib/zip-compress.ads:169-180 -> `Encoder.compress_data`
+    Zip.Create (Create_Archive / Add_Stream / Finish) zip_lib/zip-create.ads:75-211 -> `ZipCreate`
+
+All compute runs in libzada_hip.so (hand-written HIP for gfx950).  There is no CPU fallback:
+loading fails loudly when the library or a GPU is missing.
+"""
+import ctypes
+import os
+import struct
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzada_hip.so")
+
+
+class Method:
+    """Compression_Method'Pos, zip-compress.ads:59-122 (Deflation_Method subset)."""
+    Store = 0
+    Deflate_Fixed = 6
+    Deflate_0 = 7
+    Deflate_1 = 8
+    Deflate_2 = 9
+    Deflate_3 = 10
+
+
+class ZadaError(RuntimeError):
+    pass
+
+
+class CompressionInefficient(Exception):
+    """zip-compress.ads:237 -- compressed size >= uncompressed size."""
+
+
+class UserAbort(Exception):
+    """zip-compress.ads:149."""
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libzada_hip.so.  Raises ZadaError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZadaError("libzada_hip.so is missing: run __graft_entry__.build() "
+                        "(make -C zip-ada_amd/csrc). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32p, u64p, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int
+    L.zada_create.restype = vp
+    L.zada_create.argtypes = [i32]
+    L.zada_destroy.argtypes = [vp]
+    L.zada_last_error.restype = ctypes.c_char_p
+    L.zada_last_error.argtypes = [vp]
+    L.zada_version.restype = ctypes.c_char_p
+    L.zada_deflate.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, vp, vp]
+    L.zada_deflate_device.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
+    L.zada_compress_data.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, ctypes.POINTER(ctypes.c_uint16)]
+    L.zada_lz77_tokens.argtypes = [vp, i32, vp, u64, vp, u64, u64p]
+    L.zada_last_blocks.argtypes = [vp, vp, u64, u64p]
+    L.zada_last_timing.argtypes = [vp, vp, vp, i32]
+    L.zada_silesia_mix.argtypes = [u64, ctypes.c_uint, u64, u64, vp]
+    _lib = L
+    return L
+
+
+FEEDBACK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+
+
+def _addr(buf):
+    """Address of a bytes / bytearray / numpy array / ctypes buffer without copying."""
+    if isinstance(buf, bytes):
+        return ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p).value
+    if hasattr(buf, "ctypes"):
+        return buf.ctypes.data
+    return ctypes.addressof((ctypes.c_char * len(buf)).from_buffer(buf))
+
+
+class Encoder:
+    """One context = one GPU + stream + workspace (single owner, like one Ada task)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.ctx = self.lib.zada_create(device)
+        if not self.ctx:
+            raise ZadaError("zada_create(%d) failed: no usable gfx950 device (no CPU fallback)" % device)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.zada_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, rc, what):
+        raise ZadaError("%s failed: rc=%d (%s)" % (what, rc, self.lib.zada_last_error(self.ctx).decode()))
+
+    def deflate(self, data, method=Method.Deflate_3, crc=0xFFFFFFFF, feedback=None):
+        """Zip.Compress.Deflate.  Returns (raw deflate bytes, running CRC register).
+        Raises CompressionInefficient when compression_ok would be False."""
+        n = len(data)
+        out = ctypes.create_string_buffer(n + 64)
+        ol = ctypes.c_uint64(0)
+        c = ctypes.c_uint32(crc)
+        cb = FEEDBACK_FN(lambda pct, _u: 1 if feedback(pct) else 0) if feedback else None
+        rc = self.lib.zada_deflate(self.ctx, method, _addr(data) if n else None, n, ctypes.addressof(out), n + 64,
+                                   ctypes.byref(ol), ctypes.byref(c), ctypes.cast(cb, ctypes.c_void_p) if cb else None, None)
+        if rc == 1:
+            raise CompressionInefficient()
+        if rc == 2:
+            raise UserAbort()
+        if rc != 0:
+            self._err(rc, "zada_deflate")
+        return out.raw[:ol.value], c.value
+
+    def deflate_device(self, d_in_ptr, n, d_out_ptr, cap, method=Method.Deflate_3, crc=0xFFFFFFFF):
+        """Device-resident variant (pointers are HBM addresses, e.g. torch tensor .data_ptr()).
+        Returns (rc, out_len, crc); rc 1 = inefficient."""
+        ol = ctypes.c_uint64(0)
+        c = ctypes.c_uint32(crc)
+        rc = self.lib.zada_deflate_device(self.ctx, method, d_in_ptr, n, d_out_ptr, cap, ctypes.byref(ol), ctypes.byref(c))
+        if rc < 0:
+            self._err(rc, "zada_deflate_device")
+        return rc, ol.value, c.value
+
+    def compress_data(self, data, method=Method.Deflate_3):
+        """Zip.Compress.Compress_Data (single method, no password): returns
+        (payload bytes, final CRC-32, zip_type) with the Store fallback applied."""
+        n = len(data)
+        if method == Method.Store:
+            import zlib  # CRC of stored data only; not on the Deflate path
+            return bytes(data), zlib.crc32(data) & 0xFFFFFFFF, 0
+        out = ctypes.create_string_buffer(n + 64)
+        ol = ctypes.c_uint64(0)
+        c = ctypes.c_uint32(0)
+        zt = ctypes.c_uint16(0)
+        rc = self.lib.zada_compress_data(self.ctx, method, _addr(data) if n else None, n, ctypes.addressof(out), n + 64,
+                                         ctypes.byref(ol), ctypes.byref(c), ctypes.byref(zt))
+        if rc != 0:
+            self._err(rc, "zada_compress_data")
+        return out.raw[:ol.value], c.value, zt.value
+
+    def lz77_tokens(self, data, method=Method.Deflate_3):
+        import numpy as np
+        n = len(data)
+        tok = np.zeros(n + 8, dtype=np.uint32)
+        nt = ctypes.c_uint64(0)
+        rc = self.lib.zada_lz77_tokens(self.ctx, method, _addr(data) if n else None, n, tok.ctypes.data, n + 8, ctypes.byref(nt))
+        if rc != 0:
+            self._err(rc, "zada_lz77_tokens")
+        return tok[:nt.value]
+
+    def last_blocks(self):
+        import numpy as np
+        nb = ctypes.c_uint64(0)
+        self.lib.zada_last_blocks(self.ctx, None, 0, ctypes.byref(nb))
+        rec = np.zeros((max(nb.value, 1), 4), dtype=np.uint64)
+        self.lib.zada_last_blocks(self.ctx, rec.ctypes.data, nb.value, ctypes.byref(nb))
+        return rec[:nb.value]
+
+    def last_timing(self):
+        names = (ctypes.c_char_p * 64)()
+        ms = (ctypes.c_float * 64)()
+        k = self.lib.zada_last_timing(self.ctx, ctypes.cast(names, ctypes.c_void_p), ctypes.cast(ms, ctypes.c_void_p), 64)
+        return [(names[i].decode(), ms[i]) for i in range(k)]
+
+
+def silesia_mix(nbytes, seed=0x5A1E51A, class_mask=0x1F, offset=0):
+    """Deterministic synthetic corpus (csrc/silesia_mix.c), as a numpy uint8 array."""
+    import numpy as np
+    L = load_library()
+    b = np.zeros(nbytes, dtype=np.uint8)
+    if nbytes:
+        L.zada_silesia_mix(seed, class_mask, offset, nbytes, b.ctypes.data)
+    return b
+
+
+class ZipCreate:
+    """Zip.Create on a memory stream: Create_Archive / Add_Stream / Finish
+    (zip_lib/zip-create.adb:36-58, 194-297, 645-756; headers zip-headers.adb:168-195, 244-276,
+    494-511).  Zip_32 archives only."""
+
+    DEFAULT_TIME = 16789 * 65536  # zip_streams.ads:223
+
+    def __init__(self, encoder, method=Method.Deflate_3):
+        self.enc, self.method = encoder, method
+        self.buf = bytearray()
+        self.entries = []
+
+    @staticmethod
+    def _local(e):
+        return struct.pack("<4sHHHIIIIHH", b"PK\x03\x04", 10, e["flag"], e["zip_type"], e["time"], e["crc"],
+                           e["csize"], e["usize"], len(e["name"]), 0)
+
+    def add_stream(self, name, data, file_time=None, unicode_name=True):
+        nm = name.replace("\\", "/").encode("utf-8")
+        payload, crc, zt = self.enc.compress_data(data, self.method)
+        e = dict(name=nm, flag=0x0800 if unicode_name else 0, zip_type=zt, time=self.DEFAULT_TIME if file_time is None else file_time,
+                 crc=crc, csize=len(payload), usize=len(data), offset=len(self.buf))
+        if e["usize"] >= 0xFFFFFFFF - (1 << 17) or e["offset"] + e["csize"] >= 0xFFFFFFFF - (1 << 17) or len(self.entries) >= 65534:
+            raise ZadaError("Zip_64 archives are not implemented")
+        self.buf += self._local(e) + nm + payload
+        self.entries.append(e)
+        return e["csize"], zt
+
+    def finish(self):
+        cd_off = len(self.buf)
+        for e in self.entries:
+            self.buf += struct.pack("<4sHHHHIIIIHHHHHII", b"PK\x01\x02", 23, 10, e["flag"], e["zip_type"], e["time"], e["crc"],
+                                    e["csize"], e["usize"], len(e["name"]), 0, 0, 0, 0, 0, e["offset"]) + e["name"]
+        cd_size = len(self.buf) - cd_off
+        self.buf += struct.pack("<4sHHHHIIH", b"PK\x05\x06", 0, 0, len(self.entries), len(self.entries), cd_size, cd_off, 0)
+        return bytes(self.buf)

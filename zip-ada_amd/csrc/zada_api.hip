@@ -1,0 +1,353 @@
+// zada_api.hip -- C ABI (include/zada.h), context / workspace management, CRC-32 kernel and the
+// Compress_Data wrapper (Store fallback).  Host code only orchestrates: every byte of LZ77,
+// Huffman and CRC arithmetic runs in the HIP kernels of zada_lz.hip / zada_huff.hip / here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "../../include/zada.h"
+#include "zada_internal.h"
+
+struct zada_ctx { zada::Ctx c; };
+
+namespace zada {
+
+int hip_check(Ctx *c, hipError_t e, const char *what) {
+  if (e == hipSuccess) return 0;
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  c->err = buf;
+  return ZADA_E_HIP_;
+}
+
+void Ctx::tbegin() {
+  marks.clear();
+  timing.clear();
+}
+void Ctx::tmark(const char *name) {
+  if (!timing_on) return;
+  size_t k = marks.size();
+  if (k >= ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); ev_pool.push_back(e); }
+  hipEventRecord(ev_pool[k], stream);
+  marks.push_back({name, ev_pool[k]});
+}
+void Ctx::tend() {
+  if (!timing_on || marks.empty()) return;
+  hipEventSynchronize(marks.back().second);
+  for (size_t i = 1; i < marks.size(); i++) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second);
+    timing.push_back({marks[i].first, ms});
+  }
+}
+
+template <typename T>
+static int dalloc(Ctx *c, T **p, uint64_t count) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+  if (e != hipSuccess) { hip_check(c, e, "hipMalloc"); return ZADA_E_NOMEM; }
+  c->ws.allocs.push_back(q);
+  *p = (T *)q;
+  return 0;
+}
+
+static void free_workspace(Ctx *c) {
+  for (void *p : c->ws.allocs) hipFree(p);
+  c->ws = Workspace();
+}
+
+int ensure_workspace(Ctx *c, uint64_t n) {
+  Workspace &W = c->ws;
+  if (W.cap_n >= n && W.cap_n > 0) return 0;
+  free_workspace(c);
+  uint64_t cap = n < (1u << 20) ? (1u << 20) : n;
+  cap = (cap + 65535) & ~65535ull;
+  const uint64_t nch = cap / PCHUNK + 2, nseg32 = cap / 32768 + 2, nflush = cap / FLUSH + 2;
+  int rc = 0;
+#define A(ptr, cnt) if (!rc) rc = dalloc(c, &W.ptr, (cnt))
+  A(in, cap + IN_PAD + 64);
+  A(prevd, cap + IN_PAD);
+  A(tails, nseg32 * 32768);
+  A(MF, cap + 64);
+  A(MQ, cap + 64);
+  A(spec_tok, nch * PTOK_STRIDE);
+  A(fix_tok, nch * PTOK_STRIDE);
+  A(spec_cnt, nch); A(fix_cnt, nch); A(take_from, nch); A(start_pos, nch); A(counts, nch); A(offsets, nch);
+  A(scan_sums, nch / 1024 + 1024);
+  A(Fbits, cap / 32 + 64); A(Lbits, cap / 32 + 64);
+  A(spec_exits, nch); A(true_exits, nch);
+  A(dirty[0], nch + 64); A(dirty[1], nch + 64);
+  A(n_changed, 16);
+  A(descr, nflush * SLOTS * 320);
+  A(seg_nblk, nflush); A(seg_cut, nflush * MAXBLK_PER_SEG); A(seg_blk_off, nflush);
+  W.cap_blocks = nflush * MAXBLK_PER_SEG;
+  A(blocks, W.cap_blocks);
+  A(binfo, W.cap_blocks);
+  A(emit, W.cap_blocks);
+  A(codes, (W.cap_blocks + 1) * 320);
+  W.cap_pieces = cap / 32768 + W.cap_blocks + 64;
+  A(pieces, W.cap_pieces);
+  W.cap_tiles = cap / TILE + W.cap_blocks + 64;
+  A(tile_block, W.cap_tiles); A(tile_bitpos, W.cap_tiles); A(tile_bits, W.cap_tiles);
+  A(chooser, 1);
+  A(crc_part, nch);
+  W.cap_out = cap + cap / 1024 + 4096;
+  A(out, W.cap_out);
+#undef A
+  if (rc) { free_workspace(c); return rc; }
+  W.atoms = W.MF; W.apos = W.MQ;     // the atom arrays reuse the match tables (dead after the parse)
+  W.cap_n = cap;
+  // the input pad must be zero for the match finder's over-reads
+  hipMemsetAsync(W.in, 0, cap + IN_PAD + 64, c->stream);
+  return hip_check(c, hipStreamSynchronize(c->stream), "workspace init");
+}
+
+// --------------------------------------------------------------------------------------------
+// CRC-32 (zip-crc_crypto.adb:31-76): per-chunk raw registers on the GPU, GF(2) combine on the host
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_crc_chunks(const uint8_t *__restrict__ in, uint64_t n, uint32_t nch, uint32_t *__restrict__ part) {
+  __shared__ uint32_t tab[256];
+  {
+    uint32_t l = threadIdx.x;
+    for (int b = 0; b < 8; b++) l = (l & 1) ? (l >> 1) ^ 0xEDB88320u : l >> 1;      // Prepare_table :31-47
+    tab[threadIdx.x] = l;
+  }
+  __syncthreads();
+  uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nch) return;
+  uint64_t p0 = (uint64_t)k * PCHUNK, p1 = p0 + PCHUNK < n ? p0 + PCHUNK : n;
+  uint32_t r = 0;                                        // linear part: register starts at 0
+  const uint32_t *w = (const uint32_t *)(in + p0);
+  uint64_t len = p1 - p0, i = 0;
+  for (; i + 4 <= len; i += 4) {
+    uint32_t x = w[i >> 2];
+    r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;        // Update :49-60, one byte at a time
+    r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;
+    r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;
+    r = tab[(r ^ x) & 0xFF] ^ (r >> 8);
+  }
+  for (; i < len; i++) r = tab[(r ^ in[p0 + i]) & 0xFF] ^ (r >> 8);
+  part[k] = r;
+}
+
+// operator "advance the raw register over `len` zero bytes" as a 32x32 GF(2) matrix
+static void gf2_square(uint32_t *sq, const uint32_t *m) {
+  for (int i = 0; i < 32; i++) { uint32_t v = m[i], s = 0; for (int j = 0; v; j++, v >>= 1) if (v & 1) s ^= m[j]; sq[i] = s; }
+}
+static uint32_t gf2_apply(const uint32_t *m, uint32_t v) { uint32_t s = 0; for (int j = 0; v; j++, v >>= 1) if (v & 1) s ^= m[j]; return s; }
+static void zero_advance_matrix(uint64_t len, uint32_t *out) {
+  uint32_t op[32], tmp[32], acc[32];
+  // one zero BIT: r' = (r >> 1) ^ (r & 1 ? poly : 0)
+  op[0] = 0xEDB88320u;
+  for (int i = 1; i < 32; i++) op[i] = 1u << (i - 1);
+  for (int i = 0; i < 32; i++) acc[i] = 1u << i;      // identity
+  uint64_t bits = len * 8;
+  while (bits) {
+    if (bits & 1) { for (int i = 0; i < 32; i++) tmp[i] = gf2_apply(op, acc[i]); memcpy(acc, tmp, sizeof acc); }
+    gf2_square(tmp, op); memcpy(op, tmp, sizeof op);
+    bits >>= 1;
+  }
+  memcpy(out, acc, sizeof acc);
+}
+
+int crc_stage(Ctx *c, uint64_t n, uint32_t *crc_inout) {
+  if (n == 0) return 0;
+  Workspace &W = c->ws;
+  const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
+  hipLaunchKernelGGL(k_crc_chunks, dim3((nch + 255) / 256), dim3(256), 0, c->stream, W.in, n, nch, W.crc_part);
+  std::vector<uint32_t> part(nch);
+  hipMemcpyAsync(part.data(), W.crc_part, (size_t)nch * 4, hipMemcpyDeviceToHost, c->stream);
+  if (hip_check(c, hipStreamSynchronize(c->stream), "crc")) return ZADA_E_HIP_;
+  uint32_t Mfull[32], Mlast[32];
+  zero_advance_matrix(PCHUNK, Mfull);
+  uint64_t lastlen = n - (uint64_t)(nch - 1) * PCHUNK;
+  zero_advance_matrix(lastlen, Mlast);
+  uint32_t r = *crc_inout;
+  for (uint32_t k = 0; k < nch; k++) r = gf2_apply(k + 1 == nch ? Mlast : Mfull, r) ^ part[k];
+  *crc_inout = r;
+  return 0;
+}
+
+static int method_level(int method) {
+  switch (method) {
+    case ZADA_DEFLATE_FIXED: return 4;       // LZ77_choice, zip-compress-deflate.adb:1573-1579
+    case ZADA_DEFLATE_0: return 0;
+    case ZADA_DEFLATE_1: return 6;
+    case ZADA_DEFLATE_2: return 8;
+    case ZADA_DEFLATE_3: return 10;
+    default: return -1;
+  }
+}
+
+// core: input already in W.in[0..n) (pad zeroed); result in W.out
+static int deflate_core(Ctx *c, int method, uint64_t n, uint64_t *out_len, uint32_t *crc_inout, zada_feedback_fn fb, void *user) {
+  Workspace &W = c->ws;
+  hipStream_t st = c->stream;
+  const int level = method_level(method);
+  if (level < 0) { c->err = "unsupported method"; return ZADA_E_INVALID; }
+  if (fb && fb(0, user)) return ZADA_ABORTED;
+  c->tbegin();
+  c->tmark("begin");
+  hipMemsetAsync(W.in + n, 0, IN_PAD, st);
+  hipMemsetAsync(W.prevd + (n >= 2 ? n - 2 : 0), 0, 2 * 64, st);
+  hipMemsetAsync(W.out, 0, n + n / 1024 + 4096 < W.cap_out ? n + n / 1024 + 4096 : W.cap_out, st);
+  uint32_t crc = crc_inout ? *crc_inout : 0xFFFFFFFFu;
+  int rc = crc_stage(c, n, &crc);
+  if (rc) return rc;
+  c->tmark("crc");
+  if (fb && fb(5, user)) return ZADA_ABORTED;
+  uint32_t T = 0;
+  rc = lz_stage(c, level, n, &T);
+  if (rc) return rc;
+  if (fb && fb(70, user)) return ZADA_ABORTED;
+  uint64_t total_bits = 0;
+  rc = huff_stage(c, method, n, T, &total_bits);
+  if (rc) return rc;
+  if (hip_check(c, hipStreamSynchronize(st), "deflate")) return ZADA_E_HIP_;
+  c->tmark("end");
+  c->tend();
+  if (fb && fb(100, user)) return ZADA_ABORTED;
+  *out_len = (total_bits + 7) / 8;
+  if (crc_inout) *crc_inout = crc;
+  // Compression_inefficient, zip-compress.adb:479-486: final size >= input size
+  return (*out_len >= n) ? ZADA_INEFFICIENT : ZADA_OK;
+}
+
+}  // namespace zada
+
+using namespace zada;
+
+extern "C" {
+
+const char *zada_version(void) { return "zada-hip 0.1 (gfx950)"; }
+
+zada_ctx *zada_create(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  zada_ctx *z = new (std::nothrow) zada_ctx();
+  if (!z) return nullptr;
+  z->c.device = device;
+  if (hipStreamCreate(&z->c.stream) != hipSuccess) { delete z; return nullptr; }
+  return z;
+}
+
+void zada_destroy(zada_ctx *z) {
+  if (!z) return;
+  hipSetDevice(z->c.device);
+  hipStreamSynchronize(z->c.stream);
+  for (void *p : z->c.ws.allocs) hipFree(p);
+  for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
+  hipStreamDestroy(z->c.stream);
+  delete z;
+}
+
+const char *zada_last_error(const zada_ctx *z) { return z ? z->c.err.c_str() : "no context"; }
+
+static int prepare(zada_ctx *z, uint64_t n) {
+  if (!z) return ZADA_E_INVALID;
+  if (n >= (1ull << 31) - 65536) { z->c.err = "stream too large for one call"; return ZADA_E_TOO_LARGE; }
+  if (hipSetDevice(z->c.device) != hipSuccess) return ZADA_E_HIP;
+  return ensure_workspace(&z->c, n);
+}
+
+int zada_deflate(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,
+                 uint32_t *crc_inout, zada_feedback_fn fb, void *user) {
+  int rc = prepare(z, n);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  if (n) hipMemcpyAsync(c->ws.in, in, n, hipMemcpyHostToDevice, c->stream);
+  uint64_t ol = 0;
+  rc = deflate_core(c, method, n, &ol, crc_inout, fb, user);
+  if (rc < 0 || rc == ZADA_ABORTED) return rc;
+  if (out_len) *out_len = ol;
+  if (rc == ZADA_OK) {
+    if (ol > cap) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
+    hipMemcpyAsync(out, c->ws.out, ol, hipMemcpyDeviceToHost, c->stream);
+    if (hip_check(c, hipStreamSynchronize(c->stream), "copy out")) return ZADA_E_HIP;
+  }
+  return rc;
+}
+
+int zada_deflate_device(zada_ctx *z, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len,
+                        uint32_t *crc_inout) {
+  int rc = prepare(z, n);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  if (n) hipMemcpyAsync(c->ws.in, d_in, n, hipMemcpyDeviceToDevice, c->stream);
+  uint64_t ol = 0;
+  rc = deflate_core(c, method, n, &ol, crc_inout, nullptr, nullptr);
+  if (rc < 0) return rc;
+  if (out_len) *out_len = ol;
+  if (rc == ZADA_OK) {
+    if (ol > cap) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
+    hipMemcpyAsync(d_out, c->ws.out, ol, hipMemcpyDeviceToDevice, c->stream);
+    if (hip_check(c, hipStreamSynchronize(c->stream), "copy out")) return ZADA_E_HIP;
+  }
+  return rc;
+}
+
+int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
+                       const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc) {
+  int worst = 0;
+  for (int i = 0; i < count; i++) {
+    rc[i] = zada_deflate(z, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr);
+    if (rc[i] < 0) worst = rc[i];
+  }
+  return worst;
+}
+
+int zada_compress_data(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,
+                       uint32_t *crc_out, uint16_t *zip_type) {
+  uint32_t crc = 0xFFFFFFFFu;                                   // Init, zip-compress.adb:144
+  int rc = zada_deflate(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr);
+  if (rc < 0 || rc == ZADA_ABORTED) return rc;
+  *zip_type = 8;
+  crc = ~crc;                                                   // Final :218
+  if (rc == ZADA_INEFFICIENT) {                                 // :224-237 Store_data; the CRC of the same bytes is unchanged
+    if (cap < n) { z->c.err = "output buffer too small"; return ZADA_E_INVALID; }
+    memcpy(out, in, n);
+    *out_len = n; *zip_type = 0;
+  }
+  *crc_out = crc;
+  return ZADA_OK;
+}
+
+int zada_lz77_tokens(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint32_t *tokens, uint64_t cap, uint64_t *ntok) {
+  int rc = prepare(z, n);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  const int level = method_level(method);
+  if (level < 0) return ZADA_E_INVALID;
+  if (n) hipMemcpyAsync(c->ws.in, in, n, hipMemcpyHostToDevice, c->stream);
+  hipMemsetAsync(c->ws.in + n, 0, IN_PAD, c->stream);
+  hipMemsetAsync(c->ws.prevd + (n >= 2 ? n - 2 : 0), 0, 2 * 64, c->stream);
+  c->tbegin(); c->tmark("begin");
+  uint32_t T = 0;
+  rc = lz_stage(c, level, n, &T);
+  if (rc) return rc;
+  c->tmark("end"); c->tend();
+  *ntok = T;
+  uint64_t k = T < cap ? T : cap;
+  if (k) hipMemcpyAsync(tokens, c->ws.atoms, k * 4, hipMemcpyDeviceToHost, c->stream);
+  return hip_check(c, hipStreamSynchronize(c->stream), "tokens out") ? ZADA_E_HIP : ZADA_OK;
+}
+
+int zada_last_blocks(zada_ctx *z, uint64_t *rec, uint64_t cap_blocks, uint64_t *nblocks) {
+  if (!z) return ZADA_E_INVALID;
+  uint64_t nb = z->c.last_blocks.size() / 4;
+  *nblocks = nb;
+  uint64_t k = nb < cap_blocks ? nb : cap_blocks;
+  if (k) memcpy(rec, z->c.last_blocks.data(), k * 4 * sizeof(uint64_t));
+  return ZADA_OK;
+}
+
+int zada_last_timing(zada_ctx *z, const char **names, float *ms, int cap) {
+  if (!z) return 0;
+  int k = 0;
+  for (auto &t : z->c.timing) { if (k >= cap) break; names[k] = t.first; ms[k] = t.second; k++; }
+  return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,646 @@
+// zada_huff.hip -- entropy stage on gfx950: the "Taillaule" block splitter, block-format
+// chooser, Huffman code construction and bit emission of zip_lib/zip-compress-deflate.adb,
+// re-expressed over ONE global array of LZ atoms (token + byte position):
+//
+//   k_window_descr   every descriptor the scanner can ask for (initial window per 65536-atom
+//                    flush :1338-1360, sliding windows every 750 atoms :1372), one wave each:
+//                    histogram (Get_statistics :953-976) + length-limited code lengths
+//   k_cut_scan       Scan_and_send_from_main_buffer's similarity walk (:1363-1401), one wave
+//                    per flush; emits the cut positions = candidate blocks
+//   k_block_analyze  per candidate block: statistics, both descriptor variants (:1213-1219),
+//                    header costs (:549-704) and data costs (:1147-1209)
+//   k_choose         the one inherently sequential step: the format decision chain of
+//                    Send_as_block (:1222-1268) + Mark_new_block (:999-1007) + stream epilogue
+//                    (:1613-1635), a single wave walking the block table; assigns bit offsets
+//   k_block_codes / k_tile_bits / k_tile_scan / k_emit_tiles / k_emit_headers / k_copy_pieces
+//                    parallel emission: per-atom (code, length) -> prefix sums -> bit packing
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zada_logic.h"
+#include "zada_internal.h"
+
+namespace zada {
+
+// --------------------------------------------------------------------------------------------
+// helpers
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atom_symbols(uint32_t t, int &ls, int &ds) {
+  if (tok_is_match(t)) { ls = len_symbol((int)((t >> 16) & 0x1FF)); ds = dist_symbol((int)(t & 0xFFFF)); }
+  else { ls = (int)(t & 0xFF); ds = -1; }
+}
+
+__device__ __forceinline__ void put_bits_global(uint32_t *out32, uint64_t pos, uint32_t value, int nbits) {
+  if (nbits <= 0) return;
+  uint64_t w = pos >> 5; int sh = (int)(pos & 31);
+  uint64_t v = (uint64_t)value << sh;
+  atomicOr(&out32[w], (uint32_t)v);
+  if (sh + nbits > 32) atomicOr(&out32[w + 1], (uint32_t)(v >> 32));
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// --------------------------------------------------------------------------------------------
+// k_window_descr : one wave per (flush segment, slot)
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_window_descr(const uint32_t *__restrict__ atoms, uint32_t T, uint32_t kstep,
+                                                     uint8_t *__restrict__ descr) {
+  __shared__ uint32_t hist[320];
+  __shared__ uint8_t bl[320];
+  __shared__ LlhcScratch S;
+  const uint32_t slot = blockIdx.x % SLOTS, j = blockIdx.x / SLOTS;
+  const uint32_t F = j * FLUSH;
+  const uint32_t to = (F + FLUSH - 1 < T - 1) ? F + FLUSH - 1 : T - 1;
+  if (to - F < SLIDER - 1) return;                                  // :1333-1336 short flush: no scanning
+  int64_t lo, hi;
+  if (slot == 0) { lo = (j == 0) ? 0 : (int64_t)F - HALF_SLIDER; hi = lo + SLIDER - 1; }   // :1338-1360
+  else {
+    const uint32_t m = F + MIN_STEP * slot;
+    if (!((uint64_t)m + HALF_SLIDER < to)) return;                  // :1364
+    if (slot % kstep) return;
+    lo = (int64_t)m - HALF_SLIDER; hi = (int64_t)m + HALF_SLIDER;
+    // ring-index wrap => Ada null slice (:1372): first-half flushes only
+    if ((j & 1) == 0 && MIN_STEP * slot < HALF_SLIDER) { lo = 0; hi = -1; }
+  }
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 320; i += 64) hist[i] = (i == 256) ? 1u : 0u;     // empty_lit_len_stat :946
+  __syncthreads();
+  for (int64_t a = lo + lane; a <= hi; a += 64) {
+    int ls, ds; atom_symbols(atoms[a], ls, ds);
+    atomicAdd(&hist[ls], 1u);
+    if (ds >= 0) atomicAdd(&hist[288 + ds], 1u);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    patch_dist_stats(hist + 288);
+    llhc_serial(hist, 288, 15, bl, &S);
+    llhc_serial(hist + 288, 32, 15, bl + 288, &S);
+  }
+  __syncthreads();
+  uint8_t *dst = descr + ((uint64_t)j * SLOTS + slot) * 320;
+  for (int i = lane; i < 320; i += 64) dst[i] = bl[i];
+}
+
+// --------------------------------------------------------------------------------------------
+// k_cut_scan : one wave per flush segment
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_cut_scan(uint32_t T, uint32_t kstep, const uint8_t *__restrict__ descr,
+                                                 uint32_t *__restrict__ seg_nblk, uint32_t *__restrict__ seg_cut) {
+  const uint32_t j = blockIdx.x, lane = threadIdx.x;
+  const uint32_t F = j * FLUSH;
+  const uint32_t to = (F + FLUSH - 1 < T - 1) ? F + FLUSH - 1 : T - 1;
+  uint32_t *cuts = seg_cut + (uint64_t)j * MAXBLK_PER_SEG;
+  uint32_t nb = 0;
+  if (lane == 0) cuts[0] = F;
+  nb = 1;
+  if (to - F >= SLIDER - 1) {
+    const uint8_t *d0 = descr + (uint64_t)j * SLOTS * 320;
+    int init[5];
+    for (int r = 0; r < 5; r++) init[r] = tweak_value(d0[lane + 64 * r]);
+    for (uint32_t k = 1; (uint64_t)F + MIN_STEP * k + HALF_SLIDER < to; k++) {
+      if (k % kstep) continue;
+      const int thr = (k % 8 == 0) ? 420 : (k % 4 == 0) ? 430 : 2050;          // step_choice :1304-1308
+      const uint8_t *dk = d0 + (uint64_t)k * 320;
+      int sl[5]; uint32_t dist = 0;
+      for (int r = 0; r < 5; r++) { sl[r] = tweak_value(dk[lane + 64 * r]); int d = init[r] - sl[r]; dist += (uint32_t)(d < 0 ? -d : d); }
+      dist = wave_sum_u32(dist);
+      if (!(dist < (uint32_t)thr * 100u)) {                                      // not Similar => cut (:1375-1395)
+        if (lane == 0) cuts[nb] = F + MIN_STEP * k;
+        nb++;
+        for (int r = 0; r < 5; r++) init[r] = sl[r];
+      }
+    }
+  }
+  if (lane == 0) seg_nblk[j] = nb;
+}
+
+__global__ void k_fill_blocks(uint32_t T, uint32_t nseg, const uint32_t *__restrict__ seg_nblk, const uint32_t *__restrict__ seg_cut,
+                              const uint32_t *__restrict__ seg_off, BlockRange *__restrict__ blocks) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nseg) return;
+  const uint32_t F = j * FLUSH;
+  const uint32_t to = (F + FLUSH - 1 < T - 1) ? F + FLUSH - 1 : T - 1;
+  const uint32_t nb = seg_nblk[j], off = seg_off[j];
+  const uint32_t *cuts = seg_cut + (uint64_t)j * MAXBLK_PER_SEG;
+  const bool last_seg_partial = (j == nseg - 1) && (T % FLUSH != 0);
+  for (uint32_t i = 0; i < nb; i++) {
+    uint32_t first = cuts[i], end = (i + 1 < nb) ? cuts[i + 1] - 1 : to;
+    BlockRange b; b.first = first; b.count = end - first + 1; b.last_flush = (last_seg_partial && i + 1 == nb) ? 1u : 0u; b.pad = 0;
+    blocks[off + i] = b;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_block_analyze : one workgroup (256 threads) per candidate block
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_block_analyze(const uint32_t *__restrict__ atoms, const uint32_t *__restrict__ apos,
+                                                       const BlockRange *__restrict__ blocks, BlockInfo *__restrict__ binfo) {
+  __shared__ uint32_t st1[320], st2[320], dtmp[2][32];
+  __shared__ uint8_t bl1[320], bl2[320], good[320];
+  __shared__ LlhcScratch S[4];
+  __shared__ HeaderPlan hp[2];
+  __shared__ uint64_t red[3][4];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const BlockRange br = blocks[blockIdx.x];
+  for (int i = tid; i < 320; i += 256) st1[i] = (i == 256) ? 1u : 0u;
+  __syncthreads();
+  for (uint32_t a = tid; a < br.count; a += 256) {
+    int ls, ds; atom_symbols(atoms[br.first + a], ls, ds);
+    atomicAdd(&st1[ls], 1u);
+    if (ds >= 0) atomicAdd(&st1[288 + ds], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < 320; i += 256) st2[i] = st1[i];
+  __syncthreads();
+  if (tid == 0) tweak_for_better_rle(st2, 288, good);                       // :1217
+  if (tid == 64) tweak_for_better_rle(st2 + 288, 32, good + 288);           // :1218
+  __syncthreads();
+  if (lane == 0) {
+    if (w == 0) llhc_serial(st1, 288, 15, bl1, &S[0]);
+    else if (w == 1) llhc_serial(st2, 288, 15, bl2, &S[1]);
+    else if (w == 2) { for (int i = 0; i < 32; i++) dtmp[0][i] = st1[288 + i]; patch_dist_stats(dtmp[0]); llhc_serial(dtmp[0], 32, 15, bl1 + 288, &S[2]); }
+    else { for (int i = 0; i < 32; i++) dtmp[1][i] = st2[288 + i]; patch_dist_stats(dtmp[1]); llhc_serial(dtmp[1], 32, 15, bl2 + 288, &S[3]); }
+  }
+  __syncthreads();
+  if (lane == 0 && w < 2) header_plan(w == 0 ? bl1 : bl2, (w == 0 ? bl1 : bl2) + 288, &hp[w], &S[w]);
+  // data costs, Compute_sizes_of_variants :1152-1190 (EOB, symbol 256, is never counted there)
+  uint64_t cf = 0, c1 = 0, c2 = 0;
+  for (int s = tid; s < 320; s += 256) {
+    uint64_t c = st1[s];
+    if (s < 288) {
+      if (s != 256 && s <= 285) { int e = litlen_sym_extra(s); cf += c * (uint64_t)(fixed_litlen_bl(s) + e); c1 += c * (uint64_t)(bl1[s] + e); c2 += c * (uint64_t)(bl2[s] + e); }
+    } else if (s - 288 <= 29) {
+      int e = dist_sym_extra(s - 288); cf += c * (uint64_t)(5 + e); c1 += c * (uint64_t)(bl1[s] + e); c2 += c * (uint64_t)(bl2[s] + e);
+    }
+  }
+  cf = wave_sum_u64(cf); c1 = wave_sum_u64(c1); c2 = wave_sum_u64(c2);
+  if (lane == 0) { red[0][w] = cf; red[1][w] = c1; red[2][w] = c2; }
+  __syncthreads();
+  BlockInfo *bi = &binfo[blockIdx.x];
+  for (int i = tid; i < 320; i += 256) { bi->stats[i] = st1[i]; bi->bl1[i] = bl1[i]; bi->bl2[i] = bl2[i]; }
+  if (tid < 20) { bi->truc1[tid] = tid < 19 ? hp[0].truc_bl[tid] : hp[0].a_non_zero; bi->truc2[tid] = tid < 19 ? hp[1].truc_bl[tid] : hp[1].a_non_zero; }
+  if (tid == 0) {
+    bi->hdr1_bits = hp[0].bits; bi->hdr2_bits = hp[1].bits;
+    bi->fixed_data = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    bi->dyn1_data = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    bi->dyn2_data = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    bi->bytes = apos[br.first + br.count] - apos[br.first];
+    uint32_t sp = 1;
+    for (int i = 267; i <= 287; i++) if (st1[i] != 0) sp = 0;                // :1222 (Long_length_codes :1093-1095)
+    bi->stored_possible = sp;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_choose : single wave, sequential over the block table
+// --------------------------------------------------------------------------------------------
+// canonical (bit-reversed) code of symbol `sym` under lengths held 5-per-lane (symbol = lane + 64 r)
+__device__ uint32_t wave_code_of(const int (&cur)[5], int sym, int lane, int nsyms_limit /*288: lit/len tree*/) {
+  // length of sym
+  int len = __shfl(cur[sym >> 6], sym & 63);
+  if (len == 0) return 0;
+  // next_code[len] = sum over shorter lengths: bl_count[l] << (len - l); plus rank among equal lengths below sym
+  uint32_t part = 0;
+  for (int r = 0; r < 5; r++) {
+    int s = lane + 64 * r, l = cur[r];
+    if (s < nsyms_limit && l != 0) {
+      if (l < len) part += 1u << (len - l);
+      else if (l == len && s < sym) part += 1u;
+    }
+  }
+  part = wave_sum_u32(part);
+  return bit_reverse(part, len);
+}
+
+struct ChooseState {
+  int last_type, block_to_finish, last_marked;
+  int code_block, code_variant;
+  uint64_t pos;
+};
+
+__global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRange *__restrict__ blocks,
+                                               const BlockInfo *__restrict__ binfo, const uint32_t *__restrict__ apos,
+                                               EmitRec *__restrict__ emit, uint32_t *__restrict__ tile_block,
+                                               StoredPiece *__restrict__ pieces, uint32_t cap_tiles, uint32_t cap_pieces,
+                                               uint32_t *__restrict__ out32, ChooserOut *__restrict__ res,
+                                               int fixed_only /* Deflate_Fixed */) {
+  const int lane = threadIdx.x;
+  int cur[5];                                          // curr_descr lengths, symbol = lane + 64 r (:722)
+  for (int r = 0; r < 5; r++) { int s = lane + 64 * r; cur[r] = s < 288 ? fixed_litlen_bl(s) : 5; }
+  ChooseState S; S.last_type = BT_RESERVED; S.block_to_finish = 0; S.last_marked = 0; S.code_block = -1; S.code_variant = 0; S.pos = 0;
+  uint32_t ntiles = 0, npieces = 0, overflow = 0;
+
+  if (fixed_only) {
+    // Deflate_Fixed: one block for the whole stream (:1600-1603, :1615-1616)
+    if (lane == 0) { put_bits_global(out32, 0, 1, 1); put_bits_global(out32, 1, 1, 2); }
+    S.pos = 3;
+    uint64_t data = 0;
+    for (uint32_t i = 0; i < nblocks; i++) {
+      const BlockRange br = blocks[i];
+      const uint64_t d = binfo[i].fixed_data;
+      uint32_t nt = (br.count + TILE - 1) / TILE;
+      if (lane == 0) {
+        EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = S.pos + data; e.cost_bits = d; e.fmt = FMT_FIXED; e.code_block = -1; e.code_variant = 0; e.tile_base = ntiles;
+        emit[i] = e;
+      }
+      if (ntiles + nt > cap_tiles) { overflow = 1; break; }
+      for (uint32_t t = lane; t < nt; t += 64) tile_block[ntiles + t] = i;
+      ntiles += nt;
+      data += d;
+    }
+    S.pos += data + 7;                                 // fixed EOB = 7 zero bits
+    if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = 0; res->n_blocks = nblocks; res->overflow = overflow; }
+    return;
+  }
+
+  // software prefetch of the next block's record
+  uint32_t nst[5]; int nb1[5], nb2[5];
+  auto load_block = [&](uint32_t i) {
+    const BlockInfo *bi = &binfo[i];
+    for (int r = 0; r < 5; r++) { nst[r] = bi->stats[lane + 64 * r]; nb1[r] = bi->bl1[lane + 64 * r]; nb2[r] = bi->bl2[lane + 64 * r]; }
+  };
+  if (nblocks > 0) load_block(0);
+
+  for (uint32_t i = 0; i < nblocks; i++) {
+    uint32_t st[5]; int b1[5], b2[5];
+    for (int r = 0; r < 5; r++) { st[r] = nst[r]; b1[r] = nb1[r]; b2[r] = nb2[r]; }
+    const BlockInfo *bi = &binfo[i];
+    const BlockRange br = blocks[i];
+    const uint64_t fixed_data = bi->fixed_data, dyn1_data = bi->dyn1_data, dyn2_data = bi->dyn2_data;
+    const uint32_t hdr1 = bi->hdr1_bits, hdr2 = bi->hdr2_bits, bytes = bi->bytes, stored_possible = bi->stored_possible;
+    if (i + 1 < nblocks) load_block(i + 1);
+
+    // recycling (:1223-1226, Recyclable :495-508) and its cost (:1158, 1180, 1189)
+    bool bad = false; uint64_t rc = 0;
+    for (int r = 0; r < 5; r++) {
+      int s = lane + 64 * r;
+      if (cur[r] == 0 && b1[r] > 0) bad = true;
+      if (s < 288) { if (s != 256 && s <= 285) rc += (uint64_t)st[r] * (uint64_t)(cur[r] + litlen_sym_extra(s)); }
+      else if (s - 288 <= 29) rc += (uint64_t)st[r] * (uint64_t)(cur[r] + dist_sym_extra(s - 288));
+    }
+    const bool any_bad = __any(bad);
+    const uint64_t recycled_data = wave_sum_u64(rc);
+    const bool recycling_possible = S.last_type == BT_FIXED || (S.last_type == BT_DYNAMIC && !any_bad);
+    const bool finishing = S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC);
+    const int eob_len = __shfl(cur[4], 0);            // symbol 256 = lane 0, r = 4
+    const uint64_t c = 1 + (finishing ? (uint64_t)eob_len : 0);                 // :1198-1201
+    const uint64_t INF = ~0ull;
+    uint64_t stored_bits = INF;
+    if (stored_possible) { uint64_t sb = 8ull * bytes; sb += (1 + (sb / 8) / 65535) * 40; stored_bits = sb + c; }   // :1193-1196, 1202
+    const uint64_t fixed_bits = fixed_data + c + 2;
+    const uint64_t d1_bits = dyn1_data + c + 2 + hdr1, d2_bits = dyn2_data + c + 2 + hdr2;
+    const uint64_t rec_bits = recycling_possible ? recycled_data : INF;
+    uint64_t opt = stored_bits < fixed_bits ? stored_bits : fixed_bits;
+    { uint64_t m2 = d1_bits < d2_bits ? d1_bits : d2_bits; m2 = m2 < rec_bits ? m2 : rec_bits; opt = opt < m2 ? opt : m2; }
+    int fmt;
+    if (fixed_bits == opt) fmt = FMT_FIXED; else if (d1_bits == opt) fmt = FMT_DYN1; else if (d2_bits == opt) fmt = FMT_DYN2;
+    else if (rec_bits == opt) fmt = FMT_RECYCLE; else fmt = FMT_STORED;          // :1243-1268
+
+    EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = 0; e.cost_bits = opt; e.fmt = (uint32_t)fmt; e.code_block = -1; e.code_variant = 0; e.tile_base = ntiles;
+    const int last_block = (int)br.last_flush;
+
+    // Mark_new_block :999-1007 (pre-EOB of the block being finished, then BFINAL)
+    auto mark_new_block = [&](int last_for_stream) {
+      if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
+        uint32_t code = wave_code_of(cur, 256, lane, 288);
+        int l = __shfl(cur[4], 0);
+        if (lane == 0) put_bits_global(out32, S.pos, code, l);
+        S.pos += (uint64_t)l;
+      }
+      S.block_to_finish = 1;
+      if (lane == 0) put_bits_global(out32, S.pos, (uint32_t)last_for_stream, 1);
+      S.pos += 1;
+      S.last_marked = last_for_stream;
+    };
+
+    uint64_t data_bits = 0;
+    if (fmt == FMT_FIXED) {
+      if (S.last_type != BT_FIXED) {                                             // Send_fixed_block :1108-1121
+        mark_new_block(last_block);
+        for (int r = 0; r < 5; r++) { int s = lane + 64 * r; cur[r] = s < 288 ? fixed_litlen_bl(s) : 5; }
+        if (lane == 0) put_bits_global(out32, S.pos, 1, 2);
+        S.pos += 2;
+        S.last_type = BT_FIXED; S.code_block = -1; S.code_variant = 0;
+      }
+      data_bits = fixed_data;
+    } else if (fmt == FMT_DYN1 || fmt == FMT_DYN2) {                             // Send_dynamic_block :1126-1135
+      mark_new_block(last_block);
+      for (int r = 0; r < 5; r++) cur[r] = (fmt == FMT_DYN1) ? b1[r] : b2[r];
+      if (lane == 0) put_bits_global(out32, S.pos, 2, 2);
+      S.pos += 2;
+      e.hdr_bitpos = S.pos;
+      S.pos += (fmt == FMT_DYN1) ? hdr1 : hdr2;
+      S.last_type = BT_DYNAMIC; S.code_block = (int)i; S.code_variant = (fmt == FMT_DYN1) ? 1 : 2;
+      data_bits = (fmt == FMT_DYN1) ? dyn1_data : dyn2_data;
+    } else if (fmt == FMT_RECYCLE) {
+      data_bits = recycled_data;
+    } else {
+      // Expand_LZ_buffer :1010-1062 with its divide-and-conquer on the ATOM range
+      uint32_t stk_first[40], stk_last[40]; int stk_lastblk[40]; int sp = 0;
+      stk_first[0] = br.first; stk_last[0] = br.first + br.count - 1; stk_lastblk[0] = last_block; sp = 1;
+      while (sp > 0) {
+        sp--;
+        uint32_t f = stk_first[sp], l = stk_last[sp]; int lb = stk_lastblk[sp];
+        uint32_t src = apos[f], nbytes = apos[l + 1] - src;
+        if (nbytes > 0xFFFF) {
+          uint32_t mid = (uint32_t)(((uint64_t)f + (uint64_t)l) / 2);
+          // second half is processed after the first: push it first (LIFO)
+          stk_first[sp] = mid + 1; stk_last[sp] = l; stk_lastblk[sp] = lb; sp++;
+          stk_first[sp] = f; stk_last[sp] = mid; stk_lastblk[sp] = 0; sp++;
+          continue;
+        }
+        mark_new_block(lb);
+        S.last_type = BT_STORED;
+        S.pos += 2;                                                              // Put_Bits (0, 2)
+        S.pos = (S.pos + 7) & ~7ull;                                             // Flush_bit_buffer
+        if (lane == 0) {
+          put_bits_global(out32, S.pos, nbytes & 0xFFFF, 16);
+          put_bits_global(out32, S.pos + 16, (~nbytes) & 0xFFFF, 16);
+          if (npieces < cap_pieces) { StoredPiece pc; pc.dst_byte = (S.pos >> 3) + 4; pc.src_byte = src; pc.nbytes = nbytes; pieces[npieces] = pc; }
+        }
+        if (npieces >= cap_pieces) overflow = 1;
+        npieces++;
+        S.pos += 32 + 8ull * nbytes;
+      }
+    }
+    if (fmt != FMT_STORED) {
+      e.data_bitpos = S.pos;
+      e.code_block = S.code_block; e.code_variant = (uint32_t)S.code_variant;
+      S.pos += data_bits;
+      uint32_t nt = (br.count + TILE - 1) / TILE;
+      if (ntiles + nt > cap_tiles) { overflow = 1; break; }
+      for (uint32_t t = lane; t < nt; t += 64) tile_block[ntiles + t] = i;
+      ntiles += nt;
+    }
+    if (lane == 0) emit[i] = e;
+  }
+
+  // stream epilogue, Encode :1613-1635
+  if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
+    uint32_t code = wave_code_of(cur, 256, lane, 288);
+    int l = __shfl(cur[4], 0);
+    if (lane == 0) put_bits_global(out32, S.pos, code, l);
+    S.pos += (uint64_t)l;
+  }
+  if (!S.last_marked) {
+    if (lane == 0) { put_bits_global(out32, S.pos, 1, 1); put_bits_global(out32, S.pos + 1, 1, 2); }
+    S.pos += 3 + 7;                                                              // fake final fixed block: EOB = 0000000
+  }
+  if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = npieces; res->n_blocks = nblocks; res->overflow = overflow; }
+}
+
+// --------------------------------------------------------------------------------------------
+// code tables: codes[b*320 + s] = (len << 16) | bit-reversed canonical code
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_block_codes(uint32_t nblocks, const EmitRec *__restrict__ emit, const BlockInfo *__restrict__ binfo,
+                                                    uint32_t *__restrict__ codes) {
+  __shared__ uint8_t bl[320];
+  __shared__ uint16_t cd[320];
+  const uint32_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (b == nblocks) {                                                            // fixed table
+    for (int i = lane; i < 320; i += 64) bl[i] = (uint8_t)(i < 288 ? fixed_litlen_bl(i) : 5);
+  } else {
+    const uint32_t f = emit[b].fmt;
+    if (f != FMT_DYN1 && f != FMT_DYN2) return;
+    const uint8_t *src = f == FMT_DYN1 ? binfo[b].bl1 : binfo[b].bl2;
+    for (int i = lane; i < 320; i += 64) bl[i] = src[i];
+  }
+  __syncthreads();
+  if (lane == 0) canonical_codes(bl, 288, cd);
+  if (lane == 1) canonical_codes(bl + 288, 32, cd + 288);
+  __syncthreads();
+  for (int i = lane; i < 320; i += 64) codes[(uint64_t)b * 320 + i] = ((uint32_t)bl[i] << 16) | cd[i];
+}
+
+__device__ __forceinline__ uint32_t code_table_index(const EmitRec &e, uint32_t nblocks) { return e.code_block < 0 ? nblocks : (uint32_t)e.code_block; }
+
+// bits of one atom under a code table staged in LDS; value returned in v (LSB first)
+__device__ __forceinline__ int atom_bits(uint32_t t, const uint32_t *tab, uint64_t &v) {
+  if (!tok_is_match(t)) { uint32_t c = tab[t & 0xFF]; v = c & 0xFFFF; return (int)(c >> 16); }
+  const int len = (int)((t >> 16) & 0x1FF), dist = (int)(t & 0xFFFF);
+  uint32_t lc = tab[len_symbol(len)], dc = tab[288 + dist_symbol(dist)];
+  int n = (int)(lc >> 16);
+  v = lc & 0xFFFF;
+  int le = len_extra_bits(len);
+  v |= (uint64_t)len_extra_val(len) << n; n += le;
+  v |= (uint64_t)(dc & 0xFFFF) << n; n += (int)(dc >> 16);
+  int de = dist_extra_bits(dist);
+  v |= (uint64_t)dist_extra_val(dist) << n; n += de;
+  return n;
+}
+
+__global__ void __launch_bounds__(256) k_tile_bits(uint32_t nblocks, const uint32_t *__restrict__ atoms, const BlockRange *__restrict__ blocks,
+                                                   const EmitRec *__restrict__ emit, const uint32_t *__restrict__ tile_block,
+                                                   const uint32_t *__restrict__ codes, uint32_t *__restrict__ tile_bits) {
+  __shared__ uint32_t tab[320];
+  __shared__ uint32_t red[4];
+  const uint32_t t = blockIdx.x, b = tile_block[t];
+  const EmitRec e = emit[b];
+  const BlockRange br = blocks[b];
+  const uint32_t ti = t - e.tile_base;
+  const uint32_t a0 = br.first + ti * TILE, a1 = (ti * TILE + TILE < br.count) ? a0 + TILE : br.first + br.count;
+  const uint32_t *src = codes + (uint64_t)code_table_index(e, nblocks) * 320;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 320; i += 256) tab[i] = src[i];
+  __syncthreads();
+  uint32_t s = 0;
+  for (uint32_t a = a0 + tid; a < a1; a += 256) { uint64_t v; s += (uint32_t)atom_bits(atoms[a], tab, v); }
+  s = wave_sum_u32(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) tile_bits[t] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one thread per block: running bit position of its tiles
+__global__ void k_tile_scan(uint32_t nblocks, const BlockRange *__restrict__ blocks, const EmitRec *__restrict__ emit,
+                            const uint32_t *__restrict__ tile_bits, uint64_t *__restrict__ tile_bitpos) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const EmitRec e = emit[b];
+  if (e.fmt == FMT_STORED) return;
+  uint32_t nt = (blocks[b].count + TILE - 1) / TILE;
+  uint64_t pos = e.data_bitpos;
+  for (uint32_t t = 0; t < nt; t++) { tile_bitpos[e.tile_base + t] = pos; pos += tile_bits[e.tile_base + t]; }
+}
+
+// emit one tile: 256 threads x 8 consecutive atoms
+__global__ void __launch_bounds__(256) k_emit_tiles(uint32_t nblocks, const uint32_t *__restrict__ atoms, const BlockRange *__restrict__ blocks,
+                                                    const EmitRec *__restrict__ emit, const uint32_t *__restrict__ tile_block,
+                                                    const uint32_t *__restrict__ codes, const uint64_t *__restrict__ tile_bitpos,
+                                                    uint32_t *__restrict__ out32) {
+  __shared__ uint32_t tab[320];
+  __shared__ uint32_t buf[TILE * 48 / 32 + 4];
+  __shared__ uint32_t wsum[4];
+  const uint32_t t = blockIdx.x, b = tile_block[t];
+  const EmitRec e = emit[b];
+  const BlockRange br = blocks[b];
+  const uint32_t ti = t - e.tile_base;
+  const uint32_t a0 = br.first + ti * TILE, a1 = (ti * TILE + TILE < br.count) ? a0 + TILE : br.first + br.count;
+  const uint32_t *src = codes + (uint64_t)code_table_index(e, nblocks) * 320;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < 320; i += 256) tab[i] = src[i];
+  for (int i = tid; i < (int)(TILE * 48 / 32 + 4); i += 256) buf[i] = 0;
+  __syncthreads();
+  uint64_t v[8]; int nb[8]; uint32_t tot = 0;
+  for (int k = 0; k < 8; k++) {
+    uint32_t a = a0 + tid * 8 + k;
+    if (a < a1) { nb[k] = atom_bits(atoms[a], tab, v[k]); tot += (uint32_t)nb[k]; } else { nb[k] = 0; v[k] = 0; }
+  }
+  uint32_t incl = tot;
+  for (int off = 1; off < 64; off <<= 1) { uint32_t x = __shfl_up(incl, off); if (lane >= off) incl += x; }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int k = 0; k < w; k++) base += wsum[k];
+  const uint64_t b0 = tile_bitpos[t];
+  uint32_t bp = (uint32_t)(b0 & 31) + base + incl - tot;
+  for (int k = 0; k < 8; k++) {
+    if (nb[k]) {
+      uint32_t wd = bp >> 5; int sh = (int)(bp & 31);
+      uint64_t lo = v[k] << sh;
+      atomicOr(&buf[wd], (uint32_t)lo);
+      if (sh + nb[k] > 32) atomicOr(&buf[wd + 1], (uint32_t)(lo >> 32));
+      if (sh + nb[k] > 64) atomicOr(&buf[wd + 2], (uint32_t)(v[k] >> (64 - sh)));
+      bp += (uint32_t)nb[k];
+    }
+  }
+  __syncthreads();
+  const uint32_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  const uint32_t nwords = ((uint32_t)(b0 & 31) + tile_total + 31) >> 5;
+  uint32_t *dst = out32 + (b0 >> 5);
+  for (uint32_t i = tid; i < nwords; i += 256) {
+    uint32_t x = buf[i];
+    if (i == 0 || i + 1 == nwords) { if (x) atomicOr(&dst[i], x); }
+    else dst[i] = x;
+  }
+}
+
+// dynamic block headers, Put_Compression_Structure :686-703 (effective mode); lane 0 of one wave per block
+__global__ void __launch_bounds__(64) k_emit_headers(uint32_t nblocks, const EmitRec *__restrict__ emit, const BlockInfo *__restrict__ binfo,
+                                                     uint32_t *__restrict__ out32) {
+  __shared__ uint8_t bl[320], cs[320], tbl[20];
+  __shared__ uint16_t tcode[19];
+  const uint32_t b = blockIdx.x;
+  const EmitRec e = emit[b];
+  if (e.fmt != FMT_DYN1 && e.fmt != FMT_DYN2) return;
+  const int lane = threadIdx.x;
+  const BlockInfo *bi = &binfo[b];
+  const uint8_t *src = e.fmt == FMT_DYN1 ? bi->bl1 : bi->bl2;
+  const uint8_t *tsrc = e.fmt == FMT_DYN1 ? bi->truc1 : bi->truc2;
+  for (int i = lane; i < 320; i += 64) bl[i] = src[i];
+  if (lane < 20) tbl[lane] = tsrc[lane];
+  __syncthreads();
+  if (lane != 0) return;
+  int max_ll = 0, max_d = 0, n = 0;
+  for (int a = 287; a >= 0; a--) if (bl[a] > 0) { max_ll = a; break; }
+  for (int a = 31; a >= 0; a--) if (bl[288 + a] > 0) { max_d = a; break; }
+  for (int a = 0; a <= max_ll; a++) cs[n++] = bl[a];
+  for (int a = 0; a <= max_d; a++) cs[n++] = bl[288 + a];
+  canonical_codes(tbl, 19, tcode);
+  const int anz = tbl[19];
+  uint64_t pos = e.hdr_bitpos;
+  put_bits_global(out32, pos, (uint32_t)(max_ll - 256), 5); pos += 5;
+  put_bits_global(out32, pos, (uint32_t)max_d, 5); pos += 5;
+  put_bits_global(out32, pos, (uint32_t)(anz - 3), 4); pos += 4;
+  for (int a = 0; a <= anz; a++) { put_bits_global(out32, pos, tbl[header_perm(a)], 3); pos += 3; }
+  header_rle_walk(cs, n, [&](int x, uint32_t extra) {
+    put_bits_global(out32, pos, tcode[x], tbl[x]); pos += tbl[x];
+    int eb = header_extra_bits(x);
+    if (eb) { put_bits_global(out32, pos, extra, eb); pos += eb; }
+  });
+}
+
+// raw bytes of stored blocks (runs AFTER every atomic bit writer: plain byte stores)
+__global__ void __launch_bounds__(256) k_copy_pieces(uint32_t npieces, const StoredPiece *__restrict__ pieces,
+                                                     const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
+  const uint32_t p = blockIdx.x;
+  if (p >= npieces) return;
+  const StoredPiece pc = pieces[p];
+  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < pc.nbytes; i += gridDim.y * 256) out[pc.dst_byte + i] = in[(uint64_t)pc.src_byte + i];
+}
+
+__global__ void k_single_block(uint32_t T, BlockRange *blocks) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { blocks[0].first = 0; blocks[0].count = T; blocks[0].last_flush = 1; blocks[0].pad = 0; }
+}
+__global__ void k_set_u32(uint32_t *p, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+
+// --------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------
+void exclusive_scan_u32(hipStream_t st, const uint32_t *d_in, uint32_t *d_out, uint32_t *d_sums, uint32_t *d_total, uint32_t n);
+
+int huff_stage(Ctx *c, int method, uint64_t n, uint32_t T, uint64_t *total_bits) {
+  hipStream_t st = c->stream;
+  Workspace &W = c->ws;
+  const bool fixed_only = (method == 6);
+  uint32_t nblocks = 0;
+  hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, W.apos + T, (uint32_t)n);       // sentinel
+  if (T > 0) {
+    if (fixed_only) {
+      // one pseudo-block per 65536 atoms only to spread the cost analysis; emitted as ONE fixed block
+      const uint32_t nseg = (T + FLUSH - 1) / FLUSH;
+      hipMemsetAsync(W.seg_nblk, 0, 4, st);
+      // segments as blocks
+      std::vector<BlockRange> hb(nseg);
+      for (uint32_t j = 0; j < nseg; j++) { hb[j].first = j * FLUSH; hb[j].count = (j + 1 == nseg) ? T - j * FLUSH : FLUSH; hb[j].last_flush = 0; hb[j].pad = 0; }
+      hipMemcpyAsync(W.blocks, hb.data(), nseg * sizeof(BlockRange), hipMemcpyHostToDevice, st);
+      hipStreamSynchronize(st);
+      nblocks = nseg;
+    } else {
+      const uint32_t nseg = (T + FLUSH - 1) / FLUSH;
+      const uint32_t kstep = method == 8 ? 8 : method == 9 ? 4 : 1;                        // max_choice :1310-1311
+      hipLaunchKernelGGL(k_window_descr, dim3(nseg * SLOTS), dim3(64), 0, st, W.atoms, T, kstep, W.descr);
+      c->tmark("window_descr");
+      hipLaunchKernelGGL(k_cut_scan, dim3(nseg), dim3(64), 0, st, T, kstep, W.descr, W.seg_nblk, W.seg_cut);
+      exclusive_scan_u32(st, W.seg_nblk, W.seg_blk_off, W.scan_sums, W.n_changed, nseg);
+      hipMemcpyAsync(&nblocks, W.n_changed, 4, hipMemcpyDeviceToHost, st);
+      hipLaunchKernelGGL(k_fill_blocks, dim3((nseg + 255) / 256), dim3(256), 0, st, T, nseg, W.seg_nblk, W.seg_cut, W.seg_blk_off, W.blocks);
+      if (hip_check(c, hipStreamSynchronize(st), "cut_scan")) return ZADA_E_HIP_;
+      c->tmark("cut_scan");
+    }
+    if (nblocks > W.cap_blocks) { c->err = "block table overflow"; return -1; }
+    hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, W.atoms, W.apos, W.blocks, W.binfo);
+    c->tmark("block_analyze");
+  }
+  hipLaunchKernelGGL(k_choose, dim3(1), dim3(64), 0, st, nblocks, W.blocks, W.binfo, W.apos, W.emit, W.tile_block, W.pieces,
+                     (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.chooser, fixed_only ? 1 : 0);
+  ChooserOut co;
+  hipMemcpyAsync(&co, W.chooser, sizeof co, hipMemcpyDeviceToHost, st);
+  if (hip_check(c, hipStreamSynchronize(st), "choose")) return ZADA_E_HIP_;
+  c->tmark("choose");
+  if (co.overflow) { c->err = "emission table overflow"; return -1; }
+  if ((co.total_bits + 7) / 8 + 8 > W.cap_out) { c->err = "output workspace overflow"; return -1; }
+  hipLaunchKernelGGL(k_block_codes, dim3(nblocks + 1), dim3(64), 0, st, nblocks, W.emit, W.binfo, W.codes);
+  if (co.n_tiles > 0) {
+    hipLaunchKernelGGL(k_tile_bits, dim3(co.n_tiles), dim3(256), 0, st, nblocks, W.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bits);
+    hipLaunchKernelGGL(k_tile_scan, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.blocks, W.emit, W.tile_bits, W.tile_bitpos);
+    hipLaunchKernelGGL(k_emit_tiles, dim3(co.n_tiles), dim3(256), 0, st, nblocks, W.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bitpos, (uint32_t *)W.out);
+  }
+  if (nblocks > 0 && !fixed_only) hipLaunchKernelGGL(k_emit_headers, dim3(nblocks), dim3(64), 0, st, nblocks, W.emit, W.binfo, (uint32_t *)W.out);
+  if (co.n_pieces > 0) hipLaunchKernelGGL(k_copy_pieces, dim3(co.n_pieces, 16), dim3(256), 0, st, co.n_pieces, W.pieces, W.in, W.out);
+  c->tmark("emit");
+  // block trace for zada_last_blocks
+  c->last_blocks.clear();
+  if (nblocks > 0) {
+    std::vector<EmitRec> he(nblocks); std::vector<BlockRange> hb(nblocks);
+    hipMemcpyAsync(he.data(), W.emit, nblocks * sizeof(EmitRec), hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(hb.data(), W.blocks, nblocks * sizeof(BlockRange), hipMemcpyDeviceToHost, st);
+    if (hip_check(c, hipStreamSynchronize(st), "trace")) return ZADA_E_HIP_;
+    c->last_blocks.resize((size_t)nblocks * 4);
+    for (uint32_t i = 0; i < nblocks; i++) {
+      c->last_blocks[4 * i] = hb[i].first; c->last_blocks[4 * i + 1] = hb[i].count;
+      c->last_blocks[4 * i + 2] = he[i].fmt; c->last_blocks[4 * i + 3] = he[i].cost_bits;
+    }
+  }
+  *total_bits = co.total_bits;
+  return hip_check(c, hipGetLastError(), "huff_stage");
+}
+
+}  // namespace zada

@@ -1,0 +1,115 @@
+// zada_internal.h -- context, workspace layout and shared constants of libzada_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "zada_logic.h"
+
+namespace zada {
+
+constexpr int ZADA_E_HIP_ = -3;
+
+// ---- LZ stage geometry ----
+constexpr uint32_t PCHUNK = 4096;                 // bytes parsed per lane (speculative chunk)
+constexpr uint32_t PTOK_STRIDE = PCHUNK + 1024;   // token slots per chunk (a parse may overrun its chunk by < 600 B)
+constexpr uint64_t IN_PAD = 1024;                 // zero bytes kept after the input
+
+// ---- entropy stage geometry (zip-compress-deflate.adb:942, 1294, 1313) ----
+constexpr uint32_t FLUSH = 65536;                 // atoms per Flush_half_buffer
+constexpr uint32_t MIN_STEP = 750, HALF_SLIDER = 2048, SLIDER = 4096;
+constexpr uint32_t SLOTS = 88;                    // descriptor slots per flush segment (1 initial + <= 84 sliding)
+constexpr uint32_t MAXBLK_PER_SEG = 86;
+constexpr uint32_t TILE = 2048;                   // atoms per emission tile
+
+enum { FMT_STORED = 0, FMT_FIXED = 1, FMT_DYN1 = 2, FMT_DYN2 = 3, FMT_RECYCLE = 4 };
+enum { BT_STORED = 0, BT_FIXED = 1, BT_DYNAMIC = 2, BT_RESERVED = 3 };
+
+struct BlockRange { uint32_t first, count; uint32_t last_flush; uint32_t pad; };
+
+// Everything the chooser and the emitters need to know about one candidate block.
+struct BlockInfo {
+  uint32_t stats[320];          // 288 lit/len (EOB preset to 1) + 32 distance counts
+  uint8_t bl1[320], bl2[320];   // code lengths: plain / after Tweak_for_better_RLE
+  uint8_t truc1[20], truc2[20]; // 19 code-length-code lengths + a_non_zero
+  uint32_t hdr1_bits, hdr2_bits;            // Put_Compression_Structure cost (:682-685)
+  uint64_t fixed_data, dyn1_data, dyn2_data; // bits of the LZ data alone under each code set
+  uint32_t bytes;               // uncompressed bytes covered
+  uint32_t stored_possible;
+};
+
+// Decision record written by the sequential chooser.
+struct EmitRec {
+  uint64_t hdr_bitpos;          // dynamic header position (after the 3 block-header bits)
+  uint64_t data_bitpos;         // first bit of the LZ data
+  uint64_t cost_bits;           // optimal_format_bits (:1234), for the trace
+  uint32_t fmt;                 // FMT_*
+  int32_t code_block;           // block whose code table is in force (-1 = fixed table)
+  uint32_t code_variant;        // 1 or 2 (bl1 / bl2 of code_block)
+  uint32_t tile_base;           // first emission tile of this block
+};
+
+struct StoredPiece { uint64_t dst_byte; uint32_t src_byte, nbytes; };
+
+struct ChooserOut {
+  uint64_t total_bits;
+  uint32_t n_tiles, n_pieces, n_blocks, overflow;
+};
+
+struct Workspace {
+  uint64_t cap_n = 0;           // input capacity in bytes
+  uint8_t *in = nullptr;
+  uint16_t *prevd = nullptr, *tails = nullptr;
+  uint32_t *MF = nullptr, *MQ = nullptr;     // alias: atoms / apos
+  uint32_t *atoms = nullptr, *apos = nullptr;
+  uint32_t *spec_tok = nullptr, *fix_tok = nullptr;
+  uint32_t *spec_cnt = nullptr, *fix_cnt = nullptr, *take_from = nullptr, *start_pos = nullptr;
+  uint32_t *counts = nullptr, *offsets = nullptr, *scan_sums = nullptr;
+  uint32_t *Fbits = nullptr, *Lbits = nullptr;
+  ExitState *spec_exits = nullptr, *true_exits = nullptr;
+  uint8_t *dirty[2] = {nullptr, nullptr};
+  uint32_t *n_changed = nullptr;
+  // entropy stage
+  uint8_t *descr = nullptr;                  // [nseg][SLOTS][320]
+  uint32_t *seg_nblk = nullptr, *seg_cut = nullptr, *seg_blk_off = nullptr;   // cuts [nseg][MAXBLK_PER_SEG]
+  BlockRange *blocks = nullptr;
+  BlockInfo *binfo = nullptr;
+  EmitRec *emit = nullptr;
+  uint32_t *codes = nullptr;                 // [nblocks+1][320]  (len << 16 | code); last = fixed table
+  StoredPiece *pieces = nullptr;
+  uint32_t *tile_block = nullptr;            // tile -> block
+  uint64_t *tile_bitpos = nullptr;
+  uint32_t *tile_bits = nullptr;
+  ChooserOut *chooser = nullptr;
+  uint32_t *crc_part = nullptr;
+  uint8_t *out = nullptr;
+  uint64_t cap_blocks = 0, cap_tiles = 0, cap_pieces = 0, cap_out = 0;
+  std::vector<void *> allocs;
+};
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Workspace ws;
+  std::string err;
+  int parse_rounds = 0;
+  // timing
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<const char *, hipEvent_t>> marks;
+  std::vector<std::pair<const char *, float>> timing;
+  bool timing_on = true;
+  // last-call block trace
+  std::vector<uint64_t> last_blocks;
+  void tmark(const char *name);
+  void tbegin();
+  void tend();
+};
+
+int hip_check(Ctx *c, hipError_t e, const char *what);
+int ensure_workspace(Ctx *c, uint64_t n);
+int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out);
+int huff_stage(Ctx *c, int method, uint64_t n, uint32_t T, uint64_t *total_bits);
+int crc_stage(Ctx *c, uint64_t n, uint32_t *crc_inout);
+void exclusive_scan_u32(hipStream_t st, const uint32_t *d_in, uint32_t *d_out, uint32_t *d_sums, uint32_t *d_total, uint32_t n);
+
+}  // namespace zada

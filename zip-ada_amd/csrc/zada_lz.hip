@@ -1,0 +1,429 @@
+// zada_lz.hip -- LZ77 stage of the encoder on gfx950 (hand-written HIP, wave64).
+//
+// Reference semantics: zip_lib/lz77.adb:460-943 (Info-Zip deflate_slow).  The sequential
+// algorithm is refactored into data-parallel passes that compute the SAME token stream:
+//
+//   k_prev_links     per 32 KiB segment: stable LDS radix sort of positions by the 15-bit hash
+//                    (UPDATE_HASH, :553-557) -> for every position the distance to the nearest
+//                    earlier position with the same hash (what INSERT_STRING's prev[] chain
+//                    holds, :566-573); + per-segment tail table
+//   k_cross_links    links the first position of each hash bucket to the previous segment's tail
+//   k_match          Longest_Match (:715-825) for EVERY position, window + chain links staged in
+//                    LDS; produces the full-chain and quarter-chain results (good_match rule :733)
+//   k_parse_spec     lazy-evaluation parser (:827-933), one lane per 4 KiB chunk, speculatively
+//                    started in the fresh state at each chunk boundary
+//   k_parse_fix      re-parses from the previous chunk's true exit state until it meets a
+//                    history-free state of the speculative parse (splice); iterated to a fixpoint
+//   k_tok_count / k_tok_compact   gather the true tokens into one global atom array
+//
+// Why the result is identical to the sequential reference: see DESIGN.md "LZ77 stage".
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zada_logic.h"
+#include "zada_internal.h"
+
+namespace zada {
+
+// --------------------------------------------------------------------------------------------
+// k_prev_links
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash3(const uint8_t *__restrict__ in, uint64_t p) {
+  return (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ (uint32_t)in[p + 2]) & 0x7FFFu;
+}
+
+// One stable counting pass over `m` elements held by 16 waves (wave w owns [w*2048, w*2048+2048)).
+// digit(e) is given by the functor; `src` == nullptr means element i is position i.
+template <int NDIG, typename DigitFn>
+__device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[NDIG*16]*/, uint32_t *wsum /*[16]*/, uint32_t m, DigitFn digit) {
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < NDIG * 16; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  // phase A: per (digit, wave) histogram
+  for (int it = 0; it < 32; it++) {
+    uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
+    if (i < m) {
+      uint32_t e = src ? src[i] : i;
+      atomicAdd(&cnt[digit(e) * 16 + w], 1u);
+    }
+  }
+  __syncthreads();
+  // phase B: exclusive scan over (digit major, wave minor)
+  {
+    constexpr int PER = NDIG * 16 / 1024;           // 4 (256 digits) or 2 (128 digits)
+    uint32_t v[PER], s = 0;
+    for (int k = 0; k < PER; k++) { v[k] = cnt[tid * PER + k]; s += v[k]; }
+    // block exclusive scan of s
+    uint32_t incl = s;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < w; k++) base += wsum[k];
+    uint32_t run = base + incl - s;
+    for (int k = 0; k < PER; k++) { cnt[tid * PER + k] = run; run += v[k]; }
+  }
+  __syncthreads();
+  // phase C: stable scatter, 64 elements per wave step, ranks by ballot multi-split
+  for (int it = 0; it < 32; it++) {
+    uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
+    bool act = i < m;
+    uint32_t e = 0, d = 0;
+    if (act) { e = src ? src[i] : i; d = digit(e); }
+    unsigned long long mask = __ballot(act);
+    for (int b = 0; (1 << b) < NDIG; b++) {
+      unsigned long long bal = __ballot((d >> b) & 1);
+      mask &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    if (act) {
+      unsigned long long below = mask & ((1ull << lane) - 1ull);
+      uint32_t rank = __popcll(below), tot = __popcll(mask);
+      uint32_t base = cnt[d * 16 + w];
+      dst[base + rank] = (uint16_t)e;
+      if (rank == tot - 1) cnt[d * 16 + w] = base + tot;   // last lane of the group advances the cursor
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+}
+
+// grid = number of 32 KiB segments; block = 1024.  n_ins = number of inserted positions (n - 2).
+__global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins,
+                                                     uint16_t *__restrict__ prevd, uint16_t *__restrict__ tails) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint16_t *A = (uint16_t *)smem;                 // 64 KiB
+  uint16_t *B = A + 32768;                        // 64 KiB
+  uint32_t *cnt = (uint32_t *)(B + 32768);        // 16 KiB
+  uint32_t *wsum = cnt + 4096;                    // 64 B
+  const uint64_t seg = blockIdx.x, base = seg * 32768ull;
+  const uint32_t m = (uint32_t)((n_ins - base) < 32768ull ? (n_ins - base) : 32768ull);
+  const int tid = threadIdx.x;
+  uint16_t *tail = tails + seg * 32768ull;
+  for (int i = tid; i < 32768 / 8; i += 1024) ((uint4 *)tail)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  const uint8_t *sin = in + base;
+  radix_pass<256>(nullptr, A, cnt, wsum, m, [sin](uint32_t e) { return hash3(sin, e) & 0xFFu; });
+  radix_pass<128>(A, B, cnt, wsum, m, [sin](uint32_t e) { return hash3(sin, e) >> 8; });
+  // link neighbours inside each bucket (B is sorted by (hash, position))
+  for (uint32_t i = tid; i < m; i += 1024) {
+    uint32_t e = B[i], h = hash3(sin, e);
+    uint16_t d = 0;
+    if (i > 0) {
+      uint32_t e0 = B[i - 1];
+      if (hash3(sin, e0) == h && (base + e0) != 0) d = (uint16_t)(e - e0);     // NIL = position 0, lz77.adb:467
+    }
+    prevd[base + e] = d;
+    bool last = (i + 1 == m) || (hash3(sin, B[i + 1]) != h);
+    if (last) tail[h] = (uint16_t)e;
+  }
+}
+
+// grid-stride over inserted positions of segments >= 1.
+__global__ void k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, uint16_t *__restrict__ prevd,
+                              const uint16_t *__restrict__ tails) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_ins; p += stride) {
+    if (prevd[p] != 0) continue;
+    uint64_t seg = p >> 15;
+    uint32_t t = tails[(seg - 1) * 32768ull + hash3(in, p)];
+    if (t == 0xFFFFu) continue;
+    uint64_t q = (seg - 1) * 32768ull + t;
+    uint64_t d = p - q;
+    if (d <= (uint64_t)MAX_DIST && q != 0) prevd[p] = (uint16_t)d;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_match : Longest_Match for every position
+// --------------------------------------------------------------------------------------------
+// Block of MB positions [B, B+MB); LDS holds input bytes [WB, B+MB+272) and the chain links
+// (distance to previous same-hash position) of [WB, B+MB), WB = B - HALO (clamped at 0).
+constexpr int MB = 16384;
+constexpr int HALO = 32512;                       // >= MAX_DIST, multiple of 16
+constexpr int WBYTES = HALO + MB + 272;           // 49168
+constexpr int WLINKS = HALO + MB;                 // 48896
+
+__device__ __forceinline__ uint32_t lds_u32_at(const uint32_t *w, uint32_t byteoff) {
+  uint32_t i = byteoff >> 2;
+  return __builtin_amdgcn_alignbyte(w[i + 1], w[i], byteoff & 3);
+}
+
+__global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, uint64_t n,
+                                                const uint16_t *__restrict__ prevd,
+                                                uint32_t *__restrict__ MF, uint32_t *__restrict__ MQ,
+                                                int nice_cfg, int chain_cfg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t *win = (uint32_t *)smem;                               // WBYTES bytes
+  uint16_t *lnk = (uint16_t *)(smem + WBYTES);                    // WLINKS * 2 bytes
+  uint32_t &next_pos = *(uint32_t *)(smem + WBYTES + WLINKS * 2);
+  const uint64_t B = (uint64_t)blockIdx.x * MB;
+  const uint64_t WB = B >= (uint64_t)HALO ? B - HALO : 0;
+  const uint32_t woff = (uint32_t)(B - WB);                        // window index of position B
+  const uint32_t cnt = (uint32_t)((n - B) < (uint64_t)MB ? (n - B) : (uint64_t)MB);
+  const int tid = threadIdx.x;
+  // stage the window (the input buffer is padded with >= 512 zero bytes past n)
+  {
+    const uint32_t nb = woff + cnt + 272;                          // bytes to stage
+    const uint4 *src = (const uint4 *)(in + WB);
+    uint4 *dst = (uint4 *)win;
+    for (uint32_t i = tid; i < (nb + 15) / 16; i += 1024) dst[i] = src[i];
+    const uint32_t nl = woff + cnt;                                // links to stage (u16 each)
+    const uint4 *ls = (const uint4 *)(prevd + WB);
+    uint4 *ld = (uint4 *)lnk;
+    for (uint32_t i = tid; i < (nl * 2 + 15) / 16; i += 1024) ld[i] = ls[i];
+    if (tid == 0) next_pos = 0;
+  }
+  __syncthreads();
+  const int quarter = chain_cfg >> 2;
+  for (;;) {
+    uint32_t k = atomicAdd(&next_pos, 1u);
+    if (k >= cnt) break;
+    const uint32_t wi = woff + k;
+    const uint64_t p = B + k;
+    const uint64_t rem = n - p;
+    const int la = rem < 258 ? (int)rem : 258;                     // Longest_Match never returns more
+    const int nice = nice_cfg < la ? nice_cfg : la;                // lz77.adb:858-860
+    uint32_t rf = 0, rq = 0;
+    if (la >= 3) {
+      int best = 2; uint32_t bdist = 0;
+      int steps = 0;
+      bool have_q = false;
+      uint32_t cur = wi;
+      uint32_t s_end = lds_u32_at(win, wi + best - 1);             // bytes best-1, best (low 16 bits used)
+      const uint32_t s0 = lds_u32_at(win, wi);
+      for (;;) {
+        uint32_t d = lnk[cur];
+        if (d == 0) break;
+        cur -= d;
+        uint32_t dist = wi - cur;
+        if (dist > (uint32_t)(steps == 0 ? MAX_DIST : MAX_DIST - 1)) break;   // :850 first, :727-731/:820 later
+        steps++;
+        // quick reject as :754-757 (cannot beat `best` unless the bytes at best-1, best agree)
+        uint32_t c_end = lds_u32_at(win, cur + best - 1);
+        if (((c_end ^ s_end) & 0xFFFFu) == 0) {
+          uint32_t c0 = lds_u32_at(win, cur);
+          if (((c0 ^ s0) & 0xFFFFFFu) == 0) {                      // first three bytes (hash collisions differ here)
+            int len = 3;
+            while (len < la) {
+              uint32_t x = lds_u32_at(win, cur + len) ^ lds_u32_at(win, wi + len);
+              if (x) { len += __builtin_ctz(x) >> 3; break; }
+              len += 4;
+            }
+            if (len > la) len = la;
+            if (len > best) {
+              best = len; bdist = dist;
+              if (len >= nice) break;                              // :815
+              s_end = lds_u32_at(win, wi + best - 1);
+            }
+          }
+        }
+        if (steps == quarter) { have_q = true; rq = best >= 3 ? ((uint32_t)best << 16) | bdist : 0; }
+        if (steps == chain_cfg) break;                             // :821-822
+      }
+      rf = best >= 3 ? ((uint32_t)best << 16) | bdist : 0;
+      if (!have_q) rq = rf;
+    }
+    MF[p] = rf;
+    MQ[p] = rq;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// parser kernels
+// --------------------------------------------------------------------------------------------
+// one lane per chunk (the chunk logic itself is in zada_logic.h: parse_spec_chunk / parse_fix_chunk)
+__global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict__ spec_tok, uint32_t *__restrict__ spec_cnt,
+                             uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nchunks) return;
+  uint32_t ntok = 0;
+  ExitState ex;
+  parse_spec_chunk(io, k, PCHUNK, spec_tok + (uint64_t)k * PTOK_STRIDE, ntok, Fbits, Lbits, ex);
+  spec_cnt[k] = ntok;
+  exits[k] = ex;
+}
+
+// Fix-up: chunk k re-parses from the true exit of chunk k-1 until it meets the speculative parse.
+// dirty_in[k] != 0 : this chunk's entry changed since the last round and must be (re)done.
+__global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__restrict__ spec_tok, const uint32_t *__restrict__ spec_cnt,
+                            const uint32_t *__restrict__ Fbits, const uint32_t *__restrict__ Lbits,
+                            const ExitState *__restrict__ spec_exits, ExitState *__restrict__ true_exits,
+                            uint32_t *__restrict__ fix_tok, uint32_t *__restrict__ fix_cnt,
+                            uint32_t *__restrict__ take_from, uint32_t *__restrict__ start_pos,
+                            const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
+                            uint32_t *__restrict__ n_changed) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nchunks) return;
+  if (!dirty_in[k]) return;
+  ExitState entry; entry.pos = 0; entry.kind = SYNC_F;
+  if (k > 0) entry = true_exits[k - 1];
+  const ExitState old_exit = true_exits[k];
+  ExitState new_exit;
+  uint32_t ntok = 0, take = 0, u0 = 0;
+  parse_fix_chunk(io, k, PCHUNK, entry, spec_tok + (uint64_t)k * PTOK_STRIDE, spec_cnt[k], Fbits, Lbits, spec_exits[k],
+                  fix_tok + (uint64_t)k * PTOK_STRIDE, ntok, take, u0, new_exit);
+  fix_cnt[k] = ntok;
+  take_from[k] = take;
+  start_pos[k] = u0;
+  true_exits[k] = new_exit;
+  if (k + 1 < nchunks && (new_exit.pos != old_exit.pos || new_exit.kind != old_exit.kind)) {
+    dirty_out[k + 1] = 1;
+    atomicAdd(n_changed, 1u);
+  }
+}
+
+// per-chunk true token count
+__global__ void k_tok_count(uint32_t nchunks, const uint32_t *__restrict__ spec_cnt, const uint32_t *__restrict__ fix_cnt,
+                            const uint32_t *__restrict__ take_from, uint32_t *__restrict__ counts) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nchunks) counts[k] = fix_cnt[k] + (spec_cnt[k] - take_from[k]);
+}
+
+// one wave per chunk: copy tokens, compute byte position of every atom
+__global__ void __launch_bounds__(256) k_tok_compact(uint32_t nchunks, const uint32_t *__restrict__ spec_tok,
+                                                     const uint32_t *__restrict__ spec_cnt, const uint32_t *__restrict__ fix_tok,
+                                                     const uint32_t *__restrict__ fix_cnt, const uint32_t *__restrict__ take_from,
+                                                     const uint32_t *__restrict__ start_pos, const uint32_t *__restrict__ offsets,
+                                                     uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos) {
+  const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (k >= nchunks) return;
+  const uint32_t nf = fix_cnt[k], tf = take_from[k], ns = spec_cnt[k] - tf;
+  const uint32_t *ft = fix_tok + (uint64_t)k * PTOK_STRIDE;
+  const uint32_t *st = spec_tok + (uint64_t)k * PTOK_STRIDE + tf;
+  uint32_t out = offsets[k];
+  uint32_t pos = start_pos[k];
+  const uint32_t total = nf + ns;
+  for (uint32_t b = 0; b < total; b += 64) {
+    uint32_t i = b + lane;
+    uint32_t t = 0, len = 0;
+    if (i < total) { t = i < nf ? ft[i] : st[i - nf]; len = tok_len(t); }
+    uint32_t incl = len;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    if (i < total) { atoms[out + i] = t; apos[out + i] = pos + incl - len; }
+    pos += __shfl(incl, 63);
+  }
+}
+
+// ---- exclusive scan of uint32 counts (three small kernels) ----
+__global__ void __launch_bounds__(1024) k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                     uint32_t *__restrict__ block_sums, uint32_t n) {
+  __shared__ uint32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  uint32_t i = blockIdx.x * 1024 + tid;
+  uint32_t v = i < n ? in[i] : 0, incl = v;
+  for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int k = 0; k < w; k++) base += wsum[k];
+  if (i < n) out[i] = base + incl - v;
+  if (tid == 1023) block_sums[blockIdx.x] = base + incl;
+}
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *__restrict__ block_sums, uint32_t nb, uint32_t *__restrict__ total) {
+  // single block; nb <= 2^20
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b = 0; b < nb; b += 1024) {
+    uint32_t i = b + tid;
+    uint32_t v = i < nb ? block_sums[i] : 0, incl = v;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t base = carry;
+    for (int k = 0; k < w; k++) base += wsum[k];
+    if (i < nb) block_sums[i] = base + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = base + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+__global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ block_sums, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += block_sums[i >> 10];
+}
+
+// No-LZ77 front end (LZ77.No_LZ77, lz77.adb:2191-2194): every byte is a literal atom.
+__global__ void k_literal_atoms(const uint8_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos) {
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { atoms[i] = in[i]; apos[i] = (uint32_t)i; }
+}
+
+// --------------------------------------------------------------------------------------------
+// host side of the LZ stage
+// --------------------------------------------------------------------------------------------
+void exclusive_scan_u32(hipStream_t st, const uint32_t *d_in, uint32_t *d_out, uint32_t *d_sums, uint32_t *d_total, uint32_t n) {
+  uint32_t nb = (n + 1023) / 1024;
+  hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(1024), 0, st, d_in, d_out, d_sums, n);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, d_sums, nb, d_total);
+  hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, st, d_out, d_sums, n);
+}
+
+int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
+  hipStream_t st = c->stream;
+  Workspace &W = c->ws;
+  if (n == 0) { *ntok_out = 0; return 0; }
+  if (level == 0) {
+    hipLaunchKernelGGL(k_literal_atoms, dim3(2048), dim3(256), 0, st, W.in, n, W.atoms, W.apos);
+    *ntok_out = (uint32_t)n;
+    return hip_check(c, hipGetLastError(), "k_literal_atoms");
+  }
+  const LzConfig cfg = lz_config(level);
+  const uint64_t n_ins = n >= 2 ? n - 2 : 0;
+  const uint32_t nseg = (uint32_t)((n_ins + 32767) / 32768);
+  c->tmark("lz:begin");
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
+    hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16);
+    attr_done = true;
+  }
+  if (nseg > 0) {
+    hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, W.prevd, W.tails);
+    if (nseg > 1) hipLaunchKernelGGL(k_cross_links, dim3(4096), dim3(256), 0, st, W.in, n_ins, W.prevd, W.tails);
+  }
+  c->tmark("prev_links");
+  {
+    uint32_t nb = (uint32_t)((n + MB - 1) / MB);
+    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16, st, W.in, n, W.prevd, W.MF, W.MQ, cfg.nice, cfg.chain);
+  }
+  c->tmark("match");
+  const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
+  ParseIO io; io.in = W.in; io.n = n; io.MF = W.MF; io.MQ = W.MQ; io.cfg = cfg;
+  hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
+                     W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits);
+  // fixpoint of the splice: round 0 handles every chunk with the speculative exits as entries
+  hipMemcpyAsync(W.true_exits, W.spec_exits, (size_t)nch * sizeof(ExitState), hipMemcpyDeviceToDevice, st);
+  hipMemsetAsync(W.dirty[0], 1, nch, st);
+  int cur = 0, rounds = 0;
+  for (;;) {
+    hipMemsetAsync(W.dirty[cur ^ 1], 0, nch, st);
+    hipMemsetAsync(W.n_changed, 0, 4, st);
+    hipLaunchKernelGGL(k_parse_fix, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
+                       W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, W.true_exits, W.fix_tok, W.fix_cnt,
+                       W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed);
+    uint32_t changed = 0;
+    hipMemcpyAsync(&changed, W.n_changed, 4, hipMemcpyDeviceToHost, st);
+    if (hip_check(c, hipStreamSynchronize(st), "parse_fix")) return ZADA_E_HIP_;
+    rounds++;
+    if (changed == 0) break;
+    cur ^= 1;
+  }
+  c->parse_rounds = rounds;
+  c->tmark("parse");
+  hipLaunchKernelGGL(k_tok_count, dim3((nch + 255) / 256), dim3(256), 0, st, nch, W.spec_cnt, W.fix_cnt, W.take_from, W.counts);
+  exclusive_scan_u32(st, W.counts, W.offsets, W.scan_sums, W.n_changed, nch);
+  uint32_t total = 0;
+  hipMemcpyAsync(&total, W.n_changed, 4, hipMemcpyDeviceToHost, st);
+  // the atom arrays alias the match tables, which are dead from here on: wait for the scan first
+  if (hip_check(c, hipStreamSynchronize(st), "tok_scan")) return ZADA_E_HIP_;
+  hipLaunchKernelGGL(k_tok_compact, dim3((nch + 3) / 4), dim3(256), 0, st, nch, W.spec_tok, W.spec_cnt, W.fix_tok, W.fix_cnt,
+                     W.take_from, W.start_pos, W.offsets, W.atoms, W.apos);
+  c->tmark("compact");
+  *ntok_out = total;
+  return hip_check(c, hipGetLastError(), "lz_stage");
+}
+
+}  // namespace zada
