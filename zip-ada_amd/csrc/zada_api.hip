@@ -92,6 +92,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(tile_block, W.cap_tiles); A(tile_bitpos, W.cap_tiles); A(tile_bits, W.cap_tiles);
   A(chooser, 1);
   A(crc_part, nch);
+  A(dbg, 64);
   W.cap_out = cap + cap / 1024 + 4096;
   A(out, W.cap_out);
 #undef A
@@ -100,6 +101,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   W.cap_n = cap;
   // the input pad must be zero for the match finder's over-reads
   hipMemsetAsync(W.in, 0, cap + IN_PAD + 64, c->stream);
+  hipMemsetAsync(W.dbg, 0, 64 * 8, c->stream);
   return hip_check(c, hipStreamSynchronize(c->stream), "workspace init");
 }
 

@@ -82,6 +82,7 @@ struct Workspace {
   uint32_t *tile_bits = nullptr;
   ChooserOut *chooser = nullptr;
   uint32_t *crc_part = nullptr;
+  uint64_t *dbg = nullptr;
   uint8_t *out = nullptr;
   uint64_t cap_blocks = 0, cap_tiles = 0, cap_pieces = 0, cap_out = 0;
   std::vector<void *> allocs;

@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include "zada_logic.h"
 #include "zada_internal.h"
+#include <stdio.h>
 
 namespace zada {
 
@@ -146,14 +147,22 @@ __device__ __forceinline__ uint32_t lds_u32_at(const uint32_t *w, uint32_t byteo
   return __builtin_amdgcn_alignbyte(w[i + 1], w[i], byteoff & 3);
 }
 
+// Persistent-lane formulation: every lane owns one position at a time and runs a two-mode state
+// machine; a lane whose position is finished fetches the next one at once, so a wave never waits
+// for its longest chain.  Mode 0 = advance to the next candidate and test the two bytes that must
+// match for it to beat `best` (:754-757); mode 1 = compare 4 more bytes of a surviving candidate.
+// Both modes share one instruction stream: two unaligned LDS dwords at (cand + off), (scan + off).
 __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, uint64_t n,
                                                 const uint16_t *__restrict__ prevd,
                                                 uint32_t *__restrict__ MF, uint32_t *__restrict__ MQ,
-                                                int nice_cfg, int chain_cfg) {
+                                                int nice_cfg, int chain_cfg, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // WBYTES bytes
   uint16_t *lnk = (uint16_t *)(smem + WBYTES);                    // WLINKS * 2 bytes
   uint32_t &next_pos = *(uint32_t *)(smem + WBYTES + WLINKS * 2);
+#ifdef ZADA_MATCH_STATS
+  unsigned long long t_start = clock64(), t_empty = 0, iters = 0;
+#endif
   const uint64_t B = (uint64_t)blockIdx.x * MB;
   const uint64_t WB = B >= (uint64_t)HALO ? B - HALO : 0;
   const uint32_t woff = (uint32_t)(B - WB);                        // window index of position B
@@ -173,57 +182,94 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   }
   __syncthreads();
   const int quarter = chain_cfg >> 2;
-  for (;;) {
-    uint32_t k = atomicAdd(&next_pos, 1u);
-    if (k >= cnt) break;
-    const uint32_t wi = woff + k;
-    const uint64_t p = B + k;
-    const uint64_t rem = n - p;
-    const int la = rem < 258 ? (int)rem : 258;                     // Longest_Match never returns more
-    const int nice = nice_cfg < la ? nice_cfg : la;                // lz77.adb:858-860
-    uint32_t rf = 0, rq = 0;
-    if (la >= 3) {
-      int best = 2; uint32_t bdist = 0;
-      int steps = 0;
-      bool have_q = false;
-      uint32_t cur = wi;
-      uint32_t s_end = lds_u32_at(win, wi + best - 1);             // bytes best-1, best (low 16 bits used)
-      const uint32_t s0 = lds_u32_at(win, wi);
-      for (;;) {
-        uint32_t d = lnk[cur];
-        if (d == 0) break;
-        cur -= d;
-        uint32_t dist = wi - cur;
-        if (dist > (uint32_t)(steps == 0 ? MAX_DIST : MAX_DIST - 1)) break;   // :850 first, :727-731/:820 later
-        steps++;
-        // quick reject as :754-757 (cannot beat `best` unless the bytes at best-1, best agree)
-        uint32_t c_end = lds_u32_at(win, cur + best - 1);
-        if (((c_end ^ s_end) & 0xFFFFu) == 0) {
-          uint32_t c0 = lds_u32_at(win, cur);
-          if (((c0 ^ s0) & 0xFFFFFFu) == 0) {                      // first three bytes (hash collisions differ here)
-            int len = 3;
-            while (len < la) {
-              uint32_t x = lds_u32_at(win, cur + len) ^ lds_u32_at(win, wi + len);
-              if (x) { len += __builtin_ctz(x) >> 3; break; }
-              len += 4;
-            }
-            if (len > la) len = la;
-            if (len > best) {
-              best = len; bdist = dist;
-              if (len >= nice) break;                              // :815
-              s_end = lds_u32_at(win, wi + best - 1);
-            }
-          }
-        }
-        if (steps == quarter) { have_q = true; rq = best >= 3 ? ((uint32_t)best << 16) | bdist : 0; }
-        if (steps == chain_cfg) break;                             // :821-822
+  // Per-lane walker state.  `cur` is the candidate under test (already known to be in range);
+  // its chain link is loaded together with its bytes, so one LDS round trip serves a whole step.
+  struct Walker {
+    uint32_t wi, cur, bdist, rq, off, cdist, kpos;
+    int best, steps, la, nice, mode;
+    bool have_q, alive;
+  };
+  auto walker_fetch = [&](Walker &w, bool &exhausted) {
+    const uint32_t k = atomicAdd(&next_pos, 1u);
+#ifdef ZADA_MATCH_STATS
+    if (k >= cnt && t_empty == 0) t_empty = clock64();
+#endif
+    if (k >= cnt) { exhausted = true; return; }
+    w.kpos = k; w.wi = woff + k;
+    const uint64_t rem = n - (B + k);
+    w.la = rem < 258 ? (int)rem : 258;                             // Longest_Match never returns more
+    w.nice = nice_cfg < w.la ? nice_cfg : w.la;                    // lz77.adb:858-860
+    w.best = 2; w.bdist = 0; w.steps = 1; w.have_q = false; w.rq = 0; w.mode = 0; w.off = 0;
+    const uint32_t d0 = lnk[w.wi];                                 // hash_head (:842), distance <= MAX_DIST (:850)
+    w.alive = w.la >= 3 && d0 != 0;
+    w.cur = w.alive ? w.wi - d0 : w.wi;
+    w.cdist = d0;
+    if (!w.alive) { MF[B + k] = 0; MQ[B + k] = 0; }
+  };
+  auto walker_step = [&](Walker &w) {
+    const bool m0 = (w.mode == 0);
+    const uint32_t dn = lnk[w.cur];                                // link to the NEXT candidate
+    const uint32_t o = m0 ? (uint32_t)w.best - 1 : w.off;
+    const uint32_t x = lds_u32_at(win, w.cur + o) ^ lds_u32_at(win, w.wi + o);
+    const bool pass = m0 && ((x & 0xFFFFu) == 0);                  // bytes best-1, best agree (:754-755)
+    const bool mism = x != 0;
+    const uint32_t o4 = o + 4;
+    const bool cdone1 = !m0 && (mism || (int)o4 >= w.la);
+    int len = mism ? (int)o + (int)(__builtin_ctz(x | 0x80000000u) >> 3) : w.la;
+    len = len < w.la ? len : w.la;
+    const bool improved = cdone1 && len > w.best;                  // :812-817
+    w.best = improved ? len : w.best;
+    w.bdist = improved ? w.cdist : w.bdist;
+    const bool hitnice = improved && len >= w.nice;                // :815
+    const bool cand_done = (m0 && !pass) || cdone1;
+    const uint32_t packed = w.best >= 3 ? ((uint32_t)w.best << 16) | w.bdist : 0u;
+    const bool atq = cand_done && !hitnice && w.steps == quarter;  // quarter-chain snapshot (:733-735)
+    w.rq = atq ? packed : w.rq;
+    w.have_q = w.have_q || atq;
+    // advance to the next candidate (:819-822)
+    const uint32_t ncur = w.cur - dn, ndist = w.wi - ncur;
+    const bool chain_end = dn == 0 || ndist > (uint32_t)(MAX_DIST - 1) || w.steps == chain_cfg;
+    const bool finish = w.alive && (hitnice || (cand_done && chain_end));
+    const bool adv = cand_done && !chain_end;
+    w.cur = adv ? ncur : w.cur;
+    w.cdist = adv ? ndist : w.cdist;
+    w.steps += adv ? 1 : 0;
+    w.off = pass ? 0u : (m0 ? w.off : o4);
+    w.mode = pass ? 1 : (cdone1 ? 0 : w.mode);
+    if (__any(finish)) {
+      if (finish) {
+        MF[B + w.kpos] = packed;
+        MQ[B + w.kpos] = w.have_q ? w.rq : packed;
+        w.alive = false;
       }
-      rf = best >= 3 ? ((uint32_t)best << 16) | bdist : 0;
-      if (!have_q) rq = rf;
     }
-    MF[p] = rf;
-    MQ[p] = rq;
+  };
+  Walker wa, wb;
+  wa.wi = wa.cur = woff; wa.bdist = wa.rq = wa.off = wa.cdist = wa.kpos = 0; wa.best = 2; wa.steps = 1; wa.la = 3; wa.nice = 3; wa.mode = 0; wa.have_q = false; wa.alive = false;
+  wb = wa;
+  bool exhausted = false;
+  for (;;) {
+    const bool need_a = !wa.alive && !exhausted;
+    if (__any(need_a)) { if (need_a) walker_fetch(wa, exhausted); }
+    const bool need_b = !wb.alive && !exhausted;
+    if (__any(need_b)) { if (need_b) walker_fetch(wb, exhausted); }
+#ifdef ZADA_MATCH_STATS
+    iters += (wa.alive ? 1 : 0) + (wb.alive ? 1 : 0);
+#endif
+    walker_step(wa);
+    walker_step(wb);
+    if (!__any(wa.alive || wb.alive || !exhausted)) break;
   }
+#ifdef ZADA_MATCH_STATS
+  {
+    unsigned long long t_end = clock64();
+    atomicAdd(&dbg[0], iters);                                   // lane-iterations
+    atomicMax(&dbg[1], t_end - t_start);                         // longest lane lifetime (cycles)
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&dbg[2], t_end - t_start); atomicAdd(&dbg[3], 1ull); atomicAdd(&dbg[4], t_end - t_empty); }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(&dbg[5], clock64() - t_start); atomicAdd(&dbg[6], 1ull); }
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------
@@ -387,8 +433,17 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   c->tmark("prev_links");
   {
     uint32_t nb = (uint32_t)((n + MB - 1) / MB);
-    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16, st, W.in, n, W.prevd, W.MF, W.MQ, cfg.nice, cfg.chain);
+    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16, st, W.in, n, W.prevd, W.MF, W.MQ, cfg.nice, cfg.chain, (unsigned long long *)W.dbg);
   }
+#ifdef ZADA_MATCH_STATS
+  {
+    unsigned long long h[8];
+    hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[match stats] n=%llu lane_iters=%llu (%.1f/pos) max_lane_cycles=%llu avg_wave_cycles=%.0f avg_wave_tail=%.0f avg_block_cycles=%.0f blocks=%llu\n",
+            (unsigned long long)n, h[0], (double)h[0] / n, h[1], (double)h[2] / h[3], (double)h[4] / h[3], (double)h[5] / h[6], h[6]);
+    hipMemset(W.dbg, 0, 64);
+  }
+#endif
   c->tmark("match");
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
   ParseIO io; io.in = W.in; io.n = n; io.MF = W.MF; io.MQ = W.MQ; io.cfg = cfg;
