@@ -1,0 +1,152 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the oracle on the same inputs -- bit-exact (integer/byte work) -- against the committed golden
+digests, and through size-independent properties at the benchmark's full size."""
+import hashlib
+import io
+import json
+import os
+import zipfile
+import zlib
+
+import numpy as np
+import pytest
+
+from _common import GOLDEN, METHODS, edge_inputs, oracle_deflate, oracle_tokens, oracle_zip, product, silesia_mix
+
+pytestmark = pytest.mark.gpu
+FIXTURE_FILES = ("sample.xls", "sample.jpg", "sample_pgm_100k.bin")
+
+
+def gpu_deflate(enc, d, method):
+    za = product()
+    try:
+        out, crc = enc.deflate(d, method)
+        return 0, out, crc
+    except za.CompressionInefficient:
+        return 1, b"", None
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_tokens_bit_exact_vs_oracle(encoder, method):
+    """LZ77 stage alone (lz77.adb:460-943 semantics): identical token streams."""
+    for name, d in edge_inputs().items():
+        a = oracle_tokens(d, method)
+        b = encoder.lz77_tokens(d, method)
+        assert len(a) == len(b) and (a == b).all(), name
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_stream_bit_exact_vs_oracle(encoder, method):
+    """Whole path: same bytes, same CRC register, same compression_ok, same block decisions."""
+    for name, d in edge_inputs().items():
+        ob = []
+        rc, ref, crc = oracle_deflate(d, method, ob)
+        rc2, out, crc2 = gpu_deflate(encoder, d, method)
+        assert rc == rc2, name
+        if rc == 0:
+            assert out == ref, name
+            assert crc2 == crc, name
+            if method != 6:
+                gb = encoder.last_blocks()
+                assert [(int(a), int(b), int(c)) for a, b, c, _ in gb] == [(a, b, c) for a, b, c, _ in ob], name
+
+
+def test_golden_digests(encoder):
+    """Oracle-free comparison with the committed fixtures (tests/golden/deflate_digests.json)."""
+    dig = json.load(open(os.path.join(GOLDEN, "deflate_digests.json")))
+    cases = dict(edge_inputs())
+    for f in FIXTURE_FILES:
+        cases[f] = open(os.path.join(GOLDEN, f), "rb").read()
+    for key, want in dig.items():
+        name, m = key.rsplit("|", 1)
+        d = cases[name]
+        rc, out, crc = gpu_deflate(encoder, d, int(m))
+        assert rc == want["rc"], key
+        if rc == 0:
+            assert len(out) == want["size"] and hashlib.sha256(out).hexdigest() == want["sha256"], key
+            assert crc ^ 0xFFFFFFFF == want["crc"], key
+
+
+def test_multi_flush_and_long_streams(encoder):
+    """More than 65536 atoms (several Flush_half_buffer rounds, odd/even halves, look-behind
+    windows) and all five synthetic classes."""
+    for mask, n in ((0x1F, 6 << 20), (1, 3 << 20), (16, 1 << 20), (8, 2 << 20), (0x1F, (4 << 20) + 12345)):
+        d = silesia_mix(n, class_mask=mask)
+        for method in (10, 9, 8):
+            rc, ref, crc = oracle_deflate(d, method)
+            rc2, out, crc2 = gpu_deflate(encoder, d, method)
+            assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), (mask, n, method)
+
+
+def test_never_resynchronising_inputs(encoder):
+    """Periodic data: the speculative chunk parses never meet the true parse; the splice must still
+    converge to the sequential result."""
+    for d in (bytes(300000), b"ab" * 150000, b"abc" * 100000 + b"x" + b"abcd" * 1000, bytes(range(256)) * 1200):
+        for method in (10, 8):
+            rc, ref, crc = oracle_deflate(d, method)
+            rc2, out, crc2 = gpu_deflate(encoder, d, method)
+            assert rc == rc2 and out == ref and crc == crc2
+
+
+def test_compress_data_store_fallback_and_archive_bytes(encoder):
+    """Zip.Compress.Compress_Data + Zip.Create bytes == the oracle's archive; readable by zipfile."""
+    za = product()
+    entries = [("a/text.txt", silesia_mix(200000, class_mask=1)), ("b\\rand.bin", bytes(np.random.RandomState(3).randint(0, 256, 3000).astype(np.uint8))),
+               ("empty", b""), ("mix.bin", silesia_mix(1 << 20))]
+    for method in (10, 8):
+        zc = za.ZipCreate(encoder, method)
+        for name, data in entries:
+            zc.add_stream(name, data)
+        got = zc.finish()
+        assert got == oracle_zip(entries, method)
+        zf = zipfile.ZipFile(io.BytesIO(got))
+        assert zf.testzip() is None
+        for (name, data), info in zip(entries, zf.infolist()):
+            assert zf.read(info) == data
+
+
+def test_feedback_and_abort(encoder):
+    za = product()
+    d = silesia_mix(1 << 20)
+    seen = []
+    encoder.deflate(d, 10, feedback=lambda pct: seen.append(pct) or False)
+    assert seen[0] == 0 and seen[-1] == 100 and seen == sorted(seen)
+    with pytest.raises(za.UserAbort):
+        encoder.deflate(d, 10, feedback=lambda pct: pct >= 5)
+
+
+def test_device_resident_entry_point(encoder):
+    """zada_deflate_device (HBM in, HBM out) == host-buffer entry point."""
+    import torch
+    za = product()
+    d = silesia_mix(2 << 20)
+    t_in = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    t_out = torch.zeros(len(d) + 4096, dtype=torch.uint8, device="cuda")
+    rc, ol, crc = encoder.deflate_device(t_in.data_ptr(), len(d), t_out.data_ptr(), len(d) + 4096, 10)
+    ref, crc2 = encoder.deflate(d, 10)
+    assert rc == 0 and bytes(t_out[:ol].cpu().numpy()) == ref and crc == crc2
+
+
+def test_full_size_properties(encoder):
+    """BASELINE config C2 size (1 GiB, Deflate_3): properties that do not need the oracle at full size --
+    the stream inflates back to the input (independent inflater), CRC equals zlib's, and the first
+    64 MiB entry compressed alone equals the oracle's stream (the encoder is a pure function)."""
+    za = product()
+    n = 1 << 30
+    d = za.silesia_mix(n)
+    out, crc = encoder.deflate(d, 10)
+    dec = zlib.decompressobj(-15)
+    h = hashlib.sha256()
+    total = 0
+    view = memoryview(out)
+    for off in range(0, len(out), 1 << 24):
+        chunk = dec.decompress(view[off:off + (1 << 24)])
+        h.update(chunk); total += len(chunk)
+    tail = dec.flush(); h.update(tail); total += len(tail)
+    assert total == n and h.digest() == hashlib.sha256(d).digest()
+    assert crc ^ 0xFFFFFFFF == zlib.crc32(d)
+    assert 0.30 < len(out) / n < 0.42
+    head = d[:16 << 20].tobytes()
+    rc, ref, _ = oracle_deflate(head, 10)
+    got, _ = encoder.deflate(head, 10)
+    assert rc == 0 and got == ref

@@ -1,0 +1,90 @@
+"""CPU tests of the product's host/device logic (zip-ada_amd/csrc/zada_logic.h compiled for the host
+by tests/hostcheck -- a TEST library) against the oracle.  These are the per-lane routines the HIP
+kernels run; the kernels themselves are covered by the -m gpu tests."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+
+from _common import ROOT, edge_inputs, hostcheck, oracle, oracle_tokens, silesia_mix
+
+
+def test_llhc_lane_serial_equals_oracle():
+    """llhc_serial (explicit-stack boundary package-merge + the reference's quicksort) ==
+    oracle's literal restatement, ties included."""
+    O, H = oracle(), hostcheck()
+    rs = np.random.RandomState(5)
+    for it in range(3000):
+        n, mb = ((288, 15), (32, 15), (19, 7))[it % 3]
+        kind = it % 7
+        if kind == 0: f = rs.randint(0, 4, n)
+        elif kind == 1: f = rs.randint(0, 50, n)
+        elif kind == 2: f = (rs.pareto(1.0, n) * 10).astype(np.int64)
+        elif kind == 3: f = rs.randint(0, 2, n) * rs.randint(1, 100000, n)
+        elif kind == 4: f = np.where(rs.rand(n) < 0.1, rs.randint(1, 5, n), 0)
+        elif kind == 5: f = (2 ** rs.randint(0, 17, n)) * (rs.rand(n) < 0.5)
+        else: f = rs.randint(1, 3, n)
+        f = np.minimum(f, 1 << 24)
+        f64, f32 = f.astype(np.uint64), f.astype(np.uint32)
+        a = np.zeros(n, dtype=np.int32)
+        b = np.zeros(n, dtype=np.uint8)
+        assert O.zo_llhc(f64.ctypes.data, n, mb, a.ctypes.data) == 0
+        H.hc_llhc(f32.ctypes.data_as(ctypes.c_void_p), n, mb, b.ctypes.data_as(ctypes.c_void_p))
+        assert (a == b).all(), (it, n, kind)
+
+
+def test_symbol_tables_equal_rfc1951():
+    H = hostcheck()
+    lbase = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    lext = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
+    dbase = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+    dext = [0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13]
+    for L in range(3, 259):
+        s = 28 if L == 258 else max(i for i in range(28) if lbase[i] <= L)
+        assert H.hc_len_symbol(L) == 257 + s and H.hc_len_extra_bits(L) == lext[s] and H.hc_len_extra_val(L) == L - lbase[s]
+    for D in range(1, 32769):
+        s = max(i for i in range(30) if dbase[i] <= D)
+        assert H.hc_dist_symbol(D) == s and H.hc_dist_extra_bits(D) == dext[s] and H.hc_dist_extra_val(D) == D - dbase[s]
+
+
+@pytest.mark.parametrize("method", (6, 8, 9, 10))
+def test_chunked_speculative_parse_equals_sequential_reference(method):
+    """The GPU's parse = per-chunk speculative parse + splice to a fixpoint (parse_spec_chunk /
+    parse_fix_chunk) over all-position match tables.  Emulated sequentially here; must give the
+    oracle's (= the reference's sequential) token stream, also on inputs that never resynchronise."""
+    H = hostcheck()
+    level = {6: 4, 8: 6, 9: 8, 10: 10}[method]
+    cases = edge_inputs()
+    for name, d in cases.items():
+        if len(d) > 400000:
+            continue
+        a = oracle_tokens(d, method)
+        for chunk in (4096, 1024):
+            t = np.zeros(len(d) + 8, dtype=np.uint32)
+            r = ctypes.c_int(0)
+            k = H.hc_chunked_tokens(d, len(d), level, chunk, t.ctypes.data, len(t), ctypes.byref(r))
+            assert k == len(a) and (t[:k] == a).all(), (name, chunk)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The C-ABI library loads and exports every function include/zada.h declares (no compute)."""
+    hdr = open(os.path.join(ROOT, "include", "zada.h")).read()
+    names = set(re.findall(r"\b(zada_[a-z0-9_]+)\s*\(", hdr)) - {"zada_feedback_fn"}
+    assert len(names) >= 12
+    lib = ctypes.CDLL(os.path.join(ROOT, "zip-ada_amd", "libzada_hip.so"))
+    for nme in sorted(names):
+        assert hasattr(lib, nme), nme
+    lib.zada_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.zada_version()
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not import, link or execute anything under oracle/."""
+    base = os.path.join(ROOT, "zip-ada_amd")
+    for dp, _dn, fn in os.walk(base):
+        for f in fn:
+            if f.endswith((".hip", ".h", ".c", ".cpp", ".py", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "zada_oracle" not in txt and "libzada_oracle" not in txt and "zo_deflate" not in txt, f

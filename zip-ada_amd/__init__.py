@@ -205,10 +205,15 @@ class ZipCreate:
                            e["csize"], e["usize"], len(e["name"]), 0)
 
     def add_stream(self, name, data, file_time=None, unicode_name=True):
-        nm = name.replace("\\", "/").encode("utf-8")
         payload, crc, zt = self.enc.compress_data(data, self.method)
+        return self.add_compressed(name, payload, crc, len(data), zt, file_time, unicode_name)
+
+    def add_compressed(self, name, payload, crc, usize, zt, file_time=None, unicode_name=True):
+        """Entry whose payload was compressed elsewhere (another rank / GPU): the bytes written
+        are those Add_Stream would have written for the same payload."""
+        nm = name.replace("\\", "/").encode("utf-8")
         e = dict(name=nm, flag=0x0800 if unicode_name else 0, zip_type=zt, time=self.DEFAULT_TIME if file_time is None else file_time,
-                 crc=crc, csize=len(payload), usize=len(data), offset=len(self.buf))
+                 crc=crc, csize=len(payload), usize=usize, offset=len(self.buf))
         if e["usize"] >= 0xFFFFFFFF - (1 << 17) or e["offset"] + e["csize"] >= 0xFFFFFFFF - (1 << 17) or len(self.entries) >= 65534:
             raise ZadaError("Zip_64 archives are not implemented")
         self.buf += self._local(e) + nm + payload
