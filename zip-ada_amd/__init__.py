@@ -17,7 +17,7 @@ import os
 import struct
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzada_hip.so")
+LIB_PATH = os.environ.get("ZADA_LIB", os.path.join(_HERE, "libzada_hip.so"))   # ZADA_LIB: A/B builds of the same library
 
 
 class Method:

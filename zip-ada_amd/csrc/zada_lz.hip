@@ -137,6 +137,9 @@ __global__ void k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, ui
 // --------------------------------------------------------------------------------------------
 // Block of MB positions [B, B+MB); LDS holds input bytes [WB, B+MB+272) and the chain links
 // (distance to previous same-hash position) of [WB, B+MB), WB = B - HALO (clamped at 0).
+#ifndef ZADA_FAST
+#define ZADA_FAST 4
+#endif
 constexpr int MB = 16384;
 constexpr int HALO = 32512;                       // >= MAX_DIST, multiple of 16
 constexpr int WBYTES = HALO + MB + 272;           // 49168
@@ -182,83 +185,100 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   }
   __syncthreads();
   const int quarter = chain_cfg >> 2;
-  // Per-lane walker state.  `cur` is the candidate under test (already known to be in range);
-  // its chain link is loaded together with its bytes, so one LDS round trip serves a whole step.
-  struct Walker {
-    uint32_t wi, cur, bdist, rq, off, cdist, kpos;
-    int best, steps, la, nice, mode;
-    bool have_q, alive;
-  };
-  auto walker_fetch = [&](Walker &w, bool &exhausted) {
-    const uint32_t k = atomicAdd(&next_pos, 1u);
+  const uint8_t *win8 = (const uint8_t *)win;
+  // Per-lane walker: state 0 = FREE (needs a position), 1 = WALK (fast filter steps), 2 = EVENT
+  // (its current candidate passed the two-byte filter and/or its chain ended / hit a limit).
+  // FAST PHASE: ZADA_FAST filter steps with no side paths; SLOW PHASE: everything rare, once per round.
+  uint32_t wi = woff, cur = woff, ncur = woff, bdist = 0, rq = 0, kpos = 0, s_end = 0;
+  int best = 2, la = 3, nice = 3, steps_left = 1, state = 0;
+  bool have_q = false, ev_pass = false, ev_end = false, ev_lim = false, exhausted = false;
+  for (;;) {
+    // ---- fetch ----
+    const bool need = (state == 0) && !exhausted;
+    if (__any(need)) {
+      if (need) {
+        const uint32_t k = atomicAdd(&next_pos, 1u);
 #ifdef ZADA_MATCH_STATS
-    if (k >= cnt && t_empty == 0) t_empty = clock64();
+        if (k >= cnt && t_empty == 0) t_empty = clock64();
 #endif
-    if (k >= cnt) { exhausted = true; return; }
-    w.kpos = k; w.wi = woff + k;
-    const uint64_t rem = n - (B + k);
-    w.la = rem < 258 ? (int)rem : 258;                             // Longest_Match never returns more
-    w.nice = nice_cfg < w.la ? nice_cfg : w.la;                    // lz77.adb:858-860
-    w.best = 2; w.bdist = 0; w.steps = 1; w.have_q = false; w.rq = 0; w.mode = 0; w.off = 0;
-    const uint32_t d0 = lnk[w.wi];                                 // hash_head (:842), distance <= MAX_DIST (:850)
-    w.alive = w.la >= 3 && d0 != 0;
-    w.cur = w.alive ? w.wi - d0 : w.wi;
-    w.cdist = d0;
-    if (!w.alive) { MF[B + k] = 0; MQ[B + k] = 0; }
-  };
-  auto walker_step = [&](Walker &w) {
-    const bool m0 = (w.mode == 0);
-    const uint32_t dn = lnk[w.cur];                                // link to the NEXT candidate
-    const uint32_t o = m0 ? (uint32_t)w.best - 1 : w.off;
-    const uint32_t x = lds_u32_at(win, w.cur + o) ^ lds_u32_at(win, w.wi + o);
-    const bool pass = m0 && ((x & 0xFFFFu) == 0);                  // bytes best-1, best agree (:754-755)
-    const bool mism = x != 0;
-    const uint32_t o4 = o + 4;
-    const bool cdone1 = !m0 && (mism || (int)o4 >= w.la);
-    int len = mism ? (int)o + (int)(__builtin_ctz(x | 0x80000000u) >> 3) : w.la;
-    len = len < w.la ? len : w.la;
-    const bool improved = cdone1 && len > w.best;                  // :812-817
-    w.best = improved ? len : w.best;
-    w.bdist = improved ? w.cdist : w.bdist;
-    const bool hitnice = improved && len >= w.nice;                // :815
-    const bool cand_done = (m0 && !pass) || cdone1;
-    const uint32_t packed = w.best >= 3 ? ((uint32_t)w.best << 16) | w.bdist : 0u;
-    const bool atq = cand_done && !hitnice && w.steps == quarter;  // quarter-chain snapshot (:733-735)
-    w.rq = atq ? packed : w.rq;
-    w.have_q = w.have_q || atq;
-    // advance to the next candidate (:819-822)
-    const uint32_t ncur = w.cur - dn, ndist = w.wi - ncur;
-    const bool chain_end = dn == 0 || ndist > (uint32_t)(MAX_DIST - 1) || w.steps == chain_cfg;
-    const bool finish = w.alive && (hitnice || (cand_done && chain_end));
-    const bool adv = cand_done && !chain_end;
-    w.cur = adv ? ncur : w.cur;
-    w.cdist = adv ? ndist : w.cdist;
-    w.steps += adv ? 1 : 0;
-    w.off = pass ? 0u : (m0 ? w.off : o4);
-    w.mode = pass ? 1 : (cdone1 ? 0 : w.mode);
-    if (__any(finish)) {
-      if (finish) {
-        MF[B + w.kpos] = packed;
-        MQ[B + w.kpos] = w.have_q ? w.rq : packed;
-        w.alive = false;
+        if (k >= cnt) exhausted = true;
+        else {
+          kpos = k; wi = woff + k;
+          const uint64_t rem = n - (B + k);
+          la = rem < 258 ? (int)rem : 258;                         // Longest_Match never returns more
+          nice = nice_cfg < la ? nice_cfg : la;                    // lz77.adb:858-860
+          best = 2; bdist = 0; have_q = false; rq = 0; steps_left = quarter;
+          const uint32_t d0 = lnk[wi];                             // hash_head (:842); distance <= MAX_DIST (:850) by construction
+          const bool ok = la >= 3 && d0 != 0;
+          cur = ok ? wi - d0 : wi;
+          s_end = (uint32_t)win8[wi + 1] | ((uint32_t)win8[wi + 2] << 8);
+          state = ok ? 1 : 0;
+          if (!ok) { MF[B + k] = 0; MQ[B + k] = 0; }
+        }
       }
     }
-  };
-  Walker wa, wb;
-  wa.wi = wa.cur = woff; wa.bdist = wa.rq = wa.off = wa.cdist = wa.kpos = 0; wa.best = 2; wa.steps = 1; wa.la = 3; wa.nice = 3; wa.mode = 0; wa.have_q = false; wa.alive = false;
-  wb = wa;
-  bool exhausted = false;
-  for (;;) {
-    const bool need_a = !wa.alive && !exhausted;
-    if (__any(need_a)) { if (need_a) walker_fetch(wa, exhausted); }
-    const bool need_b = !wb.alive && !exhausted;
-    if (__any(need_b)) { if (need_b) walker_fetch(wb, exhausted); }
+    if (!__any(state != 0)) { if (__all(exhausted)) break; continue; }
+    // ---- fast phase ----
+#pragma unroll
+    for (int it = 0; it < ZADA_FAST; it++) {
+      if (state == 1) {
 #ifdef ZADA_MATCH_STATS
-    iters += (wa.alive ? 1 : 0) + (wb.alive ? 1 : 0);
+        iters++;
 #endif
-    walker_step(wa);
-    walker_step(wb);
-    if (!__any(wa.alive || wb.alive || !exhausted)) break;
+        const uint32_t dn = lnk[cur];                              // link to the next candidate
+        const uint32_t a = cur + (uint32_t)best;
+        const uint32_t c16 = (uint32_t)win8[a - 1] | ((uint32_t)win8[a] << 8);
+        const bool pass = c16 == s_end;                            // bytes best-1, best agree (:754-755)
+        const uint32_t nc = cur - dn, nd = wi - nc;
+        const bool end = dn == 0 || nd > (uint32_t)(MAX_DIST - 1); // :819-820
+        steps_left--;
+        const bool lim = steps_left == 0;                          // :821-822 (and the quarter-chain point)
+        const bool ev = pass || end || lim;
+        ncur = nc;
+        ev_pass = pass; ev_end = end; ev_lim = lim;
+        cur = ev ? cur : nc;
+        state = ev ? 2 : 1;
+      }
+    }
+    // ---- slow phase ----
+    if (__any(state == 2)) {
+      bool cmpa = (state == 2) && ev_pass;
+      uint32_t off = 0;
+      int len = 0;
+      while (__any(cmpa)) {
+        if (cmpa) {
+#ifdef ZADA_MATCH_STATS
+          iters++;
+#endif
+          const uint32_t x = lds_u32_at(win, cur + off) ^ lds_u32_at(win, wi + off);
+          if (x) { len = (int)off + (int)(__builtin_ctz(x) >> 3); cmpa = false; }
+          else { off += 4; if ((int)off >= la) { len = la; cmpa = false; } }
+        }
+      }
+      if (state == 2) {
+        len = len < la ? len : la;
+        const bool improved = ev_pass && len > best;               // :812-817
+        if (improved) {
+          best = len; bdist = wi - cur;
+          const uint32_t a = wi + (uint32_t)best;
+          s_end = (uint32_t)win8[a - 1] | ((uint32_t)win8[a] << 8);
+        }
+        bool fin = (improved && len >= nice) || ev_end;            // :815, :820
+        const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
+        if (!fin && ev_lim) {
+          if (!have_q) { have_q = true; rq = packed; steps_left = chain_cfg - quarter; }   // quarter-chain result (:733-735)
+          else fin = true;                                         // :821-822
+        }
+        if (fin) {
+          MF[B + kpos] = packed;
+          MQ[B + kpos] = have_q ? rq : packed;
+          state = 0;
+        } else {
+          cur = ncur;
+          state = 1;
+        }
+      }
+    }
   }
 #ifdef ZADA_MATCH_STATS
   {
