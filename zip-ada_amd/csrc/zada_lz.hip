@@ -138,7 +138,7 @@ __global__ void k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, ui
 // Block of MB positions [B, B+MB); LDS holds input bytes [WB, B+MB+272) and the chain links
 // (distance to previous same-hash position) of [WB, B+MB), WB = B - HALO (clamped at 0).
 #ifndef ZADA_FAST
-#define ZADA_FAST 4
+#define ZADA_FAST 12
 #endif
 constexpr int MB = 16384;
 constexpr int HALO = 32512;                       // >= MAX_DIST, multiple of 16
@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // WBYTES bytes
   uint16_t *lnk = (uint16_t *)(smem + WBYTES);                    // WLINKS * 2 bytes
-  uint32_t &next_pos = *(uint32_t *)(smem + WBYTES + WLINKS * 2);
+  uint32_t *next_pos = (uint32_t *)(smem + WBYTES + WLINKS * 2);     // one work counter per chain-length class
+  uint32_t *cls = next_pos + 4;                                      // 2 bits per position, MB / 16 words
 #ifdef ZADA_MATCH_STATS
   unsigned long long t_start = clock64(), t_empty = 0, iters = 0;
 #endif
@@ -181,7 +182,25 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     const uint4 *ls = (const uint4 *)(prevd + WB);
     uint4 *ld = (uint4 *)lnk;
     for (uint32_t i = tid; i < (nl * 2 + 15) / 16; i += 1024) ld[i] = ls[i];
-    if (tid == 0) next_pos = 0;
+    if (tid < 4) next_pos[tid] = 0;
+  }
+  __syncthreads();
+  // Longest-chains-first scheduling: estimate every position's chain length from the span of its
+  // first 8 links and give it a class (2 = long, 1 = medium, 0 = short).  Classes are drained in
+  // descending order so that the 4096-step walks start first and do not form the block's tail.
+  {
+    uint32_t word = 0;
+    for (int j = 0; j < 16; j++) {
+      const uint32_t k = (uint32_t)tid * 16 + j;
+      uint32_t c = 0;
+      if (k < cnt) {
+        uint32_t q = woff + k, span = 0; int hops = 0;
+        for (; hops < 8; hops++) { const uint32_t d = lnk[q]; if (d == 0 || span + d > 32505u) break; span += d; q -= d; }
+        c = hops < 8 ? 0u : (span <= 512u ? 2u : (span <= 4096u ? 1u : 0u));
+      }
+      word |= c << (2 * j);
+    }
+    cls[tid] = word;
   }
   __syncthreads();
   const int quarter = chain_cfg >> 2;
@@ -190,14 +209,19 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   // (its current candidate passed the two-byte filter and/or its chain ended / hit a limit).
   // FAST PHASE: ZADA_FAST filter steps with no side paths; SLOW PHASE: everything rare, once per round.
   uint32_t wi = woff, cur = woff, ncur = woff, bdist = 0, rq = 0, kpos = 0, s_end = 0;
-  int best = 2, la = 3, nice = 3, steps_left = 1, state = 0;
+  int best = 2, la = 3, nice = 3, steps_left = 1, state = 0, pass_cls = 2;
   bool have_q = false, ev_pass = false, ev_end = false, ev_lim = false, exhausted = false;
   for (;;) {
     // ---- fetch ----
     const bool need = (state == 0) && !exhausted;
     if (__any(need)) {
       if (need) {
-        const uint32_t k = atomicAdd(&next_pos, 1u);
+        uint32_t k = 0;
+        for (;;) {                                                 // next position of the current class
+          k = atomicAdd(&next_pos[pass_cls], 1u);
+          if (k >= cnt) { if (pass_cls == 0) break; pass_cls--; continue; }
+          if (((cls[k >> 4] >> (2 * (k & 15))) & 3u) == (uint32_t)pass_cls) break;
+        }
 #ifdef ZADA_MATCH_STATS
         if (k >= cnt && t_empty == 0) t_empty = clock64();
 #endif
@@ -443,7 +467,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
-    hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16);
+    hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16 + MB / 4);
     attr_done = true;
   }
   if (nseg > 0) {
@@ -453,7 +477,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   c->tmark("prev_links");
   {
     uint32_t nb = (uint32_t)((n + MB - 1) / MB);
-    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16, st, W.in, n, W.prevd, W.MF, W.MQ, cfg.nice, cfg.chain, (unsigned long long *)W.dbg);
+    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.prevd, W.MF, W.MQ, cfg.nice, cfg.chain, (unsigned long long *)W.dbg);
   }
 #ifdef ZADA_MATCH_STATS
   {
