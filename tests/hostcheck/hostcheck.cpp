@@ -102,3 +102,53 @@ uint64_t hc_chunked_tokens(const uint8_t *in, uint64_t n, int level, uint32_t ch
 }
 
 }  // extern "C"
+
+// ---- reference of the wave-parallel LLHC algorithm's MATH (classic package-merge with the
+// "package before leaf on ties" rule + closed-form Hoare partition), to validate it against the
+// oracle's boundary package-merge before the device version is trusted ----
+#include <algorithm>
+static void ref_partition_sort(std::vector<uint32_t> &w, std::vector<uint16_t> &s, int lo, int m) {
+  if (m < 2) return;
+  uint32_t p = w[lo + m / 2];
+  std::vector<int> I, J;
+  for (int i = 0; i < m; i++) if (w[lo + i] >= p) I.push_back(i);
+  for (int i = m - 1; i >= 0; i--) if (w[lo + i] <= p) J.push_back(i);
+  int K = 0;
+  while (K < (int)I.size() && K < (int)J.size() && I[K] < J[K]) K++;
+  for (int k = 0; k < K; k++) { std::swap(w[lo + I[k]], w[lo + J[k]]); std::swap(s[lo + I[k]], s[lo + J[k]]); }
+  int i = 1 << 30;
+  if (K < (int)I.size()) i = std::min(i, I[K]);
+  if (K > 0) i = std::min(i, J[K - 1]);
+  ref_partition_sort(w, s, lo, i);
+  ref_partition_sort(w, s, lo + i, m - i);
+}
+extern "C" void hc_llhc_pm(const uint32_t *freq, int n, int max_bits, uint8_t *bl) {
+  std::vector<uint32_t> w; std::vector<uint16_t> s;
+  for (int a = 0; a < n; a++) { bl[a] = 0; if (freq[a]) { w.push_back(freq[a]); s.push_back((uint16_t)a); } }
+  int ns = (int)w.size();
+  if (ns == 0) return;
+  if (ns == 1) { bl[s[0]] = 1; return; }
+  ref_partition_sort(w, s, 0, ns);
+  // lists: level 1 = leaves; level l = merge(leaves, packages(level l-1)), packages first on ties
+  std::vector<std::vector<uint32_t>> lists(max_bits + 1);
+  std::vector<std::vector<uint8_t>> isleaf(max_bits + 1);
+  lists[1] = w; isleaf[1].assign(ns, 1);
+  for (int l = 2; l <= max_bits; l++) {
+    std::vector<uint32_t> P;
+    for (size_t i = 0; i + 1 < lists[l - 1].size(); i += 2) P.push_back(lists[l - 1][i] + lists[l - 1][i + 1]);
+    size_t a = 0, b = 0;
+    while (a < w.size() || b < P.size()) {
+      bool takeP = b < P.size() && (a >= w.size() || P[b] <= w[a]);
+      if (takeP) { lists[l].push_back(P[b++]); isleaf[l].push_back(0); } else { lists[l].push_back(w[a++]); isleaf[l].push_back(1); }
+    }
+  }
+  int x = 2 * ns - 2;
+  std::vector<int> acnt(max_bits + 1, 0);
+  for (int l = max_bits; l >= 1; l--) {
+    int a = 0;
+    for (int i = 0; i < x && i < (int)lists[l].size(); i++) a += isleaf[l][i];
+    acnt[l] = a;
+    x = 2 * (x - a);
+  }
+  for (int r = 0; r < ns; r++) { int len = 0; for (int l = 1; l <= max_bits; l++) if (acnt[l] > r) len++; bl[s[r]] = (uint8_t)len; }
+}

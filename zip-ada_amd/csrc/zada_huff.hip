@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include "zada_logic.h"
 #include "zada_internal.h"
+#include "zada_llhc_wave.h"
 
 namespace zada {
 
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(64) k_window_descr(const uint32_t *__restrict_
                                                      uint8_t *__restrict__ descr) {
   __shared__ uint32_t hist[320];
   __shared__ uint8_t bl[320];
-  __shared__ LlhcScratch S;
+  __shared__ __attribute__((aligned(16))) uint8_t S[LLHC_WAVE_SCRATCH];
   const uint32_t slot = blockIdx.x % SLOTS, j = blockIdx.x / SLOTS;
   const uint32_t F = j * FLUSH;
   const uint32_t to = (F + FLUSH - 1 < T - 1) ? F + FLUSH - 1 : T - 1;
@@ -77,11 +78,10 @@ __global__ void __launch_bounds__(64) k_window_descr(const uint32_t *__restrict_
     if (ds >= 0) atomicAdd(&hist[288 + ds], 1u);
   }
   __syncthreads();
-  if (lane == 0) {
-    patch_dist_stats(hist + 288);
-    llhc_serial(hist, 288, 15, bl, &S);
-    llhc_serial(hist + 288, 32, 15, bl + 288, &S);
-  }
+  if (lane == 0) patch_dist_stats(hist + 288);
+  __syncthreads();
+  llhc_wave(hist, 288, 15, bl, S, lane);
+  llhc_wave(hist + 288, 32, 15, bl + 288, S, lane);
   __syncthreads();
   uint8_t *dst = descr + ((uint64_t)j * SLOTS + slot) * 320;
   for (int i = lane; i < 320; i += 64) dst[i] = bl[i];
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) k_block_analyze(const uint32_t *__restric
                                                        const BlockRange *__restrict__ blocks, BlockInfo *__restrict__ binfo) {
   __shared__ uint32_t st1[320], st2[320], dtmp[2][32];
   __shared__ uint8_t bl1[320], bl2[320], good[320];
-  __shared__ LlhcScratch S[4];
+  __shared__ __attribute__((aligned(16))) uint8_t S[4][LLHC_WAVE_SCRATCH];
   __shared__ HeaderPlan hp[2];
   __shared__ uint64_t red[3][4];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -161,14 +161,42 @@ __global__ void __launch_bounds__(256) k_block_analyze(const uint32_t *__restric
   if (tid == 0) tweak_for_better_rle(st2, 288, good);                       // :1217
   if (tid == 64) tweak_for_better_rle(st2 + 288, 32, good + 288);           // :1218
   __syncthreads();
-  if (lane == 0) {
-    if (w == 0) llhc_serial(st1, 288, 15, bl1, &S[0]);
-    else if (w == 1) llhc_serial(st2, 288, 15, bl2, &S[1]);
-    else if (w == 2) { for (int i = 0; i < 32; i++) dtmp[0][i] = st1[288 + i]; patch_dist_stats(dtmp[0]); llhc_serial(dtmp[0], 32, 15, bl1 + 288, &S[2]); }
-    else { for (int i = 0; i < 32; i++) dtmp[1][i] = st2[288 + i]; patch_dist_stats(dtmp[1]); llhc_serial(dtmp[1], 32, 15, bl2 + 288, &S[3]); }
+  if (w >= 2 && lane == 0) {
+    uint32_t *dt = dtmp[w - 2]; const uint32_t *src = (w == 2 ? st1 : st2) + 288;
+    for (int i = 0; i < 32; i++) dt[i] = src[i];
+    patch_dist_stats(dt);                                                     // :340-365, on a copy
   }
+  wave_sync();
+  if (w == 0) llhc_wave(st1, 288, 15, bl1, S[0], lane);                       // one wave per code set
+  else if (w == 1) llhc_wave(st2, 288, 15, bl2, S[1], lane);
+  else if (w == 2) llhc_wave(dtmp[0], 32, 15, bl1 + 288, S[2], lane);
+  else llhc_wave(dtmp[1], 32, 15, bl2 + 288, S[3], lane);
   __syncthreads();
-  if (lane == 0 && w < 2) header_plan(w == 0 ? bl1 : bl2, (w == 0 ? bl1 : bl2) + 288, &hp[w], &S[w]);
+  if (w < 2) {                                                                // Put_Compression_Structure, cost analysis
+    HeaderPlan *h = &hp[w];
+    const uint8_t *ll = w == 0 ? bl1 : bl2;
+    if (lane == 0) {
+      int max_ll = 0, max_d = 0, idx = 0;
+      for (int a = 287; a >= 0; a--) if (ll[a] > 0) { max_ll = a; break; }
+      for (int a = 31; a >= 0; a--) if (ll[288 + a] > 0) { max_d = a; break; }
+      for (int a = 0; a <= max_ll; a++) h->cs_bl[idx++] = ll[a];
+      for (int a = 0; a <= max_d; a++) h->cs_bl[idx++] = ll[288 + a];
+      h->last_cs_bl = (uint16_t)idx; h->hlit_m257 = (uint8_t)(max_ll - 256); h->hdist_m1 = (uint8_t)max_d;
+      for (int a = 0; a < 19; a++) h->truc_freq[a] = 0;
+      uint32_t *tf = h->truc_freq;
+      header_rle_walk(h->cs_bl, idx, [tf](int x, uint32_t) { tf[x]++; });
+    }
+    wave_sync();
+    llhc_wave(h->truc_freq, 19, 7, h->truc_bl, S[w], lane);
+    if (lane == 0) {
+      int anz = 3;
+      for (int a = 0; a <= 18; a++) if (a > anz && h->truc_bl[header_perm(a)] > 0) anz = a;
+      h->a_non_zero = (uint8_t)anz;
+      uint32_t bits = 14 + (uint32_t)(1 + anz) * 3;
+      for (int a = 0; a <= 18; a++) bits += h->truc_freq[a] * (uint32_t)(h->truc_bl[a] + header_extra_bits(a));
+      h->bits = bits;
+    }
+  }
   // data costs, Compute_sizes_of_variants :1152-1190 (EOB, symbol 256, is never counted there)
   uint64_t cf = 0, c1 = 0, c2 = 0;
   for (int s = tid; s < 320; s += 256) {
