@@ -91,7 +91,8 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   W.cap_tiles = cap / TILE + W.cap_blocks + 64;
   A(tile_block, W.cap_tiles); A(tile_bitpos, W.cap_tiles); A(tile_bits, W.cap_tiles);
   A(chooser, 1);
-  A(crc_part, nch);
+  A(crc_lvl[0], cap / CRC_SUB + 64); A(crc_lvl[1], cap / CRC_SUB / 16 + 64); A(crc_lvl[2], cap / CRC_SUB / 256 + 64); A(crc_lvl[3], cap / CRC_SUB / 4096 + 64);
+  A(crc_mat, 128);
   A(dbg, 64);
   W.cap_out = cap + cap / 1024 + 4096;
   A(out, W.cap_out);
@@ -108,7 +109,10 @@ int ensure_workspace(Ctx *c, uint64_t n) {
 // --------------------------------------------------------------------------------------------
 // CRC-32 (zip-crc_crypto.adb:31-76): per-chunk raw registers on the GPU, GF(2) combine on the host
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_crc_chunks(const uint8_t *__restrict__ in, uint64_t n, uint32_t nch, uint32_t *__restrict__ part) {
+// One lane per CRC_SUB bytes (raw register started at 0: the linear part), then the 16 sub-results of
+// each CRC_CHUNK are folded on the device with the fixed "advance by CRC_SUB zero bytes" operator
+// (mat, 32 words), leaving one value per CRC_CHUNK for the host to chain.
+__global__ void __launch_bounds__(256) k_crc_chunks(const uint8_t *__restrict__ in, uint64_t n, uint32_t nsub, uint32_t *__restrict__ sub) {
   __shared__ uint32_t tab[256];
   {
     uint32_t l = threadIdx.x;
@@ -117,20 +121,42 @@ __global__ void __launch_bounds__(256) k_crc_chunks(const uint8_t *__restrict__ 
   }
   __syncthreads();
   uint32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nch) return;
-  uint64_t p0 = (uint64_t)k * PCHUNK, p1 = p0 + PCHUNK < n ? p0 + PCHUNK : n;
-  uint32_t r = 0;                                        // linear part: register starts at 0
-  const uint32_t *w = (const uint32_t *)(in + p0);
+  if (k >= nsub) return;
+  uint64_t p0 = (uint64_t)k * CRC_SUB, p1 = p0 + CRC_SUB < n ? p0 + CRC_SUB : n;
+  uint32_t r = 0;
+  const uint4 *w = (const uint4 *)(in + p0);
   uint64_t len = p1 - p0, i = 0;
-  for (; i + 4 <= len; i += 4) {
-    uint32_t x = w[i >> 2];
-    r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;        // Update :49-60, one byte at a time
-    r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;
-    r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;
-    r = tab[(r ^ x) & 0xFF] ^ (r >> 8);
+  for (; i + 16 <= len; i += 16) {
+    const uint4 v = w[i >> 4];
+    const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint32_t x = xs[q];
+      r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;      // Update :49-60, one byte at a time
+      r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;
+      r = tab[(r ^ x) & 0xFF] ^ (r >> 8); x >>= 8;
+      r = tab[(r ^ x) & 0xFF] ^ (r >> 8);
+    }
   }
   for (; i < len; i++) r = tab[(r ^ in[p0 + i]) & 0xFF] ^ (r >> 8);
-  part[k] = r;
+  sub[k] = r;
+}
+
+// out[k] = fold of src[16k .. 16k+15] with the operator "advance by the length one src value covers"
+__global__ void __launch_bounds__(256) k_crc_fold(const uint32_t *__restrict__ src, uint32_t ngroups, const uint32_t *__restrict__ mat,
+                                                  uint32_t *__restrict__ out) {
+  __shared__ uint32_t m[32];
+  if (threadIdx.x < 32) m[threadIdx.x] = mat[threadIdx.x];
+  __syncthreads();
+  uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= ngroups) return;
+  uint32_t r = 0;
+  for (uint32_t j = 0; j < 16; j++) {
+    uint32_t s = 0, v = r;
+    for (int b = 0; v; b++, v >>= 1) if (v & 1) s ^= m[b];
+    r = s ^ src[k * 16 + j];
+  }
+  out[k] = r;
 }
 
 // operator "advance the raw register over `len` zero bytes" as a 32x32 GF(2) matrix
@@ -156,17 +182,43 @@ static void zero_advance_matrix(uint64_t len, uint32_t *out) {
 int crc_stage(Ctx *c, uint64_t n, uint32_t *crc_inout) {
   if (n == 0) return 0;
   Workspace &W = c->ws;
-  const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
-  hipLaunchKernelGGL(k_crc_chunks, dim3((nch + 255) / 256), dim3(256), 0, c->stream, W.in, n, nch, W.crc_part);
-  std::vector<uint32_t> part(nch);
-  hipMemcpyAsync(part.data(), W.crc_part, (size_t)nch * 4, hipMemcpyDeviceToHost, c->stream);
+  // level 0: one value per CRC_SUB (256 B); levels 1..3 fold 16:1 (4 KiB, 64 KiB, 1 MiB); only FULL
+  // groups are folded on the device, the host chains the few leftovers of every level
+  constexpr int NLEV = 4;
+  static uint32_t M[NLEV][32];
+  static bool mats = false;
+  if (!mats) { for (int l = 0; l < NLEV; l++) zero_advance_matrix((uint64_t)CRC_SUB << (4 * l), M[l]); mats = true; }
+  const uint32_t nsub = (uint32_t)((n + CRC_SUB - 1) / CRC_SUB);
+  const uint32_t nfull0 = (uint32_t)(n / CRC_SUB);                     // full level-0 values
+  uint32_t cnt[NLEV];
+  cnt[0] = nfull0;
+  for (int l = 1; l < NLEV; l++) cnt[l] = cnt[l - 1] / 16;
+  hipMemcpyAsync(W.crc_mat, M, sizeof(uint32_t) * 32 * (NLEV - 1), hipMemcpyHostToDevice, c->stream);
+  hipLaunchKernelGGL(k_crc_chunks, dim3((nsub + 255) / 256), dim3(256), 0, c->stream, W.in, n, nsub, W.crc_lvl[0]);
+  for (int l = 1; l < NLEV; l++)
+    if (cnt[l]) hipLaunchKernelGGL(k_crc_fold, dim3((cnt[l] + 255) / 256), dim3(256), 0, c->stream, W.crc_lvl[l - 1], cnt[l], W.crc_mat + 32 * (l - 1), W.crc_lvl[l]);
+  // values the host needs: all of the top level, and per lower level the < 16 values after the last full group
+  std::vector<uint32_t> top(cnt[NLEV - 1] ? cnt[NLEV - 1] : 1);
+  uint32_t rest[NLEV][16];
+  uint32_t nrest[NLEV];
+  if (cnt[NLEV - 1]) hipMemcpyAsync(top.data(), W.crc_lvl[NLEV - 1], (size_t)cnt[NLEV - 1] * 4, hipMemcpyDeviceToHost, c->stream);
+  for (int l = 0; l < NLEV - 1; l++) {
+    const uint32_t first = cnt[l + 1] * 16;
+    nrest[l] = (l == 0 ? nsub : cnt[l]) - first;                         // level 0 includes the final short value
+    if (nrest[l]) hipMemcpyAsync(rest[l], W.crc_lvl[l] + first, (size_t)nrest[l] * 4, hipMemcpyDeviceToHost, c->stream);
+  }
   if (hip_check(c, hipStreamSynchronize(c->stream), "crc")) return ZADA_E_HIP_;
-  uint32_t Mfull[32], Mlast[32];
-  zero_advance_matrix(PCHUNK, Mfull);
-  uint64_t lastlen = n - (uint64_t)(nch - 1) * PCHUNK;
-  zero_advance_matrix(lastlen, Mlast);
   uint32_t r = *crc_inout;
-  for (uint32_t k = 0; k < nch; k++) r = gf2_apply(k + 1 == nch ? Mlast : Mfull, r) ^ part[k];
+  for (uint32_t k = 0; k < cnt[NLEV - 1]; k++) r = gf2_apply(M[NLEV - 1], r) ^ top[k];
+  for (int l = NLEV - 2; l >= 0; l--) {
+    for (uint32_t j = 0; j < nrest[l]; j++) {
+      if (l == 0 && cnt[1] * 16 + j == nfull0) {                          // the final, short level-0 value
+        uint32_t Ml[32];
+        zero_advance_matrix(n - (uint64_t)nfull0 * CRC_SUB, Ml);
+        r = gf2_apply(Ml, r) ^ rest[0][j];
+      } else r = gf2_apply(M[l], r) ^ rest[l][j];
+    }
+  }
   *crc_inout = r;
   return 0;
 }

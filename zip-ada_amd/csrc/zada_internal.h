@@ -11,8 +11,9 @@ namespace zada {
 constexpr int ZADA_E_HIP_ = -3;
 
 // ---- LZ stage geometry ----
-constexpr uint32_t PCHUNK = 4096;                 // bytes parsed per lane (speculative chunk)
-constexpr uint32_t PTOK_STRIDE = PCHUNK + 1024;   // token slots per chunk (a parse may overrun its chunk by < 600 B)
+constexpr uint32_t PCHUNK = 1024;                 // bytes parsed per lane (speculative chunk)
+constexpr uint32_t PTOK_STRIDE = PCHUNK + 640;    // token slots per chunk (a parse may overrun its chunk by < 600 B)
+constexpr uint32_t CRC_CHUNK = 4096, CRC_SUB = 256;   // CRC: one lane per 256 B, folded to one value per 4 KiB on the device
 constexpr uint64_t IN_PAD = 1024;                 // zero bytes kept after the input
 
 // ---- entropy stage geometry (zip-compress-deflate.adb:942, 1294, 1313) ----
@@ -81,7 +82,7 @@ struct Workspace {
   uint64_t *tile_bitpos = nullptr;
   uint32_t *tile_bits = nullptr;
   ChooserOut *chooser = nullptr;
-  uint32_t *crc_part = nullptr;
+  uint32_t *crc_lvl[4] = {nullptr, nullptr, nullptr, nullptr}, *crc_mat = nullptr;
   uint64_t *dbg = nullptr;
   uint8_t *out = nullptr;
   uint64_t cap_blocks = 0, cap_tiles = 0, cap_pieces = 0, cap_out = 0;
