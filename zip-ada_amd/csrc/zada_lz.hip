@@ -245,6 +245,9 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     // ---- fast phase ----
 #pragma unroll
     for (int it = 0; it < ZADA_FAST; it++) {
+#ifdef ZADA_MINACT
+      if (it >= 2 && __popcll(__ballot(state == 1)) < ZADA_MINACT) break;
+#endif
       if (state == 1) {
 #ifdef ZADA_MATCH_STATS
         iters++;
