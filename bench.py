@@ -59,6 +59,29 @@ def cpu_baseline(za, sample_mib):
             "ratio": round(ol.value / n, 4)}, out.raw[:ol.value]
 
 
+def pmc_traffic(n):
+    """HBM bytes per k_match launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command, profiles/<round>/pmc_fetch_write_by_kernel.json; counters are
+    in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  Only valid for the 1 GiB workload
+    the profile was taken on; null otherwise."""
+    if n != (1 << 30):
+        return None
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        p = os.path.join(pdir, rnd, "pmc_fetch_write_by_kernel.json")
+        if os.path.exists(p):
+            best = p
+    if not best:
+        return None
+    d = json.load(open(best))
+    try:
+        f = d["FETCH_SIZE"]["zada::k_match"]; w = d["WRITE_SIZE"]["zada::k_match"]
+        return int((2 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +164,7 @@ def main():
                        "bytes_per_gpu": n, "compression_ratio": round(ratio, 4), "rc": rc,
                        "phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in phase_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_match", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(n),
                          "note": "algorithmic bytes = N_in + N_out per launch; the kernel is LDS-latency/issue bound (chain walk), not HBM bound"},
         }
         if not args.no_cpu_baseline:
