@@ -68,7 +68,9 @@ int ensure_workspace(Ctx *c, uint64_t n) {
 #define A(ptr, cnt) if (!rc) rc = dalloc(c, &W.ptr, (cnt))
   A(in, cap + IN_PAD + 64);
   A(prevd, cap + IN_PAD);
-  A(tails, nseg32 * 32768);
+  A(tails, nseg32 * 65536);
+  A(S3, nseg32 * 32768); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
+  A(RDD, cap + 64);
   A(MF, cap + 64);
   A(MQ, cap + 64);
   A(spec_tok, nch * PTOK_STRIDE);

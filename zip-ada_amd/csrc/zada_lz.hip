@@ -87,9 +87,33 @@ __device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[
   __syncthreads();
 }
 
-// grid = number of 32 KiB segments; block = 1024.  n_ins = number of inserted positions (n - 2).
-__global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins,
-                                                     uint16_t *__restrict__ prevd, uint16_t *__restrict__ tails) {
+__device__ __forceinline__ uint32_t load24(const uint8_t *__restrict__ in, uint64_t p) {
+  return (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16);
+}
+// 16-bit hash of the four bytes at p (second-level chains: candidates that can reach length >= 4)
+__device__ __forceinline__ uint32_t hash4(const uint8_t *__restrict__ in, uint64_t p) {
+  const uint32_t x = load24(in, p) | ((uint32_t)in[p + 3] << 24);
+  return (x * 2654435761u) >> 16;
+}
+
+// Per 32 KiB segment (grid = segments, block = 1024).  n_ins = number of inserted positions (n - 2).
+//
+// The reference walks, for position p, the chain of earlier positions with the same 15-bit hash
+// (nearest first, at most `chain` of them, within 32 505/32 506 bytes).  Two facts let the match
+// kernel visit far fewer candidates without changing its result:
+//   * the step limit is equivalent to a DISTANCE limit: "within the first k chain elements" <=>
+//     "not farther than the k-th same-hash predecessor" -> DD[p] = (distance of the 4096-th, of the
+//     1024-th predecessor), read off the sorted order by rank arithmetic;
+//   * a candidate can only beat a length-3 match if it shares FOUR bytes with p, so after the nearest
+//     true 3-byte match (dist3, RD[p]) only the positions of the same 4-byte hash chain matter.
+// Outputs: prev4 (16-bit distance to the previous position of the same hash4 bucket), tails4,
+// S3 / bstart3 / bcnt3 (sorted order and buckets of the 15-bit hash, for the next segment's
+// cross-segment resolution in k_cross_links), RD = rank | dist3 << 16, DD = Dfull | Dquarter << 16.
+constexpr uint32_t D_UNRESOLVED = 0, D_UNLIMITED = 0xFFFF, DIST3_CONTINUE = 0xFFFF;
+__global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
+                                                     uint16_t *__restrict__ prev4, uint16_t *__restrict__ tails4,
+                                                     uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
+                                                     uint2 *__restrict__ RDD) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *A = (uint16_t *)smem;                 // 64 KiB
   uint16_t *B = A + 32768;                        // 64 KiB
@@ -97,39 +121,145 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint32_t *wsum = cnt + 4096;                    // 64 B
   const uint64_t seg = blockIdx.x, base = seg * 32768ull;
   const uint32_t m = (uint32_t)((n_ins - base) < 32768ull ? (n_ins - base) : 32768ull);
-  const int tid = threadIdx.x;
-  uint16_t *tail = tails + seg * 32768ull;
-  for (int i = tid; i < 32768 / 8; i += 1024) ((uint4 *)tail)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  uint16_t *tail = tails4 + seg * 32768ull * 2;   // 65536 hash4 buckets
+  uint32_t *bsc = bsc3 + seg * 32768ull;          // bucket start | count << 16
+  uint16_t *s3 = S3 + seg * 32768ull;
+  uint8_t *t3 = T3 + seg * 32768ull;              // top three bits of byte 0: what the 15-bit hash drops
+  for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tail)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  for (int i = tid; i < 32768 / 4; i += 1024) ((uint4 *)bsc)[i] = make_uint4(0, 0, 0, 0);
   const uint8_t *sin = in + base;
+  // ---- 15-bit hash order: ranks, distance limits, nearest true 3-byte match ----
   radix_pass<256>(nullptr, A, cnt, wsum, m, [sin](uint32_t e) { return hash3(sin, e) & 0xFFu; });
   radix_pass<128>(A, B, cnt, wsum, m, [sin](uint32_t e) { return hash3(sin, e) >> 8; });
-  // link neighbours inside each bucket (B is sorted by (hash, position))
+  // A[i] := start index of the bucket that sorted element i belongs to (all LDS traffic lane-contiguous)
+  // tags: bits of the three bytes that the 15-bit hash does not determine (9 in all; 4 kept in LDS in the
+  // idle counter area, 8 in T3).  Different tag => different bytes; equal tag => verify the bytes.
+  for (int i = tid; i < 4096; i += 1024) cnt[i] = 0;
+  __syncthreads();
   for (uint32_t i = tid; i < m; i += 1024) {
-    uint32_t e = B[i], h = hash3(sin, e);
+    const uint32_t e = B[i], b0 = sin[e], b1 = sin[e + 1];
+    const uint32_t tg8 = (b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6);
+    A[i] = (uint16_t)hash3(sin, e); s3[i] = (uint16_t)e; t3[i] = (uint8_t)tg8;
+    atomicOr(&cnt[i >> 3], (tg8 & 15u) << (4 * (i & 7)));
+  }
+  __syncthreads();
+  {
+    uint32_t firstbits = 0;                          // bit k: element tid + 1024 k starts a bucket
+    for (uint32_t k = 0; k < 32; k++) { const uint32_t i = tid + 1024 * k; if (i < m && (i == 0 || A[i - 1] != A[i])) firstbits |= 1u << k; }
+    __syncthreads();
+    for (uint32_t k = 0; k < 32; k++) { const uint32_t i = tid + 1024 * k; if (i < m) A[i] = (firstbits >> k) & 1u ? (uint16_t)i : (uint16_t)0; }
+    __syncthreads();
+    // inclusive max-scan of A: wave w owns [2048 w, 2048 w + 2048), 64 contiguous elements per step
+    uint32_t carry = 0;
+    for (int it = 0; it < 32; it++) {
+      const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
+      uint32_t v = i < m ? A[i] : 0u;
+      for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if (lane >= off) v = v > t ? v : t; }
+      v = v > carry ? v : carry;
+      if (i < m) A[i] = (uint16_t)v;
+      carry = __shfl(v, 63);
+    }
+    if (lane == 0) wsum[w] = carry;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < w; k++) before = before > wsum[k] ? before : wsum[k];
+    for (int it = 0; it < 32; it++) {
+      const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
+      if (i < m) { const uint32_t v = A[i]; A[i] = (uint16_t)(v > before ? v : before); }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += 1024) {
+      const uint32_t bs = A[i];
+      const uint32_t e = B[i], r = i - bs;
+      const uint64_t p = base + e;
+      // distance limits from the ranks inside this segment; the rest is resolved by k_cross_links
+      uint32_t df = D_UNLIMITED, dq = D_UNLIMITED;
+      if (r >= (uint32_t)kfull) df = e - B[i - kfull]; else if (seg > 0) df = D_UNRESOLVED;
+      if (r >= (uint32_t)kquarter) dq = e - B[i - kquarter]; else if (seg > 0) dq = D_UNRESOLVED;
+      // nearest earlier position with the same three bytes (hash collisions are skipped)
+      uint32_t d3 = (seg > 0) ? DIST3_CONTINUE : 0u;
+      const uint32_t mytag = (cnt[i >> 3] >> (4 * (i & 7))) & 15u;
+      const uint32_t my24 = load24(sin, e);
+      for (uint32_t j = i; j > bs; j--) {
+        const uint32_t jj = j - 1;
+        const uint32_t q = B[jj], dist = e - q;
+        // NIL = position 0 (lz77.adb:467); beyond MAX_DIST nothing qualifies, exactly MAX_DIST only as
+        // the head of the chain (:850 vs :820)
+        if (base + q == 0 || dist > (uint32_t)MAX_DIST || (dist == (uint32_t)MAX_DIST && j != i)) { d3 = 0; break; }
+        if (((cnt[jj >> 3] >> (4 * (jj & 7))) & 15u) != mytag) continue;   // hash collision: not the same three bytes
+        if (load24(sin, q) != my24) continue;
+        d3 = dist;
+        break;
+      }
+      RDD[p] = make_uint2(r | (d3 << 16), df | (dq << 16));
+      if (i + 1 == m || A[i + 1] == i + 1) bsc[hash3(sin, e)] = bs | ((i - bs + 1) << 16);
+    }
+  }
+  __syncthreads();
+  // ---- 4-byte hash order: the chains the match kernel walks ----
+  radix_pass<256>(nullptr, A, cnt, wsum, m, [sin](uint32_t e) { return hash4(sin, e) & 0xFFu; });
+  radix_pass<256>(A, B, cnt, wsum, m, [sin](uint32_t e) { return hash4(sin, e) >> 8; });
+  for (uint32_t i = tid; i < m; i += 1024) {
+    uint32_t e = B[i], h = hash4(sin, e);
     uint16_t d = 0;
     if (i > 0) {
       uint32_t e0 = B[i - 1];
-      if (hash3(sin, e0) == h && (base + e0) != 0) d = (uint16_t)(e - e0);     // NIL = position 0, lz77.adb:467
+      if (hash4(sin, e0) == h && (base + e0) != 0) d = (uint16_t)(e - e0);     // NIL = position 0, lz77.adb:467
     }
-    prevd[base + e] = d;
-    bool last = (i + 1 == m) || (hash3(sin, B[i + 1]) != h);
+    prev4[base + e] = d;
+    bool last = (i + 1 == m) || (hash4(sin, B[i + 1]) != h);
     if (last) tail[h] = (uint16_t)e;
   }
 }
 
-// grid-stride over inserted positions of segments >= 1.
-__global__ void k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, uint16_t *__restrict__ prevd,
-                              const uint16_t *__restrict__ tails) {
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_ins; p += stride) {
-    if (prevd[p] != 0) continue;
-    uint64_t seg = p >> 15;
-    uint32_t t = tails[(seg - 1) * 32768ull + hash3(in, p)];
-    if (t == 0xFFFFu) continue;
-    uint64_t q = (seg - 1) * 32768ull + t;
-    uint64_t d = p - q;
-    if (d <= (uint64_t)MAX_DIST && q != 0) prevd[p] = (uint16_t)d;
+// Cross-segment resolution: one thread per inserted position of the segments >= 1.
+__global__ void __launch_bounds__(256) k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
+                                                     uint16_t *__restrict__ prev4, const uint16_t *__restrict__ tails4,
+                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
+                                                     uint2 *__restrict__ RDD) {
+  const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_ins) return;
+  const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
+  if (prev4[p] == 0) {
+    uint32_t t = tails4[(seg - 1) * 65536ull + hash4(in, p)];
+    if (t != 0xFFFFu) {
+      uint64_t q = pbase + t, d = p - q;
+      if (d <= (uint64_t)MAX_DIST && q != 0) prev4[p] = (uint16_t)d;
+    }
   }
+  const uint2 rdd = RDD[p];
+  const uint32_t rd = rdd.x, dd = rdd.y;
+  const uint32_t r = rd & 0xFFFF;
+  uint32_t d3 = rd >> 16, df = dd & 0xFFFF, dq = dd >> 16;
+  if (d3 != DIST3_CONTINUE && df != D_UNRESOLVED && dq != D_UNRESOLVED) return;
+  const uint32_t b0 = in[p];
+  const uint32_t h = ((b0 << 10) ^ ((uint32_t)in[p + 1] << 5) ^ (uint32_t)in[p + 2]) & 0x7FFFu;
+  const uint32_t bsc = bsc3[pbase + h];
+  const uint32_t pst = bsc & 0xFFFF, pct = bsc >> 16;
+  const uint16_t *ps = S3 + pbase;
+  if (df == D_UNRESOLVED) {
+    const uint32_t need = (uint32_t)kfull - r;
+    if (pct >= need) { uint64_t d = p - (pbase + ps[pst + pct - need]); df = d < 0xFFFF ? (uint32_t)d : D_UNLIMITED; } else df = D_UNLIMITED;
+  }
+  if (dq == D_UNRESOLVED) {
+    const uint32_t need = (uint32_t)kquarter - r;
+    if (pct >= need) { uint64_t d = p - (pbase + ps[pst + pct - need]); dq = d < 0xFFFF ? (uint32_t)d : D_UNLIMITED; } else dq = D_UNLIMITED;
+  }
+  if (d3 == DIST3_CONTINUE) {
+    d3 = 0;
+    const uint8_t *pt = T3 + pbase;
+    const uint32_t b1 = in[p + 1];
+    const uint32_t mytag = (b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6);
+    const uint32_t my24 = load24(in, p);
+    for (uint32_t j = pct; j > 0; j--) {
+      const uint64_t q = pbase + ps[pst + j - 1], d = p - q;
+      // beyond MAX_DIST nothing qualifies; exactly MAX_DIST only as the head of the chain (:850 vs :820)
+      if (q == 0 || d > (uint64_t)MAX_DIST || (d == (uint64_t)MAX_DIST && !(r == 0 && j == pct))) break;
+      if (pt[pst + j - 1] == mytag && load24(in, q) == my24) { d3 = (uint32_t)d; break; }
+    }
+  }
+  RDD[p] = make_uint2(r | (d3 << 16), df | (dq << 16));
 }
 
 // --------------------------------------------------------------------------------------------
@@ -157,8 +287,9 @@ __device__ __forceinline__ uint32_t lds_u32_at(const uint32_t *w, uint32_t byteo
 // Both modes share one instruction stream: two unaligned LDS dwords at (cand + off), (scan + off).
 __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, uint64_t n,
                                                 const uint16_t *__restrict__ prevd,
+                                                const uint2 *__restrict__ RDD,
                                                 uint32_t *__restrict__ MF, uint32_t *__restrict__ MQ,
-                                                int nice_cfg, int chain_cfg, unsigned long long *__restrict__ dbg) {
+                                                int nice_cfg, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // WBYTES bytes
   uint16_t *lnk = (uint16_t *)(smem + WBYTES);                    // WLINKS * 2 bytes
@@ -203,13 +334,13 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     cls[tid] = word;
   }
   __syncthreads();
-  const int quarter = chain_cfg >> 2;
   const uint8_t *win8 = (const uint8_t *)win;
   // Per-lane walker: state 0 = FREE (needs a position), 1 = WALK (fast filter steps), 2 = EVENT
   // (its current candidate passed the two-byte filter and/or its chain ended / hit a limit).
   // FAST PHASE: ZADA_FAST filter steps with no side paths; SLOW PHASE: everything rare, once per round.
   uint32_t wi = woff, cur = woff, ncur = woff, bdist = 0, rq = 0, kpos = 0, s_end = 0;
-  int best = 2, la = 3, nice = 3, steps_left = 1, state = 0, pass_cls = 2;
+  int best = 2, la = 3, nice = 3, state = 0, pass_cls = 2;
+  uint32_t lim_cur = 0, lim_full = 0;
   bool have_q = false, ev_pass = false, ev_end = false, ev_lim = false, exhausted = false;
   for (;;) {
     // ---- fetch ----
@@ -231,13 +362,28 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           const uint64_t rem = n - (B + k);
           la = rem < 258 ? (int)rem : 258;                         // Longest_Match never returns more
           nice = nice_cfg < la ? nice_cfg : la;                    // lz77.adb:858-860
-          best = 2; bdist = 0; have_q = false; rq = 0; steps_left = quarter;
-          const uint32_t d0 = lnk[wi];                             // hash_head (:842); distance <= MAX_DIST (:850) by construction
-          const bool ok = la >= 3 && d0 != 0;
+          // limits of this position's walk, as distances (see k_prev_links)
+          const uint2 rdd = RDD[B + k];
+          const uint32_t rd = rdd.x, dd = rdd.y;
+          const uint32_t d3 = rd >> 16, df = dd & 0xFFFF, dq = dd >> 16;
+          lim_full = d3 == (uint32_t)MAX_DIST ? (uint32_t)MAX_DIST : (df < (uint32_t)(MAX_DIST - 1) ? df : (uint32_t)(MAX_DIST - 1));   // :850 / :820-822
+          const uint32_t lim_q = dq < lim_full ? dq : lim_full;                                          // :733-735
+          const bool has3 = la >= 3 && d3 != 0 && d3 <= lim_full;      // nearest true 3-byte match = first candidate that counts
+          best = has3 ? 3 : 2; bdist = has3 ? d3 : 0;
+          have_q = has3 && d3 > lim_q; rq = 0;
+          lim_cur = have_q ? lim_full : lim_q;
+          // first element of the 4-byte chain (only candidates sharing four bytes can beat length 3)
+          const uint32_t d0 = lnk[wi];
+          bool ok = has3 && 3 < nice && d0 != 0 && d0 <= lim_full;
+          if (ok && !have_q && d0 > lim_q) { have_q = true; rq = (3u << 16) | bdist; lim_cur = lim_full; }
           cur = ok ? wi - d0 : wi;
-          s_end = (uint32_t)win8[wi + 1] | ((uint32_t)win8[wi + 2] << 8);
+          const uint32_t a = wi + (uint32_t)best;
+          s_end = (uint32_t)win8[a - 1] | ((uint32_t)win8[a] << 8);
           state = ok ? 1 : 0;
-          if (!ok) { MF[B + k] = 0; MQ[B + k] = 0; }
+          if (!ok) {
+            const uint32_t packed = has3 ? (3u << 16) | bdist : 0u;
+            MF[B + k] = packed; MQ[B + k] = have_q ? rq : packed;
+          }
         }
       }
     }
@@ -257,9 +403,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
         const uint32_t c16 = (uint32_t)win8[a - 1] | ((uint32_t)win8[a] << 8);
         const bool pass = c16 == s_end;                            // bytes best-1, best agree (:754-755)
         const uint32_t nc = cur - dn, nd = wi - nc;
-        const bool end = dn == 0 || nd > (uint32_t)(MAX_DIST - 1); // :819-820
-        steps_left--;
-        const bool lim = steps_left == 0;                          // :821-822 (and the quarter-chain point)
+        const bool end = dn == 0;                                  // chain exhausted
+        const bool lim = nd > lim_cur;                             // next candidate beyond the quarter / full limit (:819-822)
         const bool ev = pass || end || lim;
         ncur = nc;
         ev_pass = pass; ev_end = end; ev_lim = lim;
@@ -293,8 +438,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
         bool fin = (improved && len >= nice) || ev_end;            // :815, :820
         const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
         if (!fin && ev_lim) {
-          if (!have_q) { have_q = true; rq = packed; steps_left = chain_cfg - quarter; }   // quarter-chain result (:733-735)
-          else fin = true;                                         // :821-822
+          if (!have_q) { have_q = true; rq = packed; lim_cur = lim_full; }                 // quarter-chain result (:733-735)
+          if (wi - ncur > lim_full) fin = true;                    // :819-822
         }
         if (fin) {
           MF[B + kpos] = packed;
@@ -474,13 +619,15 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     attr_done = true;
   }
   if (nseg > 0) {
-    hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, W.prevd, W.tails);
-    if (nseg > 1) hipLaunchKernelGGL(k_cross_links, dim3(4096), dim3(256), 0, st, W.in, n_ins, W.prevd, W.tails);
+    hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2,
+                       W.prevd, W.tails, W.S3, W.T3, W.bsc3, W.RDD);
+    if (nseg > 1) hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)((n_ins - 32768 + 255) / 256)), dim3(256), 0, st, W.in, n_ins, cfg.chain, cfg.chain >> 2,
+                                     W.prevd, W.tails, W.S3, W.T3, W.bsc3, W.RDD);
   }
   c->tmark("prev_links");
   {
     uint32_t nb = (uint32_t)((n + MB - 1) / MB);
-    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.prevd, W.MF, W.MQ, cfg.nice, cfg.chain, (unsigned long long *)W.dbg);
+    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.prevd, W.RDD, W.MF, W.MQ, cfg.nice, (unsigned long long *)W.dbg);
   }
 #ifdef ZADA_MATCH_STATS
   {
