@@ -69,7 +69,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(in, cap + IN_PAD + 64);
   A(prevd, cap + IN_PAD);
   A(tails, nseg32 * 65536);
-  A(S3, nseg32 * 32768); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
+  A(S3, nseg32 * 32768); A(HS, nseg32 * 65536); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
   A(RDD, cap + 64);
   A(MF, cap + 64);
   A(MQ, cap + 64);

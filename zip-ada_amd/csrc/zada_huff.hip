@@ -287,22 +287,27 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
     return;
   }
 
-  // software prefetch of the next block's record
-  uint32_t nst[5]; int nb1[5], nb2[5];
-  auto load_block = [&](uint32_t i) {
+  // software prefetch of the whole next record (vectors AND scalars): the walk is a dependent chain,
+  // so every load of block i + 1 is issued before block i is decided
+  struct Rec { uint32_t st[5]; int b1[5], b2[5]; uint64_t fixed_data, dyn1_data, dyn2_data; uint32_t hdr1, hdr2, bytes, sp; BlockRange br; };
+  auto load_block = [&](uint32_t i, Rec &r) {
     const BlockInfo *bi = &binfo[i];
-    for (int r = 0; r < 5; r++) { nst[r] = bi->stats[lane + 64 * r]; nb1[r] = bi->bl1[lane + 64 * r]; nb2[r] = bi->bl2[lane + 64 * r]; }
+    for (int q = 0; q < 5; q++) { r.st[q] = bi->stats[lane + 64 * q]; r.b1[q] = bi->bl1[lane + 64 * q]; r.b2[q] = bi->bl2[lane + 64 * q]; }
+    r.fixed_data = bi->fixed_data; r.dyn1_data = bi->dyn1_data; r.dyn2_data = bi->dyn2_data;
+    r.hdr1 = bi->hdr1_bits; r.hdr2 = bi->hdr2_bits; r.bytes = bi->bytes; r.sp = bi->stored_possible;
+    r.br = blocks[i];
   };
-  if (nblocks > 0) load_block(0);
+  Rec nxt;
+  if (nblocks > 0) load_block(0, nxt);
 
   for (uint32_t i = 0; i < nblocks; i++) {
+    const Rec cr = nxt;
+    if (i + 1 < nblocks) load_block(i + 1, nxt);
     uint32_t st[5]; int b1[5], b2[5];
-    for (int r = 0; r < 5; r++) { st[r] = nst[r]; b1[r] = nb1[r]; b2[r] = nb2[r]; }
-    const BlockInfo *bi = &binfo[i];
-    const BlockRange br = blocks[i];
-    const uint64_t fixed_data = bi->fixed_data, dyn1_data = bi->dyn1_data, dyn2_data = bi->dyn2_data;
-    const uint32_t hdr1 = bi->hdr1_bits, hdr2 = bi->hdr2_bits, bytes = bi->bytes, stored_possible = bi->stored_possible;
-    if (i + 1 < nblocks) load_block(i + 1);
+    for (int r = 0; r < 5; r++) { st[r] = cr.st[r]; b1[r] = cr.b1[r]; b2[r] = cr.b2[r]; }
+    const BlockRange br = cr.br;
+    const uint64_t fixed_data = cr.fixed_data, dyn1_data = cr.dyn1_data, dyn2_data = cr.dyn2_data;
+    const uint32_t hdr1 = cr.hdr1, hdr2 = cr.hdr2, bytes = cr.bytes, stored_possible = cr.sp;
 
     // recycling (:1223-1226, Recyclable :495-508) and its cost (:1158, 1180, 1189)
     bool bad = false; uint64_t rc = 0;

@@ -44,7 +44,7 @@ __device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[
     uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
     if (i < m) {
       uint32_t e = src ? src[i] : i;
-      atomicAdd(&cnt[digit(e) * 16 + w], 1u);
+      atomicAdd(&cnt[w * NDIG + digit(e)], 1u);          // [wave][digit]: lanes of a wave spread over the banks
     }
   }
   __syncthreads();
@@ -52,7 +52,8 @@ __device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[
   {
     constexpr int PER = NDIG * 16 / 1024;           // 4 (256 digits) or 2 (128 digits)
     uint32_t v[PER], s = 0;
-    for (int k = 0; k < PER; k++) { v[k] = cnt[tid * PER + k]; s += v[k]; }
+    // scan order is (digit major, wave minor): entry idx = d * 16 + wv lives at cnt[wv * NDIG + d]
+    for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; v[k] = cnt[(idx & 15) * NDIG + (idx >> 4)]; s += v[k]; }
     // block exclusive scan of s
     uint32_t incl = s;
     for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
@@ -61,7 +62,7 @@ __device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[
     uint32_t base = 0;
     for (int k = 0; k < w; k++) base += wsum[k];
     uint32_t run = base + incl - s;
-    for (int k = 0; k < PER; k++) { cnt[tid * PER + k] = run; run += v[k]; }
+    for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; cnt[(idx & 15) * NDIG + (idx >> 4)] = run; run += v[k]; }
   }
   __syncthreads();
   // phase C: stable scatter, 64 elements per wave step, ranks by ballot multi-split
@@ -78,9 +79,9 @@ __device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[
     if (act) {
       unsigned long long below = mask & ((1ull << lane) - 1ull);
       uint32_t rank = __popcll(below), tot = __popcll(mask);
-      uint32_t base = cnt[d * 16 + w];
+      uint32_t base = cnt[w * NDIG + d];
       dst[base + rank] = (uint16_t)e;
-      if (rank == tot - 1) cnt[d * 16 + w] = base + tot;   // last lane of the group advances the cursor
+      if (rank == tot - 1) cnt[w * NDIG + d] = base + tot;   // last lane of the group advances the cursor
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -113,7 +114,13 @@ constexpr uint32_t D_UNRESOLVED = 0, D_UNLIMITED = 0xFFFF, DIST3_CONTINUE = 0xFF
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
                                                      uint16_t *__restrict__ prev4, uint16_t *__restrict__ tails4,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
-                                                     uint2 *__restrict__ RDD) {
+                                                     uint16_t *__restrict__ HS, uint2 *__restrict__ RDD, unsigned long long *__restrict__ dbg) {
+#ifdef ZADA_PL_STATS
+  unsigned long long tprev = clock64(); int tph = 8;
+#define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
+#else
+#define PL_STAMP() do {} while (0)
+#endif
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *A = (uint16_t *)smem;                 // 64 KiB
   uint16_t *B = A + 32768;                        // 64 KiB
@@ -129,9 +136,17 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tail)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
   for (int i = tid; i < 32768 / 4; i += 1024) ((uint4 *)bsc)[i] = make_uint4(0, 0, 0, 0);
   const uint8_t *sin = in + base;
+  // both hashes of every position, computed once with coalesced reads; later phases gather 2 bytes
+  uint16_t *h3 = HS + seg * 65536ull, *h4 = h3 + 32768;
+  PL_STAMP();   // 8: table init
+  for (uint32_t e = tid; e < m; e += 1024) { h3[e] = (uint16_t)hash3(sin, e); h4[e] = (uint16_t)hash4(sin, e); }
+  __syncthreads();
+  PL_STAMP();   // 9: hashes
   // ---- 15-bit hash order: ranks, distance limits, nearest true 3-byte match ----
-  radix_pass<256>(nullptr, A, cnt, wsum, m, [sin](uint32_t e) { return hash3(sin, e) & 0xFFu; });
-  radix_pass<128>(A, B, cnt, wsum, m, [sin](uint32_t e) { return hash3(sin, e) >> 8; });
+  radix_pass<256>(nullptr, A, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] & 0xFFu; });
+  PL_STAMP();   // 10: radix 1
+  radix_pass<128>(A, B, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] >> 8; });
+  PL_STAMP();   // 11: radix 2
   // A[i] := start index of the bucket that sorted element i belongs to (all LDS traffic lane-contiguous)
   // tags: bits of the three bytes that the 15-bit hash does not determine (9 in all; 4 kept in LDS in the
   // idle counter area, 8 in T3).  Different tag => different bytes; equal tag => verify the bytes.
@@ -140,7 +155,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   for (uint32_t i = tid; i < m; i += 1024) {
     const uint32_t e = B[i], b0 = sin[e], b1 = sin[e + 1];
     const uint32_t tg8 = (b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6);
-    A[i] = (uint16_t)hash3(sin, e); s3[i] = (uint16_t)e; t3[i] = (uint8_t)tg8;
+    A[i] = h3[e]; s3[i] = (uint16_t)e; t3[i] = (uint8_t)tg8;
     atomicOr(&cnt[i >> 3], (tg8 & 15u) << (4 * (i & 7)));
   }
   __syncthreads();
@@ -169,6 +184,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       if (i < m) { const uint32_t v = A[i]; A[i] = (uint16_t)(v > before ? v : before); }
     }
     __syncthreads();
+    PL_STAMP();   // 12: tags + scans
     for (uint32_t i = tid; i < m; i += 1024) {
       const uint32_t bs = A[i];
       const uint32_t e = B[i], r = i - bs;
@@ -193,24 +209,28 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         break;
       }
       RDD[p] = make_uint2(r | (d3 << 16), df | (dq << 16));
-      if (i + 1 == m || A[i + 1] == i + 1) bsc[hash3(sin, e)] = bs | ((i - bs + 1) << 16);
+      if (i + 1 == m || A[i + 1] == i + 1) bsc[h3[e]] = bs | ((i - bs + 1) << 16);
     }
   }
   __syncthreads();
   // ---- 4-byte hash order: the chains the match kernel walks ----
-  radix_pass<256>(nullptr, A, cnt, wsum, m, [sin](uint32_t e) { return hash4(sin, e) & 0xFFu; });
-  radix_pass<256>(A, B, cnt, wsum, m, [sin](uint32_t e) { return hash4(sin, e) >> 8; });
+  PL_STAMP();   // 13: rank/dist3 loop
+  radix_pass<256>(nullptr, A, cnt, wsum, m, [h4](uint32_t e) { return (uint32_t)h4[e] & 0xFFu; });
+  radix_pass<256>(A, B, cnt, wsum, m, [h4](uint32_t e) { return (uint32_t)h4[e] >> 8; });
+  PL_STAMP();   // 14: radix 3+4
+  for (uint32_t i = tid; i < m; i += 1024) A[i] = h4[B[i]];       // hash of each sorted element
+  __syncthreads();
   for (uint32_t i = tid; i < m; i += 1024) {
-    uint32_t e = B[i], h = hash4(sin, e);
+    const uint32_t e = B[i], h = A[i];
     uint16_t d = 0;
     if (i > 0) {
-      uint32_t e0 = B[i - 1];
-      if (hash4(sin, e0) == h && (base + e0) != 0) d = (uint16_t)(e - e0);     // NIL = position 0, lz77.adb:467
+      const uint32_t e0 = B[i - 1];
+      if (A[i - 1] == h && (base + e0) != 0) d = (uint16_t)(e - e0);          // NIL = position 0, lz77.adb:467
     }
     prev4[base + e] = d;
-    bool last = (i + 1 == m) || (hash4(sin, B[i + 1]) != h);
-    if (last) tail[h] = (uint16_t)e;
+    if (i + 1 == m || A[i + 1] != h) tail[h] = (uint16_t)e;
   }
+  PL_STAMP();   // 15: links
 }
 
 // Cross-segment resolution: one thread per inserted position of the segments >= 1.
@@ -620,7 +640,10 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   }
   if (nseg > 0) {
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2,
-                       W.prevd, W.tails, W.S3, W.T3, W.bsc3, W.RDD);
+                       W.prevd, W.tails, W.S3, W.T3, W.bsc3, W.HS, W.RDD, (unsigned long long *)W.dbg);
+#ifdef ZADA_PL_STATS
+    { unsigned long long h[16]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f hashes %.0f radix1 %.0f radix2 %.0f tags+scan %.0f rank/dist3 %.0f radix3+4 %.0f links %.0f\n", (double)h[8]/nseg,(double)h[9]/nseg,(double)h[10]/nseg,(double)h[11]/nseg,(double)h[12]/nseg,(double)h[13]/nseg,(double)h[14]/nseg,(double)h[15]/nseg); hipMemset(W.dbg, 0, 128); }
+#endif
     if (nseg > 1) hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)((n_ins - 32768 + 255) / 256)), dim3(256), 0, st, W.in, n_ins, cfg.chain, cfg.chain >> 2,
                                      W.prevd, W.tails, W.S3, W.T3, W.bsc3, W.RDD);
   }
