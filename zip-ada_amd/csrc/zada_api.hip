@@ -67,10 +67,9 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   int rc = 0;
 #define A(ptr, cnt) if (!rc) rc = dalloc(c, &W.ptr, (cnt))
   A(in, cap + IN_PAD + 64);
-  A(prevd, cap + IN_PAD);
-  A(tails, nseg32 * 65536);
-  A(S3, nseg32 * 32768); A(HS, nseg32 * 65536); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
-  A(RDD, cap + 64);
+  for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); A(ltails[l], nseg32 * 65536); }
+  A(S3, nseg32 * 32768); A(HS, nseg32 * 32768 * (1 + NLEVELS)); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
+  A(PI, (cap + 64) * 8);
   A(MF, cap + 64);
   A(MQ, cap + 64);
   A(spec_tok, nch * PTOK_STRIDE);
@@ -87,6 +86,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(blocks, W.cap_blocks);
   A(binfo, W.cap_blocks);
   A(emit, W.cap_blocks);
+  A(rel, W.cap_blocks * 6);
   A(codes, (W.cap_blocks + 1) * 320);
   W.cap_pieces = cap / 32768 + W.cap_blocks + 64;
   A(pieces, W.cap_pieces);
@@ -246,7 +246,7 @@ static int deflate_core(Ctx *c, int method, uint64_t n, uint64_t *out_len, uint3
   c->tbegin();
   c->tmark("begin");
   hipMemsetAsync(W.in + n, 0, IN_PAD, st);
-  hipMemsetAsync(W.prevd + (n >= 2 ? n - 2 : 0), 0, 2 * 64, st);
+  for (int l = 0; l < NLEVELS; l++) hipMemsetAsync(W.lprev[l] + (n >= 2 ? n - 2 : 0), 0, 2 * 64, st);
   hipMemsetAsync(W.out, 0, n + n / 1024 + 4096 < W.cap_out ? n + n / 1024 + 4096 : W.cap_out, st);
   uint32_t crc = crc_inout ? *crc_inout : 0xFFFFFFFFu;
   int rc = crc_stage(c, n, &crc);
@@ -378,7 +378,7 @@ int zada_lz77_tokens(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uin
   if (level < 0) return ZADA_E_INVALID;
   if (n) hipMemcpyAsync(c->ws.in, in, n, hipMemcpyHostToDevice, c->stream);
   hipMemsetAsync(c->ws.in + n, 0, IN_PAD, c->stream);
-  hipMemsetAsync(c->ws.prevd + (n >= 2 ? n - 2 : 0), 0, 2 * 64, c->stream);
+  for (int l = 0; l < NLEVELS; l++) hipMemsetAsync(c->ws.lprev[l] + (n >= 2 ? n - 2 : 0), 0, 2 * 64, c->stream);
   c->tbegin(); c->tmark("begin");
   uint32_t T = 0;
   rc = lz_stage(c, level, n, &T);

@@ -246,22 +246,57 @@ __device__ uint32_t wave_code_of(const int (&cur)[5], int sym, int lane, int nsy
   return bit_reverse(part, len);
 }
 
+// Per block, in parallel: everything the sequential chooser needs about "recycling" the codes that
+// are most likely in force when the block is reached -- the fixed codes (c = 0) or one of the two
+// descriptors of the PREVIOUS block (c = 1, 2): Recyclable (:495-508) and the recycled cost
+// (:1158, 1180, 1189); plus the end-of-block code of the block's own two descriptors.
+struct BlockRel { uint64_t bits[3]; uint32_t ok[3]; uint32_t eob[2]; uint32_t pad; };
+
+__global__ void __launch_bounds__(64) k_block_relate(uint32_t nblocks, const BlockInfo *__restrict__ binfo, BlockRel *__restrict__ rel) {
+  const uint32_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const BlockInfo *bi = &binfo[i];
+  uint32_t st[5]; int b1[5], b2[5];
+  for (int r = 0; r < 5; r++) { st[r] = bi->stats[lane + 64 * r]; b1[r] = bi->bl1[lane + 64 * r]; b2[r] = bi->bl2[lane + 64 * r]; }
+  BlockRel out;
+  for (int c = 0; c < 3; c++) {
+    int cur[5];
+    for (int r = 0; r < 5; r++) {
+      const int s = lane + 64 * r;
+      if (c == 0 || i == 0) cur[r] = s < 288 ? fixed_litlen_bl(s) : 5;
+      else cur[r] = c == 1 ? binfo[i - 1].bl1[s] : binfo[i - 1].bl2[s];
+    }
+    bool bad = false; uint64_t rc = 0;
+    for (int r = 0; r < 5; r++) {
+      const int s = lane + 64 * r;
+      if (cur[r] == 0 && b1[r] > 0) bad = true;
+      if (s < 288) { if (s != 256 && s <= 285) rc += (uint64_t)st[r] * (uint64_t)(cur[r] + litlen_sym_extra(s)); }
+      else if (s - 288 <= 29) rc += (uint64_t)st[r] * (uint64_t)(cur[r] + dist_sym_extra(s - 288));
+    }
+    out.ok[c] = __any(bad) ? 0u : 1u;
+    out.bits[c] = wave_sum_u64(rc);
+  }
+  out.eob[0] = ((uint32_t)__shfl(b1[4], 0) << 16) | wave_code_of(b1, 256, lane, 288);
+  out.eob[1] = ((uint32_t)__shfl(b2[4], 0) << 16) | wave_code_of(b2, 256, lane, 288);
+  out.pad = 0;
+  if (lane == 0) rel[i] = out;
+}
+
 struct ChooseState {
   int last_type, block_to_finish, last_marked;
   int code_block, code_variant;
+  uint32_t cur_eob;                                  // (length << 16) | code of symbol 256 under curr_descr
   uint64_t pos;
 };
 
 __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRange *__restrict__ blocks,
                                                const BlockInfo *__restrict__ binfo, const uint32_t *__restrict__ apos,
-                                               EmitRec *__restrict__ emit, uint32_t *__restrict__ tile_block,
+                                               const BlockRel *__restrict__ rel, EmitRec *__restrict__ emit, uint32_t *__restrict__ tile_block,
                                                StoredPiece *__restrict__ pieces, uint32_t cap_tiles, uint32_t cap_pieces,
                                                uint32_t *__restrict__ out32, ChooserOut *__restrict__ res,
                                                int fixed_only /* Deflate_Fixed */) {
   const int lane = threadIdx.x;
-  int cur[5];                                          // curr_descr lengths, symbol = lane + 64 r (:722)
-  for (int r = 0; r < 5; r++) { int s = lane + 64 * r; cur[r] = s < 288 ? fixed_litlen_bl(s) : 5; }
-  ChooseState S; S.last_type = BT_RESERVED; S.block_to_finish = 0; S.last_marked = 0; S.code_block = -1; S.code_variant = 0; S.pos = 0;
+  ChooseState S; S.last_type = BT_RESERVED; S.block_to_finish = 0; S.last_marked = 0; S.code_block = -1; S.code_variant = 0; S.pos = 0; S.cur_eob = 7u << 16;
   uint32_t ntiles = 0, npieces = 0, overflow = 0;
 
   if (fixed_only) {
@@ -287,15 +322,16 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
     return;
   }
 
-  // software prefetch of the whole next record (vectors AND scalars): the walk is a dependent chain,
-  // so every load of block i + 1 is issued before block i is decided
-  struct Rec { uint32_t st[5]; int b1[5], b2[5]; uint64_t fixed_data, dyn1_data, dyn2_data; uint32_t hdr1, hdr2, bytes, sp; BlockRange br; };
+  // software prefetch of the next record: the walk is a dependent chain, so every load of block
+  // i + 1 is issued before block i is decided.  Only scalars: the 320-element work was done per block,
+  // in parallel, by k_block_analyze / k_block_relate.
+  struct Rec { uint64_t fixed_data, dyn1_data, dyn2_data; uint32_t hdr1, hdr2, bytes, sp; BlockRange br; BlockRel rl; };
   auto load_block = [&](uint32_t i, Rec &r) {
     const BlockInfo *bi = &binfo[i];
-    for (int q = 0; q < 5; q++) { r.st[q] = bi->stats[lane + 64 * q]; r.b1[q] = bi->bl1[lane + 64 * q]; r.b2[q] = bi->bl2[lane + 64 * q]; }
     r.fixed_data = bi->fixed_data; r.dyn1_data = bi->dyn1_data; r.dyn2_data = bi->dyn2_data;
     r.hdr1 = bi->hdr1_bits; r.hdr2 = bi->hdr2_bits; r.bytes = bi->bytes; r.sp = bi->stored_possible;
     r.br = blocks[i];
+    r.rl = rel[i];
   };
   Rec nxt;
   if (nblocks > 0) load_block(0, nxt);
@@ -303,25 +339,33 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
   for (uint32_t i = 0; i < nblocks; i++) {
     const Rec cr = nxt;
     if (i + 1 < nblocks) load_block(i + 1, nxt);
-    uint32_t st[5]; int b1[5], b2[5];
-    for (int r = 0; r < 5; r++) { st[r] = cr.st[r]; b1[r] = cr.b1[r]; b2[r] = cr.b2[r]; }
     const BlockRange br = cr.br;
     const uint64_t fixed_data = cr.fixed_data, dyn1_data = cr.dyn1_data, dyn2_data = cr.dyn2_data;
     const uint32_t hdr1 = cr.hdr1, hdr2 = cr.hdr2, bytes = cr.bytes, stored_possible = cr.sp;
 
     // recycling (:1223-1226, Recyclable :495-508) and its cost (:1158, 1180, 1189)
-    bool bad = false; uint64_t rc = 0;
-    for (int r = 0; r < 5; r++) {
-      int s = lane + 64 * r;
-      if (cur[r] == 0 && b1[r] > 0) bad = true;
-      if (s < 288) { if (s != 256 && s <= 285) rc += (uint64_t)st[r] * (uint64_t)(cur[r] + litlen_sym_extra(s)); }
-      else if (s - 288 <= 29) rc += (uint64_t)st[r] * (uint64_t)(cur[r] + dist_sym_extra(s - 288));
+    bool recycling_possible = false; uint64_t recycled_data = 0;
+    if (S.last_type == BT_FIXED) { recycling_possible = true; recycled_data = cr.rl.bits[0]; }
+    else if (S.last_type == BT_DYNAMIC) {
+      if (S.code_block == (int)i - 1) { recycling_possible = cr.rl.ok[S.code_variant] != 0; recycled_data = cr.rl.bits[S.code_variant]; }
+      else {
+        // the codes in force are older than the previous block (a chain of recycled blocks): evaluate here
+        const BlockInfo *bi = &binfo[i];
+        const uint8_t *cl = S.code_variant == 1 ? binfo[S.code_block].bl1 : binfo[S.code_block].bl2;
+        bool bad = false; uint64_t rc = 0;
+        for (int r = 0; r < 5; r++) {
+          const int s = lane + 64 * r;
+          const int cu = cl[s]; const uint32_t stv = bi->stats[s];
+          if (cu == 0 && bi->bl1[s] > 0) bad = true;
+          if (s < 288) { if (s != 256 && s <= 285) rc += (uint64_t)stv * (uint64_t)(cu + litlen_sym_extra(s)); }
+          else if (s - 288 <= 29) rc += (uint64_t)stv * (uint64_t)(cu + dist_sym_extra(s - 288));
+        }
+        recycling_possible = !__any(bad);
+        recycled_data = wave_sum_u64(rc);
+      }
     }
-    const bool any_bad = __any(bad);
-    const uint64_t recycled_data = wave_sum_u64(rc);
-    const bool recycling_possible = S.last_type == BT_FIXED || (S.last_type == BT_DYNAMIC && !any_bad);
     const bool finishing = S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC);
-    const int eob_len = __shfl(cur[4], 0);            // symbol 256 = lane 0, r = 4
+    const int eob_len = (int)(S.cur_eob >> 16);
     const uint64_t c = 1 + (finishing ? (uint64_t)eob_len : 0);                 // :1198-1201
     const uint64_t INF = ~0ull;
     uint64_t stored_bits = INF;
@@ -341,9 +385,8 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
     // Mark_new_block :999-1007 (pre-EOB of the block being finished, then BFINAL)
     auto mark_new_block = [&](int last_for_stream) {
       if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
-        uint32_t code = wave_code_of(cur, 256, lane, 288);
-        int l = __shfl(cur[4], 0);
-        if (lane == 0) put_bits_global(out32, S.pos, code, l);
+        const int l = (int)(S.cur_eob >> 16);
+        if (lane == 0) put_bits_global(out32, S.pos, S.cur_eob & 0xFFFF, l);
         S.pos += (uint64_t)l;
       }
       S.block_to_finish = 1;
@@ -356,15 +399,14 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
     if (fmt == FMT_FIXED) {
       if (S.last_type != BT_FIXED) {                                             // Send_fixed_block :1108-1121
         mark_new_block(last_block);
-        for (int r = 0; r < 5; r++) { int s = lane + 64 * r; cur[r] = s < 288 ? fixed_litlen_bl(s) : 5; }
         if (lane == 0) put_bits_global(out32, S.pos, 1, 2);
         S.pos += 2;
-        S.last_type = BT_FIXED; S.code_block = -1; S.code_variant = 0;
+        S.last_type = BT_FIXED; S.code_block = -1; S.code_variant = 0; S.cur_eob = 7u << 16;
       }
       data_bits = fixed_data;
     } else if (fmt == FMT_DYN1 || fmt == FMT_DYN2) {                             // Send_dynamic_block :1126-1135
       mark_new_block(last_block);
-      for (int r = 0; r < 5; r++) cur[r] = (fmt == FMT_DYN1) ? b1[r] : b2[r];
+      S.cur_eob = cr.rl.eob[fmt == FMT_DYN1 ? 0 : 1];
       if (lane == 0) put_bits_global(out32, S.pos, 2, 2);
       S.pos += 2;
       e.hdr_bitpos = S.pos;
@@ -416,9 +458,8 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
 
   // stream epilogue, Encode :1613-1635
   if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
-    uint32_t code = wave_code_of(cur, 256, lane, 288);
-    int l = __shfl(cur[4], 0);
-    if (lane == 0) put_bits_global(out32, S.pos, code, l);
+    const int l = (int)(S.cur_eob >> 16);
+    if (lane == 0) put_bits_global(out32, S.pos, S.cur_eob & 0xFFFF, l);
     S.pos += (uint64_t)l;
   }
   if (!S.last_marked) {
@@ -642,7 +683,8 @@ int huff_stage(Ctx *c, int method, uint64_t n, uint32_t T, uint64_t *total_bits)
     hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, W.atoms, W.apos, W.blocks, W.binfo);
     c->tmark("block_analyze");
   }
-  hipLaunchKernelGGL(k_choose, dim3(1), dim3(64), 0, st, nblocks, W.blocks, W.binfo, W.apos, W.emit, W.tile_block, W.pieces,
+  if (nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, (BlockRel *)W.rel);
+  hipLaunchKernelGGL(k_choose, dim3(1), dim3(64), 0, st, nblocks, W.blocks, W.binfo, W.apos, (const BlockRel *)W.rel, W.emit, W.tile_block, W.pieces,
                      (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.chooser, fixed_only ? 1 : 0);
   ChooserOut co;
   hipMemcpyAsync(&co, W.chooser, sizeof co, hipMemcpyDeviceToHost, st);

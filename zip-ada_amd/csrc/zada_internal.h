@@ -1,5 +1,8 @@
 // zada_internal.h -- context, workspace layout and shared constants of libzada_hip.so
 #pragma once
+#ifndef ZADA_NLEVELS
+#define ZADA_NLEVELS 3
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -15,6 +18,9 @@ constexpr uint32_t PCHUNK = 1024;                 // bytes parsed per lane (spec
 constexpr uint32_t PTOK_STRIDE = PCHUNK + 640;    // token slots per chunk (a parse may overrun its chunk by < 600 B)
 constexpr uint32_t CRC_CHUNK = 4096, CRC_SUB = 256;   // CRC: one lane per 256 B, folded to one value per 4 KiB on the device
 constexpr uint64_t IN_PAD = 1024;                 // zero bytes kept after the input
+
+constexpr int NLEVELS = ZADA_NLEVELS;               // hash levels 4 .. 3+NLEVELS; the last one is the chain the match kernel walks
+struct LevelPtrs { uint16_t *prev[NLEVELS]; uint16_t *tails[NLEVELS]; };
 
 // ---- entropy stage geometry (zip-compress-deflate.adb:942, 1294, 1313) ----
 constexpr uint32_t FLUSH = 65536;                 // atoms per Flush_half_buffer
@@ -60,9 +66,9 @@ struct ChooserOut {
 struct Workspace {
   uint64_t cap_n = 0;           // input capacity in bytes
   uint8_t *in = nullptr;
-  uint16_t *prevd = nullptr, *tails = nullptr;            // hash4 chain links / per-segment bucket tails
+  uint16_t *lprev[NLEVELS] = {}, *ltails[NLEVELS] = {};   // per level: chain links (16-bit distances) / per-segment bucket tails
   uint16_t *S3 = nullptr, *HS = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
-  uint2 *RDD = nullptr;                                    // .x = rank | dist3 << 16, .y = Dfull | Dquarter << 16
+  uint16_t *PI = nullptr;                                  // 8 x u16 per position: nearest 3/4/5-byte match, -, Dfull, Dquarter, rank, -
   uint32_t *MF = nullptr, *MQ = nullptr;     // alias: atoms / apos
   uint32_t *atoms = nullptr, *apos = nullptr;
   uint32_t *spec_tok = nullptr, *fix_tok = nullptr;
@@ -78,6 +84,7 @@ struct Workspace {
   BlockRange *blocks = nullptr;
   BlockInfo *binfo = nullptr;
   EmitRec *emit = nullptr;
+  uint64_t *rel = nullptr;                   // BlockRel[nblocks] (48 B each)
   uint32_t *codes = nullptr;                 // [nblocks+1][320]  (len << 16 | code); last = fixed table
   StoredPiece *pieces = nullptr;
   uint32_t *tile_block = nullptr;            // tile -> block

@@ -97,6 +97,27 @@ __device__ __forceinline__ uint32_t hash4(const uint8_t *__restrict__ in, uint64
   return (x * 2654435761u) >> 16;
 }
 
+// eight bytes at p with three aligned dword loads (in is 4-byte aligned; the buffer is padded past n)
+__device__ __forceinline__ uint64_t load8(const uint8_t *__restrict__ in, uint64_t p) {
+  const uint32_t *w = (const uint32_t *)(in + (p & ~3ull));
+  const uint32_t a = w[0], b = w[1], c = w[2], s = (uint32_t)(p & 3);
+  return (uint64_t)__builtin_amdgcn_alignbyte(b, a, s) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, s) << 32);
+}
+__device__ __forceinline__ uint32_t hash3_of(uint64_t v) {
+  return ((((uint32_t)v & 0xFF) << 10) ^ ((((uint32_t)v >> 8) & 0xFF) << 5) ^ (((uint32_t)v >> 16) & 0xFF)) & 0x7FFFu;
+}
+// 16-bit hash of the first L (4..6) bytes: level-L chains hold the candidates that can reach length >= L
+__device__ __forceinline__ uint32_t hashL_of(uint64_t v, int L) {
+  const uint32_t x = (uint32_t)v;
+  const uint32_t y = (uint32_t)(v >> 32) & (L > 5 ? 0xFFFFu : L > 4 ? 0xFFu : 0u);
+  return (x * 2654435761u + y * 0x9E3779B1u) >> 16;
+}
+__device__ __forceinline__ uint32_t hashL(const uint8_t *__restrict__ in, uint64_t p, int L) { return hashL_of(load8(in, p), L); }
+__device__ __forceinline__ bool sameL(const uint8_t *__restrict__ in, uint64_t p, uint64_t q, int L) {
+  const uint64_t mask = (1ull << (8 * L)) - 1ull;
+  return ((load8(in, p) ^ load8(in, q)) & mask) == 0;
+}
+
 // Per 32 KiB segment (grid = segments, block = 1024).  n_ins = number of inserted positions (n - 2).
 //
 // The reference walks, for position p, the chain of earlier positions with the same 15-bit hash
@@ -112,9 +133,9 @@ __device__ __forceinline__ uint32_t hash4(const uint8_t *__restrict__ in, uint64
 // cross-segment resolution in k_cross_links), RD = rank | dist3 << 16, DD = Dfull | Dquarter << 16.
 constexpr uint32_t D_UNRESOLVED = 0, D_UNLIMITED = 0xFFFF, DIST3_CONTINUE = 0xFFFF;
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
-                                                     uint16_t *__restrict__ prev4, uint16_t *__restrict__ tails4,
+                                                     LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
-                                                     uint16_t *__restrict__ HS, uint2 *__restrict__ RDD, unsigned long long *__restrict__ dbg) {
+                                                     uint16_t *__restrict__ HS, uint16_t *__restrict__ PI, unsigned long long *__restrict__ dbg) {
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
 #define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
@@ -129,17 +150,23 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   const uint64_t seg = blockIdx.x, base = seg * 32768ull;
   const uint32_t m = (uint32_t)((n_ins - base) < 32768ull ? (n_ins - base) : 32768ull);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  uint16_t *tail = tails4 + seg * 32768ull * 2;   // 65536 hash4 buckets
   uint32_t *bsc = bsc3 + seg * 32768ull;          // bucket start | count << 16
   uint16_t *s3 = S3 + seg * 32768ull;
   uint8_t *t3 = T3 + seg * 32768ull;              // top three bits of byte 0: what the 15-bit hash drops
-  for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tail)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  for (int l = 0; l < NLEVELS; l++) {
+    uint16_t *tail = lv.tails[l] + seg * 65536ull;                  // 65536 buckets per level
+    for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tail)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  }
   for (int i = tid; i < 32768 / 4; i += 1024) ((uint4 *)bsc)[i] = make_uint4(0, 0, 0, 0);
   const uint8_t *sin = in + base;
   // both hashes of every position, computed once with coalesced reads; later phases gather 2 bytes
-  uint16_t *h3 = HS + seg * 65536ull, *h4 = h3 + 32768;
+  uint16_t *h3 = HS + seg * (32768ull * (1 + NLEVELS));
   PL_STAMP();   // 8: table init
-  for (uint32_t e = tid; e < m; e += 1024) { h3[e] = (uint16_t)hash3(sin, e); h4[e] = (uint16_t)hash4(sin, e); }
+  for (uint32_t e = tid; e < m; e += 1024) {
+    const uint64_t v = load8(sin, e);
+    h3[e] = (uint16_t)hash3_of(v);
+    for (int l = 0; l < NLEVELS; l++) h3[32768 * (l + 1) + e] = (uint16_t)hashL_of(v, 4 + l);
+  }
   __syncthreads();
   PL_STAMP();   // 9: hashes
   // ---- 15-bit hash order: ranks, distance limits, nearest true 3-byte match ----
@@ -147,111 +174,161 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   PL_STAMP();   // 10: radix 1
   radix_pass<128>(A, B, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] >> 8; });
   PL_STAMP();   // 11: radix 2
-  // A[i] := start index of the bucket that sorted element i belongs to (all LDS traffic lane-contiguous)
-  // tags: bits of the three bytes that the 15-bit hash does not determine (9 in all; 4 kept in LDS in the
-  // idle counter area, 8 in T3).  Different tag => different bytes; equal tag => verify the bytes.
-  for (int i = tid; i < 4096; i += 1024) cnt[i] = 0;
-  __syncthreads();
-  for (uint32_t i = tid; i < m; i += 1024) {
-    const uint32_t e = B[i], b0 = sin[e], b1 = sin[e + 1];
-    const uint32_t tg8 = (b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6);
-    A[i] = h3[e]; s3[i] = (uint16_t)e; t3[i] = (uint8_t)tg8;
-    atomicOr(&cnt[i >> 3], (tg8 & 15u) << (4 * (i & 7)));
-  }
-  __syncthreads();
-  {
-    uint32_t firstbits = 0;                          // bit k: element tid + 1024 k starts a bucket
-    for (uint32_t k = 0; k < 32; k++) { const uint32_t i = tid + 1024 * k; if (i < m && (i == 0 || A[i - 1] != A[i])) firstbits |= 1u << k; }
+  // Bucket boundaries of the sorted order as a bitmask F (bit i: sorted element i starts a bucket) plus, per
+  // 32-element word, the index LW of the last non-empty word at or before it: rank and bucket start of any
+  // element in O(1).  Then the A half of LDS is recycled for the segment's bytes, so that every byte
+  // comparison below is an LDS read.
+  uint32_t *F = cnt;                               // 1024 words (+1 spill word)
+  uint16_t *LW = (uint16_t *)(cnt + 1040);         // 1024 entries
+  uint8_t *sb = (uint8_t *)A;                      // 32768 + 16 bytes (after A is dead)
+  auto build_flags = [&](const uint16_t *hv) {     // hv: hash of every position of this level
+    for (uint32_t i = tid; i < m; i += 1024) A[i] = hv[B[i]];
     __syncthreads();
-    for (uint32_t k = 0; k < 32; k++) { const uint32_t i = tid + 1024 * k; if (i < m) A[i] = (firstbits >> k) & 1u ? (uint16_t)i : (uint16_t)0; }
-    __syncthreads();
-    // inclusive max-scan of A: wave w owns [2048 w, 2048 w + 2048), 64 contiguous elements per step
-    uint32_t carry = 0;
     for (int it = 0; it < 32; it++) {
       const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
-      uint32_t v = i < m ? A[i] : 0u;
+      const bool first = i < m && (i == 0 || A[i - 1] != A[i]);
+      const unsigned long long mk = __ballot(first);
+      if (lane == 0) { F[(i >> 5)] = (uint32_t)mk; F[(i >> 5) + 1] = (uint32_t)(mk >> 32); }
+    }
+    __syncthreads();
+    {
+      // LW[wd] = last word index <= wd whose F word is non-zero (word 0 always is: element 0 starts a bucket)
+      uint32_t v = F[tid] != 0 ? (uint32_t)tid : 0u;
       for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if (lane >= off) v = v > t ? v : t; }
-      v = v > carry ? v : carry;
-      if (i < m) A[i] = (uint16_t)v;
-      carry = __shfl(v, 63);
-    }
-    if (lane == 0) wsum[w] = carry;
-    __syncthreads();
-    uint32_t before = 0;
-    for (int k = 0; k < w; k++) before = before > wsum[k] ? before : wsum[k];
-    for (int it = 0; it < 32; it++) {
-      const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
-      if (i < m) { const uint32_t v = A[i]; A[i] = (uint16_t)(v > before ? v : before); }
+      if (lane == 63) wsum[w] = v;
+      __syncthreads();
+      uint32_t before = 0;
+      for (int k = 0; k < w; k++) before = before > wsum[k] ? before : wsum[k];
+      LW[tid] = (uint16_t)(v > before ? v : before);
     }
     __syncthreads();
-    PL_STAMP();   // 12: tags + scans
-    for (uint32_t i = tid; i < m; i += 1024) {
-      const uint32_t bs = A[i];
-      const uint32_t e = B[i], r = i - bs;
-      const uint64_t p = base + e;
-      // distance limits from the ranks inside this segment; the rest is resolved by k_cross_links
-      uint32_t df = D_UNLIMITED, dq = D_UNLIMITED;
-      if (r >= (uint32_t)kfull) df = e - B[i - kfull]; else if (seg > 0) df = D_UNRESOLVED;
-      if (r >= (uint32_t)kquarter) dq = e - B[i - kquarter]; else if (seg > 0) dq = D_UNRESOLVED;
-      // nearest earlier position with the same three bytes (hash collisions are skipped)
-      uint32_t d3 = (seg > 0) ? DIST3_CONTINUE : 0u;
-      const uint32_t mytag = (cnt[i >> 3] >> (4 * (i & 7))) & 15u;
-      const uint32_t my24 = load24(sin, e);
-      for (uint32_t j = i; j > bs; j--) {
-        const uint32_t jj = j - 1;
-        const uint32_t q = B[jj], dist = e - q;
-        // NIL = position 0 (lz77.adb:467); beyond MAX_DIST nothing qualifies, exactly MAX_DIST only as
-        // the head of the chain (:850 vs :820)
-        if (base + q == 0 || dist > (uint32_t)MAX_DIST || (dist == (uint32_t)MAX_DIST && j != i)) { d3 = 0; break; }
-        if (((cnt[jj >> 3] >> (4 * (jj & 7))) & 15u) != mytag) continue;   // hash collision: not the same three bytes
-        if (load24(sin, q) != my24) continue;
-        d3 = dist;
-        break;
-      }
-      RDD[p] = make_uint2(r | (d3 << 16), df | (dq << 16));
-      if (i + 1 == m || A[i + 1] == i + 1) bsc[h3[e]] = bs | ((i - bs + 1) << 16);
-    }
+    for (int i = tid; i < (32768 + 16) / 16; i += 1024) ((uint4 *)sb)[i] = ((const uint4 *)sin)[i];   // A := bytes
+    __syncthreads();
+  };
+  auto bucket_start = [&](uint32_t i) -> uint32_t {
+    const uint32_t wd = i >> 5;
+    const uint32_t own = F[wd] & (0xFFFFFFFFu >> (31 - (i & 31)));
+    if (own) return (wd << 5) + 31 - __clz((int)own);
+    const uint32_t pw = LW[wd - 1];
+    return (pw << 5) + 31 - __clz((int)F[pw]);
+  };
+  auto lb8 = [&](uint32_t e) -> uint64_t {         // eight bytes of the segment at e, from LDS
+    const uint32_t *wv = (const uint32_t *)(sb + (e & ~3u));
+    const uint32_t a0 = wv[0], a1 = wv[1], a2 = wv[2], sh = e & 3;
+    return (uint64_t)__builtin_amdgcn_alignbyte(a1, a0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(a2, a1, sh) << 32);
+  };
+  build_flags(h3);
+  for (uint32_t i = tid; i < m; i += 1024) {       // T3: tags for the cross-segment continuation (k_cross_dist)
+    const uint32_t e = B[i], b0 = sb[e], b1 = sb[e + 1];
+    s3[i] = (uint16_t)e; t3[i] = (uint8_t)((b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6));
   }
-  __syncthreads();
-  // ---- 4-byte hash order: the chains the match kernel walks ----
-  PL_STAMP();   // 13: rank/dist3 loop
-  radix_pass<256>(nullptr, A, cnt, wsum, m, [h4](uint32_t e) { return (uint32_t)h4[e] & 0xFFu; });
-  radix_pass<256>(A, B, cnt, wsum, m, [h4](uint32_t e) { return (uint32_t)h4[e] >> 8; });
-  PL_STAMP();   // 14: radix 3+4
-  for (uint32_t i = tid; i < m; i += 1024) A[i] = h4[B[i]];       // hash of each sorted element
-  __syncthreads();
+  PL_STAMP();   // 12: flags
   for (uint32_t i = tid; i < m; i += 1024) {
-    const uint32_t e = B[i], h = A[i];
-    uint16_t d = 0;
-    if (i > 0) {
-      const uint32_t e0 = B[i - 1];
-      if (A[i - 1] == h && (base + e0) != 0) d = (uint16_t)(e - e0);          // NIL = position 0, lz77.adb:467
+    const uint32_t bs = bucket_start(i);
+    const uint32_t e = B[i], r = i - bs;
+    const uint64_t p = base + e;
+    // distance limits from the ranks inside this segment; the rest is resolved by k_cross_dist
+    uint32_t df = D_UNLIMITED, dq = D_UNLIMITED;
+    if (r >= (uint32_t)kfull) df = e - B[i - kfull]; else if (seg > 0) df = D_UNRESOLVED;
+    if (r >= (uint32_t)kquarter) dq = e - B[i - kquarter]; else if (seg > 0) dq = D_UNRESOLVED;
+    // nearest earlier position with the same three bytes (hash collisions are skipped)
+    uint32_t d3 = (seg > 0) ? DIST3_CONTINUE : 0u;
+    const uint32_t my24 = (uint32_t)lb8(e) & 0xFFFFFFu;
+    for (uint32_t j = i; j > bs; j--) {
+      const uint32_t q = B[j - 1], dist = e - q;
+      // NIL = position 0 (lz77.adb:467); beyond MAX_DIST nothing qualifies, exactly MAX_DIST only as
+      // the head of the chain (:850 vs :820)
+      if (base + q == 0 || dist > (uint32_t)MAX_DIST || (dist == (uint32_t)MAX_DIST && j != i)) { d3 = 0; break; }
+      if (((uint32_t)lb8(q) & 0xFFFFFFu) != my24) continue;        // hash collision: not the same three bytes
+      d3 = dist;
+      break;
     }
-    prev4[base + e] = d;
-    if (i + 1 == m || A[i + 1] != h) tail[h] = (uint16_t)e;
+    uint16_t *pi = PI + p * 8;                                    // [0..2] nearest 3/4/5-byte match, [4] Dfull, [5] Dquarter, [6] rank
+    pi[0] = (uint16_t)d3; pi[4] = (uint16_t)df; pi[5] = (uint16_t)dq; pi[6] = (uint16_t)r;
+    const bool last = (i + 1 == m) || ((F[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
+    if (last) bsc[h3[e]] = bs | ((i - bs + 1) << 16);
   }
-  PL_STAMP();   // 15: links
+  __syncthreads();
+  // ---- levels 4 .. 3+NLEVELS: order by the hash of the first L bytes.  Intermediate levels give the
+  //      nearest position sharing L bytes (the best candidate of length exactly L); the last level's
+  //      links are the chains the match kernel walks. ----
+  PL_STAMP();   // 13: rank/dist3 loop
+  for (int l = 0; l < NLEVELS; l++) {
+    const int L = 4 + l;
+    const uint16_t *hl = h3 + 32768 * (l + 1);
+    uint16_t *prevl = lv.prev[l], *tail = lv.tails[l] + seg * 65536ull;
+    radix_pass<256>(nullptr, A, cnt, wsum, m, [hl](uint32_t e) { return (uint32_t)hl[e] & 0xFFu; });
+    radix_pass<256>(A, B, cnt, wsum, m, [hl](uint32_t e) { return (uint32_t)hl[e] >> 8; });
+    PL_STAMP();
+    build_flags(hl);
+    PL_STAMP();
+    const uint64_t lmask = (1ull << (8 * L)) - 1ull;
+    for (uint32_t i = tid; i < m; i += 1024) {
+      const uint32_t e = B[i];
+      const bool first = (F[i >> 5] >> (i & 31)) & 1u;
+      uint16_t d = 0;
+      if (!first) { const uint32_t e0 = B[i - 1]; if ((base + e0) != 0) d = (uint16_t)(e - e0); }   // NIL = position 0, lz77.adb:467
+      prevl[base + e] = d;
+      const bool last = (i + 1 == m) || ((F[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
+      if (last) tail[hl[e]] = (uint16_t)e;
+      if (l + 1 < NLEVELS) {
+        // nearest earlier position with the same L bytes, inside this segment (else: continue in k_cross_dist)
+        uint32_t dl = (seg > 0) ? DIST3_CONTINUE : 0u;
+        const uint64_t mine = lb8(e) & lmask;
+        for (uint32_t j = i; j > 0 && !((F[j >> 5] >> (j & 31)) & 1u); j--) {
+          const uint32_t q = B[j - 1], dist = e - q;
+          if (base + q == 0 || dist > (uint32_t)MAX_DIST) { dl = 0; break; }
+          if ((lb8(q) & lmask) != mine) continue;
+          dl = dist;
+          break;
+        }
+        PI[(base + e) * 8 + 1 + l] = (uint16_t)dl;
+      }
+    }
+    __syncthreads();
+    PL_STAMP();
+  }
 }
 
-// Cross-segment resolution: one thread per inserted position of the segments >= 1.
-__global__ void __launch_bounds__(256) k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
-                                                     uint16_t *__restrict__ prev4, const uint16_t *__restrict__ tails4,
-                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
-                                                     uint2 *__restrict__ RDD) {
+// Cross-segment links of every level: one thread per inserted position of the segments >= 1.
+__global__ void __launch_bounds__(256) k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, LevelPtrs lv) {
   const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_ins) return;
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
-  if (prev4[p] == 0) {
-    uint32_t t = tails4[(seg - 1) * 65536ull + hash4(in, p)];
-    if (t != 0xFFFFu) {
-      uint64_t q = pbase + t, d = p - q;
-      if (d <= (uint64_t)MAX_DIST && q != 0) prev4[p] = (uint16_t)d;
-    }
+  for (int l = 0; l < NLEVELS; l++) {
+    if (lv.prev[l][p] != 0) continue;
+    const uint32_t t = lv.tails[l][(seg - 1) * 65536ull + hashL(in, p, 4 + l)];
+    if (t == 0xFFFFu) continue;
+    const uint64_t q = pbase + t, d = p - q;
+    if (d <= (uint64_t)MAX_DIST && q != 0) lv.prev[l][p] = (uint16_t)d;
   }
-  const uint2 rdd = RDD[p];
-  const uint32_t rd = rdd.x, dd = rdd.y;
-  const uint32_t r = rd & 0xFFFF;
-  uint32_t d3 = rd >> 16, df = dd & 0xFFFF, dq = dd >> 16;
+}
+
+// Cross-segment resolution of the per-position limits and nearest matches (runs after k_cross_links).
+__global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter, LevelPtrs lv,
+                                                    const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
+                                                    uint16_t *__restrict__ PI) {
+  const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_ins) return;
+  const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
+  uint16_t *pi = PI + p * 8;
+  const uint4 v = *(const uint4 *)pi;
+  uint32_t d3 = v.x & 0xFFFF, df = v.z & 0xFFFF, dq = v.z >> 16;
+  const uint32_t r = v.w & 0xFFFF;
+  // nearest L-byte matches that were not found inside the own segment: follow the level's chain
+  for (int l = 0; l + 1 < NLEVELS; l++) {
+    if (pi[1 + l] != DIST3_CONTINUE) continue;
+    uint32_t dl = 0;
+    uint64_t q = p;
+    for (;;) {
+      const uint32_t d = lv.prev[l][q];
+      if (d == 0) break;
+      q -= d;
+      if (p - q > (uint64_t)MAX_DIST) break;
+      if (sameL(in, p, q, 4 + l)) { dl = (uint32_t)(p - q); break; }
+    }
+    pi[1 + l] = (uint16_t)dl;
+  }
   if (d3 != DIST3_CONTINUE && df != D_UNRESOLVED && dq != D_UNRESOLVED) return;
   const uint32_t b0 = in[p];
   const uint32_t h = ((b0 << 10) ^ ((uint32_t)in[p + 1] << 5) ^ (uint32_t)in[p + 2]) & 0x7FFFu;
@@ -279,7 +356,7 @@ __global__ void __launch_bounds__(256) k_cross_links(const uint8_t *__restrict__
       if (pt[pst + j - 1] == mytag && load24(in, q) == my24) { d3 = (uint32_t)d; break; }
     }
   }
-  RDD[p] = make_uint2(r | (d3 << 16), df | (dq << 16));
+  pi[0] = (uint16_t)d3; pi[4] = (uint16_t)df; pi[5] = (uint16_t)dq;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -307,7 +384,7 @@ __device__ __forceinline__ uint32_t lds_u32_at(const uint32_t *w, uint32_t byteo
 // Both modes share one instruction stream: two unaligned LDS dwords at (cand + off), (scan + off).
 __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, uint64_t n,
                                                 const uint16_t *__restrict__ prevd,
-                                                const uint2 *__restrict__ RDD,
+                                                const uint4 *__restrict__ PI,
                                                 uint32_t *__restrict__ MF, uint32_t *__restrict__ MQ,
                                                 int nice_cfg, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -382,27 +459,37 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           const uint64_t rem = n - (B + k);
           la = rem < 258 ? (int)rem : 258;                         // Longest_Match never returns more
           nice = nice_cfg < la ? nice_cfg : la;                    // lz77.adb:858-860
-          // limits of this position's walk, as distances (see k_prev_links)
-          const uint2 rdd = RDD[B + k];
-          const uint32_t rd = rdd.x, dd = rdd.y;
-          const uint32_t d3 = rd >> 16, df = dd & 0xFFFF, dq = dd >> 16;
-          lim_full = d3 == (uint32_t)MAX_DIST ? (uint32_t)MAX_DIST : (df < (uint32_t)(MAX_DIST - 1) ? df : (uint32_t)(MAX_DIST - 1));   // :850 / :820-822
+          // limits of this position's walk, as distances, and the nearest 3 .. K-1 byte matches (k_prev_links)
+          const uint4 pi = PI[B + k];
+          const uint32_t df = pi.z & 0xFFFF, dq = pi.z >> 16;
+          uint32_t dl[3] = {pi.x & 0xFFFF, pi.x >> 16, pi.y & 0xFFFF};
+          lim_full = dl[0] == (uint32_t)MAX_DIST ? (uint32_t)MAX_DIST : (df < (uint32_t)(MAX_DIST - 1) ? df : (uint32_t)(MAX_DIST - 1));   // :850 / :820-822
           const uint32_t lim_q = dq < lim_full ? dq : lim_full;                                          // :733-735
-          const bool has3 = la >= 3 && d3 != 0 && d3 <= lim_full;      // nearest true 3-byte match = first candidate that counts
-          best = has3 ? 3 : 2; bdist = has3 ? d3 : 0;
-          have_q = has3 && d3 > lim_q; rq = 0;
+          // best candidate of each length 3 .. K-1 = the nearest position sharing that many bytes; the
+          // levels are nested (a 4-byte match is a 3-byte match), so they are valid in order
+          best = 2; bdist = 0; rq = 0;
+          uint32_t qbest = 0;
+          bool chain_ok = true;
+#pragma unroll
+          for (int l = 0; l < NLEVELS; l++) {
+            const bool v = chain_ok && la >= 3 + l && dl[l] != 0 && dl[l] <= lim_full;
+            if (v) { best = 3 + l; bdist = dl[l]; if (dl[l] <= lim_q) qbest = ((uint32_t)(3 + l) << 16) | dl[l]; }
+            chain_ok = v;
+          }
+          // chain_ok: a candidate of length K-1 exists, so longer ones may: walk the level-K chain
+          have_q = chain_ok && bdist > lim_q; rq = qbest;
           lim_cur = have_q ? lim_full : lim_q;
-          // first element of the 4-byte chain (only candidates sharing four bytes can beat length 3)
           const uint32_t d0 = lnk[wi];
-          bool ok = has3 && 3 < nice && d0 != 0 && d0 <= lim_full;
-          if (ok && !have_q && d0 > lim_q) { have_q = true; rq = (3u << 16) | bdist; lim_cur = lim_full; }
+          bool ok = chain_ok && best < nice && d0 != 0 && d0 <= lim_full;
+          if (ok && !have_q && d0 > lim_q) { have_q = true; rq = ((uint32_t)best << 16) | bdist; lim_cur = lim_full; }
           cur = ok ? wi - d0 : wi;
           const uint32_t a = wi + (uint32_t)best;
           s_end = (uint32_t)win8[a - 1] | ((uint32_t)win8[a] << 8);
           state = ok ? 1 : 0;
           if (!ok) {
-            const uint32_t packed = has3 ? (3u << 16) | bdist : 0u;
-            MF[B + k] = packed; MQ[B + k] = have_q ? rq : packed;
+            const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
+            // quarter-chain result: the best level whose candidate lies within the quarter limit
+            MF[B + k] = packed; MQ[B + k] = (have_q || !chain_ok) ? qbest : packed;
           }
         }
       }
@@ -639,18 +726,23 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     attr_done = true;
   }
   if (nseg > 0) {
-    hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2,
-                       W.prevd, W.tails, W.S3, W.T3, W.bsc3, W.HS, W.RDD, (unsigned long long *)W.dbg);
+    LevelPtrs lv;
+    for (int l = 0; l < NLEVELS; l++) { lv.prev[l] = W.lprev[l]; lv.tails[l] = W.ltails[l]; }
+    hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2, lv,
+                       W.S3, W.T3, W.bsc3, W.HS, W.PI, (unsigned long long *)W.dbg);
 #ifdef ZADA_PL_STATS
-    { unsigned long long h[16]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f hashes %.0f radix1 %.0f radix2 %.0f tags+scan %.0f rank/dist3 %.0f radix3+4 %.0f links %.0f\n", (double)h[8]/nseg,(double)h[9]/nseg,(double)h[10]/nseg,(double)h[11]/nseg,(double)h[12]/nseg,(double)h[13]/nseg,(double)h[14]/nseg,(double)h[15]/nseg); hipMemset(W.dbg, 0, 128); }
+    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f hashes %.0f radix1 %.0f radix2 %.0f tags+scan %.0f rank/dist3 %.0f |", (double)h[8]/nseg,(double)h[9]/nseg,(double)h[10]/nseg,(double)h[11]/nseg,(double)h[12]/nseg,(double)h[13]/nseg); for (int q = 14; q < 14 + 3 * NLEVELS; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level: radix, hash fill, link+dist)\n"); hipMemset(W.dbg, 0, 256); }
 #endif
-    if (nseg > 1) hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)((n_ins - 32768 + 255) / 256)), dim3(256), 0, st, W.in, n_ins, cfg.chain, cfg.chain >> 2,
-                                     W.prevd, W.tails, W.S3, W.T3, W.bsc3, W.RDD);
+    if (nseg > 1) {
+      const uint32_t nb = (uint32_t)((n_ins - 32768 + 255) / 256);
+      hipLaunchKernelGGL(k_cross_links, dim3(nb), dim3(256), 0, st, W.in, n_ins, lv);
+      hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(256), 0, st, W.in, n_ins, cfg.chain, cfg.chain >> 2, lv, W.S3, W.T3, W.bsc3, W.PI);
+    }
   }
   c->tmark("prev_links");
   {
     uint32_t nb = (uint32_t)((n + MB - 1) / MB);
-    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.prevd, W.RDD, W.MF, W.MQ, cfg.nice, (unsigned long long *)W.dbg);
+    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], (const uint4 *)W.PI, W.MF, W.MQ, cfg.nice, (unsigned long long *)W.dbg);
   }
 #ifdef ZADA_MATCH_STATS
   {
