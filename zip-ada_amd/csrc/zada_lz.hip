@@ -33,19 +33,27 @@ __device__ __forceinline__ uint32_t hash3(const uint8_t *__restrict__ in, uint64
 }
 
 // One stable counting pass over `m` elements held by 16 waves (wave w owns [w*2048, w*2048+2048)).
-// digit(e) is given by the functor; `src` == nullptr means element i is position i.
-template <int NDIG, typename DigitFn>
-__device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[NDIG*16]*/, uint32_t *wsum /*[16]*/, uint32_t m, DigitFn digit) {
+// digit(e) is given by the functor; `src` == nullptr means element i is position i.  The 32 digits of a
+// lane are fetched once, back to back (32 gathers in flight per lane: the pass is latency bound), and
+// kept packed in eight registers for both the histogram and the scatter phase.
+template <int NDIG, bool HAS_SRC, typename DigitFn>
+__device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[16][NDIG]*/, uint32_t *wsum /*[16]*/, uint32_t m, DigitFn digit) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   for (int i = tid; i < NDIG * 16; i += 1024) cnt[i] = 0;
-  __syncthreads();
-  // phase A: per (digit, wave) histogram
+  uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
   for (int it = 0; it < 32; it++) {
-    uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
-    if (i < m) {
-      uint32_t e = src ? src[i] : i;
-      atomicAdd(&cnt[w * NDIG + digit(e)], 1u);          // [wave][digit]: lanes of a wave spread over the banks
-    }
+    const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
+    uint32_t d = 0;
+    if (i < m) { uint32_t e = i; if (HAS_SRC) e = src[i]; d = digit(e); }
+    dg[it >> 2] |= d << (8 * (it & 3));
+  }
+  __syncthreads();
+  // phase A: per (wave, digit) histogram
+#pragma unroll
+  for (int it = 0; it < 32; it++) {
+    const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
+    if (i < m) atomicAdd(&cnt[w * NDIG + ((dg[it >> 2] >> (8 * (it & 3))) & 0xFFu)], 1u);     // [wave][digit]: lanes spread over the banks
   }
   __syncthreads();
   // phase B: exclusive scan over (digit major, wave minor)
@@ -54,7 +62,6 @@ __device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[
     uint32_t v[PER], s = 0;
     // scan order is (digit major, wave minor): entry idx = d * 16 + wv lives at cnt[wv * NDIG + d]
     for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; v[k] = cnt[(idx & 15) * NDIG + (idx >> 4)]; s += v[k]; }
-    // block exclusive scan of s
     uint32_t incl = s;
     for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
     if (lane == 63) wsum[w] = incl;
@@ -66,17 +73,19 @@ __device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[
   }
   __syncthreads();
   // phase C: stable scatter, 64 elements per wave step, ranks by ballot multi-split
+#pragma unroll
   for (int it = 0; it < 32; it++) {
-    uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
-    bool act = i < m;
-    uint32_t e = 0, d = 0;
-    if (act) { e = src ? src[i] : i; d = digit(e); }
+    const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
+    const bool act = i < m;
+    const uint32_t d = (dg[it >> 2] >> (8 * (it & 3))) & 0xFFu;
     unsigned long long mask = __ballot(act);
     for (int b = 0; (1 << b) < NDIG; b++) {
       unsigned long long bal = __ballot((d >> b) & 1);
       mask &= ((d >> b) & 1) ? bal : ~bal;
     }
     if (act) {
+      uint32_t e = i;
+      if (HAS_SRC) e = src[i];
       unsigned long long below = mask & ((1ull << lane) - 1ull);
       uint32_t rank = __popcll(below), tot = __popcll(mask);
       uint32_t base = cnt[w * NDIG + d];
@@ -91,12 +100,6 @@ __device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[
 __device__ __forceinline__ uint32_t load24(const uint8_t *__restrict__ in, uint64_t p) {
   return (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16);
 }
-// 16-bit hash of the four bytes at p (second-level chains: candidates that can reach length >= 4)
-__device__ __forceinline__ uint32_t hash4(const uint8_t *__restrict__ in, uint64_t p) {
-  const uint32_t x = load24(in, p) | ((uint32_t)in[p + 3] << 24);
-  return (x * 2654435761u) >> 16;
-}
-
 // eight bytes at p with three aligned dword loads (in is 4-byte aligned; the buffer is padded past n)
 __device__ __forceinline__ uint64_t load8(const uint8_t *__restrict__ in, uint64_t p) {
   const uint32_t *w = (const uint32_t *)(in + (p & ~3ull));
@@ -170,9 +173,9 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   __syncthreads();
   PL_STAMP();   // 9: hashes
   // ---- 15-bit hash order: ranks, distance limits, nearest true 3-byte match ----
-  radix_pass<256>(nullptr, A, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] & 0xFFu; });
+  radix_pass<256, false>(nullptr, A, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] & 0xFFu; });
   PL_STAMP();   // 10: radix 1
-  radix_pass<128>(A, B, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] >> 8; });
+  radix_pass<128, true>(A, B, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] >> 8; });
   PL_STAMP();   // 11: radix 2
   // Bucket boundaries of the sorted order as a bitmask F (bit i: sorted element i starts a bucket) plus, per
   // 32-element word, the index LW of the last non-empty word at or before it: rank and bucket start of any
@@ -182,7 +185,13 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint16_t *LW = (uint16_t *)(cnt + 1040);         // 1024 entries
   uint8_t *sb = (uint8_t *)A;                      // 32768 + 16 bytes (after A is dead)
   auto build_flags = [&](const uint16_t *hv) {     // hv: hash of every position of this level
-    for (uint32_t i = tid; i < m; i += 1024) A[i] = hv[B[i]];
+    for (uint32_t i0 = tid; i0 < m; i0 += 8192) {     // 8 gathers in flight per lane
+      uint32_t hvv[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const uint32_t i = i0 + 1024 * k; hvv[k] = i < m ? (uint32_t)hv[B[i]] : 0u; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const uint32_t i = i0 + 1024 * k; if (i < m) A[i] = (uint16_t)hvv[k]; }
+    }
     __syncthreads();
     for (int it = 0; it < 32; it++) {
       const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
@@ -234,6 +243,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     // nearest earlier position with the same three bytes (hash collisions are skipped)
     uint32_t d3 = (seg > 0) ? DIST3_CONTINUE : 0u;
     const uint32_t my24 = (uint32_t)lb8(e) & 0xFFFFFFu;
+#ifndef ZADA_EXP_NOWALK
     for (uint32_t j = i; j > bs; j--) {
       const uint32_t q = B[j - 1], dist = e - q;
       // NIL = position 0 (lz77.adb:467); beyond MAX_DIST nothing qualifies, exactly MAX_DIST only as
@@ -243,8 +253,13 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       d3 = dist;
       break;
     }
+#endif
     uint16_t *pi = PI + p * 8;                                    // [0..2] nearest 3/4/5-byte match, [4] Dfull, [5] Dquarter, [6] rank
+#ifndef ZADA_EXP_NOSTORE
     pi[0] = (uint16_t)d3; pi[4] = (uint16_t)df; pi[5] = (uint16_t)dq; pi[6] = (uint16_t)r;
+#else
+    if (d3 + df + dq + r == 0x12345678u) pi[0] = 1;
+#endif
     const bool last = (i + 1 == m) || ((F[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
     if (last) bsc[h3[e]] = bs | ((i - bs + 1) << 16);
   }
@@ -257,8 +272,8 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     const int L = 4 + l;
     const uint16_t *hl = h3 + 32768 * (l + 1);
     uint16_t *prevl = lv.prev[l], *tail = lv.tails[l] + seg * 65536ull;
-    radix_pass<256>(nullptr, A, cnt, wsum, m, [hl](uint32_t e) { return (uint32_t)hl[e] & 0xFFu; });
-    radix_pass<256>(A, B, cnt, wsum, m, [hl](uint32_t e) { return (uint32_t)hl[e] >> 8; });
+    radix_pass<256, false>(nullptr, A, cnt, wsum, m, [hl](uint32_t e) { return (uint32_t)hl[e] & 0xFFu; });
+    radix_pass<256, true>(A, B, cnt, wsum, m, [hl](uint32_t e) { return (uint32_t)hl[e] >> 8; });
     PL_STAMP();
     build_flags(hl);
     PL_STAMP();
