@@ -69,7 +69,8 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(in, cap + IN_PAD + 64);
   for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); A(ltails[l], nseg32 * 65536); }
   A(S3, nseg32 * 32768); A(HS, nseg32 * 32768 * (1 + NLEVELS)); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
-  A(PI, (cap + 64) * 8);
+  for (int l = 0; l < NLEVELS; l++) A(dplane[l], cap + 64);
+  A(dlim, cap + 64);
   A(MF, cap + 64);
   A(MQ, cap + 64);
   A(spec_tok, nch * PTOK_STRIDE);

@@ -21,6 +21,8 @@ constexpr uint64_t IN_PAD = 1024;                 // zero bytes kept after the i
 
 constexpr int NLEVELS = ZADA_NLEVELS;               // hash levels 4 .. 3+NLEVELS; the last one is the chain the match kernel walks
 struct LevelPtrs { uint16_t *prev[NLEVELS]; uint16_t *tails[NLEVELS]; };
+// per-position planes: d[l] = distance of the nearest position sharing 3 + l bytes (0 = none); dlim = Dfull | Dquarter << 16
+struct DistPlanes { uint16_t *d[NLEVELS]; uint32_t *dlim; };
 
 // ---- entropy stage geometry (zip-compress-deflate.adb:942, 1294, 1313) ----
 constexpr uint32_t FLUSH = 65536;                 // atoms per Flush_half_buffer
@@ -68,7 +70,7 @@ struct Workspace {
   uint8_t *in = nullptr;
   uint16_t *lprev[NLEVELS] = {}, *ltails[NLEVELS] = {};   // per level: chain links (16-bit distances) / per-segment bucket tails
   uint16_t *S3 = nullptr, *HS = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
-  uint16_t *PI = nullptr;                                  // 8 x u16 per position: nearest 3/4/5-byte match, -, Dfull, Dquarter, rank, -
+  uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr;  // DistPlanes
   uint32_t *MF = nullptr, *MQ = nullptr;     // alias: atoms / apos
   uint32_t *atoms = nullptr, *apos = nullptr;
   uint32_t *spec_tok = nullptr, *fix_tok = nullptr;

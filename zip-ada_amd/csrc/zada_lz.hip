@@ -134,11 +134,11 @@ __device__ __forceinline__ bool sameL(const uint8_t *__restrict__ in, uint64_t p
 // Outputs: prev4 (16-bit distance to the previous position of the same hash4 bucket), tails4,
 // S3 / bstart3 / bcnt3 (sorted order and buckets of the 15-bit hash, for the next segment's
 // cross-segment resolution in k_cross_links), RD = rank | dist3 << 16, DD = Dfull | Dquarter << 16.
-constexpr uint32_t D_UNRESOLVED = 0, D_UNLIMITED = 0xFFFF, DIST3_CONTINUE = 0xFFFF;
+constexpr uint32_t DIST3_CONTINUE = 0xFFFF;
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
-                                                     uint16_t *__restrict__ HS, uint16_t *__restrict__ PI, unsigned long long *__restrict__ dbg) {
+                                                     uint16_t *__restrict__ HS, DistPlanes dp, unsigned long long *__restrict__ dbg) {
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
 #define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   PL_STAMP();   // 8: table init
   for (uint32_t e = tid; e < m; e += 1024) {
     const uint64_t v = load8(sin, e);
+    dp.dlim[base + e] = 0xFFFFFFFFu;                               // no chain-length limit unless k_bucket_limits finds one
     h3[e] = (uint16_t)hash3_of(v);
     for (int l = 0; l < NLEVELS; l++) h3[32768 * (l + 1) + e] = (uint16_t)hashL_of(v, 4 + l);
   }
@@ -234,12 +235,8 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   PL_STAMP();   // 12: flags
   for (uint32_t i = tid; i < m; i += 1024) {
     const uint32_t bs = bucket_start(i);
-    const uint32_t e = B[i], r = i - bs;
+    const uint32_t e = B[i];
     const uint64_t p = base + e;
-    // distance limits from the ranks inside this segment; the rest is resolved by k_cross_dist
-    uint32_t df = D_UNLIMITED, dq = D_UNLIMITED;
-    if (r >= (uint32_t)kfull) df = e - B[i - kfull]; else if (seg > 0) df = D_UNRESOLVED;
-    if (r >= (uint32_t)kquarter) dq = e - B[i - kquarter]; else if (seg > 0) dq = D_UNRESOLVED;
     // nearest earlier position with the same three bytes (hash collisions are skipped)
     uint32_t d3 = (seg > 0) ? DIST3_CONTINUE : 0u;
     const uint32_t my24 = (uint32_t)lb8(e) & 0xFFFFFFu;
@@ -254,12 +251,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       break;
     }
 #endif
-    uint16_t *pi = PI + p * 8;                                    // [0..2] nearest 3/4/5-byte match, [4] Dfull, [5] Dquarter, [6] rank
-#ifndef ZADA_EXP_NOSTORE
-    pi[0] = (uint16_t)d3; pi[4] = (uint16_t)df; pi[5] = (uint16_t)dq; pi[6] = (uint16_t)r;
-#else
-    if (d3 + df + dq + r == 0x12345678u) pi[0] = 1;
-#endif
+    dp.d[0][p] = (uint16_t)d3;
     const bool last = (i + 1 == m) || ((F[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
     if (last) bsc[h3[e]] = bs | ((i - bs + 1) << 16);
   }
@@ -297,7 +289,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           dl = dist;
           break;
         }
-        PI[(base + e) * 8 + 1 + l] = (uint16_t)dl;
+        dp.d[1 + l][base + e] = (uint16_t)dl;
       }
     }
     __syncthreads();
@@ -319,59 +311,104 @@ __global__ void __launch_bounds__(256) k_cross_links(const uint8_t *__restrict__
   }
 }
 
-// Cross-segment resolution of the per-position limits and nearest matches (runs after k_cross_links).
-__global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter, LevelPtrs lv,
+// Cross-segment continuation of the nearest 3 .. K-1 byte matches (runs after k_cross_links): one
+// thread per inserted position of the segments >= 1; only positions marked "continue" do any work.
+__global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ in, uint64_t n_ins, LevelPtrs lv,
                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
-                                                    uint16_t *__restrict__ PI) {
+                                                    DistPlanes dp) {
   const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_ins) return;
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
-  uint16_t *pi = PI + p * 8;
-  const uint4 v = *(const uint4 *)pi;
-  uint32_t d3 = v.x & 0xFFFF, df = v.z & 0xFFFF, dq = v.z >> 16;
-  const uint32_t r = v.w & 0xFFFF;
-  // nearest L-byte matches that were not found inside the own segment: follow the level's chain
-  for (int l = 0; l + 1 < NLEVELS; l++) {
-    if (pi[1 + l] != DIST3_CONTINUE) continue;
-    uint32_t dl = 0;
-    uint64_t q = p;
-    for (;;) {
-      const uint32_t d = lv.prev[l][q];
-      if (d == 0) break;
-      q -= d;
-      if (p - q > (uint64_t)MAX_DIST) break;
-      if (sameL(in, p, q, 4 + l)) { dl = (uint32_t)(p - q); break; }
-    }
-    pi[1 + l] = (uint16_t)dl;
-  }
-  if (d3 != DIST3_CONTINUE && df != D_UNRESOLVED && dq != D_UNRESOLVED) return;
-  const uint32_t b0 = in[p];
-  const uint32_t h = ((b0 << 10) ^ ((uint32_t)in[p + 1] << 5) ^ (uint32_t)in[p + 2]) & 0x7FFFu;
-  const uint32_t bsc = bsc3[pbase + h];
-  const uint32_t pst = bsc & 0xFFFF, pct = bsc >> 16;
-  const uint16_t *ps = S3 + pbase;
-  if (df == D_UNRESOLVED) {
-    const uint32_t need = (uint32_t)kfull - r;
-    if (pct >= need) { uint64_t d = p - (pbase + ps[pst + pct - need]); df = d < 0xFFFF ? (uint32_t)d : D_UNLIMITED; } else df = D_UNLIMITED;
-  }
-  if (dq == D_UNRESOLVED) {
-    const uint32_t need = (uint32_t)kquarter - r;
-    if (pct >= need) { uint64_t d = p - (pbase + ps[pst + pct - need]); dq = d < 0xFFFF ? (uint32_t)d : D_UNLIMITED; } else dq = D_UNLIMITED;
-  }
-  if (d3 == DIST3_CONTINUE) {
-    d3 = 0;
+  // level 3 first: the previous segment's bucket of the 15-bit hash, newest first
+  uint32_t dprev = dp.d[0][p];
+  if (dprev == DIST3_CONTINUE) {
+    const uint32_t b0 = in[p], b1 = in[p + 1];
+    const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (uint32_t)in[p + 2]) & 0x7FFFu;
+    const uint32_t bsc = bsc3[pbase + h], own = bsc3[seg * 32768ull + h];
+    const uint32_t pst = bsc & 0xFFFF, pct = bsc >> 16;
+    const uint16_t *ps = S3 + pbase;
     const uint8_t *pt = T3 + pbase;
-    const uint32_t b1 = in[p + 1];
+    // p heads its own-segment bucket <=> it is the bucket's first element (the 32 506 rule, :850 vs :820)
+    const bool heads = S3[seg * 32768ull + (own & 0xFFFF)] == (uint16_t)(p & 32767);
     const uint32_t mytag = (b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6);
     const uint32_t my24 = load24(in, p);
+    uint32_t d3 = 0;
     for (uint32_t j = pct; j > 0; j--) {
       const uint64_t q = pbase + ps[pst + j - 1], d = p - q;
-      // beyond MAX_DIST nothing qualifies; exactly MAX_DIST only as the head of the chain (:850 vs :820)
-      if (q == 0 || d > (uint64_t)MAX_DIST || (d == (uint64_t)MAX_DIST && !(r == 0 && j == pct))) break;
+      // beyond MAX_DIST nothing qualifies; exactly MAX_DIST only as the head of the chain
+      if (q == 0 || d > (uint64_t)MAX_DIST || (d == (uint64_t)MAX_DIST && !(heads && j == pct))) break;
       if (pt[pst + j - 1] == mytag && load24(in, q) == my24) { d3 = (uint32_t)d; break; }
     }
+    dp.d[0][p] = (uint16_t)d3;
+    dprev = d3;
   }
-  pi[0] = (uint16_t)d3; pi[4] = (uint16_t)df; pi[5] = (uint16_t)dq;
+  // levels >= 4: follow the level's chain (it crosses into the previous segment after k_cross_links).
+  // The levels are nested: no L-1 byte match => no L byte match, and an L byte match is never nearer
+  // than the nearest L-1 byte match.
+  for (int l = 0; l + 1 < NLEVELS; l++) {
+    uint32_t dl = dp.d[1 + l][p];
+    if (dl == DIST3_CONTINUE) {
+      dl = 0;
+      if (dprev != 0) {
+        uint64_t q = p;
+        const uint64_t mine = load8(in, p), mask = (1ull << (8 * (4 + l))) - 1ull;
+        for (;;) {
+          const uint32_t d = lv.prev[l][q];
+          if (d == 0) break;
+          q -= d;
+          if (p - q > (uint64_t)MAX_DIST) break;
+          if (p - q >= (uint64_t)dprev && ((load8(in, q) ^ mine) & mask) == 0) { dl = (uint32_t)(p - q); break; }
+        }
+      }
+      dp.d[1 + l][p] = (uint16_t)dl;
+    }
+    dprev = dl;
+  }
+}
+
+// Chain-length limits as distances.  "Within the first k chain elements" <=> "not farther than the k-th
+// predecessor in the 15-bit hash bucket" (own segment, then the previous one; anything older is out of
+// range anyway).  Only buckets with at least kquarter elements over the two segments matter, so the
+// per-position default (no limit) is written by k_prev_links and this kernel touches the few long
+// buckets: one workgroup per segment, long buckets listed in LDS, then processed by all threads.
+__global__ void __launch_bounds__(256) k_bucket_limits(uint64_t n_ins, int kfull, int kquarter, const uint16_t *__restrict__ S3,
+                                                       const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim) {
+  __shared__ uint32_t list[2048];
+  __shared__ uint32_t nlist;
+  const uint64_t seg = blockIdx.x, base = seg * 32768ull;
+  const int tid = threadIdx.x;
+  const uint32_t *own = bsc3 + base, *prv = seg > 0 ? bsc3 + base - 32768 : nullptr;
+  const uint16_t *s3 = S3 + base, *p3 = seg > 0 ? S3 + base - 32768 : nullptr;
+  for (uint32_t h0 = 0; h0 < 32768; h0 += 2048) {        // rounds of 2048 buckets: the list cannot overflow
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    for (uint32_t h = h0 + tid; h < h0 + 2048; h += 256) {
+      const uint32_t c = own[h] >> 16, cp = prv ? prv[h] >> 16 : 0u;
+      if (c > 0 && c - 1 + cp >= (uint32_t)kquarter) { const uint32_t k = atomicAdd(&nlist, 1u); if (k < 2048) list[k] = h; }
+    }
+    __syncthreads();
+    const uint32_t nl = nlist < 2048 ? nlist : 2048;
+    for (uint32_t li = 0; li < nl; li++) {
+      const uint32_t h = list[li];
+      const uint32_t st = own[h] & 0xFFFF, c = own[h] >> 16;
+      const uint32_t pst = prv ? prv[h] & 0xFFFF : 0u, cp = prv ? prv[h] >> 16 : 0u;
+      const uint32_t r0 = (uint32_t)kquarter > cp ? (uint32_t)kquarter - cp : 0u;
+      for (uint32_t r = r0 + tid; r < c; r += 256) {
+        const uint32_t e = s3[st + r];
+        uint32_t lim[2];
+        const uint32_t ks[2] = {(uint32_t)kfull, (uint32_t)kquarter};
+        for (int t = 0; t < 2; t++) {
+          const uint32_t k = ks[t];
+          uint64_t d = 0xFFFF;
+          if (r >= k) d = e - s3[st + r - k];
+          else if (cp >= k - r) d = (base + e) - (base - 32768 + p3[pst + cp - (k - r)]);
+          lim[t] = d < 0xFFFF ? (uint32_t)d : 0xFFFFu;
+        }
+        dlim[base + e] = lim[0] | (lim[1] << 16);
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -399,7 +436,7 @@ __device__ __forceinline__ uint32_t lds_u32_at(const uint32_t *w, uint32_t byteo
 // Both modes share one instruction stream: two unaligned LDS dwords at (cand + off), (scan + off).
 __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, uint64_t n,
                                                 const uint16_t *__restrict__ prevd,
-                                                const uint4 *__restrict__ PI,
+                                                DistPlanes dp,
                                                 uint32_t *__restrict__ MF, uint32_t *__restrict__ MQ,
                                                 int nice_cfg, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -475,9 +512,11 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           la = rem < 258 ? (int)rem : 258;                         // Longest_Match never returns more
           nice = nice_cfg < la ? nice_cfg : la;                    // lz77.adb:858-860
           // limits of this position's walk, as distances, and the nearest 3 .. K-1 byte matches (k_prev_links)
-          const uint4 pi = PI[B + k];
-          const uint32_t df = pi.z & 0xFFFF, dq = pi.z >> 16;
-          uint32_t dl[3] = {pi.x & 0xFFFF, pi.x >> 16, pi.y & 0xFFFF};
+          const uint32_t dlimv = dp.dlim[B + k];
+          const uint32_t df = dlimv & 0xFFFF, dq = dlimv >> 16;
+          uint32_t dl[NLEVELS];
+#pragma unroll
+          for (int l = 0; l < NLEVELS; l++) dl[l] = dp.d[l][B + k];
           lim_full = dl[0] == (uint32_t)MAX_DIST ? (uint32_t)MAX_DIST : (df < (uint32_t)(MAX_DIST - 1) ? df : (uint32_t)(MAX_DIST - 1));   // :850 / :820-822
           const uint32_t lim_q = dq < lim_full ? dq : lim_full;                                          // :733-735
           // best candidate of each length 3 .. K-1 = the nearest position sharing that many bytes; the
@@ -740,24 +779,31 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16 + MB / 4);
     attr_done = true;
   }
+  LevelPtrs lv;
+  DistPlanes dpl;
+  for (int l = 0; l < NLEVELS; l++) dpl.d[l] = W.dplane[l];
+  dpl.dlim = W.dlim;
   if (nseg > 0) {
-    LevelPtrs lv;
     for (int l = 0; l < NLEVELS; l++) { lv.prev[l] = W.lprev[l]; lv.tails[l] = W.ltails[l]; }
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2, lv,
-                       W.S3, W.T3, W.bsc3, W.HS, W.PI, (unsigned long long *)W.dbg);
+                       W.S3, W.T3, W.bsc3, W.HS, dpl, (unsigned long long *)W.dbg);
 #ifdef ZADA_PL_STATS
     { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f hashes %.0f radix1 %.0f radix2 %.0f tags+scan %.0f rank/dist3 %.0f |", (double)h[8]/nseg,(double)h[9]/nseg,(double)h[10]/nseg,(double)h[11]/nseg,(double)h[12]/nseg,(double)h[13]/nseg); for (int q = 14; q < 14 + 3 * NLEVELS; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level: radix, hash fill, link+dist)\n"); hipMemset(W.dbg, 0, 256); }
 #endif
+    c->tmark("prev_links");
     if (nseg > 1) {
       const uint32_t nb = (uint32_t)((n_ins - 32768 + 255) / 256);
       hipLaunchKernelGGL(k_cross_links, dim3(nb), dim3(256), 0, st, W.in, n_ins, lv);
-      hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(256), 0, st, W.in, n_ins, cfg.chain, cfg.chain >> 2, lv, W.S3, W.T3, W.bsc3, W.PI);
+      hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(256), 0, st, W.in, n_ins, lv, W.S3, W.T3, W.bsc3, dpl);
+    }
+    hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, n_ins, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim);
+    {
     }
   }
-  c->tmark("prev_links");
+  c->tmark("cross_links");
   {
     uint32_t nb = (uint32_t)((n + MB - 1) / MB);
-    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], (const uint4 *)W.PI, W.MF, W.MQ, cfg.nice, (unsigned long long *)W.dbg);
+    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.MF, W.MQ, cfg.nice, (unsigned long long *)W.dbg);
   }
 #ifdef ZADA_MATCH_STATS
   {
