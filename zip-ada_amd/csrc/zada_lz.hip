@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   // comparison below is an LDS read.
   uint32_t *F = cnt;                               // 1024 words (+1 spill word)
   uint16_t *LW = (uint16_t *)(cnt + 1040);         // 1024 entries
-  uint8_t *sb = (uint8_t *)A;                      // 32768 + 16 bytes (after A is dead)
+  uint16_t *X = A;                                 // per-position staging of one output plane (after A is dead)
   auto build_flags = [&](const uint16_t *hv) {     // hv: hash of every position of this level
     for (uint32_t i0 = tid; i0 < m; i0 += 8192) {     // 8 gathers in flight per lane
       uint32_t hvv[8];
@@ -212,7 +212,11 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       LW[tid] = (uint16_t)(v > before ? v : before);
     }
     __syncthreads();
-    for (int i = tid; i < (32768 + 16) / 16; i += 1024) ((uint4 *)sb)[i] = ((const uint4 *)sin)[i];   // A := bytes
+  };
+  // plane[base + e] = X[e] for every position of the segment, coalesced 16-byte stores
+  auto flush_plane = [&](uint16_t *plane) {
+    __syncthreads();
+    for (uint32_t i = tid; i < (m + 7) / 8; i += 1024) ((uint4 *)(plane + base))[i] = ((const uint4 *)X)[i];
     __syncthreads();
   };
   auto bucket_start = [&](uint32_t i) -> uint32_t {
@@ -222,21 +226,16 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     const uint32_t pw = LW[wd - 1];
     return (pw << 5) + 31 - __clz((int)F[pw]);
   };
-  auto lb8 = [&](uint32_t e) -> uint64_t {         // eight bytes of the segment at e, from LDS
-    const uint32_t *wv = (const uint32_t *)(sb + (e & ~3u));
-    const uint32_t a0 = wv[0], a1 = wv[1], a2 = wv[2], sh = e & 3;
-    return (uint64_t)__builtin_amdgcn_alignbyte(a1, a0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(a2, a1, sh) << 32);
-  };
+  auto lb8 = [&](uint32_t e) -> uint64_t { return load8(sin, e); };
   build_flags(h3);
   for (uint32_t i = tid; i < m; i += 1024) {       // T3: tags for the cross-segment continuation (k_cross_dist)
-    const uint32_t e = B[i], b0 = sb[e], b1 = sb[e + 1];
+    const uint32_t e = B[i], b0 = sin[e], b1 = sin[e + 1];
     s3[i] = (uint16_t)e; t3[i] = (uint8_t)((b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6));
   }
   PL_STAMP();   // 12: flags
   for (uint32_t i = tid; i < m; i += 1024) {
     const uint32_t bs = bucket_start(i);
     const uint32_t e = B[i];
-    const uint64_t p = base + e;
     // nearest earlier position with the same three bytes (hash collisions are skipped)
     uint32_t d3 = (seg > 0) ? DIST3_CONTINUE : 0u;
     const uint32_t my24 = (uint32_t)lb8(e) & 0xFFFFFFu;
@@ -251,11 +250,11 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       break;
     }
 #endif
-    dp.d[0][p] = (uint16_t)d3;
+    X[e] = (uint16_t)d3;
     const bool last = (i + 1 == m) || ((F[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
     if (last) bsc[h3[e]] = bs | ((i - bs + 1) << 16);
   }
-  __syncthreads();
+  flush_plane(dp.d[0]);
   // ---- levels 4 .. 3+NLEVELS: order by the hash of the first L bytes.  Intermediate levels give the
   //      nearest position sharing L bytes (the best candidate of length exactly L); the last level's
   //      links are the chains the match kernel walks. ----
@@ -270,17 +269,20 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     build_flags(hl);
     PL_STAMP();
     const uint64_t lmask = (1ull << (8 * L)) - 1ull;
-    for (uint32_t i = tid; i < m; i += 1024) {
+    for (uint32_t i = tid; i < m; i += 1024) {                    // sweep 1: chain links
       const uint32_t e = B[i];
       const bool first = (F[i >> 5] >> (i & 31)) & 1u;
       uint16_t d = 0;
       if (!first) { const uint32_t e0 = B[i - 1]; if ((base + e0) != 0) d = (uint16_t)(e - e0); }   // NIL = position 0, lz77.adb:467
-      prevl[base + e] = d;
+      X[e] = d;
       const bool last = (i + 1 == m) || ((F[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
       if (last) tail[hl[e]] = (uint16_t)e;
-      if (l + 1 < NLEVELS) {
-        // nearest earlier position with the same L bytes, inside this segment (else: continue in k_cross_dist)
-        uint32_t dl = (seg > 0) ? DIST3_CONTINUE : 0u;
+    }
+    flush_plane(prevl);
+    if (l + 1 < NLEVELS) {
+      for (uint32_t i = tid; i < m; i += 1024) {                  // sweep 2: nearest earlier position with the same L bytes
+        const uint32_t e = B[i];
+        uint32_t dl = (seg > 0) ? DIST3_CONTINUE : 0u;            // not found inside this segment: continue in k_cross_dist
         const uint64_t mine = lb8(e) & lmask;
         for (uint32_t j = i; j > 0 && !((F[j >> 5] >> (j & 31)) & 1u); j--) {
           const uint32_t q = B[j - 1], dist = e - q;
@@ -289,8 +291,9 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           dl = dist;
           break;
         }
-        dp.d[1 + l][base + e] = (uint16_t)dl;
+        X[e] = (uint16_t)dl;
       }
+      flush_plane(dp.d[1 + l]);
     }
     __syncthreads();
     PL_STAMP();
