@@ -68,7 +68,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
 #define A(ptr, cnt) if (!rc) rc = dalloc(c, &W.ptr, (cnt))
   A(in, cap + IN_PAD + 64);
   for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); A(ltails[l], nseg32 * 65536); }
-  A(S3, nseg32 * 32768); A(HS, nseg32 * 32768 * (1 + NLEVELS)); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
+  A(S3, nseg32 * 32768); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
   for (int l = 0; l < NLEVELS; l++) A(dplane[l], cap + 64);
   A(dlim, cap + 64);
   A(MF, cap + 64);

@@ -69,7 +69,7 @@ struct Workspace {
   uint64_t cap_n = 0;           // input capacity in bytes
   uint8_t *in = nullptr;
   uint16_t *lprev[NLEVELS] = {}, *ltails[NLEVELS] = {};   // per level: chain links (16-bit distances) / per-segment bucket tails
-  uint16_t *S3 = nullptr, *HS = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
+  uint16_t *S3 = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
   uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr;  // DistPlanes
   uint32_t *MF = nullptr, *MQ = nullptr;     // alias: atoms / apos
   uint32_t *atoms = nullptr, *apos = nullptr;

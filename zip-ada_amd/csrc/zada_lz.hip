@@ -32,71 +32,6 @@ __device__ __forceinline__ uint32_t hash3(const uint8_t *__restrict__ in, uint64
   return (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ (uint32_t)in[p + 2]) & 0x7FFFu;
 }
 
-// One stable counting pass over `m` elements held by 16 waves (wave w owns [w*2048, w*2048+2048)).
-// digit(e) is given by the functor; `src` == nullptr means element i is position i.  The 32 digits of a
-// lane are fetched once, back to back (32 gathers in flight per lane: the pass is latency bound), and
-// kept packed in eight registers for both the histogram and the scatter phase.
-template <int NDIG, bool HAS_SRC, typename DigitFn>
-__device__ void radix_pass(const uint16_t *src, uint16_t *dst, uint32_t *cnt /*[16][NDIG]*/, uint32_t *wsum /*[16]*/, uint32_t m, DigitFn digit) {
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < NDIG * 16; i += 1024) cnt[i] = 0;
-  uint32_t dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int it = 0; it < 32; it++) {
-    const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
-    uint32_t d = 0;
-    if (i < m) { uint32_t e = i; if (HAS_SRC) e = src[i]; d = digit(e); }
-    dg[it >> 2] |= d << (8 * (it & 3));
-  }
-  __syncthreads();
-  // phase A: per (wave, digit) histogram
-#pragma unroll
-  for (int it = 0; it < 32; it++) {
-    const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
-    if (i < m) atomicAdd(&cnt[w * NDIG + ((dg[it >> 2] >> (8 * (it & 3))) & 0xFFu)], 1u);     // [wave][digit]: lanes spread over the banks
-  }
-  __syncthreads();
-  // phase B: exclusive scan over (digit major, wave minor)
-  {
-    constexpr int PER = NDIG * 16 / 1024;           // 4 (256 digits) or 2 (128 digits)
-    uint32_t v[PER], s = 0;
-    // scan order is (digit major, wave minor): entry idx = d * 16 + wv lives at cnt[wv * NDIG + d]
-    for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; v[k] = cnt[(idx & 15) * NDIG + (idx >> 4)]; s += v[k]; }
-    uint32_t incl = s;
-    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int k = 0; k < w; k++) base += wsum[k];
-    uint32_t run = base + incl - s;
-    for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; cnt[(idx & 15) * NDIG + (idx >> 4)] = run; run += v[k]; }
-  }
-  __syncthreads();
-  // phase C: stable scatter, 64 elements per wave step, ranks by ballot multi-split
-#pragma unroll
-  for (int it = 0; it < 32; it++) {
-    const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
-    const bool act = i < m;
-    const uint32_t d = (dg[it >> 2] >> (8 * (it & 3))) & 0xFFu;
-    unsigned long long mask = __ballot(act);
-    for (int b = 0; (1 << b) < NDIG; b++) {
-      unsigned long long bal = __ballot((d >> b) & 1);
-      mask &= ((d >> b) & 1) ? bal : ~bal;
-    }
-    if (act) {
-      uint32_t e = i;
-      if (HAS_SRC) e = src[i];
-      unsigned long long below = mask & ((1ull << lane) - 1ull);
-      uint32_t rank = __popcll(below), tot = __popcll(mask);
-      uint32_t base = cnt[w * NDIG + d];
-      dst[base + rank] = (uint16_t)e;
-      if (rank == tot - 1) cnt[w * NDIG + d] = base + tot;   // last lane of the group advances the cursor
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-}
-
 __device__ __forceinline__ uint32_t load24(const uint8_t *__restrict__ in, uint64_t p) {
   return (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16);
 }
@@ -121,24 +56,88 @@ __device__ __forceinline__ bool sameL(const uint8_t *__restrict__ in, uint64_t p
   return ((load8(in, p) ^ load8(in, q)) & mask) == 0;
 }
 
+// --------------------------------------------------------------------------------------------
+// Stable LSD radix sort of a segment's positions by a 16-bit key, entirely in LDS and registers.
+// 16 waves; in every pass wave w owns the elements [w*2048, w*2048+2048) of the pass's input order and
+// lane handles i = w*2048 + it*64 + lane (it = 0..31).  A lane keeps its 32 (element, key) pairs packed
+// in registers for the whole pass, so the scatter may overwrite the arrays the pass was loaded from.
+// --------------------------------------------------------------------------------------------
+template <int NDIG, int SHIFT, bool LINEAR>
+__device__ __forceinline__ void sort_pass(const uint32_t (&key)[16], const uint32_t (&el)[16], uint16_t *dstE, uint16_t *dstK,
+                                          uint32_t *cnt /*[16][NDIG]*/, uint32_t *wsum /*[16]*/, uint32_t i0, int rem) {
+  // i0 = w*2048 + lane: this lane's element `it` is i0 + 64*it, and it exists iff 64*it < rem
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < NDIG * 16; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  uint32_t *mycnt = cnt + w * NDIG;
+  // phase A: per (wave, digit) histogram
+#pragma unroll
+  for (int it = 0; it < 32; it++) {
+    const uint32_t d = ((key[it >> 1] >> (16 * (it & 1))) >> SHIFT) & (uint32_t)(NDIG - 1);
+    if (it * 64 < rem) atomicAdd(&mycnt[d], 1u);                 // [wave][digit]: lanes spread over the banks
+  }
+  __syncthreads();
+  // phase B: exclusive scan over (digit major, wave minor)
+  {
+    constexpr int PER = NDIG * 16 / 1024;           // 4 (256 digits) or 2 (128 digits)
+    uint32_t v[PER], s = 0;
+    for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; v[k] = cnt[(idx & 15) * NDIG + (idx >> 4)]; s += v[k]; }
+    uint32_t incl = s;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < w; k++) base += wsum[k];
+    uint32_t run = base + incl - s;
+    for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; cnt[(idx & 15) * NDIG + (idx >> 4)] = run; run += v[k]; }
+  }
+  __syncthreads();
+  // phase C: stable scatter, 64 elements per wave step, ranks by ballot multi-split
+  const unsigned long long ltmask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int it = 0; it < 32; it++) {
+    const bool act = it * 64 < rem;
+    const uint32_t k16 = (key[it >> 1] >> (16 * (it & 1))) & 0xFFFFu;
+    const uint32_t d = (k16 >> SHIFT) & (uint32_t)(NDIG - 1);
+    unsigned long long mask = __ballot(act);
+    for (int b = 0; (1 << b) < NDIG; b++) {
+      unsigned long long bal = __ballot((d >> b) & 1);
+      mask &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    if (act) {
+      const uint32_t e = LINEAR ? i0 + it * 64 : ((el[it >> 1] >> (16 * (it & 1))) & 0xFFFFu);
+      uint32_t rank = __popcll(mask & ltmask), tot = __popcll(mask);
+      uint32_t base = mycnt[d];
+      dstE[base + rank] = (uint16_t)e;
+      dstK[base + rank] = (uint16_t)k16;
+      if (rank == tot - 1) mycnt[d] = base + tot;   // last lane of the group advances the cursor
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+}
+
 // Per 32 KiB segment (grid = segments, block = 1024).  n_ins = number of inserted positions (n - 2).
 //
 // The reference walks, for position p, the chain of earlier positions with the same 15-bit hash
-// (nearest first, at most `chain` of them, within 32 505/32 506 bytes).  Two facts let the match
-// kernel visit far fewer candidates without changing its result:
-//   * the step limit is equivalent to a DISTANCE limit: "within the first k chain elements" <=>
-//     "not farther than the k-th same-hash predecessor" -> DD[p] = (distance of the 4096-th, of the
-//     1024-th predecessor), read off the sorted order by rank arithmetic;
-//   * a candidate can only beat a length-3 match if it shares FOUR bytes with p, so after the nearest
-//     true 3-byte match (dist3, RD[p]) only the positions of the same 4-byte hash chain matter.
-// Outputs: prev4 (16-bit distance to the previous position of the same hash4 bucket), tails4,
-// S3 / bstart3 / bcnt3 (sorted order and buckets of the 15-bit hash, for the next segment's
-// cross-segment resolution in k_cross_links), RD = rank | dist3 << 16, DD = Dfull | Dquarter << 16.
+// (nearest first, at most `chain` of them, within 32 505/32 506 bytes: lz77.adb:813-860).  The match kernel
+// visits far fewer candidates with the same result thanks to what this kernel prepares:
+//   * level 3: the nearest earlier position with the same THREE bytes (plane d[0]); the sorted order
+//     S3 / tags T3 / buckets bsc3 of the 15-bit hash (for the next segment's continuation in
+//     k_cross_dist and for the chain-length limits of k_bucket_limits);
+//   * levels 4 .. 3+NLEVELS (16-bit hashes of the first L bytes): the chain links of the level
+//     (16-bit distance to the previous position of the same bucket) and, for all but the last level,
+//     the nearest earlier position sharing L bytes (planes d[1..]).  A candidate can only beat a
+//     length-L match if it shares L+1 bytes, so the match kernel only walks the LAST level's chain.
+// Every level: sort the segment's positions by the level's hash (two counting passes, keys travelling
+// with the positions so that nothing is gathered from global memory), turn the sorted order into
+// position-indexed links P in LDS, then walk those links position-parallel against the segment's bytes
+// (also in LDS); every output plane is written with coalesced stores.
 constexpr uint32_t DIST3_CONTINUE = 0xFFFF;
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
-                                                     uint16_t *__restrict__ HS, DistPlanes dp, unsigned long long *__restrict__ dbg) {
+                                                     DistPlanes dp, unsigned long long *__restrict__ dbg) {
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
 #define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
@@ -161,139 +160,217 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tail)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
   }
   for (int i = tid; i < 32768 / 4; i += 1024) ((uint4 *)bsc)[i] = make_uint4(0, 0, 0, 0);
+  for (uint32_t e = tid; e < m; e += 1024) dp.dlim[base + e] = 0xFFFFFFFFu;   // no chain-length limit unless k_bucket_limits finds one
   const uint8_t *sin = in + base;
-  // both hashes of every position, computed once with coalesced reads; later phases gather 2 bytes
-  uint16_t *h3 = HS + seg * (32768ull * (1 + NLEVELS));
   PL_STAMP();   // 8: table init
-  for (uint32_t e = tid; e < m; e += 1024) {
-    const uint64_t v = load8(sin, e);
-    dp.dlim[base + e] = 0xFFFFFFFFu;                               // no chain-length limit unless k_bucket_limits finds one
-    h3[e] = (uint16_t)hash3_of(v);
-    for (int l = 0; l < NLEVELS; l++) h3[32768 * (l + 1) + e] = (uint16_t)hashL_of(v, 4 + l);
-  }
-  __syncthreads();
-  PL_STAMP();   // 9: hashes
-  // ---- 15-bit hash order: ranks, distance limits, nearest true 3-byte match ----
-  radix_pass<256, false>(nullptr, A, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] & 0xFFu; });
-  PL_STAMP();   // 10: radix 1
-  radix_pass<128, true>(A, B, cnt, wsum, m, [h3](uint32_t e) { return (uint32_t)h3[e] >> 8; });
-  PL_STAMP();   // 11: radix 2
-  // Bucket boundaries of the sorted order as a bitmask F (bit i: sorted element i starts a bucket) plus, per
-  // 32-element word, the index LW of the last non-empty word at or before it: rank and bucket start of any
-  // element in O(1).  Then the A half of LDS is recycled for the segment's bytes, so that every byte
-  // comparison below is an LDS read.
-  uint32_t *F = cnt;                               // 1024 words (+1 spill word)
-  uint16_t *LW = (uint16_t *)(cnt + 1040);         // 1024 entries
-  uint16_t *X = A;                                 // per-position staging of one output plane (after A is dead)
-  auto build_flags = [&](const uint16_t *hv) {     // hv: hash of every position of this level
-    for (uint32_t i0 = tid; i0 < m; i0 += 8192) {     // 8 gathers in flight per lane
-      uint32_t hvv[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) { const uint32_t i = i0 + 1024 * k; hvv[k] = i < m ? (uint32_t)hv[B[i]] : 0u; }
-#pragma unroll
-      for (int k = 0; k < 8; k++) { const uint32_t i = i0 + 1024 * k; if (i < m) A[i] = (uint16_t)hvv[k]; }
-    }
-    __syncthreads();
-    for (int it = 0; it < 32; it++) {
-      const uint32_t i = (uint32_t)w * 2048 + it * 64 + lane;
-      const bool first = i < m && (i == 0 || A[i - 1] != A[i]);
-      const unsigned long long mk = __ballot(first);
-      if (lane == 0) { F[(i >> 5)] = (uint32_t)mk; F[(i >> 5) + 1] = (uint32_t)(mk >> 32); }
-    }
-    __syncthreads();
+  uint32_t *F = cnt;                               // level 3: bucket-start bitmask of the sorted order, 1024 words (+1 spill word)
+  uint16_t *LW = (uint16_t *)(cnt + 1040);         // per word: last non-empty word at or before it
+  const uint8_t *sb = (const uint8_t *)A;          // the segment's bytes (after the keys in A are dead)
+  uint16_t *P = B;                                 // position-indexed links (after the sorted positions in B are dead)
+  auto lb8 = [&](uint32_t e) -> uint64_t {         // eight bytes of the segment at e, from LDS
+    const uint32_t *wp = (const uint32_t *)(sb + (e & ~3u));
+    const uint32_t a = wp[0], b = wp[1], c = wp[2], s = e & 3u;
+    return (uint64_t)__builtin_amdgcn_alignbyte(b, a, s) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, s) << 32);
+  };
+#pragma unroll 1
+  for (int lvl = 0; lvl <= NLEVELS; lvl++) {
+    const int L = 3 + lvl;
+    // this lane's element `it` of a sweep is i0 + 64*it and exists iff 64*it < rem.  i0 is made opaque so that
+    // the 32-fold unrolled sweeps below recompute their addresses (base + immediate offset) per level
+    // instead of having hundreds of loop-invariant values hoisted out of the level loop and spilled.
+    uint32_t i0 = (uint32_t)w * 2048 + lane;
+    asm volatile("" : "+v"(i0));
+    const int rem = (int)m - (int)i0;
+    // ---- sort: A := keys, B := positions, both in (key, position) order ----
     {
-      // LW[wd] = last word index <= wd whose F word is non-zero (word 0 always is: element 0 starts a bucket)
-      uint32_t v = F[tid] != 0 ? (uint32_t)tid : 0u;
-      for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if (lane >= off) v = v > t ? v : t; }
-      if (lane == 63) wsum[w] = v;
-      __syncthreads();
-      uint32_t before = 0;
-      for (int k = 0; k < w; k++) before = before > wsum[k] ? before : wsum[k];
-      LW[tid] = (uint16_t)(v > before ? v : before);
-    }
-    __syncthreads();
-  };
-  // plane[base + e] = X[e] for every position of the segment, coalesced 16-byte stores
-  auto flush_plane = [&](uint16_t *plane) {
-    __syncthreads();
-    for (uint32_t i = tid; i < (m + 7) / 8; i += 1024) ((uint4 *)(plane + base))[i] = ((const uint4 *)X)[i];
-    __syncthreads();
-  };
-  auto bucket_start = [&](uint32_t i) -> uint32_t {
-    const uint32_t wd = i >> 5;
-    const uint32_t own = F[wd] & (0xFFFFFFFFu >> (31 - (i & 31)));
-    if (own) return (wd << 5) + 31 - __clz((int)own);
-    const uint32_t pw = LW[wd - 1];
-    return (pw << 5) + 31 - __clz((int)F[pw]);
-  };
-  auto lb8 = [&](uint32_t e) -> uint64_t { return load8(sin, e); };
-  build_flags(h3);
-  for (uint32_t i = tid; i < m; i += 1024) {       // T3: tags for the cross-segment continuation (k_cross_dist)
-    const uint32_t e = B[i], b0 = sin[e], b1 = sin[e + 1];
-    s3[i] = (uint16_t)e; t3[i] = (uint8_t)((b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6));
-  }
-  PL_STAMP();   // 12: flags
-  for (uint32_t i = tid; i < m; i += 1024) {
-    const uint32_t bs = bucket_start(i);
-    const uint32_t e = B[i];
-    // nearest earlier position with the same three bytes (hash collisions are skipped)
-    uint32_t d3 = (seg > 0) ? DIST3_CONTINUE : 0u;
-    const uint32_t my24 = (uint32_t)lb8(e) & 0xFFFFFFu;
-#ifndef ZADA_EXP_NOWALK
-    for (uint32_t j = i; j > bs; j--) {
-      const uint32_t q = B[j - 1], dist = e - q;
-      // NIL = position 0 (lz77.adb:467); beyond MAX_DIST nothing qualifies, exactly MAX_DIST only as
-      // the head of the chain (:850 vs :820)
-      if (base + q == 0 || dist > (uint32_t)MAX_DIST || (dist == (uint32_t)MAX_DIST && j != i)) { d3 = 0; break; }
-      if (((uint32_t)lb8(q) & 0xFFFFFFu) != my24) continue;        // hash collision: not the same three bytes
-      d3 = dist;
-      break;
-    }
-#endif
-    X[e] = (uint16_t)d3;
-    const bool last = (i + 1 == m) || ((F[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
-    if (last) bsc[h3[e]] = bs | ((i - bs + 1) << 16);
-  }
-  flush_plane(dp.d[0]);
-  // ---- levels 4 .. 3+NLEVELS: order by the hash of the first L bytes.  Intermediate levels give the
-  //      nearest position sharing L bytes (the best candidate of length exactly L); the last level's
-  //      links are the chains the match kernel walks. ----
-  PL_STAMP();   // 13: rank/dist3 loop
-  for (int l = 0; l < NLEVELS; l++) {
-    const int L = 4 + l;
-    const uint16_t *hl = h3 + 32768 * (l + 1);
-    uint16_t *prevl = lv.prev[l], *tail = lv.tails[l] + seg * 65536ull;
-    radix_pass<256, false>(nullptr, A, cnt, wsum, m, [hl](uint32_t e) { return (uint32_t)hl[e] & 0xFFu; });
-    radix_pass<256, true>(A, B, cnt, wsum, m, [hl](uint32_t e) { return (uint32_t)hl[e] >> 8; });
-    PL_STAMP();
-    build_flags(hl);
-    PL_STAMP();
-    const uint64_t lmask = (1ull << (8 * L)) - 1ull;
-    for (uint32_t i = tid; i < m; i += 1024) {                    // sweep 1: chain links
-      const uint32_t e = B[i];
-      const bool first = (F[i >> 5] >> (i & 31)) & 1u;
-      uint16_t d = 0;
-      if (!first) { const uint32_t e0 = B[i - 1]; if ((base + e0) != 0) d = (uint16_t)(e - e0); }   // NIL = position 0, lz77.adb:467
-      X[e] = d;
-      const bool last = (i + 1 == m) || ((F[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
-      if (last) tail[hl[e]] = (uint16_t)e;
-    }
-    flush_plane(prevl);
-    if (l + 1 < NLEVELS) {
-      for (uint32_t i = tid; i < m; i += 1024) {                  // sweep 2: nearest earlier position with the same L bytes
-        const uint32_t e = B[i];
-        uint32_t dl = (seg > 0) ? DIST3_CONTINUE : 0u;            // not found inside this segment: continue in k_cross_dist
-        const uint64_t mine = lb8(e) & lmask;
-        for (uint32_t j = i; j > 0 && !((F[j >> 5] >> (j & 31)) & 1u); j--) {
-          const uint32_t q = B[j - 1], dist = e - q;
-          if (base + q == 0 || dist > (uint32_t)MAX_DIST) { dl = 0; break; }
-          if ((lb8(q) & lmask) != mine) continue;
-          dl = dist;
-          break;
+      uint32_t key[16], el[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) { key[k] = 0; el[k] = 0; }
+      {
+        const uint32_t *wp = (const uint32_t *)(sin + (i0 & ~3u));
+        const uint32_t sh = i0 & 3u;
+#pragma unroll
+        for (int it = 0; it < 32; it++) {
+          uint32_t k = 0;
+          if (it * 64 < rem) {
+            const uint32_t a = wp[it * 16], b = wp[it * 16 + 1], c = wp[it * 16 + 2];
+            const uint64_t v = (uint64_t)__builtin_amdgcn_alignbyte(b, a, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32);
+            k = (lvl == 0) ? hash3_of(v) : hashL_of(v, L);
+          }
+          key[it >> 1] |= k << (16 * (it & 1));
         }
-        X[e] = (uint16_t)dl;
       }
-      flush_plane(dp.d[1 + l]);
+      sort_pass<256, 0, true>(key, el, A, B, cnt, wsum, i0, rem);
+#pragma unroll
+      for (int k = 0; k < 16; k++) { key[k] = 0; el[k] = 0; }
+      {
+        const uint16_t *pa = A + i0, *pb = B + i0;
+#pragma unroll
+        for (int it = 0; it < 32; it++) {
+          uint32_t k = 0, e = 0;
+          if (it * 64 < rem) { e = pa[it * 64]; k = pb[it * 64]; }
+          key[it >> 1] |= k << (16 * (it & 1));
+          el[it >> 1] |= e << (16 * (it & 1));
+        }
+      }
+      if (lvl == 0) sort_pass<128, 8, false>(key, el, B, A, cnt, wsum, i0, rem);
+      else sort_pass<256, 8, false>(key, el, B, A, cnt, wsum, i0, rem);
+    }
+    PL_STAMP();
+    // ---- links: element | last-of-bucket << 15 | distance to the bucket's previous element << 16, in registers ----
+    uint16_t *tail = lvl > 0 ? lv.tails[lvl - 1] + seg * 65536ull : nullptr;
+    uint32_t ed[32];
+    {
+      const uint16_t *pa = A + i0, *pb = B + i0;
+      uint32_t *pf = F + (i0 >> 5);
+#pragma unroll
+      for (int it = 0; it < 32; it++) {
+        uint32_t x = 0;
+        bool first = false;
+        if (it * 64 < rem) {
+          const uint32_t e = pb[it * 64], k = pa[it * 64];
+          first = (i0 + it * 64 == 0) || (pa[it * 64 - 1] != k);
+          const bool last = (it * 64 + 1 == rem) || (pa[it * 64 + 1] != k);
+          uint32_t d = 0;
+          if (!first) { const uint32_t e0 = pb[it * 64 - 1]; if ((base + e0) != 0) d = e - e0; }     // NIL = position 0, lz77.adb:467
+          x = e | ((uint32_t)last << 15) | (d << 16);
+          if (lvl > 0 && last) tail[k] = (uint16_t)e;
+        }
+        ed[it] = x;
+        if (lvl == 0) {
+          const unsigned long long mk = __ballot(first);
+          if (lane == 0) { pf[it * 2] = (uint32_t)mk; pf[it * 2 + 1] = (uint32_t)(mk >> 32); }
+        }
+      }
+    }
+    if (lvl == 0) {
+      __syncthreads();
+      {
+        // LW[wd] = last word index <= wd whose F word is non-zero (word 0 always is: element 0 starts a bucket)
+        uint32_t v = F[tid] != 0 ? (uint32_t)tid : 0u;
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if (lane >= off) v = v > t ? v : t; }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int k = 0; k < w; k++) before = before > wsum[k] ? before : wsum[k];
+        LW[tid] = (uint16_t)(v > before ? v : before);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 32; it++) {
+        const uint32_t i = i0 + it * 64;
+        if ((ed[it] >> 15) & 1u) {
+          // start of i's bucket = highest set bit of F at or below i
+          const uint32_t wd = i >> 5;
+          const uint32_t own = F[wd] & (0xFFFFFFFFu >> (31 - (i & 31)));
+          uint32_t bs;
+          if (own) bs = (wd << 5) + 31 - __clz((int)own);
+          else { const uint32_t pw = LW[wd - 1]; bs = (pw << 5) + 31 - __clz((int)F[pw]); }
+          bsc[A[i]] = bs | ((i - bs + 1) << 16);
+        }
+      }
+    }
+    __syncthreads();                                 // keys (A) and sorted positions (B) are dead from here
+    for (uint32_t i = tid; i < (m + 16 + 15) / 16; i += 1024) ((uint4 *)A)[i] = ((const uint4 *)sin)[i];   // A := bytes
+#pragma unroll
+    for (int it = 0; it < 32; it++) {
+      if (it * 64 < rem) {
+        const uint32_t e = ed[it] & 0x7FFFu;
+        P[e] = (uint16_t)(ed[it] >> 16);
+        if (lvl == 0) s3[i0 + it * 64] = (uint16_t)e;
+      }
+    }
+    __syncthreads();
+    if (lvl == 0) {
+#pragma unroll
+      for (int it = 0; it < 32; it++) {              // T3: tags for the cross-segment continuation (k_cross_dist)
+        if (it * 64 < rem) {
+          const uint32_t e = ed[it] & 0x7FFFu, b0 = sb[e], b1 = sb[e + 1];
+          t3[i0 + it * 64] = (uint8_t)((b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6));
+        }
+      }
+    } else {
+      uint16_t *prevl = lv.prev[lvl - 1];
+      for (uint32_t i = tid; i < (m + 7) / 8; i += 1024) ((uint4 *)(prevl + base))[i] = ((const uint4 *)P)[i];
+    }
+    PL_STAMP();
+    // ---- nearest earlier position of the segment with the same L bytes: walk the links, newest first ----
+    // Most positions are settled by their first candidate; the few that have to walk through hash
+    // collisions are compacted into a queue and walked densely (all lanes busy) in rounds.
+    if (lvl < NLEVELS) {
+      const uint64_t lmask = (1ull << (8 * L)) - 1ull;
+      uint16_t *plane = dp.d[lvl] + base;
+      const uint32_t dflt = (seg > 0) ? DIST3_CONTINUE : 0u;        // not found inside this segment: continue in k_cross_dist
+      constexpr uint32_t QCAP = 4000;
+      uint32_t *Qa = (uint32_t *)(smem + 32800), *Qb = Qa + QCAP;   // behind the 32 784 staged bytes
+      uint32_t *qn = wsum;
+      const unsigned long long ltm = (1ull << lane) - 1ull;
+      if (tid < 2) qn[tid] = 0;
+      __syncthreads();
+      // up to `maxs` further candidates of position e, starting behind q; true = settled (dl valid)
+      auto walk = [&](uint32_t e, uint32_t &q, uint64_t mine, uint32_t maxs, uint32_t &dl) -> bool {
+        for (uint32_t sidx = 0; sidx < maxs; sidx++) {
+          const uint32_t step = P[q];
+          if (step == 0) { dl = dflt; return true; }
+          q -= step;
+          const uint32_t dist = e - q;
+          // beyond MAX_DIST nothing qualifies; the 15-bit chain accepts exactly MAX_DIST only at its head (:850 vs :820)
+          if (dist > (uint32_t)MAX_DIST || (lvl == 0 && dist == (uint32_t)MAX_DIST)) { dl = 0; return true; }
+          if ((lb8(q) & lmask) == mine) { dl = dist; return true; }
+        }
+        return false;
+      };
+      auto push = [&](bool pend, uint32_t entry, uint32_t *dstq, uint32_t *cntp) -> bool {   // false: queue full, not stored
+        const unsigned long long mk = __ballot(pend);
+        if (mk == 0) return true;
+        uint32_t b0 = 0;
+        const int leader = __ffsll((long long)mk) - 1;
+        if (lane == leader) b0 = atomicAdd(cntp, (uint32_t)__popcll(mk));
+        b0 = __shfl(b0, leader);
+        const uint32_t idx = b0 + __popcll(mk & ltm);
+        if (pend && idx < QCAP) { dstq[idx] = entry; return true; }
+        return !pend;
+      };
+      for (uint32_t e0 = 0; e0 < m; e0 += 1024) {                   // first candidate of every position
+        const uint32_t e = e0 + tid;
+        uint32_t dl = dflt, q = e;
+        bool pend = false;
+        uint64_t mine = 0;
+        if (e < m) {
+          mine = lb8(e) & lmask;
+          const uint32_t step = P[e];
+          if (step != 0) {
+            q = e - step;
+            if (step > (uint32_t)MAX_DIST) dl = 0;
+            else if ((lb8(q) & lmask) == mine) dl = step;
+            else pend = true;
+          }
+        }
+        if (!push(pend, e | (q << 16), Qa, &qn[0])) { walk(e, q, mine, 1u << 30, dl); pend = false; }
+        if (e < m && !pend) plane[e] = (uint16_t)dl;
+      }
+      __syncthreads();
+      for (int cur = 0;; cur ^= 1) {
+        const uint32_t nq = qn[cur] < QCAP ? qn[cur] : QCAP;
+        if (nq == 0) break;
+        __syncthreads();
+        if (tid == 0) qn[cur ^ 1] = 0;
+        __syncthreads();
+        const uint32_t maxs = nq <= 1024 ? (1u << 30) : 8u;
+        for (uint32_t i0q = 0; i0q < nq; i0q += 1024) {
+          const uint32_t idx = i0q + tid;
+          bool pend = false;
+          uint32_t e = 0, q = 0, dl = 0;
+          if (idx < nq) {
+            const uint32_t ent = (cur ? Qb : Qa)[idx];
+            e = ent & 0x7FFFu; q = ent >> 16;
+            pend = !walk(e, q, lb8(e) & lmask, maxs, dl);
+            if (!pend) plane[e] = (uint16_t)dl;
+          }
+          push(pend, e | (q << 16), cur ? Qa : Qb, &qn[cur ^ 1]);
+        }
+        __syncthreads();
+      }
     }
     __syncthreads();
     PL_STAMP();
@@ -789,9 +866,9 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   if (nseg > 0) {
     for (int l = 0; l < NLEVELS; l++) { lv.prev[l] = W.lprev[l]; lv.tails[l] = W.ltails[l]; }
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2, lv,
-                       W.S3, W.T3, W.bsc3, W.HS, dpl, (unsigned long long *)W.dbg);
+                       W.S3, W.T3, W.bsc3, dpl, (unsigned long long *)W.dbg);
 #ifdef ZADA_PL_STATS
-    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f hashes %.0f radix1 %.0f radix2 %.0f tags+scan %.0f rank/dist3 %.0f |", (double)h[8]/nseg,(double)h[9]/nseg,(double)h[10]/nseg,(double)h[11]/nseg,(double)h[12]/nseg,(double)h[13]/nseg); for (int q = 14; q < 14 + 3 * NLEVELS; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level: radix, hash fill, link+dist)\n"); hipMemset(W.dbg, 0, 256); }
+    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 3 * (NLEVELS + 1); q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, walk)\n"); hipMemset(W.dbg, 0, 256); }
 #endif
     c->tmark("prev_links");
     if (nseg > 1) {
