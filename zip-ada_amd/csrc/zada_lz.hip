@@ -309,14 +309,16 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       __syncthreads();
       // up to `maxs` further candidates of position e, starting behind q; true = settled (dl valid)
       auto walk = [&](uint32_t e, uint32_t &q, uint64_t mine, uint32_t maxs, uint32_t &dl) -> bool {
+        uint32_t step = P[q];
         for (uint32_t sidx = 0; sidx < maxs; sidx++) {
-          const uint32_t step = P[q];
           if (step == 0) { dl = dflt; return true; }
           q -= step;
           const uint32_t dist = e - q;
+          step = P[q];                                              // next link and this candidate's bytes in one LDS round trip
+          const uint64_t theirs = lb8(q);
           // beyond MAX_DIST nothing qualifies; the 15-bit chain accepts exactly MAX_DIST only at its head (:850 vs :820)
           if (dist > (uint32_t)MAX_DIST || (lvl == 0 && dist == (uint32_t)MAX_DIST)) { dl = 0; return true; }
-          if ((lb8(q) & lmask) == mine) { dl = dist; return true; }
+          if ((theirs & lmask) == mine) { dl = dist; return true; }
         }
         return false;
       };
@@ -350,6 +352,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         if (e < m && !pend) plane[e] = (uint16_t)dl;
       }
       __syncthreads();
+      PL_STAMP();
       for (int cur = 0;; cur ^= 1) {
         const uint32_t nq = qn[cur] < QCAP ? qn[cur] : QCAP;
         if (nq == 0) break;
@@ -377,17 +380,29 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   }
 }
 
-// Cross-segment links of every level: one thread per inserted position of the segments >= 1.
-__global__ void __launch_bounds__(256) k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, LevelPtrs lv) {
-  const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_ins) return;
-  const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
-  for (int l = 0; l < NLEVELS; l++) {
-    if (lv.prev[l][p] != 0) continue;
-    const uint32_t t = lv.tails[l][(seg - 1) * 65536ull + hashL(in, p, 4 + l)];
+// Cross-segment links: grid = (segments - 1, levels), block = 1024.  The workgroup of (segment s, level l) stages
+// the tails table of segment s-1 (65 536 x u16: last position of every bucket) in LDS and links every
+// position of segment s that has no predecessor inside its own segment to that tail.  Staging the table
+// makes the random look-ups LDS reads; as 2-byte global gathers they fetched a whole line each.
+__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, LevelPtrs lv) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint16_t *tl = (uint16_t *)smem;                                 // 128 KiB
+  const uint64_t seg = blockIdx.x + 1, base = seg * 32768ull, pbase = base - 32768ull;
+  const int l = blockIdx.y, tid = threadIdx.x;
+  const uint32_t m = (uint32_t)((n_ins - base) < 32768ull ? (n_ins - base) : 32768ull);
+  {
+    const uint4 *src = (const uint4 *)(lv.tails[l] + (seg - 1) * 65536ull);
+    for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tl)[i] = src[i];
+  }
+  __syncthreads();
+  uint16_t *prevl = lv.prev[l] + base;
+  const uint8_t *sin = in + base;
+  for (uint32_t e = tid; e < m; e += 1024) {
+    if (prevl[e] != 0) continue;
+    const uint32_t t = tl[hashL_of(load8(sin, e), 4 + l)];
     if (t == 0xFFFFu) continue;
-    const uint64_t q = pbase + t, d = p - q;
-    if (d <= (uint64_t)MAX_DIST && q != 0) lv.prev[l][p] = (uint16_t)d;
+    const uint64_t q = pbase + t, d = base + e - q;
+    if (d <= (uint64_t)MAX_DIST && q != 0) prevl[e] = (uint16_t)d;
   }
 }
 
@@ -856,6 +871,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
+    hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16 + MB / 4);
     attr_done = true;
   }
@@ -868,12 +884,12 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2, lv,
                        W.S3, W.T3, W.bsc3, dpl, (unsigned long long *)W.dbg);
 #ifdef ZADA_PL_STATS
-    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 3 * (NLEVELS + 1); q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, walk)\n"); hipMemset(W.dbg, 0, 256); }
+    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); hipMemset(W.dbg, 0, 256); }
 #endif
     c->tmark("prev_links");
     if (nseg > 1) {
       const uint32_t nb = (uint32_t)((n_ins - 32768 + 255) / 256);
-      hipLaunchKernelGGL(k_cross_links, dim3(nb), dim3(256), 0, st, W.in, n_ins, lv);
+      hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), 131072, st, W.in, n_ins, lv);
       hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(256), 0, st, W.in, n_ins, lv, W.S3, W.T3, W.bsc3, dpl);
     }
     hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, n_ins, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim);
