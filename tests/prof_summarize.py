@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of tests/prof_bench.sh <tag> (under gpurun_out/) into the small summaries
+committed under profiles/<round>/:  bench_1gib.json, bench_1gib_kernel_stats.csv, pmc_fetch_write_by_kernel.json.
+
+    python tests/prof_summarize.py <tag> <round>       e.g.  r1d r1
+"""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, rnd = sys.argv[1], sys.argv[2]
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(P, exist_ok=True)
+shutil.copy(os.path.join(G, tag + "_bench.json"), os.path.join(P, "bench_1gib.json"))
+shutil.copy(glob.glob(os.path.join(G, tag + "_stats", "*", "*_kernel_stats.csv"))[0], os.path.join(P, "bench_1gib_kernel_stats.csv"))
+out = {}
+for ctr, sub in (("FETCH_SIZE", "_fetch"), ("WRITE_SIZE", "_write")):
+    acc = {}
+    for f in glob.glob(os.path.join(G, tag + sub, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != ctr:
+                continue
+            name = r["Kernel_Name"].split("(")[0]
+            a = acc.setdefault(name, {"sum": 0.0, "dispatches": 0})
+            a["sum"] += float(r["Counter_Value"]); a["dispatches"] += 1
+    out[ctr] = acc
+out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline` "
+                "(1 GiB Deflate_3); values in KB summed over the dispatches of each kernel; FETCH_SIZE is to be doubled on gfx950 "
+                "(MI355X_MICROARCH.md, HBM section)")
+json.dump(out, open(os.path.join(P, "pmc_fetch_write_by_kernel.json"), "w"), indent=1)
+rows = list(csv.DictReader(open(os.path.join(P, "bench_1gib_kernel_stats.csv"))))
+for r in rows[:14]:
+    k = r["Name"].split("(")[0]
+    f = out["FETCH_SIZE"].get(k); w = out["WRITE_SIZE"].get(k)
+    print("%-32s calls %3s avg %9.3f ms %6s%%  fetch(x2) %7.2f GB  write %7.2f GB per launch" % (
+        k[:32], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"][:5],
+        2 * f["sum"] / f["dispatches"] * 1024 / 1e9 if f else -1, w["sum"] / w["dispatches"] * 1024 / 1e9 if w else -1))

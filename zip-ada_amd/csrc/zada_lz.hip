@@ -397,12 +397,22 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
   __syncthreads();
   uint16_t *prevl = lv.prev[l] + base;
   const uint8_t *sin = in + base;
-  for (uint32_t e = tid; e < m; e += 1024) {
-    if (prevl[e] != 0) continue;
-    const uint32_t t = tl[hashL_of(load8(sin, e), 4 + l)];
-    if (t == 0xFFFFu) continue;
-    const uint64_t q = pbase + t, d = base + e - q;
-    if (d <= (uint64_t)MAX_DIST && q != 0) prevl[e] = (uint16_t)d;
+  for (uint32_t e0 = tid; e0 < m; e0 += 8192) {                    // 8 positions per lane in flight: the loop is latency bound
+    uint32_t pv[8];
+    uint64_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t e = e0 + 1024 * k; pv[k] = e < m ? (uint32_t)prevl[e] : 1u; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t e = e0 + 1024 * k; v[k] = pv[k] == 0 ? load8(sin, e) : 0ull; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (pv[k] != 0) continue;
+      const uint32_t e = e0 + 1024 * k;
+      const uint32_t t = tl[hashL_of(v[k], 4 + l)];
+      if (t == 0xFFFFu) continue;
+      const uint64_t q = pbase + t, d = base + e - q;
+      if (d <= (uint64_t)MAX_DIST && q != 0) prevl[e] = (uint16_t)d;
+    }
   }
 }
 
@@ -416,6 +426,9 @@ __global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ 
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
   // level 3 first: the previous segment's bucket of the 15-bit hash, newest first
   uint32_t dprev = dp.d[0][p];
+#ifdef ZADA_EXP_XD_NO3
+  if (dprev == DIST3_CONTINUE) dprev = 0;
+#endif
   if (dprev == DIST3_CONTINUE) {
     const uint32_t b0 = in[p], b1 = in[p + 1];
     const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (uint32_t)in[p + 2]) & 0x7FFFu;
@@ -442,6 +455,9 @@ __global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ 
   // than the nearest L-1 byte match.
   for (int l = 0; l + 1 < NLEVELS; l++) {
     uint32_t dl = dp.d[1 + l][p];
+#ifdef ZADA_EXP_XD_NO45
+    if (dl == DIST3_CONTINUE) dl = 0;
+#endif
     if (dl == DIST3_CONTINUE) {
       dl = 0;
       if (dprev != 0) {
@@ -519,10 +535,14 @@ constexpr int HALO = 32512;                       // >= MAX_DIST, multiple of 16
 constexpr int WBYTES = HALO + MB + 272;           // 49168
 constexpr int WLINKS = HALO + MB;                 // 48896
 
-__device__ __forceinline__ uint32_t lds_u32_at(const uint32_t *w, uint32_t byteoff) {
-  uint32_t i = byteoff >> 2;
-  return __builtin_amdgcn_alignbyte(w[i + 1], w[i], byteoff & 3);
+// Eight window bytes at any byte offset from three aligned dwords.  (gfx950 also accepts misaligned
+// ds_read addresses, but measured 35 % slower in this kernel than aligned pieces + alignbyte.)
+__device__ __forceinline__ uint64_t lds_u64_at(const uint8_t *b, uint32_t o) {
+  const uint32_t *w = (const uint32_t *)(b + (o & ~3u));
+  const uint32_t x = w[0], y = w[1], z = w[2], s = o & 3u;
+  return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
 }
+#define LDS_U16(b, o) ((uint32_t)(b)[(o)] | ((uint32_t)(b)[(o) + 1] << 8))
 
 // Persistent-lane formulation: every lane owns one position at a time and runs a two-mode state
 // machine; a lane whose position is finished fetches the next one at once, so a wave never waits
@@ -633,7 +653,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           if (ok && !have_q && d0 > lim_q) { have_q = true; rq = ((uint32_t)best << 16) | bdist; lim_cur = lim_full; }
           cur = ok ? wi - d0 : wi;
           const uint32_t a = wi + (uint32_t)best;
-          s_end = (uint32_t)win8[a - 1] | ((uint32_t)win8[a] << 8);
+          s_end = LDS_U16(win8, a - 1);
           state = ok ? 1 : 0;
           if (!ok) {
             const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
@@ -656,7 +676,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 #endif
         const uint32_t dn = lnk[cur];                              // link to the next candidate
         const uint32_t a = cur + (uint32_t)best;
-        const uint32_t c16 = (uint32_t)win8[a - 1] | ((uint32_t)win8[a] << 8);
+        const uint32_t c16 = LDS_U16(win8, a - 1);
         const bool pass = c16 == s_end;                            // bytes best-1, best agree (:754-755)
         const uint32_t nc = cur - dn, nd = wi - nc;
         const bool end = dn == 0;                                  // chain exhausted
@@ -678,9 +698,9 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 #ifdef ZADA_MATCH_STATS
           iters++;
 #endif
-          const uint32_t x = lds_u32_at(win, cur + off) ^ lds_u32_at(win, wi + off);
-          if (x) { len = (int)off + (int)(__builtin_ctz(x) >> 3); cmpa = false; }
-          else { off += 4; if ((int)off >= la) { len = la; cmpa = false; } }
+          const uint64_t x = lds_u64_at(win8, cur + off) ^ lds_u64_at(win8, wi + off);
+          if (x) { len = (int)off + (int)(__builtin_ctzll(x) >> 3); cmpa = false; }
+          else { off += 8; if ((int)off >= la) { len = la; cmpa = false; } }
         }
       }
       if (state == 2) {
@@ -689,7 +709,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
         if (improved) {
           best = len; bdist = wi - cur;
           const uint32_t a = wi + (uint32_t)best;
-          s_end = (uint32_t)win8[a - 1] | ((uint32_t)win8[a] << 8);
+          s_end = LDS_U16(win8, a - 1);
         }
         bool fin = (improved && len >= nice) || ev_end;            // :815, :820
         const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
