@@ -25,6 +25,10 @@
 
 namespace zada {
 
+// global memory accepts any byte address: one load instead of aligned pieces
+typedef uint32_t __attribute__((aligned(1))) u32u;
+typedef uint64_t __attribute__((aligned(1))) u64u;
+
 // --------------------------------------------------------------------------------------------
 // k_prev_links
 // --------------------------------------------------------------------------------------------
@@ -430,22 +434,41 @@ __global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ 
   if (dprev == DIST3_CONTINUE) dprev = 0;
 #endif
   if (dprev == DIST3_CONTINUE) {
-    const uint32_t b0 = in[p], b1 = in[p + 1];
-    const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (uint32_t)in[p + 2]) & 0x7FFFu;
-    const uint32_t bsc = bsc3[pbase + h], own = bsc3[seg * 32768ull + h];
+    const uint32_t my24 = *(const u32u *)(in + p) & 0xFFFFFFu;
+    const uint32_t b0 = my24 & 0xFF, b1 = (my24 >> 8) & 0xFF;
+    const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (my24 >> 16)) & 0x7FFFu;
+    const uint32_t bsc = bsc3[pbase + h];
     const uint32_t pst = bsc & 0xFFFF, pct = bsc >> 16;
     const uint16_t *ps = S3 + pbase;
     const uint8_t *pt = T3 + pbase;
-    // p heads its own-segment bucket <=> it is the bucket's first element (the 32 506 rule, :850 vs :820)
-    const bool heads = S3[seg * 32768ull + (own & 0xFFFF)] == (uint16_t)(p & 32767);
+    // p heads its own-segment bucket <=> it is the bucket's first element (the 32 506 rule, :850 vs :820);
+    // only looked up in the rare case of a candidate at exactly MAX_DIST
+    auto heads = [&]() -> bool {
+      const uint32_t own = bsc3[seg * 32768ull + h];
+      return S3[seg * 32768ull + (own & 0xFFFF)] == (uint16_t)(p & 32767);
+    };
     const uint32_t mytag = (b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6);
-    const uint32_t my24 = load24(in, p);
     uint32_t d3 = 0;
-    for (uint32_t j = pct; j > 0; j--) {
-      const uint64_t q = pbase + ps[pst + j - 1], d = p - q;
-      // beyond MAX_DIST nothing qualifies; exactly MAX_DIST only as the head of the chain
-      if (q == 0 || d > (uint64_t)MAX_DIST || (d == (uint64_t)MAX_DIST && !(heads && j == pct))) break;
-      if (pt[pst + j - 1] == mytag && load24(in, q) == my24) { d3 = (uint32_t)d; break; }
+    // newest first, eight tags per load: only candidates whose tag agrees are looked at (their bytes decide)
+    const uint64_t tagx8 = 0x0101010101010101ull * mytag;
+    for (uint32_t hi = pct; hi > 0 && d3 == 0;) {
+      const uint32_t lo = hi >= 8 ? hi - 8 : 0;                      // candidates [lo, hi) of the bucket: byte i <-> candidate lo + i
+      const uint64_t x = *(const u64u *)(pt + pst + lo) ^ tagx8;
+      // zero-byte detection, exact per byte
+      uint64_t z = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x | 0x7F7F7F7F7F7F7F7Full);
+      if (hi - lo < 8) z &= ~(~0ull << (8 * (hi - lo)));              // bytes past candidate hi-1 belong to the next bucket
+      bool stop = false;
+      while (z) {
+        const int byte = 7 - (__builtin_clzll(z) >> 3);                // highest = newest
+        z &= ~(0xFFull << (8 * byte));
+        const uint32_t j = lo + (uint32_t)byte;                        // candidate index in the bucket
+        const uint64_t q = pbase + ps[pst + j], d = p - q;
+        // beyond MAX_DIST nothing qualifies; exactly MAX_DIST only as the head of the chain
+        if (q == 0 || d > (uint64_t)MAX_DIST || (d == (uint64_t)MAX_DIST && !(j + 1 == pct && heads()))) { stop = true; break; }
+        if ((*(const u32u *)(in + q) & 0xFFFFFFu) == my24) { d3 = (uint32_t)d; break; }
+      }
+      if (stop) break;
+      hi = lo;
     }
     dp.d[0][p] = (uint16_t)d3;
     dprev = d3;
@@ -462,13 +485,13 @@ __global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ 
       dl = 0;
       if (dprev != 0) {
         uint64_t q = p;
-        const uint64_t mine = load8(in, p), mask = (1ull << (8 * (4 + l))) - 1ull;
+        const uint64_t mine = *(const u64u *)(in + p), mask = (1ull << (8 * (4 + l))) - 1ull;
         for (;;) {
           const uint32_t d = lv.prev[l][q];
           if (d == 0) break;
           q -= d;
           if (p - q > (uint64_t)MAX_DIST) break;
-          if (p - q >= (uint64_t)dprev && ((load8(in, q) ^ mine) & mask) == 0) { dl = (uint32_t)(p - q); break; }
+          if (p - q >= (uint64_t)dprev && ((*(const u64u *)(in + q) ^ mine) & mask) == 0) { dl = (uint32_t)(p - q); break; }
         }
       }
       dp.d[1 + l][p] = (uint16_t)dl;
