@@ -64,7 +64,9 @@ uint64_t hc_chunked_tokens(const uint8_t *in, uint64_t n, int level, uint32_t ch
   LzConfig cfg = lz_config(level);
   std::vector<uint32_t> MF, MQ;
   match_tables(in, n, cfg, MF, MQ);
-  ParseIO io{in, n, MF.data(), MQ.data(), cfg};
+  std::vector<MatchPair> M(n);
+  for (uint64_t i = 0; i < n; i++) { M[i].full = MF[i]; M[i].quarter = MQ[i]; }
+  ParseIO io{in, n, M.data(), cfg};
   const uint32_t nch = (uint32_t)((n + chunk - 1) / chunk), stride = chunk + 1024;
   std::vector<uint32_t> spec((size_t)nch * stride), fix((size_t)nch * stride), scnt(nch), fcnt(nch), take(nch), u0(nch);
   std::vector<uint32_t> Fb(n / 32 + 2, 0xDEADBEEF), Lb(n / 32 + 2, 0xDEADBEEF);

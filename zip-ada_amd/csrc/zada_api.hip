@@ -71,8 +71,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(S3, nseg32 * 32768); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
   for (int l = 0; l < NLEVELS; l++) A(dplane[l], cap + 64);
   A(dlim, cap + 64);
-  A(MF, cap + 64);
-  A(MQ, cap + 64);
+  A(M, cap + 64);
   A(spec_tok, nch * PTOK_STRIDE);
   A(fix_tok, nch * PTOK_STRIDE);
   A(spec_cnt, nch); A(fix_cnt, nch); A(take_from, nch); A(start_pos, nch); A(counts, nch); A(offsets, nch);
@@ -101,7 +100,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(out, W.cap_out);
 #undef A
   if (rc) { free_workspace(c); return rc; }
-  W.atoms = W.MF; W.apos = W.MQ;     // the atom arrays reuse the match tables (dead after the parse)
+  W.atoms = (uint32_t *)W.M; W.apos = W.atoms + (cap + 64);     // the atom arrays reuse the match tables (dead after the parse)
   W.cap_n = cap;
   // the input pad must be zero for the match finder's over-reads
   hipMemsetAsync(W.in, 0, cap + IN_PAD + 64, c->stream);

@@ -71,7 +71,7 @@ struct Workspace {
   uint16_t *lprev[NLEVELS] = {}, *ltails[NLEVELS] = {};   // per level: chain links (16-bit distances) / per-segment bucket tails
   uint16_t *S3 = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
   uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr;  // DistPlanes
-  uint32_t *MF = nullptr, *MQ = nullptr;     // alias: atoms / apos
+  MatchPair *M = nullptr;                    // match tables; alias: atoms / apos (two halves of the same buffer)
   uint32_t *atoms = nullptr, *apos = nullptr;
   uint32_t *spec_tok = nullptr, *fix_tok = nullptr;
   uint32_t *spec_cnt = nullptr, *fix_cnt = nullptr, *take_from = nullptr, *start_pos = nullptr;

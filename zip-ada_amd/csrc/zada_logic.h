@@ -114,7 +114,10 @@ ZADA_HD uint32_t parse_step(ParseState &s, uint32_t mfq, bool searched, uint32_t
 
 
 // ----- chunked speculative parse + splice (run by one GPU lane per chunk) -----
-struct ParseIO { const uint8_t *in; uint64_t n; const uint32_t *MF; const uint32_t *MQ; LzConfig cfg; };
+// Longest_Match of one position over the full chain and its snapshot at the quarter-chain limit, (len << 16) | dist
+// each; kept together so that the parser's scattered look-ups touch one 8-byte record instead of two arrays.
+struct MatchPair { uint32_t full, quarter; };
+struct ParseIO { const uint8_t *in; uint64_t n; const MatchPair *M; LzConfig cfg; };
 struct ExitState { uint32_t pos, kind; };
 
 // Writes the bits of one chunk's words [first, last] exactly once (zeros where nothing is set).
@@ -145,7 +148,7 @@ ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_
     const uint64_t la = io.n - s.p;
     const bool srch = parse_searches(s, io.cfg, la);
     uint32_t m = 0;
-    if (srch) m = parse_need_quarter(s, io.cfg) ? io.MQ[s.p] : io.MF[s.p];
+    if (srch) { const MatchPair mm = io.M[s.p]; m = parse_need_quarter(s, io.cfg) ? mm.quarter : mm.full; }
     const uint32_t bb = s.avail ? io.in[s.p - 1] : 0;
     const uint32_t t = parse_step(s, m, srch, bb);
     if (t != 0xFFFFFFFFu) tok[ntok++] = t;

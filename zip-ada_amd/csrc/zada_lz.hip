@@ -575,7 +575,7 @@ __device__ __forceinline__ uint64_t lds_u64_at(const uint8_t *b, uint32_t o) {
 __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, uint64_t n,
                                                 const uint16_t *__restrict__ prevd,
                                                 DistPlanes dp,
-                                                uint32_t *__restrict__ MF, uint32_t *__restrict__ MQ,
+                                                MatchPair *__restrict__ M,
                                                 int nice_cfg, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // WBYTES bytes
@@ -681,7 +681,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           if (!ok) {
             const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
             // quarter-chain result: the best level whose candidate lies within the quarter limit
-            MF[B + k] = packed; MQ[B + k] = (have_q || !chain_ok) ? qbest : packed;
+            MatchPair r; r.full = packed; r.quarter = (have_q || !chain_ok) ? qbest : packed;
+            M[B + k] = r;
           }
         }
       }
@@ -741,8 +742,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           if (wi - ncur > lim_full) fin = true;                    // :819-822
         }
         if (fin) {
-          MF[B + kpos] = packed;
-          MQ[B + kpos] = have_q ? rq : packed;
+          MatchPair r; r.full = packed; r.quarter = have_q ? rq : packed;
+          M[B + kpos] = r;
           state = 0;
         } else {
           cur = ncur;
@@ -942,7 +943,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   c->tmark("cross_links");
   {
     uint32_t nb = (uint32_t)((n + MB - 1) / MB);
-    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.MF, W.MQ, cfg.nice, (unsigned long long *)W.dbg);
+    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice, (unsigned long long *)W.dbg);
   }
 #ifdef ZADA_MATCH_STATS
   {
@@ -955,7 +956,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
 #endif
   c->tmark("match");
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
-  ParseIO io; io.in = W.in; io.n = n; io.MF = W.MF; io.MQ = W.MQ; io.cfg = cfg;
+  ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg;
   hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
                      W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits);
   // fixpoint of the splice: round 0 handles every chunk with the speculative exits as entries
