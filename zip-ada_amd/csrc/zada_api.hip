@@ -72,6 +72,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   for (int l = 0; l < NLEVELS; l++) A(dplane[l], cap + 64);
   A(dlim, cap + 64);
   A(M, cap + 64);
+  A(SK, nseg32 * 32768); A(idxK, cap + 64); A(cntK, cap + 64);
   A(spec_tok, nch * PTOK_STRIDE);
   A(fix_tok, nch * PTOK_STRIDE);
   A(spec_cnt, nch); A(fix_cnt, nch); A(take_from, nch); A(start_pos, nch); A(counts, nch); A(offsets, nch);
@@ -80,6 +81,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(spec_exits, nch); A(true_exits, nch);
   A(dirty[0], nch + 64); A(dirty[1], nch + 64);
   A(n_changed, 16);
+  A(blk_demand, cap / 16384 + 64); A(n_demand, 16); A(chg, nch + 64);
   A(descr, nflush * SLOTS * 320);
   A(seg_nblk, nflush); A(seg_cut, nflush * MAXBLK_PER_SEG); A(seg_blk_off, nflush);
   W.cap_blocks = nflush * MAXBLK_PER_SEG;
@@ -95,7 +97,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(chooser, 1);
   A(crc_lvl[0], cap / CRC_SUB + 64); A(crc_lvl[1], cap / CRC_SUB / 16 + 64); A(crc_lvl[2], cap / CRC_SUB / 256 + 64); A(crc_lvl[3], cap / CRC_SUB / 4096 + 64);
   A(crc_mat, 128);
-  A(dbg, 64);
+  A(dbg, 128);
   W.cap_out = cap + cap / 1024 + 4096;
   A(out, W.cap_out);
 #undef A
@@ -104,7 +106,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   W.cap_n = cap;
   // the input pad must be zero for the match finder's over-reads
   hipMemsetAsync(W.in, 0, cap + IN_PAD + 64, c->stream);
-  hipMemsetAsync(W.dbg, 0, 64 * 8, c->stream);
+  hipMemsetAsync(W.dbg, 0, 128 * 8, c->stream);
   return hip_check(c, hipStreamSynchronize(c->stream), "workspace init");
 }
 

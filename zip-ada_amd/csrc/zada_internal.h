@@ -14,7 +14,10 @@ namespace zada {
 constexpr int ZADA_E_HIP_ = -3;
 
 // ---- LZ stage geometry ----
-constexpr uint32_t PCHUNK = 1024;                 // bytes parsed per lane (speculative chunk)
+#ifndef ZADA_PCHUNK
+#define ZADA_PCHUNK 1024
+#endif
+constexpr uint32_t PCHUNK = ZADA_PCHUNK;                 // bytes parsed per lane (speculative chunk)
 constexpr uint32_t PTOK_STRIDE = PCHUNK + 640;    // token slots per chunk (a parse may overrun its chunk by < 600 B)
 constexpr uint32_t CRC_CHUNK = 4096, CRC_SUB = 256;   // CRC: one lane per 256 B, folded to one value per 4 KiB on the device
 constexpr uint64_t IN_PAD = 1024;                 // zero bytes kept after the input
@@ -22,6 +25,9 @@ constexpr uint64_t IN_PAD = 1024;                 // zero bytes kept after the i
 constexpr int NLEVELS = ZADA_NLEVELS;               // hash levels 4 .. 3+NLEVELS; the last one is the chain the match kernel walks
 struct LevelPtrs { uint16_t *prev[NLEVELS]; uint16_t *tails[NLEVELS]; };
 // per-position planes: d[l] = distance of the nearest position sharing 3 + l bytes (0 = none); dlim = Dfull | Dquarter << 16
+// Last level of the nested chains: sorted order of every segment, and per position its index in it and the number
+// of members of its bucket before it (inside the segment).
+struct RunPtrs { uint16_t *S, *idx, *cnt; };
 struct DistPlanes { uint16_t *d[NLEVELS]; uint32_t *dlim; };
 
 // ---- entropy stage geometry (zip-compress-deflate.adb:942, 1294, 1313) ----
@@ -71,6 +77,7 @@ struct Workspace {
   uint16_t *lprev[NLEVELS] = {}, *ltails[NLEVELS] = {};   // per level: chain links (16-bit distances) / per-segment bucket tails
   uint16_t *S3 = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
   uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr;  // DistPlanes
+  uint16_t *SK = nullptr, *idxK = nullptr, *cntK = nullptr;   // RunPtrs
   MatchPair *M = nullptr;                    // match tables; alias: atoms / apos (two halves of the same buffer)
   uint32_t *atoms = nullptr, *apos = nullptr;
   uint32_t *spec_tok = nullptr, *fix_tok = nullptr;
@@ -80,6 +87,8 @@ struct Workspace {
   ExitState *spec_exits = nullptr, *true_exits = nullptr;
   uint8_t *dirty[2] = {nullptr, nullptr};
   uint32_t *n_changed = nullptr;
+  uint32_t *blk_demand = nullptr, *n_demand = nullptr;   // demanded match records per k_match block / in total
+  uint8_t *chg = nullptr;                                // per parse chunk: a guess it used turned out different
   // entropy stage
   uint8_t *descr = nullptr;                  // [nseg][SLOTS][320]
   uint32_t *seg_nblk = nullptr, *seg_cut = nullptr, *seg_blk_off = nullptr;   // cuts [nseg][MAXBLK_PER_SEG]

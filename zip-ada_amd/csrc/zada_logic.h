@@ -117,6 +117,12 @@ ZADA_HD uint32_t parse_step(ParseState &s, uint32_t mfq, bool searched, uint32_t
 // Longest_Match of one position over the full chain and its snapshot at the quarter-chain limit, (len << 16) | dist
 // each; kept together so that the parser's scattered look-ups touch one 8-byte record instead of two arrays.
 struct MatchPair { uint32_t full, quarter; };
+// Flags in MatchPair::full (the value uses bits 0..24).  The match kernel first gives every position a bounded
+// number of chain steps; a search cut short leaves its best-so-far as a GUESS.  A parse that lands on a guess uses
+// it and marks it DEMANDed; demanded positions are then searched to the end, the parses that used a value which
+// changed are redone, and so on until a parse has used exact values only (zada_lz.hip, lz_stage).
+constexpr uint32_t M_GUESS = 0x80000000u, M_DEMAND = 0x40000000u, M_VALUE = 0x01FFFFFFu;
+struct NoGuess { ZADA_HD void operator()(uint32_t, uint32_t) const {} };
 struct ParseIO { const uint8_t *in; uint64_t n; const MatchPair *M; LzConfig cfg; };
 struct ExitState { uint32_t pos, kind; };
 
@@ -137,8 +143,8 @@ struct BitmapWriter {
 
 // Runs the reference parser (lz77.adb:838-932) from state `s` until on_top(s) returns true at the
 // top of the loop, or the input ends (then the trailing literal :930-932 is emitted).
-template <typename OnTop>
-ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_t &ntok, OnTop &&on_top) {
+template <typename OnTop, typename OnGuess>
+ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_t &ntok, OnTop &&on_top, OnGuess &&on_guess) {
   for (;;) {
     if ((uint64_t)s.p >= io.n) {
       if (s.avail) { tok[ntok++] = io.in[io.n - 1]; s.avail = 0; s.mlen = 2; }
@@ -148,7 +154,11 @@ ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_
     const uint64_t la = io.n - s.p;
     const bool srch = parse_searches(s, io.cfg, la);
     uint32_t m = 0;
-    if (srch) { const MatchPair mm = io.M[s.p]; m = parse_need_quarter(s, io.cfg) ? mm.quarter : mm.full; }
+    if (srch) {
+      const MatchPair mm = io.M[s.p];
+      if (mm.full & M_GUESS) on_guess(s.p, mm.full);
+      m = (parse_need_quarter(s, io.cfg) ? mm.quarter : mm.full) & M_VALUE;
+    }
     const uint32_t bb = s.avail ? io.in[s.p - 1] : 0;
     const uint32_t t = parse_step(s, m, srch, bb);
     if (t != 0xFFFFFFFFu) tok[ntok++] = t;
@@ -158,8 +168,9 @@ ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_
 // Speculative parse of chunk k, started in the fresh state at its first byte.  Records every
 // history-free state inside the chunk (F / L bitmaps) and stops at the first one at or beyond the
 // chunk's end (the chunk's exit); exit = (n, F) when the input ends first.
+template <typename OnGuess = NoGuess>
 ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uint32_t *tok, uint32_t &ntok,
-                              uint32_t *Fbits, uint32_t *Lbits, ExitState &ex) {
+                              uint32_t *Fbits, uint32_t *Lbits, ExitState &ex, OnGuess on_guess = OnGuess()) {
   const uint64_t c0 = (uint64_t)k * chunk, c1 = (c0 + chunk < io.n) ? c0 + chunk : io.n;
   ParseState s{(uint32_t)c0, 0, 2, 0};
   BitmapWriter fw, lw;
@@ -171,7 +182,7 @@ ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uin
     if ((uint64_t)st.p >= c1) { e.pos = st.p; e.kind = (uint32_t)kind; return true; }
     if (kind == SYNC_F) fw.set(st.p); else lw.set(st.p);
     return false;
-  });
+  }, on_guess);
   fw.finish((c1 - 1) >> 5);
   lw.finish((c1 - 1) >> 5);
   ex = e;
@@ -180,9 +191,11 @@ ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uin
 // True parse of chunk k from the true exit of chunk k-1 (`entry`) until it reaches a history-free
 // state that the speculative parse of chunk k also went through (then the rest of the speculative
 // tokens, from index `take`, are the true ones), or leaves the chunk unsynchronised.
+template <typename OnGuess = NoGuess>
 ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, ExitState entry,
                              const uint32_t *spec_tok, uint32_t spec_cnt, const uint32_t *Fbits, const uint32_t *Lbits,
-                             ExitState spec_exit, uint32_t *tok, uint32_t &ntok, uint32_t &take, uint32_t &u0, ExitState &new_exit) {
+                             ExitState spec_exit, uint32_t *tok, uint32_t &ntok, uint32_t &take, uint32_t &u0, ExitState &new_exit,
+                             OnGuess on_guess = OnGuess()) {
   const uint64_t c0 = (uint64_t)k * chunk, c1 = (c0 + chunk < io.n) ? c0 + chunk : io.n;
   u0 = entry.kind == SYNC_L ? entry.pos - 1 : entry.pos;      // first byte not yet emitted at entry
   ntok = 0;
@@ -202,7 +215,7 @@ ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, Exit
     uint32_t wbits = (kind == SYNC_F ? Fbits : Lbits)[st.p >> 5];
     if ((wbits >> (st.p & 31)) & 1) { synced = true; e.pos = st.p; e.kind = (uint32_t)kind; return true; }
     return false;
-  });
+  }, on_guess);
   if (synced) {
     const uint32_t u = e.kind == SYNC_L ? e.pos - 1 : e.pos;
     uint32_t cur = (uint32_t)c0, j = 0;

@@ -22,6 +22,8 @@
 #include "zada_logic.h"
 #include "zada_internal.h"
 #include <stdio.h>
+#include <stdlib.h>
+#include <unistd.h>
 
 namespace zada {
 
@@ -141,7 +143,7 @@ constexpr uint32_t DIST3_CONTINUE = 0xFFFF;
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
-                                                     DistPlanes dp, unsigned long long *__restrict__ dbg) {
+                                                     DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg) {
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
 #define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
@@ -223,6 +225,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     PL_STAMP();
     // ---- links: element | last-of-bucket << 15 | distance to the bucket's previous element << 16, in registers ----
     uint16_t *tail = lvl > 0 ? lv.tails[lvl - 1] + seg * 65536ull : nullptr;
+    const bool want_runs = lvl == 0 || lvl == NLEVELS;   // bucket boundaries of the sorted order are needed
     uint32_t ed[32];
     {
       const uint16_t *pa = A + i0, *pb = B + i0;
@@ -241,13 +244,13 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           if (lvl > 0 && last) tail[k] = (uint16_t)e;
         }
         ed[it] = x;
-        if (lvl == 0) {
+        if (want_runs) {
           const unsigned long long mk = __ballot(first);
           if (lane == 0) { pf[it * 2] = (uint32_t)mk; pf[it * 2 + 1] = (uint32_t)(mk >> 32); }
         }
       }
     }
-    if (lvl == 0) {
+    if (want_runs) {
       __syncthreads();
       {
         // LW[wd] = last word index <= wd whose F word is non-zero (word 0 always is: element 0 starts a bucket)
@@ -260,17 +263,39 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         LW[tid] = (uint16_t)(v > before ? v : before);
       }
       __syncthreads();
+      // start of i's bucket = highest set bit of F at or below i
+      auto bucket_start = [&](uint32_t i) -> uint32_t {
+        const uint32_t wd = i >> 5;
+        const uint32_t own = F[wd] & (0xFFFFFFFFu >> (31 - (i & 31)));
+        if (own) return (wd << 5) + 31 - __clz((int)own);
+        const uint32_t pw = LW[wd - 1];
+        return (pw << 5) + 31 - __clz((int)F[pw]);
+      };
+      if (lvl == 0) {
 #pragma unroll
-      for (int it = 0; it < 32; it++) {
-        const uint32_t i = i0 + it * 64;
-        if ((ed[it] >> 15) & 1u) {
-          // start of i's bucket = highest set bit of F at or below i
-          const uint32_t wd = i >> 5;
-          const uint32_t own = F[wd] & (0xFFFFFFFFu >> (31 - (i & 31)));
-          uint32_t bs;
-          if (own) bs = (wd << 5) + 31 - __clz((int)own);
-          else { const uint32_t pw = LW[wd - 1]; bs = (pw << 5) + 31 - __clz((int)F[pw]); }
-          bsc[A[i]] = bs | ((i - bs + 1) << 16);
+        for (int it = 0; it < 32; it++) {
+          const uint32_t i = i0 + it * 64;
+          if ((ed[it] >> 15) & 1u) { const uint32_t bs = bucket_start(i); bsc[A[i]] = bs | ((i - bs + 1) << 16); }
+        }
+      } else {
+        // last level: the bucket of a position is a contiguous run of the sorted order, which the demand pass
+        // of the match kernel scans instead of chasing links.  Written out: the sorted order S, and per
+        // position its index in S and the number of bucket members before it (planes, staged in A / B).
+        __syncthreads();                             // keys (A) and sorted positions (B) are dead from here
+        uint16_t *sK = rp.S + seg * 32768ull;
+#pragma unroll
+        for (int it = 0; it < 32; it++) {
+          if (it * 64 < rem) {
+            const uint32_t i = i0 + it * 64, e = ed[it] & 0x7FFFu;
+            sK[i] = (uint16_t)e;
+            A[e] = (uint16_t)i;
+            B[e] = (uint16_t)(i - bucket_start(i));
+          }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < (m + 7) / 8; i += 1024) {
+          ((uint4 *)(rp.idx + base))[i] = ((const uint4 *)A)[i];
+          ((uint4 *)(rp.cnt + base))[i] = ((const uint4 *)B)[i];
         }
       }
     }
@@ -576,7 +601,11 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
                                                 const uint16_t *__restrict__ prevd,
                                                 DistPlanes dp,
                                                 MatchPair *__restrict__ M,
-                                                int nice_cfg, unsigned long long *__restrict__ dbg) {
+                                                int nice_cfg, int budget, uint32_t *__restrict__ blk_demand,
+                                                uint8_t *__restrict__ chg, unsigned long long *__restrict__ dbg) {
+  // Every position of the block is searched for at most `budget` rounds of ZADA_FAST chain steps; a search cut
+  // short leaves its best so far as a guess (M_GUESS) that k_match_demand replaces if a parse ever lands on it.
+  constexpr bool demand_pass = false;              // the demand pass is k_match_demand
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // WBYTES bytes
   uint16_t *lnk = (uint16_t *)(smem + WBYTES);                    // WLINKS * 2 bytes
@@ -606,12 +635,13 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   // Longest-chains-first scheduling: estimate every position's chain length from the span of its
   // first 8 links and give it a class (2 = long, 1 = medium, 0 = short).  Classes are drained in
   // descending order so that the 4096-step walks start first and do not form the block's tail.
-  {
+  if (demand_pass) {
     uint32_t word = 0;
     for (int j = 0; j < 16; j++) {
       const uint32_t k = (uint32_t)tid * 16 + j;
       uint32_t c = 0;
-      if (k < cnt) {
+      if (k < cnt && (M[B + k].full & (M_GUESS | M_DEMAND)) != (M_GUESS | M_DEMAND)) c = 3;   // nothing to do
+      else if (k < cnt) {
         uint32_t q = woff + k, span = 0; int hops = 0;
         for (; hops < 8; hops++) { const uint32_t d = lnk[q]; if (d == 0 || span + d > 32505u) break; span += d; q -= d; }
         c = hops < 8 ? 0u : (span <= 512u ? 2u : (span <= 4096u ? 1u : 0u));
@@ -619,16 +649,19 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
       word |= c << (2 * j);
     }
     cls[tid] = word;
-  }
+  } else cls[tid] = 0;                                             // first pass: bounded searches, any order
   __syncthreads();
+  if (demand_pass && tid == 0) blk_demand[blockIdx.x] = 0;
   const uint8_t *win8 = (const uint8_t *)win;
   // Per-lane walker: state 0 = FREE (needs a position), 1 = WALK (fast filter steps), 2 = EVENT
   // (its current candidate passed the two-byte filter and/or its chain ended / hit a limit).
   // FAST PHASE: ZADA_FAST filter steps with no side paths; SLOW PHASE: everything rare, once per round.
   uint32_t wi = woff, cur = woff, ncur = woff, bdist = 0, rq = 0, kpos = 0, s_end = 0;
-  int best = 2, la = 3, nice = 3, state = 0, pass_cls = 2;
+  int best = 2, la = 3, nice = 3, state = 0, pass_cls = demand_pass ? 2 : 0;
   uint32_t lim_cur = 0, lim_full = 0;
   bool have_q = false, ev_pass = false, ev_end = false, ev_lim = false, exhausted = false;
+  int age = 0;                                                     // rounds spent on the current position
+  uint32_t old_full = 0, old_quarter = 0;                          // demand pass: the guess being replaced
   for (;;) {
     // ---- fetch ----
     const bool need = (state == 0) && !exhausted;
@@ -645,7 +678,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 #endif
         if (k >= cnt) exhausted = true;
         else {
-          kpos = k; wi = woff + k;
+          kpos = k; wi = woff + k; age = 0;
+          if (demand_pass) { const MatchPair og = M[B + k]; old_full = og.full & M_VALUE; old_quarter = og.quarter; }
           const uint64_t rem = n - (B + k);
           la = rem < 258 ? (int)rem : 258;                         // Longest_Match never returns more
           nice = nice_cfg < la ? nice_cfg : la;                    // lz77.adb:858-860
@@ -744,12 +778,23 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
         if (fin) {
           MatchPair r; r.full = packed; r.quarter = have_q ? rq : packed;
           M[B + kpos] = r;
+          if (demand_pass && (r.full != old_full || r.quarter != old_quarter)) {
+            const uint64_t ch = (B + kpos) / PCHUNK;
+            chg[ch] = 1; if (ch > 0) chg[ch - 1] = 1;
+          }
           state = 0;
         } else {
           cur = ncur;
           state = 1;
         }
       }
+    }
+    // first pass: a search that has had its share of rounds is cut short, its best so far becomes a guess
+    if (!demand_pass && state == 1 && ++age >= budget) {
+      const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
+      MatchPair r; r.full = packed | M_GUESS; r.quarter = have_q ? rq : packed;
+      M[B + kpos] = r;
+      state = 0;
     }
   }
 #ifdef ZADA_MATCH_STATS
@@ -765,16 +810,232 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 }
 
 // --------------------------------------------------------------------------------------------
+// Demand pass: the exact Longest_Match of the positions a parse has landed on while they only held a guess.
+// These are few and their chains are the longest, so a lane-per-position walk would leave the machine idle
+// behind a handful of 4096-step pointer chases.  Instead one WAVE takes a position and scans its candidates 64 at a
+// time: the members of a bucket of the last level are a contiguous run of the segment's sorted order (RunPtrs),
+// nearest first when read backwards, in the position's own segment and then in the previous one - no links.
+// The sequential rule "a candidate replaces the best only if strictly longer, stop at nice_match" (:812-817)
+// becomes, per batch of 64: the maximum length, at its nearest occurrence, or the nearest one reaching
+// nice_match.  The quarter-chain snapshot (:733-735) is taken when the batch crosses the quarter distance.
+// --------------------------------------------------------------------------------------------
+// value of lane j (j wave uniform) of a vector register, as a scalar
+#define RL(v, j) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (j)))
+#define RL64(v, j) ((uint64_t)RL((uint32_t)(v), (j)) | ((uint64_t)RL((uint32_t)((v) >> 32), (j)) << 32))
+#ifndef ZADA_DM_DEPTH
+#define ZADA_DM_DEPTH 1
+#endif
+#ifndef ZADA_DM_GROUP
+#define ZADA_DM_GROUP 2
+#endif
+constexpr int DM_THREADS = 512, DMB = 4096, DM_SUB = 1024, DM_GROUP = ZADA_DM_GROUP, DM_DEPTH = ZADA_DM_DEPTH;
+constexpr int DM_WBYTES = HALO + DMB + 272;
+constexpr int DM_LDS = DM_WBYTES + DM_SUB * 2 + 64;
+static_assert(MB % DMB == 0 && DM_WBYTES % 16 == 0, "demand blocks tile the first-pass blocks");
+__global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__restrict__ in, uint64_t n, DistPlanes dp, RunPtrs rp,
+                                                             const uint16_t *__restrict__ tailsK, MatchPair *__restrict__ M, int nice_cfg,
+                                                             const uint32_t *__restrict__ blk_demand, uint8_t *__restrict__ chg) {
+  const uint64_t B = (uint64_t)blockIdx.x * DMB;
+  if (blk_demand[B / MB] == 0) return;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t *win = (uint32_t *)smem;                               // DM_WBYTES bytes
+  uint16_t *list = (uint16_t *)(smem + DM_WBYTES);                // DM_SUB entries
+  uint32_t *ctr = (uint32_t *)(smem + DM_WBYTES + DM_SUB * 2);
+  const uint64_t WB = B >= (uint64_t)HALO ? B - HALO : 0;
+  const uint32_t woff = (uint32_t)(B - WB);
+  const uint32_t cnt = (uint32_t)((n - B) < (uint64_t)DMB ? (n - B) : (uint64_t)DMB);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned long long ltm = (1ull << lane) - 1ull;
+  {
+    const uint32_t nb = woff + cnt + 272;
+    const uint4 *src = (const uint4 *)(in + WB);
+    uint4 *dst = (uint4 *)win;
+    for (uint32_t i = tid; i < (nb + 15) / 16; i += DM_THREADS) dst[i] = src[i];
+  }
+  const uint8_t *win8 = (const uint8_t *)win;
+  for (uint32_t sub = 0; sub < cnt; sub += DM_SUB) {
+    if (tid == 0) ctr[0] = 0;
+    __syncthreads();
+    for (uint32_t j = tid; j < DM_SUB; j += DM_THREADS) {          // the marked positions of this part of the block
+      const uint32_t k = sub + j;
+      const bool todo = k < cnt && (M[B + k].full & (M_GUESS | M_DEMAND)) == (M_GUESS | M_DEMAND);
+      const unsigned long long mk = __ballot(todo);
+      if (mk) {
+        uint32_t b0 = 0;
+        const int leader = __ffsll((long long)mk) - 1;
+        if (lane == leader) b0 = atomicAdd(&ctr[0], (uint32_t)__popcll(mk));
+        b0 = __shfl(b0, leader);
+        if (todo) list[b0 + __popcll(mk & ltm)] = (uint16_t)k;
+      }
+    }
+    __syncthreads();
+    const uint32_t nl = ctr[0];
+    // A wave takes DM_GROUP list entries at a time.  Vector part, one lane per position: everything that is known
+    // about the position (limits, nearest 3..K-1 byte matches, where its bucket lies in the sorted orders) and the
+    // start of the search; positions with nothing to scan are finished here.  Then the positions that do have
+    // candidates are scanned one after the other by the whole wave, 64 candidates per batch, DM_DEPTH batches
+    // fetched ahead (the first ones of the next position while the current one is being worked on).
+    for (uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * DM_GROUP; g0 < nl; g0 += DM_GROUP * (DM_THREADS / 64)) {
+      const bool have = (uint32_t)lane < (uint32_t)DM_GROUP && g0 + lane < nl;
+      const uint32_t k = have ? (uint32_t)list[g0 + lane] : 0u;
+      const uint64_t p = B + k;
+      const uint32_t wi = woff + k;
+      const uint64_t rem = n - p;
+      const int la = rem < 258 ? (int)rem : 258;                   // Longest_Match never returns more
+      const int nice = nice_cfg < la ? nice_cfg : la;              // lz77.adb:858-860
+      const uint64_t seg = p >> 15, pbase = (seg << 15) - 32768;
+      const uint32_t dlimv = dp.dlim[p];
+      uint32_t dl[NLEVELS];
+#pragma unroll
+      for (int l = 0; l < NLEVELS; l++) dl[l] = dp.d[l][p];
+      const MatchPair og = M[p];
+      const uint32_t idx1 = rp.idx[p], c1 = rp.cnt[p];
+      uint32_t t = 0xFFFFu;
+      if (seg > 0) t = tailsK[(seg - 1) * 65536ull + hashL_of(lds_u64_at(win8, wi), 3 + NLEVELS)];
+      uint32_t idx2 = 0, c2 = 0;
+      if (t != 0xFFFFu) { idx2 = rp.idx[pbase + t]; c2 = (uint32_t)rp.cnt[pbase + t] + 1u; }
+      const uint32_t df = dlimv & 0xFFFF, dq = dlimv >> 16;
+      const uint32_t lim_full = dl[0] == (uint32_t)MAX_DIST ? (uint32_t)MAX_DIST : (df < (uint32_t)(MAX_DIST - 1) ? df : (uint32_t)(MAX_DIST - 1));   // :850 / :820-822
+      const uint32_t lim_q = dq < lim_full ? dq : lim_full;                                                                                               // :733-735
+      int best = 2;
+      uint32_t bdist = 0, qbest = 0;
+      bool chain_ok = true;
+#pragma unroll
+      for (int l = 0; l < NLEVELS; l++) {
+        const bool v = chain_ok && la >= 3 + l && dl[l] != 0 && dl[l] <= lim_full;
+        if (v) { best = 3 + l; bdist = dl[l]; if (dl[l] <= lim_q) qbest = ((uint32_t)(3 + l) << 16) | dl[l]; }
+        chain_ok = v;
+      }
+      bool have_q = chain_ok && bdist > lim_q;
+      uint32_t rq = qbest;
+      // candidate c of a position (nearest first), as a distance; 0 = no such candidate.  Position 0 is never a match
+      // source (:467) and ends the chain.
+      auto cand = [&](uint64_t P_, uint32_t I1, uint32_t C1, uint32_t I2, uint32_t C2, uint32_t c) -> uint32_t {
+        const uint64_t sb = (P_ >> 15) << 15;
+        uint64_t q = 0;
+        if (c < C1) q = sb + rp.S[sb + I1 - 1 - c];
+        else if (c - C1 < C2) q = sb - 32768 + rp.S[sb - 32768 + I2 - (c - C1)];
+        return q != 0 ? (uint32_t)(P_ - q) : 0u;
+      };
+      unsigned long long todo = __ballot(have && chain_ok && best < nice && c1 + c2 > 0);
+      uint32_t dnx[DM_DEPTH];                                       // the first batches of the next position to scan
+#pragma unroll
+      for (int u = 0; u < DM_DEPTH; u++) dnx[u] = 0;
+      if (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+#pragma unroll
+        for (int u = 0; u < DM_DEPTH; u++) dnx[u] = cand(RL64(p, j), RL(idx1, j), RL(c1, j), RL(idx2, j), RL(c2, j), (uint32_t)(64 * u + lane));
+      }
+      while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        uint32_t dcur[DM_DEPTH];
+#pragma unroll
+        for (int u = 0; u < DM_DEPTH; u++) dcur[u] = dnx[u];
+        {
+          const int jn = todo ? __ffsll((long long)todo) - 1 : j;  // (the last position re-fetches its own batches: harmless)
+#pragma unroll
+          for (int u = 0; u < DM_DEPTH; u++) dnx[u] = cand(RL64(p, jn), RL(idx1, jn), RL(c1, jn), RL(idx2, jn), RL(c2, jn), (uint32_t)(64 * u + lane));
+        }
+        // ---- position of lane j, the whole wave ----
+        const uint64_t P = RL64(p, j);
+        const uint32_t WI = RL(wi, j), I1 = RL(idx1, j), C1 = RL(c1, j), I2 = RL(idx2, j), C2 = RL(c2, j), TT = C1 + C2;
+        const uint32_t LF = RL(lim_full, j), LQ = RL(lim_q, j);
+        const int LA = (int)RL(la, j), NICE = (int)RL(nice, j);
+        int bst = (int)RL(best, j);
+        uint32_t bd = RL(bdist, j), rqq = RL(rq, j);
+        bool hq = RL((uint32_t)have_q, j) != 0;
+        uint32_t s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
+        bool over = false;                                         // search finished
+        // One batch of 64 candidates (distances d, nearest first).  All of them are filtered at once against the best so
+        // far (:754-757); the survivors are then taken in order, exactly like the sequential walk (:812-822): the
+        // whole wave compares one candidate with the scanned string, four bytes per lane, and if it is longer it
+        // becomes the best and the remaining survivors are filtered again.
+        auto lds_u32 = [&](uint32_t o) -> uint32_t {
+          const uint32_t *w = (const uint32_t *)(win8 + (o & ~3u));
+          return __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u);
+        };
+        auto batch = [&](uint32_t d) {
+          const bool valid = d != 0;
+          const bool inr = valid && d <= LF;
+          bool pass = false;
+          if (inr) pass = LDS_U16(win8, WI - d + (uint32_t)bst - 1) == s_end;
+          unsigned long long pm = __ballot(pass);
+          while (pm) {
+            const int j = __ffsll((long long)pm) - 1;
+            const uint32_t dj = RL(d, j);
+            if (!hq && dj > LQ) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }     // the walk crosses the quarter limit (:733-735)
+            const uint32_t o = 4u * (uint32_t)lane;
+            const uint32_t x = lds_u32(WI - dj + o) ^ lds_u32(WI + o);
+            const unsigned long long mm = __ballot(x != 0);
+            int len;
+            if (mm) { const int l0 = __ffsll((long long)mm) - 1; len = 4 * l0 + (int)(__builtin_ctz(RL(x, l0)) >> 3); }
+            else { const uint32_t y = LDS_U16(win8, WI - dj + 256) ^ LDS_U16(win8, WI + 256); len = 256 + (y == 0 ? 2 : ((y & 0xFF) == 0 ? 1 : 0)); }
+            len = len < LA ? len : LA;
+            if (len > bst) {
+              bst = len; bd = dj;
+              if (len >= NICE) { over = true; break; }                                         // :815
+              s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
+              pass = pass && lane > j && LDS_U16(win8, WI - d + (uint32_t)bst - 1) == s_end;
+            } else pass = pass && lane > j;
+            pm = __ballot(pass);
+          }
+          if (!over && !hq && __any(valid && d > LQ)) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }
+          // beyond the limit, or position 0, or no more candidates: the chain ends (:819-822)
+          if (__any(!inr)) over = true;
+        };
+        for (uint32_t c0 = 0; c0 < TT && !over; c0 += 64 * DM_DEPTH) {
+          uint32_t dfar[DM_DEPTH];                                 // the batches after these, on their way meanwhile
+          const bool more = c0 + 64 * DM_DEPTH < TT;
+#pragma unroll
+          for (int u = 0; u < DM_DEPTH; u++) dfar[u] = more ? cand(P, I1, C1, I2, C2, c0 + 64 * (DM_DEPTH + u) + (uint32_t)lane) : 0u;
+#pragma unroll
+          for (int u = 0; u < DM_DEPTH; u++) if (!over) batch(dcur[u]);
+#pragma unroll
+          for (int u = 0; u < DM_DEPTH; u++) dcur[u] = dfar[u];
+        }
+        if (lane == j) { best = bst; bdist = bd; have_q = hq; rq = rqq; }
+      }
+      if (have) {
+        const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
+        MatchPair r; r.full = packed; r.quarter = !chain_ok ? qbest : (have_q ? rq : packed);
+        M[p] = r;
+        if (r.full != (og.full & M_VALUE) || r.quarter != og.quarter) {
+          const uint64_t ch = p / PCHUNK;
+          chg[ch] = 1; if (ch > 0) chg[ch - 1] = 1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// --------------------------------------------------------------------------------------------
 // parser kernels
 // --------------------------------------------------------------------------------------------
 // one lane per chunk (the chunk logic itself is in zada_logic.h: parse_spec_chunk / parse_fix_chunk)
+// A parse that lands on a guessed match record uses it and asks for the exact value: M_DEMAND on the record, a
+// count per k_match block (so that the demand pass skips blocks without work) and a grand total for the host.
+struct DemandMarker {
+  MatchPair *M; uint32_t *blk_demand; uint32_t *n_demand;
+  __device__ void operator()(uint32_t p, uint32_t full) const {
+    if (full & M_DEMAND) return;
+    // plain stores: every concurrent writer of these three words writes the same value
+    M[p].full = full | M_DEMAND;
+    blk_demand[p / MB] = 1;
+    *n_demand = 1;
+  }
+};
+
 __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict__ spec_tok, uint32_t *__restrict__ spec_cnt,
-                             uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits) {
+                             uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits,
+                             DemandMarker dm, const uint8_t *__restrict__ redo /* null: every chunk */) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nchunks) return;
+  if (redo && !redo[k]) return;
   uint32_t ntok = 0;
   ExitState ex;
-  parse_spec_chunk(io, k, PCHUNK, spec_tok + (uint64_t)k * PTOK_STRIDE, ntok, Fbits, Lbits, ex);
+  parse_spec_chunk(io, k, PCHUNK, spec_tok + (uint64_t)k * PTOK_STRIDE, ntok, Fbits, Lbits, ex, dm);
   spec_cnt[k] = ntok;
   exits[k] = ex;
 }
@@ -787,7 +1048,7 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
                             uint32_t *__restrict__ fix_tok, uint32_t *__restrict__ fix_cnt,
                             uint32_t *__restrict__ take_from, uint32_t *__restrict__ start_pos,
                             const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
-                            uint32_t *__restrict__ n_changed) {
+                            uint32_t *__restrict__ n_changed, DemandMarker dm) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nchunks) return;
   if (!dirty_in[k]) return;
@@ -797,7 +1058,7 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
   ExitState new_exit;
   uint32_t ntok = 0, take = 0, u0 = 0;
   parse_fix_chunk(io, k, PCHUNK, entry, spec_tok + (uint64_t)k * PTOK_STRIDE, spec_cnt[k], Fbits, Lbits, spec_exits[k],
-                  fix_tok + (uint64_t)k * PTOK_STRIDE, ntok, take, u0, new_exit);
+                  fix_tok + (uint64_t)k * PTOK_STRIDE, ntok, take, u0, new_exit, dm);
   fix_cnt[k] = ntok;
   take_from[k] = take;
   start_pos[k] = u0;
@@ -917,16 +1178,18 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
     hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16 + MB / 4);
+    hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
     attr_done = true;
   }
   LevelPtrs lv;
   DistPlanes dpl;
+  RunPtrs rpt; rpt.S = W.SK; rpt.idx = W.idxK; rpt.cnt = W.cntK;
   for (int l = 0; l < NLEVELS; l++) dpl.d[l] = W.dplane[l];
   dpl.dlim = W.dlim;
   if (nseg > 0) {
     for (int l = 0; l < NLEVELS; l++) { lv.prev[l] = W.lprev[l]; lv.tails[l] = W.ltails[l]; }
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2, lv,
-                       W.S3, W.T3, W.bsc3, dpl, (unsigned long long *)W.dbg);
+                       W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg);
 #ifdef ZADA_PL_STATS
     { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); hipMemset(W.dbg, 0, 256); }
 #endif
@@ -941,41 +1204,60 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     }
   }
   c->tmark("cross_links");
-  {
-    uint32_t nb = (uint32_t)((n + MB - 1) / MB);
-    hipLaunchKernelGGL(k_match, dim3(nb), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice, (unsigned long long *)W.dbg);
-  }
-#ifdef ZADA_MATCH_STATS
-  {
-    unsigned long long h[8];
-    hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[match stats] n=%llu lane_iters=%llu (%.1f/pos) max_lane_cycles=%llu avg_wave_cycles=%.0f avg_wave_tail=%.0f avg_block_cycles=%.0f blocks=%llu\n",
-            (unsigned long long)n, h[0], (double)h[0] / n, h[1], (double)h[2] / h[3], (double)h[4] / h[3], (double)h[5] / h[6], h[6]);
-    hipMemset(W.dbg, 0, 64);
-  }
-#endif
-  c->tmark("match");
+  // ---- matches and parse, demand driven ----
+  // The parser only ever looks at about a third of the positions, and hardly ever at the ones with the longest
+  // chains (inside long matches): 9 % of all chain steps belong to positions it lands on.  So every position
+  // first gets a bounded search (exact for 85 % of them); the parse runs on that, marking the guesses it lands
+  // on; those are searched to the end; parses that used a guess which turned out different are redone; and so
+  // on until a parse has used exact values only.  The result is the parse over exact values, whatever the budget.
+  const uint32_t nbm = (uint32_t)((n + MB - 1) / MB);
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
+  static int budget_env = -1;
+  if (budget_env < 0) { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : 4; if (budget_env < 1) budget_env = 1 << 20; }
+  hipMemsetAsync(W.blk_demand, 0, (size_t)nbm * 4, st);
+  hipMemsetAsync(W.n_demand, 0, 4, st);
+  hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
+                     budget_env, W.blk_demand, W.chg, (unsigned long long *)W.dbg);
+  c->tmark("match");
   ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg;
-  hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
-                     W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits);
-  // fixpoint of the splice: round 0 handles every chunk with the speculative exits as entries
-  hipMemcpyAsync(W.true_exits, W.spec_exits, (size_t)nch * sizeof(ExitState), hipMemcpyDeviceToDevice, st);
-  hipMemsetAsync(W.dirty[0], 1, nch, st);
-  int cur = 0, rounds = 0;
-  for (;;) {
-    hipMemsetAsync(W.dirty[cur ^ 1], 0, nch, st);
-    hipMemsetAsync(W.n_changed, 0, 4, st);
-    hipLaunchKernelGGL(k_parse_fix, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
-                       W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, W.true_exits, W.fix_tok, W.fix_cnt,
-                       W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed);
-    uint32_t changed = 0;
-    hipMemcpyAsync(&changed, W.n_changed, 4, hipMemcpyDeviceToHost, st);
-    if (hip_check(c, hipStreamSynchronize(st), "parse_fix")) return ZADA_E_HIP_;
-    rounds++;
-    if (changed == 0) break;
-    cur ^= 1;
+  DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand;
+  int rounds = 0, demand_rounds = 0;
+  uint64_t demanded_total = 0;
+  for (bool first = true;; first = false) {
+    // speculative parse: every chunk the first time, afterwards the chunks flagged by the demand pass
+    hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
+                       W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, first ? (const uint8_t *)nullptr : (const uint8_t *)W.chg);
+    // fixpoint of the splice, from scratch: round 0 handles every chunk with the speculative exits as entries
+    hipMemcpyAsync(W.true_exits, W.spec_exits, (size_t)nch * sizeof(ExitState), hipMemcpyDeviceToDevice, st);
+    hipMemsetAsync(W.dirty[0], 1, nch, st);
+    int cur = 0;
+    for (;;) {
+      hipMemsetAsync(W.dirty[cur ^ 1], 0, nch, st);
+      hipMemsetAsync(W.n_changed, 0, 4, st);
+      hipLaunchKernelGGL(k_parse_fix, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
+                         W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, W.true_exits, W.fix_tok, W.fix_cnt,
+                         W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed, dm);
+      uint32_t changed = 0;
+      hipMemcpyAsync(&changed, W.n_changed, 4, hipMemcpyDeviceToHost, st);
+      if (hip_check(c, hipStreamSynchronize(st), "parse_fix")) return ZADA_E_HIP_;
+      rounds++;
+      if (changed == 0) break;
+      cur ^= 1;
+    }
+    uint32_t ndem = 0;
+    hipMemcpy(&ndem, W.n_demand, 4, hipMemcpyDeviceToHost);
+    if (ndem == 0) break;
+    demanded_total += ndem; demand_rounds++;
+    if (getenv("ZADA_TRACE_DEMAND")) { fprintf(stderr, "[demand] round %d: fix rounds so far %d\n", demand_rounds, rounds); fflush(stderr); }
+    if (demand_rounds > 1000) { c->err = "demand loop did not converge"; return ZADA_E_HIP_; }
+    hipMemsetAsync(W.n_demand, 0, 4, st);
+    hipMemsetAsync(W.chg, 0, nch, st);
+    hipLaunchKernelGGL(k_match_demand, dim3((uint32_t)((n + DMB - 1) / DMB)), dim3(DM_THREADS), DM_LDS, st, W.in, n, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
+                       W.blk_demand, W.chg);
+    hipMemsetAsync(W.blk_demand, 0, (size_t)nbm * 4, st);
   }
+  if (getenv("ZADA_TRACE_DEMAND")) fprintf(stderr, "[demand] n=%llu budget=%d demand rounds=%d demanded=%llu (%.2f%% of positions) fix rounds=%d\n",
+                                           (unsigned long long)n, budget_env, demand_rounds, (unsigned long long)demanded_total, 100.0 * demanded_total / n, rounds);
   c->parse_rounds = rounds;
   c->tmark("parse");
   hipLaunchKernelGGL(k_tok_count, dim3((nch + 255) / 256), dim3(256), 0, st, nch, W.spec_cnt, W.fix_cnt, W.take_from, W.counts);
