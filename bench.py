@@ -54,7 +54,12 @@ def cpu_baseline(za, sample_mib):
     rc = O.zo_deflate(d, n, 10, out, n + 64, ctypes.byref(ol), ctypes.byref(crc), None, None, None, None)
     dt = time.perf_counter() - t0
     assert rc == 0
+    import zlib
+    t1 = time.perf_counter()
+    z9 = len(zlib.compress(d, 9)) - 6                     # zlib -9 on the same sample (secondary anchor)
+    dz = time.perf_counter() - t1
     return {"value": round(n / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+            "zlib9": {"ratio": round(z9 / n, 4), "MB/s": round(n / dz / 1e6, 2)},
             "sample": "first %d MiB of the same silesia_mix_v1 stream, Deflate_3, oracle/zada_oracle.c single thread, %.1f s" % (sample_mib, dt),
             "ratio": round(ol.value / n, 4)}, out.raw[:ol.value]
 
