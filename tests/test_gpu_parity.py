@@ -88,6 +88,34 @@ def test_never_resynchronising_inputs(encoder):
             assert rc == rc2 and out == ref and crc == crc2
 
 
+def test_demand_driven_matching_is_budget_independent(encoder):
+    """The first pass gives every position a bounded search and the exact search only happens where a parse
+    lands.  The stream must not depend on the bound: tiny budget (nearly everything is a guess
+    and gets demanded), default, and unbounded (no guesses, the former single-pass pipeline) -- all equal
+    to the oracle, on every synthetic class and on data built to have very long chains."""
+    rep = (b"0001234,ABCD,some field,99\n" * 40 + b"0001235,ABCE,some field,98\n") * 900
+    cases = [silesia_mix(3 << 20), silesia_mix(1 << 20, class_mask=8), silesia_mix(1 << 20, class_mask=2), rep[: (1 << 20) + 77],
+             bytes(200000), b"abcdefgh" * 50000]
+    old = os.environ.get("ZADA_BUDGET")
+    try:
+        for d in cases:
+            rc, ref, crc = oracle_deflate(d, 10)
+            for budget in ("1", "2", "6", "0"):
+                os.environ["ZADA_BUDGET"] = budget
+                rc2, out, crc2 = gpu_deflate(encoder, d, 10)
+                assert rc == rc2 and out == ref and crc == crc2, (len(d), budget)
+            for method in (9, 8):
+                os.environ["ZADA_BUDGET"] = "1"
+                rc, ref, crc = oracle_deflate(d, method)
+                rc2, out, crc2 = gpu_deflate(encoder, d, method)
+                assert rc == rc2 and out == ref and crc == crc2, (len(d), method)
+    finally:
+        if old is None:
+            os.environ.pop("ZADA_BUDGET", None)
+        else:
+            os.environ["ZADA_BUDGET"] = old
+
+
 def test_compress_data_store_fallback_and_archive_bytes(encoder):
     """Zip.Compress.Compress_Data + Zip.Create bytes == the oracle's archive; readable by zipfile."""
     za = product()

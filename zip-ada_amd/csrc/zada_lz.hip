@@ -1212,8 +1212,8 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   // on until a parse has used exact values only.  The result is the parse over exact values, whatever the budget.
   const uint32_t nbm = (uint32_t)((n + MB - 1) / MB);
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
-  static int budget_env = -1;
-  if (budget_env < 0) { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : 6; if (budget_env < 1) budget_env = 1 << 20; }
+  int budget_env;                                  // read at every call: the tests compare budgets within one process
+  { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : 6; if (budget_env < 1) budget_env = 1 << 20; }
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbm * 4, st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
   hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
