@@ -822,29 +822,30 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 // value of lane j (j wave uniform) of a vector register, as a scalar
 #define RL(v, j) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (j)))
 #define RL64(v, j) ((uint64_t)RL((uint32_t)(v), (j)) | ((uint64_t)RL((uint32_t)((v) >> 32), (j)) << 32))
-#ifndef ZADA_DM_DEPTH
-#define ZADA_DM_DEPTH 1
-#endif
-#ifndef ZADA_DM_GROUP
-#define ZADA_DM_GROUP 2
-#endif
-constexpr int DM_THREADS = 512, DMB = 4096, DM_SUB = 1024, DM_GROUP = ZADA_DM_GROUP, DM_DEPTH = ZADA_DM_DEPTH;
+constexpr int DM_THREADS = 512, DMB = 4096, DM_SLICE = 256;
 constexpr int DM_WBYTES = HALO + DMB + 272;
-constexpr int DM_LDS = DM_WBYTES + DM_SUB * 2 + 64;
-static_assert(MB % DMB == 0 && DM_WBYTES % 16 == 0, "demand blocks tile the first-pass blocks");
+struct ScanDesc {                                  // a position whose candidates have to be scanned (32 bytes, in LDS)
+  uint16_t k, la, idx1, c1, idx2, c2, lim_full, lim_q;
+  uint16_t bdist, best_hq;                         // best | have_q << 15
+  uint32_t rq, og_full, og_quarter;
+};
+constexpr int DM_LDS = DM_WBYTES + DMB * 2 + DM_SLICE * (int)sizeof(ScanDesc) + 64;
+static_assert(MB % DMB == 0 && DM_WBYTES % 16 == 0 && sizeof(ScanDesc) == 32, "demand blocks tile the first-pass blocks");
 __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__restrict__ in, uint64_t n, DistPlanes dp, RunPtrs rp,
                                                              const uint16_t *__restrict__ tailsK, MatchPair *__restrict__ M, int nice_cfg,
-                                                             const uint32_t *__restrict__ blk_demand, uint8_t *__restrict__ chg) {
+                                                             const uint32_t *__restrict__ blk_demand, uint8_t *__restrict__ chg,
+                                                             const ExitState *__restrict__ spec_exits) {
+  if (blk_demand[blockIdx.x] == 0) return;
   const uint64_t B = (uint64_t)blockIdx.x * DMB;
-  if (blk_demand[B / MB] == 0) return;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // DM_WBYTES bytes
-  uint16_t *list = (uint16_t *)(smem + DM_WBYTES);                // DM_SUB entries
-  uint32_t *ctr = (uint32_t *)(smem + DM_WBYTES + DM_SUB * 2);
+  uint16_t *list = (uint16_t *)(smem + DM_WBYTES);                // the marked positions of the block, up to DMB
+  ScanDesc *desc = (ScanDesc *)(smem + DM_WBYTES + DMB * 2);      // DM_SLICE entries
+  uint32_t *ctr = (uint32_t *)(smem + DM_WBYTES + DMB * 2 + DM_SLICE * sizeof(ScanDesc));
   const uint64_t WB = B >= (uint64_t)HALO ? B - HALO : 0;
   const uint32_t woff = (uint32_t)(B - WB);
   const uint32_t cnt = (uint32_t)((n - B) < (uint64_t)DMB ? (n - B) : (uint64_t)DMB);
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long ltm = (1ull << lane) - 1ull;
   {
     const uint32_t nb = woff + cnt + 272;
@@ -853,31 +854,40 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
     for (uint32_t i = tid; i < (nb + 15) / 16; i += DM_THREADS) dst[i] = src[i];
   }
   const uint8_t *win8 = (const uint8_t *)win;
-  for (uint32_t sub = 0; sub < cnt; sub += DM_SUB) {
-    if (tid == 0) ctr[0] = 0;
-    __syncthreads();
-    for (uint32_t j = tid; j < DM_SUB; j += DM_THREADS) {          // the marked positions of this part of the block
-      const uint32_t k = sub + j;
-      const bool todo = k < cnt && (M[B + k].full & (M_GUESS | M_DEMAND)) == (M_GUESS | M_DEMAND);
-      const unsigned long long mk = __ballot(todo);
-      if (mk) {
-        uint32_t b0 = 0;
-        const int leader = __ffsll((long long)mk) - 1;
-        if (lane == leader) b0 = atomicAdd(&ctr[0], (uint32_t)__popcll(mk));
-        b0 = __shfl(b0, leader);
-        if (todo) list[b0 + __popcll(mk & ltm)] = (uint16_t)k;
-      }
+  // a changed value: the speculative parses that used the guess have to be redone (the chunk's own, and the previous
+  // chunk's if it ran over into this position)
+  auto store_result = [&](uint64_t p, uint32_t full, uint32_t quarter, uint32_t og_full, uint32_t og_quarter) {
+    MatchPair r; r.full = full; r.quarter = quarter;
+    M[p] = r;
+    if ((og_full & M_BYSPEC) && (full != (og_full & M_VALUE) || quarter != og_quarter)) {
+      const uint64_t ch = p / PCHUNK;
+      chg[ch] = 1;
+      if (ch > 0 && spec_exits[ch - 1].pos >= (uint32_t)p) chg[ch - 1] = 1;
     }
+  };
+  if (tid == 0) ctr[0] = 0;
+  __syncthreads();
+  for (uint32_t k = tid; k < DMB; k += DM_THREADS) {               // the marked positions of the block
+    const bool todo = k < cnt && (M[B + k].full & (M_GUESS | M_DEMAND)) == (M_GUESS | M_DEMAND);
+    const unsigned long long mk = __ballot(todo);
+    if (mk) {
+      uint32_t b0 = 0;
+      const int leader = __ffsll((long long)mk) - 1;
+      if (lane == leader) b0 = atomicAdd(&ctr[0], (uint32_t)__popcll(mk));
+      b0 = __shfl(b0, leader);
+      if (todo) list[b0 + __popcll(mk & ltm)] = (uint16_t)k;
+    }
+  }
+  __syncthreads();
+  const uint32_t nl = ctr[0];
+  for (uint32_t l0 = 0; l0 < nl; l0 += DM_SLICE) {
+    if (tid == 0) ctr[1] = 0;
     __syncthreads();
-    const uint32_t nl = ctr[0];
-    // A wave takes DM_GROUP list entries at a time.  Vector part, one lane per position: everything that is known
-    // about the position (limits, nearest 3..K-1 byte matches, where its bucket lies in the sorted orders) and the
-    // start of the search; positions with nothing to scan are finished here.  Then the positions that do have
-    // candidates are scanned one after the other by the whole wave, 64 candidates per batch, DM_DEPTH batches
-    // fetched ahead (the first ones of the next position while the current one is being worked on).
-    for (uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * DM_GROUP; g0 < nl; g0 += DM_GROUP * (DM_THREADS / 64)) {
-      const bool have = (uint32_t)lane < (uint32_t)DM_GROUP && g0 + lane < nl;
-      const uint32_t k = have ? (uint32_t)list[g0 + lane] : 0u;
+    // ---- phase A, one lane per marked position: everything that is known about the position (limits, nearest
+    //      3..K-1 byte matches, where its bucket lies in the sorted orders) and the start of the search.  Positions
+    //      with nothing to scan are finished here; the others leave a descriptor in LDS. ----
+    if ((uint32_t)tid < (uint32_t)DM_SLICE && l0 + tid < nl) {
+      const uint32_t k = list[l0 + tid];
       const uint64_t p = B + k;
       const uint32_t wi = woff + k;
       const uint64_t rem = n - p;
@@ -906,104 +916,86 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
         if (v) { best = 3 + l; bdist = dl[l]; if (dl[l] <= lim_q) qbest = ((uint32_t)(3 + l) << 16) | dl[l]; }
         chain_ok = v;
       }
-      bool have_q = chain_ok && bdist > lim_q;
-      uint32_t rq = qbest;
-      // candidate c of a position (nearest first), as a distance; 0 = no such candidate.  Position 0 is never a match
-      // source (:467) and ends the chain.
-      auto cand = [&](uint64_t P_, uint32_t I1, uint32_t C1, uint32_t I2, uint32_t C2, uint32_t c) -> uint32_t {
-        const uint64_t sb = (P_ >> 15) << 15;
-        uint64_t q = 0;
-        if (c < C1) q = sb + rp.S[sb + I1 - 1 - c];
-        else if (c - C1 < C2) q = sb - 32768 + rp.S[sb - 32768 + I2 - (c - C1)];
-        return q != 0 ? (uint32_t)(P_ - q) : 0u;
-      };
-      unsigned long long todo = __ballot(have && chain_ok && best < nice && c1 + c2 > 0);
-      uint32_t dnx[DM_DEPTH];                                       // the first batches of the next position to scan
-#pragma unroll
-      for (int u = 0; u < DM_DEPTH; u++) dnx[u] = 0;
-      if (todo) {
-        const int j = __ffsll((long long)todo) - 1;
-#pragma unroll
-        for (int u = 0; u < DM_DEPTH; u++) dnx[u] = cand(RL64(p, j), RL(idx1, j), RL(c1, j), RL(idx2, j), RL(c2, j), (uint32_t)(64 * u + lane));
-      }
-      while (todo) {
-        const int j = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        uint32_t dcur[DM_DEPTH];
-#pragma unroll
-        for (int u = 0; u < DM_DEPTH; u++) dcur[u] = dnx[u];
-        {
-          const int jn = todo ? __ffsll((long long)todo) - 1 : j;  // (the last position re-fetches its own batches: harmless)
-#pragma unroll
-          for (int u = 0; u < DM_DEPTH; u++) dnx[u] = cand(RL64(p, jn), RL(idx1, jn), RL(c1, jn), RL(idx2, jn), RL(c2, jn), (uint32_t)(64 * u + lane));
-        }
-        // ---- position of lane j, the whole wave ----
-        const uint64_t P = RL64(p, j);
-        const uint32_t WI = RL(wi, j), I1 = RL(idx1, j), C1 = RL(c1, j), I2 = RL(idx2, j), C2 = RL(c2, j), TT = C1 + C2;
-        const uint32_t LF = RL(lim_full, j), LQ = RL(lim_q, j);
-        const int LA = (int)RL(la, j), NICE = (int)RL(nice, j);
-        int bst = (int)RL(best, j);
-        uint32_t bd = RL(bdist, j), rqq = RL(rq, j);
-        bool hq = RL((uint32_t)have_q, j) != 0;
-        uint32_t s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
-        bool over = false;                                         // search finished
-        // One batch of 64 candidates (distances d, nearest first).  All of them are filtered at once against the best so
-        // far (:754-757); the survivors are then taken in order, exactly like the sequential walk (:812-822): the
-        // whole wave compares one candidate with the scanned string, four bytes per lane, and if it is longer it
-        // becomes the best and the remaining survivors are filtered again.
-        auto lds_u32 = [&](uint32_t o) -> uint32_t {
-          const uint32_t *w = (const uint32_t *)(win8 + (o & ~3u));
-          return __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u);
-        };
-        auto batch = [&](uint32_t d) {
-          const bool valid = d != 0;
-          const bool inr = valid && d <= LF;
-          bool pass = false;
-          if (inr) pass = LDS_U16(win8, WI - d + (uint32_t)bst - 1) == s_end;
-          unsigned long long pm = __ballot(pass);
-          while (pm) {
-            const int j = __ffsll((long long)pm) - 1;
-            const uint32_t dj = RL(d, j);
-            if (!hq && dj > LQ) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }     // the walk crosses the quarter limit (:733-735)
-            const uint32_t o = 4u * (uint32_t)lane;
-            const uint32_t x = lds_u32(WI - dj + o) ^ lds_u32(WI + o);
-            const unsigned long long mm = __ballot(x != 0);
-            int len;
-            if (mm) { const int l0 = __ffsll((long long)mm) - 1; len = 4 * l0 + (int)(__builtin_ctz(RL(x, l0)) >> 3); }
-            else { const uint32_t y = LDS_U16(win8, WI - dj + 256) ^ LDS_U16(win8, WI + 256); len = 256 + (y == 0 ? 2 : ((y & 0xFF) == 0 ? 1 : 0)); }
-            len = len < LA ? len : LA;
-            if (len > bst) {
-              bst = len; bd = dj;
-              if (len >= NICE) { over = true; break; }                                         // :815
-              s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
-              pass = pass && lane > j && LDS_U16(win8, WI - d + (uint32_t)bst - 1) == s_end;
-            } else pass = pass && lane > j;
-            pm = __ballot(pass);
-          }
-          if (!over && !hq && __any(valid && d > LQ)) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }
-          // beyond the limit, or position 0, or no more candidates: the chain ends (:819-822)
-          if (__any(!inr)) over = true;
-        };
-        for (uint32_t c0 = 0; c0 < TT && !over; c0 += 64 * DM_DEPTH) {
-          uint32_t dfar[DM_DEPTH];                                 // the batches after these, on their way meanwhile
-          const bool more = c0 + 64 * DM_DEPTH < TT;
-#pragma unroll
-          for (int u = 0; u < DM_DEPTH; u++) dfar[u] = more ? cand(P, I1, C1, I2, C2, c0 + 64 * (DM_DEPTH + u) + (uint32_t)lane) : 0u;
-#pragma unroll
-          for (int u = 0; u < DM_DEPTH; u++) if (!over) batch(dcur[u]);
-#pragma unroll
-          for (int u = 0; u < DM_DEPTH; u++) dcur[u] = dfar[u];
-        }
-        if (lane == j) { best = bst; bdist = bd; have_q = hq; rq = rqq; }
-      }
-      if (have) {
+      const bool have_q = chain_ok && bdist > lim_q;
+      if (chain_ok && best < nice && c1 + c2 > 0) {
+        ScanDesc ds;
+        ds.k = (uint16_t)k; ds.la = (uint16_t)la; ds.idx1 = (uint16_t)idx1; ds.c1 = (uint16_t)c1; ds.idx2 = (uint16_t)idx2; ds.c2 = (uint16_t)c2;
+        ds.lim_full = (uint16_t)lim_full; ds.lim_q = (uint16_t)lim_q; ds.bdist = (uint16_t)bdist; ds.best_hq = (uint16_t)((uint32_t)best | ((uint32_t)have_q << 15));
+        ds.rq = qbest; ds.og_full = og.full; ds.og_quarter = og.quarter;
+        desc[atomicAdd(&ctr[1], 1u)] = ds;
+      } else {
         const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
-        MatchPair r; r.full = packed; r.quarter = !chain_ok ? qbest : (have_q ? rq : packed);
-        M[p] = r;
-        if (r.full != (og.full & M_VALUE) || r.quarter != og.quarter) {
-          const uint64_t ch = p / PCHUNK;
-          chg[ch] = 1; if (ch > 0) chg[ch - 1] = 1;
+        store_result(p, packed, !chain_ok ? qbest : (have_q ? qbest : packed), og.full, og.quarter);
+      }
+    }
+    __syncthreads();
+    // ---- phase B, one wave per descriptor: scan the candidates, 64 per batch.  The members of the bucket are a
+    //      contiguous run of the sorted order, nearest first when read backwards, in the position's own segment
+    //      and then in the previous one.  The first batch of the wave's next descriptor is fetched meanwhile. ----
+    const uint32_t ns = ctr[1];
+    // candidate c of a descriptor's position (nearest first), as a distance; 0 = no such candidate.  Position 0 is never
+    // a match source (:467) and ends the chain.
+    auto cand = [&](const ScanDesc &ds, uint32_t c) -> uint32_t {
+      const uint64_t P_ = B + ds.k, sb = (P_ >> 15) << 15;
+      uint64_t q = 0;
+      if (c < ds.c1) q = sb + rp.S[sb + ds.idx1 - 1 - c];
+      else if (c - ds.c1 < ds.c2) q = sb - 32768 + rp.S[sb - 32768 + ds.idx2 - (c - ds.c1)];
+      return q != 0 ? (uint32_t)(P_ - q) : 0u;
+    };
+    uint32_t dnext = (uint32_t)wave < ns ? cand(desc[wave], (uint32_t)lane) : 0u;
+    for (uint32_t si = (uint32_t)wave; si < ns; si += DM_THREADS / 64) {
+      const ScanDesc ds = desc[si];
+      uint32_t d = dnext;
+      if (si + DM_THREADS / 64 < ns) dnext = cand(desc[si + DM_THREADS / 64], (uint32_t)lane);
+      const uint32_t WI = woff + ds.k, LF = ds.lim_full, LQ = ds.lim_q, TT = (uint32_t)ds.c1 + ds.c2;
+      const int LA = ds.la, NICE = nice_cfg < LA ? nice_cfg : LA;
+      int bst = ds.best_hq & 0x7FFF;
+      uint32_t bd = ds.bdist, rqq = ds.rq;
+      bool hq = (ds.best_hq >> 15) != 0;
+      uint32_t s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
+      bool over = false;                                           // search finished
+      auto lds_u32 = [&](uint32_t o) -> uint32_t {
+        const uint32_t *w = (const uint32_t *)(win8 + (o & ~3u));
+        return __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u);
+      };
+      uint32_t dn2 = TT > 64 ? cand(ds, 64 + (uint32_t)lane) : 0u;   // the batch after this one, on its way
+      for (uint32_t c0 = 0; c0 < TT && !over; c0 += 64) {
+        if (c0 > 0) { d = dn2; dn2 = c0 + 64 < TT ? cand(ds, c0 + 64 + (uint32_t)lane) : 0u; }
+        // One batch of 64 candidates (distances d, nearest first).  All of them are filtered at once against the best
+        // so far (:754-757); the survivors are then taken in order, exactly like the sequential walk (:812-822):
+        // the whole wave compares one candidate with the scanned string, four bytes per lane, and if it is longer
+        // it becomes the best and the remaining survivors are filtered again.
+        const bool valid = d != 0;
+        const bool inr = valid && d <= LF;
+        bool pass = false;
+        if (inr) pass = LDS_U16(win8, WI - d + (uint32_t)bst - 1) == s_end;
+        unsigned long long pm = __ballot(pass);
+        while (pm) {
+          const int j = __ffsll((long long)pm) - 1;
+          const uint32_t dj = RL(d, j);
+          if (!hq && dj > LQ) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }     // the walk crosses the quarter limit (:733-735)
+          const uint32_t o = 4u * (uint32_t)lane;
+          const uint32_t x = lds_u32(WI - dj + o) ^ lds_u32(WI + o);
+          const unsigned long long mm = __ballot(x != 0);
+          int len;
+          if (mm) { const int l0 = __ffsll((long long)mm) - 1; len = 4 * l0 + (int)(__builtin_ctz(RL(x, l0)) >> 3); }
+          else { const uint32_t y = LDS_U16(win8, WI - dj + 256) ^ LDS_U16(win8, WI + 256); len = 256 + (y == 0 ? 2 : ((y & 0xFF) == 0 ? 1 : 0)); }
+          len = len < LA ? len : LA;
+          if (len > bst) {
+            bst = len; bd = dj;
+            if (len >= NICE) { over = true; break; }                                             // :815
+            s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
+            pass = pass && lane > j && LDS_U16(win8, WI - d + (uint32_t)bst - 1) == s_end;
+          } else pass = pass && lane > j;
+          pm = __ballot(pass);
         }
+        if (!over && !hq && __any(valid && d > LQ)) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }
+        // beyond the limit, or position 0, or no more candidates: the chain ends (:819-822)
+        if (__any(!inr)) over = true;
+      }
+      if (lane == 0) {
+        const uint32_t packed = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u;
+        store_result(B + ds.k, packed, hq ? rqq : packed, ds.og_full, ds.og_quarter);
       }
     }
     __syncthreads();
@@ -1015,14 +1007,15 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
 // --------------------------------------------------------------------------------------------
 // one lane per chunk (the chunk logic itself is in zada_logic.h: parse_spec_chunk / parse_fix_chunk)
 // A parse that lands on a guessed match record uses it and asks for the exact value: M_DEMAND on the record, a
-// count per k_match block (so that the demand pass skips blocks without work) and a grand total for the host.
+// flag per k_match_demand block (so that the demand pass skips blocks without work) and a grand total for the host.
 struct DemandMarker {
-  MatchPair *M; uint32_t *blk_demand; uint32_t *n_demand;
+  MatchPair *M; uint32_t *blk_demand; uint32_t *n_demand; uint32_t by;   // by = M_BYSPEC for the speculative parse, 0 for the splice
   __device__ void operator()(uint32_t p, uint32_t full) const {
-    if (full & M_DEMAND) return;
-    // plain stores: every concurrent writer of these three words writes the same value
-    M[p].full = full | M_DEMAND;
-    blk_demand[p / MB] = 1;
+    const uint32_t want = M_DEMAND | by;
+    if ((full & want) == want) return;
+    // plain stores: every concurrent writer of these words writes a value that only adds flags
+    M[p].full = full | want;
+    blk_demand[p / DMB] = 1;
     *n_demand = 1;
   }
 };
@@ -1214,13 +1207,15 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
   int budget_env;                                  // read at every call: the tests compare budgets within one process
   { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : 6; if (budget_env < 1) budget_env = 1 << 20; }
-  hipMemsetAsync(W.blk_demand, 0, (size_t)nbm * 4, st);
+  const uint32_t nbd = (uint32_t)((n + DMB - 1) / DMB);
+  hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
   hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
                      budget_env, W.blk_demand, W.chg, (unsigned long long *)W.dbg);
   c->tmark("match");
   ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg;
-  DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand;
+  DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand; dm.by = M_BYSPEC;
+  DemandMarker dmf = dm; dmf.by = 0;
   int rounds = 0, demand_rounds = 0;
   uint64_t demanded_total = 0;
   for (bool first = true;; first = false) {
@@ -1236,7 +1231,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
       hipMemsetAsync(W.n_changed, 0, 4, st);
       hipLaunchKernelGGL(k_parse_fix, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
                          W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, W.true_exits, W.fix_tok, W.fix_cnt,
-                         W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed, dm);
+                         W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed, dmf);
       uint32_t changed = 0;
       hipMemcpyAsync(&changed, W.n_changed, 4, hipMemcpyDeviceToHost, st);
       if (hip_check(c, hipStreamSynchronize(st), "parse_fix")) return ZADA_E_HIP_;
@@ -1252,9 +1247,9 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     if (demand_rounds > 1000) { c->err = "demand loop did not converge"; return ZADA_E_HIP_; }
     hipMemsetAsync(W.n_demand, 0, 4, st);
     hipMemsetAsync(W.chg, 0, nch, st);
-    hipLaunchKernelGGL(k_match_demand, dim3((uint32_t)((n + DMB - 1) / DMB)), dim3(DM_THREADS), DM_LDS, st, W.in, n, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
-                       W.blk_demand, W.chg);
-    hipMemsetAsync(W.blk_demand, 0, (size_t)nbm * 4, st);
+    hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, n, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
+                       W.blk_demand, W.chg, W.spec_exits);
+    hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   }
   if (getenv("ZADA_TRACE_DEMAND")) fprintf(stderr, "[demand] n=%llu budget=%d demand rounds=%d demanded=%llu (%.2f%% of positions) fix rounds=%d\n",
                                            (unsigned long long)n, budget_env, demand_rounds, (unsigned long long)demanded_total, 100.0 * demanded_total / n, rounds);
