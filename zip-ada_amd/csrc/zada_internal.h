@@ -114,7 +114,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   Workspace ws;
   std::string err;
-  int parse_rounds = 0;
+  int parse_rounds = 0, demand_rounds = 0;
   // timing
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<const char *, hipEvent_t>> marks;

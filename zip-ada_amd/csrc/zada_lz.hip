@@ -23,7 +23,6 @@
 #include "zada_internal.h"
 #include <stdio.h>
 #include <stdlib.h>
-#include <unistd.h>
 
 namespace zada {
 
@@ -455,9 +454,6 @@ __global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ 
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
   // level 3 first: the previous segment's bucket of the 15-bit hash, newest first
   uint32_t dprev = dp.d[0][p];
-#ifdef ZADA_EXP_XD_NO3
-  if (dprev == DIST3_CONTINUE) dprev = 0;
-#endif
   if (dprev == DIST3_CONTINUE) {
     const uint32_t my24 = *(const u32u *)(in + p) & 0xFFFFFFu;
     const uint32_t b0 = my24 & 0xFF, b1 = (my24 >> 8) & 0xFF;
@@ -503,9 +499,6 @@ __global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ 
   // than the nearest L-1 byte match.
   for (int l = 0; l + 1 < NLEVELS; l++) {
     uint32_t dl = dp.d[1 + l][p];
-#ifdef ZADA_EXP_XD_NO45
-    if (dl == DIST3_CONTINUE) dl = 0;
-#endif
     if (dl == DIST3_CONTINUE) {
       dl = 0;
       if (dprev != 0) {
@@ -592,25 +585,23 @@ __device__ __forceinline__ uint64_t lds_u64_at(const uint8_t *b, uint32_t o) {
 }
 #define LDS_U16(b, o) ((uint32_t)(b)[(o)] | ((uint32_t)(b)[(o) + 1] << 8))
 
-// Persistent-lane formulation: every lane owns one position at a time and runs a two-mode state
-// machine; a lane whose position is finished fetches the next one at once, so a wave never waits
-// for its longest chain.  Mode 0 = advance to the next candidate and test the two bytes that must
-// match for it to beat `best` (:754-757); mode 1 = compare 4 more bytes of a surviving candidate.
-// Both modes share one instruction stream: two unaligned LDS dwords at (cand + off), (scan + off).
+// First pass of the match finder: a BOUNDED search for every position (see lz_stage: "demand driven").
+// 16 KiB of positions per workgroup, window bytes and last-level links in LDS.  Persistent lanes: every lane owns
+// one position at a time; a lane whose position is finished (or has used up its budget) takes the next one at
+// once.  Each round = ZADA_FAST "fast" steps (follow the link, test the two bytes a candidate must share to beat
+// `best`, :754-757) with no side paths, then one batched "slow" phase for everything rare: eight-byte compares of
+// the survivors, improvements, limits, results.
 __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, uint64_t n,
                                                 const uint16_t *__restrict__ prevd,
                                                 DistPlanes dp,
                                                 MatchPair *__restrict__ M,
-                                                int nice_cfg, int budget, uint32_t *__restrict__ blk_demand,
-                                                uint8_t *__restrict__ chg, unsigned long long *__restrict__ dbg) {
+                                                int nice_cfg, int budget, unsigned long long *__restrict__ dbg) {
   // Every position of the block is searched for at most `budget` rounds of ZADA_FAST chain steps; a search cut
   // short leaves its best so far as a guess (M_GUESS) that k_match_demand replaces if a parse ever lands on it.
-  constexpr bool demand_pass = false;              // the demand pass is k_match_demand
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // WBYTES bytes
   uint16_t *lnk = (uint16_t *)(smem + WBYTES);                    // WLINKS * 2 bytes
-  uint32_t *next_pos = (uint32_t *)(smem + WBYTES + WLINKS * 2);     // one work counter per chain-length class
-  uint32_t *cls = next_pos + 4;                                      // 2 bits per position, MB / 16 words
+  uint32_t *next_pos = (uint32_t *)(smem + WBYTES + WLINKS * 2);     // work counter
 #ifdef ZADA_MATCH_STATS
   unsigned long long t_start = clock64(), t_empty = 0, iters = 0;
 #endif
@@ -632,54 +623,27 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     if (tid < 4) next_pos[tid] = 0;
   }
   __syncthreads();
-  // Longest-chains-first scheduling: estimate every position's chain length from the span of its
-  // first 8 links and give it a class (2 = long, 1 = medium, 0 = short).  Classes are drained in
-  // descending order so that the 4096-step walks start first and do not form the block's tail.
-  if (demand_pass) {
-    uint32_t word = 0;
-    for (int j = 0; j < 16; j++) {
-      const uint32_t k = (uint32_t)tid * 16 + j;
-      uint32_t c = 0;
-      if (k < cnt && (M[B + k].full & (M_GUESS | M_DEMAND)) != (M_GUESS | M_DEMAND)) c = 3;   // nothing to do
-      else if (k < cnt) {
-        uint32_t q = woff + k, span = 0; int hops = 0;
-        for (; hops < 8; hops++) { const uint32_t d = lnk[q]; if (d == 0 || span + d > 32505u) break; span += d; q -= d; }
-        c = hops < 8 ? 0u : (span <= 512u ? 2u : (span <= 4096u ? 1u : 0u));
-      }
-      word |= c << (2 * j);
-    }
-    cls[tid] = word;
-  } else cls[tid] = 0;                                             // first pass: bounded searches, any order
-  __syncthreads();
-  if (demand_pass && tid == 0) blk_demand[blockIdx.x] = 0;
   const uint8_t *win8 = (const uint8_t *)win;
   // Per-lane walker: state 0 = FREE (needs a position), 1 = WALK (fast filter steps), 2 = EVENT
   // (its current candidate passed the two-byte filter and/or its chain ended / hit a limit).
   // FAST PHASE: ZADA_FAST filter steps with no side paths; SLOW PHASE: everything rare, once per round.
   uint32_t wi = woff, cur = woff, ncur = woff, bdist = 0, rq = 0, kpos = 0, s_end = 0;
-  int best = 2, la = 3, nice = 3, state = 0, pass_cls = demand_pass ? 2 : 0;
+  int best = 2, la = 3, nice = 3, state = 0;
   uint32_t lim_cur = 0, lim_full = 0;
   bool have_q = false, ev_pass = false, ev_end = false, ev_lim = false, exhausted = false;
   int age = 0;                                                     // rounds spent on the current position
-  uint32_t old_full = 0, old_quarter = 0;                          // demand pass: the guess being replaced
   for (;;) {
     // ---- fetch ----
     const bool need = (state == 0) && !exhausted;
     if (__any(need)) {
       if (need) {
-        uint32_t k = 0;
-        for (;;) {                                                 // next position of the current class
-          k = atomicAdd(&next_pos[pass_cls], 1u);
-          if (k >= cnt) { if (pass_cls == 0) break; pass_cls--; continue; }
-          if (((cls[k >> 4] >> (2 * (k & 15))) & 3u) == (uint32_t)pass_cls) break;
-        }
+        const uint32_t k = atomicAdd(&next_pos[0], 1u);             // next position of the block (bounded searches: any order will do)
 #ifdef ZADA_MATCH_STATS
         if (k >= cnt && t_empty == 0) t_empty = clock64();
 #endif
         if (k >= cnt) exhausted = true;
         else {
           kpos = k; wi = woff + k; age = 0;
-          if (demand_pass) { const MatchPair og = M[B + k]; old_full = og.full & M_VALUE; old_quarter = og.quarter; }
           const uint64_t rem = n - (B + k);
           la = rem < 258 ? (int)rem : 258;                         // Longest_Match never returns more
           nice = nice_cfg < la ? nice_cfg : la;                    // lz77.adb:858-860
@@ -725,9 +689,6 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     // ---- fast phase ----
 #pragma unroll
     for (int it = 0; it < ZADA_FAST; it++) {
-#ifdef ZADA_MINACT
-      if (it >= 2 && __popcll(__ballot(state == 1)) < ZADA_MINACT) break;
-#endif
       if (state == 1) {
 #ifdef ZADA_MATCH_STATS
         iters++;
@@ -778,10 +739,6 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
         if (fin) {
           MatchPair r; r.full = packed; r.quarter = have_q ? rq : packed;
           M[B + kpos] = r;
-          if (demand_pass && (r.full != old_full || r.quarter != old_quarter)) {
-            const uint64_t ch = (B + kpos) / PCHUNK;
-            chg[ch] = 1; if (ch > 0) chg[ch - 1] = 1;
-          }
           state = 0;
         } else {
           cur = ncur;
@@ -790,7 +747,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
       }
     }
     // first pass: a search that has had its share of rounds is cut short, its best so far becomes a guess
-    if (!demand_pass && state == 1 && ++age >= budget) {
+    if (state == 1 && ++age >= budget) {
       const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
       MatchPair r; r.full = packed | M_GUESS; r.quarter = have_q ? rq : packed;
       M[B + kpos] = r;
@@ -1170,7 +1127,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   if (!attr_done) {
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
     hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16 + MB / 4);
+    hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16);
     hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
     attr_done = true;
   }
@@ -1210,14 +1167,13 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   const uint32_t nbd = (uint32_t)((n + DMB - 1) / DMB);
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
-  hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), WBYTES + WLINKS * 2 + 16 + MB / 4, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
-                     budget_env, W.blk_demand, W.chg, (unsigned long long *)W.dbg);
+  hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), WBYTES + WLINKS * 2 + 16, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
+                     budget_env, (unsigned long long *)W.dbg);
   c->tmark("match");
   ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg;
   DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand; dm.by = M_BYSPEC;
   DemandMarker dmf = dm; dmf.by = 0;
   int rounds = 0, demand_rounds = 0;
-  uint64_t demanded_total = 0;
   for (bool first = true;; first = false) {
     // speculative parse: every chunk the first time, afterwards the chunks flagged by the demand pass
     hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
@@ -1242,8 +1198,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     uint32_t ndem = 0;
     hipMemcpy(&ndem, W.n_demand, 4, hipMemcpyDeviceToHost);
     if (ndem == 0) break;
-    demanded_total += ndem; demand_rounds++;
-    if (getenv("ZADA_TRACE_DEMAND")) { fprintf(stderr, "[demand] round %d: fix rounds so far %d\n", demand_rounds, rounds); fflush(stderr); }
+    demand_rounds++;
     if (demand_rounds > 1000) { c->err = "demand loop did not converge"; return ZADA_E_HIP_; }
     hipMemsetAsync(W.n_demand, 0, 4, st);
     hipMemsetAsync(W.chg, 0, nch, st);
@@ -1251,8 +1206,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
                        W.blk_demand, W.chg, W.spec_exits);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   }
-  if (getenv("ZADA_TRACE_DEMAND")) fprintf(stderr, "[demand] n=%llu budget=%d demand rounds=%d demanded=%llu (%.2f%% of positions) fix rounds=%d\n",
-                                           (unsigned long long)n, budget_env, demand_rounds, (unsigned long long)demanded_total, 100.0 * demanded_total / n, rounds);
+  c->demand_rounds = demand_rounds;
   c->parse_rounds = rounds;
   c->tmark("parse");
   hipLaunchKernelGGL(k_tok_count, dim3((nch + 255) / 256), dim3(256), 0, st, nch, W.spec_cnt, W.fix_cnt, W.take_from, W.counts);
