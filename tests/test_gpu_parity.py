@@ -88,6 +88,19 @@ def test_never_resynchronising_inputs(encoder):
             assert rc == rc2 and out == ref and crc == crc2
 
 
+def test_lds_atomics_return_in_lane_order(tmp_path):
+    """The radix passes of k_prev_links take an element's rank from the value an LDS atomicAdd returns, which is
+    stable only if lanes of one instruction that hit the same counter are served in lane order.  That is a property
+    of the hardware, not of the ISA document: check it here (65 M samples per digit count)."""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "lds_atomic_order.hip")
+    exe = str(tmp_path / "lds_atomic_order")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", src, "-o", exe], check=True, capture_output=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("digits")]
+    assert len(lines) == 7 and all(" results 0 of " in l for l in lines), out
+
+
 def test_demand_driven_matching_is_budget_independent(encoder):
     """The first pass gives every position a bounded search and the exact search only happens where a parse
     lands.  The stream must not depend on the bound: tiny budget (nearly everything is a guess

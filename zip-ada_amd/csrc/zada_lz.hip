@@ -75,11 +75,19 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&key)[16], const uint3
   for (int i = tid; i < NDIG * 16; i += 1024) cnt[i] = 0;
   __syncthreads();
   uint32_t *mycnt = cnt + w * NDIG;
-  // phase A: per (wave, digit) histogram
+  // phase A: per (wave, digit) histogram; the value an element gets back is its rank among the wave's elements with
+  // the same digit, in element order: the wave's instructions are issued in element order, and within one
+  // instruction the LDS unit serialises lanes that hit the same counter in lane order (checked on the hardware by
+  // tests/probes/lds_atomic_order.hip and, end to end, by every parity test).  Ranks are kept packed two per register.
+  uint32_t rk[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) rk[k] = 0;
 #pragma unroll
   for (int it = 0; it < 32; it++) {
     const uint32_t d = ((key[it >> 1] >> (16 * (it & 1))) >> SHIFT) & (uint32_t)(NDIG - 1);
-    if (it * 64 < rem) atomicAdd(&mycnt[d], 1u);                 // [wave][digit]: lanes spread over the banks
+    uint32_t r = 0;
+    if (it * 64 < rem) r = atomicAdd(&mycnt[d], 1u);
+    rk[it >> 1] |= r << (16 * (it & 1));
   }
   __syncthreads();
   // phase B: exclusive scan over (digit major, wave minor)
@@ -97,27 +105,17 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&key)[16], const uint3
     for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; cnt[(idx & 15) * NDIG + (idx >> 4)] = run; run += v[k]; }
   }
   __syncthreads();
-  // phase C: stable scatter, 64 elements per wave step, ranks by ballot multi-split
-  const unsigned long long ltmask = (1ull << lane) - 1ull;
+  // phase C: stable scatter
 #pragma unroll
   for (int it = 0; it < 32; it++) {
-    const bool act = it * 64 < rem;
-    const uint32_t k16 = (key[it >> 1] >> (16 * (it & 1))) & 0xFFFFu;
-    const uint32_t d = (k16 >> SHIFT) & (uint32_t)(NDIG - 1);
-    unsigned long long mask = __ballot(act);
-    for (int b = 0; (1 << b) < NDIG; b++) {
-      unsigned long long bal = __ballot((d >> b) & 1);
-      mask &= ((d >> b) & 1) ? bal : ~bal;
-    }
-    if (act) {
+    if (it * 64 < rem) {
+      const uint32_t k16 = (key[it >> 1] >> (16 * (it & 1))) & 0xFFFFu;
+      const uint32_t d = (k16 >> SHIFT) & (uint32_t)(NDIG - 1);
       const uint32_t e = LINEAR ? i0 + it * 64 : ((el[it >> 1] >> (16 * (it & 1))) & 0xFFFFu);
-      uint32_t rank = __popcll(mask & ltmask), tot = __popcll(mask);
-      uint32_t base = mycnt[d];
-      dstE[base + rank] = (uint16_t)e;
-      dstK[base + rank] = (uint16_t)k16;
-      if (rank == tot - 1) mycnt[d] = base + tot;   // last lane of the group advances the cursor
+      const uint32_t pos = mycnt[d] + ((rk[it >> 1] >> (16 * (it & 1))) & 0xFFFFu);
+      dstE[pos] = (uint16_t)e;
+      dstK[pos] = (uint16_t)k16;
     }
-    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
 }
@@ -779,7 +777,10 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 // value of lane j (j wave uniform) of a vector register, as a scalar
 #define RL(v, j) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (j)))
 #define RL64(v, j) ((uint64_t)RL((uint32_t)(v), (j)) | ((uint64_t)RL((uint32_t)((v) >> 32), (j)) << 32))
-constexpr int DM_THREADS = 512, DMB = 4096, DM_SLICE = 256;
+#ifndef ZADA_DM_THREADS
+#define ZADA_DM_THREADS 512
+#endif
+constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256;
 constexpr int DM_WBYTES = HALO + DMB + 272;
 struct ScanDesc {                                  // a position whose candidates have to be scanned (32 bytes, in LDS)
   uint16_t k, la, idx1, c1, idx2, c2, lim_full, lim_q;
