@@ -1,7 +1,7 @@
 // zada_internal.h -- context, workspace layout and shared constants of libzada_hip.so
 #pragma once
 #ifndef ZADA_NLEVELS
-#define ZADA_NLEVELS 3
+#define ZADA_NLEVELS 2
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>

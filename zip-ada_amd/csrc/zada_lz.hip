@@ -1164,7 +1164,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   const uint32_t nbm = (uint32_t)((n + MB - 1) / MB);
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
   int budget_env;                                  // read at every call: the tests compare budgets within one process
-  { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : 6; if (budget_env < 1) budget_env = 1 << 20; }
+  { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : 8; if (budget_env < 1) budget_env = 1 << 20; }
   const uint32_t nbd = (uint32_t)((n + DMB - 1) / DMB);
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
