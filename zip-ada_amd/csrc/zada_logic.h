@@ -143,8 +143,10 @@ struct BitmapWriter {
 
 // Runs the reference parser (lz77.adb:838-932) from state `s` until on_top(s) returns true at the
 // top of the loop, or the input ends (then the trailing literal :930-932 is emitted).
-template <typename OnTop, typename OnGuess>
-ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_t &ntok, OnTop &&on_top, OnGuess &&on_guess) {
+// Fetch: how a match record is read (the GPU parser keeps the 64-byte line of its last look-up in LDS).
+struct DirectFetch { const MatchPair *M; ZADA_HD MatchPair operator()(uint32_t p) const { return M[p]; } };
+template <typename OnTop, typename OnGuess, typename Fetch>
+ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_t &ntok, OnTop &&on_top, OnGuess &&on_guess, Fetch &&fetch) {
   for (;;) {
     if ((uint64_t)s.p >= io.n) {
       if (s.avail) { tok[ntok++] = io.in[io.n - 1]; s.avail = 0; s.mlen = 2; }
@@ -155,7 +157,7 @@ ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_
     const bool srch = parse_searches(s, io.cfg, la);
     uint32_t m = 0;
     if (srch) {
-      const MatchPair mm = io.M[s.p];
+      const MatchPair mm = fetch(s.p);
       if (mm.full & M_GUESS) on_guess(s.p, mm.full);
       m = (parse_need_quarter(s, io.cfg) ? mm.quarter : mm.full) & M_VALUE;
     }
@@ -168,9 +170,9 @@ ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_
 // Speculative parse of chunk k, started in the fresh state at its first byte.  Records every
 // history-free state inside the chunk (F / L bitmaps) and stops at the first one at or beyond the
 // chunk's end (the chunk's exit); exit = (n, F) when the input ends first.
-template <typename OnGuess = NoGuess>
+template <typename OnGuess, typename Fetch>
 ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uint32_t *tok, uint32_t &ntok,
-                              uint32_t *Fbits, uint32_t *Lbits, ExitState &ex, OnGuess on_guess = OnGuess()) {
+                              uint32_t *Fbits, uint32_t *Lbits, ExitState &ex, OnGuess on_guess, Fetch &&fetch) {
   const uint64_t c0 = (uint64_t)k * chunk, c1 = (c0 + chunk < io.n) ? c0 + chunk : io.n;
   ParseState s{(uint32_t)c0, 0, 2, 0};
   BitmapWriter fw, lw;
@@ -182,20 +184,24 @@ ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uin
     if ((uint64_t)st.p >= c1) { e.pos = st.p; e.kind = (uint32_t)kind; return true; }
     if (kind == SYNC_F) fw.set(st.p); else lw.set(st.p);
     return false;
-  }, on_guess);
+  }, on_guess, fetch);
   fw.finish((c1 - 1) >> 5);
   lw.finish((c1 - 1) >> 5);
   ex = e;
+}
+ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uint32_t *tok, uint32_t &ntok,
+                                     uint32_t *Fbits, uint32_t *Lbits, ExitState &ex) {
+  parse_spec_chunk(io, k, chunk, tok, ntok, Fbits, Lbits, ex, NoGuess(), DirectFetch{io.M});
 }
 
 // True parse of chunk k from the true exit of chunk k-1 (`entry`) until it reaches a history-free
 // state that the speculative parse of chunk k also went through (then the rest of the speculative
 // tokens, from index `take`, are the true ones), or leaves the chunk unsynchronised.
-template <typename OnGuess = NoGuess>
+template <typename OnGuess, typename Fetch>
 ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, ExitState entry,
                              const uint32_t *spec_tok, uint32_t spec_cnt, const uint32_t *Fbits, const uint32_t *Lbits,
                              ExitState spec_exit, uint32_t *tok, uint32_t &ntok, uint32_t &take, uint32_t &u0, ExitState &new_exit,
-                             OnGuess on_guess = OnGuess()) {
+                             OnGuess on_guess, Fetch &&fetch) {
   const uint64_t c0 = (uint64_t)k * chunk, c1 = (c0 + chunk < io.n) ? c0 + chunk : io.n;
   u0 = entry.kind == SYNC_L ? entry.pos - 1 : entry.pos;      // first byte not yet emitted at entry
   ntok = 0;
@@ -215,7 +221,7 @@ ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, Exit
     uint32_t wbits = (kind == SYNC_F ? Fbits : Lbits)[st.p >> 5];
     if ((wbits >> (st.p & 31)) & 1) { synced = true; e.pos = st.p; e.kind = (uint32_t)kind; return true; }
     return false;
-  }, on_guess);
+  }, on_guess, fetch);
   if (synced) {
     const uint32_t u = e.kind == SYNC_L ? e.pos - 1 : e.pos;
     uint32_t cur = (uint32_t)c0, j = 0;
@@ -226,6 +232,11 @@ ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, Exit
     take = spec_cnt;
     new_exit = e;
   }
+}
+ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, ExitState entry,
+                                    const uint32_t *spec_tok, uint32_t spec_cnt, const uint32_t *Fbits, const uint32_t *Lbits,
+                                    ExitState spec_exit, uint32_t *tok, uint32_t &ntok, uint32_t &take, uint32_t &u0, ExitState &new_exit) {
+  parse_fix_chunk(io, k, chunk, entry, spec_tok, spec_cnt, Fbits, Lbits, spec_exit, tok, ntok, take, u0, new_exit, NoGuess(), DirectFetch{io.M});
 }
 
 // ----- Huffman.Encoding.Length_Limited_Coding, lane-serial form -----

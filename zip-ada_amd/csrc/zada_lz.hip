@@ -978,6 +978,29 @@ struct DemandMarker {
   }
 };
 
+// The parser's look-ups walk forward through the 8-byte match records, landing on every third or so: fetching each
+// record on its own pulls the same 64-byte line from HBM several times (PMC: 27 GB per parse of 1 GiB, three times
+// the table).  Each lane keeps the line of its last look-up in LDS (lane-interleaved, so lanes never share a bank).
+struct LineFetch {
+  const MatchPair *M; uint64_t *slot;              // slot[r * 64] = record r of the cached line, for this lane
+  uint32_t tag;
+  __device__ MatchPair operator()(uint32_t p) {
+    const uint32_t t = p >> 3;
+    if (t != tag) {
+      const uint4 *src = (const uint4 *)(M + ((uint64_t)t << 3));
+      const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+      slot[0 * 64] = (uint64_t)a.x | ((uint64_t)a.y << 32); slot[1 * 64] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+      slot[2 * 64] = (uint64_t)b.x | ((uint64_t)b.y << 32); slot[3 * 64] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+      slot[4 * 64] = (uint64_t)c.x | ((uint64_t)c.y << 32); slot[5 * 64] = (uint64_t)c.z | ((uint64_t)c.w << 32);
+      slot[6 * 64] = (uint64_t)d.x | ((uint64_t)d.y << 32); slot[7 * 64] = (uint64_t)d.z | ((uint64_t)d.w << 32);
+      tag = t;
+    }
+    const uint64_t v = slot[(p & 7u) * 64];
+    MatchPair r; r.full = (uint32_t)v; r.quarter = (uint32_t)(v >> 32);
+    return r;
+  }
+};
+
 __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict__ spec_tok, uint32_t *__restrict__ spec_cnt,
                              uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits,
                              DemandMarker dm, const uint8_t *__restrict__ redo /* null: every chunk */) {
@@ -986,7 +1009,9 @@ __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict_
   if (redo && !redo[k]) return;
   uint32_t ntok = 0;
   ExitState ex;
-  parse_spec_chunk(io, k, PCHUNK, spec_tok + (uint64_t)k * PTOK_STRIDE, ntok, Fbits, Lbits, ex, dm);
+  __shared__ uint64_t lines[8 * 64];
+  LineFetch lf; lf.M = io.M; lf.slot = lines + threadIdx.x; lf.tag = 0xFFFFFFFFu;
+  parse_spec_chunk(io, k, PCHUNK, spec_tok + (uint64_t)k * PTOK_STRIDE, ntok, Fbits, Lbits, ex, dm, lf);
   spec_cnt[k] = ntok;
   exits[k] = ex;
 }
@@ -1009,7 +1034,7 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
   ExitState new_exit;
   uint32_t ntok = 0, take = 0, u0 = 0;
   parse_fix_chunk(io, k, PCHUNK, entry, spec_tok + (uint64_t)k * PTOK_STRIDE, spec_cnt[k], Fbits, Lbits, spec_exits[k],
-                  fix_tok + (uint64_t)k * PTOK_STRIDE, ntok, take, u0, new_exit, dm);
+                  fix_tok + (uint64_t)k * PTOK_STRIDE, ntok, take, u0, new_exit, dm, DirectFetch{io.M});
   fix_cnt[k] = ntok;
   take_from[k] = take;
   start_pos[k] = u0;
