@@ -3,18 +3,22 @@
 // Reference semantics: zip_lib/lz77.adb:460-943 (Info-Zip deflate_slow).  The sequential
 // algorithm is refactored into data-parallel passes that compute the SAME token stream:
 //
-//   k_prev_links     per 32 KiB segment: stable LDS radix sort of positions by the 15-bit hash
-//                    (UPDATE_HASH, :553-557) -> for every position the distance to the nearest
-//                    earlier position with the same hash (what INSERT_STRING's prev[] chain
-//                    holds, :566-573); + per-segment tail table
-//   k_cross_links    links the first position of each hash bucket to the previous segment's tail
-//   k_match          Longest_Match (:715-825) for EVERY position, window + chain links staged in
-//                    LDS; produces the full-chain and quarter-chain results (good_match rule :733)
-//   k_parse_spec     lazy-evaluation parser (:827-933), one lane per 4 KiB chunk, speculatively
-//                    started in the fresh state at each chunk boundary
+//   k_prev_links     per 32 KiB segment, for the reference's 15-bit hash (UPDATE_HASH, :553-557) and for 16-bit
+//                    hashes of the first 4 .. 3+NLEVELS bytes: stable LDS radix sort of the positions; links to
+//                    the previous position of the same bucket (what INSERT_STRING's prev[] holds, :566-573),
+//                    nearest true 3 .. 2+NLEVELS byte match of every position, sorted orders, tail tables
+//   k_cross_links    links the first position of each bucket to the previous segment's tail
+//   k_cross_dist     continues the nearest-match searches that did not end inside their own segment
+//   k_bucket_limits  the chain-length limits (max_chain_length, and a quarter of it: :733-735) as distances
+//   k_match          Longest_Match (:715-825), BOUNDED, for every position; window + links staged in LDS;
+//                    full-chain and quarter-chain results, or a guess when the budget ran out
+//   k_parse_spec     lazy-evaluation parser (:827-933), one lane per 1 KiB chunk, speculatively
+//                    started in the fresh state at each chunk boundary; marks the guesses it lands on
 //   k_parse_fix      re-parses from the previous chunk's true exit state until it meets a
 //                    history-free state of the speculative parse (splice); iterated to a fixpoint
+//   k_match_demand   exact Longest_Match of the marked guesses, one wave per position over the sorted order
 //   k_tok_count / k_tok_compact   gather the true tokens into one global atom array
+//   lz_stage         host driver: first pass, then parse / demand rounds until a parse has used exact values only
 //
 // Why the result is identical to the sequential reference: see DESIGN.md "LZ77 stage".
 #include <hip/hip_runtime.h>
