@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 #ifndef ZADA_DM_THREADS
 #define ZADA_DM_THREADS 512
 #endif
-constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256;
+constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256, DM_AHEAD = 8;
 constexpr int DM_WBYTES = HALO + DMB + 272;
 struct ScanDesc {                                  // a position whose candidates have to be scanned (32 bytes, in LDS)
   uint16_t k, la, idx1, c1, idx2, c2, lim_full, lim_q;
@@ -920,13 +920,11 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
         const uint32_t *w = (const uint32_t *)(win8 + (o & ~3u));
         return __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u);
       };
-      uint32_t dn2 = TT > 64 ? cand(ds, 64 + (uint32_t)lane) : 0u;   // the batch after this one, on its way
-      for (uint32_t c0 = 0; c0 < TT && !over; c0 += 64) {
-        if (c0 > 0) { d = dn2; dn2 = c0 + 64 < TT ? cand(ds, c0 + 64 + (uint32_t)lane) : 0u; }
-        // One batch of 64 candidates (distances d, nearest first).  All of them are filtered at once against the best
-        // so far (:754-757); the survivors are then taken in order, exactly like the sequential walk (:812-822):
-        // the whole wave compares one candidate with the scanned string, four bytes per lane, and if it is longer
-        // it becomes the best and the remaining survivors are filtered again.
+      // One batch of 64 candidates (distances d, nearest first).  All of them are filtered at once against the best
+      // so far (:754-757); the survivors are then taken in order, exactly like the sequential walk (:812-822):
+      // the whole wave compares one candidate with the scanned string, four bytes per lane, and if it is longer
+      // it becomes the best and the remaining survivors are filtered again.
+      auto batch = [&](uint32_t d) {
         const bool valid = d != 0;
         const bool inr = valid && d <= LF;
         bool pass = false;
@@ -954,6 +952,22 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
         if (!over && !hq && __any(valid && d > LQ)) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }
         // beyond the limit, or position 0, or no more candidates: the chain ends (:819-822)
         if (__any(!inr)) over = true;
+      };
+      // DM_AHEAD batches are kept on their way from the sorted order (a batch is worked off much faster than it arrives)
+      uint32_t dq[DM_AHEAD];
+      dq[0] = d;
+#pragma unroll
+      for (int u = 1; u < DM_AHEAD; u++) dq[u] = 64u * u < TT ? cand(ds, 64u * u + (uint32_t)lane) : 0u;
+      for (uint32_t c0 = 0; c0 < TT && !over; c0 += 64 * DM_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < DM_AHEAD; u++) {
+          if (c0 + 64u * u < TT && !over) {
+            const uint32_t dcur = dq[u];
+            const uint32_t cn = c0 + 64u * (u + DM_AHEAD);
+            dq[u] = cn < TT ? cand(ds, cn + (uint32_t)lane) : 0u;
+            batch(dcur);
+          }
+        }
       }
       if (lane == 0) {
         const uint32_t packed = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u;
