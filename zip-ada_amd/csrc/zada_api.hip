@@ -183,35 +183,49 @@ static void zero_advance_matrix(uint64_t len, uint32_t *out) {
   memcpy(out, acc, sizeof acc);
 }
 
-int crc_stage(Ctx *c, uint64_t n, uint32_t *crc_inout) {
+// CRC-32 runs on a second stream, next to the LZ stage (its kernels have no LDS and fit beside the one-workgroup-
+// per-CU kernels): crc_launch queues the kernels and the copies of the few values the host has to chain,
+// crc_finish waits for them and chains.
+constexpr int CRC_NLEV = 4;
+static uint32_t crc_M[CRC_NLEV][32];
+int crc_launch(Ctx *c, uint64_t n) {
   if (n == 0) return 0;
   Workspace &W = c->ws;
+  CrcPending &P = c->crc;
   // level 0: one value per CRC_SUB (256 B); levels 1..3 fold 16:1 (4 KiB, 64 KiB, 1 MiB); only FULL
   // groups are folded on the device, the host chains the few leftovers of every level
-  constexpr int NLEV = 4;
-  static uint32_t M[NLEV][32];
   static bool mats = false;
-  if (!mats) { for (int l = 0; l < NLEV; l++) zero_advance_matrix((uint64_t)CRC_SUB << (4 * l), M[l]); mats = true; }
-  const uint32_t nsub = (uint32_t)((n + CRC_SUB - 1) / CRC_SUB);
-  const uint32_t nfull0 = (uint32_t)(n / CRC_SUB);                     // full level-0 values
-  uint32_t cnt[NLEV];
-  cnt[0] = nfull0;
-  for (int l = 1; l < NLEV; l++) cnt[l] = cnt[l - 1] / 16;
-  hipMemcpyAsync(W.crc_mat, M, sizeof(uint32_t) * 32 * (NLEV - 1), hipMemcpyHostToDevice, c->stream);
-  hipLaunchKernelGGL(k_crc_chunks, dim3((nsub + 255) / 256), dim3(256), 0, c->stream, W.in, n, nsub, W.crc_lvl[0]);
-  for (int l = 1; l < NLEV; l++)
-    if (cnt[l]) hipLaunchKernelGGL(k_crc_fold, dim3((cnt[l] + 255) / 256), dim3(256), 0, c->stream, W.crc_lvl[l - 1], cnt[l], W.crc_mat + 32 * (l - 1), W.crc_lvl[l]);
+  if (!mats) { for (int l = 0; l < CRC_NLEV; l++) zero_advance_matrix((uint64_t)CRC_SUB << (4 * l), crc_M[l]); mats = true; }
+  hipStream_t s2 = c->stream2;
+  hipEventRecord(c->ev_input, c->stream);                            // the input (and its zero pad) is in place
+  hipStreamWaitEvent(s2, c->ev_input, 0);
+  P.nsub = (uint32_t)((n + CRC_SUB - 1) / CRC_SUB);
+  P.nfull0 = (uint32_t)(n / CRC_SUB);                                // full level-0 values
+  P.cnt[0] = P.nfull0;
+  for (int l = 1; l < CRC_NLEV; l++) P.cnt[l] = P.cnt[l - 1] / 16;
+  if (!W.crc_mat_ready) { hipMemcpyAsync(W.crc_mat, crc_M, sizeof(uint32_t) * 32 * (CRC_NLEV - 1), hipMemcpyHostToDevice, s2); W.crc_mat_ready = true; }
+  hipLaunchKernelGGL(k_crc_chunks, dim3((P.nsub + 255) / 256), dim3(256), 0, s2, W.in, n, P.nsub, W.crc_lvl[0]);
+  for (int l = 1; l < CRC_NLEV; l++)
+    if (P.cnt[l]) hipLaunchKernelGGL(k_crc_fold, dim3((P.cnt[l] + 255) / 256), dim3(256), 0, s2, W.crc_lvl[l - 1], P.cnt[l], W.crc_mat + 32 * (l - 1), W.crc_lvl[l]);
   // values the host needs: all of the top level, and per lower level the < 16 values after the last full group
-  std::vector<uint32_t> top(cnt[NLEV - 1] ? cnt[NLEV - 1] : 1);
-  uint32_t rest[NLEV][16];
-  uint32_t nrest[NLEV];
-  if (cnt[NLEV - 1]) hipMemcpyAsync(top.data(), W.crc_lvl[NLEV - 1], (size_t)cnt[NLEV - 1] * 4, hipMemcpyDeviceToHost, c->stream);
-  for (int l = 0; l < NLEV - 1; l++) {
-    const uint32_t first = cnt[l + 1] * 16;
-    nrest[l] = (l == 0 ? nsub : cnt[l]) - first;                         // level 0 includes the final short value
-    if (nrest[l]) hipMemcpyAsync(rest[l], W.crc_lvl[l] + first, (size_t)nrest[l] * 4, hipMemcpyDeviceToHost, c->stream);
+  P.top.resize(P.cnt[CRC_NLEV - 1] ? P.cnt[CRC_NLEV - 1] : 1);
+  if (P.cnt[CRC_NLEV - 1]) hipMemcpyAsync(P.top.data(), W.crc_lvl[CRC_NLEV - 1], (size_t)P.cnt[CRC_NLEV - 1] * 4, hipMemcpyDeviceToHost, s2);
+  for (int l = 0; l < CRC_NLEV - 1; l++) {
+    const uint32_t first = P.cnt[l + 1] * 16;
+    P.nrest[l] = (l == 0 ? P.nsub : P.cnt[l]) - first;               // level 0 includes the final short value
+    if (P.nrest[l]) hipMemcpyAsync(P.rest[l], W.crc_lvl[l] + first, (size_t)P.nrest[l] * 4, hipMemcpyDeviceToHost, s2);
   }
-  if (hip_check(c, hipStreamSynchronize(c->stream), "crc")) return ZADA_E_HIP_;
+  return hip_check(c, hipGetLastError(), "crc launch");
+}
+
+int crc_finish(Ctx *c, uint64_t n, uint32_t *crc_inout) {
+  if (n == 0) return 0;
+  constexpr int NLEV = CRC_NLEV;
+  CrcPending &P = c->crc;
+  const uint32_t *cnt = P.cnt, *nrest = P.nrest;
+  const uint32_t nfull0 = P.nfull0;
+  auto &top = P.top; auto &rest = P.rest; auto &M = crc_M;
+  if (hip_check(c, hipStreamSynchronize(c->stream2), "crc")) return ZADA_E_HIP_;
   uint32_t r = *crc_inout;
   for (uint32_t k = 0; k < cnt[NLEV - 1]; k++) r = gf2_apply(M[NLEV - 1], r) ^ top[k];
   for (int l = NLEV - 2; l >= 0; l--) {
@@ -249,20 +263,24 @@ static int deflate_core(Ctx *c, int method, uint64_t n, uint64_t *out_len, uint3
   c->tmark("begin");
   hipMemsetAsync(W.in + n, 0, IN_PAD, st);
   for (int l = 0; l < NLEVELS; l++) hipMemsetAsync(W.lprev[l] + (n >= 2 ? n - 2 : 0), 0, 2 * 64, st);
-  hipMemsetAsync(W.out, 0, n + n / 1024 + 4096 < W.cap_out ? n + n / 1024 + 4096 : W.cap_out, st);
   uint32_t crc = crc_inout ? *crc_inout : 0xFFFFFFFFu;
-  int rc = crc_stage(c, n, &crc);
+  int rc = crc_launch(c, n);
   if (rc) return rc;
-  c->tmark("crc");
+  // the output bit stream is OR-ed together: zero it meanwhile, on the second stream
+  hipMemsetAsync(W.out, 0, n + n / 1024 + 4096 < W.cap_out ? n + n / 1024 + 4096 : W.cap_out, c->stream2);
+  hipEventRecord(c->ev_out, c->stream2);
   if (fb && fb(5, user)) return ZADA_ABORTED;
   uint32_t T = 0;
   rc = lz_stage(c, level, n, &T);
   if (rc) return rc;
   if (fb && fb(70, user)) return ZADA_ABORTED;
   uint64_t total_bits = 0;
+  hipStreamWaitEvent(st, c->ev_out, 0);
   rc = huff_stage(c, method, n, T, &total_bits);
   if (rc) return rc;
   if (hip_check(c, hipStreamSynchronize(st), "deflate")) return ZADA_E_HIP_;
+  rc = crc_finish(c, n, &crc);
+  if (rc) return rc;
   c->tmark("end");
   c->tend();
   if (fb && fb(100, user)) return ZADA_ABORTED;
@@ -288,6 +306,8 @@ zada_ctx *zada_create(int device) {
   if (!z) return nullptr;
   z->c.device = device;
   if (hipStreamCreate(&z->c.stream) != hipSuccess) { delete z; return nullptr; }
+  if (hipStreamCreate(&z->c.stream2) != hipSuccess || hipEventCreateWithFlags(&z->c.ev_input, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&z->c.ev_out, hipEventDisableTiming) != hipSuccess) { delete z; return nullptr; }
   return z;
 }
 
@@ -297,6 +317,10 @@ void zada_destroy(zada_ctx *z) {
   hipStreamSynchronize(z->c.stream);
   for (void *p : z->c.ws.allocs) hipFree(p);
   for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
+  hipStreamSynchronize(z->c.stream2);
+  hipStreamDestroy(z->c.stream2);
+  hipEventDestroy(z->c.ev_input);
+  hipEventDestroy(z->c.ev_out);
   hipStreamDestroy(z->c.stream);
   delete z;
 }

@@ -103,15 +103,21 @@ struct Workspace {
   uint32_t *tile_bits = nullptr;
   ChooserOut *chooser = nullptr;
   uint32_t *crc_lvl[4] = {nullptr, nullptr, nullptr, nullptr}, *crc_mat = nullptr;
+  bool crc_mat_ready = false;
   uint64_t *dbg = nullptr;
   uint8_t *out = nullptr;
   uint64_t cap_blocks = 0, cap_tiles = 0, cap_pieces = 0, cap_out = 0;
   std::vector<void *> allocs;
 };
 
+// host side of a CRC-32 in flight (crc_launch / crc_finish)
+struct CrcPending { uint32_t nsub = 0, nfull0 = 0, cnt[4] = {0, 0, 0, 0}, nrest[4] = {0, 0, 0, 0}; uint32_t rest[4][16]; std::vector<uint32_t> top; };
+
 struct Ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: CRC-32, next to the LZ stage
+  hipEvent_t ev_input = nullptr, ev_out = nullptr;
+  CrcPending crc;
   Workspace ws;
   std::string err;
   int parse_rounds = 0, demand_rounds = 0;
@@ -131,7 +137,8 @@ int hip_check(Ctx *c, hipError_t e, const char *what);
 int ensure_workspace(Ctx *c, uint64_t n);
 int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out);
 int huff_stage(Ctx *c, int method, uint64_t n, uint32_t T, uint64_t *total_bits);
-int crc_stage(Ctx *c, uint64_t n, uint32_t *crc_inout);
+int crc_launch(Ctx *c, uint64_t n);
+int crc_finish(Ctx *c, uint64_t n, uint32_t *crc_inout);
 void exclusive_scan_u32(hipStream_t st, const uint32_t *d_in, uint32_t *d_out, uint32_t *d_sums, uint32_t *d_total, uint32_t n);
 
 }  // namespace zada
