@@ -139,7 +139,7 @@ def main():
     for _ in range(args.steps):
         rc, out_len, crc = step()
         for k, v in enc.last_timing():
-            phase_ms[k] = phase_ms.get(k, 0.0) + v
+            phase_ms[k] = phase_ms.get(k, 0.0) + v        # (names starting with '#' are counters, e.g. rounds of the demand loop)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

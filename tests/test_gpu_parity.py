@@ -117,12 +117,18 @@ def test_demand_driven_matching_is_budget_independent(encoder):
                 os.environ["ZADA_BUDGET"] = budget
                 rc2, out, crc2 = gpu_deflate(encoder, d, 10)
                 assert rc == rc2 and out == ref and crc == crc2, (len(d), budget)
+            # safety valve of the demand loop: after one round everything that is still a guess is searched
+            os.environ["ZADA_BUDGET"] = "1"; os.environ["ZADA_MAX_DEMAND_ROUNDS"] = "1"
+            rc2, out, crc2 = gpu_deflate(encoder, d, 10)
+            os.environ.pop("ZADA_MAX_DEMAND_ROUNDS")
+            assert rc == rc2 and out == ref and crc == crc2 and dict(encoder.last_timing())["#demand_rounds"] <= 2, len(d)
             for method in (9, 8):
                 os.environ["ZADA_BUDGET"] = "1"
                 rc, ref, crc = oracle_deflate(d, method)
                 rc2, out, crc2 = gpu_deflate(encoder, d, method)
                 assert rc == rc2 and out == ref and crc == crc2, (len(d), method)
     finally:
+        os.environ.pop("ZADA_MAX_DEMAND_ROUNDS", None)
         if old is None:
             os.environ.pop("ZADA_BUDGET", None)
         else:

@@ -40,6 +40,9 @@ void Ctx::tend() {
     hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second);
     timing.push_back({marks[i].first, ms});
   }
+  // counters (names start with '#'): rounds of the demand loop and of the parse splice
+  timing.push_back({"#demand_rounds", (float)demand_rounds});
+  timing.push_back({"#splice_rounds", (float)parse_rounds});
 }
 
 template <typename T>

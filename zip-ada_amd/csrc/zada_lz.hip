@@ -978,6 +978,15 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
   }
 }
 
+// Safety valve of the demand loop: every remaining guess becomes demanded (lz_stage uses it when the parse keeps
+// landing on new guesses round after round, which no ordinary input does).
+__global__ void k_demand_all(uint64_t n, MatchPair *__restrict__ M, uint32_t *__restrict__ blk_demand) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t f = M[p].full;
+  if ((f & M_GUESS) && !(f & M_DEMAND)) { M[p].full = f | M_DEMAND | M_BYSPEC; blk_demand[p / DMB] = 1; }
+}
+
 // --------------------------------------------------------------------------------------------
 // parser kernels
 // --------------------------------------------------------------------------------------------
@@ -1206,6 +1215,8 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   // on until a parse has used exact values only.  The result is the parse over exact values, whatever the budget.
   const uint32_t nbm = (uint32_t)((n + MB - 1) / MB);
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
+  int max_rounds = 12;                             // demand rounds before everything that is still a guess is searched (ZADA_MAX_DEMAND_ROUNDS)
+  { const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS"); if (e && atoi(e) > 0) max_rounds = atoi(e); }
   int budget_env;                                  // read at every call: the tests compare budgets within one process
   { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : 8; if (budget_env < 1) budget_env = 1 << 20; }
   const uint32_t nbd = (uint32_t)((n + DMB - 1) / DMB);
@@ -1246,6 +1257,8 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     if (demand_rounds > 1000) { c->err = "demand loop did not converge"; return ZADA_E_HIP_; }
     hipMemsetAsync(W.n_demand, 0, 4, st);
     hipMemsetAsync(W.chg, 0, nch, st);
+    if (demand_rounds == max_rounds)                               // enough: search everything that is still a guess
+      hipLaunchKernelGGL(k_demand_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, W.M, W.blk_demand);
     hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, n, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
                        W.blk_demand, W.chg, W.spec_exits);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
