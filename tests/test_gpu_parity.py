@@ -88,6 +88,21 @@ def test_never_resynchronising_inputs(encoder):
             assert rc == rc2 and out == ref and crc == crc2
 
 
+def test_degenerate_inputs_converge_quickly(encoder):
+    """Constant and exactly periodic data: the speculative parses never meet the true one, so the splice would
+    advance one chunk per round (65 536 rounds for 64 MiB).  k_fix_forward carries it through the runs of
+    maximal matches, and a crawling splice triggers the exact search of everything still guessed (lz_stage).
+    Parity with the oracle, and a bound on the number of rounds."""
+    row = b"0001234,ABCD,some field,99\n" * 40 + b"0001235,ABCE,some field,98\n"
+    n = 8 << 20
+    for d in (bytes(n), b"ab" * (n // 2), (bytes(range(37)) * (n // 37 + 1))[:n], (row * (n // len(row) + 1))[:n]):
+        rc, ref, crc = oracle_deflate(d, 10)
+        rc2, out, crc2 = gpu_deflate(encoder, d, 10)
+        assert rc == rc2 and out == ref and crc == crc2
+        rounds = dict(encoder.last_timing())
+        assert rounds["#splice_rounds"] <= 80 and rounds["#demand_rounds"] <= 3, rounds
+
+
 def test_lds_atomics_return_in_lane_order(tmp_path):
     """The radix passes of k_prev_links take an element's rank from the value an LDS atomicAdd returns, which is
     stable only if lanes of one instruction that hit the same counter are served in lane order.  That is a property

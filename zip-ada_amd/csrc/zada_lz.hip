@@ -1069,6 +1069,48 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
   if (k + 1 < nchunks && (new_exit.pos != old_exit.pos || new_exit.kind != old_exit.kind)) {
     dirty_out[k + 1] = 1;
     atomicAdd(n_changed, 1u);
+    atomicMin(n_changed + 1, k);                    // the lowest chunk with a new exit: its entry was final, so is its exit
+  }
+}
+
+// Runs of maximal matches.  In constant or exactly periodic data every position matches 258 bytes, the true parse is
+// "match, match, match ..." from wherever it entered the run, and the speculative parses (started at the chunk
+// boundaries) can never meet it: the splice would advance one chunk per round.  But a match of max_lazy_match or
+// more is taken at once (:849, :875-899), so from a final F state q with an exact 258-byte match the next final
+// states are q + 258, q + 516, ... for as long as every landing position also has one.  One wave follows the run
+// from the exit of the lowest chunk that changed in this round, 64 landings per step, and writes the exit of every
+// chunk it crosses; those chunks are then re-parsed, all in the same next round.
+__global__ void __launch_bounds__(64) k_fix_forward(ParseIO io, uint32_t nchunks, ExitState *__restrict__ true_exits,
+                                                    uint8_t *__restrict__ dirty_out, uint32_t *__restrict__ n_changed) {
+  const uint32_t k = n_changed[1];
+  if (k >= nchunks || 258 < io.cfg.lazy) return;
+  const ExitState e0 = true_exits[k];
+  if (e0.kind != SYNC_F) return;
+  const int lane = threadIdx.x;
+  for (uint64_t q0 = e0.pos;; q0 += 258ull * 64) {
+    const uint64_t q = q0 + 258ull * lane;
+    bool good = false;
+    if (q + 258 <= io.n) { const uint32_t f = io.M[q].full; good = !(f & M_GUESS) && ((f & M_VALUE) >> 16) == 258u; }
+    const unsigned long long bad = ~__ballot(good);
+    const int nvalid = bad ? __ffsll((long long)bad) - 1 : 64;      // landings 0 .. nvalid-1 are final F states with a 258 match
+    // landing j is a final F state if all landings before it were good; it is the exit of the chunk ending at c1
+    // if it is the first state at or beyond c1
+    if (lane <= nvalid && (lane > 0 || q0 != e0.pos)) {
+      const uint64_t c1 = (q / PCHUNK) * PCHUNK;
+      if (q - c1 < 258 && c1 >= PCHUNK) {
+        const uint32_t kk = (uint32_t)(c1 / PCHUNK) - 1;
+        if (kk > k && kk < nchunks) {
+          const ExitState old = true_exits[kk];
+          if (old.pos != (uint32_t)q || old.kind != SYNC_F) {
+            ExitState ne; ne.pos = (uint32_t)q; ne.kind = SYNC_F;
+            true_exits[kk] = ne;
+            if (kk + 1 < nchunks) dirty_out[kk + 1] = 1;
+            atomicAdd(n_changed, 1u);
+          }
+        }
+      }
+    }
+    if (nvalid < 64) break;
   }
 }
 
@@ -1229,6 +1271,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand; dm.by = M_BYSPEC;
   DemandMarker dmf = dm; dmf.by = 0;
   int rounds = 0, demand_rounds = 0;
+  bool valve_used = false;
   for (bool first = true;; first = false) {
     // speculative parse: every chunk the first time, afterwards the chunks flagged by the demand pass
     hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
@@ -1236,29 +1279,37 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     // fixpoint of the splice, from scratch: round 0 handles every chunk with the speculative exits as entries
     hipMemcpyAsync(W.true_exits, W.spec_exits, (size_t)nch * sizeof(ExitState), hipMemcpyDeviceToDevice, st);
     hipMemsetAsync(W.dirty[0], 1, nch, st);
-    int cur = 0;
+    int cur = 0, it = 0;
+    bool slow = false;                                             // the splice is crawling: stop waiting for it
     for (;;) {
       hipMemsetAsync(W.dirty[cur ^ 1], 0, nch, st);
       hipMemsetAsync(W.n_changed, 0, 4, st);
+      hipMemsetAsync(W.n_changed + 1, 0xFF, 4, st);
       hipLaunchKernelGGL(k_parse_fix, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
                          W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, W.true_exits, W.fix_tok, W.fix_cnt,
                          W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed, dmf);
+      hipLaunchKernelGGL(k_fix_forward, dim3(1), dim3(64), 0, st, io, nch, W.true_exits, W.dirty[cur ^ 1], W.n_changed);
       uint32_t changed = 0;
       hipMemcpyAsync(&changed, W.n_changed, 4, hipMemcpyDeviceToHost, st);
       if (hip_check(c, hipStreamSynchronize(st), "parse_fix")) return ZADA_E_HIP_;
       rounds++;
       if (changed == 0) break;
+      // A splice that needs this many rounds is advancing chunk by chunk through data in which the speculative parses
+      // never meet the true one; k_fix_forward would carry it through if it were not stopped by guesses.
+      if (++it >= 32 && !valve_used) { slow = true; break; }
       cur ^= 1;
     }
     uint32_t ndem = 0;
     hipMemcpy(&ndem, W.n_demand, 4, hipMemcpyDeviceToHost);
-    if (ndem == 0) break;
+    if (ndem == 0 && !slow) break;
     demand_rounds++;
     if (demand_rounds > 1000) { c->err = "demand loop did not converge"; return ZADA_E_HIP_; }
     hipMemsetAsync(W.n_demand, 0, 4, st);
     hipMemsetAsync(W.chg, 0, nch, st);
-    if (demand_rounds == max_rounds)                               // enough: search everything that is still a guess
+    if ((demand_rounds == max_rounds || slow) && !valve_used) {    // enough: search everything that is still a guess
+      valve_used = true;
       hipLaunchKernelGGL(k_demand_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, W.M, W.blk_demand);
+    }
     hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, n, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
                        W.blk_demand, W.chg, W.spec_exits);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
