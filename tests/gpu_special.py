@@ -12,7 +12,13 @@ cases = {
     "zeros": bytes(n), "period 2": b"ab" * (n // 2), "period 37": (bytes(range(37)) * (n // 37 + 1))[:n],
     "random": rng.integers(0, 256, n, dtype=np.uint8).tobytes(), "rows": (row * (n // len(row) + 1))[:n],
     "text": za.silesia_mix(n, class_mask=1).tobytes(), "db": za.silesia_mix(n, class_mask=8).tobytes(),
+    "2 symbols": (rng.integers(0, 2, n, dtype=np.uint8) + 65).tobytes(), "4 symbols": (rng.integers(0, 4, n, dtype=np.uint8) + 65).tobytes(),
+    "16 symbols": (rng.integers(0, 16, n, dtype=np.uint8) + 65).tobytes(),
+    "noisy zeros": bytes(np.where(rng.random(n) < 0.001, rng.integers(1, 256, n), 0).astype(np.uint8)),
+    "xml": za.silesia_mix(n, class_mask=2).tobytes(),
 }
+only = sys.argv[1:] 
+if only: cases = {k: v for k, v in cases.items() if k in only}
 for name, d in cases.items():
     for _ in range(2):
         t0 = time.time()
