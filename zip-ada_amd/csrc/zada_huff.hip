@@ -337,7 +337,15 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
   if (nblocks > 0) load_block(0, nxt);
 
   for (uint32_t i = 0; i < nblocks; i++) {
-    const Rec cr = nxt;
+    // the record is the same in every lane: as scalars, the whole decision below runs on the scalar unit
+    Rec cr;
+    {
+      uint32_t tmp[sizeof(Rec) / 4];
+      __builtin_memcpy(tmp, &nxt, sizeof(Rec));
+#pragma unroll
+      for (unsigned q = 0; q < sizeof(Rec) / 4; q++) tmp[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)tmp[q]);
+      __builtin_memcpy(&cr, tmp, sizeof(Rec));
+    }
     if (i + 1 < nblocks) load_block(i + 1, nxt);
     const BlockRange br = cr.br;
     const uint64_t fixed_data = cr.fixed_data, dyn1_data = cr.dyn1_data, dyn2_data = cr.dyn2_data;
@@ -361,7 +369,7 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
           else if (s - 288 <= 29) rc += (uint64_t)stv * (uint64_t)(cu + dist_sym_extra(s - 288));
         }
         recycling_possible = !__any(bad);
-        recycled_data = wave_sum_u64(rc);
+        { const uint64_t v = wave_sum_u64(rc); recycled_data = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32); }
       }
     }
     const bool finishing = S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC);
@@ -422,7 +430,7 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
       while (sp > 0) {
         sp--;
         uint32_t f = stk_first[sp], l = stk_last[sp]; int lb = stk_lastblk[sp];
-        uint32_t src = apos[f], nbytes = apos[l + 1] - src;
+        uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos[f]), nbytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos[l + 1]) - src;
         if (nbytes > 0xFFFF) {
           uint32_t mid = (uint32_t)(((uint64_t)f + (uint64_t)l) / 2);
           // second half is processed after the first: push it first (LIFO)
