@@ -102,9 +102,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # BENCH_EMULATE=1: every rank on GPU 0 over gloo -- exercises the N > 1 code path on a one-GPU box (not a measurement)
+    emulate = os.environ.get("BENCH_EMULATE") == "1"
+    if emulate:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if emulate:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the encoder has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -119,18 +126,31 @@ def main():
     # this rank's entry of the logical stream: bytes [rank * n, (rank + 1) * n)
     host = za.silesia_mix(n, seed=SEED, offset=rank * n)
     d_in = torch.from_numpy(host).to(dev)
-    d_out = torch.zeros(n + 4096, dtype=torch.uint8, device=dev)
+    # two output buffers: with N > 1 the payload of one step travels to rank 0 while the next step is compressed
+    d_outs = [torch.zeros(n + 4096, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
     torch.cuda.synchronize()
+    state = {"i": 0, "pending": None}
 
     def step():
+        d_out = d_outs[state["i"] % len(d_outs)]
+        state["i"] += 1
         rc, out_len, crc = enc.deflate_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, za.Method.Deflate_3)
         if world > 1:
             meta = torch.tensor([crc ^ 0xFFFFFFFF, n, 8 if rc == 0 else 0], dtype=torch.int64, device=dev)
-            sharding.gather_payloads(d_out, out_len if rc == 0 else 0, meta, dst=0)
+            h = sharding.gather_payloads_begin(d_out, out_len if rc == 0 else 0, meta, dst=0)
+            if state["pending"] is not None:
+                state["pending"].finish()             # the previous step's gather (it used the other buffer)
+            state["pending"] = h
         return rc, out_len, crc
+
+    def drain():
+        if state["pending"] is not None:
+            state["pending"].finish()
+            state["pending"] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     phase_ms = {}
     if world > 1:
         dist.barrier()
@@ -140,6 +160,7 @@ def main():
         rc, out_len, crc = step()
         for k, v in enc.last_timing():
             phase_ms[k] = phase_ms.get(k, 0.0) + v        # (names starting with '#' are counters, e.g. rounds of the demand loop)
+    drain()                                               # every payload has arrived on rank 0 inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -29,6 +29,13 @@ def _worker(rank, world, port, q):
     mine = sharding.entries_of_rank(len(ranges), rank, world)
     rounds = max(len(sharding.entries_of_rank(len(ranges), r, world)) for r in range(world))
     gathered = []
+    pending = None
+
+    def collect(res):
+        if rank == 0:
+            for p, m in zip(*res):
+                if int(m[3]) >= 0:
+                    gathered.append((int(m[3]), bytes(p.numpy()), int(m[0]), int(m[1]), int(m[2])))
     O = oracle()
     for i in range(rounds):
         if i < len(mine):
@@ -42,11 +49,12 @@ def _worker(rank, world, port, q):
             length = ol.value
         else:
             payload = torch.zeros(1, dtype=torch.uint8); meta = torch.tensor([0, 0, 0, -1], dtype=torch.int64); length = 0
-        res = sharding.gather_payloads(payload, length, meta, dst=0)
-        if rank == 0:
-            for p, m in zip(*res):
-                if int(m[3]) >= 0:
-                    gathered.append((int(m[3]), bytes(p.numpy()), int(m[0]), int(m[1]), int(m[2])))
+        # as bench.py does it: the gather of this entry travels while the next entry is being compressed
+        h = sharding.gather_payloads_begin(payload, length, meta, dst=0)
+        if pending is not None:
+            collect(pending.finish())
+        pending = h
+    collect(pending.finish())
     if rank == 0:
         gathered.sort()
         zc = za.ZipCreate(None, 10)

@@ -27,14 +27,35 @@ def entries_of_rank(n_entries, rank, world):
     return list(range(lo, lo + base + (1 if rank < rem else 0)))
 
 
-def gather_payloads(payload, length, meta, dst=0, group=None):
-    """Gathers one variable-length payload per rank onto `dst`.
+class PendingGather:
+    """A gather of per-rank payloads in flight (gather_payloads_begin).  finish() waits for it and returns, on dst,
+    (list of uint8 tensors trimmed to their lengths, list of meta tensors); None elsewhere.  The payload tensor
+    given to gather_payloads_begin must not be overwritten before finish()."""
+
+    def __init__(self, work, bufs, lens, hdrs, send):
+        self.work, self.bufs, self.lens, self.hdrs, self.send = work, bufs, lens, hdrs, send
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            # NCCL's wait() only orders the current stream behind the collective: the caller (another stream, or a
+            # library with its own stream) is about to overwrite the send buffer, so wait on the host as well
+            if self.send.is_cuda:
+                torch.cuda.current_stream(self.send.device).synchronize()
+        if self.bufs is None:
+            return None
+        return [b[:ln] for b, ln in zip(self.bufs, self.lens)], [h[1:] for h in self.hdrs]
+
+
+def gather_payloads_begin(payload, length, meta, dst=0, group=None):
+    """Starts gathering one variable-length payload per rank onto `dst` and returns a PendingGather.
 
     payload : 1-D uint8 tensor (device of the backend), valid in [0, length)
     meta    : 1-D int64 tensor of per-entry metadata (e.g. crc, usize, zip_type)
-    Returns on dst: (list of uint8 tensors trimmed to their lengths, list of meta tensors); else None.
-    Traffic = sum of compressed sizes: at ratio 0.37 that is ~0.37 x input, far below one xGMI link
-    per peer, so a direct gather to the root is used, not a ring."""
+    The lengths are exchanged first (a small all_gather), then the payloads travel asynchronously, so that a rank
+    can compress its next entry meanwhile.  Traffic = sum of compressed sizes: at ratio 0.37 that is ~0.37 x input,
+    far below one xGMI link per peer, so a direct gather to the root is used, not a ring."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = payload.device
@@ -47,7 +68,12 @@ def gather_payloads(payload, length, meta, dst=0, group=None):
     send = send.contiguous()
     if rank == dst:
         bufs = [torch.empty(maxlen, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist.gather(send, bufs, dst=dst, group=group)
-        return [b[:ln] for b, ln in zip(bufs, lens)], [h[1:] for h in hdrs]
-    dist.gather(send, None, dst=dst, group=group)
-    return None
+        work = dist.gather(send, bufs, dst=dst, group=group, async_op=True)
+        return PendingGather(work, bufs, lens, hdrs, send)
+    work = dist.gather(send, None, dst=dst, group=group, async_op=True)
+    return PendingGather(work, None, lens, hdrs, send)
+
+
+def gather_payloads(payload, length, meta, dst=0, group=None):
+    """gather_payloads_begin(...).finish(): the blocking form."""
+    return gather_payloads_begin(payload, length, meta, dst=dst, group=group).finish()
