@@ -92,6 +92,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(binfo, W.cap_blocks);
   A(emit, W.cap_blocks);
   A(rel, W.cap_blocks * 6);
+  A(chrec, W.cap_blocks * 16 + 16);
   A(codes, (W.cap_blocks + 1) * 320);
   W.cap_pieces = cap / 32768 + W.cap_blocks + 64;
   A(pieces, W.cap_pieces);

@@ -15,6 +15,7 @@
 //   k_block_codes / k_tile_bits / k_tile_scan / k_emit_tiles / k_emit_headers / k_copy_pieces
 //                    parallel emission: per-atom (code, length) -> prefix sums -> bit packing
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "zada_logic.h"
 #include "zada_internal.h"
@@ -252,7 +253,26 @@ __device__ uint32_t wave_code_of(const int (&cur)[5], int sym, int lane, int nsy
 // (:1158, 1180, 1189); plus the end-of-block code of the block's own two descriptors.
 struct BlockRel { uint64_t bits[3]; uint32_t ok[3]; uint32_t eob[2]; uint32_t pad; };
 
-__global__ void __launch_bounds__(64) k_block_relate(uint32_t nblocks, const BlockInfo *__restrict__ binfo, BlockRel *__restrict__ rel) {
+// Everything the sequential chooser needs about one block, with all the state-independent work done: of the five
+// costs of Compute_sizes_of_variants (:1147-1209) only "recycle" depends on what the previous blocks chose; the
+// constant c (:1198-1201) is added to the other four alike, so their minimum and the format that attains it
+// (tie order fixed, dynamic, dynamic-RLE: :1243-1250) are known in advance.
+struct ChRec {
+  uint64_t base3;                 // min(fixed, dyn1 + hdr1, dyn2 + hdr2) + 2, without c
+  uint64_t stored;                // stored-block bits without c (:1193-1196), ~0 if a match is longer than 14
+  uint64_t bits[3];               // LZ data under the fixed code / the previous block's plain / RLE-tweaked code
+  uint64_t fixed_data, dyn1_data, dyn2_data;
+  uint32_t hdr1, hdr2;
+  uint32_t ok;                    // bit k: bits[k] is usable (Recyclable :495-508)
+  uint32_t eob[2];                // this block's own end-of-block codes (len << 16 | code), plain / RLE-tweaked
+  uint32_t fmt3;                  // FMT_FIXED / FMT_DYN1 / FMT_DYN2 attaining base3
+  BlockRange br;
+  uint32_t pad[6];
+};
+static_assert(sizeof(ChRec) == 128, "ChRec");
+
+__global__ void __launch_bounds__(64) k_block_relate(uint32_t nblocks, const BlockInfo *__restrict__ binfo, const BlockRange *__restrict__ blocks,
+                                                     BlockRel *__restrict__ rel, ChRec *__restrict__ chrec) {
   const uint32_t i = blockIdx.x;
   const int lane = threadIdx.x;
   const BlockInfo *bi = &binfo[i];
@@ -279,7 +299,25 @@ __global__ void __launch_bounds__(64) k_block_relate(uint32_t nblocks, const Blo
   out.eob[0] = ((uint32_t)__shfl(b1[4], 0) << 16) | wave_code_of(b1, 256, lane, 288);
   out.eob[1] = ((uint32_t)__shfl(b2[4], 0) << 16) | wave_code_of(b2, 256, lane, 288);
   out.pad = 0;
-  if (lane == 0) rel[i] = out;
+  if (lane == 0) {
+    rel[i] = out;
+    ChRec cr;
+    const uint64_t fx = bi->fixed_data + 2, d1 = bi->dyn1_data + 2 + bi->hdr1_bits, d2 = bi->dyn2_data + 2 + bi->hdr2_bits;
+    uint64_t m = fx; uint32_t f = FMT_FIXED;
+    if (d1 < m) { m = d1; f = FMT_DYN1; }
+    if (d2 < m) { m = d2; f = FMT_DYN2; }
+    cr.base3 = m; cr.fmt3 = f;
+    cr.stored = ~0ull;
+    if (bi->stored_possible) { uint64_t sb = 8ull * bi->bytes; sb += (1 + (sb / 8) / 65535) * 40; cr.stored = sb; }   // :1193-1196
+    for (int k = 0; k < 3; k++) cr.bits[k] = out.bits[k];
+    cr.ok = (out.ok[0] ? 1u : 0u) | (out.ok[1] ? 2u : 0u) | (out.ok[2] ? 4u : 0u);
+    cr.fixed_data = bi->fixed_data; cr.dyn1_data = bi->dyn1_data; cr.dyn2_data = bi->dyn2_data;
+    cr.hdr1 = bi->hdr1_bits; cr.hdr2 = bi->hdr2_bits;
+    cr.eob[0] = out.eob[0]; cr.eob[1] = out.eob[1];
+    cr.br = blocks[i];
+    for (int k = 0; k < 6; k++) cr.pad[k] = 0;
+    chrec[i] = cr;
+  }
 }
 
 struct ChooseState {
@@ -475,6 +513,165 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
     S.pos += 3 + 7;                                                              // fake final fixed block: EOB = 0000000
   }
   if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = npieces; res->n_blocks = nblocks; res->overflow = overflow; }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_choose_lean : the sequential walk of Send_as_block's decision (:1222-1268) reduced to what really depends on the
+// previous blocks.  Per block: one 128-byte record (k_block_relate) through scalar loads, the recycle cost picked
+// by the state, three compares, the state update and the bit positions.  No stream writes for ordinary blocks (the
+// end-of-block code, BFINAL and BTYPE bits go out in parallel afterwards, k_emit_prefix) and no tile table.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRec *__restrict__ chrec, const BlockInfo *__restrict__ binfo,
+                                                    const uint32_t *__restrict__ apos, EmitRec *__restrict__ emit,
+                                                    StoredPiece *__restrict__ pieces, uint32_t cap_tiles, uint32_t cap_pieces,
+                                                    uint32_t *__restrict__ out32, ChooserOut *__restrict__ res) {
+  const int lane = threadIdx.x;
+  ChooseState S; S.last_type = BT_RESERVED; S.block_to_finish = 0; S.last_marked = 0; S.code_block = -1; S.code_variant = 0; S.pos = 0; S.cur_eob = 7u << 16;
+  uint32_t ntiles = 0, npieces = 0, overflow = 0;
+  for (uint32_t i = 0; i < nblocks; i++) {
+    const ChRec cr = chrec[i];                                     // uniform address: scalar loads
+    const BlockRange br = cr.br;
+    // recycling (:1223-1226, Recyclable :495-508) and its cost (:1158, 1180, 1189)
+    bool recycling_possible = false; uint64_t recycled_data = 0;
+    if (S.last_type == BT_FIXED) { recycling_possible = true; recycled_data = cr.bits[0]; }
+    else if (S.last_type == BT_DYNAMIC) {
+      if (S.code_block == (int)i - 1) {   // (no indexing by the variant: the record stays in registers)
+        recycling_possible = S.code_variant == 1 ? (cr.ok & 2u) != 0 : (cr.ok & 4u) != 0;
+        recycled_data = S.code_variant == 1 ? cr.bits[1] : cr.bits[2];
+      }
+      else {
+        // the codes in force are older than the previous block (a chain of recycled blocks): evaluate here
+        const BlockInfo *bi = &binfo[i];
+        const uint8_t *cl = S.code_variant == 1 ? binfo[S.code_block].bl1 : binfo[S.code_block].bl2;
+        bool bad = false; uint64_t rc = 0;
+        for (int r = 0; r < 5; r++) {
+          const int s = lane + 64 * r;
+          const int cu = cl[s]; const uint32_t stv = bi->stats[s];
+          if (cu == 0 && bi->bl1[s] > 0) bad = true;
+          if (s < 288) { if (s != 256 && s <= 285) rc += (uint64_t)stv * (uint64_t)(cu + litlen_sym_extra(s)); }
+          else if (s - 288 <= 29) rc += (uint64_t)stv * (uint64_t)(cu + dist_sym_extra(s - 288));
+        }
+        recycling_possible = !__any(bad);
+        { const uint64_t v = wave_sum_u64(rc); recycled_data = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32); }
+      }
+    }
+    const bool finishing = S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC);
+    const uint32_t eob_len = S.cur_eob >> 16;
+    const uint64_t c = 1 + (finishing ? (uint64_t)eob_len : 0);                 // :1198-1201
+    const uint64_t INF = ~0ull;
+    const uint64_t a = cr.base3 + c;                                             // the best of fixed / dynamic / dynamic-RLE
+    const uint64_t st = cr.stored == INF ? INF : cr.stored + c;
+    const uint64_t rb = recycling_possible ? recycled_data : INF;
+    int fmt; uint64_t opt;                                                       // tie order fixed, dynamic, dynamic-RLE, recycled, stored (:1243-1268)
+    if (a <= rb && a <= st) { fmt = (int)cr.fmt3; opt = a; }
+    else if (rb <= st) { fmt = FMT_RECYCLE; opt = rb; }
+    else { fmt = FMT_STORED; opt = st; }
+
+    EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = 0; e.cost_bits = opt; e.fmt = (uint32_t)fmt; e.code_block = -1; e.code_variant = 0; e.tile_base = ntiles;
+    e.pre_pos = 0; e.pre_eob = 0; e.pre_flags = 0;
+    const int last_block = (int)br.last_flush;
+    // Mark_new_block :999-1007 (end-of-block code of the block being finished, then BFINAL), recorded for k_emit_prefix
+    auto open_block = [&](int last_for_stream, uint32_t btype) {
+      e.pre_pos = S.pos;
+      if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) { e.pre_eob = S.cur_eob; S.pos += (uint64_t)(S.cur_eob >> 16); }
+      S.block_to_finish = 1;
+      S.last_marked = last_for_stream;
+      e.pre_flags = 1u | ((uint32_t)last_for_stream << 1) | (btype << 2);
+      S.pos += 3;                                                                // BFINAL + BTYPE
+    };
+    uint64_t data_bits = 0;
+    if (fmt == FMT_FIXED) {
+      if (S.last_type != BT_FIXED) {                                             // Send_fixed_block :1108-1121
+        open_block(last_block, 1);
+        S.last_type = BT_FIXED; S.code_block = -1; S.code_variant = 0; S.cur_eob = 7u << 16;
+      }
+      data_bits = cr.fixed_data;
+    } else if (fmt == FMT_DYN1 || fmt == FMT_DYN2) {                             // Send_dynamic_block :1126-1135
+      open_block(last_block, 2);
+      S.cur_eob = fmt == FMT_DYN1 ? cr.eob[0] : cr.eob[1];
+      e.hdr_bitpos = S.pos;
+      S.pos += (fmt == FMT_DYN1) ? cr.hdr1 : cr.hdr2;
+      S.last_type = BT_DYNAMIC; S.code_block = (int)i; S.code_variant = (fmt == FMT_DYN1) ? 1 : 2;
+      data_bits = (fmt == FMT_DYN1) ? cr.dyn1_data : cr.dyn2_data;
+    } else if (fmt == FMT_RECYCLE) {
+      data_bits = recycled_data;
+    } else {
+      // Expand_LZ_buffer :1010-1062 with its divide-and-conquer on the ATOM range (rare: written here, directly)
+      uint32_t stk_first[40], stk_last[40]; int stk_lastblk[40]; int sp = 0;
+      stk_first[0] = br.first; stk_last[0] = br.first + br.count - 1; stk_lastblk[0] = last_block; sp = 1;
+      while (sp > 0) {
+        sp--;
+        uint32_t f = stk_first[sp], l = stk_last[sp]; int lb = stk_lastblk[sp];
+        uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos[f]), nbytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos[l + 1]) - src;
+        if (nbytes > 0xFFFF) {
+          uint32_t mid = (uint32_t)(((uint64_t)f + (uint64_t)l) / 2);
+          // second half is processed after the first: push it first (LIFO)
+          stk_first[sp] = mid + 1; stk_last[sp] = l; stk_lastblk[sp] = lb; sp++;
+          stk_first[sp] = f; stk_last[sp] = mid; stk_lastblk[sp] = 0; sp++;
+          continue;
+        }
+        if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {      // Mark_new_block
+          const int ll = (int)(S.cur_eob >> 16);
+          if (lane == 0) put_bits_global(out32, S.pos, S.cur_eob & 0xFFFF, ll);
+          S.pos += (uint64_t)ll;
+        }
+        S.block_to_finish = 1;
+        if (lane == 0) put_bits_global(out32, S.pos, (uint32_t)lb, 1);
+        S.pos += 1;
+        S.last_marked = lb;
+        S.last_type = BT_STORED;
+        S.pos += 2;                                                              // Put_Bits (0, 2)
+        S.pos = (S.pos + 7) & ~7ull;                                             // Flush_bit_buffer
+        if (lane == 0) {
+          put_bits_global(out32, S.pos, nbytes & 0xFFFF, 16);
+          put_bits_global(out32, S.pos + 16, (~nbytes) & 0xFFFF, 16);
+          if (npieces < cap_pieces) { StoredPiece pc; pc.dst_byte = (S.pos >> 3) + 4; pc.src_byte = src; pc.nbytes = nbytes; pieces[npieces] = pc; }
+        }
+        if (npieces >= cap_pieces) overflow = 1;
+        npieces++;
+        S.pos += 32 + 8ull * nbytes;
+      }
+    }
+    if (fmt != FMT_STORED) {
+      e.data_bitpos = S.pos;
+      e.code_block = S.code_block; e.code_variant = (uint32_t)S.code_variant;
+      S.pos += data_bits;
+      const uint32_t nt = (br.count + TILE - 1) / TILE;
+      if (ntiles + nt > cap_tiles) { overflow = 1; break; }
+      ntiles += nt;
+    }
+    if (lane == 0) emit[i] = e;
+  }
+  // stream epilogue, Encode :1613-1635
+  if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
+    const int l = (int)(S.cur_eob >> 16);
+    if (lane == 0) put_bits_global(out32, S.pos, S.cur_eob & 0xFFFF, l);
+    S.pos += (uint64_t)l;
+  }
+  if (!S.last_marked) {
+    if (lane == 0) { put_bits_global(out32, S.pos, 1, 1); put_bits_global(out32, S.pos + 1, 1, 2); }
+    S.pos += 3 + 7;                                                              // fake final fixed block: EOB = 0000000
+  }
+  if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = npieces; res->n_blocks = nblocks; res->overflow = overflow; }
+}
+
+// What k_choose_lean left out, one thread per block: the bits in front of a block that opens a new Deflate block (end-of-
+// block code of the one before, BFINAL, BTYPE) and the block's entries of the tile table.
+__global__ void __launch_bounds__(256) k_emit_prefix(uint32_t nblocks, const EmitRec *__restrict__ emit, const BlockRange *__restrict__ blocks,
+                                                     uint32_t *__restrict__ tile_block, uint32_t *__restrict__ out32) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblocks) return;
+  const EmitRec e = emit[i];
+  if (e.pre_flags & 1u) {
+    uint64_t p = e.pre_pos;
+    if (e.pre_eob) { put_bits_global(out32, p, e.pre_eob & 0xFFFF, (int)(e.pre_eob >> 16)); p += e.pre_eob >> 16; }
+    put_bits_global(out32, p, (e.pre_flags >> 1) & 1u, 1);
+    put_bits_global(out32, p + 1, (e.pre_flags >> 2) & 3u, 2);
+  }
+  if (e.fmt != FMT_STORED) {
+    const uint32_t nt = (blocks[i].count + TILE - 1) / TILE;
+    for (uint32_t t = 0; t < nt; t++) tile_block[e.tile_base + t] = i;
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -691,9 +888,16 @@ int huff_stage(Ctx *c, int method, uint64_t n, uint32_t T, uint64_t *total_bits)
     hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, W.atoms, W.apos, W.blocks, W.binfo);
     c->tmark("block_analyze");
   }
-  if (nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, (BlockRel *)W.rel);
-  hipLaunchKernelGGL(k_choose, dim3(1), dim3(64), 0, st, nblocks, W.blocks, W.binfo, W.apos, (const BlockRel *)W.rel, W.emit, W.tile_block, W.pieces,
-                     (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.chooser, fixed_only ? 1 : 0);
+  if (nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (BlockRel *)W.rel, (ChRec *)W.chrec);
+  const bool old_chooser = fixed_only || getenv("ZADA_CHOOSER_OLD") != nullptr;      // the original single-kernel walk (A/B, and Deflate_Fixed)
+  if (old_chooser)
+    hipLaunchKernelGGL(k_choose, dim3(1), dim3(64), 0, st, nblocks, W.blocks, W.binfo, W.apos, (const BlockRel *)W.rel, W.emit, W.tile_block, W.pieces,
+                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.chooser, fixed_only ? 1 : 0);
+  else {
+    hipLaunchKernelGGL(k_choose_lean, dim3(1), dim3(64), 0, st, nblocks, (const ChRec *)W.chrec, W.binfo, W.apos, W.emit, W.pieces,
+                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.chooser);
+    if (nblocks > 0) hipLaunchKernelGGL(k_emit_prefix, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.emit, W.blocks, W.tile_block, (uint32_t *)W.out);
+  }
   ChooserOut co;
   hipMemcpyAsync(&co, W.chooser, sizeof co, hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "choose")) return ZADA_E_HIP_;

@@ -62,6 +62,11 @@ struct EmitRec {
   int32_t code_block;           // block whose code table is in force (-1 = fixed table)
   uint32_t code_variant;        // 1 or 2 (bl1 / bl2 of code_block)
   uint32_t tile_base;           // first emission tile of this block
+  // what precedes the block in the stream when it opens a new Deflate block (written by k_emit_prefix, not by the
+  // sequential chooser): [end-of-block code of the block being finished] BFINAL, BTYPE
+  uint64_t pre_pos;             // bit position of that prefix
+  uint32_t pre_eob;             // (len << 16) | code of the end-of-block symbol to write first, 0 = none
+  uint32_t pre_flags;           // bit 0: the prefix exists; bit 1: BFINAL; bits 2-3: BTYPE
 };
 
 struct StoredPiece { uint64_t dst_byte; uint32_t src_byte, nbytes; };
@@ -96,6 +101,7 @@ struct Workspace {
   BlockInfo *binfo = nullptr;
   EmitRec *emit = nullptr;
   uint64_t *rel = nullptr;                   // BlockRel[nblocks] (48 B each)
+  uint64_t *chrec = nullptr;                 // ChRec[nblocks] (128 B each)
   uint32_t *codes = nullptr;                 // [nblocks+1][320]  (len << 16 | code); last = fixed table
   StoredPiece *pieces = nullptr;
   uint32_t *tile_block = nullptr;            // tile -> block
