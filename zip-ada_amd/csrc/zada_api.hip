@@ -212,12 +212,13 @@ int crc_launch(Ctx *c, uint64_t n) {
   for (int l = 1; l < CRC_NLEV; l++)
     if (P.cnt[l]) hipLaunchKernelGGL(k_crc_fold, dim3((P.cnt[l] + 255) / 256), dim3(256), 0, s2, W.crc_lvl[l - 1], P.cnt[l], W.crc_mat + 32 * (l - 1), W.crc_lvl[l]);
   // values the host needs: all of the top level, and per lower level the < 16 values after the last full group
-  P.top.resize(P.cnt[CRC_NLEV - 1] ? P.cnt[CRC_NLEV - 1] : 1);
-  if (P.cnt[CRC_NLEV - 1]) hipMemcpyAsync(P.top.data(), W.crc_lvl[CRC_NLEV - 1], (size_t)P.cnt[CRC_NLEV - 1] * 4, hipMemcpyDeviceToHost, s2);
+  // (pinned host memory: a device-to-host copy into pageable memory would block this thread until the kernels are done)
+  if (P.cnt[CRC_NLEV - 1] > CRC_HOST_TOP) { c->err = "crc: too many top-level values"; return ZADA_E_TOO_LARGE; }
+  if (P.cnt[CRC_NLEV - 1]) hipMemcpyAsync(c->crc_host, W.crc_lvl[CRC_NLEV - 1], (size_t)P.cnt[CRC_NLEV - 1] * 4, hipMemcpyDeviceToHost, s2);
   for (int l = 0; l < CRC_NLEV - 1; l++) {
     const uint32_t first = P.cnt[l + 1] * 16;
     P.nrest[l] = (l == 0 ? P.nsub : P.cnt[l]) - first;               // level 0 includes the final short value
-    if (P.nrest[l]) hipMemcpyAsync(P.rest[l], W.crc_lvl[l] + first, (size_t)P.nrest[l] * 4, hipMemcpyDeviceToHost, s2);
+    if (P.nrest[l]) hipMemcpyAsync(c->crc_host + CRC_HOST_TOP + 16 * l, W.crc_lvl[l] + first, (size_t)P.nrest[l] * 4, hipMemcpyDeviceToHost, s2);
   }
   return hip_check(c, hipGetLastError(), "crc launch");
 }
@@ -228,7 +229,7 @@ int crc_finish(Ctx *c, uint64_t n, uint32_t *crc_inout) {
   CrcPending &P = c->crc;
   const uint32_t *cnt = P.cnt, *nrest = P.nrest;
   const uint32_t nfull0 = P.nfull0;
-  auto &top = P.top; auto &rest = P.rest; auto &M = crc_M;
+  const uint32_t *top = c->crc_host; const uint32_t (*rest)[16] = (const uint32_t (*)[16])(c->crc_host + CRC_HOST_TOP); auto &M = crc_M;
   if (hip_check(c, hipStreamSynchronize(c->stream2), "crc")) return ZADA_E_HIP_;
   uint32_t r = *crc_inout;
   for (uint32_t k = 0; k < cnt[NLEV - 1]; k++) r = gf2_apply(M[NLEV - 1], r) ^ top[k];
@@ -257,6 +258,13 @@ static int method_level(int method) {
 }
 
 // core: input already in W.in[0..n) (pad zeroed); result in W.out
+struct PadArgs { uint8_t *in_end; uint32_t n_in; uint16_t *link_end[NLEVELS]; };
+__global__ void k_pad_init(PadArgs a) {
+  for (uint32_t i = threadIdx.x; i < a.n_in; i += blockDim.x) a.in_end[i] = 0;
+  for (int l = 0; l < NLEVELS; l++)
+    if (threadIdx.x < 64) a.link_end[l][threadIdx.x] = 0;
+}
+
 static int deflate_core(Ctx *c, int method, uint64_t n, uint64_t *out_len, uint32_t *crc_inout, zada_feedback_fn fb, void *user) {
   Workspace &W = c->ws;
   hipStream_t st = c->stream;
@@ -265,8 +273,12 @@ static int deflate_core(Ctx *c, int method, uint64_t n, uint64_t *out_len, uint3
   if (fb && fb(0, user)) return ZADA_ABORTED;
   c->tbegin();
   c->tmark("begin");
-  hipMemsetAsync(W.in + n, 0, IN_PAD, st);
-  for (int l = 0; l < NLEVELS; l++) hipMemsetAsync(W.lprev[l] + (n >= 2 ? n - 2 : 0), 0, 2 * 64, st);
+  {
+    // zero pad behind the input and behind the link planes: one small launch (a hipMemsetAsync costs ~0.3 ms of stream time each)
+    PadArgs pa; pa.in_end = W.in + n; pa.n_in = IN_PAD;
+    for (int l = 0; l < NLEVELS; l++) pa.link_end[l] = W.lprev[l] + (n >= 2 ? n - 2 : 0);
+    hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);
+  }
   uint32_t crc = crc_inout ? *crc_inout : 0xFFFFFFFFu;
   int rc = crc_launch(c, n);
   if (rc) return rc;
@@ -310,6 +322,7 @@ zada_ctx *zada_create(int device) {
   if (!z) return nullptr;
   z->c.device = device;
   if (hipStreamCreate(&z->c.stream) != hipSuccess) { delete z; return nullptr; }
+  if (hipHostMalloc((void **)&z->c.crc_host, (CRC_HOST_TOP + 64) * 4, hipHostMallocDefault) != hipSuccess) { delete z; return nullptr; }
   if (hipStreamCreate(&z->c.stream2) != hipSuccess || hipEventCreateWithFlags(&z->c.ev_input, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&z->c.ev_out, hipEventDisableTiming) != hipSuccess) { delete z; return nullptr; }
   return z;
@@ -323,6 +336,7 @@ void zada_destroy(zada_ctx *z) {
   for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
   hipStreamSynchronize(z->c.stream2);
   hipStreamDestroy(z->c.stream2);
+  hipHostFree(z->c.crc_host);
   hipEventDestroy(z->c.ev_input);
   hipEventDestroy(z->c.ev_out);
   hipStreamDestroy(z->c.stream);
