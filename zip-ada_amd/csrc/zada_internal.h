@@ -15,9 +15,10 @@ constexpr int ZADA_E_HIP_ = -3;
 
 // ---- LZ stage geometry ----
 #ifndef ZADA_PCHUNK
-#define ZADA_PCHUNK 1024
+#define ZADA_PCHUNK 512
 #endif
-constexpr uint32_t PCHUNK = ZADA_PCHUNK;                 // bytes parsed per lane (speculative chunk)
+constexpr uint32_t PCHUNK = ZADA_PCHUNK;
+static_assert(PCHUNK > 258, "k_fix_forward: a 258-byte step crosses at most one chunk boundary");                 // bytes parsed per lane (speculative chunk)
 constexpr uint32_t PTOK_STRIDE = PCHUNK + 640;    // token slots per chunk (a parse may overrun its chunk by < 600 B)
 constexpr uint32_t CRC_CHUNK = 4096, CRC_SUB = 256;   // CRC: one lane per 256 B, folded to one value per 4 KiB on the device
 constexpr uint64_t IN_PAD = 1024;                 // zero bytes kept after the input
