@@ -788,7 +788,7 @@ constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256, DM_AHEAD
 constexpr int DM_WBYTES = HALO + DMB + 272;
 struct ScanDesc {                                  // a position whose candidates have to be scanned (32 bytes, in LDS)
   uint16_t k, la, idx1, c1, idx2, c2, lim_full, lim_q;
-  uint16_t bdist, best_hq;                         // best | have_q << 15
+  uint16_t bdist, best_hq;                         // best | reach << 14 | have_q << 15
   uint32_t rq, og_full, og_quarter;
 };
 constexpr int DM_LDS = DM_WBYTES + DMB * 2 + DM_SLICE * (int)sizeof(ScanDesc) + 64;
@@ -818,13 +818,15 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
   const uint8_t *win8 = (const uint8_t *)win;
   // a changed value: the speculative parses that used the guess have to be redone (the chunk's own, and the previous
   // chunk's if it ran over into this position)
-  auto store_result = [&](uint64_t p, uint32_t full, uint32_t quarter, uint32_t og_full, uint32_t og_quarter) {
+  // `reach`: the previous chunk's speculative parse ran over into this position (looked up in phase A, where it costs
+  // nothing: here it would be a load on the wave's critical path)
+  auto store_result = [&](uint64_t p, uint32_t full, uint32_t quarter, uint32_t og_full, uint32_t og_quarter, bool reach) {
     MatchPair r; r.full = full; r.quarter = quarter;
     M[p] = r;
     if ((og_full & M_BYSPEC) && (full != (og_full & M_VALUE) || quarter != og_quarter)) {
       const uint64_t ch = p / PCHUNK;
       chg[ch] = 1;
-      if (ch > 0 && spec_exits[ch - 1].pos >= (uint32_t)p) chg[ch - 1] = 1;
+      if (reach) chg[ch - 1] = 1;
     }
   };
   if (tid == 0) ctr[0] = 0;
@@ -879,15 +881,17 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
         chain_ok = v;
       }
       const bool have_q = chain_ok && bdist > lim_q;
+      const uint64_t chk = p / PCHUNK;
+      const bool reach = chk > 0 && spec_exits[chk - 1].pos >= (uint32_t)p;
       if (chain_ok && best < nice && c1 + c2 > 0) {
         ScanDesc ds;
         ds.k = (uint16_t)k; ds.la = (uint16_t)la; ds.idx1 = (uint16_t)idx1; ds.c1 = (uint16_t)c1; ds.idx2 = (uint16_t)idx2; ds.c2 = (uint16_t)c2;
-        ds.lim_full = (uint16_t)lim_full; ds.lim_q = (uint16_t)lim_q; ds.bdist = (uint16_t)bdist; ds.best_hq = (uint16_t)((uint32_t)best | ((uint32_t)have_q << 15));
+        ds.lim_full = (uint16_t)lim_full; ds.lim_q = (uint16_t)lim_q; ds.bdist = (uint16_t)bdist; ds.best_hq = (uint16_t)((uint32_t)best | ((uint32_t)reach << 14) | ((uint32_t)have_q << 15));
         ds.rq = qbest; ds.og_full = og.full; ds.og_quarter = og.quarter;
         desc[atomicAdd(&ctr[1], 1u)] = ds;
       } else {
         const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
-        store_result(p, packed, !chain_ok ? qbest : (have_q ? qbest : packed), og.full, og.quarter);
+        store_result(p, packed, !chain_ok ? qbest : (have_q ? qbest : packed), og.full, og.quarter, reach);
       }
     }
     __syncthreads();
@@ -911,7 +915,7 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
       if (si + DM_THREADS / 64 < ns) dnext = cand(desc[si + DM_THREADS / 64], (uint32_t)lane);
       const uint32_t WI = woff + ds.k, LF = ds.lim_full, LQ = ds.lim_q, TT = (uint32_t)ds.c1 + ds.c2;
       const int LA = ds.la, NICE = nice_cfg < LA ? nice_cfg : LA;
-      int bst = ds.best_hq & 0x7FFF;
+      int bst = ds.best_hq & 0x3FFF;
       uint32_t bd = ds.bdist, rqq = ds.rq;
       bool hq = (ds.best_hq >> 15) != 0;
       uint32_t s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
@@ -971,7 +975,7 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
       }
       if (lane == 0) {
         const uint32_t packed = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u;
-        store_result(B + ds.k, packed, hq ? rqq : packed, ds.og_full, ds.og_quarter);
+        store_result(B + ds.k, packed, hq ? rqq : packed, ds.og_full, ds.og_quarter, (ds.best_hq >> 14) & 1u);
       }
     }
     __syncthreads();
