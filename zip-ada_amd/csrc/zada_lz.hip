@@ -918,12 +918,14 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
       int bst = ds.best_hq & 0x3FFF;
       uint32_t bd = ds.bdist, rqq = ds.rq;
       bool hq = (ds.best_hq >> 15) != 0;
-      uint32_t s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
-      bool over = false;                                           // search finished
       auto lds_u32 = [&](uint32_t o) -> uint32_t {
         const uint32_t *w = (const uint32_t *)(win8 + (o & ~3u));
         return __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u);
       };
+      // filter: a candidate can only beat `bst` if it agrees with the scanned string in byte bst (:754-757); the four
+      // bytes bst-3 .. bst are tested (two LDS reads, like two single bytes), which leaves far fewer false survivors
+      uint32_t s_end = lds_u32(WI + (uint32_t)bst - 3);
+      bool over = false;                                           // search finished
       // One batch of 64 candidates (distances d, nearest first).  All of them are filtered at once against the best
       // so far (:754-757); the survivors are then taken in order, exactly like the sequential walk (:812-822):
       // the whole wave compares one candidate with the scanned string, four bytes per lane, and if it is longer
@@ -932,7 +934,7 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
         const bool valid = d != 0;
         const bool inr = valid && d <= LF;
         bool pass = false;
-        if (inr) pass = LDS_U16(win8, WI - d + (uint32_t)bst - 1) == s_end;
+        if (inr) pass = lds_u32(WI - d + (uint32_t)bst - 3) == s_end;
         unsigned long long pm = __ballot(pass);
         while (pm) {
           const int j = __ffsll((long long)pm) - 1;
@@ -948,8 +950,8 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
           if (len > bst) {
             bst = len; bd = dj;
             if (len >= NICE) { over = true; break; }                                             // :815
-            s_end = LDS_U16(win8, WI + (uint32_t)bst - 1);
-            pass = pass && lane > j && LDS_U16(win8, WI - d + (uint32_t)bst - 1) == s_end;
+            s_end = lds_u32(WI + (uint32_t)bst - 3);
+            pass = pass && lane > j && lds_u32(WI - d + (uint32_t)bst - 3) == s_end;
           } else pass = pass && lane > j;
           pm = __ballot(pass);
         }
