@@ -145,11 +145,13 @@ struct BitmapWriter {
 // top of the loop, or the input ends (then the trailing literal :930-932 is emitted).
 // Fetch: how a match record is read (the GPU parser keeps the 64-byte line of its last look-up in LDS).
 struct DirectFetch { const MatchPair *M; ZADA_HD MatchPair operator()(uint32_t p) const { return M[p]; } };
-template <typename OnTop, typename OnGuess, typename Fetch>
-ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_t &ntok, OnTop &&on_top, OnGuess &&on_guess, Fetch &&fetch) {
+// Sink: where the tokens go (the GPU's speculative parse collects eight of them in LDS before it writes).
+struct DirectSink { uint32_t *tok; uint32_t &ntok; ZADA_HD void push(uint32_t t) { tok[ntok++] = t; } };
+template <typename Sink, typename OnTop, typename OnGuess, typename Fetch>
+ZADA_HD void run_parser(ParseState &s, const ParseIO &io, Sink &&sink, OnTop &&on_top, OnGuess &&on_guess, Fetch &&fetch) {
   for (;;) {
     if ((uint64_t)s.p >= io.n) {
-      if (s.avail) { tok[ntok++] = io.in[io.n - 1]; s.avail = 0; s.mlen = 2; }
+      if (s.avail) { sink.push(io.in[io.n - 1]); s.avail = 0; s.mlen = 2; }
       return;
     }
     if (on_top(s)) return;
@@ -163,22 +165,22 @@ ZADA_HD void run_parser(ParseState &s, const ParseIO &io, uint32_t *tok, uint32_
     }
     const uint32_t bb = s.avail ? io.in[s.p - 1] : 0;
     const uint32_t t = parse_step(s, m, srch, bb);
-    if (t != 0xFFFFFFFFu) tok[ntok++] = t;
+    if (t != 0xFFFFFFFFu) sink.push(t);
   }
 }
 
 // Speculative parse of chunk k, started in the fresh state at its first byte.  Records every
 // history-free state inside the chunk (F / L bitmaps) and stops at the first one at or beyond the
 // chunk's end (the chunk's exit); exit = (n, F) when the input ends first.
-template <typename OnGuess, typename Fetch>
-ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uint32_t *tok, uint32_t &ntok,
-                              uint32_t *Fbits, uint32_t *Lbits, ExitState &ex, OnGuess on_guess, Fetch &&fetch) {
+template <typename Sink, typename OnGuess, typename Fetch>
+ZADA_HD void parse_spec_chunk_to(const ParseIO &io, uint32_t k, uint32_t chunk, Sink &&sink,
+                                 uint32_t *Fbits, uint32_t *Lbits, ExitState &ex, OnGuess on_guess, Fetch &&fetch) {
   const uint64_t c0 = (uint64_t)k * chunk, c1 = (c0 + chunk < io.n) ? c0 + chunk : io.n;
   ParseState s{(uint32_t)c0, 0, 2, 0};
   BitmapWriter fw, lw;
   fw.init(Fbits, c0 >> 5); lw.init(Lbits, c0 >> 5);
   ExitState e; e.pos = (uint32_t)io.n; e.kind = SYNC_F;
-  run_parser(s, io, tok, ntok, [&](const ParseState &st) {
+  run_parser(s, io, sink, [&](const ParseState &st) {
     int kind = sync_kind(st);
     if (kind == SYNC_NONE) return false;
     if ((uint64_t)st.p >= c1) { e.pos = st.p; e.kind = (uint32_t)kind; return true; }
@@ -189,9 +191,14 @@ ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uin
   lw.finish((c1 - 1) >> 5);
   ex = e;
 }
+template <typename OnGuess, typename Fetch>
 ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uint32_t *tok, uint32_t &ntok,
-                                     uint32_t *Fbits, uint32_t *Lbits, ExitState &ex) {
-  parse_spec_chunk(io, k, chunk, tok, ntok, Fbits, Lbits, ex, NoGuess(), DirectFetch{io.M});
+                              uint32_t *Fbits, uint32_t *Lbits, ExitState &ex, OnGuess on_guess, Fetch &&fetch) {
+  parse_spec_chunk_to(io, k, chunk, DirectSink{tok, ntok}, Fbits, Lbits, ex, on_guess, fetch);
+}
+ZADA_HD void parse_spec_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, uint32_t *tok, uint32_t &ntok,
+                              uint32_t *Fbits, uint32_t *Lbits, ExitState &ex) {
+  parse_spec_chunk_to(io, k, chunk, DirectSink{tok, ntok}, Fbits, Lbits, ex, NoGuess(), DirectFetch{io.M});
 }
 
 // True parse of chunk k from the true exit of chunk k-1 (`entry`) until it reaches a history-free
@@ -214,7 +221,7 @@ ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, Exit
   ParseState s{entry.pos, entry.kind == SYNC_L ? 1u : 0u, 2, 0};
   bool synced = false;
   ExitState e; e.pos = (uint32_t)io.n; e.kind = SYNC_F;
-  run_parser(s, io, tok, ntok, [&](const ParseState &st) {
+  run_parser(s, io, DirectSink{tok, ntok}, [&](const ParseState &st) {
     int kind = sync_kind(st);
     if (kind == SYNC_NONE) return false;
     if ((uint64_t)st.p >= c1) { e.pos = st.p; e.kind = (uint32_t)kind; return true; }

@@ -1034,6 +1034,23 @@ struct LineFetch {
   }
 };
 
+// Tokens of a chunk are written eight at a time (two 16-byte stores to the chunk's own, 32-byte aligned token area)
+// instead of one scattered 4-byte store each; the eight wait in LDS, lane-interleaved.
+struct TokSink {
+  uint32_t *dst; uint32_t *buf; uint32_t n;
+  __device__ void push(uint32_t t) {
+    buf[(n & 7u) * 64] = t;
+    n++;
+    if ((n & 7u) == 0) {
+      uint4 a, b;
+      a.x = buf[0]; a.y = buf[64]; a.z = buf[128]; a.w = buf[192]; b.x = buf[256]; b.y = buf[320]; b.z = buf[384]; b.w = buf[448];
+      uint4 *o = (uint4 *)(dst + n - 8);
+      o[0] = a; o[1] = b;
+    }
+  }
+  __device__ void flush() { for (uint32_t i = n & ~7u; i < n; i++) dst[i] = buf[(i & 7u) * 64]; }
+};
+
 __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict__ spec_tok, uint32_t *__restrict__ spec_cnt,
                              uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits,
                              DemandMarker dm, const uint8_t *__restrict__ redo /* null: every chunk */) {
@@ -1043,8 +1060,12 @@ __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict_
   uint32_t ntok = 0;
   ExitState ex;
   __shared__ uint64_t lines[8 * 64];
+  __shared__ uint32_t tbuf[8 * 64];
   LineFetch lf; lf.M = io.M; lf.slot = lines + threadIdx.x; lf.tag = 0xFFFFFFFFu;
-  parse_spec_chunk(io, k, PCHUNK, spec_tok + (uint64_t)k * PTOK_STRIDE, ntok, Fbits, Lbits, ex, dm, lf);
+  TokSink ts; ts.dst = spec_tok + (uint64_t)k * PTOK_STRIDE; ts.buf = tbuf + threadIdx.x; ts.n = 0;
+  parse_spec_chunk_to(io, k, PCHUNK, ts, Fbits, Lbits, ex, dm, lf);
+  ts.flush();
+  ntok = ts.n;
   spec_cnt[k] = ntok;
   exits[k] = ex;
 }
