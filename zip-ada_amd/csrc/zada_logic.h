@@ -6,6 +6,7 @@
 //
 // Reference semantics cited per function (paths relative to the reference's zip_lib/).
 #pragma once
+#include <type_traits>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -145,6 +146,9 @@ struct BitmapWriter {
 // top of the loop, or the input ends (then the trailing literal :930-932 is emitted).
 // Fetch: how a match record is read (the GPU parser keeps the 64-byte line of its last look-up in LDS).
 struct DirectFetch { const MatchPair *M; ZADA_HD MatchPair operator()(uint32_t p) const { return M[p]; } };
+template <typename F> struct has_byte { template <typename U> static auto test(int) -> decltype(((U *)0)->byte(0u), char()); template <typename U> static long test(...); static const bool value = sizeof(test<F>(0)) == 1; };
+template <typename F> ZADA_HD typename std::enable_if<has_byte<typename std::remove_reference<F>::type>::value, uint32_t>::type fetch_byte(F &f, const uint8_t *, uint32_t p) { return f.byte(p); }
+template <typename F> ZADA_HD typename std::enable_if<!has_byte<typename std::remove_reference<F>::type>::value, uint32_t>::type fetch_byte(F &, const uint8_t *in, uint32_t p) { return in[p]; }
 // Sink: where the tokens go (the GPU's speculative parse collects eight of them in LDS before it writes).
 struct DirectSink { uint32_t *tok; uint32_t &ntok; ZADA_HD void push(uint32_t t) { tok[ntok++] = t; } };
 template <typename Sink, typename OnTop, typename OnGuess, typename Fetch>
@@ -163,7 +167,7 @@ ZADA_HD void run_parser(ParseState &s, const ParseIO &io, Sink &&sink, OnTop &&o
       if (mm.full & M_GUESS) on_guess(s.p, mm.full);
       m = (parse_need_quarter(s, io.cfg) ? mm.quarter : mm.full) & M_VALUE;
     }
-    const uint32_t bb = s.avail ? io.in[s.p - 1] : 0;
+    const uint32_t bb = s.avail ? fetch_byte(fetch, io.in, s.p - 1) : 0;
     const uint32_t t = parse_step(s, m, srch, bb);
     if (t != 0xFFFFFFFFu) sink.push(t);
   }

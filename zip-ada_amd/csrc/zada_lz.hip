@@ -1032,6 +1032,21 @@ struct LineFetch {
     MatchPair r; r.full = (uint32_t)v; r.quarter = (uint32_t)(v >> 32);
     return r;
   }
+  // the literal byte in front of a position: 64 input bytes per lane are kept the same way
+  const uint8_t *in; uint32_t *bslot; uint32_t btag;
+  __device__ uint32_t byte(uint32_t p) {
+    const uint32_t t = p >> 6;
+    if (t != btag) {
+      const uint4 *src = (const uint4 *)(in + ((uint64_t)t << 6));
+      const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+      bslot[0 * 64] = a.x; bslot[1 * 64] = a.y; bslot[2 * 64] = a.z; bslot[3 * 64] = a.w;
+      bslot[4 * 64] = b.x; bslot[5 * 64] = b.y; bslot[6 * 64] = b.z; bslot[7 * 64] = b.w;
+      bslot[8 * 64] = c.x; bslot[9 * 64] = c.y; bslot[10 * 64] = c.z; bslot[11 * 64] = c.w;
+      bslot[12 * 64] = d.x; bslot[13 * 64] = d.y; bslot[14 * 64] = d.z; bslot[15 * 64] = d.w;
+      btag = t;
+    }
+    return (bslot[((p >> 2) & 15u) * 64] >> (8 * (p & 3u))) & 0xFFu;
+  }
 };
 
 // Tokens of a chunk are written eight at a time (two 16-byte stores to the chunk's own, 32-byte aligned token area)
@@ -1061,7 +1076,8 @@ __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict_
   ExitState ex;
   __shared__ uint64_t lines[8 * 64];
   __shared__ uint32_t tbuf[8 * 64];
-  LineFetch lf; lf.M = io.M; lf.slot = lines + threadIdx.x; lf.tag = 0xFFFFFFFFu;
+  __shared__ uint32_t blines[16 * 64];
+  LineFetch lf; lf.M = io.M; lf.slot = lines + threadIdx.x; lf.tag = 0xFFFFFFFFu; lf.in = io.in; lf.bslot = blines + threadIdx.x; lf.btag = 0xFFFFFFFFu;
   TokSink ts; ts.dst = spec_tok + (uint64_t)k * PTOK_STRIDE; ts.buf = tbuf + threadIdx.x; ts.n = 0;
   parse_spec_chunk_to(io, k, PCHUNK, ts, Fbits, Lbits, ex, dm, lf);
   ts.flush();
