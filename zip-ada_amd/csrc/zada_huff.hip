@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(64) k_window_descr(const uint32_t *__restrict_
   __syncthreads();
   if (lane == 0) patch_dist_stats(hist + 288);
   __syncthreads();
-  llhc_wave(hist, 288, 15, bl, S, lane);
-  llhc_wave(hist + 288, 32, 15, bl + 288, S, lane);
+#pragma unroll 1
+  for (int t = 0; t < 2; t++) llhc_wave<15>(hist + 288 * t, t ? 32 : 288, bl + 288 * t, S, lane);
   __syncthreads();
   uint8_t *dst = descr + ((uint64_t)j * SLOTS + slot) * 320;
   for (int i = lane; i < 320; i += 64) dst[i] = bl[i];
@@ -168,10 +168,8 @@ __global__ void __launch_bounds__(256) k_block_analyze(const uint32_t *__restric
     patch_dist_stats(dt);                                                     // :340-365, on a copy
   }
   wave_sync();
-  if (w == 0) llhc_wave(st1, 288, 15, bl1, S[0], lane);                       // one wave per code set
-  else if (w == 1) llhc_wave(st2, 288, 15, bl2, S[1], lane);
-  else if (w == 2) llhc_wave(dtmp[0], 32, 15, bl1 + 288, S[2], lane);
-  else llhc_wave(dtmp[1], 32, 15, bl2 + 288, S[3], lane);
+  llhc_wave<15>(w == 0 ? st1 : w == 1 ? st2 : dtmp[w - 2], w < 2 ? 288 : 32,      // one wave per code set
+                ((w & 1) ? bl2 : bl1) + (w < 2 ? 0 : 288), S[w], lane);
   __syncthreads();
   if (w < 2) {                                                                // Put_Compression_Structure, cost analysis
     HeaderPlan *h = &hp[w];
@@ -188,7 +186,7 @@ __global__ void __launch_bounds__(256) k_block_analyze(const uint32_t *__restric
       header_rle_walk(h->cs_bl, idx, [tf](int x, uint32_t) { tf[x]++; });
     }
     wave_sync();
-    llhc_wave(h->truc_freq, 19, 7, h->truc_bl, S[w], lane);
+    llhc_wave<7>(h->truc_freq, 19, h->truc_bl, S[w], lane);
     if (lane == 0) {
       int anz = 3;
       for (int a = 0; a <= 18; a++) if (a > anz && h->truc_bl[header_perm(a)] > 0) anz = a;

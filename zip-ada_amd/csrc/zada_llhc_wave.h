@@ -11,8 +11,8 @@
 //    64 elements, so the reference's tie-breaking order is reproduced without running its loop.
 //  * Boundary_PM (:131-163) builds, lazily, the lists of the classic package-merge algorithm in
 //    which a package precedes a leaf of equal weight (":148 sum > leaves (lastcount).weight").
-//    The lists are built here level by level with parallel merges (binary-search ranks), each
-//    level keeping one bit per item (leaf / package); Extract_Bit_Lengths (:180-189) becomes a
+//    The lists are built here level by level with parallel merges (one merge-path chunk per lane),
+//    each level keeping one bit per item (leaf / package); Extract_Bit_Lengths (:180-189) becomes a
 //    prefix popcount per level.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -20,7 +20,7 @@
 
 namespace zada {
 
-constexpr int LLHC_WAVE_SCRATCH = 6656;    // bytes of LDS per instance
+constexpr int LLHC_WAVE_SCRATCH = 4736;    // bytes of LDS per instance
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -53,7 +53,8 @@ __device__ inline void small_qsort(uint32_t *lw, uint16_t *ls, int lo0, int m0, 
 }
 
 // freq[n] (LDS or global, read once) -> bl[n].  All 64 lanes of the wave must call it together.
-__device__ inline void llhc_wave(const uint32_t *freq, int n, int max_bits, uint8_t *bl, uint8_t *scratch, int lane) {
+template <int max_bits>
+__device__ __forceinline__ void llhc_wave(const uint32_t *freq, int n, uint8_t *bl, uint8_t *scratch, int lane) {
   uint32_t *lw = (uint32_t *)scratch;                 // 288 leaf weights
   uint16_t *ls = (uint16_t *)(lw + 288);              // 288 leaf symbols
   uint8_t *u = scratch + 1728;
@@ -81,10 +82,10 @@ __device__ inline void llhc_wave(const uint32_t *freq, int n, int max_bits, uint
     uint16_t *small = stk + 64;                       // 160 x (lo, m)
     uint16_t *lstk = small + 320;                     // 64 lanes x 8
     int sp = 0, nsmall = 0;
-    auto route = [&](int lo, int m) {                 // uniform
-      if (m < 2) return;
-      if (m <= 16) { if (lane == 0) { small[2 * nsmall] = (uint16_t)lo; small[2 * nsmall + 1] = (uint16_t)m; } nsmall++; }
-      else { if (lane == 0) { stk[2 * sp] = (uint16_t)lo; stk[2 * sp + 1] = (uint16_t)m; } sp++; }
+    auto route = [&](int lo, int m) {                 // uniform; sp / nsmall advance by arithmetic (no pointer select: they stay in registers)
+      const int big = m > 16 ? 1 : 0, sml = (m >= 2 && m <= 16) ? 1 : 0;
+      if (lane == 0 && m >= 2) { uint16_t *q = big ? stk + 2 * sp : small + 2 * nsmall; q[0] = (uint16_t)lo; q[1] = (uint16_t)m; }
+      sp += big; nsmall += sml;
     };
     route(0, ns);
     wave_sync();
@@ -133,60 +134,68 @@ __device__ inline void llhc_wave(const uint32_t *freq, int n, int max_bits, uint
   }
 
   // ---- package-merge, level by level ----
+  // Level l's list = merge(leaves, packages of level l-1's list).  Each lane merges one chunk of CH
+  // consecutive items of the list (merge-path split, then a two-pointer walk), adds them up in
+  // pairs into the next level's packages, and keeps what Extract_Bit_Lengths needs from its chunk:
+  // the number of leaves before it and one leaf / package flag per item.
   {
-    uint32_t *cur = (uint32_t *)u;                    // merged list of the current level (<= 575 items)
-    uint32_t *pk = cur + 608;                         // packages made of the previous level (<= 287)
-    uint32_t *bits = pk + 304;                        // [max_bits + 1][19] leaf flags per level
-    uint16_t *acnt = (uint16_t *)(bits + 16 * 19);
-    const uint32_t *prev = lw;
-    int plen = ns;
-    for (int l = 2; l <= max_bits; l++) {
-      const int np = plen >> 1;
-      for (int i = lane; i < np; i += 64) pk[i] = prev[2 * i] + prev[2 * i + 1];
-      for (int i = lane; i < 19; i += 64) bits[l * 19 + i] = 0;
-      wave_sync();
-      // leaves: position = r + #(packages <= weight)      (a package precedes a leaf of equal weight)
-      for (int r = lane; r < ns; r += 64) {
-        const uint32_t v = lw[r];
-        int lo = 0, cnt = np;
-        while (cnt > 0) { const int half = cnt >> 1; if (pk[lo + half] <= v) { lo += half + 1; cnt -= half + 1; } else cnt = half; }
-        const int pos = r + lo;
-        cur[pos] = v;
-        atomicOr(&bits[l * 19 + (pos >> 5)], 1u << (pos & 31));
-      }
-      // packages: position = i + #(leaves < weight)
-      for (int i = lane; i < np; i += 64) {
-        const uint32_t v = pk[i];
-        int lo = 0, cnt = ns;
-        while (cnt > 0) { const int half = cnt >> 1; if (lw[lo + half] < v) { lo += half + 1; cnt -= half + 1; } else cnt = half; }
-        cur[i + lo] = v;
-      }
-      wave_sync();
-      prev = cur;
-      plen = ns + np;
-    }
-    // Extract_Bit_Lengths: number of leaves among the items in use at each level
-    int x = 2 * ns - 2;
-    for (int l = max_bits; l >= 2; l--) {
-      uint32_t c = 0;
-      if (lane < 19) {
-        const int lo_bit = lane * 32;
-        uint32_t wv = bits[l * 19 + lane];
-        if (x <= lo_bit) wv = 0;
-        else if (x < lo_bit + 32) wv &= (1u << (x - lo_bit)) - 1u;
-        c = __popc(wv);
-      }
-      for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-      if (lane == 0) acnt[l] = (uint16_t)c;
-      x = 2 * (x - (int)c);
-    }
-    if (lane == 0) acnt[1] = (uint16_t)(x < ns ? x : ns);
+    uint32_t *pk0 = (uint32_t *)u;                    // packages merged into the current level (<= 287)
+    uint32_t *pk1 = pk0 + 288;                        // packages made from the current level
+    uint32_t rec[max_bits + 1];                       // per level: leaves before the lane's chunk | flags << 16 (registers)
+    int np = ns >> 1;
+    for (int i = lane; i < np; i += 64) pk0[i] = lw[2 * i] + lw[2 * i + 1];
+    const int CH = (((2 * ns - 1 + 63) >> 6) + 1) & ~1;  // even, 64 * CH >= the longest list (2 ns - 1 items)
+    const int d0 = lane * CH;
     wave_sync();
-    for (int r = lane; r < ns; r += 64) {
-      int len = 0;
-      for (int l = 1; l <= max_bits; l++) len += acnt[l] > r ? 1 : 0;
-      bl[ls[r]] = (uint8_t)len;
+#pragma unroll
+    for (int l = 2; l <= max_bits; l++) {
+      const int total = ns + np;
+      int i = ns;
+      uint32_t flags = 0;
+      if (d0 < total) {
+        // merge path: i = leaves among the first d0 items (a package precedes a leaf of equal weight)
+        int lo = d0 > np ? d0 - np : 0, hi = d0 < ns ? d0 : ns;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (lw[mid] < pk0[d0 - 1 - mid]) lo = mid + 1; else hi = mid;
+        }
+        i = lo;
+        int a = i, b = d0 - i;
+        uint32_t va = a < ns ? lw[a] : 0u, vb = b < np ? pk0[b] : 0u, sum = 0;
+        const int cnt = total - d0 < CH ? total - d0 : CH;
+        for (int t = 0; t < cnt; t++) {
+          const bool take_p = b < np && (a >= ns || vb <= va);
+          const uint32_t v = take_p ? vb : va;
+          if (take_p) { b++; vb = b < np ? pk0[b] : 0u; }
+          else { flags |= 1u << t; a++; va = a < ns ? lw[a] : 0u; }
+          if (t & 1) pk1[(d0 + t) >> 1] = sum + v; else sum = v;
+        }
+      }
+      rec[l] = (uint32_t)i | (flags << 16);
+      wave_sync();
+      uint32_t *tp = pk0; pk0 = pk1; pk1 = tp;
+      np = total >> 1;
     }
+    // Extract_Bit_Lengths (:180-189): leaves among the x items in use at each level (uniform over the wave)
+    const float rch = 1.0f / (float)CH;
+    int x = 2 * ns - 2;
+    int len[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int l = max_bits; l >= 2; l--) {
+      const int ln = __builtin_amdgcn_readfirstlane((int)(((float)x + 0.5f) * rch)), t = x - ln * CH;   // x = ln * CH + t exactly (x <= 575)
+      int c = ns;
+      if (ln < 64) { const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rec[l], ln); c = (int)(w & 0xFFFFu) + __popc((w >> 16) & ((1u << t) - 1u)); }
+#pragma unroll
+      for (int q = 0; q < 5; q++) len[q] += c > lane + 64 * q ? 1 : 0;
+      x = 2 * (x - c);
+    }
+    {
+      const int c = x < ns ? x : ns;
+#pragma unroll
+      for (int q = 0; q < 5; q++) len[q] += c > lane + 64 * q ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; q++) { const int r = lane + 64 * q; if (r < ns) bl[ls[r]] = (uint8_t)len[q]; }
     wave_sync();
   }
 }
