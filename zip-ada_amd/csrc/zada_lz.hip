@@ -448,7 +448,12 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
 
 // Cross-segment continuation of the nearest 3 .. K-1 byte matches (runs after k_cross_links): one
 // thread per inserted position of the segments >= 1; only positions marked "continue" do any work.
-__global__ void __launch_bounds__(256) k_cross_dist(const uint8_t *__restrict__ in, uint64_t n_ins, LevelPtrs lv,
+// (one wave per workgroup: a lane with a long bucket to scan only holds up its own wave)
+#ifndef ZADA_CD_THREADS
+#define ZADA_CD_THREADS 64
+#endif
+constexpr int CD_THREADS = ZADA_CD_THREADS;
+__global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__restrict__ in, uint64_t n_ins, LevelPtrs lv,
                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
                                                     DistPlanes dp) {
   const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1283,9 +1288,9 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
 #endif
     c->tmark("prev_links");
     if (nseg > 1) {
-      const uint32_t nb = (uint32_t)((n_ins - 32768 + 255) / 256);
+      const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
       hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), 131072, st, W.in, n_ins, lv);
-      hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(256), 0, st, W.in, n_ins, lv, W.S3, W.T3, W.bsc3, dpl);
+      hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, n_ins, lv, W.S3, W.T3, W.bsc3, dpl);
     }
     hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, n_ins, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim);
     {
