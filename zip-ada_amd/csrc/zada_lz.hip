@@ -578,6 +578,7 @@ __global__ void __launch_bounds__(256) k_bucket_limits(uint64_t n_ins, int kfull
 #ifndef ZADA_FAST
 #define ZADA_FAST 12
 #endif
+static_assert(ZADA_FAST % 2 == 0, "the fast phase is unrolled in pairs of steps");
 constexpr int MB = 16384;
 constexpr int HALO = 32512;                       // >= MAX_DIST, multiple of 16
 constexpr int WBYTES = HALO + MB + 272;           // 49168
@@ -626,7 +627,9 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     const uint32_t nl = woff + cnt;                                // links to stage (u16 each)
     const uint4 *ls = (const uint4 *)(prevd + WB);
     uint4 *ld = (uint4 *)lnk;
-    for (uint32_t i = tid; i < (nl * 2 + 15) / 16; i += 1024) ld[i] = ls[i];
+    // "no predecessor" (0) becomes the distance 0xFFFF: beyond every limit, so that the walk's limit test covers it
+    auto nil2 = [](uint32_t x) -> uint32_t { return x | ((x & 0xFFFFu) ? 0u : 0xFFFFu) | ((x >> 16) ? 0u : 0xFFFF0000u); };
+    for (uint32_t i = tid; i < (nl * 2 + 15) / 16; i += 1024) { uint4 v = ls[i]; v.x = nil2(v.x); v.y = nil2(v.y); v.z = nil2(v.z); v.w = nil2(v.w); ld[i] = v; }
     if (tid < 4) next_pos[tid] = 0;
   }
   __syncthreads();
@@ -637,7 +640,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   uint32_t wi = woff, cur = woff, ncur = woff, bdist = 0, rq = 0, kpos = 0, s_end = 0;
   int best = 2, la = 3, nice = 3, state = 0;
   uint32_t lim_cur = 0, lim_full = 0;
-  bool have_q = false, ev_pass = false, ev_end = false, ev_lim = false, exhausted = false;
+  bool have_q = false, exhausted = false;
   int age = 0;                                                     // rounds spent on the current position
   for (;;) {
     // ---- fetch ----
@@ -676,8 +679,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           // chain_ok: a candidate of length K-1 exists, so longer ones may: walk the level-K chain
           have_q = chain_ok && bdist > lim_q; rq = qbest;
           lim_cur = have_q ? lim_full : lim_q;
-          const uint32_t d0 = lnk[wi];
-          bool ok = chain_ok && best < nice && d0 != 0 && d0 <= lim_full;
+          const uint32_t d0 = lnk[wi];                              // (0xFFFF = none)
+          bool ok = chain_ok && best < nice && d0 <= lim_full;
           if (ok && !have_q && d0 > lim_q) { have_q = true; rq = ((uint32_t)best << 16) | bdist; lim_cur = lim_full; }
           cur = ok ? wi - d0 : wi;
           const uint32_t a = wi + (uint32_t)best;
@@ -694,28 +697,58 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     }
     if (!__any(state != 0)) { if (__all(exhausted)) break; continue; }
     // ---- fast phase ----
+    // A step: the candidate's link and the two bytes at best-1, best (:754-755); the walk stops at a candidate
+    // that passes the filter, or whose successor lies beyond the limit (which includes "no successor").  Six vector
+    // instructions: the current and the next candidate swap registers from step to step instead of being copied,
+    // and what stopped the walk is worked out afterwards, in the slow phase.
+    {
+      bool walk = state == 1, odd_stop = false;
+      typedef const __attribute__((address_space(3))) uint8_t *lds_bytes;
+      const uint32_t off = (uint32_t)(uintptr_t)(lds_bytes)win8 + (uint32_t)best - 1u;   // LDS address of byte best-1 of candidate 0
+      const int lim_pos = (int)wi - (int)lim_cur;                  // candidates below this index are too far (:819-822)
+      uint32_t ca = cur, cb = ncur;
 #pragma unroll
-    for (int it = 0; it < ZADA_FAST; it++) {
-      if (state == 1) {
+      for (int it = 0; it < ZADA_FAST; it += 2) {
+        if (walk) {
 #ifdef ZADA_MATCH_STATS
-        iters++;
+          iters++;
 #endif
-        const uint32_t dn = lnk[cur];                              // link to the next candidate
-        const uint32_t a = cur + (uint32_t)best;
-        const uint32_t c16 = LDS_U16(win8, a - 1);
-        const bool pass = c16 == s_end;                            // bytes best-1, best agree (:754-755)
-        const uint32_t nc = cur - dn, nd = wi - nc;
-        const bool end = dn == 0;                                  // chain exhausted
-        const bool lim = nd > lim_cur;                             // next candidate beyond the quarter / full limit (:819-822)
-        const bool ev = pass || end || lim;
-        ncur = nc;
-        ev_pass = pass; ev_end = end; ev_lim = lim;
-        cur = ev ? cur : nc;
-        state = ev ? 2 : 1;
+          const uint32_t dn = lnk[ca];
+          uint32_t aa = ca + off;
+          asm("" : "+v"(aa));                                     // (keeps the + 1 of the second byte in the instruction's offset field)
+          const lds_bytes pa = (lds_bytes)aa;
+          const uint32_t c16 = (uint32_t)pa[0] | ((uint32_t)pa[1] << 8);
+          cb = ca - dn;
+          walk = !(c16 == s_end || (int)cb < lim_pos);
+        }
+        if (walk) {
+#ifdef ZADA_MATCH_STATS
+          iters++;
+#endif
+          const uint32_t dn = lnk[cb];
+          uint32_t ab = cb + off;
+          asm("" : "+v"(ab));
+          const lds_bytes pb = (lds_bytes)ab;
+          const uint32_t c16 = (uint32_t)pb[0] | ((uint32_t)pb[1] << 8);
+          ca = cb - dn;
+          walk = !(c16 == s_end || (int)ca < lim_pos);
+          odd_stop = !walk;
+        }
       }
+      // a walk that stopped in an odd step has its candidate in cb and the successor in ca
+      cur = odd_stop ? cb : ca;
+      ncur = odd_stop ? ca : cb;
+      if (state == 1 && !walk) state = 2;
     }
     // ---- slow phase ----
     if (__any(state == 2)) {
+      // what stopped the walk
+      bool ev_pass = false, ev_end = false, ev_lim = false;
+      if (state == 2) {
+        ev_pass = LDS_U16(win8, cur + (uint32_t)best - 1u) == s_end;   // bytes best-1, best agree (:754-755)
+        ev_end = lnk[cur] == 0xFFFFu;                                   // chain exhausted
+        ev_lim = (int)ncur < (int)wi - (int)lim_cur;                    // next candidate beyond the quarter / full limit (:819-822)
+      }
       bool cmpa = (state == 2) && ev_pass;
       uint32_t off = 0;
       int len = 0;
