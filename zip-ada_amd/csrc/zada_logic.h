@@ -122,7 +122,7 @@ struct MatchPair { uint32_t full, quarter; };
 // number of chain steps; a search cut short leaves its best-so-far as a GUESS.  A parse that lands on a guess uses
 // it and marks it DEMANDed; demanded positions are then searched to the end, the parses that used a value which
 // changed are redone, and so on until a parse has used exact values only (zada_lz.hip, lz_stage).
-constexpr uint32_t M_GUESS = 0x80000000u, M_DEMAND = 0x40000000u, M_BYSPEC = 0x20000000u, M_VALUE = 0x01FFFFFFu;   // M_BYSPEC: demanded by a speculative parse
+constexpr uint32_t M_GUESS = 0x80000000u, M_DEMAND = 0x40000000u, M_BYSPEC = 0x20000000u, M_HAVEQ = 0x10000000u, M_VALUE = 0x01FFFFFFu;   // M_BYSPEC: demanded by a speculative parse
 struct NoGuess { ZADA_HD void operator()(uint32_t, uint32_t) const {} };
 struct ParseIO { const uint8_t *in; uint64_t n; const MatchPair *M; LzConfig cfg; };
 struct ExitState { uint32_t pos, kind; };

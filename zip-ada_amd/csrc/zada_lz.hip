@@ -603,7 +603,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
                                                 const uint16_t *__restrict__ prevd,
                                                 DistPlanes dp,
                                                 MatchPair *__restrict__ M,
-                                                int nice_cfg, int budget, unsigned long long *__restrict__ dbg) {
+                                                int nice_cfg, int budget, unsigned long long *__restrict__ dbg,
+                                                uint16_t *__restrict__ resume) {
   // Every position of the block is searched for at most `budget` rounds of ZADA_FAST chain steps; a search cut
   // short leaves its best so far as a guess (M_GUESS) that k_match_demand replaces if a parse ever lands on it.
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -789,8 +790,10 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     // first pass: a search that has had its share of rounds is cut short, its best so far becomes a guess
     if (state == 1 && ++age >= budget) {
       const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
-      MatchPair r; r.full = packed | M_GUESS; r.quarter = have_q ? rq : packed;
+      // (k_match_demand takes the search up where it stops here: the next candidate, as a distance, goes with the guess)
+      MatchPair r; r.full = packed | M_GUESS | (have_q ? M_HAVEQ : 0u); r.quarter = have_q ? rq : packed;
       M[B + kpos] = r;
+      resume[B + kpos] = (uint16_t)(wi - cur);
       state = 0;
     }
   }
@@ -822,6 +825,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 #ifndef ZADA_DM_THREADS
 #define ZADA_DM_THREADS 512
 #endif
+static_assert(NLEVELS >= 2, "the links of level 0 are dead after k_cross_dist: their array carries the resume points of the guesses");
 constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256, DM_AHEAD = 8;
 constexpr int DM_WBYTES = HALO + DMB + 272;
 struct ScanDesc {                                  // a position whose candidates have to be scanned (32 bytes, in LDS)
@@ -834,7 +838,7 @@ static_assert(MB % DMB == 0 && DM_WBYTES % 16 == 0 && sizeof(ScanDesc) == 32, "d
 __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__restrict__ in, uint64_t n, DistPlanes dp, RunPtrs rp,
                                                              const uint16_t *__restrict__ tailsK, MatchPair *__restrict__ M, int nice_cfg,
                                                              const uint32_t *__restrict__ blk_demand, uint8_t *__restrict__ chg,
-                                                             const ExitState *__restrict__ spec_exits) {
+                                                             const ExitState *__restrict__ spec_exits, const uint16_t *__restrict__ resume) {
   if (blk_demand[blockIdx.x] == 0) return;
   const uint64_t B = (uint64_t)blockIdx.x * DMB;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -918,12 +922,26 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
         if (v) { best = 3 + l; bdist = dl[l]; if (dl[l] <= lim_q) qbest = ((uint32_t)(3 + l) << 16) | dl[l]; }
         chain_ok = v;
       }
-      const bool have_q = chain_ok && bdist > lim_q;
+      bool have_q = chain_ok && bdist > lim_q;
+      // The search was begun by k_match: its best so far is the guess, and `resume` the candidate it had come to.
+      // The candidates before that one (nearer) are dropped from the two runs.
+      uint32_t idx1r = idx1, c1r = c1, idx2r = idx2, c2r = c2;
+      if (chain_ok) {
+        const uint32_t gl = (og.full & M_VALUE) >> 16;
+        if (gl >= 3) { best = (int)gl; bdist = og.full & 0xFFFFu; }
+        have_q = (og.full & M_HAVEQ) != 0;
+        if (have_q) qbest = og.quarter;
+        const uint64_t q = p - resume[p];
+        const uint32_t iq = rp.idx[q];
+        const uint32_t skip = q >= (seg << 15) ? idx1 - 1 - iq : c1 + (idx2 - iq);   // candidates nearer than q
+        if (skip < c1) { idx1r = idx1 - skip; c1r = c1 - skip; }
+        else { const uint32_t s2 = skip - c1 < c2 ? skip - c1 : c2; c1r = 0; idx2r = idx2 - s2; c2r = c2 - s2; }
+      }
       const uint64_t chk = p / PCHUNK;
       const bool reach = chk > 0 && spec_exits[chk - 1].pos >= (uint32_t)p;
-      if (chain_ok && best < nice && c1 + c2 > 0) {
+      if (chain_ok && best < nice && c1r + c2r > 0) {
         ScanDesc ds;
-        ds.k = (uint16_t)k; ds.la = (uint16_t)la; ds.idx1 = (uint16_t)idx1; ds.c1 = (uint16_t)c1; ds.idx2 = (uint16_t)idx2; ds.c2 = (uint16_t)c2;
+        ds.k = (uint16_t)k; ds.la = (uint16_t)la; ds.idx1 = (uint16_t)idx1r; ds.c1 = (uint16_t)c1r; ds.idx2 = (uint16_t)idx2r; ds.c2 = (uint16_t)c2r;
         ds.lim_full = (uint16_t)lim_full; ds.lim_q = (uint16_t)lim_q; ds.bdist = (uint16_t)bdist; ds.best_hq = (uint16_t)((uint32_t)best | ((uint32_t)reach << 14) | ((uint32_t)have_q << 15));
         ds.rq = qbest; ds.og_full = og.full; ds.og_quarter = og.quarter;
         desc[atomicAdd(&ctr[1], 1u)] = ds;
@@ -1347,7 +1365,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
   hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), WBYTES + WLINKS * 2 + 16, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
-                     budget_env, (unsigned long long *)W.dbg);
+                     budget_env, (unsigned long long *)W.dbg, W.lprev[0]);
   c->tmark("match");
   ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg;
   DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand; dm.by = M_BYSPEC;
@@ -1393,7 +1411,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
       hipLaunchKernelGGL(k_demand_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, W.M, W.blk_demand);
     }
     hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, n, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
-                       W.blk_demand, W.chg, W.spec_exits);
+                       W.blk_demand, W.chg, W.spec_exits, W.lprev[0]);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   }
   c->demand_rounds = demand_rounds;
