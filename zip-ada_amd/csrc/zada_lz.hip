@@ -459,10 +459,15 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
   const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_ins) return;
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
+  // (what the levels >= 4 start from is loaded up front: these loads do not depend on the level-3 search)
+  uint32_t dl_first[NLEVELS > 1 ? NLEVELS - 1 : 1], link_first[NLEVELS > 1 ? NLEVELS - 1 : 1];
+#pragma unroll
+  for (int l = 0; l + 1 < NLEVELS; l++) { dl_first[l] = dp.d[1 + l][p]; link_first[l] = lv.prev[l][p]; }
+  const uint64_t mine = *(const u64u *)(in + p);
   // level 3 first: the previous segment's bucket of the 15-bit hash, newest first
   uint32_t dprev = dp.d[0][p];
   if (dprev == DIST3_CONTINUE) {
-    const uint32_t my24 = *(const u32u *)(in + p) & 0xFFFFFFu;
+    const uint32_t my24 = (uint32_t)mine & 0xFFFFFFu;
     const uint32_t b0 = my24 & 0xFF, b1 = (my24 >> 8) & 0xFF;
     const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (my24 >> 16)) & 0x7FFFu;
     const uint32_t bsc = bsc3[pbase + h];
@@ -504,15 +509,16 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
   // levels >= 4: follow the level's chain (it crosses into the previous segment after k_cross_links).
   // The levels are nested: no L-1 byte match => no L byte match, and an L byte match is never nearer
   // than the nearest L-1 byte match.
+#pragma unroll
   for (int l = 0; l + 1 < NLEVELS; l++) {
-    uint32_t dl = dp.d[1 + l][p];
+    uint32_t dl = dl_first[l];
     if (dl == DIST3_CONTINUE) {
       dl = 0;
       if (dprev != 0) {
         uint64_t q = p;
-        const uint64_t mine = *(const u64u *)(in + p), mask = (1ull << (8 * (4 + l))) - 1ull;
-        for (;;) {
-          const uint32_t d = lv.prev[l][q];
+        const uint64_t mask = (1ull << (8 * (4 + l))) - 1ull;
+        uint32_t d = link_first[l];
+        for (;; d = lv.prev[l][q]) {
           if (d == 0) break;
           q -= d;
           if (p - q > (uint64_t)MAX_DIST) break;
