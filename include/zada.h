@@ -79,8 +79,10 @@ int zada_deflate(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n,
 int zada_deflate_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n,
                         void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
 
-/* `count` independent streams (e.g. one per Zip entry), processed back to back on the context's
- * stream.  rc[i] receives the per-stream return code; crc[i] is in/out as above. */
+/* `count` independent streams (e.g. one per Zip entry: Zip.Create.Add_Stream, zip-create.adb:194-297, is per
+ * entry).  Small entries are compressed several at a time (host threads with a stream and a workspace each,
+ * owned by ctx; ZADA_BATCH_STREAMS, default 4), entries above 64 MiB one after the other.  rc[i] receives the
+ * per-stream return code; crc[i] is in/out as above.  Returns the last negative rc[i], or 0. */
 int zada_deflate_batch(zada_ctx *ctx, int method, int count,
                        const uint8_t *const *in, const uint64_t *n,
                        uint8_t *const *out, const uint64_t *cap,

@@ -2,7 +2,7 @@
 # usage (GPU box): tests/prof_trace.sh <tag> [mib]  -> gpurun_out/<tag>_ktrace.csv (kernel name, start, end; last call only)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$1 -- python3 $R/tests/gpu_perf.py ${2:-64} 1 > $R/gpurun_out/$1.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$1 -- python3 $R/tests/gpu_perf.py ${2:-64} ${3:-1} > $R/gpurun_out/$1.log 2>&1
 python3 - "$R/gpurun_out/$1" > $R/gpurun_out/$1_ktrace.txt <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]

@@ -189,6 +189,29 @@ def test_device_resident_entry_point(encoder):
     assert rc == 0 and bytes(t_out[:ol].cpu().numpy()) == ref and crc == crc2
 
 
+def test_batch_of_entries_equals_single_calls(encoder):
+    """zada_deflate_batch (entries compressed several at a time on separate streams) == one zada_deflate per entry
+    == the oracle, in entry order, including empty, stored-fallback and multi-segment entries."""
+    rng = np.random.default_rng(11)
+    mix = silesia_mix(3 << 20)
+    datas = [b"", b"a", bytes(rng.integers(0, 256, 5000, dtype=np.uint8))]          # empty, tiny, incompressible
+    off = 0
+    for k in range(40):
+        ln = int(rng.integers(1, 200000))
+        datas.append(bytes(mix[off:off + ln])); off = (off + ln) % (len(mix) - 200000)
+    datas.append(bytes(mix[:2 << 20]))                                                 # several segments
+    res = encoder.deflate_batch(datas, 10)
+    assert len(res) == len(datas)
+    for i, (d, (rc, out, crc)) in enumerate(zip(datas, res)):
+        rc1, ref, crc1 = gpu_deflate(encoder, d, 10)
+        assert rc == rc1, i
+        if rc == 0:
+            assert out == ref and crc == crc1, i
+        if i % 7 == 0:
+            rc2, oref, ocrc = oracle_deflate(d, 10, [])
+            assert rc2 == rc and (rc != 0 or (oref == out and ocrc == crc)), i
+
+
 def test_full_size_properties(encoder):
     """BASELINE config C2 size (1 GiB, Deflate_3): properties that do not need the oracle at full size --
     the stream inflates back to the input (independent inflater), CRC equals zlib's, and the first

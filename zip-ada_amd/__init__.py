@@ -63,6 +63,7 @@ def load_library():
     L.zada_version.restype = ctypes.c_char_p
     L.zada_deflate.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, vp, vp]
     L.zada_deflate_device.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
+    L.zada_deflate_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.zada_compress_data.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, ctypes.POINTER(ctypes.c_uint16)]
     L.zada_lz77_tokens.argtypes = [vp, i32, vp, u64, vp, u64, u64p]
     L.zada_last_blocks.argtypes = [vp, vp, u64, u64p]
@@ -124,6 +125,26 @@ class Encoder:
         if rc != 0:
             self._err(rc, "zada_deflate")
         return out.raw[:ol.value], c.value
+
+    def deflate_batch(self, datas, method=Method.Deflate_3, crc=0xFFFFFFFF):
+        """Independent streams (one per Zip entry) in one call: zada_deflate_batch compresses small ones several
+        at a time.  Returns a list of (rc, raw deflate bytes or None, running CRC register); rc 1 = inefficient."""
+        cnt = len(datas)
+        if cnt == 0:
+            return []
+        ns = (ctypes.c_uint64 * cnt)(*[len(d) for d in datas])
+        caps = (ctypes.c_uint64 * cnt)(*[len(d) + 64 for d in datas])
+        outs = [ctypes.create_string_buffer(len(d) + 64) for d in datas]
+        keep = [d if len(d) else b"\0" for d in datas]
+        ins = (ctypes.c_void_p * cnt)(*[_addr(d) for d in keep])
+        outp = (ctypes.c_void_p * cnt)(*[ctypes.addressof(o) for o in outs])
+        ols = (ctypes.c_uint64 * cnt)()
+        crcs = (ctypes.c_uint32 * cnt)(*([crc] * cnt))
+        rcs = (ctypes.c_int * cnt)()
+        worst = self.lib.zada_deflate_batch(self.ctx, method, cnt, ins, ns, outp, caps, ols, crcs, rcs)
+        if worst < 0:
+            self._err(worst, "zada_deflate_batch")
+        return [(rcs[i], outs[i].raw[:ols[i]] if rcs[i] == 0 else None, crcs[i]) for i in range(cnt)]
 
     def deflate_device(self, d_in_ptr, n, d_out_ptr, cap, method=Method.Deflate_3, crc=0xFFFFFFFF):
         """Device-resident variant (pointers are HBM addresses, e.g. torch tensor .data_ptr()).

@@ -6,10 +6,13 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include "../../include/zada.h"
 #include "zada_internal.h"
 
-struct zada_ctx { zada::Ctx c; };
+struct zada_ctx { zada::Ctx c; std::vector<zada_ctx *> workers; };   // workers: further contexts of zada_deflate_batch
 
 namespace zada {
 
@@ -198,8 +201,8 @@ int crc_launch(Ctx *c, uint64_t n) {
   CrcPending &P = c->crc;
   // level 0: one value per CRC_SUB (256 B); levels 1..3 fold 16:1 (4 KiB, 64 KiB, 1 MiB); only FULL
   // groups are folded on the device, the host chains the few leftovers of every level
-  static bool mats = false;
-  if (!mats) { for (int l = 0; l < CRC_NLEV; l++) zero_advance_matrix((uint64_t)CRC_SUB << (4 * l), crc_M[l]); mats = true; }
+  static std::once_flag mats;
+  std::call_once(mats, [] { for (int l = 0; l < CRC_NLEV; l++) zero_advance_matrix((uint64_t)CRC_SUB << (4 * l), crc_M[l]); });
   hipStream_t s2 = c->stream2;
   hipEventRecord(c->ev_input, c->stream);                            // the input (and its zero pad) is in place
   hipStreamWaitEvent(s2, c->ev_input, 0);
@@ -330,6 +333,7 @@ zada_ctx *zada_create(int device) {
 
 void zada_destroy(zada_ctx *z) {
   if (!z) return;
+  for (zada_ctx *w : z->workers) zada_destroy(w);
   hipSetDevice(z->c.device);
   hipStreamSynchronize(z->c.stream);
   for (void *p : z->c.ws.allocs) hipFree(p);
@@ -390,12 +394,37 @@ int zada_deflate_device(zada_ctx *z, int method, const void *d_in, uint64_t n, v
 
 int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
                        const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc) {
-  int worst = 0;
-  for (int i = 0; i < count; i++) {
-    rc[i] = zada_deflate(z, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr);
-    if (rc[i] < 0) worst = rc[i];
+  if (!z || count < 0) return ZADA_E_INVALID;
+  // A small entry leaves most of the GPU idle (one workgroup per 32 KiB segment in the link stage) and every entry
+  // has its host round trips (the demand loop): entries are therefore taken by a few host threads, each with a
+  // context (stream, workspace) of its own, so that the kernels of different entries run side by side.
+  uint64_t nmax = 0;
+  for (int i = 0; i < count; i++) nmax = n[i] > nmax ? n[i] : nmax;
+  int T = count < 4 ? count : 4;                                   // (more host threads only contend for the runtime)
+  { const char *e = getenv("ZADA_BATCH_STREAMS"); if (e && atoi(e) >= 1) T = atoi(e) < count ? atoi(e) : count; }
+  if (nmax > (64ull << 20)) T = 1;                              // big entries fill the GPU by themselves
+  while (T > 1 && (int)z->workers.size() < T - 1) {
+    zada_ctx *w = zada_create(z->c.device);
+    if (!w) { T = (int)z->workers.size() + 1; break; }
+    w->c.timing_on = false;
+    z->workers.push_back(w);
   }
-  return worst;
+  std::atomic<int> next(0), worst(0);
+  std::mutex err_lock;
+  auto work = [&](zada_ctx *ctx) {
+    for (int i; (i = next.fetch_add(1)) < count;) {
+      rc[i] = zada_deflate(ctx, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr);
+      if (rc[i] < 0) { worst.store(rc[i]); if (ctx != z) { std::lock_guard<std::mutex> g(err_lock); z->c.err = ctx->c.err; } }
+    }
+  };
+  if (T <= 1) work(z);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, z->workers[t - 1]);
+    work(z);
+    for (auto &x : th) x.join();
+  }
+  return worst.load();
 }
 
 int zada_compress_data(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,

@@ -22,6 +22,7 @@
 //
 // Why the result is identical to the sequential reference: see DESIGN.md "LZ77 stage".
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include "zada_logic.h"
 #include "zada_internal.h"
@@ -1323,14 +1324,13 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   const uint64_t n_ins = n >= 2 ? n - 2 : 0;
   const uint32_t nseg = (uint32_t)((n_ins + 32767) / 32768);
   c->tmark("lz:begin");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::once_flag attr_done;
+  std::call_once(attr_done, [] {
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
     hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16);
     hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
-    attr_done = true;
-  }
+  });
   LevelPtrs lv;
   DistPlanes dpl;
   RunPtrs rpt; rpt.S = W.SK; rpt.idx = W.idxK; rpt.cnt = W.cntK;
