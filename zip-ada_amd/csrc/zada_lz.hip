@@ -842,7 +842,8 @@ struct ScanDesc {                                  // a position whose candidate
 };
 constexpr int DM_LDS = DM_WBYTES + DMB * 2 + DM_SLICE * (int)sizeof(ScanDesc) + 64;
 static_assert(MB % DMB == 0 && DM_WBYTES % 16 == 0 && sizeof(ScanDesc) == 32, "demand blocks tile the first-pass blocks");
-__global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__restrict__ in, uint64_t n, DistPlanes dp, RunPtrs rp,
+// (six waves per SIMD, i.e. three workgroups per CU: without the bound the compiler takes 85 registers and only two fit)
+__global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *__restrict__ in, uint64_t n, DistPlanes dp, RunPtrs rp,
                                                              const uint16_t *__restrict__ tailsK, MatchPair *__restrict__ M, int nice_cfg,
                                                              const uint32_t *__restrict__ blk_demand, uint8_t *__restrict__ chg,
                                                              const ExitState *__restrict__ spec_exits, const uint16_t *__restrict__ resume) {
@@ -964,18 +965,26 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
     const uint32_t ns = ctr[1];
     // candidate c of a descriptor's position (nearest first), as a distance; 0 = no such candidate.  Position 0 is never
     // a match source (:467) and ends the chain.
-    auto cand = [&](const ScanDesc &ds, uint32_t c) -> uint32_t {
+    // The load and its use are kept apart (cand_load returns what the sorted order holds, cand_dist turns it into the
+    // distance): the loads of several batches are then in flight together instead of each being waited for.  A lane
+    // without a candidate reads the segment's first entry, so that there is no branch around the load.
+    auto cand_load = [&](const ScanDesc &ds, uint32_t c) -> uint32_t {
+      const uint64_t sb = ((B + ds.k) >> 15) << 15;
+      const bool in1 = c < ds.c1, in2 = !in1 && c - ds.c1 < ds.c2;
+      const uint64_t a = in1 ? sb + ds.idx1 - 1 - c : (in2 ? sb - 32768 + ds.idx2 - (c - ds.c1) : sb);
+      return rp.S[a];
+    };
+    auto cand_dist = [&](const ScanDesc &ds, uint32_t c, uint32_t raw) -> uint32_t {
       const uint64_t P_ = B + ds.k, sb = (P_ >> 15) << 15;
-      uint64_t q = 0;
-      if (c < ds.c1) q = sb + rp.S[sb + ds.idx1 - 1 - c];
-      else if (c - ds.c1 < ds.c2) q = sb - 32768 + rp.S[sb - 32768 + ds.idx2 - (c - ds.c1)];
+      const bool in1 = c < ds.c1, in2 = !in1 && c - ds.c1 < ds.c2;
+      const uint64_t q = in1 ? sb + raw : (in2 ? sb - 32768 + raw : 0ull);
       return q != 0 ? (uint32_t)(P_ - q) : 0u;
     };
-    uint32_t dnext = (uint32_t)wave < ns ? cand(desc[wave], (uint32_t)lane) : 0u;
+    uint32_t rnext = (uint32_t)wave < ns ? cand_load(desc[wave], (uint32_t)lane) : 0u;
     for (uint32_t si = (uint32_t)wave; si < ns; si += DM_THREADS / 64) {
       const ScanDesc ds = desc[si];
-      uint32_t d = dnext;
-      if (si + DM_THREADS / 64 < ns) dnext = cand(desc[si + DM_THREADS / 64], (uint32_t)lane);
+      const uint32_t r0 = rnext;
+      if (si + DM_THREADS / 64 < ns) rnext = cand_load(desc[si + DM_THREADS / 64], (uint32_t)lane);
       const uint32_t WI = woff + ds.k, LF = ds.lim_full, LQ = ds.lim_q, TT = (uint32_t)ds.c1 + ds.c2;
       const int LA = ds.la, NICE = nice_cfg < LA ? nice_cfg : LA;
       int bst = ds.best_hq & 0x3FFF;
@@ -1023,17 +1032,17 @@ __global__ void __launch_bounds__(DM_THREADS) k_match_demand(const uint8_t *__re
         if (__any(!inr)) over = true;
       };
       // DM_AHEAD batches are kept on their way from the sorted order (a batch is worked off much faster than it arrives)
-      uint32_t dq[DM_AHEAD];
-      dq[0] = d;
+      uint32_t dq[DM_AHEAD];                                     // what the sorted order holds for the next DM_AHEAD batches
+      dq[0] = r0;
 #pragma unroll
-      for (int u = 1; u < DM_AHEAD; u++) dq[u] = 64u * u < TT ? cand(ds, 64u * u + (uint32_t)lane) : 0u;
+      for (int u = 1; u < DM_AHEAD; u++) dq[u] = 64u * u < TT ? cand_load(ds, 64u * u + (uint32_t)lane) : 0u;
       for (uint32_t c0 = 0; c0 < TT && !over; c0 += 64 * DM_AHEAD) {
 #pragma unroll
         for (int u = 0; u < DM_AHEAD; u++) {
           if (c0 + 64u * u < TT && !over) {
-            const uint32_t dcur = dq[u];
+            const uint32_t dcur = cand_dist(ds, c0 + 64u * u + (uint32_t)lane, dq[u]);
             const uint32_t cn = c0 + 64u * (u + DM_AHEAD);
-            dq[u] = cn < TT ? cand(ds, cn + (uint32_t)lane) : 0u;
+            if (cn < TT) dq[u] = cand_load(ds, cn + (uint32_t)lane);
             batch(dcur);
           }
         }
