@@ -833,7 +833,10 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 #define ZADA_DM_THREADS 512
 #endif
 static_assert(NLEVELS >= 2, "the links of level 0 are dead after k_cross_dist: their array carries the resume points of the guesses");
-constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256, DM_AHEAD = 8;
+#ifndef ZADA_DM_AHEAD
+#define ZADA_DM_AHEAD 2
+#endif
+constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256, DM_AHEAD = ZADA_DM_AHEAD;
 constexpr int DM_WBYTES = HALO + DMB + 272;
 struct ScanDesc {                                  // a position whose candidates have to be scanned (32 bytes, in LDS)
   uint16_t k, la, idx1, c1, idx2, c2, lim_full, lim_q;
