@@ -834,7 +834,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 #endif
 static_assert(NLEVELS >= 2, "the links of level 0 are dead after k_cross_dist: their array carries the resume points of the guesses");
 #ifndef ZADA_DM_AHEAD
-#define ZADA_DM_AHEAD 2
+#define ZADA_DM_AHEAD 1
 #endif
 constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256, DM_AHEAD = ZADA_DM_AHEAD;
 constexpr int DM_WBYTES = HALO + DMB + 272;
@@ -972,16 +972,18 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
     // distance): the loads of several batches are then in flight together instead of each being waited for.  A lane
     // without a candidate reads the segment's first entry, so that there is no branch around the load.
     auto cand_load = [&](const ScanDesc &ds, uint32_t c) -> uint32_t {
-      const uint64_t sb = ((B + ds.k) >> 15) << 15;
+      // (32-bit offsets from the start of the previous segment in the sorted order)
+      const uint16_t *sprev = rp.S + ((((B + ds.k) >> 15) << 15) - 32768);
       const bool in1 = c < ds.c1, in2 = !in1 && c - ds.c1 < ds.c2;
-      const uint64_t a = in1 ? sb + ds.idx1 - 1 - c : (in2 ? sb - 32768 + ds.idx2 - (c - ds.c1) : sb);
-      return rp.S[a];
+      const uint32_t a = in1 ? 32768u + ds.idx1 - 1u - c : (in2 ? (uint32_t)ds.idx2 - (c - ds.c1) : 32768u);
+      return sprev[a];
     };
     auto cand_dist = [&](const ScanDesc &ds, uint32_t c, uint32_t raw) -> uint32_t {
-      const uint64_t P_ = B + ds.k, sb = (P_ >> 15) << 15;
+      const uint64_t P_ = B + ds.k;
+      const uint32_t po = (uint32_t)P_ & 32767u, sg = (uint32_t)(P_ >> 15);    // offset in the segment, segment (uniform)
       const bool in1 = c < ds.c1, in2 = !in1 && c - ds.c1 < ds.c2;
-      const uint64_t q = in1 ? sb + raw : (in2 ? sb - 32768 + raw : 0ull);
-      return q != 0 ? (uint32_t)(P_ - q) : 0u;
+      const bool q0 = raw == 0 && ((in1 && sg == 0) || (in2 && sg == 1));       // the candidate is position 0
+      return q0 ? 0u : (in1 ? po - raw : (in2 ? po + 32768u - raw : 0u));
     };
     uint32_t rnext = (uint32_t)wave < ns ? cand_load(desc[wave], (uint32_t)lane) : 0u;
     for (uint32_t si = (uint32_t)wave; si < ns; si += DM_THREADS / 64) {
