@@ -73,10 +73,18 @@ __global__ void __launch_bounds__(64) k_window_descr(const uint32_t *__restrict_
   const int lane = threadIdx.x;
   for (int i = lane; i < 320; i += 64) hist[i] = (i == 256) ? 1u : 0u;     // empty_lit_len_stat :946
   __syncthreads();
-  for (int64_t a = lo + lane; a <= hi; a += 64) {
-    int ls, ds; atom_symbols(atoms[a], ls, ds);
-    atomicAdd(&hist[ls], 1u);
-    if (ds >= 0) atomicAdd(&hist[288 + ds], 1u);
+  for (int64_t a0 = lo + lane; a0 <= hi; a0 += 64 * 8) {              // eight loads in flight, then their counts
+    uint32_t at[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int64_t a = a0 + 64 * u; at[u] = atoms[a <= hi ? a : hi]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (a0 + 64 * u <= hi) {
+        int ls, ds; atom_symbols(at[u], ls, ds);
+        atomicAdd(&hist[ls], 1u);
+        if (ds >= 0) atomicAdd(&hist[288 + ds], 1u);
+      }
+    }
   }
   __syncthreads();
   if (lane == 0) patch_dist_stats(hist + 288);
@@ -151,10 +159,18 @@ __global__ void __launch_bounds__(256) k_block_analyze(const uint32_t *__restric
   const BlockRange br = blocks[blockIdx.x];
   for (int i = tid; i < 320; i += 256) st1[i] = (i == 256) ? 1u : 0u;
   __syncthreads();
-  for (uint32_t a = tid; a < br.count; a += 256) {
-    int ls, ds; atom_symbols(atoms[br.first + a], ls, ds);
-    atomicAdd(&st1[ls], 1u);
-    if (ds >= 0) atomicAdd(&st1[288 + ds], 1u);
+  for (uint32_t a0 = tid; a0 < br.count; a0 += 256 * 8) {                 // eight loads in flight, then their counts
+    uint32_t at[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const uint32_t a = a0 + 256u * u; at[u] = atoms[br.first + (a < br.count ? a : br.count - 1)]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (a0 + 256u * u < br.count) {
+        int ls, ds; atom_symbols(at[u], ls, ds);
+        atomicAdd(&st1[ls], 1u);
+        if (ds >= 0) atomicAdd(&st1[288 + ds], 1u);
+      }
+    }
   }
   __syncthreads();
   for (int i = tid; i < 320; i += 256) st2[i] = st1[i];
