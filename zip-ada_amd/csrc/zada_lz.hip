@@ -590,6 +590,8 @@ constexpr int MB = 16384;
 constexpr int HALO = 32512;                       // >= MAX_DIST, multiple of 16
 constexpr int WBYTES = HALO + MB + 272;           // 49168
 constexpr int WLINKS = HALO + MB;                 // 48896
+constexpr int MATCH_LDS = WBYTES + WLINKS * 2 + 16 + 16 * 128 * 8;   // window, links, work counter, one queue of start records per wave
+static_assert(MATCH_LDS <= 160 * 1024, "k_match: one workgroup per CU");
 
 // Eight window bytes at any byte offset from three aligned dwords.  (gfx950 also accepts misaligned
 // ds_read addresses, but measured 35 % slower in this kernel than aligned pieces + alignbyte.)
@@ -650,58 +652,104 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   uint32_t lim_cur = 0, lim_full = 0;
   bool have_q = false, exhausted = false;
   int age = 0;                                                     // rounds spent on the current position
+  static_assert(NLEVELS == 2 && MB == 16384 && MAX_DIST < 32768, "packing of the queue entries");
+  constexpr uint32_t QCAP = 128;                                   // entries per wave: fewer than 64 left before a refill of at most 64
+  uint32_t *queue = next_pos + 4 + (threadIdx.x >> 6) * (2 * QCAP);
+  const int lane = threadIdx.x & 63;
+  uint32_t q_head = 0, q_tail = 0;                                 // (uniform over the wave)
+  bool blk_done = false;                                           // the block has no positions left to take
   for (;;) {
     // ---- fetch ----
+    // Positions are taken 64 at a time by the whole wave: every lane works out how one position's search starts
+    // (all lanes busy, instead of the few that happen to be free), the positions without a chain to walk are
+    // finished on the spot, and the others wait, packed in 8 bytes, in a queue of the wave in LDS from which free
+    // lanes pick them up.
     const bool need = (state == 0) && !exhausted;
-    if (__any(need)) {
-      if (need) {
-        const uint32_t k = atomicAdd(&next_pos[0], 1u);             // next position of the block (bounded searches: any order will do)
-#ifdef ZADA_MATCH_STATS
-        if (k >= cnt && t_empty == 0) t_empty = clock64();
-#endif
-        if (k >= cnt) exhausted = true;
+    const unsigned long long need_mk = __ballot(need);
+    if (need_mk) {
+      const uint32_t nneed = (uint32_t)__popcll(need_mk);
+      if (nneed > q_tail - q_head && !blk_done) {                  // (at most one refill per round)
+        uint32_t k0 = 0;
+        if (lane == 0) k0 = atomicAdd(&next_pos[0], 64u);
+        k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
+        if (k0 >= cnt) blk_done = true;
         else {
-          kpos = k; wi = woff + k; age = 0;
-          const uint64_t rem = n - (B + k);
-          la = rem < 258 ? (int)rem : 258;                         // Longest_Match never returns more
-          nice = nice_cfg < la ? nice_cfg : la;                    // lz77.adb:858-860
-          // limits of this position's walk, as distances, and the nearest 3 .. K-1 byte matches (k_prev_links)
-          const uint32_t dlimv = dp.dlim[B + k];
-          const uint32_t df = dlimv & 0xFFFF, dq = dlimv >> 16;
-          uint32_t dl[NLEVELS];
+          const uint32_t k = k0 + (uint32_t)lane;
+          bool ok = false;
+          uint32_t e_lo = 0, e_hi = 0;
+          if (k < cnt) {
+            const uint64_t rem = n - (B + k);
+            const int la_ = rem < 258 ? (int)rem : 258;            // Longest_Match never returns more
+            const int nice_ = nice_cfg < la_ ? nice_cfg : la_;     // lz77.adb:858-860
+            // limits of this position's walk, as distances, and the nearest 3 .. K-1 byte matches (k_prev_links)
+            const uint32_t dlimv = dp.dlim[B + k];
+            const uint32_t df = dlimv & 0xFFFF, dq = dlimv >> 16;
+            uint32_t dl[NLEVELS];
 #pragma unroll
-          for (int l = 0; l < NLEVELS; l++) dl[l] = dp.d[l][B + k];
-          lim_full = dl[0] == (uint32_t)MAX_DIST ? (uint32_t)MAX_DIST : (df < (uint32_t)(MAX_DIST - 1) ? df : (uint32_t)(MAX_DIST - 1));   // :850 / :820-822
-          const uint32_t lim_q = dq < lim_full ? dq : lim_full;                                          // :733-735
-          // best candidate of each length 3 .. K-1 = the nearest position sharing that many bytes; the
-          // levels are nested (a 4-byte match is a 3-byte match), so they are valid in order
-          best = 2; bdist = 0; rq = 0;
-          uint32_t qbest = 0;
-          bool chain_ok = true;
+            for (int l = 0; l < NLEVELS; l++) dl[l] = dp.d[l][B + k];
+            const uint32_t lf = dl[0] == (uint32_t)MAX_DIST ? (uint32_t)MAX_DIST : (df < (uint32_t)(MAX_DIST - 1) ? df : (uint32_t)(MAX_DIST - 1));   // :850 / :820-822
+            const uint32_t lq = dq < lf ? dq : lf;                                                       // :733-735
+            // best candidate of each length 3 .. K-1 = the nearest position sharing that many bytes; the
+            // levels are nested (a 4-byte match is a 3-byte match), so they are valid in order
+            int b_ = 2; uint32_t bd_ = 0, qbest = 0, qlev = 0;
+            bool chain_ok = true;
 #pragma unroll
-          for (int l = 0; l < NLEVELS; l++) {
-            const bool v = chain_ok && la >= 3 + l && dl[l] != 0 && dl[l] <= lim_full;
-            if (v) { best = 3 + l; bdist = dl[l]; if (dl[l] <= lim_q) qbest = ((uint32_t)(3 + l) << 16) | dl[l]; }
-            chain_ok = v;
+            for (int l = 0; l < NLEVELS; l++) {
+              const bool v = chain_ok && la_ >= 3 + l && dl[l] != 0 && dl[l] <= lf;
+              if (v) { b_ = 3 + l; bd_ = dl[l]; if (dl[l] <= lq) { qbest = ((uint32_t)(3 + l) << 16) | dl[l]; qlev = 1u + l; } }
+              chain_ok = v;
+            }
+            // chain_ok: a candidate of length K-1 exists, so longer ones may: walk the level-K chain
+            const bool hq = chain_ok && bd_ > lq;
+            const uint32_t d0 = lnk[woff + k];                       // (0xFFFF = none)
+            ok = chain_ok && b_ < nice_ && d0 <= lf;
+            if (!ok) {
+              const uint32_t packed = b_ >= 3 ? ((uint32_t)b_ << 16) | bd_ : 0u;
+              // quarter-chain result: the best level whose candidate lies within the quarter limit
+              MatchPair r; r.full = packed; r.quarter = (hq || !chain_ok) ? qbest : packed;
+              M[B + k] = r;
+            }
+            e_lo = k | ((uint32_t)(b_ - 2) << 14) | ((uint32_t)hq << 16) | (bd_ << 17);
+            e_hi = lf | (lq << 15) | (qlev << 30);
           }
-          // chain_ok: a candidate of length K-1 exists, so longer ones may: walk the level-K chain
-          have_q = chain_ok && bdist > lim_q; rq = qbest;
-          lim_cur = have_q ? lim_full : lim_q;
-          const uint32_t d0 = lnk[wi];                              // (0xFFFF = none)
-          bool ok = chain_ok && best < nice && d0 <= lim_full;
-          if (ok && !have_q && d0 > lim_q) { have_q = true; rq = ((uint32_t)best << 16) | bdist; lim_cur = lim_full; }
-          cur = ok ? wi - d0 : wi;
-          const uint32_t a = wi + (uint32_t)best;
-          s_end = LDS_U16(win8, a - 1);
-          state = ok ? 1 : 0;
-          if (!ok) {
-            const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
-            // quarter-chain result: the best level whose candidate lies within the quarter limit
-            MatchPair r; r.full = packed; r.quarter = (have_q || !chain_ok) ? qbest : packed;
-            M[B + k] = r;
-          }
+          const unsigned long long okm = __ballot(ok);
+          if (ok) { uint32_t *e = queue + 2 * ((q_tail + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull))) & (QCAP - 1)); e[0] = e_lo; e[1] = e_hi; }
+          q_tail += (uint32_t)__popcll(okm);
         }
       }
+      // free lanes take the queue's entries in lane order
+      const uint32_t avail = q_tail - q_head, rank = (uint32_t)__popcll(need_mk & ((1ull << lane) - 1ull));
+      if (need) {
+        if (rank < avail) {
+          const uint32_t *e = queue + 2 * ((q_head + rank) & (QCAP - 1));
+          const uint32_t e_lo = e[0], e_hi = e[1];
+          kpos = e_lo & 0x3FFFu; wi = woff + kpos; age = 0;
+          const uint64_t rem = n - (B + kpos);
+          la = rem < 258 ? (int)rem : 258;
+          nice = nice_cfg < la ? nice_cfg : la;
+          best = 2 + (int)((e_lo >> 14) & 3u); have_q = (e_lo >> 16) & 1u; bdist = e_lo >> 17;
+          lim_full = e_hi & 0x7FFFu;
+          const uint32_t lim_q = (e_hi >> 15) & 0x7FFFu, qlev = e_hi >> 30;
+          // quarter-chain result so far: the best level whose candidate lies within the quarter limit
+          rq = 0;
+          if (qlev != 0) {
+            const uint32_t qd = (int)qlev + 2 == best ? bdist : (uint32_t)dp.d[0][B + kpos];   // (level 3 within the limit, level 4 not: rare)
+            rq = ((qlev + 2u) << 16) | qd;
+          }
+          lim_cur = have_q ? lim_full : lim_q;
+          const uint32_t d0 = lnk[wi];
+          if (!have_q && d0 > lim_q) { have_q = true; rq = ((uint32_t)best << 16) | bdist; lim_cur = lim_full; }
+          cur = wi - d0;
+          s_end = LDS_U16(win8, wi + (uint32_t)best - 1u);
+          state = 1;
+        } else if (blk_done) {
+#ifdef ZADA_MATCH_STATS
+          if (t_empty == 0) t_empty = clock64();
+#endif
+          exhausted = true;
+        }
+      }
+      q_head += nneed < avail ? nneed : avail;
     }
     if (!__any(state != 0)) { if (__all(exhausted)) break; continue; }
     // ---- fast phase ----
@@ -1342,7 +1390,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   std::call_once(attr_done, [] {
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
     hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, WBYTES + WLINKS * 2 + 16);
+    hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS);
     hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
   });
   LevelPtrs lv;
@@ -1384,7 +1432,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   const uint32_t nbd = (uint32_t)((n + DMB - 1) / DMB);
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
-  hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), WBYTES + WLINKS * 2 + 16, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
+  hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), MATCH_LDS, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
                      budget_env, (unsigned long long *)W.dbg, W.lprev[0]);
   c->tmark("match");
   ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg;
