@@ -645,12 +645,14 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   __syncthreads();
   const uint8_t *win8 = (const uint8_t *)win;
   // Per-lane walker: state 0 = FREE (needs a position), 1 = WALK (fast filter steps), 2 = EVENT
-  // (its current candidate passed the two-byte filter and/or its chain ended / hit a limit).
+  // (its current candidate passed the two-byte filter and/or its chain ended / hit a limit), 3 = EVENT whose
+  // candidate is still being compared.
   // FAST PHASE: ZADA_FAST filter steps with no side paths; SLOW PHASE: everything rare, once per round.
   uint32_t wi = woff, cur = woff, ncur = woff, bdist = 0, rq = 0, kpos = 0, s_end = 0;
   int best = 2, la = 3, nice = 3, state = 0;
   uint32_t lim_cur = 0, lim_full = 0;
   bool have_q = false, exhausted = false;
+  uint32_t cmp_off = 0;                                            // bytes already compared (state 3)
   int age = 0;                                                     // rounds spent on the current position
   static_assert(NLEVELS == 2 && MB == 16384 && MAX_DIST < 32768, "packing of the queue entries");
   constexpr uint32_t QCAP = 128;                                   // entries per wave: fewer than 64 left before a refill of at most 64
@@ -797,18 +799,21 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
       if (state == 1 && !walk) state = 2;
     }
     // ---- slow phase ----
-    if (__any(state == 2)) {
+    if (__any(state >= 2)) {
       // what stopped the walk
       bool ev_pass = false, ev_end = false, ev_lim = false;
-      if (state == 2) {
+      if (state >= 2) {
         ev_pass = LDS_U16(win8, cur + (uint32_t)best - 1u) == s_end;   // bytes best-1, best agree (:754-755)
         ev_end = lnk[cur] == 0xFFFFu;                                   // chain exhausted
         ev_lim = (int)ncur < (int)wi - (int)lim_cur;                    // next candidate beyond the quarter / full limit (:819-822)
       }
-      bool cmpa = (state == 2) && ev_pass;
-      uint32_t off = 0;
+      // The compare takes at most two turns of eight bytes in a round; a longer one goes on in the next rounds (state 3,
+      // `cmp_off` bytes done) instead of keeping the other lanes of the wave waiting.
+      bool cmpa = (state >= 2) && ev_pass;
+      uint32_t off = state == 3 ? cmp_off : 0u;
       int len = 0;
-      while (__any(cmpa)) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
         if (cmpa) {
 #ifdef ZADA_MATCH_STATS
           iters++;
@@ -818,6 +823,8 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           else { off += 8; if ((int)off >= la) { len = la; cmpa = false; } }
         }
       }
+      if (cmpa) { cmp_off = off; state = 3; }
+      else if (state == 3) state = 2;
       if (state == 2) {
         len = len < la ? len : la;
         const bool improved = ev_pass && len > best;               // :812-817
