@@ -585,6 +585,9 @@ __global__ void __launch_bounds__(256) k_bucket_limits(uint64_t n_ins, int kfull
 #ifndef ZADA_FAST
 #define ZADA_FAST 12
 #endif
+#ifndef ZADA_CMP_TURNS
+#define ZADA_CMP_TURNS 2
+#endif
 static_assert(ZADA_FAST % 2 == 0, "the fast phase is unrolled in pairs of steps");
 constexpr int MB = 16384;
 constexpr int HALO = 32512;                       // >= MAX_DIST, multiple of 16
@@ -813,7 +816,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
       uint32_t off = state == 3 ? cmp_off : 0u;
       int len = 0;
 #pragma unroll
-      for (int t = 0; t < 2; t++) {
+      for (int t = 0; t < ZADA_CMP_TURNS; t++) {
         if (cmpa) {
 #ifdef ZADA_MATCH_STATS
           iters++;
