@@ -72,10 +72,16 @@ __device__ __forceinline__ bool sameL(const uint8_t *__restrict__ in, uint64_t p
 // lane handles i = w*2048 + it*64 + lane (it = 0..31).  A lane keeps its 32 (element, key) pairs packed
 // in registers for the whole pass, so the scatter may overwrite the arrays the pass was loaded from.
 // --------------------------------------------------------------------------------------------
-template <int NDIG, int SHIFT, bool LINEAR>
-__device__ __forceinline__ void sort_pass(const uint32_t (&key)[16], const uint32_t (&el)[16], uint16_t *dstE, uint16_t *dstK,
+template <int NDIG, int SHIFT, bool LINEAR, int NPR>
+__device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *dst,
                                           uint32_t *cnt /*[16][NDIG]*/, uint32_t *wsum /*[16]*/, uint32_t i0, int rem) {
-  // i0 = w*2048 + lane: this lane's element `it` is i0 + 64*it, and it exists iff 64*it < rem
+  // This lane's element `it` is i0 + 64*it (i0 = w*2048 + lane) and exists iff 64*it < rem.  Element and key travel as
+  // one 32-bit word, element | key << 16: one LDS write per element and pass, one read in the next.  LINEAR (first
+  // pass): the elements are still in place, pr holds the keys only, two per register; otherwise pr[it] is the word.
+  auto word = [&](int it) -> uint32_t {
+    if (LINEAR) return (i0 + it * 64) | (((pr[it >> 1] >> (16 * (it & 1))) & 0xFFFFu) << 16);
+    return pr[it];
+  };
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   for (int i = tid; i < NDIG * 16; i += 1024) cnt[i] = 0;
   __syncthreads();
@@ -89,7 +95,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&key)[16], const uint3
   for (int k = 0; k < 16; k++) rk[k] = 0;
 #pragma unroll
   for (int it = 0; it < 32; it++) {
-    const uint32_t d = ((key[it >> 1] >> (16 * (it & 1))) >> SHIFT) & (uint32_t)(NDIG - 1);
+    const uint32_t d = (word(it) >> (16 + SHIFT)) & (uint32_t)(NDIG - 1);
     uint32_t r = 0;
     if (it * 64 < rem) r = atomicAdd(&mycnt[d], 1u);
     rk[it >> 1] |= r << (16 * (it & 1));
@@ -114,12 +120,8 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&key)[16], const uint3
 #pragma unroll
   for (int it = 0; it < 32; it++) {
     if (it * 64 < rem) {
-      const uint32_t k16 = (key[it >> 1] >> (16 * (it & 1))) & 0xFFFFu;
-      const uint32_t d = (k16 >> SHIFT) & (uint32_t)(NDIG - 1);
-      const uint32_t e = LINEAR ? i0 + it * 64 : ((el[it >> 1] >> (16 * (it & 1))) & 0xFFFFu);
-      const uint32_t pos = mycnt[d] + ((rk[it >> 1] >> (16 * (it & 1))) & 0xFFFFu);
-      dstE[pos] = (uint16_t)e;
-      dstK[pos] = (uint16_t)k16;
+      const uint32_t wd = word(it), d = (wd >> (16 + SHIFT)) & (uint32_t)(NDIG - 1);
+      dst[mycnt[d] + ((rk[it >> 1] >> (16 * (it & 1))) & 0xFFFFu)] = wd;
     }
   }
   __syncthreads();
@@ -155,6 +157,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *A = (uint16_t *)smem;                 // 64 KiB
   uint16_t *B = A + 32768;                        // 64 KiB
+  uint32_t *AB = (uint32_t *)smem;                // A and B as one array of 32 768 words (the sorts)
   uint32_t *cnt = (uint32_t *)(B + 32768);        // 16 KiB
   uint32_t *wsum = cnt + 4096;                    // 64 B
   const uint64_t seg = blockIdx.x, base = seg * 32768ull;
@@ -189,12 +192,12 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     uint32_t i0 = (uint32_t)w * 2048 + lane;
     asm volatile("" : "+v"(i0));
     const int rem = (int)m - (int)i0;
-    // ---- sort: A := keys, B := positions, both in (key, position) order ----
+    // ---- sort: AB[i] := element | key << 16 in (key, position) order (A and B as one array of 32-bit words) ----
     {
-      uint32_t key[16], el[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) { key[k] = 0; el[k] = 0; }
       {
+        uint32_t key[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) key[k] = 0;
         const uint32_t *wp = (const uint32_t *)(sin + (i0 & ~3u));
         const uint32_t sh = i0 & 3u;
 #pragma unroll
@@ -207,22 +210,16 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           }
           key[it >> 1] |= k << (16 * (it & 1));
         }
+        sort_pass<256, 0, true>(key, AB, cnt, wsum, i0, rem);
       }
-      sort_pass<256, 0, true>(key, el, A, B, cnt, wsum, i0, rem);
-#pragma unroll
-      for (int k = 0; k < 16; k++) { key[k] = 0; el[k] = 0; }
+      uint32_t pr[32];
       {
-        const uint16_t *pa = A + i0, *pb = B + i0;
+        const uint32_t *pp = AB + i0;
 #pragma unroll
-        for (int it = 0; it < 32; it++) {
-          uint32_t k = 0, e = 0;
-          if (it * 64 < rem) { e = pa[it * 64]; k = pb[it * 64]; }
-          key[it >> 1] |= k << (16 * (it & 1));
-          el[it >> 1] |= e << (16 * (it & 1));
-        }
+        for (int it = 0; it < 32; it++) pr[it] = (it * 64 < rem) ? pp[it * 64] : 0u;
       }
-      if (lvl == 0) sort_pass<128, 8, false>(key, el, B, A, cnt, wsum, i0, rem);
-      else sort_pass<256, 8, false>(key, el, B, A, cnt, wsum, i0, rem);
+      if (lvl == 0) sort_pass<128, 8, false>(pr, AB, cnt, wsum, i0, rem);
+      else sort_pass<256, 8, false>(pr, AB, cnt, wsum, i0, rem);
     }
     PL_STAMP();
     // ---- links: element | last-of-bucket << 15 | distance to the bucket's previous element << 16, in registers ----
@@ -230,18 +227,20 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     const bool want_runs = lvl == 0 || lvl == NLEVELS;   // bucket boundaries of the sorted order are needed
     uint32_t ed[32];
     {
-      const uint16_t *pa = A + i0, *pb = B + i0;
+      const uint32_t *pp = AB + i0;
       uint32_t *pf = F + (i0 >> 5);
 #pragma unroll
       for (int it = 0; it < 32; it++) {
         uint32_t x = 0;
         bool first = false;
         if (it * 64 < rem) {
-          const uint32_t e = pb[it * 64], k = pa[it * 64];
-          first = (i0 + it * 64 == 0) || (pa[it * 64 - 1] != k);
-          const bool last = (it * 64 + 1 == rem) || (pa[it * 64 + 1] != k);
+          const uint32_t p0 = pp[it * 64], e = p0 & 0xFFFFu, k = p0 >> 16;
+          uint32_t pm = 0;
+          first = i0 + it * 64 == 0;
+          if (!first) { pm = pp[it * 64 - 1]; first = (pm >> 16) != k; }
+          const bool last = (it * 64 + 1 == rem) || ((pp[it * 64 + 1] >> 16) != k);
           uint32_t d = 0;
-          if (!first) { const uint32_t e0 = pb[it * 64 - 1]; if ((base + e0) != 0) d = e - e0; }     // NIL = position 0, lz77.adb:467
+          if (!first) { const uint32_t e0 = pm & 0xFFFFu; if ((base + e0) != 0) d = e - e0; }     // NIL = position 0, lz77.adb:467
           x = e | ((uint32_t)last << 15) | (d << 16);
           if (lvl > 0 && last) tail[k] = (uint16_t)e;
         }
@@ -277,7 +276,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 #pragma unroll
         for (int it = 0; it < 32; it++) {
           const uint32_t i = i0 + it * 64;
-          if ((ed[it] >> 15) & 1u) { const uint32_t bs = bucket_start(i); bsc[A[i]] = bs | ((i - bs + 1) << 16); }
+          if ((ed[it] >> 15) & 1u) { const uint32_t bs = bucket_start(i); bsc[AB[i] >> 16] = bs | ((i - bs + 1) << 16); }
         }
       } else {
         // last level: the bucket of a position is a contiguous run of the sorted order, which the demand pass
