@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       } else {
         // last level: the bucket of a position is a contiguous run of the sorted order, which the demand pass
         // of the match kernel scans instead of chasing links.  Written out: the sorted order S, and per
-        // position its index in S and the number of bucket members before it (planes, staged in A / B).
+        // position its index in S and the number of bucket members before it (planes, staged as one word per position in AB).
         __syncthreads();                             // keys (A) and sorted positions (B) are dead from here
         uint16_t *sK = rp.S + seg * 32768ull;
 #pragma unroll
@@ -289,14 +289,17 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           if (it * 64 < rem) {
             const uint32_t i = i0 + it * 64, e = ed[it] & 0x7FFFu;
             sK[i] = (uint16_t)e;
-            A[e] = (uint16_t)i;
-            B[e] = (uint16_t)(i - bucket_start(i));
+            AB[e] = i | ((i - bucket_start(i)) << 16);       // (one scatter for both planes)
           }
         }
         __syncthreads();
         for (uint32_t i = tid; i < (m + 7) / 8; i += 1024) {
-          ((uint4 *)(rp.idx + base))[i] = ((const uint4 *)A)[i];
-          ((uint4 *)(rp.cnt + base))[i] = ((const uint4 *)B)[i];
+          const uint4 p = ((const uint4 *)AB)[2 * i], q = ((const uint4 *)AB)[2 * i + 1];
+          uint4 lo, hi;
+          lo.x = (p.x & 0xFFFFu) | (p.y << 16); lo.y = (p.z & 0xFFFFu) | (p.w << 16); lo.z = (q.x & 0xFFFFu) | (q.y << 16); lo.w = (q.z & 0xFFFFu) | (q.w << 16);
+          hi.x = (p.x >> 16) | (p.y & 0xFFFF0000u); hi.y = (p.z >> 16) | (p.w & 0xFFFF0000u); hi.z = (q.x >> 16) | (q.y & 0xFFFF0000u); hi.w = (q.z >> 16) | (q.w & 0xFFFF0000u);
+          ((uint4 *)(rp.idx + base))[i] = lo;
+          ((uint4 *)(rp.cnt + base))[i] = hi;
         }
       }
     }
