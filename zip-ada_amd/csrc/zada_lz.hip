@@ -178,11 +178,13 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint16_t *LW = (uint16_t *)(cnt + 1040);         // per word: last non-empty word at or before it
   const uint8_t *sb = (const uint8_t *)A;          // the segment's bytes (after the keys in A are dead)
   uint16_t *P = B;                                 // position-indexed links (after the sorted positions in B are dead)
-  auto lb8 = [&](uint32_t e) -> uint64_t {         // eight bytes of the segment at e, from LDS
+  auto lb8 = [&](uint32_t e) -> uint64_t {         // the bytes of the segment at e, from LDS: at least five are valid
+    // (two aligned words hold bytes e .. e+4 whatever the alignment; the levels compare 3 .. 5 bytes)
     const uint32_t *wp = (const uint32_t *)(sb + (e & ~3u));
-    const uint32_t a = wp[0], b = wp[1], c = wp[2], s = e & 3u;
-    return (uint64_t)__builtin_amdgcn_alignbyte(b, a, s) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, s) << 32);
+    const uint32_t a = wp[0], b = wp[1], s = e & 3u;
+    return (uint64_t)__builtin_amdgcn_alignbyte(b, a, s) | ((uint64_t)(b >> (8u * s)) << 32);
   };
+  static_assert(3 + NLEVELS <= 5 + 1, "lb8 yields five valid bytes");
 #pragma unroll 1
   for (int lvl = 0; lvl <= NLEVELS; lvl++) {
     const int L = 3 + lvl;
