@@ -368,23 +368,30 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         if (pend && idx < QCAP) { dstq[idx] = entry; return true; }
         return !pend;
       };
-      for (uint32_t e0 = 0; e0 < m; e0 += 1024) {                   // first candidate of every position
-        const uint32_t e = e0 + tid;
-        uint32_t dl = dflt, q = e;
-        bool pend = false;
-        uint64_t mine = 0;
-        if (e < m) {
-          mine = lb8(e) & lmask;
-          const uint32_t step = P[e];
-          if (step != 0) {
+      for (uint32_t e0 = 0; e0 < m; e0 += 4096) {                   // first candidate of every position, four positions per lane at a time
+        uint32_t ee[4], st[4];
+        uint64_t mn[4], th[4];
+        bool ex[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t e = e0 + 1024u * j + tid; ex[j] = e < m; ee[j] = ex[j] ? e : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { mn[j] = lb8(ee[j]) & lmask; st[j] = P[ee[j]]; }          // (no conditions: the LDS reads overlap)
+#pragma unroll
+        for (int j = 0; j < 4; j++) th[j] = lb8(ee[j] - st[j]) & lmask;                        // (no link: its own bytes)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t e = ee[j], step = st[j];
+          uint32_t dl = dflt, q = e;
+          bool pend = false;
+          if (ex[j] && step != 0) {
             q = e - step;
             if (step > (uint32_t)MAX_DIST) dl = 0;
-            else if ((lb8(q) & lmask) == mine) dl = step;
+            else if (th[j] == mn[j]) dl = step;
             else pend = true;
           }
+          if (!push(pend, e | (q << 16), Qa, &qn[0])) { walk(e, q, mn[j], 1u << 30, dl); pend = false; }
+          if (ex[j] && !pend) plane[e] = (uint16_t)dl;
         }
-        if (!push(pend, e | (q << 16), Qa, &qn[0])) { walk(e, q, mine, 1u << 30, dl); pend = false; }
-        if (e < m && !pend) plane[e] = (uint16_t)dl;
       }
       __syncthreads();
       PL_STAMP();
