@@ -401,7 +401,51 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         __syncthreads();
         if (tid == 0) qn[cur ^ 1] = 0;
         __syncthreads();
-        const uint32_t maxs = nq <= 1024 ? (1u << 30) : 8u;
+        if (nq > 1024) {
+          // Up to four entries per lane, eight candidates each, in step with each other: the LDS reads of the four walks
+          // overlap (a walk is one dependent LDS round trip per candidate).
+          static_assert(QCAP <= 4096, "four entries per lane cover the queue");
+          const uint32_t *Qs = cur ? Qb : Qa;
+          uint32_t e4[4], q4[4], st4[4], dl4[4];
+          uint64_t mn4[4];
+          bool val[4], act[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t idx = 1024u * j + tid;
+            val[j] = idx < nq;
+            const uint32_t ent = Qs[val[j] ? idx : 0u];
+            e4[j] = ent & 0x7FFFu; q4[j] = ent >> 16; act[j] = val[j]; dl4[j] = 0;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) { mn4[j] = lb8(e4[j]) & lmask; st4[j] = P[q4[j]]; }
+          for (int sidx = 0; sidx < 8; sidx++) {
+            uint32_t qx[4], ns[4];
+            uint64_t th[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (act[j] && st4[j] == 0) { dl4[j] = dflt; act[j] = false; }                     // the chain ends inside the segment
+              qx[j] = act[j] ? q4[j] - st4[j] : q4[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ns[j] = P[qx[j]]; th[j] = lb8(qx[j]) & lmask; }      // next link and this candidate's bytes
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (act[j]) {
+                q4[j] = qx[j]; st4[j] = ns[j];
+                const uint32_t dist = e4[j] - q4[j];
+                // beyond MAX_DIST nothing qualifies; the 15-bit chain accepts exactly MAX_DIST only at its head (:850 vs :820)
+                if (dist > (uint32_t)MAX_DIST || (lvl == 0 && dist == (uint32_t)MAX_DIST)) { dl4[j] = 0; act[j] = false; }
+                else if (th[j] == mn4[j]) { dl4[j] = dist; act[j] = false; }
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (val[j] && !act[j]) plane[e4[j]] = (uint16_t)dl4[j];
+            push(val[j] && act[j], e4[j] | (q4[j] << 16), cur ? Qa : Qb, &qn[cur ^ 1]);
+          }
+        } else {
+        const uint32_t maxs = 1u << 30;
         for (uint32_t i0q = 0; i0q < nq; i0q += 1024) {
           const uint32_t idx = i0q + tid;
           bool pend = false;
@@ -413,6 +457,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
             if (!pend) plane[e] = (uint16_t)dl;
           }
           push(pend, e | (q << 16), cur ? Qa : Qb, &qn[cur ^ 1]);
+        }
         }
         __syncthreads();
       }
