@@ -121,12 +121,15 @@ struct Workspace {
 constexpr uint32_t CRC_HOST_TOP = 4096;           // top-level CRC values per call (one per MiB of input)
 struct CrcPending { uint32_t nsub = 0, nfull0 = 0, cnt[4] = {0, 0, 0, 0}, nrest[4] = {0, 0, 0, 0}; };
 
+constexpr uint64_t STAGE_BYTES = 8ull << 20;
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: CRC-32, next to the LZ stage
   hipEvent_t ev_input = nullptr, ev_out = nullptr;
   CrcPending crc;
   uint32_t *crc_host = nullptr;                     // pinned: [CRC_HOST_TOP] top-level values, then 4 x 16 leftovers
+  uint8_t *stage[2] = {nullptr, nullptr};            // pinned staging buffers of the host-buffer entry points (copy_in / copy_out)
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
   Workspace ws;
   std::string err;
   int parse_rounds = 0, demand_rounds = 0;
