@@ -87,7 +87,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(spec_exits, nch); A(true_exits, nch);
   A(dirty[0], nch + 64); A(dirty[1], nch + 64);
   A(n_changed, 16);
-  A(blk_demand, cap / 4096 + 64); A(n_demand, 16); A(chg, nch + 64);
+  A(blk_demand, cap / 4096 + 64); A(dbits, cap / 32 + 4096); A(n_demand, 16); A(chg, nch + 64);
   A(descr, nflush * SLOTS * 320);
   A(seg_nblk, nflush); A(seg_cut, nflush * MAXBLK_PER_SEG); A(seg_blk_off, nflush);
   W.cap_blocks = nflush * MAXBLK_PER_SEG;

@@ -94,6 +94,7 @@ struct Workspace {
   uint8_t *dirty[2] = {nullptr, nullptr};
   uint32_t *n_changed = nullptr;
   uint32_t *blk_demand = nullptr, *n_demand = nullptr;   // demanded match records per k_match block / in total
+  uint32_t *dbits = nullptr;                             // one bit per position: marked for the next demand pass
   uint8_t *chg = nullptr;                                // per parse chunk: a guess it used turned out different
   // entropy stage
   uint8_t *descr = nullptr;                  // [nseg][SLOTS][320]

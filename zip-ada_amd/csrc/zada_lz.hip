@@ -962,7 +962,7 @@ static_assert(MB % DMB == 0 && DM_WBYTES % 16 == 0 && sizeof(ScanDesc) == 32, "d
 // (six waves per SIMD, i.e. three workgroups per CU: without the bound the compiler takes 85 registers and only two fit)
 __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *__restrict__ in, uint64_t n, DistPlanes dp, RunPtrs rp,
                                                              const uint16_t *__restrict__ tailsK, MatchPair *__restrict__ M, int nice_cfg,
-                                                             const uint32_t *__restrict__ blk_demand, uint8_t *__restrict__ chg,
+                                                             const uint32_t *__restrict__ blk_demand, uint32_t *__restrict__ dbits, uint8_t *__restrict__ chg,
                                                              const ExitState *__restrict__ spec_exits, const uint16_t *__restrict__ resume) {
   if (blk_demand[blockIdx.x] == 0) return;
   const uint64_t B = (uint64_t)blockIdx.x * DMB;
@@ -998,15 +998,15 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
   };
   if (tid == 0) ctr[0] = 0;
   __syncthreads();
-  for (uint32_t k = tid; k < DMB; k += DM_THREADS) {               // the marked positions of the block
-    const bool todo = k < cnt && (M[B + k].full & (M_GUESS | M_DEMAND)) == (M_GUESS | M_DEMAND);
-    const unsigned long long mk = __ballot(todo);
-    if (mk) {
-      uint32_t b0 = 0;
-      const int leader = __ffsll((long long)mk) - 1;
-      if (lane == leader) b0 = atomicAdd(&ctr[0], (uint32_t)__popcll(mk));
-      b0 = __shfl(b0, leader);
-      if (todo) list[b0 + __popcll(mk & ltm)] = (uint16_t)k;
+  // the marked positions of the block, from the bit map the parsers keep (one bit per position: 512 bytes instead of the
+  // block's 32 KB of match records); the block's bits are cleared for the next round
+  if (tid < DMB / 32) {
+    uint32_t *wp = dbits + (B >> 5) + tid;
+    uint32_t bits = *wp;
+    if (bits) {
+      *wp = 0;
+      uint32_t o = atomicAdd(&ctr[0], (uint32_t)__popc(bits));
+      while (bits) { const int j = __ffs((int)bits) - 1; bits &= bits - 1; list[o++] = (uint16_t)(tid * 32 + j); }
     }
   }
   __syncthreads();
@@ -1177,11 +1177,15 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
 
 // Safety valve of the demand loop: every remaining guess becomes demanded (lz_stage uses it when the parse keeps
 // landing on new guesses round after round, which no ordinary input does).
-__global__ void k_demand_all(uint64_t n, MatchPair *__restrict__ M, uint32_t *__restrict__ blk_demand) {
+__global__ void k_demand_all(uint64_t n, MatchPair *__restrict__ M, uint32_t *__restrict__ blk_demand, uint32_t *__restrict__ dbits) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const uint32_t f = M[p].full;
-  if ((f & M_GUESS) && !(f & M_DEMAND)) { M[p].full = f | M_DEMAND | M_BYSPEC; blk_demand[p / DMB] = 1; }
+  if (f & M_GUESS) {                               // (a guess already marked has its bit set, or is set again: harmless)
+    if (!(f & M_DEMAND)) M[p].full = f | M_DEMAND | M_BYSPEC;
+    atomicOr(&dbits[p >> 5], 1u << (p & 31));
+    blk_demand[p / DMB] = 1;
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1192,11 +1196,13 @@ __global__ void k_demand_all(uint64_t n, MatchPair *__restrict__ M, uint32_t *__
 // flag per k_match_demand block (so that the demand pass skips blocks without work) and a grand total for the host.
 struct DemandMarker {
   MatchPair *M; uint32_t *blk_demand; uint32_t *n_demand; uint32_t by;   // by = M_BYSPEC for the speculative parse, 0 for the splice
+  uint32_t *dbits;                                                       // one bit per position: to be searched in the next demand pass
   __device__ void operator()(uint32_t p, uint32_t full) const {
     const uint32_t want = M_DEMAND | by;
     if ((full & want) == want) return;
     // plain stores: every concurrent writer of these words writes a value that only adds flags
     M[p].full = full | want;
+    atomicOr(&dbits[p >> 5], 1u << (p & 31));
     blk_demand[p / DMB] = 1;
     *n_demand = 1;
   }
@@ -1497,12 +1503,13 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : (n < (2u << 20) ? 0 : 8); if (budget_env < 1) budget_env = 1 << 20; }
   const uint32_t nbd = (uint32_t)((n + DMB - 1) / DMB);
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
+  hipMemsetAsync(W.dbits, 0, (size_t)nbd * (DMB / 8), st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
   hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), MATCH_LDS, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
                      budget_env, (unsigned long long *)W.dbg, W.lprev[0]);
   c->tmark("match");
   ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg;
-  DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand; dm.by = M_BYSPEC;
+  DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand; dm.by = M_BYSPEC; dm.dbits = W.dbits;
   DemandMarker dmf = dm; dmf.by = 0;
   int rounds = 0, demand_rounds = 0;
   bool valve_used = false;
@@ -1542,10 +1549,10 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
     hipMemsetAsync(W.chg, 0, nch, st);
     if ((demand_rounds == max_rounds || slow) && !valve_used) {    // enough: search everything that is still a guess
       valve_used = true;
-      hipLaunchKernelGGL(k_demand_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, W.M, W.blk_demand);
+      hipLaunchKernelGGL(k_demand_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, W.M, W.blk_demand, W.dbits);
     }
     hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, n, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
-                       W.blk_demand, W.chg, W.spec_exits, W.lprev[0]);
+                       W.blk_demand, W.dbits, W.chg, W.spec_exits, W.lprev[0]);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   }
   c->demand_rounds = demand_rounds;
