@@ -575,11 +575,14 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
         uint64_t q = p;
         const uint64_t mask = (1ull << (8 * (4 + l))) - 1ull;
         uint32_t d = link_first[l];
-        for (;; d = lv.prev[l][q]) {
+        for (;;) {
           if (d == 0) break;
           q -= d;
           if (p - q > (uint64_t)MAX_DIST) break;
-          if (p - q >= (uint64_t)dprev && ((*(const u64u *)(in + q) ^ mine) & mask) == 0) { dl = (uint32_t)(p - q); break; }
+          const uint32_t dn = lv.prev[l][q];                            // the next link and this candidate's bytes in one round trip
+          const uint64_t theirs = *(const u64u *)(in + q);
+          if (p - q >= (uint64_t)dprev && ((theirs ^ mine) & mask) == 0) { dl = (uint32_t)(p - q); break; }
+          d = dn;
         }
       }
       dp.d[1 + l][p] = (uint16_t)dl;
