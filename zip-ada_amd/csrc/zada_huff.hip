@@ -542,8 +542,17 @@ __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRe
   const int lane = threadIdx.x;
   ChooseState S; S.last_type = BT_RESERVED; S.block_to_finish = 0; S.last_marked = 0; S.code_block = -1; S.code_variant = 0; S.pos = 0; S.cur_eob = 7u << 16;
   uint32_t ntiles = 0, npieces = 0, overflow = 0;
-  for (uint32_t i = 0; i < nblocks; i++) {
-    const ChRec cr = chrec[i];                                     // uniform address: scalar loads
+  // The records are fetched four blocks ahead, one dword per lane with a vector load (these complete in order, so waiting
+  // for the oldest leaves the newer ones in flight; scalar loads would all be waited for together), and spread into
+  // scalar registers when their block's turn comes: the chain from block to block no longer contains a memory latency.
+  static_assert(sizeof(ChRec) == 128, "one dword per lane (32 lanes)");
+  auto load_rec = [&](uint32_t k) -> uint32_t { const uint32_t kk = k < nblocks ? k : nblocks - 1; return ((const uint32_t *)(chrec + kk))[lane & 31]; };
+  auto body = [&](const uint32_t i, const uint32_t rv) -> bool {         // false: stop (overflow)
+    uint32_t w[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) w[k] = (uint32_t)__builtin_amdgcn_readlane((int)rv, k);
+    ChRec cr;
+    memcpy(&cr, w, sizeof cr);
     const BlockRange br = cr.br;
     // recycling (:1223-1226, Recyclable :495-508) and its cost (:1158, 1180, 1189)
     bool recycling_possible = false; uint64_t recycled_data = 0;
@@ -651,10 +660,24 @@ __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRe
       e.code_block = S.code_block; e.code_variant = (uint32_t)S.code_variant;
       S.pos += data_bits;
       const uint32_t nt = (br.count + TILE - 1) / TILE;
-      if (ntiles + nt > cap_tiles) { overflow = 1; break; }
+      if (ntiles + nt > cap_tiles) { overflow = 1; return false; }
       ntiles += nt;
     }
     if (lane == 0) emit[i] = e;
+      return true;
+  };
+  if (nblocks > 0) {
+    uint32_t r0 = load_rec(0), r1 = load_rec(1), r2 = load_rec(2), r3 = load_rec(3);
+    bool go = true;
+    for (uint32_t i = 0; go && i < nblocks; i += 4) {
+      go = body(i, r0); r0 = load_rec(i + 4);
+      if (go && i + 1 < nblocks) go = body(i + 1, r1);
+      r1 = load_rec(i + 5);
+      if (go && i + 2 < nblocks) go = body(i + 2, r2);
+      r2 = load_rec(i + 6);
+      if (go && i + 3 < nblocks) go = body(i + 3, r3);
+      r3 = load_rec(i + 7);
+    }
   }
   // stream epilogue, Encode :1613-1635
   if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
