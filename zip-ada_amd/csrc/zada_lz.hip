@@ -953,7 +953,10 @@ static_assert(NLEVELS >= 2, "the links of level 0 are dead after k_cross_dist: t
 #ifndef ZADA_DM_AHEAD
 #define ZADA_DM_AHEAD 1
 #endif
-constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = 4096, DM_SLICE = 256, DM_AHEAD = ZADA_DM_AHEAD;
+#ifndef ZADA_DMB
+#define ZADA_DMB 4096
+#endif
+constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = ZADA_DMB, DM_SLICE = 256, DM_AHEAD = ZADA_DM_AHEAD;
 constexpr int DM_WBYTES = HALO + DMB + 272;
 struct ScanDesc {                                  // a position whose candidates have to be scanned (32 bytes, in LDS)
   uint16_t k, la, idx1, c1, idx2, c2, lim_full, lim_q;
