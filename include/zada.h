@@ -62,6 +62,10 @@ zada_ctx *zada_create(int device);
 void zada_destroy(zada_ctx *ctx);
 const char *zada_last_error(const zada_ctx *ctx);
 const char *zada_version(void);
+/* Tuning / test knobs of a context (also read from the environment when the context is created):
+ * "budget" (ZADA_BUDGET: rounds of chain steps per position in the first match pass; 0 = unbounded, -1 = default),
+ * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "batch_streams" (ZADA_BATCH_STREAMS).  None of them changes a byte. */
+int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 
 /* Zip.Compress.Deflate on host buffers (the Ada shim drains `input` with Zip.Block_Read into
  * `in`, and passes `out` through CRC_Crypto.Encode + Zip.Block_Write afterwards).

@@ -71,7 +71,8 @@ def hostcheck():
         p = os.path.join(d, "libzada_hostcheck.so")
         src = os.path.join(d, "hostcheck.cpp")
         hdr = os.path.join(ROOT, "zip-ada_amd", "csrc", "zada_logic.h")
-        if not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        hdr2 = os.path.join(d, "hostcheck_logic.h")
+        if not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", p, src], check=True)
         H = ctypes.CDLL(p)
         H.hc_chunked_tokens.restype = ctypes.c_uint64
@@ -114,17 +115,23 @@ def oracle_tokens(data, method):
     return t[:k]
 
 
-def oracle_deflate(data, method, blocks=None):
-    """Returns (rc, stream bytes, running crc).  rc 1 = Compression_inefficient."""
+def oracle_deflate(data, method, blocks=None, cuts=None, similar=None):
+    """Returns (rc, stream bytes, running crc).  rc 1 = Compression_inefficient.
+    blocks / cuts / similar collect the oracle's trace events (the reference's compile-time trace,
+    zip-compress-deflate.adb:83-90): (first atom, atoms, format, bits) / (atom, level) / (atom, distance, threshold, similar)."""
     n = len(data)
     out = ctypes.create_string_buffer(n + 64)
     ol = ctypes.c_uint64(0)
     crc = ctypes.c_uint32(0xFFFFFFFF)
     cb = None
-    if blocks is not None:
+    if blocks is not None or cuts is not None or similar is not None:
         def tr(_u, kind, a, b, c, d):
-            if kind == 2:
+            if kind == 2 and blocks is not None:
                 blocks.append((a, b, c, d))
+            elif kind == 1 and cuts is not None:
+                cuts.append((a, b))
+            elif kind == 3 and similar is not None:
+                similar.append((a, b, c, d))
         cb = TRACE(tr)
     rc = oracle().zo_deflate(data, n, method, out, n + 64, ctypes.byref(ol), ctypes.byref(crc), None, None,
                              ctypes.cast(cb, ctypes.c_void_p) if cb else None, None)
@@ -174,4 +181,95 @@ def edge_inputs():
     cases["abc_x"] = b"abc" * 30000 + b"x" + b"abc" * 100
     cases["mix_300000"] = silesia_mix(300000)
     cases["mix_1m_off"] = silesia_mix((1 << 20) + 1, offset=3 * 65536)
+    cases.update(format_inputs())
     return cases
+
+
+_LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+_LEN_EXTRA = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
+
+
+def _fixed_like(natoms, seed, pm=0.22):
+    """LZ atoms drawn i.i.d. from the distribution the FIXED Huffman code is optimal for (literals 0..143 at 2^-8,
+    144..255 at 2^-9, length codes at 2^-7 / 2^-8, distance codes uniform), realised as bytes: copies from a
+    random history.  Returns (bytes, history)."""
+    r = np.random.RandomState(seed)
+    out = bytearray(r.randint(0, 256, 40000).astype(np.uint8).tobytes())
+    start = len(out)
+    pl = np.array([2.0 ** -8] * 144 + [2.0 ** -9] * 112); pl /= pl.sum()
+    plen = np.array([2.0 ** -7] * 23 + [2.0 ** -8] * 6); plen /= plen.sum()
+    for _ in range(natoms):
+        if r.rand() < pm:
+            c = r.choice(29, p=plen)
+            L = min(_LEN_BASE[c] + (r.randint(0, 1 << _LEN_EXTRA[c]) if _LEN_EXTRA[c] else 0), 258)
+            dc = r.randint(0, 30)
+            if dc < 4:
+                d = dc + 1
+            else:
+                e = (dc >> 1) - 1
+                d = ((2 + (dc & 1)) << e) + 1 + r.randint(0, 1 << e)
+            d = min(max(d, L + 1) if d < L else d, len(out), 32000)
+            s = len(out) - d
+            for i in range(L):
+                out.append(out[s + i])
+        else:
+            out.append(int(r.choice(256, p=pl)))
+    return bytes(out[start:]), bytes(out[:start])
+
+
+def _copies(n, seed):
+    """Random bytes with a 4..12-byte copy every ~20 bytes at a log-uniform distance 4..32000: ~230 distinct
+    literals per window, so that the empty-statistics descriptor of the null-slice quirk
+    (zip-compress-deflate.adb:1372) is NOT similar to the data and Deflate_3 cuts at atom 750 of
+    every even flush."""
+    r = np.random.RandomState(seed)
+    out = bytearray(r.randint(0, 256, 64).astype(np.uint8).tobytes())
+    while len(out) < n:
+        out += r.randint(0, 256, int(r.randint(8, 32))).astype(np.uint8).tobytes()
+        L = int(r.randint(4, 13))
+        d = min(int(np.exp(r.uniform(np.log(4), np.log(32000)))), len(out))
+        s = len(out) - d
+        for i in range(L):
+            out.append(out[s + i])
+    return bytes(out[:n])
+
+
+def format_inputs():
+    """Inputs that make the chooser of Send_as_block (zip-compress-deflate.adb:1222-1268) take every one of its five
+    ways in streams with rc = 0 (tests/test_oracle.py::test_every_block_format_is_byte_compared asserts it):
+    fixed wins (tiny repetitive inputs; a tiny last flush of unseen symbols after a dynamic block; a fixed block
+    in mid stream followed by recycled ones), stored blocks inside a stream incl. two of 65 536 atoms (the halving
+    of :1024-1038), the null-slice cut (:1372), an atom count that is an exact multiple of 65 536 (:1617-1621)."""
+    rs = np.random.RandomState(7)
+    cases = {}
+    cases["abc_40"] = b"abc" * 40
+    cases["a_40"] = b"a" * 40
+    cases["abcdefghij_12"] = b"abcdefghij" * 12
+    text = silesia_mix(1 << 20, class_mask=1)
+    cases["text_rand_text"] = text[:300000] + bytes(rs.randint(0, 256, 200000).astype(np.uint8)) + silesia_mix(300000, class_mask=1, offset=1 << 20)
+    cases["copies_1500k"] = _copies(1500000, 3)
+    blob = bytearray()
+    toff = 0
+    for k in range(8):
+        a, h = _fixed_like(6000, k)
+        if k == 0:
+            blob += h
+        blob += a
+        blob += text[toff:toff + 24000]
+        toff += 24000
+    cases["fixedlike_mix"] = bytes(blob)
+    tail = bytes([1, 2, 3, 4, 5, 6, 7])                       # symbols the text never uses: not recyclable
+    cases["flush_tail_m7"] = text[:65536] + tail              # Deflate_0: 65 536 atoms, then a flush of 7
+    cases["flush_tail_m8"] = text[:364356] + tail             # Deflate_1: the same (atom counts found with the oracle)
+    cases["flush_tail_m9"] = text[:372589] + tail             # Deflate_2 and Deflate_3
+    cases["flush_exact_m9"] = text[:372589]                   # exactly 65 536 atoms: no last flush, fake final fixed block
+    return cases
+
+
+def few_symbol_inputs():
+    """2-, 4- and 16-symbol uniform random data: every position has thousands of candidates
+    (lz77.adb:715-825 at chain 4096) -- the demand path of the match finder at its worst."""
+    rs = np.random.RandomState(5)
+    return {"sym2_4m": bytes((rs.randint(0, 2, 4 << 20) + 65).astype(np.uint8)),
+            "sym4_4m": bytes((rs.randint(0, 4, 4 << 20) + 65).astype(np.uint8)),
+            "sym16_6m": bytes((rs.randint(0, 16, 6 << 20) + 65).astype(np.uint8))}

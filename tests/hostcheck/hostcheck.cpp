@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <vector>
-#include "../../zip-ada_amd/csrc/zada_logic.h"
+#include "hostcheck_logic.h"
 using namespace zada;
 
 extern "C" {

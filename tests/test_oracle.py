@@ -185,3 +185,42 @@ def test_zip_archive_is_readable_by_zipfile_and_has_reference_constants():
         assert i.create_version == 23 and i.extract_version == 10                        # zip-create.adb:126, 131
         assert i.flag_bits == 0x0800                                                     # UTF-8 names (tools/zipada.adb:131)
     assert z[10:14] == (16789 * 65536).to_bytes(4, "little")                             # zip_streams.ads:223 default time
+
+
+# ---------------------------------------------------------------- the parity matrix reaches every decision
+def test_every_block_format_is_byte_compared():
+    """The GPU parity tests compare bytes only when rc = 0.  This keeps the matrix honest: over edge_inputs() x the
+    Taillaule methods the ORACLE takes each of the five ways of Send_as_block (zip-compress-deflate.adb:1243-1268)
+    in a stream with rc = 0, and the byte-changing quirks fire: a fixed block in mid stream followed by a
+    recycled one (:1223-1226), a fixed block opened after a dynamic one (:1108-1121), stored blocks inside a
+    stream and two of 65 536 atoms (the halving of :1024-1038), the null-slice cut at atom 750 of even
+    flushes for Deflate_3 but not Deflate_2 (:1372), an atom count that is an exact multiple of
+    65 536 (:1617-1621, fake final fixed block)."""
+    seen = {}
+    per_case = {}
+    for name, d in edge_inputs().items():
+        for m in (7, 8, 9, 10):
+            ob, cuts = [], []
+            rc, z, _ = oracle_deflate(d, m, ob, cuts)
+            if rc != 0:
+                continue
+            per_case[(name, m)] = (ob, cuts, z)
+            for b in ob:
+                seen.setdefault(b[2], (name, m))
+    assert sorted(seen) == [0, 1, 2, 3, 4], seen
+    ob, cuts, z = per_case[("fixedlike_mix", 10)]
+    seq = [b[2] for b in ob]
+    assert any(a == 1 and b == 4 for a, b in zip(seq, seq[1:])), seq            # recycle after fixed, in mid stream
+    for key in (("flush_tail_m7", 7), ("flush_tail_m8", 8), ("flush_tail_m9", 9), ("flush_tail_m9", 10)):
+        ob = per_case[key][0]
+        assert [(b[0], b[1], b[2]) for b in ob[-2:]] == [(0, 65536, 2), (65536, 7, 1)], (key, ob[-2:])
+    for m in (9, 10):
+        ob, _, z = per_case[("flush_exact_m9", m)]
+        assert sum(b[1] for b in ob) == 65536 and z[-2:] != b"" and (z[-1] or z[-2])   # ends with the fake fixed block
+    for m in (7, 8, 9, 10):
+        ob = per_case[("text_rand_text", m)][0]
+        assert sum(1 for b in ob if b[2] == 0 and b[1] == 65536) >= 2, (m, ob)    # > 65 535 bytes each: halved on emission
+    c10 = [a for a, _ in per_case[("copies_1500k", 10)][1]]
+    c9 = [a for a, _ in per_case[("copies_1500k", 9)][1]]
+    evens = [131072 * k + 750 for k in range(0, 3)]
+    assert all(e in c10 for e in evens) and not any(e in c9 for e in evens), (c10, c9)

@@ -69,6 +69,7 @@ def load_library():
     L.zada_last_blocks.argtypes = [vp, vp, u64, u64p]
     L.zada_last_timing.argtypes = [vp, vp, vp, i32]
     L.zada_silesia_mix.argtypes = [u64, ctypes.c_uint, u64, u64, vp]
+    L.zada_set_knob.argtypes = [vp, ctypes.c_char_p, i32]
     _lib = L
     return L
 
@@ -104,6 +105,11 @@ class Encoder:
             self.close()
         except Exception:
             pass
+
+    def set_knob(self, name, value):
+        """Tuning / test knobs ("budget", "max_demand_rounds", "batch_streams"); none changes a byte of output."""
+        if self.lib.zada_set_knob(self.ctx, name.encode(), int(value)) != 0:
+            raise ZadaError("unknown knob %r" % name)
 
     def _err(self, rc, what):
         raise ZadaError("%s failed: rc=%d (%s)" % (what, rc, self.lib.zada_last_error(self.ctx).decode()))

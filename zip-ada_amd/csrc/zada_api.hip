@@ -94,7 +94,6 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(blocks, W.cap_blocks);
   A(binfo, W.cap_blocks);
   A(emit, W.cap_blocks);
-  A(rel, W.cap_blocks * 6);
   A(chrec, W.cap_blocks * 16 + 16);
   A(codes, (W.cap_blocks + 1) * 320);
   W.cap_pieces = cap / 32768 + W.cap_blocks + 64;
@@ -273,6 +272,7 @@ static int deflate_core(Ctx *c, int method, uint64_t n, uint64_t *out_len, uint3
   hipStream_t st = c->stream;
   const int level = method_level(method);
   if (level < 0) { c->err = "unsupported method"; return ZADA_E_INVALID; }
+  c->last_nblocks = 0;
   if (fb && fb(0, user)) return ZADA_ABORTED;
   c->tbegin();
   c->tmark("begin");
@@ -328,6 +328,10 @@ zada_ctx *zada_create(int device) {
   if (hipHostMalloc((void **)&z->c.crc_host, (CRC_HOST_TOP + 64) * 4, hipHostMallocDefault) != hipSuccess) { delete z; return nullptr; }
   if (hipStreamCreate(&z->c.stream2) != hipSuccess || hipEventCreateWithFlags(&z->c.ev_input, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&z->c.ev_out, hipEventDisableTiming) != hipSuccess) { delete z; return nullptr; }
+  // tuning knobs: read once per context
+  if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
+  if (const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS")) { if (atoi(e) > 0) z->c.knob_max_demand_rounds = atoi(e); }
+  if (const char *e = getenv("ZADA_BATCH_STREAMS")) { if (atoi(e) >= 1) z->c.knob_batch_streams = atoi(e); }
   return z;
 }
 
@@ -349,6 +353,15 @@ void zada_destroy(zada_ctx *z) {
 }
 
 const char *zada_last_error(const zada_ctx *z) { return z ? z->c.err.c_str() : "no context"; }
+
+int zada_set_knob(zada_ctx *z, const char *name, int value) {
+  if (!z || !name) return ZADA_E_INVALID;
+  if (!strcmp(name, "budget")) z->c.knob_budget = value;
+  else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
+  else if (!strcmp(name, "batch_streams")) z->c.knob_batch_streams = value >= 1 ? value : 4;
+  else return ZADA_E_INVALID;
+  return ZADA_OK;
+}
 
 // Large host buffers travel through two pinned staging buffers of the context (memcpy into one while the other is on
 // its way): measured on the MI355X box for 1 GiB, 33 ms against 67-80 ms for hipMemcpy from pageable memory and 90 ms for
@@ -453,14 +466,17 @@ int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const 
   // context (stream, workspace) of its own, so that the kernels of different entries run side by side.
   uint64_t nmax = 0;
   for (int i = 0; i < count; i++) nmax = n[i] > nmax ? n[i] : nmax;
-  int T = count < 4 ? count : 4;                                   // (more host threads only contend for the runtime)
-  { const char *e = getenv("ZADA_BATCH_STREAMS"); if (e && atoi(e) >= 1) T = atoi(e) < count ? atoi(e) : count; }
+  int T = count;                                                   // (default 4: more host threads only contend for the runtime)
+  if (z->c.knob_batch_streams >= 1) T = z->c.knob_batch_streams < count ? z->c.knob_batch_streams : count;
   if (nmax > (64ull << 20)) T = 1;                              // big entries fill the GPU by themselves
   while (T > 1 && (int)z->workers.size() < T - 1) {
     zada_ctx *w = zada_create(z->c.device);
     if (!w) { T = (int)z->workers.size() + 1; break; }
     w->c.timing_on = false;
     z->workers.push_back(w);
+  }
+  for (zada_ctx *w : z->workers) {                                 // the workers follow the owner's knobs
+    w->c.knob_budget = z->c.knob_budget; w->c.knob_max_demand_rounds = z->c.knob_max_demand_rounds;
   }
   std::atomic<int> next(0), worst(0);
   std::mutex err_lock;
@@ -518,10 +534,19 @@ int zada_lz77_tokens(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uin
 
 int zada_last_blocks(zada_ctx *z, uint64_t *rec, uint64_t cap_blocks, uint64_t *nblocks) {
   if (!z) return ZADA_E_INVALID;
-  uint64_t nb = z->c.last_blocks.size() / 4;
+  // (fetched on demand: the records stay in the workspace until the next call; copying them after every call cost a
+  // device-to-host round trip inside the timed path)
+  Ctx *c = &z->c;
+  const uint64_t nb = c->last_nblocks;
   *nblocks = nb;
-  uint64_t k = nb < cap_blocks ? nb : cap_blocks;
-  if (k) memcpy(rec, z->c.last_blocks.data(), k * 4 * sizeof(uint64_t));
+  const uint64_t k = nb < cap_blocks ? nb : cap_blocks;
+  if (k == 0) return ZADA_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return ZADA_E_HIP;
+  std::vector<EmitRec> he(k); std::vector<BlockRange> hb(k);
+  hipMemcpyAsync(he.data(), c->ws.emit, k * sizeof(EmitRec), hipMemcpyDeviceToHost, c->stream);
+  hipMemcpyAsync(hb.data(), c->ws.blocks, k * sizeof(BlockRange), hipMemcpyDeviceToHost, c->stream);
+  if (hip_check(c, hipStreamSynchronize(c->stream), "trace")) return ZADA_E_HIP;
+  for (uint64_t i = 0; i < k; i++) { rec[4 * i] = hb[i].first; rec[4 * i + 1] = hb[i].count; rec[4 * i + 2] = he[i].fmt; rec[4 * i + 3] = he[i].cost_bits; }
   return ZADA_OK;
 }
 

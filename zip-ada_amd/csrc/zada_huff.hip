@@ -39,6 +39,12 @@ __device__ __forceinline__ void put_bits_global(uint32_t *out32, uint64_t pos, u
   if (sh + nbits > 32) atomicOr(&out32[w + 1], (uint32_t)(v >> 32));
 }
 
+// the same for the writers that run BEFORE the host has seen the total size: a stream that outgrows the workspace
+// (only possible when it is also larger than the input, i.e. Compression_inefficient) must not be written past its end
+__device__ __forceinline__ void put_bits_lim(uint32_t *out32, uint64_t lim_bits, uint64_t pos, uint32_t value, int nbits) {
+  if (pos + 64 <= lim_bits) put_bits_global(out32, pos, value, nbits);
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
@@ -286,7 +292,7 @@ struct ChRec {
 static_assert(sizeof(ChRec) == 128, "ChRec");
 
 __global__ void __launch_bounds__(64) k_block_relate(uint32_t nblocks, const BlockInfo *__restrict__ binfo, const BlockRange *__restrict__ blocks,
-                                                     BlockRel *__restrict__ rel, ChRec *__restrict__ chrec) {
+                                                     ChRec *__restrict__ chrec) {
   const uint32_t i = blockIdx.x;
   const int lane = threadIdx.x;
   const BlockInfo *bi = &binfo[i];
@@ -314,7 +320,6 @@ __global__ void __launch_bounds__(64) k_block_relate(uint32_t nblocks, const Blo
   out.eob[1] = ((uint32_t)__shfl(b2[4], 0) << 16) | wave_code_of(b2, 256, lane, 288);
   out.pad = 0;
   if (lane == 0) {
-    rel[i] = out;
     ChRec cr;
     const uint64_t fx = bi->fixed_data + 2, d1 = bi->dyn1_data + 2 + bi->hdr1_bits, d2 = bi->dyn2_data + 2 + bi->hdr2_bits;
     uint64_t m = fx; uint32_t f = FMT_FIXED;
@@ -341,192 +346,31 @@ struct ChooseState {
   uint64_t pos;
 };
 
-__global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRange *__restrict__ blocks,
-                                               const BlockInfo *__restrict__ binfo, const uint32_t *__restrict__ apos,
-                                               const BlockRel *__restrict__ rel, EmitRec *__restrict__ emit, uint32_t *__restrict__ tile_block,
-                                               StoredPiece *__restrict__ pieces, uint32_t cap_tiles, uint32_t cap_pieces,
-                                               uint32_t *__restrict__ out32, ChooserOut *__restrict__ res,
-                                               int fixed_only /* Deflate_Fixed */) {
+// Deflate_Fixed: one fixed block for the whole stream (:1600-1603, :1615-1616).  The pseudo-blocks (one per 65 536
+// atoms) only spread the cost analysis; their data positions are a running sum.
+__global__ void __launch_bounds__(64) k_choose_fixed(uint32_t nblocks, const BlockRange *__restrict__ blocks, const BlockInfo *__restrict__ binfo,
+                                                     EmitRec *__restrict__ emit, uint32_t *__restrict__ tile_block, uint32_t cap_tiles,
+                                                     uint32_t *__restrict__ out32, ChooserOut *__restrict__ res) {
   const int lane = threadIdx.x;
-  ChooseState S; S.last_type = BT_RESERVED; S.block_to_finish = 0; S.last_marked = 0; S.code_block = -1; S.code_variant = 0; S.pos = 0; S.cur_eob = 7u << 16;
-  uint32_t ntiles = 0, npieces = 0, overflow = 0;
-
-  if (fixed_only) {
-    // Deflate_Fixed: one block for the whole stream (:1600-1603, :1615-1616)
-    if (lane == 0) { put_bits_global(out32, 0, 1, 1); put_bits_global(out32, 1, 1, 2); }
-    S.pos = 3;
-    uint64_t data = 0;
-    for (uint32_t i = 0; i < nblocks; i++) {
-      const BlockRange br = blocks[i];
-      const uint64_t d = binfo[i].fixed_data;
-      uint32_t nt = (br.count + TILE - 1) / TILE;
-      if (lane == 0) {
-        EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = S.pos + data; e.cost_bits = d; e.fmt = FMT_FIXED; e.code_block = -1; e.code_variant = 0; e.tile_base = ntiles;
-        emit[i] = e;
-      }
-      if (ntiles + nt > cap_tiles) { overflow = 1; break; }
-      for (uint32_t t = lane; t < nt; t += 64) tile_block[ntiles + t] = i;
-      ntiles += nt;
-      data += d;
-    }
-    S.pos += data + 7;                                 // fixed EOB = 7 zero bits
-    if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = 0; res->n_blocks = nblocks; res->overflow = overflow; }
-    return;
-  }
-
-  // software prefetch of the next record: the walk is a dependent chain, so every load of block
-  // i + 1 is issued before block i is decided.  Only scalars: the 320-element work was done per block,
-  // in parallel, by k_block_analyze / k_block_relate.
-  struct Rec { uint64_t fixed_data, dyn1_data, dyn2_data; uint32_t hdr1, hdr2, bytes, sp; BlockRange br; BlockRel rl; };
-  auto load_block = [&](uint32_t i, Rec &r) {
-    const BlockInfo *bi = &binfo[i];
-    r.fixed_data = bi->fixed_data; r.dyn1_data = bi->dyn1_data; r.dyn2_data = bi->dyn2_data;
-    r.hdr1 = bi->hdr1_bits; r.hdr2 = bi->hdr2_bits; r.bytes = bi->bytes; r.sp = bi->stored_possible;
-    r.br = blocks[i];
-    r.rl = rel[i];
-  };
-  Rec nxt;
-  if (nblocks > 0) load_block(0, nxt);
-
+  uint32_t ntiles = 0, overflow = 0;
+  if (lane == 0) { put_bits_global(out32, 0, 1, 1); put_bits_global(out32, 1, 1, 2); }
+  uint64_t pos = 3;
   for (uint32_t i = 0; i < nblocks; i++) {
-    // the record is the same in every lane: as scalars, the whole decision below runs on the scalar unit
-    Rec cr;
-    {
-      uint32_t tmp[sizeof(Rec) / 4];
-      __builtin_memcpy(tmp, &nxt, sizeof(Rec));
-#pragma unroll
-      for (unsigned q = 0; q < sizeof(Rec) / 4; q++) tmp[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)tmp[q]);
-      __builtin_memcpy(&cr, tmp, sizeof(Rec));
+    const BlockRange br = blocks[i];
+    const uint64_t d = binfo[i].fixed_data;
+    const uint32_t nt = (br.count + TILE - 1) / TILE;
+    if (lane == 0) {
+      EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = pos; e.cost_bits = d; e.fmt = FMT_FIXED; e.code_block = -1; e.code_variant = 0; e.tile_base = ntiles;
+      e.pre_pos = 0; e.pre_eob = 0; e.pre_flags = 0;
+      emit[i] = e;
     }
-    if (i + 1 < nblocks) load_block(i + 1, nxt);
-    const BlockRange br = cr.br;
-    const uint64_t fixed_data = cr.fixed_data, dyn1_data = cr.dyn1_data, dyn2_data = cr.dyn2_data;
-    const uint32_t hdr1 = cr.hdr1, hdr2 = cr.hdr2, bytes = cr.bytes, stored_possible = cr.sp;
-
-    // recycling (:1223-1226, Recyclable :495-508) and its cost (:1158, 1180, 1189)
-    bool recycling_possible = false; uint64_t recycled_data = 0;
-    if (S.last_type == BT_FIXED) { recycling_possible = true; recycled_data = cr.rl.bits[0]; }
-    else if (S.last_type == BT_DYNAMIC) {
-      if (S.code_block == (int)i - 1) { recycling_possible = cr.rl.ok[S.code_variant] != 0; recycled_data = cr.rl.bits[S.code_variant]; }
-      else {
-        // the codes in force are older than the previous block (a chain of recycled blocks): evaluate here
-        const BlockInfo *bi = &binfo[i];
-        const uint8_t *cl = S.code_variant == 1 ? binfo[S.code_block].bl1 : binfo[S.code_block].bl2;
-        bool bad = false; uint64_t rc = 0;
-        for (int r = 0; r < 5; r++) {
-          const int s = lane + 64 * r;
-          const int cu = cl[s]; const uint32_t stv = bi->stats[s];
-          if (cu == 0 && bi->bl1[s] > 0) bad = true;
-          if (s < 288) { if (s != 256 && s <= 285) rc += (uint64_t)stv * (uint64_t)(cu + litlen_sym_extra(s)); }
-          else if (s - 288 <= 29) rc += (uint64_t)stv * (uint64_t)(cu + dist_sym_extra(s - 288));
-        }
-        recycling_possible = !__any(bad);
-        { const uint64_t v = wave_sum_u64(rc); recycled_data = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32); }
-      }
-    }
-    const bool finishing = S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC);
-    const int eob_len = (int)(S.cur_eob >> 16);
-    const uint64_t c = 1 + (finishing ? (uint64_t)eob_len : 0);                 // :1198-1201
-    const uint64_t INF = ~0ull;
-    uint64_t stored_bits = INF;
-    if (stored_possible) { uint64_t sb = 8ull * bytes; sb += (1 + (sb / 8) / 65535) * 40; stored_bits = sb + c; }   // :1193-1196, 1202
-    const uint64_t fixed_bits = fixed_data + c + 2;
-    const uint64_t d1_bits = dyn1_data + c + 2 + hdr1, d2_bits = dyn2_data + c + 2 + hdr2;
-    const uint64_t rec_bits = recycling_possible ? recycled_data : INF;
-    uint64_t opt = stored_bits < fixed_bits ? stored_bits : fixed_bits;
-    { uint64_t m2 = d1_bits < d2_bits ? d1_bits : d2_bits; m2 = m2 < rec_bits ? m2 : rec_bits; opt = opt < m2 ? opt : m2; }
-    int fmt;
-    if (fixed_bits == opt) fmt = FMT_FIXED; else if (d1_bits == opt) fmt = FMT_DYN1; else if (d2_bits == opt) fmt = FMT_DYN2;
-    else if (rec_bits == opt) fmt = FMT_RECYCLE; else fmt = FMT_STORED;          // :1243-1268
-
-    EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = 0; e.cost_bits = opt; e.fmt = (uint32_t)fmt; e.code_block = -1; e.code_variant = 0; e.tile_base = ntiles;
-    const int last_block = (int)br.last_flush;
-
-    // Mark_new_block :999-1007 (pre-EOB of the block being finished, then BFINAL)
-    auto mark_new_block = [&](int last_for_stream) {
-      if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
-        const int l = (int)(S.cur_eob >> 16);
-        if (lane == 0) put_bits_global(out32, S.pos, S.cur_eob & 0xFFFF, l);
-        S.pos += (uint64_t)l;
-      }
-      S.block_to_finish = 1;
-      if (lane == 0) put_bits_global(out32, S.pos, (uint32_t)last_for_stream, 1);
-      S.pos += 1;
-      S.last_marked = last_for_stream;
-    };
-
-    uint64_t data_bits = 0;
-    if (fmt == FMT_FIXED) {
-      if (S.last_type != BT_FIXED) {                                             // Send_fixed_block :1108-1121
-        mark_new_block(last_block);
-        if (lane == 0) put_bits_global(out32, S.pos, 1, 2);
-        S.pos += 2;
-        S.last_type = BT_FIXED; S.code_block = -1; S.code_variant = 0; S.cur_eob = 7u << 16;
-      }
-      data_bits = fixed_data;
-    } else if (fmt == FMT_DYN1 || fmt == FMT_DYN2) {                             // Send_dynamic_block :1126-1135
-      mark_new_block(last_block);
-      S.cur_eob = cr.rl.eob[fmt == FMT_DYN1 ? 0 : 1];
-      if (lane == 0) put_bits_global(out32, S.pos, 2, 2);
-      S.pos += 2;
-      e.hdr_bitpos = S.pos;
-      S.pos += (fmt == FMT_DYN1) ? hdr1 : hdr2;
-      S.last_type = BT_DYNAMIC; S.code_block = (int)i; S.code_variant = (fmt == FMT_DYN1) ? 1 : 2;
-      data_bits = (fmt == FMT_DYN1) ? dyn1_data : dyn2_data;
-    } else if (fmt == FMT_RECYCLE) {
-      data_bits = recycled_data;
-    } else {
-      // Expand_LZ_buffer :1010-1062 with its divide-and-conquer on the ATOM range
-      uint32_t stk_first[40], stk_last[40]; int stk_lastblk[40]; int sp = 0;
-      stk_first[0] = br.first; stk_last[0] = br.first + br.count - 1; stk_lastblk[0] = last_block; sp = 1;
-      while (sp > 0) {
-        sp--;
-        uint32_t f = stk_first[sp], l = stk_last[sp]; int lb = stk_lastblk[sp];
-        uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos[f]), nbytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos[l + 1]) - src;
-        if (nbytes > 0xFFFF) {
-          uint32_t mid = (uint32_t)(((uint64_t)f + (uint64_t)l) / 2);
-          // second half is processed after the first: push it first (LIFO)
-          stk_first[sp] = mid + 1; stk_last[sp] = l; stk_lastblk[sp] = lb; sp++;
-          stk_first[sp] = f; stk_last[sp] = mid; stk_lastblk[sp] = 0; sp++;
-          continue;
-        }
-        mark_new_block(lb);
-        S.last_type = BT_STORED;
-        S.pos += 2;                                                              // Put_Bits (0, 2)
-        S.pos = (S.pos + 7) & ~7ull;                                             // Flush_bit_buffer
-        if (lane == 0) {
-          put_bits_global(out32, S.pos, nbytes & 0xFFFF, 16);
-          put_bits_global(out32, S.pos + 16, (~nbytes) & 0xFFFF, 16);
-          if (npieces < cap_pieces) { StoredPiece pc; pc.dst_byte = (S.pos >> 3) + 4; pc.src_byte = src; pc.nbytes = nbytes; pieces[npieces] = pc; }
-        }
-        if (npieces >= cap_pieces) overflow = 1;
-        npieces++;
-        S.pos += 32 + 8ull * nbytes;
-      }
-    }
-    if (fmt != FMT_STORED) {
-      e.data_bitpos = S.pos;
-      e.code_block = S.code_block; e.code_variant = (uint32_t)S.code_variant;
-      S.pos += data_bits;
-      uint32_t nt = (br.count + TILE - 1) / TILE;
-      if (ntiles + nt > cap_tiles) { overflow = 1; break; }
-      for (uint32_t t = lane; t < nt; t += 64) tile_block[ntiles + t] = i;
-      ntiles += nt;
-    }
-    if (lane == 0) emit[i] = e;
+    if (ntiles + nt > cap_tiles) { overflow = 1; break; }
+    for (uint32_t t = lane; t < nt; t += 64) tile_block[ntiles + t] = i;
+    ntiles += nt;
+    pos += d;
   }
-
-  // stream epilogue, Encode :1613-1635
-  if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
-    const int l = (int)(S.cur_eob >> 16);
-    if (lane == 0) put_bits_global(out32, S.pos, S.cur_eob & 0xFFFF, l);
-    S.pos += (uint64_t)l;
-  }
-  if (!S.last_marked) {
-    if (lane == 0) { put_bits_global(out32, S.pos, 1, 1); put_bits_global(out32, S.pos + 1, 1, 2); }
-    S.pos += 3 + 7;                                                              // fake final fixed block: EOB = 0000000
-  }
-  if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = npieces; res->n_blocks = nblocks; res->overflow = overflow; }
+  pos += 7;                                          // fixed EOB = 7 zero bits
+  if (lane == 0) { res->total_bits = pos; res->n_tiles = ntiles; res->n_pieces = 0; res->n_blocks = nblocks; res->overflow = overflow; }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -538,7 +382,7 @@ __global__ void __launch_bounds__(64) k_choose(uint32_t nblocks, const BlockRang
 __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRec *__restrict__ chrec, const BlockInfo *__restrict__ binfo,
                                                     const uint32_t *__restrict__ apos, EmitRec *__restrict__ emit,
                                                     StoredPiece *__restrict__ pieces, uint32_t cap_tiles, uint32_t cap_pieces,
-                                                    uint32_t *__restrict__ out32, ChooserOut *__restrict__ res) {
+                                                    uint32_t *__restrict__ out32, uint64_t lim_bits, ChooserOut *__restrict__ res) {
   const int lane = threadIdx.x;
   ChooseState S; S.last_type = BT_RESERVED; S.block_to_finish = 0; S.last_marked = 0; S.code_block = -1; S.code_variant = 0; S.pos = 0; S.cur_eob = 7u << 16;
   uint32_t ntiles = 0, npieces = 0, overflow = 0;
@@ -635,19 +479,19 @@ __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRe
         }
         if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {      // Mark_new_block
           const int ll = (int)(S.cur_eob >> 16);
-          if (lane == 0) put_bits_global(out32, S.pos, S.cur_eob & 0xFFFF, ll);
+          if (lane == 0) put_bits_lim(out32, lim_bits, S.pos, S.cur_eob & 0xFFFF, ll);
           S.pos += (uint64_t)ll;
         }
         S.block_to_finish = 1;
-        if (lane == 0) put_bits_global(out32, S.pos, (uint32_t)lb, 1);
+        if (lane == 0) put_bits_lim(out32, lim_bits, S.pos, (uint32_t)lb, 1);
         S.pos += 1;
         S.last_marked = lb;
         S.last_type = BT_STORED;
         S.pos += 2;                                                              // Put_Bits (0, 2)
         S.pos = (S.pos + 7) & ~7ull;                                             // Flush_bit_buffer
         if (lane == 0) {
-          put_bits_global(out32, S.pos, nbytes & 0xFFFF, 16);
-          put_bits_global(out32, S.pos + 16, (~nbytes) & 0xFFFF, 16);
+          put_bits_lim(out32, lim_bits, S.pos, nbytes & 0xFFFF, 16);
+          put_bits_lim(out32, lim_bits, S.pos + 16, (~nbytes) & 0xFFFF, 16);
           if (npieces < cap_pieces) { StoredPiece pc; pc.dst_byte = (S.pos >> 3) + 4; pc.src_byte = src; pc.nbytes = nbytes; pieces[npieces] = pc; }
         }
         if (npieces >= cap_pieces) overflow = 1;
@@ -682,11 +526,11 @@ __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRe
   // stream epilogue, Encode :1613-1635
   if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
     const int l = (int)(S.cur_eob >> 16);
-    if (lane == 0) put_bits_global(out32, S.pos, S.cur_eob & 0xFFFF, l);
+    if (lane == 0) put_bits_lim(out32, lim_bits, S.pos, S.cur_eob & 0xFFFF, l);
     S.pos += (uint64_t)l;
   }
   if (!S.last_marked) {
-    if (lane == 0) { put_bits_global(out32, S.pos, 1, 1); put_bits_global(out32, S.pos + 1, 1, 2); }
+    if (lane == 0) { put_bits_lim(out32, lim_bits, S.pos, 1, 1); put_bits_lim(out32, lim_bits, S.pos + 1, 1, 2); }
     S.pos += 3 + 7;                                                              // fake final fixed block: EOB = 0000000
   }
   if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = npieces; res->n_blocks = nblocks; res->overflow = overflow; }
@@ -925,45 +769,36 @@ int huff_stage(Ctx *c, int method, uint64_t n, uint32_t T, uint64_t *total_bits)
     hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, W.atoms, W.apos, W.blocks, W.binfo);
     c->tmark("block_analyze");
   }
-  if (nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (BlockRel *)W.rel, (ChRec *)W.chrec);
-  const bool old_chooser = fixed_only || getenv("ZADA_CHOOSER_OLD") != nullptr;      // the original single-kernel walk (A/B, and Deflate_Fixed)
-  if (old_chooser)
-    hipLaunchKernelGGL(k_choose, dim3(1), dim3(64), 0, st, nblocks, W.blocks, W.binfo, W.apos, (const BlockRel *)W.rel, W.emit, W.tile_block, W.pieces,
-                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.chooser, fixed_only ? 1 : 0);
-  else {
+  if (nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (ChRec *)W.chrec);
+  if (fixed_only)
+    hipLaunchKernelGGL(k_choose_fixed, dim3(1), dim3(64), 0, st, nblocks, W.blocks, W.binfo, W.emit, W.tile_block, (uint32_t)W.cap_tiles, (uint32_t *)W.out, W.chooser);
+  else
     hipLaunchKernelGGL(k_choose_lean, dim3(1), dim3(64), 0, st, nblocks, (const ChRec *)W.chrec, W.binfo, W.apos, W.emit, W.pieces,
-                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.chooser);
-    if (nblocks > 0) hipLaunchKernelGGL(k_emit_prefix, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.emit, W.blocks, W.tile_block, (uint32_t *)W.out);
-  }
+                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.cap_out * 8, W.chooser);
   ChooserOut co;
   hipMemcpyAsync(&co, W.chooser, sizeof co, hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "choose")) return ZADA_E_HIP_;
   c->tmark("choose");
-  if (co.overflow) { c->err = "emission table overflow"; return -1; }
-  if ((co.total_bits + 7) / 8 + 8 > W.cap_out) { c->err = "output workspace overflow"; return -1; }
-  hipLaunchKernelGGL(k_block_codes, dim3(nblocks + 1), dim3(64), 0, st, nblocks, W.emit, W.binfo, W.codes);
-  if (co.n_tiles > 0) {
-    hipLaunchKernelGGL(k_tile_bits, dim3(co.n_tiles), dim3(256), 0, st, nblocks, W.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bits);
-    hipLaunchKernelGGL(k_tile_scan, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.blocks, W.emit, W.tile_bits, W.tile_bitpos);
-    hipLaunchKernelGGL(k_emit_tiles, dim3(co.n_tiles), dim3(256), 0, st, nblocks, W.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bitpos, (uint32_t *)W.out);
-  }
-  if (nblocks > 0 && !fixed_only) hipLaunchKernelGGL(k_emit_headers, dim3(nblocks), dim3(64), 0, st, nblocks, W.emit, W.binfo, (uint32_t *)W.out);
-  if (co.n_pieces > 0) hipLaunchKernelGGL(k_copy_pieces, dim3(co.n_pieces, 16), dim3(256), 0, st, co.n_pieces, W.pieces, W.in, W.out);
-  c->tmark("emit");
-  // block trace for zada_last_blocks
-  c->last_blocks.clear();
-  if (nblocks > 0) {
-    std::vector<EmitRec> he(nblocks); std::vector<BlockRange> hb(nblocks);
-    hipMemcpyAsync(he.data(), W.emit, nblocks * sizeof(EmitRec), hipMemcpyDeviceToHost, st);
-    hipMemcpyAsync(hb.data(), W.blocks, nblocks * sizeof(BlockRange), hipMemcpyDeviceToHost, st);
-    if (hip_check(c, hipStreamSynchronize(st), "trace")) return ZADA_E_HIP_;
-    c->last_blocks.resize((size_t)nblocks * 4);
-    for (uint32_t i = 0; i < nblocks; i++) {
-      c->last_blocks[4 * i] = hb[i].first; c->last_blocks[4 * i + 1] = hb[i].count;
-      c->last_blocks[4 * i + 2] = he[i].fmt; c->last_blocks[4 * i + 3] = he[i].cost_bits;
-    }
-  }
   *total_bits = co.total_bits;
+  if (co.overflow) { c->err = "emission table overflow"; return -1; }
+  // Compression_inefficient (zip-compress.adb:479-486): the stream is not smaller than the input.  The reference stops
+  // writing at the first 1 MiB flush that says so; nothing is emitted here (the workspace holds n + n/1024 + 4096 bytes,
+  // so a stream that does not fit it is always in this case).
+  const bool inefficient = (co.total_bits + 7) / 8 >= n;
+  if (!inefficient && !fixed_only && nblocks > 0)
+    hipLaunchKernelGGL(k_emit_prefix, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.emit, W.blocks, W.tile_block, (uint32_t *)W.out);
+  if (!inefficient) {
+    hipLaunchKernelGGL(k_block_codes, dim3(nblocks + 1), dim3(64), 0, st, nblocks, W.emit, W.binfo, W.codes);
+    if (co.n_tiles > 0) {
+      hipLaunchKernelGGL(k_tile_bits, dim3(co.n_tiles), dim3(256), 0, st, nblocks, W.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bits);
+      hipLaunchKernelGGL(k_tile_scan, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.blocks, W.emit, W.tile_bits, W.tile_bitpos);
+      hipLaunchKernelGGL(k_emit_tiles, dim3(co.n_tiles), dim3(256), 0, st, nblocks, W.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bitpos, (uint32_t *)W.out);
+    }
+    if (nblocks > 0 && !fixed_only) hipLaunchKernelGGL(k_emit_headers, dim3(nblocks), dim3(64), 0, st, nblocks, W.emit, W.binfo, (uint32_t *)W.out);
+    if (co.n_pieces > 0) hipLaunchKernelGGL(k_copy_pieces, dim3(co.n_pieces, 16), dim3(256), 0, st, co.n_pieces, W.pieces, W.in, W.out);
+  }
+  c->tmark("emit");
+  c->last_nblocks = nblocks;                        // block trace: zada_last_blocks reads emit / blocks from the workspace
   return hip_check(c, hipGetLastError(), "huff_stage");
 }
 

@@ -102,7 +102,6 @@ struct Workspace {
   BlockRange *blocks = nullptr;
   BlockInfo *binfo = nullptr;
   EmitRec *emit = nullptr;
-  uint64_t *rel = nullptr;                   // BlockRel[nblocks] (48 B each)
   uint64_t *chrec = nullptr;                 // ChRec[nblocks] (128 B each)
   uint32_t *codes = nullptr;                 // [nblocks+1][320]  (len << 16 | code); last = fixed table
   StoredPiece *pieces = nullptr;
@@ -139,8 +138,13 @@ struct Ctx {
   std::vector<std::pair<const char *, hipEvent_t>> marks;
   std::vector<std::pair<const char *, float>> timing;
   bool timing_on = true;
-  // last-call block trace
-  std::vector<uint64_t> last_blocks;
+  // last-call block trace: fetched from the workspace when zada_last_blocks asks for it
+  uint32_t last_nblocks = 0;
+  // knobs read from the environment once, when the context is created (tests set them before zada_create, or call
+  // zada_set_knob)
+  int knob_budget = -1;             // ZADA_BUDGET: rounds of chain steps per position in the first match pass (0 = unbounded, -1 = default)
+  int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
+  int knob_batch_streams = 4;       // ZADA_BATCH_STREAMS
   void tmark(const char *name);
   void tbegin();
   void tend();

@@ -1502,11 +1502,10 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   // on until a parse has used exact values only.  The result is the parse over exact values, whatever the budget.
   const uint32_t nbm = (uint32_t)((n + MB - 1) / MB);
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
-  int max_rounds = 12;                             // demand rounds before everything that is still a guess is searched (ZADA_MAX_DEMAND_ROUNDS)
-  { const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS"); if (e && atoi(e) > 0) max_rounds = atoi(e); }
-  int budget_env;                                  // read at every call: the tests compare budgets within one process
+  const int max_rounds = c->knob_max_demand_rounds;     // demand rounds before everything that is still a guess is searched
   // (below 2 MiB the rounds cost more launches than the bounded search saves)
-  { const char *e = getenv("ZADA_BUDGET"); budget_env = e ? atoi(e) : (n < (2u << 20) ? 0 : 8); if (budget_env < 1) budget_env = 1 << 20; }
+  int budget_env = c->knob_budget >= 0 ? c->knob_budget : (n < (2u << 20) ? 0 : 8);
+  if (budget_env < 1) budget_env = 1 << 20;
   const uint32_t nbd = (uint32_t)((n + DMB - 1) / DMB);
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   hipMemsetAsync(W.dbits, 0, (size_t)nbd * (DMB / 8), st);
