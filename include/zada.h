@@ -47,7 +47,7 @@ enum {
   ZADA_E_INVALID = -1,      /* bad argument / unsupported method */
   ZADA_E_NOMEM = -2,        /* host or device allocation failed */
   ZADA_E_HIP = -3,          /* HIP runtime error; see zada_last_error() */
-  ZADA_E_TOO_LARGE = -4,    /* single stream >= 2 GiB - 64 KiB per call in this version */
+  ZADA_E_TOO_LARGE = -4,    /* one context takes < 4 GiB - 64 MiB of a stream: larger streams are cut into ranges (zada_range_*) */
   ZADA_E_NO_DEVICE = -5     /* no gfx950 device / HIP extension unusable */
 };
 
@@ -64,7 +64,8 @@ const char *zada_last_error(const zada_ctx *ctx);
 const char *zada_version(void);
 /* Tuning / test knobs of a context (also read from the environment when the context is created):
  * "budget" (ZADA_BUDGET: rounds of chain steps per position in the first match pass; 0 = unbounded, -1 = default),
- * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "batch_streams" (ZADA_BATCH_STREAMS).  None of them changes a byte. */
+ * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "batch_streams" (ZADA_BATCH_STREAMS), "shard_kib" (ZADA_SHARD_KIB: KiB of
+ * a stream the match finder takes at a time, multiple of 64).  None of them changes a byte. */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 
 /* Zip.Compress.Deflate on host buffers (the Ada shim drains `input` with Zip.Block_Read into
@@ -98,6 +99,45 @@ int zada_deflate_batch(zada_ctx *ctx, int method, int count,
 int zada_compress_data(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n,
                        uint8_t *out, uint64_t cap, uint64_t *out_len,
                        uint32_t *crc_out, uint16_t *zip_type);
+
+/* ---- One stream over several contexts (GPUs) -------------------------------------------------------------------
+ * The reference compresses an entry as ONE sequential stream (a 32 KiB window, a lazy-match state machine, a flush of the
+ * LZ buffer every 65 536 atoms and the block chooser's state all run through it: lz77.adb:827-933,
+ * zip-compress-deflate.adb:993-997, 1424-1432).  A stream is cut into RANGES at multiples of 64 KiB, one per context; the
+ * calls below run a range's stages and expose exactly the state the ranges have to exchange, so that the concatenated
+ * output is bit for bit the stream of one zada_deflate call on the whole input (tests/test_ranges.py).  The exchange itself
+ * (RCCL all_gather / send-recv in zip-ada_amd/sharding.py) is the caller's.  zada_deflate* use the same machinery inside
+ * for one range, taking `shard_kib` KiB (knob, default 1 GiB) through the match finder at a time.
+ *
+ *   1. zada_range_open    d_in = device address of stream byte lo - pre; resident: pre = (lo ? 32768 : 0) bytes before the
+ *                         range and post = min(1 MiB, stream_size - lo - n) behind it; lo, n multiples of 64 KiB (n free
+ *                         for the last range); pre + n + post < 4 GiB - 64 MiB.
+ *   2. zada_range_lz      match finding + lazy parse.  entry = the state the range before ended in (its info.exit), or
+ *                         NULL if not known yet: the parse then starts 32 KiB earlier and info.warm is the first
+ *                         history-free state at or beyond lo that it went through -- if it equals the neighbour's
+ *                         info.exit the result stands, otherwise call zada_range_lz again with that exit.
+ *   3. zada_range_edges   the range's first <= 65 536 and last <= 2 048 atoms, for its neighbours.
+ *      zada_range_place   atoms of the stream before this range / in all, and the neighbours' atoms the range lacks:
+ *                         n_lb = max(0, 2048 - (F - atoms_before)) behind, F = first multiple of 65 536 >= atoms_before,
+ *                         (0 if the range owns no flush or F = 0) and enough ahead to complete its last flush.
+ *   4. zada_range_analyze everything that does not depend on earlier blocks.
+ *   5. zada_range_choose  the block decisions, from the 352-byte state of the range before (NULL: start of the stream);
+ *                         bit_begin / bit_end: the range's bits in the stream.
+ *   6. zada_range_emit    bytes [bit_begin / 8, ceil(bit_end / 8)) of the stream into d_out; a byte shared with a
+ *                         neighbour holds only this range's bits (OR them together).
+ * CRC-32: info.crc_raw is the register of the range's bytes started from 0; zada_crc32_combine(reg, raw, n) appends. */
+typedef struct { uint64_t pos; uint32_t kind, pad; } zada_parse_state;     /* kind 1: fresh (lz77.adb:898-899), 2: literal pending */
+typedef struct { uint64_t atoms; zada_parse_state exit, warm; uint32_t crc_raw, entry_known; } zada_range_info;
+enum { ZADA_CARRY_BYTES = 352 };
+int zada_range_open(zada_ctx *ctx, int method, const void *d_in, uint64_t stream_size, uint64_t lo, uint64_t n, uint64_t pre, uint64_t post);
+int zada_range_lz(zada_ctx *ctx, const zada_parse_state *entry, zada_range_info *info);
+int zada_range_edges(zada_ctx *ctx, void *d_head_atoms, void *d_head_pos, uint32_t *n_head, void *d_tail_atoms, void *d_tail_pos, uint32_t *n_tail);
+int zada_range_place(zada_ctx *ctx, uint64_t atoms_before, uint64_t atoms_total, const void *d_lb_atoms, const void *d_lb_pos, uint32_t n_lb,
+                     const void *d_la_atoms, const void *d_la_pos, uint32_t n_la);
+int zada_range_analyze(zada_ctx *ctx);
+int zada_range_choose(zada_ctx *ctx, const void *carry_in, void *carry_out, uint64_t *bit_begin, uint64_t *bit_end);
+int zada_range_emit(zada_ctx *ctx, void *d_out, uint64_t cap, uint64_t *nbytes);
+uint32_t zada_crc32_combine(uint32_t reg, uint32_t raw, uint64_t len);
 
 /* ---- Introspection used by tests and bench.py (not part of the reference's interface) ---- */
 

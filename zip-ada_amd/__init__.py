@@ -53,6 +53,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ZadaError("libzada_hip.so is missing: run __graft_entry__.build() "
                         "(make -C zip-ada_amd/csrc). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 / libhsa-runtime64.  If this library pulled in
+    # /opt/rocm's copy first, a later `import torch` would bring up a SECOND runtime in the same process, which on some
+    # nodes cannot open the GPU any more ("No HIP GPUs are available").  Loaded after torch, libzada_hip.so binds to the
+    # runtime torch has loaded (same soname).  PyTorch is only plumbing here (device buffers, torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u64, u32p, u64p, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int
     L.zada_create.restype = vp
@@ -70,11 +78,33 @@ def load_library():
     L.zada_last_timing.argtypes = [vp, vp, vp, i32]
     L.zada_silesia_mix.argtypes = [u64, ctypes.c_uint, u64, u64, vp]
     L.zada_set_knob.argtypes = [vp, ctypes.c_char_p, i32]
+    L.zada_range_open.argtypes = [vp, i32, vp, u64, u64, u64, u64, u64]
+    L.zada_range_lz.argtypes = [vp, vp, vp]
+    L.zada_range_edges.argtypes = [vp, vp, vp, u32p, vp, vp, u32p]
+    L.zada_range_place.argtypes = [vp, u64, u64, vp, vp, ctypes.c_uint32, vp, vp, ctypes.c_uint32]
+    L.zada_range_analyze.argtypes = [vp]
+    L.zada_range_choose.argtypes = [vp, vp, vp, u64p, u64p]
+    L.zada_range_emit.argtypes = [vp, vp, u64, u64p]
+    L.zada_crc32_combine.restype = ctypes.c_uint32
+    L.zada_crc32_combine.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u64]
     _lib = L
     return L
 
 
 FEEDBACK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+CARRY_BYTES = 352          # ZADA_CARRY_BYTES
+RANGE_ALIGN = 65536        # range boundaries
+RANGE_PRE = 32768          # bytes resident before a range that does not start the stream
+RANGE_POST = 1 << 20       # ... and behind one that does not end it (or the rest of the stream, if shorter)
+EDGE_HEAD, EDGE_TAIL = 65536, 2048
+
+
+class _ParseState(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_uint64), ("kind", ctypes.c_uint32), ("pad", ctypes.c_uint32)]
+
+
+class _RangeInfo(ctypes.Structure):
+    _fields_ = [("atoms", ctypes.c_uint64), ("exit", _ParseState), ("warm", _ParseState), ("crc_raw", ctypes.c_uint32), ("entry_known", ctypes.c_uint32)]
 
 
 def _addr(buf):
@@ -188,6 +218,61 @@ class Encoder:
         if rc != 0:
             self._err(rc, "zada_lz77_tokens")
         return tok[:nt.value]
+
+    # ---- one stream over several contexts (include/zada.h "One stream over several contexts"; driver: sharding.py) ----
+    def range_open(self, d_in_ptr, stream_size, lo, n, pre, post, method=Method.Deflate_3):
+        rc = self.lib.zada_range_open(self.ctx, method, d_in_ptr, stream_size, lo, n, pre, post)
+        if rc != 0:
+            self._err(rc, "zada_range_open")
+
+    def range_lz(self, entry=None):
+        """entry: (pos, kind) the range before ended in, or None.  Returns dict(atoms, exit, warm, crc_raw, entry_known)."""
+        info = _RangeInfo()
+        e = _ParseState(entry[0], entry[1], 0) if entry is not None else None
+        rc = self.lib.zada_range_lz(self.ctx, ctypes.addressof(e) if e is not None else None, ctypes.addressof(info))
+        if rc != 0:
+            self._err(rc, "zada_range_lz")
+        return dict(atoms=info.atoms, exit=(info.exit.pos, info.exit.kind), warm=(info.warm.pos, info.warm.kind),
+                    crc_raw=info.crc_raw, entry_known=bool(info.entry_known))
+
+    def range_edges(self, head_atoms_ptr, head_pos_ptr, tail_atoms_ptr, tail_pos_ptr):
+        nh, nt = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        rc = self.lib.zada_range_edges(self.ctx, head_atoms_ptr, head_pos_ptr, ctypes.byref(nh), tail_atoms_ptr, tail_pos_ptr, ctypes.byref(nt))
+        if rc != 0:
+            self._err(rc, "zada_range_edges")
+        return nh.value, nt.value
+
+    def range_place(self, atoms_before, atoms_total, lb_atoms_ptr=None, lb_pos_ptr=None, n_lb=0, la_atoms_ptr=None, la_pos_ptr=None, n_la=0):
+        rc = self.lib.zada_range_place(self.ctx, atoms_before, atoms_total, lb_atoms_ptr, lb_pos_ptr, n_lb, la_atoms_ptr, la_pos_ptr, n_la)
+        if rc != 0:
+            self._err(rc, "zada_range_place")
+
+    def range_analyze(self):
+        rc = self.lib.zada_range_analyze(self.ctx)
+        if rc != 0:
+            self._err(rc, "zada_range_analyze")
+
+    def range_choose(self, carry_in=None):
+        """carry_in: the 352-byte state of the range before (None: the stream starts here).
+        Returns (carry_out bytes, bit_begin, bit_end)."""
+        cin = ctypes.create_string_buffer(bytes(carry_in), CARRY_BYTES) if carry_in is not None else None
+        cout = ctypes.create_string_buffer(CARRY_BYTES)
+        b0, b1 = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = self.lib.zada_range_choose(self.ctx, ctypes.addressof(cin) if cin is not None else None, ctypes.addressof(cout),
+                                        ctypes.byref(b0), ctypes.byref(b1))
+        if rc != 0:
+            self._err(rc, "zada_range_choose")
+        return cout.raw, b0.value, b1.value
+
+    def range_emit(self, d_out_ptr, cap):
+        nb = ctypes.c_uint64(0)
+        rc = self.lib.zada_range_emit(self.ctx, d_out_ptr, cap, ctypes.byref(nb))
+        if rc != 0:
+            self._err(rc, "zada_range_emit")
+        return nb.value
+
+    def crc32_combine(self, reg, raw, length):
+        return self.lib.zada_crc32_combine(reg, raw, length)
 
     def last_blocks(self):
         import numpy as np

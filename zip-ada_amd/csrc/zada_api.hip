@@ -49,29 +49,34 @@ void Ctx::tend() {
 }
 
 template <typename T>
-static int dalloc(Ctx *c, T **p, uint64_t count) {
+static int dalloc(Ctx *c, std::vector<void *> &group, T **p, uint64_t count) {
   void *q = nullptr;
   hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
-  if (e != hipSuccess) { hip_check(c, e, "hipMalloc"); return ZADA_E_NOMEM; }
-  c->ws.allocs.push_back(q);
+  if (e != hipSuccess) { hip_check(c, e, "hipMalloc"); (void)hipGetLastError(); return ZADA_E_NOMEM; }
+  group.push_back(q);
   *p = (T *)q;
   return 0;
 }
 
-static void free_workspace(Ctx *c) {
-  for (void *p : c->ws.allocs) hipFree(p);
-  c->ws = Workspace();
+static void free_group(std::vector<void *> &group) {
+  for (void *p : group) hipFree(p);
+  group.clear();
 }
 
-int ensure_workspace(Ctx *c, uint64_t n) {
+// LZ stage: per byte of shard buffer 2 x 2 (links) + 8/32768 x 65536 x 2 (tails) + 2 + 1 + 4 (15-bit order) + 2 x 2 + 4 (planes) +
+// 8 (match records) + 2 + 2 + 2 (last-level order) + 2 x 9 (tokens) + ... = about 55 bytes; the buffer is one shard of a range
+// (ZADA_SHARD_KIB, default 1 GiB) with its halo and tail.
+int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   Workspace &W = c->ws;
-  if (W.cap_n >= n && W.cap_n > 0) return 0;
-  free_workspace(c);
-  uint64_t cap = n < (1u << 20) ? (1u << 20) : n;
+  if (W.cap_n >= nbuf && W.cap_n > 0) return 0;
+  hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
+  free_group(W.allocs);
+  W.cap_n = 0;
+  uint64_t cap = nbuf < (1u << 20) ? (1u << 20) : nbuf;
   cap = (cap + 65535) & ~65535ull;
-  const uint64_t nch = cap / PCHUNK + 2, nseg32 = cap / 32768 + 2, nflush = cap / FLUSH + 2;
+  const uint64_t nch = cap / PCHUNK + 2, nseg32 = cap / 32768 + 2;
   int rc = 0;
-#define A(ptr, cnt) if (!rc) rc = dalloc(c, &W.ptr, (cnt))
+#define A(ptr, cnt) if (!rc) rc = dalloc(c, W.allocs, &W.ptr, (cnt))
   A(in, cap + IN_PAD + 64);
   for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); A(ltails[l], nseg32 * 65536); }
   A(S3, nseg32 * 32768); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768);
@@ -88,6 +93,27 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(dirty[0], nch + 64); A(dirty[1], nch + 64);
   A(n_changed, 16);
   A(blk_demand, cap / 4096 + 64); A(dbits, cap / 32 + 4096); A(n_demand, 16); A(chg, nch + 64);
+  A(dbg, 128);
+#undef A
+  if (rc) { free_group(W.allocs); return rc; }
+  W.cap_n = cap;
+  hipMemsetAsync(W.dbg, 0, 128 * 8, c->stream);
+  return hip_check(c, hipStreamSynchronize(c->stream), "workspace init");
+}
+
+// Entropy stage: sized for the atoms of one range (worst case one atom per byte) and its output.
+int ensure_entropy_workspace(Ctx *c, uint64_t atoms) {
+  Workspace &W = c->ws;
+  if (W.cap_atoms >= atoms && W.cap_atoms > 0) return 0;
+  hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
+  free_group(W.en_allocs);
+  W.cap_atoms = 0;
+  uint64_t cap = atoms < (1u << 20) ? (1u << 20) : atoms;
+  cap = (cap + 65535) & ~65535ull;
+  const uint64_t nflush = cap / FLUSH + 3;
+  int rc = 0;
+#define A(ptr, cnt) if (!rc) rc = dalloc(c, W.en_allocs, &W.ptr, (cnt))
+  A(ea_atoms, LB_CAP + cap + LA_CAP + 64); A(ea_apos, LB_CAP + cap + LA_CAP + 64);
   A(descr, nflush * SLOTS * 320);
   A(seg_nblk, nflush); A(seg_cut, nflush * MAXBLK_PER_SEG); A(seg_blk_off, nflush);
   W.cap_blocks = nflush * MAXBLK_PER_SEG;
@@ -95,25 +121,41 @@ int ensure_workspace(Ctx *c, uint64_t n) {
   A(binfo, W.cap_blocks);
   A(emit, W.cap_blocks);
   A(chrec, W.cap_blocks * 16 + 16);
-  A(codes, (W.cap_blocks + 1) * 320);
-  W.cap_pieces = cap / 32768 + W.cap_blocks + 64;
+  A(codes, (W.cap_blocks + 2) * 320);
+  W.cap_pieces = cap / 2048 + W.cap_blocks + 64;
   A(pieces, W.cap_pieces);
   W.cap_tiles = cap / TILE + W.cap_blocks + 64;
   A(tile_block, W.cap_tiles); A(tile_bitpos, W.cap_tiles); A(tile_bits, W.cap_tiles);
-  A(chooser, 1);
-  A(crc_lvl[0], cap / CRC_SUB + 64); A(crc_lvl[1], cap / CRC_SUB / 16 + 64); A(crc_lvl[2], cap / CRC_SUB / 256 + 64); A(crc_lvl[3], cap / CRC_SUB / 4096 + 64);
+  A(chooser, 1); A(carry, 2);
+  A(scan2, nflush / 1024 + 1024); A(total2, 16);
+  for (int l = 0; l < 4; l++) A(crc_lvl[l], (cap >> (4 * l)) / CRC_SUB + 64);
   A(crc_mat, 128);
-  A(dbg, 128);
-  W.cap_out = cap + cap / 1024 + 4096;
+  W.crc_mat_ready = false;
+  // the largest stream the encoder can produce for `cap` bytes: every literal in nine bits (fixed code) + block overheads
+  W.cap_out = cap + cap / 8 + (1u << 20);
   A(out, W.cap_out);
 #undef A
-  if (rc) { free_workspace(c); return rc; }
-  W.atoms = (uint32_t *)W.M; W.apos = W.atoms + (cap + 64);     // the atom arrays reuse the match tables (dead after the parse)
-  W.cap_n = cap;
-  // the input pad must be zero for the match finder's over-reads
-  hipMemsetAsync(W.in, 0, cap + IN_PAD + 64, c->stream);
-  hipMemsetAsync(W.dbg, 0, 128 * 8, c->stream);
-  return hip_check(c, hipStreamSynchronize(c->stream), "workspace init");
+  if (rc) { free_group(W.en_allocs); return rc; }
+  W.cap_atoms = cap;
+  return 0;
+}
+
+static int ensure_rin(Ctx *c, uint64_t n) {
+  Workspace &W = c->ws;
+  if (W.cap_rin >= n && W.rin_own) return 0;
+  hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
+  if (W.rin_own) hipFree(W.rin_own);
+  W.rin_own = nullptr; W.cap_rin = 0;
+  const uint64_t cap = ((n < (1u << 20) ? (1u << 20) : n) + 65535) & ~65535ull;
+  if (hipMalloc((void **)&W.rin_own, cap + 256) != hipSuccess) { (void)hipGetLastError(); c->err = "hipMalloc (input)"; return ZADA_E_NOMEM; }
+  W.cap_rin = cap;
+  return 0;
+}
+
+static void free_workspace(Ctx *c) {
+  free_group(c->ws.allocs); free_group(c->ws.en_allocs);
+  if (c->ws.rin_own) hipFree(c->ws.rin_own);
+  c->ws = Workspace();
 }
 
 // --------------------------------------------------------------------------------------------
@@ -122,7 +164,7 @@ int ensure_workspace(Ctx *c, uint64_t n) {
 // One lane per CRC_SUB bytes (raw register started at 0: the linear part), then the 16 sub-results of
 // each CRC_CHUNK are folded on the device with the fixed "advance by CRC_SUB zero bytes" operator
 // (mat, 32 words), leaving one value per CRC_CHUNK for the host to chain.
-__global__ void __launch_bounds__(256) k_crc_chunks(const uint8_t *__restrict__ in, uint64_t n, uint32_t nsub, uint32_t *__restrict__ sub) {
+__global__ void __launch_bounds__(256) k_crc_chunks(const uint8_t *__restrict__ in, uint64_t n, uint32_t nsub, uint32_t *__restrict__ sub) {   // in: 16-byte aligned
   __shared__ uint32_t tab[256];
   {
     uint32_t l = threadIdx.x;
@@ -194,7 +236,7 @@ static void zero_advance_matrix(uint64_t len, uint32_t *out) {
 // crc_finish waits for them and chains.
 constexpr int CRC_NLEV = 4;
 static uint32_t crc_M[CRC_NLEV][32];
-int crc_launch(Ctx *c, uint64_t n) {
+int crc_launch(Ctx *c, const uint8_t *d_in, uint64_t n) {
   if (n == 0) return 0;
   Workspace &W = c->ws;
   CrcPending &P = c->crc;
@@ -210,7 +252,7 @@ int crc_launch(Ctx *c, uint64_t n) {
   P.cnt[0] = P.nfull0;
   for (int l = 1; l < CRC_NLEV; l++) P.cnt[l] = P.cnt[l - 1] / 16;
   if (!W.crc_mat_ready) { hipMemcpyAsync(W.crc_mat, crc_M, sizeof(uint32_t) * 32 * (CRC_NLEV - 1), hipMemcpyHostToDevice, s2); W.crc_mat_ready = true; }
-  hipLaunchKernelGGL(k_crc_chunks, dim3((P.nsub + 255) / 256), dim3(256), 0, s2, W.in, n, P.nsub, W.crc_lvl[0]);
+  hipLaunchKernelGGL(k_crc_chunks, dim3((P.nsub + 255) / 256), dim3(256), 0, s2, d_in, n, P.nsub, W.crc_lvl[0]);
   for (int l = 1; l < CRC_NLEV; l++)
     if (P.cnt[l]) hipLaunchKernelGGL(k_crc_fold, dim3((P.cnt[l] + 255) / 256), dim3(256), 0, s2, W.crc_lvl[l - 1], P.cnt[l], W.crc_mat + 32 * (l - 1), W.crc_lvl[l]);
   // values the host needs: all of the top level, and per lower level the < 16 values after the last full group
@@ -259,7 +301,33 @@ static int method_level(int method) {
   }
 }
 
-// core: input already in W.in[0..n) (pad zeroed); result in W.out
+uint32_t crc32_advance(uint32_t reg, uint64_t len) {          // the register after `len` more zero bytes (the linear part of Update)
+  if (len == 0) return reg;
+  uint32_t m[32];
+  zero_advance_matrix(len, m);
+  return gf2_apply(m, reg);
+}
+
+// --------------------------------------------------------------------------------------------
+// Ranges.  A stream is compressed as one or more RANGES (one per GPU when several share a stream; one for the whole
+// stream otherwise), a range in SHARDS (what the LZ workspace holds at a time).  Nothing of this changes a byte:
+//   * the match finder at position p needs the bytes [p - 32 506, p + 258) only (lz77.adb:495-500), so a shard is
+//     searched in a buffer that starts 32 KiB before it and ends 4 KiB behind it;
+//   * the parser (lz77.adb:827-933) enters a shard in the history-free state the shard before ended in (first state
+//     at or beyond the boundary: the parse runs over the boundary by less than 520 bytes, inside the tail).  Where that
+//     state is not known yet (a range on another GPU) the parse is started 32 KiB earlier in the fresh state: two parses
+//     that reach the same history-free state at the same position are identical from there on, which is checked when
+//     the neighbour's state arrives (zada_range_lz is run again with it otherwise);
+//   * the LZ buffer is flushed every 65 536 atoms counted from the start of the stream (zip-compress-deflate.adb:
+//     1424-1432): a range owns the flushes whose first atom is one of its own and gets the atoms it lacks (2 048 behind,
+//     up to 65 535 ahead) from its neighbours;
+//   * Send_as_block's state (curr_descr, last_block_type, block_to_finish, last_block_marked, bit position:
+//     zip-compress-deflate.adb:722, 993-997) is handed from range to range (ChooserCarry).
+// --------------------------------------------------------------------------------------------
+constexpr uint32_t SHARD_HALO = 32768, SHARD_TAIL = 4096;
+constexpr uint64_t RANGE_POST = 1u << 20;    // bytes to keep resident behind a range: the look-ahead atoms of a block that may be
+                                             // stored are at most 65 535 x 14 bytes (:1093-1095, 1222)
+
 struct PadArgs { uint8_t *in_end; uint32_t n_in; uint16_t *link_end[NLEVELS]; };
 __global__ void k_pad_init(PadArgs a) {
   for (uint32_t i = threadIdx.x; i < a.n_in; i += blockDim.x) a.in_end[i] = 0;
@@ -267,46 +335,155 @@ __global__ void k_pad_init(PadArgs a) {
     if (threadIdx.x < 64) a.link_end[l][threadIdx.x] = 0;
 }
 
-static int deflate_core(Ctx *c, int method, uint64_t n, uint64_t *out_len, uint32_t *crc_inout, zada_feedback_fn fb, void *user) {
-  Workspace &W = c->ws;
-  hipStream_t st = c->stream;
+int range_open(Ctx *c, int method, const uint8_t *rin, uint64_t stream_size, uint64_t lo, uint64_t n, uint64_t pre, uint64_t post) {
   const int level = method_level(method);
   if (level < 0) { c->err = "unsupported method"; return ZADA_E_INVALID; }
+  if (lo + n > stream_size || n > stream_size) { c->err = "range outside the stream"; return ZADA_E_INVALID; }
+  const uint64_t behind = stream_size - (lo + n);
+  if (pre != (lo > 0 ? SHARD_HALO : 0u) || post != (behind < RANGE_POST ? behind : RANGE_POST) ||
+      (lo % 65536) != 0 || (behind > 0 && (n % 65536) != 0) || (behind > 0 && n == 0)) {
+    c->err = "range: boundaries must be multiples of 64 KiB, with 32 KiB before and min(1 MiB, rest of the stream) behind it resident";
+    return ZADA_E_INVALID;
+  }
+  if (pre + n + post >= (1ull << 32) - (1ull << 26)) { c->err = "range too large for one context (4 GiB - 64 MiB): split the stream into ranges"; return ZADA_E_TOO_LARGE; }
+  if (((uintptr_t)rin & 15) != 0) { c->err = "range: input must be 16-byte aligned"; return ZADA_E_INVALID; }
+  const uint64_t shard = (uint64_t)c->knob_shard_kib << 10;
+  int rc = ensure_entropy_workspace(c, n);
+  if (!rc) rc = ensure_lz_workspace(c, (n < shard ? n : shard) + SHARD_HALO + SHARD_TAIL);
+  if (rc) return rc;
+  Range &R = c->rg;
+  R = Range();
+  R.open = true; R.rin = rin; R.lo = lo; R.pre = pre; R.n = n; R.post = post;
+  R.first = lo == 0; R.last = behind == 0; R.method = method; R.level = level;
   c->last_nblocks = 0;
+  c->demand_rounds = 0; c->parse_rounds = 0;
+  // the output bit stream is OR-ed together: zero it meanwhile, on the second stream
+  Workspace &W = c->ws;
+  const uint64_t zbytes = n + n / 8 + (1u << 20) < W.cap_out ? n + n / 8 + (1u << 20) : W.cap_out;
+  hipMemsetAsync(W.out, 0, zbytes, c->stream2);
+  hipEventRecord(c->ev_out, c->stream2);
+  return 0;
+}
+
+// LZ stage of the whole range, shard by shard; entry = the state the range before ended in (nullptr: not known yet).
+int range_lz(Ctx *c, const GlobalState *entry, zada_feedback_fn fb, void *user) {
+  Range &R = c->rg;
+  Workspace &W = c->ws;
+  hipStream_t st = c->stream;
+  if (!R.open) { c->err = "no range open"; return ZADA_E_INVALID; }
+  const uint64_t shard = (uint64_t)c->knob_shard_kib << 10;
+  if (shard == 0 || (shard % 65536) != 0) { c->err = "shard size must be a multiple of 64 KiB"; return ZADA_E_INVALID; }
+  R.T = 0; R.placed = R.analyzed = R.chosen = false;
+  R.entry_known = R.first || entry != nullptr;
+  GlobalState cur{R.lo, SYNC_F, 0};
+  if (!R.first && entry) cur = *entry;
+  R.warm = cur;
+  bool known = R.entry_known;
+  // CRC-32 of the range's own bytes, on the second stream (register started from 0: the linear part)
+  hipEventRecord(c->ev_input, st);
+  hipStreamWaitEvent(c->stream2, c->ev_input, 0);
+  int rc = crc_launch(c, R.rin + R.pre, R.n);
+  if (rc) return rc;
+  for (uint64_t s_lo = 0; s_lo < R.n; s_lo += shard) {
+    const uint64_t s_hi = s_lo + shard < R.n ? s_lo + shard : R.n;
+    const uint32_t H = (R.pre + s_lo > 0) ? SHARD_HALO : 0u;
+    const uint64_t after = R.n + R.post - s_hi;
+    const uint32_t tail = after < SHARD_TAIL ? (uint32_t)after : SHARD_TAIL;
+    const uint64_t nbuf = H + (s_hi - s_lo) + tail;
+    const uint64_t boff = R.pre + s_lo - H;                     // the buffer's first byte in rin
+    const uint64_t gbuf = R.lo + s_lo - H;                      // ... and in the stream
+    hipMemcpyAsync(W.in, R.rin + boff, nbuf, hipMemcpyDeviceToDevice, st);
+    {
+      // zero pad behind the buffer and behind the link planes: one small launch
+      PadArgs pa; pa.in_end = W.in + nbuf; pa.n_in = IN_PAD;
+      for (int l = 0; l < NLEVELS; l++) pa.link_end[l] = W.lprev[l] + (nbuf >= 2 ? nbuf - 2 : 0);
+      hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);
+    }
+    ShardJob job;
+    job.nbuf = nbuf; job.tok_lo = H; job.tok_hi = (uint32_t)(H + (s_hi - s_lo));
+    job.final = R.last && s_hi == R.n;
+    job.entry_known = known;
+    job.entry = ExitState{(uint32_t)(cur.pos - gbuf), cur.kind};
+    job.dst_atoms = W.ea_atoms + LB_CAP + R.T; job.dst_apos = W.ea_apos + LB_CAP + R.T;
+    job.apos_bias = (uint32_t)boff;
+    job.cap_atoms = W.cap_atoms - R.T;
+    ShardResult res;
+    rc = lz_shard(c, R.level, job, &res);
+    if (rc) return rc == -2 ? ZADA_E_NOMEM : rc;
+    if (s_lo == 0 && !known) R.warm = GlobalState{gbuf + res.warm.pos, res.warm.kind, 0};
+    R.T += res.ntok;
+    cur = GlobalState{gbuf + res.exit.pos, res.exit.kind, 0};
+    known = true;
+    if (fb && fb(5 + (int)(65 * s_hi / R.n), user)) return ZADA_ABORTED;
+  }
+  R.exit = cur;
+  uint32_t raw = 0;
+  rc = crc_finish(c, R.n, &raw);
+  if (rc) return rc;
+  R.crc_raw = raw;
+  return 0;
+}
+
+// Where the range lies in the stream's atom sequence, and the neighbours' atoms it needs (already in the local array).
+int range_place(Ctx *c, uint64_t G, uint64_t T_total, uint32_t n_lb, uint32_t n_la) {
+  Range &R = c->rg;
+  if (!R.open) { c->err = "no range open"; return ZADA_E_INVALID; }
+  if (G + R.T > T_total || n_lb > LB_CAP || n_la > LA_CAP) { c->err = "range_place: inconsistent atom counts"; return ZADA_E_INVALID; }
+  R.G = G; R.T_total = T_total; R.n_lb = n_lb; R.n_la = n_la;
+  if (R.method == ZADA_DEFLATE_FIXED) {               // one fixed block: every range codes its own atoms
+    if (n_lb || n_la) { c->err = "range_place: Deflate_Fixed needs no neighbours"; return ZADA_E_INVALID; }
+    R.nflush = (uint32_t)((R.T + FLUSH - 1) / FLUSH); R.foff = 0; R.j0 = 0;
+    // (the chooser tells the end of the stream by stream_final = G + T == T_total)
+  } else {
+    const uint64_t gF0 = (G + FLUSH - 1) / FLUSH * FLUSH;
+    R.nflush = G + R.T > gF0 ? (uint32_t)((G + R.T - gF0 + FLUSH - 1) / FLUSH) : 0u;
+    R.foff = (uint32_t)(n_lb + (gF0 - G));
+    R.j0 = gF0 / FLUSH;
+    const uint64_t last_end = gF0 + (uint64_t)R.nflush * FLUSH < T_total ? gF0 + (uint64_t)R.nflush * FLUSH : T_total;
+    const uint64_t need_la = R.nflush > 0 && last_end > G + R.T ? last_end - (G + R.T) : 0;
+    const uint64_t need_lb = R.nflush > 0 && R.j0 > 0 && gF0 - G < HALF_SLIDER ? HALF_SLIDER - (gF0 - G) : 0;
+    if (n_la < need_la || n_lb < need_lb) { c->err = "range_place: neighbours' atoms missing"; return ZADA_E_INVALID; }
+    R.n_la = (uint32_t)need_la;                        // (no more than the last owned flush needs)
+    if (R.nflush == 0) R.n_la = 0;
+  }
+  R.placed = true; R.analyzed = R.chosen = false;
+  return 0;
+}
+
+// Zip.Compress.Deflate on a whole stream resident at d_in (one range): result in W.out
+static int deflate_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint64_t *out_len, uint32_t *crc_inout, zada_feedback_fn fb, void *user) {
   if (fb && fb(0, user)) return ZADA_ABORTED;
   c->tbegin();
   c->tmark("begin");
-  {
-    // zero pad behind the input and behind the link planes: one small launch (a hipMemsetAsync costs ~0.3 ms of stream time each)
-    PadArgs pa; pa.in_end = W.in + n; pa.n_in = IN_PAD;
-    for (int l = 0; l < NLEVELS; l++) pa.link_end[l] = W.lprev[l] + (n >= 2 ? n - 2 : 0);
-    hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);
-  }
-  uint32_t crc = crc_inout ? *crc_inout : 0xFFFFFFFFu;
-  int rc = crc_launch(c, n);
+  int rc = range_open(c, method, d_in, n, 0, n, 0, 0);
   if (rc) return rc;
-  // the output bit stream is OR-ed together: zero it meanwhile, on the second stream
-  hipMemsetAsync(W.out, 0, n + n / 1024 + 4096 < W.cap_out ? n + n / 1024 + 4096 : W.cap_out, c->stream2);
-  hipEventRecord(c->ev_out, c->stream2);
+  Range &R = c->rg;
   if (fb && fb(5, user)) return ZADA_ABORTED;
-  uint32_t T = 0;
-  rc = lz_stage(c, level, n, &T);
+  rc = range_lz(c, nullptr, fb, user);
   if (rc) return rc;
   if (fb && fb(70, user)) return ZADA_ABORTED;
-  uint64_t total_bits = 0;
-  hipStreamWaitEvent(st, c->ev_out, 0);
-  rc = huff_stage(c, method, n, T, &total_bits);
+  rc = range_place(c, 0, R.T, 0, 0);
+  if (!rc) rc = entropy_analyze(c);
   if (rc) return rc;
-  if (hip_check(c, hipStreamSynchronize(st), "deflate")) return ZADA_E_HIP_;
-  rc = crc_finish(c, n, &crc);
+  hipStreamWaitEvent(c->stream, c->ev_out, 0);
+  R.carry_in = ChooserCarry();
+  R.carry_in.last_type = BT_RESERVED; R.carry_in.cur_eob = 7u << 16;
+  rc = entropy_choose(c);
   if (rc) return rc;
+  *out_len = (R.co.total_bits + 7) / 8;
+  // Compression_inefficient (zip-compress.adb:479-486): the stream is not smaller than the input.  The reference stops
+  // writing at the first 1 MiB flush that says so; nothing is emitted here.
+  const bool inefficient = *out_len >= n;
+  if (!inefficient) {
+    rc = entropy_emit(c, nullptr);
+    if (rc) return rc;
+  }
+  if (hip_check(c, hipStreamSynchronize(c->stream), "deflate")) return ZADA_E_HIP_;
   c->tmark("end");
   c->tend();
+  if (crc_inout) *crc_inout = crc32_advance(*crc_inout, n) ^ R.crc_raw;
   if (fb && fb(100, user)) return ZADA_ABORTED;
-  *out_len = (total_bits + 7) / 8;
-  if (crc_inout) *crc_inout = crc;
-  // Compression_inefficient, zip-compress.adb:479-486: final size >= input size
-  return (*out_len >= n) ? ZADA_INEFFICIENT : ZADA_OK;
+  return inefficient ? ZADA_INEFFICIENT : ZADA_OK;
 }
 
 }  // namespace zada
@@ -332,6 +509,7 @@ zada_ctx *zada_create(int device) {
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
   if (const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS")) { if (atoi(e) > 0) z->c.knob_max_demand_rounds = atoi(e); }
   if (const char *e = getenv("ZADA_BATCH_STREAMS")) { if (atoi(e) >= 1) z->c.knob_batch_streams = atoi(e); }
+  if (const char *e = getenv("ZADA_SHARD_KIB")) { if (atoi(e) >= 64 && atoi(e) % 64 == 0) z->c.knob_shard_kib = atoi(e); }
   return z;
 }
 
@@ -340,9 +518,9 @@ void zada_destroy(zada_ctx *z) {
   for (zada_ctx *w : z->workers) zada_destroy(w);
   hipSetDevice(z->c.device);
   hipStreamSynchronize(z->c.stream);
-  for (void *p : z->c.ws.allocs) hipFree(p);
-  for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
   hipStreamSynchronize(z->c.stream2);
+  free_workspace(&z->c);
+  for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
   hipStreamDestroy(z->c.stream2);
   hipHostFree(z->c.crc_host);
   for (int b = 0; b < 2; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
@@ -359,6 +537,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "batch_streams")) z->c.knob_batch_streams = value >= 1 ? value : 4;
+  else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
   else return ZADA_E_INVALID;
   return ZADA_OK;
 }
@@ -416,21 +595,28 @@ static int copy_out(Ctx *c, uint8_t *dst, const void *d_src, uint64_t n) {
   return 0;
 }
 
-static int prepare(zada_ctx *z, uint64_t n) {
+static int prepare(zada_ctx *z) {
   if (!z) return ZADA_E_INVALID;
-  if (n >= (1ull << 31) - 65536) { z->c.err = "stream too large for one call"; return ZADA_E_TOO_LARGE; }
   if (hipSetDevice(z->c.device) != hipSuccess) return ZADA_E_HIP;
-  return ensure_workspace(&z->c, n);
+  return 0;
+}
+
+// a call that ends early (abort, error) must not leave work in flight on the context's streams
+static int finish_call(Ctx *c, int rc) {
+  if (rc != ZADA_OK && rc != ZADA_INEFFICIENT) { hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); (void)hipGetLastError(); c->rg.open = false; }
+  return rc;
 }
 
 int zada_deflate(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,
                  uint32_t *crc_inout, zada_feedback_fn fb, void *user) {
-  int rc = prepare(z, n);
+  int rc = prepare(z);
   if (rc) return rc;
   Ctx *c = &z->c;
-  copy_in(c, c->ws.in, in, n);
+  rc = ensure_rin(c, n);
+  if (rc) return rc;
+  copy_in(c, c->ws.rin_own, in, n);
   uint64_t ol = 0;
-  rc = deflate_core(c, method, n, &ol, crc_inout, fb, user);
+  rc = finish_call(c, deflate_core(c, method, c->ws.rin_own, n, &ol, crc_inout, fb, user));
   if (rc < 0 || rc == ZADA_ABORTED) return rc;
   if (out_len) *out_len = ol;
   if (rc == ZADA_OK) {
@@ -442,12 +628,18 @@ int zada_deflate(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t
 
 int zada_deflate_device(zada_ctx *z, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len,
                         uint32_t *crc_inout) {
-  int rc = prepare(z, n);
+  int rc = prepare(z);
   if (rc) return rc;
   Ctx *c = &z->c;
-  if (n) hipMemcpyAsync(c->ws.in, d_in, n, hipMemcpyDeviceToDevice, c->stream);
+  const uint8_t *src = (const uint8_t *)d_in;
+  if (((uintptr_t)d_in & 15) != 0 && n) {              // the kernels read 16 bytes at a time
+    rc = ensure_rin(c, n);
+    if (rc) return rc;
+    hipMemcpyAsync(c->ws.rin_own, d_in, n, hipMemcpyDeviceToDevice, c->stream);
+    src = c->ws.rin_own;
+  }
   uint64_t ol = 0;
-  rc = deflate_core(c, method, n, &ol, crc_inout, nullptr, nullptr);
+  rc = finish_call(c, deflate_core(c, method, src, n, &ol, crc_inout, nullptr, nullptr));
   if (rc < 0) return rc;
   if (out_len) *out_len = ol;
   if (rc == ZADA_OK) {
@@ -457,6 +649,116 @@ int zada_deflate_device(zada_ctx *z, int method, const void *d_in, uint64_t n, v
   }
   return rc;
 }
+
+// ---- one stream over several contexts (GPUs): see "Ranges" above and INTEGRATION.md ----
+
+int zada_range_open(zada_ctx *z, int method, const void *d_in, uint64_t stream_size, uint64_t lo, uint64_t n, uint64_t pre, uint64_t post) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  c->tbegin(); c->tmark("begin");
+  return finish_call(c, range_open(c, method, (const uint8_t *)d_in, stream_size, lo, n, pre, post));
+}
+
+int zada_range_lz(zada_ctx *z, const zada_parse_state *entry, zada_range_info *info) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  GlobalState e{0, SYNC_F, 0};
+  if (entry) { e.pos = entry->pos; e.kind = entry->kind; }
+  rc = finish_call(c, range_lz(c, entry ? &e : nullptr, nullptr, nullptr));
+  if (rc) return rc;
+  const Range &R = c->rg;
+  info->atoms = R.T;
+  info->exit.pos = R.exit.pos; info->exit.kind = R.exit.kind; info->exit.pad = 0;
+  info->warm.pos = R.warm.pos; info->warm.kind = R.warm.kind; info->warm.pad = 0;
+  info->crc_raw = R.crc_raw; info->entry_known = R.entry_known ? 1u : 0u;
+  return ZADA_OK;
+}
+
+// positions travel between ranges as the low 32 bits of the position in the STREAM
+__global__ void k_edge_copy(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ sp, uint32_t *__restrict__ da, uint32_t *__restrict__ dp,
+                            uint32_t n, uint32_t bias) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { da[i] = sa[i]; dp[i] = sp[i] + bias; }
+}
+
+int zada_range_edges(zada_ctx *z, void *d_head_atoms, void *d_head_pos, uint32_t *n_head, void *d_tail_atoms, void *d_tail_pos, uint32_t *n_tail) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  const Range &R = c->rg;
+  if (!R.open) { c->err = "no range open"; return ZADA_E_INVALID; }
+  Workspace &W = c->ws;
+  const uint32_t nh = R.T < LA_CAP ? (uint32_t)R.T : LA_CAP, nt = R.T < LB_CAP ? (uint32_t)R.T : LB_CAP;
+  const uint32_t bias = (uint32_t)(R.lo - R.pre);                  // rin-relative -> stream (low 32 bits)
+  if (nh) hipLaunchKernelGGL(k_edge_copy, dim3((nh + 255) / 256), dim3(256), 0, c->stream, W.ea_atoms + LB_CAP, W.ea_apos + LB_CAP,
+                             (uint32_t *)d_head_atoms, (uint32_t *)d_head_pos, nh, bias);
+  if (nt) hipLaunchKernelGGL(k_edge_copy, dim3((nt + 255) / 256), dim3(256), 0, c->stream, W.ea_atoms + LB_CAP + (R.T - nt), W.ea_apos + LB_CAP + (R.T - nt),
+                             (uint32_t *)d_tail_atoms, (uint32_t *)d_tail_pos, nt, bias);
+  *n_head = nh; *n_tail = nt;
+  return hip_check(c, hipStreamSynchronize(c->stream), "range_edges") ? ZADA_E_HIP : ZADA_OK;
+}
+
+int zada_range_place(zada_ctx *z, uint64_t atoms_before, uint64_t atoms_total, const void *d_lb_atoms, const void *d_lb_pos, uint32_t n_lb,
+                     const void *d_la_atoms, const void *d_la_pos, uint32_t n_la) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  Range &R = c->rg;
+  if (!R.open) { c->err = "no range open"; return ZADA_E_INVALID; }
+  if (n_lb > LB_CAP || n_la > LA_CAP) { c->err = "range_place: too many neighbour atoms"; return ZADA_E_INVALID; }
+  Workspace &W = c->ws;
+  const uint32_t bias = 0u - (uint32_t)(R.lo - R.pre);             // stream (low 32 bits) -> rin-relative
+  if (n_lb) hipLaunchKernelGGL(k_edge_copy, dim3((n_lb + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)d_lb_atoms, (const uint32_t *)d_lb_pos,
+                               W.ea_atoms + LB_CAP - n_lb, W.ea_apos + LB_CAP - n_lb, n_lb, bias);
+  if (n_la) hipLaunchKernelGGL(k_edge_copy, dim3((n_la + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)d_la_atoms, (const uint32_t *)d_la_pos,
+                               W.ea_atoms + LB_CAP + R.T, W.ea_apos + LB_CAP + R.T, n_la, bias);
+  return finish_call(c, range_place(c, atoms_before, atoms_total, n_lb, n_la));
+}
+
+int zada_range_analyze(zada_ctx *z) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  if (!c->rg.open || !c->rg.placed) { c->err = "range_analyze: range not placed"; return ZADA_E_INVALID; }
+  return finish_call(c, entropy_analyze(c));
+}
+
+int zada_range_choose(zada_ctx *z, const void *carry_in, void *carry_out, uint64_t *bit_begin, uint64_t *bit_end) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  Range &R = c->rg;
+  if (!R.open || !R.analyzed) { c->err = "range_choose: range not analysed"; return ZADA_E_INVALID; }
+  if (carry_in) memcpy(&R.carry_in, carry_in, sizeof(ChooserCarry));
+  else { R.carry_in = ChooserCarry(); R.carry_in.last_type = BT_RESERVED; R.carry_in.cur_eob = 7u << 16; }   // the stream starts here
+  hipStreamWaitEvent(c->stream, c->ev_out, 0);
+  rc = finish_call(c, entropy_choose(c));
+  if (rc) return rc;
+  if (carry_out) memcpy(carry_out, &R.carry_out, sizeof(ChooserCarry));
+  if (bit_begin) *bit_begin = R.carry_in.pos;
+  if (bit_end) *bit_end = R.carry_out.pos;
+  return ZADA_OK;
+}
+
+int zada_range_emit(zada_ctx *z, void *d_out, uint64_t cap, uint64_t *nbytes) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  Range &R = c->rg;
+  if (!R.open || !R.chosen) { c->err = "range_emit: nothing chosen"; return ZADA_E_INVALID; }
+  const uint64_t nb = (R.co.total_bits + 7) / 8;
+  if (nb > cap) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
+  rc = finish_call(c, entropy_emit(c, (uint8_t *)d_out));
+  if (rc) return rc;
+  if (hip_check(c, hipStreamSynchronize(c->stream), "range_emit")) return ZADA_E_HIP;
+  c->tmark("end"); c->tend();
+  if (nbytes) *nbytes = nb;
+  return ZADA_OK;
+}
+
+uint32_t zada_crc32_combine(uint32_t reg, uint32_t raw, uint64_t len) { return crc32_advance(reg, len) ^ raw; }
 
 int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
                        const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc) {
@@ -476,7 +778,7 @@ int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const 
     z->workers.push_back(w);
   }
   for (zada_ctx *w : z->workers) {                                 // the workers follow the owner's knobs
-    w->c.knob_budget = z->c.knob_budget; w->c.knob_max_demand_rounds = z->c.knob_max_demand_rounds;
+    w->c.knob_budget = z->c.knob_budget; w->c.knob_max_demand_rounds = z->c.knob_max_demand_rounds; w->c.knob_shard_kib = z->c.knob_shard_kib;
   }
   std::atomic<int> next(0), worst(0);
   std::mutex err_lock;
@@ -513,22 +815,20 @@ int zada_compress_data(zada_ctx *z, int method, const uint8_t *in, uint64_t n, u
 }
 
 int zada_lz77_tokens(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint32_t *tokens, uint64_t cap, uint64_t *ntok) {
-  int rc = prepare(z, n);
+  int rc = prepare(z);
   if (rc) return rc;
   Ctx *c = &z->c;
-  const int level = method_level(method);
-  if (level < 0) return ZADA_E_INVALID;
-  if (n) hipMemcpyAsync(c->ws.in, in, n, hipMemcpyHostToDevice, c->stream);
-  hipMemsetAsync(c->ws.in + n, 0, IN_PAD, c->stream);
-  for (int l = 0; l < NLEVELS; l++) hipMemsetAsync(c->ws.lprev[l] + (n >= 2 ? n - 2 : 0), 0, 2 * 64, c->stream);
-  c->tbegin(); c->tmark("begin");
-  uint32_t T = 0;
-  rc = lz_stage(c, level, n, &T);
+  rc = ensure_rin(c, n);
   if (rc) return rc;
+  if (n) hipMemcpyAsync(c->ws.rin_own, in, n, hipMemcpyHostToDevice, c->stream);
+  c->tbegin(); c->tmark("begin");
+  rc = range_open(c, method, c->ws.rin_own, n, 0, n, 0, 0);
+  if (!rc) rc = range_lz(c, nullptr, nullptr, nullptr);
+  if (finish_call(c, rc)) return rc;
   c->tmark("end"); c->tend();
-  *ntok = T;
-  uint64_t k = T < cap ? T : cap;
-  if (k) hipMemcpyAsync(tokens, c->ws.atoms, k * 4, hipMemcpyDeviceToHost, c->stream);
+  *ntok = c->rg.T;
+  const uint64_t k = c->rg.T < cap ? c->rg.T : cap;
+  if (k) hipMemcpyAsync(tokens, c->ws.ea_atoms + LB_CAP, k * 4, hipMemcpyDeviceToHost, c->stream);
   return hip_check(c, hipStreamSynchronize(c->stream), "tokens out") ? ZADA_E_HIP : ZADA_OK;
 }
 
@@ -546,7 +846,8 @@ int zada_last_blocks(zada_ctx *z, uint64_t *rec, uint64_t cap_blocks, uint64_t *
   hipMemcpyAsync(he.data(), c->ws.emit, k * sizeof(EmitRec), hipMemcpyDeviceToHost, c->stream);
   hipMemcpyAsync(hb.data(), c->ws.blocks, k * sizeof(BlockRange), hipMemcpyDeviceToHost, c->stream);
   if (hip_check(c, hipStreamSynchronize(c->stream), "trace")) return ZADA_E_HIP;
-  for (uint64_t i = 0; i < k; i++) { rec[4 * i] = hb[i].first; rec[4 * i + 1] = hb[i].count; rec[4 * i + 2] = he[i].fmt; rec[4 * i + 3] = he[i].cost_bits; }
+  const uint64_t g0 = c->rg.G - c->rg.n_lb;            // index in the stream of element 0 of the range's local atom array
+  for (uint64_t i = 0; i < k; i++) { rec[4 * i] = g0 + hb[i].first; rec[4 * i + 1] = hb[i].count; rec[4 * i + 2] = he[i].fmt; rec[4 * i + 3] = he[i].cost_bits; }
   return ZADA_OK;
 }
 

@@ -57,24 +57,25 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 // --------------------------------------------------------------------------------------------
 // k_window_descr : one wave per (flush segment, slot)
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_window_descr(const uint32_t *__restrict__ atoms, uint32_t T, uint32_t kstep,
-                                                     uint8_t *__restrict__ descr) {
+__global__ void __launch_bounds__(64) k_window_descr(EntropyView v, uint32_t kstep, uint8_t *__restrict__ descr) {
   __shared__ uint32_t hist[320];
   __shared__ uint8_t bl[320];
   __shared__ __attribute__((aligned(16))) uint8_t S[LLHC_WAVE_SCRATCH];
-  const uint32_t slot = blockIdx.x % SLOTS, j = blockIdx.x / SLOTS;
-  const uint32_t F = j * FLUSH;
-  const uint32_t to = (F + FLUSH - 1 < T - 1) ? F + FLUSH - 1 : T - 1;
+  const uint32_t *__restrict__ atoms = v.atoms;
+  const uint32_t slot = blockIdx.x % SLOTS, j = blockIdx.x / SLOTS;       // j: owned flush (local number)
+  const uint64_t gj = v.j0 + j;                                             // its number in the stream
+  const uint32_t F = v.foff + j * FLUSH;                                    // local index of its first atom
+  const uint32_t to = (F + FLUSH - 1 < v.lvalid - 1) ? F + FLUSH - 1 : v.lvalid - 1;
   if (to - F < SLIDER - 1) return;                                  // :1333-1336 short flush: no scanning
   int64_t lo, hi;
-  if (slot == 0) { lo = (j == 0) ? 0 : (int64_t)F - HALF_SLIDER; hi = lo + SLIDER - 1; }   // :1338-1360
+  if (slot == 0) { lo = (gj == 0) ? (int64_t)F : (int64_t)F - HALF_SLIDER; hi = lo + SLIDER - 1; }   // :1338-1360
   else {
     const uint32_t m = F + MIN_STEP * slot;
     if (!((uint64_t)m + HALF_SLIDER < to)) return;                  // :1364
     if (slot % kstep) return;
     lo = (int64_t)m - HALF_SLIDER; hi = (int64_t)m + HALF_SLIDER;
     // ring-index wrap => Ada null slice (:1372): first-half flushes only
-    if ((j & 1) == 0 && MIN_STEP * slot < HALF_SLIDER) { lo = 0; hi = -1; }
+    if ((gj & 1) == 0 && MIN_STEP * slot < HALF_SLIDER) { lo = 0; hi = -1; }
   }
   const int lane = threadIdx.x;
   for (int i = lane; i < 320; i += 64) hist[i] = (i == 256) ? 1u : 0u;     // empty_lit_len_stat :946
@@ -105,11 +106,11 @@ __global__ void __launch_bounds__(64) k_window_descr(const uint32_t *__restrict_
 // --------------------------------------------------------------------------------------------
 // k_cut_scan : one wave per flush segment
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_cut_scan(uint32_t T, uint32_t kstep, const uint8_t *__restrict__ descr,
+__global__ void __launch_bounds__(64) k_cut_scan(EntropyView v, uint32_t kstep, const uint8_t *__restrict__ descr,
                                                  uint32_t *__restrict__ seg_nblk, uint32_t *__restrict__ seg_cut) {
   const uint32_t j = blockIdx.x, lane = threadIdx.x;
-  const uint32_t F = j * FLUSH;
-  const uint32_t to = (F + FLUSH - 1 < T - 1) ? F + FLUSH - 1 : T - 1;
+  const uint32_t F = v.foff + j * FLUSH;
+  const uint32_t to = (F + FLUSH - 1 < v.lvalid - 1) ? F + FLUSH - 1 : v.lvalid - 1;
   uint32_t *cuts = seg_cut + (uint64_t)j * MAXBLK_PER_SEG;
   uint32_t nb = 0;
   if (lane == 0) cuts[0] = F;
@@ -135,20 +136,35 @@ __global__ void __launch_bounds__(64) k_cut_scan(uint32_t T, uint32_t kstep, con
   if (lane == 0) seg_nblk[j] = nb;
 }
 
-__global__ void k_fill_blocks(uint32_t T, uint32_t nseg, const uint32_t *__restrict__ seg_nblk, const uint32_t *__restrict__ seg_cut,
+__global__ void k_fill_blocks(EntropyView v, const uint32_t *__restrict__ seg_nblk, const uint32_t *__restrict__ seg_cut,
                               const uint32_t *__restrict__ seg_off, BlockRange *__restrict__ blocks) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nseg) return;
-  const uint32_t F = j * FLUSH;
-  const uint32_t to = (F + FLUSH - 1 < T - 1) ? F + FLUSH - 1 : T - 1;
+  if (j >= v.nflush) return;
+  const uint32_t F = v.foff + j * FLUSH;
+  const uint32_t to = (F + FLUSH - 1 < v.lvalid - 1) ? F + FLUSH - 1 : v.lvalid - 1;
   const uint32_t nb = seg_nblk[j], off = seg_off[j];
   const uint32_t *cuts = seg_cut + (uint64_t)j * MAXBLK_PER_SEG;
-  const bool last_seg_partial = (j == nseg - 1) && (T % FLUSH != 0);
+  // the stream's last flush, if it is not a full one, is sent with last_flush = True (:1613-1623)
+  const bool last_seg_partial = (j == v.nflush - 1) && v.stream_final && (v.lvalid - F < FLUSH);
   for (uint32_t i = 0; i < nb; i++) {
     uint32_t first = cuts[i], end = (i + 1 < nb) ? cuts[i + 1] - 1 : to;
     BlockRange b; b.first = first; b.count = end - first + 1; b.last_flush = (last_seg_partial && i + 1 == nb) ? 1u : 0u; b.pad = 0;
     blocks[off + i] = b;
   }
+}
+
+// Deflate_Fixed: the range's own atoms in pieces of 65 536 (only to spread the cost analysis and the emission)
+__global__ void k_fill_blocks_fixed(uint32_t first, uint32_t T, uint32_t nb, BlockRange *__restrict__ blocks) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nb) return;
+  BlockRange b; b.first = first + j * FLUSH; b.count = (j + 1 == nb) ? T - j * FLUSH : FLUSH; b.last_flush = 0; b.pad = 0;
+  blocks[j] = b;
+}
+
+// byte position behind the last atom of the local array (what apos[lvalid] would be): the blocks' byte counts are
+// differences of positions
+__global__ void k_apos_sentinel(const uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos, uint32_t lvalid) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && lvalid > 0) apos[lvalid] = apos[lvalid - 1] + tok_len(atoms[lvalid - 1]);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -347,20 +363,26 @@ struct ChooseState {
 };
 
 // Deflate_Fixed: one fixed block for the whole stream (:1600-1603, :1615-1616).  The pseudo-blocks (one per 65 536
-// atoms) only spread the cost analysis; their data positions are a running sum.
+// atoms) only spread the cost analysis; their data positions are a running sum.  The range that starts the stream writes
+// the block header, the one that ends it the end-of-block code.
 __global__ void __launch_bounds__(64) k_choose_fixed(uint32_t nblocks, const BlockRange *__restrict__ blocks, const BlockInfo *__restrict__ binfo,
                                                      EmitRec *__restrict__ emit, uint32_t *__restrict__ tile_block, uint32_t cap_tiles,
-                                                     uint32_t *__restrict__ out32, ChooserOut *__restrict__ res) {
+                                                     uint32_t *__restrict__ out32, uint64_t lim_bits, ChooserOut *__restrict__ res,
+                                                     const ChooserCarry *__restrict__ cin, ChooserCarry *__restrict__ cout, uint64_t base_bits,
+                                                     int stream_first, int stream_last) {
   const int lane = threadIdx.x;
   uint32_t ntiles = 0, overflow = 0;
-  if (lane == 0) { put_bits_global(out32, 0, 1, 1); put_bits_global(out32, 1, 1, 2); }
-  uint64_t pos = 3;
+  uint64_t pos = cin->pos - base_bits;
+  if (stream_first) {
+    if (lane == 0) { put_bits_lim(out32, lim_bits, pos, 1, 1); put_bits_lim(out32, lim_bits, pos + 1, 1, 2); }
+    pos += 3;
+  }
   for (uint32_t i = 0; i < nblocks; i++) {
     const BlockRange br = blocks[i];
     const uint64_t d = binfo[i].fixed_data;
     const uint32_t nt = (br.count + TILE - 1) / TILE;
     if (lane == 0) {
-      EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = pos; e.cost_bits = d; e.fmt = FMT_FIXED; e.code_block = -1; e.code_variant = 0; e.tile_base = ntiles;
+      EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = pos; e.cost_bits = d; e.fmt = FMT_FIXED; e.code_block = CODE_FIXED; e.code_variant = 0; e.tile_base = ntiles;
       e.pre_pos = 0; e.pre_eob = 0; e.pre_flags = 0;
       emit[i] = e;
     }
@@ -369,8 +391,11 @@ __global__ void __launch_bounds__(64) k_choose_fixed(uint32_t nblocks, const Blo
     ntiles += nt;
     pos += d;
   }
-  pos += 7;                                          // fixed EOB = 7 zero bits
-  if (lane == 0) { res->total_bits = pos; res->n_tiles = ntiles; res->n_pieces = 0; res->n_blocks = nblocks; res->overflow = overflow; }
+  if (stream_last) pos += 7;                         // fixed EOB = 7 zero bits
+  if (lane == 0) {
+    res->total_bits = pos; res->n_tiles = ntiles; res->n_pieces = 0; res->n_blocks = nblocks; res->overflow = overflow;
+    cout->pos = pos + base_bits; cout->last_type = BT_FIXED; cout->block_to_finish = 1; cout->last_marked = 1; cout->cur_eob = 7u << 16;
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -382,9 +407,16 @@ __global__ void __launch_bounds__(64) k_choose_fixed(uint32_t nblocks, const Blo
 __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRec *__restrict__ chrec, const BlockInfo *__restrict__ binfo,
                                                     const uint32_t *__restrict__ apos, EmitRec *__restrict__ emit,
                                                     StoredPiece *__restrict__ pieces, uint32_t cap_tiles, uint32_t cap_pieces,
-                                                    uint32_t *__restrict__ out32, uint64_t lim_bits, ChooserOut *__restrict__ res) {
+                                                    uint32_t *__restrict__ out32, uint64_t lim_bits, ChooserOut *__restrict__ res,
+                                                    const ChooserCarry *__restrict__ cin, ChooserCarry *__restrict__ cout, uint64_t base_bits,
+                                                    int do_epilogue) {
   const int lane = threadIdx.x;
-  ChooseState S; S.last_type = BT_RESERVED; S.block_to_finish = 0; S.last_marked = 0; S.code_block = -1; S.code_variant = 0; S.pos = 0; S.cur_eob = 7u << 16;
+  // the state the blocks before this range left behind (zip-compress-deflate.adb:722, 993-997); a fresh stream starts
+  // with last_block_type = reserved, nothing to finish, nothing marked, bit position 0
+  ChooseState S;
+  S.last_type = cin->last_type; S.block_to_finish = cin->block_to_finish; S.last_marked = cin->last_marked;
+  S.code_block = S.last_type == BT_DYNAMIC ? CODE_CARRIED : CODE_FIXED; S.code_variant = 0;
+  S.pos = cin->pos - base_bits; S.cur_eob = cin->cur_eob;
   uint32_t ntiles = 0, npieces = 0, overflow = 0;
   // The records are fetched four blocks ahead, one dword per lane with a vector load (these complete in order, so waiting
   // for the oldest leaves the newer ones in flight; scalar loads would all be waited for together), and spread into
@@ -409,7 +441,7 @@ __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRe
       else {
         // the codes in force are older than the previous block (a chain of recycled blocks): evaluate here
         const BlockInfo *bi = &binfo[i];
-        const uint8_t *cl = S.code_variant == 1 ? binfo[S.code_block].bl1 : binfo[S.code_block].bl2;
+        const uint8_t *cl = S.code_block == CODE_CARRIED ? cin->bl : (S.code_variant == 1 ? binfo[S.code_block].bl1 : binfo[S.code_block].bl2);
         bool bad = false; uint64_t rc = 0;
         for (int r = 0; r < 5; r++) {
           const int s = lane + 64 * r;
@@ -434,7 +466,7 @@ __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRe
     else if (rb <= st) { fmt = FMT_RECYCLE; opt = rb; }
     else { fmt = FMT_STORED; opt = st; }
 
-    EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = 0; e.cost_bits = opt; e.fmt = (uint32_t)fmt; e.code_block = -1; e.code_variant = 0; e.tile_base = ntiles;
+    EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = 0; e.cost_bits = opt; e.fmt = (uint32_t)fmt; e.code_block = CODE_FIXED; e.code_variant = 0; e.tile_base = ntiles;
     e.pre_pos = 0; e.pre_eob = 0; e.pre_flags = 0;
     const int last_block = (int)br.last_flush;
     // Mark_new_block :999-1007 (end-of-block code of the block being finished, then BFINAL), recorded for k_emit_prefix
@@ -450,7 +482,7 @@ __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRe
     if (fmt == FMT_FIXED) {
       if (S.last_type != BT_FIXED) {                                             // Send_fixed_block :1108-1121
         open_block(last_block, 1);
-        S.last_type = BT_FIXED; S.code_block = -1; S.code_variant = 0; S.cur_eob = 7u << 16;
+        S.last_type = BT_FIXED; S.code_block = CODE_FIXED; S.code_variant = 0; S.cur_eob = 7u << 16;
       }
       data_bits = cr.fixed_data;
     } else if (fmt == FMT_DYN1 || fmt == FMT_DYN2) {                             // Send_dynamic_block :1126-1135
@@ -523,17 +555,29 @@ __global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRe
       r3 = load_rec(i + 7);
     }
   }
-  // stream epilogue, Encode :1613-1635
-  if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
-    const int l = (int)(S.cur_eob >> 16);
-    if (lane == 0) put_bits_lim(out32, lim_bits, S.pos, S.cur_eob & 0xFFFF, l);
-    S.pos += (uint64_t)l;
-  }
-  if (!S.last_marked) {
-    if (lane == 0) { put_bits_lim(out32, lim_bits, S.pos, 1, 1); put_bits_lim(out32, lim_bits, S.pos + 1, 1, 2); }
-    S.pos += 3 + 7;                                                              // fake final fixed block: EOB = 0000000
+  // stream epilogue, Encode :1613-1635 (by the range that owns the stream's last flush)
+  if (do_epilogue) {
+    if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
+      const int l = (int)(S.cur_eob >> 16);
+      if (lane == 0) put_bits_lim(out32, lim_bits, S.pos, S.cur_eob & 0xFFFF, l);
+      S.pos += (uint64_t)l;
+    }
+    if (!S.last_marked) {
+      if (lane == 0) { put_bits_lim(out32, lim_bits, S.pos, 1, 1); put_bits_lim(out32, lim_bits, S.pos + 1, 1, 2); }
+      S.pos += 3 + 7;                                                            // fake final fixed block: EOB = 0000000
+    }
   }
   if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = npieces; res->n_blocks = nblocks; res->overflow = overflow; }
+  // the state for the range that follows
+  {
+    const uint8_t *cl = nullptr;
+    if (S.last_type == BT_DYNAMIC) cl = S.code_block == CODE_CARRIED ? cin->bl : (S.code_variant == 1 ? binfo[S.code_block].bl1 : binfo[S.code_block].bl2);
+    for (int r = 0; r < 5; r++) cout->bl[lane + 64 * r] = cl ? cl[lane + 64 * r] : (uint8_t)0;
+    if (lane == 0) {
+      cout->pos = S.pos + base_bits; cout->last_type = S.last_type; cout->block_to_finish = S.block_to_finish; cout->last_marked = S.last_marked;
+      cout->cur_eob = S.cur_eob; cout->pad[0] = cout->pad[1] = 0;
+    }
+  }
 }
 
 // What k_choose_lean left out, one thread per block: the bits in front of a block that opens a new Deflate block (end-of-
@@ -559,13 +603,15 @@ __global__ void __launch_bounds__(256) k_emit_prefix(uint32_t nblocks, const Emi
 // code tables: codes[b*320 + s] = (len << 16) | bit-reversed canonical code
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_block_codes(uint32_t nblocks, const EmitRec *__restrict__ emit, const BlockInfo *__restrict__ binfo,
-                                                    uint32_t *__restrict__ codes) {
+                                                    uint32_t *__restrict__ codes, const ChooserCarry *__restrict__ cin) {
   __shared__ uint8_t bl[320];
   __shared__ uint16_t cd[320];
   const uint32_t b = blockIdx.x;
   const int lane = threadIdx.x;
   if (b == nblocks) {                                                            // fixed table
     for (int i = lane; i < 320; i += 64) bl[i] = (uint8_t)(i < 288 ? fixed_litlen_bl(i) : 5);
+  } else if (b == nblocks + 1) {                                                 // the table in force when the range began
+    for (int i = lane; i < 320; i += 64) bl[i] = cin->bl[i];
   } else {
     const uint32_t f = emit[b].fmt;
     if (f != FMT_DYN1 && f != FMT_DYN2) return;
@@ -579,7 +625,9 @@ __global__ void __launch_bounds__(64) k_block_codes(uint32_t nblocks, const Emit
   for (int i = lane; i < 320; i += 64) codes[(uint64_t)b * 320 + i] = ((uint32_t)bl[i] << 16) | cd[i];
 }
 
-__device__ __forceinline__ uint32_t code_table_index(const EmitRec &e, uint32_t nblocks) { return e.code_block < 0 ? nblocks : (uint32_t)e.code_block; }
+__device__ __forceinline__ uint32_t code_table_index(const EmitRec &e, uint32_t nblocks) {
+  return e.code_block == CODE_FIXED ? nblocks : (e.code_block == CODE_CARRIED ? nblocks + 1 : (uint32_t)e.code_block);
+}
 
 // bits of one atom under a code table staged in LDS; value returned in v (LSB first)
 __device__ __forceinline__ int atom_bits(uint32_t t, const uint32_t *tab, uint64_t &v) {
@@ -726,80 +774,111 @@ __global__ void __launch_bounds__(256) k_copy_pieces(uint32_t npieces, const Sto
   for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < pc.nbytes; i += gridDim.y * 256) out[pc.dst_byte + i] = in[(uint64_t)pc.src_byte + i];
 }
 
-__global__ void k_single_block(uint32_t T, BlockRange *blocks) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { blocks[0].first = 0; blocks[0].count = T; blocks[0].last_flush = 1; blocks[0].pad = 0; }
-}
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 
 // --------------------------------------------------------------------------------------------
-// host side
+// host side: the entropy stage of the range in flight (c->rg), in three steps so that ranges on different GPUs can
+// exchange what they need in between (zada_range_*):
+//   entropy_analyze   everything that does not depend on the blocks before the range: descriptors, cuts, block analysis
+//   entropy_choose    the sequential walk, from the state the range before left behind (carry_in) to carry_out
+//   entropy_emit      code tables, bit emission, stored bytes
 // --------------------------------------------------------------------------------------------
-void exclusive_scan_u32(hipStream_t st, const uint32_t *d_in, uint32_t *d_out, uint32_t *d_sums, uint32_t *d_total, uint32_t n);
+static EntropyView range_view(Ctx *c) {
+  const Range &R = c->rg;
+  Workspace &W = c->ws;
+  EntropyView v;
+  v.atoms = W.ea_atoms + (LB_CAP - R.n_lb); v.apos = W.ea_apos + (LB_CAP - R.n_lb);
+  v.foff = R.foff; v.nflush = R.nflush; v.lvalid = (uint32_t)(R.n_lb + R.T + R.n_la);
+  v.stream_final = (R.G + R.T + R.n_la == R.T_total) ? 1u : 0u;
+  v.j0 = R.j0;
+  return v;
+}
 
-int huff_stage(Ctx *c, int method, uint64_t n, uint32_t T, uint64_t *total_bits) {
+int entropy_analyze(Ctx *c) {
   hipStream_t st = c->stream;
   Workspace &W = c->ws;
-  const bool fixed_only = (method == 6);
+  Range &R = c->rg;
+  const bool fixed_only = (R.method == 6);
+  const EntropyView v = range_view(c);
   uint32_t nblocks = 0;
-  hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, W.apos + T, (uint32_t)n);       // sentinel
-  if (T > 0) {
+  hipLaunchKernelGGL(k_apos_sentinel, dim3(1), dim3(1), 0, st, v.atoms, (uint32_t *)v.apos, v.lvalid);
+  if (v.nflush > 0) {
     if (fixed_only) {
-      // one pseudo-block per 65536 atoms only to spread the cost analysis; emitted as ONE fixed block
-      const uint32_t nseg = (T + FLUSH - 1) / FLUSH;
-      hipMemsetAsync(W.seg_nblk, 0, 4, st);
-      // segments as blocks
-      std::vector<BlockRange> hb(nseg);
-      for (uint32_t j = 0; j < nseg; j++) { hb[j].first = j * FLUSH; hb[j].count = (j + 1 == nseg) ? T - j * FLUSH : FLUSH; hb[j].last_flush = 0; hb[j].pad = 0; }
-      hipMemcpyAsync(W.blocks, hb.data(), nseg * sizeof(BlockRange), hipMemcpyHostToDevice, st);
-      hipStreamSynchronize(st);
-      nblocks = nseg;
+      nblocks = v.nflush;
+      hipLaunchKernelGGL(k_fill_blocks_fixed, dim3((nblocks + 255) / 256), dim3(256), 0, st, v.foff, (uint32_t)R.T, nblocks, W.blocks);
     } else {
-      const uint32_t nseg = (T + FLUSH - 1) / FLUSH;
-      const uint32_t kstep = method == 8 ? 8 : method == 9 ? 4 : 1;                        // max_choice :1310-1311
-      hipLaunchKernelGGL(k_window_descr, dim3(nseg * SLOTS), dim3(64), 0, st, W.atoms, T, kstep, W.descr);
+      const uint32_t kstep = R.method == 8 ? 8 : R.method == 9 ? 4 : 1;                        // max_choice :1310-1311
+      hipLaunchKernelGGL(k_window_descr, dim3(v.nflush * SLOTS), dim3(64), 0, st, v, kstep, W.descr);
       c->tmark("window_descr");
-      hipLaunchKernelGGL(k_cut_scan, dim3(nseg), dim3(64), 0, st, T, kstep, W.descr, W.seg_nblk, W.seg_cut);
-      exclusive_scan_u32(st, W.seg_nblk, W.seg_blk_off, W.scan_sums, W.n_changed, nseg);
-      hipMemcpyAsync(&nblocks, W.n_changed, 4, hipMemcpyDeviceToHost, st);
-      hipLaunchKernelGGL(k_fill_blocks, dim3((nseg + 255) / 256), dim3(256), 0, st, T, nseg, W.seg_nblk, W.seg_cut, W.seg_blk_off, W.blocks);
+      hipLaunchKernelGGL(k_cut_scan, dim3(v.nflush), dim3(64), 0, st, v, kstep, W.descr, W.seg_nblk, W.seg_cut);
+      exclusive_scan_u32(st, W.seg_nblk, W.seg_blk_off, W.scan2, W.total2, v.nflush);
+      hipMemcpyAsync(&nblocks, W.total2, 4, hipMemcpyDeviceToHost, st);
+      hipLaunchKernelGGL(k_fill_blocks, dim3((v.nflush + 255) / 256), dim3(256), 0, st, v, W.seg_nblk, W.seg_cut, W.seg_blk_off, W.blocks);
       if (hip_check(c, hipStreamSynchronize(st), "cut_scan")) return ZADA_E_HIP_;
       c->tmark("cut_scan");
     }
     if (nblocks > W.cap_blocks) { c->err = "block table overflow"; return -1; }
-    hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, W.atoms, W.apos, W.blocks, W.binfo);
+    hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, v.atoms, v.apos, W.blocks, W.binfo);
     c->tmark("block_analyze");
+    if (!fixed_only) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (ChRec *)W.chrec);
   }
-  if (nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (ChRec *)W.chrec);
+  R.nblocks = nblocks;
+  R.analyzed = true;
+  return hip_check(c, hipGetLastError(), "entropy_analyze");
+}
+
+int entropy_choose(Ctx *c) {
+  hipStream_t st = c->stream;
+  Workspace &W = c->ws;
+  Range &R = c->rg;
+  const bool fixed_only = (R.method == 6);
+  const EntropyView v = range_view(c);
+  R.base_bits = R.carry_in.pos & ~7ull;
+  hipMemcpyAsync(W.carry, &R.carry_in, sizeof(ChooserCarry), hipMemcpyHostToDevice, st);
+  // the chooser itself writes the few bits of stored-block headers and of the epilogue: the output must be zero before
+  const uint64_t lim_bits = W.cap_out * 8;
   if (fixed_only)
-    hipLaunchKernelGGL(k_choose_fixed, dim3(1), dim3(64), 0, st, nblocks, W.blocks, W.binfo, W.emit, W.tile_block, (uint32_t)W.cap_tiles, (uint32_t *)W.out, W.chooser);
-  else
-    hipLaunchKernelGGL(k_choose_lean, dim3(1), dim3(64), 0, st, nblocks, (const ChRec *)W.chrec, W.binfo, W.apos, W.emit, W.pieces,
-                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, W.cap_out * 8, W.chooser);
-  ChooserOut co;
-  hipMemcpyAsync(&co, W.chooser, sizeof co, hipMemcpyDeviceToHost, st);
+    hipLaunchKernelGGL(k_choose_fixed, dim3(1), dim3(64), 0, st, R.nblocks, W.blocks, W.binfo, W.emit, W.tile_block, (uint32_t)W.cap_tiles,
+                       (uint32_t *)W.out, lim_bits, W.chooser, W.carry, W.carry + 1, R.base_bits, R.G == 0 ? 1 : 0, v.stream_final ? 1 : 0);
+  else {
+    const int do_epilogue = v.stream_final && (v.nflush > 0 || R.T_total == 0);
+    hipLaunchKernelGGL(k_choose_lean, dim3(1), dim3(64), 0, st, R.nblocks, (const ChRec *)W.chrec, W.binfo, v.apos, W.emit, W.pieces,
+                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, lim_bits, W.chooser, W.carry, W.carry + 1, R.base_bits, do_epilogue);
+  }
+  hipMemcpyAsync(&R.co, W.chooser, sizeof(ChooserOut), hipMemcpyDeviceToHost, st);
+  hipMemcpyAsync(&R.carry_out, W.carry + 1, sizeof(ChooserCarry), hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "choose")) return ZADA_E_HIP_;
   c->tmark("choose");
-  *total_bits = co.total_bits;
-  if (co.overflow) { c->err = "emission table overflow"; return -1; }
-  // Compression_inefficient (zip-compress.adb:479-486): the stream is not smaller than the input.  The reference stops
-  // writing at the first 1 MiB flush that says so; nothing is emitted here (the workspace holds n + n/1024 + 4096 bytes,
-  // so a stream that does not fit it is always in this case).
-  const bool inefficient = (co.total_bits + 7) / 8 >= n;
-  if (!inefficient && !fixed_only && nblocks > 0)
+  if (R.co.overflow) { c->err = "emission table overflow"; return -1; }
+  R.chosen = true;
+  c->last_nblocks = R.nblocks;                        // block trace: zada_last_blocks reads emit / blocks from the workspace
+  return 0;
+}
+
+// Emits the range's bits into W.out (zeroed before entropy_choose; the chooser has already written the stored-block
+// headers there) and copies them to d_out if given.  Bit 0 of W.out is stream bit base_bits.
+int entropy_emit(Ctx *c, uint8_t *d_out) {
+  hipStream_t st = c->stream;
+  Workspace &W = c->ws;
+  Range &R = c->rg;
+  const bool fixed_only = (R.method == 6);
+  const uint32_t nblocks = R.nblocks;
+  const ChooserOut &co = R.co;
+  if ((co.total_bits + 7) / 8 + 8 > W.cap_out) { c->err = "output workspace overflow"; return -1; }
+  if (!fixed_only && nblocks > 0)
     hipLaunchKernelGGL(k_emit_prefix, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.emit, W.blocks, W.tile_block, (uint32_t *)W.out);
-  if (!inefficient) {
-    hipLaunchKernelGGL(k_block_codes, dim3(nblocks + 1), dim3(64), 0, st, nblocks, W.emit, W.binfo, W.codes);
-    if (co.n_tiles > 0) {
-      hipLaunchKernelGGL(k_tile_bits, dim3(co.n_tiles), dim3(256), 0, st, nblocks, W.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bits);
-      hipLaunchKernelGGL(k_tile_scan, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.blocks, W.emit, W.tile_bits, W.tile_bitpos);
-      hipLaunchKernelGGL(k_emit_tiles, dim3(co.n_tiles), dim3(256), 0, st, nblocks, W.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bitpos, (uint32_t *)W.out);
-    }
-    if (nblocks > 0 && !fixed_only) hipLaunchKernelGGL(k_emit_headers, dim3(nblocks), dim3(64), 0, st, nblocks, W.emit, W.binfo, (uint32_t *)W.out);
-    if (co.n_pieces > 0) hipLaunchKernelGGL(k_copy_pieces, dim3(co.n_pieces, 16), dim3(256), 0, st, co.n_pieces, W.pieces, W.in, W.out);
+  hipLaunchKernelGGL(k_block_codes, dim3(nblocks + 2), dim3(64), 0, st, nblocks, W.emit, W.binfo, W.codes, W.carry);
+  const EntropyView v = range_view(c);
+  if (co.n_tiles > 0) {
+    hipLaunchKernelGGL(k_tile_bits, dim3(co.n_tiles), dim3(256), 0, st, nblocks, v.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bits);
+    hipLaunchKernelGGL(k_tile_scan, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.blocks, W.emit, W.tile_bits, W.tile_bitpos);
+    hipLaunchKernelGGL(k_emit_tiles, dim3(co.n_tiles), dim3(256), 0, st, nblocks, v.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bitpos, (uint32_t *)W.out);
   }
+  if (nblocks > 0 && !fixed_only) hipLaunchKernelGGL(k_emit_headers, dim3(nblocks), dim3(64), 0, st, nblocks, W.emit, W.binfo, (uint32_t *)W.out);
+  if (co.n_pieces > 0) hipLaunchKernelGGL(k_copy_pieces, dim3(co.n_pieces, 16), dim3(256), 0, st, co.n_pieces, W.pieces, R.rin, W.out);
+  if (d_out) hipMemcpyAsync(d_out, W.out, (co.total_bits + 7) / 8, hipMemcpyDeviceToDevice, st);
   c->tmark("emit");
-  c->last_nblocks = nblocks;                        // block trace: zada_last_blocks reads emit / blocks from the workspace
-  return hip_check(c, hipGetLastError(), "huff_stage");
+  return hip_check(c, hipGetLastError(), "entropy_emit");
 }
 
 }  // namespace zada

@@ -41,6 +41,7 @@ constexpr uint32_t TILE = 2048;                   // atoms per emission tile
 enum { FMT_STORED = 0, FMT_FIXED = 1, FMT_DYN1 = 2, FMT_DYN2 = 3, FMT_RECYCLE = 4 };
 enum { BT_STORED = 0, BT_FIXED = 1, BT_DYNAMIC = 2, BT_RESERVED = 3 };
 
+// A candidate block: atoms [first, first + count) of the range's LOCAL atom array (see EntropyView).
 struct BlockRange { uint32_t first, count; uint32_t last_flush; uint32_t pad; };
 
 // Everything the chooser and the emitters need to know about one candidate block.
@@ -54,13 +55,15 @@ struct BlockInfo {
   uint32_t stored_possible;
 };
 
-// Decision record written by the sequential chooser.
+// Decision record written by the sequential chooser.  Bit positions are relative to the range's output base
+// (Range::base_bits, a multiple of 8).
 struct EmitRec {
   uint64_t hdr_bitpos;          // dynamic header position (after the 3 block-header bits)
   uint64_t data_bitpos;         // first bit of the LZ data
   uint64_t cost_bits;           // optimal_format_bits (:1234), for the trace
   uint32_t fmt;                 // FMT_*
-  int32_t code_block;           // block whose code table is in force (-1 = fixed table)
+  int32_t code_block;           // block whose code table is in force (CODE_FIXED = fixed table, CODE_CARRIED = the table
+                                // that was in force when the range began)
   uint32_t code_variant;        // 1 or 2 (bl1 / bl2 of code_block)
   uint32_t tile_base;           // first emission tile of this block
   // what precedes the block in the stream when it opens a new Deflate block (written by k_emit_prefix, not by the
@@ -69,23 +72,52 @@ struct EmitRec {
   uint32_t pre_eob;             // (len << 16) | code of the end-of-block symbol to write first, 0 = none
   uint32_t pre_flags;           // bit 0: the prefix exists; bit 1: BFINAL; bits 2-3: BTYPE
 };
+constexpr int32_t CODE_FIXED = -1, CODE_CARRIED = -2;
 
-struct StoredPiece { uint64_t dst_byte; uint32_t src_byte, nbytes; };
+struct StoredPiece { uint64_t dst_byte; uint32_t src_byte, nbytes; };   // src_byte: offset in the range's input (Range::rin)
+
+// The cross-block state of the reference's encoder (zip-compress-deflate.adb:722, 993-997) at a range boundary: what
+// Send_as_block needs to know about the blocks before -- last_block_type, block_to_finish, last_block_marked,
+// curr_descr (its code lengths; the codes follow from them) -- and the bit position in the stream.
+struct ChooserCarry {
+  uint64_t pos;                 // bits written so far (global, from the start of the stream)
+  int32_t last_type, block_to_finish, last_marked;
+  uint32_t cur_eob;             // (length << 16) | code of symbol 256 under curr_descr
+  uint8_t bl[320];              // code lengths of curr_descr (meaningful when last_type is BT_DYNAMIC)
+  uint32_t pad[2];
+};
+static_assert(sizeof(ChooserCarry) == 352, "ChooserCarry is exchanged between ranks as bytes");
 
 struct ChooserOut {
-  uint64_t total_bits;
+  uint64_t total_bits;          // position after the range's last bit, relative to the range's output base
   uint32_t n_tiles, n_pieces, n_blocks, overflow;
 };
 
+// How the entropy kernels see the atoms of a range: one LOCAL array = [look-behind atoms of the previous range]
+// [the range's own atoms][look-ahead atoms of the next ranges, up to the end of the last flush the range owns].
+// The reference flushes its LZ buffer every 65 536 atoms counted from the start of the STREAM
+// (zip-compress-deflate.adb:1424-1432); a range owns the flushes whose first atom is one of its own.
+struct EntropyView {
+  const uint32_t *atoms, *apos; // local arrays
+  uint32_t foff;                // local index of the first atom of the first owned flush
+  uint32_t nflush;              // owned flushes
+  uint32_t lvalid;              // atoms in the local array
+  uint32_t stream_final;        // the array ends where the stream ends
+  uint64_t j0;                  // number of the first owned flush in the stream (parity and "first flush" matter)
+};
+
+// Look-behind / look-ahead capacity of the local atom array
+constexpr uint32_t LB_CAP = HALF_SLIDER, LA_CAP = FLUSH;
+
 struct Workspace {
-  uint64_t cap_n = 0;           // input capacity in bytes
+  // ---- LZ stage: sized for one shard (cap_n bytes of input buffer) ----
+  uint64_t cap_n = 0;           // shard buffer capacity in bytes
   uint8_t *in = nullptr;
   uint16_t *lprev[NLEVELS] = {}, *ltails[NLEVELS] = {};   // per level: chain links (16-bit distances) / per-segment bucket tails
   uint16_t *S3 = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
   uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr;  // DistPlanes
   uint16_t *SK = nullptr, *idxK = nullptr, *cntK = nullptr;   // RunPtrs
-  MatchPair *M = nullptr;                    // match tables; alias: atoms / apos (two halves of the same buffer)
-  uint32_t *atoms = nullptr, *apos = nullptr;
+  MatchPair *M = nullptr;                    // match tables
   uint32_t *spec_tok = nullptr, *fix_tok = nullptr;
   uint32_t *spec_cnt = nullptr, *fix_cnt = nullptr, *take_from = nullptr, *start_pos = nullptr;
   uint32_t *counts = nullptr, *offsets = nullptr, *scan_sums = nullptr;
@@ -96,25 +128,58 @@ struct Workspace {
   uint32_t *blk_demand = nullptr, *n_demand = nullptr;   // demanded match records per k_match block / in total
   uint32_t *dbits = nullptr;                             // one bit per position: marked for the next demand pass
   uint8_t *chg = nullptr;                                // per parse chunk: a guess it used turned out different
-  // entropy stage
-  uint8_t *descr = nullptr;                  // [nseg][SLOTS][320]
-  uint32_t *seg_nblk = nullptr, *seg_cut = nullptr, *seg_blk_off = nullptr;   // cuts [nseg][MAXBLK_PER_SEG]
+  uint32_t *crc_lvl[4] = {nullptr, nullptr, nullptr, nullptr}, *crc_mat = nullptr;
+  bool crc_mat_ready = false;
+  uint64_t *dbg = nullptr;
+  std::vector<void *> allocs;   // of the LZ group
+  // ---- entropy stage: sized for the atoms of one range (cap_atoms) ----
+  uint64_t cap_atoms = 0;
+  uint32_t *ea_atoms = nullptr, *ea_apos = nullptr;   // local atom array: LB_CAP slots, the range's atoms, LA_CAP slots (+ sentinel)
+  uint8_t *descr = nullptr;                  // [nflush][SLOTS][320]
+  uint32_t *seg_nblk = nullptr, *seg_cut = nullptr, *seg_blk_off = nullptr;   // cuts [nflush][MAXBLK_PER_SEG]
   BlockRange *blocks = nullptr;
   BlockInfo *binfo = nullptr;
   EmitRec *emit = nullptr;
   uint64_t *chrec = nullptr;                 // ChRec[nblocks] (128 B each)
-  uint32_t *codes = nullptr;                 // [nblocks+1][320]  (len << 16 | code); last = fixed table
+  uint32_t *codes = nullptr;                 // [nblocks+2][320]  (len << 16 | code); the last two = fixed table, carried table
   StoredPiece *pieces = nullptr;
   uint32_t *tile_block = nullptr;            // tile -> block
   uint64_t *tile_bitpos = nullptr;
   uint32_t *tile_bits = nullptr;
   ChooserOut *chooser = nullptr;
-  uint32_t *crc_lvl[4] = {nullptr, nullptr, nullptr, nullptr}, *crc_mat = nullptr;
-  bool crc_mat_ready = false;
-  uint64_t *dbg = nullptr;
-  uint8_t *out = nullptr;
-  uint64_t cap_blocks = 0, cap_tiles = 0, cap_pieces = 0, cap_out = 0;
-  std::vector<void *> allocs;
+  ChooserCarry *carry = nullptr;             // [2]: in, out
+  uint32_t *scan2 = nullptr, *total2 = nullptr;   // scan scratch of the entropy stage
+  uint64_t cap_blocks = 0, cap_tiles = 0, cap_pieces = 0;
+  std::vector<void *> en_allocs;
+  // ---- buffers of the host-buffer entry points ----
+  uint8_t *rin_own = nullptr; uint64_t cap_rin = 0;   // the range's input, copied from the host
+  uint8_t *out = nullptr; uint64_t cap_out = 0;       // the range's output
+};
+
+// One range of a stream in flight on this context (zada_range_* / deflate_core): bytes [lo, lo + n) of the stream, with
+// `pre` bytes before and `post` bytes after it also resident at rin (halo for the match finder, and the bytes of the
+// look-ahead atoms).
+struct GlobalState { uint64_t pos; uint32_t kind, pad; };      // parser state at a history-free point: stream position, SYNC_F / SYNC_L
+struct Range {
+  bool open = false;
+  const uint8_t *rin = nullptr;      // device: stream byte lo - pre
+  uint64_t lo = 0, pre = 0, n = 0, post = 0;
+  bool first = true, last = true;
+  int method = 0, level = 0;
+  uint64_t T = 0;                    // the range's own atoms
+  uint32_t n_lb = 0, n_la = 0;       // look-behind / look-ahead atoms in the local array
+  GlobalState exit{}, warm{};        // exit: first history-free state at or beyond the end of the range; warm: the one at or
+                                     // beyond its start, found by the warm-up parse when the entry was not known
+  bool entry_known = true;
+  uint64_t G = 0, T_total = 0;       // atoms of the stream before the range / in all
+  bool placed = false;               // G / T_total / neighbours' atoms are known
+  uint32_t nflush = 0, foff = 0, nblocks = 0;
+  uint64_t j0 = 0;
+  uint64_t base_bits = 0;            // output base: carry_in.pos rounded down to a byte
+  ChooserCarry carry_in{}, carry_out{};
+  ChooserOut co{};
+  bool analyzed = false, chosen = false;
+  uint32_t crc_raw = 0;              // CRC register of the range's bytes started from 0 (the linear part)
 };
 
 // host side of a CRC-32 in flight (crc_launch / crc_finish)
@@ -131,8 +196,10 @@ struct Ctx {
   uint8_t *stage[2] = {nullptr, nullptr};            // pinned staging buffers of the host-buffer entry points (copy_in / copy_out)
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   Workspace ws;
+  Range rg;                                          // the range in flight
   std::string err;
   int parse_rounds = 0, demand_rounds = 0;
+  bool lz_attrs_set = false;
   // timing
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<const char *, hipEvent_t>> marks;
@@ -145,16 +212,36 @@ struct Ctx {
   int knob_budget = -1;             // ZADA_BUDGET: rounds of chain steps per position in the first match pass (0 = unbounded, -1 = default)
   int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
   int knob_batch_streams = 4;       // ZADA_BATCH_STREAMS
+  int knob_shard_kib = 1 << 20;     // ZADA_SHARD_KIB: bytes of a range the LZ stage takes at a time, in KiB (multiple of 64)
   void tmark(const char *name);
   void tbegin();
   void tend();
 };
 
 int hip_check(Ctx *c, hipError_t e, const char *what);
-int ensure_workspace(Ctx *c, uint64_t n);
-int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out);
-int huff_stage(Ctx *c, int method, uint64_t n, uint32_t T, uint64_t *total_bits);
-int crc_launch(Ctx *c, uint64_t n);
+int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
+int ensure_entropy_workspace(Ctx *c, uint64_t atoms);
+
+// One shard of a range through the LZ stage.  W.in holds `nbuf` bytes (zero pad behind): a 32 KiB halo in front of the
+// shard unless it starts the stream, the shard, and a tail behind it unless it ends the stream.  The tokens of the parse
+// chunks [tok_lo / PCHUNK, tok_hi / PCHUNK) are the shard's atoms (all chunks from tok_lo on when `final`).
+struct ShardJob {
+  uint64_t nbuf = 0;
+  uint32_t tok_lo = 0, tok_hi = 0;
+  bool final = false;                 // the buffer ends where the stream ends
+  bool entry_known = true;            // else: warm-up parse from the start of the buffer
+  ExitState entry{0, SYNC_F};         // buffer coordinates
+  uint32_t *dst_atoms = nullptr, *dst_apos = nullptr;
+  uint32_t apos_bias = 0;             // added to buffer positions: offset of the buffer in the range's input
+  uint64_t cap_atoms = 0;             // room at dst
+};
+struct ShardResult { uint32_t ntok = 0; ExitState exit{0, SYNC_F}, warm{0, SYNC_F}; };
+int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res);
+
+int entropy_analyze(Ctx *c);
+int entropy_choose(Ctx *c);
+int entropy_emit(Ctx *c, uint8_t *d_out);
+int crc_launch(Ctx *c, const uint8_t *d_in, uint64_t n);
 int crc_finish(Ctx *c, uint64_t n, uint32_t *crc_inout);
 void exclusive_scan_u32(hipStream_t st, const uint32_t *d_in, uint32_t *d_out, uint32_t *d_sums, uint32_t *d_total, uint32_t n);
 

@@ -1297,11 +1297,11 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
                             uint32_t *__restrict__ fix_tok, uint32_t *__restrict__ fix_cnt,
                             uint32_t *__restrict__ take_from, uint32_t *__restrict__ start_pos,
                             const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
-                            uint32_t *__restrict__ n_changed, DemandMarker dm) {
+                            uint32_t *__restrict__ n_changed, DemandMarker dm, ExitState entry0) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nchunks) return;
   if (!dirty_in[k]) return;
-  ExitState entry; entry.pos = 0; entry.kind = SYNC_F;
+  ExitState entry = entry0;                          // the state the parse of this buffer starts from
   if (k > 0) entry = true_exits[k - 1];
   const ExitState old_exit = true_exits[k];
   ExitState new_exit;
@@ -1360,6 +1360,13 @@ __global__ void __launch_bounds__(64) k_fix_forward(ParseIO io, uint32_t nchunks
   }
 }
 
+// A parse that enters the buffer at `e` (the exit of the shard before): the chunks in front of e.pos emit nothing and
+// hand the state on unchanged.
+__global__ void k_seed_entry(ExitState *__restrict__ true_exits, uint32_t kE, ExitState e) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < kE) true_exits[k] = e;
+}
+
 // per-chunk true token count
 __global__ void k_tok_count(uint32_t nchunks, const uint32_t *__restrict__ spec_cnt, const uint32_t *__restrict__ fix_cnt,
                             const uint32_t *__restrict__ take_from, uint32_t *__restrict__ counts) {
@@ -1372,15 +1379,17 @@ __global__ void __launch_bounds__(256) k_tok_compact(uint32_t nchunks, const uin
                                                      const uint32_t *__restrict__ spec_cnt, const uint32_t *__restrict__ fix_tok,
                                                      const uint32_t *__restrict__ fix_cnt, const uint32_t *__restrict__ take_from,
                                                      const uint32_t *__restrict__ start_pos, const uint32_t *__restrict__ offsets,
-                                                     uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos) {
-  const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                     uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos, uint32_t k0, uint32_t apos_bias) {
+  // chunks [k0, k0 + nchunks); offsets[] is the exclusive scan over exactly these chunks
+  const uint32_t kk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (k >= nchunks) return;
+  if (kk >= nchunks) return;
+  const uint32_t k = k0 + kk;
   const uint32_t nf = fix_cnt[k], tf = take_from[k], ns = spec_cnt[k] - tf;
   const uint32_t *ft = fix_tok + (uint64_t)k * PTOK_STRIDE;
   const uint32_t *st = spec_tok + (uint64_t)k * PTOK_STRIDE + tf;
-  uint32_t out = offsets[k];
-  uint32_t pos = start_pos[k];
+  uint32_t out = offsets[kk];
+  uint32_t pos = start_pos[k] + apos_bias;
   const uint32_t total = nf + ns;
   for (uint32_t b = 0; b < total; b += 64) {
     uint32_t i = b + lane;
@@ -1436,9 +1445,9 @@ __global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restric
 }
 
 // No-LZ77 front end (LZ77.No_LZ77, lz77.adb:2191-2194): every byte is a literal atom.
-__global__ void k_literal_atoms(const uint8_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos) {
+__global__ void k_literal_atoms(const uint8_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos, uint32_t bias) {
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { atoms[i] = in[i]; apos[i] = (uint32_t)i; }
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { atoms[i] = in[i]; apos[i] = (uint32_t)i + bias; }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1451,26 +1460,31 @@ void exclusive_scan_u32(hipStream_t st, const uint32_t *d_in, uint32_t *d_out, u
   hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, st, d_out, d_sums, n);
 }
 
-int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
+int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   hipStream_t st = c->stream;
   Workspace &W = c->ws;
-  if (n == 0) { *ntok_out = 0; return 0; }
+  const uint64_t n = job.nbuf;
+  res->ntok = 0; res->exit = ExitState{(uint32_t)n, SYNC_F}; res->warm = ExitState{job.tok_lo, SYNC_F};
+  if (n == 0) return 0;
   if (level == 0) {
-    hipLaunchKernelGGL(k_literal_atoms, dim3(2048), dim3(256), 0, st, W.in, n, W.atoms, W.apos);
-    *ntok_out = (uint32_t)n;
+    const uint64_t hi = job.final ? n : job.tok_hi, cnt = hi - job.tok_lo;
+    if (cnt > job.cap_atoms) { c->err = "atom array overflow"; return -2; }
+    if (cnt) hipLaunchKernelGGL(k_literal_atoms, dim3(2048), dim3(256), 0, st, W.in + job.tok_lo, cnt, job.dst_atoms, job.dst_apos, job.apos_bias + job.tok_lo);
+    res->ntok = (uint32_t)cnt;
+    res->exit = ExitState{(uint32_t)hi, SYNC_F};
     return hip_check(c, hipGetLastError(), "k_literal_atoms");
   }
   const LzConfig cfg = lz_config(level);
   const uint64_t n_ins = n >= 2 ? n - 2 : 0;
   const uint32_t nseg = (uint32_t)((n_ins + 32767) / 32768);
   c->tmark("lz:begin");
-  static std::once_flag attr_done;
-  std::call_once(attr_done, [] {
+  if (!c->lz_attrs_set) {                            // per context: the attribute belongs to the function object of the current device
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
     hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS);
     hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
-  });
+    c->lz_attrs_set = true;
+  }
   LevelPtrs lv;
   DistPlanes dpl;
   RunPtrs rpt; rpt.S = W.SK; rpt.idx = W.idxK; rpt.cnt = W.cntK;
@@ -1518,12 +1532,17 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
   DemandMarker dmf = dm; dmf.by = 0;
   int rounds = 0, demand_rounds = 0;
   bool valve_used = false;
+  // where the parse enters the buffer: at its first byte in the fresh state (the stream starts here, or a warm-up parse
+  // through the halo), or in the state the shard before ended in
+  const ExitState entry0 = job.entry_known ? job.entry : ExitState{0, SYNC_F};
+  const uint32_t kE = job.entry_known ? (entry0.pos / PCHUNK < nch ? entry0.pos / PCHUNK : nch) : 0u;
   for (bool first = true;; first = false) {
     // speculative parse: every chunk the first time, afterwards the chunks flagged by the demand pass
     hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
                        W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, first ? (const uint8_t *)nullptr : (const uint8_t *)W.chg);
     // fixpoint of the splice, from scratch: round 0 handles every chunk with the speculative exits as entries
     hipMemcpyAsync(W.true_exits, W.spec_exits, (size_t)nch * sizeof(ExitState), hipMemcpyDeviceToDevice, st);
+    if (kE > 0) hipLaunchKernelGGL(k_seed_entry, dim3((kE + 255) / 256), dim3(256), 0, st, W.true_exits, kE, entry0);
     hipMemsetAsync(W.dirty[0], 1, nch, st);
     int cur = 0, it = 0;
     bool slow = false;                                             // the splice is crawling: stop waiting for it
@@ -1533,7 +1552,7 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
       hipMemsetAsync(W.n_changed + 1, 0xFF, 4, st);
       hipLaunchKernelGGL(k_parse_fix, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
                          W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, W.true_exits, W.fix_tok, W.fix_cnt,
-                         W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed, dmf);
+                         W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed, dmf, entry0);
       hipLaunchKernelGGL(k_fix_forward, dim3(1), dim3(64), 0, st, io, nch, W.true_exits, W.dirty[cur ^ 1], W.n_changed);
       uint32_t changed = 0;
       hipMemcpyAsync(&changed, W.n_changed, 4, hipMemcpyDeviceToHost, st);
@@ -1560,20 +1579,26 @@ int lz_stage(Ctx *c, int level, uint64_t n, uint32_t *ntok_out) {
                        W.blk_demand, W.dbits, W.chg, W.spec_exits, W.lprev[0]);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   }
-  c->demand_rounds = demand_rounds;
-  c->parse_rounds = rounds;
+  c->demand_rounds += demand_rounds;
+  c->parse_rounds += rounds;
   c->tmark("parse");
+  // the shard's tokens: those of the chunks [k0, k1)
+  const uint32_t k0 = job.tok_lo / PCHUNK, k1 = job.final ? nch : job.tok_hi / PCHUNK, nk = k1 - k0;
+  if (nk == 0) { c->err = "empty shard"; return -1; }
   hipLaunchKernelGGL(k_tok_count, dim3((nch + 255) / 256), dim3(256), 0, st, nch, W.spec_cnt, W.fix_cnt, W.take_from, W.counts);
-  exclusive_scan_u32(st, W.counts, W.offsets, W.scan_sums, W.n_changed, nch);
-  uint32_t total = 0;
-  hipMemcpyAsync(&total, W.n_changed, 4, hipMemcpyDeviceToHost, st);
-  // the atom arrays alias the match tables, which are dead from here on: wait for the scan first
+  exclusive_scan_u32(st, W.counts + k0, W.offsets, W.scan_sums, W.n_changed, nk);
+  struct { uint32_t total; ExitState ex, warm; } h;
+  h.ex = ExitState{(uint32_t)n, SYNC_F}; h.warm = ExitState{0, SYNC_F};
+  hipMemcpyAsync(&h.total, W.n_changed, 4, hipMemcpyDeviceToHost, st);
+  if (!job.final) hipMemcpyAsync(&h.ex, W.true_exits + (k1 - 1), sizeof(ExitState), hipMemcpyDeviceToHost, st);
+  if (k0 > 0) hipMemcpyAsync(&h.warm, W.true_exits + (k0 - 1), sizeof(ExitState), hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "tok_scan")) return ZADA_E_HIP_;
-  hipLaunchKernelGGL(k_tok_compact, dim3((nch + 3) / 4), dim3(256), 0, st, nch, W.spec_tok, W.spec_cnt, W.fix_tok, W.fix_cnt,
-                     W.take_from, W.start_pos, W.offsets, W.atoms, W.apos);
+  if (h.total > job.cap_atoms) { c->err = "atom array overflow"; return -2; }
+  hipLaunchKernelGGL(k_tok_compact, dim3((nk + 3) / 4), dim3(256), 0, st, nk, W.spec_tok, W.spec_cnt, W.fix_tok, W.fix_cnt,
+                     W.take_from, W.start_pos, W.offsets, job.dst_atoms, job.dst_apos, k0, job.apos_bias);
   c->tmark("compact");
-  *ntok_out = total;
-  return hip_check(c, hipGetLastError(), "lz_stage");
+  res->ntok = h.total; res->exit = h.ex; res->warm = h.warm;
+  return hip_check(c, hipGetLastError(), "lz_shard");
 }
 
 }  // namespace zada

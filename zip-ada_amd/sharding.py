@@ -77,3 +77,209 @@ def gather_payloads_begin(payload, length, meta, dst=0, group=None):
 def gather_payloads(payload, length, meta, dst=0, group=None):
     """gather_payloads_begin(...).finish(): the blocking form."""
     return gather_payloads_begin(payload, length, meta, dst=dst, group=group).finish()
+
+
+# ======================================================================================================================
+# ONE stream over several GPUs (SURVEY.md 8e, primary mode): the stream is cut into ranges at multiples of 64 KiB, rank r
+# compresses range r with the zada_range_* calls of libzada_hip.so and the ranks exchange exactly the state the
+# reference's sequential encoder carries through the stream (include/zada.h "One stream over several contexts"):
+#
+#   a. parser state at the range boundaries   all_gather of (atoms, exit, warm) -- 40 bytes per rank.  A range whose
+#                                             warm-up parse did not meet its neighbour's exit state re-runs its LZ stage
+#                                             from that state (degenerate data only, e.g. one long run)
+#   b. atom counts -> position of every range on the stream's 65 536-atom flush grid (zip-compress-deflate.adb:1424-1432)
+#   c. boundary atoms                         all_gather of each range's first 65 536 and last 2 048 atoms (540 KB per
+#                                             rank): a range completes its last flush with its successors' atoms and
+#                                             reads 2 048 atoms back into its predecessors' (:1338-1360, 1372)
+#   d. Send_as_block's state                  352 bytes handed from rank to rank (send / recv), the one sequential step
+#   e. payloads                               gathered onto rank 0 (gather_payloads), OR-ed together at the shared bytes
+#
+# With torch.distributed's "nccl" backend these are RCCL collectives over xGMI; TorchComm runs the same code on "gloo"
+# (CPU tests), ThreadComm inside one process (several contexts on one GPU: tests/test_ranges.py).
+# ======================================================================================================================
+RANGE_ALIGN, RANGE_PRE, RANGE_POST, EDGE_HEAD, EDGE_TAIL, FLUSH, HALF_SLIDER = 65536, 32768, 1 << 20, 65536, 2048, 65536, 2048
+
+
+def stream_ranges(stream_size, world):
+    """Cuts [0, stream_size) into `world` ranges at multiples of 64 KiB, as even as possible; trailing ranges may be
+    empty for tiny streams (they are dropped: fewer ranks take part).  Returns [(lo, n), ...] of the non-empty ranges
+    (at least one, possibly (0, 0))."""
+    units = (stream_size + RANGE_ALIGN - 1) // RANGE_ALIGN
+    base, rem = divmod(units, world)
+    out, lo = [], 0
+    for r in range(world):
+        u = base + (1 if r < rem else 0)
+        n = min(u * RANGE_ALIGN, stream_size - lo)
+        if n > 0:
+            out.append((lo, n))
+        lo += n
+    return out or [(0, 0)]
+
+
+def range_window(stream_size, lo, n):
+    """Bytes of the stream a rank must hold for range [lo, lo + n): (first byte, pre, post)."""
+    pre = RANGE_PRE if lo > 0 else 0
+    post = min(RANGE_POST, stream_size - (lo + n))
+    return lo - pre, pre, post
+
+
+def needed_neighbour_atoms(before, own, total, fixed_only=False):
+    """How many atoms of its predecessors (look-behind) and successors (look-ahead) a range needs, given the atoms of
+    the stream before it, its own and the stream's total.  Mirrors range_place in csrc/zada_api.hip."""
+    if fixed_only:
+        return 0, 0
+    f0 = (before + FLUSH - 1) // FLUSH * FLUSH
+    nflush = (before + own - f0 + FLUSH - 1) // FLUSH if before + own > f0 else 0
+    if nflush == 0:
+        return 0, 0
+    last_end = min(f0 + nflush * FLUSH, total)
+    n_la = max(0, last_end - (before + own))
+    n_lb = HALF_SLIDER - (f0 - before) if (f0 > 0 and f0 - before < HALF_SLIDER) else 0
+    return n_lb, n_la
+
+
+class TorchComm:
+    """The exchanges of deflate_stream_rank over torch.distributed (RCCL on the GPU box, gloo in the CPU tests)."""
+
+    def __init__(self, device, group=None):
+        self.group, self.device = group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_gather_obj(self, obj):
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def bcast_obj(self, obj, src):
+        box = [obj]
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
+    def all_gather_dev(self, t):
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return out
+
+    def send_bytes(self, b, dst):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(self.device)
+        dist.send(t, dst=dst, group=self.group)
+
+    def recv_bytes(self, n, src):
+        t = torch.empty(n, dtype=torch.uint8, device=self.device)
+        dist.recv(t, src=src, group=self.group)
+        return bytes(t.cpu().numpy())
+
+    def gather_payload(self, payload, length, dst=0):
+        res = gather_payloads(payload, length, torch.zeros(1, dtype=torch.int64), dst=dst, group=self.group)
+        return None if res is None else res[0]
+
+
+def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, method, alloc_u32, alloc_out):
+    """Rank `comm.rank`'s part of compressing ONE stream cut into `ranges` (stream_ranges); ranks beyond len(ranges)
+    only take part in the collectives.
+
+    enc        Encoder (or a test double with the same range_* methods)
+    d_in_ptr   device address of stream byte lo - pre of this rank's window (range_window)
+    alloc_u32  n -> 1-D uint32 tensor of n elements on the encoder's device (exchange buffers)
+    alloc_out  n -> 1-D uint8 tensor (this rank's payload)
+    tensors    module with the tensor ops the protocol needs (torch)
+    Returns dict(bit_begin, bit_end, total_bits, payload (uint8 tensor holding stream bytes [bit_begin // 8,
+    ceil(bit_end / 8))), nbytes, crc_raw, n, infos, inefficient)."""
+    r, W = comm.rank, comm.world
+    nr = len(ranges)
+    active = r < nr
+    fixed_only = method == 6
+    info = None
+    if active:
+        lo, n = ranges[r]
+        _, pre, post = range_window(stream_size, lo, n)
+        enc.range_open(d_in_ptr, stream_size, lo, n, pre, post, method)
+        info = enc.range_lz(None)
+        info["n"] = n
+    # ---- a. parser states at the boundaries
+    infos = comm.all_gather_obj(info)
+    for k in range(1, nr):
+        if tuple(infos[k]["warm"]) != tuple(infos[k - 1]["exit"]):
+            # the warm-up parse of range k did not meet the true one: run it again from the true state (rare)
+            if r == k:
+                info = enc.range_lz(tuple(infos[k - 1]["exit"]))
+                info["n"] = ranges[k][1]
+            infos[k] = comm.bcast_obj(info if r == k else None, src=k)
+    # ---- b. the ranges on the flush grid
+    counts = [infos[k]["atoms"] for k in range(nr)]
+    total = sum(counts)
+    before = [sum(counts[:k]) for k in range(nr)]
+    # ---- c. boundary atoms
+    head_a, head_p, tail_a, tail_p = alloc_u32(EDGE_HEAD), alloc_u32(EDGE_HEAD), alloc_u32(EDGE_TAIL), alloc_u32(EDGE_TAIL)
+    if active and not fixed_only:
+        enc.range_edges(head_a.data_ptr(), head_p.data_ptr(), tail_a.data_ptr(), tail_p.data_ptr())
+    need = [needed_neighbour_atoms(before[k], counts[k], total, fixed_only) for k in range(nr)]
+    lb_a = lb_p = la_a = la_p = None
+    n_lb = n_la = 0
+    if not fixed_only and any(a or b for a, b in need):
+        heads_a, heads_p = comm.all_gather_dev(head_a), comm.all_gather_dev(head_p)
+        tails_a, tails_p = comm.all_gather_dev(tail_a), comm.all_gather_dev(tail_p)
+        if active:
+            n_lb, n_la = need[r]
+            if n_lb:                                  # the last n_lb (<= 2 048) atoms before this range: tails of r-1, r-2, ...
+                parts_a, parts_p, left, k = [], [], n_lb, r - 1
+                while left > 0:
+                    have = min(counts[k], EDGE_TAIL)  # tails[k] holds the last `have` atoms of range k
+                    take = min(left, have)
+                    parts_a.insert(0, tails_a[k][have - take:have]); parts_p.insert(0, tails_p[k][have - take:have])
+                    left -= take
+                    k -= 1
+                lb_a, lb_p = tensors.cat(parts_a).contiguous(), tensors.cat(parts_p).contiguous()
+            if n_la:                                  # the first n_la (< 65 536) atoms behind this range: heads of r+1, r+2, ...
+                parts_a, parts_p, left, k = [], [], n_la, r + 1
+                while left > 0:
+                    take = min(left, counts[k], EDGE_HEAD)
+                    parts_a.append(heads_a[k][:take]); parts_p.append(heads_p[k][:take])
+                    left -= take
+                    k += 1
+                la_a, la_p = tensors.cat(parts_a).contiguous(), tensors.cat(parts_p).contiguous()
+    if active:
+        if (n_lb or n_la) and hasattr(tensors, "cuda") and (lb_a if n_lb else la_a).is_cuda:
+            tensors.cuda.current_stream().synchronize()      # the slices were put together on torch's stream, the encoder reads them on its own
+        enc.range_place(before[r], total, lb_a.data_ptr() if n_lb else None, lb_p.data_ptr() if n_lb else None, n_lb,
+                        la_a.data_ptr() if n_la else None, la_p.data_ptr() if n_la else None, n_la)
+        enc.range_analyze()
+    # ---- d. the block decisions: the one sequential step, 352 bytes from rank to rank
+    bit_begin = bit_end = 0
+    if active:
+        carry = comm.recv_bytes(352, r - 1) if r > 0 else None
+        carry_out, bit_begin, bit_end = enc.range_choose(carry)
+        if r + 1 < nr:
+            comm.send_bytes(carry_out, r + 1)
+    spans = comm.all_gather_obj((bit_begin, bit_end) if active else None)
+    total_bits = spans[nr - 1][1]
+    inefficient = (total_bits + 7) // 8 >= stream_size            # Compression_inefficient, zip-compress.adb:479-486
+    # ---- e. this rank's bytes of the stream
+    payload, nbytes = None, 0
+    if active and not inefficient:
+        cap = (bit_end + 7) // 8 - bit_begin // 8 + 64
+        payload = alloc_out(cap)
+        nbytes = enc.range_emit(payload.data_ptr(), cap)
+    return dict(bit_begin=bit_begin, bit_end=bit_end, total_bits=total_bits, payload=payload, nbytes=nbytes, spans=spans,
+                infos=infos, inefficient=inefficient, crc_raw=info["crc_raw"] if active else 0)
+
+
+def stitch_stream(tensors, payloads, spans, total_bits, device):
+    """Rank 0: the ranges' bytes OR-ed into one stream (a byte shared by two ranges holds bits of both)."""
+    out = tensors.zeros((total_bits + 7) // 8, dtype=tensors.uint8, device=device)
+    for p, span in zip(payloads, spans):
+        if span is None or p is None:
+            continue
+        b0, b1 = span
+        off, ln = b0 // 8, (b1 + 7) // 8 - b0 // 8
+        if ln > 0:
+            out[off:off + ln] |= p[:ln].to(device)
+    return out
+
+
+def stream_crc(enc_or_lib_combine, infos, reg=0xFFFFFFFF):
+    """CRC-32 register after the whole stream from the ranges' raw registers (zada_crc32_combine)."""
+    for i in infos:
+        if i is not None:
+            reg = enc_or_lib_combine(reg, i["crc_raw"], i["n"])
+    return reg
