@@ -172,3 +172,22 @@ int zp_zlib_position_tokens(const uint8_t *in, uint64_t n, int good, int lazy, i
 int zp_stream_position_tokens(const uint8_t *z, uint64_t zn, const uint8_t *orig, uint64_t n, uint32_t *postok) {
   return tokens_of_stream(z, zn, postok, orig, n);
 }
+
+/* libz alone, tuned to (good, lazy, nice, chain): compressed size, or < 0.  The secondary CPU anchor of bench.py
+ * (deflateTune(34, 258, 258, 4096) = the reference's IZ_10 row, lz77.adb:546). */
+int64_t zp_zlib_tuned_size(const uint8_t *in, uint64_t n, int good, int lazy, int nice, int chain) {
+  z_stream s;
+  uint64_t cap = n + n / 8 + 1024;
+  uint8_t *z = (uint8_t *)malloc(cap);
+  if (!z) return -100;
+  memset(&s, 0, sizeof s);
+  if (deflateInit2(&s, 9, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { free(z); return -101; }
+  if (deflateTune(&s, good, lazy, nice, chain) != Z_OK) { deflateEnd(&s); free(z); return -102; }
+  s.next_in = (Bytef *)in; s.avail_in = (uInt)n;
+  s.next_out = z; s.avail_out = (uInt)cap;
+  if (deflate(&s, Z_FINISH) != Z_STREAM_END) { deflateEnd(&s); free(z); return -103; }
+  int64_t zn = (int64_t)s.total_out;
+  deflateEnd(&s);
+  free(z);
+  return zn;
+}

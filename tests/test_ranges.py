@@ -185,3 +185,24 @@ def test_ranges_with_shards_and_tiny_tail():
         rc, ref, crc = oracle_deflate(d, 10)
         rc2, out, crc2, _ = deflate_over_contexts(d, 4, 10)
         assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), n
+
+
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (torch.distributed: one process per rank, sharding.TorchComm, gather + stitch on rank 0) with
+    every rank on GPU 0 over gloo (BENCH_EMULATE=1): the stitched stream inflates to the input's CRC and the sample
+    equals the CPU port's stream."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_EMULATE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1", "--mib", "48",
+           "--cpu-sample-mib", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 3 and res["config"]["rc"] == 0
+    assert res["checks"] == {"stream_inflates_to_input_crc": True, "sample_stream_equals_cpu_port": True}, res["checks"]

@@ -162,6 +162,17 @@ class Encoder:
             self._err(rc, "zada_deflate")
         return out.raw[:ol.value], c.value
 
+    def deflate_into(self, data, out, method=Method.Deflate_3, crc=0xFFFFFFFF):
+        """Zip.Compress.Deflate into a caller-owned buffer (bytearray / numpy uint8 / ctypes, len(out) >= len(data) + 64):
+        no allocation on the way.  Returns (rc, out_len, running CRC register); rc 1 = inefficient."""
+        n = len(data)
+        ol = ctypes.c_uint64(0)
+        c = ctypes.c_uint32(crc)
+        rc = self.lib.zada_deflate(self.ctx, method, _addr(data) if n else None, n, _addr(out), len(out), ctypes.byref(ol), ctypes.byref(c), None, None)
+        if rc < 0 or rc == 2:
+            self._err(rc, "zada_deflate")
+        return rc, ol.value, c.value
+
     def deflate_batch(self, datas, method=Method.Deflate_3, crc=0xFFFFFFFF):
         """Independent streams (one per Zip entry) in one call: zada_deflate_batch compresses small ones several
         at a time.  Returns a list of (rc, raw deflate bytes or None, running CRC register); rc 1 = inefficient."""

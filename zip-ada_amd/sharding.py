@@ -156,6 +156,12 @@ class TorchComm:
         return box[0]
 
     def all_gather_dev(self, t):
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":     # CPU-only transport (tests, BENCH_EMULATE): stage through the host
+            torch.cuda.synchronize()
+            h = t.cpu()
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(out, h, group=self.group)
+            return [o.to(t.device) for o in out]
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t, group=self.group)
         return out
