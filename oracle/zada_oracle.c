@@ -901,6 +901,8 @@ static void Send_as_block(deflate_ctx *c, const lz_slice *lzb, int last_block, i
              dynamic_format_bits_2 = 0, recycled_format_bits = 0, optimal_format_bits, cc, m1, m2;
   int stored_format_possible, recycling_possible, choice;
 
+  /* test hook (not in the reference): the bit position in the stream at which this block's decision is taken */
+  if (c->trace) c->trace(c->tr_user, ZO_TR_BITPOS, g_first, (int64_t)((c->output_size + c->OutBufIdx - 1) * 8 + (uint64_t)c->valid_bits), 0, 0);
   Get_statistics(lzb, stats_lit_len, stats_dis);                                                /* :1213 */
   Build_descriptors_stats(stats_lit_len, stats_dis, &new_descr);
   memcpy(stats_lit_len_2, stats_lit_len, sizeof stats_lit_len);

@@ -56,7 +56,7 @@ enum { ZO_OK = 0, ZO_INEFFICIENT = 1, ZO_ABORTED = 2, ZO_EINVAL = -1, ZO_ENOMEM 
 typedef int (*zo_feedback_fn)(int percents_done, int entry_skipped, void *user);
 
 /* Trace events (the reference's compile-time trace, zip-compress-deflate.adb:83-90) */
-enum { ZO_TR_CUT = 1, ZO_TR_BLOCK = 2, ZO_TR_SIMILAR = 3 };
+enum { ZO_TR_CUT = 1, ZO_TR_BLOCK = 2, ZO_TR_SIMILAR = 3, ZO_TR_BITPOS = 4 /* test hook: stream bit position before a block */ };
 typedef void (*zo_trace_fn)(void *user, int kind, int64_t a, int64_t b, int64_t c, int64_t d);
 
 /* CRC-32, zip-crc_crypto.adb:49-76.  Init = 0xFFFFFFFF, Final = NOT. */

@@ -115,7 +115,7 @@ def oracle_tokens(data, method):
     return t[:k]
 
 
-def oracle_deflate(data, method, blocks=None, cuts=None, similar=None):
+def oracle_deflate(data, method, blocks=None, cuts=None, similar=None, bitpos=None):
     """Returns (rc, stream bytes, running crc).  rc 1 = Compression_inefficient.
     blocks / cuts / similar collect the oracle's trace events (the reference's compile-time trace,
     zip-compress-deflate.adb:83-90): (first atom, atoms, format, bits) / (atom, level) / (atom, distance, threshold, similar)."""
@@ -124,7 +124,7 @@ def oracle_deflate(data, method, blocks=None, cuts=None, similar=None):
     ol = ctypes.c_uint64(0)
     crc = ctypes.c_uint32(0xFFFFFFFF)
     cb = None
-    if blocks is not None or cuts is not None or similar is not None:
+    if blocks is not None or cuts is not None or similar is not None or bitpos is not None:
         def tr(_u, kind, a, b, c, d):
             if kind == 2 and blocks is not None:
                 blocks.append((a, b, c, d))
@@ -132,6 +132,8 @@ def oracle_deflate(data, method, blocks=None, cuts=None, similar=None):
                 cuts.append((a, b))
             elif kind == 3 and similar is not None:
                 similar.append((a, b, c, d))
+            elif kind == 4 and bitpos is not None:
+                bitpos.append((a, b))
         cb = TRACE(tr)
     rc = oracle().zo_deflate(data, n, method, out, n + 64, ctypes.byref(ol), ctypes.byref(crc), None, None,
                              ctypes.cast(cb, ctypes.c_void_p) if cb else None, None)

@@ -85,3 +85,167 @@ def test_two_rank_gather_and_stitch_equals_single_process_archive():
     assert got == oracle_zip(entries, 10)
     zf = zipfile.ZipFile(io.BytesIO(got))
     assert zf.testzip() is None and len(zf.infolist()) == len(entries)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ONE stream over several ranks (sharding.deflate_stream_rank) on gloo, with a CPU model of the range calls
+# ----------------------------------------------------------------------------------------------------------------------
+class OracleRangeModel:
+    """CPU stand-in for the zada_range_* calls of one rank, built from ONE run of the oracle over the whole stream: the
+    rank's atoms are the oracle's tokens that start inside its range, its bits those of the blocks of the flushes it owns.
+    It checks everything the protocol hands it (atom offsets, neighbours' atoms, bit position) against the oracle, so the
+    test covers sharding.py's bookkeeping: counts -> flush grid -> look-behind / look-ahead assembly -> chooser chain ->
+    byte offsets and OR-merge of the payloads."""
+
+    def __init__(self, data, method, lie_once=False):
+        import numpy as np
+        from _common import oracle_deflate, oracle_tokens, oracle
+        self.np, self.data, self.method = np, data, method
+        self.blocks, self.bitpos = [], []
+        rc, self.stream, crc = oracle_deflate(data, method, self.blocks, None, None, self.bitpos)
+        assert rc == 0
+        self.tok = oracle_tokens(data, method)
+        lens = np.where(self.tok & 0x80000000, (self.tok >> 16) & 0x1FF, 1).astype(np.int64)
+        self.start = np.concatenate(([0], np.cumsum(lens)))          # start[i] = byte position of token i; start[-1] = n
+        self.total_bits = len(self.stream) * 8
+        self.lie_once = lie_once
+        self.O = oracle()
+
+    @staticmethod
+    def _arr(ptr, n):
+        import ctypes
+        import numpy as np
+        return np.ctypeslib.as_array((ctypes.c_uint32 * n).from_address(ptr)) if n else np.zeros(0, dtype=np.uint32)
+
+    def range_open(self, d_in_ptr, stream_size, lo, n, pre, post, method):
+        assert stream_size == len(self.data) and method == self.method
+        assert lo % 65536 == 0 and pre == (32768 if lo else 0) and post == min(1 << 20, stream_size - lo - n)
+        self.lo, self.n = lo, n
+
+    def _first_token_at_or_after(self, p):
+        return int(self.np.searchsorted(self.start[:-1], p, side="left"))
+
+    def range_lz(self, entry):
+        i0, i1 = self._first_token_at_or_after(self.lo), self._first_token_at_or_after(self.lo + self.n)
+        self.i0, self.i1 = i0, i1
+        warm = (int(self.start[i0]), 1)
+        if entry is None and self.lie_once and self.lo > 0:           # a warm-up parse that did not synchronise
+            warm = (warm[0] + 1, 2)
+        if entry is not None:
+            assert tuple(entry) == (int(self.start[i0]), 1), entry    # the true state of the range before
+        raw = self.O.zo_crc32_update(0, self.data[self.lo:self.lo + self.n], self.n)
+        return dict(atoms=i1 - i0, exit=(int(self.start[i1]), 1), warm=warm, crc_raw=raw, entry_known=entry is not None or self.lo == 0)
+
+    def range_edges(self, ha, hp, ta, tp):
+        nh, nt = min(self.i1 - self.i0, 65536), min(self.i1 - self.i0, 2048)
+        self._arr(ha, 65536)[:nh] = self.tok[self.i0:self.i0 + nh]; self._arr(hp, 65536)[:nh] = self.start[self.i0:self.i0 + nh] & 0xFFFFFFFF
+        self._arr(ta, 2048)[:nt] = self.tok[self.i1 - nt:self.i1]; self._arr(tp, 2048)[:nt] = self.start[self.i1 - nt:self.i1] & 0xFFFFFFFF
+        return nh, nt
+
+    def range_place(self, before, total, lba, lbp, n_lb, laa, lap, n_la):
+        np = self.np
+        assert before == self.i0 and total == len(self.tok)
+        if n_lb:
+            assert (self._arr(lba, n_lb) == self.tok[before - n_lb:before]).all() and (self._arr(lbp, n_lb) == (self.start[before - n_lb:before] & 0xFFFFFFFF)).all()
+        if n_la:
+            assert (self._arr(laa, n_la) == self.tok[self.i1:self.i1 + n_la]).all() and (self._arr(lap, n_la) == (self.start[self.i1:self.i1 + n_la] & 0xFFFFFFFF)).all()
+        f0 = (before + 65535) // 65536 * 65536
+        self.own_lo, self.own_hi = f0, f0
+        if self.i1 > f0:
+            nfl = (self.i1 - f0 + 65535) // 65536
+            self.own_hi = f0 + nfl * 65536
+            # every window the splitter looks at must be inside [before - n_lb, i1 + n_la)
+            assert min(self.own_hi, total) <= self.i1 + n_la
+            assert f0 == 0 or f0 - 2048 >= before - n_lb
+
+    def range_analyze(self):
+        pass
+
+    def range_choose(self, carry):
+        import struct
+        pos_in = struct.unpack_from("<Q", carry, 0)[0] if carry is not None else 0
+        mine = [k for k, b in enumerate(self.blocks) if self.own_lo <= b[0] < self.own_hi]
+        begin, end = pos_in, pos_in
+        if mine:
+            assert self.bitpos[mine[0]][1] == pos_in, (self.bitpos[mine[0]], pos_in)
+            nxt = mine[-1] + 1
+            end = self.bitpos[nxt][1] if nxt < len(self.blocks) else self.total_bits
+        elif len(self.tok) == 0 or (self.own_lo >= len(self.tok) and self.i1 == len(self.tok) and not self.blocks):
+            end = self.total_bits
+        self.span = (begin, end)
+        out = bytearray(352)
+        struct.pack_into("<Q", out, 0, end)
+        return bytes(out), begin, end
+
+    def range_emit(self, d_out_ptr, cap):
+        import ctypes
+        b0, b1 = self.span
+        off, ln = b0 // 8, (b1 + 7) // 8 - b0 // 8
+        buf = bytearray(self.stream[off:off + ln])
+        if ln:
+            buf[0] &= (0xFF << (b0 & 7)) & 0xFF                       # bits before bit_begin belong to the range before
+            if b1 & 7:
+                buf[-1] &= (1 << (b1 & 7)) - 1                        # ... and those from bit_end on to the next one
+        assert ln <= cap
+        ctypes.memmove(d_out_ptr, bytes(buf), ln)
+        return ln
+
+
+def _stream_worker(rank, world, port, q, n, method, lie):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import importlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding = importlib.import_module("zip-ada_amd.sharding")
+    za = importlib.import_module("zip-ada_amd")
+    data = silesia_mix(n)
+    ranges = sharding.stream_ranges(n, world)
+    enc = OracleRangeModel(data, method, lie_once=lie)
+    comm = sharding.TorchComm(torch.device("cpu"))
+    res = sharding.deflate_stream_rank(enc, comm, torch, n, ranges, 0, method,
+                                       lambda k: torch.zeros(k, dtype=torch.int32), lambda k: torch.zeros(k, dtype=torch.uint8))
+    payload = res["payload"] if res["payload"] is not None else torch.zeros(1, dtype=torch.uint8)
+    got = sharding.gather_payloads(payload, res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
+    if rank == 0:
+        out = sharding.stitch_stream(torch, got[0], res["spans"], res["total_bits"], torch.device("cpu"))
+        lib = za.load_library()
+        crc = sharding.stream_crc(lib.zada_crc32_combine, res["infos"])
+        q.put((bytes(out.numpy()), crc, [i["atoms"] for i in res["infos"] if i is not None]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_stream(world, n, method, lie=False):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + world * 7 + n) % 2000
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, q, n, method, lie)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_one_stream_over_two_and_three_ranks_protocol():
+    """The exchange protocol of sharding.deflate_stream_rank over gloo: stitched stream == the oracle's stream, combined
+    CRC == zlib's; range boundaries inside flushes (3 MiB, ~900 000 atoms at Deflate_3) and ranges without a flush of
+    their own (Deflate_0 on 200 000 bytes over 3 ranks: 65 536, 65 536 and 68 928 atoms)."""
+    import zlib
+    from _common import oracle_deflate
+    for world, n, method, lie in ((2, 3 << 20, 10, False), (3, (2 << 20) + 77, 10, True), (3, 200000, 7, False)):
+        data = silesia_mix(n)
+        rc, ref, _ = oracle_deflate(data, method)
+        out, crc, atoms = _run_stream(world, n, method, lie)
+        assert rc == 0 and out == ref, (world, n, method)
+        assert crc ^ 0xFFFFFFFF == zlib.crc32(data)
+        assert len(atoms) == len([r for r in importlib_sharding().stream_ranges(n, world)])
+
+
+def importlib_sharding():
+    import importlib
+    return importlib.import_module("zip-ada_amd.sharding")
