@@ -150,6 +150,12 @@ int zada_lz77_tokens(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n,
  * format (0 stored, 1 fixed, 2 dynamic, 3 dynamic RLE-tweaked, 4 recycled), bit cost. */
 int zada_last_blocks(zada_ctx *ctx, uint64_t *rec, uint64_t cap_blocks, uint64_t *nblocks);
 
+/* The similarity tests of the Taillaule splitter in the last zada_deflate* call / range, as the reference's trace log lists
+ * them (zip-compress-deflate.adb:480-488, 1384-1390): rec[3*i+0..2] = atom (index in the stream) at which a sliding window
+ * was compared with the reference descriptor, L1 distance of the tweaked code-length vectors, step level that cut there
+ * (1, 2, 3; 0 = similar).  One record per test point: the reference tests up to three levels there, with the same distance. */
+int zada_last_trace(zada_ctx *ctx, uint64_t *rec, uint64_t cap, uint64_t *count);
+
 /* Per-phase device time of the last call, measured with HIP events on the context's stream.
  * names[i] are static strings; ms[i] milliseconds.  Returns the number of phases. */
 int zada_last_timing(zada_ctx *ctx, const char **names, float *ms, int cap);

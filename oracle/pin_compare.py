@@ -1,0 +1,43 @@
+"""Second half of pin_with_gnat.sh: runs the reference's zipada on every input of the parity matrix and compares the raw
+Deflate streams with the committed digests of the oracle's streams (tests/golden/deflate_digests.json)."""
+import hashlib
+import json
+import os
+import struct
+import subprocess
+import sys
+
+zipada, work, root = sys.argv[1:4]
+sys.path.insert(0, os.path.join(root, "tests"))
+from _common import GOLDEN, edge_inputs  # noqa: E402
+
+OPT = {6: "-edf", 7: "-ed0", 8: "-ed1", 9: "-ed2", 10: "-ed3"}
+cases = dict(edge_inputs())
+for f in ("sample.xls", "sample.jpg", "sample_pgm_100k.bin"):
+    cases[f] = open(os.path.join(GOLDEN, f), "rb").read()
+dig = json.load(open(os.path.join(GOLDEN, "deflate_digests.json")))
+bad = checked = 0
+for name, data in sorted(cases.items()):
+    src = os.path.join(work, "in.bin")
+    open(src, "wb").write(data)
+    for m, opt in OPT.items():
+        want = dig["%s|%d" % (name, m)]
+        arc = os.path.join(work, "out.zip")
+        if os.path.exists(arc):
+            os.remove(arc)
+        subprocess.run([zipada, opt, arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
+        z = open(arc, "rb").read()
+        sig, ver, flag, method, tm, crc, csize, usize, nl, xl = struct.unpack("<4sHHHIIIIHH", z[:30])
+        assert sig == b"PK\x03\x04"
+        payload = z[30 + nl + xl:30 + nl + xl + csize]
+        checked += 1
+        if want["rc"] == 1:                                   # Compression_inefficient: the entry must have been stored
+            ok = method == 0 and payload == data
+        else:
+            ok = method == 8 and csize == want["size"] and hashlib.sha256(payload).hexdigest() == want["sha256"]
+        if not ok:
+            bad += 1
+            print("DIFFERENT: %s method %d: zipada wrote %d bytes (zip method %d), the oracle %s" % (name, m, csize, method, want["size"]))
+print("%d streams compared, %d different" % (checked, bad))
+print("PINNED: the oracle's streams are the Ada binary's" if bad == 0 else "NOT pinned")
+sys.exit(1 if bad else 0)

@@ -98,11 +98,16 @@ int zo_compress_data(const uint8_t *in, uint64_t n, int method,
                      uint32_t *crc_out, uint16_t *zip_type);
 
 /* Archive writer either side of the hot path (zada_oracle_zip.c): Zip.Create.Create_Archive /
- * Add_Stream / Finish on a memory stream, Zip_32 archives only. */
+ * Add_Stream / Finish on a memory stream, incl. the Zip_64 promotion.  zo_zip_add_compressed / zo_zip_set_bias are
+ * test hooks: an entry whose payload was made elsewhere (with any recorded uncompressed size), and a pretended number of
+ * bytes in front of the buffer, so that the Zip_64 paths can be compared without 4 GiB of data. */
 typedef struct zoz_archive zoz_archive;
 zoz_archive *zo_zip_create(int method);
 int zo_zip_add(zoz_archive *a, const char *entry_name, const uint8_t *data, uint64_t n,
                uint32_t file_time, int unicode_name);
+int zo_zip_add_compressed(zoz_archive *a, const char *entry_name, const uint8_t *payload, uint64_t payload_len, uint32_t crc,
+                          uint64_t uncompressed_size, int zip_type, uint32_t file_time, int unicode_name);
+void zo_zip_set_bias(zoz_archive *a, uint64_t bias);
 int zo_zip_finish(zoz_archive *a, const uint8_t **bytes, uint64_t *len);
 void zo_zip_free(zoz_archive *a);
 

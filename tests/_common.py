@@ -48,6 +48,9 @@ def oracle():
         O.zo_zip_create.argtypes = [ctypes.c_int]
         O.zo_zip_add.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
         O.zo_zip_finish.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+        O.zo_zip_add_compressed.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64,
+                                            ctypes.c_int, ctypes.c_uint32, ctypes.c_int]
+        O.zo_zip_set_bias.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         O.zo_zip_free.argtypes = [ctypes.c_void_p]
         _cache["o"] = O
     return _cache["o"]
@@ -148,6 +151,23 @@ def oracle_zip(entries, method):
         for name, data in entries:
             rc = O.zo_zip_add(a, name.encode("utf-8"), data, len(data), 16789 * 65536, 1)
             assert rc == 0, rc
+        p = ctypes.c_void_p()
+        ln = ctypes.c_uint64()
+        assert O.zo_zip_finish(a, ctypes.byref(p), ctypes.byref(ln)) == 0
+        return ctypes.string_at(p.value, ln.value)
+    finally:
+        O.zo_zip_free(a)
+
+
+def oracle_zip_compressed(entries, bias=0):
+    """entries: list of (name, payload, crc, uncompressed size, zip_type) made elsewhere.  The archive bytes
+    Zip.Create would write for them (bias: pretended number of bytes in front of the archive)."""
+    O = oracle()
+    a = O.zo_zip_create(10)
+    try:
+        O.zo_zip_set_bias(a, bias)
+        for name, payload, crc, usize, zt in entries:
+            assert O.zo_zip_add_compressed(a, name.encode("utf-8"), payload, len(payload), crc, usize, zt, 16789 * 65536, 1) == 0
         p = ctypes.c_void_p()
         ln = ctypes.c_uint64()
         assert O.zo_zip_finish(a, ctypes.byref(p), ctypes.byref(ln)) == 0

@@ -81,6 +81,24 @@ def test_multi_flush_and_long_streams(encoder):
             assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), (mask, n, method)
 
 
+def test_splitter_trace_equals_the_oracles(encoder):
+    """The reference's trace events (zip-compress-deflate.adb:83-90): similarity distance at every test point
+    (:480-488), cut position and step level (:1384-1390), from the product (zada_last_trace) == from the oracle."""
+    cases = dict(edge_inputs())
+    for name in ("mix_1m_off", "text_rand_text", "copies_1500k", "fixedlike_mix"):
+        d = cases[name]
+        for method in (10, 9, 8):
+            cuts, sim = [], []
+            rc, ref, crc = oracle_deflate(d, method, None, cuts, sim)
+            rc2, out, crc2 = gpu_deflate(encoder, d, method)
+            assert rc == rc2 == 0
+            tr = [(int(a), int(b), int(c)) for a, b, c in encoder.last_trace()]
+            dist = {a: b for a, b, _ in tr}
+            assert len(sim) > 0 and all(dist.get(w) == dd for w, dd, thr, _ in sim), (name, method)
+            assert sorted(set(w for w, _, _, _ in sim)) == sorted(dist), (name, method)   # the same test points
+            assert [(a, c) for a, _, c in tr if c] == cuts, (name, method)
+
+
 def test_few_symbol_random_data(encoder):
     """2-, 4- and 16-symbol uniform random data at 4-6 MiB with the default budget: every position has thousands of
     candidates (lz77.adb:715-825 at chain 4096 / 1024), the demand-driven match finder at its worst."""

@@ -88,3 +88,49 @@ def test_product_never_references_the_oracle():
             if f.endswith((".hip", ".h", ".c", ".cpp", ".py", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "zada_oracle" not in txt and "libzada_oracle" not in txt and "zo_deflate" not in txt, f
+
+
+def test_zip64_promotion_of_the_container_writer():
+    """Zip_64 in ZipCreate (zip-create.adb:161-179, 237-251, 682-752; zip-headers.adb:197-210, 534-579) without 4 GiB of
+    data: entries made elsewhere with recorded sizes beyond 4 GiB, a pretended archive offset beyond 4 GiB, and 65 535
+    entries.  Bytes == the oracle's Zip.Create restatement; Python's zipfile (independent reader) accepts what it can see."""
+    import io
+    import zipfile
+    import zlib
+    from _common import oracle_zip_compressed
+    from _common import product
+    za = product()
+    small = zlib.compress(b"hello " * 100, 9)[2:-4]
+    crc = zlib.crc32(b"hello " * 100)
+
+    def both(entries, bias=0):
+        zc = za.ZipCreate(None, 10, _offset_bias=bias)
+        for name, payload, c, usize, zt in entries:
+            zc.add_compressed(name, payload, c, usize, zt)
+        got = zc.finish()
+        assert got == oracle_zip_compressed(entries, bias)
+        return got
+
+    # (a) plain Zip_32 stays Zip_32
+    got = both([("a.txt", small, crc, 600, 8), ("b\\c.txt", b"xyz", zlib.crc32(b"xyz"), 3, 0)])
+    assert b"PK\x06\x06" not in got and zipfile.ZipFile(io.BytesIO(got)).read("a.txt") == b"hello " * 100
+    # (b) an uncompressed size beyond 4 GiB: local extension (20 bytes), central extension (28), Zip64 end records
+    big = 5 * 2 ** 30 + 123
+    got = both([("a.txt", small, crc, 600, 8), ("big.bin", small, crc, big, 8), ("c.txt", small, crc, 600, 8)])
+    zf = zipfile.ZipFile(io.BytesIO(got))
+    assert [i.file_size for i in zf.infolist()] == [600, big, 600] and zf.read("c.txt") == b"hello " * 100
+    assert got.count(b"PK\x06\x06") == 1 and got.count(b"PK\x06\x07") == 1
+    # (c) Check_Size: a size just under 4 GiB promotes the ARCHIVE (end records) but needs no extension
+    got = both([("edge.bin", small, crc, 2 ** 32 - 65644, 8)])
+    assert b"PK\x06\x06" in got and got[28:30] == b"\x00\x00"
+    got = both([("edge.bin", small, crc, 2 ** 32 - 65645, 8)])
+    assert b"PK\x06\x06" not in got
+    # (d) offsets beyond 4 GiB (pretended): the extension is decided by the offset alone
+    got = both([("late.bin", small, crc, 600, 8), ("later.bin", b"", 0, 0, 0)], bias=2 ** 32 + 5)
+    assert got[28:30] == b"\x14\x00"
+    # (e) 65 534 entries stay Zip_32, 65 535 need Zip_64 (:682-687)
+    for count, z64 in ((65534, False), (65535, True), (65540, True)):
+        entries = [("e%05d" % i, b"", 0, 0, 0) for i in range(count)]
+        got = both(entries)
+        assert (b"PK\x06\x06" in got[-200:]) == z64
+        assert len(zipfile.ZipFile(io.BytesIO(got)).infolist()) == count

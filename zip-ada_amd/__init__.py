@@ -76,6 +76,7 @@ def load_library():
     L.zada_lz77_tokens.argtypes = [vp, i32, vp, u64, vp, u64, u64p]
     L.zada_last_blocks.argtypes = [vp, vp, u64, u64p]
     L.zada_last_timing.argtypes = [vp, vp, vp, i32]
+    L.zada_last_trace.argtypes = [vp, vp, u64, u64p]
     L.zada_silesia_mix.argtypes = [u64, ctypes.c_uint, u64, u64, vp]
     L.zada_set_knob.argtypes = [vp, ctypes.c_char_p, i32]
     L.zada_range_open.argtypes = [vp, i32, vp, u64, u64, u64, u64, u64]
@@ -293,6 +294,15 @@ class Encoder:
         self.lib.zada_last_blocks(self.ctx, rec.ctypes.data, nb.value, ctypes.byref(nb))
         return rec[:nb.value]
 
+    def last_trace(self):
+        """Similarity tests of the block splitter in the last call: array of (atom, L1 distance, cut level or 0)."""
+        import numpy as np
+        k = ctypes.c_uint64(0)
+        self.lib.zada_last_trace(self.ctx, None, 0, ctypes.byref(k))
+        rec = np.zeros((max(k.value, 1), 3), dtype=np.uint64)
+        self.lib.zada_last_trace(self.ctx, rec.ctypes.data, k.value, ctypes.byref(k))
+        return rec[:k.value]
+
     def last_timing(self):
         names = (ctypes.c_char_p * 64)()
         ms = (ctypes.c_float * 64)()
@@ -312,20 +322,28 @@ def silesia_mix(nbytes, seed=0x5A1E51A, class_mask=0x1F, offset=0):
 
 class ZipCreate:
     """Zip.Create on a memory stream: Create_Archive / Add_Stream / Finish
-    (zip_lib/zip-create.adb:36-58, 194-297, 645-756; headers zip-headers.adb:168-195, 244-276,
-    494-511).  Zip_32 archives only."""
+    (zip_lib/zip-create.adb:36-58, 194-297, 645-756; headers zip-headers.adb:168-195, 244-276, 494-511), incl. the
+    promotion to Zip_64 (Check_Size zip-create.adb:161-179; local header extension :237-251, 283-289 and
+    zip-headers.adb:197-210, 336-355; central extension and Zip64 end records zip-create.adb:682-752,
+    zip-headers.adb:534-579)."""
 
     DEFAULT_TIME = 16789 * 65536  # zip_streams.ads:223
+    _MARGIN = 22 + 56 + 20 + 2 ** 16 + 10   # Check_Size, zip-create.adb:165-169
 
-    def __init__(self, encoder, method=Method.Deflate_3):
+    def __init__(self, encoder, method=Method.Deflate_3, _offset_bias=0):
         self.enc, self.method = encoder, method
         self.buf = bytearray()
         self.entries = []
+        self.zip64 = False
+        self._bias = _offset_bias       # test hook: pretend that this many bytes precede the buffer
+
+    def _check_size(self, value):
+        if not self.zip64 and value >= 2 ** 32 - self._MARGIN:
+            self.zip64 = True
 
     @staticmethod
-    def _local(e):
-        return struct.pack("<4sHHHIIIIHH", b"PK\x03\x04", 10, e["flag"], e["zip_type"], e["time"], e["crc"],
-                           e["csize"], e["usize"], len(e["name"]), 0)
+    def _needs_zip64(csize, usize, offset):      # Needs_Local_Zip_64_Header_Extension, zip-headers.adb:197-210
+        return csize >= 0xFFFFFFFF or usize >= 0xFFFFFFFF or offset >= 0xFFFFFFFF
 
     def add_stream(self, name, data, file_time=None, unicode_name=True):
         payload, crc, zt = self.enc.compress_data(data, self.method)
@@ -336,18 +354,44 @@ class ZipCreate:
         are those Add_Stream would have written for the same payload."""
         nm = name.replace("\\", "/").encode("utf-8")
         e = dict(name=nm, flag=0x0800 if unicode_name else 0, zip_type=zt, time=self.DEFAULT_TIME if file_time is None else file_time,
-                 crc=crc, csize=len(payload), usize=usize, offset=len(self.buf))
-        if e["usize"] >= 0xFFFFFFFF - (1 << 17) or e["offset"] + e["csize"] >= 0xFFFFFFFF - (1 << 17) or len(self.entries) >= 65534:
-            raise ZadaError("Zip_64 archives are not implemented")
-        self.buf += self._local(e) + nm + payload
+                 crc=crc, csize=len(payload), usize=usize, offset=len(self.buf) + self._bias)
+        self._check_size(usize)
+        # the local header's form is decided before compression, on the provisional sizes (:231-241)
+        z64 = self._needs_zip64(usize, usize, e["offset"])
+        if z64:
+            hdr = struct.pack("<4sHHHIIIIHH", b"PK\x03\x04", 10, e["flag"], zt, e["time"], crc, 0xFFFFFFFF, 0xFFFFFFFF, len(nm), 20)
+            ext = struct.pack("<HHQQ", 1, 16, usize, e["csize"])
+        else:
+            hdr = struct.pack("<4sHHHIIIIHH", b"PK\x03\x04", 10, e["flag"], zt, e["time"], crc, e["csize"], usize, len(nm), 0)
+            ext = b""
+        self.buf += hdr + nm + ext + payload
         self.entries.append(e)
         return e["csize"], zt
 
     def finish(self):
-        cd_off = len(self.buf)
+        cd_off = len(self.buf) + self._bias
+        if not self.zip64 and len(self.entries) >= 0xFFFF:
+            self.zip64 = True
+        cd_size = 0
         for e in self.entries:
+            z64 = self._needs_zip64(e["csize"], e["usize"], e["offset"])
+            if z64:
+                self.zip64 = True
+            m = 0xFFFFFFFF
             self.buf += struct.pack("<4sHHHHIIIIHHHHHII", b"PK\x01\x02", 23, 10, e["flag"], e["zip_type"], e["time"], e["crc"],
-                                    e["csize"], e["usize"], len(e["name"]), 0, 0, 0, 0, 0, e["offset"]) + e["name"]
-        cd_size = len(self.buf) - cd_off
-        self.buf += struct.pack("<4sHHHHIIH", b"PK\x05\x06", 0, 0, len(self.entries), len(self.entries), cd_size, cd_off, 0)
+                                    m if z64 else e["csize"], m if z64 else e["usize"], len(e["name"]), 28 if z64 else 0, 0, 0, 0, 0,
+                                    m if z64 else e["offset"]) + e["name"]
+            if z64:
+                self.buf += struct.pack("<HHQQQ", 1, 24, e["usize"], e["csize"], e["offset"])
+            cd_size += 46 + len(e["name"]) + (28 if z64 else 0)
+        if self.entries:
+            self._check_size(len(self.buf) + self._bias + 1)
+        n = len(self.entries)
+        if self.zip64:
+            e64_off = len(self.buf) + self._bias
+            self.buf += struct.pack("<4sQHHIIQQQQ", b"PK\x06\x06", 44, 0x2D, 0x2D, 0, 0, n, n, cd_size, cd_off)
+            self.buf += struct.pack("<4sIQI", b"PK\x06\x07", 0, e64_off, 1)
+            self.buf += struct.pack("<4sHHHHIIH", b"PK\x05\x06", 0, 0, 0xFFFF, 0xFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0)
+        else:
+            self.buf += struct.pack("<4sHHHHIIH", b"PK\x05\x06", 0, 0, n, n, cd_size, cd_off, 0)
         return bytes(self.buf)

@@ -116,6 +116,7 @@ int ensure_entropy_workspace(Ctx *c, uint64_t atoms) {
   A(ea_atoms, LB_CAP + cap + LA_CAP + 64); A(ea_apos, LB_CAP + cap + LA_CAP + 64);
   A(descr, nflush * SLOTS * 320);
   A(seg_nblk, nflush); A(seg_cut, nflush * MAXBLK_PER_SEG); A(seg_blk_off, nflush);
+  A(cut_trace, nflush * SLOTS * 2);
   W.cap_blocks = nflush * MAXBLK_PER_SEG;
   A(blocks, W.cap_blocks);
   A(binfo, W.cap_blocks);
@@ -848,6 +849,32 @@ int zada_last_blocks(zada_ctx *z, uint64_t *rec, uint64_t cap_blocks, uint64_t *
   if (hip_check(c, hipStreamSynchronize(c->stream), "trace")) return ZADA_E_HIP;
   const uint64_t g0 = c->rg.G - c->rg.n_lb;            // index in the stream of element 0 of the range's local atom array
   for (uint64_t i = 0; i < k; i++) { rec[4 * i] = g0 + hb[i].first; rec[4 * i + 1] = hb[i].count; rec[4 * i + 2] = he[i].fmt; rec[4 * i + 3] = he[i].cost_bits; }
+  return ZADA_OK;
+}
+
+// The similarity tests of the Taillaule splitter in the last call, as the reference's trace lists them
+// (zip-compress-deflate.adb:480-488, 1384-1390): rec[3*i+0..2] = atom (index in the stream) at which a window was
+// compared with the reference descriptor, the L1 distance of the tweaked length vectors, the step level that cut there
+// (1: 6000-atom steps / threshold 420, 2: 3000 / 430, 3: 750 / 2050; 0 = similar, no cut).
+int zada_last_trace(zada_ctx *z, uint64_t *rec, uint64_t cap, uint64_t *count) {
+  if (!z) return ZADA_E_INVALID;
+  Ctx *c = &z->c;
+  const Range &R = c->rg;
+  *count = 0;
+  if (!R.analyzed || R.method == ZADA_DEFLATE_FIXED || R.nflush == 0) return ZADA_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return ZADA_E_HIP;
+  std::vector<uint32_t> h((size_t)R.nflush * SLOTS * 2);
+  hipMemcpyAsync(h.data(), c->ws.cut_trace, h.size() * 4, hipMemcpyDeviceToHost, c->stream);
+  if (hip_check(c, hipStreamSynchronize(c->stream), "trace")) return ZADA_E_HIP;
+  uint64_t k = 0;
+  for (uint32_t j = 0; j < R.nflush; j++)
+    for (uint32_t s = 1; s < SLOTS; s++) {
+      const uint32_t d = h[((size_t)j * SLOTS + s) * 2], lvl = h[((size_t)j * SLOTS + s) * 2 + 1];
+      if (d == 0xFFFFFFFFu) continue;
+      if (k < cap) { rec[3 * k] = (R.j0 + j) * FLUSH + (uint64_t)MIN_STEP * s; rec[3 * k + 1] = d; rec[3 * k + 2] = lvl; }
+      k++;
+    }
+  *count = k;
   return ZADA_OK;
 }
 

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(64) k_window_descr(EntropyView v, uint32_t kst
 // k_cut_scan : one wave per flush segment
 // --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_cut_scan(EntropyView v, uint32_t kstep, const uint8_t *__restrict__ descr,
-                                                 uint32_t *__restrict__ seg_nblk, uint32_t *__restrict__ seg_cut) {
+                                                 uint32_t *__restrict__ seg_nblk, uint32_t *__restrict__ seg_cut, uint32_t *__restrict__ trace) {
   const uint32_t j = blockIdx.x, lane = threadIdx.x;
   const uint32_t F = v.foff + j * FLUSH;
   const uint32_t to = (F + FLUSH - 1 < v.lvalid - 1) ? F + FLUSH - 1 : v.lvalid - 1;
@@ -115,6 +115,8 @@ __global__ void __launch_bounds__(64) k_cut_scan(EntropyView v, uint32_t kstep, 
   uint32_t nb = 0;
   if (lane == 0) cuts[0] = F;
   nb = 1;
+  for (uint32_t k = lane; k < SLOTS; k += 64) { trace[((uint64_t)j * SLOTS + k) * 2] = 0xFFFFFFFFu; trace[((uint64_t)j * SLOTS + k) * 2 + 1] = 0; }   // no test here
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
   if (to - F >= SLIDER - 1) {
     const uint8_t *d0 = descr + (uint64_t)j * SLOTS * 320;
     int init[5];
@@ -126,6 +128,8 @@ __global__ void __launch_bounds__(64) k_cut_scan(EntropyView v, uint32_t kstep, 
       int sl[5]; uint32_t dist = 0;
       for (int r = 0; r < 5; r++) { sl[r] = tweak_value(dk[lane + 64 * r]); int d = init[r] - sl[r]; dist += (uint32_t)(d < 0 ? -d : d); }
       dist = wave_sum_u32(dist);
+      // the reference's trace (:480-488, 1384-1390): the distance at every test point, and which step level cut
+      if (lane == 0) { uint32_t *t = trace + ((uint64_t)j * SLOTS + k) * 2; t[0] = dist; t[1] = dist < (uint32_t)thr * 100u ? 0u : ((k % 8 == 0) ? 1u : (k % 4 == 0) ? 2u : 3u); }
       if (!(dist < (uint32_t)thr * 100u)) {                                      // not Similar => cut (:1375-1395)
         if (lane == 0) cuts[nb] = F + MIN_STEP * k;
         nb++;
@@ -810,7 +814,7 @@ int entropy_analyze(Ctx *c) {
       const uint32_t kstep = R.method == 8 ? 8 : R.method == 9 ? 4 : 1;                        // max_choice :1310-1311
       hipLaunchKernelGGL(k_window_descr, dim3(v.nflush * SLOTS), dim3(64), 0, st, v, kstep, W.descr);
       c->tmark("window_descr");
-      hipLaunchKernelGGL(k_cut_scan, dim3(v.nflush), dim3(64), 0, st, v, kstep, W.descr, W.seg_nblk, W.seg_cut);
+      hipLaunchKernelGGL(k_cut_scan, dim3(v.nflush), dim3(64), 0, st, v, kstep, W.descr, W.seg_nblk, W.seg_cut, W.cut_trace);
       exclusive_scan_u32(st, W.seg_nblk, W.seg_blk_off, W.scan2, W.total2, v.nflush);
       hipMemcpyAsync(&nblocks, W.total2, 4, hipMemcpyDeviceToHost, st);
       hipLaunchKernelGGL(k_fill_blocks, dim3((v.nflush + 255) / 256), dim3(256), 0, st, v, W.seg_nblk, W.seg_cut, W.seg_blk_off, W.blocks);

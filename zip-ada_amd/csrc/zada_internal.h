@@ -137,6 +137,7 @@ struct Workspace {
   uint32_t *ea_atoms = nullptr, *ea_apos = nullptr;   // local atom array: LB_CAP slots, the range's atoms, LA_CAP slots (+ sentinel)
   uint8_t *descr = nullptr;                  // [nflush][SLOTS][320]
   uint32_t *seg_nblk = nullptr, *seg_cut = nullptr, *seg_blk_off = nullptr;   // cuts [nflush][MAXBLK_PER_SEG]
+  uint32_t *cut_trace = nullptr;             // [nflush][SLOTS][2]: similarity distance and cut level at every test point
   BlockRange *blocks = nullptr;
   BlockInfo *binfo = nullptr;
   EmitRec *emit = nullptr;
