@@ -285,6 +285,11 @@ def format_inputs():
     cases["flush_tail_m8"] = text[:364356] + tail             # Deflate_1: the same (atom counts found with the oracle)
     cases["flush_tail_m9"] = text[:372589] + tail             # Deflate_2 and Deflate_3
     cases["flush_exact_m9"] = text[:372589]                   # exactly 65 536 atoms: no last flush, fake final fixed block
+    # the only earlier occurrence lies exactly MAX_DIST = 32 506 back: the reference accepts it as the head of the hash chain
+    # (lz77.adb:850) but not behind it (:820); one byte nearer / farther for contrast; text so that chains are not empty
+    for per in (32505, 32506, 32507):
+        blk = bytes(rs.randint(0, 256, per - 2000).astype(np.uint8)) + text[500000:502000]
+        cases["period_%d" % per] = blk * 3 + blk[:1234]
     return cases
 
 

@@ -335,7 +335,11 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     if (lvl < NLEVELS) {
       const uint64_t lmask = (1ull << (8 * L)) - 1ull;
       uint16_t *plane = dp.d[lvl] + base;
-      const uint32_t dflt = (seg > 0) ? DIST3_CONTINUE : 0u;        // not found inside this segment: continue in k_cross_dist
+      // not found inside this segment: continue in k_cross_dist.  Level 3 (lvl 0) only looks TOO_FAR back: a three-byte match
+      // farther away is dropped by the parser anyway (lz77.adb:867-871) and any longer match is found through the levels
+      // above, so plane d[0] holds the nearest three-byte match within 4096, or none (0), or MAX_DIST for the one candidate
+      // the reference accepts at exactly that distance (the head of the 15-bit chain, :850 vs :820; k_cross_dist).
+      auto dflt_of = [&](uint32_t e) -> uint32_t { return (seg > 0 && (lvl > 0 || e < (uint32_t)TOO_FAR)) ? DIST3_CONTINUE : 0u; };
       constexpr uint32_t QCAP = 4000;
       uint32_t *Qa = (uint32_t *)(smem + 32800), *Qb = Qa + QCAP;   // behind the 32 784 staged bytes
       uint32_t *qn = wsum;
@@ -346,13 +350,13 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       auto walk = [&](uint32_t e, uint32_t &q, uint64_t mine, uint32_t maxs, uint32_t &dl) -> bool {
         uint32_t step = P[q];
         for (uint32_t sidx = 0; sidx < maxs; sidx++) {
-          if (step == 0) { dl = dflt; return true; }
+          if (step == 0) { dl = dflt_of(e); return true; }
           q -= step;
           const uint32_t dist = e - q;
           step = P[q];                                              // next link and this candidate's bytes in one LDS round trip
           const uint64_t theirs = lb8(q);
-          // beyond MAX_DIST nothing qualifies; the 15-bit chain accepts exactly MAX_DIST only at its head (:850 vs :820)
-          if (dist > (uint32_t)MAX_DIST || (lvl == 0 && dist == (uint32_t)MAX_DIST)) { dl = 0; return true; }
+          // beyond MAX_DIST nothing qualifies (level 3: beyond TOO_FAR nothing matters)
+          if (dist > (uint32_t)(lvl == 0 ? TOO_FAR : MAX_DIST)) { dl = 0; return true; }
           if ((theirs & lmask) == mine) { dl = dist; return true; }
         }
         return false;
@@ -381,13 +385,20 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const uint32_t e = ee[j], step = st[j];
-          uint32_t dl = dflt, q = e;
+          uint32_t dl = dflt_of(e), q = e;
           bool pend = false;
           if (ex[j] && step != 0) {
             q = e - step;
-            if (step > (uint32_t)MAX_DIST) dl = 0;
-            else if (th[j] == mn[j]) dl = step;
-            else pend = true;
+            if (lvl == 0) {
+              // the head of the 15-bit chain: accepted up to exactly MAX_DIST (:850); the walk behind it only to TOO_FAR
+              if (th[j] == mn[j] && (step <= (uint32_t)TOO_FAR || step == (uint32_t)MAX_DIST)) dl = step;
+              else if (step >= (uint32_t)TOO_FAR) dl = 0;
+              else pend = true;
+            } else {
+              if (step > (uint32_t)MAX_DIST) dl = 0;
+              else if (th[j] == mn[j]) dl = step;
+              else pend = true;
+            }
           }
           if (!push(pend, e | (q << 16), Qa, &qn[0])) { walk(e, q, mn[j], 1u << 30, dl); pend = false; }
           if (ex[j] && !pend) plane[e] = (uint16_t)dl;
@@ -423,7 +434,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
             uint64_t th[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              if (act[j] && st4[j] == 0) { dl4[j] = dflt; act[j] = false; }                     // the chain ends inside the segment
+              if (act[j] && st4[j] == 0) { dl4[j] = dflt_of(e4[j]); act[j] = false; }           // the chain ends inside the segment
               qx[j] = act[j] ? q4[j] - st4[j] : q4[j];
             }
 #pragma unroll
@@ -433,8 +444,8 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
               if (act[j]) {
                 q4[j] = qx[j]; st4[j] = ns[j];
                 const uint32_t dist = e4[j] - q4[j];
-                // beyond MAX_DIST nothing qualifies; the 15-bit chain accepts exactly MAX_DIST only at its head (:850 vs :820)
-                if (dist > (uint32_t)MAX_DIST || (lvl == 0 && dist == (uint32_t)MAX_DIST)) { dl4[j] = 0; act[j] = false; }
+                // beyond MAX_DIST nothing qualifies (level 3: beyond TOO_FAR nothing matters)
+                if (dist > (uint32_t)(lvl == 0 ? TOO_FAR : MAX_DIST)) { dl4[j] = 0; act[j] = false; }
                 else if (th[j] == mn4[j]) { dl4[j] = dist; act[j] = false; }
               }
             }
@@ -521,28 +532,24 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 #pragma unroll
   for (int l = 0; l + 1 < NLEVELS; l++) { dl_first[l] = dp.d[1 + l][p]; link_first[l] = lv.prev[l][p]; }
   const uint64_t mine = *(const u64u *)(in + p);
-  // level 3 first: the previous segment's bucket of the 15-bit hash, newest first
-  uint32_t dprev = dp.d[0][p];
+  // level 3 first: the previous segment's bucket of the 15-bit hash, newest first, as far back as TOO_FAR (see k_prev_links)
+  const uint32_t d3_stored = dp.d[0][p];
+  uint32_t dprev = d3_stored;
+  const uint32_t my24 = (uint32_t)mine & 0xFFFFFFu;
+  const uint32_t b0 = my24 & 0xFF, b1 = (my24 >> 8) & 0xFF;
+  const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (my24 >> 16)) & 0x7FFFu;
   if (dprev == DIST3_CONTINUE) {
-    const uint32_t my24 = (uint32_t)mine & 0xFFFFFFu;
-    const uint32_t b0 = my24 & 0xFF, b1 = (my24 >> 8) & 0xFF;
-    const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (my24 >> 16)) & 0x7FFFu;
     const uint32_t bsc = bsc3[pbase + h];
     const uint32_t pst = bsc & 0xFFFF, pct = bsc >> 16;
     const uint16_t *ps = S3 + pbase;
     const uint8_t *pt = T3 + pbase;
-    // p heads its own-segment bucket <=> it is the bucket's first element (the 32 506 rule, :850 vs :820);
-    // only looked up in the rare case of a candidate at exactly MAX_DIST
-    auto heads = [&]() -> bool {
-      const uint32_t own = bsc3[seg * 32768ull + h];
-      return S3[seg * 32768ull + (own & 0xFFFF)] == (uint16_t)(p & 32767);
-    };
     const uint32_t mytag = (b0 >> 5) | ((b1 & 7u) << 3) | ((b0 & 3u) << 6);
     uint32_t d3 = 0;
     // newest first, eight tags per load: only candidates whose tag agrees are looked at (their bytes decide)
     const uint64_t tagx8 = 0x0101010101010101ull * mytag;
     for (uint32_t hi = pct; hi > 0 && d3 == 0;) {
       const uint32_t lo = hi >= 8 ? hi - 8 : 0;                      // candidates [lo, hi) of the bucket: byte i <-> candidate lo + i
+      // the oldest candidate of this batch of eight already too far?  (positions ascend inside a bucket)
       const uint64_t x = *(const u64u *)(pt + pst + lo) ^ tagx8;
       // zero-byte detection, exact per byte
       uint64_t z = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x | 0x7F7F7F7F7F7F7F7Full);
@@ -553,25 +560,39 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
         z &= ~(0xFFull << (8 * byte));
         const uint32_t j = lo + (uint32_t)byte;                        // candidate index in the bucket
         const uint64_t q = pbase + ps[pst + j], d = p - q;
-        // beyond MAX_DIST nothing qualifies; exactly MAX_DIST only as the head of the chain
-        if (q == 0 || d > (uint64_t)MAX_DIST || (d == (uint64_t)MAX_DIST && !(j + 1 == pct && heads()))) { stop = true; break; }
+        if (q == 0 || d > (uint64_t)TOO_FAR) { stop = true; break; }   // position 0 is never a match source (:467)
         if ((*(const u32u *)(in + q) & 0xFFFFFFu) == my24) { d3 = (uint32_t)d; break; }
       }
       if (stop) break;
+      // nothing among these eight: go on only while the next older candidates can still be within TOO_FAR
+      if (lo > 0 && p - (pbase + ps[pst + lo - 1]) > (uint64_t)TOO_FAR) break;
       hi = lo;
     }
-    dp.d[0][p] = (uint16_t)d3;
     dprev = d3;
   }
+  // The one candidate beyond TOO_FAR that matters: the reference accepts the HEAD of the 15-bit chain at a distance of
+  // exactly MAX_DIST (:850), everything behind it only below (:820).  Here: the candidate lies in the previous segment
+  // (own-segment heads are k_prev_links' first candidates), p has no same-hash predecessor in its own segment and the
+  // candidate is the last member of its bucket.
+  if (dprev == 0 && (p & 32767u) < (uint32_t)MAX_DIST) {
+    const uint64_t q = p - (uint64_t)MAX_DIST;
+    if (q != 0 && (*(const u32u *)(in + q) & 0xFFFFFFu) == my24) {
+      const uint32_t own = bsc3[seg * 32768ull + h], prv = bsc3[pbase + h];
+      const bool p_first = S3[seg * 32768ull + (own & 0xFFFF)] == (uint16_t)(p & 32767);
+      const bool q_last = (prv >> 16) != 0 && S3[pbase + (prv & 0xFFFF) + (prv >> 16) - 1] == (uint16_t)(q & 32767);
+      if (p_first && q_last) dprev = (uint32_t)MAX_DIST;
+    }
+  }
+  if (dprev != d3_stored) dp.d[0][p] = (uint16_t)dprev;
   // levels >= 4: follow the level's chain (it crosses into the previous segment after k_cross_links).
-  // The levels are nested: no L-1 byte match => no L byte match, and an L byte match is never nearer
-  // than the nearest L-1 byte match.
+  // The levels are nested: an L byte match is never nearer than the nearest L-1 byte match (when that one is known:
+  // level 3 only looks TOO_FAR back).
 #pragma unroll
   for (int l = 0; l + 1 < NLEVELS; l++) {
     uint32_t dl = dl_first[l];
     if (dl == DIST3_CONTINUE) {
       dl = 0;
-      if (dprev != 0) {
+      {
         uint64_t q = p;
         const uint64_t mask = (1ull << (8 * (4 + l))) - 1ull;
         uint32_t d = link_first[l];
@@ -757,9 +778,11 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
             // levels are nested (a 4-byte match is a 3-byte match), so they are valid in order
             int b_ = 2; uint32_t bd_ = 0, qbest = 0, qlev = 0;
             bool chain_ok = true;
+            // (every level on its own: plane d[0] only knows three-byte matches up to TOO_FAR back, so "no three-byte
+            // match" there does not mean "no four-byte match"; a valid level l implies the levels below it)
 #pragma unroll
             for (int l = 0; l < NLEVELS; l++) {
-              const bool v = chain_ok && la_ >= 3 + l && dl[l] != 0 && dl[l] <= lf;
+              const bool v = la_ >= 3 + l && dl[l] != 0 && dl[l] <= lf;
               if (v) { b_ = 3 + l; bd_ = dl[l]; if (dl[l] <= lq) { qbest = ((uint32_t)(3 + l) << 16) | dl[l]; qlev = 1u + l; } }
               chain_ok = v;
             }
@@ -1048,8 +1071,8 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       uint32_t bdist = 0, qbest = 0;
       bool chain_ok = true;
 #pragma unroll
-      for (int l = 0; l < NLEVELS; l++) {
-        const bool v = chain_ok && la >= 3 + l && dl[l] != 0 && dl[l] <= lim_full;
+      for (int l = 0; l < NLEVELS; l++) {                            // (levels on their own: see k_match)
+        const bool v = la >= 3 + l && dl[l] != 0 && dl[l] <= lim_full;
         if (v) { best = 3 + l; bdist = dl[l]; if (dl[l] <= lim_q) qbest = ((uint32_t)(3 + l) << 16) | dl[l]; }
         chain_ok = v;
       }
