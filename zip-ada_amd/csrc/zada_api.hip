@@ -122,6 +122,7 @@ int ensure_entropy_workspace(Ctx *c, uint64_t atoms) {
   A(binfo, W.cap_blocks);
   A(emit, W.cap_blocks);
   A(chrec, W.cap_blocks * 16 + 16);
+  A(chw, W.cap_blocks * 4 + 16); A(piece_base, W.cap_blocks + 16);
   A(codes, (W.cap_blocks + 2) * 320);
   W.cap_pieces = cap / 2048 + W.cap_blocks + 64;
   A(pieces, W.cap_pieces);

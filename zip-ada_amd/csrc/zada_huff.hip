@@ -403,185 +403,325 @@ __global__ void __launch_bounds__(64) k_choose_fixed(uint32_t nblocks, const Blo
 }
 
 // --------------------------------------------------------------------------------------------
-// k_choose_lean : the sequential walk of Send_as_block's decision (:1222-1268) reduced to what really depends on the
-// previous blocks.  Per block: one 128-byte record (k_block_relate) through scalar loads, the recycle cost picked
-// by the state, three compares, the state update and the bit positions.  No stream writes for ordinary blocks (the
-// end-of-block code, BFINAL and BTYPE bits go out in parallel afterwards, k_emit_prefix) and no tile table.
+// The block chooser: Send_as_block's decision (:1222-1268), Mark_new_block (:999-1007), Expand_LZ_buffer's split of
+// oversized stored blocks (:1024-1038) and the stream epilogue (:1613-1635), WITHOUT the sequential walk over all blocks.
+//
+// What the reference carries from block to block is (last_block_type, curr_descr, block_to_finish, last_block_marked, bit
+// position).  A block that is sent fixed, dynamic or stored leaves a state that depends on that block alone; only a
+// RECYCLED block (no header, the codes in force go on) hands its predecessor's state through.  And of the five costs only
+// "recycle" depends on the state at all (the constant c of :1198-1201 is added to the other four alike).  So:
+//   k_ch_tentative   every block decides as if its predecessor had taken its own best non-recycled format (which is
+//                    state-independent): right whenever the predecessor does not recycle.
+//   k_ch_resolve     one wave visits only the blocks that recycle and those behind them (whose assumption was wrong),
+//                    jumping from one tentative recycle to the next, 64 blocks per step.
+//   k_ch_stored      the stored blocks count their pieces (:1024-1038 halves the ATOM range until a piece has < 64 KiB).
+//   k_ch_layout      bit positions: a block maps the position p before it to p + a, a stored block to align8 (p + a) + b
+//                    -- closed under composition, hence a parallel scan; tile and piece numbers; the state for the next
+//                    range; the epilogue.
+//   k_ch_stored_emit BFINAL / BTYPE / LEN / NLEN and the copy list of the stored pieces.
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_choose_lean(uint32_t nblocks, const ChRec *__restrict__ chrec, const BlockInfo *__restrict__ binfo,
-                                                    const uint32_t *__restrict__ apos, EmitRec *__restrict__ emit,
-                                                    StoredPiece *__restrict__ pieces, uint32_t cap_tiles, uint32_t cap_pieces,
-                                                    uint32_t *__restrict__ out32, uint64_t lim_bits, ChooserOut *__restrict__ res,
-                                                    const ChooserCarry *__restrict__ cin, ChooserCarry *__restrict__ cout, uint64_t base_bits,
-                                                    int do_epilogue) {
-  const int lane = threadIdx.x;
-  // the state the blocks before this range left behind (zip-compress-deflate.adb:722, 993-997); a fresh stream starts
-  // with last_block_type = reserved, nothing to finish, nothing marked, bit position 0
-  ChooseState S;
-  S.last_type = cin->last_type; S.block_to_finish = cin->block_to_finish; S.last_marked = cin->last_marked;
-  S.code_block = S.last_type == BT_DYNAMIC ? CODE_CARRIED : CODE_FIXED; S.code_variant = 0;
-  S.pos = cin->pos - base_bits; S.cur_eob = cin->cur_eob;
-  uint32_t ntiles = 0, npieces = 0, overflow = 0;
-  // The records are fetched four blocks ahead, one dword per lane with a vector load (these complete in order, so waiting
-  // for the oldest leaves the newer ones in flight; scalar loads would all be waited for together), and spread into
-  // scalar registers when their block's turn comes: the chain from block to block no longer contains a memory latency.
-  static_assert(sizeof(ChRec) == 128, "one dword per lane (32 lanes)");
-  auto load_rec = [&](uint32_t k) -> uint32_t { const uint32_t kk = k < nblocks ? k : nblocks - 1; return ((const uint32_t *)(chrec + kk))[lane & 31]; };
-  auto body = [&](const uint32_t i, const uint32_t rv) -> bool {         // false: stop (overflow)
-    uint32_t w[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) w[k] = (uint32_t)__builtin_amdgcn_readlane((int)rv, k);
-    ChRec cr;
-    memcpy(&cr, w, sizeof cr);
-    const BlockRange br = cr.br;
-    // recycling (:1223-1226, Recyclable :495-508) and its cost (:1158, 1180, 1189)
-    bool recycling_possible = false; uint64_t recycled_data = 0;
-    if (S.last_type == BT_FIXED) { recycling_possible = true; recycled_data = cr.bits[0]; }
-    else if (S.last_type == BT_DYNAMIC) {
-      if (S.code_block == (int)i - 1) {   // (no indexing by the variant: the record stays in registers)
-        recycling_possible = S.code_variant == 1 ? (cr.ok & 2u) != 0 : (cr.ok & 4u) != 0;
-        recycled_data = S.code_variant == 1 ? cr.bits[1] : cr.bits[2];
-      }
-      else {
-        // the codes in force are older than the previous block (a chain of recycled blocks): evaluate here
-        const BlockInfo *bi = &binfo[i];
-        const uint8_t *cl = S.code_block == CODE_CARRIED ? cin->bl : (S.code_variant == 1 ? binfo[S.code_block].bl1 : binfo[S.code_block].bl2);
-        bool bad = false; uint64_t rc = 0;
-        for (int r = 0; r < 5; r++) {
-          const int s = lane + 64 * r;
-          const int cu = cl[s]; const uint32_t stv = bi->stats[s];
-          if (cu == 0 && bi->bl1[s] > 0) bad = true;
-          if (s < 288) { if (s != 256 && s <= 285) rc += (uint64_t)stv * (uint64_t)(cu + litlen_sym_extra(s)); }
-          else if (s - 288 <= 29) rc += (uint64_t)stv * (uint64_t)(cu + dist_sym_extra(s - 288));
-        }
-        recycling_possible = !__any(bad);
-        { const uint64_t v = wave_sum_u64(rc); recycled_data = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32); }
-      }
-    }
-    const bool finishing = S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC);
-    const uint32_t eob_len = S.cur_eob >> 16;
-    const uint64_t c = 1 + (finishing ? (uint64_t)eob_len : 0);                 // :1198-1201
-    const uint64_t INF = ~0ull;
-    const uint64_t a = cr.base3 + c;                                             // the best of fixed / dynamic / dynamic-RLE
-    const uint64_t st = cr.stored == INF ? INF : cr.stored + c;
-    const uint64_t rb = recycling_possible ? recycled_data : INF;
-    int fmt; uint64_t opt;                                                       // tie order fixed, dynamic, dynamic-RLE, recycled, stored (:1243-1268)
-    if (a <= rb && a <= st) { fmt = (int)cr.fmt3; opt = a; }
-    else if (rb <= st) { fmt = FMT_RECYCLE; opt = rb; }
-    else { fmt = FMT_STORED; opt = st; }
+struct ChW {                      // what the chooser kernels pass on about a block
+  uint64_t rdata;                 // LZ data bits under the codes in force (when the block recycles them)
+  uint32_t eob_in;                // (length << 16) | code of symbol 256 under the codes in force before the block
+  uint8_t dec, T_in, B_in, pad;   // decision FMT_*; last_block_type and block_to_finish before the block
+  int32_t code_block;             // codes in force before the block (for a recycled block: the table it is coded with)
+  uint32_t code_variant;
+  uint32_t npieces;               // stored: pieces of < 64 KiB
+  uint32_t bytes_pad;
+};
+static_assert(sizeof(ChW) == 32, "ChW");
 
-    EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = 0; e.cost_bits = opt; e.fmt = (uint32_t)fmt; e.code_block = CODE_FIXED; e.code_variant = 0; e.tile_base = ntiles;
-    e.pre_pos = 0; e.pre_eob = 0; e.pre_flags = 0;
-    const int last_block = (int)br.last_flush;
-    // Mark_new_block :999-1007 (end-of-block code of the block being finished, then BFINAL), recorded for k_emit_prefix
-    auto open_block = [&](int last_for_stream, uint32_t btype) {
-      e.pre_pos = S.pos;
-      if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) { e.pre_eob = S.cur_eob; S.pos += (uint64_t)(S.cur_eob >> 16); }
-      S.block_to_finish = 1;
-      S.last_marked = last_for_stream;
-      e.pre_flags = 1u | ((uint32_t)last_for_stream << 1) | (btype << 2);
-      S.pos += 3;                                                                // BFINAL + BTYPE
-    };
-    uint64_t data_bits = 0;
-    if (fmt == FMT_FIXED) {
-      if (S.last_type != BT_FIXED) {                                             // Send_fixed_block :1108-1121
-        open_block(last_block, 1);
-        S.last_type = BT_FIXED; S.code_block = CODE_FIXED; S.code_variant = 0; S.cur_eob = 7u << 16;
-      }
-      data_bits = cr.fixed_data;
-    } else if (fmt == FMT_DYN1 || fmt == FMT_DYN2) {                             // Send_dynamic_block :1126-1135
-      open_block(last_block, 2);
-      S.cur_eob = fmt == FMT_DYN1 ? cr.eob[0] : cr.eob[1];
-      e.hdr_bitpos = S.pos;
-      S.pos += (fmt == FMT_DYN1) ? cr.hdr1 : cr.hdr2;
-      S.last_type = BT_DYNAMIC; S.code_block = (int)i; S.code_variant = (fmt == FMT_DYN1) ? 1 : 2;
-      data_bits = (fmt == FMT_DYN1) ? cr.dyn1_data : cr.dyn2_data;
-    } else if (fmt == FMT_RECYCLE) {
-      data_bits = recycled_data;
-    } else {
-      // Expand_LZ_buffer :1010-1062 with its divide-and-conquer on the ATOM range (rare: written here, directly)
-      uint32_t stk_first[40], stk_last[40]; int stk_lastblk[40]; int sp = 0;
-      stk_first[0] = br.first; stk_last[0] = br.first + br.count - 1; stk_lastblk[0] = last_block; sp = 1;
-      while (sp > 0) {
-        sp--;
-        uint32_t f = stk_first[sp], l = stk_last[sp]; int lb = stk_lastblk[sp];
-        uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos[f]), nbytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos[l + 1]) - src;
-        if (nbytes > 0xFFFF) {
-          uint32_t mid = (uint32_t)(((uint64_t)f + (uint64_t)l) / 2);
-          // second half is processed after the first: push it first (LIFO)
-          stk_first[sp] = mid + 1; stk_last[sp] = l; stk_lastblk[sp] = lb; sp++;
-          stk_first[sp] = f; stk_last[sp] = mid; stk_lastblk[sp] = 0; sp++;
-          continue;
-        }
-        if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {      // Mark_new_block
-          const int ll = (int)(S.cur_eob >> 16);
-          if (lane == 0) put_bits_lim(out32, lim_bits, S.pos, S.cur_eob & 0xFFFF, ll);
-          S.pos += (uint64_t)ll;
-        }
-        S.block_to_finish = 1;
-        if (lane == 0) put_bits_lim(out32, lim_bits, S.pos, (uint32_t)lb, 1);
-        S.pos += 1;
-        S.last_marked = lb;
-        S.last_type = BT_STORED;
-        S.pos += 2;                                                              // Put_Bits (0, 2)
-        S.pos = (S.pos + 7) & ~7ull;                                             // Flush_bit_buffer
-        if (lane == 0) {
-          put_bits_lim(out32, lim_bits, S.pos, nbytes & 0xFFFF, 16);
-          put_bits_lim(out32, lim_bits, S.pos + 16, (~nbytes) & 0xFFFF, 16);
-          if (npieces < cap_pieces) { StoredPiece pc; pc.dst_byte = (S.pos >> 3) + 4; pc.src_byte = src; pc.nbytes = nbytes; pieces[npieces] = pc; }
-        }
-        if (npieces >= cap_pieces) overflow = 1;
-        npieces++;
-        S.pos += 32 + 8ull * nbytes;
-      }
+__device__ __forceinline__ uint32_t ch_nonrec(const ChRec &r) { return r.base3 <= r.stored ? r.fmt3 : (uint32_t)FMT_STORED; }   // (a <= st <=> base3 <= stored: same c)
+
+// the decision of :1243-1268 given the costs; tie order fixed / dynamic / dynamic-RLE (inside base3), recycled, stored
+__device__ __forceinline__ uint32_t ch_decide(const ChRec &r, uint64_t c, uint64_t rb) {
+  const uint64_t INF = ~0ull;
+  const uint64_t a = r.base3 + c, st = r.stored == INF ? INF : r.stored + c;
+  if (a <= rb && a <= st) return r.fmt3;
+  return rb <= st ? (uint32_t)FMT_RECYCLE : (uint32_t)FMT_STORED;
+}
+
+__global__ void __launch_bounds__(256) k_ch_tentative(uint32_t nblocks, const ChRec *__restrict__ chrec, ChW *__restrict__ chw) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblocks) return;
+  ChW w; w.rdata = 0; w.eob_in = 7u << 16; w.dec = 0xFF; w.T_in = BT_RESERVED; w.B_in = 1; w.pad = 0; w.code_block = CODE_FIXED; w.code_variant = 0; w.npieces = 0; w.bytes_pad = 0;
+  if (i > 0) {
+    const ChRec r = chrec[i], pr = chrec[i - 1];
+    const uint32_t pn = ch_nonrec(pr);
+    const uint64_t INF = ~0ull;
+    uint64_t rb = INF, c = 1;
+    if (pn == FMT_FIXED) { w.T_in = BT_FIXED; w.eob_in = 7u << 16; w.code_block = CODE_FIXED; rb = r.bits[0]; c += 7; }
+    else if (pn == FMT_STORED) { w.T_in = BT_STORED; }
+    else {
+      const int v = pn == FMT_DYN1 ? 1 : 2;
+      w.T_in = BT_DYNAMIC; w.eob_in = pr.eob[v - 1]; w.code_block = (int32_t)(i - 1); w.code_variant = (uint32_t)v;
+      if ((r.ok >> v) & 1u) rb = r.bits[v];
+      c += (uint64_t)(w.eob_in >> 16);
     }
-    if (fmt != FMT_STORED) {
-      e.data_bitpos = S.pos;
-      e.code_block = S.code_block; e.code_variant = (uint32_t)S.code_variant;
-      S.pos += data_bits;
-      const uint32_t nt = (br.count + TILE - 1) / TILE;
-      if (ntiles + nt > cap_tiles) { overflow = 1; return false; }
-      ntiles += nt;
-    }
-    if (lane == 0) emit[i] = e;
-      return true;
+    w.dec = (uint8_t)ch_decide(r, c, rb);
+    w.rdata = rb;
+  }
+  chw[i] = w;                      // (block 0 is decided by k_ch_resolve, from the state the range before left behind)
+}
+
+__global__ void __launch_bounds__(64) k_ch_resolve(uint32_t nblocks, const ChRec *__restrict__ chrec, const BlockInfo *__restrict__ binfo,
+                                                   ChW *__restrict__ chw, const ChooserCarry *__restrict__ cin) {
+  const int lane = threadIdx.x;
+  if (nblocks == 0) return;
+  // actual state (uniform over the wave)
+  int T = cin->last_type, B = cin->block_to_finish;
+  uint32_t eob = cin->cur_eob;
+  int code_block = T == BT_DYNAMIC ? CODE_CARRIED : CODE_FIXED, code_variant = 0;
+  const uint64_t INF = ~0ull;
+  auto out_state = [&](uint32_t k) {                 // the state block k leaves behind when it does not recycle
+    const ChRec r = chrec[k];
+    const uint32_t f = ch_nonrec(r);
+    B = 1;
+    if (f == FMT_FIXED) { T = BT_FIXED; eob = 7u << 16; code_block = CODE_FIXED; code_variant = 0; }
+    else if (f == FMT_STORED) { T = BT_STORED; }
+    else { T = BT_DYNAMIC; code_variant = f == FMT_DYN1 ? 1 : 2; eob = r.eob[code_variant - 1]; code_block = (int)k; }
   };
-  if (nblocks > 0) {
-    uint32_t r0 = load_rec(0), r1 = load_rec(1), r2 = load_rec(2), r3 = load_rec(3);
-    bool go = true;
-    for (uint32_t i = 0; go && i < nblocks; i += 4) {
-      go = body(i, r0); r0 = load_rec(i + 4);
-      if (go && i + 1 < nblocks) go = body(i + 1, r1);
-      r1 = load_rec(i + 5);
-      if (go && i + 2 < nblocks) go = body(i + 2, r2);
-      r2 = load_rec(i + 6);
-      if (go && i + 3 < nblocks) go = body(i + 3, r3);
-      r3 = load_rec(i + 7);
+  uint32_t i = 0;
+  bool need_eval = true;
+  while (i < nblocks) {
+    uint32_t dec;
+    if (need_eval) {
+      // Send_as_block's decision for block i with the actual state
+      const ChRec r = chrec[i];
+      uint64_t rb = INF;
+      if (T == BT_FIXED) rb = r.bits[0];
+      else if (T == BT_DYNAMIC) {
+        if (code_block == (int)i - 1) { if ((r.ok >> code_variant) & 1u) rb = r.bits[code_variant]; }
+        else {
+          // the codes in force are older than the previous block (a chain of recycled blocks, or carried over): evaluate here
+          const BlockInfo *bi = &binfo[i];
+          const uint8_t *cl = code_block == CODE_CARRIED ? cin->bl : (code_variant == 1 ? binfo[code_block].bl1 : binfo[code_block].bl2);
+          bool bad = false; uint64_t rc = 0;
+          for (int q = 0; q < 5; q++) {
+            const int s = lane + 64 * q;
+            const int cu = cl[s]; const uint32_t stv = bi->stats[s];
+            if (cu == 0 && bi->bl1[s] > 0) bad = true;                           // Recyclable :495-508
+            if (s < 288) { if (s != 256 && s <= 285) rc += (uint64_t)stv * (uint64_t)(cu + litlen_sym_extra(s)); }
+            else if (s - 288 <= 29) rc += (uint64_t)stv * (uint64_t)(cu + dist_sym_extra(s - 288));
+          }
+          rc = wave_sum_u64(rc);
+          if (!__any(bad)) rb = rc;
+        }
+      }
+      const bool finishing = B && (T == BT_FIXED || T == BT_DYNAMIC);
+      const uint64_t c = 1 + (finishing ? (uint64_t)(eob >> 16) : 0);               // :1198-1201
+      dec = ch_decide(r, c, rb);
+      if (lane == 0) {
+        ChW w; w.rdata = rb; w.eob_in = eob; w.dec = (uint8_t)dec; w.T_in = (uint8_t)T; w.B_in = (uint8_t)B; w.pad = 0;
+        w.code_block = code_block; w.code_variant = (uint32_t)code_variant; w.npieces = 0; w.bytes_pad = 0;
+        chw[i] = w;
+      }
+    } else dec = FMT_RECYCLE;
+    if (dec != FMT_RECYCLE) {
+      // from here the tentative decisions hold up to and including the next block that recycles
+      uint32_t j = nblocks;
+      for (uint32_t b0 = i + 1; b0 < nblocks && j == nblocks; b0 += 64) {
+        const uint32_t k = b0 + (uint32_t)lane;
+        const bool rcy = k < nblocks && chw[k].dec == FMT_RECYCLE;
+        const unsigned long long m = __ballot(rcy);
+        if (m) j = b0 + (uint32_t)(__ffsll((long long)m) - 1);
+      }
+      if (j == nblocks) break;
+      out_state(j - 1);                              // (j - 1 does not recycle: its own best format, as block j assumed)
+      i = j; need_eval = false;
+    } else {
+      i++; need_eval = true;                         // the state goes through a recycled block unchanged
     }
+  }
+}
+
+// pieces of a stored block: Expand_LZ_buffer halves the ATOM range while it holds more than 65 535 bytes (:1024-1038)
+template <typename F>
+__device__ __forceinline__ uint32_t ch_stored_walk(const uint32_t *__restrict__ apos, uint32_t first, uint32_t count, int last_block, F &&piece) {
+  uint32_t stk_first[40], stk_last[40]; int stk_lb[40]; int sp = 0;
+  uint32_t np = 0;
+  stk_first[0] = first; stk_last[0] = first + count - 1; stk_lb[0] = last_block; sp = 1;
+  while (sp > 0) {
+    sp--;
+    const uint32_t f = stk_first[sp], l = stk_last[sp]; const int lb = stk_lb[sp];
+    const uint32_t src = apos[f], nbytes = apos[l + 1] - src;
+    if (nbytes > 0xFFFF) {
+      const uint32_t mid = (uint32_t)(((uint64_t)f + (uint64_t)l) / 2);
+      stk_first[sp] = mid + 1; stk_last[sp] = l; stk_lb[sp] = lb; sp++;          // the second half comes after the first: pushed first
+      stk_first[sp] = f; stk_last[sp] = mid; stk_lb[sp] = 0; sp++;
+      continue;
+    }
+    piece(np, src, nbytes, lb);
+    np++;
+  }
+  return np;
+}
+
+__global__ void __launch_bounds__(64) k_ch_stored(uint32_t nblocks, const ChRec *__restrict__ chrec, const uint32_t *__restrict__ apos, ChW *__restrict__ chw) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblocks || chw[i].dec != FMT_STORED) return;
+  const BlockRange br = chrec[i].br;
+  chw[i].npieces = ch_stored_walk(apos, br.first, br.count, (int)br.last_flush, [](uint32_t, uint32_t, uint32_t, int) {});
+}
+
+// position transform of a block: kind 0: p -> p + a; kind 1: p -> align8 (p + a) + b
+struct PosFn { uint64_t a, b; uint32_t kind; };
+__device__ __forceinline__ PosFn posfn_compose(const PosFn &f, const PosFn &g) {   // first f, then g
+  PosFn h;
+  if (g.kind == 0) { h.kind = f.kind; h.a = f.kind ? f.a : f.a + g.a; h.b = f.kind ? f.b + g.a : 0; }
+  else if (f.kind == 0) { h.kind = 1; h.a = f.a + g.a; h.b = g.b; }
+  else { h.kind = 1; h.a = f.a; h.b = ((f.b + g.a + 7) & ~7ull) + g.b; }
+  return h;
+}
+__device__ __forceinline__ uint64_t posfn_apply(const PosFn &f, uint64_t p) { return f.kind ? ((p + f.a + 7) & ~7ull) + f.b : p + f.a; }
+
+__global__ void __launch_bounds__(1024) k_ch_layout(uint32_t nblocks, const ChRec *__restrict__ chrec, const BlockInfo *__restrict__ binfo, const ChW *__restrict__ chw,
+                                                    EmitRec *__restrict__ emit, uint32_t *__restrict__ piece_base, uint32_t cap_tiles, uint32_t cap_pieces,
+                                                    uint32_t *__restrict__ out32, uint64_t lim_bits, ChooserOut *__restrict__ res,
+                                                    const ChooserCarry *__restrict__ cin, ChooserCarry *__restrict__ cout, uint64_t base_bits, int do_epilogue) {
+  __shared__ PosFn wfn[16];
+  __shared__ uint32_t wtiles[16], wpieces[16], wlast[16];
+  __shared__ uint64_t s_pos; __shared__ uint32_t s_tiles, s_pieces, s_last;      // carried from tile to tile
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) { s_pos = cin->pos - base_bits; s_tiles = 0; s_pieces = 0; s_last = 0xFFFFFFFFu; }
+  __syncthreads();
+  for (uint32_t t0 = 0; t0 < nblocks; t0 += 1024) {
+    const uint32_t i = t0 + (uint32_t)tid;
+    const bool ex = i < nblocks;
+    PosFn f; f.kind = 0; f.a = 0; f.b = 0;
+    uint32_t nt = 0, np = 0, opener = 0xFFFFFFFFu;
+    ChRec r; ChW cw;
+    uint64_t pre_bits = 0, hdr = 0, data = 0, opt = 0;
+    bool opens = false;
+    if (ex) {
+      r = chrec[i]; cw = chw[i];
+      const bool fin = cw.B_in && (cw.T_in == BT_FIXED || cw.T_in == BT_DYNAMIC);
+      const uint64_t eobl = fin ? (uint64_t)(cw.eob_in >> 16) : 0;
+      const uint64_t c = 1 + eobl;
+      if (cw.dec == FMT_STORED) {
+        np = cw.npieces;
+        // piece 1: [end-of-block code] BFINAL, BTYPE, pad, LEN, NLEN, bytes; every further piece starts byte aligned: 8 + 32 bits + bytes
+        f.kind = 1; f.a = eobl + 3; f.b = 32ull * np + 8ull * (np - 1) + 8ull * binfo[i].bytes;
+        opt = r.stored + c; opener = i;
+      } else {
+        nt = (r.br.count + TILE - 1) / TILE;
+        if (cw.dec == FMT_RECYCLE) { data = cw.rdata; opt = cw.rdata; }
+        else if (cw.dec == FMT_FIXED) { opens = cw.T_in != BT_FIXED; data = r.fixed_data; opt = r.base3 + c; }      // Send_fixed_block :1108-1121
+        else { opens = true; hdr = cw.dec == FMT_DYN1 ? r.hdr1 : r.hdr2; data = cw.dec == FMT_DYN1 ? r.dyn1_data : r.dyn2_data; opt = r.base3 + c; }
+        if (opens) { pre_bits = eobl + 3; opener = i; }
+        f.a = pre_bits + hdr + data;
+      }
+    }
+    // inclusive scans over the tile: position transforms (composition), tiles, pieces, last block that opened a Deflate block
+    PosFn inc = f; uint32_t it = nt, ip = np, il = opener;
+    for (int off = 1; off < 64; off <<= 1) {
+      PosFn o; o.a = __shfl_up(inc.a, off); o.b = __shfl_up(inc.b, off); o.kind = __shfl_up(inc.kind, off);
+      const uint32_t ot = __shfl_up(it, off), op = __shfl_up(ip, off), ol = __shfl_up(il, off);
+      if (lane >= off) { inc = posfn_compose(o, inc); it += ot; ip += op; il = il == 0xFFFFFFFFu ? ol : il; }
+    }
+    if (lane == 63) { wfn[w] = inc; wtiles[w] = it; wpieces[w] = ip; }
+    {
+      // last opener of the wave: highest lane with one
+      const unsigned long long m = __ballot(opener != 0xFFFFFFFFu);
+      if (lane == 0) wlast[w] = m ? t0 + (uint32_t)(w * 64 + 63 - __builtin_clzll(m)) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    PosFn before; before.kind = 0; before.a = 0; before.b = 0;
+    uint32_t tb = 0, pb = 0;
+    for (int k = 0; k < w; k++) { before = posfn_compose(before, wfn[k]); tb += wtiles[k]; pb += wpieces[k]; }
+    // exclusive within the wave: shift the inclusive values by one lane
+    PosFn exl; exl.a = __shfl_up(inc.a, 1); exl.b = __shfl_up(inc.b, 1); exl.kind = __shfl_up(inc.kind, 1);
+    uint32_t ext = __shfl_up(it, 1), exp_ = __shfl_up(ip, 1);
+    if (lane == 0) { exl.kind = 0; exl.a = 0; exl.b = 0; ext = 0; exp_ = 0; }
+    const PosFn upto = posfn_compose(before, exl);
+    const uint64_t p0 = posfn_apply(upto, s_pos);                   // bit position before this block
+    const uint32_t tile0 = s_tiles + tb + ext, piece0 = s_pieces + pb + exp_;
+    if (ex) {
+      EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = 0; e.cost_bits = opt; e.fmt = cw.dec; e.code_block = CODE_FIXED; e.code_variant = 0; e.tile_base = tile0;
+      e.pre_pos = 0; e.pre_eob = 0; e.pre_flags = 0;
+      if (cw.dec == FMT_STORED) {
+        e.pre_pos = p0;                                              // (k_ch_stored_emit starts here)
+        e.pre_eob = (cw.B_in && (cw.T_in == BT_FIXED || cw.T_in == BT_DYNAMIC)) ? cw.eob_in : 0u;
+        piece_base[i] = piece0;
+      } else {
+        if (opens) {
+          e.pre_pos = p0;
+          e.pre_eob = (cw.B_in && (cw.T_in == BT_FIXED || cw.T_in == BT_DYNAMIC)) ? cw.eob_in : 0u;
+          e.pre_flags = 1u | (r.br.last_flush << 1) | ((cw.dec == FMT_FIXED ? 1u : 2u) << 2);
+        }
+        e.hdr_bitpos = p0 + pre_bits;
+        e.data_bitpos = p0 + pre_bits + hdr;
+        if (cw.dec == FMT_RECYCLE || (cw.dec == FMT_FIXED && !opens)) { e.code_block = cw.code_block; e.code_variant = cw.code_variant; }
+        else if (cw.dec == FMT_FIXED) { e.code_block = CODE_FIXED; e.code_variant = 0; }
+        else { e.code_block = (int32_t)i; e.code_variant = cw.dec == FMT_DYN1 ? 1u : 2u; }
+      }
+      emit[i] = e;
+    }
+    __syncthreads();
+    if (tid == 1023) {                                               // totals of the tile -> carried state
+      const PosFn all = posfn_compose(before, inc);
+      s_pos = posfn_apply(all, s_pos); s_tiles += tb + it; s_pieces += pb + ip;
+    }
+    if (tid == 0) { for (int k = 15; k >= 0; k--) if (wlast[k] != 0xFFFFFFFFu) { s_last = wlast[k]; break; } }
+    __syncthreads();
+  }
+  // the state after the range (uniform values: every lane computes them)
+  uint64_t pos = s_pos;
+  int T = cin->last_type, B = cin->block_to_finish, M = cin->last_marked;
+  uint32_t eob = cin->cur_eob;
+  const uint8_t *cl = T == BT_DYNAMIC ? cin->bl : nullptr;
+  if (s_last != 0xFFFFFFFFu) {
+    const uint32_t k = s_last;
+    const uint32_t dec = chw[k].dec;
+    const ChRec r = chrec[k];
+    B = 1; M = (int)r.br.last_flush; cl = nullptr;
+    if (dec == FMT_STORED) T = BT_STORED;
+    else if (dec == FMT_FIXED) { T = BT_FIXED; eob = 7u << 16; }
+    else { T = BT_DYNAMIC; eob = r.eob[dec == FMT_DYN1 ? 0 : 1]; cl = dec == FMT_DYN1 ? binfo[k].bl1 : binfo[k].bl2; }
+    if (dec == FMT_STORED) eob = chw[k].eob_in;                     // (cur_eob is not touched by a stored block)
   }
   // stream epilogue, Encode :1613-1635 (by the range that owns the stream's last flush)
   if (do_epilogue) {
-    if (S.block_to_finish && (S.last_type == BT_FIXED || S.last_type == BT_DYNAMIC)) {
-      const int l = (int)(S.cur_eob >> 16);
-      if (lane == 0) put_bits_lim(out32, lim_bits, S.pos, S.cur_eob & 0xFFFF, l);
-      S.pos += (uint64_t)l;
+    if (B && (T == BT_FIXED || T == BT_DYNAMIC)) {
+      if (tid == 0) put_bits_lim(out32, lim_bits, pos, eob & 0xFFFF, (int)(eob >> 16));
+      pos += (uint64_t)(eob >> 16);
     }
-    if (!S.last_marked) {
-      if (lane == 0) { put_bits_lim(out32, lim_bits, S.pos, 1, 1); put_bits_lim(out32, lim_bits, S.pos + 1, 1, 2); }
-      S.pos += 3 + 7;                                                            // fake final fixed block: EOB = 0000000
-    }
-  }
-  if (lane == 0) { res->total_bits = S.pos; res->n_tiles = ntiles; res->n_pieces = npieces; res->n_blocks = nblocks; res->overflow = overflow; }
-  // the state for the range that follows
-  {
-    const uint8_t *cl = nullptr;
-    if (S.last_type == BT_DYNAMIC) cl = S.code_block == CODE_CARRIED ? cin->bl : (S.code_variant == 1 ? binfo[S.code_block].bl1 : binfo[S.code_block].bl2);
-    for (int r = 0; r < 5; r++) cout->bl[lane + 64 * r] = cl ? cl[lane + 64 * r] : (uint8_t)0;
-    if (lane == 0) {
-      cout->pos = S.pos + base_bits; cout->last_type = S.last_type; cout->block_to_finish = S.block_to_finish; cout->last_marked = S.last_marked;
-      cout->cur_eob = S.cur_eob; cout->pad[0] = cout->pad[1] = 0;
+    if (!M) {
+      if (tid == 0) { put_bits_lim(out32, lim_bits, pos, 1, 1); put_bits_lim(out32, lim_bits, pos + 1, 1, 2); }
+      pos += 3 + 7;                                                            // fake final fixed block: EOB = 0000000
     }
   }
+  if (tid < 320) cout->bl[tid] = cl ? cl[tid] : (uint8_t)0;
+  if (tid == 0) {
+    res->total_bits = pos; res->n_tiles = s_tiles; res->n_pieces = s_pieces; res->n_blocks = nblocks;
+    res->overflow = (s_tiles > cap_tiles || s_pieces > cap_pieces) ? 1u : 0u;
+    cout->pos = pos + base_bits; cout->last_type = T; cout->block_to_finish = B; cout->last_marked = M; cout->cur_eob = eob; cout->pad[0] = cout->pad[1] = 0;
+  }
+}
+
+// the stored blocks' headers and copy list, one lane per stored block (Mark_new_block + :1040-1051 for every piece)
+__global__ void __launch_bounds__(64) k_ch_stored_emit(uint32_t nblocks, const ChRec *__restrict__ chrec, const ChW *__restrict__ chw, const EmitRec *__restrict__ emit,
+                                                       const uint32_t *__restrict__ piece_base, const uint32_t *__restrict__ apos,
+                                                       StoredPiece *__restrict__ pieces, uint32_t *__restrict__ out32, uint64_t lim_bits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblocks || chw[i].dec != FMT_STORED) return;
+  const BlockRange br = chrec[i].br;
+  const EmitRec e = emit[i];
+  uint64_t pos = e.pre_pos;
+  const uint32_t pb = piece_base[i];
+  bool first = true;
+  ch_stored_walk(apos, br.first, br.count, (int)br.last_flush, [&](uint32_t k, uint32_t src, uint32_t nbytes, int lb) {
+    if (first && e.pre_eob) { put_bits_lim(out32, lim_bits, pos, e.pre_eob & 0xFFFF, (int)(e.pre_eob >> 16)); pos += e.pre_eob >> 16; }
+    first = false;
+    put_bits_lim(out32, lim_bits, pos, (uint32_t)lb, 1);                       // Mark_new_block: BFINAL; then BTYPE 00
+    pos += 3;
+    pos = (pos + 7) & ~7ull;                                                   // Flush_bit_buffer
+    put_bits_lim(out32, lim_bits, pos, nbytes & 0xFFFF, 16);
+    put_bits_lim(out32, lim_bits, pos + 16, (~nbytes) & 0xFFFF, 16);
+    StoredPiece pc; pc.dst_byte = (pos >> 3) + 4; pc.src_byte = src; pc.nbytes = nbytes;
+    pieces[pb + k] = pc;
+    pos += 32 + 8ull * nbytes;
+  });
 }
 
 // What k_choose_lean left out, one thread per block: the bits in front of a block that opens a new Deflate block (end-of-
@@ -846,7 +986,14 @@ int entropy_choose(Ctx *c) {
                        (uint32_t *)W.out, lim_bits, W.chooser, W.carry, W.carry + 1, R.base_bits, R.G == 0 ? 1 : 0, v.stream_final ? 1 : 0);
   else {
     const int do_epilogue = v.stream_final && (v.nflush > 0 || R.T_total == 0);
-    hipLaunchKernelGGL(k_choose_lean, dim3(1), dim3(64), 0, st, R.nblocks, (const ChRec *)W.chrec, W.binfo, v.apos, W.emit, W.pieces,
+    const uint32_t nb = R.nblocks;
+    ChW *chw = (ChW *)W.chw;
+    if (nb > 0) {
+      hipLaunchKernelGGL(k_ch_tentative, dim3((nb + 255) / 256), dim3(256), 0, st, nb, (const ChRec *)W.chrec, chw);
+      hipLaunchKernelGGL(k_ch_resolve, dim3(1), dim3(64), 0, st, nb, (const ChRec *)W.chrec, W.binfo, chw, W.carry);
+      hipLaunchKernelGGL(k_ch_stored, dim3((nb + 63) / 64), dim3(64), 0, st, nb, (const ChRec *)W.chrec, v.apos, chw);
+    }
+    hipLaunchKernelGGL(k_ch_layout, dim3(1), dim3(1024), 0, st, nb, (const ChRec *)W.chrec, W.binfo, chw, W.emit, W.piece_base,
                        (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, lim_bits, W.chooser, W.carry, W.carry + 1, R.base_bits, do_epilogue);
   }
   hipMemcpyAsync(&R.co, W.chooser, sizeof(ChooserOut), hipMemcpyDeviceToHost, st);
@@ -879,7 +1026,11 @@ int entropy_emit(Ctx *c, uint8_t *d_out) {
     hipLaunchKernelGGL(k_emit_tiles, dim3(co.n_tiles), dim3(256), 0, st, nblocks, v.atoms, W.blocks, W.emit, W.tile_block, W.codes, W.tile_bitpos, (uint32_t *)W.out);
   }
   if (nblocks > 0 && !fixed_only) hipLaunchKernelGGL(k_emit_headers, dim3(nblocks), dim3(64), 0, st, nblocks, W.emit, W.binfo, (uint32_t *)W.out);
-  if (co.n_pieces > 0) hipLaunchKernelGGL(k_copy_pieces, dim3(co.n_pieces, 16), dim3(256), 0, st, co.n_pieces, W.pieces, R.rin, W.out);
+  if (co.n_pieces > 0) {
+    hipLaunchKernelGGL(k_ch_stored_emit, dim3((nblocks + 63) / 64), dim3(64), 0, st, nblocks, (const ChRec *)W.chrec, (const ChW *)W.chw, W.emit, W.piece_base, v.apos,
+                       W.pieces, (uint32_t *)W.out, W.cap_out * 8);
+    hipLaunchKernelGGL(k_copy_pieces, dim3(co.n_pieces, 16), dim3(256), 0, st, co.n_pieces, W.pieces, R.rin, W.out);
+  }
   if (d_out) hipMemcpyAsync(d_out, W.out, (co.total_bits + 7) / 8, hipMemcpyDeviceToDevice, st);
   c->tmark("emit");
   return hip_check(c, hipGetLastError(), "entropy_emit");

@@ -142,6 +142,8 @@ struct Workspace {
   BlockInfo *binfo = nullptr;
   EmitRec *emit = nullptr;
   uint64_t *chrec = nullptr;                 // ChRec[nblocks] (128 B each)
+  uint64_t *chw = nullptr;                   // ChW[nblocks] (32 B each): the chooser's per-block results
+  uint32_t *piece_base = nullptr;            // first piece of a stored block
   uint32_t *codes = nullptr;                 // [nblocks+2][320]  (len << 16 | code); the last two = fixed table, carried table
   StoredPiece *pieces = nullptr;
   uint32_t *tile_block = nullptr;            // tile -> block
