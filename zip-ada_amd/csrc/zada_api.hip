@@ -330,6 +330,18 @@ constexpr uint32_t SHARD_HALO = 32768, SHARD_TAIL = 4096;
 constexpr uint64_t RANGE_POST = 1u << 20;    // bytes to keep resident behind a range: the look-ahead atoms of a block that may be
                                              // stored are at most 65 535 x 14 bytes (:1093-1095, 1222)
 
+// the shard's bytes into the LZ buffer: 16 bytes per lane, four loads in flight (the runtime's copy kernel reaches a
+// third of this)
+__global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n16) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 struct PadArgs { uint8_t *in_end; uint32_t n_in; uint16_t *link_end[NLEVELS]; };
 __global__ void k_pad_init(PadArgs a) {
   for (uint32_t i = threadIdx.x; i < a.n_in; i += blockDim.x) a.in_end[i] = 0;
@@ -394,7 +406,11 @@ int range_lz(Ctx *c, const GlobalState *entry, zada_feedback_fn fb, void *user) 
     const uint64_t nbuf = H + (s_hi - s_lo) + tail;
     const uint64_t boff = R.pre + s_lo - H;                     // the buffer's first byte in rin
     const uint64_t gbuf = R.lo + s_lo - H;                      // ... and in the stream
-    hipMemcpyAsync(W.in, R.rin + boff, nbuf, hipMemcpyDeviceToDevice, st);
+    // (boff is a multiple of 32 KiB and rin 16-byte aligned; the last 16-byte piece may read up to 15 bytes of the resident
+    // tail / allocation slack behind the buffer, which the pad kernel below overwrites with zeros)
+    if (nbuf >= (1u << 20) && (R.pre + R.n + R.post) - boff >= ((nbuf + 15) & ~15ull))
+      hipLaunchKernelGGL(k_copy16, dim3(4096), dim3(256), 0, st, (const uint4 *)(R.rin + boff), (uint4 *)W.in, (nbuf + 15) / 16);
+    else hipMemcpyAsync(W.in, R.rin + boff, nbuf, hipMemcpyDeviceToDevice, st);
     {
       // zero pad behind the buffer and behind the link planes: one small launch
       PadArgs pa; pa.in_end = W.in + nbuf; pa.n_in = IN_PAD;

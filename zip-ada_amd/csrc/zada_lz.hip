@@ -143,7 +143,8 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
 // with the positions so that nothing is gathered from global memory), turn the sorted order into
 // position-indexed links P in LDS, then walk those links position-parallel against the segment's bytes
 // (also in LDS); every output plane is written with coalesced stores.
-constexpr uint32_t DIST3_CONTINUE = 0xFFFF;
+constexpr uint32_t DIST3_CONTINUE = 0xFFFF, DISTL_CONTINUE = 0x8000;
+static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
@@ -339,7 +340,13 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       // farther away is dropped by the parser anyway (lz77.adb:867-871) and any longer match is found through the levels
       // above, so plane d[0] holds the nearest three-byte match within 4096, or none (0), or MAX_DIST for the one candidate
       // the reference accepts at exactly that distance (the head of the 15-bit chain, :850 vs :820; k_cross_dist).
-      auto dflt_of = [&](uint32_t e) -> uint32_t { return (seg > 0 && (lvl > 0 || e < (uint32_t)TOO_FAR)) ? DIST3_CONTINUE : 0u; };
+      // Levels >= 4 say where to continue: the chain ended at q, the first member of the bucket in this segment, whose link
+      // k_cross_links will point into the previous segment (0x8000 | e - q; distances proper stay below 0x8000).
+      auto dflt_of = [&](uint32_t e, uint32_t q) -> uint32_t {
+        if (seg == 0) return 0u;
+        if (lvl == 0) return e < (uint32_t)TOO_FAR ? DIST3_CONTINUE : 0u;
+        return DISTL_CONTINUE | (e - q);
+      };
       constexpr uint32_t QCAP = 4000;
       uint32_t *Qa = (uint32_t *)(smem + 32800), *Qb = Qa + QCAP;   // behind the 32 784 staged bytes
       uint32_t *qn = wsum;
@@ -350,7 +357,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       auto walk = [&](uint32_t e, uint32_t &q, uint64_t mine, uint32_t maxs, uint32_t &dl) -> bool {
         uint32_t step = P[q];
         for (uint32_t sidx = 0; sidx < maxs; sidx++) {
-          if (step == 0) { dl = dflt_of(e); return true; }
+          if (step == 0) { dl = dflt_of(e, q); return true; }
           q -= step;
           const uint32_t dist = e - q;
           step = P[q];                                              // next link and this candidate's bytes in one LDS round trip
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const uint32_t e = ee[j], step = st[j];
-          uint32_t dl = dflt_of(e), q = e;
+          uint32_t dl = dflt_of(e, e), q = e;
           bool pend = false;
           if (ex[j] && step != 0) {
             q = e - step;
@@ -434,7 +441,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
             uint64_t th[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              if (act[j] && st4[j] == 0) { dl4[j] = dflt_of(e4[j]); act[j] = false; }           // the chain ends inside the segment
+              if (act[j] && st4[j] == 0) { dl4[j] = dflt_of(e4[j], q4[j]); act[j] = false; }    // the chain ends inside the segment
               qx[j] = act[j] ? q4[j] - st4[j] : q4[j];
             }
 #pragma unroll
@@ -590,12 +597,13 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 #pragma unroll
   for (int l = 0; l + 1 < NLEVELS; l++) {
     uint32_t dl = dl_first[l];
-    if (dl == DIST3_CONTINUE) {
+    if (dl & DISTL_CONTINUE) {
+      // the chain of p's bucket ended, inside p's segment, at q0 (the bucket's first member there): go on from its link
+      uint64_t q = p - (dl & 0x7FFFu);
       dl = 0;
       {
-        uint64_t q = p;
         const uint64_t mask = (1ull << (8 * (4 + l))) - 1ull;
-        uint32_t d = link_first[l];
+        uint32_t d = q == p ? link_first[l] : (uint32_t)lv.prev[l][q];
         for (;;) {
           if (d == 0) break;
           q -= d;
