@@ -1,14 +1,27 @@
-"""Throughput of many small entries: zada_deflate_batch vs one zada_deflate call per entry."""
+"""Perf probe (GPU box): a batch of 10 000 entries of 16 KiB through zada_deflate_batch against one call per entry and the
+single-thread oracle."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _common import oracle_deflate
 za = importlib.import_module("zip-ada_amd")
 enc = za.Encoder(0)
-mix = za.silesia_mix(64 << 20).tobytes()
-for size, cnt in ((16 << 10, 512), (256 << 10, 128), (4 << 20, 16)):
-    datas = [mix[(i * size) % (len(mix) - size):][:size] for i in range(cnt)]
-    enc.deflate_batch(datas[:8], 10)                       # warm-up (worker contexts, workspaces)
-    t0 = time.time(); single = [enc.deflate(d, 10)[0] for d in datas]; t1 = time.time()
-    res = enc.deflate_batch(datas, 10); t2 = time.time()
-    ok = all(r[1] == s for r, s in zip(res, single))
-    print("%4d entries of %7d B: one call each %.1f MB/s, batch %.1f MB/s, identical %s" % (cnt, size, cnt * size / (t1 - t0) / 1e6, cnt * size / (t2 - t1) / 1e6, ok))
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+mix = za.silesia_mix(count * size).tobytes()
+datas = [mix[i * size:(i + 1) * size] for i in range(count)]
+enc.deflate_batch(datas[:64], 10)
+t0 = time.time(); res = enc.deflate_batch(datas, 10); dt = time.time() - t0
+print("batch: %d entries of %d bytes in %.3f s = %.1f MB/s; phases %s" % (count, size, dt, count * size / dt / 1e6, [(k, round(v, 2)) for k, v in enc.last_timing()]))
+t0 = time.time()
+for d in datas[:200]:
+    enc.deflate(d, 10)
+dt1 = (time.time() - t0) / 200
+print("one call per entry: %.3f ms each = %.1f MB/s" % (dt1 * 1e3, size / dt1 / 1e6))
+t0 = time.time()
+for d in datas[:200]:
+    oracle_deflate(d, 10)
+dto = (time.time() - t0) / 200
+print("oracle, one thread: %.3f ms each = %.1f MB/s  -> batch is %.0fx" % (dto * 1e3, size / dto / 1e6, (count * size / dt) / (size / dto)))
+ok = all(oracle_deflate(datas[i], 10)[1] == res[i][1] for i in range(0, count, max(1, count // 50)))
+print("sampled parity with the oracle:", ok)

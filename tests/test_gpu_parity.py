@@ -269,6 +269,32 @@ def test_batch_of_entries_equals_single_calls(encoder):
             assert rc2 == rc and (rc != 0 or (oref == out and ocrc == crc)), i
 
 
+def test_batch_is_one_launch_sequence_and_bit_exact(encoder):
+    """zada_deflate_batch: many small entries through ONE launch sequence (per-entry layout of the LZ buffer, flush grid,
+    chooser state and output).  Every entry's stream, CRC and return code == the oracle's, for entry sizes around the
+    segment (32 KiB) and flush boundaries, empty and 1-byte entries, incompressible ones and ones with stored blocks."""
+    rng = np.random.default_rng(5)
+    mix = silesia_mix(6 << 20)
+    text = silesia_mix(1 << 20, class_mask=1)
+    datas = [b"", b"a", b"ab" * 5, bytes(rng.integers(0, 256, 5000, dtype=np.uint8)), text[:32768], text[:32767], text[:32769], text[:65536],
+             text[:65537], text[:3], bytes(40000), b"abc" * 20000, mix[:300000], text[:400000],
+             text[:150000] + bytes(rng.integers(0, 256, 100000, dtype=np.uint8)) + text[150000:300000]]
+    off = 0
+    for k in range(300):
+        ln = int(rng.integers(1, 60000))
+        datas.append(bytes(mix[off:off + ln])); off = (off + ln) % (len(mix) - 70000)
+    datas.append(b"")
+    for method in (10, 8):
+        res = encoder.deflate_batch(datas, method)
+        assert len(res) == len(datas)
+        for i, (d, (rc, out, crc)) in enumerate(zip(datas, res)):
+            rc2, ref, crc2 = oracle_deflate(d, method)
+            assert rc == rc2, (i, len(d), method)
+            assert crc == crc2, (i, len(d), method)
+            if rc == 0:
+                assert out == ref, (i, len(d), method)
+
+
 def test_full_size_properties(encoder):
     """BASELINE config C2 size (1 GiB, Deflate_3): properties that do not need the oracle at full size --
     the stream inflates back to the input (independent inflater), CRC equals zlib's, and the first

@@ -102,15 +102,16 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
 }
 
 // Entropy stage: sized for the atoms of one range (worst case one atom per byte) and its output.
-int ensure_entropy_workspace(Ctx *c, uint64_t atoms) {
+int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes) {
   Workspace &W = c->ws;
-  if (W.cap_atoms >= atoms && W.cap_atoms > 0) return 0;
+  if (W.cap_atoms >= atoms && W.cap_flush >= flushes && W.cap_atoms > 0) return 0;
   hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
   free_group(W.en_allocs);
-  W.cap_atoms = 0;
+  W.cap_atoms = 0; W.cap_flush = 0;
   uint64_t cap = atoms < (1u << 20) ? (1u << 20) : atoms;
   cap = (cap + 65535) & ~65535ull;
-  const uint64_t nflush = cap / FLUSH + 3;
+  // flushes: one per 65 536 atoms of a stream; a batch of small entries has (at least) one per entry
+  const uint64_t nflush = (cap / FLUSH > flushes ? cap / FLUSH : flushes + flushes / 4) + 3;
   int rc = 0;
 #define A(ptr, cnt) if (!rc) rc = dalloc(c, W.en_allocs, &W.ptr, (cnt))
   A(ea_atoms, LB_CAP + cap + LA_CAP + 64); A(ea_apos, LB_CAP + cap + LA_CAP + 64);
@@ -128,6 +129,7 @@ int ensure_entropy_workspace(Ctx *c, uint64_t atoms) {
   A(pieces, W.cap_pieces);
   W.cap_tiles = cap / TILE + W.cap_blocks + 64;
   A(tile_block, W.cap_tiles); A(tile_bitpos, W.cap_tiles); A(tile_bits, W.cap_tiles);
+  A(blk_entry, W.cap_blocks + 16);
   A(chooser, 1); A(carry, 2);
   A(scan2, nflush / 1024 + 1024); A(total2, 16);
   for (int l = 0; l < 4; l++) A(crc_lvl[l], (cap >> (4 * l)) / CRC_SUB + 64);
@@ -138,7 +140,25 @@ int ensure_entropy_workspace(Ctx *c, uint64_t atoms) {
   A(out, W.cap_out);
 #undef A
   if (rc) { free_group(W.en_allocs); return rc; }
-  W.cap_atoms = cap;
+  W.cap_atoms = cap; W.cap_flush = nflush - 3;
+  return 0;
+}
+
+int ensure_batch_workspace(Ctx *c, uint64_t entries, uint64_t fslots, uint64_t segs) {
+  Workspace &W = c->ws;
+  if (W.cap_ent >= entries && W.cap_fslots >= fslots && W.cap_bseg >= segs && W.cap_ent > 0) return 0;
+  hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
+  free_group(W.bt_allocs);
+  W.cap_ent = W.cap_fslots = W.cap_bseg = 0;
+  const uint64_t ce = entries + entries / 4 + 1024, cf = fslots + fslots / 4 + 1024, cs = segs + segs / 4 + 1024;
+  int rc = 0;
+#define A(ptr, cnt) if (!rc) rc = dalloc(c, W.bt_allocs, &W.ptr, (cnt))
+  A(ftab, cf); A(ent_out, ce);
+  A(ent_chunk0, ce + 1); A(ent_fl0, ce + 1); A(ent_start, ce + 1); A(ent_len, ce + 1); A(ent_bytes, ce + 1); A(ent_base, ce + 1); A(ent_crc, ce + 1);
+  A(segend, cs + 1);
+#undef A
+  if (rc) { free_group(W.bt_allocs); return rc; }
+  W.cap_ent = ce; W.cap_fslots = cf; W.cap_bseg = cs;
   return 0;
 }
 
@@ -155,7 +175,7 @@ static int ensure_rin(Ctx *c, uint64_t n) {
 }
 
 static void free_workspace(Ctx *c) {
-  free_group(c->ws.allocs); free_group(c->ws.en_allocs);
+  free_group(c->ws.allocs); free_group(c->ws.en_allocs); free_group(c->ws.bt_allocs);
   if (c->ws.rin_own) hipFree(c->ws.rin_own);
   c->ws = Workspace();
 }
@@ -362,7 +382,7 @@ int range_open(Ctx *c, int method, const uint8_t *rin, uint64_t stream_size, uin
   if (pre + n + post >= (1ull << 32) - (1ull << 26)) { c->err = "range too large for one context (4 GiB - 64 MiB): split the stream into ranges"; return ZADA_E_TOO_LARGE; }
   if (((uintptr_t)rin & 15) != 0) { c->err = "range: input must be 16-byte aligned"; return ZADA_E_INVALID; }
   const uint64_t shard = (uint64_t)c->knob_shard_kib << 10;
-  int rc = ensure_entropy_workspace(c, n);
+  int rc = ensure_entropy_workspace(c, n, 0);
   if (!rc) rc = ensure_lz_workspace(c, (n < shard ? n : shard) + SHARD_HALO + SHARD_TAIL);
   if (rc) return rc;
   Range &R = c->rg;
@@ -504,6 +524,163 @@ static int deflate_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uin
   return inefficient ? ZADA_INEFFICIENT : ZADA_OK;
 }
 
+// --------------------------------------------------------------------------------------------
+// Batches of small entries: ONE launch sequence for many independent streams (Zip.Create.Add_Stream is per entry,
+// zip-create.adb:194-297; zipada's usual workload is many small files, tools/zipada.adb:126-134).  Every entry takes whole
+// 32 KiB segments of the LZ buffer (Layout, zada_lz.hip), has its own flush grid, chooser state and place in the output
+// (FlushGeom / EntOut, zada_huff.hip).  The bytes are those of one zada_deflate call per entry.
+// --------------------------------------------------------------------------------------------
+constexpr uint64_t BATCH_ENTRY_MAX = 4ull << 20;      // larger entries fill the GPU well enough by themselves
+constexpr uint64_t BATCH_BYTES_MAX = 512ull << 20;    // slots of one batch (LZ workspace: 55 bytes per byte)
+
+// CRC-32 of every entry (zip-crc_crypto.adb:49-60), one wave per entry: lane j takes the j-th 1/64 of the entry byte by
+// byte from register 0; the pieces are chained with the GF(2) operator "advance by L zero bytes", L being the piece length,
+// built by the wave itself (32 lanes hold its columns; squaring = 32 shuffles).
+__device__ __forceinline__ uint32_t gf2_apply_wave(uint32_t col, uint32_t v, int lane) {       // sum of the columns j with bit j of v set
+  uint32_t x = (lane < 32 && ((v >> lane) & 1u)) ? col : 0u;
+  for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+  return x;
+}
+__device__ __forceinline__ uint32_t gf2_compose_wave(uint32_t a, uint32_t b, int lane) {      // column `lane` of a o b
+  uint32_t r = 0;
+  for (int j = 0; j < 32; j++) { const uint32_t aj = __shfl(a, j); if ((b >> j) & 1u) r ^= aj; }
+  return r;
+}
+__device__ uint32_t gf2_advance_cols(const uint32_t *tab, uint64_t len, int lane) {           // column `lane` of "advance by len zero bytes"
+  uint32_t op = 1u << (lane & 31);
+  op = tab[op & 0xFF] ^ (op >> 8);                                    // one zero byte
+  uint32_t acc = 1u << (lane & 31);                                   // identity
+  while (len) {
+    if (len & 1) acc = gf2_compose_wave(op, acc, lane);
+    op = gf2_compose_wave(op, op, lane);
+    len >>= 1;
+  }
+  return acc;
+}
+__global__ void __launch_bounds__(64) k_batch_crc(uint32_t E, const uint8_t *__restrict__ in, const uint32_t *__restrict__ ent_start, const uint32_t *__restrict__ ent_len,
+                                                  uint32_t *__restrict__ crc_inout) {
+  __shared__ uint32_t tab[256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) { uint32_t l = (uint32_t)i; for (int b = 0; b < 8; b++) l = (l & 1) ? (l >> 1) ^ 0xEDB88320u : l >> 1; tab[i] = l; }
+  __syncthreads();
+  const uint32_t e = blockIdx.x;
+  if (e >= E) return;
+  const uint32_t len = ent_len[e];
+  uint32_t reg = crc_inout[e];
+  if (len == 0) return;
+  const uint32_t L = (len + 63) / 64, ns = (len + L - 1) / L, Llast = len - (ns - 1) * L;      // ns pieces of L bytes, the last of Llast
+  const uint8_t *p = in + ent_start[e];
+  uint32_t raw = 0;
+  if ((uint32_t)lane < ns) {
+    const uint32_t o = (uint32_t)lane * L, k = (uint32_t)lane + 1 == ns ? Llast : L;
+    for (uint32_t i = 0; i < k; i++) raw = tab[(raw ^ p[o + i]) & 0xFF] ^ (raw >> 8);
+  }
+  const uint32_t mL = gf2_advance_cols(tab, L, lane), mLast = Llast == L ? mL : gf2_advance_cols(tab, Llast, lane);
+  for (uint32_t j = 0; j < ns; j++) reg = gf2_apply_wave(j + 1 == ns ? mLast : mL, reg, lane) ^ __shfl(raw, (int)j);
+  if (lane == 0) crc_inout[e] = reg;
+}
+
+static int grow_pinned(void **p, uint64_t *cap, uint64_t need) {
+  if (*cap >= need && *p) return 0;
+  if (*p) hipHostFree(*p);
+  *p = nullptr; *cap = 0;
+  const uint64_t c = need + need / 4 + (1u << 20);
+  if (hipHostMalloc(p, c, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ZADA_E_NOMEM; }
+  *cap = c;
+  return 0;
+}
+
+// entries idx[0 .. E) of the caller's arrays through one launch sequence
+static int batch_core(Ctx *c, int method, const int *idx, uint32_t E, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
+                      const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc_out) {
+  const int level = method_level(method);
+  Workspace &W = c->ws;
+  hipStream_t st = c->stream;
+  // ---- layout
+  std::vector<uint32_t> start(E + 1), fl0(E + 1), chunk0(E + 1), len(E + 1), crc_in(E + 1);
+  uint64_t total = 0, nfs = 0;
+  for (uint32_t e = 0; e < E; e++) {
+    const uint64_t ln = n[idx[e]], slot = ((ln ? ln : 1) + 32767) & ~32767ull;
+    start[e] = (uint32_t)total; len[e] = (uint32_t)ln; chunk0[e] = (uint32_t)(total / PCHUNK); fl0[e] = (uint32_t)nfs;
+    crc_in[e] = crc ? crc[idx[e]] : 0xFFFFFFFFu;
+    total += slot; nfs += ln ? (ln + FLUSH - 1) / FLUSH : 1;
+  }
+  start[E] = (uint32_t)total; fl0[E] = (uint32_t)nfs; chunk0[E] = (uint32_t)(total / PCHUNK); len[E] = 0;
+  const uint32_t nseg = (uint32_t)(total >> 15);
+  int rc = ensure_lz_workspace(c, total + 4096);
+  if (!rc) rc = ensure_entropy_workspace(c, total, nfs);
+  if (!rc) rc = ensure_batch_workspace(c, E, nfs, nseg);
+  if (!rc) rc = grow_pinned((void **)&c->bstage, &c->cap_bstage, total + total / 8 + (1u << 20));
+  const uint64_t tabw = (uint64_t)nseg + 6ull * (E + 1) + 64;
+  uint64_t capw = c->cap_btab * 4;
+  if (!rc) { rc = grow_pinned((void **)&c->btab, &capw, tabw * 4); c->cap_btab = capw / 4; }
+  if (rc) return rc;
+  // ---- pack the entries and the tables (pinned), one copy each
+  uint32_t *t_seg = c->btab, *t_ent = c->btab + nseg;
+  for (uint32_t e = 0; e < E; e++) {
+    if (len[e]) memcpy(c->bstage + start[e], in[idx[e]], len[e]);
+    for (uint32_t s = start[e] >> 15; s < (start[e + 1] >> 15); s++) t_seg[s] = (start[e] + len[e]) | (s == (start[e] >> 15) ? 0x80000000u : 0u);
+  }
+  memcpy(t_ent, chunk0.data(), (E + 1) * 4); memcpy(t_ent + (E + 1), fl0.data(), (E + 1) * 4); memcpy(t_ent + 2 * (E + 1), start.data(), (E + 1) * 4);
+  memcpy(t_ent + 3 * (E + 1), len.data(), (E + 1) * 4); memcpy(t_ent + 4 * (E + 1), crc_in.data(), (E + 1) * 4);
+  c->tbegin(); c->tmark("begin");
+  hipMemcpyAsync(W.in, c->bstage, total, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.segend, t_seg, (size_t)nseg * 4, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.ent_chunk0, t_ent, (size_t)(E + 1) * 4, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.ent_fl0, t_ent + (E + 1), (size_t)(E + 1) * 4, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.ent_start, t_ent + 2 * (E + 1), (size_t)(E + 1) * 4, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.ent_len, t_ent + 3 * (E + 1), (size_t)(E + 1) * 4, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.ent_crc, t_ent + 4 * (E + 1), (size_t)(E + 1) * 4, hipMemcpyHostToDevice, st);
+  {
+    PadArgs pa; pa.in_end = W.in + total; pa.n_in = IN_PAD;
+    for (int l = 0; l < NLEVELS; l++) pa.link_end[l] = W.lprev[l] + (total >= 2 ? total - 2 : 0);
+    hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);
+  }
+  const uint64_t zbytes = total + total / 8 + (1u << 20) < W.cap_out ? total + total / 8 + (1u << 20) : W.cap_out;
+  hipMemsetAsync(W.out, 0, zbytes, c->stream2);
+  hipEventRecord(c->ev_out, c->stream2);
+  // ---- LZ stage of all entries
+  Range &R = c->rg;
+  R = Range();
+  R.open = true; R.batch = true; R.n_entries = E; R.rin = W.in; R.n = total; R.method = method; R.level = level;
+  c->last_nblocks = 0; c->demand_rounds = 0; c->parse_rounds = 0;
+  hipLaunchKernelGGL(k_batch_crc, dim3(E), dim3(64), 0, st, E, W.in, W.ent_start, W.ent_len, W.ent_crc);
+  ShardJob job;
+  job.nbuf = total; job.tok_lo = 0; job.tok_hi = (uint32_t)total; job.final = true; job.entry_known = true; job.entry = ExitState{0, SYNC_F};
+  job.dst_atoms = W.ea_atoms + LB_CAP; job.dst_apos = W.ea_apos + LB_CAP; job.apos_bias = 0; job.cap_atoms = W.cap_atoms; job.segend = W.segend;
+  ShardResult res;
+  rc = lz_shard(c, level, job, &res);
+  if (rc) return rc == -2 ? ZADA_E_NOMEM : rc;
+  R.T = res.ntok; R.T_total = res.ntok; R.G = 0; R.n_lb = R.n_la = 0; R.nflush = (uint32_t)nfs; R.foff = 0; R.j0 = 0; R.placed = true;
+  // ---- entropy stage, every entry a stream of its own
+  rc = batch_geometry(c, E, W.n_changed);            // (lz_shard left the total atom count there)
+  if (!rc) rc = entropy_analyze(c);
+  if (rc) return rc;
+  hipStreamWaitEvent(st, c->ev_out, 0);
+  rc = entropy_choose(c);
+  if (!rc) rc = entropy_emit(c, nullptr);
+  if (rc) return rc;
+  // ---- results: sizes, places, CRCs; then the streams
+  const uint64_t obytes = (R.co.total_bits + 7) / 8;
+  uint32_t *h_bytes = c->btab, *h_base = c->btab + (E + 1), *h_crc = c->btab + 2 * (E + 1);
+  hipMemcpyAsync(h_bytes, W.ent_bytes, (size_t)E * 4, hipMemcpyDeviceToHost, st);
+  hipMemcpyAsync(h_base, W.ent_base, (size_t)E * 4, hipMemcpyDeviceToHost, st);
+  hipMemcpyAsync(h_crc, W.ent_crc, (size_t)E * 4, hipMemcpyDeviceToHost, st);
+  if (obytes) hipMemcpyAsync(c->bstage, W.out, obytes, hipMemcpyDeviceToHost, st);
+  if (hip_check(c, hipStreamSynchronize(st), "batch out")) return ZADA_E_HIP_;
+  c->tmark("end"); c->tend();
+  for (uint32_t e = 0; e < E; e++) {
+    const int i = idx[e];
+    out_len[i] = h_bytes[e];
+    if (crc) crc[i] = h_crc[e];
+    if (h_bytes[e] >= n[i]) { rc_out[i] = ZADA_INEFFICIENT; continue; }       // zip-compress.adb:479-486
+    if (h_bytes[e] > cap[i]) { rc_out[i] = ZADA_E_INVALID; c->err = "output buffer too small"; continue; }
+    memcpy(out[i], c->bstage + h_base[e], h_bytes[e]);
+    rc_out[i] = ZADA_OK;
+  }
+  return 0;
+}
+
 }  // namespace zada
 
 using namespace zada;
@@ -542,6 +719,8 @@ void zada_destroy(zada_ctx *z) {
   hipStreamDestroy(z->c.stream2);
   hipHostFree(z->c.crc_host);
   for (int b = 0; b < 2; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
+  if (z->c.bstage) hipHostFree(z->c.bstage);
+  if (z->c.btab) hipHostFree(z->c.btab);
   hipEventDestroy(z->c.ev_input);
   hipEventDestroy(z->c.ev_out);
   hipStreamDestroy(z->c.stream);
@@ -781,39 +960,37 @@ uint32_t zada_crc32_combine(uint32_t reg, uint32_t raw, uint64_t len) { return c
 int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
                        const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc) {
   if (!z || count < 0) return ZADA_E_INVALID;
-  // A small entry leaves most of the GPU idle (one workgroup per 32 KiB segment in the link stage) and every entry
-  // has its host round trips (the demand loop): entries are therefore taken by a few host threads, each with a
-  // context (stream, workspace) of its own, so that the kernels of different entries run side by side.
-  uint64_t nmax = 0;
-  for (int i = 0; i < count; i++) nmax = n[i] > nmax ? n[i] : nmax;
-  int T = count;                                                   // (default 4: more host threads only contend for the runtime)
-  if (z->c.knob_batch_streams >= 1) T = z->c.knob_batch_streams < count ? z->c.knob_batch_streams : count;
-  if (nmax > (64ull << 20)) T = 1;                              // big entries fill the GPU by themselves
-  while (T > 1 && (int)z->workers.size() < T - 1) {
-    zada_ctx *w = zada_create(z->c.device);
-    if (!w) { T = (int)z->workers.size() + 1; break; }
-    w->c.timing_on = false;
-    z->workers.push_back(w);
-  }
-  for (zada_ctx *w : z->workers) {                                 // the workers follow the owner's knobs
-    w->c.knob_budget = z->c.knob_budget; w->c.knob_max_demand_rounds = z->c.knob_max_demand_rounds; w->c.knob_shard_kib = z->c.knob_shard_kib;
-  }
-  std::atomic<int> next(0), worst(0);
-  std::mutex err_lock;
-  auto work = [&](zada_ctx *ctx) {
-    for (int i; (i = next.fetch_add(1)) < count;) {
-      rc[i] = zada_deflate(ctx, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr);
-      if (rc[i] < 0) { worst.store(rc[i]); if (ctx != z) { std::lock_guard<std::mutex> g(err_lock); z->c.err = ctx->c.err; } }
-    }
+  int prc = prepare(z);
+  if (prc) return prc;
+  Ctx *c = &z->c;
+  int worst = 0;
+  // Entries of up to 4 MiB go through ONE launch sequence, as many at a time as the workspace takes (batch_core); larger
+  // ones fill the GPU by themselves and are compressed one after the other.  (Deflate_Fixed / Deflate_0 entries take the
+  // single-entry path: their front ends have no per-entry layout.)
+  const bool batchable = method == ZADA_DEFLATE_1 || method == ZADA_DEFLATE_2 || method == ZADA_DEFLATE_3;
+  std::vector<int> group;
+  uint64_t gbytes = 0;
+  auto flush_group = [&]() {
+    if (group.empty()) return;
+    int r = group.size() == 1 ? 1 : finish_call(c, batch_core(c, method, group.data(), (uint32_t)group.size(), in, n, out, cap, out_len, crc, rc));
+    if (group.size() == 1 || r == ZADA_E_NOMEM) {            // a single entry, or no room for the batch tables: one by one
+      for (int i : group) { rc[i] = zada_deflate(z, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr); if (rc[i] < 0) worst = rc[i]; }
+    } else if (r < 0) { for (int i : group) rc[i] = r; worst = r; }
+    else { for (int i : group) if (rc[i] < 0) worst = rc[i]; }
+    group.clear(); gbytes = 0;
   };
-  if (T <= 1) work(z);
-  else {
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(work, z->workers[t - 1]);
-    work(z);
-    for (auto &x : th) x.join();
+  for (int i = 0; i < count; i++) {
+    if (batchable && n[i] <= BATCH_ENTRY_MAX) {
+      const uint64_t slot = ((n[i] ? n[i] : 1) + 32767) & ~32767ull;
+      if (gbytes + slot > BATCH_BYTES_MAX) flush_group();
+      group.push_back(i); gbytes += slot;
+    } else {
+      rc[i] = zada_deflate(z, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr);
+      if (rc[i] < 0) worst = rc[i];
+    }
   }
-  return worst.load();
+  flush_group();
+  return worst;
 }
 
 int zada_compress_data(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,

@@ -54,6 +54,21 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
   return v;
 }
 
+// geometry of owned flush j: first atom F, last atom `to`, number in its stream gj; false: empty slot (batches only)
+__device__ __forceinline__ bool flush_geom(const EntropyView &v, uint32_t j, uint32_t &F, uint32_t &to, uint64_t &gj, uint32_t &flags) {
+  if (v.ftab) {
+    const FlushGeom g = v.ftab[j];
+    F = g.F; to = g.to; gj = g.gj; flags = g.flags;
+    return !(g.flags & FG_EMPTY);
+  }
+  F = v.foff + j * FLUSH;
+  to = (F + FLUSH - 1 < v.lvalid - 1) ? F + FLUSH - 1 : v.lvalid - 1;
+  gj = v.j0 + j;
+  // the stream's last flush, if it is not a full one, is sent with last_flush = True (:1613-1623)
+  flags = ((j == v.nflush - 1) && v.stream_final && (v.lvalid - F < FLUSH)) ? (uint32_t)FG_LAST_PARTIAL : 0u;
+  return true;
+}
+
 // --------------------------------------------------------------------------------------------
 // k_window_descr : one wave per (flush segment, slot)
 // --------------------------------------------------------------------------------------------
@@ -63,9 +78,8 @@ __global__ void __launch_bounds__(64) k_window_descr(EntropyView v, uint32_t kst
   __shared__ __attribute__((aligned(16))) uint8_t S[LLHC_WAVE_SCRATCH];
   const uint32_t *__restrict__ atoms = v.atoms;
   const uint32_t slot = blockIdx.x % SLOTS, j = blockIdx.x / SLOTS;       // j: owned flush (local number)
-  const uint64_t gj = v.j0 + j;                                             // its number in the stream
-  const uint32_t F = v.foff + j * FLUSH;                                    // local index of its first atom
-  const uint32_t to = (F + FLUSH - 1 < v.lvalid - 1) ? F + FLUSH - 1 : v.lvalid - 1;
+  uint64_t gj; uint32_t F, to, fl;                                          // its number in the stream, its first and last atom
+  if (!flush_geom(v, j, F, to, gj, fl)) return;
   if (to - F < SLIDER - 1) return;                                  // :1333-1336 short flush: no scanning
   int64_t lo, hi;
   if (slot == 0) { lo = (gj == 0) ? (int64_t)F : (int64_t)F - HALF_SLIDER; hi = lo + SLIDER - 1; }   // :1338-1360
@@ -109,8 +123,8 @@ __global__ void __launch_bounds__(64) k_window_descr(EntropyView v, uint32_t kst
 __global__ void __launch_bounds__(64) k_cut_scan(EntropyView v, uint32_t kstep, const uint8_t *__restrict__ descr,
                                                  uint32_t *__restrict__ seg_nblk, uint32_t *__restrict__ seg_cut, uint32_t *__restrict__ trace) {
   const uint32_t j = blockIdx.x, lane = threadIdx.x;
-  const uint32_t F = v.foff + j * FLUSH;
-  const uint32_t to = (F + FLUSH - 1 < v.lvalid - 1) ? F + FLUSH - 1 : v.lvalid - 1;
+  uint64_t gj; uint32_t F, to, fl;
+  if (!flush_geom(v, j, F, to, gj, fl)) { if (lane == 0) seg_nblk[j] = 0; return; }
   uint32_t *cuts = seg_cut + (uint64_t)j * MAXBLK_PER_SEG;
   uint32_t nb = 0;
   if (lane == 0) cuts[0] = F;
@@ -141,18 +155,22 @@ __global__ void __launch_bounds__(64) k_cut_scan(EntropyView v, uint32_t kstep, 
 }
 
 __global__ void k_fill_blocks(EntropyView v, const uint32_t *__restrict__ seg_nblk, const uint32_t *__restrict__ seg_cut,
-                              const uint32_t *__restrict__ seg_off, BlockRange *__restrict__ blocks) {
+                              const uint32_t *__restrict__ seg_off, BlockRange *__restrict__ blocks, uint32_t *__restrict__ blk_entry) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= v.nflush) return;
-  const uint32_t F = v.foff + j * FLUSH;
-  const uint32_t to = (F + FLUSH - 1 < v.lvalid - 1) ? F + FLUSH - 1 : v.lvalid - 1;
+  uint64_t gj; uint32_t F, to, fl;
+  if (!flush_geom(v, j, F, to, gj, fl)) return;
   const uint32_t nb = seg_nblk[j], off = seg_off[j];
   const uint32_t *cuts = seg_cut + (uint64_t)j * MAXBLK_PER_SEG;
-  // the stream's last flush, if it is not a full one, is sent with last_flush = True (:1613-1623)
-  const bool last_seg_partial = (j == v.nflush - 1) && v.stream_final && (v.lvalid - F < FLUSH);
   for (uint32_t i = 0; i < nb; i++) {
     uint32_t first = cuts[i], end = (i + 1 < nb) ? cuts[i + 1] - 1 : to;
-    BlockRange b; b.first = first; b.count = end - first + 1; b.last_flush = (last_seg_partial && i + 1 == nb) ? 1u : 0u; b.pad = 0;
+    BlockRange b; b.first = first; b.count = end - first + 1; b.pad = 0;
+    b.last_flush = ((fl & FG_LAST_PARTIAL) && i + 1 == nb) ? (uint32_t)BR_LAST_FLUSH : 0u;
+    if (v.ftab) {
+      if ((fl & FG_ENTRY_FIRST) && i == 0) b.last_flush |= BR_ENTRY_FIRST;
+      if ((fl & FG_ENTRY_LAST) && i + 1 == nb) { b.last_flush |= BR_ENTRY_LAST; b.pad = v.ftab[j].end_byte; }
+      blk_entry[off + i] = v.ftab[j].entry;
+    }
     blocks[off + i] = b;
   }
 }
@@ -259,7 +277,7 @@ __global__ void __launch_bounds__(256) k_block_analyze(const uint32_t *__restric
     bi->fixed_data = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     bi->dyn1_data = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     bi->dyn2_data = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-    bi->bytes = apos[br.first + br.count] - apos[br.first];
+    bi->bytes = (br.pad ? br.pad : apos[br.first + br.count]) - apos[br.first];     // (pad: the entry ends here, in a batch)
     uint32_t sp = 1;
     for (int i = 267; i <= 287; i++) if (st1[i] != 0) sp = 0;                // :1222 (Long_length_codes :1093-1095)
     bi->stored_possible = sp;
@@ -445,7 +463,11 @@ __global__ void __launch_bounds__(256) k_ch_tentative(uint32_t nblocks, const Ch
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nblocks) return;
   ChW w; w.rdata = 0; w.eob_in = 7u << 16; w.dec = 0xFF; w.T_in = BT_RESERVED; w.B_in = 1; w.pad = 0; w.code_block = CODE_FIXED; w.code_variant = 0; w.npieces = 0; w.bytes_pad = 0;
-  if (i > 0) {
+  if (chrec[i].br.last_flush & BR_ENTRY_FIRST) {
+    // a batch: the block starts its entry, i.e. a stream (last_block_type reserved, nothing to finish, nothing to recycle)
+    w.B_in = 0; w.rdata = ~0ull;
+    w.dec = (uint8_t)ch_decide(chrec[i], 1, ~0ull);
+  } else if (i > 0) {
     const ChRec r = chrec[i], pr = chrec[i - 1];
     const uint32_t pn = ch_nonrec(pr);
     const uint64_t INF = ~0ull;
@@ -465,7 +487,7 @@ __global__ void __launch_bounds__(256) k_ch_tentative(uint32_t nblocks, const Ch
 }
 
 __global__ void __launch_bounds__(64) k_ch_resolve(uint32_t nblocks, const ChRec *__restrict__ chrec, const BlockInfo *__restrict__ binfo,
-                                                   ChW *__restrict__ chw, const ChooserCarry *__restrict__ cin) {
+                                                   ChW *__restrict__ chw, const ChooserCarry *__restrict__ cin, int batch) {
   const int lane = threadIdx.x;
   if (nblocks == 0) return;
   // actual state (uniform over the wave)
@@ -482,9 +504,10 @@ __global__ void __launch_bounds__(64) k_ch_resolve(uint32_t nblocks, const ChRec
     else { T = BT_DYNAMIC; code_variant = f == FMT_DYN1 ? 1 : 2; eob = r.eob[code_variant - 1]; code_block = (int)k; }
   };
   uint32_t i = 0;
-  bool need_eval = true;
+  bool need_eval = !batch;                           // (a batch: block 0 starts an entry and has decided for itself)
   while (i < nblocks) {
     uint32_t dec;
+    if (need_eval && batch && (chrec[i].br.last_flush & BR_ENTRY_FIRST)) need_eval = false;   // a new entry: nothing carries over
     if (need_eval) {
       // Send_as_block's decision for block i with the actual state
       const ChRec r = chrec[i];
@@ -516,7 +539,7 @@ __global__ void __launch_bounds__(64) k_ch_resolve(uint32_t nblocks, const ChRec
         w.code_block = code_block; w.code_variant = (uint32_t)code_variant; w.npieces = 0; w.bytes_pad = 0;
         chw[i] = w;
       }
-    } else dec = FMT_RECYCLE;
+    } else dec = chw[i].dec;
     if (dec != FMT_RECYCLE) {
       // from here the tentative decisions hold up to and including the next block that recycles
       uint32_t j = nblocks;
@@ -537,14 +560,15 @@ __global__ void __launch_bounds__(64) k_ch_resolve(uint32_t nblocks, const ChRec
 
 // pieces of a stored block: Expand_LZ_buffer halves the ATOM range while it holds more than 65 535 bytes (:1024-1038)
 template <typename F>
-__device__ __forceinline__ uint32_t ch_stored_walk(const uint32_t *__restrict__ apos, uint32_t first, uint32_t count, int last_block, F &&piece) {
+__device__ __forceinline__ uint32_t ch_stored_walk(const uint32_t *__restrict__ apos, uint32_t first, uint32_t count, uint32_t end_byte, int last_block, F &&piece) {
   uint32_t stk_first[40], stk_last[40]; int stk_lb[40]; int sp = 0;
   uint32_t np = 0;
   stk_first[0] = first; stk_last[0] = first + count - 1; stk_lb[0] = last_block; sp = 1;
   while (sp > 0) {
     sp--;
     const uint32_t f = stk_first[sp], l = stk_last[sp]; const int lb = stk_lb[sp];
-    const uint32_t src = apos[f], nbytes = apos[l + 1] - src;
+    // (end_byte: the block ends its entry of a batch, whose last atom has no successor in the position array)
+    const uint32_t src = apos[f], nbytes = ((end_byte && l + 1 == first + count) ? end_byte : apos[l + 1]) - src;
     if (nbytes > 0xFFFF) {
       const uint32_t mid = (uint32_t)(((uint64_t)f + (uint64_t)l) / 2);
       stk_first[sp] = mid + 1; stk_last[sp] = l; stk_lb[sp] = lb; sp++;          // the second half comes after the first: pushed first
@@ -561,24 +585,28 @@ __global__ void __launch_bounds__(64) k_ch_stored(uint32_t nblocks, const ChRec 
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nblocks || chw[i].dec != FMT_STORED) return;
   const BlockRange br = chrec[i].br;
-  chw[i].npieces = ch_stored_walk(apos, br.first, br.count, (int)br.last_flush, [](uint32_t, uint32_t, uint32_t, int) {});
+  chw[i].npieces = ch_stored_walk(apos, br.first, br.count, br.pad, (int)(br.last_flush & BR_LAST_FLUSH), [](uint32_t, uint32_t, uint32_t, int) {});
 }
 
-// position transform of a block: kind 0: p -> p + a; kind 1: p -> align8 (p + a) + b
+// position transform of a block: kind 0: p -> p + a; kind 1: p -> align8 (p + a) + b; kind 2: p -> b (the first block of an
+// entry of a batch: positions restart).  Closed under composition.
 struct PosFn { uint64_t a, b; uint32_t kind; };
+__device__ __forceinline__ uint64_t posfn_apply(const PosFn &f, uint64_t p) { return f.kind == 2 ? f.b : f.kind ? ((p + f.a + 7) & ~7ull) + f.b : p + f.a; }
 __device__ __forceinline__ PosFn posfn_compose(const PosFn &f, const PosFn &g) {   // first f, then g
   PosFn h;
+  if (g.kind == 2) return g;
+  if (f.kind == 2) { h.kind = 2; h.a = 0; h.b = posfn_apply(g, f.b); return h; }
   if (g.kind == 0) { h.kind = f.kind; h.a = f.kind ? f.a : f.a + g.a; h.b = f.kind ? f.b + g.a : 0; }
   else if (f.kind == 0) { h.kind = 1; h.a = f.a + g.a; h.b = g.b; }
   else { h.kind = 1; h.a = f.a; h.b = ((f.b + g.a + 7) & ~7ull) + g.b; }
   return h;
 }
-__device__ __forceinline__ uint64_t posfn_apply(const PosFn &f, uint64_t p) { return f.kind ? ((p + f.a + 7) & ~7ull) + f.b : p + f.a; }
 
 __global__ void __launch_bounds__(1024) k_ch_layout(uint32_t nblocks, const ChRec *__restrict__ chrec, const BlockInfo *__restrict__ binfo, const ChW *__restrict__ chw,
                                                     EmitRec *__restrict__ emit, uint32_t *__restrict__ piece_base, uint32_t cap_tiles, uint32_t cap_pieces,
                                                     uint32_t *__restrict__ out32, uint64_t lim_bits, ChooserOut *__restrict__ res,
-                                                    const ChooserCarry *__restrict__ cin, ChooserCarry *__restrict__ cout, uint64_t base_bits, int do_epilogue) {
+                                                    const ChooserCarry *__restrict__ cin, ChooserCarry *__restrict__ cout, uint64_t base_bits, int do_epilogue,
+                                                    const uint32_t *__restrict__ blk_entry, EntOut *__restrict__ ent_out /* batches; else null */) {
   __shared__ PosFn wfn[16];
   __shared__ uint32_t wtiles[16], wpieces[16], wlast[16];
   __shared__ uint64_t s_pos; __shared__ uint32_t s_tiles, s_pieces, s_last;      // carried from tile to tile
@@ -612,6 +640,10 @@ __global__ void __launch_bounds__(1024) k_ch_layout(uint32_t nblocks, const ChRe
         f.a = pre_bits + hdr + data;
       }
     }
+    // a batch: the first block of an entry starts at the entry's bit 0 whatever came before
+    const bool efirst = ex && ent_out && (r.br.last_flush & BR_ENTRY_FIRST), elast = ex && ent_out && (r.br.last_flush & BR_ENTRY_LAST);
+    const PosFn fown = f;
+    if (efirst) { f.kind = 2; f.a = 0; f.b = posfn_apply(fown, 0); }
     // inclusive scans over the tile: position transforms (composition), tiles, pieces, last block that opened a Deflate block
     PosFn inc = f; uint32_t it = nt, ip = np, il = opener;
     for (int off = 1; off < 64; off <<= 1) {
@@ -634,7 +666,7 @@ __global__ void __launch_bounds__(1024) k_ch_layout(uint32_t nblocks, const ChRe
     uint32_t ext = __shfl_up(it, 1), exp_ = __shfl_up(ip, 1);
     if (lane == 0) { exl.kind = 0; exl.a = 0; exl.b = 0; ext = 0; exp_ = 0; }
     const PosFn upto = posfn_compose(before, exl);
-    const uint64_t p0 = posfn_apply(upto, s_pos);                   // bit position before this block
+    const uint64_t p0 = efirst ? 0 : posfn_apply(upto, s_pos);      // bit position before this block
     const uint32_t tile0 = s_tiles + tb + ext, piece0 = s_pieces + pb + exp_;
     if (ex) {
       EmitRec e; e.hdr_bitpos = 0; e.data_bitpos = 0; e.cost_bits = opt; e.fmt = cw.dec; e.code_block = CODE_FIXED; e.code_variant = 0; e.tile_base = tile0;
@@ -647,7 +679,7 @@ __global__ void __launch_bounds__(1024) k_ch_layout(uint32_t nblocks, const ChRe
         if (opens) {
           e.pre_pos = p0;
           e.pre_eob = (cw.B_in && (cw.T_in == BT_FIXED || cw.T_in == BT_DYNAMIC)) ? cw.eob_in : 0u;
-          e.pre_flags = 1u | (r.br.last_flush << 1) | ((cw.dec == FMT_FIXED ? 1u : 2u) << 2);
+          e.pre_flags = 1u | ((r.br.last_flush & BR_LAST_FLUSH) << 1) | ((cw.dec == FMT_FIXED ? 1u : 2u) << 2);
         }
         e.hdr_bitpos = p0 + pre_bits;
         e.data_bitpos = p0 + pre_bits + hdr;
@@ -656,6 +688,19 @@ __global__ void __launch_bounds__(1024) k_ch_layout(uint32_t nblocks, const ChRe
         else { e.code_block = (int32_t)i; e.code_variant = cw.dec == FMT_DYN1 ? 1u : 2u; }
       }
       emit[i] = e;
+      if (elast) {
+        // the entry ends behind this block: what its epilogue (Encode :1613-1635) has to write follows from the last block
+        // of the entry that opened a Deflate block (the entry's first block always does)
+        uint32_t lo = il;
+        if (lo == 0xFFFFFFFFu) { for (int k = w - 1; k >= 0; k--) if (wlast[k] != 0xFFFFFFFFu) { lo = wlast[k]; break; } }
+        if (lo == 0xFFFFFFFFu) lo = s_last;
+        const uint32_t dk = chw[lo].dec;
+        const ChRec rk = chrec[lo];
+        EntOut eo; eo.bits = posfn_apply(fown, p0);
+        eo.eob = dk == FMT_STORED ? 0u : dk == FMT_FIXED ? (7u << 16) : rk.eob[dk == FMT_DYN1 ? 0 : 1];
+        eo.fake = (rk.br.last_flush & BR_LAST_FLUSH) ? 0u : 1u;
+        ent_out[blk_entry[i]] = eo;
+      }
     }
     __syncthreads();
     if (tid == 1023) {                                               // totals of the tile -> carried state
@@ -674,7 +719,7 @@ __global__ void __launch_bounds__(1024) k_ch_layout(uint32_t nblocks, const ChRe
     const uint32_t k = s_last;
     const uint32_t dec = chw[k].dec;
     const ChRec r = chrec[k];
-    B = 1; M = (int)r.br.last_flush; cl = nullptr;
+    B = 1; M = (int)(r.br.last_flush & BR_LAST_FLUSH); cl = nullptr;
     if (dec == FMT_STORED) T = BT_STORED;
     else if (dec == FMT_FIXED) { T = BT_FIXED; eob = 7u << 16; }
     else { T = BT_DYNAMIC; eob = r.eob[dec == FMT_DYN1 ? 0 : 1]; cl = dec == FMT_DYN1 ? binfo[k].bl1 : binfo[k].bl2; }
@@ -699,6 +744,55 @@ __global__ void __launch_bounds__(1024) k_ch_layout(uint32_t nblocks, const ChRe
   }
 }
 
+// ---- batches of entries: what is per entry -------------------------------------------------------------------------
+// Flush table of a batch: entry e has atoms [offsets[chunk0[e]], offsets[chunk0[e + 1]]) (exclusive scan of the parse chunks'
+// token counts) and was given the flush slots [fl0[e], fl0[e + 1]) from its byte length.
+__global__ void k_batch_geom(uint32_t E, const uint32_t *__restrict__ chunk0, const uint32_t *__restrict__ fl0, const uint32_t *__restrict__ ent_start,
+                             const uint32_t *__restrict__ ent_len, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ total_atoms,
+                             FlushGeom *__restrict__ ftab, EntOut *__restrict__ ent_out) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const uint32_t a0 = offsets[chunk0[e]], a1 = e + 1 < E ? offsets[chunk0[e + 1]] : *total_atoms, T = a1 - a0;
+  const uint32_t nfl = (T + FLUSH - 1) / FLUSH;
+  for (uint32_t s = fl0[e], k = 0; s < fl0[e + 1]; s++, k++) {
+    FlushGeom g; g.F = a0 + k * FLUSH; g.to = 0; g.gj = k; g.flags = FG_EMPTY; g.end_byte = ent_start[e] + ent_len[e]; g.entry = e; g.pad[0] = g.pad[1] = 0;
+    if (k < nfl) {
+      g.to = g.F + FLUSH - 1 < a1 - 1 ? g.F + FLUSH - 1 : a1 - 1;
+      g.flags = (k == 0 ? (uint32_t)FG_ENTRY_FIRST : 0u) | (k + 1 == nfl ? (uint32_t)FG_ENTRY_LAST : 0u) |
+                ((k + 1 == nfl && (T % FLUSH) != 0) ? (uint32_t)FG_LAST_PARTIAL : 0u);
+    }
+    ftab[s] = g;
+  }
+  EntOut eo; eo.bits = 0; eo.eob = 0; eo.fake = 1;     // an entry without atoms: the fake final block alone (empty input: 03 00)
+  ent_out[e] = eo;
+}
+
+// bytes of every entry's stream (epilogue included)
+__global__ void k_batch_sizes(uint32_t E, const EntOut *__restrict__ ent_out, uint32_t *__restrict__ ent_bytes) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const EntOut eo = ent_out[e];
+  ent_bytes[e] = (uint32_t)((eo.bits + (eo.eob >> 16) + (eo.fake ? 10u : 0u) + 7) / 8);
+}
+
+// block positions were laid out from the entry's bit 0: move them to the entry's place in the output
+__global__ void k_batch_rebase(uint32_t nblocks, const uint32_t *__restrict__ blk_entry, const uint32_t *__restrict__ ent_base, EmitRec *__restrict__ emit) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblocks) return;
+  const uint64_t b = 8ull * ent_base[blk_entry[i]];
+  emit[i].hdr_bitpos += b; emit[i].data_bitpos += b; emit[i].pre_pos += b;
+}
+
+// the epilogue of every entry (Encode :1613-1635): end-of-block code of the block being finished, fake final fixed block
+__global__ void k_batch_finish(uint32_t E, const EntOut *__restrict__ ent_out, const uint32_t *__restrict__ ent_base, uint32_t *__restrict__ out32, uint64_t lim_bits) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const EntOut eo = ent_out[e];
+  uint64_t pos = 8ull * ent_base[e] + eo.bits;
+  if (eo.eob) { put_bits_lim(out32, lim_bits, pos, eo.eob & 0xFFFF, (int)(eo.eob >> 16)); pos += eo.eob >> 16; }
+  if (eo.fake) { put_bits_lim(out32, lim_bits, pos, 1, 1); put_bits_lim(out32, lim_bits, pos + 1, 1, 2); }
+}
+
 // the stored blocks' headers and copy list, one lane per stored block (Mark_new_block + :1040-1051 for every piece)
 __global__ void __launch_bounds__(64) k_ch_stored_emit(uint32_t nblocks, const ChRec *__restrict__ chrec, const ChW *__restrict__ chw, const EmitRec *__restrict__ emit,
                                                        const uint32_t *__restrict__ piece_base, const uint32_t *__restrict__ apos,
@@ -710,7 +804,7 @@ __global__ void __launch_bounds__(64) k_ch_stored_emit(uint32_t nblocks, const C
   uint64_t pos = e.pre_pos;
   const uint32_t pb = piece_base[i];
   bool first = true;
-  ch_stored_walk(apos, br.first, br.count, (int)br.last_flush, [&](uint32_t k, uint32_t src, uint32_t nbytes, int lb) {
+  ch_stored_walk(apos, br.first, br.count, br.pad, (int)(br.last_flush & BR_LAST_FLUSH), [&](uint32_t k, uint32_t src, uint32_t nbytes, int lb) {
     if (first && e.pre_eob) { put_bits_lim(out32, lim_bits, pos, e.pre_eob & 0xFFFF, (int)(e.pre_eob >> 16)); pos += e.pre_eob >> 16; }
     first = false;
     put_bits_lim(out32, lim_bits, pos, (uint32_t)lb, 1);                       // Mark_new_block: BFINAL; then BTYPE 00
@@ -931,11 +1025,19 @@ static EntropyView range_view(Ctx *c) {
   const Range &R = c->rg;
   Workspace &W = c->ws;
   EntropyView v;
+  v.ftab = R.batch ? W.ftab : nullptr;
   v.atoms = W.ea_atoms + (LB_CAP - R.n_lb); v.apos = W.ea_apos + (LB_CAP - R.n_lb);
   v.foff = R.foff; v.nflush = R.nflush; v.lvalid = (uint32_t)(R.n_lb + R.T + R.n_la);
   v.stream_final = (R.G + R.T + R.n_la == R.T_total) ? 1u : 0u;
   v.j0 = R.j0;
   return v;
+}
+
+int batch_geometry(Ctx *c, uint32_t E, const uint32_t *d_total_atoms) {
+  Workspace &W = c->ws;
+  hipLaunchKernelGGL(k_batch_geom, dim3((E + 255) / 256), dim3(256), 0, c->stream, E, W.ent_chunk0, W.ent_fl0, W.ent_start, W.ent_len, W.offsets,
+                     d_total_atoms, W.ftab, W.ent_out);
+  return hip_check(c, hipGetLastError(), "batch_geometry");
 }
 
 int entropy_analyze(Ctx *c) {
@@ -957,14 +1059,14 @@ int entropy_analyze(Ctx *c) {
       hipLaunchKernelGGL(k_cut_scan, dim3(v.nflush), dim3(64), 0, st, v, kstep, W.descr, W.seg_nblk, W.seg_cut, W.cut_trace);
       exclusive_scan_u32(st, W.seg_nblk, W.seg_blk_off, W.scan2, W.total2, v.nflush);
       hipMemcpyAsync(&nblocks, W.total2, 4, hipMemcpyDeviceToHost, st);
-      hipLaunchKernelGGL(k_fill_blocks, dim3((v.nflush + 255) / 256), dim3(256), 0, st, v, W.seg_nblk, W.seg_cut, W.seg_blk_off, W.blocks);
+      hipLaunchKernelGGL(k_fill_blocks, dim3((v.nflush + 255) / 256), dim3(256), 0, st, v, W.seg_nblk, W.seg_cut, W.seg_blk_off, W.blocks, W.blk_entry);
       if (hip_check(c, hipStreamSynchronize(st), "cut_scan")) return ZADA_E_HIP_;
       c->tmark("cut_scan");
     }
     if (nblocks > W.cap_blocks) { c->err = "block table overflow"; return -1; }
-    hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, v.atoms, v.apos, W.blocks, W.binfo);
+    if (nblocks > 0) hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, v.atoms, v.apos, W.blocks, W.binfo);
     c->tmark("block_analyze");
-    if (!fixed_only) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (ChRec *)W.chrec);
+    if (!fixed_only && nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (ChRec *)W.chrec);
   }
   R.nblocks = nblocks;
   R.analyzed = true;
@@ -977,6 +1079,7 @@ int entropy_choose(Ctx *c) {
   Range &R = c->rg;
   const bool fixed_only = (R.method == 6);
   const EntropyView v = range_view(c);
+  if (R.batch) { R.carry_in = ChooserCarry(); R.carry_in.last_type = BT_RESERVED; R.carry_in.cur_eob = 7u << 16; }
   R.base_bits = R.carry_in.pos & ~7ull;
   hipMemcpyAsync(W.carry, &R.carry_in, sizeof(ChooserCarry), hipMemcpyHostToDevice, st);
   // the chooser itself writes the few bits of stored-block headers and of the epilogue: the output must be zero before
@@ -985,22 +1088,34 @@ int entropy_choose(Ctx *c) {
     hipLaunchKernelGGL(k_choose_fixed, dim3(1), dim3(64), 0, st, R.nblocks, W.blocks, W.binfo, W.emit, W.tile_block, (uint32_t)W.cap_tiles,
                        (uint32_t *)W.out, lim_bits, W.chooser, W.carry, W.carry + 1, R.base_bits, R.G == 0 ? 1 : 0, v.stream_final ? 1 : 0);
   else {
-    const int do_epilogue = v.stream_final && (v.nflush > 0 || R.T_total == 0);
+    const int do_epilogue = !R.batch && v.stream_final && (v.nflush > 0 || R.T_total == 0);
     const uint32_t nb = R.nblocks;
     ChW *chw = (ChW *)W.chw;
     if (nb > 0) {
       hipLaunchKernelGGL(k_ch_tentative, dim3((nb + 255) / 256), dim3(256), 0, st, nb, (const ChRec *)W.chrec, chw);
-      hipLaunchKernelGGL(k_ch_resolve, dim3(1), dim3(64), 0, st, nb, (const ChRec *)W.chrec, W.binfo, chw, W.carry);
+      hipLaunchKernelGGL(k_ch_resolve, dim3(1), dim3(64), 0, st, nb, (const ChRec *)W.chrec, W.binfo, chw, W.carry, R.batch ? 1 : 0);
       hipLaunchKernelGGL(k_ch_stored, dim3((nb + 63) / 64), dim3(64), 0, st, nb, (const ChRec *)W.chrec, v.apos, chw);
     }
     hipLaunchKernelGGL(k_ch_layout, dim3(1), dim3(1024), 0, st, nb, (const ChRec *)W.chrec, W.binfo, chw, W.emit, W.piece_base,
-                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, lim_bits, W.chooser, W.carry, W.carry + 1, R.base_bits, do_epilogue);
+                       (uint32_t)W.cap_tiles, (uint32_t)W.cap_pieces, (uint32_t *)W.out, lim_bits, W.chooser, W.carry, W.carry + 1, R.base_bits, do_epilogue,
+                       W.blk_entry, R.batch ? W.ent_out : nullptr);
+    if (R.batch) {
+      // every entry's stream at its own place in the output: sizes -> byte offsets -> positions and epilogues
+      const uint32_t E = R.n_entries;
+      hipLaunchKernelGGL(k_batch_sizes, dim3((E + 255) / 256), dim3(256), 0, st, E, W.ent_out, W.ent_bytes);
+      exclusive_scan_u32(st, W.ent_bytes, W.ent_base, W.scan2, W.total2, E);
+      if (nb > 0) hipLaunchKernelGGL(k_batch_rebase, dim3((nb + 255) / 256), dim3(256), 0, st, nb, W.blk_entry, W.ent_base, W.emit);
+      hipLaunchKernelGGL(k_batch_finish, dim3((E + 255) / 256), dim3(256), 0, st, E, W.ent_out, W.ent_base, (uint32_t *)W.out, lim_bits);
+    }
   }
+  uint32_t batch_bytes = 0;
+  if (R.batch) hipMemcpyAsync(&batch_bytes, W.total2, 4, hipMemcpyDeviceToHost, st);
   hipMemcpyAsync(&R.co, W.chooser, sizeof(ChooserOut), hipMemcpyDeviceToHost, st);
   hipMemcpyAsync(&R.carry_out, W.carry + 1, sizeof(ChooserCarry), hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "choose")) return ZADA_E_HIP_;
   c->tmark("choose");
   if (R.co.overflow) { c->err = "emission table overflow"; return -1; }
+  if (R.batch) R.co.total_bits = 8ull * batch_bytes;
   R.chosen = true;
   c->last_nblocks = R.nblocks;                        // block trace: zada_last_blocks reads emit / blocks from the workspace
   return 0;

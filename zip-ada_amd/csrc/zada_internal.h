@@ -97,7 +97,29 @@ struct ChooserOut {
 // [the range's own atoms][look-ahead atoms of the next ranges, up to the end of the last flush the range owns].
 // The reference flushes its LZ buffer every 65 536 atoms counted from the start of the STREAM
 // (zip-compress-deflate.adb:1424-1432); a range owns the flushes whose first atom is one of its own.
+// A batch of independent streams (Zip entries) through ONE launch sequence: every entry has its own flush grid, chooser
+// state and output.  The flushes of all entries are listed in a table (slots reserved from the entries' byte lengths; a slot
+// may stay empty when the entry has fewer atoms than bytes).
+struct FlushGeom {
+  uint32_t F, to;               // first and last atom of the flush (index in the atom array)
+  uint32_t gj;                  // number of the flush inside its entry
+  uint32_t flags;               // FG_*
+  uint32_t end_byte;            // position behind the entry's last byte (the position array has no sentinel per entry)
+  uint32_t entry;               // index of the entry in the batch
+  uint32_t pad[2];
+};
+enum { FG_EMPTY = 1, FG_LAST_PARTIAL = 2, FG_ENTRY_FIRST = 4, FG_ENTRY_LAST = 8 };
+// BlockRange::last_flush carries flags: bit 0 = the reference's last_flush (BFINAL candidate); batches: bit 1 = first block
+// of its entry, bit 2 = last block of its entry; BlockRange::pad = end_byte of the entry for an entry's last block
+enum { BR_LAST_FLUSH = 1, BR_ENTRY_FIRST = 2, BR_ENTRY_LAST = 4 };
+struct EntOut {                 // what k_ch_layout leaves per entry of a batch
+  uint64_t bits;                // bits of the entry's stream before the epilogue (relative to the entry's first bit)
+  uint32_t eob;                 // end-of-block code to write in the epilogue ((length << 16) | code), 0 = none
+  uint32_t fake;                // 1: the fake final fixed block follows (:1624-1634)
+};
+
 struct EntropyView {
+  const FlushGeom *ftab;        // batch: the flush table (nflush slots); nullptr: one range, flushes computed from foff / j0
   const uint32_t *atoms, *apos; // local arrays
   uint32_t foff;                // local index of the first atom of the first owned flush
   uint32_t nflush;              // owned flushes
@@ -133,7 +155,7 @@ struct Workspace {
   uint64_t *dbg = nullptr;
   std::vector<void *> allocs;   // of the LZ group
   // ---- entropy stage: sized for the atoms of one range (cap_atoms) ----
-  uint64_t cap_atoms = 0;
+  uint64_t cap_atoms = 0, cap_flush = 0;
   uint32_t *ea_atoms = nullptr, *ea_apos = nullptr;   // local atom array: LB_CAP slots, the range's atoms, LA_CAP slots (+ sentinel)
   uint8_t *descr = nullptr;                  // [nflush][SLOTS][320]
   uint32_t *seg_nblk = nullptr, *seg_cut = nullptr, *seg_blk_off = nullptr;   // cuts [nflush][MAXBLK_PER_SEG]
@@ -153,7 +175,15 @@ struct Workspace {
   ChooserCarry *carry = nullptr;             // [2]: in, out
   uint32_t *scan2 = nullptr, *total2 = nullptr;   // scan scratch of the entropy stage
   uint64_t cap_blocks = 0, cap_tiles = 0, cap_pieces = 0;
+  uint32_t *blk_entry = nullptr;             // batches: entry of a block
   std::vector<void *> en_allocs;
+  // ---- batches of entries (zada_deflate_batch): per entry / per flush slot / per segment tables ----
+  uint64_t cap_ent = 0, cap_fslots = 0, cap_bseg = 0;
+  FlushGeom *ftab = nullptr;
+  EntOut *ent_out = nullptr;
+  uint32_t *ent_chunk0 = nullptr, *ent_fl0 = nullptr, *ent_start = nullptr, *ent_len = nullptr, *ent_bytes = nullptr, *ent_base = nullptr, *ent_crc = nullptr;
+  uint32_t *segend = nullptr;
+  std::vector<void *> bt_allocs;
   // ---- buffers of the host-buffer entry points ----
   uint8_t *rin_own = nullptr; uint64_t cap_rin = 0;   // the range's input, copied from the host
   uint8_t *out = nullptr; uint64_t cap_out = 0;       // the range's output
@@ -165,6 +195,8 @@ struct Workspace {
 struct GlobalState { uint64_t pos; uint32_t kind, pad; };      // parser state at a history-free point: stream position, SYNC_F / SYNC_L
 struct Range {
   bool open = false;
+  bool batch = false;                // a batch of entries instead of a range of one stream (entropy stage per entry)
+  uint32_t n_entries = 0;
   const uint8_t *rin = nullptr;      // device: stream byte lo - pre
   uint64_t lo = 0, pre = 0, n = 0, post = 0;
   bool first = true, last = true;
@@ -197,6 +229,8 @@ struct Ctx {
   CrcPending crc;
   uint32_t *crc_host = nullptr;                     // pinned: [CRC_HOST_TOP] top-level values, then 4 x 16 leftovers
   uint8_t *stage[2] = {nullptr, nullptr};            // pinned staging buffers of the host-buffer entry points (copy_in / copy_out)
+  uint8_t *bstage = nullptr; uint64_t cap_bstage = 0; // pinned: a batch's packed input, then its output
+  uint32_t *btab = nullptr; uint64_t cap_btab = 0;    // pinned: a batch's tables on their way to / from the device
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   Workspace ws;
   Range rg;                                          // the range in flight
@@ -223,7 +257,7 @@ struct Ctx {
 
 int hip_check(Ctx *c, hipError_t e, const char *what);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
-int ensure_entropy_workspace(Ctx *c, uint64_t atoms);
+int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);
 
 // One shard of a range through the LZ stage.  W.in holds `nbuf` bytes (zero pad behind): a 32 KiB halo in front of the
 // shard unless it starts the stream, the shard, and a tail behind it unless it ends the stream.  The tokens of the parse
@@ -237,10 +271,13 @@ struct ShardJob {
   uint32_t *dst_atoms = nullptr, *dst_apos = nullptr;
   uint32_t apos_bias = 0;             // added to buffer positions: offset of the buffer in the range's input
   uint64_t cap_atoms = 0;             // room at dst
+  const uint32_t *segend = nullptr;   // a batch of entries in the buffer (Layout); then tok_lo = 0, final, entry at 0
 };
 struct ShardResult { uint32_t ntok = 0; ExitState exit{0, SYNC_F}, warm{0, SYNC_F}; };
 int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res);
 
+int ensure_batch_workspace(Ctx *c, uint64_t entries, uint64_t fslots, uint64_t segs);
+int batch_geometry(Ctx *c, uint32_t E, const uint32_t *d_total_atoms);
 int entropy_analyze(Ctx *c);
 int entropy_choose(Ctx *c);
 int entropy_emit(Ctx *c, uint8_t *d_out);

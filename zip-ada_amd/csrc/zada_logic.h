@@ -124,7 +124,9 @@ struct MatchPair { uint32_t full, quarter; };
 // changed are redone, and so on until a parse has used exact values only (zada_lz.hip, lz_stage).
 constexpr uint32_t M_GUESS = 0x80000000u, M_DEMAND = 0x40000000u, M_BYSPEC = 0x20000000u, M_HAVEQ = 0x10000000u, M_VALUE = 0x01FFFFFFu;   // M_BYSPEC: demanded by a speculative parse
 struct NoGuess { ZADA_HD void operator()(uint32_t, uint32_t) const {} };
-struct ParseIO { const uint8_t *in; uint64_t n; const MatchPair *M; LzConfig cfg; };
+struct ParseIO { const uint8_t *in; uint64_t n; const MatchPair *M; LzConfig cfg; const uint32_t *segend; };   // segend: see Layout
+// Where the entries of a batch lie in the LZ buffer (csrc/zada_lz.hip "Layout of the LZ buffer"); segend = nullptr: one stream [0, n)
+struct Layout { const uint32_t *segend; uint64_t n; };
 struct ExitState { uint32_t pos, kind; };
 
 // Writes the bits of one chunk's words [first, last] exactly once (zeros where nothing is set).
@@ -191,8 +193,9 @@ ZADA_HD void parse_spec_chunk_to(const ParseIO &io, uint32_t k, uint32_t chunk, 
     if (kind == SYNC_F) fw.set(st.p); else lw.set(st.p);
     return false;
   }, on_guess, fetch);
-  fw.finish((c1 - 1) >> 5);
-  lw.finish((c1 - 1) >> 5);
+  const uint64_t lastw = c1 > c0 ? (c1 - 1) >> 5 : c0 >> 5;     // (a chunk behind the end of its entry, in a batch: its own first word)
+  fw.finish(lastw);
+  lw.finish(lastw);
   ex = e;
 }
 template <typename OnGuess, typename Fetch>

@@ -36,6 +36,21 @@ typedef uint32_t __attribute__((aligned(1))) u32u;
 typedef uint64_t __attribute__((aligned(1))) u64u;
 
 // --------------------------------------------------------------------------------------------
+// Layout of the LZ buffer: ONE stream [0, n), or a BATCH of independent streams (Zip entries), each starting at a multiple
+// of 32 KiB and taking whole segments.  segend[seg] = offset of the end of the entry the segment belongs to, bit 31 set for
+// the entry's first segment.  An entry's first segment has no previous segment (no links, planes or limits reach back),
+// its first position is never a match source (NIL, lz77.adb:467) and every bound the kernels take from "the end of the
+// input" (lz77.adb:858-865, 887-893) is the end of the entry.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t lay_end(const Layout &L, uint64_t seg) { return L.segend ? (uint64_t)(L.segend[seg] & 0x7FFFFFFFu) : L.n; }
+__device__ __forceinline__ bool lay_first(const Layout &L, uint64_t seg) { return L.segend ? (L.segend[seg] >> 31) != 0 : seg == 0; }
+// inserted positions of a segment (every position with three bytes before the end of its entry: :841-843, 887-893)
+__device__ __forceinline__ uint32_t lay_inserted(const Layout &L, uint64_t seg) {
+  const uint64_t base = seg << 15, e = lay_end(L, seg), ie = e >= 2 ? e - 2 : 0;
+  return ie > base ? (uint32_t)((ie - base) < 32768ull ? (ie - base) : 32768ull) : 0u;
+}
+
+// --------------------------------------------------------------------------------------------
 // k_prev_links
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t hash3(const uint8_t *__restrict__ in, uint64_t p) {
@@ -145,7 +160,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
 // (also in LDS); every output plane is written with coalesced stores.
 constexpr uint32_t DIST3_CONTINUE = 0xFFFF, DISTL_CONTINUE = 0x8000;
 static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
-__global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, uint64_t n_ins, int kfull, int kquarter,
+__global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, Layout L, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
                                                      DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg) {
@@ -162,7 +177,8 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint32_t *cnt = (uint32_t *)(B + 32768);        // 16 KiB
   uint32_t *wsum = cnt + 4096;                    // 64 B
   const uint64_t seg = blockIdx.x, base = seg * 32768ull;
-  const uint32_t m = (uint32_t)((n_ins - base) < 32768ull ? (n_ins - base) : 32768ull);
+  const uint32_t m = lay_inserted(L, seg);
+  const bool first_seg = lay_first(L, seg);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   uint32_t *bsc = bsc3 + seg * 32768ull;          // bucket start | count << 16
   uint16_t *s3 = S3 + seg * 32768ull;
@@ -243,7 +259,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           if (!first) { pm = pp[it * 64 - 1]; first = (pm >> 16) != k; }
           const bool last = (it * 64 + 1 == rem) || ((pp[it * 64 + 1] >> 16) != k);
           uint32_t d = 0;
-          if (!first) { const uint32_t e0 = pm & 0xFFFFu; if ((base + e0) != 0) d = e - e0; }     // NIL = position 0, lz77.adb:467
+          if (!first) { const uint32_t e0 = pm & 0xFFFFu; if (!(first_seg && e0 == 0)) d = e - e0; }     // NIL = position 0, lz77.adb:467
           x = e | ((uint32_t)last << 15) | (d << 16);
           if (lvl > 0 && last) tail[k] = (uint16_t)e;
         }
@@ -343,7 +359,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       // Levels >= 4 say where to continue: the chain ended at q, the first member of the bucket in this segment, whose link
       // k_cross_links will point into the previous segment (0x8000 | e - q; distances proper stay below 0x8000).
       auto dflt_of = [&](uint32_t e, uint32_t q) -> uint32_t {
-        if (seg == 0) return 0u;
+        if (first_seg) return 0u;
         if (lvl == 0) return e < (uint32_t)TOO_FAR ? DIST3_CONTINUE : 0u;
         return DISTL_CONTINUE | (e - q);
       };
@@ -489,12 +505,14 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 // the tails table of segment s-1 (65 536 x u16: last position of every bucket) in LDS and links every
 // position of segment s that has no predecessor inside its own segment to that tail.  Staging the table
 // makes the random look-ups LDS reads; as 2-byte global gathers they fetched a whole line each.
-__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, uint64_t n_ins, LevelPtrs lv) {
+__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *tl = (uint16_t *)smem;                                 // 128 KiB
   const uint64_t seg = blockIdx.x + 1, base = seg * 32768ull, pbase = base - 32768ull;
   const int l = blockIdx.y, tid = threadIdx.x;
-  const uint32_t m = (uint32_t)((n_ins - base) < 32768ull ? (n_ins - base) : 32768ull);
+  if (lay_first(L, seg)) return;                                   // an entry's first segment has nothing before it
+  const uint32_t m = lay_inserted(L, seg);
+  const bool prev_first = lay_first(L, seg - 1);
   {
     const uint4 *src = (const uint4 *)(lv.tails[l] + (seg - 1) * 65536ull);
     for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tl)[i] = src[i];
@@ -516,7 +534,7 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
       const uint32_t t = tl[hashL_of(v[k], 4 + l)];
       if (t == 0xFFFFu) continue;
       const uint64_t q = pbase + t, d = base + e - q;
-      if (d <= (uint64_t)MAX_DIST && q != 0) prevl[e] = (uint16_t)d;
+      if (d <= (uint64_t)MAX_DIST && !(prev_first && t == 0)) prevl[e] = (uint16_t)d;
     }
   }
 }
@@ -528,12 +546,14 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
 #define ZADA_CD_THREADS 64
 #endif
 constexpr int CD_THREADS = ZADA_CD_THREADS;
-__global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__restrict__ in, uint64_t n_ins, LevelPtrs lv,
+__global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv,
                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
                                                     DistPlanes dp) {
   const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_ins) return;
+  if (p >= L.n) return;
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
+  if (lay_first(L, seg) || (uint32_t)(p & 32767u) >= lay_inserted(L, seg)) return;
+  const bool prev_first = lay_first(L, seg - 1);
   // (what the levels >= 4 start from is loaded up front: these loads do not depend on the level-3 search)
   uint32_t dl_first[NLEVELS > 1 ? NLEVELS - 1 : 1], link_first[NLEVELS > 1 ? NLEVELS - 1 : 1];
 #pragma unroll
@@ -567,7 +587,7 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
         z &= ~(0xFFull << (8 * byte));
         const uint32_t j = lo + (uint32_t)byte;                        // candidate index in the bucket
         const uint64_t q = pbase + ps[pst + j], d = p - q;
-        if (q == 0 || d > (uint64_t)TOO_FAR) { stop = true; break; }   // position 0 is never a match source (:467)
+        if ((prev_first && q == pbase) || d > (uint64_t)TOO_FAR) { stop = true; break; }   // position 0 is never a match source (:467)
         if ((*(const u32u *)(in + q) & 0xFFFFFFu) == my24) { d3 = (uint32_t)d; break; }
       }
       if (stop) break;
@@ -583,7 +603,7 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
   // candidate is the last member of its bucket.
   if (dprev == 0 && (p & 32767u) < (uint32_t)MAX_DIST) {
     const uint64_t q = p - (uint64_t)MAX_DIST;
-    if (q != 0 && (*(const u32u *)(in + q) & 0xFFFFFFu) == my24) {
+    if (!(prev_first && q == pbase) && (*(const u32u *)(in + q) & 0xFFFFFFu) == my24) {
       const uint32_t own = bsc3[seg * 32768ull + h], prv = bsc3[pbase + h];
       const bool p_first = S3[seg * 32768ull + (own & 0xFFFF)] == (uint16_t)(p & 32767);
       const bool q_last = (prv >> 16) != 0 && S3[pbase + (prv & 0xFFFF) + (prv >> 16) - 1] == (uint16_t)(q & 32767);
@@ -625,14 +645,15 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 // range anyway).  Only buckets with at least kquarter elements over the two segments matter, so the
 // per-position default (no limit) is written by k_prev_links and this kernel touches the few long
 // buckets: one workgroup per segment, long buckets listed in LDS, then processed by all threads.
-__global__ void __launch_bounds__(256) k_bucket_limits(uint64_t n_ins, int kfull, int kquarter, const uint16_t *__restrict__ S3,
+__global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int kquarter, const uint16_t *__restrict__ S3,
                                                        const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim) {
   __shared__ uint32_t list[2048];
   __shared__ uint32_t nlist;
   const uint64_t seg = blockIdx.x, base = seg * 32768ull;
   const int tid = threadIdx.x;
-  const uint32_t *own = bsc3 + base, *prv = seg > 0 ? bsc3 + base - 32768 : nullptr;
-  const uint16_t *s3 = S3 + base, *p3 = seg > 0 ? S3 + base - 32768 : nullptr;
+  const bool has_prev = !lay_first(L, seg);
+  const uint32_t *own = bsc3 + base, *prv = has_prev ? bsc3 + base - 32768 : nullptr;
+  const uint16_t *s3 = S3 + base, *p3 = has_prev ? S3 + base - 32768 : nullptr;
   for (uint32_t h0 = 0; h0 < 32768; h0 += 2048) {        // rounds of 2048 buckets: the list cannot overflow
     if (tid == 0) nlist = 0;
     __syncthreads();
@@ -699,7 +720,7 @@ __device__ __forceinline__ uint64_t lds_u64_at(const uint8_t *b, uint32_t o) {
 // once.  Each round = ZADA_FAST "fast" steps (follow the link, test the two bytes a candidate must share to beat
 // `best`, :754-757) with no side paths, then one batched "slow" phase for everything rare: eight-byte compares of
 // the survivors, improvements, limits, results.
-__global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, uint64_t n,
+__global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, Layout L,
                                                 const uint16_t *__restrict__ prevd,
                                                 DistPlanes dp,
                                                 MatchPair *__restrict__ M,
@@ -717,8 +738,10 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   const uint64_t B = (uint64_t)blockIdx.x * MB;
   const uint64_t WB = B >= (uint64_t)HALO ? B - HALO : 0;
   const uint32_t woff = (uint32_t)(B - WB);                        // window index of position B
-  const uint32_t cnt = (uint32_t)((n - B) < (uint64_t)MB ? (n - B) : (uint64_t)MB);
+  const uint64_t n = lay_end(L, B >> 15);                          // end of the stream / of the entry this block lies in
+  const uint32_t cnt = n > B ? (uint32_t)((n - B) < (uint64_t)MB ? (n - B) : (uint64_t)MB) : 0u;
   const int tid = threadIdx.x;
+  if (cnt == 0) return;
   // stage the window (the input buffer is padded with >= 512 zero bytes past n)
   {
     const uint32_t nb = woff + cnt + 272;                          // bytes to stage
@@ -997,7 +1020,7 @@ struct ScanDesc {                                  // a position whose candidate
 constexpr int DM_LDS = DM_WBYTES + DMB * 2 + DM_SLICE * (int)sizeof(ScanDesc) + 64;
 static_assert(MB % DMB == 0 && DM_WBYTES % 16 == 0 && sizeof(ScanDesc) == 32, "demand blocks tile the first-pass blocks");
 // (six waves per SIMD, i.e. three workgroups per CU: without the bound the compiler takes 85 registers and only two fit)
-__global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *__restrict__ in, uint64_t n, DistPlanes dp, RunPtrs rp,
+__global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *__restrict__ in, Layout L, DistPlanes dp, RunPtrs rp,
                                                              const uint16_t *__restrict__ tailsK, MatchPair *__restrict__ M, int nice_cfg,
                                                              const uint32_t *__restrict__ blk_demand, uint32_t *__restrict__ dbits, uint8_t *__restrict__ chg,
                                                              const ExitState *__restrict__ spec_exits, const uint16_t *__restrict__ resume) {
@@ -1010,7 +1033,9 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
   uint32_t *ctr = (uint32_t *)(smem + DM_WBYTES + DMB * 2 + DM_SLICE * sizeof(ScanDesc));
   const uint64_t WB = B >= (uint64_t)HALO ? B - HALO : 0;
   const uint32_t woff = (uint32_t)(B - WB);
-  const uint32_t cnt = (uint32_t)((n - B) < (uint64_t)DMB ? (n - B) : (uint64_t)DMB);
+  const uint64_t n = lay_end(L, B >> 15);
+  const uint32_t cnt = n > B ? (uint32_t)((n - B) < (uint64_t)DMB ? (n - B) : (uint64_t)DMB) : 0u;
+  const bool seg_first = lay_first(L, B >> 15), prev_first = (B >> 15) > 0 && lay_first(L, (B >> 15) - 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long ltm = (1ull << lane) - 1ull;
   {
@@ -1069,7 +1094,7 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       const MatchPair og = M[p];
       const uint32_t idx1 = rp.idx[p], c1 = rp.cnt[p];
       uint32_t t = 0xFFFFu;
-      if (seg > 0) t = tailsK[(seg - 1) * 65536ull + hashL_of(lds_u64_at(win8, wi), 3 + NLEVELS)];
+      if (!seg_first) t = tailsK[(seg - 1) * 65536ull + hashL_of(lds_u64_at(win8, wi), 3 + NLEVELS)];
       uint32_t idx2 = 0, c2 = 0;
       if (t != 0xFFFFu) { idx2 = rp.idx[pbase + t]; c2 = (uint32_t)rp.cnt[pbase + t] + 1u; }
       const uint32_t df = dlimv & 0xFFFF, dq = dlimv >> 16;
@@ -1133,7 +1158,7 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       const uint64_t P_ = B + ds.k;
       const uint32_t po = (uint32_t)P_ & 32767u, sg = (uint32_t)(P_ >> 15);    // offset in the segment, segment (uniform)
       const bool in1 = c < ds.c1, in2 = !in1 && c - ds.c1 < ds.c2;
-      const bool q0 = raw == 0 && ((in1 && sg == 0) || (in2 && sg == 1));       // the candidate is position 0
+      const bool q0 = raw == 0 && ((in1 && seg_first) || (in2 && prev_first));   // the candidate is position 0 of the stream
       return q0 ? 0u : (in1 ? po - raw : (in2 ? po + 32768u - raw : 0u));
     };
     uint32_t rnext = (uint32_t)wave < ns ? cand_load(desc[wave], (uint32_t)lane) : 0u;
@@ -1214,9 +1239,9 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
 
 // Safety valve of the demand loop: every remaining guess becomes demanded (lz_stage uses it when the parse keeps
 // landing on new guesses round after round, which no ordinary input does).
-__global__ void k_demand_all(uint64_t n, MatchPair *__restrict__ M, uint32_t *__restrict__ blk_demand, uint32_t *__restrict__ dbits) {
+__global__ void k_demand_all(Layout L, MatchPair *__restrict__ M, uint32_t *__restrict__ blk_demand, uint32_t *__restrict__ dbits) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
+  if (p >= L.n || p >= lay_end(L, p >> 15)) return;
   const uint32_t f = M[p].full;
   if (f & M_GUESS) {                               // (a guess already marked has its bit set, or is set again: harmless)
     if (!(f & M_DEMAND)) M[p].full = f | M_DEMAND | M_BYSPEC;
@@ -1306,6 +1331,7 @@ __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict_
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nchunks) return;
   if (redo && !redo[k]) return;
+  if (io.segend) io.n = io.segend[((uint64_t)k * PCHUNK) >> 15] & 0x7FFFFFFFu;     // a batch: the input ends where the chunk's entry ends
   uint32_t ntok = 0;
   ExitState ex;
   __shared__ uint64_t lines[8 * 64];
@@ -1334,6 +1360,11 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
   if (!dirty_in[k]) return;
   ExitState entry = entry0;                          // the state the parse of this buffer starts from
   if (k > 0) entry = true_exits[k - 1];
+  if (io.segend) {                                   // a batch: every entry is parsed from its own first byte to its own end
+    const uint32_t se = io.segend[((uint64_t)k * PCHUNK) >> 15];
+    io.n = se & 0x7FFFFFFFu;
+    if ((se >> 31) && ((k * PCHUNK) & 32767u) == 0) entry = ExitState{k * PCHUNK, SYNC_F};
+  }
   const ExitState old_exit = true_exits[k];
   ExitState new_exit;
   uint32_t ntok = 0, take = 0, u0 = 0;
@@ -1360,7 +1391,7 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
 __global__ void __launch_bounds__(64) k_fix_forward(ParseIO io, uint32_t nchunks, ExitState *__restrict__ true_exits,
                                                     uint8_t *__restrict__ dirty_out, uint32_t *__restrict__ n_changed) {
   const uint32_t k = n_changed[1];
-  if (k >= nchunks || 258 < io.cfg.lazy) return;
+  if (k >= nchunks || 258 < io.cfg.lazy || io.segend) return;     // (batches: entries are small, the plain splice is enough)
   const ExitState e0 = true_exits[k];
   if (e0.kind != SYNC_F) return;
   const int lane = threadIdx.x;
@@ -1506,7 +1537,8 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     return hip_check(c, hipGetLastError(), "k_literal_atoms");
   }
   const LzConfig cfg = lz_config(level);
-  const uint64_t n_ins = n >= 2 ? n - 2 : 0;
+  const Layout L{job.segend, n};
+  const uint64_t n_ins = job.segend ? n : (n >= 2 ? n - 2 : 0);
   const uint32_t nseg = (uint32_t)((n_ins + 32767) / 32768);
   c->tmark("lz:begin");
   if (!c->lz_attrs_set) {                            // per context: the attribute belongs to the function object of the current device
@@ -1523,7 +1555,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   dpl.dlim = W.dlim;
   if (nseg > 0) {
     for (int l = 0; l < NLEVELS; l++) { lv.prev[l] = W.lprev[l]; lv.tails[l] = W.ltails[l]; }
-    hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, n_ins, cfg.chain, cfg.chain >> 2, lv,
+    hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
                        W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg);
 #ifdef ZADA_PL_STATS
     { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); hipMemset(W.dbg, 0, 256); }
@@ -1531,10 +1563,10 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     c->tmark("prev_links");
     if (nseg > 1) {
       const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
-      hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), 131072, st, W.in, n_ins, lv);
-      hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, n_ins, lv, W.S3, W.T3, W.bsc3, dpl);
+      hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), 131072, st, W.in, L, lv);
+      hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl);
     }
-    hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, n_ins, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim);
+    hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim);
     {
     }
   }
@@ -1555,10 +1587,10 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   hipMemsetAsync(W.dbits, 0, (size_t)nbd * (DMB / 8), st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
-  hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), MATCH_LDS, st, W.in, n, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
+  hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), MATCH_LDS, st, W.in, L, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
                      budget_env, (unsigned long long *)W.dbg, W.lprev[0]);
   c->tmark("match");
-  ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg;
+  ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg; io.segend = job.segend;
   DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand; dm.by = M_BYSPEC; dm.dbits = W.dbits;
   DemandMarker dmf = dm; dmf.by = 0;
   int rounds = 0, demand_rounds = 0;
@@ -1604,9 +1636,9 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     hipMemsetAsync(W.chg, 0, nch, st);
     if ((demand_rounds == max_rounds || slow) && !valve_used) {    // enough: search everything that is still a guess
       valve_used = true;
-      hipLaunchKernelGGL(k_demand_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, W.M, W.blk_demand, W.dbits);
+      hipLaunchKernelGGL(k_demand_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, L, W.M, W.blk_demand, W.dbits);
     }
-    hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, n, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
+    hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, L, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
                        W.blk_demand, W.dbits, W.chg, W.spec_exits, W.lprev[0]);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   }
