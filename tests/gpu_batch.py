@@ -13,6 +13,18 @@ datas = [mix[i * size:(i + 1) * size] for i in range(count)]
 enc.deflate_batch(datas[:64], 10)
 t0 = time.time(); res = enc.deflate_batch(datas, 10); dt = time.time() - t0
 print("batch: %d entries of %d bytes in %.3f s = %.1f MB/s; phases %s" % (count, size, dt, count * size / dt / 1e6, [(k, round(v, 2)) for k, v in enc.last_timing()]))
+import numpy as np, ctypes
+cnt = count
+lens = np.full(cnt, size, dtype=np.uint64); caps = lens + 64
+arena = np.empty(int(caps.sum()), dtype=np.uint8); offs = np.arange(cnt, dtype=np.uint64) * (size + 64)
+outp = (arena.ctypes.data + offs).astype(np.uint64)
+base = ctypes.cast(ctypes.c_char_p(mix), ctypes.c_void_p).value
+ins = (base + np.arange(cnt, dtype=np.uint64) * size).astype(np.uint64)
+ols = np.zeros(cnt, dtype=np.uint64); crcs = np.full(cnt, 0xFFFFFFFF, dtype=np.uint32); rcs = np.zeros(cnt, dtype=np.int32)
+t0 = time.time()
+enc.lib.zada_deflate_batch(enc.ctx, 10, cnt, ins.ctypes.data, lens.ctypes.data, outp.ctypes.data, caps.ctypes.data, ols.ctypes.data, crcs.ctypes.data, rcs.ctypes.data)
+dtc = time.time() - t0
+print("C entry point alone: %.3f s = %.1f MB/s" % (dtc, count * size / dtc / 1e6))
 t0 = time.time()
 for d in datas[:200]:
     enc.deflate(d, 10)

@@ -295,6 +295,25 @@ def test_batch_is_one_launch_sequence_and_bit_exact(encoder):
                 assert out == ref, (i, len(d), method)
 
 
+def test_archive_of_many_small_files_equals_the_oracles(encoder):
+    """zipada's usual workload (tools/zipada.adb:126-134): many small files into one archive.  ZipCreate.add_streams
+    (one batch) writes the bytes Zip.Create writes entry after entry, incl. stored entries."""
+    za = product()
+    rng = np.random.default_rng(8)
+    mix = silesia_mix(4 << 20)
+    entries, off = [], 0
+    for k in range(120):
+        ln = int(rng.integers(0, 50000))
+        d = bytes(mix[off:off + ln]) if k % 9 else bytes(rng.integers(0, 256, ln, dtype=np.uint8))
+        entries.append(("dir/f%03d.txt" % k, d)); off = (off + ln) % (len(mix) - 60000)
+    zc = za.ZipCreate(encoder, 10)
+    zc.add_streams([n for n, _ in entries], [d for _, d in entries])
+    got = zc.finish()
+    assert got == oracle_zip(entries, 10)
+    zf = zipfile.ZipFile(io.BytesIO(got))
+    assert zf.testzip() is None and [zf.read(i) for i in zf.infolist()] == [d for _, d in entries]
+
+
 def test_full_size_properties(encoder):
     """BASELINE config C2 size (1 GiB, Deflate_3): properties that do not need the oracle at full size --
     the stream inflates back to the input (independent inflater), CRC equals zlib's, and the first

@@ -175,24 +175,29 @@ class Encoder:
         return rc, ol.value, c.value
 
     def deflate_batch(self, datas, method=Method.Deflate_3, crc=0xFFFFFFFF):
-        """Independent streams (one per Zip entry) in one call: zada_deflate_batch compresses small ones several
-        at a time.  Returns a list of (rc, raw deflate bytes or None, running CRC register); rc 1 = inefficient."""
+        """Independent streams (one per Zip entry, Zip.Create.Add_Stream is per entry) in one call: zada_deflate_batch takes
+        the entries of up to 4 MiB through ONE launch sequence.  Returns a list of (rc, raw deflate bytes or None, running
+        CRC register); rc 1 = inefficient (the caller Stores the entry)."""
+        import numpy as np
         cnt = len(datas)
         if cnt == 0:
             return []
-        ns = (ctypes.c_uint64 * cnt)(*[len(d) for d in datas])
-        caps = (ctypes.c_uint64 * cnt)(*[len(d) + 64 for d in datas])
-        outs = [ctypes.create_string_buffer(len(d) + 64) for d in datas]
+        lens = np.fromiter((len(d) for d in datas), dtype=np.uint64, count=cnt)
+        caps = lens + 64
+        offs = np.concatenate(([0], np.cumsum(caps)[:-1])).astype(np.uint64)
+        arena = np.empty(int(caps.sum()), dtype=np.uint8)                       # one output arena instead of one buffer per entry
+        outp = (arena.ctypes.data + offs).astype(np.uint64)
         keep = [d if len(d) else b"\0" for d in datas]
-        ins = (ctypes.c_void_p * cnt)(*[_addr(d) for d in keep])
-        outp = (ctypes.c_void_p * cnt)(*[ctypes.addressof(o) for o in outs])
-        ols = (ctypes.c_uint64 * cnt)()
-        crcs = (ctypes.c_uint32 * cnt)(*([crc] * cnt))
-        rcs = (ctypes.c_int * cnt)()
-        worst = self.lib.zada_deflate_batch(self.ctx, method, cnt, ins, ns, outp, caps, ols, crcs, rcs)
+        ins = np.fromiter((_addr(d) for d in keep), dtype=np.uint64, count=cnt)
+        ols = np.zeros(cnt, dtype=np.uint64)
+        crcs = np.full(cnt, crc, dtype=np.uint32)
+        rcs = np.zeros(cnt, dtype=np.int32)
+        worst = self.lib.zada_deflate_batch(self.ctx, method, cnt, ins.ctypes.data, lens.ctypes.data, outp.ctypes.data, caps.ctypes.data,
+                                            ols.ctypes.data, crcs.ctypes.data, rcs.ctypes.data)
         if worst < 0:
             self._err(worst, "zada_deflate_batch")
-        return [(rcs[i], outs[i].raw[:ols[i]] if rcs[i] == 0 else None, crcs[i]) for i in range(cnt)]
+        mv = memoryview(arena)
+        return [(int(rcs[i]), bytes(mv[int(offs[i]):int(offs[i]) + int(ols[i])]) if rcs[i] == 0 else None, int(crcs[i])) for i in range(cnt)]
 
     def deflate_device(self, d_in_ptr, n, d_out_ptr, cap, method=Method.Deflate_3, crc=0xFFFFFFFF):
         """Device-resident variant (pointers are HBM addresses, e.g. torch tensor .data_ptr()).
@@ -348,6 +353,21 @@ class ZipCreate:
     def add_stream(self, name, data, file_time=None, unicode_name=True):
         payload, crc, zt = self.enc.compress_data(data, self.method)
         return self.add_compressed(name, payload, crc, len(data), zt, file_time, unicode_name)
+
+    def add_streams(self, names, datas, file_time=None, unicode_name=True):
+        """Add_Stream for many entries at once: the entries are compressed as one batch (zada_deflate_batch: one launch
+        sequence for all the small ones), with Compress_Data's Store fallback (zip-compress.adb:224-237) and CRC Init / Final
+        (:144, 218) per entry.  The archive is the one Add_Stream after Add_Stream writes."""
+        import zlib
+        if self.method == Method.Store:
+            res = [(1, None, 0)] * len(datas)
+        else:
+            res = self.enc.deflate_batch(datas, self.method)
+        for name, data, (rc, payload, crc) in zip(names, datas, res):
+            if rc == 0:
+                self.add_compressed(name, payload, crc ^ 0xFFFFFFFF, len(data), 8, file_time, unicode_name)
+            else:
+                self.add_compressed(name, bytes(data), zlib.crc32(data) if self.method == Method.Store else crc ^ 0xFFFFFFFF, len(data), 0, file_time, unicode_name)
 
     def add_compressed(self, name, payload, crc, usize, zt, file_time=None, unicode_name=True):
         """Entry whose payload was compressed elsewhere (another rank / GPU): the bytes written
