@@ -328,14 +328,29 @@ def main():
             if world == 1:
                 checks["stream_inflates_to_input_crc"] = bool(inflate_check(stream, total, zlib.crc32(host)) and (crc ^ 0xFFFFFFFF) == zlib.crc32(host))
             else:
-                # (the input of the other ranks is not here: the CRC-32 the ranks computed and combined must be the decoded data's)
+                # Rank 0 holds range 0 of the input only.  The stream is inflated (independent inflater) through range 0, across
+                # the first joint and 64 MiB into range 1 -- all of it when it is at most 3 GiB, then also against the CRC-32
+                # the ranks computed and combined; range 0 of the decoded data must be rank 0's input.
+                want = total if total <= (3 << 30) else n + (64 << 20)
                 dec = zlib.decompressobj(-15)
-                c2, tot = 0, 0
+                c_all, c0, tot = 0, 0, 0
                 view = memoryview(stream)
-                for off in range(0, len(view), 1 << 24):
-                    ch = dec.decompress(view[off:off + (1 << 24)]); c2 = zlib.crc32(ch, c2); tot += len(ch)
-                tl = dec.flush(); c2 = zlib.crc32(tl, c2); tot += len(tl)
-                checks["stream_inflates_to_input_crc"] = bool(tot == total and c2 == (crc ^ 0xFFFFFFFF))
+                off = 0
+                while tot < want and off < len(view):
+                    ch = dec.decompress(view[off:off + (1 << 22)], want - tot)
+                    off += 1 << 22                          # (what the call leaves unconsumed is drained by the inner loop)
+                    while True:
+                        c_all = zlib.crc32(ch, c_all)
+                        c0 = zlib.crc32(ch[:max(0, min(len(ch), n - tot))], c0)
+                        tot += len(ch)
+                        if not dec.unconsumed_tail or tot >= want:
+                            break
+                        ch = dec.decompress(dec.unconsumed_tail, want - tot)
+                ok = tot == want and c0 == zlib.crc32(host[pre:pre + n])
+                if want == total:
+                    ok = ok and dec.eof and c_all == (crc ^ 0xFFFFFFFF)
+                checks["stream_inflates_to_input_crc"] = bool(ok)
+                checks["inflated_bytes"] = int(tot)
             if ref is not None:
                 head = za.silesia_mix(args.cpu_sample_mib << 20, seed=SEED).tobytes()
                 g, _ = enc.deflate(head, za.Method.Deflate_3)

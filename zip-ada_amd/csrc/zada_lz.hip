@@ -163,7 +163,7 @@ static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, Layout L, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
-                                                     DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg) {
+                                                     DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg, uint32_t *__restrict__ segmax) {
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
 #define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       }
     }
     if (want_runs) {
+      if (tid == 0) cnt[2048] = 0;                   // (free between the sorts: the largest bucket of the segment, level 3)
       __syncthreads();
       {
         // LW[wd] = last word index <= wd whose F word is non-zero (word 0 always is: element 0 starts a bucket)
@@ -292,11 +293,14 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         return (pw << 5) + 31 - __clz((int)F[pw]);
       };
       if (lvl == 0) {
+        uint32_t mx = 0;                               // largest bucket of the segment: k_bucket_limits skips segments without long ones
 #pragma unroll
         for (int it = 0; it < 32; it++) {
           const uint32_t i = i0 + it * 64;
-          if ((ed[it] >> 15) & 1u) { const uint32_t bs = bucket_start(i); bsc[AB[i] >> 16] = bs | ((i - bs + 1) << 16); }
+          if ((ed[it] >> 15) & 1u) { const uint32_t bs = bucket_start(i); bsc[AB[i] >> 16] = bs | ((i - bs + 1) << 16); mx = mx > i - bs + 1 ? mx : i - bs + 1; }
         }
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(mx, off); mx = mx > o ? mx : o; }
+        if (lane == 0 && mx) atomicMax(&cnt[2048], mx);
       } else {
         // last level: the bucket of a position is a contiguous run of the sorted order, which the demand pass
         // of the match kernel scans instead of chasing links.  Written out: the sorted order S, and per
@@ -323,6 +327,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       }
     }
     __syncthreads();                                 // keys (A) and sorted positions (B) are dead from here
+    if (lvl == 0 && tid == 0) segmax[seg] = cnt[2048];
     for (uint32_t i = tid; i < (m + 16 + 15) / 16; i += 1024) ((uint4 *)A)[i] = ((const uint4 *)sin)[i];   // A := bytes
 #pragma unroll
     for (int it = 0; it < 32; it++) {
@@ -646,12 +651,18 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 // per-position default (no limit) is written by k_prev_links and this kernel touches the few long
 // buckets: one workgroup per segment, long buckets listed in LDS, then processed by all threads.
 __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int kquarter, const uint16_t *__restrict__ S3,
-                                                       const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim) {
+                                                       const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim, const uint32_t *__restrict__ segmax) {
   __shared__ uint32_t list[2048];
   __shared__ uint32_t nlist;
   const uint64_t seg = blockIdx.x, base = seg * 32768ull;
   const int tid = threadIdx.x;
   const bool has_prev = !lay_first(L, seg);
+  // a bucket matters only with at least kquarter members in this segment and the previous one together (see above): none
+  // can have that many if the largest buckets of the two segments do not add up to it -- the usual case
+  {
+    const uint32_t mo = segmax[seg], mp = has_prev ? segmax[seg - 1] : 0u;
+    if (mo == 0 || mo - 1 + mp < (uint32_t)kquarter) return;
+  }
   const uint32_t *own = bsc3 + base, *prv = has_prev ? bsc3 + base - 32768 : nullptr;
   const uint16_t *s3 = S3 + base, *p3 = has_prev ? S3 + base - 32768 : nullptr;
   for (uint32_t h0 = 0; h0 < 32768; h0 += 2048) {        // rounds of 2048 buckets: the list cannot overflow
@@ -1556,7 +1567,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   if (nseg > 0) {
     for (int l = 0; l < NLEVELS; l++) { lv.prev[l] = W.lprev[l]; lv.tails[l] = W.ltails[l]; }
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
-                       W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg);
+                       W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax);
 #ifdef ZADA_PL_STATS
     { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); hipMemset(W.dbg, 0, 256); }
 #endif
@@ -1566,7 +1577,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), 131072, st, W.in, L, lv);
       hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl);
     }
-    hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim);
+    hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax);
     {
     }
   }
@@ -1608,6 +1619,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     if (kE > 0) hipLaunchKernelGGL(k_seed_entry, dim3((kE + 255) / 256), dim3(256), 0, st, W.true_exits, kE, entry0);
     hipMemsetAsync(W.dirty[0], 1, nch, st);
     int cur = 0, it = 0;
+    uint32_t ndem = 0;                                             // a parse of this round landed on a guess
     bool slow = false;                                             // the splice is crawling: stop waiting for it
     for (;;) {
       hipMemsetAsync(W.dirty[cur ^ 1], 0, nch, st);
@@ -1619,6 +1631,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       hipLaunchKernelGGL(k_fix_forward, dim3(1), dim3(64), 0, st, io, nch, W.true_exits, W.dirty[cur ^ 1], W.n_changed);
       uint32_t changed = 0;
       hipMemcpyAsync(&changed, W.n_changed, 4, hipMemcpyDeviceToHost, st);
+      hipMemcpyAsync(&ndem, W.n_demand, 4, hipMemcpyDeviceToHost, st);     // (with the same round trip; the last one read counts)
       if (hip_check(c, hipStreamSynchronize(st), "parse_fix")) return ZADA_E_HIP_;
       rounds++;
       if (changed == 0) break;
@@ -1627,8 +1640,6 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       if (++it >= 32 && !valve_used) { slow = true; break; }
       cur ^= 1;
     }
-    uint32_t ndem = 0;
-    hipMemcpy(&ndem, W.n_demand, 4, hipMemcpyDeviceToHost);
     if (ndem == 0 && !slow) break;
     demand_rounds++;
     if (demand_rounds > 1000) { c->err = "demand loop did not converge"; return ZADA_E_HIP_; }
