@@ -510,17 +510,22 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 // the tails table of segment s-1 (65 536 x u16: last position of every bucket) in LDS and links every
 // position of segment s that has no predecessor inside its own segment to that tail.  Staging the table
 // makes the random look-ups LDS reads; as 2-byte global gathers they fetched a whole line each.
+#ifndef ZADA_CL_SPLIT
+#define ZADA_CL_SPLIT 1
+#endif
+constexpr int CL_SPLIT = ZADA_CL_SPLIT;            // parts of a tails table a workgroup stages (A/B: 2 parts, two workgroups per CU: 6 % slower, 4 parts: 45 %; every part re-reads the positions)
 __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint16_t *tl = (uint16_t *)smem;                                 // 128 KiB
+  uint16_t *tl = (uint16_t *)smem;                                 // 128 KiB / CL_SPLIT
   const uint64_t seg = blockIdx.x + 1, base = seg * 32768ull, pbase = base - 32768ull;
-  const int l = blockIdx.y, tid = threadIdx.x;
+  const int l = blockIdx.y / CL_SPLIT, part = blockIdx.y % CL_SPLIT, tid = threadIdx.x;
+  constexpr uint32_t PART = 65536u / CL_SPLIT;
   if (lay_first(L, seg)) return;                                   // an entry's first segment has nothing before it
   const uint32_t m = lay_inserted(L, seg);
   const bool prev_first = lay_first(L, seg - 1);
   {
-    const uint4 *src = (const uint4 *)(lv.tails[l] + (seg - 1) * 65536ull);
-    for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tl)[i] = src[i];
+    const uint4 *src = (const uint4 *)(lv.tails[l] + (seg - 1) * 65536ull + (uint64_t)part * PART);
+    for (int i = tid; i < (int)(PART / 8); i += 1024) ((uint4 *)tl)[i] = src[i];
   }
   __syncthreads();
   uint16_t *prevl = lv.prev[l] + base;
@@ -536,7 +541,9 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
     for (int k = 0; k < 8; k++) {
       if (pv[k] != 0) continue;
       const uint32_t e = e0 + 1024 * k;
-      const uint32_t t = tl[hashL_of(v[k], 4 + l)];
+      const uint32_t h = hashL_of(v[k], 4 + l);
+      if (h / PART != (uint32_t)part) continue;                      // (the other workgroups of this segment and level)
+      const uint32_t t = tl[h % PART];
       if (t == 0xFFFFu) continue;
       const uint64_t q = pbase + t, d = base + e - q;
       if (d <= (uint64_t)MAX_DIST && !(prev_first && t == 0)) prevl[e] = (uint16_t)d;
@@ -1554,7 +1561,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   c->tmark("lz:begin");
   if (!c->lz_attrs_set) {                            // per context: the attribute belongs to the function object of the current device
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
-    hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 / CL_SPLIT);
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS);
     hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
     c->lz_attrs_set = true;
@@ -1574,7 +1581,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     c->tmark("prev_links");
     if (nseg > 1) {
       const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
-      hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), 131072, st, W.in, L, lv);
+      hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS * CL_SPLIT), dim3(1024), 131072 / CL_SPLIT, st, W.in, L, lv);
       hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl);
     }
     hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax);
