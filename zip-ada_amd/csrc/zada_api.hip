@@ -702,6 +702,7 @@ zada_ctx *zada_create(int device) {
       hipEventCreateWithFlags(&z->c.ev_out, hipEventDisableTiming) != hipSuccess) { delete z; return nullptr; }
   // tuning knobs: read once per context
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
+  if (const char *e = getenv("ZADA_INNER_BUDGET")) z->c.knob_inner_budget = atoi(e);
   if (const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS")) { if (atoi(e) > 0) z->c.knob_max_demand_rounds = atoi(e); }
   if (const char *e = getenv("ZADA_BATCH_STREAMS")) { if (atoi(e) >= 1) z->c.knob_batch_streams = atoi(e); }
   if (const char *e = getenv("ZADA_SHARD_KIB")) { if (atoi(e) >= 64 && atoi(e) % 64 == 0) z->c.knob_shard_kib = atoi(e); }
@@ -732,6 +733,7 @@ const char *zada_last_error(const zada_ctx *z) { return z ? z->c.err.c_str() : "
 int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!z || !name) return ZADA_E_INVALID;
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
+  else if (!strcmp(name, "inner_budget")) z->c.knob_inner_budget = value;
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "batch_streams")) z->c.knob_batch_streams = value >= 1 ? value : 4;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }

@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
                                                 DistPlanes dp,
                                                 MatchPair *__restrict__ M,
                                                 int nice_cfg, int budget, unsigned long long *__restrict__ dbg,
-                                                uint16_t *__restrict__ resume) {
+                                                uint16_t *__restrict__ resume, int short_budget) {
   // Every position of the block is searched for at most `budget` rounds of ZADA_FAST chain steps; a search cut
   // short leaves its best so far as a guess (M_GUESS) that k_match_demand replaces if a parse ever lands on it.
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
   uint32_t lim_cur = 0, lim_full = 0;
   bool have_q = false, exhausted = false;
   uint32_t cmp_off = 0;                                            // bytes already compared (state 3)
-  int age = 0;                                                     // rounds spent on the current position
+  int age = 0, mybudget = budget;                                  // rounds spent on the current position / allowed for it
   static_assert(NLEVELS == 2 && MB == 16384 && MAX_DIST < 32768, "packing of the queue entries");
   constexpr uint32_t QCAP = 128;                                   // entries per wave: fewer than 64 left before a refill of at most 64
   uint32_t *queue = next_pos + 4 + (threadIdx.x >> 6) * (2 * QCAP);
@@ -845,7 +845,15 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
               MatchPair r; r.full = packed; r.quarter = (hq || !chain_ok) ? qbest : packed;
               M[B + k] = r;
             }
-            e_lo = k | ((uint32_t)(b_ - 2) << 14) | ((uint32_t)hq << 16) | (bd_ << 17);
+            // Positions deep inside a match (the nearest four-byte match lies at the same distance as for the two positions
+            // before) are hardly ever looked at by the parser -- and hold most of the chain steps: they get a single round.
+            // The result does not depend on the budget (a parse that does land there demands the exact search).
+            bool inner = false;
+#ifndef ZADA_NO_INNER
+            if (ok && k >= 2 && short_budget > 0) { const uint32_t m1 = dp.d[NLEVELS - 1][B + k - 1], m2 = dp.d[NLEVELS - 1][B + k - 2]; inner = dl[NLEVELS - 1] == m1 && m1 == m2; }
+#endif
+            // (hq is recomputed at pick-up: for a queued position it is bd_ > lq)
+            e_lo = k | ((uint32_t)(b_ - 2) << 14) | ((uint32_t)inner << 16) | (bd_ << 17);
             e_hi = lf | (lq << 15) | (qlev << 30);
           }
           const unsigned long long okm = __ballot(ok);
@@ -863,9 +871,11 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           const uint64_t rem = n - (B + kpos);
           la = rem < 258 ? (int)rem : 258;
           nice = nice_cfg < la ? nice_cfg : la;
-          best = 2 + (int)((e_lo >> 14) & 3u); have_q = (e_lo >> 16) & 1u; bdist = e_lo >> 17;
+          best = 2 + (int)((e_lo >> 14) & 3u); bdist = e_lo >> 17;
+          mybudget = ((e_lo >> 16) & 1u) ? short_budget : budget;
           lim_full = e_hi & 0x7FFFu;
           const uint32_t lim_q = (e_hi >> 15) & 0x7FFFu, qlev = e_hi >> 30;
+          have_q = bdist > lim_q;
           // quarter-chain result so far: the best level whose candidate lies within the quarter limit
           rq = 0;
           if (qlev != 0) {
@@ -984,7 +994,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
       }
     }
     // first pass: a search that has had its share of rounds is cut short, its best so far becomes a guess
-    if (state == 1 && ++age >= budget) {
+    if (state == 1 && ++age >= mybudget) {
       const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
       // (k_match_demand takes the search up where it stops here: the next candidate, as a distance, goes with the guess)
       MatchPair r; r.full = packed | M_GUESS | (have_q ? M_HAVEQ : 0u); r.quarter = have_q ? rq : packed;
@@ -1606,7 +1616,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   hipMemsetAsync(W.dbits, 0, (size_t)nbd * (DMB / 8), st);
   hipMemsetAsync(W.n_demand, 0, 4, st);
   hipLaunchKernelGGL(k_match, dim3(nbm), dim3(1024), MATCH_LDS, st, W.in, L, W.lprev[NLEVELS - 1], dpl, W.M, cfg.nice,
-                     budget_env, (unsigned long long *)W.dbg, W.lprev[0]);
+                     budget_env, (unsigned long long *)W.dbg, W.lprev[0], budget_env > c->knob_inner_budget ? c->knob_inner_budget : 0);
   c->tmark("match");
   ParseIO io; io.in = W.in; io.n = n; io.M = W.M; io.cfg = cfg; io.segend = job.segend;
   DemandMarker dm; dm.M = W.M; dm.blk_demand = W.blk_demand; dm.n_demand = W.n_demand; dm.by = M_BYSPEC; dm.dbits = W.dbits;
