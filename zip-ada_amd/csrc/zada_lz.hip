@@ -158,7 +158,9 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
 // with the positions so that nothing is gathered from global memory), turn the sorted order into
 // position-indexed links P in LDS, then walk those links position-parallel against the segment's bytes
 // (also in LDS); every output plane is written with coalesced stores.
-constexpr uint32_t DIST3_CONTINUE = 0xFFFF, DISTL_CONTINUE = 0x8000;
+// markers in the level-3 plane for k_cross_dist: the search goes on in the previous segment (p has / has no earlier position
+// with its 15-bit hash in its own segment); only the head of the chain at exactly MAX_DIST is left to check
+constexpr uint32_t DIST3_CONTINUE = 0xFFFF, DIST3_HEADCHK = 0xFFFE, DIST3_CONT_FIRST = 0xFFFD, DISTL_CONTINUE = 0x8000;
 static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, Layout L, int kfull, int kquarter,
                                                      LevelPtrs lv,
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       // k_cross_links will point into the previous segment (0x8000 | e - q; distances proper stay below 0x8000).
       auto dflt_of = [&](uint32_t e, uint32_t q) -> uint32_t {
         if (first_seg) return 0u;
-        if (lvl == 0) return e < (uint32_t)TOO_FAR ? DIST3_CONTINUE : 0u;
+        if (lvl == 0) return e < (uint32_t)TOO_FAR ? (q == e ? DIST3_CONT_FIRST : DIST3_CONTINUE) : (q == e ? DIST3_HEADCHK : 0u);
         return DISTL_CONTINUE | (e - q);
       };
       constexpr uint32_t QCAP = 4000;
@@ -510,43 +512,69 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 // the tails table of segment s-1 (65 536 x u16: last position of every bucket) in LDS and links every
 // position of segment s that has no predecessor inside its own segment to that tail.  Staging the table
 // makes the random look-ups LDS reads; as 2-byte global gathers they fetched a whole line each.
-#ifndef ZADA_CL_SPLIT
-#define ZADA_CL_SPLIT 1
-#endif
-constexpr int CL_SPLIT = ZADA_CL_SPLIT;            // parts of a tails table a workgroup stages (A/B: 2 parts, two workgroups per CU: 6 % slower, 4 parts: 45 %; every part re-reads the positions)
-__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv) {
+// Cross-segment links: grid = (segments - 1, levels), block = 1024.  The workgroup of (segment s, level l) stages
+// the tails table of segment s-1 (65 536 x u16: last position of every bucket) in LDS and links every
+// position of segment s that has no predecessor inside its own segment to that tail.  Staging the table
+// makes the random look-ups LDS reads; as 2-byte global gathers they fetched a whole line each.
+//
+// For the levels that have a plane (nearest match of exactly that many bytes) the same look-up settles most of the searches
+// that did not end inside the segment: the chain of p's bucket goes on, in the previous segment, at that bucket's tail --
+// the most recent position there with the same hash, which usually IS a match.  The previous segment's bytes are staged
+// next to the table (32 KiB; the two fill the CU's LDS exactly) and the candidate is compared here; only a hash collision
+// leaves the search to k_cross_dist, which would otherwise pay two dependent global round trips for each of them (a
+// third of all positions).  (A/B, ZADA_CL_SPLIT: the table in 2 / 4 parts with as many workgroups per CU is 6 % / 45 %
+// slower: every part re-reads the positions.)
+constexpr int CL_LDS_PLANE = 131072 + 32768;
+__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv, DistPlanes dp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint16_t *tl = (uint16_t *)smem;                                 // 128 KiB / CL_SPLIT
+  uint16_t *tl = (uint16_t *)smem;                                 // 128 KiB
+  const uint8_t *pb = smem + 131072;                               // the previous segment's bytes (levels with a plane)
   const uint64_t seg = blockIdx.x + 1, base = seg * 32768ull, pbase = base - 32768ull;
-  const int l = blockIdx.y / CL_SPLIT, part = blockIdx.y % CL_SPLIT, tid = threadIdx.x;
-  constexpr uint32_t PART = 65536u / CL_SPLIT;
+  const int l = blockIdx.y, tid = threadIdx.x;
+  const bool has_plane = l + 1 < NLEVELS;
   if (lay_first(L, seg)) return;                                   // an entry's first segment has nothing before it
   const uint32_t m = lay_inserted(L, seg);
   const bool prev_first = lay_first(L, seg - 1);
   {
-    const uint4 *src = (const uint4 *)(lv.tails[l] + (seg - 1) * 65536ull + (uint64_t)part * PART);
-    for (int i = tid; i < (int)(PART / 8); i += 1024) ((uint4 *)tl)[i] = src[i];
+    const uint4 *src = (const uint4 *)(lv.tails[l] + (seg - 1) * 65536ull);
+    for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tl)[i] = src[i];
+    if (has_plane) {
+      const uint4 *bs = (const uint4 *)(in + pbase);
+      for (int i = tid; i < 32768 / 16; i += 1024) ((uint4 *)(smem + 131072))[i] = bs[i];
+    }
   }
   __syncthreads();
   uint16_t *prevl = lv.prev[l] + base;
+  uint16_t *plane = has_plane ? dp.d[1 + l] + base : nullptr;
   const uint8_t *sin = in + base;
+  const uint32_t cmask = 0xFFFFFFFFu;                              // (the only level with a plane, l = 0, compares four bytes)
+  static_assert(NLEVELS <= 2, "the candidate compare of k_cross_links takes four bytes");
   for (uint32_t e0 = tid; e0 < m; e0 += 8192) {                    // 8 positions per lane in flight: the loop is latency bound
-    uint32_t pv[8];
+    uint32_t pv[8], pl[8];
     uint64_t v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const uint32_t e = e0 + 1024 * k; pv[k] = e < m ? (uint32_t)prevl[e] : 1u; }
+    for (int k = 0; k < 8; k++) { const uint32_t e = e0 + 1024 * k; pv[k] = e < m ? (uint32_t)prevl[e] : 1u; pl[k] = (has_plane && e < m) ? (uint32_t)plane[e] : 0u; }
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const uint32_t e = e0 + 1024 * k; v[k] = pv[k] == 0 ? load8(sin, e) : 0ull; }
+    for (int k = 0; k < 8; k++) { const uint32_t e = e0 + 1024 * k; v[k] = (pv[k] == 0 || (pl[k] & DISTL_CONTINUE)) ? load8(sin, e) : 0ull; }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      if (pv[k] != 0) continue;
+      const bool cont = (pl[k] & DISTL_CONTINUE) != 0;
+      if (pv[k] != 0 && !cont) continue;
       const uint32_t e = e0 + 1024 * k;
-      const uint32_t h = hashL_of(v[k], 4 + l);
-      if (h / PART != (uint32_t)part) continue;                      // (the other workgroups of this segment and level)
-      const uint32_t t = tl[h % PART];
-      if (t == 0xFFFFu) continue;
+      const uint32_t t = tl[hashL_of(v[k], 4 + l)];
       const uint64_t q = pbase + t, d = base + e - q;
-      if (d <= (uint64_t)MAX_DIST && !(prev_first && t == 0)) prevl[e] = (uint16_t)d;
+      const bool reach = t != 0xFFFFu && d <= (uint64_t)MAX_DIST && !(prev_first && t == 0);    // position 0 is never a match source (:467)
+      if (pv[k] == 0 && reach) prevl[e] = (uint16_t)d;
+      if (cont) {
+        // the search for the nearest position sharing 4 + l bytes goes on at the tail: none in reach -> none at all (older
+        // members of the bucket are farther still); a true match -> settled; a hash collision -> left to k_cross_dist
+        if (!reach) plane[e] = 0;
+        else if (t <= 32768u - 4u) {
+          const uint32_t *wp = (const uint32_t *)(pb + (t & ~3u));
+          const uint32_t theirs = __builtin_amdgcn_alignbyte(wp[1], wp[0], t & 3u);   // (t <= 32764: both words inside the staged bytes)
+          if (((theirs ^ (uint32_t)v[k]) & cmask) == 0) plane[e] = (uint16_t)d;
+        }
+      }
     }
   }
 }
@@ -566,18 +594,26 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
   if (lay_first(L, seg) || (uint32_t)(p & 32767u) >= lay_inserted(L, seg)) return;
   const bool prev_first = lay_first(L, seg - 1);
-  // (what the levels >= 4 start from is loaded up front: these loads do not depend on the level-3 search)
+  // Everything a position can need is loaded up front, coalesced and independent of each other (the kernel is a chain of
+  // load latencies: looking at the markers first and loading afterwards was 12 % slower); then only the positions
+  // k_prev_links / k_cross_links left a marker for go on.
+  const uint32_t d3_stored = dp.d[0][p];
   uint32_t dl_first[NLEVELS > 1 ? NLEVELS - 1 : 1], link_first[NLEVELS > 1 ? NLEVELS - 1 : 1];
 #pragma unroll
   for (int l = 0; l + 1 < NLEVELS; l++) { dl_first[l] = dp.d[1 + l][p]; link_first[l] = lv.prev[l][p]; }
   const uint64_t mine = *(const u64u *)(in + p);
+  // (only where the head of the chain may lie exactly MAX_DIST back; p >= 32 768 > MAX_DIST)
+  const uint32_t far24 = (d3_stored == DIST3_HEADCHK || d3_stored == DIST3_CONT_FIRST) ? *(const u32u *)(in + p - (uint64_t)MAX_DIST) & 0xFFFFFFu : 0xFFFFFFFFu;
+  bool need = d3_stored >= DIST3_CONT_FIRST;
+#pragma unroll
+  for (int l = 0; l + 1 < NLEVELS; l++) need = need || (dl_first[l] & DISTL_CONTINUE);
+  if (!need) return;
   // level 3 first: the previous segment's bucket of the 15-bit hash, newest first, as far back as TOO_FAR (see k_prev_links)
-  const uint32_t d3_stored = dp.d[0][p];
-  uint32_t dprev = d3_stored;
+  uint32_t dprev = d3_stored >= DIST3_CONT_FIRST ? 0u : d3_stored;
   const uint32_t my24 = (uint32_t)mine & 0xFFFFFFu;
   const uint32_t b0 = my24 & 0xFF, b1 = (my24 >> 8) & 0xFF;
   const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (my24 >> 16)) & 0x7FFFu;
-  if (dprev == DIST3_CONTINUE) {
+  if (d3_stored == DIST3_CONTINUE || d3_stored == DIST3_CONT_FIRST) {
     const uint32_t bsc = bsc3[pbase + h];
     const uint32_t pst = bsc & 0xFFFF, pct = bsc >> 16;
     const uint16_t *ps = S3 + pbase;
@@ -613,13 +649,12 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
   // exactly MAX_DIST (:850), everything behind it only below (:820).  Here: the candidate lies in the previous segment
   // (own-segment heads are k_prev_links' first candidates), p has no same-hash predecessor in its own segment and the
   // candidate is the last member of its bucket.
-  if (dprev == 0 && (p & 32767u) < (uint32_t)MAX_DIST) {
+  if (dprev == 0 && (d3_stored == DIST3_HEADCHK || d3_stored == DIST3_CONT_FIRST) && (p & 32767u) < (uint32_t)MAX_DIST) {
     const uint64_t q = p - (uint64_t)MAX_DIST;
-    if (!(prev_first && q == pbase) && (*(const u32u *)(in + q) & 0xFFFFFFu) == my24) {
-      const uint32_t own = bsc3[seg * 32768ull + h], prv = bsc3[pbase + h];
-      const bool p_first = S3[seg * 32768ull + (own & 0xFFFF)] == (uint16_t)(p & 32767);
+    if (!(prev_first && q == pbase) && far24 == my24) {
+      const uint32_t prv = bsc3[pbase + h];
       const bool q_last = (prv >> 16) != 0 && S3[pbase + (prv & 0xFFFF) + (prv >> 16) - 1] == (uint16_t)(q & 32767);
-      if (p_first && q_last) dprev = (uint32_t)MAX_DIST;
+      if (q_last) dprev = (uint32_t)MAX_DIST;
     }
   }
   if (dprev != d3_stored) dp.d[0][p] = (uint16_t)dprev;
@@ -1571,7 +1606,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   c->tmark("lz:begin");
   if (!c->lz_attrs_set) {                            // per context: the attribute belongs to the function object of the current device
     hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
-    hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 / CL_SPLIT);
+    hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS_PLANE);
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS);
     hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
     c->lz_attrs_set = true;
@@ -1591,7 +1626,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     c->tmark("prev_links");
     if (nseg > 1) {
       const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
-      hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS * CL_SPLIT), dim3(1024), 131072 / CL_SPLIT, st, W.in, L, lv);
+      hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl);
       hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl);
     }
     hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax);
