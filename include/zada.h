@@ -64,7 +64,7 @@ const char *zada_last_error(const zada_ctx *ctx);
 const char *zada_version(void);
 /* Tuning / test knobs of a context (also read from the environment when the context is created):
  * "budget" (ZADA_BUDGET: rounds of chain steps per position in the first match pass; 0 = unbounded, -1 = default),
- * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "batch_streams" (ZADA_BATCH_STREAMS), "shard_kib" (ZADA_SHARD_KIB: KiB of
+ * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of
  * a stream the match finder takes at a time, multiple of 64).  None of them changes a byte. */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 
@@ -85,9 +85,10 @@ int zada_deflate_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n,
                         void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
 
 /* `count` independent streams (e.g. one per Zip entry: Zip.Create.Add_Stream, zip-create.adb:194-297, is per
- * entry).  Small entries are compressed several at a time (host threads with a stream and a workspace each,
- * owned by ctx; ZADA_BATCH_STREAMS, default 4), entries above 64 MiB one after the other.  rc[i] receives the
- * per-stream return code; crc[i] is in/out as above.  Returns the last negative rc[i], or 0. */
+ * entry; zipada's usual workload is many small files, tools/zipada.adb:126-134).  Entries of up to 4 MiB (Deflate_1 / 2 / 3)
+ * go through ONE launch sequence, up to 512 MiB of them at a time; larger ones, and Deflate_Fixed / Deflate_0 entries, one
+ * after the other.  The bytes are those of one zada_deflate call per entry.  rc[i] receives the per-stream return code
+ * (0, 1 = inefficient: Store it, or < 0); crc[i] is in/out as above.  Returns the last negative rc[i], or 0. */
 int zada_deflate_batch(zada_ctx *ctx, int method, int count,
                        const uint8_t *const *in, const uint64_t *n,
                        uint8_t *const *out, const uint64_t *cap,

@@ -12,7 +12,7 @@
 #include "../../include/zada.h"
 #include "zada_internal.h"
 
-struct zada_ctx { zada::Ctx c; std::vector<zada_ctx *> workers; };   // workers: further contexts of zada_deflate_batch
+struct zada_ctx { zada::Ctx c; };
 
 namespace zada {
 
@@ -590,6 +590,16 @@ static int grow_pinned(void **p, uint64_t *cap, uint64_t need) {
   return 0;
 }
 
+// fn(e) for e in [0, E) on a few host threads (packing and unpacking a batch is memcpy-bound: one thread moves ~8 GB/s)
+template <typename F>
+static void parallel_entries(uint32_t E, uint64_t bytes, F &&fn) {
+  const unsigned T = bytes < (16u << 20) ? 1u : 4u;
+  if (T == 1) { for (uint32_t e = 0; e < E; e++) fn(e); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { for (uint32_t e = (uint32_t)((uint64_t)E * t / T); e < (uint32_t)((uint64_t)E * (t + 1) / T); e++) fn(e); });
+  for (auto &x : th) x.join();
+}
+
 // entries idx[0 .. E) of the caller's arrays through one launch sequence
 static int batch_core(Ctx *c, int method, const int *idx, uint32_t E, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
                       const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc_out) {
@@ -617,10 +627,10 @@ static int batch_core(Ctx *c, int method, const int *idx, uint32_t E, const uint
   if (rc) return rc;
   // ---- pack the entries and the tables (pinned), one copy each
   uint32_t *t_seg = c->btab, *t_ent = c->btab + nseg;
-  for (uint32_t e = 0; e < E; e++) {
+  parallel_entries(E, total, [&](uint32_t e) {
     if (len[e]) memcpy(c->bstage + start[e], in[idx[e]], len[e]);
     for (uint32_t s = start[e] >> 15; s < (start[e + 1] >> 15); s++) t_seg[s] = (start[e] + len[e]) | (s == (start[e] >> 15) ? 0x80000000u : 0u);
-  }
+  });
   memcpy(t_ent, chunk0.data(), (E + 1) * 4); memcpy(t_ent + (E + 1), fl0.data(), (E + 1) * 4); memcpy(t_ent + 2 * (E + 1), start.data(), (E + 1) * 4);
   memcpy(t_ent + 3 * (E + 1), len.data(), (E + 1) * 4); memcpy(t_ent + 4 * (E + 1), crc_in.data(), (E + 1) * 4);
   c->tbegin(); c->tmark("begin");
@@ -669,15 +679,17 @@ static int batch_core(Ctx *c, int method, const int *idx, uint32_t E, const uint
   if (obytes) hipMemcpyAsync(c->bstage, W.out, obytes, hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "batch out")) return ZADA_E_HIP_;
   c->tmark("end"); c->tend();
-  for (uint32_t e = 0; e < E; e++) {
+  std::atomic<int> too_small(0);
+  parallel_entries(E, obytes, [&](uint32_t e) {
     const int i = idx[e];
     out_len[i] = h_bytes[e];
     if (crc) crc[i] = h_crc[e];
-    if (h_bytes[e] >= n[i]) { rc_out[i] = ZADA_INEFFICIENT; continue; }       // zip-compress.adb:479-486
-    if (h_bytes[e] > cap[i]) { rc_out[i] = ZADA_E_INVALID; c->err = "output buffer too small"; continue; }
+    if (h_bytes[e] >= n[i]) { rc_out[i] = ZADA_INEFFICIENT; return; }         // zip-compress.adb:479-486
+    if (h_bytes[e] > cap[i]) { rc_out[i] = ZADA_E_INVALID; too_small.store(1); return; }
     memcpy(out[i], c->bstage + h_base[e], h_bytes[e]);
     rc_out[i] = ZADA_OK;
-  }
+  });
+  if (too_small.load()) c->err = "output buffer too small";
   return 0;
 }
 
@@ -704,14 +716,12 @@ zada_ctx *zada_create(int device) {
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
   if (const char *e = getenv("ZADA_INNER_BUDGET")) z->c.knob_inner_budget = atoi(e);
   if (const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS")) { if (atoi(e) > 0) z->c.knob_max_demand_rounds = atoi(e); }
-  if (const char *e = getenv("ZADA_BATCH_STREAMS")) { if (atoi(e) >= 1) z->c.knob_batch_streams = atoi(e); }
   if (const char *e = getenv("ZADA_SHARD_KIB")) { if (atoi(e) >= 64 && atoi(e) % 64 == 0) z->c.knob_shard_kib = atoi(e); }
   return z;
 }
 
 void zada_destroy(zada_ctx *z) {
   if (!z) return;
-  for (zada_ctx *w : z->workers) zada_destroy(w);
   hipSetDevice(z->c.device);
   hipStreamSynchronize(z->c.stream);
   hipStreamSynchronize(z->c.stream2);
@@ -735,7 +745,6 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
   else if (!strcmp(name, "inner_budget")) z->c.knob_inner_budget = value;
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
-  else if (!strcmp(name, "batch_streams")) z->c.knob_batch_streams = value >= 1 ? value : 4;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
   else return ZADA_E_INVALID;
   return ZADA_OK;
