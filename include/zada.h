@@ -65,7 +65,8 @@ const char *zada_version(void);
 /* Tuning / test knobs of a context (also read from the environment when the context is created):
  * "budget" (ZADA_BUDGET: rounds of chain steps per position in the first match pass; 0 = unbounded, -1 = default),
  * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of
- * a stream the match finder takes at a time, multiple of 64).  None of them changes a byte. */
+ * a stream the match finder takes at a time, multiple of 64), "batch_mib" (MiB one batch of small entries may take).  None
+ * of them changes a byte. */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 
 /* Zip.Compress.Deflate on host buffers (the Ada shim drains `input` with Zip.Block_Read into

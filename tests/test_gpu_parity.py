@@ -284,8 +284,12 @@ def test_batch_is_one_launch_sequence_and_bit_exact(encoder):
         ln = int(rng.integers(1, 60000))
         datas.append(bytes(mix[off:off + ln])); off = (off + ln) % (len(mix) - 70000)
     datas.append(b"")
-    for method in (10, 8):
-        res = encoder.deflate_batch(datas, method)
+    for method, batch_mib in ((10, 512), (8, 512), (9, 1)):          # (1 MiB: the entries go through many small batches)
+        encoder.set_knob("batch_mib", batch_mib)
+        try:
+            res = encoder.deflate_batch(datas, method)
+        finally:
+            encoder.set_knob("batch_mib", 512)
         assert len(res) == len(datas)
         for i, (d, (rc, out, crc)) in enumerate(zip(datas, res)):
             rc2, ref, crc2 = oracle_deflate(d, method)

@@ -531,7 +531,7 @@ static int deflate_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uin
 // (FlushGeom / EntOut, zada_huff.hip).  The bytes are those of one zada_deflate call per entry.
 // --------------------------------------------------------------------------------------------
 constexpr uint64_t BATCH_ENTRY_MAX = 4ull << 20;      // larger entries fill the GPU well enough by themselves
-constexpr uint64_t BATCH_BYTES_MAX = 512ull << 20;    // slots of one batch (LZ workspace: 55 bytes per byte)
+// (slots of one batch: knob "batch_mib", default 512; the LZ workspace takes 55 bytes per byte)
 
 // CRC-32 of every entry (zip-crc_crypto.adb:49-60), one wave per entry: lane j takes the j-th 1/64 of the entry byte by
 // byte from register 0; the pieces are chained with the GF(2) operator "advance by L zero bytes", L being the piece length,
@@ -744,6 +744,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!z || !name) return ZADA_E_INVALID;
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
   else if (!strcmp(name, "inner_budget")) z->c.knob_inner_budget = value;
+  else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
   else return ZADA_E_INVALID;
@@ -993,7 +994,7 @@ int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const 
   for (int i = 0; i < count; i++) {
     if (batchable && n[i] <= BATCH_ENTRY_MAX) {
       const uint64_t slot = ((n[i] ? n[i] : 1) + 32767) & ~32767ull;
-      if (gbytes + slot > BATCH_BYTES_MAX) flush_group();
+      if (gbytes + slot > ((uint64_t)c->knob_batch_mib << 20)) flush_group();
       group.push_back(i); gbytes += slot;
     } else {
       rc[i] = zada_deflate(z, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr);

@@ -250,6 +250,7 @@ struct Ctx {
   int knob_budget = -1;             // ZADA_BUDGET: rounds of chain steps per position in the first match pass (0 = unbounded, -1 = default)
   int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
   int knob_inner_budget = 0;        // ZADA_INNER_BUDGET: rounds for positions deep inside a match (0 = as every other position; A/B: 1 round saves 4.7 ms in k_match and costs 8.9 ms of demand searches, 2 rounds: -3.2 / +3.7)
+  int knob_batch_mib = 512;         // MiB of LZ buffer one batch of small entries may take (zada_deflate_batch)
   int knob_shard_kib = 1 << 20;     // ZADA_SHARD_KIB: bytes of a range the LZ stage takes at a time, in KiB (multiple of 64)
   void tmark(const char *name);
   void tbegin();
