@@ -47,7 +47,7 @@ enum {
   ZADA_E_INVALID = -1,      /* bad argument / unsupported method */
   ZADA_E_NOMEM = -2,        /* host or device allocation failed */
   ZADA_E_HIP = -3,          /* HIP runtime error; see zada_last_error() */
-  ZADA_E_TOO_LARGE = -4,    /* one context takes < 4 GiB - 64 MiB of a stream: larger streams are cut into ranges (zada_range_*) */
+  ZADA_E_TOO_LARGE = -4,    /* zada_range_open: a range is < 4 GiB - 64 MiB (zada_deflate* take streams of any length, span after span) */
   ZADA_E_NO_DEVICE = -5     /* no gfx950 device / HIP extension unusable */
 };
 
@@ -65,8 +65,8 @@ const char *zada_version(void);
 /* Tuning / test knobs of a context (also read from the environment when the context is created):
  * "budget" (ZADA_BUDGET: rounds of chain steps per position in the first match pass; 0 = unbounded, -1 = default),
  * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of
- * a stream the match finder takes at a time, multiple of 64), "batch_mib" (MiB one batch of small entries may take).  None
- * of them changes a byte. */
+ * a stream the match finder takes at a time, multiple of 64), "span_mib" (MiB of a stream one pass takes; longer streams go span after
+ * span, default 2048), "batch_mib" (MiB one batch of small entries may take).  None of them changes a byte. */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 
 /* Zip.Compress.Deflate on host buffers (the Ada shim drains `input` with Zip.Block_Read into

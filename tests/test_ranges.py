@@ -207,3 +207,34 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     assert res["n_gpus"] == 3 and res["config"]["rc"] == 0
     assert res["checks"]["stream_inflates_to_input_crc"] is True and res["checks"]["sample_stream_equals_cpu_port"] is True, res["checks"]
     assert res["checks"]["inflated_bytes"] == 3 * (48 << 20)
+
+
+def test_spans_on_one_context(encoder):
+    """Streams longer than one pass takes ("span_mib") go through one context span after span: parser state, the atoms behind
+    the last whole flush (with their bytes), the chooser's state and the shared output byte are kept from span to span.
+    8 MiB in 1 MiB and 3 MiB spans == the oracle, for every method; zeros (the carried atoms span many spans: 4 000 atoms per
+    MiB), incompressible stretches (stored pieces of carried atoms), and the device-resident entry point."""
+    import torch
+    za = product()
+    rng = np.random.default_rng(3)
+    mix = silesia_mix((8 << 20) + 12345)
+    cases = [mix, bytes(5 << 20) + mix[:100000], mix[:1 << 20] + bytes(rng.integers(0, 256, 3 << 20, dtype=np.uint8)) + mix[:(1 << 20) + 7],
+             edge_inputs()["copies_1500k"] * 3, silesia_mix(4 << 20, class_mask=1)]
+    try:
+        for d in cases:
+            for method in (10, 8, 7, 6):
+                ob = []
+                rc, ref, crc = oracle_deflate(d, method, ob)
+                for span in (1, 3):
+                    encoder.set_knob("span_mib", span)
+                    rc2, out, crc2 = gpu_deflate(encoder, d, method)
+                    assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), (len(d), method, span)
+        d = mix
+        rc, ref, crc = oracle_deflate(d, 10)
+        encoder.set_knob("span_mib", 2)
+        t_in = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        t_out = torch.zeros(len(d) + 4096, dtype=torch.uint8, device="cuda")
+        rc2, ol, crc2 = encoder.deflate_device(t_in.data_ptr(), len(d), t_out.data_ptr(), len(d) + 4096, 10)
+        assert rc2 == 0 and bytes(t_out[:ol].cpu().numpy()) == ref and crc2 == crc
+    finally:
+        encoder.set_knob("span_mib", 2048)

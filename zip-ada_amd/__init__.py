@@ -138,7 +138,7 @@ class Encoder:
             pass
 
     def set_knob(self, name, value):
-        """Tuning / test knobs ("budget", "max_demand_rounds", "inner_budget", "shard_kib", "batch_mib"); none changes a byte of output."""
+        """Tuning / test knobs ("budget", "max_demand_rounds", "inner_budget", "shard_kib", "span_mib", "batch_mib"); none changes a byte of output."""
         if self.lib.zada_set_knob(self.ctx, name.encode(), int(value)) != 0:
             raise ZadaError("unknown knob %r" % name)
 

@@ -369,12 +369,14 @@ __global__ void k_pad_init(PadArgs a) {
     if (threadIdx.x < 64) a.link_end[l][threadIdx.x] = 0;
 }
 
-int range_open(Ctx *c, int method, const uint8_t *rin, uint64_t stream_size, uint64_t lo, uint64_t n, uint64_t pre, uint64_t post) {
+int range_open(Ctx *c, int method, const uint8_t *rin, uint64_t stream_size, uint64_t lo, uint64_t n, uint64_t pre, uint64_t post, uint64_t carry_atoms = 0) {
   const int level = method_level(method);
   if (level < 0) { c->err = "unsupported method"; return ZADA_E_INVALID; }
   if (lo + n > stream_size || n > stream_size) { c->err = "range outside the stream"; return ZADA_E_INVALID; }
   const uint64_t behind = stream_size - (lo + n);
-  if (pre != (lo > 0 ? SHARD_HALO : 0u) || post != (behind < RANGE_POST ? behind : RANGE_POST) ||
+  // (spans of one stream on one context keep more than the halo before the range resident: the bytes of the atoms carried over)
+  const bool pre_ok = pre == (lo > 0 ? SHARD_HALO : 0u) || (carry_atoms > 0 && pre <= lo && pre >= SHARD_HALO && (pre % 32768) == 0) || (lo > 0 && pre == 65536);
+  if (!pre_ok || post != (behind < RANGE_POST ? behind : RANGE_POST) ||
       (lo % 65536) != 0 || (behind > 0 && (n % 65536) != 0) || (behind > 0 && n == 0)) {
     c->err = "range: boundaries must be multiples of 64 KiB, with 32 KiB before and min(1 MiB, rest of the stream) behind it resident";
     return ZADA_E_INVALID;
@@ -382,11 +384,12 @@ int range_open(Ctx *c, int method, const uint8_t *rin, uint64_t stream_size, uin
   if (pre + n + post >= (1ull << 32) - (1ull << 26)) { c->err = "range too large for one context (4 GiB - 64 MiB): split the stream into ranges"; return ZADA_E_TOO_LARGE; }
   if (((uintptr_t)rin & 15) != 0) { c->err = "range: input must be 16-byte aligned"; return ZADA_E_INVALID; }
   const uint64_t shard = (uint64_t)c->knob_shard_kib << 10;
-  int rc = ensure_entropy_workspace(c, n, 0);
+  int rc = ensure_entropy_workspace(c, n + carry_atoms, 0);
   if (!rc) rc = ensure_lz_workspace(c, (n < shard ? n : shard) + SHARD_HALO + SHARD_TAIL);
   if (rc) return rc;
   Range &R = c->rg;
   R = Range();
+  R.T_carried = carry_atoms;
   R.open = true; R.rin = rin; R.lo = lo; R.pre = pre; R.n = n; R.post = post;
   R.first = lo == 0; R.last = behind == 0; R.method = method; R.level = level;
   c->last_nblocks = 0;
@@ -407,7 +410,7 @@ int range_lz(Ctx *c, const GlobalState *entry, zada_feedback_fn fb, void *user) 
   if (!R.open) { c->err = "no range open"; return ZADA_E_INVALID; }
   const uint64_t shard = (uint64_t)c->knob_shard_kib << 10;
   if (shard == 0 || (shard % 65536) != 0) { c->err = "shard size must be a multiple of 64 KiB"; return ZADA_E_INVALID; }
-  R.T = 0; R.placed = R.analyzed = R.chosen = false;
+  R.T = R.T_carried; R.placed = R.analyzed = R.chosen = false;
   R.entry_known = R.first || entry != nullptr;
   GlobalState cur{R.lo, SYNC_F, 0};
   if (!R.first && entry) cur = *entry;
@@ -522,6 +525,115 @@ static int deflate_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uin
   if (crc_inout) *crc_inout = crc32_advance(*crc_inout, n) ^ R.crc_raw;
   if (fb && fb(100, user)) return ZADA_ABORTED;
   return inefficient ? ZADA_INEFFICIENT : ZADA_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// Spans: a stream longer than one pass takes ("span_mib", default 2 GiB; a range is limited to 4 GiB - 64 MiB) on ONE
+// context, span after span.  What a range would get from its neighbours on other GPUs is here simply kept: the parser
+// state at the end of a span, the atoms behind its last complete 65 536-atom flush (they open the next span's atom array,
+// with 2 048 atoms of look-behind in front) together with the bytes they stand for (the next span's input window starts at
+// the first of them), Send_as_block's state and the last, partly filled byte of the output.
+// --------------------------------------------------------------------------------------------
+}  // namespace zada
+static void copy_in(zada::Ctx *c, void *d_dst, const uint8_t *src, uint64_t n);
+static int copy_out(zada::Ctx *c, uint8_t *dst, const void *d_src, uint64_t n);
+namespace zada {
+__global__ void k_add_u32(uint32_t *__restrict__ p, uint32_t n, uint32_t delta) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += delta;
+}
+
+static int deflate_spans(Ctx *c, int method, const uint8_t *d_src, const uint8_t *h_src, uint64_t n, uint8_t *d_dst, uint8_t *h_dst, uint64_t cap,
+                         uint64_t *out_len, uint32_t *crc_inout, zada_feedback_fn fb, void *user) {
+  Workspace &W = c->ws;
+  hipStream_t st = c->stream;
+  const uint64_t span = (uint64_t)c->knob_span_mib << 20;
+  if (fb && fb(0, user)) return ZADA_ABORTED;
+  c->tbegin(); c->tmark("begin");
+  int rc = ensure_entropy_workspace(c, span + FLUSH + 4096, 0);         // (never re-allocated between spans: the carried atoms live in it)
+  if (rc) return rc;
+  GlobalState entry{0, SYNC_F, 0};
+  uint64_t G = 0, ws_prev = 0, carry_first_byte = 0, base_bytes = 0;
+  uint32_t Tc = 0, nlb = 0, crc = crc_inout ? *crc_inout : 0xFFFFFFFFu;
+  uint8_t shared = 0;
+  ChooserCarry cc = ChooserCarry();
+  cc.last_type = BT_RESERVED; cc.cur_eob = 7u << 16;
+  bool inefficient = false;
+  int total_demand = 0, total_splice = 0;
+  for (uint64_t lo = 0; lo < n; lo += span) {
+    const uint64_t hi = lo + span < n ? lo + span : n;
+    const bool last = hi == n;
+    uint64_t ws = lo >= 65536 ? lo - 65536 : 0;                         // input window: 64 KiB before the span (its halo and then some) ...
+    if (Tc > 0 && (carry_first_byte & ~65535ull) < ws) ws = carry_first_byte & ~65535ull;   // ... or from the first carried atom's byte
+    const uint64_t post = n - hi < RANGE_POST ? n - hi : RANGE_POST;
+    const uint8_t *rin;
+    if (d_src) rin = d_src + ws;
+    else {
+      rc = ensure_rin(c, hi + post - ws);
+      if (rc) return rc;
+      copy_in(c, W.rin_own, h_src + ws, hi + post - ws);
+      rin = W.rin_own;
+    }
+    rc = range_open(c, method, rin, n, lo, hi - lo, lo - ws, post, lo > 0 ? (uint64_t)Tc + 1 : 0);
+    if (rc) return rc;
+    Range &R = c->rg;
+    R.T_carried = Tc; R.n_lb = nlb;
+    // the carried atoms' positions were relative to the window before
+    if (nlb + Tc > 0 && ws != ws_prev)
+      hipLaunchKernelGGL(k_add_u32, dim3((nlb + Tc + 255) / 256), dim3(256), 0, st, W.ea_apos + LB_CAP - nlb, nlb + Tc, (uint32_t)(ws_prev - ws));
+    rc = range_lz(c, lo > 0 ? &entry : nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    total_demand += c->demand_rounds; total_splice += c->parse_rounds;
+    // what the entropy stage takes now: whole flushes (the stream's position on the flush grid is G, a multiple of 65 536)
+    const uint64_t tview = last ? R.T : R.T / FLUSH * FLUSH;
+    R.G = G; R.n_la = 0; R.T_view = tview; R.T_total = last ? G + R.T : ~0ull >> 2;
+    R.nflush = (uint32_t)((tview + FLUSH - 1) / FLUSH); R.foff = nlb; R.j0 = G / FLUSH; R.placed = true;
+    if (R.nflush > 0 || last) {
+      rc = entropy_analyze(c);
+      if (rc) return rc;
+      hipStreamWaitEvent(st, c->ev_out, 0);
+      if (cc.pos & 7) hipMemcpyAsync(W.out, &shared, 1, hipMemcpyHostToDevice, st);       // the byte this span shares with the one before
+      R.carry_in = cc;
+      rc = entropy_choose(c);
+      if (rc) return rc;
+      cc = R.carry_out;
+      const uint64_t nb = (R.co.total_bits + 7) / 8;
+      if (base_bytes + nb >= n) { inefficient = true; base_bytes += nb; break; }             // zip-compress.adb:479-486: the reference stops here as well
+      rc = entropy_emit(c, nullptr);
+      if (rc) return rc;
+      if (base_bytes + nb > cap) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
+      if (d_dst) hipMemcpyAsync(d_dst + base_bytes, W.out, nb, hipMemcpyDeviceToDevice, st);
+      else if (copy_out(c, h_dst + base_bytes, W.out, nb)) return ZADA_E_HIP_;
+      if ((cc.pos & 7) && nb) hipMemcpyAsync(&shared, W.out + nb - 1, 1, hipMemcpyDeviceToHost, st);
+      if (hip_check(c, hipStreamSynchronize(st), "span out")) return ZADA_E_HIP_;
+      base_bytes = cc.pos / 8;                                           // (the next span rewrites the shared byte with its bits added)
+    }
+    if (!last) {
+      // carry: the atoms behind the last whole flush, with up to 2 048 atoms of look-behind in front of them
+      const uint32_t tc2 = (uint32_t)(R.T - tview), avail = nlb + (uint32_t)tview, nlb2 = avail < LB_CAP ? avail : LB_CAP;
+      const uint32_t cnt = nlb2 + tc2;
+      const uint64_t src = LB_CAP + tview - nlb2, dst = LB_CAP - nlb2;
+      if (src != dst && cnt) {                                           // (through a scratch array: the two places may overlap)
+        hipMemcpyAsync(W.spec_tok, W.ea_atoms + src, (size_t)cnt * 4, hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(W.spec_tok + cnt, W.ea_apos + src, (size_t)cnt * 4, hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(W.ea_atoms + dst, W.spec_tok, (size_t)cnt * 4, hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(W.ea_apos + dst, W.spec_tok + cnt, (size_t)cnt * 4, hipMemcpyDeviceToDevice, st);
+      }
+      uint32_t first_pos = 0;
+      if (tc2) hipMemcpyAsync(&first_pos, W.ea_apos + LB_CAP, 4, hipMemcpyDeviceToHost, st);
+      if (hip_check(c, hipStreamSynchronize(st), "span carry")) return ZADA_E_HIP_;
+      carry_first_byte = ws + first_pos;
+      G += tview; Tc = tc2; nlb = nlb2;
+    }
+    entry = R.exit; ws_prev = ws;
+    crc = crc32_advance(crc, hi - lo) ^ R.crc_raw;
+    if (fb && fb((int)(100 * hi / n), user)) return ZADA_ABORTED;
+  }
+  c->demand_rounds = total_demand; c->parse_rounds = total_splice;
+  c->tmark("end"); c->tend();
+  *out_len = inefficient ? base_bytes : (cc.pos + 7) / 8;
+  if (crc_inout) *crc_inout = crc;
+  return (inefficient || *out_len >= n) ? ZADA_INEFFICIENT : ZADA_OK;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -744,6 +856,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!z || !name) return ZADA_E_INVALID;
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
   else if (!strcmp(name, "inner_budget")) z->c.knob_inner_budget = value;
+  else if (!strcmp(name, "span_mib")) { if (value < 1 || value > 3968) return ZADA_E_INVALID; z->c.knob_span_mib = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
@@ -821,6 +934,12 @@ int zada_deflate(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t
   int rc = prepare(z);
   if (rc) return rc;
   Ctx *c = &z->c;
+  if (n > ((uint64_t)c->knob_span_mib << 20)) {                   // longer than one pass takes: span after span
+    uint64_t ol = 0;
+    rc = finish_call(c, deflate_spans(c, method, nullptr, in, n, nullptr, out, cap, &ol, crc_inout, fb, user));
+    if (out_len && rc >= 0 && rc != ZADA_ABORTED) *out_len = ol;
+    return rc;
+  }
   rc = ensure_rin(c, n);
   if (rc) return rc;
   copy_in(c, c->ws.rin_own, in, n);
@@ -840,6 +959,12 @@ int zada_deflate_device(zada_ctx *z, int method, const void *d_in, uint64_t n, v
   int rc = prepare(z);
   if (rc) return rc;
   Ctx *c = &z->c;
+  if (n > ((uint64_t)c->knob_span_mib << 20) && ((uintptr_t)d_in & 15) == 0) {
+    uint64_t ol = 0;
+    rc = finish_call(c, deflate_spans(c, method, (const uint8_t *)d_in, nullptr, n, (uint8_t *)d_out, nullptr, cap, &ol, crc_inout, nullptr, nullptr));
+    if (out_len && rc >= 0) *out_len = ol;
+    return rc;
+  }
   const uint8_t *src = (const uint8_t *)d_in;
   if (((uintptr_t)d_in & 15) != 0 && n) {              // the kernels read 16 bytes at a time
     rc = ensure_rin(c, n);

@@ -1027,8 +1027,9 @@ static EntropyView range_view(Ctx *c) {
   EntropyView v;
   v.ftab = R.batch ? W.ftab : nullptr;
   v.atoms = W.ea_atoms + (LB_CAP - R.n_lb); v.apos = W.ea_apos + (LB_CAP - R.n_lb);
-  v.foff = R.foff; v.nflush = R.nflush; v.lvalid = (uint32_t)(R.n_lb + R.T + R.n_la);
-  v.stream_final = (R.G + R.T + R.n_la == R.T_total) ? 1u : 0u;
+  const uint64_t tv = R.T_view == ~0ull ? R.T : R.T_view;
+  v.foff = R.foff; v.nflush = R.nflush; v.lvalid = (uint32_t)(R.n_lb + tv + R.n_la);
+  v.stream_final = (R.G + tv + R.n_la == R.T_total) ? 1u : 0u;
   v.j0 = R.j0;
   return v;
 }
@@ -1051,7 +1052,7 @@ int entropy_analyze(Ctx *c) {
   if (v.nflush > 0) {
     if (fixed_only) {
       nblocks = v.nflush;
-      hipLaunchKernelGGL(k_fill_blocks_fixed, dim3((nblocks + 255) / 256), dim3(256), 0, st, v.foff, (uint32_t)R.T, nblocks, W.blocks);
+      hipLaunchKernelGGL(k_fill_blocks_fixed, dim3((nblocks + 255) / 256), dim3(256), 0, st, v.foff, v.lvalid - v.foff, nblocks, W.blocks);
     } else {
       const uint32_t kstep = R.method == 8 ? 8 : R.method == 9 ? 4 : 1;                        // max_choice :1310-1311
       hipLaunchKernelGGL(k_window_descr, dim3(v.nflush * SLOTS), dim3(64), 0, st, v, kstep, W.descr);

@@ -203,6 +203,8 @@ struct Range {
   bool first = true, last = true;
   int method = 0, level = 0;
   uint64_t T = 0;                    // the range's own atoms
+  uint64_t T_carried = 0;            // ... of which already in the array when the LZ stage starts (carried over from the span before)
+  uint64_t T_view = ~0ull;           // own atoms the entropy stage takes now (spans: whole flushes only); ~0 = all
   uint32_t n_lb = 0, n_la = 0;       // look-behind / look-ahead atoms in the local array
   GlobalState exit{}, warm{};        // exit: first history-free state at or beyond the end of the range; warm: the one at or
                                      // beyond its start, found by the warm-up parse when the entry was not known
@@ -250,6 +252,7 @@ struct Ctx {
   int knob_budget = -1;             // ZADA_BUDGET: rounds of chain steps per position in the first match pass (0 = unbounded, -1 = default)
   int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
   int knob_inner_budget = 0;        // ZADA_INNER_BUDGET: rounds for positions deep inside a match (0 = as every other position; A/B: 1 round saves 4.7 ms in k_match and costs 8.9 ms of demand searches, 2 rounds: -3.2 / +3.7)
+  int knob_span_mib = 2048;         // MiB of a stream one pass takes (longer streams: spans one after the other, deflate_spans)
   int knob_batch_mib = 512;         // MiB of LZ buffer one batch of small entries may take (zada_deflate_batch)
   int knob_shard_kib = 1 << 20;     // ZADA_SHARD_KIB: bytes of a range the LZ stage takes at a time, in KiB (multiple of 64)
   void tmark(const char *name);
