@@ -86,9 +86,8 @@ int zada_deflate_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n,
                         void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
 
 /* `count` independent streams (e.g. one per Zip entry: Zip.Create.Add_Stream, zip-create.adb:194-297, is per
- * entry; zipada's usual workload is many small files, tools/zipada.adb:126-134).  Entries of up to 4 MiB (Deflate_1 / 2 / 3)
- * go through ONE launch sequence, up to 512 MiB of them at a time; larger ones, and Deflate_Fixed / Deflate_0 entries, one
- * after the other.  The bytes are those of one zada_deflate call per entry.  rc[i] receives the per-stream return code
+ * entry; zipada's usual workload is many small files, tools/zipada.adb:126-134).  Entries of up to 4 MiB go through ONE
+ * launch sequence, up to 512 MiB of them at a time ("batch_mib"); larger ones one after the other.  The bytes are those of one zada_deflate call per entry.  rc[i] receives the per-stream return code
  * (0, 1 = inefficient: Store it, or < 0); crc[i] is in/out as above.  Returns the last negative rc[i], or 0. */
 int zada_deflate_batch(zada_ctx *ctx, int method, int count,
                        const uint8_t *const *in, const uint64_t *n,

@@ -284,7 +284,7 @@ def test_batch_is_one_launch_sequence_and_bit_exact(encoder):
         ln = int(rng.integers(1, 60000))
         datas.append(bytes(mix[off:off + ln])); off = (off + ln) % (len(mix) - 70000)
     datas.append(b"")
-    for method, batch_mib in ((10, 512), (8, 512), (9, 1)):          # (1 MiB: the entries go through many small batches)
+    for method, batch_mib in ((10, 512), (8, 512), (9, 1), (7, 512), (6, 512), (6, 1)):   # (1 MiB: the entries go through many small batches)
         encoder.set_knob("batch_mib", batch_mib)
         try:
             res = encoder.deflate_batch(datas, method)

@@ -1102,9 +1102,8 @@ int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const 
   Ctx *c = &z->c;
   int worst = 0;
   // Entries of up to 4 MiB go through ONE launch sequence, as many at a time as the workspace takes (batch_core); larger
-  // ones fill the GPU by themselves and are compressed one after the other.  (Deflate_Fixed / Deflate_0 entries take the
-  // single-entry path: their front ends have no per-entry layout.)
-  const bool batchable = method == ZADA_DEFLATE_1 || method == ZADA_DEFLATE_2 || method == ZADA_DEFLATE_3;
+  // ones fill the GPU by themselves and are compressed one after the other.
+  const bool batchable = method >= ZADA_DEFLATE_FIXED && method <= ZADA_DEFLATE_3;
   std::vector<int> group;
   uint64_t gbytes = 0;
   auto flush_group = [&]() {

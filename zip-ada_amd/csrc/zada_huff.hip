@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64) k_cut_scan(EntropyView v, uint32_t kstep, 
 }
 
 __global__ void k_fill_blocks(EntropyView v, const uint32_t *__restrict__ seg_nblk, const uint32_t *__restrict__ seg_cut,
-                              const uint32_t *__restrict__ seg_off, BlockRange *__restrict__ blocks, uint32_t *__restrict__ blk_entry) {
+                              const uint32_t *__restrict__ seg_off, BlockRange *__restrict__ blocks, uint32_t *__restrict__ blk_entry, int fixed_only) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= v.nflush) return;
   uint64_t gj; uint32_t F, to, fl;
@@ -166,6 +166,8 @@ __global__ void k_fill_blocks(EntropyView v, const uint32_t *__restrict__ seg_nb
     uint32_t first = cuts[i], end = (i + 1 < nb) ? cuts[i + 1] - 1 : to;
     BlockRange b; b.first = first; b.count = end - first + 1; b.pad = 0;
     b.last_flush = ((fl & FG_LAST_PARTIAL) && i + 1 == nb) ? (uint32_t)BR_LAST_FLUSH : 0u;
+    // Deflate_Fixed (batches): ONE fixed block per entry, marked final where it is opened (:1600-1603)
+    if (fixed_only) b.last_flush = ((fl & FG_ENTRY_FIRST) && i == 0) ? (uint32_t)BR_LAST_FLUSH : 0u;
     if (v.ftab) {
       if ((fl & FG_ENTRY_FIRST) && i == 0) b.last_flush |= BR_ENTRY_FIRST;
       if ((fl & FG_ENTRY_LAST) && i + 1 == nb) { b.last_flush |= BR_ENTRY_LAST; b.pad = v.ftab[j].end_byte; }
@@ -459,11 +461,15 @@ __device__ __forceinline__ uint32_t ch_decide(const ChRec &r, uint64_t c, uint64
   return rb <= st ? (uint32_t)FMT_RECYCLE : (uint32_t)FMT_STORED;
 }
 
-__global__ void __launch_bounds__(256) k_ch_tentative(uint32_t nblocks, const ChRec *__restrict__ chrec, ChW *__restrict__ chw) {
+__global__ void __launch_bounds__(256) k_ch_tentative(uint32_t nblocks, const ChRec *__restrict__ chrec, ChW *__restrict__ chw, int fixed_only) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nblocks) return;
   ChW w; w.rdata = 0; w.eob_in = 7u << 16; w.dec = 0xFF; w.T_in = BT_RESERVED; w.B_in = 1; w.pad = 0; w.code_block = CODE_FIXED; w.code_variant = 0; w.npieces = 0; w.bytes_pad = 0;
-  if (chrec[i].br.last_flush & BR_ENTRY_FIRST) {
+  if (fixed_only) {
+    // Deflate_Fixed in a batch: every block is sent fixed; an entry's first block opens the one Deflate block, the others go on in it
+    w.dec = FMT_FIXED;
+    if (chrec[i].br.last_flush & BR_ENTRY_FIRST) w.B_in = 0; else w.T_in = BT_FIXED;
+  } else if (chrec[i].br.last_flush & BR_ENTRY_FIRST) {
     // a batch: the block starts its entry, i.e. a stream (last_block_type reserved, nothing to finish, nothing to recycle)
     w.B_in = 0; w.rdata = ~0ull;
     w.dec = (uint8_t)ch_decide(chrec[i], 1, ~0ull);
@@ -1050,24 +1056,24 @@ int entropy_analyze(Ctx *c) {
   uint32_t nblocks = 0;
   hipLaunchKernelGGL(k_apos_sentinel, dim3(1), dim3(1), 0, st, v.atoms, (uint32_t *)v.apos, v.lvalid);
   if (v.nflush > 0) {
-    if (fixed_only) {
+    if (fixed_only && !R.batch) {
       nblocks = v.nflush;
       hipLaunchKernelGGL(k_fill_blocks_fixed, dim3((nblocks + 255) / 256), dim3(256), 0, st, v.foff, v.lvalid - v.foff, nblocks, W.blocks);
     } else {
-      const uint32_t kstep = R.method == 8 ? 8 : R.method == 9 ? 4 : 1;                        // max_choice :1310-1311
-      hipLaunchKernelGGL(k_window_descr, dim3(v.nflush * SLOTS), dim3(64), 0, st, v, kstep, W.descr);
+      const uint32_t kstep = fixed_only ? (1u << 30) : R.method == 8 ? 8 : R.method == 9 ? 4 : 1;   // max_choice :1310-1311 (Deflate_Fixed in a batch: no scanning, one block per flush)
+      if (!fixed_only) hipLaunchKernelGGL(k_window_descr, dim3(v.nflush * SLOTS), dim3(64), 0, st, v, kstep, W.descr);
       c->tmark("window_descr");
       hipLaunchKernelGGL(k_cut_scan, dim3(v.nflush), dim3(64), 0, st, v, kstep, W.descr, W.seg_nblk, W.seg_cut, W.cut_trace);
       exclusive_scan_u32(st, W.seg_nblk, W.seg_blk_off, W.scan2, W.total2, v.nflush);
       hipMemcpyAsync(&nblocks, W.total2, 4, hipMemcpyDeviceToHost, st);
-      hipLaunchKernelGGL(k_fill_blocks, dim3((v.nflush + 255) / 256), dim3(256), 0, st, v, W.seg_nblk, W.seg_cut, W.seg_blk_off, W.blocks, W.blk_entry);
+      hipLaunchKernelGGL(k_fill_blocks, dim3((v.nflush + 255) / 256), dim3(256), 0, st, v, W.seg_nblk, W.seg_cut, W.seg_blk_off, W.blocks, W.blk_entry, fixed_only ? 1 : 0);
       if (hip_check(c, hipStreamSynchronize(st), "cut_scan")) return ZADA_E_HIP_;
       c->tmark("cut_scan");
     }
     if (nblocks > W.cap_blocks) { c->err = "block table overflow"; return -1; }
     if (nblocks > 0) hipLaunchKernelGGL(k_block_analyze, dim3(nblocks), dim3(256), 0, st, v.atoms, v.apos, W.blocks, W.binfo);
     c->tmark("block_analyze");
-    if (!fixed_only && nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (ChRec *)W.chrec);
+    if ((!fixed_only || R.batch) && nblocks > 0) hipLaunchKernelGGL(k_block_relate, dim3(nblocks), dim3(64), 0, st, nblocks, W.binfo, W.blocks, (ChRec *)W.chrec);
   }
   R.nblocks = nblocks;
   R.analyzed = true;
@@ -1085,7 +1091,7 @@ int entropy_choose(Ctx *c) {
   hipMemcpyAsync(W.carry, &R.carry_in, sizeof(ChooserCarry), hipMemcpyHostToDevice, st);
   // the chooser itself writes the few bits of stored-block headers and of the epilogue: the output must be zero before
   const uint64_t lim_bits = W.cap_out * 8;
-  if (fixed_only)
+  if (fixed_only && !R.batch)
     hipLaunchKernelGGL(k_choose_fixed, dim3(1), dim3(64), 0, st, R.nblocks, W.blocks, W.binfo, W.emit, W.tile_block, (uint32_t)W.cap_tiles,
                        (uint32_t *)W.out, lim_bits, W.chooser, W.carry, W.carry + 1, R.base_bits, R.G == 0 ? 1 : 0, v.stream_final ? 1 : 0);
   else {
@@ -1093,8 +1099,8 @@ int entropy_choose(Ctx *c) {
     const uint32_t nb = R.nblocks;
     ChW *chw = (ChW *)W.chw;
     if (nb > 0) {
-      hipLaunchKernelGGL(k_ch_tentative, dim3((nb + 255) / 256), dim3(256), 0, st, nb, (const ChRec *)W.chrec, chw);
-      hipLaunchKernelGGL(k_ch_resolve, dim3(1), dim3(64), 0, st, nb, (const ChRec *)W.chrec, W.binfo, chw, W.carry, R.batch ? 1 : 0);
+      hipLaunchKernelGGL(k_ch_tentative, dim3((nb + 255) / 256), dim3(256), 0, st, nb, (const ChRec *)W.chrec, chw, fixed_only ? 1 : 0);
+      if (!fixed_only) hipLaunchKernelGGL(k_ch_resolve, dim3(1), dim3(64), 0, st, nb, (const ChRec *)W.chrec, W.binfo, chw, W.carry, R.batch ? 1 : 0);
       hipLaunchKernelGGL(k_ch_stored, dim3((nb + 63) / 64), dim3(64), 0, st, nb, (const ChRec *)W.chrec, v.apos, chw);
     }
     hipLaunchKernelGGL(k_ch_layout, dim3(1), dim3(1024), 0, st, nb, (const ChRec *)W.chrec, W.binfo, chw, W.emit, W.piece_base,
@@ -1132,7 +1138,7 @@ int entropy_emit(Ctx *c, uint8_t *d_out) {
   const uint32_t nblocks = R.nblocks;
   const ChooserOut &co = R.co;
   if ((co.total_bits + 7) / 8 + 8 > W.cap_out) { c->err = "output workspace overflow"; return -1; }
-  if (!fixed_only && nblocks > 0)
+  if ((!fixed_only || R.batch) && nblocks > 0)
     hipLaunchKernelGGL(k_emit_prefix, dim3((nblocks + 255) / 256), dim3(256), 0, st, nblocks, W.emit, W.blocks, W.tile_block, (uint32_t *)W.out);
   hipLaunchKernelGGL(k_block_codes, dim3(nblocks + 2), dim3(64), 0, st, nblocks, W.emit, W.binfo, W.codes, W.carry);
   const EntropyView v = range_view(c);

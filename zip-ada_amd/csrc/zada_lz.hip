@@ -1575,6 +1575,21 @@ __global__ void k_literal_atoms(const uint8_t *__restrict__ in, uint64_t n, uint
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { atoms[i] = in[i]; apos[i] = (uint32_t)i + bias; }
 }
 
+// the same for a batch of entries: per parse chunk, the bytes that belong to its entry (every byte a literal atom)
+__global__ void k_literal_counts(uint32_t nchunks, Layout L, uint32_t *__restrict__ counts) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nchunks) return;
+  const uint64_t c0 = (uint64_t)k * PCHUNK, e = lay_end(L, c0 >> 15);
+  counts[k] = e > c0 ? (uint32_t)(e - c0 < PCHUNK ? e - c0 : PCHUNK) : 0u;
+}
+__global__ void __launch_bounds__(256) k_literal_atoms_batch(uint32_t nchunks, const uint8_t *__restrict__ in, const uint32_t *__restrict__ counts,
+                                                             const uint32_t *__restrict__ offsets, uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos) {
+  const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (k >= nchunks) return;
+  const uint32_t cnt = counts[k], o = offsets[k], c0 = k * PCHUNK;
+  for (uint32_t i = lane; i < cnt; i += 64) { atoms[o + i] = in[c0 + i]; apos[o + i] = c0 + i; }
+}
+
 // --------------------------------------------------------------------------------------------
 // host side of the LZ stage
 // --------------------------------------------------------------------------------------------
@@ -1591,6 +1606,19 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   const uint64_t n = job.nbuf;
   res->ntok = 0; res->exit = ExitState{(uint32_t)n, SYNC_F}; res->warm = ExitState{job.tok_lo, SYNC_F};
   if (n == 0) return 0;
+  if (level == 0 && job.segend) {                  // a batch: the chunks' byte counts stand for their token counts (zada_api.hip, batch_core)
+    const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
+    const Layout L{job.segend, n};
+    hipLaunchKernelGGL(k_literal_counts, dim3((nch + 255) / 256), dim3(256), 0, st, nch, L, W.counts);
+    exclusive_scan_u32(st, W.counts, W.offsets, W.scan_sums, W.n_changed, nch);
+    uint32_t total = 0;
+    hipMemcpyAsync(&total, W.n_changed, 4, hipMemcpyDeviceToHost, st);
+    if (hip_check(c, hipStreamSynchronize(st), "literal counts")) return ZADA_E_HIP_;
+    if (total > job.cap_atoms) { c->err = "atom array overflow"; return -2; }
+    hipLaunchKernelGGL(k_literal_atoms_batch, dim3((nch + 3) / 4), dim3(256), 0, st, nch, W.in, W.counts, W.offsets, job.dst_atoms, job.dst_apos);
+    res->ntok = total;
+    return hip_check(c, hipGetLastError(), "k_literal_atoms_batch");
+  }
   if (level == 0) {
     const uint64_t hi = job.final ? n : job.tok_hi, cnt = hi - job.tok_lo;
     if (cnt > job.cap_atoms) { c->err = "atom array overflow"; return -2; }
