@@ -86,7 +86,7 @@ void zo_prepare_codes(const int *lengths, int n, int max_huffman_bits, int inver
 /*  huffman-encoding-length_limited_coding.adb:46-280                         */
 /* ------------------------------------------------------------------------- */
 
-#define LL_MAX_BITS 15
+#define LL_MAX_BITS 17   /* capacity of the tables: Deflate instantiates 15 and 7, BZip2 15, 16 and 17 (bzip2-encoding.adb:900-903) */
 #define LL_MAX_ALPHA 288
 #define LL_NULL (-1)
 

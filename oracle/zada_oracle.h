@@ -41,7 +41,10 @@ enum {
   ZO_DEFLATE_1 = 8,
   ZO_DEFLATE_2 = 9,
   ZO_DEFLATE_3 = 10,
-  ZO_DEFLATE_R = 11
+  ZO_DEFLATE_R = 11,
+  ZO_BZIP2_1 = 12,
+  ZO_BZIP2_2 = 13,
+  ZO_BZIP2_3 = 14
 };
 
 /* Return codes of zo_deflate */
@@ -110,6 +113,28 @@ int zo_zip_add_compressed(zoz_archive *a, const char *entry_name, const uint8_t 
 void zo_zip_set_bias(zoz_archive *a, uint64_t bias);
 int zo_zip_finish(zoz_archive *a, const uint8_t **bytes, uint64_t *len);
 void zo_zip_free(zoz_archive *a);
+
+/* ---- BZip2 (zada_oracle_bz2.c) ---- */
+/* BZip2.Encoding.Encode (bzip2-encoding.adb:87): option 0/1/2 = block_100k/400k/900k, size_hint = -1 when unknown.
+ * The trace callback is called once per Read_and_Split_Block with the raw range and the splitting tactic kept
+ * (0 single, 1 parts_4, 2 segmented_1, 3 segmented_2) and its number of sub-blocks. */
+typedef void (*zo_bz2_trace_fn)(void *user, int64_t raw_start, int64_t raw_len, int tactic, int sub_blocks);
+int zo_bzip2_encode(const uint8_t *in, uint64_t n, int option, int64_t size_hint, uint8_t *out, uint64_t cap, uint64_t *out_len,
+                    zo_bz2_trace_fn tr, void *tr_user);
+/* Zip.Compress.BZip2_E (zip-compress-bzip2_e.adb): method ZO_BZIP2_1..3; crc_inout = running Zip CRC register. */
+int zo_bzip2(const uint8_t *in, uint64_t n, int method, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
+/* BZip2.CRC over a buffer (Init, Update, Final). */
+uint32_t zo_bz2_crc(const uint8_t *buf, uint64_t n);
+/* Stages of one Encode_Block (test hooks). */
+typedef struct {
+  int32_t rle_n, bwt_index, mtf_n, selector_count;
+  int32_t coders, max_code_len, sample_width, alphabet;
+  uint32_t block_crc, pad;
+  uint64_t bits;            /* size of the block in the stream */
+} zo_bz2_block_info;
+int zo_bz2_block(const uint8_t *raw, int32_t n, int option, uint8_t *rle_out, uint8_t *bwt_out, uint16_t *mtf_out,
+                 uint8_t *selectors_out, uint8_t *lens_out, zo_bz2_block_info *info, uint8_t *bits_out, uint64_t bits_cap);
+int32_t zo_bz2_segments(const uint8_t *buf, int32_t len, int tactic, int32_t *seg, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,82 @@
+"""BZip2 helpers for the tests: ctypes bindings of the oracle's BZip2 half (checker) and of the product's stage hook."""
+import ctypes
+
+import numpy as np
+
+from _common import oracle, product
+
+
+class BlockInfo(ctypes.Structure):
+    _fields_ = [("rle_n", ctypes.c_int32), ("bwt_index", ctypes.c_int32), ("mtf_n", ctypes.c_int32), ("selector_count", ctypes.c_int32),
+                ("coders", ctypes.c_int32), ("max_code_len", ctypes.c_int32), ("sample_width", ctypes.c_int32), ("alphabet", ctypes.c_int32),
+                ("block_crc", ctypes.c_uint32), ("pad", ctypes.c_uint32), ("bits", ctypes.c_uint64)]
+
+
+BZ_TRACE = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int)
+
+
+def bz_oracle():
+    O = oracle()
+    if not getattr(O, "_bz_ready", False):
+        vp = ctypes.c_void_p
+        O.zo_bzip2_encode.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int64, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), vp, vp]
+        O.zo_bzip2.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+        O.zo_bz2_crc.restype = ctypes.c_uint32
+        O.zo_bz2_crc.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
+        O.zo_bz2_block.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.POINTER(BlockInfo), vp, ctypes.c_uint64]
+        O.zo_bz2_segments.restype = ctypes.c_int32
+        O.zo_bz2_segments.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int, vp, ctypes.c_int32]
+        O._bz_ready = True
+    return O
+
+
+def oracle_encode(data, option=2, known=True):
+    """-> (stream bytes, [(raw_start, raw_len, tactic, sub_blocks)])"""
+    O = bz_oracle()
+    cap = len(data) * 2 + 2_000_000
+    out = ctypes.create_string_buffer(cap)
+    n = ctypes.c_uint64()
+    ev = []
+    cb = BZ_TRACE(lambda u, a, b, t, s: ev.append((a, b, t, s)))
+    rc = O.zo_bzip2_encode(data, len(data), option, len(data) if known else -1, out, cap, ctypes.byref(n), ctypes.cast(cb, ctypes.c_void_p), None)
+    assert rc == 0, rc
+    return out.raw[:n.value], ev
+
+
+def oracle_block(raw, option=2, want_bits=False):
+    """Stages of one Encode_Block -> dict(rle, bwt, mtf, selectors, lens, info, bits)."""
+    O = bz_oracle()
+    n = len(raw)
+    rle = np.zeros(n + n // 4 + 16, np.uint8)
+    bwt = np.zeros(n + n // 4 + 16, np.uint8)
+    mtf = np.zeros(2 * (n + n // 4) + 16, np.uint16)
+    sel = np.zeros((n + n // 4) // 50 + 8, np.uint8)
+    lens = np.zeros(6 * 258, np.uint8)
+    info = BlockInfo()
+    bits = np.zeros(2 * n + 1_000_000 if want_bits else 1, np.uint8)
+    rc = O.zo_bz2_block(bytes(raw), n, option, rle.ctypes.data, bwt.ctypes.data, mtf.ctypes.data, sel.ctypes.data, lens.ctypes.data, ctypes.byref(info),
+                        bits.ctypes.data if want_bits else None, bits.size)
+    assert rc == 0, rc
+    return dict(rle=rle[:info.rle_n], bwt=bwt[:info.rle_n], mtf=mtf[:info.mtf_n], selectors=sel[:info.selector_count], lens=lens.reshape(6, 258),
+                info=info, bits=bits[:(info.bits + 7) // 8] if want_bits else None)
+
+
+def product_stages(enc, data, starts, lens, option=2):
+    """RLE_1 / CRC / BWT of sub-blocks of `data` through the product's test hook."""
+    Z = product()
+    L = Z.load_library()
+    vp = ctypes.c_void_p
+    L.zada_bz2_stages.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, vp]
+    nsb = len(starts)
+    st = np.asarray(starts, np.uint64)
+    ln = np.asarray(lens, np.uint32)
+    cap = int(sum(int(x) + int(x) // 4 + 8 for x in lens)) + 64
+    rle_n = np.zeros(nsb, np.uint32); bwt_index = np.zeros(nsb, np.uint32); crc = np.zeros(nsb, np.uint32); inuse = np.zeros((nsb, 8), np.uint32)
+    rle = np.zeros(cap, np.uint8); bwt = np.zeros(cap, np.uint8); info = np.zeros(8, np.uint32)
+    rc = L.zada_bz2_stages(enc.ctx, bytes(data), len(data), nsb, st.ctypes.data, ln.ctypes.data, option, rle_n.ctypes.data, bwt_index.ctypes.data,
+                           crc.ctypes.data, inuse.ctypes.data, rle.ctypes.data, bwt.ctypes.data, cap, info.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("zada_bz2_stages rc=%d: %s" % (rc, L.zada_last_error(enc.ctx).decode()))
+    off = np.concatenate([[0], np.cumsum(rle_n)]).astype(np.int64)
+    return dict(rle_n=rle_n, bwt_index=bwt_index, crc=crc, inuse=inuse, info=info,
+                rle=[rle[off[i]:off[i + 1]] for i in range(nsb)], bwt=[bwt[off[i]:off[i + 1]] for i in range(nsb)])

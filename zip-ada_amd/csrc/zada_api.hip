@@ -837,6 +837,7 @@ void zada_destroy(zada_ctx *z) {
   hipSetDevice(z->c.device);
   hipStreamSynchronize(z->c.stream);
   hipStreamSynchronize(z->c.stream2);
+  bz2_destroy(&z->c);
   free_workspace(&z->c);
   for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
   hipStreamDestroy(z->c.stream2);

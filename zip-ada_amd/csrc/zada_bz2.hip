@@ -1,0 +1,669 @@
+// zada_bz2.hip -- BZip2 encoder: zip-ada's BZip2.Encoding.Encode (zip_lib/bzip2-encoding.adb:87-1431)
+// behind Zip.Compress.BZip2_E (zip_lib/zip-compress-bzip2_e.adb:44-157), on the GPU.
+//
+// The format makes blocks independent, and the reference adds more independent work per block: four splitting tactics
+// (:1214-1345) whose sub-blocks are each a complete Encode_Block (:148-1134).  The unit of work here is therefore the
+// SUB-BLOCK (one Encode_Block: a raw range of the input), and a batch of sub-blocks goes through every stage together:
+//
+//   acquisition (block limits, :1161-1209)  ->  segmentation (data_segmentation.adb:39-105)  ->  per sub-block:
+//   RLE_1 + CRC (:167-213)  ->  BWT (:222-300)  ->  MTF + RLE_2 (:320-412)  ->  entropy coders (:418-1010)  ->  bits (:1014-1116)
+//   ->  per block: smallest tactic (:1312-1318), bit-shifted concatenation.
+//
+// Element space: the RLE_1 bytes of the batch's sub-blocks, back to back (sub-block s owns [off[s], off[s] + n[s])).  The
+// rotation sort keeps every sub-block's rows inside that same index range, so one segmented radix sort pass serves all.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <vector>
+#include "../../include/zada.h"
+#include "zada_internal.h"
+#include "zada_llhc_wave.h"
+
+namespace zada {
+
+#define BZ_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_check(c, e__, #call); } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+//  small device helpers
+// ---------------------------------------------------------------------------------------------------------------
+struct OpSum { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } static constexpr uint32_t identity = 0; };
+struct OpMax { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } static constexpr uint32_t identity = 0; };
+
+template <class Op>
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane, Op op) {
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off); if (lane >= off) v = op(v, t); }
+  return v;
+}
+// inclusive scan over the threads of a workgroup (blockDim.x a multiple of 64, <= 1024); *total = the reduction
+template <class Op>
+__device__ __forceinline__ uint32_t wg_scan_incl(uint32_t v, uint32_t *lds17, Op op, uint32_t *total) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const uint32_t incl = wave_scan_incl(v, lane, op);
+  __syncthreads();
+  if (lane == 63) lds17[w] = incl;
+  __syncthreads();
+  uint32_t base = Op::identity, tot = Op::identity;
+  for (int k = 0; k < nw; k++) { const uint32_t x = lds17[k]; if (k < w) base = op(base, x); tot = op(tot, x); }
+  if (total) *total = tot;
+  return op(base, incl);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//  generic scans of uint32 arrays (three kernels: tile aggregates, scan of the aggregates, apply)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SC_TILE = 8192;   // 1024 threads x 8
+
+template <class Op, class F>
+__global__ void __launch_bounds__(1024) k_scan_agg(F f, uint64_t n, uint32_t *__restrict__ agg) {
+  __shared__ uint32_t l17[17];
+  const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * 8;
+  Op op;
+  uint32_t v = Op::identity;
+#pragma unroll
+  for (int k = 0; k < 8; k++) if (base + k < n) v = op(v, f(base + k));
+  uint32_t tot;
+  wg_scan_incl(v, l17, op, &tot);
+  if (threadIdx.x == 0) agg[blockIdx.x] = tot;
+}
+// exclusive scan of the aggregates in place (one workgroup); *total (may be null) receives the reduction
+template <class Op>
+__global__ void __launch_bounds__(1024) k_scan_aggs(uint32_t *__restrict__ agg, uint32_t nb, uint32_t *__restrict__ total) {
+  __shared__ uint32_t l17[17];
+  __shared__ uint32_t carry_s;
+  Op op;
+  if (threadIdx.x == 0) carry_s = Op::identity;
+  __syncthreads();
+  for (uint32_t b = 0; b < nb; b += 1024) {
+    const uint32_t i = b + threadIdx.x;
+    const uint32_t v = i < nb ? agg[i] : Op::identity;
+    uint32_t tot;
+    const uint32_t incl = wg_scan_incl(v, l17, op, &tot);
+    const uint32_t carry = carry_s;
+    // exclusive value = carry op (inclusive without own): recompute from the neighbour
+    uint32_t excl = __shfl_up(incl, 1);
+    if ((threadIdx.x & 63) == 0) {
+      excl = Op::identity;
+      for (int k = 0; k < (int)(threadIdx.x >> 6); k++) excl = op(excl, l17[k]);
+    }
+    if (i < nb) agg[i] = op(carry, excl);
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = op(carry, tot);
+    __syncthreads();
+  }
+  if (total && threadIdx.x == 0) *total = carry_s;
+}
+template <class Op, bool INCLUSIVE, class F>
+__global__ void __launch_bounds__(1024) k_scan_apply(F f, uint64_t n, const uint32_t *__restrict__ agg, uint32_t *__restrict__ out) {
+  __shared__ uint32_t l17[17];
+  const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * 8;
+  Op op;
+  uint32_t x[8], v = Op::identity;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { x[k] = base + k < n ? f(base + k) : Op::identity; v = op(v, x[k]); }
+  const uint32_t incl = wg_scan_incl(v, l17, op, nullptr);
+  // exclusive prefix of this thread = carry op (everything before this thread in the tile)
+  uint32_t before = __shfl_up(incl, 1);
+  if ((threadIdx.x & 63) == 0) { before = Op::identity; for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before = op(before, l17[k]); }
+  uint32_t run = op(agg[blockIdx.x], before);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (base + k < n) {
+      if (INCLUSIVE) { run = op(run, x[k]); out[base + k] = run; }
+      else { out[base + k] = run; run = op(run, x[k]); }
+    }
+  }
+}
+template <class Op, bool INCLUSIVE, class F>
+static void scan_launch(hipStream_t st, F f, uint64_t n, uint32_t *agg, uint32_t *out, uint32_t *d_total) {
+  if (n == 0) { if (d_total) hipMemsetAsync(d_total, 0, 4, st); return; }
+  const uint32_t nb = (uint32_t)((n + SC_TILE - 1) / SC_TILE);
+  hipLaunchKernelGGL((k_scan_agg<Op, F>), dim3(nb), dim3(1024), 0, st, f, n, agg);
+  hipLaunchKernelGGL((k_scan_aggs<Op>), dim3(1), dim3(1024), 0, st, agg, nb, d_total);
+  hipLaunchKernelGGL((k_scan_apply<Op, INCLUSIVE, F>), dim3(nb), dim3(1024), 0, st, f, n, agg, out);
+}
+
+struct FArr { const uint32_t *a; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return a[i]; } };
+
+// ---------------------------------------------------------------------------------------------------------------
+//  sub-block tables (device, structure of arrays)
+// ---------------------------------------------------------------------------------------------------------------
+struct SubTab {
+  const uint64_t *raw_start;   // offset in the input
+  const uint32_t *raw_len;
+  uint32_t *off;               // element offset (RLE_1 bytes of the sub-blocks, back to back)
+  uint32_t *n;                 // RLE_1 size
+  uint32_t *inuse;             // [nsb][8]: bytes in use (bit b of word b >> 5)
+  uint32_t *crc;               // block CRC (final)
+  uint32_t *bwt_index;
+  uint32_t nsb;
+};
+
+// A tile of a sub-block: `lo` is the offset inside the sub-block (raw space or element space)
+struct Tile { uint32_t sb, lo; };
+
+// ---------------------------------------------------------------------------------------------------------------
+//  RLE_1 (:167-213).  The reference's state machine cuts a run of equal bytes into pieces of at most 259 bytes,
+//  restarting at the sub-block's first byte; a piece of r bytes is stored as min(4, r) bytes plus, when r >= 4, the count r - 4.
+//  Byte p (offset o in its clipped run) therefore emits itself when o % 259 < 4 and, if it ends its piece, the count.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RT_TILE = 8192;     // raw bytes per tile, 256 threads x 32
+
+// per thread: 32 bytes.  run0 = offset of the thread's first byte in its clipped run (from the workgroup max-scan)
+struct RleThread {
+  uint32_t emits;
+  uint32_t use_lo[8];
+};
+
+// Offsets within the sub-block: tile covers [lo, hi).  Returns for the calling thread the number of bytes it emits; if
+// `dst` is non-null also writes them at dst[prefix ...] (prefix = exclusive scan of the emit counts, computed inside).
+template <bool EMIT>
+__device__ __forceinline__ uint32_t rle1_tile(const uint8_t *__restrict__ raw, uint32_t len, uint32_t lo, uint32_t *l17,
+                                              uint8_t *__restrict__ dst, uint32_t dst_base, uint32_t *inuse8) {
+  const int tid = threadIdx.x;
+  const uint32_t p0 = lo + (uint32_t)tid * 32;
+  uint8_t b[34];   // b[0] = byte before the thread's first, b[1..32] = the thread's bytes, b[33] = byte after
+#pragma unroll
+  for (int k = 0; k < 34; k++) { const int64_t p = (int64_t)p0 + k - 1; b[k] = (p >= 0 && p < (int64_t)len) ? raw[p] : 0; }
+  // last run start (sub-block offset + 1, 0 = none) among the thread's bytes
+  uint32_t last = 0;
+#pragma unroll
+  for (int k = 0; k < 32; k++) { const uint32_t p = p0 + k; if (p < len && (p == 0 || b[k + 1] != b[k])) last = p + 1; }
+  OpMax mx;
+  const uint32_t incl = wg_scan_incl(last, l17, mx, nullptr);
+  uint32_t before = __shfl_up(incl, 1);
+  if ((tid & 63) == 0) { before = 0; for (int k = 0; k < (tid >> 6); k++) before = mx(before, l17[k]); }
+  __syncthreads();
+  // run start of the byte before the tile: look back (bounded by the sub-block's start); only thread 0's answer is used
+  __shared__ uint32_t tile_rs;
+  if (tid == 0) {
+    uint32_t rs = 0;
+    if (lo > 0) { uint32_t p = lo; const uint8_t v = raw[lo]; while (p > 0 && raw[p - 1] == v) p--; rs = p; }   // start of the run that contains byte lo
+    tile_rs = rs;
+  }
+  __syncthreads();
+  uint32_t rs = before ? before - 1 : tile_rs;     // run start for the thread's first byte, unless it starts a run itself
+  uint32_t emits = 0;
+  uint8_t outb[40];
+#pragma unroll
+  for (int k = 0; k < 32; k++) {
+    const uint32_t p = p0 + k;
+    if (p < len) {
+      if (p == 0 || b[k + 1] != b[k]) rs = p;
+      const uint32_t r = (p - rs) % 259u;
+      const bool piece_end = r == 258u || p + 1 == len || b[k + 2] != b[k + 1];
+      if (r < 4) { if (EMIT) outb[emits] = b[k + 1]; emits++; }
+      if (piece_end && r + 1 >= 4) { if (EMIT) outb[emits] = (uint8_t)(r + 1 - 4); emits++; }
+    }
+  }
+  if (!EMIT) return emits;
+  OpSum sm;
+  const uint32_t inc2 = wg_scan_incl(emits, l17, sm, nullptr);
+  uint32_t pre = __shfl_up(inc2, 1);
+  if ((tid & 63) == 0) { pre = 0; for (int k = 0; k < (tid >> 6); k++) pre += l17[k]; }
+  for (uint32_t k = 0; k < emits; k++) {
+    dst[dst_base + pre + k] = outb[k];
+    atomicOr(&inuse8[outb[k] >> 5], 1u << (outb[k] & 31));
+  }
+  return emits;
+}
+
+// NB the look-back of thread 0 is linear in the length of the run before the tile; runs are cut by the reference's block
+// limits (at most ten times the block capacity), and such data leaves next to nothing to do downstream.
+
+__global__ void __launch_bounds__(256) k_bz_rle_count(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles,
+                                                      uint32_t *__restrict__ tile_cnt) {
+  __shared__ uint32_t l17[17];
+  const Tile t = tiles[blockIdx.x];
+  const uint8_t *raw = in + T.raw_start[t.sb];
+  const uint32_t e = rle1_tile<false>(raw, T.raw_len[t.sb], t.lo, l17, nullptr, 0, nullptr);
+  OpSum sm;
+  uint32_t tot;
+  wg_scan_incl(e, l17, sm, &tot);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+// exclusive scan of per-tile values inside each sub-block (tiles of a sub-block are consecutive); total -> T.n / other
+__global__ void __launch_bounds__(64) k_bz_tile_scan(const uint32_t *__restrict__ first_tile /*[nsb+1]*/, uint32_t *__restrict__ tile_val,
+                                                     uint32_t *__restrict__ totals) {
+  const uint32_t s = blockIdx.x, t0 = first_tile[s], t1 = first_tile[s + 1];
+  const int lane = threadIdx.x;
+  uint32_t carry = 0;
+  OpSum sm;
+  for (uint32_t b = t0; b < t1; b += 64) {
+    const uint32_t i = b + lane;
+    const uint32_t v = i < t1 ? tile_val[i] : 0;
+    const uint32_t incl = wave_scan_incl(v, lane, sm);
+    if (i < t1) tile_val[i] = carry + incl - v;
+    carry += __shfl(incl, 63);
+  }
+  if (lane == 0) totals[s] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_bz_rle_emit(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles,
+                                                     const uint32_t *__restrict__ tile_off, uint8_t *__restrict__ rle) {
+  __shared__ uint32_t l17[17];
+  __shared__ uint32_t use8[8];
+  const Tile t = tiles[blockIdx.x];
+  if (threadIdx.x < 8) use8[threadIdx.x] = 0;
+  __syncthreads();
+  const uint8_t *raw = in + T.raw_start[t.sb];
+  rle1_tile<true>(raw, T.raw_len[t.sb], t.lo, l17, rle, T.off[t.sb] + tile_off[blockIdx.x], use8);
+  __syncthreads();
+  if (threadIdx.x < 8 && use8[threadIdx.x]) atomicOr(&T.inuse[t.sb * 8 + threadIdx.x], use8[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//  BZip2.CRC (bzip2.adb): MSB-first CRC-32, polynomial 0x04C11DB7.  One lane per raw tile, then one lane per sub-block
+//  folds the tiles: crc(A ++ B) = crc_reg(A) * x^(8 |B|) + crc_0(B)  in GF(2)[x] / P.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bzcrc_mulx8(uint32_t r) {     // r * x^8 mod P
+#pragma unroll
+  for (int k = 0; k < 8; k++) r = (r & 0x80000000u) ? (r << 1) ^ 0x04C11DB7u : r << 1;
+  return r;
+}
+__device__ __forceinline__ uint32_t bzcrc_mul(uint32_t a, uint32_t b) {   // a * b mod P (polynomials, bit 31 = x^31)
+  uint32_t r = 0;
+  for (int k = 0; k < 32; k++) {
+    r = (r & 0x80000000u) ? (r << 1) ^ 0x04C11DB7u : r << 1;      // r *= x
+    if (b & (0x80000000u >> k)) r ^= a;                           // + a * (bit of b, from x^31 down)
+  }
+  return r;
+}
+__device__ __forceinline__ uint32_t bzcrc_xpow8(uint32_t nbytes) {       // x^(8 nbytes) mod P
+  uint32_t result = 1, base = 0x100;                                     // x^8
+  while (nbytes) { if (nbytes & 1) result = bzcrc_mul(result, base); base = bzcrc_mul(base, base); nbytes >>= 1; }
+  return result;
+}
+__global__ void __launch_bounds__(64) k_bz_crc_tiles(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles, uint32_t ntiles,
+                                                     uint32_t *__restrict__ tile_crc) {
+  __shared__ uint32_t tab[256];
+  for (int i = threadIdx.x; i < 256; i += 64) tab[i] = bzcrc_mulx8((uint32_t)i << 24);
+  __syncthreads();
+  const uint32_t ti = blockIdx.x * 64 + threadIdx.x;
+  if (ti >= ntiles) return;
+  const Tile t = tiles[ti];
+  const uint8_t *raw = in + T.raw_start[t.sb] + t.lo;
+  const uint32_t len = min((uint32_t)RT_TILE, T.raw_len[t.sb] - t.lo);
+  uint32_t r = 0;
+  for (uint32_t k = 0; k < len; k++) r = tab[(r >> 24) ^ raw[k]] ^ (r << 8);
+  tile_crc[ti] = r;
+}
+__global__ void k_bz_crc_fold(SubTab T, const uint32_t *__restrict__ first_tile, const uint32_t *__restrict__ tile_crc) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= T.nsb) return;
+  const uint32_t t0 = first_tile[s], t1 = first_tile[s + 1], len = T.raw_len[s];
+  const uint32_t xt = bzcrc_xpow8(RT_TILE);
+  // register after |len| bytes from the all-ones start: 0xFFFFFFFF * x^(8 len) + crc_0(data)
+  uint32_t r = 0;
+  for (uint32_t t = t0; t < t1; t++) {
+    const uint32_t tl = min((uint32_t)RT_TILE, len - (t - t0) * RT_TILE);
+    r = bzcrc_mul(r, tl == RT_TILE ? xt : bzcrc_xpow8(tl)) ^ tile_crc[t];
+  }
+  r ^= bzcrc_mul(0xFFFFFFFFu, bzcrc_xpow8(len));
+  T.crc[s] = ~r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//  BWT (:222-300): rotation sort by prefix doubling.  SA[i] = element (global index) of the i-th smallest rotation of
+//  its sub-block, CL[g] = class of element g = the index of the first row of its group of rotations that agree on the
+//  first h bytes.  Round: rows shifted back by h are already ordered by their second half, so one stable sort of those by
+//  the class of their first half orders them by 2h bytes.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BW_TILE = 8192;    // elements per tile, 1024 threads x 8 (wave w owns 512 consecutive elements)
+
+// stable radix pass over (key, val) pairs, segmented by sub-block: digit = (key >> shift) & 255
+__global__ void __launch_bounds__(1024) k_bz_radix_hist(const uint32_t *__restrict__ key, SubTab T, const Tile *__restrict__ tiles,
+                                                        const uint32_t *__restrict__ first_tile, const uint8_t *__restrict__ done, int shift,
+                                                        uint32_t *__restrict__ H) {
+  __shared__ uint32_t cnt[256];
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t n = T.n[t.sb], base = T.off[t.sb] + t.lo, m = done[t.sb] ? 0u : min((uint32_t)BW_TILE, n - t.lo);
+  if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) atomicAdd(&cnt[(key[base + i] >> shift) & 255u], 1u);
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const uint32_t t0 = first_tile[t.sb], ts = first_tile[t.sb + 1] - t0;
+    H[(uint64_t)t0 * 256 + (uint64_t)threadIdx.x * ts + (blockIdx.x - t0)] = cnt[threadIdx.x];
+  }
+}
+__global__ void __launch_bounds__(1024) k_bz_radix_scatter(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, SubTab T,
+                                                           const Tile *__restrict__ tiles, const uint32_t *__restrict__ first_tile,
+                                                           const uint8_t *__restrict__ done, int shift,
+                                                           const uint32_t *__restrict__ H, uint32_t *__restrict__ key_out, uint32_t *__restrict__ val_out) {
+  __shared__ uint32_t cnt[16 * 256];
+  const Tile t = tiles[blockIdx.x];
+  if (done[t.sb]) return;
+  const uint32_t n = T.n[t.sb], base = T.off[t.sb] + t.lo, m = min((uint32_t)BW_TILE, n - t.lo);
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 16 * 256; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  uint32_t kx[8], vx[8], rk[8];
+  uint32_t *mycnt = cnt + w * 256;
+  // rank among the wave's elements with the same digit, in element order (LDS atomics of one instruction are served in lane
+  // order; see sort_pass in zada_lz.hip and tests/probes/lds_atomic_order.hip)
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const uint32_t i = (uint32_t)w * 512 + it * 64 + lane;
+    kx[it] = 0; vx[it] = 0; rk[it] = 0;
+    if (i < m) { kx[it] = key[base + i]; vx[it] = val[base + i]; rk[it] = atomicAdd(&mycnt[(kx[it] >> shift) & 255u], 1u); }
+  }
+  __syncthreads();
+  // per digit: exclusive prefix over the waves, plus the tile's base from the scanned histogram
+  if (tid < 256) {
+    const uint32_t t0 = first_tile[t.sb], ts = first_tile[t.sb + 1] - t0;
+    // the scan runs over all sub-blocks' histograms; a sub-block's own part starts at its first entry
+    uint32_t run = T.off[t.sb] + H[(uint64_t)t0 * 256 + (uint64_t)tid * ts + (blockIdx.x - t0)] - H[(uint64_t)t0 * 256];
+    for (int k = 0; k < 16; k++) { const uint32_t x = cnt[k * 256 + tid]; cnt[k * 256 + tid] = run; run += x; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const uint32_t i = (uint32_t)w * 512 + it * 64 + lane;
+    if (i < m) { const uint32_t d = mycnt[(kx[it] >> shift) & 255u] + rk[it]; key_out[d] = kx[it]; val_out[d] = vx[it]; }
+  }
+}
+
+// first keys: four bytes of the rotation starting at the element, big end first
+__global__ void k_bz_bwt_init(const uint8_t *__restrict__ rle, SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+    const uint32_t l = t.lo + i;
+    uint32_t k = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { uint32_t q = l + j; q = q >= n ? q % n : q; k = (k << 8) | rle[off + q]; }
+    key[off + l] = k; val[off + l] = off + l;
+  }
+}
+
+// head values after the first sort: row i starts a group iff its key differs from row i - 1's (or it is the sub-block's first row).
+// hv[i] = i + 1 for heads, 0 otherwise: an inclusive max-scan turns it into "my group's first row + 1".
+__global__ void __launch_bounds__(1024) k_bz_heads0(const uint32_t *__restrict__ key, SubTab T, const Tile *__restrict__ tiles,
+                                                    const uint8_t *__restrict__ done, uint32_t *__restrict__ hv) {
+  const Tile t = tiles[blockIdx.x];
+  if (done[t.sb]) return;
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, g = off + l;
+    hv[g] = (l == 0 || key[g] != key[g - 1]) ? g + 1 : 0u;
+  }
+}
+// rows shifted back by h (cyclically inside the sub-block), keyed by the local class of the shifted element
+__global__ void __launch_bounds__(1024) k_bz_shift(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T,
+                                                   const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t h,
+                                                   uint32_t *__restrict__ key_out, uint32_t *__restrict__ val_out) {
+  const Tile t = tiles[blockIdx.x];
+  if (done[t.sb]) return;
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t g = off + t.lo + i;
+    uint32_t l = sa[g] - off;
+    l = l >= h ? l - h : l + n - h;          // h < n for a sub-block that is not done
+    val_out[g] = off + l;
+    key_out[g] = cl[off + l] - off;
+  }
+}
+// second halves: sec[i] = class of the element h behind row i's
+__global__ void __launch_bounds__(1024) k_bz_second(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T,
+                                                    const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ sec) {
+  const Tile t = tiles[blockIdx.x];
+  if (done[t.sb]) return;
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t g = off + t.lo + i;
+    uint32_t l = sa[g] - off + h;
+    if (l >= n) l -= n;
+    sec[g] = cl[off + l];
+  }
+}
+__global__ void __launch_bounds__(1024) k_bz_headsH(const uint32_t *__restrict__ key, const uint32_t *__restrict__ sec, SubTab T,
+                                                    const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t *__restrict__ hv) {
+  const Tile t = tiles[blockIdx.x];
+  if (done[t.sb]) return;
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, g = off + l;
+    hv[g] = (l == 0 || key[g] != key[g - 1] || sec[g] != sec[g - 1]) ? g + 1 : 0u;
+  }
+}
+// classes from the scanned head values; counts the rows of groups that still have more than one member
+__global__ void __launch_bounds__(1024) k_bz_set_class(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ hv, const uint32_t *__restrict__ hr,
+                                                       SubTab T, const Tile *__restrict__ tiles, const uint8_t *__restrict__ done,
+                                                       uint32_t *__restrict__ cl, uint32_t *__restrict__ unsorted /*[nsb]*/) {
+  const Tile t = tiles[blockIdx.x];
+  if (done[t.sb]) return;
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  uint32_t cnt = 0;
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, g = off + l;
+    cl[sa[g]] = hr[g] - 1;
+    const bool single = hv[g] != 0 && (l + 1 == n || hv[g + 1] != 0);
+    cnt += single ? 0u : 1u;
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&unsorted[t.sb], cnt);
+}
+// after a round that has ordered the rows by `prefix` bytes: a sub-block is done when every group is a single row or the
+// prefix covers the whole rotation.  *active = number of sub-blocks that go on.
+__global__ void k_bz_round_end(SubTab T, uint32_t prefix, uint32_t *__restrict__ unsorted, uint8_t *__restrict__ done, uint32_t *__restrict__ active) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= T.nsb) return;
+  if (!done[s]) {
+    if (unsorted[s] == 0 || prefix >= T.n[s]) done[s] = 1; else atomicAdd(active, 1u);
+    unsorted[s] = 0;
+  }
+}
+// last column (:266-276): the byte in front of each row's rotation; the original message is the first row of its group
+__global__ void __launch_bounds__(1024) k_bz_bwt_out(const uint8_t *__restrict__ rle, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T,
+                                                     const Tile *__restrict__ tiles, uint8_t *__restrict__ bwt) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t g = off + t.lo + i, l = sa[g] - off;
+    bwt[g] = rle[off + (l == 0 ? n - 1 : l - 1)];
+  }
+  if (t.lo == 0 && threadIdx.x == 0) T.bwt_index[t.sb] = cl[off] - off;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+//  host side
+// ---------------------------------------------------------------------------------------------------------------
+struct DBuf {
+  void *p = nullptr; size_t cap = 0;
+  template <class X> X *as() const { return (X *)p; }
+};
+static int dbuf_ensure(Ctx *c, DBuf &b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return 0;
+  if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  const size_t want = bytes + bytes / 8 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { (void)hipGetLastError(); hip_check(c, e, "hipMalloc (bzip2 workspace)"); b.p = nullptr; return ZADA_E_NOMEM; }
+  b.cap = want;
+  return 0;
+}
+
+struct Bz2State {
+  // sub-block tables
+  DBuf raw_start, raw_len, off, n, inuse, crc, bwt_index, done, unsorted, scal;
+  // tiles
+  DBuf rtiles, rtile_first, rtile_val, rtile_crc, etiles, etile_first;
+  // element space
+  DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg;
+  std::vector<DBuf *> all() {
+    return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
+            &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg};
+  }
+  // host mirrors of the batch in flight
+  std::vector<uint64_t> h_raw_start;
+  std::vector<uint32_t> h_raw_len, h_n, h_off;
+  uint32_t nsb = 0, ntot = 0, n_etiles = 0;
+  int bwt_rounds = 0;
+};
+
+static Bz2State *bz_state(Ctx *c) {
+  if (!c->bz) c->bz = new Bz2State();
+  return (Bz2State *)c->bz;
+}
+void bz2_destroy(Ctx *c) {
+  if (!c->bz) return;
+  Bz2State *B = (Bz2State *)c->bz;
+  for (DBuf *b : B->all()) if (b->p) hipFree(b->p);
+  delete B;
+  c->bz = nullptr;
+}
+
+static void build_tiles(const std::vector<uint32_t> &len, uint32_t tile, std::vector<Tile> &tiles, std::vector<uint32_t> &first) {
+  tiles.clear(); first.clear();
+  for (uint32_t s = 0; s < len.size(); s++) {
+    first.push_back((uint32_t)tiles.size());
+    for (uint32_t lo = 0; lo < len[s]; lo += tile) tiles.push_back({s, lo});
+  }
+  first.push_back((uint32_t)tiles.size());
+}
+
+static SubTab subtab(Bz2State *B) {
+  SubTab T;
+  T.raw_start = B->raw_start.as<uint64_t>(); T.raw_len = B->raw_len.as<uint32_t>(); T.off = B->off.as<uint32_t>(); T.n = B->n.as<uint32_t>();
+  T.inuse = B->inuse.as<uint32_t>(); T.crc = B->crc.as<uint32_t>(); T.bwt_index = B->bwt_index.as<uint32_t>(); T.nsb = B->nsb;
+  return T;
+}
+
+// RLE_1, CRC and BWT of a batch of sub-blocks of d_in.  Leaves rle / bwt / tables in the state.
+static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t> &starts, const std::vector<uint32_t> &lens) {
+  Bz2State *B = bz_state(c);
+  hipStream_t st = c->stream;
+  const uint32_t nsb = (uint32_t)starts.size();
+  B->nsb = nsb; B->h_raw_start = starts; B->h_raw_len = lens;
+  int rc;
+  if ((rc = dbuf_ensure(c, B->raw_start, 8ull * nsb)) || (rc = dbuf_ensure(c, B->raw_len, 4ull * nsb)) || (rc = dbuf_ensure(c, B->off, 4ull * (nsb + 1))) ||
+      (rc = dbuf_ensure(c, B->n, 4ull * nsb)) || (rc = dbuf_ensure(c, B->inuse, 32ull * nsb)) || (rc = dbuf_ensure(c, B->crc, 4ull * nsb)) ||
+      (rc = dbuf_ensure(c, B->bwt_index, 4ull * nsb)) || (rc = dbuf_ensure(c, B->done, nsb)) || (rc = dbuf_ensure(c, B->unsorted, 4ull * nsb)) ||
+      (rc = dbuf_ensure(c, B->scal, 64))) return rc;
+  BZ_HIP(hipMemcpyAsync(B->raw_start.p, starts.data(), 8ull * nsb, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemcpyAsync(B->raw_len.p, lens.data(), 4ull * nsb, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemsetAsync(B->inuse.p, 0, 32ull * nsb, st));
+  BZ_HIP(hipMemsetAsync(B->done.p, 0, nsb, st));
+  BZ_HIP(hipMemsetAsync(B->unsorted.p, 0, 4ull * nsb, st));
+  BZ_HIP(hipMemsetAsync(B->bwt_index.p, 0, 4ull * nsb, st));
+  // raw tiles
+  std::vector<Tile> rt; std::vector<uint32_t> rfirst;
+  build_tiles(lens, RT_TILE, rt, rfirst);
+  const uint32_t nrt = (uint32_t)rt.size();
+  if ((rc = dbuf_ensure(c, B->rtiles, sizeof(Tile) * (size_t)nrt)) || (rc = dbuf_ensure(c, B->rtile_first, 4ull * (nsb + 1))) ||
+      (rc = dbuf_ensure(c, B->rtile_val, 4ull * nrt)) || (rc = dbuf_ensure(c, B->rtile_crc, 4ull * nrt))) return rc;
+  BZ_HIP(hipMemcpyAsync(B->rtiles.p, rt.data(), sizeof(Tile) * (size_t)nrt, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemcpyAsync(B->rtile_first.p, rfirst.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
+  SubTab T = subtab(B);
+  if (nrt) hipLaunchKernelGGL(k_bz_rle_count, dim3(nrt), dim3(256), 0, st, d_in, T, B->rtiles.as<Tile>(), B->rtile_val.as<uint32_t>());
+  hipLaunchKernelGGL(k_bz_tile_scan, dim3(nsb), dim3(64), 0, st, B->rtile_first.as<uint32_t>(), B->rtile_val.as<uint32_t>(), B->n.as<uint32_t>());
+  B->h_n.resize(nsb);
+  BZ_HIP(hipMemcpyAsync(B->h_n.data(), B->n.p, 4ull * nsb, hipMemcpyDeviceToHost, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  B->h_off.resize(nsb + 1);
+  uint64_t tot = 0;
+  for (uint32_t s = 0; s < nsb; s++) { B->h_off[s] = (uint32_t)tot; tot += B->h_n[s]; }
+  if (tot >= (1ull << 31)) { c->err = "bzip2: batch too large"; return ZADA_E_TOO_LARGE; }
+  B->h_off[nsb] = (uint32_t)tot; B->ntot = (uint32_t)tot;
+  BZ_HIP(hipMemcpyAsync(B->off.p, B->h_off.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
+  const size_t ne = (size_t)tot + 16;
+  if ((rc = dbuf_ensure(c, B->rle, ne)) || (rc = dbuf_ensure(c, B->bwt, ne))) return rc;
+  if (nrt) {
+    hipLaunchKernelGGL(k_bz_rle_emit, dim3(nrt), dim3(256), 0, st, d_in, T, B->rtiles.as<Tile>(), B->rtile_val.as<uint32_t>(), B->rle.as<uint8_t>());
+    hipLaunchKernelGGL(k_bz_crc_tiles, dim3((nrt + 63) / 64), dim3(64), 0, st, d_in, T, B->rtiles.as<Tile>(), nrt, B->rtile_crc.as<uint32_t>());
+  }
+  hipLaunchKernelGGL(k_bz_crc_fold, dim3((nsb + 63) / 64), dim3(64), 0, st, T, B->rtile_first.as<uint32_t>(), B->rtile_crc.as<uint32_t>());
+  // element tiles
+  std::vector<Tile> et; std::vector<uint32_t> efirst;
+  build_tiles(B->h_n, BW_TILE, et, efirst);
+  const uint32_t net = (uint32_t)et.size();
+  B->n_etiles = net;
+  if ((rc = dbuf_ensure(c, B->etiles, sizeof(Tile) * (size_t)net)) || (rc = dbuf_ensure(c, B->etile_first, 4ull * (nsb + 1)))) return rc;
+  BZ_HIP(hipMemcpyAsync(B->etiles.p, et.data(), sizeof(Tile) * (size_t)net, hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemcpyAsync(B->etile_first.p, efirst.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
+  if ((rc = dbuf_ensure(c, B->keyA, 4 * ne)) || (rc = dbuf_ensure(c, B->keyB, 4 * ne)) || (rc = dbuf_ensure(c, B->valA, 4 * ne)) ||
+      (rc = dbuf_ensure(c, B->valB, 4 * ne)) || (rc = dbuf_ensure(c, B->cl, 4 * ne)) || (rc = dbuf_ensure(c, B->hv, 4 * ne)) ||
+      (rc = dbuf_ensure(c, B->hr, 4 * ne)) || (rc = dbuf_ensure(c, B->H, 1024ull * net + 1024)) ||
+      (rc = dbuf_ensure(c, B->agg, 4ull * ((1024ull * net / 4 + ne) / SC_TILE + 16)))) return rc;
+  BZ_HIP(hipStreamSynchronize(st));   // rt / et vectors go out of scope
+  B->bwt_rounds = 0;
+  if (net == 0) return 0;
+  const Tile *ET = B->etiles.as<Tile>();
+  const uint32_t *EF = B->etile_first.as<uint32_t>();
+  uint8_t *done = B->done.as<uint8_t>();
+  uint32_t *keyA = B->keyA.as<uint32_t>(), *keyB = B->keyB.as<uint32_t>(), *valA = B->valA.as<uint32_t>(), *valB = B->valB.as<uint32_t>();
+  uint32_t *H = B->H.as<uint32_t>(), *agg = B->agg.as<uint32_t>(), *hv = B->hv.as<uint32_t>(), *hr = B->hr.as<uint32_t>(), *cl = B->cl.as<uint32_t>();
+  uint32_t *active = B->scal.as<uint32_t>();
+  auto radix = [&](const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int shift) {
+    hipLaunchKernelGGL(k_bz_radix_hist, dim3(net), dim3(1024), 0, st, ki, T, ET, EF, done, shift, H);
+    scan_launch<OpSum, false>(st, FArr{H}, 256ull * net, agg, H, nullptr);
+    hipLaunchKernelGGL(k_bz_radix_scatter, dim3(net), dim3(1024), 0, st, ki, vi, T, ET, EF, done, shift, H, ko, vo);
+  };
+  auto classes = [&](uint32_t prefix) -> int {
+    scan_launch<OpMax, true>(st, FArr{hv}, tot, agg, hr, nullptr);
+    hipLaunchKernelGGL(k_bz_set_class, dim3(net), dim3(1024), 0, st, valA, hv, hr, T, ET, done, cl, B->unsorted.as<uint32_t>());
+    BZ_HIP(hipMemsetAsync(active, 0, 4, st));
+    hipLaunchKernelGGL(k_bz_round_end, dim3((nsb + 255) / 256), dim3(256), 0, st, T, prefix, B->unsorted.as<uint32_t>(), done, active);
+    return 0;
+  };
+  hipLaunchKernelGGL(k_bz_bwt_init, dim3(net), dim3(1024), 0, st, B->rle.as<uint8_t>(), T, ET, keyA, valA);
+  radix(keyA, valA, keyB, valB, 0); radix(keyB, valB, keyA, valA, 8); radix(keyA, valA, keyB, valB, 16); radix(keyB, valB, keyA, valA, 24);
+  hipLaunchKernelGGL(k_bz_heads0, dim3(net), dim3(1024), 0, st, keyA, T, ET, done, hv);
+  if ((rc = classes(4))) return rc;
+  for (uint32_t h = 4;; h *= 2) {
+    uint32_t h_active = 0;
+    BZ_HIP(hipMemcpyAsync(&h_active, active, 4, hipMemcpyDeviceToHost, st));
+    BZ_HIP(hipStreamSynchronize(st));
+    if (h_active == 0) break;
+    B->bwt_rounds++;
+    hipLaunchKernelGGL(k_bz_shift, dim3(net), dim3(1024), 0, st, valA, cl, T, ET, done, h, keyB, valB);
+    radix(keyB, valB, keyA, valA, 0); radix(keyA, valA, keyB, valB, 8);
+    radix(keyB, valB, keyA, valA, 16);     // local classes are below 2^20 (block capacity 900 000)
+    hipLaunchKernelGGL(k_bz_second, dim3(net), dim3(1024), 0, st, valA, cl, T, ET, done, h, hr);
+    hipLaunchKernelGGL(k_bz_headsH, dim3(net), dim3(1024), 0, st, keyA, hr, T, ET, done, hv);
+    if ((rc = classes(2 * h))) return rc;
+  }
+  hipLaunchKernelGGL(k_bz_bwt_out, dim3(net), dim3(1024), 0, st, B->rle.as<uint8_t>(), valA, cl, T, ET, B->bwt.as<uint8_t>());
+  BZ_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace zada
+
+struct zada_ctx { zada::Ctx c; };
+using namespace zada;
+
+extern "C" int zada_bz2_stages(zada_ctx *z, const uint8_t *in, uint64_t n, uint32_t nsb, const uint64_t *starts, const uint32_t *lens, int option,
+                               uint32_t *rle_n, uint32_t *bwt_index, uint32_t *crc, uint32_t *inuse, uint8_t *rle, uint8_t *bwt, uint64_t cap_elems,
+                               uint32_t *info) {
+  if (!z || (!in && n)) return ZADA_E_INVALID;
+  Ctx *c = &z->c;
+  (void)option;
+  hipSetDevice(c->device);
+  uint8_t *d_in = nullptr;
+  if (hipMalloc(&d_in, n + 64) != hipSuccess) return ZADA_E_NOMEM;
+  hipMemcpy(d_in, in, n, hipMemcpyHostToDevice);
+  hipMemset(d_in + n, 0, 64);
+  std::vector<uint64_t> s(starts, starts + nsb);
+  std::vector<uint32_t> l(lens, lens + nsb);
+  int rc = bz_transform(c, d_in, s, l);
+  Bz2State *B = bz_state(c);
+  if (rc == 0) {
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(rle_n, B->n.p, 4ull * nsb, hipMemcpyDeviceToHost);
+    hipMemcpy(bwt_index, B->bwt_index.p, 4ull * nsb, hipMemcpyDeviceToHost);
+    hipMemcpy(crc, B->crc.p, 4ull * nsb, hipMemcpyDeviceToHost);
+    hipMemcpy(inuse, B->inuse.p, 32ull * nsb, hipMemcpyDeviceToHost);
+    if (B->ntot <= cap_elems) {
+      hipMemcpy(rle, B->rle.p, B->ntot, hipMemcpyDeviceToHost);
+      hipMemcpy(bwt, B->bwt.p, B->ntot, hipMemcpyDeviceToHost);
+    } else rc = ZADA_E_INVALID;
+    if (info) { info[0] = B->ntot; info[1] = (uint32_t)B->bwt_rounds; }
+  }
+  hipFree(d_in);
+  return rc;
+}

@@ -240,6 +240,7 @@ struct Ctx {
   std::string err;
   int parse_rounds = 0, demand_rounds = 0;
   bool lz_attrs_set = false;
+  void *bz = nullptr;                                // BZip2 state (zada_bz2.hip), made on first use
   // timing
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<const char *, hipEvent_t>> marks;
@@ -261,6 +262,7 @@ struct Ctx {
 };
 
 int hip_check(Ctx *c, hipError_t e, const char *what);
+void bz2_destroy(Ctx *c);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);
 
