@@ -66,17 +66,19 @@ def product_stages(enc, data, starts, lens, option=2):
     Z = product()
     L = Z.load_library()
     vp = ctypes.c_void_p
-    L.zada_bz2_stages.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, vp]
+    L.zada_bz2_stages.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, vp, vp, ctypes.c_uint64, vp]
     nsb = len(starts)
     st = np.asarray(starts, np.uint64)
     ln = np.asarray(lens, np.uint32)
     cap = int(sum(int(x) + int(x) // 4 + 8 for x in lens)) + 64
     rle_n = np.zeros(nsb, np.uint32); bwt_index = np.zeros(nsb, np.uint32); crc = np.zeros(nsb, np.uint32); inuse = np.zeros((nsb, 8), np.uint32)
     rle = np.zeros(cap, np.uint8); bwt = np.zeros(cap, np.uint8); info = np.zeros(8, np.uint32)
+    mtf_n = np.zeros(nsb, np.uint32); mtf = np.zeros(cap + nsb + 16, np.uint16)
     rc = L.zada_bz2_stages(enc.ctx, bytes(data), len(data), nsb, st.ctypes.data, ln.ctypes.data, option, rle_n.ctypes.data, bwt_index.ctypes.data,
-                           crc.ctypes.data, inuse.ctypes.data, rle.ctypes.data, bwt.ctypes.data, cap, info.ctypes.data)
+                           crc.ctypes.data, inuse.ctypes.data, rle.ctypes.data, bwt.ctypes.data, cap, mtf_n.ctypes.data, mtf.ctypes.data, mtf.size, info.ctypes.data)
     if rc != 0:
         raise RuntimeError("zada_bz2_stages rc=%d: %s" % (rc, L.zada_last_error(enc.ctx).decode()))
     off = np.concatenate([[0], np.cumsum(rle_n)]).astype(np.int64)
-    return dict(rle_n=rle_n, bwt_index=bwt_index, crc=crc, inuse=inuse, info=info,
+    moff = np.concatenate([[0], np.cumsum(mtf_n)]).astype(np.int64)
+    return dict(rle_n=rle_n, bwt_index=bwt_index, crc=crc, inuse=inuse, info=info, mtf_n=mtf_n, mtf=[mtf[moff[i]:moff[i + 1]] for i in range(nsb)],
                 rle=[rle[off[i]:off[i + 1]] for i in range(nsb)], bwt=[bwt[off[i]:off[i + 1]] for i in range(nsb)])

@@ -26,11 +26,12 @@ for name, data in cases:
     for i, (s, l) in enumerate(zip(starts, lens)):
         o = oracle_block(data[s:s + l])
         ok = (int(P["rle_n"][i]) == o["info"].rle_n and np.array_equal(P["rle"][i], o["rle"]) and int(P["crc"][i]) == o["info"].block_crc
-              and np.array_equal(P["bwt"][i], o["bwt"]) and int(P["bwt_index"][i]) == o["info"].bwt_index)
+              and np.array_equal(P["bwt"][i], o["bwt"]) and int(P["bwt_index"][i]) == o["info"].bwt_index
+              and int(P["mtf_n"][i]) == o["info"].mtf_n and np.array_equal(P["mtf"][i], o["mtf"]))
         if not ok:
             bad += 1
             print("MISMATCH", name, i, s, l, "rle_n", int(P["rle_n"][i]), o["info"].rle_n, "rle", np.array_equal(P["rle"][i], o["rle"]),
-                  "crc", hex(int(P["crc"][i])), hex(o["info"].block_crc), "bwt", np.array_equal(P["bwt"][i], o["bwt"]), "idx", int(P["bwt_index"][i]), o["info"].bwt_index)
+                  "crc", hex(int(P["crc"][i])), hex(o["info"].block_crc), "bwt", np.array_equal(P["bwt"][i], o["bwt"]), "idx", int(P["bwt_index"][i]), o["info"].bwt_index, "mtf_n", int(P["mtf_n"][i]), o["info"].mtf_n, "mtf", np.array_equal(P["mtf"][i], o["mtf"]))
     print(name, n, "rounds", int(P["info"][1]), "ok" if not bad else "BAD", round(time.time() - t0, 1), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

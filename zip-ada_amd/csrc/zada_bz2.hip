@@ -471,6 +471,165 @@ __global__ void __launch_bounds__(1024) k_bz_bwt_out(const uint8_t *__restrict__
 
 
 // ---------------------------------------------------------------------------------------------------------------
+//  MTF + RLE_2 (:320-412).  The move-to-front list in front of a chunk of the last column depends on what came before only
+//  through the order of the last occurrences: pass 1 finds each chunk's distinct symbols by recency, pass 2 (one wave per
+//  sub-block, chunk after chunk) turns them into the list in front of every chunk, pass 3 runs the plain algorithm inside
+//  the chunks, all at once.  Zero runs (:363-379) are independent of the list: a zero is a byte equal to its predecessor.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int MTF_CHUNK = 512;
+constexpr int MTF_PER_TILE = BW_TILE / MTF_CHUNK;   // 16
+
+// byte -> sequence number among the bytes in use (Prepare_Mapping :322-337); nsym[s] = normal_symbols_in_use
+__global__ void __launch_bounds__(64) k_bz_seqmap(SubTab T, uint8_t *__restrict__ seq /*[nsb][256]*/, uint32_t *__restrict__ nsym) {
+  const uint32_t s = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int k = 0; k < 4; k++) {
+    const int b = lane * 4 + k;
+    uint32_t cnt = 0;
+    for (int w = 0; w < 8; w++) {
+      const uint32_t bits = T.inuse[s * 8 + w];
+      if (w < (b >> 5)) cnt += __popc(bits);
+      else if (w == (b >> 5)) cnt += __popc(bits & ((1u << (b & 31)) - 1u));
+    }
+    seq[s * 256 + b] = (uint8_t)cnt;
+  }
+  if (lane == 0) { uint32_t tot = 0; for (int w = 0; w < 8; w++) tot += __popc(T.inuse[s * 8 + w]); nsym[s] = tot; }
+}
+
+// pass 1: per chunk, its distinct symbols most recent first (rec[chunk][..cnt]) and their set (bm[chunk][8])
+__global__ void __launch_bounds__(64) k_bz_mtf_recency(const uint8_t *__restrict__ bwt, SubTab T, const Tile *__restrict__ tiles, uint32_t ntiles,
+                                                       const uint8_t *__restrict__ seq, uint8_t *__restrict__ rec, uint32_t *__restrict__ bm,
+                                                       uint32_t *__restrict__ cnt) {
+  __shared__ uint32_t seen[8 * 64];
+  const uint32_t slot = blockIdx.x * 64 + threadIdx.x, ti = slot / MTF_PER_TILE, j = slot % MTF_PER_TILE;
+  const int lane = threadIdx.x;
+  if (ti >= ntiles) return;
+  const Tile t = tiles[ti];
+  const uint32_t n = T.n[t.sb], lo = t.lo + j * MTF_CHUNK;
+  if (lo >= n) { cnt[slot] = 0; return; }
+  const uint32_t m = min((uint32_t)MTF_CHUNK, n - lo);
+  const uint8_t *src = bwt + T.off[t.sb] + lo, *sq = seq + t.sb * 256;
+  for (int w = 0; w < 8; w++) seen[w * 64 + lane] = 0;
+  uint32_t c = 0;
+  uint8_t *out = rec + (uint64_t)slot * 256;
+  for (int i = (int)m - 1; i >= 0; i--) {
+    const uint32_t y = sq[src[i]];
+    const uint32_t w = seen[(y >> 5) * 64 + lane];
+    if (!((w >> (y & 31)) & 1u)) { seen[(y >> 5) * 64 + lane] = w | (1u << (y & 31)); out[c++] = (uint8_t)y; }
+  }
+  for (int w = 0; w < 8; w++) bm[(uint64_t)slot * 8 + w] = seen[w * 64 + lane];
+  cnt[slot] = c;
+}
+
+// pass 2: one wave per sub-block; lists[slot][256] = the list in front of the chunk
+__global__ void __launch_bounds__(64) k_bz_mtf_lists(SubTab T, const uint32_t *__restrict__ first_tile, const uint8_t *__restrict__ rec,
+                                                     const uint32_t *__restrict__ bm, const uint32_t *__restrict__ cnt, uint8_t *__restrict__ lists) {
+  __shared__ __align__(16) uint8_t L[2][256];
+  __shared__ uint32_t B[8];
+  const uint32_t s = blockIdx.x, n = T.n[s];
+  const int lane = threadIdx.x;
+  const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
+  const uint64_t slot0 = (uint64_t)first_tile[s] * MTF_PER_TILE;
+  for (int k = 0; k < 4; k++) L[0][k * 64 + lane] = (uint8_t)(k * 64 + lane);
+  int cur = 0;
+  wave_sync();
+  for (uint32_t ch = 0; ch < nchunks; ch++) {
+    const uint64_t slot = slot0 + ch;
+    ((uint32_t *)(lists + slot * 256))[lane] = ((const uint32_t *)L[cur])[lane];
+    const uint32_t r = cnt[slot];
+    if (lane < 8) B[lane] = bm[slot * 8 + lane];
+    wave_sync();
+    uint32_t kept = r;
+    for (int k = 0; k < 4; k++) {
+      const uint32_t y = L[cur][k * 64 + lane];
+      const bool keep = !((B[y >> 5] >> (y & 31)) & 1u);
+      const unsigned long long mask = __ballot(keep);
+      if (keep) L[cur ^ 1][kept + __popcll(mask & ((1ull << lane) - 1ull))] = (uint8_t)y;
+      kept += __popcll(mask);
+    }
+    for (uint32_t i = lane; i < r; i += 64) L[cur ^ 1][i] = rec[slot * 256 + i];
+    cur ^= 1;
+    wave_sync();
+  }
+}
+
+// pass 3: the move-to-front indices of a chunk
+__global__ void __launch_bounds__(64) k_bz_mtf_apply(const uint8_t *__restrict__ bwt, SubTab T, const Tile *__restrict__ tiles, uint32_t ntiles,
+                                                     const uint8_t *__restrict__ seq, const uint8_t *__restrict__ lists, uint8_t *__restrict__ idx_out) {
+  __shared__ uint8_t L[256 * 64];   // [position][lane]
+  const uint32_t slot = blockIdx.x * 64 + threadIdx.x, ti = slot / MTF_PER_TILE, j = slot % MTF_PER_TILE;
+  const int lane = threadIdx.x;
+  if (ti >= ntiles) return;
+  const Tile t = tiles[ti];
+  const uint32_t n = T.n[t.sb], lo = t.lo + j * MTF_CHUNK;
+  if (lo >= n) return;
+  const uint32_t m = min((uint32_t)MTF_CHUNK, n - lo);
+  const uint8_t *src = bwt + T.off[t.sb] + lo, *sq = seq + t.sb * 256, *l0 = lists + (uint64_t)slot * 256;
+  uint8_t *dst = idx_out + T.off[t.sb] + lo;
+  for (int i = 0; i < 256; i++) L[i * 64 + lane] = l0[i];
+  for (uint32_t i = 0; i < m; i++) {
+    const uint8_t y = sq[src[i]];
+    int idx = 0;
+    uint8_t prev = L[lane], curv;
+    if (prev != y) {
+      do { idx++; curv = L[idx * 64 + lane]; L[idx * 64 + lane] = prev; prev = curv; } while (curv != y);
+      L[lane] = y;
+    }
+    dst[i] = (uint8_t)idx;
+  }
+}
+
+// zero runs: position after the last non-zero index in front of g (the run's first element)
+__global__ void __launch_bounds__(1024) k_bz_rle2_val(const uint8_t *__restrict__ idx, SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ v) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, g = off + l;
+    v[g] = idx[g] != 0 ? g + 1 : (l == 0 ? g : 0u);
+  }
+}
+// symbols produced at element g: 1 for a non-zero index, the run's binary digits at the end of a zero run (:363-379)
+__global__ void __launch_bounds__(1024) k_bz_rle2_cnt(const uint8_t *__restrict__ idx, const uint32_t *__restrict__ rs, SubTab T, const Tile *__restrict__ tiles,
+                                                      uint32_t *__restrict__ cnt) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, g = off + l;
+    uint32_t c = 1;
+    if (idx[g] == 0) {
+      c = 0;
+      if (l + 1 == n || idx[g + 1] != 0) { const uint32_t run = g - rs[g] + 1; c = 31 - __clz(run + 1); }
+    }
+    cnt[g] = c;
+  }
+}
+// symbol space: sub-block s owns [soff[s], soff[s] + mtf_n[s]); soff[s] = symbols of the sub-blocks before + s (their EOBs)
+__global__ void k_bz_sym_layout(SubTab T, const uint32_t *__restrict__ P, const uint32_t *__restrict__ nsym, uint32_t *__restrict__ soff, uint32_t *__restrict__ mtf_n,
+                                uint16_t *__restrict__ sym) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= T.nsb) return;
+  const uint32_t a = P[T.off[s]], b = P[T.off[s] + T.n[s]];
+  soff[s] = a + s;
+  mtf_n[s] = b - a + 1;
+  sym[a + s + (b - a)] = (uint16_t)(nsym[s] + 1);      // EOB = last_symbol_in_use (:331-335)
+}
+__global__ void __launch_bounds__(1024) k_bz_rle2_emit(const uint8_t *__restrict__ idx, const uint32_t *__restrict__ rs, const uint32_t *__restrict__ P, SubTab T,
+                                                       const Tile *__restrict__ tiles, const uint32_t *__restrict__ soff, uint16_t *__restrict__ sym) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  const uint32_t base = soff[t.sb] - P[off];
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, g = off + l;
+    const uint32_t x = idx[g];
+    if (x != 0) sym[base + P[g]] = (uint16_t)(x + 1);
+    else if (l + 1 == n || idx[g + 1] != 0) {
+      uint32_t rc = g - rs[g] + 2, o = base + P[g];
+      do { sym[o++] = (uint16_t)(rc & 1u); rc >>= 1; } while (rc >= 2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 //  host side
 // ---------------------------------------------------------------------------------------------------------------
 struct DBuf {
@@ -494,9 +653,13 @@ struct Bz2State {
   DBuf rtiles, rtile_first, rtile_val, rtile_crc, etiles, etile_first;
   // element space
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg;
+  // MTF / symbol space
+  DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
+  uint32_t nsymtot = 0;
   std::vector<DBuf *> all() {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
-            &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg};
+            &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
+            &sym, &soff, &mtf_n};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -632,6 +795,44 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   return 0;
 }
 
+struct FZero { __device__ __forceinline__ uint32_t operator()(uint64_t) const { return 0; } };
+struct FArrPad { const uint32_t *a; uint64_t n; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return i < n ? a[i] : 0u; } };
+
+// MTF + RLE_2 of the batch that bz_transform has left in the state: symbols (u16) in B->sym, tables soff / mtf_n / nsym / seq
+static int bz_mtf(Ctx *c) {
+  Bz2State *B = bz_state(c);
+  hipStream_t st = c->stream;
+  const uint32_t nsb = B->nsb, net = B->n_etiles, tot = B->ntot;
+  const uint64_t slots = (uint64_t)net * MTF_PER_TILE;
+  int rc;
+  if ((rc = dbuf_ensure(c, B->seq, 256ull * nsb)) || (rc = dbuf_ensure(c, B->nsym, 4ull * nsb)) || (rc = dbuf_ensure(c, B->rec, 256 * slots + 256)) ||
+      (rc = dbuf_ensure(c, B->recbm, 32 * slots + 32)) || (rc = dbuf_ensure(c, B->reccnt, 4 * slots + 4)) || (rc = dbuf_ensure(c, B->lists, 256 * slots + 256)) ||
+      (rc = dbuf_ensure(c, B->sym, 2ull * ((uint64_t)tot + nsb + 16))) || (rc = dbuf_ensure(c, B->soff, 4ull * (nsb + 1))) ||
+      (rc = dbuf_ensure(c, B->mtf_n, 4ull * nsb))) return rc;
+  SubTab T = subtab(B);
+  const Tile *ET = B->etiles.as<Tile>();
+  uint8_t *idx = B->rle.as<uint8_t>();      // the RLE_1 bytes are no longer needed: their place takes the move-to-front indices
+  uint32_t *hv = B->hv.as<uint32_t>(), *hr = B->hr.as<uint32_t>(), *cnt = B->keyA.as<uint32_t>(), *P = B->keyB.as<uint32_t>(), *agg = B->agg.as<uint32_t>();
+  hipLaunchKernelGGL(k_bz_seqmap, dim3(nsb), dim3(64), 0, st, T, B->seq.as<uint8_t>(), B->nsym.as<uint32_t>());
+  if (net) {
+    const uint32_t nb = (uint32_t)((slots + 63) / 64);
+    hipLaunchKernelGGL(k_bz_mtf_recency, dim3(nb), dim3(64), 0, st, B->bwt.as<uint8_t>(), T, ET, net, B->seq.as<uint8_t>(), B->rec.as<uint8_t>(),
+                       B->recbm.as<uint32_t>(), B->reccnt.as<uint32_t>());
+    hipLaunchKernelGGL(k_bz_mtf_lists, dim3(nsb), dim3(64), 0, st, T, B->etile_first.as<uint32_t>(), B->rec.as<uint8_t>(), B->recbm.as<uint32_t>(),
+                       B->reccnt.as<uint32_t>(), B->lists.as<uint8_t>());
+    hipLaunchKernelGGL(k_bz_mtf_apply, dim3(nb), dim3(64), 0, st, B->bwt.as<uint8_t>(), T, ET, net, B->seq.as<uint8_t>(), B->lists.as<uint8_t>(), idx);
+    hipLaunchKernelGGL(k_bz_rle2_val, dim3(net), dim3(1024), 0, st, idx, T, ET, hv);
+    scan_launch<OpMax, true>(st, FArr{hv}, tot, agg, hr, nullptr);
+    hipLaunchKernelGGL(k_bz_rle2_cnt, dim3(net), dim3(1024), 0, st, idx, hr, T, ET, cnt);
+  }
+  scan_launch<OpSum, false>(st, FArrPad{cnt, tot}, (uint64_t)tot + 1, agg, P, nullptr);
+  hipLaunchKernelGGL(k_bz_sym_layout, dim3((nsb + 255) / 256), dim3(256), 0, st, T, P, B->nsym.as<uint32_t>(), B->soff.as<uint32_t>(), B->mtf_n.as<uint32_t>(),
+                     B->sym.as<uint16_t>());
+  if (net) hipLaunchKernelGGL(k_bz_rle2_emit, dim3(net), dim3(1024), 0, st, idx, hr, P, T, ET, B->soff.as<uint32_t>(), B->sym.as<uint16_t>());
+  BZ_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace zada
 
 struct zada_ctx { zada::Ctx c; };
@@ -639,7 +840,7 @@ using namespace zada;
 
 extern "C" int zada_bz2_stages(zada_ctx *z, const uint8_t *in, uint64_t n, uint32_t nsb, const uint64_t *starts, const uint32_t *lens, int option,
                                uint32_t *rle_n, uint32_t *bwt_index, uint32_t *crc, uint32_t *inuse, uint8_t *rle, uint8_t *bwt, uint64_t cap_elems,
-                               uint32_t *info) {
+                               uint32_t *mtf_n, uint16_t *mtf, uint64_t cap_mtf, uint32_t *info) {
   if (!z || (!in && n)) return ZADA_E_INVALID;
   Ctx *c = &z->c;
   (void)option;
@@ -663,6 +864,16 @@ extern "C" int zada_bz2_stages(zada_ctx *z, const uint8_t *in, uint64_t n, uint3
       hipMemcpy(bwt, B->bwt.p, B->ntot, hipMemcpyDeviceToHost);
     } else rc = ZADA_E_INVALID;
     if (info) { info[0] = B->ntot; info[1] = (uint32_t)B->bwt_rounds; }
+    if (rc == 0 && mtf_n) {
+      rc = bz_mtf(c);
+      if (rc == 0) {
+        hipStreamSynchronize(c->stream);
+        hipMemcpy(mtf_n, B->mtf_n.p, 4ull * nsb, hipMemcpyDeviceToHost);
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < nsb; i++) total += mtf_n[i];
+        if (total <= cap_mtf) hipMemcpy(mtf, B->sym.p, 2 * total, hipMemcpyDeviceToHost); else rc = ZADA_E_INVALID;
+      }
+    }
   }
   hipFree(d_in);
   return rc;
