@@ -61,24 +61,50 @@ def oracle_block(raw, option=2, want_bits=False):
                 info=info, bits=bits[:(info.bits + 7) // 8] if want_bits else None)
 
 
-def product_stages(enc, data, starts, lens, option=2):
-    """RLE_1 / CRC / BWT of sub-blocks of `data` through the product's test hook."""
+def _fetch(L, enc, name, dtype, cap_items):
+    buf = np.zeros(max(int(cap_items), 4), dtype)
+    n = ctypes.c_uint64()
+    rc = L.zada_bz2_fetch(enc.ctx, name.encode(), buf.ctypes.data, buf.nbytes, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError("zada_bz2_fetch(%s) rc=%d (needs %d bytes, has %d)" % (name, rc, n.value, buf.nbytes))
+    return buf[:n.value // buf.itemsize]
+
+
+def product_stages(enc, data, starts, lens, option=2, stages=3):
+    """Sub-blocks of `data` through the product's stage hooks: 1 = RLE_1 / CRC / BWT, 2 = + MTF / RLE_2, 3 = + entropy coders and bits."""
     Z = product()
     L = Z.load_library()
     vp = ctypes.c_void_p
-    L.zada_bz2_stages.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, vp, vp, ctypes.c_uint64, vp]
+    L.zada_bz2_run.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, vp, vp, ctypes.c_int, ctypes.c_int]
+    L.zada_bz2_fetch.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     nsb = len(starts)
     st = np.asarray(starts, np.uint64)
     ln = np.asarray(lens, np.uint32)
-    cap = int(sum(int(x) + int(x) // 4 + 8 for x in lens)) + 64
-    rle_n = np.zeros(nsb, np.uint32); bwt_index = np.zeros(nsb, np.uint32); crc = np.zeros(nsb, np.uint32); inuse = np.zeros((nsb, 8), np.uint32)
-    rle = np.zeros(cap, np.uint8); bwt = np.zeros(cap, np.uint8); info = np.zeros(8, np.uint32)
-    mtf_n = np.zeros(nsb, np.uint32); mtf = np.zeros(cap + nsb + 16, np.uint16)
-    rc = L.zada_bz2_stages(enc.ctx, bytes(data), len(data), nsb, st.ctypes.data, ln.ctypes.data, option, rle_n.ctypes.data, bwt_index.ctypes.data,
-                           crc.ctypes.data, inuse.ctypes.data, rle.ctypes.data, bwt.ctypes.data, cap, mtf_n.ctypes.data, mtf.ctypes.data, mtf.size, info.ctypes.data)
+    rc = L.zada_bz2_run(enc.ctx, bytes(data), len(data), nsb, st.ctypes.data, ln.ctypes.data, option, stages)
     if rc != 0:
-        raise RuntimeError("zada_bz2_stages rc=%d: %s" % (rc, L.zada_last_error(enc.ctx).decode()))
+        raise RuntimeError("zada_bz2_run rc=%d: %s" % (rc, L.zada_last_error(enc.ctx).decode()))
+    cap = int(sum(int(x) + int(x) // 4 + 8 for x in lens)) + 64
+    rle_n = _fetch(L, enc, "n", np.uint32, nsb)
     off = np.concatenate([[0], np.cumsum(rle_n)]).astype(np.int64)
-    moff = np.concatenate([[0], np.cumsum(mtf_n)]).astype(np.int64)
-    return dict(rle_n=rle_n, bwt_index=bwt_index, crc=crc, inuse=inuse, info=info, mtf_n=mtf_n, mtf=[mtf[moff[i]:moff[i + 1]] for i in range(nsb)],
-                rle=[rle[off[i]:off[i + 1]] for i in range(nsb)], bwt=[bwt[off[i]:off[i + 1]] for i in range(nsb)])
+    bwt = _fetch(L, enc, "bwt", np.uint8, cap)
+    R = dict(rle_n=rle_n, bwt_index=_fetch(L, enc, "bwt_index", np.uint32, nsb), crc=_fetch(L, enc, "crc", np.uint32, nsb),
+             inuse=_fetch(L, enc, "inuse", np.uint32, 8 * nsb).reshape(nsb, 8), info=_fetch(L, enc, "info", np.uint32, 4),
+             bwt=[bwt[off[i]:off[i + 1]] for i in range(nsb)])
+    if stages == 1:
+        rle = _fetch(L, enc, "rle", np.uint8, cap)
+        R["rle"] = [rle[off[i]:off[i + 1]] for i in range(nsb)]
+    if stages >= 2:
+        R["mtf_n"] = _fetch(L, enc, "mtf_n", np.uint32, nsb)
+        soff = _fetch(L, enc, "soff", np.uint32, nsb).astype(np.int64)
+        sym = _fetch(L, enc, "sym", np.uint16, cap + nsb + 16)
+        R["mtf"] = [sym[soff[i]:soff[i] + int(R["mtf_n"][i])] for i in range(nsb)]
+    if stages >= 3:
+        res = _fetch(L, enc, "res", np.uint32, 8 * nsb).reshape(nsb, 8)
+        so = _fetch(L, enc, "sel_off", np.uint32, nsb + 1).astype(np.int64)
+        sel = _fetch(L, enc, "sel", np.uint8, cap // 50 + 2 * nsb + 64)
+        lens_t = _fetch(L, enc, "lens", np.uint8, 6 * 260 * nsb).reshape(nsb, 6, 260)
+        woff = _fetch(L, enc, "woff", np.uint32, nsb + 1).astype(np.int64)
+        words = _fetch(L, enc, "words", np.uint32, int(cap) // 2 + 300000 * nsb // 100 + 4096 * nsb + 1024)
+        R.update(res=res, selectors=[sel[so[i]:so[i] + int(res[i, 3])] for i in range(nsb)], lens=lens_t[:, :, :258],
+                 bits=[words[woff[i]:woff[i + 1]].byteswap().view(np.uint8)[:(int(res[i, 7]) + 7) // 8] for i in range(nsb)])
+    return R

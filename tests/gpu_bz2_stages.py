@@ -22,12 +22,22 @@ for name, data in cases:
         q = n // 4
         starts += [0, q, 2 * q, 3 * q]; lens += [q, q, q, n - 3 * q]
         starts += [n // 3]; lens += [n - n // 3]
-    P = product_stages(enc, data, starts, lens)
+    P1 = product_stages(enc, data, starts, lens, stages=1)
+    P = product_stages(enc, data, starts, lens, stages=3)
+    P["rle"] = P1["rle"]
     for i, (s, l) in enumerate(zip(starts, lens)):
-        o = oracle_block(data[s:s + l])
+        o = oracle_block(data[s:s + l], want_bits=True)
         ok = (int(P["rle_n"][i]) == o["info"].rle_n and np.array_equal(P["rle"][i], o["rle"]) and int(P["crc"][i]) == o["info"].block_crc
               and np.array_equal(P["bwt"][i], o["bwt"]) and int(P["bwt_index"][i]) == o["info"].bwt_index
               and int(P["mtf_n"][i]) == o["info"].mtf_n and np.array_equal(P["mtf"][i], o["mtf"]))
+        oi = o["info"]
+        ok3 = (int(P["res"][i, 0]) == oi.coders and int(P["res"][i, 1]) == oi.max_code_len and int(P["res"][i, 2]) == oi.sample_width
+               and np.array_equal(P["selectors"][i], o["selectors"]) and np.array_equal(P["lens"][i], o["lens"]) and int(P["res"][i, 7]) == oi.bits
+               and np.array_equal(P["bits"][i], o["bits"]))
+        if ok and not ok3:
+            bad += 1
+            print("ENTROPY MISMATCH", name, i, s, l, "res", P["res"][i].tolist(), (oi.coders, oi.max_code_len, oi.sample_width, oi.selector_count, oi.bits),
+                  "sel", np.array_equal(P["selectors"][i], o["selectors"]), "lens", np.array_equal(P["lens"][i], o["lens"]), "bits", np.array_equal(P["bits"][i], o["bits"]))
         if not ok:
             bad += 1
             print("MISMATCH", name, i, s, l, "rle_n", int(P["rle_n"][i]), o["info"].rle_n, "rle", np.array_equal(P["rle"][i], o["rle"]),

@@ -630,6 +630,403 @@ __global__ void __launch_bounds__(1024) k_bz_rle2_emit(const uint8_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+//  Entropy coders (:418-1010).  One workgroup per sub-block runs the reference's brute-force search as it stands: for every
+//  (max code length, sample width, number of coders) on the list, start from the ranking of the groups of 50 symbols
+//  (:555-635), then up to ten rounds of {code lengths per cluster, every group to its cheapest coder} (:781-811), and keep
+//  the cheapest total (:926-950).  The order of equal keys in the ranking is the one GNAT's heap sort leaves (see
+//  oracle/zada_oracle_bz2.c): k_bz_rank replays that sort, one lane per ranking, in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BZ_GROUP = 50;
+constexpr int BZ_MAX_SEL = 18002;          // 1 + 900 005 / 50
+constexpr int BZ_LSTRIDE = 260;            // row stride of the code length tables
+
+struct EntTab {
+  const uint16_t *sym; const uint32_t *soff, *mtf_n, *nsym, *sel_off;
+  uint16_t *rank_idx;          // [2][selcap]: 1-based group numbers in ranking order, per sample width
+  uint32_t selcap;
+  uint16_t *gcost;             // [selcap][8]: bits of a group under each coder
+  uint8_t *sel;                // [selcap]: the coder of each group (1 ..)
+  uint8_t *lens;               // [nsb][6][260]
+  uint32_t *res;               // [nsb][8]: coders, max code length, sample width, groups, data bits, selector bits, tree bits, block bits
+  int option;                  // 0 / 1 / 2 = block_100k / 400k / 900k
+};
+
+__global__ void __launch_bounds__(128) k_bz_rank(EntTab E, uint32_t nsb) {
+  extern __shared__ uint8_t dyn[];
+  const uint32_t s = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int width = E.option == 2 ? 3 + w : 4;
+  if (E.option != 2 && w == 1) return;
+  uint8_t *K = dyn + (size_t)w * (BZ_MAX_SEL * 3 + 64);      // keys, 1-based
+  uint16_t *I = (uint16_t *)(K + ((BZ_MAX_SEL + 15) & ~15));  // group numbers, 1-based
+  const uint32_t m = E.mtf_n[s], ns = 1 + (m - 1) / BZ_GROUP;
+  const uint16_t *sym = E.sym + E.soff[s];
+  const int eob = (int)E.nsym[s] + 1;
+  const int last_sampled = eob - 1 < width - 1 ? eob - 1 : width - 1;          // :595
+  for (uint32_t g = lane; g < ns; g += 64) {
+    const uint32_t cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
+    uint32_t key = 0;
+    for (uint32_t k = 0; k < cnt; k++) key += (int)sym[g * BZ_GROUP + k] <= last_sampled ? 1u : 0u;
+    K[g + 1] = (uint8_t)key; I[g + 1] = (uint16_t)(g + 1);
+  }
+  wave_sync();
+  if (lane == 0) {
+    int Max = (int)ns;
+    uint8_t tk; uint16_t ti;
+    auto sift = [&](int S) {
+      int C = S;
+      for (;;) {
+        int Son = 2 * C;
+        if (Son > Max) break;
+        if (Son < Max && K[Son] < K[Son + 1]) Son++;
+        K[C] = K[Son]; I[C] = I[Son];
+        C = Son;
+      }
+      while (C != S) {
+        const int F = C / 2;
+        if (K[F] < tk) { K[C] = K[F]; I[C] = I[F]; C = F; } else break;
+      }
+      K[C] = tk; I[C] = ti;
+    };
+    for (int J = Max / 2; J >= 1; J--) { tk = K[J]; ti = I[J]; sift(J); }
+    while (Max > 1) {
+      tk = K[Max]; ti = I[Max];
+      K[Max] = K[1]; I[Max] = I[1];
+      Max--;
+      sift(1);
+    }
+  }
+  wave_sync();
+  uint16_t *out = E.rank_idx + (size_t)w * E.selcap + E.sel_off[s];
+  for (uint32_t i = lane; i < ns; i += 64) out[i] = I[i + 1];
+}
+
+constexpr int EN_THREADS = 512;
+
+__global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t nsb) {
+  __shared__ uint8_t sel[BZ_MAX_SEL + 14];
+  __shared__ uint32_t freq[6 * BZ_LSTRIDE];
+  __shared__ uint8_t lens[6 * BZ_LSTRIDE];
+  __shared__ __align__(16) uint8_t scratch[6 * LLHC_WAVE_SCRATCH];
+  __shared__ uint32_t st_out[EN_THREADS];
+  __shared__ uint32_t red[16];
+  const uint32_t s = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t m = E.mtf_n[s], A = E.nsym[s] + 2, ns = 1 + (m - 1) / BZ_GROUP;
+  const uint16_t *sym = E.sym + E.soff[s];
+  const uint32_t so = E.sel_off[s];
+  uint16_t *gc = E.gcost + (size_t)so * 8;
+  const uint32_t G = (ns + EN_THREADS - 1) / EN_THREADS;
+  const uint32_t g0 = min((uint32_t)tid * G, ns), g1 = min(g0 + G, ns);
+
+  auto define_descriptors = [&](int ec, int ml) {                                   // :637-660, :497-517
+    for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) freq[i] = 0;
+    __syncthreads();
+    for (uint32_t j = tid; j < m; j += EN_THREADS) atomicAdd(&freq[(sel[j / BZ_GROUP] - 1) * BZ_LSTRIDE + sym[j]], 1u);
+    __syncthreads();
+    if (w < ec) {
+      uint32_t *f = freq + w * BZ_LSTRIDE;
+      int zeroes = 0;
+      for (uint32_t base = 0; base < A; base += 64) { const uint32_t a = base + lane; zeroes += __popcll(__ballot(a < A && f[a] == 0)); }
+      if (zeroes > 0) {                                                               // Avoid_Zeros :436-460
+        for (uint32_t a = lane; a < A; a += 64) { const uint32_t v = f[a]; f[a] = zeroes <= 100 ? (v < 1 ? 1u : v) : (v == 0 ? 1u : v * 2); }
+      }
+      wave_sync();
+      uint8_t *bl = lens + w * BZ_LSTRIDE, *sc = scratch + w * LLHC_WAVE_SCRATCH;
+      if (ml == 15) llhc_wave<15>(f, (int)A, bl, sc, lane);
+      else if (ml == 16) llhc_wave<16>(f, (int)A, bl, sc, lane);
+      else llhc_wave<17>(f, (int)A, bl, sc, lane);
+    }
+    __syncthreads();
+  };
+  auto compute_costs = [&](int ec) {                                                  // the bit_count of :735-739, all groups at once
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) {
+      const uint32_t cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
+      uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+      for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t y = sym[g * BZ_GROUP + k];
+        c0 += lens[y]; c1 += lens[BZ_LSTRIDE + y];
+        if (ec > 2) c2 += lens[2 * BZ_LSTRIDE + y];
+        if (ec > 3) c3 += lens[3 * BZ_LSTRIDE + y];
+        if (ec > 4) c4 += lens[4 * BZ_LSTRIDE + y];
+        if (ec > 5) c5 += lens[5 * BZ_LSTRIDE + y];
+      }
+      uint4 v; v.x = c0 | (c1 << 16); v.y = c2 | (c3 << 16); v.z = c4 | (c5 << 16); v.w = 0;
+      ((uint4 *)gc)[g] = v;
+    }
+    __syncthreads();
+  };
+  // Simulate_Entropy_Coding_Variants_and_Reclassify (:664-752).  The choice of a group depends on the groups before it
+  // only through the move-to-front order of the coders; every thread runs its stretch of groups from a guessed order,
+  // then again whenever the stretch before it hands over a different one (thread 0 is right at once).
+  auto chain = [&](int ec, uint32_t &defectors, uint32_t &selbits) {
+    const uint32_t ident = 0x654321u;
+    uint32_t used = ident, outv = ident, def = 0, selc = 0;
+    auto run = [&]() {
+      uint32_t perm = used;
+      def = 0; selc = 0;
+      for (uint32_t g = g0; g < g1; g++) {
+        const uint4 cv = ((const uint4 *)gc)[g];
+        const uint64_t cp = (uint64_t)(cv.x & 0xFFFFu) | ((uint64_t)(cv.x >> 16) << 10) | ((uint64_t)(cv.y & 0xFFFFu) << 20) |
+                            ((uint64_t)(cv.y >> 16) << 30) | ((uint64_t)(cv.z & 0xFFFFu) << 40) | ((uint64_t)(cv.z >> 16) << 50);
+        const uint32_t old = sel[g] & 7u;
+        uint32_t bestc = 0xFFFFFFFFu, bestcl = old, bestpos = 1;
+        for (int j = 0; j < ec; j++) {
+          const uint32_t cl = (perm >> (4 * j)) & 15u;
+          const uint32_t cost = (uint32_t)((cp >> (10 * (cl - 1))) & 1023u) + (uint32_t)j + 1;
+          if (cost < bestc || (cost == bestc && cl < bestcl)) { bestc = cost; bestcl = cl; bestpos = (uint32_t)j + 1; }
+        }
+        if (bestcl != old) def++;
+        selc += bestpos;
+        const uint32_t lowm = (1u << (4 * (bestpos - 1))) - 1u, upto = bestpos >= 8 ? 0xFFFFFFFFu : (1u << (4 * bestpos)) - 1u;
+        perm = (perm & ~upto) | ((perm & lowm) << 4) | bestcl;
+        sel[g] = (uint8_t)(old | (bestcl << 4));
+      }
+      outv = perm;
+    };
+    run();
+    st_out[tid] = outv;
+    for (;;) {
+      __syncthreads();
+      const uint32_t in = tid ? st_out[tid - 1] : ident;
+      const int need = in != used;
+      if (!__syncthreads_or(need)) break;
+      if (need) { used = in; run(); }
+      st_out[tid] = outv;
+    }
+    if (tid < 2) red[tid] = 0;
+    __syncthreads();
+    if (def) atomicAdd(&red[0], def);
+    if (selc) atomicAdd(&red[1], selc);
+    for (uint32_t g = g0; g < g1; g++) sel[g] = sel[g] >> 4;
+    __syncthreads();
+    defectors = red[0]; selbits = red[1];
+    __syncthreads();
+  };
+  auto cluster_statistics = [&](int ec) -> bool {                                     // :756-779
+    if (tid < 8) red[8 + tid] = 0;
+    __syncthreads();
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) atomicAdd(&red[8 + sel[g]], 1u);
+    __syncthreads();
+    const uint32_t uniform_usage = ns / (uint32_t)ec;
+    bool low = false;
+    for (int cidx = 1; cidx <= ec; cidx++) if (red[8 + cidx] < uniform_usage / 2) low = true;
+    __syncthreads();
+    return low;
+  };
+  struct Cost { uint32_t data, selb, tree; };
+  auto construct = [&](int ec, int ml, int widx, bool &low) -> Cost {                 // :781-811 and :813-890
+    {                                                                                 // Initial_Clustering_by_Rank :574-591
+      const uint32_t attr = ec == 2 ? 0x12u : ec == 3 ? 0x213u : ec == 4 ? 0x3124u : ec == 5 ? 0x42135u : 0x531246u;
+      const uint16_t *rk = E.rank_idx + (size_t)widx * E.selcap + so;
+      for (uint32_t i = tid; i < ns; i += EN_THREADS) {
+        uint32_t a32 = 1;
+        while ((uint32_t)(a32 * ns / (uint32_t)ec) < i + 1) a32++;
+        sel[rk[i] - 1] = (uint8_t)((attr >> (4 * (a32 - 1))) & 15u);
+      }
+      __syncthreads();
+    }
+    uint32_t defectors = 0, selbits = 0;
+    for (int it = 1; it <= 10; it++) {
+      define_descriptors(ec, ml);
+      compute_costs(ec);
+      chain(ec, defectors, selbits);
+      if (defectors == 0) break;
+    }
+    if (defectors > 0) { define_descriptors(ec, ml); compute_costs(ec); }
+    low = cluster_statistics(ec);
+    // Compute_Total_Entropy_Cost: data, selectors (their move-to-front indices were summed by the last chain), code lengths
+    if (tid < 2) red[tid] = 0;
+    __syncthreads();
+    uint32_t d = 0;
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) d += gc[g * 8 + (sel[g] - 1)];
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
+    if (lane == 0 && d) atomicAdd(&red[0], d);
+    uint32_t tb = 0;
+    for (uint32_t q = tid; q < (uint32_t)ec * A; q += EN_THREADS) {
+      const uint32_t cl = q / A, i = q % A;
+      const int cur = lens[cl * BZ_LSTRIDE + i], prev = lens[cl * BZ_LSTRIDE + (i ? i - 1 : 0)];
+      tb += 1u + 2u * (uint32_t)(cur > prev ? cur - prev : prev - cur) + (i == 0 ? 5u : 0u);
+    }
+    for (int o = 32; o > 0; o >>= 1) tb += __shfl_down(tb, o);
+    if (lane == 0 && tb) atomicAdd(&red[1], tb);
+    __syncthreads();
+    Cost r{red[0], selbits, red[1]};
+    __syncthreads();
+    return r;
+  };
+
+  int mcl[2], nmcl, cc[4], ncc, nsw;
+  if (E.option == 2) {                                                                // :900-925
+    mcl[0] = 15; mcl[1] = 17; nmcl = 2; nsw = 2;
+    if (m <= 5000) { cc[0] = 2; cc[1] = 3; cc[2] = 6; ncc = 3; }
+    else if (m <= 10000) { cc[0] = 3; cc[1] = 4; cc[2] = 6; ncc = 3; }
+    else { cc[0] = 3; cc[1] = 4; cc[2] = 5; cc[3] = 6; ncc = 4; }
+  } else { mcl[0] = 16; nmcl = 1; nsw = 1; cc[0] = 4; cc[1] = 6; ncc = 2; }
+  bool low = false;
+  uint32_t best_cost = 0x7FFFFFFFu;
+  int best_ec = 2, best_ml = mcl[0], best_w = 0;
+  for (int a = 0; a < nmcl; a++)
+    for (int b = 0; b < nsw; b++)
+      for (int ec = 6; ec >= 2; ec--) {
+        bool listed = false;
+        for (int q = 0; q < ncc; q++) listed |= cc[q] == ec;
+        if (!(low || listed)) continue;
+        const Cost k = construct(ec, mcl[a], b, low);
+        const uint32_t cost = k.data + k.selb + k.tree;
+        if (cost < best_cost) { best_cost = cost; best_ec = ec; best_ml = mcl[a]; best_w = b; }
+      }
+  const Cost k = construct(best_ec, best_ml, best_w, low);
+  for (uint32_t g = tid; g < ns; g += EN_THREADS) E.sel[so + g] = sel[g];
+  for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) E.lens[(size_t)s * 6 * BZ_LSTRIDE + i] = (i / BZ_LSTRIDE < best_ec && (uint32_t)(i % BZ_LSTRIDE) < A) ? lens[i] : 0;
+  if (tid == 0) {
+    uint32_t *r = E.res + (size_t)s * 8;
+    r[0] = (uint32_t)best_ec; r[1] = (uint32_t)best_ml; r[2] = (uint32_t)(E.option == 2 ? 3 + best_w : 4); r[3] = ns;
+    r[4] = k.data; r[5] = k.selb; r[6] = k.tree; r[7] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//  Output (:1014-1116; Put_Bits is most significant bit first, bzip2-buffers.adb:21-33).  Bit strings are built in 32-bit
+//  words whose bit 31 comes first; the final copy swaps them into bytes.
+// ---------------------------------------------------------------------------------------------------------------
+struct BitW {      // appends to a zero-initialised word array with atomicOr, so that neighbours may share a word
+  uint32_t *w; uint64_t acc; uint32_t fill; uint64_t word;
+  __device__ __forceinline__ void start(uint32_t *base, uint64_t bitpos) { w = base; word = bitpos >> 5; fill = (uint32_t)(bitpos & 31u); acc = 0; }
+  __device__ __forceinline__ void put(uint32_t code, uint32_t len) {        // len <= 32
+    acc = (acc << len) | code; fill += len;
+    if (fill >= 32) { fill -= 32; const uint32_t x = (uint32_t)(acc >> fill); if (x) atomicOr(&w[word], x); word++; acc &= (1ull << fill) - 1ull; }
+  }
+  __device__ __forceinline__ void flush() { if (fill) { const uint32_t x = (uint32_t)(acc << (32 - fill)); if (x) atomicOr(&w[word], x); } }
+};
+
+constexpr uint32_t BZ_FIXED_HEAD_BITS = 48 + 32 + 1 + 24;
+
+// bits of every part of a block; res[7] = the block's size
+__global__ void k_bz_block_bits(SubTab T, uint32_t *__restrict__ res) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= T.nsb) return;
+  uint32_t used16 = 0;
+  for (int i = 0; i < 16; i++) used16 += ((T.inuse[s * 8 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu) ? 1u : 0u;
+  uint32_t *r = res + (size_t)s * 8;
+  r[7] = BZ_FIXED_HEAD_BITS + 16 + 16 * used16 + 3 + 15 + r[5] + r[6] + r[4];
+}
+
+// block header, mapping table, selectors, code lengths: one wave per sub-block, lane 0 writes
+__global__ void __launch_bounds__(64) k_bz_emit_head(SubTab T, EntTab E, const uint32_t *__restrict__ woff, uint32_t *__restrict__ words) {
+  const uint32_t s = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const uint32_t *r = E.res + (size_t)s * 8;
+  const uint32_t ec = r[0], ns = r[3], A = E.nsym[s] + 2;
+  BitW o; o.start(words + woff[s], 0);
+  o.put(0x314159u, 24); o.put(0x265359u, 24);                       // "1AY&SY"
+  o.put(T.crc[s], 32);
+  o.put(0, 1);
+  o.put(T.bwt_index[s], 24);
+  uint32_t used16 = 0;
+  for (int i = 0; i < 16; i++) if ((T.inuse[s * 8 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu) used16 |= 1u << i;
+  for (int i = 0; i < 16; i++) o.put((used16 >> i) & 1u, 1);
+  for (int i = 0; i < 16; i++) if ((used16 >> i) & 1u) {
+    const uint32_t bits = (T.inuse[s * 8 + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu;
+    for (int j = 0; j < 16; j++) o.put((bits >> j) & 1u, 1);
+  }
+  o.put(ec, 3);
+  o.put(ns, 15);
+  {                                                                   // Put_Selectors :1052-1079
+    uint32_t perm = 0x654321u;
+    const uint8_t *sel = E.sel + E.sel_off[s];
+    for (uint32_t g = 0; g < ns; g++) {
+      const uint32_t v = sel[g];
+      uint32_t pos = 1;
+      while (((perm >> (4 * (pos - 1))) & 15u) != v) pos++;
+      const uint32_t lowm = (1u << (4 * (pos - 1))) - 1u, upto = (1u << (4 * pos)) - 1u;
+      perm = (perm & ~upto) | ((perm & lowm) << 4) | v;
+      o.put(((1u << (pos - 1)) - 1u) << 1, pos);                      // pos - 1 ones, then a zero
+    }
+  }
+  const uint8_t *lens = E.lens + (size_t)s * 6 * BZ_LSTRIDE;
+  for (uint32_t cdr = 0; cdr < ec; cdr++) {                           // Put_Huffman_Bit_Lengths :1081-1105
+    int cur = lens[cdr * BZ_LSTRIDE];
+    o.put((uint32_t)cur, 5);
+    for (uint32_t i = 0; i < A; i++) {
+      const int nw = lens[cdr * BZ_LSTRIDE + i];
+      while (cur != nw) { if (cur < nw) { cur++; o.put(2, 2); } else { cur--; o.put(3, 2); } }
+      o.put(0, 1);
+    }
+  }
+  o.flush();
+}
+
+// Entropy_Output :1115-1138: one workgroup per sub-block; the groups' bit offsets by a scan, every thread writes its groups
+__global__ void __launch_bounds__(EN_THREADS) k_bz_emit_data(SubTab T, EntTab E, const uint32_t *__restrict__ woff, uint32_t *__restrict__ words) {
+  __shared__ uint32_t code[6 * BZ_LSTRIDE];
+  __shared__ uint8_t lens[6 * BZ_LSTRIDE];
+  __shared__ uint32_t l17[17];
+  const uint32_t s = blockIdx.x;
+  const int tid = threadIdx.x;
+  const uint32_t *r = E.res + (size_t)s * 8;
+  const uint32_t ec = r[0], ml = r[1], ns = r[3], A = E.nsym[s] + 2, m = E.mtf_n[s];
+  const uint16_t *sym = E.sym + E.soff[s];
+  const uint8_t *sel = E.sel + E.sel_off[s];
+  const uint16_t *gc = E.gcost + (size_t)E.sel_off[s] * 8;
+  for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) lens[i] = E.lens[(size_t)s * 6 * BZ_LSTRIDE + i];
+  __syncthreads();
+  if ((uint32_t)tid < ec) {                                           // Prepare_Codes (huffman-encoding.adb:45-80), bit order kept
+    uint32_t bl_count[24], next_code[24];
+    for (int i = 0; i < 24; i++) { bl_count[i] = 0; next_code[i] = 0; }
+    for (uint32_t i = 0; i < A; i++) bl_count[lens[tid * BZ_LSTRIDE + i]]++;
+    uint32_t cd = 0;
+    for (uint32_t b = 1; b <= ml; b++) { cd = (cd + bl_count[b - 1]) * 2; next_code[b] = cd; }
+    for (uint32_t i = 0; i < A; i++) { const uint32_t bl = lens[tid * BZ_LSTRIDE + i]; code[tid * BZ_LSTRIDE + i] = bl ? next_code[bl]++ : 0u; }
+  }
+  __syncthreads();
+  const uint32_t G = (ns + EN_THREADS - 1) / EN_THREADS;
+  const uint32_t g0 = min((uint32_t)tid * G, ns), g1 = min(g0 + G, ns);
+  uint32_t mine = 0;
+  for (uint32_t g = g0; g < g1; g++) mine += gc[g * 8 + (sel[g] - 1)];
+  OpSum sm;
+  const uint32_t incl = wg_scan_incl(mine, l17, sm, nullptr);
+  const uint32_t head_bits = r[7] - r[4];
+  BitW o; o.start(words + woff[s], (uint64_t)head_bits + incl - mine);
+  for (uint32_t g = g0; g < g1; g++) {
+    const uint32_t cl = sel[g] - 1, cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
+    for (uint32_t k = 0; k < cnt; k++) { const uint32_t y = sym[g * BZ_GROUP + k]; o.put(code[cl * BZ_LSTRIDE + y], lens[cl * BZ_LSTRIDE + y]); }
+  }
+  o.flush();
+}
+
+// A job copies `bits` bits from src (bit 0 = bit 31 of src word 0) to the destination at bit `dpos`
+struct CopyJob { uint64_t src_word; uint64_t dpos; uint64_t bits; uint64_t first_dst_word; };
+__global__ void __launch_bounds__(256) k_bz_assemble(const CopyJob *__restrict__ jobs, const uint64_t *__restrict__ job_first /* running count of destination words */,
+                                                     uint32_t njobs, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
+  const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // index in the concatenation of the jobs' destination word ranges
+  if (q >= job_first[njobs]) return;
+  uint32_t lo = 0, hi = njobs;                                        // job with job_first[j] <= q < job_first[j + 1]
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (job_first[mid] <= q) lo = mid; else hi = mid; }
+  const CopyJob J = jobs[lo];
+  const uint64_t dw = J.first_dst_word + (q - job_first[lo]);        // destination word
+  // destination bits [dw * 32, dw * 32 + 32) intersected with [dpos, dpos + bits)
+  const int64_t a = (int64_t)(dw * 32) - (int64_t)J.dpos;            // source bit of the word's first bit (may be negative)
+  uint32_t out = 0;
+  const uint32_t *sp = src + J.src_word;
+  const int64_t nb = (int64_t)J.bits;
+  // word made of source bits a .. a + 31
+  const int64_t k = a >= 0 ? a >> 5 : -((-a + 31) >> 5);
+  const int sh = (int)(a - k * 32);                                   // 0 .. 31
+  const int64_t nwords = (nb + 31) >> 5;
+  const uint32_t w0 = (k >= 0 && k < nwords) ? sp[k] : 0u, w1 = (k + 1 >= 0 && k + 1 < nwords) ? sp[k + 1] : 0u;
+  out = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
+  // mask off bits outside [0, nb)
+  if (a < 0) { const int z = (int)(-a); out = z >= 32 ? 0u : (out & (0xFFFFFFFFu >> z)); }
+  if (a + 32 > nb) { const int64_t keep = nb - a; out = keep <= 0 ? 0u : (out & ~((keep >= 32) ? 0u : (0xFFFFFFFFu >> keep))); }
+  if (out) atomicOr(&dst[dw], out);
+}
+__global__ void k_bz_words_to_bytes(const uint32_t *__restrict__ words, uint64_t nwords, uint32_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nwords) out[i] = __builtin_bswap32(words[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 //  host side
 // ---------------------------------------------------------------------------------------------------------------
 struct DBuf {
@@ -655,11 +1052,16 @@ struct Bz2State {
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg;
   // MTF / symbol space
   DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
-  uint32_t nsymtot = 0;
+  // entropy coders and output
+  DBuf sel_off, rank_idx, gcost, sel, lens, res, woff, words, jobs, job_first, outw;
+  std::vector<uint32_t> h_res, h_woff, h_crc;
+  uint64_t nwords = 0;
+  uint32_t selcap = 0;
+  bool rank_attr = false;
   std::vector<DBuf *> all() {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
-            &sym, &soff, &mtf_n};
+            &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -833,17 +1235,60 @@ static int bz_mtf(Ctx *c) {
   return 0;
 }
 
+// entropy coders + bit strings of the batch: words at B->words, sub-block s at word h_woff[s], h_res[8 s + 7] bits
+static int bz_entropy_emit(Ctx *c, int option) {
+  Bz2State *B = bz_state(c);
+  hipStream_t st = c->stream;
+  const uint32_t nsb = B->nsb;
+  int rc;
+  std::vector<uint32_t> so(nsb + 1);
+  for (uint32_t s = 0; s <= nsb; s++) so[s] = B->h_off[s] / BZ_GROUP + 2 * s;
+  const uint32_t selcap = so[nsb] + 8;
+  B->selcap = selcap;
+  if ((rc = dbuf_ensure(c, B->sel_off, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->rank_idx, 4ull * selcap)) || (rc = dbuf_ensure(c, B->gcost, 16ull * selcap)) ||
+      (rc = dbuf_ensure(c, B->sel, selcap)) || (rc = dbuf_ensure(c, B->lens, 6ull * BZ_LSTRIDE * nsb)) || (rc = dbuf_ensure(c, B->res, 32ull * nsb)) ||
+      (rc = dbuf_ensure(c, B->woff, 4ull * (nsb + 1)))) return rc;
+  BZ_HIP(hipMemcpyAsync(B->sel_off.p, so.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
+  EntTab E;
+  E.sym = B->sym.as<uint16_t>(); E.soff = B->soff.as<uint32_t>(); E.mtf_n = B->mtf_n.as<uint32_t>(); E.nsym = B->nsym.as<uint32_t>();
+  E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<uint16_t>();
+  E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option;
+  SubTab T = subtab(B);
+  const size_t rank_lds = 2 * (size_t)(BZ_MAX_SEL * 3 + 64);
+  if (!B->rank_attr) {
+    BZ_HIP(hipFuncSetAttribute((const void *)k_bz_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
+    B->rank_attr = true;
+  }
+  hipLaunchKernelGGL(k_bz_rank, dim3(nsb), dim3(128), rank_lds, st, E, nsb);
+  hipLaunchKernelGGL(k_bz_entropy, dim3(nsb), dim3(EN_THREADS), 0, st, E, nsb);
+  hipLaunchKernelGGL(k_bz_block_bits, dim3((nsb + 255) / 256), dim3(256), 0, st, T, B->res.as<uint32_t>());
+  B->h_res.resize(8ull * nsb); B->h_crc.resize(nsb);
+  BZ_HIP(hipMemcpyAsync(B->h_res.data(), B->res.p, 32ull * nsb, hipMemcpyDeviceToHost, st));
+  BZ_HIP(hipMemcpyAsync(B->h_crc.data(), B->crc.p, 4ull * nsb, hipMemcpyDeviceToHost, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  B->h_woff.resize(nsb + 1);
+  uint64_t w = 0;
+  for (uint32_t s = 0; s < nsb; s++) { B->h_woff[s] = (uint32_t)w; w += (B->h_res[8ull * s + 7] + 31) / 32 + 1; }
+  if (w >= (1ull << 32)) { c->err = "bzip2: batch output too large"; return ZADA_E_TOO_LARGE; }
+  B->h_woff[nsb] = (uint32_t)w; B->nwords = w;
+  if ((rc = dbuf_ensure(c, B->words, 4 * (w + 16)))) return rc;
+  BZ_HIP(hipMemcpyAsync(B->woff.p, B->h_woff.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
+  BZ_HIP(hipMemsetAsync(B->words.p, 0, 4 * (w + 16), st));
+  hipLaunchKernelGGL(k_bz_emit_head, dim3(nsb), dim3(64), 0, st, T, E, B->woff.as<uint32_t>(), B->words.as<uint32_t>());
+  hipLaunchKernelGGL(k_bz_emit_data, dim3(nsb), dim3(EN_THREADS), 0, st, T, E, B->woff.as<uint32_t>(), B->words.as<uint32_t>());
+  BZ_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace zada
 
 struct zada_ctx { zada::Ctx c; };
 using namespace zada;
 
-extern "C" int zada_bz2_stages(zada_ctx *z, const uint8_t *in, uint64_t n, uint32_t nsb, const uint64_t *starts, const uint32_t *lens, int option,
-                               uint32_t *rle_n, uint32_t *bwt_index, uint32_t *crc, uint32_t *inuse, uint8_t *rle, uint8_t *bwt, uint64_t cap_elems,
-                               uint32_t *mtf_n, uint16_t *mtf, uint64_t cap_mtf, uint32_t *info) {
-  if (!z || (!in && n)) return ZADA_E_INVALID;
+// ---- test hooks: run a list of sub-blocks of a host buffer through the stages, then fetch any table of the state ----
+extern "C" int zada_bz2_run(zada_ctx *z, const uint8_t *in, uint64_t n, uint32_t nsb, const uint64_t *starts, const uint32_t *lens, int option, int stages) {
+  if (!z || (!in && n) || option < 0 || option > 2) return ZADA_E_INVALID;
   Ctx *c = &z->c;
-  (void)option;
   hipSetDevice(c->device);
   uint8_t *d_in = nullptr;
   if (hipMalloc(&d_in, n + 64) != hipSuccess) return ZADA_E_NOMEM;
@@ -852,29 +1297,39 @@ extern "C" int zada_bz2_stages(zada_ctx *z, const uint8_t *in, uint64_t n, uint3
   std::vector<uint64_t> s(starts, starts + nsb);
   std::vector<uint32_t> l(lens, lens + nsb);
   int rc = bz_transform(c, d_in, s, l);
-  Bz2State *B = bz_state(c);
-  if (rc == 0) {
-    hipStreamSynchronize(c->stream);
-    hipMemcpy(rle_n, B->n.p, 4ull * nsb, hipMemcpyDeviceToHost);
-    hipMemcpy(bwt_index, B->bwt_index.p, 4ull * nsb, hipMemcpyDeviceToHost);
-    hipMemcpy(crc, B->crc.p, 4ull * nsb, hipMemcpyDeviceToHost);
-    hipMemcpy(inuse, B->inuse.p, 32ull * nsb, hipMemcpyDeviceToHost);
-    if (B->ntot <= cap_elems) {
-      hipMemcpy(rle, B->rle.p, B->ntot, hipMemcpyDeviceToHost);
-      hipMemcpy(bwt, B->bwt.p, B->ntot, hipMemcpyDeviceToHost);
-    } else rc = ZADA_E_INVALID;
-    if (info) { info[0] = B->ntot; info[1] = (uint32_t)B->bwt_rounds; }
-    if (rc == 0 && mtf_n) {
-      rc = bz_mtf(c);
-      if (rc == 0) {
-        hipStreamSynchronize(c->stream);
-        hipMemcpy(mtf_n, B->mtf_n.p, 4ull * nsb, hipMemcpyDeviceToHost);
-        uint64_t total = 0;
-        for (uint32_t i = 0; i < nsb; i++) total += mtf_n[i];
-        if (total <= cap_mtf) hipMemcpy(mtf, B->sym.p, 2 * total, hipMemcpyDeviceToHost); else rc = ZADA_E_INVALID;
-      }
-    }
-  }
+  if (rc == 0 && stages >= 2) rc = bz_mtf(c);
+  if (rc == 0 && stages >= 3) rc = bz_entropy_emit(c, option);
+  hipStreamSynchronize(c->stream);
   hipFree(d_in);
   return rc;
+}
+extern "C" int zada_bz2_fetch(zada_ctx *z, const char *name, void *dst, uint64_t cap, uint64_t *nbytes) {
+  if (!z || !name) return ZADA_E_INVALID;
+  Ctx *c = &z->c;
+  Bz2State *B = bz_state(c);
+  hipSetDevice(c->device);
+  const uint32_t nsb = B->nsb;
+  const void *src = nullptr; uint64_t len = 0;
+  uint32_t tmp[4];
+  if (!strcmp(name, "n")) { src = B->n.p; len = 4ull * nsb; }
+  else if (!strcmp(name, "bwt_index")) { src = B->bwt_index.p; len = 4ull * nsb; }
+  else if (!strcmp(name, "crc")) { src = B->crc.p; len = 4ull * nsb; }
+  else if (!strcmp(name, "inuse")) { src = B->inuse.p; len = 32ull * nsb; }
+  else if (!strcmp(name, "rle")) { src = B->rle.p; len = B->ntot; }      // the move-to-front indices once stage 2 has run
+  else if (!strcmp(name, "bwt")) { src = B->bwt.p; len = B->ntot; }
+  else if (!strcmp(name, "mtf_n")) { src = B->mtf_n.p; len = 4ull * nsb; }
+  else if (!strcmp(name, "soff")) { src = B->soff.p; len = 4ull * nsb; }
+  else if (!strcmp(name, "sym")) { src = B->sym.p; len = 2ull * ((uint64_t)B->ntot + nsb); }
+  else if (!strcmp(name, "res")) { src = B->res.p; len = 32ull * nsb; }
+  else if (!strcmp(name, "sel_off")) { src = B->sel_off.p; len = 4ull * (nsb + 1); }
+  else if (!strcmp(name, "sel")) { src = B->sel.p; len = B->selcap; }
+  else if (!strcmp(name, "lens")) { src = B->lens.p; len = 6ull * BZ_LSTRIDE * nsb; }
+  else if (!strcmp(name, "woff")) { src = B->woff.p; len = 4ull * (nsb + 1); }
+  else if (!strcmp(name, "words")) { src = B->words.p; len = 4ull * B->nwords; }
+  else if (!strcmp(name, "info")) { tmp[0] = B->ntot; tmp[1] = (uint32_t)B->bwt_rounds; tmp[2] = nsb; tmp[3] = 0; if (cap < 16) return ZADA_E_INVALID; memcpy(dst, tmp, 16); if (nbytes) *nbytes = 16; return 0; }
+  else return ZADA_E_INVALID;
+  if (nbytes) *nbytes = len;
+  if (len > cap) return ZADA_E_INVALID;
+  if (len && hipMemcpy(dst, src, len, hipMemcpyDeviceToHost) != hipSuccess) return ZADA_E_HIP;
+  return 0;
 }
