@@ -33,7 +33,10 @@ enum {
   ZADA_DEFLATE_1 = 8,       /* IZ_6  (8,16,128,128),   1 scan level     (:1576, lz77.adb:542) */
   ZADA_DEFLATE_2 = 9,       /* IZ_8  (32,128,258,1024), 2 scan levels   (:1577, lz77.adb:544) */
   ZADA_DEFLATE_3 = 10,      /* IZ_10 (34,258,258,4096), 3 scan levels   (:1578, lz77.adb:546) */
-  ZADA_DEFLATE_R = 11       /* LZ77.Rich -- not implemented (out of scope) */
+  ZADA_DEFLATE_R = 11,      /* LZ77.Rich -- not implemented (out of scope) */
+  ZADA_BZIP2_1 = 12,        /* BZip2, 100 000-byte blocks  (zip-compress-bzip2_e.adb:138-142, bzip2-encoding.adb:93-98) */
+  ZADA_BZIP2_2 = 13,        /* BZip2, 400 000-byte blocks */
+  ZADA_BZIP2_3 = 14         /* BZip2, 900 000-byte blocks, four splitting tactics per block (bzip2-encoding.adb:1214-1345) */
 };
 
 /* Return codes.  1 and 2 mirror the reference's two non-error outcomes:
@@ -163,6 +166,28 @@ int zada_last_timing(zada_ctx *ctx, const char **names, float *ms, int cap);
 
 /* Deterministic synthetic corpus "silesia_mix_v1" (bench / tests): bytes [offset, offset+len). */
 void zada_silesia_mix(uint64_t seed, unsigned class_mask, uint64_t offset, uint64_t len, uint8_t *dst);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * BZip2.  Replaces the body of Zip.Compress.BZip2_E (zip_lib/zip-compress-bzip2_e.ads, .adb:44-157),
+ * i.e. BZip2.Encoding.Encode (zip_lib/bzip2-encoding.adb:87-1431) with size_hint = the input's size (zip-create.adb:256-257).
+ * Same conventions as zada_deflate: method = Compression_Method'Pos (ZADA_BZIP2_1 .. _3), crc_inout = the running Zip CRC-32
+ * register, return ZADA_OK / ZADA_INEFFICIENT (stream not smaller than the input: compression_ok := False) / ZADA_ABORTED / < 0.
+ * The stream is the complete BZip2 stream ("BZh9" ... footer).  Unlike zada_deflate it is also delivered with
+ * ZADA_INEFFICIENT when it fits `cap` (*out_len <= cap), so the entry points serve a stand-alone .bz2 writer (bzip2_enc.adb) too.
+ * Streams of 2 GiB and more: ZADA_E_TOO_LARGE (not built yet).
+ * --------------------------------------------------------------------------------------------------------------- */
+int zada_bzip2(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,
+               uint32_t *crc_inout, zada_feedback_fn fb, void *user);
+/* the same with input and output in device memory (d_out: cap bytes) */
+int zada_bzip2_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len,
+                      uint32_t *crc_inout);
+/* Trace of the last zada_bzip2* call: per block of Read_and_Split_Block (bzip2-encoding.adb:1144) four values -- raw start,
+ * raw length, splitting tactic kept (0 single, 1 parts_4, 2 segmented_1, 3 segmented_2), its number of sub-blocks.
+ * Returns the number of values there are; at most cap_items are stored. */
+uint64_t zada_bz2_last_blocks(zada_ctx *ctx, uint64_t *dst, uint64_t cap_items);
+/* Test hooks: sub-blocks (Encode_Block jobs) of a host buffer through the stages, and the tables they leave. */
+int zada_bz2_run(zada_ctx *ctx, const uint8_t *in, uint64_t n, uint32_t nsb, const uint64_t *starts, const uint32_t *lens, int option, int stages);
+int zada_bz2_fetch(zada_ctx *ctx, const char *name, void *dst, uint64_t cap, uint64_t *nbytes);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,10 @@ def load_library():
     L.zada_range_analyze.argtypes = [vp]
     L.zada_range_choose.argtypes = [vp, vp, vp, u64p, u64p]
     L.zada_range_emit.argtypes = [vp, vp, u64, u64p]
+    L.zada_bzip2.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, vp, vp]
+    L.zada_bzip2_device.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
+    L.zada_bz2_last_blocks.restype = ctypes.c_uint64
+    L.zada_bz2_last_blocks.argtypes = [vp, vp, u64]
     L.zada_crc32_combine.restype = ctypes.c_uint32
     L.zada_crc32_combine.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u64]
     _lib = L
@@ -162,6 +166,40 @@ class Encoder:
         if rc != 0:
             self._err(rc, "zada_deflate")
         return out.raw[:ol.value], c.value
+
+    def bzip2(self, data, method=14, crc=0xFFFFFFFF, feedback=None, cap=None):
+        """Zip.Compress.BZip2_E (method 12 / 13 / 14 = BZip2_1 / _2 / _3).  Returns (rc, BZip2 stream, running CRC register);
+        rc 1 = not smaller than the input (the stream is still returned when it fits `cap`, default len(data) * 5 // 4 + 4096)."""
+        n = len(data)
+        cap = int(cap if cap is not None else n + n // 4 + 4096)
+        out = ctypes.create_string_buffer(cap)
+        ol = ctypes.c_uint64(0)
+        c = ctypes.c_uint32(crc)
+        cb = FEEDBACK_FN(lambda pct, _u: 1 if feedback(pct) else 0) if feedback else None
+        rc = self.lib.zada_bzip2(self.ctx, method, _addr(data) if n else None, n, ctypes.addressof(out), cap, ctypes.byref(ol), ctypes.byref(c),
+                                 ctypes.cast(cb, ctypes.c_void_p) if cb else None, None)
+        if rc == 2:
+            raise UserAbort()
+        if rc < 0:
+            self._err(rc, "zada_bzip2")
+        return rc, (out.raw[:ol.value] if ol.value <= cap else None), c.value
+
+    def bzip2_device(self, d_in, n, d_out, cap, method=14, crc=0xFFFFFFFF):
+        """BZip2 stream of n bytes at device address d_in into d_out (cap bytes).  Returns (rc, length, running CRC register)."""
+        ol = ctypes.c_uint64(0)
+        c = ctypes.c_uint32(crc)
+        rc = self.lib.zada_bzip2_device(self.ctx, method, d_in, n, d_out, cap, ctypes.byref(ol), ctypes.byref(c))
+        if rc < 0:
+            self._err(rc, "zada_bzip2_device")
+        return rc, ol.value, c.value
+
+    def bz2_last_blocks(self):
+        """[(raw start, raw length, tactic, sub-blocks)] of the last bzip2 call (bzip2-encoding.adb:1144, :1312-1318)."""
+        import numpy as np
+        k = self.lib.zada_bz2_last_blocks(self.ctx, None, 0)
+        buf = np.zeros(max(int(k), 1), np.uint64)
+        self.lib.zada_bz2_last_blocks(self.ctx, buf.ctypes.data, k)
+        return [tuple(int(x) for x in buf[i:i + 4]) for i in range(0, int(k), 4)]
 
     def deflate_into(self, data, out, method=Method.Deflate_3, crc=0xFFFFFFFF):
         """Zip.Compress.Deflate into a caller-owned buffer (bytearray / numpy uint8 / ctypes, len(out) >= len(data) + 64):

@@ -132,15 +132,29 @@ int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes) {
   A(blk_entry, W.cap_blocks + 16);
   A(chooser, 1); A(carry, 2);
   A(scan2, nflush / 1024 + 1024); A(total2, 16);
-  for (int l = 0; l < 4; l++) A(crc_lvl[l], (cap >> (4 * l)) / CRC_SUB + 64);
-  A(crc_mat, 128);
-  W.crc_mat_ready = false;
   // the largest stream the encoder can produce for `cap` bytes: every literal in nine bits (fixed code) + block overheads
   W.cap_out = cap + cap / 8 + (1u << 20);
   A(out, W.cap_out);
 #undef A
+  if (!rc) rc = ensure_crc_workspace(c, cap);
   if (rc) { free_group(W.en_allocs); return rc; }
   W.cap_atoms = cap; W.cap_flush = nflush - 3;
+  return 0;
+}
+
+int ensure_crc_workspace(Ctx *c, uint64_t n) {
+  Workspace &W = c->ws;
+  if (W.cap_crc >= n && W.cap_crc > 0) return 0;
+  hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
+  free_group(W.crc_allocs);
+  W.cap_crc = 0;
+  const uint64_t cap = ((n < (1u << 20) ? (1u << 20) : n) + 65535) & ~65535ull;
+  int rc = 0;
+  for (int l = 0; l < 4 && !rc; l++) rc = dalloc(c, W.crc_allocs, &W.crc_lvl[l], (cap >> (4 * l)) / CRC_SUB + 64);
+  if (!rc) rc = dalloc(c, W.crc_allocs, &W.crc_mat, 128);
+  W.crc_mat_ready = false;
+  if (rc) { free_group(W.crc_allocs); return rc; }
+  W.cap_crc = cap;
   return 0;
 }
 
@@ -175,7 +189,7 @@ static int ensure_rin(Ctx *c, uint64_t n) {
 }
 
 static void free_workspace(Ctx *c) {
-  free_group(c->ws.allocs); free_group(c->ws.en_allocs); free_group(c->ws.bt_allocs);
+  free_group(c->ws.allocs); free_group(c->ws.en_allocs); free_group(c->ws.bt_allocs); free_group(c->ws.crc_allocs);
   if (c->ws.rin_own) hipFree(c->ws.rin_own);
   c->ws = Workspace();
 }
@@ -858,6 +872,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
   else if (!strcmp(name, "inner_budget")) z->c.knob_inner_budget = value;
   else if (!strcmp(name, "span_mib")) { if (value < 1 || value > 3968) return ZADA_E_INVALID; z->c.knob_span_mib = value; }
+  else if (!strcmp(name, "bz_batch_melems")) { if (value < 1 || value > 1536) return ZADA_E_INVALID; z->c.knob_bz_batch_melems = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
@@ -954,6 +969,55 @@ int zada_deflate(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t
   }
   return rc;
 }
+
+// ---- BZip2: Zip.Compress.BZip2_E, zip-compress-bzip2_e.adb:44-157 ----
+static int bzip2_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout,
+                      zada_feedback_fn fb, void *user) {
+  if (method < ZADA_BZIP2_1 || method > ZADA_BZIP2_3) { c->err = "not a BZip2 method"; return ZADA_E_INVALID; }
+  int rc;
+  c->tbegin();
+  c->tmark("bz:begin");
+  if (crc_inout && n) {
+    if ((rc = ensure_crc_workspace(c, n)) || (rc = crc_launch(c, d_in, n))) return rc;
+  }
+  rc = bz2_encode_device(c, method - ZADA_BZIP2_1, d_in, n, (int64_t)n, d_out, cap, out_len, fb, user);
+  c->tmark("bz:end");
+  c->tend();
+  if (rc < 0 || rc == ZADA_ABORTED) return rc;
+  if (crc_inout && n) { const int r2 = crc_finish(c, n, crc_inout); if (r2) return r2; }
+  return rc;
+}
+int zada_bzip2_device(zada_ctx *z, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  const uint8_t *src = (const uint8_t *)d_in;
+  if (((uintptr_t)d_in & 15) != 0 && n) {
+    if ((rc = ensure_rin(c, n))) return rc;
+    hipMemcpyAsync(c->ws.rin_own, d_in, n, hipMemcpyDeviceToDevice, c->stream);
+    src = c->ws.rin_own;
+  }
+  uint64_t ol = 0;
+  rc = finish_call(c, bzip2_core(c, method, src, n, (uint8_t *)d_out, cap, &ol, crc_inout, nullptr, nullptr));
+  if (out_len && rc >= 0) *out_len = ol;
+  return rc;
+}
+int zada_bzip2(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout,
+               zada_feedback_fn fb, void *user) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  if ((rc = ensure_rin(c, n + cap + 64))) return rc;           // input, then the stream, in one device buffer
+  copy_in(c, c->ws.rin_own, in, n);
+  uint8_t *d_out = c->ws.rin_own + ((n + 63) & ~63ull);
+  uint64_t ol = 0;
+  rc = finish_call(c, bzip2_core(c, method, c->ws.rin_own, n, d_out, cap, &ol, crc_inout, fb, user));
+  if (rc < 0 || rc == ZADA_ABORTED) return rc;
+  if (out_len) *out_len = ol;
+  if (ol <= cap && copy_out(c, out, d_out, ol)) return ZADA_E_HIP;
+  return rc;
+}
+uint64_t zada_bz2_last_blocks(zada_ctx *z, uint64_t *dst, uint64_t cap_items) { return z ? bz2_last_blocks(&z->c, dst, cap_items) : 0; }
 
 int zada_deflate_device(zada_ctx *z, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len,
                         uint32_t *crc_inout) {

@@ -1027,6 +1027,127 @@ __global__ void k_bz_words_to_bytes(const uint32_t *__restrict__ words, uint64_t
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+//  Data acquisition (:1161-1209): a block ends one byte after the piece that takes the simulated RLE_1 size to capacity - 5,
+//  after ten capacities of raw bytes, or with the stream.  With E[q] = RLE_1 bytes of the pieces that end before q (pieces
+//  phased from the stream's runs) the end is a search in E, except inside the block's first run, whose pieces restart at
+//  the block's first byte.  One wave walks the blocks; the searches are 64-ary.
+// ---------------------------------------------------------------------------------------------------------------
+struct FRunStart1 {     // p + 1 where a run of equal bytes starts, else 0; its inclusive max-scan is RS1[p] = start of p's run + 1
+  const uint8_t *in;
+  __device__ __forceinline__ uint32_t operator()(uint64_t p) const { return (p == 0 || in[p] != in[p - 1]) ? (uint32_t)p + 1u : 0u; }
+};
+struct FPieceEnd {      // RLE_1 bytes of the piece that ends at p (0 if none ends there)
+  const uint8_t *in; const uint32_t *rs1; uint64_t n;
+  __device__ __forceinline__ uint32_t operator()(uint64_t p) const {
+    if (p >= n) return 0u;
+    const uint32_t r = (uint32_t)((p - (rs1[p] - 1u)) % 259u);
+    const bool end = r == 258u || p + 1 == n || in[p + 1] != in[p];
+    return end ? (r + 1 < 4 ? r + 1 : 5u) : 0u;
+  }
+};
+// first index in [lo, hi) with arr[index] >= target, else hi (arr non-decreasing); the whole wave calls it
+__device__ __forceinline__ uint64_t wave_lower_bound(const uint32_t *__restrict__ arr, uint64_t lo, uint64_t hi, uint64_t target, int lane) {
+  while (hi - lo > 64) {
+    const uint64_t step = (hi - lo + 63) / 64, idx = lo + (uint64_t)lane * step;
+    const bool pred = idx >= hi || (uint64_t)arr[idx] >= target;
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) { lo = lo + 63 * step + 1; continue; }
+    const int f = __ffsll((long long)mask) - 1;
+    if (f == 0) return lo;
+    const uint64_t nlo = lo + (uint64_t)(f - 1) * step + 1, nhi = lo + (uint64_t)f * step;
+    lo = nlo; hi = nhi < hi ? nhi : hi;
+  }
+  const uint64_t idx = lo + lane;
+  const bool pred = idx >= hi || (uint64_t)arr[idx] >= target;
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0) return hi;                        // a full last stretch of 64 with no hit
+  const uint64_t r = lo + (uint64_t)(__ffsll((long long)mask) - 1);
+  return r < hi ? r : hi;
+}
+__device__ __forceinline__ uint32_t rle1_size_of_run(uint64_t L) {      // a run of L equal bytes from a block's first byte on
+  const uint64_t k = (L - 1) / 259, rem = L - 259 * k;
+  return (uint32_t)(5 * k + (rem < 4 ? rem : 5));
+}
+__global__ void __launch_bounds__(64) k_bz_acquire(const uint32_t *__restrict__ rs1, const uint32_t *__restrict__ E, uint64_t n, int64_t size_hint,
+                                                   int32_t block_capacity, float f_lo, float f_hi, uint64_t *__restrict__ bstart, uint32_t *__restrict__ blen,
+                                                   uint32_t cap_blocks, uint32_t *__restrict__ count) {
+  const int lane = threadIdx.x;
+  uint64_t pos = 0;
+  uint32_t nb = 0;
+  do {
+    const int64_t stream_rest = size_hint < 0 ? -1 : size_hint - (int64_t)pos;                 // :1411-1423
+    const float fr = (float)stream_rest;
+    const int32_t cap = (fr >= f_lo && fr <= f_hi) ? (int32_t)(stream_rest / 2) : block_capacity;
+    const uint64_t raw_last = 10ull * (uint64_t)cap;
+    const uint64_t limit = n - pos < raw_last ? n - pos : raw_last;
+    uint64_t consumed = limit;
+    if (limit > 0) {
+      const int64_t t = (int64_t)cap - 5;                // bytes are read while the simulated size stays below t
+      const uint64_t s = pos, b = wave_lower_bound(rs1, s + 1, s + limit, (uint64_t)rs1[s] + 1, lane);   // where the block's first run ends
+      const uint64_t L0 = b - s;
+      const uint64_t i1 = 259ull * (uint64_t)((t + 4) / 5) + 1;    // first count at which whole pieces of the first run alone reach t
+      if (i1 <= L0) consumed = i1 < limit ? i1 : limit;
+      else if (b < s + limit) {
+        const int64_t tq = t - (int64_t)rle1_size_of_run(L0) + (int64_t)E[b];
+        const uint64_t q = tq <= (int64_t)E[b] ? b : wave_lower_bound(E, b, s + limit, (uint64_t)tq, lane);
+        consumed = q < s + limit ? q - s + 1 : limit;
+      }
+    }
+    if (lane == 0 && nb < cap_blocks) { bstart[nb] = pos; blen[nb] = (uint32_t)consumed; }
+    nb++;
+    pos += consumed;
+  } while (pos < n);
+  if (lane == 0) *count = nb;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//  Data_Segmentation.Segment_by_Entropy (data_segmentation.adb:39-105) for the tactics segmented_1 / segmented_2
+//  (:1255-1263: thresholds 0.6 / 0.4, distances 4000 / 8000, window 16000).  The running entropy is a chain of `digits 15`
+//  additions, so it is walked in order, one lane per block; both tactics read the same chain.  etab[f] = -(p Log p) for
+//  p = f / window, tabulated by the host with the C library's log, the function GNAT's Log maps to.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SEG_WINDOW = 16000;
+__global__ void __launch_bounds__(64) k_bz_segment(const uint8_t *__restrict__ in, const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ blen,
+                                                   uint32_t nblk, const double *__restrict__ etab, double thr1, double thr2,
+                                                   const uint32_t *__restrict__ seg_off /*[2 nblk + 1]*/, uint32_t *__restrict__ seg, uint32_t *__restrict__ seg_cnt) {
+  __shared__ uint16_t freq[256 * 64];
+  const int lane = threadIdx.x;
+  const uint32_t blk = blockIdx.x * 64 + lane;
+  if (blk >= nblk) return;
+  for (int b = 0; b < 256; b++) freq[b * 64 + lane] = 0;
+  const uint8_t *buf = in + bstart[blk];
+  const uint32_t len = blen[blk];
+  uint32_t *s1 = seg + seg_off[2 * blk], *s2 = seg + seg_off[2 * blk + 1];
+  uint32_t n1 = 0, n2 = 0;
+  if (len > SEG_WINDOW + 4000) {
+    const bool t2 = len > SEG_WINDOW + 8000;
+    double entropy = 0.0, mark1 = 0.0, mark2 = 0.0;
+    uint32_t im1 = 1, im2 = 1;
+    for (uint32_t i = 1; i <= len; i++) {
+      uint32_t bt = buf[i - 1];
+      const uint32_t f = ++freq[bt * 64 + lane];
+      if (i == SEG_WINDOW) {
+        for (int b = 0; b < 256; b++) { const uint32_t fb = freq[b * 64 + lane]; if (fb) entropy = entropy + etab[fb]; }
+        mark1 = entropy; mark2 = entropy;
+      } else if (i > SEG_WINDOW) {
+        entropy = entropy - etab[f - 1];
+        entropy = entropy + etab[f];
+        bt = buf[i - SEG_WINDOW - 1];
+        const uint32_t g = freq[bt * 64 + lane];
+        entropy = entropy - etab[g];
+        freq[bt * 64 + lane] = (uint16_t)(g - 1);
+        if (g - 1 > 0) entropy = entropy + etab[g - 1];
+        const uint32_t seg_point = i - SEG_WINDOW;
+        if (fabs(entropy - mark1) > thr1 && seg_point - im1 > 4000u && seg_point > im1) { s1[n1++] = seg_point; im1 = seg_point; mark1 = entropy; }
+        if (t2 && fabs(entropy - mark2) > thr2 && seg_point - im2 > 8000u && seg_point > im2) { s2[n2++] = seg_point; im2 = seg_point; mark2 = entropy; }
+      }
+    }
+  }
+  if (len > 0) { s1[n1++] = len; s2[n2++] = len; }
+  seg_cnt[2 * blk] = n1; seg_cnt[2 * blk + 1] = n2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 //  host side
 // ---------------------------------------------------------------------------------------------------------------
 struct DBuf {
@@ -1054,6 +1175,10 @@ struct Bz2State {
   DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
   // entropy coders and output
   DBuf sel_off, rank_idx, gcost, sel, lens, res, woff, words, jobs, job_first, outw;
+  // stream level
+  DBuf rs1, epre, bstart, blen, etab, seg_off, seg, seg_cnt, extra;
+  bool etab_ready = false;
+  std::vector<uint64_t> trace;      // per block: raw start, raw length, tactic kept, its number of sub-blocks
   std::vector<uint32_t> h_res, h_woff, h_crc;
   uint64_t nwords = 0;
   uint32_t selcap = 0;
@@ -1061,7 +1186,8 @@ struct Bz2State {
   std::vector<DBuf *> all() {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
-            &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw};
+            &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
+            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -1278,6 +1404,182 @@ static int bz_entropy_emit(Ctx *c, int option) {
   hipLaunchKernelGGL(k_bz_emit_data, dim3(nsb), dim3(EN_THREADS), 0, st, T, E, B->woff.as<uint32_t>(), B->words.as<uint32_t>());
   BZ_HIP(hipGetLastError());
   return 0;
+}
+
+// BZip2.Encoding.Encode (:87-1431) of n bytes at d_in; the stream goes to d_out (cap bytes).  Returns ZADA_OK, ZADA_INEFFICIENT
+// when the stream is not smaller than the input (it is still delivered if it fits), ZADA_ABORTED, or an error.
+int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64_t size_hint, uint8_t *d_out, uint64_t cap, uint64_t *out_len,
+                      zada_feedback_fn fb, void *user) {
+  Bz2State *B = bz_state(c);
+  hipStream_t st = c->stream;
+  int rc;
+  if (n >= (1ull << 31)) { c->err = "bzip2: streams of 2 GiB and more are not taken yet"; return ZADA_E_TOO_LARGE; }
+  if (cap < 64) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
+  const int level = option == 0 ? 1 : option == 1 ? 4 : 9;
+  const int32_t block_capacity = 100000 * level;
+  B->trace.clear();
+  if (fb && fb(0, user)) return ZADA_ABORTED;
+  // ---- block limits ----
+  const uint32_t cap_blocks = (uint32_t)(n / ((uint64_t)block_capacity * 3 / 8) + 8);
+  if ((rc = dbuf_ensure(c, B->rs1, 4 * (n + 16))) || (rc = dbuf_ensure(c, B->epre, 4 * (n + 16))) || (rc = dbuf_ensure(c, B->agg, 4 * ((n + 16) / SC_TILE + 16))) ||
+      (rc = dbuf_ensure(c, B->bstart, 8ull * cap_blocks)) || (rc = dbuf_ensure(c, B->blen, 4ull * cap_blocks)) || (rc = dbuf_ensure(c, B->scal, 64))) return rc;
+  uint32_t *rs1 = B->rs1.as<uint32_t>(), *E = B->epre.as<uint32_t>(), *agg = B->agg.as<uint32_t>();
+  scan_launch<OpMax, true>(st, FRunStart1{d_in}, n, agg, rs1, nullptr);
+  scan_launch<OpSum, false>(st, FPieceEnd{d_in, rs1, n}, n + 1, agg, E, nullptr);
+  const float fc = (float)block_capacity, f_lo = fc * 1.05f, f_hi = fc * 1.30f;        // :1406-1414
+  uint32_t *d_count = B->scal.as<uint32_t>() + 8;
+  hipLaunchKernelGGL(k_bz_acquire, dim3(1), dim3(64), 0, st, rs1, E, n, size_hint, block_capacity, f_lo, f_hi, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(),
+                     cap_blocks, d_count);
+  uint32_t nblk = 0;
+  BZ_HIP(hipMemcpyAsync(&nblk, d_count, 4, hipMemcpyDeviceToHost, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  if (nblk > cap_blocks) { c->err = "bzip2: block table overflow"; return ZADA_E_HIP; }
+  std::vector<uint64_t> bstart(nblk); std::vector<uint32_t> blen(nblk);
+  BZ_HIP(hipMemcpy(bstart.data(), B->bstart.p, 8ull * nblk, hipMemcpyDeviceToHost));
+  BZ_HIP(hipMemcpy(blen.data(), B->blen.p, 4ull * nblk, hipMemcpyDeviceToHost));
+  if (fb && fb(3, user)) return ZADA_ABORTED;
+  // ---- segmentation (block_900k only) ----
+  std::vector<uint32_t> seg_off(2ull * nblk + 1, 0), seg, seg_cnt(2ull * nblk, 0);
+  if (option == 2) {
+    if (!B->etab_ready) {
+      std::vector<double> et(SEG_WINDOW + 2);
+      const double inv = 1.0 / (double)SEG_WINDOW;
+      et[0] = 0.0;
+      for (int f = 1; f <= SEG_WINDOW + 1; f++) { const double pr = (double)f * inv; et[f] = -(pr * log(pr)); }
+      if ((rc = dbuf_ensure(c, B->etab, 8ull * et.size()))) return rc;
+      BZ_HIP(hipMemcpy(B->etab.p, et.data(), 8ull * et.size(), hipMemcpyHostToDevice));
+      B->etab_ready = true;
+    }
+    uint64_t so = 0;
+    for (uint32_t k = 0; k < nblk; k++) { seg_off[2 * k] = (uint32_t)so; so += blen[k] / 4000 + 2; seg_off[2 * k + 1] = (uint32_t)so; so += blen[k] / 8000 + 2; }
+    seg_off[2ull * nblk] = (uint32_t)so;
+    if ((rc = dbuf_ensure(c, B->seg_off, 4ull * (2ull * nblk + 1))) || (rc = dbuf_ensure(c, B->seg, 4 * so + 16)) || (rc = dbuf_ensure(c, B->seg_cnt, 8ull * nblk + 16))) return rc;
+    BZ_HIP(hipMemcpyAsync(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bz_segment, dim3((nblk + 63) / 64), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
+                       (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
+    seg.resize(so);
+    BZ_HIP(hipMemcpyAsync(seg.data(), B->seg.p, 4 * so, hipMemcpyDeviceToHost, st));
+    BZ_HIP(hipMemcpyAsync(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost, st));
+    BZ_HIP(hipStreamSynchronize(st));
+  }
+  if (fb && fb(6, user)) return ZADA_ABORTED;
+  // ---- final stream: words with bit 31 first ----
+  const uint64_t capw = cap / 4 + 8;
+  if ((rc = dbuf_ensure(c, B->outw, 4 * capw + 64)) || (rc = dbuf_ensure(c, B->extra, 64))) return rc;
+  BZ_HIP(hipMemsetAsync(B->outw.p, 0, 4 * capw + 64, st));
+  {
+    const uint32_t head = ((uint32_t)'B' << 24) | ((uint32_t)'Z' << 16) | ((uint32_t)'h' << 8) | (uint32_t)('0' + level);   // :1380-1387
+    BZ_HIP(hipMemcpyAsync(B->outw.p, &head, 4, hipMemcpyHostToDevice, st));
+  }
+  uint64_t bitpos = 32;
+  uint32_t combined_crc = 0;
+  const uint64_t cap_bits = cap * 8;
+  bool overflow = false;
+  const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 192) << 20;
+  // ---- batches of blocks ----
+  struct Plan { std::vector<uint32_t> tac[4]; };
+  uint32_t k0 = 0;
+  while (k0 < nblk && !overflow) {
+    std::vector<uint64_t> starts; std::vector<uint32_t> lens; std::vector<Plan> plans;
+    uint64_t est = 0;
+    uint32_t k1 = k0;
+    for (; k1 < nblk; k1++) {
+      Plan P;
+      const uint64_t bs = bstart[k1]; const uint32_t bl = blen[k1];
+      const size_t first_sub = starts.size();
+      auto sub_of = [&](uint64_t s0, uint32_t l0) -> uint32_t {
+        for (size_t i = first_sub; i < starts.size(); i++) if (starts[i] == s0 && lens[i] == l0) return (uint32_t)i;
+        starts.push_back(s0); lens.push_back(l0);
+        return (uint32_t)(starts.size() - 1);
+      };
+      uint64_t e_blk = 0;
+      const size_t before = starts.size();
+      P.tac[0].push_back(sub_of(bs, bl));                                            // single
+      if (option == 2) {
+        const uint32_t size = bl / 4;                                                  // parts_4 :1237-1253
+        uint32_t stop = 0;
+        for (uint32_t count = 1; count <= 4; count++) { const uint32_t start = stop + 1; stop = count == 4 ? bl : count * size; P.tac[1].push_back(sub_of(bs + start - 1, stop - start + 1)); }
+        for (int t = 0; t < 2; t++) {                                                  // segmented_1 / _2 :1265-1297
+          const uint32_t cnt = seg_cnt[2 * k1 + t], *sp = seg.data() + seg_off[2 * k1 + t];
+          if (cnt == 0) P.tac[2 + t].push_back(sub_of(bs, 0));
+          uint32_t index_start = 1;
+          for (uint32_t q = 0; q < cnt; q++) { P.tac[2 + t].push_back(sub_of(bs + index_start - 1, sp[q] - index_start + 1)); index_start = sp[q] + 1; }
+        }
+      }
+      for (size_t i = before; i < starts.size(); i++) e_blk += (uint64_t)lens[i] + lens[i] / 4 + 8;
+      if (!plans.empty() && est + e_blk > batch_elems) { starts.resize(before); lens.resize(before); break; }
+      est += e_blk;
+      plans.push_back(std::move(P));
+    }
+    if ((rc = bz_transform(c, d_in, starts, lens)) || (rc = bz_mtf(c)) || (rc = bz_entropy_emit(c, option))) return rc;
+    // ---- smallest tactic per block (:1312-1318), copy jobs ----
+    std::vector<CopyJob> jobs; std::vector<uint64_t> job_first;
+    uint64_t dstw = 0;
+    for (uint32_t k = k0; k < k1 && !overflow; k++) {
+      const Plan &P = plans[k - k0];
+      const uint64_t phase = bitpos & 7;
+      int best = 0; uint64_t best_idx = 0, best_bits = 0;
+      for (int t = 0; t < (option == 2 ? 4 : 1); t++) {
+        uint64_t bits = 0;
+        for (uint32_t sb : P.tac[t]) bits += B->h_res[8ull * sb + 7];
+        const uint64_t idx = (phase + bits) / 8;                                       // destination_index: whole bytes written
+        if (t == 0 || idx < best_idx) { best = t; best_idx = idx; best_bits = bits; }
+      }
+      if (bitpos + best_bits + 80 + 8 > cap_bits) { overflow = true; bitpos += best_bits; break; }
+      for (uint32_t sb : P.tac[best]) {
+        const uint64_t bits = B->h_res[8ull * sb + 7];
+        combined_crc = ((combined_crc << 1) | (combined_crc >> 31)) ^ B->h_crc[sb];
+        CopyJob J; J.src_word = B->h_woff[sb]; J.dpos = bitpos; J.bits = bits; J.first_dst_word = bitpos >> 5;
+        job_first.push_back(dstw);
+        dstw += ((bitpos + bits + 31) >> 5) - (bitpos >> 5);
+        jobs.push_back(J);
+        bitpos += bits;
+      }
+      B->trace.push_back(bstart[k]); B->trace.push_back(blen[k]); B->trace.push_back((uint64_t)best); B->trace.push_back(P.tac[best].size());
+    }
+    if (!jobs.empty()) {
+      job_first.push_back(dstw);
+      if ((rc = dbuf_ensure(c, B->jobs, sizeof(CopyJob) * jobs.size())) || (rc = dbuf_ensure(c, B->job_first, 8 * job_first.size()))) return rc;
+      BZ_HIP(hipMemcpyAsync(B->jobs.p, jobs.data(), sizeof(CopyJob) * jobs.size(), hipMemcpyHostToDevice, st));
+      BZ_HIP(hipMemcpyAsync(B->job_first.p, job_first.data(), 8 * job_first.size(), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_bz_assemble, dim3((uint32_t)((dstw + 255) / 256)), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), (uint32_t)jobs.size(),
+                         B->words.as<uint32_t>(), B->outw.as<uint32_t>());
+      BZ_HIP(hipStreamSynchronize(st));     // the job vectors go out of scope; the next batch reuses the words
+    }
+    k0 = k1;
+    if (fb && fb(6 + (int)(90.0 * (double)k0 / (double)nblk), user)) return ZADA_ABORTED;
+  }
+  if (overflow) {      // not smaller than the input: Compression_inefficient (zip-compress.adb:479-486)
+    if (out_len) *out_len = (bitpos + 80 + 7) / 8;
+    return ZADA_INEFFICIENT;
+  }
+  {                    // Write_Stream_Footer :1391-1403
+    uint32_t foot[4] = {0x17724538u, 0x50900000u | (combined_crc >> 16), combined_crc << 16, 0};
+    BZ_HIP(hipMemcpyAsync(B->extra.p, foot, 16, hipMemcpyHostToDevice, st));
+    CopyJob J; J.src_word = 0; J.dpos = bitpos; J.bits = 80; J.first_dst_word = bitpos >> 5;
+    uint64_t jf[2] = {0, ((bitpos + 80 + 31) >> 5) - (bitpos >> 5)};
+    if ((rc = dbuf_ensure(c, B->jobs, sizeof(CopyJob))) || (rc = dbuf_ensure(c, B->job_first, 16))) return rc;
+    BZ_HIP(hipMemcpyAsync(B->jobs.p, &J, sizeof J, hipMemcpyHostToDevice, st));
+    BZ_HIP(hipMemcpyAsync(B->job_first.p, jf, 16, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bz_assemble, dim3(1), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), 1u, B->extra.as<uint32_t>(), B->outw.as<uint32_t>());
+    bitpos += 80;
+  }
+  const uint64_t nbytes = (bitpos + 7) / 8, nw = (nbytes + 3) / 4;
+  if (((uintptr_t)d_out & 3) != 0 || nw * 4 > cap) {      // swap in place, then copy the bytes
+    hipLaunchKernelGGL(k_bz_words_to_bytes, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, st, B->outw.as<uint32_t>(), nw, B->outw.as<uint32_t>());
+    BZ_HIP(hipMemcpyAsync(d_out, B->outw.p, nbytes, hipMemcpyDeviceToDevice, st));
+  } else hipLaunchKernelGGL(k_bz_words_to_bytes, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, st, B->outw.as<uint32_t>(), nw, (uint32_t *)d_out);
+  BZ_HIP(hipStreamSynchronize(st));
+  if (out_len) *out_len = nbytes;
+  if (fb && fb(100, user)) return ZADA_ABORTED;
+  return nbytes >= n ? ZADA_INEFFICIENT : ZADA_OK;
+}
+
+uint64_t bz2_last_blocks(Ctx *c, uint64_t *dst, uint64_t cap_items) {
+  Bz2State *B = bz_state(c);
+  const uint64_t k = B->trace.size() < cap_items ? B->trace.size() : cap_items;
+  if (dst && k) memcpy(dst, B->trace.data(), 8 * k);
+  return B->trace.size();
 }
 
 }  // namespace zada

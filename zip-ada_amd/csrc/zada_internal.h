@@ -178,6 +178,8 @@ struct Workspace {
   uint64_t cap_blocks = 0, cap_tiles = 0, cap_pieces = 0;
   uint32_t *blk_entry = nullptr;             // batches: entry of a block
   std::vector<void *> en_allocs;
+  std::vector<void *> crc_allocs;                    // CRC-32 levels (their own group: the BZip2 path needs them without the Deflate entropy workspace)
+  uint64_t cap_crc = 0;
   // ---- batches of entries (zada_deflate_batch): per entry / per flush slot / per segment tables ----
   uint64_t cap_ent = 0, cap_fslots = 0, cap_bseg = 0;
   FlushGeom *ftab = nullptr;
@@ -255,6 +257,7 @@ struct Ctx {
   int knob_inner_budget = 0;        // ZADA_INNER_BUDGET: rounds for positions deep inside a match (0 = as every other position; A/B: 1 round saves 4.7 ms in k_match and costs 8.9 ms of demand searches, 2 rounds: -3.2 / +3.7)
   int knob_span_mib = 2048;         // MiB of a stream one pass takes (longer streams: spans one after the other, deflate_spans)
   int knob_batch_mib = 512;         // MiB of LZ buffer one batch of small entries may take (zada_deflate_batch)
+  int knob_bz_batch_melems = 192;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
   int knob_shard_kib = 1 << 20;     // ZADA_SHARD_KIB: bytes of a range the LZ stage takes at a time, in KiB (multiple of 64)
   void tmark(const char *name);
   void tbegin();
@@ -263,8 +266,12 @@ struct Ctx {
 
 int hip_check(Ctx *c, hipError_t e, const char *what);
 void bz2_destroy(Ctx *c);
+int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64_t size_hint, uint8_t *d_out, uint64_t cap, uint64_t *out_len,
+                      int (*fb)(int, void *), void *user);
+uint64_t bz2_last_blocks(Ctx *c, uint64_t *dst, uint64_t cap_items);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);
+int ensure_crc_workspace(Ctx *c, uint64_t n);
 
 // One shard of a range through the LZ stage.  W.in holds `nbuf` bytes (zero pad behind): a 32 KiB halo in front of the
 // shard unless it starts the stream, the shard, and a tail behind it unless it ends the stream.  The tokens of the parse
