@@ -1,0 +1,28 @@
+"""GPU script: BZip2_3 throughput on silesia_mix with input and output resident in HBM, and the phases' shares."""
+import sys, os, time, ctypes
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import torch
+from _common import product
+Z = product()
+enc = Z.Encoder(0)
+L = Z.load_library()
+for mib in [int(x) for x in os.environ.get("BZ_MIBS", "64,256").split(",")]:
+    n = mib << 20
+    h = np.zeros(n, np.uint8)
+    L.zada_silesia_mix(0, 0x5A1E51A, 0, n, h.ctypes.data)
+    d_in = torch.from_numpy(h).cuda()
+    d_out = torch.zeros(n + 4096, dtype=torch.uint8, device="cuda")
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        rc, ol, crc = enc.bzip2_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 14)
+        dt = time.time() - t0
+    tim = {}
+    for k, v in enc.last_timing():
+        tim[k] = tim.get(k, 0.0) + v
+    blocks = enc.bz2_last_blocks()
+    tac = [0, 0, 0, 0]
+    for b in blocks: tac[b[2]] += 1
+    print("%d MiB: rc %d, %.1f ms, %.1f MB/s, ratio %.4f, blocks %d, tactics %s" % (mib, rc, dt * 1e3, n / dt / 1e6, ol / n, len(blocks), tac))
+    print("   ", {k: round(v, 1) for k, v in tim.items() if not k.startswith("#")}, flush=True)

@@ -603,15 +603,16 @@ __global__ void __launch_bounds__(1024) k_bz_rle2_cnt(const uint8_t *__restrict_
     cnt[g] = c;
   }
 }
-// symbol space: sub-block s owns [soff[s], soff[s] + mtf_n[s]); soff[s] = symbols of the sub-blocks before + s (their EOBs)
+// symbol space: sub-block s owns [soff[s], soff[s] + mtf_n[s]); the sub-blocks follow each other with at most two symbols between them
 __global__ void k_bz_sym_layout(SubTab T, const uint32_t *__restrict__ P, const uint32_t *__restrict__ nsym, uint32_t *__restrict__ soff, uint32_t *__restrict__ mtf_n,
                                 uint16_t *__restrict__ sym) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= T.nsb) return;
   const uint32_t a = P[T.off[s]], b = P[T.off[s] + T.n[s]];
-  soff[s] = a + s;
+  const uint32_t o = a + 2 * s + (a & 1u);             // even, so that a group's fifty symbols can be read as 25 words
+  soff[s] = o;
   mtf_n[s] = b - a + 1;
-  sym[a + s + (b - a)] = (uint16_t)(nsym[s] + 1);      // EOB = last_symbol_in_use (:331-335)
+  sym[o + (b - a)] = (uint16_t)(nsym[s] + 1);          // EOB = last_symbol_in_use (:331-335)
 }
 __global__ void __launch_bounds__(1024) k_bz_rle2_emit(const uint8_t *__restrict__ idx, const uint32_t *__restrict__ rs, const uint32_t *__restrict__ P, SubTab T,
                                                        const Tile *__restrict__ tiles, const uint32_t *__restrict__ soff, uint16_t *__restrict__ sym) {
@@ -644,10 +645,12 @@ struct EntTab {
   const uint16_t *sym; const uint32_t *soff, *mtf_n, *nsym, *sel_off;
   uint16_t *rank_idx;          // [2][selcap]: 1-based group numbers in ranking order, per sample width
   uint32_t selcap;
-  uint16_t *gcost;             // [selcap][8]: bits of a group under each coder
+  unsigned long long *gcost;   // [selcap]: bits of a group under each of the six coders, ten bits apart
   uint8_t *sel;                // [selcap]: the coder of each group (1 ..)
   uint8_t *lens;               // [nsb][6][260]
   uint32_t *res;               // [nsb][8]: coders, max code length, sample width, groups, data bits, selector bits, tree bits, block bits
+  uint32_t *deflist;           // [selcap]: the groups that change coder in a round
+  unsigned long long *dbg;     // [nsb][8] clock counts (profiling aid): histogram, code lengths, costs, chain, passes, rounds, constructs, total
   int option;                  // 0 / 1 / 2 = block_100k / 400k / 900k
 };
 
@@ -703,29 +706,82 @@ __global__ void __launch_bounds__(128) k_bz_rank(EntTab E, uint32_t nsb) {
 
 constexpr int EN_THREADS = 512;
 
+// Move-to-front order of the (at most six) coders, and the effect of a stretch of groups on it: the coders chosen in the
+// stretch, most recent first.  Both are lists of nibbles (entry j in bits 4j .. 4j+3) with their length in bits 28 .. 30; the
+// stretch B after the stretch (or state) A leaves B's list followed by what A's list holds besides.
+__device__ __forceinline__ uint32_t mtf_compose(uint32_t A, uint32_t B) {
+  const uint32_t kA = A >> 28, kB = B >> 28;
+  uint32_t inB = 0;
+  for (uint32_t j = 0; j < kB; j++) inB |= 1u << ((B >> (4 * j)) & 15u);
+  uint32_t list = B & 0x0FFFFFFFu, k = kB;
+  for (uint32_t j = 0; j < kA; j++) {
+    const uint32_t x = (A >> (4 * j)) & 15u;
+    if (!((inB >> x) & 1u)) { list |= x << (4 * k); k++; }
+  }
+  return list | (k << 28);
+}
+
 __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t nsb) {
   __shared__ uint8_t sel[BZ_MAX_SEL + 14];
-  __shared__ uint32_t freq[6 * BZ_LSTRIDE];
+  __shared__ uint32_t freq[6 * BZ_LSTRIDE];          // symbol counts per cluster
+  __shared__ uint32_t fwork[6 * BZ_LSTRIDE];         // ... after Avoid_Zeros, as the code length procedure reads them
   __shared__ uint8_t lens[6 * BZ_LSTRIDE];
+  __shared__ unsigned long long lens6[BZ_LSTRIDE];   // the six coders' lengths of a symbol, ten bits apart
   __shared__ __align__(16) uint8_t scratch[6 * LLHC_WAVE_SCRATCH];
-  __shared__ uint32_t st_out[EN_THREADS];
+  __shared__ uint32_t wtot[EN_THREADS / 64];
   __shared__ uint32_t red[16];
   const uint32_t s = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t m = E.mtf_n[s], A = E.nsym[s] + 2, ns = 1 + (m - 1) / BZ_GROUP;
   const uint16_t *sym = E.sym + E.soff[s];
   const uint32_t so = E.sel_off[s];
-  uint16_t *gc = E.gcost + (size_t)so * 8;
+  unsigned long long *gc = (unsigned long long *)E.gcost + so;
   const uint32_t G = (ns + EN_THREADS - 1) / EN_THREADS;
   const uint32_t g0 = min((uint32_t)tid * G, ns), g1 = min(g0 + G, ns);
+  unsigned long long t_hist = 0, t_llhc = 0, t_cost = 0, t_chain = 0, n_pass = 0, n_round = 0, n_constr = 0;
+  const unsigned long long t_begin = wall_clock64();
 
-  auto define_descriptors = [&](int ec, int ml) {                                   // :637-660, :497-517
+  // counts of one group's symbols go to (sign > 0) or leave (sign < 0) a cluster; the four most frequent symbols (the two
+  // run digits and the first two move-to-front ranks) are gathered in registers first: they would queue up at the LDS
+  // a group's fifty symbols as 25 words, all loads in flight together (the symbol space starts at an even offset and is padded)
+  auto load_group = [&](uint32_t g, uint32_t (&v)[25]) {
+    const uint32_t *p = (const uint32_t *)(sym + (size_t)g * BZ_GROUP);
+#pragma unroll
+    for (int k = 0; k < 25; k++) v[k] = p[k];
+  };
+  // counts of one group's symbols leave cluster `from` and go to cluster `to` (either may be none: 6); the four most frequent
+  // symbols (the two run digits and the first two move-to-front ranks) are gathered in registers first: they would queue up at the LDS
+  auto count_group = [&](uint32_t g, uint32_t from, uint32_t to) {
+    const uint32_t cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
+    uint32_t v[25];
+    load_group(g, v);
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    uint32_t *ff = freq + (from < 6 ? from : 0) * BZ_LSTRIDE, *ft = freq + (to < 6 ? to : 0) * BZ_LSTRIDE;
+#pragma unroll
+    for (int k = 0; k < 50; k++) {
+      if ((uint32_t)k < cnt) {
+        const uint32_t y = (v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+        if (y == 0) c0++; else if (y == 1) c1++; else if (y == 2) c2++; else if (y == 3) c3++;
+        else { if (from < 6) atomicSub(&ff[y], 1u); if (to < 6) atomicAdd(&ft[y], 1u); }
+      }
+    }
+    if (from < 6) { if (c0) atomicSub(&ff[0], c0); if (c1) atomicSub(&ff[1], c1); if (c2) atomicSub(&ff[2], c2); if (c3) atomicSub(&ff[3], c3); }
+    if (to < 6) { if (c0) atomicAdd(&ft[0], c0); if (c1) atomicAdd(&ft[1], c1); if (c2) atomicAdd(&ft[2], c2); if (c3) atomicAdd(&ft[3], c3); }
+  };
+  auto histogram = [&]() {                                                            // :637-655
+    const unsigned long long ta = wall_clock64();
     for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) freq[i] = 0;
     __syncthreads();
-    for (uint32_t j = tid; j < m; j += EN_THREADS) atomicAdd(&freq[(sel[j / BZ_GROUP] - 1) * BZ_LSTRIDE + sym[j]], 1u);
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) count_group(g, 6, sel[g] - 1u);
+    __syncthreads();
+    t_hist += wall_clock64() - ta;
+  };
+  auto define_descriptors = [&](int ec, int ml) {                                   // :656-659, :497-517
+    const unsigned long long tb = wall_clock64();
+    for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) fwork[i] = freq[i];
     __syncthreads();
     if (w < ec) {
-      uint32_t *f = freq + w * BZ_LSTRIDE;
+      uint32_t *f = fwork + w * BZ_LSTRIDE;
       int zeroes = 0;
       for (uint32_t base = 0; base < A; base += 64) { const uint32_t a = base + lane; zeroes += __popcll(__ballot(a < A && f[a] == 0)); }
       if (zeroes > 0) {                                                               // Avoid_Zeros :436-460
@@ -738,37 +794,41 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
       else llhc_wave<17>(f, (int)A, bl, sc, lane);
     }
     __syncthreads();
-  };
-  auto compute_costs = [&](int ec) {                                                  // the bit_count of :735-739, all groups at once
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) {
-      const uint32_t cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
-      uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-      for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t y = sym[g * BZ_GROUP + k];
-        c0 += lens[y]; c1 += lens[BZ_LSTRIDE + y];
-        if (ec > 2) c2 += lens[2 * BZ_LSTRIDE + y];
-        if (ec > 3) c3 += lens[3 * BZ_LSTRIDE + y];
-        if (ec > 4) c4 += lens[4 * BZ_LSTRIDE + y];
-        if (ec > 5) c5 += lens[5 * BZ_LSTRIDE + y];
-      }
-      uint4 v; v.x = c0 | (c1 << 16); v.y = c2 | (c3 << 16); v.z = c4 | (c5 << 16); v.w = 0;
-      ((uint4 *)gc)[g] = v;
+    for (uint32_t y = tid; y < A; y += EN_THREADS) {
+      unsigned long long v = 0;
+      for (int cl = 0; cl < ec; cl++) v |= (unsigned long long)lens[cl * BZ_LSTRIDE + y] << (10 * cl);
+      lens6[y] = v;
     }
     __syncthreads();
+    t_llhc += wall_clock64() - tb;
+  };
+  auto compute_costs = [&]() {                                                        // the bit_count of :735-739, all groups at once
+    const unsigned long long ta = wall_clock64();
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) {
+      const uint32_t cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
+      uint32_t v[25];
+      load_group(g, v);
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int k = 0; k < 50; k++) if ((uint32_t)k < cnt) acc += lens6[(v[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+      gc[g] = acc;
+    }
+    __syncthreads();
+    t_cost += wall_clock64() - ta;
   };
   // Simulate_Entropy_Coding_Variants_and_Reclassify (:664-752).  The choice of a group depends on the groups before it
-  // only through the move-to-front order of the coders; every thread runs its stretch of groups from a guessed order,
-  // then again whenever the stretch before it hands over a different one (thread 0 is right at once).
+  // only through the move-to-front order of the coders.  Every thread runs its stretch of groups from a guessed order; a
+  // scan over the stretches' effects gives every stretch the order it really starts from; stretches that guessed wrong run
+  // again, until nothing moves (the choices rarely depend on the order, so this takes two or three turns).
   auto chain = [&](int ec, uint32_t &defectors, uint32_t &selbits) {
-    const uint32_t ident = 0x654321u;
-    uint32_t used = ident, outv = ident, def = 0, selc = 0;
+    const unsigned long long ta = wall_clock64();
+    const uint32_t ident = 0x654321u | (6u << 28);
+    uint32_t used = ident & 0x0FFFFFFFu, outv = 0, def = 0, selc = 0, chosen = 0;
     auto run = [&]() {
       uint32_t perm = used;
-      def = 0; selc = 0;
+      def = 0; selc = 0; chosen = 0;
       for (uint32_t g = g0; g < g1; g++) {
-        const uint4 cv = ((const uint4 *)gc)[g];
-        const uint64_t cp = (uint64_t)(cv.x & 0xFFFFu) | ((uint64_t)(cv.x >> 16) << 10) | ((uint64_t)(cv.y & 0xFFFFu) << 20) |
-                            ((uint64_t)(cv.y >> 16) << 30) | ((uint64_t)(cv.z & 0xFFFFu) << 40) | ((uint64_t)(cv.z >> 16) << 50);
+        const unsigned long long cp = gc[g];
         const uint32_t old = sel[g] & 7u;
         uint32_t bestc = 0xFFFFFFFFu, bestcl = old, bestpos = 1;
         for (int j = 0; j < ec; j++) {
@@ -778,30 +838,53 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
         }
         if (bestcl != old) def++;
         selc += bestpos;
-        const uint32_t lowm = (1u << (4 * (bestpos - 1))) - 1u, upto = bestpos >= 8 ? 0xFFFFFFFFu : (1u << (4 * bestpos)) - 1u;
+        chosen |= 1u << bestcl;
+        const uint32_t lowm = (1u << (4 * (bestpos - 1))) - 1u, upto = (1u << (4 * bestpos)) - 1u;
         perm = (perm & ~upto) | ((perm & lowm) << 4) | bestcl;
         sel[g] = (uint8_t)(old | (bestcl << 4));
       }
-      outv = perm;
+      const uint32_t k = __popc(chosen);
+      outv = (perm & ((1u << (4 * k)) - 1u)) | (k << 28);                              // the stretch's effect
     };
-    run();
-    st_out[tid] = outv;
+    bool need = true;
     for (;;) {
+      if (need) run();
+      n_pass++;
+      // exclusive scan of the effects over the threads, from the initial order
+      uint32_t incl = outv;
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl = mtf_compose(t, incl); }
+      if (lane == 63) wtot[w] = incl;
       __syncthreads();
-      const uint32_t in = tid ? st_out[tid - 1] : ident;
-      const int need = in != used;
-      if (!__syncthreads_or(need)) break;
-      if (need) { used = in; run(); }
-      st_out[tid] = outv;
+      uint32_t before = ident;
+      for (int k = 0; k < w; k++) before = mtf_compose(before, wtot[k]);
+      const uint32_t prev = __shfl_up(incl, 1);
+      if (lane) before = mtf_compose(before, prev);
+      const uint32_t in = before & 0x0FFFFFFFu;
+      need = in != used;
+      used = in;
+      if (!__syncthreads_or(need ? 1 : 0)) break;
     }
-    if (tid < 2) red[tid] = 0;
+    const unsigned long long tu = wall_clock64();
+    if (tid < 3) red[tid] = 0;
     __syncthreads();
     if (def) atomicAdd(&red[0], def);
     if (selc) atomicAdd(&red[1], selc);
-    for (uint32_t g = g0; g < g1; g++) sel[g] = sel[g] >> 4;
+    for (uint32_t g = g0; g < g1; g++) {                                                // the groups that change party: listed, ...
+      const uint32_t v = sel[g], old = v & 7u, nw = v >> 4;
+      if (nw != old) E.deflist[so + atomicAdd(&red[2], 1u)] = g | ((old - 1) << 16) | ((nw - 1) << 20);
+      sel[g] = (uint8_t)nw;
+    }
+    __syncthreads();
+    const uint32_t ndef = red[2];
+    for (uint32_t i = tid; i < ndef; i += EN_THREADS) {                                 // ... they take their counts along, all threads sharing the work
+      const uint32_t v = E.deflist[so + i];
+      count_group(v & 0xFFFFu, (v >> 16) & 15u, (v >> 20) & 15u);
+    }
     __syncthreads();
     defectors = red[0]; selbits = red[1];
     __syncthreads();
+    t_chain += wall_clock64() - ta;
+    n_constr += wall_clock64() - tu;
   };
   auto cluster_statistics = [&](int ec) -> bool {                                     // :756-779
     if (tid < 8) red[8 + tid] = 0;
@@ -826,20 +909,22 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
       }
       __syncthreads();
     }
+    histogram();
     uint32_t defectors = 0, selbits = 0;
     for (int it = 1; it <= 10; it++) {
+      n_round++;
       define_descriptors(ec, ml);
-      compute_costs(ec);
+      compute_costs();
       chain(ec, defectors, selbits);
       if (defectors == 0) break;
     }
-    if (defectors > 0) { define_descriptors(ec, ml); compute_costs(ec); }
+    if (defectors > 0) { define_descriptors(ec, ml); compute_costs(); }
     low = cluster_statistics(ec);
     // Compute_Total_Entropy_Cost: data, selectors (their move-to-front indices were summed by the last chain), code lengths
     if (tid < 2) red[tid] = 0;
     __syncthreads();
     uint32_t d = 0;
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) d += gc[g * 8 + (sel[g] - 1)];
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) d += (uint32_t)((gc[g] >> (10 * (sel[g] - 1))) & 1023u);
     for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
     if (lane == 0 && d) atomicAdd(&red[0], d);
     uint32_t tb = 0;
@@ -883,6 +968,8 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     uint32_t *r = E.res + (size_t)s * 8;
     r[0] = (uint32_t)best_ec; r[1] = (uint32_t)best_ml; r[2] = (uint32_t)(E.option == 2 ? 3 + best_w : 4); r[3] = ns;
     r[4] = k.data; r[5] = k.selb; r[6] = k.tree; r[7] = 0;
+    unsigned long long *d = E.dbg + (size_t)s * 8;
+    d[0] = t_hist; d[1] = t_llhc; d[2] = t_cost; d[3] = t_chain; d[4] = n_pass; d[5] = n_round; d[6] = n_constr; d[7] = wall_clock64() - t_begin;
   }
 }
 
@@ -968,7 +1055,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_emit_data(SubTab T, EntTab E,
   const uint32_t ec = r[0], ml = r[1], ns = r[3], A = E.nsym[s] + 2, m = E.mtf_n[s];
   const uint16_t *sym = E.sym + E.soff[s];
   const uint8_t *sel = E.sel + E.sel_off[s];
-  const uint16_t *gc = E.gcost + (size_t)E.sel_off[s] * 8;
+  const unsigned long long *gc = E.gcost + E.sel_off[s];
   for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) lens[i] = E.lens[(size_t)s * 6 * BZ_LSTRIDE + i];
   __syncthreads();
   if ((uint32_t)tid < ec) {                                           // Prepare_Codes (huffman-encoding.adb:45-80), bit order kept
@@ -983,7 +1070,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_emit_data(SubTab T, EntTab E,
   const uint32_t G = (ns + EN_THREADS - 1) / EN_THREADS;
   const uint32_t g0 = min((uint32_t)tid * G, ns), g1 = min(g0 + G, ns);
   uint32_t mine = 0;
-  for (uint32_t g = g0; g < g1; g++) mine += gc[g * 8 + (sel[g] - 1)];
+  for (uint32_t g = g0; g < g1; g++) mine += (uint32_t)((gc[g] >> (10 * (sel[g] - 1))) & 1023u);
   OpSum sm;
   const uint32_t incl = wg_scan_incl(mine, l17, sm, nullptr);
   const uint32_t head_bits = r[7] - r[4];
@@ -1174,7 +1261,7 @@ struct Bz2State {
   // MTF / symbol space
   DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
   // entropy coders and output
-  DBuf sel_off, rank_idx, gcost, sel, lens, res, woff, words, jobs, job_first, outw;
+  DBuf sel_off, rank_idx, gcost, sel, lens, res, woff, words, jobs, job_first, outw, dbg, deflist;
   // stream level
   DBuf rs1, epre, bstart, blen, etab, seg_off, seg, seg_cnt, extra;
   bool etab_ready = false;
@@ -1187,7 +1274,7 @@ struct Bz2State {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
-            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra};
+            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -1268,6 +1355,7 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
     hipLaunchKernelGGL(k_bz_crc_tiles, dim3((nrt + 63) / 64), dim3(64), 0, st, d_in, T, B->rtiles.as<Tile>(), nrt, B->rtile_crc.as<uint32_t>());
   }
   hipLaunchKernelGGL(k_bz_crc_fold, dim3((nsb + 63) / 64), dim3(64), 0, st, T, B->rtile_first.as<uint32_t>(), B->rtile_crc.as<uint32_t>());
+  c->tmark("bz:rle1");
   // element tiles
   std::vector<Tile> et; std::vector<uint32_t> efirst;
   build_tiles(B->h_n, BW_TILE, et, efirst);
@@ -1319,6 +1407,7 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
     if ((rc = classes(2 * h))) return rc;
   }
   hipLaunchKernelGGL(k_bz_bwt_out, dim3(net), dim3(1024), 0, st, B->rle.as<uint8_t>(), valA, cl, T, ET, B->bwt.as<uint8_t>());
+  c->tmark("bz:bwt");
   BZ_HIP(hipGetLastError());
   return 0;
 }
@@ -1335,7 +1424,7 @@ static int bz_mtf(Ctx *c) {
   int rc;
   if ((rc = dbuf_ensure(c, B->seq, 256ull * nsb)) || (rc = dbuf_ensure(c, B->nsym, 4ull * nsb)) || (rc = dbuf_ensure(c, B->rec, 256 * slots + 256)) ||
       (rc = dbuf_ensure(c, B->recbm, 32 * slots + 32)) || (rc = dbuf_ensure(c, B->reccnt, 4 * slots + 4)) || (rc = dbuf_ensure(c, B->lists, 256 * slots + 256)) ||
-      (rc = dbuf_ensure(c, B->sym, 2ull * ((uint64_t)tot + nsb + 16))) || (rc = dbuf_ensure(c, B->soff, 4ull * (nsb + 1))) ||
+      (rc = dbuf_ensure(c, B->sym, 2ull * ((uint64_t)tot + 2ull * nsb + 64))) || (rc = dbuf_ensure(c, B->soff, 4ull * (nsb + 1))) ||
       (rc = dbuf_ensure(c, B->mtf_n, 4ull * nsb))) return rc;
   SubTab T = subtab(B);
   const Tile *ET = B->etiles.as<Tile>();
@@ -1357,6 +1446,7 @@ static int bz_mtf(Ctx *c) {
   hipLaunchKernelGGL(k_bz_sym_layout, dim3((nsb + 255) / 256), dim3(256), 0, st, T, P, B->nsym.as<uint32_t>(), B->soff.as<uint32_t>(), B->mtf_n.as<uint32_t>(),
                      B->sym.as<uint16_t>());
   if (net) hipLaunchKernelGGL(k_bz_rle2_emit, dim3(net), dim3(1024), 0, st, idx, hr, P, T, ET, B->soff.as<uint32_t>(), B->sym.as<uint16_t>());
+  c->tmark("bz:mtf");
   BZ_HIP(hipGetLastError());
   return 0;
 }
@@ -1371,14 +1461,14 @@ static int bz_entropy_emit(Ctx *c, int option) {
   for (uint32_t s = 0; s <= nsb; s++) so[s] = B->h_off[s] / BZ_GROUP + 2 * s;
   const uint32_t selcap = so[nsb] + 8;
   B->selcap = selcap;
-  if ((rc = dbuf_ensure(c, B->sel_off, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->rank_idx, 4ull * selcap)) || (rc = dbuf_ensure(c, B->gcost, 16ull * selcap)) ||
+  if ((rc = dbuf_ensure(c, B->sel_off, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->rank_idx, 4ull * selcap)) || (rc = dbuf_ensure(c, B->gcost, 8ull * selcap)) ||
       (rc = dbuf_ensure(c, B->sel, selcap)) || (rc = dbuf_ensure(c, B->lens, 6ull * BZ_LSTRIDE * nsb)) || (rc = dbuf_ensure(c, B->res, 32ull * nsb)) ||
-      (rc = dbuf_ensure(c, B->woff, 4ull * (nsb + 1)))) return rc;
+      (rc = dbuf_ensure(c, B->woff, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->dbg, 64ull * nsb)) || (rc = dbuf_ensure(c, B->deflist, 4ull * selcap))) return rc;
   BZ_HIP(hipMemcpyAsync(B->sel_off.p, so.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
   EntTab E;
   E.sym = B->sym.as<uint16_t>(); E.soff = B->soff.as<uint32_t>(); E.mtf_n = B->mtf_n.as<uint32_t>(); E.nsym = B->nsym.as<uint32_t>();
-  E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<uint16_t>();
-  E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option;
+  E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<unsigned long long>();
+  E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option; E.dbg = B->dbg.as<unsigned long long>(); E.deflist = B->deflist.as<uint32_t>();
   SubTab T = subtab(B);
   const size_t rank_lds = 2 * (size_t)(BZ_MAX_SEL * 3 + 64);
   if (!B->rank_attr) {
@@ -1386,8 +1476,10 @@ static int bz_entropy_emit(Ctx *c, int option) {
     B->rank_attr = true;
   }
   hipLaunchKernelGGL(k_bz_rank, dim3(nsb), dim3(128), rank_lds, st, E, nsb);
+  c->tmark("bz:rank");
   hipLaunchKernelGGL(k_bz_entropy, dim3(nsb), dim3(EN_THREADS), 0, st, E, nsb);
   hipLaunchKernelGGL(k_bz_block_bits, dim3((nsb + 255) / 256), dim3(256), 0, st, T, B->res.as<uint32_t>());
+  c->tmark("bz:entropy");
   B->h_res.resize(8ull * nsb); B->h_crc.resize(nsb);
   BZ_HIP(hipMemcpyAsync(B->h_res.data(), B->res.p, 32ull * nsb, hipMemcpyDeviceToHost, st));
   BZ_HIP(hipMemcpyAsync(B->h_crc.data(), B->crc.p, 4ull * nsb, hipMemcpyDeviceToHost, st));
@@ -1402,6 +1494,7 @@ static int bz_entropy_emit(Ctx *c, int option) {
   BZ_HIP(hipMemsetAsync(B->words.p, 0, 4 * (w + 16), st));
   hipLaunchKernelGGL(k_bz_emit_head, dim3(nsb), dim3(64), 0, st, T, E, B->woff.as<uint32_t>(), B->words.as<uint32_t>());
   hipLaunchKernelGGL(k_bz_emit_data, dim3(nsb), dim3(EN_THREADS), 0, st, T, E, B->woff.as<uint32_t>(), B->words.as<uint32_t>());
+  c->tmark("bz:emit");
   BZ_HIP(hipGetLastError());
   return 0;
 }
@@ -1430,6 +1523,7 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
   uint32_t *d_count = B->scal.as<uint32_t>() + 8;
   hipLaunchKernelGGL(k_bz_acquire, dim3(1), dim3(64), 0, st, rs1, E, n, size_hint, block_capacity, f_lo, f_hi, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(),
                      cap_blocks, d_count);
+  c->tmark("bz:acquire");
   uint32_t nblk = 0;
   BZ_HIP(hipMemcpyAsync(&nblk, d_count, 4, hipMemcpyDeviceToHost, st));
   BZ_HIP(hipStreamSynchronize(st));
@@ -1457,6 +1551,7 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
     BZ_HIP(hipMemcpyAsync(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_bz_segment, dim3((nblk + 63) / 64), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
                        (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
+    c->tmark("bz:segment");
     seg.resize(so);
     BZ_HIP(hipMemcpyAsync(seg.data(), B->seg.p, 4 * so, hipMemcpyDeviceToHost, st));
     BZ_HIP(hipMemcpyAsync(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost, st));
@@ -1544,6 +1639,7 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
       BZ_HIP(hipMemcpyAsync(B->job_first.p, job_first.data(), 8 * job_first.size(), hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(k_bz_assemble, dim3((uint32_t)((dstw + 255) / 256)), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), (uint32_t)jobs.size(),
                          B->words.as<uint32_t>(), B->outw.as<uint32_t>());
+      c->tmark("bz:assemble");
       BZ_HIP(hipStreamSynchronize(st));     // the job vectors go out of scope; the next batch reuses the words
     }
     k0 = k1;
@@ -1621,11 +1717,12 @@ extern "C" int zada_bz2_fetch(zada_ctx *z, const char *name, void *dst, uint64_t
   else if (!strcmp(name, "bwt")) { src = B->bwt.p; len = B->ntot; }
   else if (!strcmp(name, "mtf_n")) { src = B->mtf_n.p; len = 4ull * nsb; }
   else if (!strcmp(name, "soff")) { src = B->soff.p; len = 4ull * nsb; }
-  else if (!strcmp(name, "sym")) { src = B->sym.p; len = 2ull * ((uint64_t)B->ntot + nsb); }
+  else if (!strcmp(name, "sym")) { src = B->sym.p; len = 2ull * ((uint64_t)B->ntot + 2ull * nsb + 2); }
   else if (!strcmp(name, "res")) { src = B->res.p; len = 32ull * nsb; }
   else if (!strcmp(name, "sel_off")) { src = B->sel_off.p; len = 4ull * (nsb + 1); }
   else if (!strcmp(name, "sel")) { src = B->sel.p; len = B->selcap; }
   else if (!strcmp(name, "lens")) { src = B->lens.p; len = 6ull * BZ_LSTRIDE * nsb; }
+  else if (!strcmp(name, "dbg")) { src = B->dbg.p; len = 64ull * nsb; }
   else if (!strcmp(name, "woff")) { src = B->woff.p; len = 4ull * (nsb + 1); }
   else if (!strcmp(name, "words")) { src = B->words.p; len = 4ull * B->nwords; }
   else if (!strcmp(name, "info")) { tmp[0] = B->ntot; tmp[1] = (uint32_t)B->bwt_rounds; tmp[2] = nsb; tmp[3] = 0; if (cap < 16) return ZADA_E_INVALID; memcpy(dst, tmp, 16); if (nbytes) *nbytes = 16; return 0; }
