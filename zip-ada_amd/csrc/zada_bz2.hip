@@ -1194,44 +1194,74 @@ __global__ void __launch_bounds__(64) k_bz_acquire(const uint32_t *__restrict__ 
 //  p = f / window, tabulated by the host with the C library's log, the function GNAT's Log maps to.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int SEG_WINDOW = 16000;
+__device__ __forceinline__ double lane_value(double x, int j) {      // x of lane j (j uniform)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), j), hi = __builtin_amdgcn_readlane(__double2hiint(x), j);
+  return __hiloint2double(hi, lo);
+}
+// One wave per block.  64 steps at a time: the lanes work out, together, the byte counts every step sees (the counts at the
+// start of the stretch plus the bytes that came and went in the steps before it: a broadcast loop over the lanes) and fetch
+// the four table values of their step; then the additions run in order, every lane following.
 __global__ void __launch_bounds__(64) k_bz_segment(const uint8_t *__restrict__ in, const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ blen,
                                                    uint32_t nblk, const double *__restrict__ etab, double thr1, double thr2,
                                                    const uint32_t *__restrict__ seg_off /*[2 nblk + 1]*/, uint32_t *__restrict__ seg, uint32_t *__restrict__ seg_cnt) {
-  __shared__ uint16_t freq[256 * 64];
+  __shared__ uint32_t freq[256];
   const int lane = threadIdx.x;
-  const uint32_t blk = blockIdx.x * 64 + lane;
-  if (blk >= nblk) return;
-  for (int b = 0; b < 256; b++) freq[b * 64 + lane] = 0;
+  const uint32_t blk = blockIdx.x;
+  for (int b = lane; b < 256; b += 64) freq[b] = 0;
   const uint8_t *buf = in + bstart[blk];
   const uint32_t len = blen[blk];
   uint32_t *s1 = seg + seg_off[2 * blk], *s2 = seg + seg_off[2 * blk + 1];
   uint32_t n1 = 0, n2 = 0;
+  wave_sync();
   if (len > SEG_WINDOW + 4000) {
     const bool t2 = len > SEG_WINDOW + 8000;
-    double entropy = 0.0, mark1 = 0.0, mark2 = 0.0;
+    for (uint32_t i = lane; i < SEG_WINDOW; i += 64) atomicAdd(&freq[buf[i]], 1u);       // steps 1 .. window: the window fills up
+    wave_sync();
+    double entropy = 0.0;
+    {
+      double v[4];
+      uint32_t fb[4];
+      for (int q = 0; q < 4; q++) { fb[q] = freq[q * 64 + lane]; v[q] = etab[fb[q]]; }
+      for (int q = 0; q < 4; q++)
+        for (int j = 0; j < 64; j++) {
+          const double x = lane_value(v[q], j);
+          if (__builtin_amdgcn_readlane((int)fb[q], j)) entropy = entropy + x;
+        }
+    }
+    double mark1 = entropy, mark2 = entropy;
     uint32_t im1 = 1, im2 = 1;
-    for (uint32_t i = 1; i <= len; i++) {
-      uint32_t bt = buf[i - 1];
-      const uint32_t f = ++freq[bt * 64 + lane];
-      if (i == SEG_WINDOW) {
-        for (int b = 0; b < 256; b++) { const uint32_t fb = freq[b * 64 + lane]; if (fb) entropy = entropy + etab[fb]; }
-        mark1 = entropy; mark2 = entropy;
-      } else if (i > SEG_WINDOW) {
-        entropy = entropy - etab[f - 1];
-        entropy = entropy + etab[f];
-        bt = buf[i - SEG_WINDOW - 1];
-        const uint32_t g = freq[bt * 64 + lane];
-        entropy = entropy - etab[g];
-        freq[bt * 64 + lane] = (uint16_t)(g - 1);
-        if (g - 1 > 0) entropy = entropy + etab[g - 1];
-        const uint32_t seg_point = i - SEG_WINDOW;
-        if (fabs(entropy - mark1) > thr1 && seg_point - im1 > 4000u && seg_point > im1) { s1[n1++] = seg_point; im1 = seg_point; mark1 = entropy; }
-        if (t2 && fabs(entropy - mark2) > thr2 && seg_point - im2 > 8000u && seg_point > im2) { s2[n2++] = seg_point; im2 = seg_point; mark2 = entropy; }
+    for (uint32_t i0 = SEG_WINDOW + 1; i0 <= len; i0 += 64) {
+      const uint32_t cnt = min(64u, len - i0 + 1), i = i0 + lane;
+      const bool valid = (uint32_t)lane < cnt;
+      const uint32_t xin = valid ? buf[i - 1] : 0u, xout = valid ? buf[i - SEG_WINDOW - 1] : 0u;
+      const uint32_t f0in = freq[xin], f0out = freq[xout];
+      wave_sync();
+      uint32_t ii = 0, oi = 0, io = 0, oo = 0;
+      for (int j = 0; j < (int)cnt; j++) {
+        const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)xin, j), bo = (uint32_t)__builtin_amdgcn_readlane((int)xout, j);
+        if (j < lane) { ii += bi == xin; oi += bo == xin; io += bi == xout; oo += bo == xout; }
+      }
+      if (valid) { atomicAdd(&freq[xin], 1u); atomicSub(&freq[xout], 1u); }
+      const uint32_t f = f0in + ii - oi + 1, g = f0out + io + (xin == xout ? 1u : 0u) - oo;
+      double A = 0.0, Bv = 0.0, C = 0.0, D = 0.0;
+      int hasD = 0;
+      if (valid) { A = etab[f - 1]; Bv = etab[f]; C = etab[g]; hasD = g - 1 > 0; if (hasD) D = etab[g - 1]; }
+      wave_sync();
+      for (int j = 0; j < (int)cnt; j++) {
+        entropy = entropy - lane_value(A, j);
+        entropy = entropy + lane_value(Bv, j);
+        entropy = entropy - lane_value(C, j);
+        if (__builtin_amdgcn_readlane(hasD, j)) entropy = entropy + lane_value(D, j);
+        const uint32_t seg_point = i0 + (uint32_t)j - SEG_WINDOW;
+        if (fabs(entropy - mark1) > thr1 && seg_point > im1 && seg_point - im1 > 4000u) { if (lane == 0) s1[n1] = seg_point; n1++; im1 = seg_point; mark1 = entropy; }
+        if (t2 && fabs(entropy - mark2) > thr2 && seg_point > im2 && seg_point - im2 > 8000u) { if (lane == 0) s2[n2] = seg_point; n2++; im2 = seg_point; mark2 = entropy; }
       }
     }
   }
-  if (len > 0) { s1[n1++] = len; s2[n2++] = len; }
-  seg_cnt[2 * blk] = n1; seg_cnt[2 * blk + 1] = n2;
+  if (lane == 0) {
+    if (len > 0) { s1[n1++] = len; s2[n2++] = len; }
+    seg_cnt[2 * blk] = n1; seg_cnt[2 * blk + 1] = n2;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1549,7 +1579,7 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
     seg_off[2ull * nblk] = (uint32_t)so;
     if ((rc = dbuf_ensure(c, B->seg_off, 4ull * (2ull * nblk + 1))) || (rc = dbuf_ensure(c, B->seg, 4 * so + 16)) || (rc = dbuf_ensure(c, B->seg_cnt, 8ull * nblk + 16))) return rc;
     BZ_HIP(hipMemcpyAsync(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_bz_segment, dim3((nblk + 63) / 64), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
+    hipLaunchKernelGGL(k_bz_segment, dim3(nblk), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
                        (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
     c->tmark("bz:segment");
     seg.resize(so);
