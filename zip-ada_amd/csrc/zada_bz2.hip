@@ -126,6 +126,7 @@ static void scan_launch(hipStream_t st, F f, uint64_t n, uint32_t *agg, uint32_t
 }
 
 struct FArr { const uint32_t *a; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return a[i]; } };
+struct FArrPad { const uint32_t *a; uint64_t n; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return i < n ? a[i] : 0u; } };
 
 // ---------------------------------------------------------------------------------------------------------------
 //  sub-block tables (device, structure of arrays)
@@ -392,70 +393,105 @@ __global__ void __launch_bounds__(1024) k_bz_heads0(const uint32_t *__restrict__
     hv[g] = (l == 0 || key[g] != key[g - 1]) ? g + 1 : 0u;
   }
 }
-// rows shifted back by h (cyclically inside the sub-block), keyed by the local class of the shifted element
-__global__ void __launch_bounds__(1024) k_bz_shift(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T,
-                                                   const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t h,
-                                                   uint32_t *__restrict__ key_out, uint32_t *__restrict__ val_out) {
-  const Tile t = tiles[blockIdx.x];
-  if (done[t.sb]) return;
-  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t g = off + t.lo + i;
-    uint32_t l = sa[g] - off;
-    l = l >= h ? l - h : l + n - h;          // h < n for a sub-block that is not done
-    val_out[g] = off + l;
-    key_out[g] = cl[off + l] - off;
-  }
-}
-// second halves: sec[i] = class of the element h behind row i's
-__global__ void __launch_bounds__(1024) k_bz_second(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T,
-                                                    const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ sec) {
-  const Tile t = tiles[blockIdx.x];
-  if (done[t.sb]) return;
-  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t g = off + t.lo + i;
-    uint32_t l = sa[g] - off + h;
-    if (l >= n) l -= n;
-    sec[g] = cl[off + l];
-  }
-}
-__global__ void __launch_bounds__(1024) k_bz_headsH(const uint32_t *__restrict__ key, const uint32_t *__restrict__ sec, SubTab T,
-                                                    const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t *__restrict__ hv) {
-  const Tile t = tiles[blockIdx.x];
-  if (done[t.sb]) return;
-  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, g = off + l;
-    hv[g] = (l == 0 || key[g] != key[g - 1] || sec[g] != sec[g - 1]) ? g + 1 : 0u;
-  }
-}
-// classes from the scanned head values; counts the rows of groups that still have more than one member
+// classes from the scanned head values of the first sort; the elements of groups of more than one row are marked (acte)
 __global__ void __launch_bounds__(1024) k_bz_set_class(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ hv, const uint32_t *__restrict__ hr,
-                                                       SubTab T, const Tile *__restrict__ tiles, const uint8_t *__restrict__ done,
-                                                       uint32_t *__restrict__ cl, uint32_t *__restrict__ unsorted /*[nsb]*/) {
+                                                       SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte) {
   const Tile t = tiles[blockIdx.x];
-  if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  uint32_t cnt = 0;
   for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, g = off + l;
-    cl[sa[g]] = hr[g] - 1;
+    const uint32_t l = t.lo + i, g = off + l, e = sa[g];
+    cl[e] = hr[g] - 1;
     const bool single = hv[g] != 0 && (l + 1 == n || hv[g + 1] != 0);
-    cnt += single ? 0u : 1u;
+    if (!single) atomicOr(&acte[e >> 5], 1u << (e & 31));
   }
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&unsorted[t.sb], cnt);
 }
-// after a round that has ordered the rows by `prefix` bytes: a sub-block is done when every group is a single row or the
-// prefix covers the whole rotation.  *active = number of sub-blocks that go on.
-__global__ void k_bz_round_end(SubTab T, uint32_t prefix, uint32_t *__restrict__ unsorted, uint8_t *__restrict__ done, uint32_t *__restrict__ active) {
+// A doubling round only moves the rows of groups that still have more than one row.  The rows, read in order and shifted
+// back by h, are in the order of their second halves; those whose shifted element is still unsorted are filtered out (in
+// that order), sorted by the first row of that element's group (stable: three passes over the filtered rows only), and
+// written back to the group's rows.
+__global__ void __launch_bounds__(1024) k_bz_filter(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, SubTab T, const Tile *__restrict__ tiles,
+                                                    const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ flag, uint32_t *__restrict__ stash) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  const bool dn = done[t.sb];
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t g = off + t.lo + i;
+    uint32_t f = 0;
+    if (!dn) {
+      uint32_t l = sa[g] - off;
+      l = l >= h ? l - h : l + n - h;               // h < n for a sub-block that is not done
+      const uint32_t e = off + l;
+      f = (acte[e >> 5] >> (e & 31)) & 1u;
+      stash[g] = e;
+    }
+    flag[g] = f;
+  }
+}
+__global__ void k_bz_counts(SubTab T, const uint32_t *__restrict__ P, uint32_t *__restrict__ coff, uint32_t *__restrict__ cm) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= T.nsb) return;
-  if (!done[s]) {
-    if (unsorted[s] == 0 || prefix >= T.n[s]) done[s] = 1; else atomicAdd(active, 1u);
-    unsorted[s] = 0;
+  const uint32_t a = P[T.off[s]], b = P[T.off[s] + T.n[s]];
+  coff[s] = a; cm[s] = b - a;
+  if (s + 1 == T.nsb) coff[s + 1] = b;
+}
+__global__ void __launch_bounds__(1024) k_bz_compact(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ P, const uint32_t *__restrict__ stash,
+                                                     const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles, const uint8_t *__restrict__ done,
+                                                     uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval) {
+  const Tile t = tiles[blockIdx.x];
+  if (done[t.sb]) return;
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t g = off + t.lo + i;
+    if (flag[g]) { const uint32_t j = P[g], e = stash[g]; ckey[j] = cl[e] - off; cval[j] = e; }
   }
+}
+// C = the filtered rows' space (sub-block s owns [coff[s], coff[s] + cm[s])), its tiles in `tiles`
+__global__ void __launch_bounds__(1024) k_bz_runfirst(const uint32_t *__restrict__ ckey, SubTab C, const Tile *__restrict__ tiles, uint32_t *__restrict__ rf) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t n = C.n[t.sb], off = C.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, j = off + l;
+    rf[j] = (l == 0 || ckey[j] != ckey[j - 1]) ? j + 1 : 0u;
+  }
+}
+__global__ void __launch_bounds__(1024) k_bz_place(const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cval, const uint32_t *__restrict__ rfs, SubTab T, SubTab C,
+                                                   const Tile *__restrict__ tiles, const uint32_t *__restrict__ cl, uint32_t h, uint32_t *__restrict__ sa,
+                                                   uint32_t *__restrict__ sec, uint32_t *__restrict__ rowbuf) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo), n = T.n[t.sb], off = T.off[t.sb];
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t j = coff + t.lo + i, e = cval[j];
+    const uint32_t row = off + ckey[j] + (j - (rfs[j] - 1));
+    sa[row] = e;
+    rowbuf[j] = row;
+    uint32_t l = e - off + h;
+    if (l >= n) l -= n;
+    sec[j] = cl[off + l];
+  }
+}
+__global__ void __launch_bounds__(1024) k_bz_heads(const uint32_t *__restrict__ rf, const uint32_t *__restrict__ sec, const uint32_t *__restrict__ rowbuf, SubTab C,
+                                                   const Tile *__restrict__ tiles, uint32_t *__restrict__ hd) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t j = coff + t.lo + i;
+    hd[j] = (rf[j] != 0 || sec[j] != sec[j - 1]) ? rowbuf[j] + 1 : 0u;
+  }
+}
+__global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict__ cval, const uint32_t *__restrict__ hd, const uint32_t *__restrict__ hds, SubTab C,
+                                                      const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte) {
+  const Tile t = tiles[blockIdx.x];
+  const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, j = coff + l, e = cval[j];
+    cl[e] = hds[j] - 1;
+    if (hd[j] != 0 && (l + 1 == cn || hd[j + 1] != 0)) atomicAnd(&acte[e >> 5], ~(1u << (e & 31)));
+  }
+}
+// rows ordered by `prefix` bytes: a sub-block whose rotations are that short is done (equal rotations stay in one group)
+__global__ void k_bz_done(SubTab T, uint32_t prefix, uint8_t *__restrict__ done) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < T.nsb && prefix >= T.n[s]) done[s] = 1;
 }
 // last column (:266-276): the byte in front of each row's rotation; the original message is the first row of its group
 __global__ void __launch_bounds__(1024) k_bz_bwt_out(const uint8_t *__restrict__ rle, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T,
@@ -1287,7 +1323,9 @@ struct Bz2State {
   // tiles
   DBuf rtiles, rtile_first, rtile_val, rtile_crc, etiles, etile_first;
   // element space
-  DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg;
+  DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
+  std::vector<uint32_t> h_cm, h_cfirst;
+  std::vector<Tile> h_ct;
   // MTF / symbol space
   DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
   // entropy coders and output
@@ -1302,7 +1340,7 @@ struct Bz2State {
   bool rank_attr = false;
   std::vector<DBuf *> all() {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
-            &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
+            &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
             &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist};
   }
@@ -1396,7 +1434,9 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   BZ_HIP(hipMemcpyAsync(B->etile_first.p, efirst.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
   if ((rc = dbuf_ensure(c, B->keyA, 4 * ne)) || (rc = dbuf_ensure(c, B->keyB, 4 * ne)) || (rc = dbuf_ensure(c, B->valA, 4 * ne)) ||
       (rc = dbuf_ensure(c, B->valB, 4 * ne)) || (rc = dbuf_ensure(c, B->cl, 4 * ne)) || (rc = dbuf_ensure(c, B->hv, 4 * ne)) ||
-      (rc = dbuf_ensure(c, B->hr, 4 * ne)) || (rc = dbuf_ensure(c, B->H, 1024ull * net + 1024)) ||
+      (rc = dbuf_ensure(c, B->hr, 4 * ne)) || (rc = dbuf_ensure(c, B->H, 1024ull * (net + nsb) + 1024)) || (rc = dbuf_ensure(c, B->cv0, 4 * ne)) ||
+      (rc = dbuf_ensure(c, B->cv1, 4 * ne)) || (rc = dbuf_ensure(c, B->acte, 4 * (ne / 32 + 4))) || (rc = dbuf_ensure(c, B->coff, 4ull * (nsb + 2))) ||
+      (rc = dbuf_ensure(c, B->cm, 4ull * (nsb + 2))) || (rc = dbuf_ensure(c, B->ctile_first, 4ull * (nsb + 2))) ||
       (rc = dbuf_ensure(c, B->agg, 4ull * ((1024ull * net / 4 + ne) / SC_TILE + 16)))) return rc;
   BZ_HIP(hipStreamSynchronize(st));   // rt / et vectors go out of scope
   B->bwt_rounds = 0;
@@ -1405,36 +1445,54 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   const uint32_t *EF = B->etile_first.as<uint32_t>();
   uint8_t *done = B->done.as<uint8_t>();
   uint32_t *keyA = B->keyA.as<uint32_t>(), *keyB = B->keyB.as<uint32_t>(), *valA = B->valA.as<uint32_t>(), *valB = B->valB.as<uint32_t>();
+  uint32_t *cv0 = B->cv0.as<uint32_t>(), *cv1 = B->cv1.as<uint32_t>(), *acte = B->acte.as<uint32_t>();
   uint32_t *H = B->H.as<uint32_t>(), *agg = B->agg.as<uint32_t>(), *hv = B->hv.as<uint32_t>(), *hr = B->hr.as<uint32_t>(), *cl = B->cl.as<uint32_t>();
-  uint32_t *active = B->scal.as<uint32_t>();
-  auto radix = [&](const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int shift) {
-    hipLaunchKernelGGL(k_bz_radix_hist, dim3(net), dim3(1024), 0, st, ki, T, ET, EF, done, shift, H);
-    scan_launch<OpSum, false>(st, FArr{H}, 256ull * net, agg, H, nullptr);
-    hipLaunchKernelGGL(k_bz_radix_scatter, dim3(net), dim3(1024), 0, st, ki, vi, T, ET, EF, done, shift, H, ko, vo);
+  auto radix = [&](const SubTab &S, const Tile *tl, const uint32_t *tf, uint32_t nt, const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int shift) {
+    hipLaunchKernelGGL(k_bz_radix_hist, dim3(nt), dim3(1024), 0, st, ki, S, tl, tf, done, shift, H);
+    scan_launch<OpSum, false>(st, FArr{H}, 256ull * nt, agg, H, nullptr);
+    hipLaunchKernelGGL(k_bz_radix_scatter, dim3(nt), dim3(1024), 0, st, ki, vi, S, tl, tf, done, shift, H, ko, vo);
   };
-  auto classes = [&](uint32_t prefix) -> int {
-    scan_launch<OpMax, true>(st, FArr{hv}, tot, agg, hr, nullptr);
-    hipLaunchKernelGGL(k_bz_set_class, dim3(net), dim3(1024), 0, st, valA, hv, hr, T, ET, done, cl, B->unsorted.as<uint32_t>());
-    BZ_HIP(hipMemsetAsync(active, 0, 4, st));
-    hipLaunchKernelGGL(k_bz_round_end, dim3((nsb + 255) / 256), dim3(256), 0, st, T, prefix, B->unsorted.as<uint32_t>(), done, active);
-    return 0;
-  };
+  // first sort: four bytes
+  BZ_HIP(hipMemsetAsync(acte, 0, 4 * ((size_t)tot / 32 + 2), st));
   hipLaunchKernelGGL(k_bz_bwt_init, dim3(net), dim3(1024), 0, st, B->rle.as<uint8_t>(), T, ET, keyA, valA);
-  radix(keyA, valA, keyB, valB, 0); radix(keyB, valB, keyA, valA, 8); radix(keyA, valA, keyB, valB, 16); radix(keyB, valB, keyA, valA, 24);
+  radix(T, ET, EF, net, keyA, valA, keyB, valB, 0); radix(T, ET, EF, net, keyB, valB, keyA, valA, 8);
+  radix(T, ET, EF, net, keyA, valA, keyB, valB, 16); radix(T, ET, EF, net, keyB, valB, keyA, valA, 24);
   hipLaunchKernelGGL(k_bz_heads0, dim3(net), dim3(1024), 0, st, keyA, T, ET, done, hv);
-  if ((rc = classes(4))) return rc;
+  scan_launch<OpMax, true>(st, FArr{hv}, tot, agg, hr, nullptr);
+  hipLaunchKernelGGL(k_bz_set_class, dim3(net), dim3(1024), 0, st, valA, hv, hr, T, ET, cl, acte);
+  hipLaunchKernelGGL(k_bz_done, dim3((nsb + 255) / 256), dim3(256), 0, st, T, 4u, done);
+  SubTab C = T;
+  C.off = B->coff.as<uint32_t>(); C.n = B->cm.as<uint32_t>();
+  std::vector<uint32_t> &h_cm = B->h_cm;
+  std::vector<Tile> &ct = B->h_ct; std::vector<uint32_t> &cfirst = B->h_cfirst;
   for (uint32_t h = 4;; h *= 2) {
-    uint32_t h_active = 0;
-    BZ_HIP(hipMemcpyAsync(&h_active, active, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_bz_filter, dim3(net), dim3(1024), 0, st, valA, acte, T, ET, done, h, hv, valB);
+    scan_launch<OpSum, false>(st, FArrPad{hv, tot}, (uint64_t)tot + 1, agg, hr, nullptr);
+    hipLaunchKernelGGL(k_bz_counts, dim3((nsb + 255) / 256), dim3(256), 0, st, T, hr, C.off, C.n);
+    h_cm.resize(nsb);
+    BZ_HIP(hipMemcpyAsync(h_cm.data(), C.n, 4ull * nsb, hipMemcpyDeviceToHost, st));
     BZ_HIP(hipStreamSynchronize(st));
-    if (h_active == 0) break;
+    build_tiles(h_cm, BW_TILE, ct, cfirst);
+    const uint32_t nct = (uint32_t)ct.size();
+    if (nct == 0) break;
     B->bwt_rounds++;
-    hipLaunchKernelGGL(k_bz_shift, dim3(net), dim3(1024), 0, st, valA, cl, T, ET, done, h, keyB, valB);
-    radix(keyB, valB, keyA, valA, 0); radix(keyA, valA, keyB, valB, 8);
-    radix(keyB, valB, keyA, valA, 16);     // local classes are below 2^20 (block capacity 900 000)
-    hipLaunchKernelGGL(k_bz_second, dim3(net), dim3(1024), 0, st, valA, cl, T, ET, done, h, hr);
-    hipLaunchKernelGGL(k_bz_headsH, dim3(net), dim3(1024), 0, st, keyA, hr, T, ET, done, hv);
-    if ((rc = classes(2 * h))) return rc;
+    if ((rc = dbuf_ensure(c, B->ctiles, sizeof(Tile) * (size_t)nct))) return rc;
+    BZ_HIP(hipMemcpyAsync(B->ctiles.p, ct.data(), sizeof(Tile) * (size_t)nct, hipMemcpyHostToDevice, st));
+    BZ_HIP(hipMemcpyAsync(B->ctile_first.p, cfirst.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
+    const Tile *CT = B->ctiles.as<Tile>();
+    const uint32_t *CF = B->ctile_first.as<uint32_t>();
+    uint64_t M = 0;
+    for (uint32_t s2 = 0; s2 < nsb; s2++) M += h_cm[s2];
+    hipLaunchKernelGGL(k_bz_compact, dim3(net), dim3(1024), 0, st, hv, hr, valB, cl, T, ET, done, keyA, cv0);
+    radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 0); radix(C, CT, CF, nct, keyB, cv1, keyA, cv0, 8);
+    radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 16);        // first rows are below 2^20 (block capacity 900 000)
+    hipLaunchKernelGGL(k_bz_runfirst, dim3(nct), dim3(1024), 0, st, keyB, C, CT, hv);
+    scan_launch<OpMax, true>(st, FArr{hv}, M, agg, hr, nullptr);
+    hipLaunchKernelGGL(k_bz_place, dim3(nct), dim3(1024), 0, st, keyB, cv1, hr, T, C, CT, cl, h, valA, valB, cv0);
+    hipLaunchKernelGGL(k_bz_heads, dim3(nct), dim3(1024), 0, st, hv, valB, cv0, C, CT, keyA);
+    scan_launch<OpMax, true>(st, FArr{keyA}, M, agg, hr, nullptr);
+    hipLaunchKernelGGL(k_bz_newclass, dim3(nct), dim3(1024), 0, st, cv1, keyA, hr, C, CT, cl, acte);
+    hipLaunchKernelGGL(k_bz_done, dim3((nsb + 255) / 256), dim3(256), 0, st, T, 2 * h, done);
   }
   hipLaunchKernelGGL(k_bz_bwt_out, dim3(net), dim3(1024), 0, st, B->rle.as<uint8_t>(), valA, cl, T, ET, B->bwt.as<uint8_t>());
   c->tmark("bz:bwt");
@@ -1442,8 +1500,6 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   return 0;
 }
 
-struct FZero { __device__ __forceinline__ uint32_t operator()(uint64_t) const { return 0; } };
-struct FArrPad { const uint32_t *a; uint64_t n; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return i < n ? a[i] : 0u; } };
 
 // MTF + RLE_2 of the batch that bz_transform has left in the state: symbols (u16) in B->sym, tables soff / mtf_n / nsym / seq
 static int bz_mtf(Ctx *c) {
