@@ -3,7 +3,7 @@ import ctypes
 
 import numpy as np
 
-from _common import oracle, product
+from _common import oracle, product, edge_inputs
 
 
 class BlockInfo(ctypes.Structure):
@@ -13,6 +13,31 @@ class BlockInfo(ctypes.Structure):
 
 
 BZ_TRACE = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int)
+
+
+def bz_inputs():
+    """The parity matrix of the BZip2 half: the Deflate edge set plus inputs on which the reference keeps each of its
+    splitting tactics (bzip2-encoding.adb:1214-1345): parts_4 wins on `copies_1500k` (edge set), segmented_1 on
+    `seg1_az_digits`, segmented_2 on `seg2_alphabets` (the oracle's trace says so; test_bzip2_oracle.py asserts it)."""
+    cases = dict(edge_inputs())
+    rng = np.random.default_rng(11)
+    text = cases["text_rand_text"][:300000]
+
+    def letters(r, n, k, base=97):
+        return r.integers(base, base + k, n, dtype=np.uint8)
+    cases["seg1_az_digits"] = bytes(np.concatenate([letters(rng, 150000, 26), rng.integers(48, 58, 150000, dtype=np.uint8), letters(rng, 100000, 4)]))
+    rng = np.random.default_rng(12)
+    v = None
+    for _trial in range(3):
+        parts = []
+        for _j in range(rng.integers(3, 7)):
+            k = int(rng.choice([2, 3, 4, 6, 8, 12, 16, 24, 26]))
+            n = int(rng.integers(30000, 120000))
+            parts.append(letters(rng, n, k, int(rng.choice([48, 65, 97]))))
+        v = bytes(np.concatenate(parts))
+    cases["seg2_alphabets"] = v
+    del text
+    return cases
 
 
 def bz_oracle():

@@ -10,6 +10,8 @@
   deflate_digests.json  SHA-256 + size of the oracle's stream for every (input, method) of the
                       parity matrix ("self-pinned": detects any later drift of the oracle and gives
                       the GPU tests a second, oracle-free comparison)
+  bzip2_digests.json  the same for the BZip2 half (methods 12 .. 14), with the block / tactic trace; every stream was
+                      decompressed with libbz2 when the file was made
   zlib_tokens_*.npz   position-indexed LZ77 tokens made by libz 1.2.11 deflateTune for the
                       fixture files (the independent pin of the LZ77 stage)
 """
@@ -82,9 +84,33 @@ def digests():
     json.dump(out, open(os.path.join(HERE, "deflate_digests.json"), "w"), indent=0, sort_keys=True)
 
 
+def bzip2_digests():
+    """bzip2_digests.json: SHA-256 + size of the oracle's BZip2 stream per (input, method 12..14), the block trace (raw start,
+    raw length, tactic, sub-blocks) and whether libbz2 gives the input back ("self-pinned" + round trip)."""
+    import bz2
+    from _bzip2 import oracle_encode, bz_inputs
+    cases = bz_inputs()
+    for f in ("sample.xls", "sample.jpg", "sample_pgm_100k.bin"):
+        cases[f] = open(os.path.join(HERE, f), "rb").read()
+    out = {}
+    for name, d in sorted(cases.items()):
+        for m in (12, 13, 14):
+            if m != 14 and len(d) > 400000:
+                continue
+            z, ev = oracle_encode(d, m - 12)
+            if len(d):
+                assert bz2.decompress(z) == d, (name, m)
+            out["%s|%d" % (name, m)] = dict(size=len(z), sha256=hashlib.sha256(z).hexdigest(), in_sha256=hashlib.sha256(d).hexdigest(), blocks=ev)
+    json.dump(out, open(os.path.join(HERE, "bzip2_digests.json"), "w"), indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "bzip2":
+        bzip2_digests()
+        sys.exit(0)
     llhc_vectors()
     data_files()
     zlib_tokens()
     digests()
+    bzip2_digests()
     print("golden fixtures written to", HERE)

@@ -1,0 +1,105 @@
+"""GPU parity tests of the BZip2 path (zada_bzip2*): the product, through the C ABI, against the
+oracle's restatement of bzip2-encoding.adb and against the committed digests."""
+import bz2
+import hashlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from _common import GOLDEN, product
+from _bzip2 import bz_inputs, oracle_block, oracle_encode, product_stages
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub_blocks(n):
+    starts, lens = [0], [n]
+    if n >= 8:
+        q = n // 4
+        starts += [0, q, 2 * q, 3 * q, n // 3]
+        lens += [q, q, q, n - 3 * q, n - n // 3]
+    return starts, lens
+
+
+def test_every_stage_of_encode_block_bit_exact(encoder):
+    """RLE_1, block CRC, BWT + index, MTF / RLE_2 symbols, coders / selectors / code lengths and the block's bits."""
+    cases = {k: v for k, v in bz_inputs().items() if 0 < len(v) <= 450000}
+    cases["zeros_3m"] = bytes(3_000_000)
+    cases["ab_period"] = b"ab" * 300000
+    for name, data in cases.items():
+        starts, lens = _sub_blocks(len(data))
+        P1 = product_stages(encoder, data, starts, lens, stages=1)
+        P = product_stages(encoder, data, starts, lens, stages=3)
+        for i, (s, l) in enumerate(zip(starts, lens)):
+            o = oracle_block(data[s:s + l], want_bits=True)
+            oi = o["info"]
+            assert int(P["rle_n"][i]) == oi.rle_n and np.array_equal(P1["rle"][i], o["rle"]), (name, i, "RLE_1")
+            assert int(P["crc"][i]) == oi.block_crc, (name, i, "CRC")
+            assert np.array_equal(P["bwt"][i], o["bwt"]) and int(P["bwt_index"][i]) == oi.bwt_index, (name, i, "BWT")
+            assert int(P["mtf_n"][i]) == oi.mtf_n and np.array_equal(P["mtf"][i], o["mtf"]), (name, i, "MTF / RLE_2")
+            assert (int(P["res"][i, 0]), int(P["res"][i, 1]), int(P["res"][i, 2])) == (oi.coders, oi.max_code_len, oi.sample_width), (name, i, "coders")
+            assert np.array_equal(P["selectors"][i], o["selectors"]) and np.array_equal(P["lens"][i], o["lens"]), (name, i, "selectors / lengths")
+            assert int(P["res"][i, 7]) == oi.bits and np.array_equal(P["bits"][i], o["bits"]), (name, i, "bits")
+
+
+@pytest.mark.parametrize("method", [12, 13, 14])
+def test_streams_bit_exact_vs_oracle_and_digests(encoder, method):
+    dig = json.load(open(os.path.join(GOLDEN, "bzip2_digests.json")))
+    tactics = set()
+    for name, data in bz_inputs().items():
+        if method != 14 and len(data) > 400000:
+            continue
+        o, ev = oracle_encode(data, method - 12)
+        rc, p, crc = encoder.bzip2(data, method, cap=len(data) * 2 + 100000)
+        assert p == o, (name, method)
+        assert encoder.bz2_last_blocks() == ev, (name, method)
+        assert rc == (1 if len(o) >= len(data) else 0) and (crc ^ 0xFFFFFFFF) == zlib.crc32(data), (name, method)
+        want = dig["%s|%d" % (name, method)]
+        assert len(p) == want["size"] and hashlib.sha256(p).hexdigest() == want["sha256"], (name, method)
+        if len(data):
+            assert bz2.decompress(p) == data
+        tactics |= {e[2] for e in ev}
+    if method == 14:
+        assert tactics == {0, 1, 2, 3}
+
+
+def test_many_blocks_and_batches(encoder):
+    """A stream of a few dozen blocks; the same stream when the blocks go through the stages a few at a time."""
+    Z = product()
+    data = Z.silesia_mix(24 << 20).tobytes()
+    o, ev = oracle_encode(data, 2)
+    rc, p, crc = encoder.bzip2(data, 14)
+    assert rc == 0 and p == o and encoder.bz2_last_blocks() == ev and (crc ^ 0xFFFFFFFF) == zlib.crc32(data)
+    encoder.set_knob("bz_batch_melems", 3)
+    try:
+        rc, p2, _ = encoder.bzip2(data, 14)
+    finally:
+        encoder.set_knob("bz_batch_melems", 192)
+    assert rc == 0 and p2 == o
+
+
+def test_device_entry_feedback_abort_and_inefficient(encoder):
+    import torch
+    Z = product()
+    data = Z.silesia_mix(3 << 20)
+    d_in = torch.from_numpy(data).cuda()
+    d_out = torch.zeros(data.size + 4096, dtype=torch.uint8, device="cuda")
+    rc, n, crc = encoder.bzip2_device(d_in.data_ptr(), data.size, d_out.data_ptr(), data.size + 4096, 14)
+    o, _ = oracle_encode(data.tobytes(), 2)
+    assert rc == 0 and bytes(d_out[:n].cpu().numpy()) == o and (crc ^ 0xFFFFFFFF) == zlib.crc32(data.tobytes())
+    seen = []
+    rc, p, _ = encoder.bzip2(data.tobytes(), 14, feedback=lambda pct: seen.append(pct) and False)
+    assert rc == 0 and p == o and seen[0] == 0 and seen[-1] == 100 and seen == sorted(seen)
+    with pytest.raises(Z.UserAbort):
+        encoder.bzip2(data.tobytes(), 14, feedback=lambda pct: pct >= 6)
+    rc, p, _ = encoder.bzip2(data.tobytes(), 14)                   # the context is usable after an abort
+    assert rc == 0 and p == o
+    rnd = os.urandom(200000)
+    o2, _ = oracle_encode(rnd, 2)
+    rc, p, _ = encoder.bzip2(rnd, 14)
+    assert rc == 1 and p == o2                                      # compression_ok = False; the stream is still delivered when it fits
+    rc, p, _ = encoder.bzip2(rnd, 14, cap=len(rnd))                 # ... and only announced when it does not
+    assert rc == 1 and p is None
