@@ -157,6 +157,54 @@ def inflate_check(stream, n, crc_expected):
     return total == n and crc == crc_expected
 
 
+def bzip2_leg(za, enc, mib, with_cpu, with_checks):
+    """Secondary measurement (BASELINE config 5's method): BZip2_3 of `mib` MiB of the same synthetic
+    stream, input and output resident in HBM; the oracle on a 2 MiB sample beside it; the stream through libbz2."""
+    import bz2
+    import numpy as np
+    import torch
+    n = mib << 20
+    host = za.silesia_mix(n, seed=SEED)
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.zeros(n + 4096, dtype=torch.uint8, device="cuda")
+    enc.bzip2_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 14)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc, ol, crc = enc.bzip2_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 14)
+    dt = time.perf_counter() - t0
+    tim = {}
+    for k, v in enc.last_timing():
+        if not k.startswith("#") and k != "bz:end":
+            tim[k] = round(tim.get(k, 0.0) + v, 1)
+    blocks = enc.bz2_last_blocks()
+    out = {"metric": "BZip2_3 encode MB/s (stream bit-exact with the CPU restatement of the reference, Ada parity unpinned)", "value": round(n / dt / 1e6, 2),
+           "unit": "MB/s", "workload": "%d MiB silesia_mix_v1, one stream, input and output resident in HBM" % mib, "ms": round(dt * 1e3, 1), "rc": rc,
+           "compression_ratio": round(ol / n, 4), "blocks": len(blocks), "tactics_kept": [sum(1 for b in blocks if b[2] == t) for t in range(4)], "phase_ms": tim}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _bzip2 import oracle_encode
+        sample = host[:2 << 20].tobytes()
+        t1 = time.perf_counter()
+        ref, _ = oracle_encode(sample, 2)
+        dtc = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(len(sample) / dtc / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+                               "sample": "first 2 MiB of the workload, oracle/zada_oracle_bz2.c (its BWT is a prefix-doubling sort: faster than the reference's comparison sort)"}
+        if with_checks:
+            _, g, _ = enc.bzip2(sample, 14)
+            out["sample_stream_equals_cpu_port"] = bool(g == ref)
+    if with_checks and rc == 0:
+        stream = bytes(d_out[:ol].cpu().numpy())
+        dec = bz2.BZ2Decompressor()
+        c, tot, off = 0, 0, 0
+        while off < len(stream):
+            ch = dec.decompress(stream[off:off + (1 << 22)])
+            off += 1 << 22
+            c = zlib.crc32(ch, c)
+            tot += len(ch)
+        out["stream_decompresses_to_input_crc"] = bool(tot == n and dec.eof and c == zlib.crc32(host) and (crc ^ 0xFFFFFFFF) == c)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +215,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-checks", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--bzip2-mib", type=int, default=256, help="input MiB of the secondary BZip2_3 measurement at one GPU (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -356,6 +405,8 @@ def main():
                 g, _ = enc.deflate(head, za.Method.Deflate_3)
                 checks["sample_stream_equals_cpu_port"] = bool(g == ref)
             res["checks"] = checks
+        if world == 1 and args.bzip2_mib > 0:
+            res["bzip2"] = bzip2_leg(za, enc, args.bzip2_mib, not args.no_cpu_baseline, not args.no_checks)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -87,6 +87,7 @@ def oracle_block(raw, option=2, want_bits=False):
 
 
 def _fetch(L, enc, name, dtype, cap_items):
+    L.zada_bz2_fetch.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     buf = np.zeros(max(int(cap_items), 4), dtype)
     n = ctypes.c_uint64()
     rc = L.zada_bz2_fetch(enc.ctx, name.encode(), buf.ctypes.data, buf.nbytes, ctypes.byref(n))

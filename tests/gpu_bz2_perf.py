@@ -26,3 +26,12 @@ for mib in [int(x) for x in os.environ.get("BZ_MIBS", "64,256").split(",")]:
     for b in blocks: tac[b[2]] += 1
     print("%d MiB: rc %d, %.1f ms, %.1f MB/s, ratio %.4f, blocks %d, tactics %s" % (mib, rc, dt * 1e3, n / dt / 1e6, ol / n, len(blocks), tac))
     print("   ", {k: round(v, 1) for k, v in tim.items() if not k.startswith("#")}, flush=True)
+    if os.environ.get("BZ_DBG"):
+        from _bzip2 import _fetch
+        info = _fetch(L, enc, "info", np.uint32, 4)
+        nsb = int(info[2])
+        d = _fetch(L, enc, "dbg", np.uint64, 8 * nsb).reshape(-1, 8)
+        res = _fetch(L, enc, "res", np.uint32, 8 * nsb).reshape(-1, 8)
+        tot = d[:, 7] / 1e5
+        print("    last batch: %d sub-blocks, WG time sum %.0f ms, max %.1f, mean %.1f; hist %.0f llhc %.0f cost %.0f chain %.0f; groups mean %.0f max %d" % (
+            nsb, tot.sum(), tot.max(), tot.mean(), d[:, 0].sum() / 1e5, d[:, 1].sum() / 1e5, d[:, 2].sum() / 1e5, d[:, 3].sum() / 1e5, res[:, 3].mean(), res[:, 3].max()))

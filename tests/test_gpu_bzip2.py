@@ -77,7 +77,7 @@ def test_many_blocks_and_batches(encoder):
     try:
         rc, p2, _ = encoder.bzip2(data, 14)
     finally:
-        encoder.set_knob("bz_batch_melems", 192)
+        encoder.set_knob("bz_batch_melems", 640)
     assert rc == 0 and p2 == o
 
 

@@ -686,13 +686,14 @@ struct EntTab {
   uint8_t *lens;               // [nsb][6][260]
   uint32_t *res;               // [nsb][8]: coders, max code length, sample width, groups, data bits, selector bits, tree bits, block bits
   uint32_t *deflist;           // [selcap]: the groups that change coder in a round
+  const uint32_t *order;       // sub-blocks, largest first: workgroup b takes sub-block order[b] (the long ones must not start last)
   unsigned long long *dbg;     // [nsb][8] clock counts (profiling aid): histogram, code lengths, costs, chain, passes, rounds, constructs, total
   int option;                  // 0 / 1 / 2 = block_100k / 400k / 900k
 };
 
 __global__ void __launch_bounds__(128) k_bz_rank(EntTab E, uint32_t nsb) {
   extern __shared__ uint8_t dyn[];
-  const uint32_t s = blockIdx.x;
+  const uint32_t s = E.order[blockIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int width = E.option == 2 ? 3 + w : 4;
   if (E.option != 2 && w == 1) return;
@@ -766,7 +767,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
   __shared__ __align__(16) uint8_t scratch[6 * LLHC_WAVE_SCRATCH];
   __shared__ uint32_t wtot[EN_THREADS / 64];
   __shared__ uint32_t red[16];
-  const uint32_t s = blockIdx.x;
+  const uint32_t s = E.order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t m = E.mtf_n[s], A = E.nsym[s] + 2, ns = 1 + (m - 1) / BZ_GROUP;
   const uint16_t *sym = E.sym + E.soff[s];
@@ -1329,7 +1330,7 @@ struct Bz2State {
   // MTF / symbol space
   DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
   // entropy coders and output
-  DBuf sel_off, rank_idx, gcost, sel, lens, res, woff, words, jobs, job_first, outw, dbg, deflist;
+  DBuf sel_off, rank_idx, gcost, sel, lens, res, woff, words, jobs, job_first, outw, dbg, deflist, order;
   // stream level
   DBuf rs1, epre, bstart, blen, etab, seg_off, seg, seg_cnt, extra;
   bool etab_ready = false;
@@ -1342,7 +1343,7 @@ struct Bz2State {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
-            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist};
+            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -1551,10 +1552,15 @@ static int bz_entropy_emit(Ctx *c, int option) {
       (rc = dbuf_ensure(c, B->sel, selcap)) || (rc = dbuf_ensure(c, B->lens, 6ull * BZ_LSTRIDE * nsb)) || (rc = dbuf_ensure(c, B->res, 32ull * nsb)) ||
       (rc = dbuf_ensure(c, B->woff, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->dbg, 64ull * nsb)) || (rc = dbuf_ensure(c, B->deflist, 4ull * selcap))) return rc;
   BZ_HIP(hipMemcpyAsync(B->sel_off.p, so.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
+  std::vector<uint32_t> order(nsb);
+  for (uint32_t s = 0; s < nsb; s++) order[s] = s;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return B->h_n[a] > B->h_n[b]; });
+  if ((rc = dbuf_ensure(c, B->order, 4ull * nsb))) return rc;
+  BZ_HIP(hipMemcpyAsync(B->order.p, order.data(), 4ull * nsb, hipMemcpyHostToDevice, st));
   EntTab E;
   E.sym = B->sym.as<uint16_t>(); E.soff = B->soff.as<uint32_t>(); E.mtf_n = B->mtf_n.as<uint32_t>(); E.nsym = B->nsym.as<uint32_t>();
   E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<unsigned long long>();
-  E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option; E.dbg = B->dbg.as<unsigned long long>(); E.deflist = B->deflist.as<uint32_t>();
+  E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option; E.dbg = B->dbg.as<unsigned long long>(); E.deflist = B->deflist.as<uint32_t>(); E.order = B->order.as<uint32_t>();
   SubTab T = subtab(B);
   const size_t rank_lds = 2 * (size_t)(BZ_MAX_SEL * 3 + 64);
   if (!B->rank_attr) {
@@ -1656,7 +1662,7 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
   uint32_t combined_crc = 0;
   const uint64_t cap_bits = cap * 8;
   bool overflow = false;
-  const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 192) << 20;
+  const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 640) << 20;
   // ---- batches of blocks ----
   struct Plan { std::vector<uint32_t> tac[4]; };
   uint32_t k0 = 0;
