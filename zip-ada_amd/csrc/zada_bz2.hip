@@ -670,8 +670,8 @@ __global__ void __launch_bounds__(1024) k_bz_rle2_emit(const uint8_t *__restrict
 //  Entropy coders (:418-1010).  One workgroup per sub-block runs the reference's brute-force search as it stands: for every
 //  (max code length, sample width, number of coders) on the list, start from the ranking of the groups of 50 symbols
 //  (:555-635), then up to ten rounds of {code lengths per cluster, every group to its cheapest coder} (:781-811), and keep
-//  the cheapest total (:926-950).  The order of equal keys in the ranking is the one GNAT's heap sort leaves (see
-//  oracle/zada_oracle_bz2.c): k_bz_rank replays that sort, one lane per ranking, in LDS.
+//  the cheapest total (:926-950).  The order of equal keys in the ranking is the one GNAT's heap sort leaves (DESIGN.md §9,
+//  exactness notes): k_bz_rank replays that sort, one lane per ranking, in LDS.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BZ_GROUP = 50;
 constexpr int BZ_MAX_SEL = 18002;          // 1 + 900 005 / 50
