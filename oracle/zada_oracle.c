@@ -1283,9 +1283,14 @@ int zo_compress_data(const uint8_t *in, uint64_t n, int method, uint8_t *out, ui
     *out_len = n; *zip_type = 0; *crc_out = zo_crc32_final(CRC);
     return ZO_OK;
   }
-  rc = zo_deflate(in, n, method, out, cap, out_len, &CRC, NULL, NULL, NULL, NULL);   /* :197-202 */
+  if (method >= ZO_BZIP2_1 && method <= ZO_BZIP2_3) {                /* :204-209 */
+    rc = zo_bzip2(in, n, method, out, cap, out_len, &CRC);
+    *zip_type = 12;                                                  /* bzip2_code, zip.ads:502 */
+  } else {
+    rc = zo_deflate(in, n, method, out, cap, out_len, &CRC, NULL, NULL, NULL, NULL);   /* :197-202 */
+    *zip_type = 8;
+  }
   if (rc < 0 || rc == ZO_ABORTED) return rc;
-  *zip_type = 8;
   CRC = zo_crc32_final(CRC);                                         /* :218 */
   if (rc == ZO_INEFFICIENT) {                                        /* :224-237 */
     if (cap < n) return ZO_EINVAL;

@@ -103,3 +103,24 @@ def test_device_entry_feedback_abort_and_inefficient(encoder):
     assert rc == 1 and p == o2                                      # compression_ok = False; the stream is still delivered when it fits
     rc, p, _ = encoder.bzip2(rnd, 14, cap=len(rnd))                 # ... and only announced when it does not
     assert rc == 1 and p is None
+
+
+def test_zip_archive_with_bzip2_entries(encoder):
+    """Zip.Create with a BZip2 method (zip-compress.adb:204-209: format code 12; needed version stays 10, zip-create.adb:131):
+    archive bytes == the oracle's Zip.Create restatement; Python's zipfile (libbz2) reads every entry back, incl. stored ones."""
+    import io
+    import zipfile
+    from _common import oracle_zip
+    Z = product()
+    rng = np.random.default_rng(21)
+    mix = Z.silesia_mix(2 << 20)
+    entries = [("a/text.txt", bytes(mix[:300000])), ("a/empty", b""), ("b/random.bin", bytes(rng.integers(0, 256, 5000, dtype=np.uint8))),
+               ("b/tiny", b"x"), ("c/more.txt", bytes(mix[300000:1500000]))]
+    zc = Z.ZipCreate(encoder, 14)
+    for name, d in entries:
+        zc.add_stream(name, d)
+    got = zc.finish()
+    assert got == oracle_zip(entries, 14)
+    zf = zipfile.ZipFile(io.BytesIO(got))
+    assert zf.testzip() is None and [zf.read(i) for i in zf.infolist()] == [d for _, d in entries]
+    assert [i.compress_type for i in zf.infolist()] == [12, 0, 0, 0, 12]

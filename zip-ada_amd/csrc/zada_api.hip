@@ -1197,9 +1197,10 @@ int zada_deflate_batch(zada_ctx *z, int method, int count, const uint8_t *const 
 int zada_compress_data(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,
                        uint32_t *crc_out, uint16_t *zip_type) {
   uint32_t crc = 0xFFFFFFFFu;                                   // Init, zip-compress.adb:144
-  int rc = zada_deflate(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr);
+  const bool bz = method >= ZADA_BZIP2_1 && method <= ZADA_BZIP2_3;                  // :204-209 (bzip2_code = 12, zip.ads:502)
+  int rc = bz ? zada_bzip2(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr) : zada_deflate(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr);
   if (rc < 0 || rc == ZADA_ABORTED) return rc;
-  *zip_type = 8;
+  *zip_type = bz ? 12 : 8;
   crc = ~crc;                                                   // Final :218
   if (rc == ZADA_INEFFICIENT) {                                 // :224-237 Store_data; the CRC of the same bytes is unchanged
     if (cap < n) { z->c.err = "output buffer too small"; return ZADA_E_INVALID; }

@@ -767,6 +767,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
   __shared__ __align__(16) uint8_t scratch[6 * LLHC_WAVE_SCRATCH];
   __shared__ uint32_t wtot[EN_THREADS / 64];
   __shared__ uint32_t red[16];
+  __shared__ uint32_t dirty;                         // clusters whose counts changed since their code lengths were made
   const uint32_t s = E.order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t m = E.mtf_n[s], A = E.nsym[s] + 2, ns = 1 + (m - 1) / BZ_GROUP;
@@ -810,6 +811,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) freq[i] = 0;
     __syncthreads();
     for (uint32_t g = tid; g < ns; g += EN_THREADS) count_group(g, 6, sel[g] - 1u);
+    if (tid == 0) dirty = 63u;
     __syncthreads();
     t_hist += wall_clock64() - ta;
   };
@@ -817,7 +819,8 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     const unsigned long long tb = wall_clock64();
     for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) fwork[i] = freq[i];
     __syncthreads();
-    if (w < ec) {
+    const uint32_t todo = dirty;                                                      // same counts, same code lengths: only the clusters that changed
+    if (w < ec && ((todo >> w) & 1u)) {
       uint32_t *f = fwork + w * BZ_LSTRIDE;
       int zeroes = 0;
       for (uint32_t base = 0; base < A; base += 64) { const uint32_t a = base + lane; zeroes += __popcll(__ballot(a < A && f[a] == 0)); }
@@ -831,6 +834,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
       else llhc_wave<17>(f, (int)A, bl, sc, lane);
     }
     __syncthreads();
+    if (tid == 0) dirty = 0;
     for (uint32_t y = tid; y < A; y += EN_THREADS) {
       unsigned long long v = 0;
       for (int cl = 0; cl < ec; cl++) v |= (unsigned long long)lens[cl * BZ_LSTRIDE + y] << (10 * cl);
@@ -916,6 +920,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     for (uint32_t i = tid; i < ndef; i += EN_THREADS) {                                 // ... they take their counts along, all threads sharing the work
       const uint32_t v = E.deflist[so + i];
       count_group(v & 0xFFFFu, (v >> 16) & 15u, (v >> 20) & 15u);
+      atomicOr(&dirty, (1u << ((v >> 16) & 15u)) | (1u << ((v >> 20) & 15u)));
     }
     __syncthreads();
     defectors = red[0]; selbits = red[1];
@@ -1326,6 +1331,7 @@ struct Bz2State {
   // element space
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
   std::vector<uint32_t> h_cm, h_cfirst;
+  std::vector<uint64_t> m_hist;     // rows the doubling rounds of the last batch had to sort (profiling aid)
   std::vector<Tile> h_ct;
   // MTF / symbol space
   DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
@@ -1453,6 +1459,8 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
     scan_launch<OpSum, false>(st, FArr{H}, 256ull * nt, agg, H, nullptr);
     hipLaunchKernelGGL(k_bz_radix_scatter, dim3(nt), dim3(1024), 0, st, ki, vi, S, tl, tf, done, shift, H, ko, vo);
   };
+  B->m_hist.clear();
+  B->m_hist.push_back(tot);
   // first sort: four bytes
   BZ_HIP(hipMemsetAsync(acte, 0, 4 * ((size_t)tot / 32 + 2), st));
   hipLaunchKernelGGL(k_bz_bwt_init, dim3(net), dim3(1024), 0, st, B->rle.as<uint8_t>(), T, ET, keyA, valA);
@@ -1484,6 +1492,7 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
     const uint32_t *CF = B->ctile_first.as<uint32_t>();
     uint64_t M = 0;
     for (uint32_t s2 = 0; s2 < nsb; s2++) M += h_cm[s2];
+    B->m_hist.push_back(M);
     hipLaunchKernelGGL(k_bz_compact, dim3(net), dim3(1024), 0, st, hv, hr, valB, cl, T, ET, done, keyA, cv0);
     radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 0); radix(C, CT, CF, nct, keyB, cv1, keyA, cv0, 8);
     radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 16);        // first rows are below 2^20 (block capacity 900 000)
@@ -1814,6 +1823,7 @@ extern "C" int zada_bz2_fetch(zada_ctx *z, const char *name, void *dst, uint64_t
   else if (!strcmp(name, "sel_off")) { src = B->sel_off.p; len = 4ull * (nsb + 1); }
   else if (!strcmp(name, "sel")) { src = B->sel.p; len = B->selcap; }
   else if (!strcmp(name, "lens")) { src = B->lens.p; len = 6ull * BZ_LSTRIDE * nsb; }
+  else if (!strcmp(name, "bwt_m")) { len = 8ull * B->m_hist.size(); if (nbytes) *nbytes = len; if (len > cap) return ZADA_E_INVALID; memcpy(dst, B->m_hist.data(), len); return 0; }
   else if (!strcmp(name, "dbg")) { src = B->dbg.p; len = 64ull * nsb; }
   else if (!strcmp(name, "woff")) { src = B->woff.p; len = 4ull * (nsb + 1); }
   else if (!strcmp(name, "words")) { src = B->words.p; len = 4ull * B->nwords; }
