@@ -409,41 +409,56 @@ __global__ void __launch_bounds__(1024) k_bz_set_class(const uint32_t *__restric
 // back by h, are in the order of their second halves; those whose shifted element is still unsorted are filtered out (in
 // that order), sorted by the first row of that element's group (stable: three passes over the filtered rows only), and
 // written back to the group's rows.
-__global__ void __launch_bounds__(1024) k_bz_filter(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, SubTab T, const Tile *__restrict__ tiles,
-                                                    const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ flag, uint32_t *__restrict__ stash) {
+// pass 1: per tile of rows, how many survive the filter; pass 2 (after a scan of the tile counts) writes them in order.  Both
+// read the rows and the mark of the shifted element; nothing per row is stored in between.
+__device__ __forceinline__ uint32_t bz_shifted_active(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, uint32_t g, uint32_t off, uint32_t n,
+                                                       uint32_t h, uint32_t *e_out) {
+  uint32_t l = sa[g] - off;
+  l = l >= h ? l - h : l + n - h;               // h < n for a sub-block that is not done
+  const uint32_t e = off + l;
+  *e_out = e;
+  return (acte[e >> 5] >> (e & 31)) & 1u;
+}
+__global__ void __launch_bounds__(1024) k_bz_filter_count(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, SubTab T, const Tile *__restrict__ tiles,
+                                                          const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ tile_cnt) {
+  __shared__ uint32_t l17[17];
   const Tile t = tiles[blockIdx.x];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  const bool dn = done[t.sb];
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t g = off + t.lo + i;
-    uint32_t f = 0;
-    if (!dn) {
-      uint32_t l = sa[g] - off;
-      l = l >= h ? l - h : l + n - h;               // h < n for a sub-block that is not done
-      const uint32_t e = off + l;
-      f = (acte[e >> 5] >> (e & 31)) & 1u;
-      stash[g] = e;
-    }
-    flag[g] = f;
+  uint32_t c = 0;
+  if (!done[t.sb]) {
+    const uint32_t r0 = threadIdx.x * 8;
+    for (uint32_t k = 0; k < 8; k++) if (r0 + k < m) { uint32_t e; c += bz_shifted_active(sa, acte, off + t.lo + r0 + k, off, n, h, &e); }
   }
+  OpSum sm;
+  uint32_t tot;
+  wg_scan_incl(c, l17, sm, &tot);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
 }
-__global__ void k_bz_counts(SubTab T, const uint32_t *__restrict__ P, uint32_t *__restrict__ coff, uint32_t *__restrict__ cm) {
+// tscan = exclusive scan of tile_cnt over all tiles (entry ntiles = the total)
+__global__ void k_bz_counts(SubTab T, const uint32_t *__restrict__ first_tile, const uint32_t *__restrict__ tscan, uint32_t *__restrict__ coff, uint32_t *__restrict__ cm) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= T.nsb) return;
-  const uint32_t a = P[T.off[s]], b = P[T.off[s] + T.n[s]];
+  const uint32_t a = tscan[first_tile[s]], b = tscan[first_tile[s + 1]];
   coff[s] = a; cm[s] = b - a;
   if (s + 1 == T.nsb) coff[s + 1] = b;
 }
-__global__ void __launch_bounds__(1024) k_bz_compact(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ P, const uint32_t *__restrict__ stash,
-                                                     const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles, const uint8_t *__restrict__ done,
-                                                     uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval) {
+__global__ void __launch_bounds__(1024) k_bz_filter_emit(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, const uint32_t *__restrict__ cl, SubTab T,
+                                                         const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t h,
+                                                         const uint32_t *__restrict__ tscan, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval) {
+  __shared__ uint32_t l17[17];
   const Tile t = tiles[blockIdx.x];
   if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t g = off + t.lo + i;
-    if (flag[g]) { const uint32_t j = P[g], e = stash[g]; ckey[j] = cl[e] - off; cval[j] = e; }
+  const uint32_t r0 = threadIdx.x * 8;
+  uint32_t ev[8], fl = 0, c = 0;
+  for (uint32_t k = 0; k < 8; k++) {
+    ev[k] = 0;
+    if (r0 + k < m && bz_shifted_active(sa, acte, off + t.lo + r0 + k, off, n, h, &ev[k])) { fl |= 1u << k; c++; }
   }
+  OpSum sm;
+  const uint32_t incl = wg_scan_incl(c, l17, sm, nullptr);
+  uint32_t j = tscan[blockIdx.x] + incl - c;
+  for (uint32_t k = 0; k < 8; k++) if ((fl >> k) & 1u) { ckey[j] = cl[ev[k]] - off; cval[j] = ev[k]; j++; }
 }
 // C = the filtered rows' space (sub-block s owns [coff[s], coff[s] + cm[s])), its tiles in `tiles`
 __global__ void __launch_bounds__(1024) k_bz_runfirst(const uint32_t *__restrict__ ckey, SubTab C, const Tile *__restrict__ tiles, uint32_t *__restrict__ rf) {
@@ -1475,9 +1490,9 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   std::vector<uint32_t> &h_cm = B->h_cm;
   std::vector<Tile> &ct = B->h_ct; std::vector<uint32_t> &cfirst = B->h_cfirst;
   for (uint32_t h = 4;; h *= 2) {
-    hipLaunchKernelGGL(k_bz_filter, dim3(net), dim3(1024), 0, st, valA, acte, T, ET, done, h, hv, valB);
-    scan_launch<OpSum, false>(st, FArrPad{hv, tot}, (uint64_t)tot + 1, agg, hr, nullptr);
-    hipLaunchKernelGGL(k_bz_counts, dim3((nsb + 255) / 256), dim3(256), 0, st, T, hr, C.off, C.n);
+    hipLaunchKernelGGL(k_bz_filter_count, dim3(net), dim3(1024), 0, st, valA, acte, T, ET, done, h, hv);
+    scan_launch<OpSum, false>(st, FArrPad{hv, net}, (uint64_t)net + 1, agg, hr, nullptr);          // hr[t] = filtered rows before tile t
+    hipLaunchKernelGGL(k_bz_counts, dim3((nsb + 255) / 256), dim3(256), 0, st, T, EF, hr, C.off, C.n);
     h_cm.resize(nsb);
     BZ_HIP(hipMemcpyAsync(h_cm.data(), C.n, 4ull * nsb, hipMemcpyDeviceToHost, st));
     BZ_HIP(hipStreamSynchronize(st));
@@ -1493,7 +1508,7 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
     uint64_t M = 0;
     for (uint32_t s2 = 0; s2 < nsb; s2++) M += h_cm[s2];
     B->m_hist.push_back(M);
-    hipLaunchKernelGGL(k_bz_compact, dim3(net), dim3(1024), 0, st, hv, hr, valB, cl, T, ET, done, keyA, cv0);
+    hipLaunchKernelGGL(k_bz_filter_emit, dim3(net), dim3(1024), 0, st, valA, acte, cl, T, ET, done, h, hr, keyA, cv0);
     radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 0); radix(C, CT, CF, nct, keyB, cv1, keyA, cv0, 8);
     radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 16);        // first rows are below 2^20 (block capacity 900 000)
     hipLaunchKernelGGL(k_bz_runfirst, dim3(nct), dim3(1024), 0, st, keyB, C, CT, hv);
