@@ -34,6 +34,10 @@ for mib in [int(x) for x in os.environ.get("BZ_MIBS", "64,256").split(",")]:
         res = _fetch(L, enc, "res", np.uint32, 8 * nsb).reshape(-1, 8)
         mh = _fetch(L, enc, "bwt_m", np.uint64, 64)
         print("    BWT rows per round (share of all %d): %s" % (int(mh[0]), " ".join("%.3f" % (x / mh[0]) for x in mh[1:])))
+        st = d[:, 6].astype(np.int64); en = st + d[:, 7].astype(np.int64); t0 = st.min(); span = (en.max() - t0) / 1e5
+        grid = np.linspace(t0, en.max(), 41)[:-1]
+        conc = [int(((st <= g) & (en > g)).sum()) for g in grid]
+        print("    entropy kernel span %.1f ms; workgroups in flight over time: %s" % (span, conc))
         tot = d[:, 7] / 1e5
         print("    last batch: %d sub-blocks, WG time sum %.0f ms, max %.1f, mean %.1f; hist %.0f llhc %.0f cost %.0f chain %.0f; groups mean %.0f max %d" % (
             nsb, tot.sum(), tot.max(), tot.mean(), d[:, 0].sum() / 1e5, d[:, 1].sum() / 1e5, d[:, 2].sum() / 1e5, d[:, 3].sum() / 1e5, res[:, 3].mean(), res[:, 3].max()))

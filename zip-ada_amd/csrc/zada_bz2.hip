@@ -604,10 +604,11 @@ __global__ void __launch_bounds__(64) k_bz_mtf_lists(SubTab T, const uint32_t *_
   }
 }
 
-// pass 3: the move-to-front indices of a chunk
+// pass 3: the move-to-front indices of a chunk.  A lane's list is 64 words (+ 1 of padding, so that lanes at the same
+// position hit different banks); the search compares four entries per step and the shift moves four per step.
 __global__ void __launch_bounds__(64) k_bz_mtf_apply(const uint8_t *__restrict__ bwt, SubTab T, const Tile *__restrict__ tiles, uint32_t ntiles,
                                                      const uint8_t *__restrict__ seq, const uint8_t *__restrict__ lists, uint8_t *__restrict__ idx_out) {
-  __shared__ uint8_t L[256 * 64];   // [position][lane]
+  __shared__ uint32_t L[65 * 64];
   const uint32_t slot = blockIdx.x * 64 + threadIdx.x, ti = slot / MTF_PER_TILE, j = slot % MTF_PER_TILE;
   const int lane = threadIdx.x;
   if (ti >= ntiles) return;
@@ -615,16 +616,25 @@ __global__ void __launch_bounds__(64) k_bz_mtf_apply(const uint8_t *__restrict__
   const uint32_t n = T.n[t.sb], lo = t.lo + j * MTF_CHUNK;
   if (lo >= n) return;
   const uint32_t m = min((uint32_t)MTF_CHUNK, n - lo);
-  const uint8_t *src = bwt + T.off[t.sb] + lo, *sq = seq + t.sb * 256, *l0 = lists + (uint64_t)slot * 256;
+  const uint8_t *src = bwt + T.off[t.sb] + lo, *sq = seq + t.sb * 256;
+  const uint32_t *l0 = (const uint32_t *)(lists + (uint64_t)slot * 256);
   uint8_t *dst = idx_out + T.off[t.sb] + lo;
-  for (int i = 0; i < 256; i++) L[i * 64 + lane] = l0[i];
+  uint32_t *my = L + lane * 65;                                   // entry p = byte p & 3 of word p >> 2
+  for (int i = 0; i < 64; i++) my[i] = l0[i];
   for (uint32_t i = 0; i < m; i++) {
-    const uint8_t y = sq[src[i]];
-    int idx = 0;
-    uint8_t prev = L[lane], curv;
-    if (prev != y) {
-      do { idx++; curv = L[idx * 64 + lane]; L[idx * 64 + lane] = prev; prev = curv; } while (curv != y);
-      L[lane] = y;
+    const uint32_t y = sq[src[i]], yy = y * 0x01010101u;
+    uint32_t wi = 0, wv = my[0], x = wv ^ yy;
+    while (!((x - 0x01010101u) & ~x & 0x80808080u)) { wi++; wv = my[wi]; x = wv ^ yy; }       // no zero byte: y is not among these four
+    const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;      // lowest set bit marks the first zero byte (no borrow can reach below it)
+    const uint32_t b = (uint32_t)(__ffs((int)z) - 1) >> 3;        // its byte
+    const uint32_t idx = wi * 4 + b;
+    if (idx) {
+      // entries 0 .. idx - 1 move up by one, y goes to the front: whole words below wi, part of word wi
+      const uint32_t keep = b == 3 ? 0u : (wv & (0xFFFFFFFFu << (8 * (b + 1))));
+      uint32_t carry = y;
+      for (uint32_t k = 0; k < wi; k++) { const uint32_t w = my[k]; my[k] = (w << 8) | carry; carry = w >> 24; }
+      const uint32_t lowmask = (1u << (8 * b)) - 1u;               // the bytes of word wi in front of y
+      my[wi] = keep | ((((wv & lowmask) << 8) | carry) & ((b == 3) ? 0xFFFFFFFFu : ((1u << (8 * (b + 1))) - 1u)));
     }
     dst[i] = (uint8_t)idx;
   }
@@ -706,13 +716,12 @@ struct EntTab {
   int option;                  // 0 / 1 / 2 = block_100k / 400k / 900k
 };
 
-__global__ void __launch_bounds__(128) k_bz_rank(EntTab E, uint32_t nsb) {
+__global__ void __launch_bounds__(64) k_bz_rank(EntTab E, uint32_t nsb) {
   extern __shared__ uint8_t dyn[];
   const uint32_t s = E.order[blockIdx.x];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x, w = blockIdx.y;                // one ranking (sample width) per workgroup
   const int width = E.option == 2 ? 3 + w : 4;
-  if (E.option != 2 && w == 1) return;
-  uint8_t *K = dyn + (size_t)w * (BZ_MAX_SEL * 3 + 64);      // keys, 1-based
+  uint8_t *K = dyn;                                            // keys, 1-based
   uint16_t *I = (uint16_t *)(K + ((BZ_MAX_SEL + 15) & ~15));  // group numbers, 1-based
   const uint32_t m = E.mtf_n[s], ns = 1 + (m - 1) / BZ_GROUP;
   const uint16_t *sym = E.sym + E.soff[s];
@@ -1026,7 +1035,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     r[0] = (uint32_t)best_ec; r[1] = (uint32_t)best_ml; r[2] = (uint32_t)(E.option == 2 ? 3 + best_w : 4); r[3] = ns;
     r[4] = k.data; r[5] = k.selb; r[6] = k.tree; r[7] = 0;
     unsigned long long *d = E.dbg + (size_t)s * 8;
-    d[0] = t_hist; d[1] = t_llhc; d[2] = t_cost; d[3] = t_chain; d[4] = n_pass; d[5] = n_round; d[6] = n_constr; d[7] = wall_clock64() - t_begin;
+    d[0] = t_hist; d[1] = t_llhc; d[2] = t_cost; d[3] = t_chain; d[4] = n_pass; d[5] = n_round; d[6] = t_begin; d[7] = wall_clock64() - t_begin;
   }
 }
 
@@ -1586,12 +1595,12 @@ static int bz_entropy_emit(Ctx *c, int option) {
   E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<unsigned long long>();
   E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option; E.dbg = B->dbg.as<unsigned long long>(); E.deflist = B->deflist.as<uint32_t>(); E.order = B->order.as<uint32_t>();
   SubTab T = subtab(B);
-  const size_t rank_lds = 2 * (size_t)(BZ_MAX_SEL * 3 + 64);
+  const size_t rank_lds = (size_t)(BZ_MAX_SEL * 3 + 64);
   if (!B->rank_attr) {
     BZ_HIP(hipFuncSetAttribute((const void *)k_bz_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
     B->rank_attr = true;
   }
-  hipLaunchKernelGGL(k_bz_rank, dim3(nsb), dim3(128), rank_lds, st, E, nsb);
+  hipLaunchKernelGGL(k_bz_rank, dim3(nsb, option == 2 ? 2 : 1), dim3(64), rank_lds, st, E, nsb);
   c->tmark("bz:rank");
   hipLaunchKernelGGL(k_bz_entropy, dim3(nsb), dim3(EN_THREADS), 0, st, E, nsb);
   hipLaunchKernelGGL(k_bz_block_bits, dim3((nsb + 255) / 256), dim3(256), 0, st, T, B->res.as<uint32_t>());
