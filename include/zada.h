@@ -174,7 +174,7 @@ void zada_silesia_mix(uint64_t seed, unsigned class_mask, uint64_t offset, uint6
  * register, return ZADA_OK / ZADA_INEFFICIENT (stream not smaller than the input: compression_ok := False) / ZADA_ABORTED / < 0.
  * The stream is the complete BZip2 stream ("BZh9" ... footer).  Unlike zada_deflate it is also delivered with
  * ZADA_INEFFICIENT when it fits `cap` (*out_len <= cap), so the entry points serve a stand-alone .bz2 writer (bzip2_enc.adb) too.
- * Streams of 2 GiB and more: ZADA_E_TOO_LARGE (not built yet).
+ * Streams of any length: the block limits are found a span of the stream at a time (knob "bz_span_mib", default 1024).
  * --------------------------------------------------------------------------------------------------------------- */
 int zada_bzip2(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,
                uint32_t *crc_inout, zada_feedback_fn fb, void *user);

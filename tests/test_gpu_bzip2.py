@@ -79,6 +79,15 @@ def test_many_blocks_and_batches(encoder):
     finally:
         encoder.set_knob("bz_batch_melems", 640)
     assert rc == 0 and p2 == o
+    encoder.set_knob("bz_span_mib", 24)                 # the block chain walked a stretch of the stream at a time (streams of 4 GiB and more need it)
+    try:
+        data2 = Z.silesia_mix(70 << 20).tobytes()
+        rc, p3, _ = encoder.bzip2(data2, 14)
+        blocks3 = encoder.bz2_last_blocks()
+    finally:
+        encoder.set_knob("bz_span_mib", 1024)
+    rc, p4, _ = encoder.bzip2(data2, 14)
+    assert rc == 0 and p3 == p4 and blocks3 == encoder.bz2_last_blocks() and bz2.decompress(p3) == data2
 
 
 def test_device_entry_feedback_abort_and_inefficient(encoder):

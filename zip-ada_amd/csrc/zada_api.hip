@@ -872,6 +872,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
   else if (!strcmp(name, "inner_budget")) z->c.knob_inner_budget = value;
   else if (!strcmp(name, "span_mib")) { if (value < 1 || value > 3968) return ZADA_E_INVALID; z->c.knob_span_mib = value; }
+  else if (!strcmp(name, "bz_span_mib")) { if (value < 24 || value > 3072) return ZADA_E_INVALID; z->c.knob_bz_span_mib = value; }
   else if (!strcmp(name, "bz_batch_melems")) { if (value < 1 || value > 1536) return ZADA_E_INVALID; z->c.knob_bz_batch_melems = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
@@ -977,14 +978,17 @@ static int bzip2_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint8
   int rc;
   c->tbegin();
   c->tmark("bz:begin");
-  if (crc_inout && n) {
-    if ((rc = ensure_crc_workspace(c, n)) || (rc = crc_launch(c, d_in, n))) return rc;
+  if (crc_inout && n) {                                            // the Zip CRC-32 of the input, 2 GiB at a time (next to nothing)
+    const uint64_t piece = 2ull << 30;
+    if ((rc = ensure_crc_workspace(c, n < piece ? n : piece))) return rc;
+    for (uint64_t o = 0; o < n; o += piece) {
+      const uint64_t k = n - o < piece ? n - o : piece;
+      if ((rc = crc_launch(c, d_in + o, k)) || (rc = crc_finish(c, k, crc_inout))) return rc;
+    }
   }
   rc = bz2_encode_device(c, method - ZADA_BZIP2_1, d_in, n, (int64_t)n, d_out, cap, out_len, fb, user);
   c->tmark("bz:end");
   c->tend();
-  if (rc < 0 || rc == ZADA_ABORTED) return rc;
-  if (crc_inout && n) { const int r2 = crc_finish(c, n, crc_inout); if (r2) return r2; }
   return rc;
 }
 int zada_bzip2_device(zada_ctx *z, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout) {

@@ -1631,58 +1631,11 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
   Bz2State *B = bz_state(c);
   hipStream_t st = c->stream;
   int rc;
-  if (n >= (1ull << 31)) { c->err = "bzip2: streams of 2 GiB and more are not taken yet"; return ZADA_E_TOO_LARGE; }
   if (cap < 64) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
   const int level = option == 0 ? 1 : option == 1 ? 4 : 9;
   const int32_t block_capacity = 100000 * level;
   B->trace.clear();
   if (fb && fb(0, user)) return ZADA_ABORTED;
-  // ---- block limits ----
-  const uint32_t cap_blocks = (uint32_t)(n / ((uint64_t)block_capacity * 3 / 8) + 8);
-  if ((rc = dbuf_ensure(c, B->rs1, 4 * (n + 16))) || (rc = dbuf_ensure(c, B->epre, 4 * (n + 16))) || (rc = dbuf_ensure(c, B->agg, 4 * ((n + 16) / SC_TILE + 16))) ||
-      (rc = dbuf_ensure(c, B->bstart, 8ull * cap_blocks)) || (rc = dbuf_ensure(c, B->blen, 4ull * cap_blocks)) || (rc = dbuf_ensure(c, B->scal, 64))) return rc;
-  uint32_t *rs1 = B->rs1.as<uint32_t>(), *E = B->epre.as<uint32_t>(), *agg = B->agg.as<uint32_t>();
-  scan_launch<OpMax, true>(st, FRunStart1{d_in}, n, agg, rs1, nullptr);
-  scan_launch<OpSum, false>(st, FPieceEnd{d_in, rs1, n}, n + 1, agg, E, nullptr);
-  const float fc = (float)block_capacity, f_lo = fc * 1.05f, f_hi = fc * 1.30f;        // :1406-1414
-  uint32_t *d_count = B->scal.as<uint32_t>() + 8;
-  hipLaunchKernelGGL(k_bz_acquire, dim3(1), dim3(64), 0, st, rs1, E, n, size_hint, block_capacity, f_lo, f_hi, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(),
-                     cap_blocks, d_count);
-  c->tmark("bz:acquire");
-  uint32_t nblk = 0;
-  BZ_HIP(hipMemcpyAsync(&nblk, d_count, 4, hipMemcpyDeviceToHost, st));
-  BZ_HIP(hipStreamSynchronize(st));
-  if (nblk > cap_blocks) { c->err = "bzip2: block table overflow"; return ZADA_E_HIP; }
-  std::vector<uint64_t> bstart(nblk); std::vector<uint32_t> blen(nblk);
-  BZ_HIP(hipMemcpy(bstart.data(), B->bstart.p, 8ull * nblk, hipMemcpyDeviceToHost));
-  BZ_HIP(hipMemcpy(blen.data(), B->blen.p, 4ull * nblk, hipMemcpyDeviceToHost));
-  if (fb && fb(3, user)) return ZADA_ABORTED;
-  // ---- segmentation (block_900k only) ----
-  std::vector<uint32_t> seg_off(2ull * nblk + 1, 0), seg, seg_cnt(2ull * nblk, 0);
-  if (option == 2) {
-    if (!B->etab_ready) {
-      std::vector<double> et(SEG_WINDOW + 2);
-      const double inv = 1.0 / (double)SEG_WINDOW;
-      et[0] = 0.0;
-      for (int f = 1; f <= SEG_WINDOW + 1; f++) { const double pr = (double)f * inv; et[f] = -(pr * log(pr)); }
-      if ((rc = dbuf_ensure(c, B->etab, 8ull * et.size()))) return rc;
-      BZ_HIP(hipMemcpy(B->etab.p, et.data(), 8ull * et.size(), hipMemcpyHostToDevice));
-      B->etab_ready = true;
-    }
-    uint64_t so = 0;
-    for (uint32_t k = 0; k < nblk; k++) { seg_off[2 * k] = (uint32_t)so; so += blen[k] / 4000 + 2; seg_off[2 * k + 1] = (uint32_t)so; so += blen[k] / 8000 + 2; }
-    seg_off[2ull * nblk] = (uint32_t)so;
-    if ((rc = dbuf_ensure(c, B->seg_off, 4ull * (2ull * nblk + 1))) || (rc = dbuf_ensure(c, B->seg, 4 * so + 16)) || (rc = dbuf_ensure(c, B->seg_cnt, 8ull * nblk + 16))) return rc;
-    BZ_HIP(hipMemcpyAsync(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_bz_segment, dim3(nblk), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
-                       (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
-    c->tmark("bz:segment");
-    seg.resize(so);
-    BZ_HIP(hipMemcpyAsync(seg.data(), B->seg.p, 4 * so, hipMemcpyDeviceToHost, st));
-    BZ_HIP(hipMemcpyAsync(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost, st));
-    BZ_HIP(hipStreamSynchronize(st));
-  }
-  if (fb && fb(6, user)) return ZADA_ABORTED;
   // ---- final stream: words with bit 31 first ----
   const uint64_t capw = cap / 4 + 8;
   if ((rc = dbuf_ensure(c, B->outw, 4 * capw + 64)) || (rc = dbuf_ensure(c, B->extra, 64))) return rc;
@@ -1696,80 +1649,141 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
   const uint64_t cap_bits = cap * 8;
   bool overflow = false;
   const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 640) << 20;
-  // ---- batches of blocks ----
-  struct Plan { std::vector<uint32_t> tac[4]; };
-  uint32_t k0 = 0;
-  while (k0 < nblk && !overflow) {
-    std::vector<uint64_t> starts; std::vector<uint32_t> lens; std::vector<Plan> plans;
-    uint64_t est = 0;
-    uint32_t k1 = k0;
-    for (; k1 < nblk; k1++) {
-      Plan P;
-      const uint64_t bs = bstart[k1]; const uint32_t bl = blen[k1];
-      const size_t first_sub = starts.size();
-      auto sub_of = [&](uint64_t s0, uint32_t l0) -> uint32_t {
-        for (size_t i = first_sub; i < starts.size(); i++) if (starts[i] == s0 && lens[i] == l0) return (uint32_t)i;
-        starts.push_back(s0); lens.push_back(l0);
-        return (uint32_t)(starts.size() - 1);
-      };
-      uint64_t e_blk = 0;
-      const size_t before = starts.size();
-      P.tac[0].push_back(sub_of(bs, bl));                                            // single
-      if (option == 2) {
-        const uint32_t size = bl / 4;                                                  // parts_4 :1237-1253
-        uint32_t stop = 0;
-        for (uint32_t count = 1; count <= 4; count++) { const uint32_t start = stop + 1; stop = count == 4 ? bl : count * size; P.tac[1].push_back(sub_of(bs + start - 1, stop - start + 1)); }
-        for (int t = 0; t < 2; t++) {                                                  // segmented_1 / _2 :1265-1297
-          const uint32_t cnt = seg_cnt[2 * k1 + t], *sp = seg.data() + seg_off[2 * k1 + t];
-          if (cnt == 0) P.tac[2 + t].push_back(sub_of(bs, 0));
-          uint32_t index_start = 1;
-          for (uint32_t q = 0; q < cnt; q++) { P.tac[2 + t].push_back(sub_of(bs + index_start - 1, sp[q] - index_start + 1)); index_start = sp[q] + 1; }
+  const float fc = (float)block_capacity, f_lo = fc * 1.05f, f_hi = fc * 1.30f;        // :1406-1414
+  const uint64_t span_max = (uint64_t)(c->knob_bz_span_mib > 0 ? c->knob_bz_span_mib : 1024) << 20;
+  // ---- spans: the block chain is walked a stretch of the stream at a time (32-bit scans); a span starts where a block starts ----
+  uint64_t pos0 = 0;
+  do {
+    const uint64_t span_len = n - pos0 < span_max ? n - pos0 : span_max;
+    const bool last_span = pos0 + span_len == n;
+    // ---- block limits ----
+    const uint32_t cap_blocks = (uint32_t)(span_len / ((uint64_t)block_capacity * 3 / 8) + 8);
+    if ((rc = dbuf_ensure(c, B->rs1, 4 * (span_len + 16))) || (rc = dbuf_ensure(c, B->epre, 4 * (span_len + 16))) || (rc = dbuf_ensure(c, B->agg, 4 * ((span_len + 16) / SC_TILE + 16))) ||
+        (rc = dbuf_ensure(c, B->bstart, 8ull * cap_blocks)) || (rc = dbuf_ensure(c, B->blen, 4ull * cap_blocks)) || (rc = dbuf_ensure(c, B->scal, 64))) return rc;
+    uint32_t *rs1 = B->rs1.as<uint32_t>(), *E = B->epre.as<uint32_t>(), *agg = B->agg.as<uint32_t>();
+    scan_launch<OpMax, true>(st, FRunStart1{d_in + pos0}, span_len, agg, rs1, nullptr);
+    scan_launch<OpSum, false>(st, FPieceEnd{d_in + pos0, rs1, span_len}, span_len + 1, agg, E, nullptr);
+    uint32_t *d_count = B->scal.as<uint32_t>() + 8;
+    hipLaunchKernelGGL(k_bz_acquire, dim3(1), dim3(64), 0, st, rs1, E, span_len, size_hint < 0 ? size_hint : size_hint - (int64_t)pos0, block_capacity, f_lo, f_hi, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(),
+                       cap_blocks, d_count);
+    c->tmark("bz:acquire");
+    uint32_t nblk = 0;
+    BZ_HIP(hipMemcpyAsync(&nblk, d_count, 4, hipMemcpyDeviceToHost, st));
+    BZ_HIP(hipStreamSynchronize(st));
+    if (nblk > cap_blocks) { c->err = "bzip2: block table overflow"; return ZADA_E_HIP; }
+    std::vector<uint64_t> bstart(nblk); std::vector<uint32_t> blen(nblk);
+    BZ_HIP(hipMemcpy(bstart.data(), B->bstart.p, 8ull * nblk, hipMemcpyDeviceToHost));
+    BZ_HIP(hipMemcpy(blen.data(), B->blen.p, 4ull * nblk, hipMemcpyDeviceToHost));
+    if (!last_span) {      // a block that ends where the span ends was cut by the span, not by the rule: it opens the next span
+      while (nblk > 0 && bstart[nblk - 1] + blen[nblk - 1] >= span_len) nblk--;
+      if (nblk == 0) { c->err = "bzip2: span shorter than a block"; return ZADA_E_INVALID; }
+      bstart.resize(nblk); blen.resize(nblk);
+      BZ_HIP(hipMemcpy(B->bstart.p, bstart.data(), 8ull * nblk, hipMemcpyHostToDevice));
+    }
+    for (uint32_t k = 0; k < nblk; k++) bstart[k] += pos0;      // stream positions from here on
+    BZ_HIP(hipMemcpy(B->bstart.p, bstart.data(), 8ull * nblk, hipMemcpyHostToDevice));
+    // ---- segmentation (block_900k only) ----
+    std::vector<uint32_t> seg_off(2ull * nblk + 1, 0), seg, seg_cnt(2ull * nblk, 0);
+    if (option == 2) {
+      if (!B->etab_ready) {
+        std::vector<double> et(SEG_WINDOW + 2);
+        const double inv = 1.0 / (double)SEG_WINDOW;
+        et[0] = 0.0;
+        for (int f = 1; f <= SEG_WINDOW + 1; f++) { const double pr = (double)f * inv; et[f] = -(pr * log(pr)); }
+        if ((rc = dbuf_ensure(c, B->etab, 8ull * et.size()))) return rc;
+        BZ_HIP(hipMemcpy(B->etab.p, et.data(), 8ull * et.size(), hipMemcpyHostToDevice));
+        B->etab_ready = true;
+      }
+      uint64_t so = 0;
+      for (uint32_t k = 0; k < nblk; k++) { seg_off[2 * k] = (uint32_t)so; so += blen[k] / 4000 + 2; seg_off[2 * k + 1] = (uint32_t)so; so += blen[k] / 8000 + 2; }
+      seg_off[2ull * nblk] = (uint32_t)so;
+      if ((rc = dbuf_ensure(c, B->seg_off, 4ull * (2ull * nblk + 1))) || (rc = dbuf_ensure(c, B->seg, 4 * so + 16)) || (rc = dbuf_ensure(c, B->seg_cnt, 8ull * nblk + 16))) return rc;
+      BZ_HIP(hipMemcpyAsync(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_bz_segment, dim3(nblk), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
+                         (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
+      c->tmark("bz:segment");
+      seg.resize(so);
+      BZ_HIP(hipMemcpyAsync(seg.data(), B->seg.p, 4 * so, hipMemcpyDeviceToHost, st));
+      BZ_HIP(hipMemcpyAsync(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost, st));
+      BZ_HIP(hipStreamSynchronize(st));
+    }
+    const uint64_t span_used = bstart[nblk - 1] + blen[nblk - 1] - pos0;
+    // ---- batches of blocks ----
+    struct Plan { std::vector<uint32_t> tac[4]; };
+    uint32_t k0 = 0;
+    while (k0 < nblk && !overflow) {
+      std::vector<uint64_t> starts; std::vector<uint32_t> lens; std::vector<Plan> plans;
+      uint64_t est = 0;
+      uint32_t k1 = k0;
+      for (; k1 < nblk; k1++) {
+        Plan P;
+        const uint64_t bs = bstart[k1]; const uint32_t bl = blen[k1];
+        const size_t first_sub = starts.size();
+        auto sub_of = [&](uint64_t s0, uint32_t l0) -> uint32_t {
+          for (size_t i = first_sub; i < starts.size(); i++) if (starts[i] == s0 && lens[i] == l0) return (uint32_t)i;
+          starts.push_back(s0); lens.push_back(l0);
+          return (uint32_t)(starts.size() - 1);
+        };
+        uint64_t e_blk = 0;
+        const size_t before = starts.size();
+        P.tac[0].push_back(sub_of(bs, bl));                                            // single
+        if (option == 2) {
+          const uint32_t size = bl / 4;                                                  // parts_4 :1237-1253
+          uint32_t stop = 0;
+          for (uint32_t count = 1; count <= 4; count++) { const uint32_t start = stop + 1; stop = count == 4 ? bl : count * size; P.tac[1].push_back(sub_of(bs + start - 1, stop - start + 1)); }
+          for (int t = 0; t < 2; t++) {                                                  // segmented_1 / _2 :1265-1297
+            const uint32_t cnt = seg_cnt[2 * k1 + t], *sp = seg.data() + seg_off[2 * k1 + t];
+            if (cnt == 0) P.tac[2 + t].push_back(sub_of(bs, 0));
+            uint32_t index_start = 1;
+            for (uint32_t q = 0; q < cnt; q++) { P.tac[2 + t].push_back(sub_of(bs + index_start - 1, sp[q] - index_start + 1)); index_start = sp[q] + 1; }
+          }
         }
+        for (size_t i = before; i < starts.size(); i++) e_blk += (uint64_t)lens[i] + lens[i] / 4 + 8;
+        if (!plans.empty() && est + e_blk > batch_elems) { starts.resize(before); lens.resize(before); break; }
+        est += e_blk;
+        plans.push_back(std::move(P));
       }
-      for (size_t i = before; i < starts.size(); i++) e_blk += (uint64_t)lens[i] + lens[i] / 4 + 8;
-      if (!plans.empty() && est + e_blk > batch_elems) { starts.resize(before); lens.resize(before); break; }
-      est += e_blk;
-      plans.push_back(std::move(P));
-    }
-    if ((rc = bz_transform(c, d_in, starts, lens)) || (rc = bz_mtf(c)) || (rc = bz_entropy_emit(c, option))) return rc;
-    // ---- smallest tactic per block (:1312-1318), copy jobs ----
-    std::vector<CopyJob> jobs; std::vector<uint64_t> job_first;
-    uint64_t dstw = 0;
-    for (uint32_t k = k0; k < k1 && !overflow; k++) {
-      const Plan &P = plans[k - k0];
-      const uint64_t phase = bitpos & 7;
-      int best = 0; uint64_t best_idx = 0, best_bits = 0;
-      for (int t = 0; t < (option == 2 ? 4 : 1); t++) {
-        uint64_t bits = 0;
-        for (uint32_t sb : P.tac[t]) bits += B->h_res[8ull * sb + 7];
-        const uint64_t idx = (phase + bits) / 8;                                       // destination_index: whole bytes written
-        if (t == 0 || idx < best_idx) { best = t; best_idx = idx; best_bits = bits; }
+      if ((rc = bz_transform(c, d_in, starts, lens)) || (rc = bz_mtf(c)) || (rc = bz_entropy_emit(c, option))) return rc;
+      // ---- smallest tactic per block (:1312-1318), copy jobs ----
+      std::vector<CopyJob> jobs; std::vector<uint64_t> job_first;
+      uint64_t dstw = 0;
+      for (uint32_t k = k0; k < k1 && !overflow; k++) {
+        const Plan &P = plans[k - k0];
+        const uint64_t phase = bitpos & 7;
+        int best = 0; uint64_t best_idx = 0, best_bits = 0;
+        for (int t = 0; t < (option == 2 ? 4 : 1); t++) {
+          uint64_t bits = 0;
+          for (uint32_t sb : P.tac[t]) bits += B->h_res[8ull * sb + 7];
+          const uint64_t idx = (phase + bits) / 8;                                       // destination_index: whole bytes written
+          if (t == 0 || idx < best_idx) { best = t; best_idx = idx; best_bits = bits; }
+        }
+        if (bitpos + best_bits + 80 + 8 > cap_bits) { overflow = true; bitpos += best_bits; break; }
+        for (uint32_t sb : P.tac[best]) {
+          const uint64_t bits = B->h_res[8ull * sb + 7];
+          combined_crc = ((combined_crc << 1) | (combined_crc >> 31)) ^ B->h_crc[sb];
+          CopyJob J; J.src_word = B->h_woff[sb]; J.dpos = bitpos; J.bits = bits; J.first_dst_word = bitpos >> 5;
+          job_first.push_back(dstw);
+          dstw += ((bitpos + bits + 31) >> 5) - (bitpos >> 5);
+          jobs.push_back(J);
+          bitpos += bits;
+        }
+        B->trace.push_back(bstart[k]); B->trace.push_back(blen[k]); B->trace.push_back((uint64_t)best); B->trace.push_back(P.tac[best].size());
       }
-      if (bitpos + best_bits + 80 + 8 > cap_bits) { overflow = true; bitpos += best_bits; break; }
-      for (uint32_t sb : P.tac[best]) {
-        const uint64_t bits = B->h_res[8ull * sb + 7];
-        combined_crc = ((combined_crc << 1) | (combined_crc >> 31)) ^ B->h_crc[sb];
-        CopyJob J; J.src_word = B->h_woff[sb]; J.dpos = bitpos; J.bits = bits; J.first_dst_word = bitpos >> 5;
+      if (!jobs.empty()) {
         job_first.push_back(dstw);
-        dstw += ((bitpos + bits + 31) >> 5) - (bitpos >> 5);
-        jobs.push_back(J);
-        bitpos += bits;
+        if ((rc = dbuf_ensure(c, B->jobs, sizeof(CopyJob) * jobs.size())) || (rc = dbuf_ensure(c, B->job_first, 8 * job_first.size()))) return rc;
+        BZ_HIP(hipMemcpyAsync(B->jobs.p, jobs.data(), sizeof(CopyJob) * jobs.size(), hipMemcpyHostToDevice, st));
+        BZ_HIP(hipMemcpyAsync(B->job_first.p, job_first.data(), 8 * job_first.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_bz_assemble, dim3((uint32_t)((dstw + 255) / 256)), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), (uint32_t)jobs.size(),
+                           B->words.as<uint32_t>(), B->outw.as<uint32_t>());
+        c->tmark("bz:assemble");
+        BZ_HIP(hipStreamSynchronize(st));     // the job vectors go out of scope; the next batch reuses the words
       }
-      B->trace.push_back(bstart[k]); B->trace.push_back(blen[k]); B->trace.push_back((uint64_t)best); B->trace.push_back(P.tac[best].size());
+      k0 = k1;
+      if (fb && fb(3 + (int)(95.0 * ((double)pos0 + (double)(k0 < nblk ? bstart[k0] - pos0 : span_used)) / (double)(n ? n : 1)), user)) return ZADA_ABORTED;
     }
-    if (!jobs.empty()) {
-      job_first.push_back(dstw);
-      if ((rc = dbuf_ensure(c, B->jobs, sizeof(CopyJob) * jobs.size())) || (rc = dbuf_ensure(c, B->job_first, 8 * job_first.size()))) return rc;
-      BZ_HIP(hipMemcpyAsync(B->jobs.p, jobs.data(), sizeof(CopyJob) * jobs.size(), hipMemcpyHostToDevice, st));
-      BZ_HIP(hipMemcpyAsync(B->job_first.p, job_first.data(), 8 * job_first.size(), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_bz_assemble, dim3((uint32_t)((dstw + 255) / 256)), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), (uint32_t)jobs.size(),
-                         B->words.as<uint32_t>(), B->outw.as<uint32_t>());
-      c->tmark("bz:assemble");
-      BZ_HIP(hipStreamSynchronize(st));     // the job vectors go out of scope; the next batch reuses the words
-    }
-    k0 = k1;
-    if (fb && fb(6 + (int)(90.0 * (double)k0 / (double)nblk), user)) return ZADA_ABORTED;
-  }
+    pos0 += span_used;
+  } while (pos0 < n && !overflow);
   if (overflow) {      // not smaller than the input: Compression_inefficient (zip-compress.adb:479-486)
     if (out_len) *out_len = (bitpos + 80 + 7) / 8;
     return ZADA_INEFFICIENT;

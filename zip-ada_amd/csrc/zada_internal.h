@@ -257,6 +257,7 @@ struct Ctx {
   int knob_inner_budget = 0;        // ZADA_INNER_BUDGET: rounds for positions deep inside a match (0 = as every other position; A/B: 1 round saves 4.7 ms in k_match and costs 8.9 ms of demand searches, 2 rounds: -3.2 / +3.7)
   int knob_span_mib = 2048;         // MiB of a stream one pass takes (longer streams: spans one after the other, deflate_spans)
   int knob_batch_mib = 512;         // MiB of LZ buffer one batch of small entries may take (zada_deflate_batch)
+  int knob_bz_span_mib = 1024;      // BZip2: MiB of the stream whose block limits are found at a time
   int knob_bz_batch_melems = 640;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
   int knob_shard_kib = 1 << 20;     // ZADA_SHARD_KIB: bytes of a range the LZ stage takes at a time, in KiB (multiple of 64)
   void tmark(const char *name);
