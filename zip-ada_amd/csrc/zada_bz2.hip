@@ -707,6 +707,7 @@ struct EntTab {
   uint16_t *rank_idx;          // [2][selcap]: 1-based group numbers in ranking order, per sample width
   uint32_t selcap;
   unsigned long long *gcost;   // [selcap]: bits of a group under each of the six coders, ten bits apart
+  unsigned long long *gcbest;  // ... of the best candidate so far
   uint8_t *sel;                // [selcap]: the coder of each group (1 ..)
   uint8_t *lens;               // [nsb][6][260]
   uint32_t *res;               // [nsb][8]: coders, max code length, sample width, groups, data bits, selector bits, tree bits, block bits
@@ -782,10 +783,9 @@ __device__ __forceinline__ uint32_t mtf_compose(uint32_t A, uint32_t B) {
   return list | (k << 28);
 }
 
-__global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t nsb) {
-  __shared__ uint8_t sel[BZ_MAX_SEL + 14];
+__global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t nsb) {
+  __shared__ uint32_t sel4[(BZ_MAX_SEL + 7) / 8 + 2];  // the coder of each group, four bits each (LDS decides how many workgroups a CU holds)
   __shared__ uint32_t freq[6 * BZ_LSTRIDE];          // symbol counts per cluster
-  __shared__ uint32_t fwork[6 * BZ_LSTRIDE];         // ... after Avoid_Zeros, as the code length procedure reads them
   __shared__ uint8_t lens[6 * BZ_LSTRIDE];
   __shared__ unsigned long long lens6[BZ_LSTRIDE];   // the six coders' lengths of a symbol, ten bits apart
   __shared__ __align__(16) uint8_t scratch[6 * LLHC_WAVE_SCRATCH];
@@ -798,7 +798,8 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
   const uint16_t *sym = E.sym + E.soff[s];
   const uint32_t so = E.sel_off[s];
   unsigned long long *gc = (unsigned long long *)E.gcost + so;
-  const uint32_t G = (ns + EN_THREADS - 1) / EN_THREADS;
+  const uint32_t G = (((ns + EN_THREADS - 1) / EN_THREADS) + 7) & ~7u;             // groups per thread in the chain: whole words of sel4
+  auto sel_get = [&](uint32_t g) -> uint32_t { return (sel4[g >> 3] >> (4 * (g & 7))) & 15u; };
   const uint32_t g0 = min((uint32_t)tid * G, ns), g1 = min(g0 + G, ns);
   unsigned long long t_hist = 0, t_llhc = 0, t_cost = 0, t_chain = 0, n_pass = 0, n_round = 0, n_constr = 0;
   const unsigned long long t_begin = wall_clock64();
@@ -834,18 +835,20 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     const unsigned long long ta = wall_clock64();
     for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) freq[i] = 0;
     __syncthreads();
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) count_group(g, 6, sel[g] - 1u);
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) count_group(g, 6, sel_get(g) - 1u);
     if (tid == 0) dirty = 63u;
     __syncthreads();
     t_hist += wall_clock64() - ta;
   };
   auto define_descriptors = [&](int ec, int ml) {                                   // :656-659, :497-517
     const unsigned long long tb = wall_clock64();
-    for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) fwork[i] = freq[i];
+    // the counts as the code length procedure reads them (after Avoid_Zeros) sit in that procedure's own scratch, in the part it
+    // only uses once the counts have been read
+    for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) ((uint32_t *)(scratch + (i / BZ_LSTRIDE) * LLHC_WAVE_SCRATCH + 1728))[i % BZ_LSTRIDE] = freq[i];
     __syncthreads();
     const uint32_t todo = dirty;                                                      // same counts, same code lengths: only the clusters that changed
     if (w < ec && ((todo >> w) & 1u)) {
-      uint32_t *f = fwork + w * BZ_LSTRIDE;
+      uint32_t *f = (uint32_t *)(scratch + w * LLHC_WAVE_SCRATCH + 1728);
       int zeroes = 0;
       for (uint32_t base = 0; base < A; base += 64) { const uint32_t a = base + lane; zeroes += __popcll(__ballot(a < A && f[a] == 0)); }
       if (zeroes > 0) {                                                               // Avoid_Zeros :436-460
@@ -889,12 +892,13 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     const unsigned long long ta = wall_clock64();
     const uint32_t ident = 0x654321u | (6u << 28);
     uint32_t used = ident & 0x0FFFFFFFu, outv = 0, def = 0, selc = 0, chosen = 0;
+    unsigned long long nw0 = 0, nw1 = 0;                                               // the stretch's new coders, three bits each
     auto run = [&]() {
       uint32_t perm = used;
-      def = 0; selc = 0; chosen = 0;
+      def = 0; selc = 0; chosen = 0; nw0 = 0; nw1 = 0;
       for (uint32_t g = g0; g < g1; g++) {
         const unsigned long long cp = gc[g];
-        const uint32_t old = sel[g] & 7u;
+        const uint32_t old = sel_get(g);
         uint32_t bestc = 0xFFFFFFFFu, bestcl = old, bestpos = 1;
         for (int j = 0; j < ec; j++) {
           const uint32_t cl = (perm >> (4 * j)) & 15u;
@@ -906,7 +910,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
         chosen |= 1u << bestcl;
         const uint32_t lowm = (1u << (4 * (bestpos - 1))) - 1u, upto = (1u << (4 * bestpos)) - 1u;
         perm = (perm & ~upto) | ((perm & lowm) << 4) | bestcl;
-        sel[g] = (uint8_t)(old | (bestcl << 4));
+        { const uint32_t q = g - g0; if (q < 21) nw0 |= (unsigned long long)bestcl << (3 * q); else nw1 |= (unsigned long long)bestcl << (3 * (q - 21)); }
       }
       const uint32_t k = __popc(chosen);
       outv = (perm & ((1u << (4 * k)) - 1u)) | (k << 28);                              // the stretch's effect
@@ -934,10 +938,15 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     __syncthreads();
     if (def) atomicAdd(&red[0], def);
     if (selc) atomicAdd(&red[1], selc);
-    for (uint32_t g = g0; g < g1; g++) {                                                // the groups that change party: listed, ...
-      const uint32_t v = sel[g], old = v & 7u, nw = v >> 4;
-      if (nw != old) E.deflist[so + atomicAdd(&red[2], 1u)] = g | ((old - 1) << 16) | ((nw - 1) << 20);
-      sel[g] = (uint8_t)nw;
+    for (uint32_t gw = g0; gw < g1; gw += 8) {                                          // the groups that change party: listed, ...
+      uint32_t word = 0;
+      for (uint32_t g = gw; g < gw + 8 && g < g1; g++) {
+        const uint32_t q = g - g0, old = sel_get(g);
+        const uint32_t nw = (uint32_t)((q < 21 ? nw0 >> (3 * q) : nw1 >> (3 * (q - 21))) & 7u);
+        if (nw != old) E.deflist[so + atomicAdd(&red[2], 1u)] = g | ((old - 1) << 16) | ((nw - 1) << 20);
+        word |= nw << (4 * (g & 7));
+      }
+      sel4[gw >> 3] = word;
     }
     __syncthreads();
     const uint32_t ndef = red[2];
@@ -955,7 +964,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
   auto cluster_statistics = [&](int ec) -> bool {                                     // :756-779
     if (tid < 8) red[8 + tid] = 0;
     __syncthreads();
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) atomicAdd(&red[8 + sel[g]], 1u);
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) atomicAdd(&red[8 + sel_get(g)], 1u);
     __syncthreads();
     const uint32_t uniform_usage = ns / (uint32_t)ec;
     bool low = false;
@@ -968,10 +977,13 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     {                                                                                 // Initial_Clustering_by_Rank :574-591
       const uint32_t attr = ec == 2 ? 0x12u : ec == 3 ? 0x213u : ec == 4 ? 0x3124u : ec == 5 ? 0x42135u : 0x531246u;
       const uint16_t *rk = E.rank_idx + (size_t)widx * E.selcap + so;
+      for (uint32_t i = tid; i < (ns + 7) / 8 + 1; i += EN_THREADS) sel4[i] = 0;
+      __syncthreads();
       for (uint32_t i = tid; i < ns; i += EN_THREADS) {
         uint32_t a32 = 1;
         while ((uint32_t)(a32 * ns / (uint32_t)ec) < i + 1) a32++;
-        sel[rk[i] - 1] = (uint8_t)((attr >> (4 * (a32 - 1))) & 15u);
+        const uint32_t g = rk[i] - 1u;
+        atomicOr(&sel4[g >> 3], ((attr >> (4 * (a32 - 1))) & 15u) << (4 * (g & 7)));
       }
       __syncthreads();
     }
@@ -990,7 +1002,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
     if (tid < 2) red[tid] = 0;
     __syncthreads();
     uint32_t d = 0;
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) d += (uint32_t)((gc[g] >> (10 * (sel[g] - 1))) & 1023u);
+    for (uint32_t g = tid; g < ns; g += EN_THREADS) d += (uint32_t)((gc[g] >> (10 * (sel_get(g) - 1))) & 1023u);
     for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
     if (lane == 0 && d) atomicAdd(&red[0], d);
     uint32_t tb = 0;
@@ -1025,15 +1037,20 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_entropy(EntTab E, uint32_t ns
         if (!(low || listed)) continue;
         const Cost k = construct(ec, mcl[a], b, low);
         const uint32_t cost = k.data + k.selb + k.tree;
-        if (cost < best_cost) { best_cost = cost; best_ec = ec; best_ml = mcl[a]; best_w = b; }
+        if (cost < best_cost) {      // :926-950; the reference constructs the winner once more at the end (:952-960): same input, same result, so it is kept here
+          best_cost = cost; best_ec = ec; best_ml = mcl[a]; best_w = b;
+          for (uint32_t g = tid; g < ns; g += EN_THREADS) { E.sel[so + g] = (uint8_t)sel_get(g); E.gcbest[so + g] = gc[g]; }
+          for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) E.lens[(size_t)s * 6 * BZ_LSTRIDE + i] = (i / BZ_LSTRIDE < ec && (uint32_t)(i % BZ_LSTRIDE) < A) ? lens[i] : 0;
+          if (tid == 0) {
+            uint32_t *r = E.res + (size_t)s * 8;
+            r[0] = (uint32_t)ec; r[1] = (uint32_t)mcl[a]; r[2] = (uint32_t)(E.option == 2 ? 3 + b : 4); r[3] = ns;
+            r[4] = k.data; r[5] = k.selb; r[6] = k.tree; r[7] = 0;
+          }
+          __syncthreads();
+        }
       }
-  const Cost k = construct(best_ec, best_ml, best_w, low);
-  for (uint32_t g = tid; g < ns; g += EN_THREADS) E.sel[so + g] = sel[g];
-  for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) E.lens[(size_t)s * 6 * BZ_LSTRIDE + i] = (i / BZ_LSTRIDE < best_ec && (uint32_t)(i % BZ_LSTRIDE) < A) ? lens[i] : 0;
+  (void)best_ec; (void)best_ml; (void)best_w;
   if (tid == 0) {
-    uint32_t *r = E.res + (size_t)s * 8;
-    r[0] = (uint32_t)best_ec; r[1] = (uint32_t)best_ml; r[2] = (uint32_t)(E.option == 2 ? 3 + best_w : 4); r[3] = ns;
-    r[4] = k.data; r[5] = k.selb; r[6] = k.tree; r[7] = 0;
     unsigned long long *d = E.dbg + (size_t)s * 8;
     d[0] = t_hist; d[1] = t_llhc; d[2] = t_cost; d[3] = t_chain; d[4] = n_pass; d[5] = n_round; d[6] = t_begin; d[7] = wall_clock64() - t_begin;
   }
@@ -1121,7 +1138,7 @@ __global__ void __launch_bounds__(EN_THREADS) k_bz_emit_data(SubTab T, EntTab E,
   const uint32_t ec = r[0], ml = r[1], ns = r[3], A = E.nsym[s] + 2, m = E.mtf_n[s];
   const uint16_t *sym = E.sym + E.soff[s];
   const uint8_t *sel = E.sel + E.sel_off[s];
-  const unsigned long long *gc = E.gcost + E.sel_off[s];
+  const unsigned long long *gc = E.gcbest + E.sel_off[s];
   for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) lens[i] = E.lens[(size_t)s * 6 * BZ_LSTRIDE + i];
   __syncthreads();
   if ((uint32_t)tid < ec) {                                           // Prepare_Codes (huffman-encoding.adb:45-80), bit order kept
@@ -1360,7 +1377,7 @@ struct Bz2State {
   // MTF / symbol space
   DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
   // entropy coders and output
-  DBuf sel_off, rank_idx, gcost, sel, lens, res, woff, words, jobs, job_first, outw, dbg, deflist, order;
+  DBuf sel_off, rank_idx, gcost, gcbest, sel, lens, res, woff, words, jobs, job_first, outw, dbg, deflist, order;
   // stream level
   DBuf rs1, epre, bstart, blen, etab, seg_off, seg, seg_cnt, extra;
   bool etab_ready = false;
@@ -1373,7 +1390,7 @@ struct Bz2State {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
-            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order};
+            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -1581,7 +1598,7 @@ static int bz_entropy_emit(Ctx *c, int option) {
   for (uint32_t s = 0; s <= nsb; s++) so[s] = B->h_off[s] / BZ_GROUP + 2 * s;
   const uint32_t selcap = so[nsb] + 8;
   B->selcap = selcap;
-  if ((rc = dbuf_ensure(c, B->sel_off, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->rank_idx, 4ull * selcap)) || (rc = dbuf_ensure(c, B->gcost, 8ull * selcap)) ||
+  if ((rc = dbuf_ensure(c, B->sel_off, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->rank_idx, 4ull * selcap)) || (rc = dbuf_ensure(c, B->gcost, 8ull * selcap)) || (rc = dbuf_ensure(c, B->gcbest, 8ull * selcap)) ||
       (rc = dbuf_ensure(c, B->sel, selcap)) || (rc = dbuf_ensure(c, B->lens, 6ull * BZ_LSTRIDE * nsb)) || (rc = dbuf_ensure(c, B->res, 32ull * nsb)) ||
       (rc = dbuf_ensure(c, B->woff, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->dbg, 64ull * nsb)) || (rc = dbuf_ensure(c, B->deflist, 4ull * selcap))) return rc;
   BZ_HIP(hipMemcpyAsync(B->sel_off.p, so.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
@@ -1592,7 +1609,7 @@ static int bz_entropy_emit(Ctx *c, int option) {
   BZ_HIP(hipMemcpyAsync(B->order.p, order.data(), 4ull * nsb, hipMemcpyHostToDevice, st));
   EntTab E;
   E.sym = B->sym.as<uint16_t>(); E.soff = B->soff.as<uint32_t>(); E.mtf_n = B->mtf_n.as<uint32_t>(); E.nsym = B->nsym.as<uint32_t>();
-  E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<unsigned long long>();
+  E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<unsigned long long>(); E.gcbest = B->gcbest.as<unsigned long long>();
   E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option; E.dbg = B->dbg.as<unsigned long long>(); E.deflist = B->deflist.as<uint32_t>(); E.order = B->order.as<uint32_t>();
   SubTab T = subtab(B);
   const size_t rank_lds = (size_t)(BZ_MAX_SEL * 3 + 64);
