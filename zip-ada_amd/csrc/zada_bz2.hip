@@ -460,47 +460,90 @@ __global__ void __launch_bounds__(1024) k_bz_filter_emit(const uint32_t *__restr
   uint32_t j = tscan[blockIdx.x] + incl - c;
   for (uint32_t k = 0; k < 8; k++) if ((fl >> k) & 1u) { ckey[j] = cl[ev[k]] - off; cval[j] = ev[k]; j++; }
 }
-// C = the filtered rows' space (sub-block s owns [coff[s], coff[s] + cm[s])), its tiles in `tiles`
-__global__ void __launch_bounds__(1024) k_bz_runfirst(const uint32_t *__restrict__ ckey, SubTab C, const Tile *__restrict__ tiles, uint32_t *__restrict__ rf) {
+// C = the filtered rows' space (sub-block s owns [coff[s], coff[s] + cm[s])), its tiles in `tiles`.  After the sort the rows of a
+// group are together (equal keys).  Three kernels, a thread taking eight consecutive slots, scans inside the tile and a carry
+// from a scan over the tiles' aggregates:  (1) per tile, the last slot that starts a run of equal keys;  (2) every slot's run
+// start -> its row; the element goes there; slots whose second half differs from the slot before start a new group (hd);
+// (3) every slot's group start -> its element's class; elements alone in their group stop being marked.
+__global__ void __launch_bounds__(1024) k_bz_rf_agg(const uint32_t *__restrict__ ckey, SubTab C, const Tile *__restrict__ tiles, uint32_t *__restrict__ agg_out) {
+  __shared__ uint32_t l17[17];
   const Tile t = tiles[blockIdx.x];
-  const uint32_t n = C.n[t.sb], off = C.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, j = off + l;
-    rf[j] = (l == 0 || ckey[j] != ckey[j - 1]) ? j + 1 : 0u;
-  }
+  const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo);
+  const uint32_t r0 = threadIdx.x * 8;
+  uint32_t v = 0;
+  for (uint32_t k = 0; k < 8; k++) if (r0 + k < m) { const uint32_t l = t.lo + r0 + k, j = coff + l; if (l == 0 || ckey[j] != ckey[j - 1]) v = j + 1; }
+  OpMax mx;
+  uint32_t tot;
+  wg_scan_incl(v, l17, mx, &tot);
+  if (threadIdx.x == 0) agg_out[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(1024) k_bz_place(const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cval, const uint32_t *__restrict__ rfs, SubTab T, SubTab C,
+__global__ void __launch_bounds__(1024) k_bz_place(const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cval, const uint32_t *__restrict__ carry_rf, SubTab T, SubTab C,
                                                    const Tile *__restrict__ tiles, const uint32_t *__restrict__ cl, uint32_t h, uint32_t *__restrict__ sa,
-                                                   uint32_t *__restrict__ sec, uint32_t *__restrict__ rowbuf) {
+                                                   uint32_t *__restrict__ hd, uint32_t *__restrict__ agg_out) {
+  __shared__ uint32_t l17[17];
   const Tile t = tiles[blockIdx.x];
   const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo), n = T.n[t.sb], off = T.off[t.sb];
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t j = coff + t.lo + i, e = cval[j];
-    const uint32_t row = off + ckey[j] + (j - (rfs[j] - 1));
-    sa[row] = e;
-    rowbuf[j] = row;
-    uint32_t l = e - off + h;
-    if (l >= n) l -= n;
-    sec[j] = cl[off + l];
+  const uint32_t r0 = threadIdx.x * 8;
+  uint32_t key[8], val[8], flags = 0, last = 0;
+  auto second = [&](uint32_t e) -> uint32_t { uint32_t l = e - off + h; if (l >= n) l -= n; return cl[off + l]; };
+  uint32_t sec_prev = 0;
+  for (uint32_t k = 0; k < 8; k++) {
+    key[k] = 0; val[k] = 0;
+    if (r0 + k < m) {
+      const uint32_t l = t.lo + r0 + k, j = coff + l;
+      key[k] = ckey[j]; val[k] = cval[j];
+      const uint32_t pk = k ? key[k - 1] : (l ? ckey[j - 1] : 0u);
+      if (l == 0 || key[k] != pk) { flags |= 1u << k; last = j + 1; }
+    }
   }
-}
-__global__ void __launch_bounds__(1024) k_bz_heads(const uint32_t *__restrict__ rf, const uint32_t *__restrict__ sec, const uint32_t *__restrict__ rowbuf, SubTab C,
-                                                   const Tile *__restrict__ tiles, uint32_t *__restrict__ hd) {
-  const Tile t = tiles[blockIdx.x];
-  const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t j = coff + t.lo + i;
-    hd[j] = (rf[j] != 0 || sec[j] != sec[j - 1]) ? rowbuf[j] + 1 : 0u;
+  if (r0 < m && t.lo + r0 > 0) sec_prev = second(cval[coff + t.lo + r0 - 1]);       // the slot in front of this thread's first
+  OpMax mx;
+  const uint32_t incl = wg_scan_incl(last, l17, mx, nullptr);
+  uint32_t before = __shfl_up(incl, 1);
+  if ((threadIdx.x & 63) == 0) { before = 0; for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before = mx(before, l17[k]); }
+  uint32_t run = mx(carry_rf[blockIdx.x], before), hmax = 0;
+  for (uint32_t k = 0; k < 8; k++) {
+    if (r0 + k < m) {
+      const uint32_t j = coff + t.lo + r0 + k, e = val[k];
+      if ((flags >> k) & 1u) run = j + 1;
+      const uint32_t row = off + key[k] + (j - (run - 1));
+      sa[row] = e;
+      const uint32_t sc = second(e);
+      const uint32_t hv = (((flags >> k) & 1u) || sc != sec_prev) ? row + 1 : 0u;
+      hd[j] = hv;
+      hmax = mx(hmax, hv);
+      sec_prev = sc;
+    }
   }
+  __syncthreads();
+  uint32_t tot;
+  wg_scan_incl(hmax, l17, mx, &tot);
+  if (threadIdx.x == 0) agg_out[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict__ cval, const uint32_t *__restrict__ hd, const uint32_t *__restrict__ hds, SubTab C,
+__global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict__ cval, const uint32_t *__restrict__ hd, const uint32_t *__restrict__ carry_hd, SubTab C,
                                                       const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte) {
+  __shared__ uint32_t l17[17];
   const Tile t = tiles[blockIdx.x];
   const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, j = coff + l, e = cval[j];
-    cl[e] = hds[j] - 1;
-    if (hd[j] != 0 && (l + 1 == cn || hd[j + 1] != 0)) atomicAnd(&acte[e >> 5], ~(1u << (e & 31)));
+  const uint32_t r0 = threadIdx.x * 8;
+  uint32_t hv[9], last = 0;
+  for (uint32_t k = 0; k < 9; k++) {
+    const uint32_t l = t.lo + r0 + k;
+    hv[k] = l < cn ? hd[coff + l] : 1u;                                        // beyond the sub-block: as if a group started there
+    if (k < 8 && r0 + k < m && hv[k]) last = hv[k];
+  }
+  OpMax mx;
+  const uint32_t incl = wg_scan_incl(last, l17, mx, nullptr);
+  uint32_t before = __shfl_up(incl, 1);
+  if ((threadIdx.x & 63) == 0) { before = 0; for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before = mx(before, l17[k]); }
+  uint32_t run = mx(carry_hd[blockIdx.x], before);
+  for (uint32_t k = 0; k < 8; k++) {
+    if (r0 + k < m) {
+      const uint32_t j = coff + t.lo + r0 + k, e = cval[j];
+      if (hv[k]) run = hv[k];
+      cl[e] = run - 1;
+      if (hv[k] != 0 && hv[k + 1] != 0) atomicAnd(&acte[e >> 5], ~(1u << (e & 31)));
+    }
   }
 }
 // rows ordered by `prefix` bytes: a sub-block whose rotations are that short is done (equal rotations stay in one group)
@@ -1537,11 +1580,10 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
     hipLaunchKernelGGL(k_bz_filter_emit, dim3(net), dim3(1024), 0, st, valA, acte, cl, T, ET, done, h, hr, keyA, cv0);
     radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 0); radix(C, CT, CF, nct, keyB, cv1, keyA, cv0, 8);
     radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 16);        // first rows are below 2^20 (block capacity 900 000)
-    hipLaunchKernelGGL(k_bz_runfirst, dim3(nct), dim3(1024), 0, st, keyB, C, CT, hv);
-    scan_launch<OpMax, true>(st, FArr{hv}, M, agg, hr, nullptr);
-    hipLaunchKernelGGL(k_bz_place, dim3(nct), dim3(1024), 0, st, keyB, cv1, hr, T, C, CT, cl, h, valA, valB, cv0);
-    hipLaunchKernelGGL(k_bz_heads, dim3(nct), dim3(1024), 0, st, hv, valB, cv0, C, CT, keyA);
-    scan_launch<OpMax, true>(st, FArr{keyA}, M, agg, hr, nullptr);
+    hipLaunchKernelGGL(k_bz_rf_agg, dim3(nct), dim3(1024), 0, st, keyB, C, CT, hv);
+    scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last run start before tile t
+    hipLaunchKernelGGL(k_bz_place, dim3(nct), dim3(1024), 0, st, keyB, cv1, hr, T, C, CT, cl, h, valA, keyA, hv);
+    scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last group start before tile t
     hipLaunchKernelGGL(k_bz_newclass, dim3(nct), dim3(1024), 0, st, cv1, keyA, hr, C, CT, cl, acte);
     hipLaunchKernelGGL(k_bz_done, dim3((nsb + 255) / 256), dim3(256), 0, st, T, 2 * h, done);
   }
