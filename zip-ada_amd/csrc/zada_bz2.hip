@@ -1370,17 +1370,19 @@ __global__ void __launch_bounds__(64) k_bz_segment(const uint8_t *__restrict__ i
       if (valid) { atomicAdd(&freq[xin], 1u); atomicSub(&freq[xout], 1u); }
       const uint32_t f = f0in + ii - oi + 1, g = f0out + io + (xin == xout ? 1u : 0u) - oo;
       double A = 0.0, Bv = 0.0, C = 0.0, D = 0.0;
-      int hasD = 0;
-      if (valid) { A = etab[f - 1]; Bv = etab[f]; C = etab[g]; hasD = g - 1 > 0; if (hasD) D = etab[g - 1]; }
+      if (valid) { A = etab[f - 1]; Bv = etab[f]; C = etab[g]; D = etab[g - 1]; }       // etab[0] = 0.0
       wave_sync();
       for (int j = 0; j < (int)cnt; j++) {
         entropy = entropy - lane_value(A, j);
         entropy = entropy + lane_value(Bv, j);
         entropy = entropy - lane_value(C, j);
-        if (__builtin_amdgcn_readlane(hasD, j)) entropy = entropy + lane_value(D, j);
-        const uint32_t seg_point = i0 + (uint32_t)j - SEG_WINDOW;
-        if (fabs(entropy - mark1) > thr1 && seg_point > im1 && seg_point - im1 > 4000u) { if (lane == 0) s1[n1] = seg_point; n1++; im1 = seg_point; mark1 = entropy; }
-        if (t2 && fabs(entropy - mark2) > thr2 && seg_point > im2 && seg_point - im2 > 8000u) { if (lane == 0) s2[n2] = seg_point; n2++; im2 = seg_point; mark2 = entropy; }
+        entropy = entropy + lane_value(D, j);           // 0.0 where the reference adds nothing (the byte has left the window): the same value
+        // the marks move rarely: one uniform test for both profiles, the rest behind it
+        if (__ballot(fabs(entropy - mark1) > thr1 || (t2 && fabs(entropy - mark2) > thr2))) {
+          const uint32_t seg_point = i0 + (uint32_t)j - SEG_WINDOW;
+          if (fabs(entropy - mark1) > thr1 && seg_point > im1 && seg_point - im1 > 4000u) { if (lane == 0) s1[n1] = seg_point; n1++; im1 = seg_point; mark1 = entropy; }
+          if (t2 && fabs(entropy - mark2) > thr2 && seg_point > im2 && seg_point - im2 > 8000u) { if (lane == 0) s2[n2] = seg_point; n2++; im2 = seg_point; mark2 = entropy; }
+        }
       }
     }
   }
