@@ -760,13 +760,11 @@ struct EntTab {
   int option;                  // 0 / 1 / 2 = block_100k / 400k / 900k
 };
 
-__global__ void __launch_bounds__(64) k_bz_rank(EntTab E, uint32_t nsb) {
-  extern __shared__ uint8_t dyn[];
-  const uint32_t s = E.order[blockIdx.x];
+__global__ void __launch_bounds__(64) k_bz_rank(EntTab E, uint32_t first) {
+  extern __shared__ __align__(8) uint32_t P[];                 // key << 16 | group number, 1-based: a node's two sons are one 8-byte read
+  const uint32_t s = E.order[first + blockIdx.x];
   const int lane = threadIdx.x, w = blockIdx.y;                // one ranking (sample width) per workgroup
   const int width = E.option == 2 ? 3 + w : 4;
-  uint8_t *K = dyn;                                            // keys, 1-based
-  uint16_t *I = (uint16_t *)(K + ((BZ_MAX_SEL + 15) & ~15));  // group numbers, 1-based
   const uint32_t m = E.mtf_n[s], ns = 1 + (m - 1) / BZ_GROUP;
   const uint16_t *sym = E.sym + E.soff[s];
   const int eob = (int)E.nsym[s] + 1;
@@ -775,38 +773,41 @@ __global__ void __launch_bounds__(64) k_bz_rank(EntTab E, uint32_t nsb) {
     const uint32_t cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
     uint32_t key = 0;
     for (uint32_t k = 0; k < cnt; k++) key += (int)sym[g * BZ_GROUP + k] <= last_sampled ? 1u : 0u;
-    K[g + 1] = (uint8_t)key; I[g + 1] = (uint16_t)(g + 1);
+    P[g + 1] = (key << 16) | (g + 1);
   }
   wave_sync();
   if (lane == 0) {
     int Max = (int)ns;
-    uint8_t tk; uint16_t ti;
+    uint32_t t;
     auto sift = [&](int S) {
       int C = S;
       for (;;) {
         int Son = 2 * C;
         if (Son > Max) break;
-        if (Son < Max && K[Son] < K[Son + 1]) Son++;
-        K[C] = K[Son]; I[C] = I[Son];
+        const uint2 two = *(const uint2 *)&P[Son];
+        uint32_t v = two.x;
+        if (Son < Max && (two.x >> 16) < (two.y >> 16)) { Son++; v = two.y; }
+        P[C] = v;
         C = Son;
       }
       while (C != S) {
         const int F = C / 2;
-        if (K[F] < tk) { K[C] = K[F]; I[C] = I[F]; C = F; } else break;
+        const uint32_t f = P[F];
+        if ((f >> 16) < (t >> 16)) { P[C] = f; C = F; } else break;
       }
-      K[C] = tk; I[C] = ti;
+      P[C] = t;
     };
-    for (int J = Max / 2; J >= 1; J--) { tk = K[J]; ti = I[J]; sift(J); }
+    for (int J = Max / 2; J >= 1; J--) { t = P[J]; sift(J); }
     while (Max > 1) {
-      tk = K[Max]; ti = I[Max];
-      K[Max] = K[1]; I[Max] = I[1];
+      t = P[Max];
+      P[Max] = P[1];
       Max--;
       sift(1);
     }
   }
   wave_sync();
   uint16_t *out = E.rank_idx + (size_t)w * E.selcap + E.sel_off[s];
-  for (uint32_t i = lane; i < ns; i += 64) out[i] = I[i + 1];
+  for (uint32_t i = lane; i < ns; i += 64) out[i] = (uint16_t)(P[i + 1] & 0xFFFFu);
 }
 
 constexpr int EN_THREADS = 512;
@@ -1656,12 +1657,18 @@ static int bz_entropy_emit(Ctx *c, int option) {
   E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<unsigned long long>(); E.gcbest = B->gcbest.as<unsigned long long>();
   E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option; E.dbg = B->dbg.as<unsigned long long>(); E.deflist = B->deflist.as<uint32_t>(); E.order = B->order.as<uint32_t>();
   SubTab T = subtab(B);
-  const size_t rank_lds = (size_t)(BZ_MAX_SEL * 3 + 64);
+  // the rankings are replayed by single lanes: the small ones (most of them) take little LDS, so that many share a CU
+  constexpr uint32_t RANK_SMALL_NS = 2040;
+  const size_t rank_lds_big = 4 * (size_t)(BZ_MAX_SEL + 6), rank_lds_small = 4 * (size_t)(RANK_SMALL_NS + 8);
   if (!B->rank_attr) {
-    BZ_HIP(hipFuncSetAttribute((const void *)k_bz_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
+    BZ_HIP(hipFuncSetAttribute((const void *)k_bz_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds_big));
     B->rank_attr = true;
   }
-  hipLaunchKernelGGL(k_bz_rank, dim3(nsb, option == 2 ? 2 : 1), dim3(64), rank_lds, st, E, nsb);
+  uint32_t nbig = 0;
+  while (nbig < nsb && 1 + B->h_n[order[nbig]] / BZ_GROUP > RANK_SMALL_NS) nbig++;       // order: largest first
+  const uint32_t nwid = option == 2 ? 2 : 1;
+  if (nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nbig, nwid), dim3(64), rank_lds_big, st, E, 0u);
+  if (nsb > nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nsb - nbig, nwid), dim3(64), rank_lds_small, st, E, nbig);
   c->tmark("bz:rank");
   hipLaunchKernelGGL(k_bz_entropy, dim3(nsb), dim3(EN_THREADS), 0, st, E, nsb);
   hipLaunchKernelGGL(k_bz_block_bits, dim3((nsb + 255) / 256), dim3(256), 0, st, T, B->res.as<uint32_t>());
