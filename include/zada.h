@@ -185,6 +185,28 @@ int zada_bzip2_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n, v
  * raw length, splitting tactic kept (0 single, 1 parts_4, 2 segmented_1, 3 segmented_2), its number of sub-blocks.
  * Returns the number of values there are; at most cap_items are stored. */
 uint64_t zada_bz2_last_blocks(zada_ctx *ctx, uint64_t *dst, uint64_t cap_items);
+/* One BZip2 stream over several contexts / GPUs (BASELINE config 5: blocks sharded over the GPUs of a node).  Blocks are
+ * independent once their limits are known (bzip2-encoding.adb:1161-1209) and once the bit phase in front of them is known
+ * (:1312-1318), so a context takes the blocks that START inside its range of the stream:
+ *   zada_bz2_range_open     d_buf holds the stream bytes [buf_off, buf_off + buf_len): the range and, behind it, enough of the
+ *                           next ranges for the last block (a block takes at most ten capacities: 9 000 000 bytes + 259).  `start`
+ *                           = where the range's first block starts (0 for the first range, the previous range's *next_start
+ *                           otherwise: the one sequential hand-over, 8 bytes), own_end = where the range ends.  Fast (block limits only).
+ *   zada_bz2_range_encode   every piece of every tactic of those blocks through Encode_Block (the work).
+ *   zada_bz2_range_table    per block 12 values -- per tactic: bits, pieces, the pieces' CRCs folded from zero.  All ranks'
+ *                           tables, in stream order, go to
+ *   zada_bz2_select         (pure host arithmetic, any rank): tactic per block, stream bit position and combined CRC behind
+ *                           the blocks, from the position / CRC in front of them (32 and 0 at the stream's start).
+ *   zada_bz2_range_assemble the range's bytes of the stream from byte bit_begin / 8 on; flags: 1 = stream header in front
+ *                           (bit_begin must be 32), 2 = footer with footer_crc behind.  Neighbours share a byte when a
+ *                           range does not end on a byte: the gatherer ORs (as for the Deflate ranges). */
+int zada_bz2_range_open(zada_ctx *ctx, int method, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t stream_total,
+                        uint64_t start, uint64_t own_end, uint64_t *next_start, uint64_t *nblocks);
+int zada_bz2_range_encode(zada_ctx *ctx);
+uint64_t zada_bz2_range_table(zada_ctx *ctx, uint64_t *tab, uint64_t cap_blocks);
+void zada_bz2_select(uint64_t nblk, const uint64_t *tab, uint64_t bitpos_in, uint32_t crc_in, uint8_t *choice, uint64_t *bitpos_out, uint32_t *crc_out);
+int zada_bz2_range_assemble(zada_ctx *ctx, const uint8_t *choice, uint64_t nblk, uint64_t bit_begin, int flags, uint32_t footer_crc,
+                            void *d_out, uint64_t cap, uint64_t *nbytes);
 /* Test hooks: sub-blocks (Encode_Block jobs) of a host buffer through the stages, and the tables they leave. */
 int zada_bz2_run(zada_ctx *ctx, const uint8_t *in, uint64_t n, uint32_t nsb, const uint64_t *starts, const uint32_t *lens, int option, int stages);
 int zada_bz2_fetch(zada_ctx *ctx, const char *name, void *dst, uint64_t cap, uint64_t *nbytes);

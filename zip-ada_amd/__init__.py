@@ -88,6 +88,13 @@ def load_library():
     L.zada_range_emit.argtypes = [vp, vp, u64, u64p]
     L.zada_bzip2.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, vp, vp]
     L.zada_bzip2_device.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
+    L.zada_bz2_range_open.argtypes = [vp, i32, vp, u64, u64, u64, u64, u64, u64p, u64p]
+    L.zada_bz2_range_encode.argtypes = [vp]
+    L.zada_bz2_range_table.restype = ctypes.c_uint64
+    L.zada_bz2_range_table.argtypes = [vp, vp, u64]
+    L.zada_bz2_select.restype = None
+    L.zada_bz2_select.argtypes = [u64, vp, u64, ctypes.c_uint32, vp, u64p, u32p]
+    L.zada_bz2_range_assemble.argtypes = [vp, vp, u64, u64, i32, ctypes.c_uint32, vp, u64, u64p]
     L.zada_bz2_last_blocks.restype = ctypes.c_uint64
     L.zada_bz2_last_blocks.argtypes = [vp, vp, u64]
     L.zada_crc32_combine.restype = ctypes.c_uint32
@@ -192,6 +199,49 @@ class Encoder:
         if rc < 0:
             self._err(rc, "zada_bzip2_device")
         return rc, ol.value, c.value
+
+    # ---- one BZip2 stream over several contexts (zada_bz2_range_*, include/zada.h) ----
+    def bz2_range_open(self, d_buf, buf_len, buf_off, stream_total, start, own_end, method=14):
+        """Block limits of the blocks that start in [start, own_end).  Returns (next_start, number of blocks)."""
+        nxt, nb = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = self.lib.zada_bz2_range_open(self.ctx, method, d_buf, buf_len, buf_off, stream_total, start, own_end, ctypes.byref(nxt), ctypes.byref(nb))
+        if rc != 0:
+            self._err(rc, "zada_bz2_range_open")
+        return nxt.value, nb.value
+
+    def bz2_range_encode(self):
+        rc = self.lib.zada_bz2_range_encode(self.ctx)
+        if rc != 0:
+            self._err(rc, "zada_bz2_range_encode")
+
+    def bz2_range_table(self):
+        """numpy uint64 [blocks, 4 tactics, 3]: bits (all ones: the block has no such tactic), pieces, folded CRC."""
+        import numpy as np
+        nb = self.lib.zada_bz2_range_table(self.ctx, None, 0)
+        tab = np.zeros((max(int(nb), 1), 4, 3), np.uint64)
+        self.lib.zada_bz2_range_table(self.ctx, tab.ctypes.data, nb)
+        return tab[:nb]
+
+    def bz2_select(self, tab, bitpos_in=32, crc_in=0):
+        """Tactic per block along the stream.  Returns (choices uint8 array, bit position behind, combined CRC behind)."""
+        import numpy as np
+        tab = np.ascontiguousarray(tab, np.uint64)
+        nb = tab.shape[0]
+        choice = np.zeros(max(nb, 1), np.uint8)
+        bp, crc = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        self.lib.zada_bz2_select(nb, tab.ctypes.data, bitpos_in, crc_in, choice.ctypes.data, ctypes.byref(bp), ctypes.byref(crc))
+        return choice[:nb], bp.value, crc.value
+
+    def bz2_range_assemble(self, choice, bit_begin, d_out, cap, header=False, footer_crc=None):
+        """The range's bytes of the stream (from byte bit_begin // 8 on) into d_out.  Returns their number."""
+        import numpy as np
+        choice = np.ascontiguousarray(choice, np.uint8)
+        nbytes = ctypes.c_uint64(0)
+        flags = (1 if header else 0) | (2 if footer_crc is not None else 0)
+        rc = self.lib.zada_bz2_range_assemble(self.ctx, choice.ctypes.data if len(choice) else None, len(choice), bit_begin, flags, footer_crc or 0, d_out, cap, ctypes.byref(nbytes))
+        if rc != 0:
+            self._err(rc, "zada_bz2_range_assemble")
+        return nbytes.value
 
     def bz2_last_blocks(self):
         """[(raw start, raw length, tactic, sub-blocks)] of the last bzip2 call (bzip2-encoding.adb:1144, :1312-1318)."""

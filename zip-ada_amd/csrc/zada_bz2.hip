@@ -1428,6 +1428,12 @@ struct Bz2State {
   DBuf rs1, epre, bstart, blen, etab, seg_off, seg, seg_cnt, extra;
   bool etab_ready = false;
   std::vector<uint64_t> trace;      // per block: raw start, raw length, tactic kept, its number of sub-blocks
+  // the call in flight: every unique piece's bits are kept until the tactics are chosen
+  struct KeptSub { uint64_t bits, woff; uint32_t crc, buf; };
+  struct BlkPlan { uint64_t start = 0; uint32_t len = 0; std::vector<uint32_t> tac[4]; };
+  std::vector<KeptSub> kept; std::vector<BlkPlan> plans; std::vector<DBuf> kept_bufs;
+  uint64_t min_bits_sum = 0;
+  std::vector<uint64_t> rg_bstart; std::vector<uint32_t> rg_blen; int rg_option = 2; const uint8_t *rg_in = nullptr;
   std::vector<uint32_t> h_res, h_woff, h_crc;
   uint64_t nwords = 0;
   uint32_t selcap = 0;
@@ -1453,6 +1459,7 @@ void bz2_destroy(Ctx *c) {
   if (!c->bz) return;
   Bz2State *B = (Bz2State *)c->bz;
   for (DBuf *b : B->all()) if (b->p) hipFree(b->p);
+  for (DBuf &b : B->kept_bufs) if (b.p) hipFree(b.p);
   delete B;
   c->bz = nullptr;
 }
@@ -1692,172 +1699,211 @@ static int bz_entropy_emit(Ctx *c, int option) {
   return 0;
 }
 
-// BZip2.Encoding.Encode (:87-1431) of n bytes at d_in; the stream goes to d_out (cap bytes).  Returns ZADA_OK, ZADA_INEFFICIENT
-// when the stream is not smaller than the input (it is still delivered if it fits), ZADA_ABORTED, or an error.
-int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64_t size_hint, uint8_t *d_out, uint64_t cap, uint64_t *out_len,
-                      zada_feedback_fn fb, void *user) {
+// ---------------------------------------------------------------------------------------------------------------
+//  The stream level.  Encoding and choosing are separate: every unique sub-block of every block is encoded first (its bits
+//  are kept on the device), then the tactics are chosen along the stream (the choice of a block depends on the bit phase
+//  the blocks before it leave, :1312-1318), then the chosen pieces are copied to their places.  That order is what lets
+//  several GPUs take block ranges of one stream (zada_bz2_range_*): sizes are exchanged, the choice is replayed everywhere.
+// ---------------------------------------------------------------------------------------------------------------
+using KeptSub = Bz2State::KeptSub;
+using BlkPlan = Bz2State::BlkPlan;
+static void bz_reset_call(Ctx *c) {
+  Bz2State *B = bz_state(c);
+  for (DBuf &b : B->kept_bufs) if (b.p) hipFree(b.p);
+  B->kept_bufs.clear(); B->kept.clear(); B->plans.clear();       // (the trace of the last call stays)
+  B->min_bits_sum = 0;
+}
+
+// Block limits (:1161-1209, :1406-1423) of the stretch [pos0, pos0 + span_len) of the stream; d_in is indexed by stream position.
+// ends_stream: the stretch ends where the stream ends; otherwise a block that reaches the stretch's end was cut by it and is
+// left out.  Blocks that start at or after own_end are left out as well.  *next = where the first block left out starts.
+static int bz_span_blocks(Ctx *c, int option, const uint8_t *d_in, uint64_t pos0, uint64_t span_len, bool ends_stream, int64_t size_hint, uint64_t own_end,
+                          std::vector<uint64_t> &bstart, std::vector<uint32_t> &blen, uint64_t *next) {
   Bz2State *B = bz_state(c);
   hipStream_t st = c->stream;
   int rc;
-  if (cap < 64) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
   const int level = option == 0 ? 1 : option == 1 ? 4 : 9;
   const int32_t block_capacity = 100000 * level;
-  B->trace.clear();
-  if (fb && fb(0, user)) return ZADA_ABORTED;
-  // ---- final stream: words with bit 31 first ----
-  const uint64_t capw = cap / 4 + 8;
-  if ((rc = dbuf_ensure(c, B->outw, 4 * capw + 64)) || (rc = dbuf_ensure(c, B->extra, 64))) return rc;
-  BZ_HIP(hipMemsetAsync(B->outw.p, 0, 4 * capw + 64, st));
-  {
+  const float fc = (float)block_capacity, f_lo = fc * 1.05f, f_hi = fc * 1.30f;        // :1406-1414
+  const uint32_t cap_blocks = (uint32_t)(span_len / ((uint64_t)block_capacity * 3 / 8) + 8);
+  if ((rc = dbuf_ensure(c, B->rs1, 4 * (span_len + 16))) || (rc = dbuf_ensure(c, B->epre, 4 * (span_len + 16))) || (rc = dbuf_ensure(c, B->agg, 4 * ((span_len + 16) / SC_TILE + 16))) ||
+      (rc = dbuf_ensure(c, B->bstart, 8ull * cap_blocks)) || (rc = dbuf_ensure(c, B->blen, 4ull * cap_blocks)) || (rc = dbuf_ensure(c, B->scal, 64))) return rc;
+  uint32_t *rs1 = B->rs1.as<uint32_t>(), *E = B->epre.as<uint32_t>(), *agg = B->agg.as<uint32_t>();
+  scan_launch<OpMax, true>(st, FRunStart1{d_in + pos0}, span_len, agg, rs1, nullptr);
+  scan_launch<OpSum, false>(st, FPieceEnd{d_in + pos0, rs1, span_len}, span_len + 1, agg, E, nullptr);
+  uint32_t *d_count = B->scal.as<uint32_t>() + 8;
+  hipLaunchKernelGGL(k_bz_acquire, dim3(1), dim3(64), 0, st, rs1, E, span_len, size_hint < 0 ? size_hint : size_hint - (int64_t)pos0, block_capacity, f_lo, f_hi,
+                     B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), cap_blocks, d_count);
+  c->tmark("bz:acquire");
+  uint32_t nblk = 0;
+  BZ_HIP(hipMemcpyAsync(&nblk, d_count, 4, hipMemcpyDeviceToHost, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  if (nblk > cap_blocks) { c->err = "bzip2: block table overflow"; return ZADA_E_HIP; }
+  bstart.resize(nblk); blen.resize(nblk);
+  BZ_HIP(hipMemcpy(bstart.data(), B->bstart.p, 8ull * nblk, hipMemcpyDeviceToHost));
+  BZ_HIP(hipMemcpy(blen.data(), B->blen.p, 4ull * nblk, hipMemcpyDeviceToHost));
+  if (!ends_stream) while (nblk > 0 && bstart[nblk - 1] + blen[nblk - 1] >= span_len) nblk--;
+  for (uint32_t k = 0; k < nblk; k++) bstart[k] += pos0;                              // stream positions from here on
+  uint32_t keep = nblk;
+  while (keep > 0 && bstart[keep - 1] >= own_end) keep--;
+  *next = keep < nblk ? bstart[keep] : (nblk ? bstart[nblk - 1] + blen[nblk - 1] : pos0);
+  bstart.resize(keep); blen.resize(keep);
+  return 0;
+}
+
+// Segmentation and every stage of Encode_Block for the given blocks: appends to B->plans / B->kept.
+static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::vector<uint64_t> &bstart, const std::vector<uint32_t> &blen,
+                            zada_feedback_fn fb, void *user, double prog0, double prog1) {
+  Bz2State *B = bz_state(c);
+  hipStream_t st = c->stream;
+  int rc;
+  const uint32_t nblk = (uint32_t)bstart.size();
+  if (nblk == 0) return 0;
+  if ((rc = dbuf_ensure(c, B->bstart, 8ull * nblk)) || (rc = dbuf_ensure(c, B->blen, 4ull * nblk))) return rc;
+  BZ_HIP(hipMemcpy(B->bstart.p, bstart.data(), 8ull * nblk, hipMemcpyHostToDevice));
+  BZ_HIP(hipMemcpy(B->blen.p, blen.data(), 4ull * nblk, hipMemcpyHostToDevice));
+  // ---- segmentation (block_900k only) ----
+  std::vector<uint32_t> seg_off(2ull * nblk + 1, 0), seg, seg_cnt(2ull * nblk, 0);
+  if (option == 2) {
+    if (!B->etab_ready) {
+      std::vector<double> et(SEG_WINDOW + 2);
+      const double inv = 1.0 / (double)SEG_WINDOW;
+      et[0] = 0.0;
+      for (int f = 1; f <= SEG_WINDOW + 1; f++) { const double pr = (double)f * inv; et[f] = -(pr * log(pr)); }
+      if ((rc = dbuf_ensure(c, B->etab, 8ull * et.size()))) return rc;
+      BZ_HIP(hipMemcpy(B->etab.p, et.data(), 8ull * et.size(), hipMemcpyHostToDevice));
+      B->etab_ready = true;
+    }
+    uint64_t so = 0;
+    for (uint32_t k = 0; k < nblk; k++) { seg_off[2 * k] = (uint32_t)so; so += blen[k] / 4000 + 2; seg_off[2 * k + 1] = (uint32_t)so; so += blen[k] / 8000 + 2; }
+    seg_off[2ull * nblk] = (uint32_t)so;
+    if ((rc = dbuf_ensure(c, B->seg_off, 4ull * (2ull * nblk + 1))) || (rc = dbuf_ensure(c, B->seg, 4 * so + 16)) || (rc = dbuf_ensure(c, B->seg_cnt, 8ull * nblk + 16))) return rc;
+    BZ_HIP(hipMemcpyAsync(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bz_segment, dim3(nblk), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
+                       (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
+    c->tmark("bz:segment");
+    seg.resize(so);
+    BZ_HIP(hipMemcpyAsync(seg.data(), B->seg.p, 4 * so, hipMemcpyDeviceToHost, st));
+    BZ_HIP(hipMemcpyAsync(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost, st));
+    BZ_HIP(hipStreamSynchronize(st));
+  }
+  const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 640) << 20;
+  uint32_t k0 = 0;
+  while (k0 < nblk) {
+    std::vector<uint64_t> starts; std::vector<uint32_t> lens;
+    const size_t plan0 = B->plans.size();
+    uint64_t est = 0;
+    uint32_t k1 = k0;
+    for (; k1 < nblk; k1++) {
+      BlkPlan P;
+      const uint64_t bs = bstart[k1]; const uint32_t bl = blen[k1];
+      P.start = bs; P.len = bl;
+      const size_t first_sub = starts.size();
+      auto sub_of = [&](uint64_t s0, uint32_t l0) -> uint32_t {                       // pieces that several tactics share are encoded once
+        for (size_t i = first_sub; i < starts.size(); i++) if (starts[i] == s0 && lens[i] == l0) return (uint32_t)i;
+        starts.push_back(s0); lens.push_back(l0);
+        return (uint32_t)(starts.size() - 1);
+      };
+      uint64_t e_blk = 0;
+      const size_t before = starts.size();
+      P.tac[0].push_back(sub_of(bs, bl));                                            // single
+      if (option == 2) {
+        const uint32_t size = bl / 4;                                                  // parts_4 :1237-1253
+        uint32_t stop = 0;
+        for (uint32_t count = 1; count <= 4; count++) { const uint32_t start = stop + 1; stop = count == 4 ? bl : count * size; P.tac[1].push_back(sub_of(bs + start - 1, stop - start + 1)); }
+        for (int t = 0; t < 2; t++) {                                                  // segmented_1 / _2 :1265-1297
+          const uint32_t cnt = seg_cnt[2 * k1 + t], *sp = seg.data() + seg_off[2 * k1 + t];
+          if (cnt == 0) P.tac[2 + t].push_back(sub_of(bs, 0));
+          uint32_t index_start = 1;
+          for (uint32_t q = 0; q < cnt; q++) { P.tac[2 + t].push_back(sub_of(bs + index_start - 1, sp[q] - index_start + 1)); index_start = sp[q] + 1; }
+        }
+      }
+      for (size_t i = before; i < starts.size(); i++) e_blk += (uint64_t)lens[i] + lens[i] / 4 + 8;
+      if (k1 > k0 && est + e_blk > batch_elems) { starts.resize(before); lens.resize(before); break; }
+      est += e_blk;
+      B->plans.push_back(std::move(P));
+    }
+    if ((rc = bz_transform(c, d_in, starts, lens)) || (rc = bz_mtf(c)) || (rc = bz_entropy_emit(c, option))) return rc;
+    // keep the batch's bit strings; the plans' piece numbers become numbers in B->kept
+    const uint32_t base = (uint32_t)B->kept.size(), bufno = (uint32_t)B->kept_bufs.size();
+    DBuf kb;
+    if ((rc = dbuf_ensure(c, kb, 4 * (B->nwords + 16)))) return rc;
+    BZ_HIP(hipMemcpyAsync(kb.p, B->words.p, 4 * B->nwords, hipMemcpyDeviceToDevice, st));
+    B->kept_bufs.push_back(kb);
+    for (uint32_t s = 0; s < B->nsb; s++) B->kept.push_back({B->h_res[8ull * s + 7], B->h_woff[s], B->h_crc[s], bufno});
+    for (size_t q = plan0; q < B->plans.size(); q++) {
+      uint64_t mn = ~0ull;
+      for (int t = 0; t < 4; t++) {
+        uint64_t bits = 0;
+        for (uint32_t &sb : B->plans[q].tac[t]) { sb += base; bits += B->kept[sb].bits; }
+        if (!B->plans[q].tac[t].empty() && bits < mn) mn = bits;
+      }
+      B->min_bits_sum += mn;
+    }
+    c->tmark("bz:keep");
+    BZ_HIP(hipStreamSynchronize(st));
+    k0 = k1;
+    if (fb && fb((int)(prog0 + (prog1 - prog0) * (double)k0 / (double)nblk), user)) return ZADA_ABORTED;
+  }
+  return 0;
+}
+
+// per block and tactic: bits, number of pieces, and the pieces' CRCs folded from zero (the combined CRC after the block is
+// rotl(before, pieces) xor that value, :1023-1026); bits = all ones for a tactic the block does not have
+static void bz_fill_table(Bz2State *B, std::vector<uint64_t> &tab) {
+  tab.assign(12 * B->plans.size(), 0);
+  for (size_t q = 0; q < B->plans.size(); q++)
+    for (int t = 0; t < 4; t++) {
+      const std::vector<uint32_t> &v = B->plans[q].tac[t];
+      uint64_t bits = 0; uint32_t fold = 0;
+      for (uint32_t sb : v) { bits += B->kept[sb].bits; fold = ((fold << 1) | (fold >> 31)) ^ B->kept[sb].crc; }
+      tab[12 * q + 3 * t] = v.empty() ? ~0ull : bits; tab[12 * q + 3 * t + 1] = v.size(); tab[12 * q + 3 * t + 2] = fold;
+    }
+}
+
+// the chosen pieces of the plans, bit-shifted to their places: the range's bytes from stream byte bit_begin / 8 on
+static int bz_assemble_range(Ctx *c, int option, const uint8_t *choice, uint64_t bit_begin, int flags, uint32_t footer_crc, uint8_t *d_out, uint64_t cap, uint64_t *nbytes_out) {
+  Bz2State *B = bz_state(c);
+  hipStream_t st = c->stream;
+  int rc;
+  const int level = option == 0 ? 1 : option == 1 ? 4 : 9;
+  const uint64_t base_bits = (flags & 1) ? 0 : (bit_begin & ~7ull);
+  uint64_t bitpos = bit_begin - base_bits, total = bitpos;
+  for (size_t q = 0; q < B->plans.size(); q++) for (uint32_t sb : B->plans[q].tac[choice[q]]) total += B->kept[sb].bits;
+  if (flags & 2) total += 80;
+  const uint64_t nbytes = (total + 7) / 8, nw = (nbytes + 3) / 4;
+  if (nbytes_out) *nbytes_out = nbytes;
+  if (nbytes > cap) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
+  if ((rc = dbuf_ensure(c, B->outw, 4 * nw + 64)) || (rc = dbuf_ensure(c, B->extra, 64))) return rc;
+  BZ_HIP(hipMemsetAsync(B->outw.p, 0, 4 * nw + 64, st));
+  if (flags & 1) {
     const uint32_t head = ((uint32_t)'B' << 24) | ((uint32_t)'Z' << 16) | ((uint32_t)'h' << 8) | (uint32_t)('0' + level);   // :1380-1387
     BZ_HIP(hipMemcpyAsync(B->outw.p, &head, 4, hipMemcpyHostToDevice, st));
   }
-  uint64_t bitpos = 32;
-  uint32_t combined_crc = 0;
-  const uint64_t cap_bits = cap * 8;
-  bool overflow = false;
-  const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 640) << 20;
-  const float fc = (float)block_capacity, f_lo = fc * 1.05f, f_hi = fc * 1.30f;        // :1406-1414
-  const uint64_t span_max = (uint64_t)(c->knob_bz_span_mib > 0 ? c->knob_bz_span_mib : 1024) << 20;
-  // ---- spans: the block chain is walked a stretch of the stream at a time (32-bit scans); a span starts where a block starts ----
-  uint64_t pos0 = 0;
-  do {
-    const uint64_t span_len = n - pos0 < span_max ? n - pos0 : span_max;
-    const bool last_span = pos0 + span_len == n;
-    // ---- block limits ----
-    const uint32_t cap_blocks = (uint32_t)(span_len / ((uint64_t)block_capacity * 3 / 8) + 8);
-    if ((rc = dbuf_ensure(c, B->rs1, 4 * (span_len + 16))) || (rc = dbuf_ensure(c, B->epre, 4 * (span_len + 16))) || (rc = dbuf_ensure(c, B->agg, 4 * ((span_len + 16) / SC_TILE + 16))) ||
-        (rc = dbuf_ensure(c, B->bstart, 8ull * cap_blocks)) || (rc = dbuf_ensure(c, B->blen, 4ull * cap_blocks)) || (rc = dbuf_ensure(c, B->scal, 64))) return rc;
-    uint32_t *rs1 = B->rs1.as<uint32_t>(), *E = B->epre.as<uint32_t>(), *agg = B->agg.as<uint32_t>();
-    scan_launch<OpMax, true>(st, FRunStart1{d_in + pos0}, span_len, agg, rs1, nullptr);
-    scan_launch<OpSum, false>(st, FPieceEnd{d_in + pos0, rs1, span_len}, span_len + 1, agg, E, nullptr);
-    uint32_t *d_count = B->scal.as<uint32_t>() + 8;
-    hipLaunchKernelGGL(k_bz_acquire, dim3(1), dim3(64), 0, st, rs1, E, span_len, size_hint < 0 ? size_hint : size_hint - (int64_t)pos0, block_capacity, f_lo, f_hi, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(),
-                       cap_blocks, d_count);
-    c->tmark("bz:acquire");
-    uint32_t nblk = 0;
-    BZ_HIP(hipMemcpyAsync(&nblk, d_count, 4, hipMemcpyDeviceToHost, st));
-    BZ_HIP(hipStreamSynchronize(st));
-    if (nblk > cap_blocks) { c->err = "bzip2: block table overflow"; return ZADA_E_HIP; }
-    std::vector<uint64_t> bstart(nblk); std::vector<uint32_t> blen(nblk);
-    BZ_HIP(hipMemcpy(bstart.data(), B->bstart.p, 8ull * nblk, hipMemcpyDeviceToHost));
-    BZ_HIP(hipMemcpy(blen.data(), B->blen.p, 4ull * nblk, hipMemcpyDeviceToHost));
-    if (!last_span) {      // a block that ends where the span ends was cut by the span, not by the rule: it opens the next span
-      while (nblk > 0 && bstart[nblk - 1] + blen[nblk - 1] >= span_len) nblk--;
-      if (nblk == 0) { c->err = "bzip2: span shorter than a block"; return ZADA_E_INVALID; }
-      bstart.resize(nblk); blen.resize(nblk);
-      BZ_HIP(hipMemcpy(B->bstart.p, bstart.data(), 8ull * nblk, hipMemcpyHostToDevice));
+  std::vector<std::vector<CopyJob>> jobs(B->kept_bufs.size());
+  std::vector<std::vector<uint64_t>> first(B->kept_bufs.size());
+  std::vector<uint64_t> dstw(B->kept_bufs.size(), 0);
+  for (size_t q = 0; q < B->plans.size(); q++)
+    for (uint32_t sb : B->plans[q].tac[choice[q]]) {
+      const KeptSub &K = B->kept[sb];
+      CopyJob J; J.src_word = K.woff; J.dpos = bitpos; J.bits = K.bits; J.first_dst_word = bitpos >> 5;
+      first[K.buf].push_back(dstw[K.buf]);
+      dstw[K.buf] += ((bitpos + K.bits + 31) >> 5) - (bitpos >> 5);
+      jobs[K.buf].push_back(J);
+      bitpos += K.bits;
     }
-    for (uint32_t k = 0; k < nblk; k++) bstart[k] += pos0;      // stream positions from here on
-    BZ_HIP(hipMemcpy(B->bstart.p, bstart.data(), 8ull * nblk, hipMemcpyHostToDevice));
-    // ---- segmentation (block_900k only) ----
-    std::vector<uint32_t> seg_off(2ull * nblk + 1, 0), seg, seg_cnt(2ull * nblk, 0);
-    if (option == 2) {
-      if (!B->etab_ready) {
-        std::vector<double> et(SEG_WINDOW + 2);
-        const double inv = 1.0 / (double)SEG_WINDOW;
-        et[0] = 0.0;
-        for (int f = 1; f <= SEG_WINDOW + 1; f++) { const double pr = (double)f * inv; et[f] = -(pr * log(pr)); }
-        if ((rc = dbuf_ensure(c, B->etab, 8ull * et.size()))) return rc;
-        BZ_HIP(hipMemcpy(B->etab.p, et.data(), 8ull * et.size(), hipMemcpyHostToDevice));
-        B->etab_ready = true;
-      }
-      uint64_t so = 0;
-      for (uint32_t k = 0; k < nblk; k++) { seg_off[2 * k] = (uint32_t)so; so += blen[k] / 4000 + 2; seg_off[2 * k + 1] = (uint32_t)so; so += blen[k] / 8000 + 2; }
-      seg_off[2ull * nblk] = (uint32_t)so;
-      if ((rc = dbuf_ensure(c, B->seg_off, 4ull * (2ull * nblk + 1))) || (rc = dbuf_ensure(c, B->seg, 4 * so + 16)) || (rc = dbuf_ensure(c, B->seg_cnt, 8ull * nblk + 16))) return rc;
-      BZ_HIP(hipMemcpyAsync(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_bz_segment, dim3(nblk), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
-                         (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
-      c->tmark("bz:segment");
-      seg.resize(so);
-      BZ_HIP(hipMemcpyAsync(seg.data(), B->seg.p, 4 * so, hipMemcpyDeviceToHost, st));
-      BZ_HIP(hipMemcpyAsync(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost, st));
-      BZ_HIP(hipStreamSynchronize(st));
-    }
-    const uint64_t span_used = bstart[nblk - 1] + blen[nblk - 1] - pos0;
-    // ---- batches of blocks ----
-    struct Plan { std::vector<uint32_t> tac[4]; };
-    uint32_t k0 = 0;
-    while (k0 < nblk && !overflow) {
-      std::vector<uint64_t> starts; std::vector<uint32_t> lens; std::vector<Plan> plans;
-      uint64_t est = 0;
-      uint32_t k1 = k0;
-      for (; k1 < nblk; k1++) {
-        Plan P;
-        const uint64_t bs = bstart[k1]; const uint32_t bl = blen[k1];
-        const size_t first_sub = starts.size();
-        auto sub_of = [&](uint64_t s0, uint32_t l0) -> uint32_t {
-          for (size_t i = first_sub; i < starts.size(); i++) if (starts[i] == s0 && lens[i] == l0) return (uint32_t)i;
-          starts.push_back(s0); lens.push_back(l0);
-          return (uint32_t)(starts.size() - 1);
-        };
-        uint64_t e_blk = 0;
-        const size_t before = starts.size();
-        P.tac[0].push_back(sub_of(bs, bl));                                            // single
-        if (option == 2) {
-          const uint32_t size = bl / 4;                                                  // parts_4 :1237-1253
-          uint32_t stop = 0;
-          for (uint32_t count = 1; count <= 4; count++) { const uint32_t start = stop + 1; stop = count == 4 ? bl : count * size; P.tac[1].push_back(sub_of(bs + start - 1, stop - start + 1)); }
-          for (int t = 0; t < 2; t++) {                                                  // segmented_1 / _2 :1265-1297
-            const uint32_t cnt = seg_cnt[2 * k1 + t], *sp = seg.data() + seg_off[2 * k1 + t];
-            if (cnt == 0) P.tac[2 + t].push_back(sub_of(bs, 0));
-            uint32_t index_start = 1;
-            for (uint32_t q = 0; q < cnt; q++) { P.tac[2 + t].push_back(sub_of(bs + index_start - 1, sp[q] - index_start + 1)); index_start = sp[q] + 1; }
-          }
-        }
-        for (size_t i = before; i < starts.size(); i++) e_blk += (uint64_t)lens[i] + lens[i] / 4 + 8;
-        if (!plans.empty() && est + e_blk > batch_elems) { starts.resize(before); lens.resize(before); break; }
-        est += e_blk;
-        plans.push_back(std::move(P));
-      }
-      if ((rc = bz_transform(c, d_in, starts, lens)) || (rc = bz_mtf(c)) || (rc = bz_entropy_emit(c, option))) return rc;
-      // ---- smallest tactic per block (:1312-1318), copy jobs ----
-      std::vector<CopyJob> jobs; std::vector<uint64_t> job_first;
-      uint64_t dstw = 0;
-      for (uint32_t k = k0; k < k1 && !overflow; k++) {
-        const Plan &P = plans[k - k0];
-        const uint64_t phase = bitpos & 7;
-        int best = 0; uint64_t best_idx = 0, best_bits = 0;
-        for (int t = 0; t < (option == 2 ? 4 : 1); t++) {
-          uint64_t bits = 0;
-          for (uint32_t sb : P.tac[t]) bits += B->h_res[8ull * sb + 7];
-          const uint64_t idx = (phase + bits) / 8;                                       // destination_index: whole bytes written
-          if (t == 0 || idx < best_idx) { best = t; best_idx = idx; best_bits = bits; }
-        }
-        if (bitpos + best_bits + 80 + 8 > cap_bits) { overflow = true; bitpos += best_bits; break; }
-        for (uint32_t sb : P.tac[best]) {
-          const uint64_t bits = B->h_res[8ull * sb + 7];
-          combined_crc = ((combined_crc << 1) | (combined_crc >> 31)) ^ B->h_crc[sb];
-          CopyJob J; J.src_word = B->h_woff[sb]; J.dpos = bitpos; J.bits = bits; J.first_dst_word = bitpos >> 5;
-          job_first.push_back(dstw);
-          dstw += ((bitpos + bits + 31) >> 5) - (bitpos >> 5);
-          jobs.push_back(J);
-          bitpos += bits;
-        }
-        B->trace.push_back(bstart[k]); B->trace.push_back(blen[k]); B->trace.push_back((uint64_t)best); B->trace.push_back(P.tac[best].size());
-      }
-      if (!jobs.empty()) {
-        job_first.push_back(dstw);
-        if ((rc = dbuf_ensure(c, B->jobs, sizeof(CopyJob) * jobs.size())) || (rc = dbuf_ensure(c, B->job_first, 8 * job_first.size()))) return rc;
-        BZ_HIP(hipMemcpyAsync(B->jobs.p, jobs.data(), sizeof(CopyJob) * jobs.size(), hipMemcpyHostToDevice, st));
-        BZ_HIP(hipMemcpyAsync(B->job_first.p, job_first.data(), 8 * job_first.size(), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_bz_assemble, dim3((uint32_t)((dstw + 255) / 256)), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), (uint32_t)jobs.size(),
-                           B->words.as<uint32_t>(), B->outw.as<uint32_t>());
-        c->tmark("bz:assemble");
-        BZ_HIP(hipStreamSynchronize(st));     // the job vectors go out of scope; the next batch reuses the words
-      }
-      k0 = k1;
-      if (fb && fb(3 + (int)(95.0 * ((double)pos0 + (double)(k0 < nblk ? bstart[k0] - pos0 : span_used)) / (double)(n ? n : 1)), user)) return ZADA_ABORTED;
-    }
-    pos0 += span_used;
-  } while (pos0 < n && !overflow);
-  if (overflow) {      // not smaller than the input: Compression_inefficient (zip-compress.adb:479-486)
-    if (out_len) *out_len = (bitpos + 80 + 7) / 8;
-    return ZADA_INEFFICIENT;
+  for (size_t b = 0; b < jobs.size(); b++) {
+    if (jobs[b].empty()) continue;
+    first[b].push_back(dstw[b]);
+    if ((rc = dbuf_ensure(c, B->jobs, sizeof(CopyJob) * jobs[b].size())) || (rc = dbuf_ensure(c, B->job_first, 8 * first[b].size()))) return rc;
+    BZ_HIP(hipMemcpyAsync(B->jobs.p, jobs[b].data(), sizeof(CopyJob) * jobs[b].size(), hipMemcpyHostToDevice, st));
+    BZ_HIP(hipMemcpyAsync(B->job_first.p, first[b].data(), 8 * first[b].size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bz_assemble, dim3((uint32_t)((dstw[b] + 255) / 256)), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), (uint32_t)jobs[b].size(),
+                       B->kept_bufs[b].as<uint32_t>(), B->outw.as<uint32_t>());
+    BZ_HIP(hipStreamSynchronize(st));          // the job tables are reused by the next buffer
   }
-  {                    // Write_Stream_Footer :1391-1403
-    uint32_t foot[4] = {0x17724538u, 0x50900000u | (combined_crc >> 16), combined_crc << 16, 0};
+  if (flags & 2) {      // Write_Stream_Footer :1391-1403
+    uint32_t foot[4] = {0x17724538u, 0x50900000u | (footer_crc >> 16), footer_crc << 16, 0};
     BZ_HIP(hipMemcpyAsync(B->extra.p, foot, 16, hipMemcpyHostToDevice, st));
     CopyJob J; J.src_word = 0; J.dpos = bitpos; J.bits = 80; J.first_dst_word = bitpos >> 5;
     uint64_t jf[2] = {0, ((bitpos + 80 + 31) >> 5) - (bitpos >> 5)};
@@ -1865,17 +1911,136 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
     BZ_HIP(hipMemcpyAsync(B->jobs.p, &J, sizeof J, hipMemcpyHostToDevice, st));
     BZ_HIP(hipMemcpyAsync(B->job_first.p, jf, 16, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_bz_assemble, dim3(1), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), 1u, B->extra.as<uint32_t>(), B->outw.as<uint32_t>());
-    bitpos += 80;
   }
-  const uint64_t nbytes = (bitpos + 7) / 8, nw = (nbytes + 3) / 4;
+  c->tmark("bz:assemble");
   if (((uintptr_t)d_out & 3) != 0 || nw * 4 > cap) {      // swap in place, then copy the bytes
     hipLaunchKernelGGL(k_bz_words_to_bytes, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, st, B->outw.as<uint32_t>(), nw, B->outw.as<uint32_t>());
     BZ_HIP(hipMemcpyAsync(d_out, B->outw.p, nbytes, hipMemcpyDeviceToDevice, st));
   } else hipLaunchKernelGGL(k_bz_words_to_bytes, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, st, B->outw.as<uint32_t>(), nw, (uint32_t *)d_out);
   BZ_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // namespace zada
+
+// The tactic of every block along the stream (:1312-1318) and the combined CRC (:1023-1026).  tab: 12 values per block, see
+// bz_fill_table.  Pure host arithmetic: every rank of a multi-GPU run replays it on the gathered tables.
+extern "C" void zada_bz2_select(uint64_t nblk, const uint64_t *tab, uint64_t bitpos_in, uint32_t crc_in, uint8_t *choice, uint64_t *bitpos_out, uint32_t *crc_out) {
+  uint64_t bitpos = bitpos_in;
+  uint32_t crc = crc_in;
+  for (uint64_t q = 0; q < nblk; q++) {
+    const uint64_t phase = bitpos & 7, *t = tab + 12 * q;
+    int best = 0; uint64_t best_idx = 0;
+    for (int k = 0; k < 4; k++) {
+      if (t[3 * k] == ~0ull) continue;
+      const uint64_t idx = (phase + t[3 * k]) / 8;                                   // destination_index: whole bytes written
+      if (k == 0 || idx < best_idx) { best = k; best_idx = idx; }
+    }
+    if (choice) choice[q] = (uint8_t)best;
+    const uint32_t rot = (uint32_t)(t[3 * best + 1] & 31u);
+    crc = (rot ? ((crc << rot) | (crc >> (32 - rot))) : crc) ^ (uint32_t)t[3 * best + 2];
+    bitpos += t[3 * best];
+  }
+  if (bitpos_out) *bitpos_out = bitpos;
+  if (crc_out) *crc_out = crc;
+}
+
+namespace zada {
+
+static void bz_set_trace(Bz2State *B, const uint8_t *choice) {
+  B->trace.clear();
+  for (size_t q = 0; q < B->plans.size(); q++) {
+    B->trace.push_back(B->plans[q].start); B->trace.push_back(B->plans[q].len); B->trace.push_back(choice[q]); B->trace.push_back(B->plans[q].tac[choice[q]].size());
+  }
+}
+
+// BZip2.Encoding.Encode (:87-1431) of n bytes at d_in; the stream goes to d_out (cap bytes).  Returns ZADA_OK, ZADA_INEFFICIENT
+// when the stream is not smaller than the input (it is still delivered if it fits), ZADA_ABORTED, or an error.
+int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64_t size_hint, uint8_t *d_out, uint64_t cap, uint64_t *out_len,
+                      zada_feedback_fn fb, void *user) {
+  Bz2State *B = bz_state(c);
+  int rc;
+  if (cap < 64) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
+  bz_reset_call(c);
+  B->trace.clear();
+  if (fb && fb(0, user)) return ZADA_ABORTED;
+  const uint64_t span_max = (uint64_t)(c->knob_bz_span_mib > 0 ? c->knob_bz_span_mib : 1024) << 20;
+  // ---- spans: the block chain is walked a stretch of the stream at a time (32-bit scans); a span starts where a block starts ----
+  uint64_t pos0 = 0;
+  do {
+    const uint64_t span_len = n - pos0 < span_max ? n - pos0 : span_max;
+    std::vector<uint64_t> bstart; std::vector<uint32_t> blen;
+    uint64_t next = pos0;
+    if ((rc = bz_span_blocks(c, option, d_in, pos0, span_len, pos0 + span_len == n, size_hint, ~0ull, bstart, blen, &next))) return rc;
+    if (bstart.empty()) { c->err = "bzip2: span shorter than a block"; return ZADA_E_INVALID; }
+    if ((rc = bz_blocks_encode(c, option, d_in, bstart, blen, fb, user, 3.0 + 95.0 * (double)pos0 / (double)(n ? n : 1), 3.0 + 95.0 * (double)next / (double)(n ? n : 1)))) return rc;
+    pos0 = next;
+    if (B->min_bits_sum + 32 + 80 > cap * 8) {      // cannot fit any more, whatever is chosen: Compression_inefficient (zip-compress.adb:479-486)
+      if (out_len) *out_len = (B->min_bits_sum + 32 + 80 + 7) / 8;
+      bz_reset_call(c);
+      return ZADA_INEFFICIENT;
+    }
+  } while (pos0 < n);
+  std::vector<uint64_t> tab;
+  bz_fill_table(B, tab);
+  std::vector<uint8_t> choice(B->plans.size());
+  uint64_t bit_end = 0; uint32_t crc = 0;
+  zada_bz2_select(B->plans.size(), tab.data(), 32, 0, choice.data(), &bit_end, &crc);
+  bz_set_trace(B, choice.data());
+  uint64_t nbytes = (bit_end + 80 + 7) / 8;
   if (out_len) *out_len = nbytes;
+  if (nbytes > cap) { bz_reset_call(c); return ZADA_INEFFICIENT; }
+  rc = bz_assemble_range(c, option, choice.data(), 32, 3, crc, d_out, cap, &nbytes);
+  bz_reset_call(c);
+  if (rc) return rc;
   if (fb && fb(100, user)) return ZADA_ABORTED;
   return nbytes >= n ? ZADA_INEFFICIENT : ZADA_OK;
+}
+
+// ---- one stream over several contexts / GPUs: a context takes the blocks that start inside its range ----
+int bz2_range_open(Ctx *c, int option, const uint8_t *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t stream_total, uint64_t start, uint64_t own_end,
+                   uint64_t *next_start, uint64_t *nblocks) {
+  Bz2State *B = bz_state(c);
+  int rc;
+  bz_reset_call(c);
+  B->trace.clear();
+  B->rg_bstart.clear(); B->rg_blen.clear();
+  B->rg_option = option; B->rg_in = d_buf - buf_off;
+  const uint64_t buf_end = buf_off + buf_len, span_max = (uint64_t)(c->knob_bz_span_mib > 0 ? c->knob_bz_span_mib : 1024) << 20;
+  uint64_t pos0 = start;
+  if (start < buf_off || start > buf_end || own_end > stream_total) { c->err = "bzip2 range: start outside the buffer"; return ZADA_E_INVALID; }
+  while (pos0 < own_end || (stream_total == 0 && B->rg_bstart.empty())) {
+    const uint64_t span_len = buf_end - pos0 < span_max ? buf_end - pos0 : span_max;
+    std::vector<uint64_t> bstart; std::vector<uint32_t> blen;
+    uint64_t next = pos0;
+    if ((rc = bz_span_blocks(c, option, B->rg_in, pos0, span_len, pos0 + span_len == stream_total, (int64_t)stream_total, own_end, bstart, blen, &next))) return rc;
+    if (bstart.empty()) { c->err = "bzip2 range: the bytes behind the range do not hold its last block"; return ZADA_E_INVALID; }
+    B->rg_bstart.insert(B->rg_bstart.end(), bstart.begin(), bstart.end());
+    B->rg_blen.insert(B->rg_blen.end(), blen.begin(), blen.end());
+    pos0 = next;
+    if (stream_total == 0) break;
+  }
+  if (next_start) *next_start = pos0;
+  if (nblocks) *nblocks = B->rg_bstart.size();
+  return 0;
+}
+int bz2_range_encode(Ctx *c) {
+  Bz2State *B = bz_state(c);
+  return bz_blocks_encode(c, B->rg_option, B->rg_in, B->rg_bstart, B->rg_blen, nullptr, nullptr, 0, 0);
+}
+uint64_t bz2_range_table(Ctx *c, uint64_t *tab, uint64_t cap_blocks) {
+  Bz2State *B = bz_state(c);
+  std::vector<uint64_t> t;
+  bz_fill_table(B, t);
+  if (tab && B->plans.size() <= cap_blocks) memcpy(tab, t.data(), 8 * t.size());
+  return B->plans.size();
+}
+int bz2_range_assemble(Ctx *c, const uint8_t *choice, uint64_t nblk, uint64_t bit_begin, int flags, uint32_t footer_crc, uint8_t *d_out, uint64_t cap, uint64_t *nbytes) {
+  Bz2State *B = bz_state(c);
+  if (nblk != B->plans.size()) { c->err = "bzip2 range: one choice per block"; return ZADA_E_INVALID; }
+  for (uint64_t q = 0; q < nblk; q++) if (choice[q] > 3 || B->plans[q].tac[choice[q]].empty()) { c->err = "bzip2 range: no such tactic"; return ZADA_E_INVALID; }
+  bz_set_trace(B, choice);
+  return bz_assemble_range(c, B->rg_option, choice, bit_begin, flags, footer_crc, d_out, cap, nbytes);
 }
 
 uint64_t bz2_last_blocks(Ctx *c, uint64_t *dst, uint64_t cap_items) {
@@ -1889,6 +2054,31 @@ uint64_t bz2_last_blocks(Ctx *c, uint64_t *dst, uint64_t cap_items) {
 
 struct zada_ctx { zada::Ctx c; };
 using namespace zada;
+
+// ---- one stream over several contexts (include/zada.h) ----
+extern "C" int zada_bz2_range_open(zada_ctx *z, int method, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t stream_total, uint64_t start, uint64_t own_end,
+                                   uint64_t *next_start, uint64_t *nblocks) {
+  if (!z || method < ZADA_BZIP2_1 || method > ZADA_BZIP2_3) return ZADA_E_INVALID;
+  hipSetDevice(z->c.device);
+  z->c.tbegin();
+  z->c.tmark("bz:begin");
+  return bz2_range_open(&z->c, method - ZADA_BZIP2_1, (const uint8_t *)d_buf, buf_len, buf_off, stream_total, start, own_end, next_start, nblocks);
+}
+extern "C" int zada_bz2_range_encode(zada_ctx *z) {
+  if (!z) return ZADA_E_INVALID;
+  hipSetDevice(z->c.device);
+  return bz2_range_encode(&z->c);
+}
+extern "C" uint64_t zada_bz2_range_table(zada_ctx *z, uint64_t *tab, uint64_t cap_blocks) { return z ? bz2_range_table(&z->c, tab, cap_blocks) : 0; }
+extern "C" int zada_bz2_range_assemble(zada_ctx *z, const uint8_t *choice, uint64_t nblk, uint64_t bit_begin, int flags, uint32_t footer_crc, void *d_out, uint64_t cap,
+                                       uint64_t *nbytes) {
+  if (!z) return ZADA_E_INVALID;
+  hipSetDevice(z->c.device);
+  const int rc = bz2_range_assemble(&z->c, choice, nblk, bit_begin, flags, footer_crc, (uint8_t *)d_out, cap, nbytes);
+  z->c.tmark("bz:end");
+  z->c.tend();
+  return rc;
+}
 
 // ---- test hooks: run a list of sub-blocks of a host buffer through the stages, then fetch any table of the state ----
 extern "C" int zada_bz2_run(zada_ctx *z, const uint8_t *in, uint64_t n, uint32_t nsb, const uint64_t *starts, const uint32_t *lens, int option, int stages) {

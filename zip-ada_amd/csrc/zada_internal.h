@@ -270,6 +270,11 @@ void bz2_destroy(Ctx *c);
 int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64_t size_hint, uint8_t *d_out, uint64_t cap, uint64_t *out_len,
                       int (*fb)(int, void *), void *user);
 uint64_t bz2_last_blocks(Ctx *c, uint64_t *dst, uint64_t cap_items);
+int bz2_range_open(Ctx *c, int option, const uint8_t *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t stream_total, uint64_t start, uint64_t own_end,
+                   uint64_t *next_start, uint64_t *nblocks);
+int bz2_range_encode(Ctx *c);
+uint64_t bz2_range_table(Ctx *c, uint64_t *tab, uint64_t cap_blocks);
+int bz2_range_assemble(Ctx *c, const uint8_t *choice, uint64_t nblk, uint64_t bit_begin, int flags, uint32_t footer_crc, uint8_t *d_out, uint64_t cap, uint64_t *nbytes);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);
 int ensure_crc_workspace(Ctx *c, uint64_t n);
