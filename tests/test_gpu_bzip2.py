@@ -133,3 +133,60 @@ def test_zip_archive_with_bzip2_entries(encoder):
     zf = zipfile.ZipFile(io.BytesIO(got))
     assert zf.testzip() is None and [zf.read(i) for i in zf.infolist()] == [d for _, d in entries]
     assert [i.compress_type for i in zf.infolist()] == [12, 0, 0, 0, 12]
+
+
+def _bzip2_over_contexts(data, world, method=14):
+    """The stream compressed by `world` contexts on cuda:0, one thread each, through sharding.bzip2_stream_rank."""
+    import importlib
+    import threading
+    import torch
+    from test_ranges import ThreadComm
+    Z = product()
+    sh = importlib.import_module("zip-ada_amd.sharding")
+    n = len(data)
+    ranges = sh.bzip2_ranges(n, world)
+    shared = ThreadComm.Shared(world)
+    dev = torch.device("cuda", 0)
+    whole = torch.frombuffer(bytearray(data) if n else bytearray(1), dtype=torch.uint8).to(dev)
+    results, errors = [None] * world, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            enc = Z.Encoder(0)
+            comm = ThreadComm(shared, r)
+            ptr = 0
+            if r < len(ranges):
+                off, _ = sh.bzip2_window(n, *ranges[r])
+                ptr = whole.data_ptr() + off
+            results[r] = sh.bzip2_stream_rank(enc, comm, n, ranges, ptr, method, lambda k: torch.zeros(k, dtype=torch.uint8, device=dev))
+            torch.cuda.synchronize()
+            enc.close()
+        except Exception as e:                      # noqa: BLE001
+            errors.append((r, repr(e)))
+            shared.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    res0 = results[0]
+    stream = sh.stitch_stream(torch, [x["payload"] for x in results], [results[k]["spans"][k] if k < len(ranges) else None for k in range(world)], res0["total_bits"], dev)
+    blocks = [b for x in results for b in x["blocks"]]
+    return bytes(stream.cpu().numpy()), blocks, len(ranges)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_stream_over_several_contexts(encoder, world):
+    """BASELINE config 5 in small: one BZip2_3 stream cut over `world` contexts (block chain handed on, tables gathered, the
+    choice replayed, payloads OR-ed at the joints) == the stream of one call == the oracle's."""
+    Z = product()
+    data = Z.silesia_mix(64 << 20).tobytes()
+    rc, one, _ = encoder.bzip2(data, 14)
+    want_blocks = encoder.bz2_last_blocks()
+    got, blocks, nr = _bzip2_over_contexts(data, world)
+    assert nr == world and rc == 0
+    assert got == one and blocks == want_blocks
+    small = data[:5 << 20]                                          # shorter than two halos per rank: fewer ranges than contexts
+    o, ev = oracle_encode(small, 2)
+    got, blocks, nr = _bzip2_over_contexts(small, world)
+    assert nr == 1 and got == o and blocks == ev

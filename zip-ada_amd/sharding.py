@@ -289,3 +289,66 @@ def stream_crc(enc_or_lib_combine, infos, reg=0xFFFFFFFF):
         if i is not None:
             reg = enc_or_lib_combine(reg, i["crc_raw"], i["n"])
     return reg
+
+
+# ------------------------------------------------------------------------------------------------------------------
+#  One BZip2 stream over the GPUs of a node (BASELINE config 5).  A rank takes the blocks that START inside its range; the
+#  block chain (where the next block starts) and the bit phase are the only things that run along the stream:
+#    a. 8 bytes from rank to rank: where the range's first block starts (block limits only: milliseconds per GiB)
+#    b. every rank encodes every piece of every tactic of its blocks (the work, no communication)
+#    c. all_gather of the per-block tables (12 values per block); every rank replays the choice of the tactics
+#    d. every rank assembles its bytes of the stream; the payloads are gathered and OR-ed at the joints (stitch_stream)
+# ------------------------------------------------------------------------------------------------------------------
+BZ_HALO = 10 * 900_000 + 512        # bytes of the following ranges a rank needs behind its own: a block takes at most ten capacities
+
+
+def bzip2_ranges(stream_size, world):
+    """Ranges of at least a halo each (so that a rank's halo lies in the next range or two); fewer ranges than ranks for short streams."""
+    nr = max(1, min(world, stream_size // (2 * BZ_HALO)))
+    step = (stream_size + nr - 1) // nr if stream_size else 0
+    return [(k * step, min(step, stream_size - k * step)) for k in range(nr)] if stream_size else [(0, 0)]
+
+
+def bzip2_window(stream_size, lo, n):
+    """The bytes a rank holds: its range and the halo behind it.  Returns (buffer offset in the stream, buffer length)."""
+    return lo, min(stream_size, lo + n + BZ_HALO) - lo
+
+
+def bzip2_stream_rank(enc, comm, stream_size, ranges, d_buf_ptr, method, alloc_out):
+    """Rank `comm.rank`'s part of ONE BZip2 stream cut into `ranges` (bzip2_ranges); d_buf_ptr = device address of the rank's
+    window (bzip2_window).  Returns dict(bit_begin, bit_end, total_bits, payload, nbytes, spans, blocks, inefficient)."""
+    import numpy as np
+    r, nr = comm.rank, len(ranges)
+    active = r < nr
+    tab = np.zeros((0, 4, 3), np.uint64)
+    if active:
+        lo, n = ranges[r]
+        off, blen = bzip2_window(stream_size, lo, n)
+        start = int.from_bytes(comm.recv_bytes(8, r - 1), "little") if r > 0 else 0
+        nxt, _nb = enc.bz2_range_open(d_buf_ptr, blen, off, stream_size, start, lo + n if r + 1 < nr else stream_size, method)
+        if r + 1 < nr:
+            comm.send_bytes(int(nxt).to_bytes(8, "little"), r + 1)
+        enc.bz2_range_encode()
+        tab = enc.bz2_range_table()
+    tabs = comm.all_gather_obj(tab.tobytes() if active else None)
+    bp, crc = 32, 0
+    spans, mine = [], None
+    for k in range(nr):
+        tk = np.frombuffer(tabs[k], np.uint64).reshape(-1, 4, 3)
+        ch, bp2, crc2 = enc.bz2_select(tk, bp, crc)
+        b0 = 0 if k == 0 else bp
+        b1 = bp2 + (80 if k == nr - 1 else 0)
+        spans.append((b0, b1))
+        if k == r:
+            mine = (ch, bp)
+        bp, crc = bp2, crc2
+    total_bits = bp + 80
+    inefficient = (total_bits + 7) // 8 >= stream_size
+    payload, nbytes = None, 0
+    if active:
+        b0, b1 = spans[r]
+        cap = (b1 + 7) // 8 - b0 // 8 + 64
+        payload = alloc_out(cap)
+        nbytes = enc.bz2_range_assemble(mine[0], mine[1], payload.data_ptr(), cap, header=(r == 0), footer_crc=crc if r == nr - 1 else None)
+    return dict(bit_begin=spans[r][0] if active else 0, bit_end=spans[r][1] if active else 0, total_bits=total_bits, payload=payload, nbytes=nbytes,
+                spans=spans, blocks=enc.bz2_last_blocks() if active else [], inefficient=inefficient, combined_crc=crc)
