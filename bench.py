@@ -205,6 +205,80 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
     return out
 
 
+def bzip2_main(args, za, sharding, enc, torch, dist, rank, world, dev, emulate):
+    """BASELINE config 5: ONE BZip2_3 stream of world x mib MiB, the blocks sharded over the GPUs (sharding.bzip2_stream_rank):
+    same contract as the Deflate line (W warm-up steps, K timed steps between barriers, max over ranks, one JSON line)."""
+    import bz2
+    mib = args.mib or 1024
+    n = mib << 20
+    total = n * world
+    ranges = sharding.bzip2_ranges(total, world)
+    active = rank < len(ranges)
+    off, blen = sharding.bzip2_window(total, *ranges[rank]) if active else (0, 1)
+    host = za.silesia_mix(blen, seed=SEED, offset=off)
+    d_buf = torch.from_numpy(host).to(dev)
+
+    class Solo:                                       # one GPU: the same protocol without a process group
+        rank, world = 0, 1
+
+        def all_gather_obj(self, obj):
+            return [obj]
+    comm = sharding.TorchComm(torch.device("cpu") if emulate else dev) if world > 1 else Solo()
+    state = {}
+
+    def step():
+        res = sharding.bzip2_stream_rank(enc, comm, total, ranges, d_buf.data_ptr(), 14, lambda k: torch.zeros(k, dtype=torch.uint8, device=dev))
+        if world > 1:
+            payload = res["payload"] if res["payload"] is not None else torch.zeros(1, dtype=torch.uint8, device=dev)
+            if emulate:
+                torch.cuda.synchronize()
+                payload = payload.cpu()
+            got = sharding.gather_payloads(payload, res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
+            if got is not None:
+                state["stream"] = sharding.stitch_stream(torch, got[0], res["spans"], res["total_bits"], dev)
+        else:
+            state["stream"] = res["payload"][:res["nbytes"]]
+        state["res"] = res
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if emulate else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    res = state["res"]
+    nbytes = (res["total_bits"] + 7) // 8
+    out = {"metric": "BZip2_3 encode MB/s (one stream, blocks sharded over the GPUs; bit-exact with the CPU restatement of the reference, Ada parity unpinned)",
+           "value": round(total * args.steps / dt / 1e6, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "C5: BZip2_3, one stream of %d x %d MiB synthetic silesia_mix_v1, %d block ranges, input resident in HBM" % (world, mib, len(ranges)),
+                      "bytes_per_gpu": n, "stream_bytes": total, "compression_ratio": round(nbytes / total, 4), "blocks_rank0": len(res["blocks"])}}
+    if not args.no_checks and total <= (3 << 30):
+        stream = bytes(state["stream"].cpu().numpy())
+        dec = bz2.BZ2Decompressor()
+        c, tot, o = 0, 0, 0
+        while o < len(stream):
+            ch = dec.decompress(stream[o:o + (1 << 22)])
+            o += 1 << 22
+            if tot < len(host):
+                c = zlib.crc32(ch[:max(0, len(host) - tot)], c)
+            tot += len(ch)
+        out["checks"] = {"stream_decompresses": bool(tot == total and dec.eof), "rank0_window_crc": bool(c == zlib.crc32(host[:min(len(host), total)]))}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +289,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-checks", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--method", choices=("deflate", "bzip2"), default="deflate", help="bzip2: BASELINE config 5 -- ONE BZip2_3 stream of N x --mib (default 1024) MiB over N GPUs")
     ap.add_argument("--bzip2-mib", type=int, default=256, help="input MiB of the secondary BZip2_3 measurement at one GPU (0 = skip)")
     args = ap.parse_args()
 
@@ -241,6 +316,12 @@ def main():
     za = importlib.import_module("zip-ada_amd")
     sharding = importlib.import_module("zip-ada_amd.sharding")
     enc = za.Encoder(local_rank)
+    if args.method == "bzip2":
+        bzip2_main(args, za, sharding, enc, torch, dist, rank, world, dev, emulate)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     mib = args.mib or (1024 if world == 1 else 2048)
     n = mib << 20                                     # bytes per GPU
     total = n * world                                 # the stream

@@ -103,3 +103,64 @@ def test_zip_entry_semantics():
     d = os.urandom(3000)                                            # not smaller than the input: compression_ok := False
     assert O.zo_bzip2(d, len(d), 14, out, len(d) + 64, ctypes.byref(n), ctypes.byref(crc)) == 1
     assert O.zo_bzip2(d, len(d), 10, out, len(d) + 64, ctypes.byref(n), ctypes.byref(crc)) < 0
+
+
+def test_tactic_choice_replay_and_stream_ranges():
+    """zada_bz2_select (the product's host-side replay of bzip2-encoding.adb:1312-1318 and :1023-1026, which every rank of a
+    multi-GPU run executes on the gathered tables) against the oracle: tables built from the oracle's own Encode_Block sizes of
+    every piece of every tactic must lead to the oracle's choices, stream length and footer CRC.  Also the range geometry."""
+    import importlib
+    from _common import product
+    Z = product()
+    L = Z.load_library()                                             # loads without a GPU; zada_bz2_select is plain host arithmetic
+    sh = importlib.import_module("zip-ada_amd.sharding")
+    O = bz_oracle()
+    cases = bz_inputs()
+    for name in ("seg1_az_digits", "seg2_alphabets", "copies_1500k"):
+        data = cases[name]
+        z, ev = oracle_encode(data, 2)
+        tab = np.zeros((len(ev), 4, 3), np.uint64)
+        for q, (start, ln, _t, _k) in enumerate(ev):
+            raw = data[start:start + ln]
+            pieces = {0: [(0, ln)]}
+            size, stop, p4 = ln // 4, 0, []
+            for count in range(1, 5):
+                s0 = stop + 1
+                stop = ln if count == 4 else count * size
+                p4.append((s0 - 1, stop - s0 + 1))
+            pieces[1] = p4
+            for t in (2, 3):
+                seg = np.zeros(ln // 4000 + 4, np.int32)
+                k = O.zo_bz2_segments(raw, ln, t, seg.ctypes.data, seg.size)
+                idx, lst = 1, []
+                for e in seg[:k]:
+                    lst.append((idx - 1, int(e) - idx + 1)); idx = int(e) + 1
+                pieces[t] = lst
+            memo = {}
+            for t in range(4):
+                bits, fold = 0, 0
+                for (o, l) in pieces[t]:
+                    if (o, l) not in memo:
+                        info = oracle_block(raw[o:o + l])["info"]
+                        memo[(o, l)] = (info.bits, info.block_crc)
+                    b, c = memo[(o, l)]
+                    bits += b
+                    fold = (((fold << 1) | (fold >> 31)) & 0xFFFFFFFF) ^ c
+                tab[q, t] = (bits, len(pieces[t]), fold)
+        choice = np.zeros(len(ev), np.uint8)
+        bp, crc = ctypes.c_uint64(), ctypes.c_uint32()
+        L.zada_bz2_select.restype = None
+        L.zada_bz2_select.argtypes = [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+        L.zada_bz2_select(len(ev), tab.ctypes.data, 32, 0, choice.ctypes.data, ctypes.byref(bp), ctypes.byref(crc))
+        assert choice.tolist() == [e[2] for e in ev], name
+        assert (bp.value + 80 + 7) // 8 == len(z), name
+        bits = int.from_bytes(z, "big")
+        assert any(((bits >> sh_) & 0xFFFFFFFF) == crc.value for sh_ in range(8)), name
+    # ranges: at least two halos each, together the stream; a window ends with the stream or a halo behind the range
+    for total, world in ((0, 4), (5 << 20, 8), (300 << 20, 8), (8 << 30, 8)):
+        r = sh.bzip2_ranges(total, world)
+        assert sum(n for _, n in r) == total and all(r[k][0] + r[k][1] == r[k + 1][0] for k in range(len(r) - 1))
+        assert len(r) == 1 or all(n >= 2 * sh.BZ_HALO for _, n in r[:-1])
+        for lo, n in r:
+            off, ln = sh.bzip2_window(total, lo, n)
+            assert off == lo and ln == min(total - lo, n + sh.BZ_HALO)

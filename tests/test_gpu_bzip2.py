@@ -190,3 +190,19 @@ def test_one_stream_over_several_contexts(encoder, world):
     o, ev = oracle_encode(small, 2)
     got, blocks, nr = _bzip2_over_contexts(small, world)
     assert nr == 1 and got == o and blocks == ev
+
+
+def test_bench_bzip2_multi_rank_path_on_one_gpu():
+    """bench.py --method bzip2 at N = 3 (torch.distributed, one process per rank, TorchComm hand-over and gathers, payload
+    gather + stitch on rank 0) with every rank on GPU 0 over gloo (BENCH_EMULATE=1): the stitched stream decompresses to the input."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_EMULATE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(root, "bench.py"), "--gpus", "3", "--method", "bzip2", "--steps", "1", "--warmup", "1", "--mib", "40"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 3 and "3 block ranges" in res["config"]["workload"]
+    assert res["checks"] == {"stream_decompresses": True, "rank0_window_crc": True}, res["checks"]
