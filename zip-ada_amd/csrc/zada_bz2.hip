@@ -144,6 +144,14 @@ struct SubTab {
 
 // A tile of a sub-block: `lo` is the offset inside the sub-block (raw space or element space)
 struct Tile { uint32_t sb, lo; };
+// Workgroups are dealt to the eight XCDs in turn; each XCD has its own L2.  The rotation sort's kernels look up classes and marks
+// all over a sub-block, so the tiles of a sub-block should meet in ONE L2: workgroup b of a grid of 8 * ceil(n / 8) takes tile
+// (b % 8) * ceil(n / 8) + b / 8, i.e. every XCD walks a contiguous eighth of the tile list.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t ntiles) {
+  const uint32_t per = (ntiles + 7) >> 3;
+  return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+static inline uint32_t xcd_grid(uint32_t ntiles) { return ((ntiles + 7) >> 3) << 3; }
 
 // ---------------------------------------------------------------------------------------------------------------
 //  RLE_1 (:167-213).  The reference's state machine cuts a run of equal bytes into pieces of at most 259 bytes,
@@ -318,9 +326,11 @@ constexpr int BW_TILE = 8192;    // elements per tile, 1024 threads x 8 (wave w 
 // stable radix pass over (key, val) pairs, segmented by sub-block: digit = (key >> shift) & 255
 __global__ void __launch_bounds__(1024) k_bz_radix_hist(const uint32_t *__restrict__ key, SubTab T, const Tile *__restrict__ tiles,
                                                         const uint32_t *__restrict__ first_tile, const uint8_t *__restrict__ done, int shift,
-                                                        uint32_t *__restrict__ H) {
+                                                        uint32_t *__restrict__ H, uint32_t ntiles_x) {
   __shared__ uint32_t cnt[256];
-  const Tile t = tiles[blockIdx.x];
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   const uint32_t n = T.n[t.sb], base = T.off[t.sb] + t.lo, m = done[t.sb] ? 0u : min((uint32_t)BW_TILE, n - t.lo);
   if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -328,15 +338,17 @@ __global__ void __launch_bounds__(1024) k_bz_radix_hist(const uint32_t *__restri
   __syncthreads();
   if (threadIdx.x < 256) {
     const uint32_t t0 = first_tile[t.sb], ts = first_tile[t.sb + 1] - t0;
-    H[(uint64_t)t0 * 256 + (uint64_t)threadIdx.x * ts + (blockIdx.x - t0)] = cnt[threadIdx.x];
+    H[(uint64_t)t0 * 256 + (uint64_t)threadIdx.x * ts + (bx - t0)] = cnt[threadIdx.x];
   }
 }
 __global__ void __launch_bounds__(1024) k_bz_radix_scatter(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, SubTab T,
                                                            const Tile *__restrict__ tiles, const uint32_t *__restrict__ first_tile,
                                                            const uint8_t *__restrict__ done, int shift,
-                                                           const uint32_t *__restrict__ H, uint32_t *__restrict__ key_out, uint32_t *__restrict__ val_out) {
+                                                           const uint32_t *__restrict__ H, uint32_t *__restrict__ key_out, uint32_t *__restrict__ val_out, uint32_t ntiles_x) {
   __shared__ uint32_t cnt[16 * 256];
-  const Tile t = tiles[blockIdx.x];
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], base = T.off[t.sb] + t.lo, m = min((uint32_t)BW_TILE, n - t.lo);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -357,7 +369,7 @@ __global__ void __launch_bounds__(1024) k_bz_radix_scatter(const uint32_t *__res
   if (tid < 256) {
     const uint32_t t0 = first_tile[t.sb], ts = first_tile[t.sb + 1] - t0;
     // the scan runs over all sub-blocks' histograms; a sub-block's own part starts at its first entry
-    uint32_t run = T.off[t.sb] + H[(uint64_t)t0 * 256 + (uint64_t)tid * ts + (blockIdx.x - t0)] - H[(uint64_t)t0 * 256];
+    uint32_t run = T.off[t.sb] + H[(uint64_t)t0 * 256 + (uint64_t)tid * ts + (bx - t0)] - H[(uint64_t)t0 * 256];
     for (int k = 0; k < 16; k++) { const uint32_t x = cnt[k * 256 + tid]; cnt[k * 256 + tid] = run; run += x; }
   }
   __syncthreads();
@@ -369,8 +381,10 @@ __global__ void __launch_bounds__(1024) k_bz_radix_scatter(const uint32_t *__res
 }
 
 // first keys: four bytes of the rotation starting at the element, big end first
-__global__ void k_bz_bwt_init(const uint8_t *__restrict__ rle, SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
-  const Tile t = tiles[blockIdx.x];
+__global__ void k_bz_bwt_init(const uint8_t *__restrict__ rle, SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ key, uint32_t *__restrict__ val, uint32_t ntiles_x) {
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
     const uint32_t l = t.lo + i;
@@ -384,8 +398,10 @@ __global__ void k_bz_bwt_init(const uint8_t *__restrict__ rle, SubTab T, const T
 // head values after the first sort: row i starts a group iff its key differs from row i - 1's (or it is the sub-block's first row).
 // hv[i] = i + 1 for heads, 0 otherwise: an inclusive max-scan turns it into "my group's first row + 1".
 __global__ void __launch_bounds__(1024) k_bz_heads0(const uint32_t *__restrict__ key, SubTab T, const Tile *__restrict__ tiles,
-                                                    const uint8_t *__restrict__ done, uint32_t *__restrict__ hv) {
-  const Tile t = tiles[blockIdx.x];
+                                                    const uint8_t *__restrict__ done, uint32_t *__restrict__ hv, uint32_t ntiles_x) {
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   for (uint32_t i = threadIdx.x; i < m; i += 1024) {
@@ -395,8 +411,10 @@ __global__ void __launch_bounds__(1024) k_bz_heads0(const uint32_t *__restrict__
 }
 // classes from the scanned head values of the first sort; the elements of groups of more than one row are marked (acte)
 __global__ void __launch_bounds__(1024) k_bz_set_class(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ hv, const uint32_t *__restrict__ hr,
-                                                       SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte) {
-  const Tile t = tiles[blockIdx.x];
+                                                       SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte, uint32_t ntiles_x) {
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   for (uint32_t i = threadIdx.x; i < m; i += 1024) {
     const uint32_t l = t.lo + i, g = off + l, e = sa[g];
@@ -420,9 +438,11 @@ __device__ __forceinline__ uint32_t bz_shifted_active(const uint32_t *__restrict
   return (acte[e >> 5] >> (e & 31)) & 1u;
 }
 __global__ void __launch_bounds__(1024) k_bz_filter_count(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, SubTab T, const Tile *__restrict__ tiles,
-                                                          const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ tile_cnt) {
+                                                          const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ tile_cnt, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
-  const Tile t = tiles[blockIdx.x];
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   uint32_t c = 0;
   if (!done[t.sb]) {
@@ -432,7 +452,7 @@ __global__ void __launch_bounds__(1024) k_bz_filter_count(const uint32_t *__rest
   OpSum sm;
   uint32_t tot;
   wg_scan_incl(c, l17, sm, &tot);
-  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+  if (threadIdx.x == 0) tile_cnt[bx] = tot;
 }
 // tscan = exclusive scan of tile_cnt over all tiles (entry ntiles = the total)
 __global__ void k_bz_counts(SubTab T, const uint32_t *__restrict__ first_tile, const uint32_t *__restrict__ tscan, uint32_t *__restrict__ coff, uint32_t *__restrict__ cm) {
@@ -444,9 +464,11 @@ __global__ void k_bz_counts(SubTab T, const uint32_t *__restrict__ first_tile, c
 }
 __global__ void __launch_bounds__(1024) k_bz_filter_emit(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, const uint32_t *__restrict__ cl, SubTab T,
                                                          const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t h,
-                                                         const uint32_t *__restrict__ tscan, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval) {
+                                                         const uint32_t *__restrict__ tscan, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
-  const Tile t = tiles[blockIdx.x];
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   const uint32_t r0 = threadIdx.x * 8;
@@ -457,7 +479,7 @@ __global__ void __launch_bounds__(1024) k_bz_filter_emit(const uint32_t *__restr
   }
   OpSum sm;
   const uint32_t incl = wg_scan_incl(c, l17, sm, nullptr);
-  uint32_t j = tscan[blockIdx.x] + incl - c;
+  uint32_t j = tscan[bx] + incl - c;
   for (uint32_t k = 0; k < 8; k++) if ((fl >> k) & 1u) { ckey[j] = cl[ev[k]] - off; cval[j] = ev[k]; j++; }
 }
 // C = the filtered rows' space (sub-block s owns [coff[s], coff[s] + cm[s])), its tiles in `tiles`.  After the sort the rows of a
@@ -465,9 +487,11 @@ __global__ void __launch_bounds__(1024) k_bz_filter_emit(const uint32_t *__restr
 // from a scan over the tiles' aggregates:  (1) per tile, the last slot that starts a run of equal keys;  (2) every slot's run
 // start -> its row; the element goes there; slots whose second half differs from the slot before start a new group (hd);
 // (3) every slot's group start -> its element's class; elements alone in their group stop being marked.
-__global__ void __launch_bounds__(1024) k_bz_rf_agg(const uint32_t *__restrict__ ckey, SubTab C, const Tile *__restrict__ tiles, uint32_t *__restrict__ agg_out) {
+__global__ void __launch_bounds__(1024) k_bz_rf_agg(const uint32_t *__restrict__ ckey, SubTab C, const Tile *__restrict__ tiles, uint32_t *__restrict__ agg_out, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
-  const Tile t = tiles[blockIdx.x];
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo);
   const uint32_t r0 = threadIdx.x * 8;
   uint32_t v = 0;
@@ -475,13 +499,15 @@ __global__ void __launch_bounds__(1024) k_bz_rf_agg(const uint32_t *__restrict__
   OpMax mx;
   uint32_t tot;
   wg_scan_incl(v, l17, mx, &tot);
-  if (threadIdx.x == 0) agg_out[blockIdx.x] = tot;
+  if (threadIdx.x == 0) agg_out[bx] = tot;
 }
 __global__ void __launch_bounds__(1024) k_bz_place(const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cval, const uint32_t *__restrict__ carry_rf, SubTab T, SubTab C,
                                                    const Tile *__restrict__ tiles, const uint32_t *__restrict__ cl, uint32_t h, uint32_t *__restrict__ sa,
-                                                   uint32_t *__restrict__ hd, uint32_t *__restrict__ agg_out) {
+                                                   uint32_t *__restrict__ hd, uint32_t *__restrict__ agg_out, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
-  const Tile t = tiles[blockIdx.x];
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo), n = T.n[t.sb], off = T.off[t.sb];
   const uint32_t r0 = threadIdx.x * 8;
   uint32_t key[8], val[8], flags = 0, last = 0;
@@ -501,7 +527,7 @@ __global__ void __launch_bounds__(1024) k_bz_place(const uint32_t *__restrict__ 
   const uint32_t incl = wg_scan_incl(last, l17, mx, nullptr);
   uint32_t before = __shfl_up(incl, 1);
   if ((threadIdx.x & 63) == 0) { before = 0; for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before = mx(before, l17[k]); }
-  uint32_t run = mx(carry_rf[blockIdx.x], before), hmax = 0;
+  uint32_t run = mx(carry_rf[bx], before), hmax = 0;
   for (uint32_t k = 0; k < 8; k++) {
     if (r0 + k < m) {
       const uint32_t j = coff + t.lo + r0 + k, e = val[k];
@@ -518,12 +544,14 @@ __global__ void __launch_bounds__(1024) k_bz_place(const uint32_t *__restrict__ 
   __syncthreads();
   uint32_t tot;
   wg_scan_incl(hmax, l17, mx, &tot);
-  if (threadIdx.x == 0) agg_out[blockIdx.x] = tot;
+  if (threadIdx.x == 0) agg_out[bx] = tot;
 }
 __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict__ cval, const uint32_t *__restrict__ hd, const uint32_t *__restrict__ carry_hd, SubTab C,
-                                                      const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte) {
+                                                      const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
-  const Tile t = tiles[blockIdx.x];
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   const uint32_t cn = C.n[t.sb], coff = C.off[t.sb], m = min((uint32_t)BW_TILE, cn - t.lo);
   const uint32_t r0 = threadIdx.x * 8;
   uint32_t hv[9], last = 0;
@@ -536,7 +564,7 @@ __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict
   const uint32_t incl = wg_scan_incl(last, l17, mx, nullptr);
   uint32_t before = __shfl_up(incl, 1);
   if ((threadIdx.x & 63) == 0) { before = 0; for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before = mx(before, l17[k]); }
-  uint32_t run = mx(carry_hd[blockIdx.x], before);
+  uint32_t run = mx(carry_hd[bx], before);
   for (uint32_t k = 0; k < 8; k++) {
     if (r0 + k < m) {
       const uint32_t j = coff + t.lo + r0 + k, e = cval[j];
@@ -553,8 +581,10 @@ __global__ void k_bz_done(SubTab T, uint32_t prefix, uint8_t *__restrict__ done)
 }
 // last column (:266-276): the byte in front of each row's rotation; the original message is the first row of its group
 __global__ void __launch_bounds__(1024) k_bz_bwt_out(const uint8_t *__restrict__ rle, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T,
-                                                     const Tile *__restrict__ tiles, uint8_t *__restrict__ bwt) {
-  const Tile t = tiles[blockIdx.x];
+                                                     const Tile *__restrict__ tiles, uint8_t *__restrict__ bwt, uint32_t ntiles_x) {
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   for (uint32_t i = threadIdx.x; i < m; i += 1024) {
     const uint32_t g = off + t.lo + i, l = sa[g] - off;
@@ -1549,27 +1579,27 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   uint32_t *cv0 = B->cv0.as<uint32_t>(), *cv1 = B->cv1.as<uint32_t>(), *acte = B->acte.as<uint32_t>();
   uint32_t *H = B->H.as<uint32_t>(), *agg = B->agg.as<uint32_t>(), *hv = B->hv.as<uint32_t>(), *hr = B->hr.as<uint32_t>(), *cl = B->cl.as<uint32_t>();
   auto radix = [&](const SubTab &S, const Tile *tl, const uint32_t *tf, uint32_t nt, const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int shift) {
-    hipLaunchKernelGGL(k_bz_radix_hist, dim3(nt), dim3(1024), 0, st, ki, S, tl, tf, done, shift, H);
+    hipLaunchKernelGGL(k_bz_radix_hist, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, S, tl, tf, done, shift, H, nt);
     scan_launch<OpSum, false>(st, FArr{H}, 256ull * nt, agg, H, nullptr);
-    hipLaunchKernelGGL(k_bz_radix_scatter, dim3(nt), dim3(1024), 0, st, ki, vi, S, tl, tf, done, shift, H, ko, vo);
+    hipLaunchKernelGGL(k_bz_radix_scatter, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, vi, S, tl, tf, done, shift, H, ko, vo, nt);
   };
   B->m_hist.clear();
   B->m_hist.push_back(tot);
   // first sort: four bytes
   BZ_HIP(hipMemsetAsync(acte, 0, 4 * ((size_t)tot / 32 + 2), st));
-  hipLaunchKernelGGL(k_bz_bwt_init, dim3(net), dim3(1024), 0, st, B->rle.as<uint8_t>(), T, ET, keyA, valA);
+  hipLaunchKernelGGL(k_bz_bwt_init, dim3(xcd_grid(net)), dim3(1024), 0, st, B->rle.as<uint8_t>(), T, ET, keyA, valA, net);
   radix(T, ET, EF, net, keyA, valA, keyB, valB, 0); radix(T, ET, EF, net, keyB, valB, keyA, valA, 8);
   radix(T, ET, EF, net, keyA, valA, keyB, valB, 16); radix(T, ET, EF, net, keyB, valB, keyA, valA, 24);
-  hipLaunchKernelGGL(k_bz_heads0, dim3(net), dim3(1024), 0, st, keyA, T, ET, done, hv);
+  hipLaunchKernelGGL(k_bz_heads0, dim3(xcd_grid(net)), dim3(1024), 0, st, keyA, T, ET, done, hv, net);
   scan_launch<OpMax, true>(st, FArr{hv}, tot, agg, hr, nullptr);
-  hipLaunchKernelGGL(k_bz_set_class, dim3(net), dim3(1024), 0, st, valA, hv, hr, T, ET, cl, acte);
+  hipLaunchKernelGGL(k_bz_set_class, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, hv, hr, T, ET, cl, acte, net);
   hipLaunchKernelGGL(k_bz_done, dim3((nsb + 255) / 256), dim3(256), 0, st, T, 4u, done);
   SubTab C = T;
   C.off = B->coff.as<uint32_t>(); C.n = B->cm.as<uint32_t>();
   std::vector<uint32_t> &h_cm = B->h_cm;
   std::vector<Tile> &ct = B->h_ct; std::vector<uint32_t> &cfirst = B->h_cfirst;
   for (uint32_t h = 4;; h *= 2) {
-    hipLaunchKernelGGL(k_bz_filter_count, dim3(net), dim3(1024), 0, st, valA, acte, T, ET, done, h, hv);
+    hipLaunchKernelGGL(k_bz_filter_count, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, acte, T, ET, done, h, hv, net);
     scan_launch<OpSum, false>(st, FArrPad{hv, net}, (uint64_t)net + 1, agg, hr, nullptr);          // hr[t] = filtered rows before tile t
     hipLaunchKernelGGL(k_bz_counts, dim3((nsb + 255) / 256), dim3(256), 0, st, T, EF, hr, C.off, C.n);
     h_cm.resize(nsb);
@@ -1587,17 +1617,17 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
     uint64_t M = 0;
     for (uint32_t s2 = 0; s2 < nsb; s2++) M += h_cm[s2];
     B->m_hist.push_back(M);
-    hipLaunchKernelGGL(k_bz_filter_emit, dim3(net), dim3(1024), 0, st, valA, acte, cl, T, ET, done, h, hr, keyA, cv0);
+    hipLaunchKernelGGL(k_bz_filter_emit, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, acte, cl, T, ET, done, h, hr, keyA, cv0, net);
     radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 0); radix(C, CT, CF, nct, keyB, cv1, keyA, cv0, 8);
     radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 16);        // first rows are below 2^20 (block capacity 900 000)
-    hipLaunchKernelGGL(k_bz_rf_agg, dim3(nct), dim3(1024), 0, st, keyB, C, CT, hv);
+    hipLaunchKernelGGL(k_bz_rf_agg, dim3(xcd_grid(nct)), dim3(1024), 0, st, keyB, C, CT, hv, nct);
     scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last run start before tile t
-    hipLaunchKernelGGL(k_bz_place, dim3(nct), dim3(1024), 0, st, keyB, cv1, hr, T, C, CT, cl, h, valA, keyA, hv);
+    hipLaunchKernelGGL(k_bz_place, dim3(xcd_grid(nct)), dim3(1024), 0, st, keyB, cv1, hr, T, C, CT, cl, h, valA, keyA, hv, nct);
     scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last group start before tile t
-    hipLaunchKernelGGL(k_bz_newclass, dim3(nct), dim3(1024), 0, st, cv1, keyA, hr, C, CT, cl, acte);
+    hipLaunchKernelGGL(k_bz_newclass, dim3(xcd_grid(nct)), dim3(1024), 0, st, cv1, keyA, hr, C, CT, cl, acte, nct);
     hipLaunchKernelGGL(k_bz_done, dim3((nsb + 255) / 256), dim3(256), 0, st, T, 2 * h, done);
   }
-  hipLaunchKernelGGL(k_bz_bwt_out, dim3(net), dim3(1024), 0, st, B->rle.as<uint8_t>(), valA, cl, T, ET, B->bwt.as<uint8_t>());
+  hipLaunchKernelGGL(k_bz_bwt_out, dim3(xcd_grid(net)), dim3(1024), 0, st, B->rle.as<uint8_t>(), valA, cl, T, ET, B->bwt.as<uint8_t>(), net);
   c->tmark("bz:bwt");
   BZ_HIP(hipGetLastError());
   return 0;
