@@ -42,6 +42,17 @@ typedef uint64_t __attribute__((aligned(1))) u64u;
 // its first position is never a match source (NIL, lz77.adb:467) and every bound the kernels take from "the end of the
 // input" (lz77.adb:858-865, 887-893) is the end of the entry.
 // --------------------------------------------------------------------------------------------
+// Workgroups are dealt to the eight XCDs in turn and every XCD has its own L2.  Neighbouring segments read each other's
+// tables (the chains continue in the segment before), so neighbouring segments should share an L2: workgroup b takes the
+// piece (b % 8) * (n / 8) + b / 8 of the grid's n pieces (the last n % 8 keep their place): every XCD walks a contiguous eighth.
+#ifndef ZADA_NO_XCD_MAP
+__device__ __forceinline__ uint32_t xcd_block() {
+  const uint32_t n = gridDim.x, full = n & ~7u, b = blockIdx.x;
+  return b < full ? (b & 7u) * (full >> 3) + (b >> 3) : b;
+}
+#else
+__device__ __forceinline__ uint32_t xcd_block() { return blockIdx.x; }
+#endif
 __device__ __forceinline__ uint64_t lay_end(const Layout &L, uint64_t seg) { return L.segend ? (uint64_t)(L.segend[seg] & 0x7FFFFFFFu) : L.n; }
 __device__ __forceinline__ bool lay_first(const Layout &L, uint64_t seg) { return L.segend ? (L.segend[seg] >> 31) != 0 : seg == 0; }
 // inserted positions of a segment (every position with three bytes before the end of its entry: :841-843, 887-893)
@@ -788,7 +799,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 #ifdef ZADA_MATCH_STATS
   unsigned long long t_start = clock64(), t_empty = 0, iters = 0;
 #endif
-  const uint64_t B = (uint64_t)blockIdx.x * MB;
+  const uint64_t B = (uint64_t)xcd_block() * MB;
   const uint64_t WB = B >= (uint64_t)HALO ? B - HALO : 0;
   const uint32_t woff = (uint32_t)(B - WB);                        // window index of position B
   const uint64_t n = lay_end(L, B >> 15);                          // end of the stream / of the entry this block lies in
@@ -1087,8 +1098,8 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
                                                              const uint16_t *__restrict__ tailsK, MatchPair *__restrict__ M, int nice_cfg,
                                                              const uint32_t *__restrict__ blk_demand, uint32_t *__restrict__ dbits, uint8_t *__restrict__ chg,
                                                              const ExitState *__restrict__ spec_exits, const uint16_t *__restrict__ resume) {
-  if (blk_demand[blockIdx.x] == 0) return;
-  const uint64_t B = (uint64_t)blockIdx.x * DMB;
+  if (blk_demand[xcd_block()] == 0) return;
+  const uint64_t B = (uint64_t)xcd_block() * DMB;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // DM_WBYTES bytes
   uint16_t *list = (uint16_t *)(smem + DM_WBYTES);                // the marked positions of the block, up to DMB
