@@ -1460,7 +1460,8 @@ struct Bz2State {
   std::vector<uint64_t> trace;      // per block: raw start, raw length, tactic kept, its number of sub-blocks
   // the call in flight: every unique piece's bits are kept until the tactics are chosen
   struct KeptSub { uint64_t bits, woff; uint32_t crc, buf; };
-  struct BlkPlan { uint64_t start = 0; uint32_t len = 0; std::vector<uint32_t> tac[4]; };
+  struct Piece { uint64_t start; uint32_t len, kept; };
+  struct BlkPlan { uint64_t start = 0; uint32_t len = 0; std::vector<uint32_t> tac[4]; std::vector<Piece> pieces; };
   std::vector<KeptSub> kept; std::vector<BlkPlan> plans; std::vector<DBuf> kept_bufs;
   uint64_t min_bits_sum = 0;
   std::vector<uint64_t> rg_bstart; std::vector<uint32_t> rg_blen; int rg_option = 2; const uint8_t *rg_in = nullptr;
@@ -1785,15 +1786,17 @@ static int bz_span_blocks(Ctx *c, int option, const uint8_t *d_in, uint64_t pos0
 static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::vector<uint64_t> &bstart, const std::vector<uint32_t> &blen,
                             zada_feedback_fn fb, void *user, double prog0, double prog1) {
   Bz2State *B = bz_state(c);
-  hipStream_t st = c->stream;
+  hipStream_t st = c->stream, st2 = c->stream2;
   int rc;
   const uint32_t nblk = (uint32_t)bstart.size();
   if (nblk == 0) return 0;
   if ((rc = dbuf_ensure(c, B->bstart, 8ull * nblk)) || (rc = dbuf_ensure(c, B->blen, 4ull * nblk))) return rc;
   BZ_HIP(hipMemcpy(B->bstart.p, bstart.data(), 8ull * nblk, hipMemcpyHostToDevice));
   BZ_HIP(hipMemcpy(B->blen.p, blen.data(), 4ull * nblk, hipMemcpyHostToDevice));
-  // ---- segmentation (block_900k only) ----
+  // ---- segmentation (block_900k only): one wave per block and a serial chain of additions, i.e. next to no load for the GPU
+  //      but 0.16 s of latency -- it runs on the second stream while the pieces that do not depend on it are encoded ----
   std::vector<uint32_t> seg_off(2ull * nblk + 1, 0), seg, seg_cnt(2ull * nblk, 0);
+  uint64_t seg_total = 0;
   if (option == 2) {
     if (!B->etab_ready) {
       std::vector<double> et(SEG_WINDOW + 2);
@@ -1807,73 +1810,103 @@ static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::
     uint64_t so = 0;
     for (uint32_t k = 0; k < nblk; k++) { seg_off[2 * k] = (uint32_t)so; so += blen[k] / 4000 + 2; seg_off[2 * k + 1] = (uint32_t)so; so += blen[k] / 8000 + 2; }
     seg_off[2ull * nblk] = (uint32_t)so;
+    seg_total = so;
     if ((rc = dbuf_ensure(c, B->seg_off, 4ull * (2ull * nblk + 1))) || (rc = dbuf_ensure(c, B->seg, 4 * so + 16)) || (rc = dbuf_ensure(c, B->seg_cnt, 8ull * nblk + 16))) return rc;
-    BZ_HIP(hipMemcpyAsync(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_bz_segment, dim3(nblk), dim3(64), 0, st, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
+    BZ_HIP(hipMemcpy(B->seg_off.p, seg_off.data(), 4ull * (2ull * nblk + 1), hipMemcpyHostToDevice));
+    BZ_HIP(hipStreamSynchronize(st));                                    // the input is in place
+    hipLaunchKernelGGL(k_bz_segment, dim3(nblk), dim3(64), 0, st2, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
                        (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
-    c->tmark("bz:segment");
-    seg.resize(so);
-    BZ_HIP(hipMemcpyAsync(seg.data(), B->seg.p, 4 * so, hipMemcpyDeviceToHost, st));
-    BZ_HIP(hipMemcpyAsync(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost, st));
-    BZ_HIP(hipStreamSynchronize(st));
   }
   const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 640) << 20;
-  uint32_t k0 = 0;
-  while (k0 < nblk) {
-    std::vector<uint64_t> starts; std::vector<uint32_t> lens;
-    const size_t plan0 = B->plans.size();
-    uint64_t est = 0;
-    uint32_t k1 = k0;
-    for (; k1 < nblk; k1++) {
-      BlkPlan P;
-      const uint64_t bs = bstart[k1]; const uint32_t bl = blen[k1];
-      P.start = bs; P.len = bl;
-      const size_t first_sub = starts.size();
-      auto sub_of = [&](uint64_t s0, uint32_t l0) -> uint32_t {                       // pieces that several tactics share are encoded once
-        for (size_t i = first_sub; i < starts.size(); i++) if (starts[i] == s0 && lens[i] == l0) return (uint32_t)i;
-        starts.push_back(s0); lens.push_back(l0);
-        return (uint32_t)(starts.size() - 1);
-      };
-      uint64_t e_blk = 0;
-      const size_t before = starts.size();
-      P.tac[0].push_back(sub_of(bs, bl));                                            // single
-      if (option == 2) {
-        const uint32_t size = bl / 4;                                                  // parts_4 :1237-1253
-        uint32_t stop = 0;
-        for (uint32_t count = 1; count <= 4; count++) { const uint32_t start = stop + 1; stop = count == 4 ? bl : count * size; P.tac[1].push_back(sub_of(bs + start - 1, stop - start + 1)); }
-        for (int t = 0; t < 2; t++) {                                                  // segmented_1 / _2 :1265-1297
-          const uint32_t cnt = seg_cnt[2 * k1 + t], *sp = seg.data() + seg_off[2 * k1 + t];
-          if (cnt == 0) P.tac[2 + t].push_back(sub_of(bs, 0));
-          uint32_t index_start = 1;
-          for (uint32_t q = 0; q < cnt; q++) { P.tac[2 + t].push_back(sub_of(bs + index_start - 1, sp[q] - index_start + 1)); index_start = sp[q] + 1; }
+  const size_t plan_base = B->plans.size();
+  constexpr uint32_t KEPT = 0x80000000u;                                   // piece number that already is a number in B->kept
+  // pass 0: the single block and its four quarters; pass 1: the segments (those that are not one of the former)
+  for (int pass = 0; pass < (option == 2 ? 2 : 1); pass++) {
+    if (pass == 1) {
+      BZ_HIP(hipStreamSynchronize(st2));
+      c->tmark("bz:segment");                                              // what of it was not hidden
+      seg.resize(seg_total);
+      BZ_HIP(hipMemcpy(seg.data(), B->seg.p, 4 * seg_total, hipMemcpyDeviceToHost));
+      BZ_HIP(hipMemcpy(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost));
+    }
+    uint32_t k0 = 0;
+    while (k0 < nblk) {
+      std::vector<uint64_t> starts; std::vector<uint32_t> lens;
+      uint64_t est = 0;
+      uint32_t k1 = k0;
+      for (; k1 < nblk; k1++) {
+        if (pass == 0) { BlkPlan Pn; Pn.start = bstart[k1]; Pn.len = blen[k1]; B->plans.push_back(std::move(Pn)); }
+        BlkPlan &P = B->plans[plan_base + k1];
+        const uint64_t bs = bstart[k1]; const uint32_t bl = blen[k1];
+        const size_t first_sub = starts.size();
+        auto sub_of = [&](uint64_t s0, uint32_t l0) -> uint32_t {                       // pieces that several tactics share are encoded once
+          for (const auto &pc : P.pieces) if (pc.start == s0 && pc.len == l0) return pc.kept | KEPT;
+          for (size_t i = first_sub; i < starts.size(); i++) if (starts[i] == s0 && lens[i] == l0) return (uint32_t)i;
+          starts.push_back(s0); lens.push_back(l0);
+          return (uint32_t)(starts.size() - 1);
+        };
+        uint64_t e_blk = 0;
+        const size_t before = starts.size();
+        std::vector<uint32_t> t0, t1;
+        if (pass == 0) {
+          t0.push_back(sub_of(bs, bl));                                                  // single
+          if (option == 2) {
+            const uint32_t size = bl / 4;                                                // parts_4 :1237-1253
+            uint32_t stop = 0;
+            for (uint32_t count = 1; count <= 4; count++) { const uint32_t start = stop + 1; stop = count == 4 ? bl : count * size; t1.push_back(sub_of(bs + start - 1, stop - start + 1)); }
+          }
+        } else {
+          for (int t = 0; t < 2; t++) {                                                  // segmented_1 / _2 :1265-1297
+            std::vector<uint32_t> &tv = t ? t1 : t0;
+            const uint32_t cnt = seg_cnt[2 * k1 + t], *sp = seg.data() + seg_off[2 * k1 + t];
+            if (cnt == 0) tv.push_back(sub_of(bs, 0));
+            uint32_t index_start = 1;
+            for (uint32_t q = 0; q < cnt; q++) { tv.push_back(sub_of(bs + index_start - 1, sp[q] - index_start + 1)); index_start = sp[q] + 1; }
+          }
         }
+        for (size_t i = before; i < starts.size(); i++) e_blk += (uint64_t)lens[i] + lens[i] / 4 + 8;
+        if (k1 > k0 && est + e_blk > batch_elems) { starts.resize(before); lens.resize(before); if (pass == 0) B->plans.pop_back(); break; }
+        est += e_blk;
+        P.tac[2 * pass] = std::move(t0); P.tac[2 * pass + 1] = std::move(t1);
       }
-      for (size_t i = before; i < starts.size(); i++) e_blk += (uint64_t)lens[i] + lens[i] / 4 + 8;
-      if (k1 > k0 && est + e_blk > batch_elems) { starts.resize(before); lens.resize(before); break; }
-      est += e_blk;
-      B->plans.push_back(std::move(P));
-    }
-    if ((rc = bz_transform(c, d_in, starts, lens)) || (rc = bz_mtf(c)) || (rc = bz_entropy_emit(c, option))) return rc;
-    // keep the batch's bit strings; the plans' piece numbers become numbers in B->kept
-    const uint32_t base = (uint32_t)B->kept.size(), bufno = (uint32_t)B->kept_bufs.size();
-    DBuf kb;
-    if ((rc = dbuf_ensure(c, kb, 4 * (B->nwords + 16)))) return rc;
-    BZ_HIP(hipMemcpyAsync(kb.p, B->words.p, 4 * B->nwords, hipMemcpyDeviceToDevice, st));
-    B->kept_bufs.push_back(kb);
-    for (uint32_t s = 0; s < B->nsb; s++) B->kept.push_back({B->h_res[8ull * s + 7], B->h_woff[s], B->h_crc[s], bufno});
-    for (size_t q = plan0; q < B->plans.size(); q++) {
-      uint64_t mn = ~0ull;
-      for (int t = 0; t < 4; t++) {
-        uint64_t bits = 0;
-        for (uint32_t &sb : B->plans[q].tac[t]) { sb += base; bits += B->kept[sb].bits; }
-        if (!B->plans[q].tac[t].empty() && bits < mn) mn = bits;
+      if (!starts.empty()) {
+        if ((rc = bz_transform(c, d_in, starts, lens)) || (rc = bz_mtf(c)) || (rc = bz_entropy_emit(c, option))) return rc;
+        // keep the batch's bit strings; the plans' piece numbers become numbers in B->kept
+        const uint32_t base = (uint32_t)B->kept.size(), bufno = (uint32_t)B->kept_bufs.size();
+        DBuf kb;
+        if ((rc = dbuf_ensure(c, kb, 4 * (B->nwords + 16)))) return rc;
+        BZ_HIP(hipMemcpyAsync(kb.p, B->words.p, 4 * B->nwords, hipMemcpyDeviceToDevice, st));
+        B->kept_bufs.push_back(kb);
+        for (uint32_t s = 0; s < B->nsb; s++) B->kept.push_back({B->h_res[8ull * s + 7], B->h_woff[s], B->h_crc[s], bufno});
+        for (uint32_t k = k0; k < k1; k++) {
+          BlkPlan &P = B->plans[plan_base + k];
+          for (int t = 2 * pass; t < 2 * pass + 2; t++)
+            for (uint32_t &sb : P.tac[t]) {
+              if (sb & KEPT) { sb &= ~KEPT; continue; }
+              sb += base;
+              bool known = false;
+              for (const auto &pc : P.pieces) known |= pc.kept == sb;
+              if (!known) P.pieces.push_back({starts[sb - base], lens[sb - base], sb});
+            }
+        }
+        c->tmark("bz:keep");
+        BZ_HIP(hipStreamSynchronize(st));
+      } else {
+        for (uint32_t k = k0; k < k1; k++) for (int t = 2 * pass; t < 2 * pass + 2; t++) for (uint32_t &sb : B->plans[plan_base + k].tac[t]) sb &= ~KEPT;
       }
-      B->min_bits_sum += mn;
+      k0 = k1;
+      const double done = ((double)pass + (double)k0 / (double)nblk) / (option == 2 ? 2.0 : 1.0);
+      if (fb && fb((int)(prog0 + (prog1 - prog0) * done), user)) { hipStreamSynchronize(st2); return ZADA_ABORTED; }
     }
-    c->tmark("bz:keep");
-    BZ_HIP(hipStreamSynchronize(st));
-    k0 = k1;
-    if (fb && fb((int)(prog0 + (prog1 - prog0) * (double)k0 / (double)nblk), user)) return ZADA_ABORTED;
+  }
+  for (size_t q = plan_base; q < B->plans.size(); q++) {
+    uint64_t mn = ~0ull;
+    for (int t = 0; t < 4; t++) {
+      uint64_t bits = 0;
+      for (uint32_t sb : B->plans[q].tac[t]) bits += B->kept[sb].bits;
+      if (!B->plans[q].tac[t].empty() && bits < mn) mn = bits;
+    }
+    B->min_bits_sum += mn;
   }
   return 0;
 }
