@@ -180,6 +180,12 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
     out = {"metric": "BZip2_3 encode MB/s (stream bit-exact with the CPU restatement of the reference, Ada parity unpinned)", "value": round(n / dt / 1e6, 2),
            "unit": "MB/s", "workload": "%d MiB silesia_mix_v1, one stream, input and output resident in HBM" % mib, "ms": round(dt * 1e3, 1), "rc": rc,
            "compression_ratio": round(ol / n, 4), "blocks": len(blocks), "tactics_kept": [sum(1 for b in blocks if b[2] == t) for t in range(4)], "phase_ms": tim}
+    dom = max((k for k in tim if k in ("bz:bwt", "bz:entropy", "bz:mtf", "bz:rank")), key=lambda k: tim[k])
+    ach = (n + ol) / (tim[dom] * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": {"bz:bwt": "rotation sort (k_bz_radix_* / k_bz_filter_* / k_bz_place / k_bz_newclass, %d rounds)" % 14,
+                                                  "bz:entropy": "k_bz_entropy", "bz:mtf": "k_bz_mtf_*", "bz:rank": "k_bz_rank"}[dom],
+                       "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                       "note": "algorithmic bytes = N_in + N_out over the longest phase; the path is bound by LDS round trips (package-merge, heap replay) and random class look-ups, not by HBM (DESIGN.md 9)"}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _bzip2 import oracle_encode
