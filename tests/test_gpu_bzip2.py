@@ -66,6 +66,18 @@ def test_streams_bit_exact_vs_oracle_and_digests(encoder, method):
         assert tactics == {0, 1, 2, 3}
 
 
+@pytest.mark.parametrize("method", [12, 13])
+def test_small_block_options_many_blocks(encoder, method):
+    """BZip2_1 / BZip2_2 (100 000 / 400 000-byte blocks, no splitting tactics, one candidate list of the entropy search,
+    bzip2-encoding.adb:900-925) on a stream of dozens of blocks, incl. the balanced last two blocks (:1406-1423)."""
+    Z = product()
+    data = Z.silesia_mix((3 << 20) + 77777).tobytes()
+    o, ev = oracle_encode(data, method - 12)
+    rc, p, crc = encoder.bzip2(data, method)
+    assert rc == 0 and p == o and encoder.bz2_last_blocks() == ev and bz2.decompress(p) == data
+    assert len(ev) > (30 if method == 12 else 7) and all(e[2] == 0 for e in ev)
+
+
 def test_many_blocks_and_batches(encoder):
     """A stream of a few dozen blocks; the same stream when the blocks go through the stages a few at a time."""
     Z = product()
