@@ -169,7 +169,7 @@ struct RleThread {
 // Offsets within the sub-block: tile covers [lo, hi).  Returns for the calling thread the number of bytes it emits; if
 // `dst` is non-null also writes them at dst[prefix ...] (prefix = exclusive scan of the emit counts, computed inside).
 template <bool EMIT>
-__device__ __forceinline__ uint32_t rle1_tile(const uint8_t *__restrict__ raw, uint32_t len, uint32_t lo, uint32_t *l17,
+__device__ __forceinline__ uint32_t rle1_tile(const uint8_t *__restrict__ raw, uint32_t len, uint32_t lo, uint32_t carry_rs1, uint32_t *l17,
                                               uint8_t *__restrict__ dst, uint32_t dst_base, uint32_t *inuse8) {
   const int tid = threadIdx.x;
   const uint32_t p0 = lo + (uint32_t)tid * 32;
@@ -185,15 +185,9 @@ __device__ __forceinline__ uint32_t rle1_tile(const uint8_t *__restrict__ raw, u
   uint32_t before = __shfl_up(incl, 1);
   if ((tid & 63) == 0) { before = 0; for (int k = 0; k < (tid >> 6); k++) before = mx(before, l17[k]); }
   __syncthreads();
-  // run start of the byte before the tile: look back (bounded by the sub-block's start); only thread 0's answer is used
-  __shared__ uint32_t tile_rs;
-  if (tid == 0) {
-    uint32_t rs = 0;
-    if (lo > 0) { uint32_t p = lo; const uint8_t v = raw[lo]; while (p > 0 && raw[p - 1] == v) p--; rs = p; }   // start of the run that contains byte lo
-    tile_rs = rs;
-  }
-  __syncthreads();
-  uint32_t rs = before ? before - 1 : tile_rs;     // run start for the thread's first byte, unless it starts a run itself
+  // a thread whose bytes follow no run start inside the tile continues the run the tile begins in: its start comes with the
+  // tile (carry_rs1 = last run start in the tiles before + 1, from a scan over the sub-block's tiles)
+  uint32_t rs = before ? before - 1 : (carry_rs1 ? carry_rs1 - 1 : 0u);
   uint32_t emits = 0;
   uint8_t outb[40];
 #pragma unroll
@@ -219,15 +213,45 @@ __device__ __forceinline__ uint32_t rle1_tile(const uint8_t *__restrict__ raw, u
   return emits;
 }
 
-// NB the look-back of thread 0 is linear in the length of the run before the tile; runs are cut by the reference's block
-// limits (at most ten times the block capacity), and such data leaves next to nothing to do downstream.
-
-__global__ void __launch_bounds__(256) k_bz_rle_count(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles,
+// last run start (+ 1; 0 = none) among a tile's bytes
+__global__ void __launch_bounds__(256) k_bz_rle_runs(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ tile_last) {
+  __shared__ uint32_t l17[17];
+  const Tile t = tiles[blockIdx.x];
+  const uint8_t *raw = in + T.raw_start[t.sb];
+  const uint32_t len = T.raw_len[t.sb], p0 = t.lo + threadIdx.x * 32;
+  uint32_t last = 0;
+  uint8_t prev = p0 > 0 && p0 - 1 < len ? raw[p0 - 1] : 0;
+  for (uint32_t k = 0; k < 32; k++) {
+    const uint32_t p = p0 + k;
+    if (p < len) { const uint8_t b = raw[p]; if (p == 0 || b != prev) last = p + 1; prev = b; }
+  }
+  OpMax mx;
+  uint32_t tot;
+  wg_scan_incl(last, l17, mx, &tot);
+  if (threadIdx.x == 0) tile_last[blockIdx.x] = tot;
+}
+// exclusive max-scan of per-tile values inside each sub-block
+__global__ void __launch_bounds__(64) k_bz_tile_scan_max(const uint32_t *__restrict__ first_tile, uint32_t *__restrict__ tile_val) {
+  const uint32_t s = blockIdx.x, t0 = first_tile[s], t1 = first_tile[s + 1];
+  const int lane = threadIdx.x;
+  uint32_t carry = 0;
+  OpMax mx;
+  for (uint32_t b = t0; b < t1; b += 64) {
+    const uint32_t i = b + lane;
+    const uint32_t v = i < t1 ? tile_val[i] : 0;
+    const uint32_t incl = wave_scan_incl(v, lane, mx);
+    uint32_t excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0;
+    if (i < t1) tile_val[i] = mx(carry, excl);
+    carry = mx(carry, __shfl(incl, 63));
+  }
+}
+__global__ void __launch_bounds__(256) k_bz_rle_count(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_rs,
                                                       uint32_t *__restrict__ tile_cnt) {
   __shared__ uint32_t l17[17];
   const Tile t = tiles[blockIdx.x];
   const uint8_t *raw = in + T.raw_start[t.sb];
-  const uint32_t e = rle1_tile<false>(raw, T.raw_len[t.sb], t.lo, l17, nullptr, 0, nullptr);
+  const uint32_t e = rle1_tile<false>(raw, T.raw_len[t.sb], t.lo, tile_rs[blockIdx.x], l17, nullptr, 0, nullptr);
   OpSum sm;
   uint32_t tot;
   wg_scan_incl(e, l17, sm, &tot);
@@ -251,7 +275,7 @@ __global__ void __launch_bounds__(64) k_bz_tile_scan(const uint32_t *__restrict_
   if (lane == 0) totals[s] = carry;
 }
 
-__global__ void __launch_bounds__(256) k_bz_rle_emit(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles,
+__global__ void __launch_bounds__(256) k_bz_rle_emit(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_rs,
                                                      const uint32_t *__restrict__ tile_off, uint8_t *__restrict__ rle) {
   __shared__ uint32_t l17[17];
   __shared__ uint32_t use8[8];
@@ -259,7 +283,7 @@ __global__ void __launch_bounds__(256) k_bz_rle_emit(const uint8_t *__restrict__
   if (threadIdx.x < 8) use8[threadIdx.x] = 0;
   __syncthreads();
   const uint8_t *raw = in + T.raw_start[t.sb];
-  rle1_tile<true>(raw, T.raw_len[t.sb], t.lo, l17, rle, T.off[t.sb] + tile_off[blockIdx.x], use8);
+  rle1_tile<true>(raw, T.raw_len[t.sb], t.lo, tile_rs[blockIdx.x], l17, rle, T.off[t.sb] + tile_off[blockIdx.x], use8);
   __syncthreads();
   if (threadIdx.x < 8 && use8[threadIdx.x]) atomicOr(&T.inuse[t.sb * 8 + threadIdx.x], use8[threadIdx.x]);
 }
@@ -1444,7 +1468,7 @@ struct Bz2State {
   // sub-block tables
   DBuf raw_start, raw_len, off, n, inuse, crc, bwt_index, done, unsorted, scal;
   // tiles
-  DBuf rtiles, rtile_first, rtile_val, rtile_crc, etiles, etile_first;
+  DBuf rtiles, rtile_first, rtile_val, rtile_crc, rtile_rs, etiles, etile_first;
   // element space
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
   std::vector<uint32_t> h_cm, h_cfirst;
@@ -1470,7 +1494,7 @@ struct Bz2State {
   uint32_t selcap = 0;
   bool rank_attr = false;
   std::vector<DBuf *> all() {
-    return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc,
+    return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc, &rtile_rs,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
             &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest};
@@ -1533,11 +1557,15 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   build_tiles(lens, RT_TILE, rt, rfirst);
   const uint32_t nrt = (uint32_t)rt.size();
   if ((rc = dbuf_ensure(c, B->rtiles, sizeof(Tile) * (size_t)nrt)) || (rc = dbuf_ensure(c, B->rtile_first, 4ull * (nsb + 1))) ||
-      (rc = dbuf_ensure(c, B->rtile_val, 4ull * nrt)) || (rc = dbuf_ensure(c, B->rtile_crc, 4ull * nrt))) return rc;
+      (rc = dbuf_ensure(c, B->rtile_val, 4ull * nrt)) || (rc = dbuf_ensure(c, B->rtile_crc, 4ull * nrt)) || (rc = dbuf_ensure(c, B->rtile_rs, 4ull * nrt))) return rc;
   BZ_HIP(hipMemcpyAsync(B->rtiles.p, rt.data(), sizeof(Tile) * (size_t)nrt, hipMemcpyHostToDevice, st));
   BZ_HIP(hipMemcpyAsync(B->rtile_first.p, rfirst.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
   SubTab T = subtab(B);
-  if (nrt) hipLaunchKernelGGL(k_bz_rle_count, dim3(nrt), dim3(256), 0, st, d_in, T, B->rtiles.as<Tile>(), B->rtile_val.as<uint32_t>());
+  if (nrt) {
+    hipLaunchKernelGGL(k_bz_rle_runs, dim3(nrt), dim3(256), 0, st, d_in, T, B->rtiles.as<Tile>(), B->rtile_rs.as<uint32_t>());
+    hipLaunchKernelGGL(k_bz_tile_scan_max, dim3(nsb), dim3(64), 0, st, B->rtile_first.as<uint32_t>(), B->rtile_rs.as<uint32_t>());
+    hipLaunchKernelGGL(k_bz_rle_count, dim3(nrt), dim3(256), 0, st, d_in, T, B->rtiles.as<Tile>(), B->rtile_rs.as<uint32_t>(), B->rtile_val.as<uint32_t>());
+  }
   hipLaunchKernelGGL(k_bz_tile_scan, dim3(nsb), dim3(64), 0, st, B->rtile_first.as<uint32_t>(), B->rtile_val.as<uint32_t>(), B->n.as<uint32_t>());
   B->h_n.resize(nsb);
   BZ_HIP(hipMemcpyAsync(B->h_n.data(), B->n.p, 4ull * nsb, hipMemcpyDeviceToHost, st));
@@ -1551,7 +1579,7 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   const size_t ne = (size_t)tot + 16;
   if ((rc = dbuf_ensure(c, B->rle, ne)) || (rc = dbuf_ensure(c, B->bwt, ne))) return rc;
   if (nrt) {
-    hipLaunchKernelGGL(k_bz_rle_emit, dim3(nrt), dim3(256), 0, st, d_in, T, B->rtiles.as<Tile>(), B->rtile_val.as<uint32_t>(), B->rle.as<uint8_t>());
+    hipLaunchKernelGGL(k_bz_rle_emit, dim3(nrt), dim3(256), 0, st, d_in, T, B->rtiles.as<Tile>(), B->rtile_rs.as<uint32_t>(), B->rtile_val.as<uint32_t>(), B->rle.as<uint8_t>());
     hipLaunchKernelGGL(k_bz_crc_tiles, dim3((nrt + 63) / 64), dim3(64), 0, st, d_in, T, B->rtiles.as<Tile>(), nrt, B->rtile_crc.as<uint32_t>());
   }
   hipLaunchKernelGGL(k_bz_crc_fold, dim3((nsb + 63) / 64), dim3(64), 0, st, T, B->rtile_first.as<uint32_t>(), B->rtile_crc.as<uint32_t>());
