@@ -249,3 +249,147 @@ def test_one_stream_over_two_and_three_ranks_protocol():
 def importlib_sharding():
     import importlib
     return importlib.import_module("zip-ada_amd.sharding")
+
+
+class OracleBz2RangeModel:
+    """The BZip2 range methods of Encoder (zada_bz2_range_*) made of oracle calls: block limits from the oracle's trace of the
+    whole stream, every piece of every tactic through zo_bz2_block, the choice through the product's host function
+    zada_bz2_select (no GPU needed), the bytes put together with Python integers.  Stands in for the GPU encoder in the
+    gloo test of sharding.bzip2_stream_rank."""
+
+    def __init__(self, data, method):
+        import importlib
+        from _bzip2 import oracle_encode
+        self.data, self.method, self.option = data, method, method - 12
+        self.ref, self.trace = oracle_encode(data, self.option)
+        self.lib = importlib.import_module("zip-ada_amd").load_library()
+
+    def bz2_range_open(self, d_buf, buf_len, buf_off, stream_total, start, own_end, method=14):
+        mine = [b for b in self.trace if start <= b[0] < own_end]
+        assert all(b[0] + b[1] <= buf_off + buf_len for b in mine), "halo too short"
+        assert not mine or mine[0][0] == start, "the hand-over must be the start of a block"
+        self.blocks = mine
+        return (mine[-1][0] + mine[-1][1]) if mine else start, len(mine)
+
+    def bz2_range_encode(self):
+        import numpy as np
+        from _bzip2 import bz_oracle, oracle_block
+        O = bz_oracle()
+        self.pieces, self.bits = [], {}
+        for (st, ln, _t, _k) in self.blocks:
+            raw = self.data[st:st + ln]
+            tac = {0: [(0, ln)]}
+            if self.option == 2:
+                size, stop, p4 = ln // 4, 0, []
+                for count in range(1, 5):
+                    s0 = stop + 1
+                    stop = ln if count == 4 else count * size
+                    p4.append((s0 - 1, stop - s0 + 1))
+                tac[1] = p4
+                for t in (2, 3):
+                    seg = np.zeros(ln // 4000 + 4, np.int32)
+                    k = O.zo_bz2_segments(raw, ln, t, seg.ctypes.data, seg.size)
+                    idx, lst = 1, []
+                    for e in seg[:k]:
+                        lst.append((idx - 1, int(e) - idx + 1)); idx = int(e) + 1
+                    tac[t] = lst
+            for t in tac:
+                for (o, l) in tac[t]:
+                    if (st + o, l) not in self.bits:
+                        ob = oracle_block(raw[o:o + l], self.option, want_bits=True)
+                        self.bits[(st + o, l)] = (ob["info"].bits, ob["info"].block_crc, bytes(ob["bits"]))
+            self.pieces.append({t: [(st + o, l) for (o, l) in v] for t, v in tac.items()})
+
+    def bz2_range_table(self):
+        import numpy as np
+        tab = np.zeros((len(self.blocks), 4, 3), np.uint64)
+        for q, tac in enumerate(self.pieces):
+            for t in range(4):
+                if t not in tac:
+                    tab[q, t] = (0xFFFFFFFFFFFFFFFF, 0, 0)
+                    continue
+                bits, fold = 0, 0
+                for key in tac[t]:
+                    b, c, _ = self.bits[key]
+                    bits += b
+                    fold = (((fold << 1) | (fold >> 31)) & 0xFFFFFFFF) ^ c
+                tab[q, t] = (bits, len(tac[t]), fold)
+        return tab
+
+    def bz2_select(self, tab, bitpos_in=32, crc_in=0):
+        import ctypes
+        import numpy as np
+        tab = np.ascontiguousarray(tab, np.uint64)
+        nb = tab.shape[0]
+        choice = np.zeros(max(nb, 1), np.uint8)
+        bp, crc = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        self.lib.zada_bz2_select(nb, tab.ctypes.data, bitpos_in, crc_in, choice.ctypes.data, ctypes.byref(bp), ctypes.byref(crc))
+        return choice[:nb], bp.value, crc.value
+
+    def bz2_range_assemble(self, choice, bit_begin, d_out, cap, header=False, footer_crc=None):
+        import ctypes
+        base = 0 if header else bit_begin // 8 * 8
+        acc, nbits = 0, bit_begin - base                       # acc holds nbits bits, most significant first
+        if header:
+            acc, nbits = int.from_bytes(b"BZh" + bytes([48 + (1, 4, 9)[self.option]]), "big"), 32
+        for q, tac in enumerate(self.pieces):
+            for key in tac[int(choice[q])]:
+                b, _c, by = self.bits[key]
+                acc = (acc << b) | (int.from_bytes(by, "big") >> (len(by) * 8 - b))
+                nbits += b
+        if footer_crc is not None:
+            acc = (acc << 80) | (0x177245385090 << 32) | footer_crc
+            nbits += 80
+        ln = (nbits + 7) // 8
+        buf = (acc << (ln * 8 - nbits)).to_bytes(ln, "big") if ln else b""
+        assert ln <= cap
+        ctypes.memmove(d_out, buf, ln)
+        self.last = [(b[0], b[1], int(choice[q]), len(self.pieces[q][int(choice[q])])) for q, b in enumerate(self.blocks)]
+        return ln
+
+    def bz2_last_blocks(self):
+        return self.last
+
+
+def _bz_stream_worker(rank, world, port, q, n, method):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import importlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding = importlib.import_module("zip-ada_amd.sharding")
+    data = bytes(silesia_mix(n))
+    ranges = sharding.bzip2_ranges(n, world, method)
+    enc = OracleBz2RangeModel(data, method)
+    comm = sharding.TorchComm(torch.device("cpu"))
+    res = sharding.bzip2_stream_rank(enc, comm, n, ranges, 0, method, lambda k: torch.zeros(k, dtype=torch.uint8))
+    payload = res["payload"] if res["payload"] is not None else torch.zeros(1, dtype=torch.uint8)
+    got = sharding.gather_payloads(payload, res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
+    blocks = [None] * world
+    dist.all_gather_object(blocks, res["blocks"])
+    if rank == 0:
+        out = sharding.stitch_stream(torch, got[0], res["spans"], res["total_bits"], torch.device("cpu"))
+        q.put((bytes(out.numpy()), [b for bl in blocks for b in bl], len(ranges), enc.ref, enc.trace))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_bzip2_stream_over_two_and_three_ranks_protocol():
+    """sharding.bzip2_stream_rank over gloo (block-chain hand-over by send / recv, all_gather of the tables, the choice
+    replayed on every rank, payload gather, OR at the joints): stitched stream == the oracle's stream, block for block."""
+    import bz2
+    for world, n, method in ((2, (5 << 20) + 333, 12), (3, 7 << 20, 12), (2, 1 << 20, 14)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 33500 + (os.getpid() + world * 11 + n) % 2000
+        procs = [ctx.Process(target=_bz_stream_worker, args=(r, world, port, q, n, method)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out, blocks, nr, ref, trace = q.get(timeout=240)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert nr == (world if method == 12 else 1)
+        assert out == ref and blocks == trace, (world, n, method)
+        assert bz2.decompress(out) == bytes(silesia_mix(n))

@@ -299,19 +299,24 @@ def stream_crc(enc_or_lib_combine, infos, reg=0xFFFFFFFF):
 #    c. all_gather of the per-block tables (12 values per block); every rank replays the choice of the tactics
 #    d. every rank assembles its bytes of the stream; the payloads are gathered and OR-ed at the joints (stitch_stream)
 # ------------------------------------------------------------------------------------------------------------------
-BZ_HALO = 10 * 900_000 + 512        # bytes of the following ranges a rank needs behind its own: a block takes at most ten capacities
+def bzip2_halo(method=14):
+    """Bytes of the following ranges a rank needs behind its own: a block takes at most ten capacities (bzip2-encoding.adb:1156-1158)."""
+    return 10 * {12: 100_000, 13: 400_000, 14: 900_000}[method] + 512
 
 
-def bzip2_ranges(stream_size, world):
-    """Ranges of at least a halo each (so that a rank's halo lies in the next range or two); fewer ranges than ranks for short streams."""
-    nr = max(1, min(world, stream_size // (2 * BZ_HALO)))
+BZ_HALO = bzip2_halo(14)
+
+
+def bzip2_ranges(stream_size, world, method=14):
+    """Ranges of at least two halos each (so that a rank's halo lies in the next range); fewer ranges than ranks for short streams."""
+    nr = max(1, min(world, stream_size // (2 * bzip2_halo(method))))
     step = (stream_size + nr - 1) // nr if stream_size else 0
     return [(k * step, min(step, stream_size - k * step)) for k in range(nr)] if stream_size else [(0, 0)]
 
 
-def bzip2_window(stream_size, lo, n):
+def bzip2_window(stream_size, lo, n, method=14):
     """The bytes a rank holds: its range and the halo behind it.  Returns (buffer offset in the stream, buffer length)."""
-    return lo, min(stream_size, lo + n + BZ_HALO) - lo
+    return lo, min(stream_size, lo + n + bzip2_halo(method)) - lo
 
 
 def bzip2_stream_rank(enc, comm, stream_size, ranges, d_buf_ptr, method, alloc_out):
@@ -323,7 +328,7 @@ def bzip2_stream_rank(enc, comm, stream_size, ranges, d_buf_ptr, method, alloc_o
     tab = np.zeros((0, 4, 3), np.uint64)
     if active:
         lo, n = ranges[r]
-        off, blen = bzip2_window(stream_size, lo, n)
+        off, blen = bzip2_window(stream_size, lo, n, method)
         start = int.from_bytes(comm.recv_bytes(8, r - 1), "little") if r > 0 else 0
         nxt, _nb = enc.bz2_range_open(d_buf_ptr, blen, off, stream_size, start, lo + n if r + 1 < nr else stream_size, method)
         if r + 1 < nr:
