@@ -181,6 +181,13 @@ int zada_bzip2(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t
 /* the same with input and output in device memory (d_out: cap bytes) */
 int zada_bzip2_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len,
                       uint32_t *crc_inout);
+/* Many entries in one call (zipada's usual workload: many small files): the entries that are one block each -- up to 0.8 block
+ * capacities, 720 000 bytes for BZip2_3 -- go through ONE launch sequence (every entry is a block of the call with its own stream
+ * header, tactic choice and footer); longer ones are taken one after the other.  Arrays as for zada_deflate_batch; rc[i] is
+ * zada_bzip2's return code for entry i, the stream is delivered whenever it fits cap[i].  Knob "bz_batch_mib" (default 256):
+ * MiB of entries per launch sequence.  Returns the worst rc. */
+int zada_bzip2_batch(zada_ctx *ctx, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
+                     const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc);
 /* Trace of the last zada_bzip2* call: per block of Read_and_Split_Block (bzip2-encoding.adb:1144) four values -- raw start,
  * raw length, splitting tactic kept (0 single, 1 parts_4, 2 segmented_1, 3 segmented_2), its number of sub-blocks.
  * Returns the number of values there are; at most cap_items are stored. */

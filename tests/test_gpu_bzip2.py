@@ -218,3 +218,35 @@ def test_bench_bzip2_multi_rank_path_on_one_gpu():
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 3 and "3 block ranges" in res["config"]["workload"]
     assert res["checks"] == {"stream_decompresses": True, "rank0_window_crc": True}, res["checks"]
+
+
+def test_batch_of_small_entries_is_bit_exact(encoder):
+    """zada_bzip2_batch: entries of one block each through one launch sequence == one call per entry == the oracle; entries
+    longer than a block, empty and incompressible ones in the same call; several launch sequences (bz_batch_mib)."""
+    Z = product()
+    rng = np.random.default_rng(33)
+    mix = Z.silesia_mix(6 << 20)
+    datas, off = [], 0
+    for k in range(60):
+        ln = int(rng.integers(0, 120000)) if k % 7 else int(rng.integers(0, 300))
+        datas.append(bytes(mix[off:off + ln]) if k % 9 else bytes(rng.integers(0, 256, ln, dtype=np.uint8)))
+        off = (off + ln) % (len(mix) - 130000)
+    datas.append(b"")
+    datas.append(bytes(mix[:800000]))                       # more than one block's worth: taken by itself
+    datas.append(bytes(mix[1000:720000]))                   # just below the limit
+    for method, mib in ((14, 256), (12, 256), (14, 1)):
+        sel = datas if method == 14 else datas[:40]
+        encoder.set_knob("bz_batch_mib", mib)
+        try:
+            res = encoder.bzip2_batch(sel, method)
+        finally:
+            encoder.set_knob("bz_batch_mib", 256)
+        for d, (rc, p, crc) in zip(sel, res):
+            o, _ = oracle_encode(d, method - 12)
+            assert p == o and rc == (1 if len(o) >= len(d) else 0) and (crc ^ 0xFFFFFFFF) == zlib.crc32(d), (method, mib, len(d))
+    # the container writer takes the batch path for BZip2 methods too
+    from _common import oracle_zip
+    entries = [("f%02d" % k, d) for k, d in enumerate(datas[:25])]
+    zc = Z.ZipCreate(encoder, 14)
+    zc.add_streams([n for n, _ in entries], [d for _, d in entries])
+    assert zc.finish() == oracle_zip(entries, 14)

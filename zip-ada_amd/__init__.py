@@ -95,6 +95,7 @@ def load_library():
     L.zada_bz2_select.restype = None
     L.zada_bz2_select.argtypes = [u64, vp, u64, ctypes.c_uint32, vp, u64p, u32p]
     L.zada_bz2_range_assemble.argtypes = [vp, vp, u64, u64, i32, ctypes.c_uint32, vp, u64, u64p]
+    L.zada_bzip2_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.zada_bz2_last_blocks.restype = ctypes.c_uint64
     L.zada_bz2_last_blocks.argtypes = [vp, vp, u64]
     L.zada_crc32_combine.restype = ctypes.c_uint32
@@ -190,6 +191,31 @@ class Encoder:
         if rc < 0:
             self._err(rc, "zada_bzip2")
         return rc, (out.raw[:ol.value] if ol.value <= cap else None), c.value
+
+    def bzip2_batch(self, datas, method=14, crc=0xFFFFFFFF):
+        """Independent BZip2 streams (one per Zip entry) in one call: zada_bzip2_batch takes the entries that are one block each
+        (up to 0.8 block capacities) through ONE launch sequence.  Returns a list of (rc, stream or None, running CRC register);
+        rc 1 = not smaller than the input (the stream is still there when it fits len + len // 4 + 128 bytes)."""
+        import numpy as np
+        cnt = len(datas)
+        if cnt == 0:
+            return []
+        lens = np.fromiter((len(d) for d in datas), dtype=np.uint64, count=cnt)
+        caps = lens + lens // 4 + 128
+        offs = np.concatenate(([0], np.cumsum(caps)[:-1])).astype(np.uint64)
+        arena = np.empty(int(caps.sum()), dtype=np.uint8)
+        outp = (arena.ctypes.data + offs).astype(np.uint64)
+        keep = [d if len(d) else b"\0" for d in datas]
+        ins = np.fromiter((_addr(d) for d in keep), dtype=np.uint64, count=cnt)
+        ols = np.zeros(cnt, dtype=np.uint64)
+        crcs = np.full(cnt, crc, dtype=np.uint32)
+        rcs = np.zeros(cnt, dtype=np.int32)
+        worst = self.lib.zada_bzip2_batch(self.ctx, method, cnt, ins.ctypes.data, lens.ctypes.data, outp.ctypes.data, caps.ctypes.data,
+                                          ols.ctypes.data, crcs.ctypes.data, rcs.ctypes.data)
+        if worst < 0:
+            self._err(worst, "zada_bzip2_batch")
+        mv = memoryview(arena)
+        return [(int(rcs[i]), bytes(mv[int(offs[i]):int(offs[i]) + int(ols[i])]) if rcs[i] >= 0 and ols[i] <= caps[i] else None, int(crcs[i])) for i in range(cnt)]
 
     def bzip2_device(self, d_in, n, d_out, cap, method=14, crc=0xFFFFFFFF):
         """BZip2 stream of n bytes at device address d_in into d_out (cap bytes).  Returns (rc, length, running CRC register)."""
@@ -449,11 +475,13 @@ class ZipCreate:
         import zlib
         if self.method == Method.Store:
             res = [(1, None, 0)] * len(datas)
+        elif 12 <= self.method <= 14:
+            res = self.enc.bzip2_batch(datas, self.method)
         else:
             res = self.enc.deflate_batch(datas, self.method)
         for name, data, (rc, payload, crc) in zip(names, datas, res):
             if rc == 0:
-                self.add_compressed(name, payload, crc ^ 0xFFFFFFFF, len(data), 8, file_time, unicode_name)
+                self.add_compressed(name, payload, crc ^ 0xFFFFFFFF, len(data), 12 if 12 <= self.method <= 14 else 8, file_time, unicode_name)
             else:
                 self.add_compressed(name, bytes(data), zlib.crc32(data) if self.method == Method.Store else crc ^ 0xFFFFFFFF, len(data), 0, file_time, unicode_name)
 

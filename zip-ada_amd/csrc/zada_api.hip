@@ -872,6 +872,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
   else if (!strcmp(name, "inner_budget")) z->c.knob_inner_budget = value;
   else if (!strcmp(name, "span_mib")) { if (value < 1 || value > 3968) return ZADA_E_INVALID; z->c.knob_span_mib = value; }
+  else if (!strcmp(name, "bz_batch_mib")) { if (value < 1 || value > 2048) return ZADA_E_INVALID; z->c.knob_bz_batch_mib = value; }
   else if (!strcmp(name, "bz_span_mib")) { if (value < 24 || value > 3072) return ZADA_E_INVALID; z->c.knob_bz_span_mib = value; }
   else if (!strcmp(name, "bz_batch_melems")) { if (value < 1 || value > 1536) return ZADA_E_INVALID; z->c.knob_bz_batch_melems = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
@@ -1020,6 +1021,84 @@ int zada_bzip2(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *
   if (out_len) *out_len = ol;
   if (ol <= cap && copy_out(c, out, d_out, ol)) return ZADA_E_HIP;
   return rc;
+}
+// entries idx[0 .. E) of the caller's arrays, each short enough for one block, through one launch sequence
+static int bzip2_batch_core(Ctx *c, int method, const int *idx, uint32_t E, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out, const uint64_t *cap,
+                            uint64_t *out_len, uint32_t *crc, int *rc_out) {
+  hipStream_t st = c->stream;
+  std::vector<uint64_t> start(E); std::vector<uint32_t> start32(E + 1), len(E + 1), crc_in(E + 1);
+  uint64_t total = 0;
+  for (uint32_t e = 0; e < E; e++) {
+    start[e] = total; start32[e] = (uint32_t)total; len[e] = (uint32_t)n[idx[e]]; crc_in[e] = crc ? crc[idx[e]] : 0xFFFFFFFFu;
+    total += (n[idx[e]] + 63) & ~63ull;
+  }
+  if (total >= (1ull << 32)) return ZADA_E_TOO_LARGE;
+  const uint64_t out_cap = total + total / 4 + 128ull * E + (1u << 20);
+  int rc = ensure_rin(c, total + 64 + 16ull * (E + 1));
+  if (!rc) rc = grow_pinned((void **)&c->bstage, &c->cap_bstage, (total > out_cap ? total : out_cap) + 64);
+  if (rc) return rc;
+  parallel_entries(E, total, [&](uint32_t e) { if (len[e]) memcpy(c->bstage + start[e], in[idx[e]], len[e]); });
+  c->tbegin(); c->tmark("bz:begin");
+  uint8_t *d_arena = c->ws.rin_own;
+  uint32_t *d_tab = (uint32_t *)(d_arena + ((total + 63) & ~63ull));          // starts, lengths, CRC registers behind the entries
+  hipMemcpyAsync(d_arena, c->bstage, total, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_tab, start32.data(), 4ull * E, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_tab + E, len.data(), 4ull * E, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_tab + 2 * E, crc_in.data(), 4ull * E, hipMemcpyHostToDevice, st);
+  hipLaunchKernelGGL(k_batch_crc, dim3(E), dim3(64), 0, st, E, d_arena, d_tab, d_tab + E, d_tab + 2 * E);
+  hipMemcpyAsync(crc_in.data(), d_tab + 2 * E, 4ull * E, hipMemcpyDeviceToHost, st);
+  if (hip_check(c, hipStreamSynchronize(st), "bzip2 batch in")) return ZADA_E_HIP;
+  std::vector<uint64_t> off(E), bytes(E);
+  rc = bz2_batch_encode(c, method - ZADA_BZIP2_1, d_arena, E, start.data(), len.data(), c->bstage, out_cap, off.data(), bytes.data());
+  c->tmark("bz:end"); c->tend();
+  if (rc) return rc;
+  std::atomic<int> bad(0);
+  parallel_entries(E, out_cap, [&](uint32_t e) {
+    const int i = idx[e];
+    out_len[i] = bytes[e];
+    if (crc) crc[i] = crc_in[e];
+    rc_out[i] = bytes[e] >= n[i] ? ZADA_INEFFICIENT : ZADA_OK;                    // zip-compress.adb:479-486
+    if (bytes[e] <= cap[i]) memcpy(out[i], c->bstage + off[e], bytes[e]);
+    else if (rc_out[i] == ZADA_OK) { rc_out[i] = ZADA_E_INVALID; bad = 1; }
+  });
+  if (bad) c->err = "output buffer too small";
+  return 0;
+}
+
+int zada_bzip2_batch(zada_ctx *z, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out, const uint64_t *cap, uint64_t *out_len,
+                     uint32_t *crc, int *rc) {
+  if (!z || count < 0 || method < ZADA_BZIP2_1 || method > ZADA_BZIP2_3) return ZADA_E_INVALID;
+  int prc = prepare(z);
+  if (prc) return prc;
+  Ctx *c = &z->c;
+  // an entry whose RLE_1 form cannot reach the block capacity is one block (bzip2-encoding.adb:1161-1209: bytes are taken while
+  // the simulated size + 5 stays below the capacity; RLE_1 grows data by a quarter at most); it also stays below the sizes
+  // at which the last two blocks are balanced (:1406-1423)
+  const uint64_t capacity = method == ZADA_BZIP2_1 ? 100000 : method == ZADA_BZIP2_2 ? 400000 : 900000, one_block = (capacity - 16) * 4 / 5;
+  int worst = 0;
+  std::vector<int> group;
+  uint64_t gbytes = 0;
+  auto flush_group = [&]() {
+    if (group.empty()) return;
+    int r = group.size() == 1 ? 1 : finish_call(c, bzip2_batch_core(c, method, group.data(), (uint32_t)group.size(), in, n, out, cap, out_len, crc, rc));
+    if (group.size() == 1 || r == ZADA_E_NOMEM || r == ZADA_E_TOO_LARGE) {
+      for (int i : group) { rc[i] = zada_bzip2(z, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr); if (rc[i] < 0) worst = rc[i]; }
+    } else if (r < 0) { for (int i : group) rc[i] = r; worst = r; }
+    else { for (int i : group) if (rc[i] < 0) worst = rc[i]; }
+    group.clear(); gbytes = 0;
+  };
+  for (int i = 0; i < count; i++) {
+    if (n[i] <= one_block) {
+      const uint64_t slot = (n[i] + 63) & ~63ull;
+      if (gbytes + slot > ((uint64_t)c->knob_bz_batch_mib << 20)) flush_group();
+      group.push_back(i); gbytes += slot;
+    } else {
+      rc[i] = zada_bzip2(z, method, in[i], n[i], out[i], cap[i], &out_len[i], crc ? &crc[i] : nullptr, nullptr, nullptr);
+      if (rc[i] < 0) worst = rc[i];
+    }
+  }
+  flush_group();
+  return worst;
 }
 uint64_t zada_bz2_last_blocks(zada_ctx *z, uint64_t *dst, uint64_t cap_items) { return z ? bz2_last_blocks(&z->c, dst, cap_items) : 0; }
 

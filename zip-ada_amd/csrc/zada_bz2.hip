@@ -2088,6 +2088,78 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
   return nbytes >= n ? ZADA_INEFFICIENT : ZADA_OK;
 }
 
+// ---- many small entries (zipada's usual workload, tools/zipada.adb:126-134), one launch sequence: every entry is a stream of
+//      its own with ONE block (the caller only sends entries short enough for that), so the entries are simply the blocks of a
+//      call; each gets its own header, choice (from bit 32) and footer.  h_out: host buffer for the streams, entry q's at
+//      out_off[q] (4-byte aligned), out_bytes[q] long.  Returns ZADA_E_TOO_LARGE if h_out (cap bytes) cannot take them.
+int bz2_batch_encode(Ctx *c, int option, const uint8_t *d_arena, uint32_t E, const uint64_t *starts, const uint32_t *lens, uint8_t *h_out, uint64_t cap,
+                     uint64_t *out_off, uint64_t *out_bytes) {
+  Bz2State *B = bz_state(c);
+  hipStream_t st = c->stream;
+  int rc;
+  bz_reset_call(c);
+  B->trace.clear();
+  std::vector<uint64_t> bstart(starts, starts + E);
+  std::vector<uint32_t> blen(lens, lens + E);
+  if ((rc = bz_blocks_encode(c, option, d_arena, bstart, blen, nullptr, nullptr, 0, 0))) return rc;
+  std::vector<uint64_t> tab;
+  bz_fill_table(B, tab);
+  const int level = option == 0 ? 1 : option == 1 ? 4 : 9;
+  std::vector<uint8_t> choice(E);
+  std::vector<uint32_t> extra(4ull * E);
+  std::vector<uint64_t> woff(E + 1);
+  uint64_t w = 0;
+  for (uint32_t q = 0; q < E; q++) {
+    uint64_t bit_end = 0; uint32_t crc = 0;
+    zada_bz2_select(1, tab.data() + 12ull * q, 32, 0, &choice[q], &bit_end, &crc);
+    extra[4ull * q] = ((uint32_t)'B' << 24) | ((uint32_t)'Z' << 16) | ((uint32_t)'h' << 8) | (uint32_t)('0' + level);
+    extra[4ull * q + 1] = 0x17724538u; extra[4ull * q + 2] = 0x50900000u | (crc >> 16); extra[4ull * q + 3] = crc << 16;
+    woff[q] = w;
+    out_off[q] = 4 * w; out_bytes[q] = (bit_end + 80 + 7) / 8;
+    w += (bit_end + 80 + 31) / 32 + 1;
+  }
+  woff[E] = w;
+  bz_set_trace(B, choice.data());
+  if (4 * w > cap) { bz_reset_call(c); return ZADA_E_TOO_LARGE; }
+  if ((rc = dbuf_ensure(c, B->outw, 4 * w + 64)) || (rc = dbuf_ensure(c, B->extra, 16ull * E + 64))) return rc;
+  BZ_HIP(hipMemsetAsync(B->outw.p, 0, 4 * w + 64, st));
+  BZ_HIP(hipMemcpyAsync(B->extra.p, extra.data(), 16ull * E, hipMemcpyHostToDevice, st));
+  // copy jobs: per source buffer (the kept bit strings of every batch of pieces, and the headers / footers)
+  const size_t nsrc = B->kept_bufs.size() + 1;
+  std::vector<std::vector<CopyJob>> jobs(nsrc);
+  std::vector<std::vector<uint64_t>> first(nsrc);
+  std::vector<uint64_t> dstw(nsrc, 0);
+  auto add = [&](size_t src, uint64_t src_word, uint64_t dpos, uint64_t bits) {
+    CopyJob J; J.src_word = src_word; J.dpos = dpos; J.bits = bits; J.first_dst_word = dpos >> 5;
+    first[src].push_back(dstw[src]);
+    dstw[src] += ((dpos + bits + 31) >> 5) - (dpos >> 5);
+    jobs[src].push_back(J);
+  };
+  for (uint32_t q = 0; q < E; q++) {
+    uint64_t bitpos = 32 * woff[q];
+    add(nsrc - 1, 4ull * q, bitpos, 32);
+    bitpos += 32;
+    for (uint32_t sb : B->plans[q].tac[choice[q]]) { const KeptSub &K = B->kept[sb]; add(K.buf, K.woff, bitpos, K.bits); bitpos += K.bits; }
+    add(nsrc - 1, 4ull * q + 1, bitpos, 80);
+  }
+  for (size_t b = 0; b < nsrc; b++) {
+    if (jobs[b].empty()) continue;
+    first[b].push_back(dstw[b]);
+    if ((rc = dbuf_ensure(c, B->jobs, sizeof(CopyJob) * jobs[b].size())) || (rc = dbuf_ensure(c, B->job_first, 8 * first[b].size()))) return rc;
+    BZ_HIP(hipMemcpyAsync(B->jobs.p, jobs[b].data(), sizeof(CopyJob) * jobs[b].size(), hipMemcpyHostToDevice, st));
+    BZ_HIP(hipMemcpyAsync(B->job_first.p, first[b].data(), 8 * first[b].size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bz_assemble, dim3((uint32_t)((dstw[b] + 255) / 256)), dim3(256), 0, st, B->jobs.as<CopyJob>(), B->job_first.as<uint64_t>(), (uint32_t)jobs[b].size(),
+                       b + 1 == nsrc ? B->extra.as<uint32_t>() : B->kept_bufs[b].as<uint32_t>(), B->outw.as<uint32_t>());
+    BZ_HIP(hipStreamSynchronize(st));
+  }
+  c->tmark("bz:assemble");
+  hipLaunchKernelGGL(k_bz_words_to_bytes, dim3((uint32_t)((w + 255) / 256)), dim3(256), 0, st, B->outw.as<uint32_t>(), w, B->outw.as<uint32_t>());
+  BZ_HIP(hipMemcpyAsync(h_out, B->outw.p, 4 * w, hipMemcpyDeviceToHost, st));
+  BZ_HIP(hipStreamSynchronize(st));
+  bz_reset_call(c);
+  return 0;
+}
+
 // ---- one stream over several contexts / GPUs: a context takes the blocks that start inside its range ----
 int bz2_range_open(Ctx *c, int option, const uint8_t *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t stream_total, uint64_t start, uint64_t own_end,
                    uint64_t *next_start, uint64_t *nblocks) {

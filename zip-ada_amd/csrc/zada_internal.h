@@ -257,6 +257,7 @@ struct Ctx {
   int knob_inner_budget = 0;        // ZADA_INNER_BUDGET: rounds for positions deep inside a match (0 = as every other position; A/B: 1 round saves 4.7 ms in k_match and costs 8.9 ms of demand searches, 2 rounds: -3.2 / +3.7)
   int knob_span_mib = 2048;         // MiB of a stream one pass takes (longer streams: spans one after the other, deflate_spans)
   int knob_batch_mib = 512;         // MiB of LZ buffer one batch of small entries may take (zada_deflate_batch)
+  int knob_bz_batch_mib = 256;      // BZip2: MiB of small entries zada_bzip2_batch takes through one launch sequence
   int knob_bz_span_mib = 1024;      // BZip2: MiB of the stream whose block limits are found at a time
   int knob_bz_batch_melems = 640;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
   int knob_shard_kib = 1 << 20;     // ZADA_SHARD_KIB: bytes of a range the LZ stage takes at a time, in KiB (multiple of 64)
@@ -270,6 +271,8 @@ void bz2_destroy(Ctx *c);
 int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64_t size_hint, uint8_t *d_out, uint64_t cap, uint64_t *out_len,
                       int (*fb)(int, void *), void *user);
 uint64_t bz2_last_blocks(Ctx *c, uint64_t *dst, uint64_t cap_items);
+int bz2_batch_encode(Ctx *c, int option, const uint8_t *d_arena, uint32_t E, const uint64_t *starts, const uint32_t *lens, uint8_t *h_out, uint64_t cap,
+                     uint64_t *out_off, uint64_t *out_bytes);
 int bz2_range_open(Ctx *c, int option, const uint8_t *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t stream_total, uint64_t start, uint64_t own_end,
                    uint64_t *next_start, uint64_t *nblocks);
 int bz2_range_encode(Ctx *c);
