@@ -1,5 +1,5 @@
 """Second half of pin_with_gnat.sh: runs the reference's zipada on every input of the parity matrix and compares the raw
-Deflate streams with the committed digests of the oracle's streams (tests/golden/deflate_digests.json)."""
+Deflate and BZip2 streams with the committed digests of the oracle's streams (tests/golden/deflate_digests.json, bzip2_digests.json)."""
 import hashlib
 import json
 import os
@@ -38,6 +38,32 @@ for name, data in sorted(cases.items()):
         if not ok:
             bad += 1
             print("DIFFERENT: %s method %d: zipada wrote %d bytes (zip method %d), the oracle %s" % (name, m, csize, method, want["size"]))
+# ---- the BZip2 half (tests/golden/bzip2_digests.json): zipada -eb1 / -eb2 / -eb3 ----
+from _bzip2 import bz_inputs  # noqa: E402
+bdig = json.load(open(os.path.join(GOLDEN, "bzip2_digests.json")))
+bcases = bz_inputs()
+for f in ("sample.xls", "sample.jpg", "sample_pgm_100k.bin"):
+    bcases[f] = open(os.path.join(GOLDEN, f), "rb").read()
+for key, want in sorted(bdig.items()):
+    name, m = key.split("|")
+    data = bcases[name]
+    src = os.path.join(work, "in.bin")
+    open(src, "wb").write(data)
+    arc = os.path.join(work, "out.zip")
+    if os.path.exists(arc):
+        os.remove(arc)
+    subprocess.run([zipada, {"12": "-eb1", "13": "-eb2", "14": "-eb3"}[m], arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
+    z = open(arc, "rb").read()
+    sig, ver, flag, method, tm, crc, csize, usize, nl, xl = struct.unpack("<4sHHHIIIIHH", z[:30])
+    payload = z[30 + nl + xl:30 + nl + xl + csize]
+    checked += 1
+    if want["size"] >= len(data):                             # compression_ok = False: stored
+        ok = method == 0 and payload == data
+    else:
+        ok = method == 12 and csize == want["size"] and hashlib.sha256(payload).hexdigest() == want["sha256"]
+    if not ok:
+        bad += 1
+        print("DIFFERENT: %s BZip2 method %s: zipada wrote %d bytes (zip method %d), the oracle %s" % (name, m, csize, method, want["size"]))
 print("%d streams compared, %d different" % (checked, bad))
 print("PINNED: the oracle's streams are the Ada binary's" if bad == 0 else "NOT pinned")
 sys.exit(1 if bad else 0)
