@@ -195,13 +195,13 @@ class Encoder:
     def bzip2_batch(self, datas, method=14, crc=0xFFFFFFFF):
         """Independent BZip2 streams (one per Zip entry) in one call: zada_bzip2_batch takes the entries that are one block each
         (up to 0.8 block capacities) through ONE launch sequence.  Returns a list of (rc, stream or None, running CRC register);
-        rc 1 = not smaller than the input (the stream is still there when it fits len + len // 4 + 128 bytes)."""
+        rc 1 = not smaller than the input (the stream is still there when it fits len + len // 4 + 1024 bytes)."""
         import numpy as np
         cnt = len(datas)
         if cnt == 0:
             return []
         lens = np.fromiter((len(d) for d in datas), dtype=np.uint64, count=cnt)
-        caps = lens + lens // 4 + 128
+        caps = lens + lens // 4 + 1024
         offs = np.concatenate(([0], np.cumsum(caps)[:-1])).astype(np.uint64)
         arena = np.empty(int(caps.sum()), dtype=np.uint8)
         outp = (arena.ctypes.data + offs).astype(np.uint64)
