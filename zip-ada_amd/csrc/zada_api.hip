@@ -856,7 +856,7 @@ void zada_destroy(zada_ctx *z) {
   for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
   hipStreamDestroy(z->c.stream2);
   hipHostFree(z->c.crc_host);
-  for (int b = 0; b < 2; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
+  for (int b = 0; b < 8; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
   if (z->c.bstage) hipHostFree(z->c.bstage);
   if (z->c.btab) hipHostFree(z->c.btab);
   hipEventDestroy(z->c.ev_input);
@@ -885,12 +885,17 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
 // Large host buffers travel through two pinned staging buffers of the context (memcpy into one while the other is on
 // its way): measured on the MI355X box for 1 GiB, 33 ms against 67-80 ms for hipMemcpy from pageable memory and 90 ms for
 // hipHostRegister + copy (tests/probes/h2d_paths.hip).
-static bool ensure_staging(Ctx *c) {
-  if (c->stage[0]) return true;
-  for (int b = 0; b < 2; b++) {
+// Host buffers travel through pinned staging buffers, 8 MiB at a time.  One thread moves ~12-25 GB/s through memcpy, the link
+// takes 55 GB/s: large copies go over COPY_LANES lanes, a host thread and two staging buffers each, taking every fourth piece
+// (the pieces go to their own places, so their order on the stream does not matter).
+constexpr int COPY_LANES = 4;
+constexpr uint64_t COPY_MT_MIN = 64ull << 20;
+static bool ensure_staging(Ctx *c, int lanes) {
+  for (int b = 0; b < 2 * lanes; b++) {
+    if (c->stage[b]) continue;
     if (hipHostMalloc((void **)&c->stage[b], STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_stage[b], hipEventDisableTiming) != hipSuccess) {
-      for (int k = 0; k < 2; k++) { if (c->stage[k]) hipHostFree(c->stage[k]); c->stage[k] = nullptr; if (c->ev_stage[k]) hipEventDestroy(c->ev_stage[k]); c->ev_stage[k] = nullptr; }
+      if (c->stage[b]) { hipHostFree(c->stage[b]); c->stage[b] = nullptr; }
       (void)hipGetLastError();
       return false;
     }
@@ -898,11 +903,11 @@ static bool ensure_staging(Ctx *c) {
   return true;
 }
 
-static void copy_in(Ctx *c, void *d_dst, const uint8_t *src, uint64_t n) {
-  if (n < 2 * STAGE_BYTES || !ensure_staging(c)) { if (n) hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, c->stream); return; }
+// lane `t` of `T`: the pieces t, t + T, ... of the copy
+static void copy_in_lane(Ctx *c, void *d_dst, const uint8_t *src, uint64_t n, int t, int T) {
   uint64_t i = 0;
-  for (uint64_t o = 0; o < n; o += STAGE_BYTES, i++) {
-    const int b = (int)(i & 1);
+  for (uint64_t o = (uint64_t)t * STAGE_BYTES; o < n; o += (uint64_t)T * STAGE_BYTES, i++) {
+    const int b = 2 * t + (int)(i & 1);
     if (i >= 2) hipEventSynchronize(c->ev_stage[b]);             // the copy that last used this buffer has left it
     const uint64_t k = n - o < STAGE_BYTES ? n - o : STAGE_BYTES;
     memcpy(c->stage[b], src + o, k);
@@ -910,28 +915,48 @@ static void copy_in(Ctx *c, void *d_dst, const uint8_t *src, uint64_t n) {
     hipEventRecord(c->ev_stage[b], c->stream);
   }
 }
+static void copy_in(Ctx *c, void *d_dst, const uint8_t *src, uint64_t n) {
+  const int T = n >= COPY_MT_MIN ? COPY_LANES : 1;
+  if (n < 2 * STAGE_BYTES || !ensure_staging(c, T)) { if (n) hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, c->stream); return; }
+  if (T == 1) { copy_in_lane(c, d_dst, src, n, 0, 1); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back([=] { hipSetDevice(c->device); copy_in_lane(c, d_dst, src, n, t, T); });
+  copy_in_lane(c, d_dst, src, n, 0, T);
+  for (auto &x : th) x.join();
+}
 
-static int copy_out(Ctx *c, uint8_t *dst, const void *d_src, uint64_t n) {
-  if (n < 2 * STAGE_BYTES || !ensure_staging(c)) {
-    if (n) hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, c->stream);
-    return hip_check(c, hipStreamSynchronize(c->stream), "copy out");
-  }
-  // (the staging buffers are free: every copy_in of this call was consumed before the kernels ran)
+static int copy_out_lane(Ctx *c, uint8_t *dst, const void *d_src, uint64_t n, int t, int T) {
   uint64_t i = 0, prev_o = 0, prev_k = 0;
-  for (uint64_t o = 0; o < n; o += STAGE_BYTES, i++) {
-    const int b = (int)(i & 1);
+  for (uint64_t o = (uint64_t)t * STAGE_BYTES; o < n; o += (uint64_t)T * STAGE_BYTES, i++) {
+    const int b = 2 * t + (int)(i & 1);
     const uint64_t k = n - o < STAGE_BYTES ? n - o : STAGE_BYTES;
     hipMemcpyAsync(c->stage[b], (const uint8_t *)d_src + o, k, hipMemcpyDeviceToHost, c->stream);
     hipEventRecord(c->ev_stage[b], c->stream);
     if (i >= 1) {                                                 // meanwhile: the previous piece goes to the caller's buffer
-      if (hip_check(c, hipEventSynchronize(c->ev_stage[b ^ 1]), "copy out")) return ZADA_E_HIP_;
+      if (hipEventSynchronize(c->ev_stage[b ^ 1]) != hipSuccess) return ZADA_E_HIP_;
       memcpy(dst + prev_o, c->stage[b ^ 1], prev_k);
     }
     prev_o = o; prev_k = k;
   }
-  const int last = (int)((i - 1) & 1);
-  if (hip_check(c, hipEventSynchronize(c->ev_stage[last]), "copy out")) return ZADA_E_HIP_;
+  if (i == 0) return 0;
+  const int last = 2 * t + (int)((i - 1) & 1);
+  if (hipEventSynchronize(c->ev_stage[last]) != hipSuccess) return ZADA_E_HIP_;
   memcpy(dst + prev_o, c->stage[last], prev_k);
+  return 0;
+}
+static int copy_out(Ctx *c, uint8_t *dst, const void *d_src, uint64_t n) {
+  const int T = n >= COPY_MT_MIN ? COPY_LANES : 1;
+  if (n < 2 * STAGE_BYTES || !ensure_staging(c, T)) {
+    if (n) hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, c->stream);
+    return hip_check(c, hipStreamSynchronize(c->stream), "copy out");
+  }
+  // (the staging buffers are free: every copy_in of this call was consumed before the kernels ran)
+  int rcs[COPY_LANES] = {0, 0, 0, 0};
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back([=, &rcs] { hipSetDevice(c->device); rcs[t] = copy_out_lane(c, dst, d_src, n, t, T); });
+  rcs[0] = copy_out_lane(c, dst, d_src, n, 0, T);
+  for (auto &x : th) x.join();
+  for (int t = 0; t < T; t++) if (rcs[t]) { hip_check(c, hipGetLastError(), "copy out"); return ZADA_E_HIP_; }
   return 0;
 }
 

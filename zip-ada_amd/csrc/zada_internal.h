@@ -233,10 +233,10 @@ struct Ctx {
   hipEvent_t ev_input = nullptr, ev_out = nullptr;
   CrcPending crc;
   uint32_t *crc_host = nullptr;                     // pinned: [CRC_HOST_TOP] top-level values, then 4 x 16 leftovers
-  uint8_t *stage[2] = {nullptr, nullptr};            // pinned staging buffers of the host-buffer entry points (copy_in / copy_out)
+  uint8_t *stage[8] = {};                            // pinned staging buffers of the host-buffer entry points: four copy lanes x two (copy_in / copy_out)
   uint8_t *bstage = nullptr; uint64_t cap_bstage = 0; // pinned: a batch's packed input, then its output
   uint32_t *btab = nullptr; uint64_t cap_btab = 0;    // pinned: a batch's tables on their way to / from the device
-  hipEvent_t ev_stage[2] = {nullptr, nullptr};
+  hipEvent_t ev_stage[8] = {};
   Workspace ws;
   Range rg;                                          // the range in flight
   std::string err;
