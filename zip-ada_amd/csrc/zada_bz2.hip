@@ -1466,7 +1466,7 @@ static int dbuf_ensure(Ctx *c, DBuf &b, size_t bytes) {
 
 struct Bz2State {
   // sub-block tables
-  DBuf raw_start, raw_len, off, n, inuse, crc, bwt_index, done, unsorted, scal;
+  DBuf raw_start, raw_len, off, n, inuse, crc, bwt_index, done, scal;
   // tiles
   DBuf rtiles, rtile_first, rtile_val, rtile_crc, rtile_rs, etiles, etile_first;
   // element space
@@ -1494,7 +1494,7 @@ struct Bz2State {
   uint32_t selcap = 0;
   bool rank_attr = false;
   std::vector<DBuf *> all() {
-    return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &unsorted, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc, &rtile_rs,
+    return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc, &rtile_rs,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
             &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest};
@@ -1544,13 +1544,12 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   int rc;
   if ((rc = dbuf_ensure(c, B->raw_start, 8ull * nsb)) || (rc = dbuf_ensure(c, B->raw_len, 4ull * nsb)) || (rc = dbuf_ensure(c, B->off, 4ull * (nsb + 1))) ||
       (rc = dbuf_ensure(c, B->n, 4ull * nsb)) || (rc = dbuf_ensure(c, B->inuse, 32ull * nsb)) || (rc = dbuf_ensure(c, B->crc, 4ull * nsb)) ||
-      (rc = dbuf_ensure(c, B->bwt_index, 4ull * nsb)) || (rc = dbuf_ensure(c, B->done, nsb)) || (rc = dbuf_ensure(c, B->unsorted, 4ull * nsb)) ||
+      (rc = dbuf_ensure(c, B->bwt_index, 4ull * nsb)) || (rc = dbuf_ensure(c, B->done, nsb)) ||
       (rc = dbuf_ensure(c, B->scal, 64))) return rc;
   BZ_HIP(hipMemcpyAsync(B->raw_start.p, starts.data(), 8ull * nsb, hipMemcpyHostToDevice, st));
   BZ_HIP(hipMemcpyAsync(B->raw_len.p, lens.data(), 4ull * nsb, hipMemcpyHostToDevice, st));
   BZ_HIP(hipMemsetAsync(B->inuse.p, 0, 32ull * nsb, st));
   BZ_HIP(hipMemsetAsync(B->done.p, 0, nsb, st));
-  BZ_HIP(hipMemsetAsync(B->unsorted.p, 0, 4ull * nsb, st));
   BZ_HIP(hipMemsetAsync(B->bwt_index.p, 0, 4ull * nsb, st));
   // raw tiles
   std::vector<Tile> rt; std::vector<uint32_t> rfirst;
