@@ -207,6 +207,9 @@ uint64_t zada_bz2_last_blocks(zada_ctx *ctx, uint64_t *dst, uint64_t cap_items);
  *   zada_bz2_range_assemble the range's bytes of the stream from byte bit_begin / 8 on; flags: 1 = stream header in front
  *                           (bit_begin must be 32), 2 = footer with footer_crc behind.  Neighbours share a byte when a
  *                           range does not end on a byte: the gatherer ORs (as for the Deflate ranges). */
+/* Raw CRC-32 register (started from 0) of n bytes in device memory (16-byte aligned): a rank's piece of the stream's Zip CRC-32;
+ * zada_crc32_combine chains the pieces in stream order. */
+int zada_crc32_device(zada_ctx *ctx, const void *d_in, uint64_t n, uint32_t *raw);
 int zada_bz2_range_open(zada_ctx *ctx, int method, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t stream_total,
                         uint64_t start, uint64_t own_end, uint64_t *next_start, uint64_t *nblocks);
 int zada_bz2_range_encode(zada_ctx *ctx);

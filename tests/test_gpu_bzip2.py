@@ -184,6 +184,12 @@ def _bzip2_over_contexts(data, world, method=14):
     res0 = results[0]
     stream = sh.stitch_stream(torch, [x["payload"] for x in results], [results[k]["spans"][k] if k < len(ranges) else None for k in range(world)], res0["total_bits"], dev)
     blocks = [b for x in results for b in x["blocks"]]
+    reg = 0xFFFFFFFF
+    for x in results:                                   # the stream's Zip CRC-32 from the ranks' pieces
+        if x["crc_raw"] is not None:
+            reg = Z.load_library().zada_crc32_combine(reg, x["crc_raw"], x["n"])
+    if n and all(x["crc_raw"] is not None for x in results[:len(ranges)]):
+        assert (reg ^ 0xFFFFFFFF) == zlib.crc32(data)
     return bytes(stream.cpu().numpy()), blocks, len(ranges)
 
 

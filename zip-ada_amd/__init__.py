@@ -95,6 +95,7 @@ def load_library():
     L.zada_bz2_select.restype = None
     L.zada_bz2_select.argtypes = [u64, vp, u64, ctypes.c_uint32, vp, u64p, u32p]
     L.zada_bz2_range_assemble.argtypes = [vp, vp, u64, u64, i32, ctypes.c_uint32, vp, u64, u64p]
+    L.zada_crc32_device.argtypes = [vp, vp, u64, u32p]
     L.zada_bzip2_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.zada_bz2_last_blocks.restype = ctypes.c_uint64
     L.zada_bz2_last_blocks.argtypes = [vp, vp, u64]
@@ -225,6 +226,14 @@ class Encoder:
         if rc < 0:
             self._err(rc, "zada_bzip2_device")
         return rc, ol.value, c.value
+
+    def crc32_device(self, d_ptr, n):
+        """Raw CRC-32 register (started from 0) of n bytes at a 16-byte aligned device address (see crc32_combine)."""
+        raw = ctypes.c_uint32(0)
+        rc = self.lib.zada_crc32_device(self.ctx, d_ptr, n, ctypes.byref(raw))
+        if rc != 0:
+            self._err(rc, "zada_crc32_device")
+        return raw.value
 
     # ---- one BZip2 stream over several contexts (zada_bz2_range_*, include/zada.h) ----
     def bz2_range_open(self, d_buf, buf_len, buf_off, stream_total, start, own_end, method=14):

@@ -1125,6 +1125,23 @@ int zada_bzip2_batch(zada_ctx *z, int method, int count, const uint8_t *const *i
   flush_group();
   return worst;
 }
+// raw CRC-32 register (started from 0) of n bytes in device memory: the piece a rank contributes to a stream's CRC
+// (zada_crc32_combine chains the pieces)
+int zada_crc32_device(zada_ctx *z, const void *d_in, uint64_t n, uint32_t *raw) {
+  int rc = prepare(z);
+  if (rc || !raw) return rc ? rc : ZADA_E_INVALID;
+  Ctx *c = &z->c;
+  uint32_t reg = 0;
+  const uint64_t piece = 2ull << 30;
+  if (n && ((uintptr_t)d_in & 15) != 0) { c->err = "zada_crc32_device: the buffer must be 16-byte aligned"; return ZADA_E_INVALID; }
+  if (n && (rc = ensure_crc_workspace(c, n < piece ? n : piece))) return rc;
+  for (uint64_t o = 0; o < n; o += piece) {
+    const uint64_t k = n - o < piece ? n - o : piece;
+    if ((rc = crc_launch(c, (const uint8_t *)d_in + o, k)) || (rc = crc_finish(c, k, &reg))) return finish_call(c, rc);
+  }
+  *raw = reg;
+  return 0;
+}
 uint64_t zada_bz2_last_blocks(zada_ctx *z, uint64_t *dst, uint64_t cap_items) { return z ? bz2_last_blocks(&z->c, dst, cap_items) : 0; }
 
 int zada_deflate_device(zada_ctx *z, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len,

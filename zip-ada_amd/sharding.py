@@ -326,6 +326,7 @@ def bzip2_stream_rank(enc, comm, stream_size, ranges, d_buf_ptr, method, alloc_o
     r, nr = comm.rank, len(ranges)
     active = r < nr
     tab = np.zeros((0, 4, 3), np.uint64)
+    crc_raw = None
     if active:
         lo, n = ranges[r]
         off, blen = bzip2_window(stream_size, lo, n, method)
@@ -335,6 +336,8 @@ def bzip2_stream_rank(enc, comm, stream_size, ranges, d_buf_ptr, method, alloc_o
             comm.send_bytes(int(nxt).to_bytes(8, "little"), r + 1)
         enc.bz2_range_encode()
         tab = enc.bz2_range_table()
+        if hasattr(enc, "crc32_device") and n and d_buf_ptr % 16 == 0:      # the rank's piece of the Zip CRC-32 (its own range, not the halo)
+            crc_raw = enc.crc32_device(d_buf_ptr, n)
     tabs = comm.all_gather_obj(tab.tobytes() if active else None)
     bp, crc = 32, 0
     spans, mine = [], None
@@ -356,4 +359,5 @@ def bzip2_stream_rank(enc, comm, stream_size, ranges, d_buf_ptr, method, alloc_o
         payload = alloc_out(cap)
         nbytes = enc.bz2_range_assemble(mine[0], mine[1], payload.data_ptr(), cap, header=(r == 0), footer_crc=crc if r == nr - 1 else None)
     return dict(bit_begin=spans[r][0] if active else 0, bit_end=spans[r][1] if active else 0, total_bits=total_bits, payload=payload, nbytes=nbytes,
-                spans=spans, blocks=enc.bz2_last_blocks() if active else [], inefficient=inefficient, combined_crc=crc)
+                spans=spans, blocks=enc.bz2_last_blocks() if active else [], inefficient=inefficient, combined_crc=crc,
+                crc_raw=crc_raw, n=ranges[r][1] if active else 0)
