@@ -98,6 +98,12 @@ __device__ __forceinline__ bool sameL(const uint8_t *__restrict__ in, uint64_t p
 // lane handles i = w*2048 + it*64 + lane (it = 0..31).  A lane keeps its 32 (element, key) pairs packed
 // in registers for the whole pass, so the scatter may overwrite the arrays the pass was loaded from.
 // --------------------------------------------------------------------------------------------
+#ifdef ZADA_PL_STATS
+__device__ unsigned long long g_sort_dbg[8];
+#define SP_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_sort_dbg[k], t_ - tsp); tsp = t_; } } while (0)
+#else
+#define SP_STAMP(k) do {} while (0)
+#endif
 template <int NDIG, int SHIFT, bool LINEAR, int NPR>
 __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *dst,
                                           uint32_t *cnt /*[16][NDIG]*/, uint32_t *wsum /*[16]*/, uint32_t i0, int rem) {
@@ -109,8 +115,12 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
     return pr[it];
   };
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+#ifdef ZADA_PL_STATS
+  unsigned long long tsp = clock64();
+#endif
   for (int i = tid; i < NDIG * 16; i += 1024) cnt[i] = 0;
   __syncthreads();
+  SP_STAMP(0);
   uint32_t *mycnt = cnt + w * NDIG;
   // phase A: per (wave, digit) histogram; the value an element gets back is its rank among the wave's elements with
   // the same digit, in element order: the wave's instructions are issued in element order, and within one
@@ -127,6 +137,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
     rk[it >> 1] |= r << (16 * (it & 1));
   }
   __syncthreads();
+  SP_STAMP(1);
   // phase B: exclusive scan over (digit major, wave minor)
   {
     constexpr int PER = NDIG * 16 / 1024;           // 4 (256 digits) or 2 (128 digits)
@@ -142,6 +153,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
     for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; cnt[(idx & 15) * NDIG + (idx >> 4)] = run; run += v[k]; }
   }
   __syncthreads();
+  SP_STAMP(2);
   // phase C: stable scatter
 #pragma unroll
   for (int it = 0; it < 32; it++) {
@@ -151,6 +163,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
     }
   }
   __syncthreads();
+  SP_STAMP(3);
 }
 
 // Per 32 KiB segment (grid = segments, block = 1024).  n_ins = number of inserted positions (n - 2).
@@ -1660,7 +1673,8 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
                        W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax);
 #ifdef ZADA_PL_STATS
-    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); hipMemset(W.dbg, 0, 256); }
+    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); hipMemset(W.dbg, 0, 256);
+      unsigned long long sd[8]; hipMemcpyFromSymbol(sd, HIP_SYMBOL(g_sort_dbg), sizeof sd); fprintf(stderr, "[sort_pass cycles/segment, all six passes] clear %.0f  rank (LDS atomics) %.0f  scan %.0f  scatter %.0f\n", (double)sd[0] / nseg, (double)sd[1] / nseg, (double)sd[2] / nseg, (double)sd[3] / nseg); for (int q = 0; q < 8; q++) sd[q] = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_sort_dbg), sd, sizeof sd); }
 #endif
     c->tmark("prev_links");
     if (nseg > 1) {
