@@ -245,15 +245,21 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         for (int k = 0; k < 16; k++) key[k] = 0;
         const uint32_t *wp = (const uint32_t *)(sin + (i0 & ~3u));
         const uint32_t sh = i0 & 3u;
+        // the loads are not guarded (the buffer is padded past its end), so that eight elements' words are in flight together
+        // instead of one global round trip per element; what lies beyond the segment's elements gets key 0 and is not sorted
 #pragma unroll
-        for (int it = 0; it < 32; it++) {
-          uint32_t k = 0;
-          if (it * 64 < rem) {
-            const uint32_t a = wp[it * 16], b = wp[it * 16 + 1], c = wp[it * 16 + 2];
-            const uint64_t v = (uint64_t)__builtin_amdgcn_alignbyte(b, a, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32);
-            k = (lvl == 0) ? hash3_of(v) : hashL_of(v, L);
+        for (int g8 = 0; g8 < 4; g8++) {
+          uint32_t wa[8], wb[8], wc[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) { const int it = g8 * 8 + q; wa[q] = wp[it * 16]; wb[q] = wp[it * 16 + 1]; wc[q] = wp[it * 16 + 2]; }
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const int it = g8 * 8 + q;
+            const uint64_t v = (uint64_t)__builtin_amdgcn_alignbyte(wb[q], wa[q], sh) | ((uint64_t)__builtin_amdgcn_alignbyte(wc[q], wb[q], sh) << 32);
+            uint32_t k = (lvl == 0) ? hash3_of(v) : hashL_of(v, L);
+            if (!(it * 64 < rem)) k = 0;
+            key[it >> 1] |= k << (16 * (it & 1));
           }
-          key[it >> 1] |= k << (16 * (it & 1));
         }
         sort_pass<256, 0, true>(key, AB, cnt, wsum, i0, rem);
       }
