@@ -1,5 +1,6 @@
 """Second half of pin_with_gnat.sh: runs the reference's zipada on every input of the parity matrix and compares the raw
-Deflate and BZip2 streams with the committed digests of the oracle's streams (tests/golden/deflate_digests.json, bzip2_digests.json)."""
+Deflate, BZip2 and LZMA streams with the committed digests of the oracle's streams (tests/golden/deflate_digests.json, bzip2_digests.json,
+lzma_digests.json)."""
 import hashlib
 import json
 import os
@@ -64,6 +65,32 @@ for key, want in sorted(bdig.items()):
     if not ok:
         bad += 1
         print("DIFFERENT: %s BZip2 method %s: zipada wrote %d bytes (zip method %d), the oracle %s" % (name, m, csize, method, want["size"]))
+# ---- the LZMA half (tests/golden/lzma_digests.json): zipada -el0 / -el1 / -el2 / -el3 ----
+from _lzmah import lz_inputs  # noqa: E402
+ldig = json.load(open(os.path.join(GOLDEN, "lzma_digests.json")))
+lcases = lz_inputs()
+for f in ("sample.xls", "sample.jpg", "sample_pgm_100k.bin"):
+    lcases[f] = open(os.path.join(GOLDEN, f), "rb").read()
+for key, want in sorted(ldig.items()):
+    name, m = key.split("|")
+    data = lcases[name]
+    src = os.path.join(work, "in.bin")
+    open(src, "wb").write(data)
+    arc = os.path.join(work, "out.zip")
+    if os.path.exists(arc):
+        os.remove(arc)
+    subprocess.run([zipada, {"15": "-el0", "16": "-el1", "17": "-el2", "18": "-el3"}[m], arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
+    z = open(arc, "rb").read()
+    sig, ver, flag, method, tm, crc, csize, usize, nl, xl = struct.unpack("<4sHHHIIIIHH", z[:30])
+    payload = z[30 + nl + xl:30 + nl + xl + csize]
+    checked += 1
+    if want["rc"] == 1:                                       # compression_ok = False: stored
+        ok = method == 0 and payload == data
+    else:
+        ok = method == 14 and csize == want["size"] and hashlib.sha256(payload).hexdigest() == want["sha256"]
+    if not ok:
+        bad += 1
+        print("DIFFERENT: %s LZMA method %s: zipada wrote %d bytes (zip method %d), the oracle %s" % (name, m, csize, method, want["size"]))
 print("%d streams compared, %d different" % (checked, bad))
 print("PINNED: the oracle's streams are the Ada binary's" if bad == 0 else "NOT pinned")
 sys.exit(1 if bad else 0)

@@ -1286,6 +1286,9 @@ int zo_compress_data(const uint8_t *in, uint64_t n, int method, uint8_t *out, ui
   if (method >= ZO_BZIP2_1 && method <= ZO_BZIP2_3) {                /* :204-209 */
     rc = zo_bzip2(in, n, method, out, cap, out_len, &CRC);
     *zip_type = 12;                                                  /* bzip2_code, zip.ads:502 */
+  } else if (method >= ZO_LZMA_0 && method <= ZO_LZMA_3) {           /* :211-216 */
+    rc = zo_lzma(in, n, method, out, cap, out_len, &CRC);
+    *zip_type = 14;                                                  /* lzma_code, zip.ads:503 */
   } else {
     rc = zo_deflate(in, n, method, out, cap, out_len, &CRC, NULL, NULL, NULL, NULL);   /* :197-202 */
     *zip_type = 8;

@@ -44,7 +44,11 @@ enum {
   ZO_DEFLATE_R = 11,
   ZO_BZIP2_1 = 12,
   ZO_BZIP2_2 = 13,
-  ZO_BZIP2_3 = 14
+  ZO_BZIP2_3 = 14,
+  ZO_LZMA_0 = 15,
+  ZO_LZMA_1 = 16,
+  ZO_LZMA_2 = 17,
+  ZO_LZMA_3 = 18
 };
 
 /* Return codes of zo_deflate */
@@ -135,6 +139,19 @@ typedef struct {
 int zo_bz2_block(const uint8_t *raw, int32_t n, int option, uint8_t *rle_out, uint8_t *bwt_out, uint16_t *mtf_out,
                  uint8_t *selectors_out, uint8_t *lens_out, zo_bz2_block_info *info, uint8_t *bits_out, uint64_t bits_cap);
 int32_t zo_bz2_segments(const uint8_t *buf, int32_t len, int tactic, int32_t *seg, int32_t cap);
+
+/* ---- LZMA (row f4): zada_oracle_lzma.c ---- */
+
+/* LZMA.Encoding.Encode (lzma-encoding.adb:59-1563): level 0..3 = Level_0 .. Level_3, uncompressed_size_info = False.
+ * Output: the 5-byte LZMA header, then the range-coded stream.  stats8 (may be NULL) receives counters of the choices taken:
+ * [0] literal then DL (probable literal), [1] literal then DL (estimate), [2] DL then literal, [3] DL expanded, [4] DL split,
+ * [5] short repeat matches, [6] repeat matches, [7] simple matches. */
+int zo_lzma_encode(const uint8_t *in, uint64_t n, int level, int lc, int lp, int pb, int end_marker, int64_t dictionary_size,
+                   uint8_t *out, uint64_t cap, uint64_t *out_len, uint64_t *stats8);
+
+/* Zip.Compress.LZMA_E (zip-compress-lzma_e.adb:121-172) for methods ZO_LZMA_0 .. ZO_LZMA_3: the Zip payload (4-byte prefix,
+ * LZMA header, stream with end marker).  Return codes as zo_deflate. */
+int zo_lzma(const uint8_t *in, uint64_t n, int method, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
 
 #ifdef __cplusplus
 }

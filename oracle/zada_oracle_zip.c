@@ -118,6 +118,7 @@ static int add_entry(zoz_archive *a, const char *entry_name, const uint8_t *data
     if (rc != ZO_OK) return rc;
   }
   h->crc_32 = crc; h->compressed_size = out_len; h->zip_type = zt;
+  if (zt == 14) h->bit_flag |= 0x0002;                            /* LZMA_EOS_Flag_Bit :266-278 */
   a->len += out_len;
   write_local(a->buf + mem1, h, z64);                             /* rewrite :279-283 */
   memcpy(a->buf + mem1 + 30, h->name, nl);

@@ -10,6 +10,7 @@
   deflate_digests.json  SHA-256 + size of the oracle's stream for every (input, method) of the
                       parity matrix ("self-pinned": detects any later drift of the oracle and gives
                       the GPU tests a second, oracle-free comparison)
+  lzma_digests.json   the same for the LZMA half (methods 15 .. 18), with the counters of the DL-code variants taken
   bzip2_digests.json  the same for the BZip2 half (methods 12 .. 14), with the block / tactic trace; every stream was
                       decompressed with libbz2 when the file was made
   zlib_tokens_*.npz   position-indexed LZ77 tokens made by libz 1.2.11 deflateTune for the
@@ -104,13 +105,34 @@ def bzip2_digests():
     json.dump(out, open(os.path.join(HERE, "bzip2_digests.json"), "w"), indent=0, sort_keys=True)
 
 
+def lzma_digests():
+    """lzma_digests.json: SHA-256 + size of the oracle's Zip LZMA payload per (input, method 15..18) and the counters of the
+    choices taken ("self-pinned"); liblzma gives the input back for every one of them."""
+    from _lzmah import oracle_lzma, oracle_lzma_encode, lz_inputs, lzma_decode
+    cases = lz_inputs()
+    for f in ("sample.xls", "sample.jpg", "sample_pgm_100k.bin"):
+        cases[f] = open(os.path.join(HERE, f), "rb").read()
+    out = {}
+    for name, d in sorted(cases.items()):
+        for m in (15, 16, 17, 18):
+            rc, z, crc = oracle_lzma(d, m)
+            assert lzma_decode(z, 4) == d, (name, m)
+            st = oracle_lzma_encode(d, m - 15)[1]
+            out["%s|%d" % (name, m)] = dict(rc=rc, size=len(z), sha256=hashlib.sha256(z).hexdigest(), in_sha256=hashlib.sha256(d).hexdigest(), choices=st)
+    json.dump(out, open(os.path.join(HERE, "lzma_digests.json"), "w"), indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bzip2":
         bzip2_digests()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lzma":
+        lzma_digests()
         sys.exit(0)
     llhc_vectors()
     data_files()
     zlib_tokens()
     digests()
     bzip2_digests()
+    lzma_digests()
     print("golden fixtures written to", HERE)

@@ -498,7 +498,8 @@ class ZipCreate:
         """Entry whose payload was compressed elsewhere (another rank / GPU): the bytes written
         are those Add_Stream would have written for the same payload."""
         nm = name.replace("\\", "/").encode("utf-8")
-        e = dict(name=nm, flag=0x0800 if unicode_name else 0, zip_type=zt, time=self.DEFAULT_TIME if file_time is None else file_time,
+        e = dict(name=nm, flag=(0x0800 if unicode_name else 0) | (0x0002 if zt == 14 else 0),   # LZMA_EOS_Flag_Bit, zip-create.adb:266-278
+                 zip_type=zt, time=self.DEFAULT_TIME if file_time is None else file_time,
                  crc=crc, csize=len(payload), usize=usize, offset=len(self.buf) + self._bias)
         self._check_size(usize)
         # the local header's form is decided before compression, on the provisional sizes (:231-241)
