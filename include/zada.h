@@ -36,7 +36,11 @@ enum {
   ZADA_DEFLATE_R = 11,      /* LZ77.Rich -- not implemented (out of scope) */
   ZADA_BZIP2_1 = 12,        /* BZip2, 100 000-byte blocks  (zip-compress-bzip2_e.adb:138-142, bzip2-encoding.adb:93-98) */
   ZADA_BZIP2_2 = 13,        /* BZip2, 400 000-byte blocks */
-  ZADA_BZIP2_3 = 14         /* BZip2, 900 000-byte blocks, four splitting tactics per block (bzip2-encoding.adb:1214-1345) */
+  ZADA_BZIP2_3 = 14,        /* BZip2, 900 000-byte blocks, four splitting tactics per block (bzip2-encoding.adb:1214-1345) */
+  ZADA_LZMA_0 = 15,         /* LZMA, no LZ77: literals and short repeats only (lzma-encoding.adb:118-122) */
+  ZADA_LZMA_1 = 16,         /* LZMA, Info-Zip matcher level 6, matches written as they come */
+  ZADA_LZMA_2 = 17,         /* LZMA, Info-Zip matcher level 10, simple comparison of the ways to write a match */
+  ZADA_LZMA_3 = 18          /* LZMA, BT4 matcher, dictionary = the entry's size (up to 256 MiB), all comparisons incl. splitting */
 };
 
 /* Return codes.  1 and 2 mirror the reference's two non-error outcomes:
@@ -188,6 +192,22 @@ int zada_bzip2_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n, v
  * MiB of entries per launch sequence.  Returns the worst rc. */
 int zada_bzip2_batch(zada_ctx *ctx, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
                      const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc);
+/* ---------------------------------------------------------------------------------------------------------------
+ * LZMA.  Replaces the body of Zip.Compress.LZMA_E (zip_lib/zip-compress-lzma_e.ads, .adb:29-184) for the
+ * methods LZMA_0 .. LZMA_3, i.e. LZMA.Encoding.Encode (zip_lib/lzma-encoding.adb:59-1563) with lc = 3, lp = 0, pb = 2, an end
+ * marker and dictionary_size = the input's size (zip-compress-lzma_e.adb:121-126, 160-165).  Conventions as zada_deflate:
+ * method = Compression_Method'Pos, crc_inout = the running Zip CRC-32 register, return ZADA_OK / ZADA_INEFFICIENT / < 0.
+ * The output is the Zip payload: the four bytes 16, 2, 5, 0 (:155-158), the 5-byte LZMA header, the range-coded stream.
+ * A stream is one chain of dependent steps (adaptive probabilities): one workgroup codes it; entries are what runs in
+ * parallel -- use zada_lzma_batch for many of them.  Entries below 2 GiB.
+ * --------------------------------------------------------------------------------------------------------------- */
+int zada_lzma(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
+/* the same with input and output in device memory (d_out: cap bytes) */
+int zada_lzma_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
+/* Many entries, one launch of the coder for all of them.  Arrays as for zada_deflate_batch; rc[i] is zada_lzma's return code
+ * for entry i.  Returns the worst rc. */
+int zada_lzma_batch(zada_ctx *ctx, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,
+                    const uint64_t *cap, uint64_t *out_len, uint32_t *crc, int *rc);
 /* Trace of the last zada_bzip2* call: per block of Read_and_Split_Block (bzip2-encoding.adb:1144) four values -- raw start,
  * raw length, splitting tactic kept (0 single, 1 parts_4, 2 segmented_1, 3 segmented_2), its number of sub-blocks.
  * Returns the number of values there are; at most cap_items are stored. */

@@ -28,6 +28,8 @@ class Method:
     Deflate_1 = 8
     Deflate_2 = 9
     Deflate_3 = 10
+    BZip2_1, BZip2_2, BZip2_3 = 12, 13, 14
+    LZMA_0, LZMA_1, LZMA_2, LZMA_3 = 15, 16, 17, 18
 
 
 class ZadaError(RuntimeError):
@@ -97,6 +99,9 @@ def load_library():
     L.zada_bz2_range_assemble.argtypes = [vp, vp, u64, u64, i32, ctypes.c_uint32, vp, u64, u64p]
     L.zada_crc32_device.argtypes = [vp, vp, u64, u32p]
     L.zada_bzip2_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.zada_lzma.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
+    L.zada_lzma_device.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
+    L.zada_lzma_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.zada_bz2_last_blocks.restype = ctypes.c_uint64
     L.zada_bz2_last_blocks.argtypes = [vp, vp, u64]
     L.zada_crc32_combine.restype = ctypes.c_uint32
@@ -217,6 +222,52 @@ class Encoder:
             self._err(worst, "zada_bzip2_batch")
         mv = memoryview(arena)
         return [(int(rcs[i]), bytes(mv[int(offs[i]):int(offs[i]) + int(ols[i])]) if rcs[i] >= 0 and ols[i] <= caps[i] else None, int(crcs[i])) for i in range(cnt)]
+
+    def lzma(self, data, method=18, crc=0xFFFFFFFF, cap=None):
+        """Zip.Compress.LZMA_E (method 15 .. 18 = LZMA_0 .. LZMA_3).  Returns (rc, Zip payload, running CRC register); rc 1 = not
+        smaller than the input (the payload is still returned when it fits `cap`, default len(data) * 9 // 8 + 4096)."""
+        n = len(data)
+        cap = int(cap if cap is not None else n + n // 8 + 4096)
+        out = ctypes.create_string_buffer(cap)
+        ol = ctypes.c_uint64(0)
+        c = ctypes.c_uint32(crc)
+        rc = self.lib.zada_lzma(self.ctx, method, _addr(data) if n else None, n, ctypes.addressof(out), cap, ctypes.byref(ol), ctypes.byref(c))
+        if rc < 0:
+            self._err(rc, "zada_lzma")
+        return rc, (out.raw[:ol.value] if ol.value <= cap else None), c.value
+
+    def lzma_batch(self, datas, method=18, crc=0xFFFFFFFF):
+        """Independent LZMA payloads (one per Zip entry) in one call: every entry is a workgroup of ONE launch of the coder.
+        Returns a list of (rc, payload or None, running CRC register)."""
+        import numpy as np
+        cnt = len(datas)
+        if cnt == 0:
+            return []
+        lens = np.fromiter((len(d) for d in datas), dtype=np.uint64, count=cnt)
+        caps = lens + lens // 8 + 128
+        offs = np.concatenate(([0], np.cumsum(caps)[:-1])).astype(np.uint64)
+        arena = np.empty(int(caps.sum()), dtype=np.uint8)
+        outp = (arena.ctypes.data + offs).astype(np.uint64)
+        keep = [d if len(d) else b"\0" for d in datas]
+        ins = np.fromiter((_addr(d) for d in keep), dtype=np.uint64, count=cnt)
+        ols = np.zeros(cnt, dtype=np.uint64)
+        crcs = np.full(cnt, crc, dtype=np.uint32)
+        rcs = np.zeros(cnt, dtype=np.int32)
+        worst = self.lib.zada_lzma_batch(self.ctx, method, cnt, ins.ctypes.data, lens.ctypes.data, outp.ctypes.data, caps.ctypes.data,
+                                         ols.ctypes.data, crcs.ctypes.data, rcs.ctypes.data)
+        if worst < 0:
+            self._err(worst, "zada_lzma_batch")
+        mv = memoryview(arena)
+        return [(int(rcs[i]), bytes(mv[int(offs[i]):int(offs[i]) + int(ols[i])]) if rcs[i] >= 0 and ols[i] <= caps[i] else None, int(crcs[i])) for i in range(cnt)]
+
+    def lzma_device(self, d_in, n, d_out, cap, method=18, crc=0xFFFFFFFF):
+        """LZMA payload of n bytes at device address d_in into d_out (cap bytes).  Returns (rc, length, running CRC register)."""
+        ol = ctypes.c_uint64(0)
+        c = ctypes.c_uint32(crc)
+        rc = self.lib.zada_lzma_device(self.ctx, method, d_in, n, d_out, cap, ctypes.byref(ol), ctypes.byref(c))
+        if rc < 0:
+            self._err(rc, "zada_lzma_device")
+        return rc, ol.value, c.value
 
     def bzip2_device(self, d_in, n, d_out, cap, method=14, crc=0xFFFFFFFF):
         """BZip2 stream of n bytes at device address d_in into d_out (cap bytes).  Returns (rc, length, running CRC register)."""
@@ -486,11 +537,13 @@ class ZipCreate:
             res = [(1, None, 0)] * len(datas)
         elif 12 <= self.method <= 14:
             res = self.enc.bzip2_batch(datas, self.method)
+        elif 15 <= self.method <= 18:
+            res = self.enc.lzma_batch(datas, self.method)
         else:
             res = self.enc.deflate_batch(datas, self.method)
         for name, data, (rc, payload, crc) in zip(names, datas, res):
             if rc == 0:
-                self.add_compressed(name, payload, crc ^ 0xFFFFFFFF, len(data), 12 if 12 <= self.method <= 14 else 8, file_time, unicode_name)
+                self.add_compressed(name, payload, crc ^ 0xFFFFFFFF, len(data), 12 if 12 <= self.method <= 14 else 14 if 15 <= self.method <= 18 else 8, file_time, unicode_name)
             else:
                 self.add_compressed(name, bytes(data), zlib.crc32(data) if self.method == Method.Store else crc ^ 0xFFFFFFFF, len(data), 0, file_time, unicode_name)
 

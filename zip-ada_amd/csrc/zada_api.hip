@@ -846,12 +846,14 @@ zada_ctx *zada_create(int device) {
   return z;
 }
 
+static void lzma_free(zada::Ctx *c);
 void zada_destroy(zada_ctx *z) {
   if (!z) return;
   hipSetDevice(z->c.device);
   hipStreamSynchronize(z->c.stream);
   hipStreamSynchronize(z->c.stream2);
   bz2_destroy(&z->c);
+  lzma_free(&z->c);
   free_workspace(&z->c);
   for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
   hipStreamDestroy(z->c.stream2);
@@ -1125,6 +1127,201 @@ int zada_bzip2_batch(zada_ctx *z, int method, int count, const uint8_t *const *i
   flush_group();
   return worst;
 }
+// --------------------------------------------------------------------------------------------
+// LZMA: Zip.Compress.LZMA_E (zip-compress-lzma_e.adb:121-172) for LZMA_0 .. LZMA_3.  One stream per
+// workgroup of k_lzma_encode (zada_lzma.hip); Level_1 / Level_2 take their tokens from the LZ stage of the Deflate path.
+// --------------------------------------------------------------------------------------------
+static int lz_grow(Ctx *c, void **p, size_t *cap, size_t bytes) {
+  if (*p && *cap >= bytes) return 0;
+  hipStreamSynchronize(c->stream);
+  if (*p) { hipFree(*p); *p = nullptr; *cap = 0; }
+  const size_t want = bytes + bytes / 8 + 4096;
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) { (void)hipGetLastError(); hip_check(c, e, "hipMalloc (LZMA workspace)"); *p = nullptr; return ZADA_E_NOMEM; }
+  *cap = want;
+  return 0;
+}
+static void lzma_free(Ctx *c) {
+  if (c->lz_tab) hipFree(c->lz_tab);
+  if (c->lz_ws) hipFree(c->lz_ws);
+  if (c->lz_tok) hipFree(c->lz_tok);
+  c->lz_tab = c->lz_ws = c->lz_tok = nullptr; c->cap_lz_tab = c->cap_lz_ws = c->cap_lz_tok = 0;
+}
+// jobs: ws_off / sbs / hash4_size are filled here.  res: 2 per job (stream bytes, input bytes coded).
+static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, std::vector<uint64_t> &res) {
+  const uint32_t E = (uint32_t)jobs.size();
+  uint64_t ws_ints = 0;
+  for (LzmaJob &j : jobs) {
+    j.sbs = lzma_string_buffer_size(j.level, j.n);                 // dictionary_size = the entry's size, zip-compress-lzma_e.adb:165
+    j.hash4_size = j.level == 3 ? lzma_hash4_size(j.sbs) : 0;
+    j.ws_off = ws_ints;
+    ws_ints += (lzma_workspace_ints(j.level, j.sbs) + 15) & ~15ull;
+  }
+  int rc = lz_grow(c, &c->lz_tab, &c->cap_lz_tab, (sizeof(LzmaJob) + 16) * (size_t)E + 64);
+  if (!rc && ws_ints) rc = lz_grow(c, &c->lz_ws, &c->cap_lz_ws, ws_ints * 4);
+  if (rc) return rc;
+  LzmaJob *d_jobs = (LzmaJob *)c->lz_tab;
+  uint64_t *d_res = (uint64_t *)((uint8_t *)c->lz_tab + ((sizeof(LzmaJob) * (size_t)E + 63) & ~63ull));
+  hipMemcpyAsync(d_jobs, jobs.data(), sizeof(LzmaJob) * (size_t)E, hipMemcpyHostToDevice, c->stream);
+  if (ws_ints) hipMemsetAsync(c->lz_ws, 0, ws_ints * 4, c->stream);
+  if ((rc = lzma_launch(c, d_jobs, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res))) return rc;
+  res.resize(2 * (size_t)E);
+  hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
+  if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
+  for (uint32_t e = 0; e < E; e++) if (res[2 * e + 1] != jobs[e].n) { c->err = "LZMA: the coder did not consume the entry"; return ZADA_E_HIP; }
+  return 0;
+}
+static int lzma_tokens(Ctx *c, int level, const uint8_t *d_in, uint64_t n, uint64_t *ntok) {     // IZ_6 / IZ_10, lzma-encoding.adb:118-122
+  int rc = range_open(c, level == 1 ? ZADA_DEFLATE_1 : ZADA_DEFLATE_3, d_in, n, 0, n, 0, 0);
+  if (!rc) rc = range_lz(c, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  if (hip_check(c, hipStreamSynchronize(c->stream2), "LZMA tokens")) return ZADA_E_HIP;             // (range_lz runs the range's CRC there)
+  *ntok = c->rg.T;
+  c->rg.open = false;
+  return 0;
+}
+static int lzma_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout) {
+  if (method < ZADA_LZMA_0 || method > ZADA_LZMA_3) { c->err = "not an LZMA method"; return ZADA_E_INVALID; }
+  if (n >= (2ull << 30) - 65536) { c->err = "LZMA: entries of 2 GiB and more are not taken yet"; return ZADA_E_TOO_LARGE; }
+  const int level = method - ZADA_LZMA_0;
+  int rc;
+  c->tbegin(); c->tmark("lzma:begin");
+  if (crc_inout && n) {
+    if ((rc = ensure_crc_workspace(c, n))) return rc;
+    if ((rc = crc_launch(c, d_in, n)) || (rc = crc_finish(c, n, crc_inout))) return rc;
+  }
+  std::vector<LzmaJob> jobs(1);
+  LzmaJob &J = jobs[0];
+  memset(&J, 0, sizeof J);
+  J.n = n; J.cap = cap; J.level = level; J.zip_prefix = 1;
+  const uint32_t *d_tok = nullptr;
+  if ((level == 1 || level == 2) && n) {
+    if ((rc = lzma_tokens(c, level, d_in, n, &J.ntok))) return rc;
+    d_tok = c->ws.ea_atoms + LB_CAP;
+  }
+  c->tmark("lzma:tokens");
+  std::vector<uint64_t> res;
+  if ((rc = lzma_run(c, jobs, d_in, d_tok, d_out, res))) return rc;
+  c->tmark("lzma:end"); c->tend();
+  *out_len = res[0];
+  if (res[0] > cap) { if (res[0] >= n) return ZADA_INEFFICIENT; c->err = "output buffer too small"; return ZADA_E_INVALID; }
+  return res[0] >= n ? ZADA_INEFFICIENT : ZADA_OK;                   // zip-compress.adb:479-486
+}
+int zada_lzma_device(zada_ctx *z, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  const uint8_t *src = (const uint8_t *)d_in;
+  if (((uintptr_t)d_in & 15) != 0 && n) {
+    if ((rc = ensure_rin(c, n))) return rc;
+    hipMemcpyAsync(c->ws.rin_own, d_in, n, hipMemcpyDeviceToDevice, c->stream);
+    src = c->ws.rin_own;
+  }
+  uint64_t ol = 0;
+  rc = finish_call(c, lzma_core(c, method, src, n, (uint8_t *)d_out, cap, &ol, crc_inout));
+  if (out_len && rc >= 0) *out_len = ol;
+  return rc;
+}
+int zada_lzma(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout) {
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  if ((rc = ensure_rin(c, n + cap + 128))) return rc;           // input, then the stream, in one device buffer
+  copy_in(c, c->ws.rin_own, in, n);
+  uint8_t *d_out = c->ws.rin_own + ((n + 63) & ~63ull);
+  uint64_t ol = 0;
+  rc = finish_call(c, lzma_core(c, method, c->ws.rin_own, n, d_out, cap, &ol, crc_inout));
+  if (rc < 0 || rc == ZADA_ABORTED) return rc;
+  if (out_len) *out_len = ol;
+  if (ol <= cap && copy_out(c, out, d_out, ol)) return ZADA_E_HIP;
+  return rc;
+}
+// Many entries in one call: every entry is a stream of ONE launch of k_lzma_encode -- the only parallelism LZMA's chain of
+// adaptive probabilities leaves (see zada_lzma.hip).  Level_1 / Level_2: the LZ stage runs entry after entry before it.
+static int lzma_batch_core(Ctx *c, int method, const int *idx, uint32_t E, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out, const uint64_t *cap,
+                           uint64_t *out_len, uint32_t *crc, int *rc_out) {
+  hipStream_t st = c->stream;
+  const int level = method - ZADA_LZMA_0;
+  std::vector<uint64_t> start(E), ostart(E); std::vector<uint32_t> start32(E + 1), len(E + 1), crc_in(E + 1);
+  uint64_t total = 0, ototal = 0;
+  for (uint32_t e = 0; e < E; e++) {
+    start[e] = total; start32[e] = (uint32_t)total; len[e] = (uint32_t)n[idx[e]]; crc_in[e] = crc ? crc[idx[e]] : 0xFFFFFFFFu;
+    total += ((n[idx[e]] ? n[idx[e]] : 1) + 65535) & ~65535ull;                  // (64 KiB slots: a slot is a range of the LZ stage)
+    ostart[e] = ototal; ototal += (n[idx[e]] + n[idx[e]] / 8 + 128 + 63) & ~63ull;
+  }
+  if (total >= (1ull << 32)) return ZADA_E_TOO_LARGE;
+  int rc = ensure_rin(c, total + ototal + 64 + 16ull * (E + 1));
+  if (!rc) rc = grow_pinned((void **)&c->bstage, &c->cap_bstage, (total > ototal ? total : ototal) + 64);
+  if (!rc && (level == 1 || level == 2)) rc = lz_grow(c, &c->lz_tok, &c->cap_lz_tok, 4 * total + 64);
+  if (rc) return rc;
+  parallel_entries(E, total, [&](uint32_t e) { if (len[e]) memcpy(c->bstage + start[e], in[idx[e]], len[e]); });
+  c->tbegin(); c->tmark("lzma:begin");
+  uint8_t *d_arena = c->ws.rin_own, *d_out = d_arena + total;
+  uint32_t *d_tab = (uint32_t *)(d_out + ototal);
+  hipMemcpyAsync(d_arena, c->bstage, total, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_tab, start32.data(), 4ull * E, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_tab + E, len.data(), 4ull * E, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_tab + 2 * E, crc_in.data(), 4ull * E, hipMemcpyHostToDevice, st);
+  hipLaunchKernelGGL(k_batch_crc, dim3(E), dim3(64), 0, st, E, d_arena, d_tab, d_tab + E, d_tab + 2 * E);
+  hipMemcpyAsync(crc_in.data(), d_tab + 2 * E, 4ull * E, hipMemcpyDeviceToHost, st);
+  if (hip_check(c, hipStreamSynchronize(st), "LZMA batch in")) return ZADA_E_HIP;
+  std::vector<LzmaJob> jobs(E);
+  uint64_t tok = 0;
+  for (uint32_t e = 0; e < E; e++) {
+    LzmaJob &J = jobs[e];
+    memset(&J, 0, sizeof J);
+    J.in_off = start[e]; J.n = len[e]; J.out_off = ostart[e]; J.cap = (len[e] + len[e] / 8 + 128ull); J.level = level; J.zip_prefix = 1;
+    if ((level == 1 || level == 2) && len[e]) {
+      if ((rc = lzma_tokens(c, level, d_arena + start[e], len[e], &J.ntok))) return rc;
+      J.tok_off = tok;
+      hipMemcpyAsync((uint32_t *)c->lz_tok + tok, c->ws.ea_atoms + LB_CAP, 4 * J.ntok, hipMemcpyDeviceToDevice, st);
+      tok += J.ntok;
+    }
+  }
+  c->tmark("lzma:tokens");
+  std::vector<uint64_t> res;
+  if ((rc = lzma_run(c, jobs, d_arena, (const uint32_t *)c->lz_tok, d_out, res))) return rc;
+  hipMemcpyAsync(c->bstage, d_out, ototal, hipMemcpyDeviceToHost, st);
+  if (hip_check(c, hipStreamSynchronize(st), "LZMA batch out")) return ZADA_E_HIP;
+  c->tmark("lzma:end"); c->tend();
+  std::atomic<int> bad(0);
+  parallel_entries(E, ototal, [&](uint32_t e) {
+    const int i = idx[e];
+    const uint64_t bytes = res[2 * e];
+    out_len[i] = bytes;
+    if (crc) crc[i] = crc_in[e];
+    rc_out[i] = bytes >= n[i] ? ZADA_INEFFICIENT : ZADA_OK;
+    if (bytes <= cap[i] && bytes <= jobs[e].cap) memcpy(out[i], c->bstage + ostart[e], bytes);
+    else if (rc_out[i] == ZADA_OK) { rc_out[i] = ZADA_E_INVALID; bad = 1; }
+  });
+  if (bad) c->err = "output buffer too small";
+  return 0;
+}
+int zada_lzma_batch(zada_ctx *z, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out, const uint64_t *cap, uint64_t *out_len,
+                    uint32_t *crc, int *rc) {
+  if (!z || count < 0 || method < ZADA_LZMA_0 || method > ZADA_LZMA_3) return ZADA_E_INVALID;
+  int prc = prepare(z);
+  if (prc) return prc;
+  Ctx *c = &z->c;
+  int worst = 0;
+  std::vector<int> group;
+  uint64_t gbytes = 0;
+  auto flush_group = [&]() {
+    if (group.empty()) return;
+    int r = finish_call(c, lzma_batch_core(c, method, group.data(), (uint32_t)group.size(), in, n, out, cap, out_len, crc, rc));
+    if (r < 0) { for (int i : group) rc[i] = r; worst = r; }
+    else { for (int i : group) if (rc[i] < 0) worst = rc[i]; }
+    group.clear(); gbytes = 0;
+  };
+  for (int i = 0; i < count; i++) {
+    if (n[i] >= (2ull << 30) - 65536) { rc[i] = ZADA_E_TOO_LARGE; worst = rc[i]; continue; }
+    const uint64_t slot = ((n[i] ? n[i] : 1) + 65535) & ~65535ull;
+    if (gbytes + slot > (2ull << 30)) flush_group();
+    group.push_back(i); gbytes += slot;
+  }
+  flush_group();
+  return worst;
+}
 // raw CRC-32 register (started from 0) of n bytes in device memory: the piece a rank contributes to a stream's CRC
 // (zada_crc32_combine chains the pieces)
 int zada_crc32_device(zada_ctx *z, const void *d_in, uint64_t n, uint32_t *raw) {
@@ -1323,9 +1520,12 @@ int zada_compress_data(zada_ctx *z, int method, const uint8_t *in, uint64_t n, u
                        uint32_t *crc_out, uint16_t *zip_type) {
   uint32_t crc = 0xFFFFFFFFu;                                   // Init, zip-compress.adb:144
   const bool bz = method >= ZADA_BZIP2_1 && method <= ZADA_BZIP2_3;                  // :204-209 (bzip2_code = 12, zip.ads:502)
-  int rc = bz ? zada_bzip2(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr) : zada_deflate(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr);
+  const bool lz = method >= ZADA_LZMA_0 && method <= ZADA_LZMA_3;                    // :211-216 (lzma_code = 14, zip.ads:503)
+  int rc = bz ? zada_bzip2(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr)
+         : lz ? zada_lzma(z, method, in, n, out, cap, out_len, &crc)
+              : zada_deflate(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr);
   if (rc < 0 || rc == ZADA_ABORTED) return rc;
-  *zip_type = bz ? 12 : 8;
+  *zip_type = bz ? 12 : lz ? 14 : 8;
   crc = ~crc;                                                   // Final :218
   if (rc == ZADA_INEFFICIENT) {                                 // :224-237 Store_data; the CRC of the same bytes is unchanged
     if (cap < n) { z->c.err = "output buffer too small"; return ZADA_E_INVALID; }

@@ -243,6 +243,9 @@ struct Ctx {
   int parse_rounds = 0, demand_rounds = 0;
   bool lz_attrs_set = false;
   void *bz = nullptr;                                // BZip2 state (zada_bz2.hip), made on first use
+  void *lz_tab = nullptr; size_t cap_lz_tab = 0;     // LZMA (zada_lzma.hip): job table + results
+  void *lz_ws = nullptr; size_t cap_lz_ws = 0;       // ... the BT4 matcher's hash tables and trees (Level_3)
+  void *lz_tok = nullptr; size_t cap_lz_tok = 0;     // ... a batch's LZ77 tokens (Level_1 / Level_2)
   // timing
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<const char *, hipEvent_t>> marks;
@@ -278,6 +281,19 @@ int bz2_range_open(Ctx *c, int option, const uint8_t *d_buf, uint64_t buf_len, u
 int bz2_range_encode(Ctx *c);
 uint64_t bz2_range_table(Ctx *c, uint64_t *tab, uint64_t cap_blocks);
 int bz2_range_assemble(Ctx *c, const uint8_t *choice, uint64_t nblk, uint64_t bit_begin, int flags, uint32_t footer_crc, uint8_t *d_out, uint64_t cap, uint64_t *nbytes);
+// LZMA (zada_lzma.hip): one stream per job.  Offsets in bytes / tokens / ints from the bases given to lzma_launch.
+struct LzmaJob {
+  uint64_t in_off, n;               // the entry
+  uint64_t tok_off, ntok;           // its LZ77 tokens (Level_1 / Level_2)
+  uint64_t out_off, cap;            // where the stream goes (the bytes beyond cap are counted, not written)
+  uint64_t ws_off;                  // Level_3: hash2 (1024) | hash3 (65536) | hash4 | tree (2 x sbs), all zero
+  uint32_t sbs, hash4_size;         // String_buffer_size (lzma-encoding.adb:137-149), BT4's hash4 size (lz77.adb:1019-1032)
+  int32_t level, zip_prefix;        // 0 .. 3; 1: the four bytes of zip-compress-lzma_e.adb:155-158 go first
+};
+uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size);
+uint32_t lzma_hash4_size(uint32_t sbs);
+uint64_t lzma_workspace_ints(int level, uint32_t sbs);
+int lzma_launch(Ctx *c, const LzmaJob *d_jobs, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);
 int ensure_crc_workspace(Ctx *c, uint64_t n);

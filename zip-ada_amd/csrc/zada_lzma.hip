@@ -1,0 +1,895 @@
+// zada_lzma.hip -- LZMA encoding for gfx950: LZMA.Encoding.Encode (zip_lib/lzma-encoding.adb:59-1563) with the
+// parameters of Zip.Compress.LZMA_E's methods LZMA_0 .. LZMA_3 (zip-compress-lzma_e.adb:121-126: lc 3, lp 0, pb 2, end marker).
+//
+// What is parallel and what is not.  The range coder (:964-1039) and the choice between the ways of writing a match (:349-946)
+// both read the adaptive bit probabilities, which every coded bit updates: a stream is one chain of dependent steps, and the
+// stream's bytes have to be the reference's.  So the unit of parallelism is the STREAM: one workgroup per Zip entry, the entry's
+// probability model (7 992 probabilities, 16 KB) and its two match lists in LDS, lane 0 walks the chain.  Level_1 / Level_2 take
+// their LZ77 tokens from the Info-Zip matcher kernels of the Deflate path (IZ_6 / IZ_10, :118-122; zada_lz.hip) -- that part IS
+// data parallel; Level_3 runs the BT4 binary-tree matcher (lz77.adb:953-1827, insertion order matters) inside the chain, with its
+// hash tables and tree in HBM.  The floating-point estimates are IEEE doubles multiplied in the reference's order, without
+// contraction, so they are the values the Ada code computes.
+//
+// The sliding text buffer of the reference (Text_Buf, a ring of String_buffer_size bytes) only ever holds bytes of the input at
+// their own positions -- also ahead of the encoder, where matches under test are expanded early (:1338-1353, 1488-1492) -- so the
+// kernel reads the input itself: Text_Buf ((R - d) and mask) = in [total_pos - d].
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/zada.h"
+#include "zada_internal.h"
+
+namespace zada {
+namespace {
+
+constexpr int LZ_LIT = 0x300 << 3;             // lc = 3, lp = 0
+constexpr uint32_t LZ_PBM = 3;                 // pb = 2
+constexpr int LZ_MAXM = 288;                   // matches of one position: lengths strictly increase from 2 to 273, + 1 repeat match
+
+struct LenProbs { uint16_t c1, c2, low[16][8], mid[16][8], high[256]; };
+struct LzProbs {                               // lzma.ads:137-201
+  uint16_t lit[LZ_LIT];
+  uint16_t slot[4][64], align[16], pos[116];   // pos_coder (-1 .. 114) at +1
+  LenProbs len, rep_len;
+  uint16_t match[12][16], rep[12], g0[12], g1[12], g2[12], rep0_long[12][16];
+};
+struct Matches { int count; int dist[LZ_MAXM], len[LZ_MAXM]; };     // lz77.ads:70-75, (1 .. count)
+
+struct MS {                                    // Machine_State :212-219 without R (= total_pos mod the ring size)
+  uint32_t state, pos_state, prev_byte;
+  uint32_t rep[4];
+  uint64_t pos;
+};
+
+struct Enc {
+  LzProbs *P;
+  const uint8_t *in; uint64_t n;
+  int cv;                                      // compare_variants: 0 None, 1 Simple, 2 Splitting (:1539-1546)
+  MS ES;
+  uint32_t width; uint64_t low; uint32_t cache; uint64_t cache_size;      // Range_Encoder :952-957
+  uint8_t *out; uint64_t cap, olen;
+};
+
+__device__ const uint8_t T_LIT[12]  = {0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 4, 5};          // lzma.ads:86-89
+__device__ const uint8_t T_MATCH[12] = {7, 7, 7, 7, 7, 7, 7, 10, 10, 10, 10, 10};
+__device__ const uint8_t T_REP[12]  = {8, 8, 8, 8, 8, 8, 8, 11, 11, 11, 11, 11};
+__device__ const uint8_t T_SREP[12] = {9, 9, 9, 9, 9, 9, 9, 11, 11, 11, 11, 11};
+
+__device__ inline uint32_t TB(const Enc &E, int64_t p) { return p < 0 ? 0u : (uint32_t)E.in[p]; }
+
+__device__ inline uint32_t dist_slot(uint32_t d) {                               // Get_dist_slot :73-102
+  if (d <= 4) return d;
+  const int i = 31 - __clz(d);
+  return (uint32_t)(i * 2) + ((d >> (i - 1)) & 1);
+}
+
+// ---------------------------------------------------------------- Estimates :349-946
+
+__device__ inline double tbe(uint16_t p, uint32_t sym) {                         // Test_Bit_Encoding :359-370
+  const double b = (double)sym;
+  return b + (1.0 - 2.0 * b) * ((double)p * (1.0 / 2048.0));
+}
+
+__device__ double test_simple_literal(const Enc &E, uint32_t b, uint32_t b_match, const uint16_t *prob, const MS &sim) {   // :372-419
+  double pl = tbe(E.P->match[sim.state][sim.pos_state], 0);
+  uint32_t symb = b | 0x100;
+  if (sim.state < 7) {
+    do { pl = pl * tbe(prob[symb >> 8], (symb >> 7) & 1); symb <<= 1; } while (symb < 0x10000);
+  } else {
+    uint32_t offs = 0x100, match = b_match;
+    do {
+      match <<= 1;
+      pl = pl * tbe(prob[offs + (match & offs) + (symb >> 8)], (symb >> 7) & 1);
+      symb <<= 1;
+      offs &= ~(match ^ symb);
+    } while (symb < 0x10000);
+  }
+  return pl;
+}
+
+__device__ inline double test_short_rep(const Enc &E, const MS &sim) {           // :421-428
+  const LzProbs &P = *E.P;
+  return tbe(P.match[sim.state][sim.pos_state], 1) * tbe(P.rep[sim.state], 1) * tbe(P.g0[sim.state], 0) * tbe(P.rep0_long[sim.state][sim.pos_state], 0);
+}
+
+__device__ inline int lit_idx(uint32_t prev_byte) { return 0x300 * (int)(prev_byte >> 5); }    // Idx_for_Literal_prob :193-201
+
+__device__ __noinline__ void sim_literal(const Enc &E, uint32_t b, MS &sim, double &prob) {    // Simulate_Literal_Byte :431-458
+  const int idx = lit_idx(sim.prev_byte);
+  const uint32_t b_match = TB(E, (int64_t)sim.pos - (int64_t)sim.rep[0] - 1);
+  sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
+  const double ltr = test_simple_literal(E, b, b_match, E.P->lit + idx, sim);
+  bool srep = false;
+  if (b == b_match && sim.pos > (uint64_t)(uint32_t)(sim.rep[0] + 1)) {
+    const double srm = test_short_rep(E, sim);
+    if (srm > ltr) { sim.state = T_SREP[sim.state]; prob = prob * srm; srep = true; }
+  }
+  if (!srep) { sim.state = T_LIT[sim.state]; prob = prob * ltr; }
+  sim.pos += 1;
+  sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
+  sim.prev_byte = b;
+}
+
+__device__ inline double test_literal_byte(const Enc &E, uint32_t b, const MS &sim) {          // :460-468
+  MS v = sim; double prob = 1.0;
+  sim_literal(E, b, v, prob);
+  return prob;
+}
+
+__device__ inline double sim_bit_tree(const uint16_t *prob, int num_bits, uint32_t symbol) {   // :470-481
+  double res = 1.0; uint32_t m = 1;
+  for (int i = num_bits - 1; i >= 0; i--) { const uint32_t bit = (symbol >> i) & 1; res = res * tbe(prob[m], bit); m = 2 * m + bit; }
+  return res;
+}
+__device__ inline double sim_bit_tree_rev(const uint16_t *prob, int num_bits, uint32_t symbol) {   // :548-563
+  double res = 1.0; uint32_t m = 1;
+  for (int c = num_bits; c >= 1; c--) { const uint32_t bit = symbol & 1; res = res * tbe(prob[m], bit); m = 2 * m + bit; symbol >>= 1; }
+  return res;
+}
+
+__device__ double test_length(const LenProbs &pl, uint32_t length, uint32_t ps) {              // :483-509
+  uint32_t len = length - 2; double res;
+  if (len < 8) res = tbe(pl.c1, 0) * sim_bit_tree(pl.low[ps], 3, len);
+  else {
+    res = tbe(pl.c1, 1); len -= 8;
+    if (len < 8) res = res * tbe(pl.c2, 0) * sim_bit_tree(pl.mid[ps], 3, len);
+    else { res = res * tbe(pl.c2, 1); len -= 8; res = res * sim_bit_tree(pl.high, 8, len); }
+  }
+  return res;
+}
+
+__device__ double test_repeat_match(const Enc &E, int index_rm, uint32_t length, const MS &sim) {   // :511-538
+  const LzProbs &P = *E.P;
+  double res = tbe(P.rep[sim.state], 1);
+  switch (index_rm) {
+    case 0: res = res * tbe(P.g0[sim.state], 0) * tbe(P.rep0_long[sim.state][sim.pos_state], 1); break;
+    case 1: res = res * tbe(P.g0[sim.state], 1) * tbe(P.g1[sim.state], 0); break;
+    case 2: res = res * tbe(P.g0[sim.state], 1) * tbe(P.g1[sim.state], 1) * tbe(P.g2[sim.state], 0); break;
+    default: res = res * tbe(P.g0[sim.state], 1) * tbe(P.g1[sim.state], 1) * tbe(P.g2[sim.state], 1); break;
+  }
+  return res * test_length(P.rep_len, length, sim.pos_state);
+}
+
+__device__ double test_simple_match(const Enc &E, uint32_t distance, uint32_t length, const MS &sim) {   // :540-601
+  const LzProbs &P = *E.P;
+  const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(distance);
+  double td = sim_bit_tree(P.slot[len_state], 6, ds);
+  if (ds >= 4) {
+    const int footer = (int)(ds >> 1) - 1;
+    const uint32_t base = (2 | (ds & 1)) << footer, red = distance - base;
+    if (ds < 14) td = td * sim_bit_tree_rev(P.pos + ((int)base - (int)ds - 1) + 1, footer, red);
+    else {
+      double h = 1.0;
+      for (int i = 0; i < footer - 4; i++) h = h * 0.5;                          // 0.5 ** (footerBits - align_bits), exact
+      td = td * h * sim_bit_tree_rev(P.align, 4, red & 15);
+    }
+  }
+  return tbe(P.rep[sim.state], 0) * test_length(P.len, length, sim.pos_state) * td;
+}
+
+__device__ __noinline__ void sim_strict(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) {   // Simulate_Strict_DL_Code :605-659
+  const uint32_t dist_ip = distance - 1;
+  int found = -1;
+  const double dlc = tbe(E.P->match[sim.state][sim.pos_state], 1);
+  const double sma = test_simple_match(E, dist_ip, (uint32_t)length, sim);
+  for (int i = 0; i < 4; i++) if (dist_ip == sim.rep[i]) { found = i; break; }
+  bool rep = false;
+  if (found >= 0) {
+    const double rma = test_repeat_match(E, found, (uint32_t)length, sim);
+    if (rma >= sma * 0.55) {                                                       // Malus_simple_match_vs_rep :301
+      prob = prob * dlc * rma;
+      const uint32_t aux = sim.rep[found];
+      for (int i = found; i >= 1; i--) sim.rep[i] = sim.rep[i - 1];
+      sim.rep[0] = aux;
+      sim.state = T_REP[sim.state];
+      rep = true;
+    }
+  }
+  if (!rep) {
+    prob = prob * dlc * sma;
+    sim.rep[3] = sim.rep[2]; sim.rep[2] = sim.rep[1]; sim.rep[1] = sim.rep[0]; sim.rep[0] = dist_ip;
+    sim.state = T_MATCH[sim.state];
+  }
+  sim.pos += (uint64_t)length;
+  sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
+  sim.prev_byte = TB(E, (int64_t)sim.pos - 1);
+}
+
+__device__ inline double test_strict(const Enc &E, uint32_t distance, int length, const MS &sim) {   // :661-677
+  MS v = sim; double prob = 1.0;
+  sim_strict(E, distance, length, v, prob);
+  return prob;
+}
+
+__device__ double test_expanded(const Enc &E, uint32_t distance, int length, double give_up, const MS &sim) {   // :680-726
+  MS v = sim; double p = 1.0;
+  const int64_t copy_start = (int64_t)sim.pos - (int64_t)distance;
+  for (int x = 1; x <= length; x++) {
+    const uint32_t b = TB(E, copy_start + (x - 1));
+    sim_literal(E, b, v, p);
+    if (p < give_up) break;
+    v.prev_byte = b;
+  }
+  return p;
+}
+
+__device__ inline double fmax0(double x) { return x > 0.0 ? x : 0.0; }
+
+enum { W_STRICT = 0, W_LIT_DL = 1, W_DL_LIT = 2, W_EXPAND = 3, W_SPLIT = 4 };
+
+template <int R> __device__ void sim_any(const Enc &E, uint32_t distance, int length, MS &sim, double &prob);   // Simulate_any_DL_Code, recursion_limit = R
+
+// The body of Generic_any_DL_Code (:740-832) up to its choice; NEW = new_recursion_limit.  The simulations it asks for nest at
+// most three deep (the limit goes down by one per level, :756-764), so the recursion of the reference unrolls into templates.
+template <int NEW> __device__ __noinline__ int decide(const Enc &E, uint32_t distance, int length, const MS &sim, int &best_cut) {
+  double strict_dlc = 0.0, expanded_dlc = 0.0, soe = 0.0;
+  if (E.cv >= 1) {
+    strict_dlc = test_strict(E, distance, length, sim);
+    expanded_dlc = test_expanded(E, distance, length, strict_dlc, sim);
+    soe = strict_dlc > expanded_dlc ? strict_dlc : expanded_dlc;
+    if (length > 2) {
+      const uint32_t b_head = TB(E, (int64_t)sim.pos - (int64_t)distance);
+      const double head_lit = test_literal_byte(E, b_head, sim);
+      if (head_lit >= 0.875) return W_LIT_DL;                                      // Lit_then_DL_threshold :306
+      MS after = sim;
+      after.state = T_LIT[sim.state]; after.pos = sim.pos + 1; after.pos_state = (uint32_t)after.pos & LZ_PBM; after.prev_byte = b_head;
+      double dal = 1.0;
+      sim_any<NEW>(E, distance, length - 1, after, dal);
+      if (head_lit * dal * fmax0(0.064 - (double)distance * 1.0e-9 - (double)length * 3.0e-5) > soe) return W_LIT_DL;
+      {                                                                            // DL_code_then_Literal :869-889
+        MS v = sim;
+        double p = fmax0(0.135 - (double)distance * 1.0e-8 - (double)length * 1.0e-4);
+        sim_any<NEW>(E, distance, length - 1, v, p);
+        sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, p);
+        if (p > soe) return W_DL_LIT;
+      }
+    }
+    if (expanded_dlc > strict_dlc) return W_EXPAND;
+  }
+  if (E.cv >= 2) {                                                                 // Test_Split_DL :901-944
+    constexpr int LOW = NEW - 1 > 0 ? NEW - 1 : 0;
+    const double malus = fmax0(0.27 - (double)distance * 2.0e-6);
+    double best_prob = 0.0;
+    best_cut = 2;
+    if (!(malus < soe)) {
+      for (int cut = 2; cut <= length - 2; cut++) {
+        const int rest = length - cut;
+        if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) {
+          double p = malus;
+          MS v = sim;
+          sim_any<LOW>(E, distance, cut, v, p);
+          if (!(p <= soe)) {
+            sim_any<LOW>(E, distance, rest, v, p);
+            if (p > best_prob) { best_prob = p; best_cut = cut; }
+          }
+        }
+      }
+    }
+    if (best_prob > soe) return W_SPLIT;
+  }
+  return W_STRICT;
+}
+
+template <int R> __device__ __noinline__ void sim_any_impl(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) {
+  if constexpr (R - 1 < 0) {
+    sim_strict(E, distance, length, sim, prob);
+  } else {
+    constexpr int NEW = R - 1;
+    int cut = 2;
+    switch (decide<NEW>(E, distance, length, sim, cut)) {
+      case W_LIT_DL:
+        sim_literal(E, TB(E, (int64_t)sim.pos - (int64_t)distance), sim, prob);
+        sim_any<NEW>(E, distance, length - 1, sim, prob);
+        break;
+      case W_DL_LIT:
+        sim_any<NEW>(E, distance, length - 1, sim, prob);
+        sim_literal(E, TB(E, (int64_t)sim.pos - (int64_t)distance), sim, prob);
+        break;
+      case W_EXPAND:
+        for (int x = 1; x <= length; x++) sim_literal(E, TB(E, (int64_t)sim.pos - (int64_t)distance), sim, prob);
+        break;
+      case W_SPLIT:
+        sim_any<NEW>(E, distance, cut, sim, prob);
+        sim_any<NEW>(E, distance, length - cut, sim, prob);
+        break;
+      default:
+        sim_strict(E, distance, length, sim, prob);
+    }
+  }
+}
+template <int R> __device__ void sim_any(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) { sim_any_impl<R>(E, distance, length, sim, prob); }
+
+// ---------------------------------------------------------------- range coder :964-1039
+
+__device__ inline void put_byte(Enc &E, uint32_t b) { if (E.olen < E.cap) E.out[E.olen] = (uint8_t)b; E.olen++; }
+
+__device__ __noinline__ void shift_low(Enc &E) {
+  const uint64_t top = E.low >> 32;
+  const uint32_t bottom = (uint32_t)E.low;
+  if (bottom < 0xFF000000u || top != 0) {
+    uint32_t temp = E.cache;
+    const uint32_t carry = (uint32_t)top & 0xFF;
+    do { put_byte(E, (temp + carry) & 0xFF); temp = 0xFF; E.cache_size--; } while (E.cache_size != 0);
+    E.cache = (bottom >> 24) & 0xFF;
+  }
+  E.cache_size++;
+  E.low = (uint64_t)(uint32_t)(bottom << 8);
+}
+
+__device__ inline void normalize(Enc &E) { if (E.width < (1u << 24)) { E.width <<= 8; shift_low(E); } }
+
+__device__ inline void encode_bit(Enc &E, uint16_t &prob, uint32_t symbol) {
+  const uint32_t cur = prob, bound = (E.width >> 11) * cur;
+  if (symbol == 0) { E.width = bound; normalize(E); prob = (uint16_t)(cur + ((2048 - cur) >> 5)); }
+  else { E.low += bound; E.width -= bound; normalize(E); prob = (uint16_t)(cur - (cur >> 5)); }
+}
+
+__device__ void bit_tree_encode(Enc &E, uint16_t *prob, int num_bits, uint32_t symbol) {
+  uint32_t m = 1;
+  for (int i = num_bits - 1; i >= 0; i--) { const uint32_t bit = (symbol >> i) & 1; encode_bit(E, prob[m], bit); m = 2 * m + bit; }
+}
+__device__ void bit_tree_rev_encode(Enc &E, uint16_t *prob, int num_bits, uint32_t symbol) {
+  uint32_t m = 1;
+  for (int c = num_bits; c >= 1; c--) { const uint32_t bit = symbol & 1; encode_bit(E, prob[m], bit); m = 2 * m + bit; symbol >>= 1; }
+}
+
+// ---------------------------------------------------------------- the machine :1045-1361
+
+__device__ __noinline__ void emit_literal(Enc &E, uint32_t b) {                   // LZ77_emits_literal_byte :1097-1130
+  LzProbs &P = *E.P;
+  MS &S = E.ES;
+  const int idx = lit_idx(S.prev_byte);
+  const uint32_t b_match = TB(E, (int64_t)S.pos - (int64_t)S.rep[0] - 1);
+  if (b == b_match && S.pos > (uint64_t)(uint32_t)(S.rep[0] + 1) &&
+      (E.cv == 0 || test_short_rep(E, S) > test_simple_literal(E, b, b_match, P.lit + idx, S))) {
+    encode_bit(E, P.match[S.state][S.pos_state], 1);
+    encode_bit(E, P.rep[S.state], 1);
+    encode_bit(E, P.g0[S.state], 0);
+    encode_bit(E, P.rep0_long[S.state][S.pos_state], 0);
+    S.state = T_SREP[S.state];
+  } else {
+    encode_bit(E, P.match[S.state][S.pos_state], 0);
+    uint16_t *prob = P.lit + idx;
+    uint32_t symb = b | 0x100;
+    if (S.state < 7) {
+      do { encode_bit(E, prob[symb >> 8], (symb >> 7) & 1); symb <<= 1; } while (symb < 0x10000);
+    } else {
+      uint32_t offs = 0x100, match = b_match;
+      do {
+        match <<= 1;
+        encode_bit(E, prob[offs + (match & offs) + (symb >> 8)], (symb >> 7) & 1);
+        symb <<= 1;
+        offs &= ~(match ^ symb);
+      } while (symb < 0x10000);
+    }
+    S.state = T_LIT[S.state];
+  }
+  S.pos += 1;
+  S.pos_state = (uint32_t)S.pos & LZ_PBM;
+  S.prev_byte = b;
+}
+
+__device__ void encode_length(Enc &E, LenProbs &pl, uint32_t length) {            // :1160-1181
+  uint32_t len = length - 2;
+  const uint32_t ps = E.ES.pos_state;
+  if (len < 8) { encode_bit(E, pl.c1, 0); bit_tree_encode(E, pl.low[ps], 3, len); }
+  else {
+    encode_bit(E, pl.c1, 1); len -= 8;
+    if (len < 8) { encode_bit(E, pl.c2, 0); bit_tree_encode(E, pl.mid[ps], 3, len); }
+    else { encode_bit(E, pl.c2, 1); len -= 8; bit_tree_encode(E, pl.high, 8, len); }
+  }
+}
+
+__device__ __noinline__ void write_simple_match(Enc &E, uint32_t dist_ip, uint32_t length) {   // :1183-1255
+  LzProbs &P = *E.P;
+  MS &S = E.ES;
+  encode_bit(E, P.rep[S.state], 0);
+  S.state = T_MATCH[S.state];
+  encode_length(E, P.len, length);
+  const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(dist_ip);
+  bit_tree_encode(E, P.slot[len_state], 6, ds);
+  if (ds >= 4) {
+    const int footer = (int)(ds >> 1) - 1;
+    const uint32_t base = (2 | (ds & 1)) << footer, red = dist_ip - base;
+    if (ds < 14) bit_tree_rev_encode(E, P.pos + ((int)base - (int)ds - 1) + 1, footer, red);
+    else {
+      const uint32_t value = red >> 4;
+      for (int i = footer - 4 - 1; i >= 0; i--) {                                  // Encode_Direct_Bits :1205-1215
+        E.width >>= 1;
+        E.low += (uint64_t)E.width & (0 - (uint64_t)((value >> i) & 1));
+        normalize(E);
+      }
+      bit_tree_rev_encode(E, P.align, 4, red & 15);
+    }
+  }
+  S.rep[3] = S.rep[2]; S.rep[2] = S.rep[1]; S.rep[1] = S.rep[0]; S.rep[0] = dist_ip;
+}
+
+__device__ __noinline__ void write_repeat_match(Enc &E, int index_rm, uint32_t length) {   // :1257-1286
+  LzProbs &P = *E.P;
+  MS &S = E.ES;
+  encode_bit(E, P.rep[S.state], 1);
+  switch (index_rm) {
+    case 0: encode_bit(E, P.g0[S.state], 0); encode_bit(E, P.rep0_long[S.state][S.pos_state], 1); break;
+    case 1: encode_bit(E, P.g0[S.state], 1); encode_bit(E, P.g1[S.state], 0); break;
+    case 2: encode_bit(E, P.g0[S.state], 1); encode_bit(E, P.g1[S.state], 1); encode_bit(E, P.g2[S.state], 0); break;
+    default: encode_bit(E, P.g0[S.state], 1); encode_bit(E, P.g1[S.state], 1); encode_bit(E, P.g2[S.state], 1); break;
+  }
+  const uint32_t aux = S.rep[index_rm];
+  for (int i = index_rm; i >= 1; i--) S.rep[i] = S.rep[i - 1];
+  S.rep[0] = aux;
+  encode_length(E, P.rep_len, length);
+  S.state = T_REP[S.state];
+}
+
+__device__ __noinline__ void write_strict(Enc &E, uint32_t distance, int length) {   // Write_Strict_DL_Code :1288-1328
+  MS &S = E.ES;
+  const uint32_t dist_ip = distance - 1;
+  int found = -1;
+  encode_bit(E, E.P->match[S.state][S.pos_state], 1);
+  for (int i = 0; i < 4; i++) if (dist_ip == S.rep[i]) { found = i; break; }
+  if (found >= 0 && (E.cv == 0 || test_repeat_match(E, found, (uint32_t)length, S) >= test_simple_match(E, dist_ip, (uint32_t)length, S) * 0.55))
+    write_repeat_match(E, found, (uint32_t)length);
+  else
+    write_simple_match(E, dist_ip, (uint32_t)length);
+  S.pos += (uint64_t)length;
+  S.pos_state = (uint32_t)S.pos & LZ_PBM;
+  S.prev_byte = TB(E, (int64_t)S.pos - 1);
+}
+
+// LZ77_emits_DL_code :1355-1361 = Write_any_DL_code (..., ES, max_recursion): the writing instance of Generic_any_DL_Code does not
+// lower its limit (:756-760), so its own recursion can go a match length deep; it is a work list here.  An item is a length
+// still to be written at `distance`, or the literal that follows a shortened match (:797-805).
+__device__ __noinline__ void emit_dl(Enc &E, uint32_t distance, int length0) {
+  constexpr uint16_t POST_LIT = 0xFFFF;
+  uint16_t stack[2 * 280];
+  int sp = 0;
+  stack[sp++] = (uint16_t)length0;
+  while (sp > 0) {
+    const uint16_t it = stack[--sp];
+    if (it == POST_LIT) { emit_literal(E, TB(E, (int64_t)E.ES.pos - (int64_t)distance)); continue; }
+    const int length = it;
+    int cut = 2;
+    switch (decide<2>(E, distance, length, E.ES, cut)) {
+      case W_LIT_DL:
+        emit_literal(E, TB(E, (int64_t)E.ES.pos - (int64_t)distance));
+        stack[sp++] = (uint16_t)(length - 1);
+        break;
+      case W_DL_LIT:
+        stack[sp++] = POST_LIT;
+        stack[sp++] = (uint16_t)(length - 1);
+        break;
+      case W_EXPAND:
+        for (int x = 1; x <= length; x++) emit_literal(E, TB(E, (int64_t)E.ES.pos - (int64_t)distance));
+        break;
+      case W_SPLIT:
+        stack[sp++] = (uint16_t)(length - cut);
+        stack[sp++] = (uint16_t)cut;
+        break;
+      default:
+        write_strict(E, distance, length);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- Estimate_DL_Codes_for_LZ77 :1363-1498
+
+struct ScoreCtx { const Matches *m; int old_index, last_pos_any; MS sim_new; double head_lit_prob; };
+
+template <int LEVEL> __device__ __noinline__ void scoring(const Enc &E, const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {   // :1385-1469
+  prob = 0.0;
+  for (int m = 0; m <= 1; m++) {
+    const Matches &M = S.m[m];
+    for (int i = 1; i <= M.count; i++) {
+      const int last_pos_i = M.len[i] + (m != S.old_index ? 1 : 0);
+      if (last_pos_i < start) continue;
+      if (last_pos_i < S.last_pos_any && LEVEL >= 2) continue;
+      MS t; double p;
+      if (m != S.old_index && start == 1) { t = S.sim_new; p = S.head_lit_prob; } else { t = state; p = 1.0; }
+      int trunc;
+      if (m == S.old_index) trunc = M.len[i] - start + 1;
+      else if (start == 1) trunc = M.len[i];
+      else trunc = M.len[i] - start + 2;
+      if (trunc == 1) sim_literal(E, TB(E, (int64_t)state.pos), t, p);
+      else sim_any<1>(E, (uint32_t)M.dist[i], trunc, t, p);
+      if constexpr (LEVEL < 2) {
+        if (last_pos_i < S.last_pos_any) {
+          double tail; int si = 1, sm = 0;
+          scoring<LEVEL + 1>(E, S, t, last_pos_i + 1, tail, si, sm);
+          p = p * tail;
+        }
+      }
+      if (p > prob) { prob = p; index = i; match_set = m; }
+    }
+  }
+}
+
+__device__ void estimate_dl_codes(const Enc &E, const Matches *matches, int old_index, uint32_t prefix1, int &best_index, int &best_set) {
+  ScoreCtx S;
+  S.m = matches; S.old_index = old_index; S.last_pos_any = 0; S.sim_new = E.ES;
+  for (int m = 0; m <= 1; m++)
+    for (int i = 1; i <= matches[m].count; i++) {
+      const int lp = matches[m].len[i] + (m != old_index ? 1 : 0);
+      if (lp > S.last_pos_any) S.last_pos_any = lp;
+    }
+  S.head_lit_prob = 1.0;
+  sim_literal(E, prefix1, S.sim_new, S.head_lit_prob);
+  best_index = 1; best_set = old_index;
+  double best;
+  const MS sim_old = E.ES;
+  scoring<1>(E, S, sim_old, 1, best, best_index, best_set);
+}
+
+// ---------------------------------------------------------------- LZ77_using_BT4 (lz77.adb:953-1827)
+
+struct BT4 {
+  int sbs, readPos, readLimit, writePos, pendingSize;
+  int keepSizeBefore, keepSizeAfter, buf_len;
+  int64_t moved;                                   // sum of the window moves: buf (i) = in [i + moved]
+  uint64_t in_pos;
+  uint32_t hash_4_mask, h2, h3, h4;
+  int32_t *hash2, *hash3, *hash4, *tree;
+  int cyclicPos, lzPos, max_dist;
+  int readAhead, rep_dist[4], len_rep[4], best_len_rep, best_rep_index;
+  int cur;                                         // current_match_index
+  uint32_t cur_literal;
+};
+constexpr int BT_LOOK = 273, BT_NICE = 162, BT_MIN = 2, BT_DEPTH = 48, BT_OPTS = 4096;
+
+__device__ inline uint32_t crc_tab(uint32_t i) {                                  // Hash234.crcTable :1091-1101
+  uint32_t r = i;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r = (r & 1) ? (r >> 1) ^ 0xEDB88320u : r >> 1;
+  return r;
+}
+#define BUF(i) ((uint32_t)E.in[(int64_t)(i) + B.moved])
+
+__device__ inline int bt_available(const BT4 &B) { return B.writePos - B.readPos - 1; }
+
+__device__ inline int bt_move_pos(BT4 &B) {                                       // Move_Pos_in_BT4 :1127-1150 (finishing = False, :959)
+  B.readPos++;
+  int avail = bt_available(B);
+  if (avail < BT_NICE) { B.pendingSize++; avail = 0; }
+  if (avail != 0) {
+    B.lzPos++;                                     // (normalisation at Integer'Last cannot be reached below 2 GiB of input)
+    B.cyclicPos++;
+    if (B.cyclicPos == B.sbs) B.cyclicPos = 0;
+  }
+  return avail;
+}
+
+__device__ inline void bt_hashes(const Enc &E, BT4 &B) {                           // calcHashes :1061-1069
+  const int off = B.readPos;
+  uint32_t t = crc_tab(BUF(off)) ^ BUF(off + 1);
+  B.h2 = t & 1023;
+  t ^= BUF(off + 2) << 8;
+  B.h3 = t & 65535;
+  t ^= crc_tab(BUF(off + 3)) << 5;
+  B.h4 = t & B.hash_4_mask;
+}
+
+__device__ __noinline__ void bt_skip_update(const Enc &E, BT4 &B, int niceLenLimit, int currentMatch) {   // Skip_and_Update_Tree :1154-1206
+  int32_t *tree = B.tree;
+  int depth = BT_DEPTH, ptr0 = B.cyclicPos * 2 + 1, ptr1 = B.cyclicPos * 2, len0 = 0, len1 = 0;
+  const int rp = B.readPos;
+  for (;;) {
+    const int delta0 = B.lzPos - currentMatch;
+    if (depth == 0 || delta0 >= B.max_dist) { tree[ptr0] = -1; tree[ptr1] = -1; return; }
+    depth--;
+    const int pair = (B.cyclicPos - delta0 + (B.cyclicPos - delta0 < 0 ? B.sbs : 0)) * 2;
+    int len = len0 < len1 ? len0 : len1;
+    if (BUF(rp + len - delta0) == BUF(rp + len)) {
+      for (;;) {
+        len++;
+        if (len == niceLenLimit) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return; }
+        if (BUF(rp + len - delta0) != BUF(rp + len)) break;
+      }
+    }
+    if (BUF(rp + len - delta0) < BUF(rp + len)) { tree[ptr1] = currentMatch; ptr1 = pair + 1; currentMatch = tree[ptr1]; len1 = len; }
+    else { tree[ptr0] = currentMatch; ptr0 = pair; currentMatch = tree[ptr0]; len0 = len; }
+  }
+}
+
+__device__ void bt_skip(const Enc &E, BT4 &B, int len) {                           // BT4_Algo.Skip :1208-1232
+  for (int count = len; count >= 1; count--) {
+    int nice = BT_NICE;
+    const int avail = bt_move_pos(B);
+    if (avail < nice) { if (avail == 0) continue; nice = avail; }
+    bt_hashes(E, B);
+    const int currentMatch = B.hash4[B.h4];
+    B.hash2[B.h2] = B.lzPos; B.hash3[B.h3] = B.lzPos; B.hash4[B.h4] = B.lzPos;
+    bt_skip_update(E, B, nice, currentMatch);
+  }
+}
+
+__device__ __noinline__ void bt_get_matches(const Enc &E, BT4 &B, Matches &M) {     // BT4_Algo.Read_One_and_Get_Matches :1234-1361
+  int32_t *tree = B.tree;
+  int matchLenLimit = BT_LOOK, nice = BT_NICE;
+  M.count = 0;
+  const int avail = bt_move_pos(B);
+  if (avail < matchLenLimit) {
+    if (avail == 0) return;
+    matchLenLimit = avail;
+    if (nice > avail) nice = avail;
+  }
+  const int rp = B.readPos;
+  bt_hashes(E, B);
+  int delta2 = B.lzPos - B.hash2[B.h2];
+  const int delta3 = B.lzPos - B.hash3[B.h3];
+  int currentMatch = B.hash4[B.h4];
+  B.hash2[B.h2] = B.lzPos; B.hash3[B.h3] = B.lzPos; B.hash4[B.h4] = B.lzPos;
+  int lenBest = 0;
+  if (delta2 < B.max_dist && BUF(rp - delta2) == BUF(rp)) { lenBest = 2; M.count = 1; M.len[1] = 2; M.dist[1] = delta2; }
+  if (delta2 != delta3 && delta3 < B.max_dist && BUF(rp - delta3) == BUF(rp)) { lenBest = 3; M.count++; M.dist[M.count] = delta3; delta2 = delta3; }
+  if (M.count > 0) {
+    while (lenBest < matchLenLimit && BUF(rp + lenBest - delta2) == BUF(rp + lenBest)) lenBest++;
+    M.len[M.count] = lenBest;
+    if (lenBest >= nice) { bt_skip_update(E, B, nice, currentMatch); return; }
+  }
+  if (lenBest < 3) lenBest = 3;
+  int depth = BT_DEPTH, ptr0 = B.cyclicPos * 2 + 1, ptr1 = B.cyclicPos * 2, len0 = 0, len1 = 0;
+  for (;;) {
+    const int delta0 = B.lzPos - currentMatch;
+    if (depth == 0 || delta0 >= B.max_dist) { tree[ptr0] = -1; tree[ptr1] = -1; return; }
+    depth--;
+    const int pair = (B.cyclicPos - delta0 + (B.cyclicPos - delta0 < 0 ? B.sbs : 0)) * 2;
+    int len = len0 < len1 ? len0 : len1;
+    if (BUF(rp + len - delta0) == BUF(rp + len)) {
+      do { len++; } while (!(len >= matchLenLimit || BUF(rp + len - delta0) != BUF(rp + len)));
+      if (len > lenBest) {
+        lenBest = len;
+        M.count++;
+        M.len[M.count] = len; M.dist[M.count] = delta0;
+        if (len >= nice) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return; }
+      }
+    }
+    if (BUF(rp + len - delta0) < BUF(rp + len)) { tree[ptr1] = currentMatch; ptr1 = pair + 1; currentMatch = tree[ptr1]; len1 = len; }
+    else { tree[ptr0] = currentMatch; ptr0 = pair; currentMatch = tree[ptr0]; len0 = len; }
+  }
+}
+
+__device__ int bt_fill_window(const Enc &E, BT4 &B, int len_initial) {             // Fill_Window :1389-1440, Move_Window :1375-1386
+  int len = len_initial;
+  if (B.readPos >= B.buf_len - B.keepSizeAfter) {
+    const int moveOffset = ((B.readPos + 1 - B.keepSizeBefore) / 16) * 16;
+    B.moved += moveOffset;
+    B.readPos -= moveOffset; B.readLimit -= moveOffset; B.writePos -= moveOffset;
+  }
+  if (len > B.buf_len - B.writePos) len = B.buf_len - B.writePos;
+  const uint64_t left = E.n - B.in_pos;
+  const int actual = (uint64_t)len < left ? len : (int)left;
+  B.writePos += actual; B.in_pos += (uint64_t)actual;
+  if (B.writePos >= B.keepSizeAfter) B.readLimit = B.writePos - B.keepSizeAfter;
+  if (B.pendingSize > 0 && B.readPos < B.readLimit) {                               // processPendingBytes :1397-1406
+    const int old = B.pendingSize;
+    B.readPos -= B.pendingSize;
+    B.pendingSize = 0;
+    bt_skip(E, B, old);
+  }
+  return actual;
+}
+
+__device__ inline int bt_match_len(const Enc &E, const BT4 &B, int distance, int limit) {   // Compute_Match_Length :1442-1460
+  if (distance < 2) return 0;
+  const int back = B.readPos - distance;
+  int len = 0;
+  while (len < limit && BUF(B.readPos + len) == BUF(back + len)) len++;
+  return len;
+}
+__device__ inline bool much_smaller(int smallDist, int bigDist) { return (smallDist - 1) < (bigDist - 1) / 128; }   // :1469-1473
+
+__device__ void lz_read_one(const Enc &E, BT4 &B, Matches &M) {                     // Read_One_and_Get_Matches :1477-1503
+  B.readAhead++;
+  bt_get_matches(E, B, M);
+  B.best_len_rep = 0;
+  const int a = bt_available(B), avail = a < BT_LOOK ? a : BT_LOOK;
+  if (avail >= BT_MIN) {
+    for (int rep = 0; rep < 4; rep++) {
+      const int len = bt_match_len(E, B, B.rep_dist[rep], avail);
+      B.len_rep[rep] = len;
+      if (len > B.best_len_rep) { B.best_rep_index = rep; B.best_len_rep = len; }
+    }
+  } else {
+    for (int rep = 0; rep < 4; rep++) B.len_rep[rep] = 0;
+  }
+}
+
+__device__ void lz_supplement(const BT4 &B, Matches &M) {                           // Get_supplemental_Matches_from_Repeat_Matches :1505-1566
+  if (M.count == 0 && B.best_len_rep >= BT_MIN) { M.dist[1] = B.rep_dist[B.best_rep_index]; M.len[1] = B.best_len_rep; M.count = 1; }
+  for (int rep = 0; rep < 4; rep++) {
+    const int len = B.len_rep[rep];
+    if (len < BT_MIN) continue;
+    int ins = 0;
+    for (int i = M.count; i >= 1; i--) {
+      if (len == M.len[i]) {
+        if (B.rep_dist[rep] != M.dist[i]) { ins = much_smaller(M.dist[i], B.rep_dist[rep]) ? i : i + 1; break; }
+      } else if (i < M.count) {
+        if (len > M.len[i] && len < M.len[i + 1]) { ins = i + 1; break; }
+      } else if (len > M.len[i]) { ins = i + 1; break; }
+    }
+    if (ins > 0) {
+      for (int i = M.count; i >= ins; i--) { M.dist[i + 1] = M.dist[i]; M.len[i + 1] = M.len[i]; }
+      M.dist[ins] = B.rep_dist[rep]; M.len[ins] = len;
+      M.count++;
+      break;
+    }
+  }
+}
+
+__device__ inline void lz_reduce(Matches &m) {                                       // Reduce_consecutive_max_lengths :1575-1585
+  while (m.count > 1 && m.len[m.count] == m.len[m.count - 1] + 1 && much_smaller(m.dist[m.count - 1], m.dist[m.count])) m.count--;
+}
+
+__device__ void lz_send_dl(Enc &E, BT4 &B, int distance, int length) {               // Send_DL_code :1627-1659
+  emit_dl(E, (uint32_t)distance, length);
+  B.readAhead -= length;
+  int found = -1;
+  for (int i = 0; i < 4; i++) if (distance == B.rep_dist[i]) { found = i; break; }
+  if (found >= 0) {
+    const int aux = B.rep_dist[found];
+    for (int i = found; i >= 1; i--) B.rep_dist[i] = B.rep_dist[i - 1];
+    B.rep_dist[0] = aux;
+  } else {
+    B.rep_dist[3] = B.rep_dist[2]; B.rep_dist[2] = B.rep_dist[1]; B.rep_dist[1] = B.rep_dist[0]; B.rep_dist[0] = distance;
+  }
+}
+__device__ inline void lz_send_literal(Enc &E, BT4 &B) { emit_literal(E, B.cur_literal); B.readAhead--; }
+__device__ inline void lz_skip(const Enc &E, BT4 &B, int len) { B.readAhead += len; bt_skip(E, B, len); }
+
+__device__ __noinline__ void lz_next_symbol(Enc &E, BT4 &B, Matches *MM) {           // Get_Next_Symbol :1605-1796
+  constexpr int hurdle = 40;
+  if (B.readAhead == -1) lz_read_one(E, B, MM[B.cur]);
+  B.cur_literal = BUF(B.readPos);
+  const int a = bt_available(B), avail = a < BT_LOOK ? a : BT_LOOK;
+  if (avail < BT_MIN) { lz_send_literal(E, B); return; }
+  if (B.best_len_rep >= BT_NICE) {
+    lz_skip(E, B, B.best_len_rep - 1);
+    lz_send_dl(E, B, B.rep_dist[B.best_rep_index], B.best_len_rep);
+    return;
+  }
+  int main_len = 1, main_dist = 1;
+  {
+    Matches &C = MM[B.cur];
+    if (C.count > 0) {
+      main_len = C.len[C.count]; main_dist = C.dist[C.count];
+      if (main_len >= BT_NICE) { lz_skip(E, B, main_len - 1); lz_send_dl(E, B, main_dist, main_len); return; }
+      lz_reduce(C);
+      lz_supplement(B, C);
+      main_len = C.len[C.count]; main_dist = C.dist[C.count];
+      if (main_len == BT_MIN && main_dist > 128) main_len = 1;
+    }
+  }
+  if (B.best_len_rep > BT_MIN &&
+      (B.best_len_rep >= main_len || (B.best_len_rep >= main_len - 2 && main_dist > (1 << 9)) || (B.best_len_rep >= main_len - 3 && main_dist > (1 << 15)))) {
+    lz_skip(E, B, B.best_len_rep - 1);
+    lz_send_dl(E, B, B.rep_dist[B.best_rep_index], B.best_len_rep);
+    return;
+  }
+  if (main_len < BT_MIN || avail <= BT_MIN) { lz_send_literal(E, B); return; }
+  B.cur = 1 - B.cur;
+  lz_read_one(E, B, MM[B.cur]);
+  {
+    Matches &C = MM[B.cur];
+    if (C.count > 0) {
+      const int nl = C.len[C.count], nd = C.dist[C.count];
+      if ((nl >= main_len + hurdle && nd < main_dist) || (nl == main_len + hurdle + 1 && !much_smaller(main_dist, nd)) || nl > main_len + hurdle + 1 ||
+          (nl >= main_len + hurdle - 1 && main_len >= BT_MIN + 1 && much_smaller(nd, main_dist))) {
+        lz_send_literal(E, B);
+        return;
+      }
+      lz_reduce(C);
+      lz_supplement(B, C);
+      int idx = 1, set = 1 - B.cur;
+      estimate_dl_codes(E, MM, 1 - B.cur, B.cur_literal, idx, set);
+      if (set == 1 - B.cur) { main_len = MM[set].len[idx]; main_dist = MM[set].dist[idx]; }
+      else { lz_send_literal(E, B); return; }
+    }
+  }
+  const int limit = main_len - 1 > BT_MIN ? main_len - 1 : BT_MIN;
+  for (int rep = 0; rep < 4; rep++)
+    if (bt_match_len(E, B, B.rep_dist[rep], limit) == limit) { lz_send_literal(E, B); return; }
+  lz_skip(E, B, main_len - 2);
+  lz_send_dl(E, B, main_dist, main_len);
+}
+
+__device__ void lz_bt4(Enc &E, Matches *MM, int sbs, int32_t *ws, uint32_t hash4_size) {
+  BT4 B;
+  B.sbs = sbs; B.readPos = -1; B.readLimit = -1; B.writePos = 0; B.pendingSize = 0;
+  B.keepSizeBefore = BT_OPTS + sbs;
+  B.keepSizeAfter = BT_OPTS + BT_LOOK;
+  const int64_t r = (int64_t)sbs / 2 + 256 * 1024, rmax = 512ll << 20;
+  B.buf_len = B.keepSizeBefore + B.keepSizeAfter + (int)(r < rmax ? r : rmax) + 1;
+  B.moved = 0; B.in_pos = 0;
+  B.hash_4_mask = hash4_size - 1;
+  B.hash2 = ws; B.hash3 = ws + 1024; B.hash4 = ws + 1024 + 65536; B.tree = ws + 1024 + 65536 + hash4_size;
+  B.cyclicPos = -1; B.lzPos = sbs; B.max_dist = sbs - (BT_LOOK + 2);
+  B.readAhead = -1;
+  for (int i = 0; i < 4; i++) { B.rep_dist[i] = 1; B.len_rep[i] = 0; }
+  B.best_len_rep = 0; B.best_rep_index = 0;
+  B.cur = 0; B.cur_literal = 0;
+  MM[0].count = 0; MM[1].count = 0;
+  int written = bt_fill_window(E, B, sbs);
+  if (written > 0) {
+    for (;;) {
+      lz_next_symbol(E, B, MM);
+      if (bt_available(B) == 0) {
+        written = bt_fill_window(E, B, sbs);
+        if (written == 0) break;
+      }
+    }
+  }
+}
+#undef BUF
+
+// ---------------------------------------------------------------- one stream per workgroup
+
+__global__ void __launch_bounds__(64) k_lzma_encode(const LzmaJob *jobs, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
+                                                    int32_t *ws_base, uint64_t *result) {
+  __shared__ LzProbs P;
+  __shared__ Matches MM[2];
+  const LzmaJob J = jobs[blockIdx.x];
+  {
+    uint16_t *p = (uint16_t *)&P;
+    for (uint32_t i = threadIdx.x; i < sizeof(LzProbs) / 2; i += 64) p[i] = 1024;    // initial_probability
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  Enc E;
+  E.P = &P; E.in = in_base + J.in_off; E.n = J.n;
+  E.cv = J.level <= 1 ? 0 : J.level == 2 ? 1 : 2;
+  E.ES.state = 0; E.ES.pos_state = 0; E.ES.prev_byte = 0; E.ES.pos = 0;
+  E.ES.rep[0] = E.ES.rep[1] = E.ES.rep[2] = E.ES.rep[3] = 0;
+  E.width = 0xFFFFFFFFu; E.low = 0; E.cache = 0; E.cache_size = 1;
+  E.out = out_base + J.out_off; E.cap = J.cap; E.olen = 0;
+  if (J.zip_prefix) { put_byte(E, 16); put_byte(E, 2); put_byte(E, 5); put_byte(E, 0); }   // zip-compress-lzma_e.adb:155-158
+  put_byte(E, 3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
+  for (int i = 0; i < 4; i++) put_byte(E, (J.sbs >> (8 * i)) & 255);
+  if (J.level == 0) {
+    for (uint64_t i = 0; i < J.n; i++) emit_literal(E, E.in[i]);                     // No_LZ77
+  } else if (J.level <= 2) {
+    const uint32_t *tok = tok_base + J.tok_off;
+    for (uint64_t t = 0; t < J.ntok; t++) {
+      const uint32_t tk = tok[t];
+      if (tk & 0x80000000u) emit_dl(E, tk & 0xFFFF, (int)((tk >> 16) & 0x7FFF)); else emit_literal(E, tk & 0xFF);
+    }
+  } else {
+    lz_bt4(E, MM, (int)J.sbs, ws_base + J.ws_off, J.hash4_size);
+  }
+  encode_bit(E, P.match[E.ES.state][E.ES.pos_state], 1);                             // end marker :1549-1556
+  write_simple_match(E, 0xFFFFFFFFu, 2);
+  for (int i = 0; i < 5; i++) shift_low(E);                                          // Flush_range_encoder
+  result[2 * blockIdx.x] = E.olen;
+  result[2 * blockIdx.x + 1] = E.ES.pos;
+}
+
+}  // namespace
+
+// String_buffer_size of a level (:137-149) and the BT4 hash size (lz77.adb:1019-1032)
+uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size) {
+  if (level == 0) return 16;
+  if (level <= 2) return 1u << 15;
+  uint64_t x = dictionary_size + 273 + 1 + 64, p = 1;
+  while (p < 0x7FFFFFFFull / 2 && p < x) p *= 2;
+  if (p < x) p = x;
+  if (p > (1ull << 28)) p = 1ull << 28;
+  if (p < 4096) p = 4096;
+  return (uint32_t)p;
+}
+uint32_t lzma_hash4_size(uint32_t sbs) {
+  uint32_t h = sbs - 1;
+  h |= h >> 1; h |= h >> 2; h |= h >> 4; h |= h >> 8;
+  h >>= 1;
+  h |= 0xFFFF;
+  if (h > (1u << 24)) h >>= 1;
+  return h + 1;
+}
+uint64_t lzma_workspace_ints(int level, uint32_t sbs) { return level == 3 ? 1024ull + 65536 + lzma_hash4_size(sbs) + 2ull * sbs : 0; }
+
+// jobs[0 .. count): device array; results: 2 x count uint64 (stream bytes, input bytes coded).  Level_3 hash tables must be zero.
+int lzma_launch(Ctx *c, const LzmaJob *d_jobs, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result) {
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_in, d_tok, d_out, d_ws, d_result);
+  return hip_check(c, hipGetLastError(), "k_lzma_encode") ? ZADA_E_HIP : 0;
+}
+
+}  // namespace zada
