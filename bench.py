@@ -211,6 +211,50 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
     return out
 
 
+def lzma_leg(za, enc, entries, kib, with_cpu, with_checks):
+    """Secondary measurement (BASELINE config 4's method): LZMA_3 of `entries` Zip entries of `kib` KiB
+    (slices of the same synthetic stream) through ONE launch of the coder -- a stream is a chain of dependent steps, so entries
+    are what runs in parallel -- and ONE stream alone beside it (config 4's shape).  Host buffers in, host buffers out."""
+    import lzma
+    size = kib << 10
+    host = za.silesia_mix(entries * size, seed=SEED)
+    datas = [host[i * size:(i + 1) * size].tobytes() for i in range(entries)]
+    enc.lzma_batch(datas[:8], 18)
+    t0 = time.perf_counter()
+    res = enc.lzma_batch(datas, 18)
+    dt = time.perf_counter() - t0
+    tim = {k: round(v, 1) for k, v in enc.last_timing() if not k.startswith("#")}
+    out_bytes = sum(len(z) for _, z, _ in res)
+    out = {"metric": "LZMA_3 encode MB/s over a batch of Zip entries (payloads bit-exact with the CPU restatement of the reference, Ada parity unpinned)",
+           "value": round(entries * size / dt / 1e6, 3), "unit": "MB/s", "workload": "%d entries of %d KiB, silesia_mix_v1, one launch" % (entries, kib),
+           "ms": round(dt * 1e3, 1), "compression_ratio": round(out_bytes / (entries * size), 4), "phase_ms": tim}
+    one = datas[0] * max(1, 64 // kib)
+    t1 = time.perf_counter()
+    rc1, z1, _ = enc.lzma(one, 18)
+    d1 = time.perf_counter() - t1
+    out["one_stream"] = {"value": round(len(one) / d1 / 1e6, 4), "unit": "MB/s", "bytes": len(one),
+                         "note": "config 4 is ONE 1 GiB stream: it runs at this rate (lane 0 of one workgroup walks the chain of adaptive probabilities)"}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _lzmah import oracle_lzma
+        k = min(entries, max(1, (2 << 20) // size))
+        t2 = time.perf_counter()
+        ref = [oracle_lzma(d, 18) for d in datas[:k]]
+        dtc = time.perf_counter() - t2
+        out["cpu_baseline"] = {"value": round(k * size / dtc / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+                               "sample": "the first %d entries, oracle/zada_oracle_lzma.c" % k}
+        if with_checks:
+            out["sample_payloads_equal_cpu_port"] = bool(all(res[i] == ref[i] for i in range(k)))
+    if with_checks:
+        ok = True
+        for d, (rc, z, crc) in zip(datas, res):
+            ds = int.from_bytes(z[5:9], "little")
+            dec = lzma.LZMADecompressor(format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA1, "dict_size": ds, "lc": 3, "lp": 0, "pb": 2}])
+            ok = ok and dec.decompress(z[9:]) == d and (crc ^ 0xFFFFFFFF) == zlib.crc32(d)
+        out["payloads_decode_to_input_crc"] = bool(ok)
+    return out
+
+
 def bzip2_main(args, za, sharding, enc, torch, dist, rank, world, dev, emulate):
     """BASELINE config 5: ONE BZip2_3 stream of world x mib MiB, the blocks sharded over the GPUs (sharding.bzip2_stream_rank):
     same contract as the Deflate line (W warm-up steps, K timed steps between barriers, max over ranks, one JSON line)."""
@@ -297,6 +341,8 @@ def main():
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--method", choices=("deflate", "bzip2"), default="deflate", help="bzip2: BASELINE config 5 -- ONE BZip2_3 stream of N x --mib (default 1024) MiB over N GPUs")
     ap.add_argument("--bzip2-mib", type=int, default=256, help="input MiB of the secondary BZip2_3 measurement at one GPU (0 = skip)")
+    ap.add_argument("--lzma-entries", type=int, default=1024, help="entries of the secondary LZMA_3 batch measurement at one GPU (0 = skip)")
+    ap.add_argument("--lzma-kib", type=int, default=16, help="KiB per entry of the LZMA_3 batch")
     args = ap.parse_args()
 
     import torch
@@ -494,6 +540,8 @@ def main():
             res["checks"] = checks
         if world == 1 and args.bzip2_mib > 0:
             res["bzip2"] = bzip2_leg(za, enc, args.bzip2_mib, not args.no_cpu_baseline, not args.no_checks)
+        if world == 1 and args.lzma_entries > 0:
+            res["lzma"] = lzma_leg(za, enc, args.lzma_entries, args.lzma_kib, not args.no_cpu_baseline, not args.no_checks)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,114 @@
+"""GPU parity tests of the LZMA path (zada_lzma*): the product, through the C ABI, against the oracle's
+restatement of lzma-encoding.adb / lz77.adb's BT4 and against the committed digests.  A stream is one chain of dependent steps
+(one workgroup codes it), so the matrix goes through zada_lzma_batch -- all its streams at once -- and single calls cover the
+other entry points."""
+import hashlib
+import io
+import json
+import os
+import zipfile
+import zlib
+
+import numpy as np
+import pytest
+
+from _common import GOLDEN, product, oracle_zip
+from _lzmah import lz_inputs, oracle_lzma, lzma_decode, LZMA_METHODS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("method", LZMA_METHODS)
+def test_streams_bit_exact_vs_oracle_and_digests(encoder, method):
+    """Every input of the matrix, one batch per method: payload, return code and CRC equal the oracle's; digests as committed.
+    (LZMA_3 on the GPU takes tens of microseconds per byte of one stream: the longest inputs set the time of the launch.)"""
+    dig = json.load(open(os.path.join(GOLDEN, "lzma_digests.json")))
+    cases = {k: v for k, v in lz_inputs().items() if len(v) <= (110000 if method >= 17 else 400000)}
+    names = sorted(cases)
+    res = encoder.lzma_batch([cases[k] for k in names], method)
+    for name, (rc, z, crc) in zip(names, res):
+        d = cases[name]
+        orc, oz, ocrc = oracle_lzma(d, method)
+        assert (rc, crc) == (orc, ocrc), (name, method)
+        assert z == oz, (name, method, len(z or b""), len(oz))
+        want = dig["%s|%d" % (name, method)]
+        assert (want["rc"], want["size"], want["sha256"]) == (rc, len(z), hashlib.sha256(z).hexdigest()), name
+        assert crc ^ 0xFFFFFFFF == zlib.crc32(d)
+
+
+def test_single_calls_host_and_device_entry(encoder):
+    """zada_lzma and zada_lzma_device on the mixed corpus (every variant of a DL code is taken there), all four methods;
+    liblzma decodes what the product wrote."""
+    import torch
+    Z = product()
+    d = lz_inputs()["mix_256k"][:98304]
+    for method in LZMA_METHODS:
+        rc, z, crc = encoder.lzma(d, method)
+        assert (rc, z, crc) == oracle_lzma(d, method), method
+        assert lzma_decode(z, 4) == d
+    t = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    out = torch.empty(len(d) + 4096, dtype=torch.uint8, device="cuda")
+    for method in (16, 18):
+        rc, ln, crc = encoder.lzma_device(t.data_ptr(), len(d), out.data_ptr(), out.numel(), method)
+        orc, oz, ocrc = oracle_lzma(d, method)
+        assert (rc, crc, bytes(out[:ln].cpu().numpy())) == (orc, ocrc, oz), method
+    del Z
+
+
+def test_inefficient_and_small_buffers(encoder):
+    """compression_ok = False (zip-compress.adb:479-486) when the payload is not smaller; an output buffer that cannot hold an
+    efficient payload is an error, one that cannot hold an inefficient one is not."""
+    rng = np.random.default_rng(5)
+    rnd = bytes(rng.integers(0, 256, 30000, dtype=np.uint8))
+    for method in (15, 16, 18):
+        rc, z, crc = encoder.lzma(rnd, method)
+        assert rc == 1 and (rc, z, crc) == oracle_lzma(rnd, method)
+        rc, z, _ = encoder.lzma(rnd, method, cap=len(rnd))
+        assert rc == 1 and z is None
+    text = lz_inputs()["text_32768"]
+    with pytest.raises(Exception):
+        encoder.lzma(text, 16, cap=100)
+
+
+def test_zip_archive_with_lzma_entries(encoder):
+    """Zip.Create with an LZMA method (zip-compress.adb:211-216: format code 14; general purpose bit 1 for the end marker,
+    zip-create.adb:266-278): archive bytes == the oracle's Zip.Create restatement, entry by entry and as one batch;
+    Python's zipfile (liblzma) reads every entry back."""
+    Z = product()
+    rng = np.random.default_rng(21)
+    mix = Z.silesia_mix(1 << 20)
+    entries = [("a/text.txt", bytes(mix[:60000])), ("a/empty", b""), ("b/random.bin", bytes(rng.integers(0, 256, 5000, dtype=np.uint8))),
+               ("b/tiny", b"x"), ("c/more.txt", bytes(mix[300000:390000]))]
+    for method in (16, 18):
+        want = oracle_zip(entries, method)
+        zc = Z.ZipCreate(encoder, method)
+        for name, d in entries:
+            zc.add_stream(name, d)
+        assert zc.finish() == want
+        zb = Z.ZipCreate(encoder, method)
+        zb.add_streams([n for n, _ in entries], [d for _, d in entries])
+        got = zb.finish()
+        assert got == want
+        zf = zipfile.ZipFile(io.BytesIO(got))
+        assert zf.testzip() is None and [zf.read(i) for i in zf.infolist()] == [d for _, d in entries]
+        assert [i.compress_type for i in zf.infolist()] == [14, 0, 0, 0, 14]
+        assert [i.flag_bits & 2 for i in zf.infolist()] == [2, 0, 0, 0, 2]
+
+
+def test_batch_of_many_small_entries(encoder):
+    """zipada's usual workload: many small files.  2 000 entries of 1 .. 12 KiB through one launch; a sample is compared with
+    the oracle, all of them are decoded."""
+    Z = product()
+    rng = np.random.default_rng(33)
+    mix = Z.silesia_mix(8 << 20)
+    datas = []
+    for i in range(2000):
+        n = int(rng.integers(1024, 12289))
+        o = int(rng.integers(0, len(mix) - n))
+        datas.append(bytes(mix[o:o + n]))
+    for method in (16, 18):
+        res = encoder.lzma_batch(datas, method)
+        for i in range(0, len(datas), 40):
+            assert res[i] == oracle_lzma(datas[i], method), (i, method)
+        for d, (rc, z, crc) in zip(datas, res):
+            assert lzma_decode(z, 4) == d and crc ^ 0xFFFFFFFF == zlib.crc32(d)

@@ -87,7 +87,7 @@ def test_product_never_references_the_oracle():
         for f in fn:
             if f.endswith((".hip", ".h", ".c", ".cpp", ".py", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
-                assert "zada_oracle" not in txt and "libzada_oracle" not in txt and "zo_deflate" not in txt and "zo_bz" not in txt, f
+                assert "zada_oracle" not in txt and "libzada_oracle" not in txt and "zo_deflate" not in txt and "zo_bz" not in txt and "zo_lzma" not in txt, f
 
 
 def test_zip64_promotion_of_the_container_writer():
