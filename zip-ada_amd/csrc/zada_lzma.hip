@@ -33,7 +33,7 @@ struct LzProbs {                               // lzma.ads:137-201
   LenProbs len, rep_len;
   uint16_t match[12][16], rep[12], g0[12], g1[12], g2[12], rep0_long[12][16];
 };
-struct Matches { int count; int dist[LZ_MAXM], len[LZ_MAXM]; };     // lz77.ads:70-75, (1 .. count)
+struct Matches { int count; int dist[LZ_MAXM]; uint16_t len[LZ_MAXM]; };     // lz77.ads:70-75, (1 .. count); lengths are 2 .. 273
 
 struct MS {                                    // Machine_State :212-219 without R (= total_pos mod the ring size)
   uint32_t state, pos_state, prev_byte;
@@ -623,7 +623,7 @@ __device__ __noinline__ void bt_get_matches(const Enc &E, BT4 &B, Matches &M) { 
   if (delta2 != delta3 && delta3 < B.max_dist && BUF(rp - delta3) == BUF(rp)) { lenBest = 3; M.count++; M.dist[M.count] = delta3; delta2 = delta3; }
   if (M.count > 0) {
     while (lenBest < matchLenLimit && BUF(rp + lenBest - delta2) == BUF(rp + lenBest)) lenBest++;
-    M.len[M.count] = lenBest;
+    M.len[M.count] = (uint16_t)lenBest;
     if (lenBest >= nice) { bt_skip_update(E, B, nice, currentMatch); return; }
   }
   if (lenBest < 3) lenBest = 3;
@@ -639,7 +639,7 @@ __device__ __noinline__ void bt_get_matches(const Enc &E, BT4 &B, Matches &M) { 
       if (len > lenBest) {
         lenBest = len;
         M.count++;
-        M.len[M.count] = len; M.dist[M.count] = delta0;
+        M.len[M.count] = (uint16_t)len; M.dist[M.count] = delta0;
         if (len >= nice) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return; }
       }
     }
@@ -695,7 +695,7 @@ __device__ void lz_read_one(const Enc &E, BT4 &B, Matches &M) {                 
 }
 
 __device__ void lz_supplement(const BT4 &B, Matches &M) {                           // Get_supplemental_Matches_from_Repeat_Matches :1505-1566
-  if (M.count == 0 && B.best_len_rep >= BT_MIN) { M.dist[1] = B.rep_dist[B.best_rep_index]; M.len[1] = B.best_len_rep; M.count = 1; }
+  if (M.count == 0 && B.best_len_rep >= BT_MIN) { M.dist[1] = B.rep_dist[B.best_rep_index]; M.len[1] = (uint16_t)B.best_len_rep; M.count = 1; }
   for (int rep = 0; rep < 4; rep++) {
     const int len = B.len_rep[rep];
     if (len < BT_MIN) continue;
@@ -709,7 +709,7 @@ __device__ void lz_supplement(const BT4 &B, Matches &M) {                       
     }
     if (ins > 0) {
       for (int i = M.count; i >= ins; i--) { M.dist[i + 1] = M.dist[i]; M.len[i + 1] = M.len[i]; }
-      M.dist[ins] = B.rep_dist[rep]; M.len[ins] = len;
+      M.dist[ins] = B.rep_dist[rep]; M.len[ins] = (uint16_t)len;
       M.count++;
       break;
     }
@@ -823,7 +823,7 @@ __device__ void lz_bt4(Enc &E, Matches *MM, int sbs, int32_t *ws, uint32_t hash4
 
 // ---------------------------------------------------------------- one stream per workgroup
 
-__global__ void __launch_bounds__(64) k_lzma_encode(const LzmaJob *jobs, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
+__global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
                                                     int32_t *ws_base, uint64_t *result) {
   __shared__ LzProbs P;
   __shared__ Matches MM[2];
