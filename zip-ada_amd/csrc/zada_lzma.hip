@@ -16,6 +16,7 @@
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/zada.h"
 #include "zada_internal.h"
 
@@ -48,7 +49,17 @@ struct Enc {
   MS ES;
   uint32_t width; uint64_t low; uint32_t cache; uint64_t cache_size;      // Range_Encoder :952-957
   uint8_t *out; uint64_t cap, olen;
+  double *xch;                                 // 64 doubles of LDS: what the lanes hand each other at a fork
 };
+
+#ifdef ZADA_LZ_PROF
+__device__ unsigned long long g_lzprof[8];
+#define PROF_T0 const unsigned long long prof_t0 = clock64()
+#define PROF_ADD(i) g_lzprof[i] += clock64() - prof_t0
+#else
+#define PROF_T0
+#define PROF_ADD(i)
+#endif
 
 __device__ const uint8_t T_LIT[12]  = {0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 4, 5};          // lzma.ads:86-89
 __device__ const uint8_t T_MATCH[12] = {7, 7, 7, 7, 7, 7, 7, 10, 10, 10, 10, 10};
@@ -221,8 +232,14 @@ template <int R> __device__ void sim_any(const Enc &E, uint32_t distance, int le
 
 // The body of Generic_any_DL_Code (:740-832) up to its choice; NEW = new_recursion_limit.  The simulations it asks for nest at
 // most three deep (the limit goes down by one per level, :756-764), so the recursion of the reference unrolls into templates.
-template <int NEW> __device__ __noinline__ int decide(const Enc &E, uint32_t distance, int length, const MS &sim, int &best_cut) {
+//
+// PAR: the call comes from the chain itself, which all 64 lanes walk in step (same data, same branches: the cost of one lane).
+// Where the reference compares INDEPENDENT simulations -- literal + code against code + literal (:783-805), the cuts of
+// Test_Split_DL (:924-943) -- the lanes part: one simulation each, from their own copy of the state, nothing written but the
+// result; the results are then compared by all lanes in the reference's order.  Same doubles, a shorter critical path.
+template <int NEW, bool PAR> __device__ __noinline__ int decide(const Enc &E, uint32_t distance, int length, const MS &sim, int &best_cut) {
   double strict_dlc = 0.0, expanded_dlc = 0.0, soe = 0.0;
+  [[maybe_unused]] const int lane = (int)threadIdx.x;
   if (E.cv >= 1) {
     strict_dlc = test_strict(E, distance, length, sim);
     expanded_dlc = test_expanded(E, distance, length, strict_dlc, sim);
@@ -233,38 +250,78 @@ template <int NEW> __device__ __noinline__ int decide(const Enc &E, uint32_t dis
       if (head_lit >= 0.875) return W_LIT_DL;                                      // Lit_then_DL_threshold :306
       MS after = sim;
       after.state = T_LIT[sim.state]; after.pos = sim.pos + 1; after.pos_state = (uint32_t)after.pos & LZ_PBM; after.prev_byte = b_head;
-      double dal = 1.0;
-      sim_any<NEW>(E, distance, length - 1, after, dal);
-      if (head_lit * dal * fmax0(0.064 - (double)distance * 1.0e-9 - (double)length * 3.0e-5) > soe) return W_LIT_DL;
-      {                                                                            // DL_code_then_Literal :869-889
+      const double malus_dtl = fmax0(0.135 - (double)distance * 1.0e-8 - (double)length * 1.0e-4);     // DL_code_then_Literal :869-889
+      double dal, dtl;
+      if constexpr (PAR) {
+        double r = 0.0;
+        if (lane < 2) {
+          MS v = lane == 0 ? after : sim;
+          double p = lane == 0 ? 1.0 : malus_dtl;
+          sim_any<NEW>(E, distance, length - 1, v, p);
+          if (lane == 1) sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, p);
+          r = p;
+        }
+        E.xch[lane] = r;
+        __syncthreads();
+        dal = E.xch[0]; dtl = E.xch[1];
+        __syncthreads();
+      } else {
+        dal = 1.0;
+        sim_any<NEW>(E, distance, length - 1, after, dal);
         MS v = sim;
-        double p = fmax0(0.135 - (double)distance * 1.0e-8 - (double)length * 1.0e-4);
-        sim_any<NEW>(E, distance, length - 1, v, p);
-        sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, p);
-        if (p > soe) return W_DL_LIT;
+        dtl = malus_dtl;
+        sim_any<NEW>(E, distance, length - 1, v, dtl);
+        sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, dtl);
       }
+      if (head_lit * dal * fmax0(0.064 - (double)distance * 1.0e-9 - (double)length * 3.0e-5) > soe) return W_LIT_DL;
+      if (dtl > soe) return W_DL_LIT;
     }
     if (expanded_dlc > strict_dlc) return W_EXPAND;
   }
   if (E.cv >= 2) {                                                                 // Test_Split_DL :901-944
+    PROF_T0;
     constexpr int LOW = NEW - 1 > 0 ? NEW - 1 : 0;
     const double malus = fmax0(0.27 - (double)distance * 2.0e-6);
     double best_prob = 0.0;
     best_cut = 2;
     if (!(malus < soe)) {
-      for (int cut = 2; cut <= length - 2; cut++) {
-        const int rest = length - cut;
-        if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) {
+      if constexpr (PAR) {
+        int cuts[12], nc = 0;                                                      // cut or length - cut in 4 .. 9 (:899, 925)
+        for (int cut = 2; cut <= length - 2; cut++) {
+          const int rest = length - cut;
+          if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) cuts[nc++] = cut;
+        }
+        double pm = 0.0, pf = 0.0;
+        if (lane < nc) {
+          const int cut = cuts[lane];
           double p = malus;
           MS v = sim;
           sim_any<LOW>(E, distance, cut, v, p);
-          if (!(p <= soe)) {
-            sim_any<LOW>(E, distance, rest, v, p);
-            if (p > best_prob) { best_prob = p; best_cut = cut; }
+          pm = p; pf = p;
+          if (!(p <= soe)) { sim_any<LOW>(E, distance, length - cut, v, p); pf = p; }
+        }
+        E.xch[2 * lane] = pm; E.xch[2 * lane + 1] = pf;
+        __syncthreads();
+        for (int k = 0; k < nc; k++) {
+          if (!(E.xch[2 * k] <= soe)) { const double p = E.xch[2 * k + 1]; if (p > best_prob) { best_prob = p; best_cut = cuts[k]; } }
+        }
+        __syncthreads();
+      } else {
+        for (int cut = 2; cut <= length - 2; cut++) {
+          const int rest = length - cut;
+          if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) {
+            double p = malus;
+            MS v = sim;
+            sim_any<LOW>(E, distance, cut, v, p);
+            if (!(p <= soe)) {
+              sim_any<LOW>(E, distance, rest, v, p);
+              if (p > best_prob) { best_prob = p; best_cut = cut; }
+            }
           }
         }
       }
     }
+    PROF_ADD(6);
     if (best_prob > soe) return W_SPLIT;
   }
   return W_STRICT;
@@ -276,7 +333,7 @@ template <int R> __device__ __noinline__ void sim_any_impl(const Enc &E, uint32_
   } else {
     constexpr int NEW = R - 1;
     int cut = 2;
-    switch (decide<NEW>(E, distance, length, sim, cut)) {
+    switch (decide<NEW, false>(E, distance, length, sim, cut)) {
       case W_LIT_DL:
         sim_literal(E, TB(E, (int64_t)sim.pos - (int64_t)distance), sim, prob);
         sim_any<NEW>(E, distance, length - 1, sim, prob);
@@ -336,6 +393,7 @@ __device__ void bit_tree_rev_encode(Enc &E, uint16_t *prob, int num_bits, uint32
 // ---------------------------------------------------------------- the machine :1045-1361
 
 __device__ __noinline__ void emit_literal(Enc &E, uint32_t b) {                   // LZ77_emits_literal_byte :1097-1130
+  PROF_T0;
   LzProbs &P = *E.P;
   MS &S = E.ES;
   const int idx = lit_idx(S.prev_byte);
@@ -367,6 +425,7 @@ __device__ __noinline__ void emit_literal(Enc &E, uint32_t b) {                 
   S.pos += 1;
   S.pos_state = (uint32_t)S.pos & LZ_PBM;
   S.prev_byte = b;
+  PROF_ADD(1);
 }
 
 __device__ void encode_length(Enc &E, LenProbs &pl, uint32_t length) {            // :1160-1181
@@ -441,6 +500,7 @@ __device__ __noinline__ void write_strict(Enc &E, uint32_t distance, int length)
 // lower its limit (:756-760), so its own recursion can go a match length deep; it is a work list here.  An item is a length
 // still to be written at `distance`, or the literal that follows a shortened match (:797-805).
 __device__ __noinline__ void emit_dl(Enc &E, uint32_t distance, int length0) {
+  PROF_T0;
   constexpr uint16_t POST_LIT = 0xFFFF;
   uint16_t stack[2 * 280];
   int sp = 0;
@@ -450,7 +510,7 @@ __device__ __noinline__ void emit_dl(Enc &E, uint32_t distance, int length0) {
     if (it == POST_LIT) { emit_literal(E, TB(E, (int64_t)E.ES.pos - (int64_t)distance)); continue; }
     const int length = it;
     int cut = 2;
-    switch (decide<2>(E, distance, length, E.ES, cut)) {
+    switch (decide<2, true>(E, distance, length, E.ES, cut)) {
       case W_LIT_DL:
         emit_literal(E, TB(E, (int64_t)E.ES.pos - (int64_t)distance));
         stack[sp++] = (uint16_t)(length - 1);
@@ -470,13 +530,37 @@ __device__ __noinline__ void emit_dl(Enc &E, uint32_t distance, int length0) {
         write_strict(E, distance, length);
     }
   }
+  PROF_ADD(2);
 }
 
 // ---------------------------------------------------------------- Estimate_DL_Codes_for_LZ77 :1363-1498
 
 struct ScoreCtx { const Matches *m; int old_index, last_pos_any; MS sim_new; double head_lit_prob; };
 
-template <int LEVEL> __device__ __noinline__ void scoring(const Enc &E, const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {   // :1385-1469
+// One candidate of Scoring (:1404-1468): the probability of the message that starts with match i of set m.
+template <int LEVEL> __device__ void scoring(const Enc &E, const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set);
+template <int LEVEL> __device__ inline double score_candidate(const Enc &E, const ScoreCtx &S, const MS &state, int start, int m, int i) {
+  const Matches &M = S.m[m];
+  const int last_pos_i = M.len[i] + (m != S.old_index ? 1 : 0);
+  MS t; double p;
+  if (m != S.old_index && start == 1) { t = S.sim_new; p = S.head_lit_prob; } else { t = state; p = 1.0; }
+  int trunc;
+  if (m == S.old_index) trunc = M.len[i] - start + 1;
+  else if (start == 1) trunc = M.len[i];
+  else trunc = M.len[i] - start + 2;
+  if (trunc == 1) sim_literal(E, TB(E, (int64_t)state.pos), t, p);
+  else sim_any<1>(E, (uint32_t)M.dist[i], trunc, t, p);
+  if constexpr (LEVEL < 2) {
+    if (last_pos_i < S.last_pos_any) {
+      double tail; int si = 1, sm = 0;
+      scoring<LEVEL + 1>(E, S, t, last_pos_i + 1, tail, si, sm);
+      p = p * tail;
+    }
+  }
+  return p;
+}
+
+template <int LEVEL> __device__ __noinline__ void scoring_impl(const Enc &E, const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {   // :1385-1469
   prob = 0.0;
   for (int m = 0; m <= 1; m++) {
     const Matches &M = S.m[m];
@@ -484,27 +568,38 @@ template <int LEVEL> __device__ __noinline__ void scoring(const Enc &E, const Sc
       const int last_pos_i = M.len[i] + (m != S.old_index ? 1 : 0);
       if (last_pos_i < start) continue;
       if (last_pos_i < S.last_pos_any && LEVEL >= 2) continue;
-      MS t; double p;
-      if (m != S.old_index && start == 1) { t = S.sim_new; p = S.head_lit_prob; } else { t = state; p = 1.0; }
-      int trunc;
-      if (m == S.old_index) trunc = M.len[i] - start + 1;
-      else if (start == 1) trunc = M.len[i];
-      else trunc = M.len[i] - start + 2;
-      if (trunc == 1) sim_literal(E, TB(E, (int64_t)state.pos), t, p);
-      else sim_any<1>(E, (uint32_t)M.dist[i], trunc, t, p);
-      if constexpr (LEVEL < 2) {
-        if (last_pos_i < S.last_pos_any) {
-          double tail; int si = 1, sm = 0;
-          scoring<LEVEL + 1>(E, S, t, last_pos_i + 1, tail, si, sm);
-          p = p * tail;
-        }
-      }
+      const double p = score_candidate<LEVEL>(E, S, state, start, m, i);
       if (p > prob) { prob = p; index = i; match_set = m; }
     }
   }
 }
+template <int LEVEL> __device__ void scoring(const Enc &E, const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {
+  scoring_impl<LEVEL>(E, S, state, start, prob, index, match_set);
+}
+
+// Scoring at level 1, start 1, called from the chain (all lanes in step): every match of both sets is a candidate (their
+// last positions are >= 1), one lane each; the best is then picked by all lanes in the reference's order (first strict maximum).
+__device__ __noinline__ void scoring_top(const Enc &E, const ScoreCtx &S, const MS &state, double &prob, int &index, int &match_set) {
+  const int lane = (int)threadIdx.x, c0 = S.m[0].count, total = c0 + S.m[1].count;
+  prob = 0.0;
+  for (int base = 0; base < total; base += 64) {
+    const int k = base + lane;
+    double p = 0.0;
+    if (k < total) p = score_candidate<1>(E, S, state, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
+    E.xch[lane] = p;
+    __syncthreads();
+    const int cnt = total - base < 64 ? total - base : 64;
+    for (int j = 0; j < cnt; j++) {
+      const double pj = E.xch[j];
+      const int kk = base + j;
+      if (pj > prob) { prob = pj; index = (kk < c0 ? kk : kk - c0) + 1; match_set = kk < c0 ? 0 : 1; }
+    }
+    __syncthreads();
+  }
+}
 
 __device__ void estimate_dl_codes(const Enc &E, const Matches *matches, int old_index, uint32_t prefix1, int &best_index, int &best_set) {
+  PROF_T0;
   ScoreCtx S;
   S.m = matches; S.old_index = old_index; S.last_pos_any = 0; S.sim_new = E.ES;
   for (int m = 0; m <= 1; m++)
@@ -517,7 +612,8 @@ __device__ void estimate_dl_codes(const Enc &E, const Matches *matches, int old_
   best_index = 1; best_set = old_index;
   double best;
   const MS sim_old = E.ES;
-  scoring<1>(E, S, sim_old, 1, best, best_index, best_set);
+  scoring_top(E, S, sim_old, best, best_index, best_set);
+  PROF_ADD(3);
 }
 
 // ---------------------------------------------------------------- LZ77_using_BT4 (lz77.adb:953-1827)
@@ -679,6 +775,7 @@ __device__ inline int bt_match_len(const Enc &E, const BT4 &B, int distance, int
 __device__ inline bool much_smaller(int smallDist, int bigDist) { return (smallDist - 1) < (bigDist - 1) / 128; }   // :1469-1473
 
 __device__ void lz_read_one(const Enc &E, BT4 &B, Matches &M) {                     // Read_One_and_Get_Matches :1477-1503
+  PROF_T0;
   B.readAhead++;
   bt_get_matches(E, B, M);
   B.best_len_rep = 0;
@@ -692,6 +789,7 @@ __device__ void lz_read_one(const Enc &E, BT4 &B, Matches &M) {                 
   } else {
     for (int rep = 0; rep < 4; rep++) B.len_rep[rep] = 0;
   }
+  PROF_ADD(4);
 }
 
 __device__ void lz_supplement(const BT4 &B, Matches &M) {                           // Get_supplemental_Matches_from_Repeat_Matches :1505-1566
@@ -734,7 +832,7 @@ __device__ void lz_send_dl(Enc &E, BT4 &B, int distance, int length) {          
   }
 }
 __device__ inline void lz_send_literal(Enc &E, BT4 &B) { emit_literal(E, B.cur_literal); B.readAhead--; }
-__device__ inline void lz_skip(const Enc &E, BT4 &B, int len) { B.readAhead += len; bt_skip(E, B, len); }
+__device__ inline void lz_skip(const Enc &E, BT4 &B, int len) { PROF_T0; B.readAhead += len; bt_skip(E, B, len); PROF_ADD(5); }
 
 __device__ __noinline__ void lz_next_symbol(Enc &E, BT4 &B, Matches *MM) {           // Get_Next_Symbol :1605-1796
   constexpr int hurdle = 40;
@@ -827,13 +925,17 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
                                                     int32_t *ws_base, uint64_t *result) {
   __shared__ LzProbs P;
   __shared__ Matches MM[2];
+  __shared__ double xch[128];
   const LzmaJob J = jobs[blockIdx.x];
   {
     uint16_t *p = (uint16_t *)&P;
     for (uint32_t i = threadIdx.x; i < sizeof(LzProbs) / 2; i += 64) p[i] = 1024;    // initial_probability
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+#ifdef ZADA_LZ_PROF
+  const unsigned long long prof_k0 = clock64();
+  for (int i = 0; i < 8; i++) g_lzprof[i] = 0;
+#endif
   Enc E;
   E.P = &P; E.in = in_base + J.in_off; E.n = J.n;
   E.cv = J.level <= 1 ? 0 : J.level == 2 ? 1 : 2;
@@ -841,6 +943,7 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   E.ES.rep[0] = E.ES.rep[1] = E.ES.rep[2] = E.ES.rep[3] = 0;
   E.width = 0xFFFFFFFFu; E.low = 0; E.cache = 0; E.cache_size = 1;
   E.out = out_base + J.out_off; E.cap = J.cap; E.olen = 0;
+  E.xch = xch;
   if (J.zip_prefix) { put_byte(E, 16); put_byte(E, 2); put_byte(E, 5); put_byte(E, 0); }   // zip-compress-lzma_e.adb:155-158
   put_byte(E, 3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
   for (int i = 0; i < 4; i++) put_byte(E, (J.sbs >> (8 * i)) & 255);
@@ -858,6 +961,9 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   encode_bit(E, P.match[E.ES.state][E.ES.pos_state], 1);                             // end marker :1549-1556
   write_simple_match(E, 0xFFFFFFFFu, 2);
   for (int i = 0; i < 5; i++) shift_low(E);                                          // Flush_range_encoder
+#ifdef ZADA_LZ_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) printf("LZPROF total %llu literal %llu emit_dl %llu estimate %llu bt_get %llu bt_skip %llu split(all levels) %llu\n", clock64() - prof_k0, g_lzprof[1], g_lzprof[2], g_lzprof[3], g_lzprof[4], g_lzprof[5], g_lzprof[6]);
+#endif
   result[2 * blockIdx.x] = E.olen;
   result[2 * blockIdx.x + 1] = E.ES.pos;
 }
