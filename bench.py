@@ -341,7 +341,7 @@ def main():
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--method", choices=("deflate", "bzip2"), default="deflate", help="bzip2: BASELINE config 5 -- ONE BZip2_3 stream of N x --mib (default 1024) MiB over N GPUs")
     ap.add_argument("--bzip2-mib", type=int, default=256, help="input MiB of the secondary BZip2_3 measurement at one GPU (0 = skip)")
-    ap.add_argument("--lzma-entries", type=int, default=1024, help="entries of the secondary LZMA_3 batch measurement at one GPU (0 = skip)")
+    ap.add_argument("--lzma-entries", type=int, default=4096, help="entries of the secondary LZMA_3 batch measurement at one GPU (0 = skip)")
     ap.add_argument("--lzma-kib", type=int, default=16, help="KiB per entry of the LZMA_3 batch")
     args = ap.parse_args()
 

@@ -1144,11 +1144,11 @@ static int lz_grow(Ctx *c, void **p, size_t *cap, size_t bytes) {
 static void lzma_free(Ctx *c) {
   if (c->lz_tab) hipFree(c->lz_tab);
   if (c->lz_ws) hipFree(c->lz_ws);
-  if (c->lz_tok) hipFree(c->lz_tok);
-  c->lz_tab = c->lz_ws = c->lz_tok = nullptr; c->cap_lz_tab = c->cap_lz_ws = c->cap_lz_tok = 0;
+  c->lz_tab = c->lz_ws = nullptr; c->cap_lz_tab = c->cap_lz_ws = 0;
 }
 // jobs: ws_off / sbs / hash4_size are filled here.  res: 2 per job (stream bytes, input bytes coded).
-static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, std::vector<uint64_t> &res) {
+static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, std::vector<uint64_t> &res,
+                    const uint32_t *d_apos = nullptr, uint32_t T = 0, const uint32_t *d_ent_start = nullptr) {
   const uint32_t E = (uint32_t)jobs.size();
   uint64_t ws_ints = 0;
   for (LzmaJob &j : jobs) {
@@ -1164,6 +1164,7 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, con
   uint64_t *d_res = (uint64_t *)((uint8_t *)c->lz_tab + ((sizeof(LzmaJob) * (size_t)E + 63) & ~63ull));
   hipMemcpyAsync(d_jobs, jobs.data(), sizeof(LzmaJob) * (size_t)E, hipMemcpyHostToDevice, c->stream);
   if (ws_ints) hipMemsetAsync(c->lz_ws, 0, ws_ints * 4, c->stream);
+  if (d_apos && (rc = lzma_token_ranges(c, E, d_apos, T, d_ent_start, d_jobs))) return rc;   // token ranges of a batch, found on the device
   if ((rc = lzma_launch(c, d_jobs, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res))) return rc;
   res.resize(2 * (size_t)E);
   hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
@@ -1237,7 +1238,7 @@ int zada_lzma(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *o
   return rc;
 }
 // Many entries in one call: every entry is a stream of ONE launch of k_lzma_encode -- the only parallelism LZMA's chain of
-// adaptive probabilities leaves (see zada_lzma.hip).  Level_1 / Level_2: the LZ stage runs entry after entry before it.
+// adaptive probabilities leaves (see zada_lzma.hip).  This one: Level_0 and Level_3 (no tokens from the LZ stage).
 static int lzma_batch_core(Ctx *c, int method, const int *idx, uint32_t E, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out, const uint64_t *cap,
                            uint64_t *out_len, uint32_t *crc, int *rc_out) {
   hipStream_t st = c->stream;
@@ -1252,7 +1253,6 @@ static int lzma_batch_core(Ctx *c, int method, const int *idx, uint32_t E, const
   if (total >= (1ull << 32)) return ZADA_E_TOO_LARGE;
   int rc = ensure_rin(c, total + ototal + 64 + 16ull * (E + 1));
   if (!rc) rc = grow_pinned((void **)&c->bstage, &c->cap_bstage, (total > ototal ? total : ototal) + 64);
-  if (!rc && (level == 1 || level == 2)) rc = lz_grow(c, &c->lz_tok, &c->cap_lz_tok, 4 * total + 64);
   if (rc) return rc;
   parallel_entries(E, total, [&](uint32_t e) { if (len[e]) memcpy(c->bstage + start[e], in[idx[e]], len[e]); });
   c->tbegin(); c->tmark("lzma:begin");
@@ -1266,21 +1266,95 @@ static int lzma_batch_core(Ctx *c, int method, const int *idx, uint32_t E, const
   hipMemcpyAsync(crc_in.data(), d_tab + 2 * E, 4ull * E, hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "LZMA batch in")) return ZADA_E_HIP;
   std::vector<LzmaJob> jobs(E);
-  uint64_t tok = 0;
   for (uint32_t e = 0; e < E; e++) {
     LzmaJob &J = jobs[e];
     memset(&J, 0, sizeof J);
     J.in_off = start[e]; J.n = len[e]; J.out_off = ostart[e]; J.cap = (len[e] + len[e] / 8 + 128ull); J.level = level; J.zip_prefix = 1;
-    if ((level == 1 || level == 2) && len[e]) {
-      if ((rc = lzma_tokens(c, level, d_arena + start[e], len[e], &J.ntok))) return rc;
-      J.tok_off = tok;
-      hipMemcpyAsync((uint32_t *)c->lz_tok + tok, c->ws.ea_atoms + LB_CAP, 4 * J.ntok, hipMemcpyDeviceToDevice, st);
-      tok += J.ntok;
-    }
   }
   c->tmark("lzma:tokens");
   std::vector<uint64_t> res;
-  if ((rc = lzma_run(c, jobs, d_arena, (const uint32_t *)c->lz_tok, d_out, res))) return rc;
+  if ((rc = lzma_run(c, jobs, d_arena, nullptr, d_out, res))) return rc;
+  hipMemcpyAsync(c->bstage, d_out, ototal, hipMemcpyDeviceToHost, st);
+  if (hip_check(c, hipStreamSynchronize(st), "LZMA batch out")) return ZADA_E_HIP;
+  c->tmark("lzma:end"); c->tend();
+  std::atomic<int> bad(0);
+  parallel_entries(E, ototal, [&](uint32_t e) {
+    const int i = idx[e];
+    const uint64_t bytes = res[2 * e];
+    out_len[i] = bytes;
+    if (crc) crc[i] = crc_in[e];
+    rc_out[i] = bytes >= n[i] ? ZADA_INEFFICIENT : ZADA_OK;
+    if (bytes <= cap[i] && bytes <= jobs[e].cap) memcpy(out[i], c->bstage + ostart[e], bytes);
+    else if (rc_out[i] == ZADA_OK) { rc_out[i] = ZADA_E_INVALID; bad = 1; }
+  });
+  if (bad) c->err = "output buffer too small";
+  return 0;
+}
+// Level_1 / Level_2 batches: the tokens of ALL entries from one pass of the LZ stage (the batch layout of batch_core above:
+// 32 KiB slots, the segment table that ends every entry's searches at its own end), then one launch of the coder.
+static int lzma_batch_iz(Ctx *c, int method, const int *idx, uint32_t E, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out, const uint64_t *cap,
+                         uint64_t *out_len, uint32_t *crc, int *rc_out) {
+  const int level = method - ZADA_LZMA_0, iz_level = level == 1 ? 6 : 10;
+  Workspace &W = c->ws;
+  hipStream_t st = c->stream;
+  std::vector<uint32_t> start(E + 1), len(E + 1), crc_in(E + 1);
+  std::vector<uint64_t> ostart(E);
+  uint64_t total = 0, nfs = 0, ototal = 0;
+  for (uint32_t e = 0; e < E; e++) {
+    const uint64_t ln = n[idx[e]], slot = ((ln ? ln : 1) + 32767) & ~32767ull;
+    start[e] = (uint32_t)total; len[e] = (uint32_t)ln; crc_in[e] = crc ? crc[idx[e]] : 0xFFFFFFFFu;
+    total += slot; nfs += ln ? (ln + FLUSH - 1) / FLUSH : 1;
+    ostart[e] = ototal; ototal += (ln + ln / 8 + 128 + 63) & ~63ull;
+  }
+  start[E] = (uint32_t)total; len[E] = 0;
+  if (total >= (1ull << 31)) return ZADA_E_TOO_LARGE;
+  const uint32_t nseg = (uint32_t)(total >> 15);
+  int rc = ensure_lz_workspace(c, total + 4096);
+  if (!rc) rc = ensure_entropy_workspace(c, total, nfs);
+  if (!rc) rc = ensure_batch_workspace(c, E, nfs, nseg);
+  if (!rc) rc = ensure_rin(c, ototal + 64);
+  if (!rc) rc = grow_pinned((void **)&c->bstage, &c->cap_bstage, (total > ototal ? total : ototal) + 64);
+  const uint64_t tabw = (uint64_t)nseg + 3ull * (E + 1) + 64;
+  uint64_t capw = c->cap_btab * 4;
+  if (!rc) { rc = grow_pinned((void **)&c->btab, &capw, tabw * 4); c->cap_btab = capw / 4; }
+  if (rc) return rc;
+  uint32_t *t_seg = c->btab, *t_ent = c->btab + nseg;
+  parallel_entries(E, total, [&](uint32_t e) {
+    if (len[e]) memcpy(c->bstage + start[e], in[idx[e]], len[e]);
+    for (uint32_t s = start[e] >> 15; s < (start[e + 1] >> 15); s++) t_seg[s] = (start[e] + len[e]) | (s == (start[e] >> 15) ? 0x80000000u : 0u);
+  });
+  memcpy(t_ent, start.data(), (E + 1) * 4); memcpy(t_ent + (E + 1), len.data(), (E + 1) * 4); memcpy(t_ent + 2 * (E + 1), crc_in.data(), (E + 1) * 4);
+  c->tbegin(); c->tmark("lzma:begin");
+  hipMemcpyAsync(W.in, c->bstage, total, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.segend, t_seg, (size_t)nseg * 4, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.ent_start, t_ent, (size_t)(E + 1) * 4, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.ent_len, t_ent + (E + 1), (size_t)(E + 1) * 4, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(W.ent_crc, t_ent + 2 * (E + 1), (size_t)(E + 1) * 4, hipMemcpyHostToDevice, st);
+  {
+    PadArgs pa; pa.in_end = W.in + total; pa.n_in = IN_PAD;
+    for (int l = 0; l < NLEVELS; l++) pa.link_end[l] = W.lprev[l] + (total >= 2 ? total - 2 : 0);
+    hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);
+  }
+  c->rg = Range();
+  c->last_nblocks = 0; c->demand_rounds = 0; c->parse_rounds = 0;
+  hipLaunchKernelGGL(k_batch_crc, dim3(E), dim3(64), 0, st, E, W.in, W.ent_start, W.ent_len, W.ent_crc);
+  ShardJob job;
+  job.nbuf = total; job.tok_lo = 0; job.tok_hi = (uint32_t)total; job.final = true; job.entry_known = true; job.entry = ExitState{0, SYNC_F};
+  job.dst_atoms = W.ea_atoms + LB_CAP; job.dst_apos = W.ea_apos + LB_CAP; job.apos_bias = 0; job.cap_atoms = W.cap_atoms; job.segend = W.segend;
+  ShardResult sres;
+  rc = lz_shard(c, iz_level, job, &sres);
+  if (rc) return rc == -2 ? ZADA_E_NOMEM : rc;
+  c->tmark("lzma:tokens");
+  std::vector<LzmaJob> jobs(E);
+  for (uint32_t e = 0; e < E; e++) {
+    LzmaJob &J = jobs[e];
+    memset(&J, 0, sizeof J);
+    J.in_off = start[e]; J.n = len[e]; J.out_off = ostart[e]; J.cap = len[e] + len[e] / 8 + 128ull; J.level = level; J.zip_prefix = 1;
+  }
+  std::vector<uint64_t> res;
+  uint8_t *d_out = c->ws.rin_own;
+  if ((rc = lzma_run(c, jobs, W.in, W.ea_atoms + LB_CAP, d_out, res, W.ea_apos + LB_CAP, sres.ntok, W.ent_start))) return rc;
+  hipMemcpyAsync(crc_in.data(), W.ent_crc, 4ull * E, hipMemcpyDeviceToHost, st);
   hipMemcpyAsync(c->bstage, d_out, ototal, hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "LZMA batch out")) return ZADA_E_HIP;
   c->tmark("lzma:end"); c->tend();
@@ -1308,7 +1382,9 @@ int zada_lzma_batch(zada_ctx *z, int method, int count, const uint8_t *const *in
   uint64_t gbytes = 0;
   auto flush_group = [&]() {
     if (group.empty()) return;
-    int r = finish_call(c, lzma_batch_core(c, method, group.data(), (uint32_t)group.size(), in, n, out, cap, out_len, crc, rc));
+    const bool iz = method == ZADA_LZMA_1 || method == ZADA_LZMA_2;
+    int r = finish_call(c, iz ? lzma_batch_iz(c, method, group.data(), (uint32_t)group.size(), in, n, out, cap, out_len, crc, rc)
+                              : lzma_batch_core(c, method, group.data(), (uint32_t)group.size(), in, n, out, cap, out_len, crc, rc));
     if (r < 0) { for (int i : group) rc[i] = r; worst = r; }
     else { for (int i : group) if (rc[i] < 0) worst = rc[i]; }
     group.clear(); gbytes = 0;
@@ -1316,7 +1392,7 @@ int zada_lzma_batch(zada_ctx *z, int method, int count, const uint8_t *const *in
   for (int i = 0; i < count; i++) {
     if (n[i] >= (2ull << 30) - 65536) { rc[i] = ZADA_E_TOO_LARGE; worst = rc[i]; continue; }
     const uint64_t slot = ((n[i] ? n[i] : 1) + 65535) & ~65535ull;
-    if (gbytes + slot > (2ull << 30)) flush_group();
+    if (gbytes + slot > (1ull << 30)) flush_group();
     group.push_back(i); gbytes += slot;
   }
   flush_group();

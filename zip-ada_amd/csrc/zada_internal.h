@@ -245,7 +245,6 @@ struct Ctx {
   void *bz = nullptr;                                // BZip2 state (zada_bz2.hip), made on first use
   void *lz_tab = nullptr; size_t cap_lz_tab = 0;     // LZMA (zada_lzma.hip): job table + results
   void *lz_ws = nullptr; size_t cap_lz_ws = 0;       // ... the BT4 matcher's hash tables and trees (Level_3)
-  void *lz_tok = nullptr; size_t cap_lz_tok = 0;     // ... a batch's LZ77 tokens (Level_1 / Level_2)
   // timing
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<const char *, hipEvent_t>> marks;
@@ -293,6 +292,7 @@ struct LzmaJob {
 uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size);
 uint32_t lzma_hash4_size(uint32_t sbs);
 uint64_t lzma_workspace_ints(int level, uint32_t sbs);
+int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, const uint32_t *d_ent_start, LzmaJob *d_jobs);
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);

@@ -84,17 +84,22 @@ __device__ inline double tbe(uint16_t p, uint32_t sym) {                        
 __device__ double test_simple_literal(const Enc &E, uint32_t b, uint32_t b_match, const uint16_t *prob, const MS &sim) {   // :372-419
   double pl = tbe(E.P->match[sim.state][sim.pos_state], 0);
   uint32_t symb = b | 0x100;
+  uint16_t pr[8];                                 // the eight probabilities first (their addresses do not depend on each other), then the products in order
   if (sim.state < 7) {
-    do { pl = pl * tbe(prob[symb >> 8], (symb >> 7) & 1); symb <<= 1; } while (symb < 0x10000);
+#pragma unroll
+    for (int k = 0; k < 8; k++) pr[k] = prob[(symb << k) >> 8];
   } else {
-    uint32_t offs = 0x100, match = b_match;
-    do {
+    uint32_t offs = 0x100, match = b_match, sy = symb;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
       match <<= 1;
-      pl = pl * tbe(prob[offs + (match & offs) + (symb >> 8)], (symb >> 7) & 1);
-      symb <<= 1;
-      offs &= ~(match ^ symb);
-    } while (symb < 0x10000);
+      pr[k] = prob[offs + (match & offs) + (sy >> 8)];
+      sy <<= 1;
+      offs &= ~(match ^ sy);
+    }
   }
+#pragma unroll
+  for (int k = 0; k < 8; k++) pl = pl * tbe(pr[k], (symb >> (7 - k)) & 1);
   return pl;
 }
 
@@ -127,9 +132,14 @@ __device__ inline double test_literal_byte(const Enc &E, uint32_t b, const MS &s
   return prob;
 }
 
-__device__ inline double sim_bit_tree(const uint16_t *prob, int num_bits, uint32_t symbol) {   // :470-481
-  double res = 1.0; uint32_t m = 1;
-  for (int i = num_bits - 1; i >= 0; i--) { const uint32_t bit = (symbol >> i) & 1; res = res * tbe(prob[m], bit); m = 2 * m + bit; }
+template <int NB> __device__ inline double sim_bit_tree(const uint16_t *prob, uint32_t symbol) {   // Simulate_Bit_Tree :470-481
+  uint16_t pr[NB];
+  uint32_t m = 1;
+#pragma unroll
+  for (int k = 0; k < NB; k++) { pr[k] = prob[m]; m = 2 * m + ((symbol >> (NB - 1 - k)) & 1); }
+  double res = 1.0;
+#pragma unroll
+  for (int k = 0; k < NB; k++) res = res * tbe(pr[k], (symbol >> (NB - 1 - k)) & 1);
   return res;
 }
 __device__ inline double sim_bit_tree_rev(const uint16_t *prob, int num_bits, uint32_t symbol) {   // :548-563
@@ -140,11 +150,11 @@ __device__ inline double sim_bit_tree_rev(const uint16_t *prob, int num_bits, ui
 
 __device__ double test_length(const LenProbs &pl, uint32_t length, uint32_t ps) {              // :483-509
   uint32_t len = length - 2; double res;
-  if (len < 8) res = tbe(pl.c1, 0) * sim_bit_tree(pl.low[ps], 3, len);
+  if (len < 8) res = tbe(pl.c1, 0) * sim_bit_tree<3>(pl.low[ps], len);
   else {
     res = tbe(pl.c1, 1); len -= 8;
-    if (len < 8) res = res * tbe(pl.c2, 0) * sim_bit_tree(pl.mid[ps], 3, len);
-    else { res = res * tbe(pl.c2, 1); len -= 8; res = res * sim_bit_tree(pl.high, 8, len); }
+    if (len < 8) res = res * tbe(pl.c2, 0) * sim_bit_tree<3>(pl.mid[ps], len);
+    else { res = res * tbe(pl.c2, 1); len -= 8; res = res * sim_bit_tree<8>(pl.high, len); }
   }
   return res;
 }
@@ -164,7 +174,7 @@ __device__ double test_repeat_match(const Enc &E, int index_rm, uint32_t length,
 __device__ double test_simple_match(const Enc &E, uint32_t distance, uint32_t length, const MS &sim) {   // :540-601
   const LzProbs &P = *E.P;
   const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(distance);
-  double td = sim_bit_tree(P.slot[len_state], 6, ds);
+  double td = sim_bit_tree<6>(P.slot[len_state], ds);
   if (ds >= 4) {
     const int footer = (int)(ds >> 1) - 1;
     const uint32_t base = (2 | (ds & 1)) << footer, red = distance - base;
@@ -990,6 +1000,29 @@ uint32_t lzma_hash4_size(uint32_t sbs) {
   return h + 1;
 }
 uint64_t lzma_workspace_ints(int level, uint32_t sbs) { return level == 3 ? 1024ull + 65536 + lzma_hash4_size(sbs) + 2ull * sbs : 0; }
+
+// A batch whose tokens came from ONE pass of the LZ stage over all entries (zada_api.hip, lzma_batch_iz): entry e's tokens are
+// those whose positions lie in its slot [ent_start[e], ent_start[e + 1]) of the packed buffer.
+namespace {
+__global__ void __launch_bounds__(256) k_lzma_token_ranges(uint32_t E, const uint32_t *__restrict__ apos, uint32_t T, const uint32_t *__restrict__ ent_start, LzmaJob *jobs) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  uint32_t bound[2];
+  for (int k = 0; k < 2; k++) {
+    const uint32_t key = ent_start[e + k];
+    uint32_t lo = 0, hi = T;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (apos[mid] < key) lo = mid + 1; else hi = mid; }
+    bound[k] = lo;
+  }
+  jobs[e].tok_off = bound[0];
+  jobs[e].ntok = bound[1] - bound[0];
+}
+}  // namespace
+int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, const uint32_t *d_ent_start, LzmaJob *d_jobs) {
+  if (E == 0) return 0;
+  hipLaunchKernelGGL(k_lzma_token_ranges, dim3((E + 255) / 256), dim3(256), 0, c->stream, E, d_apos, T, d_ent_start, d_jobs);
+  return hip_check(c, hipGetLastError(), "k_lzma_token_ranges") ? ZADA_E_HIP : 0;
+}
 
 // jobs[0 .. count): device array; results: 2 x count uint64 (stream bytes, input bytes coded).  Level_3 hash tables must be zero.
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result) {
