@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from _common import GOLDEN, product, oracle_zip
-from _lzmah import lz_inputs, oracle_lzma, lzma_decode, LZMA_METHODS
+from _lzmah import lz_inputs, oracle_lzma, oracle_lzma_encode, lzma_decode, LZMA_METHODS
 
 pytestmark = pytest.mark.gpu
 
@@ -112,3 +112,19 @@ def test_batch_of_many_small_entries(encoder):
             assert res[i] == oracle_lzma(datas[i], method), (i, method)
         for d, (rc, z, crc) in zip(datas, res):
             assert lzma_decode(z, 4) == d and crc ^ 0xFFFFFFFF == zlib.crc32(d)
+
+
+def test_dictionary_smaller_than_the_entry(encoder):
+    """Entries beyond 256 MiB get a dictionary smaller than themselves (lzma-encoding.adb:137-149): BT4's window then moves
+    (lz77.adb:1375-1386), its cyclic tree wraps and pending positions are caught up after every fill (:1397-1406).  Exercised at a
+    small scale through the reference's own dictionary_size parameter (knob "lzma_dict"): payload == the oracle's for the same value."""
+    m = lz_inputs()["mix_256k"]
+    try:
+        for ds, d in ((20000, m + m[:150000]), (10000, m + m[:47856])):     # 32 KiB / 16 KiB dictionaries: the window moves at 315 / 291 KB
+            encoder.set_knob("lzma_dict", ds)
+            rc, z, crc = encoder.lzma(d, 18)
+            want, _ = oracle_lzma_encode(d, 3, dictionary_size=ds)
+            assert z == bytes([16, 2, 5, 0]) + want, ds
+            assert lzma_decode(z, 4) == d
+    finally:
+        encoder.set_knob("lzma_dict", 0)

@@ -156,7 +156,8 @@ class Encoder:
             pass
 
     def set_knob(self, name, value):
-        """Tuning / test knobs ("budget", "max_demand_rounds", "inner_budget", "shard_kib", "span_mib", "batch_mib"); none changes a byte of output."""
+        """Tuning / test knobs ("budget", "max_demand_rounds", "inner_budget", "shard_kib", "span_mib", "batch_mib"); none changes a byte of output.
+        "lzma_dict" is the reference's dictionary_size parameter for LZMA_3 (0 = the entry's size, what Zip.Compress.LZMA_E passes)."""
         if self.lib.zada_set_knob(self.ctx, name.encode(), int(value)) != 0:
             raise ZadaError("unknown knob %r" % name)
 

@@ -880,6 +880,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
+  else if (!strcmp(name, "lzma_dict")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_lzma_dict = value; }
   else return ZADA_E_INVALID;
   return ZADA_OK;
 }
@@ -1152,7 +1153,7 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, con
   const uint32_t E = (uint32_t)jobs.size();
   uint64_t ws_ints = 0;
   for (LzmaJob &j : jobs) {
-    j.sbs = lzma_string_buffer_size(j.level, j.n);                 // dictionary_size = the entry's size, zip-compress-lzma_e.adb:165
+    j.sbs = lzma_string_buffer_size(j.level, c->knob_lzma_dict > 0 ? (uint64_t)c->knob_lzma_dict : j.n);   // dictionary_size = the entry's size, zip-compress-lzma_e.adb:165
     j.hash4_size = j.level == 3 ? lzma_hash4_size(j.sbs) : 0;
     j.ws_off = ws_ints;
     ws_ints += (lzma_workspace_ints(j.level, j.sbs) + 15) & ~15ull;

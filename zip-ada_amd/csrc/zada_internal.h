@@ -262,6 +262,8 @@ struct Ctx {
   int knob_bz_batch_mib = 256;      // BZip2: MiB of small entries zada_bzip2_batch takes through one launch sequence
   int knob_bz_span_mib = 1024;      // BZip2: MiB of the stream whose block limits are found at a time
   int knob_bz_batch_melems = 640;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
+  int knob_lzma_dict = 0;           // LZMA_3: dictionary_size in bytes instead of the entry's size (0 = the entry's size, as Zip.Compress.LZMA_E asks;
+                                    // lzma_enc.adb's default is 32 KiB) -- this one DOES change the output: it is the reference's parameter
   int knob_shard_kib = 1 << 20;     // ZADA_SHARD_KIB: bytes of a range the LZ stage takes at a time, in KiB (multiple of 64)
   void tmark(const char *name);
   void tbegin();
