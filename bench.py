@@ -233,7 +233,7 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks):
     rc1, z1, _ = enc.lzma(one, 18)
     d1 = time.perf_counter() - t1
     out["one_stream"] = {"value": round(len(one) / d1 / 1e6, 4), "unit": "MB/s", "bytes": len(one),
-                         "note": "config 4 is ONE 1 GiB stream: it runs at this rate (lane 0 of one workgroup walks the chain of adaptive probabilities)"}
+                         "note": "config 4 is ONE 1 GiB stream: it runs at this rate (one wave walks the chain of adaptive probabilities; the independent simulations of a step run one per lane)"}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _lzmah import oracle_lzma
