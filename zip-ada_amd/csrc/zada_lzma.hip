@@ -42,14 +42,18 @@ struct MS {                                    // Machine_State :212-219 without
   uint64_t pos;
 };
 
+// The entry's probability model, the two match sets of BT4's look-ahead and what the lanes hand each other at a fork: file-scope LDS
+// objects, so that every access is a ds_ instruction (through a pointer in a struct they were flat loads: 36 M of them per 64 KiB).
+__shared__ LzProbs s_P;
+__shared__ Matches s_MM[2];
+__shared__ double s_xch[128];
+
 struct Enc {
-  LzProbs *P;
   const uint8_t *in; uint64_t n;
   int cv;                                      // compare_variants: 0 None, 1 Simple, 2 Splitting (:1539-1546)
   MS ES;
   uint32_t width; uint64_t low; uint32_t cache; uint64_t cache_size;      // Range_Encoder :952-957
   uint8_t *out; uint64_t cap, olen;
-  double *xch;                                 // 64 doubles of LDS: what the lanes hand each other at a fork
 };
 
 #ifdef ZADA_LZ_PROF
@@ -76,13 +80,17 @@ __device__ inline uint32_t dist_slot(uint32_t d) {                              
 
 // ---------------------------------------------------------------- Estimates :349-946
 
-__device__ inline double tbe(uint16_t p, uint32_t sym) {                         // Test_Bit_Encoding :359-370
-  const double b = (double)sym;
-  return b + (1.0 - 2.0 * b) * ((double)p * (1.0 / 2048.0));
+// Test_Bit_Encoding :359-370 is b + (1.0 - 2.0 * b) * (prob * 2**-11) with b = 0.0 or 1.0.  prob * 2**-11 is exact; for b = 0 the
+// result is that value (0.0 + 1.0 * x), for b = 1 it is 1.0 - x = (2048 - prob) * 2**-11, representable, so the one rounding of the
+// reference's sum returns exactly it.  Hence: pick the integer, convert, scale -- the same double with two operations instead of five.
+__device__ inline double tbe(uint16_t p, uint32_t sym) {
+  const uint32_t q = sym ? 2048u - (uint32_t)p : (uint32_t)p;
+  return (double)q * (1.0 / 2048.0);
 }
 
-__device__ double test_simple_literal(const Enc &E, uint32_t b, uint32_t b_match, const uint16_t *prob, const MS &sim) {   // :372-419
-  double pl = tbe(E.P->match[sim.state][sim.pos_state], 0);
+__device__ double test_simple_literal(const Enc &E, uint32_t b, uint32_t b_match, int idx, const MS &sim) {   // :372-419
+  const uint16_t *prob = s_P.lit + idx;
+  double pl = tbe(s_P.match[sim.state][sim.pos_state], 0);
   uint32_t symb = b | 0x100;
   uint16_t pr[8];                                 // the eight probabilities first (their addresses do not depend on each other), then the products in order
   if (sim.state < 7) {
@@ -104,17 +112,17 @@ __device__ double test_simple_literal(const Enc &E, uint32_t b, uint32_t b_match
 }
 
 __device__ inline double test_short_rep(const Enc &E, const MS &sim) {           // :421-428
-  const LzProbs &P = *E.P;
+  const LzProbs &P = s_P;
   return tbe(P.match[sim.state][sim.pos_state], 1) * tbe(P.rep[sim.state], 1) * tbe(P.g0[sim.state], 0) * tbe(P.rep0_long[sim.state][sim.pos_state], 0);
 }
 
 __device__ inline int lit_idx(uint32_t prev_byte) { return 0x300 * (int)(prev_byte >> 5); }    // Idx_for_Literal_prob :193-201
 
-__device__ __noinline__ void sim_literal(const Enc &E, uint32_t b, MS &sim, double &prob) {    // Simulate_Literal_Byte :431-458
+__device__ __forceinline__ void sim_literal(const Enc &E, uint32_t b, MS &sim, double &prob) {    // Simulate_Literal_Byte :431-458
   const int idx = lit_idx(sim.prev_byte);
   const uint32_t b_match = TB(E, (int64_t)sim.pos - (int64_t)sim.rep[0] - 1);
   sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
-  const double ltr = test_simple_literal(E, b, b_match, E.P->lit + idx, sim);
+  const double ltr = test_simple_literal(E, b, b_match, idx, sim);
   bool srep = false;
   if (b == b_match && sim.pos > (uint64_t)(uint32_t)(sim.rep[0] + 1)) {
     const double srm = test_short_rep(E, sim);
@@ -148,7 +156,8 @@ __device__ inline double sim_bit_tree_rev(const uint16_t *prob, int num_bits, ui
   return res;
 }
 
-__device__ double test_length(const LenProbs &pl, uint32_t length, uint32_t ps) {              // :483-509
+__device__ double test_length(bool rep, uint32_t length, uint32_t ps) {              // :483-509
+  const LenProbs &pl = rep ? s_P.rep_len : s_P.len;
   uint32_t len = length - 2; double res;
   if (len < 8) res = tbe(pl.c1, 0) * sim_bit_tree<3>(pl.low[ps], len);
   else {
@@ -160,7 +169,7 @@ __device__ double test_length(const LenProbs &pl, uint32_t length, uint32_t ps) 
 }
 
 __device__ double test_repeat_match(const Enc &E, int index_rm, uint32_t length, const MS &sim) {   // :511-538
-  const LzProbs &P = *E.P;
+  const LzProbs &P = s_P;
   double res = tbe(P.rep[sim.state], 1);
   switch (index_rm) {
     case 0: res = res * tbe(P.g0[sim.state], 0) * tbe(P.rep0_long[sim.state][sim.pos_state], 1); break;
@@ -168,11 +177,11 @@ __device__ double test_repeat_match(const Enc &E, int index_rm, uint32_t length,
     case 2: res = res * tbe(P.g0[sim.state], 1) * tbe(P.g1[sim.state], 1) * tbe(P.g2[sim.state], 0); break;
     default: res = res * tbe(P.g0[sim.state], 1) * tbe(P.g1[sim.state], 1) * tbe(P.g2[sim.state], 1); break;
   }
-  return res * test_length(P.rep_len, length, sim.pos_state);
+  return res * test_length(true, length, sim.pos_state);
 }
 
 __device__ double test_simple_match(const Enc &E, uint32_t distance, uint32_t length, const MS &sim) {   // :540-601
-  const LzProbs &P = *E.P;
+  const LzProbs &P = s_P;
   const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(distance);
   double td = sim_bit_tree<6>(P.slot[len_state], ds);
   if (ds >= 4) {
@@ -185,13 +194,13 @@ __device__ double test_simple_match(const Enc &E, uint32_t distance, uint32_t le
       td = td * h * sim_bit_tree_rev(P.align, 4, red & 15);
     }
   }
-  return tbe(P.rep[sim.state], 0) * test_length(P.len, length, sim.pos_state) * td;
+  return tbe(P.rep[sim.state], 0) * test_length(false, length, sim.pos_state) * td;
 }
 
-__device__ __noinline__ void sim_strict(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) {   // Simulate_Strict_DL_Code :605-659
+__device__ __forceinline__ void sim_strict(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) {   // Simulate_Strict_DL_Code :605-659
   const uint32_t dist_ip = distance - 1;
   int found = -1;
-  const double dlc = tbe(E.P->match[sim.state][sim.pos_state], 1);
+  const double dlc = tbe(s_P.match[sim.state][sim.pos_state], 1);
   const double sma = test_simple_match(E, dist_ip, (uint32_t)length, sim);
   for (int i = 0; i < 4; i++) if (dist_ip == sim.rep[i]) { found = i; break; }
   bool rep = false;
@@ -271,9 +280,9 @@ template <int NEW, bool PAR> __device__ __noinline__ int decide(const Enc &E, ui
           if (lane == 1) sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, p);
           r = p;
         }
-        E.xch[lane] = r;
+        s_xch[lane] = r;
         __syncthreads();
-        dal = E.xch[0]; dtl = E.xch[1];
+        dal = s_xch[0]; dtl = s_xch[1];
         __syncthreads();
       } else {
         dal = 1.0;
@@ -310,10 +319,10 @@ template <int NEW, bool PAR> __device__ __noinline__ int decide(const Enc &E, ui
           pm = p; pf = p;
           if (!(p <= soe)) { sim_any<LOW>(E, distance, length - cut, v, p); pf = p; }
         }
-        E.xch[2 * lane] = pm; E.xch[2 * lane + 1] = pf;
+        s_xch[2 * lane] = pm; s_xch[2 * lane + 1] = pf;
         __syncthreads();
         for (int k = 0; k < nc; k++) {
-          if (!(E.xch[2 * k] <= soe)) { const double p = E.xch[2 * k + 1]; if (p > best_prob) { best_prob = p; best_cut = cuts[k]; } }
+          if (!(s_xch[2 * k] <= soe)) { const double p = s_xch[2 * k + 1]; if (p > best_prob) { best_prob = p; best_cut = cuts[k]; } }
         }
         __syncthreads();
       } else {
@@ -364,7 +373,10 @@ template <int R> __device__ __noinline__ void sim_any_impl(const Enc &E, uint32_
     }
   }
 }
-template <int R> __device__ void sim_any(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) { sim_any_impl<R>(E, distance, length, sim, prob); }
+template <int R> __device__ __forceinline__ void sim_any(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) {
+  if constexpr (R - 1 < 0) sim_strict(E, distance, length, sim, prob);      // limit used up (:761-764): no call in between
+  else sim_any_impl<R>(E, distance, length, sim, prob);
+}
 
 // ---------------------------------------------------------------- range coder :964-1039
 
@@ -391,11 +403,11 @@ __device__ inline void encode_bit(Enc &E, uint16_t &prob, uint32_t symbol) {
   else { E.low += bound; E.width -= bound; normalize(E); prob = (uint16_t)(cur - (cur >> 5)); }
 }
 
-__device__ void bit_tree_encode(Enc &E, uint16_t *prob, int num_bits, uint32_t symbol) {
+__device__ __forceinline__ void bit_tree_encode(Enc &E, uint16_t *prob, int num_bits, uint32_t symbol) {
   uint32_t m = 1;
   for (int i = num_bits - 1; i >= 0; i--) { const uint32_t bit = (symbol >> i) & 1; encode_bit(E, prob[m], bit); m = 2 * m + bit; }
 }
-__device__ void bit_tree_rev_encode(Enc &E, uint16_t *prob, int num_bits, uint32_t symbol) {
+__device__ __forceinline__ void bit_tree_rev_encode(Enc &E, uint16_t *prob, int num_bits, uint32_t symbol) {
   uint32_t m = 1;
   for (int c = num_bits; c >= 1; c--) { const uint32_t bit = symbol & 1; encode_bit(E, prob[m], bit); m = 2 * m + bit; symbol >>= 1; }
 }
@@ -404,12 +416,12 @@ __device__ void bit_tree_rev_encode(Enc &E, uint16_t *prob, int num_bits, uint32
 
 __device__ __noinline__ void emit_literal(Enc &E, uint32_t b) {                   // LZ77_emits_literal_byte :1097-1130
   PROF_T0;
-  LzProbs &P = *E.P;
+  LzProbs &P = s_P;
   MS &S = E.ES;
   const int idx = lit_idx(S.prev_byte);
   const uint32_t b_match = TB(E, (int64_t)S.pos - (int64_t)S.rep[0] - 1);
   if (b == b_match && S.pos > (uint64_t)(uint32_t)(S.rep[0] + 1) &&
-      (E.cv == 0 || test_short_rep(E, S) > test_simple_literal(E, b, b_match, P.lit + idx, S))) {
+      (E.cv == 0 || test_short_rep(E, S) > test_simple_literal(E, b, b_match, idx, S))) {
     encode_bit(E, P.match[S.state][S.pos_state], 1);
     encode_bit(E, P.rep[S.state], 1);
     encode_bit(E, P.g0[S.state], 0);
@@ -438,7 +450,8 @@ __device__ __noinline__ void emit_literal(Enc &E, uint32_t b) {                 
   PROF_ADD(1);
 }
 
-__device__ void encode_length(Enc &E, LenProbs &pl, uint32_t length) {            // :1160-1181
+__device__ void encode_length(Enc &E, bool rep, uint32_t length) {            // :1160-1181
+  LenProbs &pl = rep ? s_P.rep_len : s_P.len;
   uint32_t len = length - 2;
   const uint32_t ps = E.ES.pos_state;
   if (len < 8) { encode_bit(E, pl.c1, 0); bit_tree_encode(E, pl.low[ps], 3, len); }
@@ -450,11 +463,11 @@ __device__ void encode_length(Enc &E, LenProbs &pl, uint32_t length) {          
 }
 
 __device__ __noinline__ void write_simple_match(Enc &E, uint32_t dist_ip, uint32_t length) {   // :1183-1255
-  LzProbs &P = *E.P;
+  LzProbs &P = s_P;
   MS &S = E.ES;
   encode_bit(E, P.rep[S.state], 0);
   S.state = T_MATCH[S.state];
-  encode_length(E, P.len, length);
+  encode_length(E, false, length);
   const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(dist_ip);
   bit_tree_encode(E, P.slot[len_state], 6, ds);
   if (ds >= 4) {
@@ -475,7 +488,7 @@ __device__ __noinline__ void write_simple_match(Enc &E, uint32_t dist_ip, uint32
 }
 
 __device__ __noinline__ void write_repeat_match(Enc &E, int index_rm, uint32_t length) {   // :1257-1286
-  LzProbs &P = *E.P;
+  LzProbs &P = s_P;
   MS &S = E.ES;
   encode_bit(E, P.rep[S.state], 1);
   switch (index_rm) {
@@ -487,7 +500,7 @@ __device__ __noinline__ void write_repeat_match(Enc &E, int index_rm, uint32_t l
   const uint32_t aux = S.rep[index_rm];
   for (int i = index_rm; i >= 1; i--) S.rep[i] = S.rep[i - 1];
   S.rep[0] = aux;
-  encode_length(E, P.rep_len, length);
+  encode_length(E, true, length);
   S.state = T_REP[S.state];
 }
 
@@ -495,7 +508,7 @@ __device__ __noinline__ void write_strict(Enc &E, uint32_t distance, int length)
   MS &S = E.ES;
   const uint32_t dist_ip = distance - 1;
   int found = -1;
-  encode_bit(E, E.P->match[S.state][S.pos_state], 1);
+  encode_bit(E, s_P.match[S.state][S.pos_state], 1);
   for (int i = 0; i < 4; i++) if (dist_ip == S.rep[i]) { found = i; break; }
   if (found >= 0 && (E.cv == 0 || test_repeat_match(E, found, (uint32_t)length, S) >= test_simple_match(E, dist_ip, (uint32_t)length, S) * 0.55))
     write_repeat_match(E, found, (uint32_t)length);
@@ -596,11 +609,11 @@ __device__ __noinline__ void scoring_top(const Enc &E, const ScoreCtx &S, const 
     const int k = base + lane;
     double p = 0.0;
     if (k < total) p = score_candidate<1>(E, S, state, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
-    E.xch[lane] = p;
+    s_xch[lane] = p;
     __syncthreads();
     const int cnt = total - base < 64 ? total - base : 64;
     for (int j = 0; j < cnt; j++) {
-      const double pj = E.xch[j];
+      const double pj = s_xch[j];
       const int kk = base + j;
       if (pj > prob) { prob = pj; index = (kk < c0 ? kk : kk - c0) + 1; match_set = kk < c0 ? 0 : 1; }
     }
@@ -933,9 +946,8 @@ __device__ void lz_bt4(Enc &E, Matches *MM, int sbs, int32_t *ws, uint32_t hash4
 
 __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
                                                     int32_t *ws_base, uint64_t *result) {
-  __shared__ LzProbs P;
-  __shared__ Matches MM[2];
-  __shared__ double xch[128];
+  LzProbs &P = s_P;
+  Matches *MM = s_MM;
   const LzmaJob J = jobs[blockIdx.x];
   {
     uint16_t *p = (uint16_t *)&P;
@@ -947,13 +959,12 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   for (int i = 0; i < 8; i++) g_lzprof[i] = 0;
 #endif
   Enc E;
-  E.P = &P; E.in = in_base + J.in_off; E.n = J.n;
+  E.in = in_base + J.in_off; E.n = J.n;
   E.cv = J.level <= 1 ? 0 : J.level == 2 ? 1 : 2;
   E.ES.state = 0; E.ES.pos_state = 0; E.ES.prev_byte = 0; E.ES.pos = 0;
   E.ES.rep[0] = E.ES.rep[1] = E.ES.rep[2] = E.ES.rep[3] = 0;
   E.width = 0xFFFFFFFFu; E.low = 0; E.cache = 0; E.cache_size = 1;
   E.out = out_base + J.out_off; E.cap = J.cap; E.olen = 0;
-  E.xch = xch;
   if (J.zip_prefix) { put_byte(E, 16); put_byte(E, 2); put_byte(E, 5); put_byte(E, 0); }   // zip-compress-lzma_e.adb:155-158
   put_byte(E, 3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
   for (int i = 0; i < 4; i++) put_byte(E, (J.sbs >> (8 * i)) & 255);
