@@ -256,7 +256,7 @@ template <int R> __device__ void sim_any(const Enc &E, uint32_t distance, int le
 // Where the reference compares INDEPENDENT simulations -- literal + code against code + literal (:783-805), the cuts of
 // Test_Split_DL (:924-943) -- the lanes part: one simulation each, from their own copy of the state, nothing written but the
 // result; the results are then compared by all lanes in the reference's order.  Same doubles, a shorter critical path.
-template <int NEW, bool PAR> __device__ __noinline__ int decide(const Enc &E, uint32_t distance, int length, const MS &sim, int &best_cut) {
+template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E, uint32_t distance, int length, const MS &sim, int &best_cut) {
   double strict_dlc = 0.0, expanded_dlc = 0.0, soe = 0.0;
   [[maybe_unused]] const int lane = (int)threadIdx.x;
   if (E.cv >= 1) {
