@@ -663,6 +663,21 @@ __device__ inline uint32_t crc_tab(uint32_t i) {                                
 }
 #define BUF(i) ((uint32_t)E.in[(int64_t)(i) + B.moved])
 
+// First index k in [len, limit) at which buf [a + k] /= buf [b + k], or limit: the byte loops of lz77.adb:1183-1191, 1287-1291,
+// 1331-1335, 1456-1458, eight bytes at a time while eight remain below the limit (nothing beyond a + limit / b + limit is read).
+__device__ inline int bt_extend(const uint8_t *buf, int64_t a, int64_t b, int len, int limit) {
+  while (len + 8 <= limit) {
+    unsigned long long x, y;
+    __builtin_memcpy(&x, buf + a + len, 8);
+    __builtin_memcpy(&y, buf + b + len, 8);
+    x ^= y;
+    if (x) return len + (__builtin_ctzll(x) >> 3);
+    len += 8;
+  }
+  while (len < limit && buf[a + len] == buf[b + len]) len++;
+  return len;
+}
+
 __device__ inline int bt_available(const BT4 &B) { return B.writePos - B.readPos - 1; }
 
 __device__ inline int bt_move_pos(BT4 &B) {                                       // Move_Pos_in_BT4 :1127-1150 (finishing = False, :959)
@@ -697,13 +712,8 @@ __device__ __noinline__ void bt_skip_update(const Enc &E, BT4 &B, int niceLenLim
     depth--;
     const int pair = (B.cyclicPos - delta0 + (B.cyclicPos - delta0 < 0 ? B.sbs : 0)) * 2;
     int len = len0 < len1 ? len0 : len1;
-    if (BUF(rp + len - delta0) == BUF(rp + len)) {
-      for (;;) {
-        len++;
-        if (len == niceLenLimit) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return; }
-        if (BUF(rp + len - delta0) != BUF(rp + len)) break;
-      }
-    }
+    len = bt_extend(E.in + B.moved, (int64_t)rp - delta0, rp, len, niceLenLimit);
+    if (len == niceLenLimit) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return; }
     if (BUF(rp + len - delta0) < BUF(rp + len)) { tree[ptr1] = currentMatch; ptr1 = pair + 1; currentMatch = tree[ptr1]; len1 = len; }
     else { tree[ptr0] = currentMatch; ptr0 = pair; currentMatch = tree[ptr0]; len0 = len; }
   }
@@ -741,7 +751,7 @@ __device__ __noinline__ void bt_get_matches(const Enc &E, BT4 &B, Matches &M) { 
   if (delta2 < B.max_dist && BUF(rp - delta2) == BUF(rp)) { lenBest = 2; M.count = 1; M.len[1] = 2; M.dist[1] = delta2; }
   if (delta2 != delta3 && delta3 < B.max_dist && BUF(rp - delta3) == BUF(rp)) { lenBest = 3; M.count++; M.dist[M.count] = delta3; delta2 = delta3; }
   if (M.count > 0) {
-    while (lenBest < matchLenLimit && BUF(rp + lenBest - delta2) == BUF(rp + lenBest)) lenBest++;
+    lenBest = bt_extend(E.in + B.moved, (int64_t)rp - delta2, rp, lenBest, matchLenLimit);
     M.len[M.count] = (uint16_t)lenBest;
     if (lenBest >= nice) { bt_skip_update(E, B, nice, currentMatch); return; }
   }
@@ -754,7 +764,7 @@ __device__ __noinline__ void bt_get_matches(const Enc &E, BT4 &B, Matches &M) { 
     const int pair = (B.cyclicPos - delta0 + (B.cyclicPos - delta0 < 0 ? B.sbs : 0)) * 2;
     int len = len0 < len1 ? len0 : len1;
     if (BUF(rp + len - delta0) == BUF(rp + len)) {
-      do { len++; } while (!(len >= matchLenLimit || BUF(rp + len - delta0) != BUF(rp + len)));
+      len = bt_extend(E.in + B.moved, (int64_t)rp - delta0, rp, len + 1, matchLenLimit);
       if (len > lenBest) {
         lenBest = len;
         M.count++;
@@ -790,10 +800,7 @@ __device__ int bt_fill_window(const Enc &E, BT4 &B, int len_initial) {          
 
 __device__ inline int bt_match_len(const Enc &E, const BT4 &B, int distance, int limit) {   // Compute_Match_Length :1442-1460
   if (distance < 2) return 0;
-  const int back = B.readPos - distance;
-  int len = 0;
-  while (len < limit && BUF(B.readPos + len) == BUF(back + len)) len++;
-  return len;
+  return bt_extend(E.in + B.moved, (int64_t)B.readPos - distance, B.readPos, 0, limit);
 }
 __device__ inline bool much_smaller(int smallDist, int bigDist) { return (smallDist - 1) < (bigDist - 1) / 128; }   // :1469-1473
 
