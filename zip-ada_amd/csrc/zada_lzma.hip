@@ -40,6 +40,7 @@ struct MS {                                    // Machine_State :212-219 without
   uint32_t state, pos_state, prev_byte;
   uint32_t rep[4];
   uint64_t pos;
+  int tw;                                        // simulations: width of the team of lanes that runs this one in step (1: a lane alone) -- see decide
 };
 
 // The entry's probability model, the two match sets of BT4's look-ahead and what the lanes hand each other at a fork: file-scope LDS
@@ -245,6 +246,9 @@ __device__ double test_expanded(const Enc &E, uint32_t distance, int length, dou
 
 __device__ inline double fmax0(double x) { return x > 0.0 ? x : 0.0; }
 
+// largest power of two t with n * t <= 64 (n >= 1): the lanes a task gets when n tasks share the wave
+__device__ inline int team_width(int n) { return n <= 1 ? 64 : n <= 2 ? 32 : n <= 4 ? 16 : n <= 8 ? 8 : n <= 16 ? 4 : n <= 32 ? 2 : 1; }
+
 enum { W_STRICT = 0, W_LIT_DL = 1, W_DL_LIT = 2, W_EXPAND = 3, W_SPLIT = 4 };
 
 template <int R> __device__ void sim_any(const Enc &E, uint32_t distance, int length, MS &sim, double &prob);   // Simulate_any_DL_Code, recursion_limit = R
@@ -272,17 +276,15 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E,
       const double malus_dtl = fmax0(0.135 - (double)distance * 1.0e-8 - (double)length * 1.0e-4);     // DL_code_then_Literal :869-889
       double dal, dtl;
       if constexpr (PAR) {
-        double r = 0.0;
-        if (lane < 2) {
-          MS v = lane == 0 ? after : sim;
-          double p = lane == 0 ? 1.0 : malus_dtl;
-          sim_any<NEW>(E, distance, length - 1, v, p);
-          if (lane == 1) sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, p);
-          r = p;
-        }
-        s_xch[lane] = r;
+        const int task = lane >> 5;                                                // two tasks, 32 lanes each
+        MS v = task == 0 ? after : sim;
+        v.tw = 32;
+        double p = task == 0 ? 1.0 : malus_dtl;
+        sim_any<NEW>(E, distance, length - 1, v, p);
+        if (task == 1) sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, p);
+        s_xch[lane] = p;
         __syncthreads();
-        dal = s_xch[0]; dtl = s_xch[1];
+        dal = s_xch[0]; dtl = s_xch[32];
         __syncthreads();
       } else {
         dal = 1.0;
@@ -310,11 +312,13 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E,
           const int rest = length - cut;
           if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) cuts[nc++] = cut;
         }
+        const int tw = team_width(nc), task = lane / tw;                           // one cut per team of tw lanes
         double pm = 0.0, pf = 0.0;
-        if (lane < nc) {
-          const int cut = cuts[lane];
+        if (task < nc) {
+          const int cut = cuts[task];
           double p = malus;
           MS v = sim;
+          v.tw = tw;
           sim_any<LOW>(E, distance, cut, v, p);
           pm = p; pf = p;
           if (!(p <= soe)) { sim_any<LOW>(E, distance, length - cut, v, p); pf = p; }
@@ -322,9 +326,35 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E,
         s_xch[2 * lane] = pm; s_xch[2 * lane + 1] = pf;
         __syncthreads();
         for (int k = 0; k < nc; k++) {
-          if (!(s_xch[2 * k] <= soe)) { const double p = s_xch[2 * k + 1]; if (p > best_prob) { best_prob = p; best_cut = cuts[k]; } }
+          if (!(s_xch[2 * k * tw] <= soe)) { const double p = s_xch[2 * k * tw + 1]; if (p > best_prob) { best_prob = p; best_cut = cuts[k]; } }
         }
         __syncthreads();
+      } else if (sim.tw > 1) {
+        // A team of sim.tw lanes runs this simulation in step (same state, same branches).  Its cuts are independent simulations
+        // again: a lane each, tw at a time; the results go round the team by cross-lane reads and are taken in cut order.
+        const int tw = sim.tw, tl = lane & (tw - 1), tb = lane & ~(tw - 1);
+        int cuts[12], nc = 0;
+        for (int cut = 2; cut <= length - 2; cut++) {
+          const int rest = length - cut;
+          if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) cuts[nc++] = cut;
+        }
+        for (int r = 0; r * tw < nc; r++) {
+          const int k = r * tw + tl;
+          double pm = 0.0, pf = 0.0;
+          if (k < nc) {
+            const int cut = cuts[k];
+            double p = malus;
+            MS v = sim;
+            v.tw = 1;
+            sim_any<LOW>(E, distance, cut, v, p);
+            pm = p; pf = p;
+            if (!(p <= soe)) { sim_any<LOW>(E, distance, length - cut, v, p); pf = p; }
+          }
+          for (int j = 0; j < tw && r * tw + j < nc; j++) {
+            const double pmk = __shfl(pm, tb + j), pfk = __shfl(pf, tb + j);
+            if (!(pmk <= soe)) { if (pfk > best_prob) { best_prob = pfk; best_cut = cuts[r * tw + j]; } }
+          }
+        }
       } else {
         for (int cut = 2; cut <= length - 2; cut++) {
           const int rest = length - cut;
@@ -567,6 +597,7 @@ template <int LEVEL> __device__ inline double score_candidate(const Enc &E, cons
   const int last_pos_i = M.len[i] + (m != S.old_index ? 1 : 0);
   MS t; double p;
   if (m != S.old_index && start == 1) { t = S.sim_new; p = S.head_lit_prob; } else { t = state; p = 1.0; }
+  t.tw = state.tw;
   int trunc;
   if (m == S.old_index) trunc = M.len[i] - start + 1;
   else if (start == 1) trunc = M.len[i];
@@ -604,16 +635,19 @@ template <int LEVEL> __device__ void scoring(const Enc &E, const ScoreCtx &S, co
 // last positions are >= 1), one lane each; the best is then picked by all lanes in the reference's order (first strict maximum).
 __device__ __noinline__ void scoring_top(const Enc &E, const ScoreCtx &S, const MS &state, double &prob, int &index, int &match_set) {
   const int lane = (int)threadIdx.x, c0 = S.m[0].count, total = c0 + S.m[1].count;
+  const int tw = team_width(total), per_round = 64 / tw;                           // a team of tw lanes per candidate
+  MS st = state;
+  st.tw = tw;
   prob = 0.0;
-  for (int base = 0; base < total; base += 64) {
-    const int k = base + lane;
+  for (int base = 0; base < total; base += per_round) {
+    const int k = base + lane / tw;
     double p = 0.0;
-    if (k < total) p = score_candidate<1>(E, S, state, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
+    if (k < total) p = score_candidate<1>(E, S, st, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
     s_xch[lane] = p;
     __syncthreads();
-    const int cnt = total - base < 64 ? total - base : 64;
+    const int cnt = total - base < per_round ? total - base : per_round;
     for (int j = 0; j < cnt; j++) {
-      const double pj = s_xch[j];
+      const double pj = s_xch[j * tw];
       const int kk = base + j;
       if (pj > prob) { prob = pj; index = (kk < c0 ? kk : kk - c0) + 1; match_set = kk < c0 ? 0 : 1; }
     }
@@ -968,7 +1002,7 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   Enc E;
   E.in = in_base + J.in_off; E.n = J.n;
   E.cv = J.level <= 1 ? 0 : J.level == 2 ? 1 : 2;
-  E.ES.state = 0; E.ES.pos_state = 0; E.ES.prev_byte = 0; E.ES.pos = 0;
+  E.ES.state = 0; E.ES.pos_state = 0; E.ES.prev_byte = 0; E.ES.pos = 0; E.ES.tw = 1;
   E.ES.rep[0] = E.ES.rep[1] = E.ES.rep[2] = E.ES.rep[3] = 0;
   E.width = 0xFFFFFFFFu; E.low = 0; E.cache = 0; E.cache_size = 1;
   E.out = out_base + J.out_off; E.cap = J.cap; E.olen = 0;
