@@ -403,8 +403,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       constexpr uint32_t QCAP = 4000;
       uint32_t *Qa = (uint32_t *)(smem + 32800), *Qb = Qa + QCAP;   // behind the 32 784 staged bytes
       uint32_t *qn = wsum;
-      const unsigned long long ltm = (1ull << lane) - 1ull;
-      if (tid < 2) qn[tid] = 0;
+          if (tid < 2) qn[tid] = 0;
       __syncthreads();
       // up to `maxs` further candidates of position e, starting behind q; true = settled (dl valid)
       auto walk = [&](uint32_t e, uint32_t &q, uint64_t mine, uint32_t maxs, uint32_t &dl) -> bool {
@@ -1249,7 +1248,7 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
     };
     auto cand_dist = [&](const ScanDesc &ds, uint32_t c, uint32_t raw) -> uint32_t {
       const uint64_t P_ = B + ds.k;
-      const uint32_t po = (uint32_t)P_ & 32767u, sg = (uint32_t)(P_ >> 15);    // offset in the segment, segment (uniform)
+      const uint32_t po = (uint32_t)P_ & 32767u;                                // offset in the segment
       const bool in1 = c < ds.c1, in2 = !in1 && c - ds.c1 < ds.c2;
       const bool q0 = raw == 0 && ((in1 && seg_first) || (in2 && prev_first));   // the candidate is position 0 of the stream
       return q0 ? 0u : (in1 ? po - raw : (in2 ? po + 32768u - raw : 0u));
