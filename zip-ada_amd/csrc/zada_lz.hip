@@ -403,7 +403,8 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       constexpr uint32_t QCAP = 4000;
       uint32_t *Qa = (uint32_t *)(smem + 32800), *Qb = Qa + QCAP;   // behind the 32 784 staged bytes
       uint32_t *qn = wsum;
-          if (tid < 2) qn[tid] = 0;
+      const unsigned long long ltm = (1ull << lane) - 1ull;
+      if (tid < 2) qn[tid] = 0;
       __syncthreads();
       // up to `maxs` further candidates of position e, starting behind q; true = settled (dl valid)
       auto walk = [&](uint32_t e, uint32_t &q, uint64_t mine, uint32_t maxs, uint32_t &dl) -> bool {
@@ -1129,7 +1130,6 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
   const uint32_t cnt = n > B ? (uint32_t)((n - B) < (uint64_t)DMB ? (n - B) : (uint64_t)DMB) : 0u;
   const bool seg_first = lay_first(L, B >> 15), prev_first = (B >> 15) > 0 && lay_first(L, (B >> 15) - 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long ltm = (1ull << lane) - 1ull;
   {
     const uint32_t nb = woff + cnt + 272;
     const uint4 *src = (const uint4 *)(in + WB);
