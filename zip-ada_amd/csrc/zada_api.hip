@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
 #include <atomic>
 #include <mutex>
@@ -1158,15 +1159,20 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, con
     j.ws_off = ws_ints;
     ws_ints += (lzma_workspace_ints(j.level, j.sbs) + 15) & ~15ull;
   }
-  int rc = lz_grow(c, &c->lz_tab, &c->cap_lz_tab, (sizeof(LzmaJob) + 16) * (size_t)E + 64);
+  int rc = lz_grow(c, &c->lz_tab, &c->cap_lz_tab, (sizeof(LzmaJob) + 16 + 4) * (size_t)E + 192);
   if (!rc && ws_ints) rc = lz_grow(c, &c->lz_ws, &c->cap_lz_ws, ws_ints * 4);
   if (rc) return rc;
   LzmaJob *d_jobs = (LzmaJob *)c->lz_tab;
   uint64_t *d_res = (uint64_t *)((uint8_t *)c->lz_tab + ((sizeof(LzmaJob) * (size_t)E + 63) & ~63ull));
+  uint32_t *d_order = (uint32_t *)((uint8_t *)d_res + ((16 * (size_t)E + 63) & ~63ull));
+  std::vector<uint32_t> order(E);                                  // a stream's time goes with its length: the longest first
+  for (uint32_t e = 0; e < E; e++) order[e] = e;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n > jobs[b].n; });
   hipMemcpyAsync(d_jobs, jobs.data(), sizeof(LzmaJob) * (size_t)E, hipMemcpyHostToDevice, c->stream);
+  hipMemcpyAsync(d_order, order.data(), 4 * (size_t)E, hipMemcpyHostToDevice, c->stream);
   if (ws_ints) hipMemsetAsync(c->lz_ws, 0, ws_ints * 4, c->stream);
   if (d_apos && (rc = lzma_token_ranges(c, E, d_apos, T, d_ent_start, d_jobs))) return rc;   // token ranges of a batch, found on the device
-  if ((rc = lzma_launch(c, d_jobs, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res))) return rc;
+  if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res))) return rc;
   res.resize(2 * (size_t)E);
   hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
   if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;

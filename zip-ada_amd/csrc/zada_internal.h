@@ -295,7 +295,7 @@ uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size);
 uint32_t lzma_hash4_size(uint32_t sbs);
 uint64_t lzma_workspace_ints(int level, uint32_t sbs);
 int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, const uint32_t *d_ent_start, LzmaJob *d_jobs);
-int lzma_launch(Ctx *c, const LzmaJob *d_jobs, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result);
+int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);
 int ensure_crc_workspace(Ctx *c, uint64_t n);

@@ -985,11 +985,12 @@ __device__ void lz_bt4(Enc &E, Matches *MM, int sbs, int32_t *ws, uint32_t hash4
 
 // ---------------------------------------------------------------- one stream per workgroup
 
-__global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
+__global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint32_t *order, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
                                                     int32_t *ws_base, uint64_t *result) {
   LzProbs &P = s_P;
   Matches *MM = s_MM;
-  const LzmaJob J = jobs[blockIdx.x];
+  const uint32_t job = order ? order[blockIdx.x] : blockIdx.x;      // the longest entries first: workgroups start in index order
+  const LzmaJob J = jobs[job];
   {
     uint16_t *p = (uint16_t *)&P;
     for (uint32_t i = threadIdx.x; i < sizeof(LzProbs) / 2; i += 64) p[i] = 1024;    // initial_probability
@@ -1026,8 +1027,8 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
 #ifdef ZADA_LZ_PROF
   if (blockIdx.x == 0 && threadIdx.x == 0) printf("LZPROF total %llu literal %llu emit_dl %llu estimate %llu bt_get %llu bt_skip %llu split(all levels) %llu\n", clock64() - prof_k0, g_lzprof[1], g_lzprof[2], g_lzprof[3], g_lzprof[4], g_lzprof[5], g_lzprof[6]);
 #endif
-  result[2 * blockIdx.x] = E.olen;
-  result[2 * blockIdx.x + 1] = E.ES.pos;
+  result[2 * job] = E.olen;
+  result[2 * job + 1] = E.ES.pos;
 }
 
 }  // namespace
@@ -1077,9 +1078,9 @@ int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, co
 }
 
 // jobs[0 .. count): device array; results: 2 x count uint64 (stream bytes, input bytes coded).  Level_3 hash tables must be zero.
-int lzma_launch(Ctx *c, const LzmaJob *d_jobs, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result) {
+int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result) {
   if (count == 0) return 0;
-  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_in, d_tok, d_out, d_ws, d_result);
+  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, d_ws, d_result);
   return hip_check(c, hipGetLastError(), "k_lzma_encode") ? ZADA_E_HIP : 0;
 }
 
