@@ -25,7 +25,7 @@ namespace {
 
 constexpr int LZ_LIT = 0x300 << 3;             // lc = 3, lp = 0
 constexpr uint32_t LZ_PBM = 3;                 // pb = 2
-constexpr int LZ_MAXM = 288;                   // matches of one position: lengths strictly increase from 2 to 273, + 1 repeat match
+constexpr int LZ_MAXM = 276;                   // matches of one position: lengths strictly increase from 2 to 273 (272 of them), + 1 repeat match, (1 .. count)
 
 struct LenProbs { uint16_t c1, c2, low[16][8], mid[16][8], high[256]; };
 struct LzProbs {                               // lzma.ads:137-201
@@ -47,7 +47,6 @@ struct MS {                                    // Machine_State :212-219 without
 // objects, so that every access is a ds_ instruction (through a pointer in a struct they were flat loads: 36 M of them per 64 KiB).
 __shared__ LzProbs s_P;
 __shared__ Matches s_MM[2];
-__shared__ double s_xch[128];
 
 struct Enc {
   const uint8_t *in; uint64_t n;
@@ -56,6 +55,9 @@ struct Enc {
   uint32_t width; uint64_t low; uint32_t cache; uint64_t cache_size;      // Range_Encoder :952-957
   uint8_t *out; uint64_t cap, olen;
 };
+// The encoder's state as well: every lane holds the same values outside the forks, the simulations only read it.  (As a local of
+// the kernel it was reached through a pointer into scratch: a flat load, 100+ cycles and both wait counters, per field read.)
+__shared__ Enc s_E;
 
 #ifdef ZADA_LZ_PROF
 __device__ unsigned long long g_lzprof[8];
@@ -71,7 +73,7 @@ __device__ const uint8_t T_MATCH[12] = {7, 7, 7, 7, 7, 7, 7, 10, 10, 10, 10, 10}
 __device__ const uint8_t T_REP[12]  = {8, 8, 8, 8, 8, 8, 8, 11, 11, 11, 11, 11};
 __device__ const uint8_t T_SREP[12] = {9, 9, 9, 9, 9, 9, 9, 11, 11, 11, 11, 11};
 
-__device__ inline uint32_t TB(const Enc &E, int64_t p) { return p < 0 ? 0u : (uint32_t)E.in[p]; }
+__device__ inline uint32_t TB(int64_t p) { return p < 0 ? 0u : (uint32_t)s_E.in[p]; }
 
 __device__ inline uint32_t dist_slot(uint32_t d) {                               // Get_dist_slot :73-102
   if (d <= 4) return d;
@@ -89,7 +91,7 @@ __device__ inline double tbe(uint16_t p, uint32_t sym) {
   return (double)q * (1.0 / 2048.0);
 }
 
-__device__ double test_simple_literal(const Enc &E, uint32_t b, uint32_t b_match, int idx, const MS &sim) {   // :372-419
+__device__ double test_simple_literal(uint32_t b, uint32_t b_match, int idx, const MS &sim) {   // :372-419
   const uint16_t *prob = s_P.lit + idx;
   double pl = tbe(s_P.match[sim.state][sim.pos_state], 0);
   uint32_t symb = b | 0x100;
@@ -112,21 +114,21 @@ __device__ double test_simple_literal(const Enc &E, uint32_t b, uint32_t b_match
   return pl;
 }
 
-__device__ inline double test_short_rep(const Enc &E, const MS &sim) {           // :421-428
+__device__ inline double test_short_rep(const MS &sim) {           // :421-428
   const LzProbs &P = s_P;
   return tbe(P.match[sim.state][sim.pos_state], 1) * tbe(P.rep[sim.state], 1) * tbe(P.g0[sim.state], 0) * tbe(P.rep0_long[sim.state][sim.pos_state], 0);
 }
 
 __device__ inline int lit_idx(uint32_t prev_byte) { return 0x300 * (int)(prev_byte >> 5); }    // Idx_for_Literal_prob :193-201
 
-__device__ __forceinline__ void sim_literal(const Enc &E, uint32_t b, MS &sim, double &prob) {    // Simulate_Literal_Byte :431-458
+__device__ __forceinline__ void sim_literal(uint32_t b, MS &sim, double &prob) {    // Simulate_Literal_Byte :431-458
   const int idx = lit_idx(sim.prev_byte);
-  const uint32_t b_match = TB(E, (int64_t)sim.pos - (int64_t)sim.rep[0] - 1);
+  const uint32_t b_match = TB((int64_t)sim.pos - (int64_t)sim.rep[0] - 1);
   sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
-  const double ltr = test_simple_literal(E, b, b_match, idx, sim);
+  const double ltr = test_simple_literal(b, b_match, idx, sim);
   bool srep = false;
   if (b == b_match && sim.pos > (uint64_t)(uint32_t)(sim.rep[0] + 1)) {
-    const double srm = test_short_rep(E, sim);
+    const double srm = test_short_rep(sim);
     if (srm > ltr) { sim.state = T_SREP[sim.state]; prob = prob * srm; srep = true; }
   }
   if (!srep) { sim.state = T_LIT[sim.state]; prob = prob * ltr; }
@@ -135,9 +137,9 @@ __device__ __forceinline__ void sim_literal(const Enc &E, uint32_t b, MS &sim, d
   sim.prev_byte = b;
 }
 
-__device__ inline double test_literal_byte(const Enc &E, uint32_t b, const MS &sim) {          // :460-468
+__device__ inline double test_literal_byte(uint32_t b, const MS &sim) {          // :460-468
   MS v = sim; double prob = 1.0;
-  sim_literal(E, b, v, prob);
+  sim_literal(b, v, prob);
   return prob;
 }
 
@@ -169,7 +171,7 @@ __device__ double test_length(bool rep, uint32_t length, uint32_t ps) {         
   return res;
 }
 
-__device__ double test_repeat_match(const Enc &E, int index_rm, uint32_t length, const MS &sim) {   // :511-538
+__device__ double test_repeat_match(int index_rm, uint32_t length, const MS &sim) {   // :511-538
   const LzProbs &P = s_P;
   double res = tbe(P.rep[sim.state], 1);
   switch (index_rm) {
@@ -181,7 +183,7 @@ __device__ double test_repeat_match(const Enc &E, int index_rm, uint32_t length,
   return res * test_length(true, length, sim.pos_state);
 }
 
-__device__ double test_simple_match(const Enc &E, uint32_t distance, uint32_t length, const MS &sim) {   // :540-601
+__device__ double test_simple_match(uint32_t distance, uint32_t length, const MS &sim) {   // :540-601
   const LzProbs &P = s_P;
   const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(distance);
   double td = sim_bit_tree<6>(P.slot[len_state], ds);
@@ -198,15 +200,15 @@ __device__ double test_simple_match(const Enc &E, uint32_t distance, uint32_t le
   return tbe(P.rep[sim.state], 0) * test_length(false, length, sim.pos_state) * td;
 }
 
-__device__ __forceinline__ void sim_strict(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) {   // Simulate_Strict_DL_Code :605-659
+__device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &sim, double &prob) {   // Simulate_Strict_DL_Code :605-659
   const uint32_t dist_ip = distance - 1;
   int found = -1;
   const double dlc = tbe(s_P.match[sim.state][sim.pos_state], 1);
-  const double sma = test_simple_match(E, dist_ip, (uint32_t)length, sim);
+  const double sma = test_simple_match(dist_ip, (uint32_t)length, sim);
   for (int i = 0; i < 4; i++) if (dist_ip == sim.rep[i]) { found = i; break; }
   bool rep = false;
   if (found >= 0) {
-    const double rma = test_repeat_match(E, found, (uint32_t)length, sim);
+    const double rma = test_repeat_match(found, (uint32_t)length, sim);
     if (rma >= sma * 0.55) {                                                       // Malus_simple_match_vs_rep :301
       prob = prob * dlc * rma;
       const uint32_t aux = sim.rep[found];
@@ -223,21 +225,21 @@ __device__ __forceinline__ void sim_strict(const Enc &E, uint32_t distance, int 
   }
   sim.pos += (uint64_t)length;
   sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
-  sim.prev_byte = TB(E, (int64_t)sim.pos - 1);
+  sim.prev_byte = TB((int64_t)sim.pos - 1);
 }
 
-__device__ inline double test_strict(const Enc &E, uint32_t distance, int length, const MS &sim) {   // :661-677
+__device__ inline double test_strict(uint32_t distance, int length, const MS &sim) {   // :661-677
   MS v = sim; double prob = 1.0;
-  sim_strict(E, distance, length, v, prob);
+  sim_strict(distance, length, v, prob);
   return prob;
 }
 
-__device__ double test_expanded(const Enc &E, uint32_t distance, int length, double give_up, const MS &sim) {   // :680-726
+__device__ double test_expanded(uint32_t distance, int length, double give_up, const MS &sim) {   // :680-726
   MS v = sim; double p = 1.0;
   const int64_t copy_start = (int64_t)sim.pos - (int64_t)distance;
   for (int x = 1; x <= length; x++) {
-    const uint32_t b = TB(E, copy_start + (x - 1));
-    sim_literal(E, b, v, p);
+    const uint32_t b = TB(copy_start + (x - 1));
+    sim_literal(b, v, p);
     if (p < give_up) break;
     v.prev_byte = b;
   }
@@ -251,7 +253,7 @@ __device__ inline int team_width(int n) { return n <= 1 ? 64 : n <= 2 ? 32 : n <
 
 enum { W_STRICT = 0, W_LIT_DL = 1, W_DL_LIT = 2, W_EXPAND = 3, W_SPLIT = 4 };
 
-template <int R> __device__ void sim_any(const Enc &E, uint32_t distance, int length, MS &sim, double &prob);   // Simulate_any_DL_Code, recursion_limit = R
+template <int R> __device__ void sim_any(uint32_t distance, int length, MS &sim, double &prob);   // Simulate_any_DL_Code, recursion_limit = R
 
 // The body of Generic_any_DL_Code (:740-832) up to its choice; NEW = new_recursion_limit.  The simulations it asks for nest at
 // most three deep (the limit goes down by one per level, :756-764), so the recursion of the reference unrolls into templates.
@@ -260,16 +262,16 @@ template <int R> __device__ void sim_any(const Enc &E, uint32_t distance, int le
 // Where the reference compares INDEPENDENT simulations -- literal + code against code + literal (:783-805), the cuts of
 // Test_Split_DL (:924-943) -- the lanes part: one simulation each, from their own copy of the state, nothing written but the
 // result; the results are then compared by all lanes in the reference's order.  Same doubles, a shorter critical path.
-template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E, uint32_t distance, int length, const MS &sim, int &best_cut) {
+template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t distance, int length, const MS &sim, int &best_cut) {
   double strict_dlc = 0.0, expanded_dlc = 0.0, soe = 0.0;
   [[maybe_unused]] const int lane = (int)threadIdx.x;
-  if (E.cv >= 1) {
-    strict_dlc = test_strict(E, distance, length, sim);
-    expanded_dlc = test_expanded(E, distance, length, strict_dlc, sim);
+  if (s_E.cv >= 1) {
+    strict_dlc = test_strict(distance, length, sim);
+    expanded_dlc = test_expanded(distance, length, strict_dlc, sim);
     soe = strict_dlc > expanded_dlc ? strict_dlc : expanded_dlc;
     if (length > 2) {
-      const uint32_t b_head = TB(E, (int64_t)sim.pos - (int64_t)distance);
-      const double head_lit = test_literal_byte(E, b_head, sim);
+      const uint32_t b_head = TB((int64_t)sim.pos - (int64_t)distance);
+      const double head_lit = test_literal_byte(b_head, sim);
       if (head_lit >= 0.875) return W_LIT_DL;                                      // Lit_then_DL_threshold :306
       MS after = sim;
       after.state = T_LIT[sim.state]; after.pos = sim.pos + 1; after.pos_state = (uint32_t)after.pos & LZ_PBM; after.prev_byte = b_head;
@@ -280,26 +282,23 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E,
         MS v = task == 0 ? after : sim;
         v.tw = 32;
         double p = task == 0 ? 1.0 : malus_dtl;
-        sim_any<NEW>(E, distance, length - 1, v, p);
-        if (task == 1) sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, p);
-        s_xch[lane] = p;
-        __syncthreads();
-        dal = s_xch[0]; dtl = s_xch[32];
-        __syncthreads();
+        sim_any<NEW>(distance, length - 1, v, p);
+        if (task == 1) sim_literal(TB((int64_t)v.pos - (int64_t)distance), v, p);
+        dal = __shfl(p, 0); dtl = __shfl(p, 32);
       } else {
         dal = 1.0;
-        sim_any<NEW>(E, distance, length - 1, after, dal);
+        sim_any<NEW>(distance, length - 1, after, dal);
         MS v = sim;
         dtl = malus_dtl;
-        sim_any<NEW>(E, distance, length - 1, v, dtl);
-        sim_literal(E, TB(E, (int64_t)v.pos - (int64_t)distance), v, dtl);
+        sim_any<NEW>(distance, length - 1, v, dtl);
+        sim_literal(TB((int64_t)v.pos - (int64_t)distance), v, dtl);
       }
       if (head_lit * dal * fmax0(0.064 - (double)distance * 1.0e-9 - (double)length * 3.0e-5) > soe) return W_LIT_DL;
       if (dtl > soe) return W_DL_LIT;
     }
     if (expanded_dlc > strict_dlc) return W_EXPAND;
   }
-  if (E.cv >= 2) {                                                                 // Test_Split_DL :901-944
+  if (s_E.cv >= 2) {                                                                 // Test_Split_DL :901-944
     PROF_T0;
     constexpr int LOW = NEW - 1 > 0 ? NEW - 1 : 0;
     const double malus = fmax0(0.27 - (double)distance * 2.0e-6);
@@ -319,16 +318,14 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E,
           double p = malus;
           MS v = sim;
           v.tw = tw;
-          sim_any<LOW>(E, distance, cut, v, p);
+          sim_any<LOW>(distance, cut, v, p);
           pm = p; pf = p;
-          if (!(p <= soe)) { sim_any<LOW>(E, distance, length - cut, v, p); pf = p; }
+          if (!(p <= soe)) { sim_any<LOW>(distance, length - cut, v, p); pf = p; }
         }
-        s_xch[2 * lane] = pm; s_xch[2 * lane + 1] = pf;
-        __syncthreads();
         for (int k = 0; k < nc; k++) {
-          if (!(s_xch[2 * k * tw] <= soe)) { const double p = s_xch[2 * k * tw + 1]; if (p > best_prob) { best_prob = p; best_cut = cuts[k]; } }
+          const double pmk = __shfl(pm, k * tw), pfk = __shfl(pf, k * tw);
+          if (!(pmk <= soe)) { if (pfk > best_prob) { best_prob = pfk; best_cut = cuts[k]; } }
         }
-        __syncthreads();
       } else if (sim.tw > 1) {
         // A team of sim.tw lanes runs this simulation in step (same state, same branches).  Its cuts are independent simulations
         // again: a lane each, tw at a time; the results go round the team by cross-lane reads and are taken in cut order.
@@ -346,9 +343,9 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E,
             double p = malus;
             MS v = sim;
             v.tw = 1;
-            sim_any<LOW>(E, distance, cut, v, p);
+            sim_any<LOW>(distance, cut, v, p);
             pm = p; pf = p;
-            if (!(p <= soe)) { sim_any<LOW>(E, distance, length - cut, v, p); pf = p; }
+            if (!(p <= soe)) { sim_any<LOW>(distance, length - cut, v, p); pf = p; }
           }
           for (int j = 0; j < tw && r * tw + j < nc; j++) {
             const double pmk = __shfl(pm, tb + j), pfk = __shfl(pf, tb + j);
@@ -361,9 +358,9 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E,
           if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) {
             double p = malus;
             MS v = sim;
-            sim_any<LOW>(E, distance, cut, v, p);
+            sim_any<LOW>(distance, cut, v, p);
             if (!(p <= soe)) {
-              sim_any<LOW>(E, distance, rest, v, p);
+              sim_any<LOW>(distance, rest, v, p);
               if (p > best_prob) { best_prob = p; best_cut = cut; }
             }
           }
@@ -376,98 +373,98 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(const Enc &E,
   return W_STRICT;
 }
 
-template <int R> __device__ __noinline__ void sim_any_impl(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) {
+template <int R> __device__ __noinline__ void sim_any_impl(uint32_t distance, int length, MS &sim, double &prob) {
   if constexpr (R - 1 < 0) {
-    sim_strict(E, distance, length, sim, prob);
+    sim_strict(distance, length, sim, prob);
   } else {
     constexpr int NEW = R - 1;
     int cut = 2;
-    switch (decide<NEW, false>(E, distance, length, sim, cut)) {
+    switch (decide<NEW, false>(distance, length, sim, cut)) {
       case W_LIT_DL:
-        sim_literal(E, TB(E, (int64_t)sim.pos - (int64_t)distance), sim, prob);
-        sim_any<NEW>(E, distance, length - 1, sim, prob);
+        sim_literal(TB((int64_t)sim.pos - (int64_t)distance), sim, prob);
+        sim_any<NEW>(distance, length - 1, sim, prob);
         break;
       case W_DL_LIT:
-        sim_any<NEW>(E, distance, length - 1, sim, prob);
-        sim_literal(E, TB(E, (int64_t)sim.pos - (int64_t)distance), sim, prob);
+        sim_any<NEW>(distance, length - 1, sim, prob);
+        sim_literal(TB((int64_t)sim.pos - (int64_t)distance), sim, prob);
         break;
       case W_EXPAND:
-        for (int x = 1; x <= length; x++) sim_literal(E, TB(E, (int64_t)sim.pos - (int64_t)distance), sim, prob);
+        for (int x = 1; x <= length; x++) sim_literal(TB((int64_t)sim.pos - (int64_t)distance), sim, prob);
         break;
       case W_SPLIT:
-        sim_any<NEW>(E, distance, cut, sim, prob);
-        sim_any<NEW>(E, distance, length - cut, sim, prob);
+        sim_any<NEW>(distance, cut, sim, prob);
+        sim_any<NEW>(distance, length - cut, sim, prob);
         break;
       default:
-        sim_strict(E, distance, length, sim, prob);
+        sim_strict(distance, length, sim, prob);
     }
   }
 }
-template <int R> __device__ __forceinline__ void sim_any(const Enc &E, uint32_t distance, int length, MS &sim, double &prob) {
-  if constexpr (R - 1 < 0) sim_strict(E, distance, length, sim, prob);      // limit used up (:761-764): no call in between
-  else sim_any_impl<R>(E, distance, length, sim, prob);
+template <int R> __device__ __forceinline__ void sim_any(uint32_t distance, int length, MS &sim, double &prob) {
+  if constexpr (R - 1 < 0) sim_strict(distance, length, sim, prob);      // limit used up (:761-764): no call in between
+  else sim_any_impl<R>(distance, length, sim, prob);
 }
 
 // ---------------------------------------------------------------- range coder :964-1039
 
-__device__ inline void put_byte(Enc &E, uint32_t b) { if (E.olen < E.cap) E.out[E.olen] = (uint8_t)b; E.olen++; }
+__device__ inline void put_byte(uint32_t b) { if (s_E.olen < s_E.cap) s_E.out[s_E.olen] = (uint8_t)b; s_E.olen++; }
 
-__device__ __noinline__ void shift_low(Enc &E) {
-  const uint64_t top = E.low >> 32;
-  const uint32_t bottom = (uint32_t)E.low;
+__device__ __noinline__ void shift_low() {
+  const uint64_t top = s_E.low >> 32;
+  const uint32_t bottom = (uint32_t)s_E.low;
   if (bottom < 0xFF000000u || top != 0) {
-    uint32_t temp = E.cache;
+    uint32_t temp = s_E.cache;
     const uint32_t carry = (uint32_t)top & 0xFF;
-    do { put_byte(E, (temp + carry) & 0xFF); temp = 0xFF; E.cache_size--; } while (E.cache_size != 0);
-    E.cache = (bottom >> 24) & 0xFF;
+    do { put_byte((temp + carry) & 0xFF); temp = 0xFF; s_E.cache_size--; } while (s_E.cache_size != 0);
+    s_E.cache = (bottom >> 24) & 0xFF;
   }
-  E.cache_size++;
-  E.low = (uint64_t)(uint32_t)(bottom << 8);
+  s_E.cache_size++;
+  s_E.low = (uint64_t)(uint32_t)(bottom << 8);
 }
 
-__device__ inline void normalize(Enc &E) { if (E.width < (1u << 24)) { E.width <<= 8; shift_low(E); } }
+__device__ inline void normalize() { if (s_E.width < (1u << 24)) { s_E.width <<= 8; shift_low(); } }
 
-__device__ inline void encode_bit(Enc &E, uint16_t &prob, uint32_t symbol) {
-  const uint32_t cur = prob, bound = (E.width >> 11) * cur;
-  if (symbol == 0) { E.width = bound; normalize(E); prob = (uint16_t)(cur + ((2048 - cur) >> 5)); }
-  else { E.low += bound; E.width -= bound; normalize(E); prob = (uint16_t)(cur - (cur >> 5)); }
+__device__ inline void encode_bit(uint16_t &prob, uint32_t symbol) {
+  const uint32_t cur = prob, bound = (s_E.width >> 11) * cur;
+  if (symbol == 0) { s_E.width = bound; normalize(); prob = (uint16_t)(cur + ((2048 - cur) >> 5)); }
+  else { s_E.low += bound; s_E.width -= bound; normalize(); prob = (uint16_t)(cur - (cur >> 5)); }
 }
 
-__device__ __forceinline__ void bit_tree_encode(Enc &E, uint16_t *prob, int num_bits, uint32_t symbol) {
+__device__ __forceinline__ void bit_tree_encode(uint16_t *prob, int num_bits, uint32_t symbol) {
   uint32_t m = 1;
-  for (int i = num_bits - 1; i >= 0; i--) { const uint32_t bit = (symbol >> i) & 1; encode_bit(E, prob[m], bit); m = 2 * m + bit; }
+  for (int i = num_bits - 1; i >= 0; i--) { const uint32_t bit = (symbol >> i) & 1; encode_bit(prob[m], bit); m = 2 * m + bit; }
 }
-__device__ __forceinline__ void bit_tree_rev_encode(Enc &E, uint16_t *prob, int num_bits, uint32_t symbol) {
+__device__ __forceinline__ void bit_tree_rev_encode(uint16_t *prob, int num_bits, uint32_t symbol) {
   uint32_t m = 1;
-  for (int c = num_bits; c >= 1; c--) { const uint32_t bit = symbol & 1; encode_bit(E, prob[m], bit); m = 2 * m + bit; symbol >>= 1; }
+  for (int c = num_bits; c >= 1; c--) { const uint32_t bit = symbol & 1; encode_bit(prob[m], bit); m = 2 * m + bit; symbol >>= 1; }
 }
 
 // ---------------------------------------------------------------- the machine :1045-1361
 
-__device__ __noinline__ void emit_literal(Enc &E, uint32_t b) {                   // LZ77_emits_literal_byte :1097-1130
+__device__ __noinline__ void emit_literal(uint32_t b) {                   // LZ77_emits_literal_byte :1097-1130
   PROF_T0;
   LzProbs &P = s_P;
-  MS &S = E.ES;
+  MS &S = s_E.ES;
   const int idx = lit_idx(S.prev_byte);
-  const uint32_t b_match = TB(E, (int64_t)S.pos - (int64_t)S.rep[0] - 1);
+  const uint32_t b_match = TB((int64_t)S.pos - (int64_t)S.rep[0] - 1);
   if (b == b_match && S.pos > (uint64_t)(uint32_t)(S.rep[0] + 1) &&
-      (E.cv == 0 || test_short_rep(E, S) > test_simple_literal(E, b, b_match, idx, S))) {
-    encode_bit(E, P.match[S.state][S.pos_state], 1);
-    encode_bit(E, P.rep[S.state], 1);
-    encode_bit(E, P.g0[S.state], 0);
-    encode_bit(E, P.rep0_long[S.state][S.pos_state], 0);
+      (s_E.cv == 0 || test_short_rep(S) > test_simple_literal(b, b_match, idx, S))) {
+    encode_bit(P.match[S.state][S.pos_state], 1);
+    encode_bit(P.rep[S.state], 1);
+    encode_bit(P.g0[S.state], 0);
+    encode_bit(P.rep0_long[S.state][S.pos_state], 0);
     S.state = T_SREP[S.state];
   } else {
-    encode_bit(E, P.match[S.state][S.pos_state], 0);
+    encode_bit(P.match[S.state][S.pos_state], 0);
     uint16_t *prob = P.lit + idx;
     uint32_t symb = b | 0x100;
     if (S.state < 7) {
-      do { encode_bit(E, prob[symb >> 8], (symb >> 7) & 1); symb <<= 1; } while (symb < 0x10000);
+      do { encode_bit(prob[symb >> 8], (symb >> 7) & 1); symb <<= 1; } while (symb < 0x10000);
     } else {
       uint32_t offs = 0x100, match = b_match;
       do {
         match <<= 1;
-        encode_bit(E, prob[offs + (match & offs) + (symb >> 8)], (symb >> 7) & 1);
+        encode_bit(prob[offs + (match & offs) + (symb >> 8)], (symb >> 7) & 1);
         symb <<= 1;
         offs &= ~(match ^ symb);
       } while (symb < 0x10000);
@@ -480,79 +477,79 @@ __device__ __noinline__ void emit_literal(Enc &E, uint32_t b) {                 
   PROF_ADD(1);
 }
 
-__device__ void encode_length(Enc &E, bool rep, uint32_t length) {            // :1160-1181
+__device__ void encode_length(bool rep, uint32_t length) {            // :1160-1181
   LenProbs &pl = rep ? s_P.rep_len : s_P.len;
   uint32_t len = length - 2;
-  const uint32_t ps = E.ES.pos_state;
-  if (len < 8) { encode_bit(E, pl.c1, 0); bit_tree_encode(E, pl.low[ps], 3, len); }
+  const uint32_t ps = s_E.ES.pos_state;
+  if (len < 8) { encode_bit(pl.c1, 0); bit_tree_encode(pl.low[ps], 3, len); }
   else {
-    encode_bit(E, pl.c1, 1); len -= 8;
-    if (len < 8) { encode_bit(E, pl.c2, 0); bit_tree_encode(E, pl.mid[ps], 3, len); }
-    else { encode_bit(E, pl.c2, 1); len -= 8; bit_tree_encode(E, pl.high, 8, len); }
+    encode_bit(pl.c1, 1); len -= 8;
+    if (len < 8) { encode_bit(pl.c2, 0); bit_tree_encode(pl.mid[ps], 3, len); }
+    else { encode_bit(pl.c2, 1); len -= 8; bit_tree_encode(pl.high, 8, len); }
   }
 }
 
-__device__ __noinline__ void write_simple_match(Enc &E, uint32_t dist_ip, uint32_t length) {   // :1183-1255
+__device__ __noinline__ void write_simple_match(uint32_t dist_ip, uint32_t length) {   // :1183-1255
   LzProbs &P = s_P;
-  MS &S = E.ES;
-  encode_bit(E, P.rep[S.state], 0);
+  MS &S = s_E.ES;
+  encode_bit(P.rep[S.state], 0);
   S.state = T_MATCH[S.state];
-  encode_length(E, false, length);
+  encode_length(false, length);
   const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(dist_ip);
-  bit_tree_encode(E, P.slot[len_state], 6, ds);
+  bit_tree_encode(P.slot[len_state], 6, ds);
   if (ds >= 4) {
     const int footer = (int)(ds >> 1) - 1;
     const uint32_t base = (2 | (ds & 1)) << footer, red = dist_ip - base;
-    if (ds < 14) bit_tree_rev_encode(E, P.pos + ((int)base - (int)ds - 1) + 1, footer, red);
+    if (ds < 14) bit_tree_rev_encode(P.pos + ((int)base - (int)ds - 1) + 1, footer, red);
     else {
       const uint32_t value = red >> 4;
       for (int i = footer - 4 - 1; i >= 0; i--) {                                  // Encode_Direct_Bits :1205-1215
-        E.width >>= 1;
-        E.low += (uint64_t)E.width & (0 - (uint64_t)((value >> i) & 1));
-        normalize(E);
+        s_E.width >>= 1;
+        s_E.low += (uint64_t)s_E.width & (0 - (uint64_t)((value >> i) & 1));
+        normalize();
       }
-      bit_tree_rev_encode(E, P.align, 4, red & 15);
+      bit_tree_rev_encode(P.align, 4, red & 15);
     }
   }
   S.rep[3] = S.rep[2]; S.rep[2] = S.rep[1]; S.rep[1] = S.rep[0]; S.rep[0] = dist_ip;
 }
 
-__device__ __noinline__ void write_repeat_match(Enc &E, int index_rm, uint32_t length) {   // :1257-1286
+__device__ __noinline__ void write_repeat_match(int index_rm, uint32_t length) {   // :1257-1286
   LzProbs &P = s_P;
-  MS &S = E.ES;
-  encode_bit(E, P.rep[S.state], 1);
+  MS &S = s_E.ES;
+  encode_bit(P.rep[S.state], 1);
   switch (index_rm) {
-    case 0: encode_bit(E, P.g0[S.state], 0); encode_bit(E, P.rep0_long[S.state][S.pos_state], 1); break;
-    case 1: encode_bit(E, P.g0[S.state], 1); encode_bit(E, P.g1[S.state], 0); break;
-    case 2: encode_bit(E, P.g0[S.state], 1); encode_bit(E, P.g1[S.state], 1); encode_bit(E, P.g2[S.state], 0); break;
-    default: encode_bit(E, P.g0[S.state], 1); encode_bit(E, P.g1[S.state], 1); encode_bit(E, P.g2[S.state], 1); break;
+    case 0: encode_bit(P.g0[S.state], 0); encode_bit(P.rep0_long[S.state][S.pos_state], 1); break;
+    case 1: encode_bit(P.g0[S.state], 1); encode_bit(P.g1[S.state], 0); break;
+    case 2: encode_bit(P.g0[S.state], 1); encode_bit(P.g1[S.state], 1); encode_bit(P.g2[S.state], 0); break;
+    default: encode_bit(P.g0[S.state], 1); encode_bit(P.g1[S.state], 1); encode_bit(P.g2[S.state], 1); break;
   }
   const uint32_t aux = S.rep[index_rm];
   for (int i = index_rm; i >= 1; i--) S.rep[i] = S.rep[i - 1];
   S.rep[0] = aux;
-  encode_length(E, true, length);
+  encode_length(true, length);
   S.state = T_REP[S.state];
 }
 
-__device__ __noinline__ void write_strict(Enc &E, uint32_t distance, int length) {   // Write_Strict_DL_Code :1288-1328
-  MS &S = E.ES;
+__device__ __noinline__ void write_strict(uint32_t distance, int length) {   // Write_Strict_DL_Code :1288-1328
+  MS &S = s_E.ES;
   const uint32_t dist_ip = distance - 1;
   int found = -1;
-  encode_bit(E, s_P.match[S.state][S.pos_state], 1);
+  encode_bit(s_P.match[S.state][S.pos_state], 1);
   for (int i = 0; i < 4; i++) if (dist_ip == S.rep[i]) { found = i; break; }
-  if (found >= 0 && (E.cv == 0 || test_repeat_match(E, found, (uint32_t)length, S) >= test_simple_match(E, dist_ip, (uint32_t)length, S) * 0.55))
-    write_repeat_match(E, found, (uint32_t)length);
+  if (found >= 0 && (s_E.cv == 0 || test_repeat_match(found, (uint32_t)length, S) >= test_simple_match(dist_ip, (uint32_t)length, S) * 0.55))
+    write_repeat_match(found, (uint32_t)length);
   else
-    write_simple_match(E, dist_ip, (uint32_t)length);
+    write_simple_match(dist_ip, (uint32_t)length);
   S.pos += (uint64_t)length;
   S.pos_state = (uint32_t)S.pos & LZ_PBM;
-  S.prev_byte = TB(E, (int64_t)S.pos - 1);
+  S.prev_byte = TB((int64_t)S.pos - 1);
 }
 
 // LZ77_emits_DL_code :1355-1361 = Write_any_DL_code (..., ES, max_recursion): the writing instance of Generic_any_DL_Code does not
 // lower its limit (:756-760), so its own recursion can go a match length deep; it is a work list here.  An item is a length
 // still to be written at `distance`, or the literal that follows a shortened match (:797-805).
-__device__ __noinline__ void emit_dl(Enc &E, uint32_t distance, int length0) {
+__device__ __noinline__ void emit_dl(uint32_t distance, int length0) {
   PROF_T0;
   constexpr uint16_t POST_LIT = 0xFFFF;
   uint16_t stack[2 * 280];
@@ -560,12 +557,12 @@ __device__ __noinline__ void emit_dl(Enc &E, uint32_t distance, int length0) {
   stack[sp++] = (uint16_t)length0;
   while (sp > 0) {
     const uint16_t it = stack[--sp];
-    if (it == POST_LIT) { emit_literal(E, TB(E, (int64_t)E.ES.pos - (int64_t)distance)); continue; }
+    if (it == POST_LIT) { emit_literal(TB((int64_t)s_E.ES.pos - (int64_t)distance)); continue; }
     const int length = it;
     int cut = 2;
-    switch (decide<2, true>(E, distance, length, E.ES, cut)) {
+    switch (decide<2, true>(distance, length, s_E.ES, cut)) {
       case W_LIT_DL:
-        emit_literal(E, TB(E, (int64_t)E.ES.pos - (int64_t)distance));
+        emit_literal(TB((int64_t)s_E.ES.pos - (int64_t)distance));
         stack[sp++] = (uint16_t)(length - 1);
         break;
       case W_DL_LIT:
@@ -573,14 +570,14 @@ __device__ __noinline__ void emit_dl(Enc &E, uint32_t distance, int length0) {
         stack[sp++] = (uint16_t)(length - 1);
         break;
       case W_EXPAND:
-        for (int x = 1; x <= length; x++) emit_literal(E, TB(E, (int64_t)E.ES.pos - (int64_t)distance));
+        for (int x = 1; x <= length; x++) emit_literal(TB((int64_t)s_E.ES.pos - (int64_t)distance));
         break;
       case W_SPLIT:
         stack[sp++] = (uint16_t)(length - cut);
         stack[sp++] = (uint16_t)cut;
         break;
       default:
-        write_strict(E, distance, length);
+        write_strict(distance, length);
     }
   }
   PROF_ADD(2);
@@ -588,12 +585,12 @@ __device__ __noinline__ void emit_dl(Enc &E, uint32_t distance, int length0) {
 
 // ---------------------------------------------------------------- Estimate_DL_Codes_for_LZ77 :1363-1498
 
-struct ScoreCtx { const Matches *m; int old_index, last_pos_any; MS sim_new; double head_lit_prob; };
+struct ScoreCtx { int old_index, last_pos_any; MS sim_new; double head_lit_prob; };
 
 // One candidate of Scoring (:1404-1468): the probability of the message that starts with match i of set m.
-template <int LEVEL> __device__ void scoring(const Enc &E, const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set);
-template <int LEVEL> __device__ inline double score_candidate(const Enc &E, const ScoreCtx &S, const MS &state, int start, int m, int i) {
-  const Matches &M = S.m[m];
+template <int LEVEL> __device__ void scoring(const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set);
+template <int LEVEL> __device__ inline double score_candidate(const ScoreCtx &S, const MS &state, int start, int m, int i) {
+  const Matches &M = s_MM[m];
   const int last_pos_i = M.len[i] + (m != S.old_index ? 1 : 0);
   MS t; double p;
   if (m != S.old_index && start == 1) { t = S.sim_new; p = S.head_lit_prob; } else { t = state; p = 1.0; }
@@ -602,39 +599,39 @@ template <int LEVEL> __device__ inline double score_candidate(const Enc &E, cons
   if (m == S.old_index) trunc = M.len[i] - start + 1;
   else if (start == 1) trunc = M.len[i];
   else trunc = M.len[i] - start + 2;
-  if (trunc == 1) sim_literal(E, TB(E, (int64_t)state.pos), t, p);
-  else sim_any<1>(E, (uint32_t)M.dist[i], trunc, t, p);
+  if (trunc == 1) sim_literal(TB((int64_t)state.pos), t, p);
+  else sim_any<1>((uint32_t)M.dist[i], trunc, t, p);
   if constexpr (LEVEL < 2) {
     if (last_pos_i < S.last_pos_any) {
       double tail; int si = 1, sm = 0;
-      scoring<LEVEL + 1>(E, S, t, last_pos_i + 1, tail, si, sm);
+      scoring<LEVEL + 1>(S, t, last_pos_i + 1, tail, si, sm);
       p = p * tail;
     }
   }
   return p;
 }
 
-template <int LEVEL> __device__ __noinline__ void scoring_impl(const Enc &E, const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {   // :1385-1469
+template <int LEVEL> __device__ __noinline__ void scoring_impl(const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {   // :1385-1469
   prob = 0.0;
   for (int m = 0; m <= 1; m++) {
-    const Matches &M = S.m[m];
+    const Matches &M = s_MM[m];
     for (int i = 1; i <= M.count; i++) {
       const int last_pos_i = M.len[i] + (m != S.old_index ? 1 : 0);
       if (last_pos_i < start) continue;
       if (last_pos_i < S.last_pos_any && LEVEL >= 2) continue;
-      const double p = score_candidate<LEVEL>(E, S, state, start, m, i);
+      const double p = score_candidate<LEVEL>(S, state, start, m, i);
       if (p > prob) { prob = p; index = i; match_set = m; }
     }
   }
 }
-template <int LEVEL> __device__ void scoring(const Enc &E, const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {
-  scoring_impl<LEVEL>(E, S, state, start, prob, index, match_set);
+template <int LEVEL> __device__ void scoring(const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {
+  scoring_impl<LEVEL>(S, state, start, prob, index, match_set);
 }
 
 // Scoring at level 1, start 1, called from the chain (all lanes in step): every match of both sets is a candidate (their
 // last positions are >= 1), one lane each; the best is then picked by all lanes in the reference's order (first strict maximum).
-__device__ __noinline__ void scoring_top(const Enc &E, const ScoreCtx &S, const MS &state, double &prob, int &index, int &match_set) {
-  const int lane = (int)threadIdx.x, c0 = S.m[0].count, total = c0 + S.m[1].count;
+__device__ __noinline__ void scoring_top(const ScoreCtx &S, const MS &state, double &prob, int &index, int &match_set) {
+  const int lane = (int)threadIdx.x, c0 = s_MM[0].count, total = c0 + s_MM[1].count;
   const int tw = team_width(total), per_round = 64 / tw;                           // a team of tw lanes per candidate
   MS st = state;
   st.tw = tw;
@@ -642,34 +639,31 @@ __device__ __noinline__ void scoring_top(const Enc &E, const ScoreCtx &S, const 
   for (int base = 0; base < total; base += per_round) {
     const int k = base + lane / tw;
     double p = 0.0;
-    if (k < total) p = score_candidate<1>(E, S, st, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
-    s_xch[lane] = p;
-    __syncthreads();
+    if (k < total) p = score_candidate<1>(S, st, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
     const int cnt = total - base < per_round ? total - base : per_round;
     for (int j = 0; j < cnt; j++) {
-      const double pj = s_xch[j * tw];
+      const double pj = __shfl(p, j * tw);
       const int kk = base + j;
       if (pj > prob) { prob = pj; index = (kk < c0 ? kk : kk - c0) + 1; match_set = kk < c0 ? 0 : 1; }
     }
-    __syncthreads();
   }
 }
 
-__device__ void estimate_dl_codes(const Enc &E, const Matches *matches, int old_index, uint32_t prefix1, int &best_index, int &best_set) {
+__device__ void estimate_dl_codes(int old_index, uint32_t prefix1, int &best_index, int &best_set) {
   PROF_T0;
   ScoreCtx S;
-  S.m = matches; S.old_index = old_index; S.last_pos_any = 0; S.sim_new = E.ES;
+  S.old_index = old_index; S.last_pos_any = 0; S.sim_new = s_E.ES;
   for (int m = 0; m <= 1; m++)
-    for (int i = 1; i <= matches[m].count; i++) {
-      const int lp = matches[m].len[i] + (m != old_index ? 1 : 0);
+    for (int i = 1; i <= s_MM[m].count; i++) {
+      const int lp = s_MM[m].len[i] + (m != old_index ? 1 : 0);
       if (lp > S.last_pos_any) S.last_pos_any = lp;
     }
   S.head_lit_prob = 1.0;
-  sim_literal(E, prefix1, S.sim_new, S.head_lit_prob);
+  sim_literal(prefix1, S.sim_new, S.head_lit_prob);
   best_index = 1; best_set = old_index;
   double best;
-  const MS sim_old = E.ES;
-  scoring_top(E, S, sim_old, best, best_index, best_set);
+  const MS sim_old = s_E.ES;
+  scoring_top(S, sim_old, best, best_index, best_set);
   PROF_ADD(3);
 }
 
@@ -687,6 +681,7 @@ struct BT4 {
   int cur;                                         // current_match_index
   uint32_t cur_literal;
 };
+__shared__ BT4 s_B;
 constexpr int BT_LOOK = 273, BT_NICE = 162, BT_MIN = 2, BT_DEPTH = 48, BT_OPTS = 4096;
 
 __device__ inline uint32_t crc_tab(uint32_t i) {                                  // Hash234.crcTable :1091-1101
@@ -695,7 +690,7 @@ __device__ inline uint32_t crc_tab(uint32_t i) {                                
   for (int j = 0; j < 8; j++) r = (r & 1) ? (r >> 1) ^ 0xEDB88320u : r >> 1;
   return r;
 }
-#define BUF(i) ((uint32_t)E.in[(int64_t)(i) + B.moved])
+#define BUF(i) ((uint32_t)s_E.in[(int64_t)(i) + s_B.moved])
 
 // First index k in [len, limit) at which buf [a + k] /= buf [b + k], or limit: the byte loops of lz77.adb:1183-1191, 1287-1291,
 // 1331-1335, 1456-1458, eight bytes at a time while eight remain below the limit (nothing beyond a + limit / b + limit is read).
@@ -712,93 +707,94 @@ __device__ inline int bt_extend(const uint8_t *buf, int64_t a, int64_t b, int le
   return len;
 }
 
-__device__ inline int bt_available(const BT4 &B) { return B.writePos - B.readPos - 1; }
+__device__ inline int bt_available() { return s_B.writePos - s_B.readPos - 1; }
 
-__device__ inline int bt_move_pos(BT4 &B) {                                       // Move_Pos_in_BT4 :1127-1150 (finishing = False, :959)
-  B.readPos++;
-  int avail = bt_available(B);
-  if (avail < BT_NICE) { B.pendingSize++; avail = 0; }
+__device__ inline int bt_move_pos() {                                       // Move_Pos_in_BT4 :1127-1150 (finishing = False, :959)
+  s_B.readPos++;
+  int avail = bt_available();
+  if (avail < BT_NICE) { s_B.pendingSize++; avail = 0; }
   if (avail != 0) {
-    B.lzPos++;                                     // (normalisation at Integer'Last cannot be reached below 2 GiB of input)
-    B.cyclicPos++;
-    if (B.cyclicPos == B.sbs) B.cyclicPos = 0;
+    s_B.lzPos++;                                     // (normalisation at Integer'Last cannot be reached below 2 GiB of input)
+    s_B.cyclicPos++;
+    if (s_B.cyclicPos == s_B.sbs) s_B.cyclicPos = 0;
   }
   return avail;
 }
 
-__device__ inline void bt_hashes(const Enc &E, BT4 &B) {                           // calcHashes :1061-1069
-  const int off = B.readPos;
+__device__ inline void bt_hashes() {                           // calcHashes :1061-1069
+  const int off = s_B.readPos;
   uint32_t t = crc_tab(BUF(off)) ^ BUF(off + 1);
-  B.h2 = t & 1023;
+  s_B.h2 = t & 1023;
   t ^= BUF(off + 2) << 8;
-  B.h3 = t & 65535;
+  s_B.h3 = t & 65535;
   t ^= crc_tab(BUF(off + 3)) << 5;
-  B.h4 = t & B.hash_4_mask;
+  s_B.h4 = t & s_B.hash_4_mask;
 }
 
-__device__ __noinline__ void bt_skip_update(const Enc &E, BT4 &B, int niceLenLimit, int currentMatch) {   // Skip_and_Update_Tree :1154-1206
-  int32_t *tree = B.tree;
-  int depth = BT_DEPTH, ptr0 = B.cyclicPos * 2 + 1, ptr1 = B.cyclicPos * 2, len0 = 0, len1 = 0;
-  const int rp = B.readPos;
+__device__ __noinline__ void bt_skip_update(int niceLenLimit, int currentMatch) {   // Skip_and_Update_Tree :1154-1206
+  int32_t *tree = s_B.tree;
+  int depth = BT_DEPTH, ptr0 = s_B.cyclicPos * 2 + 1, ptr1 = s_B.cyclicPos * 2, len0 = 0, len1 = 0;
+  const int rp = s_B.readPos;
   for (;;) {
-    const int delta0 = B.lzPos - currentMatch;
-    if (depth == 0 || delta0 >= B.max_dist) { tree[ptr0] = -1; tree[ptr1] = -1; return; }
+    const int delta0 = s_B.lzPos - currentMatch;
+    if (depth == 0 || delta0 >= s_B.max_dist) { tree[ptr0] = -1; tree[ptr1] = -1; return; }
     depth--;
-    const int pair = (B.cyclicPos - delta0 + (B.cyclicPos - delta0 < 0 ? B.sbs : 0)) * 2;
+    const int pair = (s_B.cyclicPos - delta0 + (s_B.cyclicPos - delta0 < 0 ? s_B.sbs : 0)) * 2;
     int len = len0 < len1 ? len0 : len1;
-    len = bt_extend(E.in + B.moved, (int64_t)rp - delta0, rp, len, niceLenLimit);
+    len = bt_extend(s_E.in + s_B.moved, (int64_t)rp - delta0, rp, len, niceLenLimit);
     if (len == niceLenLimit) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return; }
     if (BUF(rp + len - delta0) < BUF(rp + len)) { tree[ptr1] = currentMatch; ptr1 = pair + 1; currentMatch = tree[ptr1]; len1 = len; }
     else { tree[ptr0] = currentMatch; ptr0 = pair; currentMatch = tree[ptr0]; len0 = len; }
   }
 }
 
-__device__ void bt_skip(const Enc &E, BT4 &B, int len) {                           // BT4_Algo.Skip :1208-1232
+__device__ void bt_skip(int len) {                           // BT4_Algo.Skip :1208-1232
   for (int count = len; count >= 1; count--) {
     int nice = BT_NICE;
-    const int avail = bt_move_pos(B);
+    const int avail = bt_move_pos();
     if (avail < nice) { if (avail == 0) continue; nice = avail; }
-    bt_hashes(E, B);
-    const int currentMatch = B.hash4[B.h4];
-    B.hash2[B.h2] = B.lzPos; B.hash3[B.h3] = B.lzPos; B.hash4[B.h4] = B.lzPos;
-    bt_skip_update(E, B, nice, currentMatch);
+    bt_hashes();
+    const int currentMatch = s_B.hash4[s_B.h4];
+    s_B.hash2[s_B.h2] = s_B.lzPos; s_B.hash3[s_B.h3] = s_B.lzPos; s_B.hash4[s_B.h4] = s_B.lzPos;
+    bt_skip_update(nice, currentMatch);
   }
 }
 
-__device__ __noinline__ void bt_get_matches(const Enc &E, BT4 &B, Matches &M) {     // BT4_Algo.Read_One_and_Get_Matches :1234-1361
-  int32_t *tree = B.tree;
+__device__ __noinline__ void bt_get_matches(int set) {
+  Matches &M = s_MM[set];     // BT4_Algo.Read_One_and_Get_Matches :1234-1361
+  int32_t *tree = s_B.tree;
   int matchLenLimit = BT_LOOK, nice = BT_NICE;
   M.count = 0;
-  const int avail = bt_move_pos(B);
+  const int avail = bt_move_pos();
   if (avail < matchLenLimit) {
     if (avail == 0) return;
     matchLenLimit = avail;
     if (nice > avail) nice = avail;
   }
-  const int rp = B.readPos;
-  bt_hashes(E, B);
-  int delta2 = B.lzPos - B.hash2[B.h2];
-  const int delta3 = B.lzPos - B.hash3[B.h3];
-  int currentMatch = B.hash4[B.h4];
-  B.hash2[B.h2] = B.lzPos; B.hash3[B.h3] = B.lzPos; B.hash4[B.h4] = B.lzPos;
+  const int rp = s_B.readPos;
+  bt_hashes();
+  int delta2 = s_B.lzPos - s_B.hash2[s_B.h2];
+  const int delta3 = s_B.lzPos - s_B.hash3[s_B.h3];
+  int currentMatch = s_B.hash4[s_B.h4];
+  s_B.hash2[s_B.h2] = s_B.lzPos; s_B.hash3[s_B.h3] = s_B.lzPos; s_B.hash4[s_B.h4] = s_B.lzPos;
   int lenBest = 0;
-  if (delta2 < B.max_dist && BUF(rp - delta2) == BUF(rp)) { lenBest = 2; M.count = 1; M.len[1] = 2; M.dist[1] = delta2; }
-  if (delta2 != delta3 && delta3 < B.max_dist && BUF(rp - delta3) == BUF(rp)) { lenBest = 3; M.count++; M.dist[M.count] = delta3; delta2 = delta3; }
+  if (delta2 < s_B.max_dist && BUF(rp - delta2) == BUF(rp)) { lenBest = 2; M.count = 1; M.len[1] = 2; M.dist[1] = delta2; }
+  if (delta2 != delta3 && delta3 < s_B.max_dist && BUF(rp - delta3) == BUF(rp)) { lenBest = 3; M.count++; M.dist[M.count] = delta3; delta2 = delta3; }
   if (M.count > 0) {
-    lenBest = bt_extend(E.in + B.moved, (int64_t)rp - delta2, rp, lenBest, matchLenLimit);
+    lenBest = bt_extend(s_E.in + s_B.moved, (int64_t)rp - delta2, rp, lenBest, matchLenLimit);
     M.len[M.count] = (uint16_t)lenBest;
-    if (lenBest >= nice) { bt_skip_update(E, B, nice, currentMatch); return; }
+    if (lenBest >= nice) { bt_skip_update(nice, currentMatch); return; }
   }
   if (lenBest < 3) lenBest = 3;
-  int depth = BT_DEPTH, ptr0 = B.cyclicPos * 2 + 1, ptr1 = B.cyclicPos * 2, len0 = 0, len1 = 0;
+  int depth = BT_DEPTH, ptr0 = s_B.cyclicPos * 2 + 1, ptr1 = s_B.cyclicPos * 2, len0 = 0, len1 = 0;
   for (;;) {
-    const int delta0 = B.lzPos - currentMatch;
-    if (depth == 0 || delta0 >= B.max_dist) { tree[ptr0] = -1; tree[ptr1] = -1; return; }
+    const int delta0 = s_B.lzPos - currentMatch;
+    if (depth == 0 || delta0 >= s_B.max_dist) { tree[ptr0] = -1; tree[ptr1] = -1; return; }
     depth--;
-    const int pair = (B.cyclicPos - delta0 + (B.cyclicPos - delta0 < 0 ? B.sbs : 0)) * 2;
+    const int pair = (s_B.cyclicPos - delta0 + (s_B.cyclicPos - delta0 < 0 ? s_B.sbs : 0)) * 2;
     int len = len0 < len1 ? len0 : len1;
     if (BUF(rp + len - delta0) == BUF(rp + len)) {
-      len = bt_extend(E.in + B.moved, (int64_t)rp - delta0, rp, len + 1, matchLenLimit);
+      len = bt_extend(s_E.in + s_B.moved, (int64_t)rp - delta0, rp, len + 1, matchLenLimit);
       if (len > lenBest) {
         lenBest = len;
         M.count++;
@@ -811,171 +807,172 @@ __device__ __noinline__ void bt_get_matches(const Enc &E, BT4 &B, Matches &M) { 
   }
 }
 
-__device__ int bt_fill_window(const Enc &E, BT4 &B, int len_initial) {             // Fill_Window :1389-1440, Move_Window :1375-1386
+__device__ int bt_fill_window(int len_initial) {             // Fill_Window :1389-1440, Move_Window :1375-1386
   int len = len_initial;
-  if (B.readPos >= B.buf_len - B.keepSizeAfter) {
-    const int moveOffset = ((B.readPos + 1 - B.keepSizeBefore) / 16) * 16;
-    B.moved += moveOffset;
-    B.readPos -= moveOffset; B.readLimit -= moveOffset; B.writePos -= moveOffset;
+  if (s_B.readPos >= s_B.buf_len - s_B.keepSizeAfter) {
+    const int moveOffset = ((s_B.readPos + 1 - s_B.keepSizeBefore) / 16) * 16;
+    s_B.moved += moveOffset;
+    s_B.readPos -= moveOffset; s_B.readLimit -= moveOffset; s_B.writePos -= moveOffset;
   }
-  if (len > B.buf_len - B.writePos) len = B.buf_len - B.writePos;
-  const uint64_t left = E.n - B.in_pos;
+  if (len > s_B.buf_len - s_B.writePos) len = s_B.buf_len - s_B.writePos;
+  const uint64_t left = s_E.n - s_B.in_pos;
   const int actual = (uint64_t)len < left ? len : (int)left;
-  B.writePos += actual; B.in_pos += (uint64_t)actual;
-  if (B.writePos >= B.keepSizeAfter) B.readLimit = B.writePos - B.keepSizeAfter;
-  if (B.pendingSize > 0 && B.readPos < B.readLimit) {                               // processPendingBytes :1397-1406
-    const int old = B.pendingSize;
-    B.readPos -= B.pendingSize;
-    B.pendingSize = 0;
-    bt_skip(E, B, old);
+  s_B.writePos += actual; s_B.in_pos += (uint64_t)actual;
+  if (s_B.writePos >= s_B.keepSizeAfter) s_B.readLimit = s_B.writePos - s_B.keepSizeAfter;
+  if (s_B.pendingSize > 0 && s_B.readPos < s_B.readLimit) {                               // processPendingBytes :1397-1406
+    const int old = s_B.pendingSize;
+    s_B.readPos -= s_B.pendingSize;
+    s_B.pendingSize = 0;
+    bt_skip(old);
   }
   return actual;
 }
 
-__device__ inline int bt_match_len(const Enc &E, const BT4 &B, int distance, int limit) {   // Compute_Match_Length :1442-1460
+__device__ inline int bt_match_len(int distance, int limit) {   // Compute_Match_Length :1442-1460
   if (distance < 2) return 0;
-  return bt_extend(E.in + B.moved, (int64_t)B.readPos - distance, B.readPos, 0, limit);
+  return bt_extend(s_E.in + s_B.moved, (int64_t)s_B.readPos - distance, s_B.readPos, 0, limit);
 }
 __device__ inline bool much_smaller(int smallDist, int bigDist) { return (smallDist - 1) < (bigDist - 1) / 128; }   // :1469-1473
 
-__device__ void lz_read_one(const Enc &E, BT4 &B, Matches &M) {                     // Read_One_and_Get_Matches :1477-1503
+__device__ void lz_read_one(int set) {                     // Read_One_and_Get_Matches :1477-1503
   PROF_T0;
-  B.readAhead++;
-  bt_get_matches(E, B, M);
-  B.best_len_rep = 0;
-  const int a = bt_available(B), avail = a < BT_LOOK ? a : BT_LOOK;
+  s_B.readAhead++;
+  bt_get_matches(set);
+  s_B.best_len_rep = 0;
+  const int a = bt_available(), avail = a < BT_LOOK ? a : BT_LOOK;
   if (avail >= BT_MIN) {
     for (int rep = 0; rep < 4; rep++) {
-      const int len = bt_match_len(E, B, B.rep_dist[rep], avail);
-      B.len_rep[rep] = len;
-      if (len > B.best_len_rep) { B.best_rep_index = rep; B.best_len_rep = len; }
+      const int len = bt_match_len(s_B.rep_dist[rep], avail);
+      s_B.len_rep[rep] = len;
+      if (len > s_B.best_len_rep) { s_B.best_rep_index = rep; s_B.best_len_rep = len; }
     }
   } else {
-    for (int rep = 0; rep < 4; rep++) B.len_rep[rep] = 0;
+    for (int rep = 0; rep < 4; rep++) s_B.len_rep[rep] = 0;
   }
   PROF_ADD(4);
 }
 
-__device__ void lz_supplement(const BT4 &B, Matches &M) {                           // Get_supplemental_Matches_from_Repeat_Matches :1505-1566
-  if (M.count == 0 && B.best_len_rep >= BT_MIN) { M.dist[1] = B.rep_dist[B.best_rep_index]; M.len[1] = (uint16_t)B.best_len_rep; M.count = 1; }
+__device__ void lz_supplement(int set) {
+  Matches &M = s_MM[set];                           // Get_supplemental_Matches_from_Repeat_Matches :1505-1566
+  if (M.count == 0 && s_B.best_len_rep >= BT_MIN) { M.dist[1] = s_B.rep_dist[s_B.best_rep_index]; M.len[1] = (uint16_t)s_B.best_len_rep; M.count = 1; }
   for (int rep = 0; rep < 4; rep++) {
-    const int len = B.len_rep[rep];
+    const int len = s_B.len_rep[rep];
     if (len < BT_MIN) continue;
     int ins = 0;
     for (int i = M.count; i >= 1; i--) {
       if (len == M.len[i]) {
-        if (B.rep_dist[rep] != M.dist[i]) { ins = much_smaller(M.dist[i], B.rep_dist[rep]) ? i : i + 1; break; }
+        if (s_B.rep_dist[rep] != M.dist[i]) { ins = much_smaller(M.dist[i], s_B.rep_dist[rep]) ? i : i + 1; break; }
       } else if (i < M.count) {
         if (len > M.len[i] && len < M.len[i + 1]) { ins = i + 1; break; }
       } else if (len > M.len[i]) { ins = i + 1; break; }
     }
     if (ins > 0) {
       for (int i = M.count; i >= ins; i--) { M.dist[i + 1] = M.dist[i]; M.len[i + 1] = M.len[i]; }
-      M.dist[ins] = B.rep_dist[rep]; M.len[ins] = (uint16_t)len;
+      M.dist[ins] = s_B.rep_dist[rep]; M.len[ins] = (uint16_t)len;
       M.count++;
       break;
     }
   }
 }
 
-__device__ inline void lz_reduce(Matches &m) {                                       // Reduce_consecutive_max_lengths :1575-1585
+__device__ inline void lz_reduce(int set) {
+  Matches &m = s_MM[set];                                       // Reduce_consecutive_max_lengths :1575-1585
   while (m.count > 1 && m.len[m.count] == m.len[m.count - 1] + 1 && much_smaller(m.dist[m.count - 1], m.dist[m.count])) m.count--;
 }
 
-__device__ void lz_send_dl(Enc &E, BT4 &B, int distance, int length) {               // Send_DL_code :1627-1659
-  emit_dl(E, (uint32_t)distance, length);
-  B.readAhead -= length;
+__device__ void lz_send_dl(int distance, int length) {               // Send_DL_code :1627-1659
+  emit_dl((uint32_t)distance, length);
+  s_B.readAhead -= length;
   int found = -1;
-  for (int i = 0; i < 4; i++) if (distance == B.rep_dist[i]) { found = i; break; }
+  for (int i = 0; i < 4; i++) if (distance == s_B.rep_dist[i]) { found = i; break; }
   if (found >= 0) {
-    const int aux = B.rep_dist[found];
-    for (int i = found; i >= 1; i--) B.rep_dist[i] = B.rep_dist[i - 1];
-    B.rep_dist[0] = aux;
+    const int aux = s_B.rep_dist[found];
+    for (int i = found; i >= 1; i--) s_B.rep_dist[i] = s_B.rep_dist[i - 1];
+    s_B.rep_dist[0] = aux;
   } else {
-    B.rep_dist[3] = B.rep_dist[2]; B.rep_dist[2] = B.rep_dist[1]; B.rep_dist[1] = B.rep_dist[0]; B.rep_dist[0] = distance;
+    s_B.rep_dist[3] = s_B.rep_dist[2]; s_B.rep_dist[2] = s_B.rep_dist[1]; s_B.rep_dist[1] = s_B.rep_dist[0]; s_B.rep_dist[0] = distance;
   }
 }
-__device__ inline void lz_send_literal(Enc &E, BT4 &B) { emit_literal(E, B.cur_literal); B.readAhead--; }
-__device__ inline void lz_skip(const Enc &E, BT4 &B, int len) { PROF_T0; B.readAhead += len; bt_skip(E, B, len); PROF_ADD(5); }
+__device__ inline void lz_send_literal() { emit_literal(s_B.cur_literal); s_B.readAhead--; }
+__device__ inline void lz_skip(int len) { PROF_T0; s_B.readAhead += len; bt_skip(len); PROF_ADD(5); }
 
-__device__ __noinline__ void lz_next_symbol(Enc &E, BT4 &B, Matches *MM) {           // Get_Next_Symbol :1605-1796
+__device__ __noinline__ void lz_next_symbol() {           // Get_Next_Symbol :1605-1796
   constexpr int hurdle = 40;
-  if (B.readAhead == -1) lz_read_one(E, B, MM[B.cur]);
-  B.cur_literal = BUF(B.readPos);
-  const int a = bt_available(B), avail = a < BT_LOOK ? a : BT_LOOK;
-  if (avail < BT_MIN) { lz_send_literal(E, B); return; }
-  if (B.best_len_rep >= BT_NICE) {
-    lz_skip(E, B, B.best_len_rep - 1);
-    lz_send_dl(E, B, B.rep_dist[B.best_rep_index], B.best_len_rep);
+  if (s_B.readAhead == -1) lz_read_one(s_B.cur);
+  s_B.cur_literal = BUF(s_B.readPos);
+  const int a = bt_available(), avail = a < BT_LOOK ? a : BT_LOOK;
+  if (avail < BT_MIN) { lz_send_literal(); return; }
+  if (s_B.best_len_rep >= BT_NICE) {
+    lz_skip(s_B.best_len_rep - 1);
+    lz_send_dl(s_B.rep_dist[s_B.best_rep_index], s_B.best_len_rep);
     return;
   }
   int main_len = 1, main_dist = 1;
   {
-    Matches &C = MM[B.cur];
+    Matches &C = s_MM[s_B.cur];
     if (C.count > 0) {
       main_len = C.len[C.count]; main_dist = C.dist[C.count];
-      if (main_len >= BT_NICE) { lz_skip(E, B, main_len - 1); lz_send_dl(E, B, main_dist, main_len); return; }
-      lz_reduce(C);
-      lz_supplement(B, C);
+      if (main_len >= BT_NICE) { lz_skip(main_len - 1); lz_send_dl(main_dist, main_len); return; }
+      lz_reduce(s_B.cur);
+      lz_supplement(s_B.cur);
       main_len = C.len[C.count]; main_dist = C.dist[C.count];
       if (main_len == BT_MIN && main_dist > 128) main_len = 1;
     }
   }
-  if (B.best_len_rep > BT_MIN &&
-      (B.best_len_rep >= main_len || (B.best_len_rep >= main_len - 2 && main_dist > (1 << 9)) || (B.best_len_rep >= main_len - 3 && main_dist > (1 << 15)))) {
-    lz_skip(E, B, B.best_len_rep - 1);
-    lz_send_dl(E, B, B.rep_dist[B.best_rep_index], B.best_len_rep);
+  if (s_B.best_len_rep > BT_MIN &&
+      (s_B.best_len_rep >= main_len || (s_B.best_len_rep >= main_len - 2 && main_dist > (1 << 9)) || (s_B.best_len_rep >= main_len - 3 && main_dist > (1 << 15)))) {
+    lz_skip(s_B.best_len_rep - 1);
+    lz_send_dl(s_B.rep_dist[s_B.best_rep_index], s_B.best_len_rep);
     return;
   }
-  if (main_len < BT_MIN || avail <= BT_MIN) { lz_send_literal(E, B); return; }
-  B.cur = 1 - B.cur;
-  lz_read_one(E, B, MM[B.cur]);
+  if (main_len < BT_MIN || avail <= BT_MIN) { lz_send_literal(); return; }
+  s_B.cur = 1 - s_B.cur;
+  lz_read_one(s_B.cur);
   {
-    Matches &C = MM[B.cur];
+    Matches &C = s_MM[s_B.cur];
     if (C.count > 0) {
       const int nl = C.len[C.count], nd = C.dist[C.count];
       if ((nl >= main_len + hurdle && nd < main_dist) || (nl == main_len + hurdle + 1 && !much_smaller(main_dist, nd)) || nl > main_len + hurdle + 1 ||
           (nl >= main_len + hurdle - 1 && main_len >= BT_MIN + 1 && much_smaller(nd, main_dist))) {
-        lz_send_literal(E, B);
+        lz_send_literal();
         return;
       }
-      lz_reduce(C);
-      lz_supplement(B, C);
-      int idx = 1, set = 1 - B.cur;
-      estimate_dl_codes(E, MM, 1 - B.cur, B.cur_literal, idx, set);
-      if (set == 1 - B.cur) { main_len = MM[set].len[idx]; main_dist = MM[set].dist[idx]; }
-      else { lz_send_literal(E, B); return; }
+      lz_reduce(s_B.cur);
+      lz_supplement(s_B.cur);
+      int idx = 1, set = 1 - s_B.cur;
+      estimate_dl_codes(1 - s_B.cur, s_B.cur_literal, idx, set);
+      if (set == 1 - s_B.cur) { main_len = s_MM[set].len[idx]; main_dist = s_MM[set].dist[idx]; }
+      else { lz_send_literal(); return; }
     }
   }
   const int limit = main_len - 1 > BT_MIN ? main_len - 1 : BT_MIN;
   for (int rep = 0; rep < 4; rep++)
-    if (bt_match_len(E, B, B.rep_dist[rep], limit) == limit) { lz_send_literal(E, B); return; }
-  lz_skip(E, B, main_len - 2);
-  lz_send_dl(E, B, main_dist, main_len);
+    if (bt_match_len(s_B.rep_dist[rep], limit) == limit) { lz_send_literal(); return; }
+  lz_skip(main_len - 2);
+  lz_send_dl(main_dist, main_len);
 }
 
-__device__ void lz_bt4(Enc &E, Matches *MM, int sbs, int32_t *ws, uint32_t hash4_size) {
-  BT4 B;
-  B.sbs = sbs; B.readPos = -1; B.readLimit = -1; B.writePos = 0; B.pendingSize = 0;
-  B.keepSizeBefore = BT_OPTS + sbs;
-  B.keepSizeAfter = BT_OPTS + BT_LOOK;
+__device__ void lz_bt4(int sbs, int32_t *ws, uint32_t hash4_size) {
+  s_B.sbs = sbs; s_B.readPos = -1; s_B.readLimit = -1; s_B.writePos = 0; s_B.pendingSize = 0;
+  s_B.keepSizeBefore = BT_OPTS + sbs;
+  s_B.keepSizeAfter = BT_OPTS + BT_LOOK;
   const int64_t r = (int64_t)sbs / 2 + 256 * 1024, rmax = 512ll << 20;
-  B.buf_len = B.keepSizeBefore + B.keepSizeAfter + (int)(r < rmax ? r : rmax) + 1;
-  B.moved = 0; B.in_pos = 0;
-  B.hash_4_mask = hash4_size - 1;
-  B.hash2 = ws; B.hash3 = ws + 1024; B.hash4 = ws + 1024 + 65536; B.tree = ws + 1024 + 65536 + hash4_size;
-  B.cyclicPos = -1; B.lzPos = sbs; B.max_dist = sbs - (BT_LOOK + 2);
-  B.readAhead = -1;
-  for (int i = 0; i < 4; i++) { B.rep_dist[i] = 1; B.len_rep[i] = 0; }
-  B.best_len_rep = 0; B.best_rep_index = 0;
-  B.cur = 0; B.cur_literal = 0;
-  MM[0].count = 0; MM[1].count = 0;
-  int written = bt_fill_window(E, B, sbs);
+  s_B.buf_len = s_B.keepSizeBefore + s_B.keepSizeAfter + (int)(r < rmax ? r : rmax) + 1;
+  s_B.moved = 0; s_B.in_pos = 0;
+  s_B.hash_4_mask = hash4_size - 1;
+  s_B.hash2 = ws; s_B.hash3 = ws + 1024; s_B.hash4 = ws + 1024 + 65536; s_B.tree = ws + 1024 + 65536 + hash4_size;
+  s_B.cyclicPos = -1; s_B.lzPos = sbs; s_B.max_dist = sbs - (BT_LOOK + 2);
+  s_B.readAhead = -1;
+  for (int i = 0; i < 4; i++) { s_B.rep_dist[i] = 1; s_B.len_rep[i] = 0; }
+  s_B.best_len_rep = 0; s_B.best_rep_index = 0;
+  s_B.cur = 0; s_B.cur_literal = 0;
+  s_MM[0].count = 0; s_MM[1].count = 0;
+  int written = bt_fill_window(sbs);
   if (written > 0) {
     for (;;) {
-      lz_next_symbol(E, B, MM);
-      if (bt_available(B) == 0) {
-        written = bt_fill_window(E, B, sbs);
+      lz_next_symbol();
+      if (bt_available() == 0) {
+        written = bt_fill_window(sbs);
         if (written == 0) break;
       }
     }
@@ -988,7 +985,6 @@ __device__ void lz_bt4(Enc &E, Matches *MM, int sbs, int32_t *ws, uint32_t hash4
 __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint32_t *order, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
                                                     int32_t *ws_base, uint64_t *result) {
   LzProbs &P = s_P;
-  Matches *MM = s_MM;
   const uint32_t job = order ? order[blockIdx.x] : blockIdx.x;      // the longest entries first: workgroups start in index order
   const LzmaJob J = jobs[job];
   {
@@ -1000,35 +996,34 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   const unsigned long long prof_k0 = clock64();
   for (int i = 0; i < 8; i++) g_lzprof[i] = 0;
 #endif
-  Enc E;
-  E.in = in_base + J.in_off; E.n = J.n;
-  E.cv = J.level <= 1 ? 0 : J.level == 2 ? 1 : 2;
-  E.ES.state = 0; E.ES.pos_state = 0; E.ES.prev_byte = 0; E.ES.pos = 0; E.ES.tw = 1;
-  E.ES.rep[0] = E.ES.rep[1] = E.ES.rep[2] = E.ES.rep[3] = 0;
-  E.width = 0xFFFFFFFFu; E.low = 0; E.cache = 0; E.cache_size = 1;
-  E.out = out_base + J.out_off; E.cap = J.cap; E.olen = 0;
-  if (J.zip_prefix) { put_byte(E, 16); put_byte(E, 2); put_byte(E, 5); put_byte(E, 0); }   // zip-compress-lzma_e.adb:155-158
-  put_byte(E, 3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
-  for (int i = 0; i < 4; i++) put_byte(E, (J.sbs >> (8 * i)) & 255);
+  s_E.in = in_base + J.in_off; s_E.n = J.n;
+  s_E.cv = J.level <= 1 ? 0 : J.level == 2 ? 1 : 2;
+  s_E.ES.state = 0; s_E.ES.pos_state = 0; s_E.ES.prev_byte = 0; s_E.ES.pos = 0; s_E.ES.tw = 1;
+  s_E.ES.rep[0] = s_E.ES.rep[1] = s_E.ES.rep[2] = s_E.ES.rep[3] = 0;
+  s_E.width = 0xFFFFFFFFu; s_E.low = 0; s_E.cache = 0; s_E.cache_size = 1;
+  s_E.out = out_base + J.out_off; s_E.cap = J.cap; s_E.olen = 0;
+  if (J.zip_prefix) { put_byte(16); put_byte(2); put_byte(5); put_byte(0); }   // zip-compress-lzma_e.adb:155-158
+  put_byte(3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
+  for (int i = 0; i < 4; i++) put_byte((J.sbs >> (8 * i)) & 255);
   if (J.level == 0) {
-    for (uint64_t i = 0; i < J.n; i++) emit_literal(E, E.in[i]);                     // No_LZ77
+    for (uint64_t i = 0; i < J.n; i++) emit_literal(s_E.in[i]);                     // No_LZ77
   } else if (J.level <= 2) {
     const uint32_t *tok = tok_base + J.tok_off;
     for (uint64_t t = 0; t < J.ntok; t++) {
       const uint32_t tk = tok[t];
-      if (tk & 0x80000000u) emit_dl(E, tk & 0xFFFF, (int)((tk >> 16) & 0x7FFF)); else emit_literal(E, tk & 0xFF);
+      if (tk & 0x80000000u) emit_dl(tk & 0xFFFF, (int)((tk >> 16) & 0x7FFF)); else emit_literal(tk & 0xFF);
     }
   } else {
-    lz_bt4(E, MM, (int)J.sbs, ws_base + J.ws_off, J.hash4_size);
+    lz_bt4((int)J.sbs, ws_base + J.ws_off, J.hash4_size);
   }
-  encode_bit(E, P.match[E.ES.state][E.ES.pos_state], 1);                             // end marker :1549-1556
-  write_simple_match(E, 0xFFFFFFFFu, 2);
-  for (int i = 0; i < 5; i++) shift_low(E);                                          // Flush_range_encoder
+  encode_bit(P.match[s_E.ES.state][s_E.ES.pos_state], 1);                             // end marker :1549-1556
+  write_simple_match(0xFFFFFFFFu, 2);
+  for (int i = 0; i < 5; i++) shift_low();                                          // Flush_range_encoder
 #ifdef ZADA_LZ_PROF
   if (blockIdx.x == 0 && threadIdx.x == 0) printf("LZPROF total %llu literal %llu emit_dl %llu estimate %llu bt_get %llu bt_skip %llu split(all levels) %llu\n", clock64() - prof_k0, g_lzprof[1], g_lzprof[2], g_lzprof[3], g_lzprof[4], g_lzprof[5], g_lzprof[6]);
 #endif
-  result[2 * job] = E.olen;
-  result[2 * job + 1] = E.ES.pos;
+  result[2 * job] = s_E.olen;
+  result[2 * job + 1] = s_E.ES.pos;
 }
 
 }  // namespace
