@@ -373,7 +373,9 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t dist
   return W_STRICT;
 }
 
-template <int R> __device__ __noinline__ void sim_any_impl(uint32_t distance, int length, MS &sim, double &prob) {
+// (the state and the probability go in and come back BY VALUE -- 14 registers -- instead of through references into scratch)
+struct SimRes { MS sim; double prob; };
+template <int R> __device__ __noinline__ SimRes sim_any_impl(uint32_t distance, int length, MS sim, double prob) {
   if constexpr (R - 1 < 0) {
     sim_strict(distance, length, sim, prob);
   } else {
@@ -399,10 +401,11 @@ template <int R> __device__ __noinline__ void sim_any_impl(uint32_t distance, in
         sim_strict(distance, length, sim, prob);
     }
   }
+  return SimRes{sim, prob};
 }
 template <int R> __device__ __forceinline__ void sim_any(uint32_t distance, int length, MS &sim, double &prob) {
   if constexpr (R - 1 < 0) sim_strict(distance, length, sim, prob);      // limit used up (:761-764): no call in between
-  else sim_any_impl<R>(distance, length, sim, prob);
+  else { const SimRes r = sim_any_impl<R>(distance, length, sim, prob); sim = r.sim; prob = r.prob; }
 }
 
 // ---------------------------------------------------------------- range coder :964-1039
