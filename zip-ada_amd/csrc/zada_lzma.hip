@@ -3,12 +3,14 @@
 //
 // What is parallel and what is not.  The range coder (:964-1039) and the choice between the ways of writing a match (:349-946)
 // both read the adaptive bit probabilities, which every coded bit updates: a stream is one chain of dependent steps, and the
-// stream's bytes have to be the reference's.  So the unit of parallelism is the STREAM: one workgroup per Zip entry, the entry's
-// probability model (7 992 probabilities, 16 KB) and its two match lists in LDS, lane 0 walks the chain.  Level_1 / Level_2 take
-// their LZ77 tokens from the Info-Zip matcher kernels of the Deflate path (IZ_6 / IZ_10, :118-122; zada_lz.hip) -- that part IS
-// data parallel; Level_3 runs the BT4 binary-tree matcher (lz77.adb:953-1827, insertion order matters) inside the chain, with its
-// hash tables and tree in HBM.  The floating-point estimates are IEEE doubles multiplied in the reference's order, without
-// contraction, so they are the values the Ada code computes.
+// stream's bytes have to be the reference's.  So the unit of parallelism is the STREAM: one 64-lane workgroup per Zip entry, the
+// entry's probability model (7 992 probabilities, 16 KB), its two match lists and the encoder's own state in LDS.  All lanes walk
+// the chain in step (same data, same branches: the cost of one lane) and part where the reference compares INDEPENDENT
+// simulations of what to write next -- a team of lanes per simulation, one lane per cut inside it (decide, scoring_top) -- to
+// compare the results in the reference's order.  Level_1 / Level_2 take their LZ77 tokens from the Info-Zip matcher kernels of the
+// Deflate path (IZ_6 / IZ_10, :118-122; zada_lz.hip) -- that part IS data parallel; Level_3 runs the BT4 binary-tree matcher
+// (lz77.adb:953-1827, insertion order matters) inside the chain, with its hash tables and tree in HBM.  The floating-point
+// estimates are IEEE doubles multiplied in the reference's order, without contraction, so they are the values the Ada code computes.
 //
 // The sliding text buffer of the reference (Text_Buf, a ring of String_buffer_size bytes) only ever holds bytes of the input at
 // their own positions -- also ahead of the encoder, where matches under test are expanded early (:1338-1353, 1488-1492) -- so the
