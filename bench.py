@@ -228,6 +228,10 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks):
     out = {"metric": "LZMA_3 encode MB/s over a batch of Zip entries (payloads bit-exact with the CPU restatement of the reference, Ada parity unpinned)",
            "value": round(entries * size / dt / 1e6, 3), "unit": "MB/s", "workload": "%d entries of %d KiB, silesia_mix_v1, one launch" % (entries, kib),
            "ms": round(dt * 1e3, 1), "compression_ratio": round(out_bytes / (entries * size), 4), "phase_ms": tim}
+    kms = tim.get("lzma:end", dt * 1e3)
+    ach = (entries * size + out_bytes) / (kms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": "k_lzma_encode", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 7), "traffic": None,
+                       "note": "algorithmic bytes = N_in + N_out over the coder's launch; the bound is neither HBM nor MFMA but the latency of one dependent instruction stream per entry (adaptive probabilities), 2 048 entries in flight (DESIGN.md 10)"}
     one = datas[0] * max(1, 64 // kib)
     t1 = time.perf_counter()
     rc1, z1, _ = enc.lzma(one, 18)
