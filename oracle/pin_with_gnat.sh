@@ -9,7 +9,9 @@
 # It builds the reference's own zipada tool (gprbuild -P zipada.gpr), compresses every input of the parity matrix
 # (tests/_common.py:edge_inputs() + the fixture files) with zipada -edf / -ed0 / -ed1 / -ed2 / -ed3, cuts the raw Deflate
 # stream out of each archive and compares size and SHA-256 with tests/golden/deflate_digests.json -- the digests of the
-# oracle's streams, which the GPU path is tested against bit for bit.  Exit 0: the oracle is pinned to the Ada binary.
+# oracle's streams, which the GPU path is tested against bit for bit; the same for zipada -eb1 .. -eb3 against bzip2_digests.json
+# (oracle/zada_oracle_bz2.c) and zipada -el0 .. -el3 against lzma_digests.json (oracle/zada_oracle_lzma.c).  Exit 0: the oracle is
+# pinned to the Ada binary.
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
 ROOT=$(dirname "$HERE")
