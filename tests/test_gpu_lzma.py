@@ -52,6 +52,9 @@ def test_single_calls_host_and_device_entry(encoder):
         rc, ln, crc = encoder.lzma_device(t.data_ptr(), len(d), out.data_ptr(), out.numel(), method)
         orc, oz, ocrc = oracle_lzma(d, method)
         assert (rc, crc, bytes(out[:ln].cpu().numpy())) == (orc, ocrc, oz), method
+    # an input that is not 16-byte aligned in device memory (the entry point takes a copy)
+    rc, ln, crc = encoder.lzma_device(t.data_ptr() + 3, 20000, out.data_ptr(), out.numel(), 17)
+    assert (rc, bytes(out[:ln].cpu().numpy()), crc) == oracle_lzma(d[3:20003], 17)
     del Z
 
 
