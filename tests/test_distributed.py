@@ -3,6 +3,8 @@ gathered onto rank 0 and stitched into one .zip stream that equals the single-pr
 The compressor is injected (the oracle stands in for the GPU encoder here, which needs a GPU)."""
 import io
 import os
+
+import pytest
 import sys
 import zipfile
 
@@ -13,7 +15,7 @@ import torch.multiprocessing as mp
 from _common import ROOT, oracle_zip, silesia_mix
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, method=10):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, ROOT)
     import importlib
@@ -43,7 +45,7 @@ def _worker(rank, world, port, q):
             d = silesia_mix(ln, offset=off)
             out = ctypes.create_string_buffer(ln + 64)
             ol = ctypes.c_uint64(0); crc = ctypes.c_uint32(0); zt = ctypes.c_uint16(0)
-            assert O.zo_compress_data(d, ln, 10, out, ln + 64, ctypes.byref(ol), ctypes.byref(crc), ctypes.byref(zt)) == 0
+            assert O.zo_compress_data(d, ln, method, out, ln + 64, ctypes.byref(ol), ctypes.byref(crc), ctypes.byref(zt)) == 0
             payload = torch.frombuffer(bytearray(out.raw[:ol.value]), dtype=torch.uint8)
             meta = torch.tensor([crc.value, ln, zt.value, mine[i]], dtype=torch.int64)
             length = ol.value
@@ -57,7 +59,7 @@ def _worker(rank, world, port, q):
     collect(pending.finish())
     if rank == 0:
         gathered.sort()
-        zc = za.ZipCreate(None, 10)
+        zc = za.ZipCreate(None, method)
         for idx, payload, crc, usize, zt in gathered:
             zc.add_compressed("entry_%04d.bin" % idx, payload, crc, usize, zt)
         q.put(zc.finish())
@@ -65,11 +67,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_and_stitch_equals_single_process_archive():
+@pytest.mark.parametrize("method", [10, 18])
+def test_two_rank_gather_and_stitch_equals_single_process_archive(method):
+    """Entries of an archive over two ranks (independent objects: no collective on the data path, a gather of the payloads at the
+    end) -- Deflate_3, and LZMA_3, whose only parallelism IS the entries: Zip format 14, end-marker flag."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + method * 7) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, method)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=180)
@@ -82,9 +87,10 @@ def test_two_rank_gather_and_stitch_equals_single_process_archive():
         ln = min(entry, total - off)
         entries.append(("entry_%04d.bin" % i, silesia_mix(ln, offset=off)))
         off += ln; i += 1
-    assert got == oracle_zip(entries, 10)
+    assert got == oracle_zip(entries, method)
     zf = zipfile.ZipFile(io.BytesIO(got))
     assert zf.testzip() is None and len(zf.infolist()) == len(entries)
+    assert all(i.compress_type == (14 if method == 18 else 8) for i in zf.infolist())
 
 
 # ----------------------------------------------------------------------------------------------------------------------
