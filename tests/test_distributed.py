@@ -3,11 +3,10 @@ gathered onto rank 0 and stitched into one .zip stream that equals the single-pr
 The compressor is injected (the oracle stands in for the GPU encoder here, which needs a GPU)."""
 import io
 import os
-
-import pytest
 import sys
 import zipfile
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
