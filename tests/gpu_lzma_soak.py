@@ -1,5 +1,5 @@
 """GPU script: random entries (sizes 0 .. 48 KiB, every class mix of silesia_mix_v1, runs, few-symbol data) through zada_lzma_batch,
-every payload against the oracle.  SOAK_SEEDS (default 3) x 400 entries x methods 15 .. 18."""
+every payload against the oracle.  SOAK_SEEDS (default 3) x SOAK_ENTRIES (400) entries x methods 15 .. 18; SOAK_MAX (49152) = largest size."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
@@ -7,11 +7,12 @@ from _common import product
 from _lzmah import oracle_lzma, lzma_decode
 Z = product(); enc = Z.Encoder(0)
 bad = 0; total = 0
+MAXN = int(os.environ.get("SOAK_MAX", "49152"))
 for seed in range(int(os.environ.get("SOAK_SEEDS", "3"))):
     rng = np.random.default_rng(1000 + seed)
     datas = []
-    for i in range(400):
-        n = int(rng.choice([0, 1, 2, 3, 161, 162, 163, 273, 274, 4096, int(rng.integers(0, 49152)), int(rng.integers(0, 49152)), int(rng.integers(0, 2000))]))
+    for i in range(int(os.environ.get("SOAK_ENTRIES", "400"))):
+        n = int(rng.choice([0, 1, 2, 3, 161, 162, 163, 273, 274, 4096, int(rng.integers(0, MAXN)), int(rng.integers(0, MAXN)), int(rng.integers(0, 2000))]))
         kind = int(rng.integers(0, 6))
         if kind == 0:
             d = bytes(rng.integers(0, 256, n, dtype=np.uint8))
