@@ -73,7 +73,9 @@ const char *zada_version(void);
  * "budget" (ZADA_BUDGET: rounds of chain steps per position in the first match pass; 0 = unbounded, -1 = default),
  * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of
  * a stream the match finder takes at a time, multiple of 64), "span_mib" (MiB of a stream one pass takes; longer streams go span after
- * span, default 2048), "batch_mib" (MiB one batch of small entries may take).  None of them changes a byte. */
+ * span, default 2048), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
+ * batching).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's
+ * dictionary_size for LZMA_3 in bytes (0, the default: the entry's size, as Zip.Compress.LZMA_E passes it; lzma_enc.adb uses 32 KiB). */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 
 /* Zip.Compress.Deflate on host buffers (the Ada shim drains `input` with Zip.Block_Read into
