@@ -333,6 +333,22 @@ def bzip2_main(args, za, sharding, enc, torch, dist, rank, world, dev, emulate):
     print(json.dumps(out))
 
 
+def launch_ranks(n):
+    """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <the same arguments>` as a child process, relays its
+    output (rank 0 prints the JSON line) and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -349,13 +365,23 @@ def main():
     ap.add_argument("--lzma-kib", type=int, default=16, help="KiB per entry of the LZMA_3 batch")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process only starts the N ranks (one per GPU) and waits for them.  It never
+        # touches the GPU itself, so nothing that has initialised HIP is ever replaced or forked.
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     # BENCH_EMULATE=1: every rank on GPU 0 over gloo -- exercises the N > 1 code path on a one-GPU box (not a measurement)
     emulate = os.environ.get("BENCH_EMULATE") == "1"
+    if not emulate and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (world, torch.cuda.device_count()))
     if emulate:
         local_rank = 0
     if world > 1:

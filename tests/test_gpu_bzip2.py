@@ -124,6 +124,8 @@ def test_device_entry_feedback_abort_and_inefficient(encoder):
     assert rc == 1 and p == o2                                      # compression_ok = False; the stream is still delivered when it fits
     rc, p, _ = encoder.bzip2(rnd, 14, cap=len(rnd))                 # ... and only announced when it does not
     assert rc == 1 and p is None
+    with pytest.raises(Z.ZadaError, match="too small"):           # a compressible entry and a buffer it does not fit: an error, not "inefficient"
+        encoder.bzip2(data.tobytes(), 14, cap=100000)
 
 
 def test_zip_archive_with_bzip2_entries(encoder):
@@ -217,8 +219,9 @@ def test_bench_bzip2_multi_rank_path_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BENCH_EMULATE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", os.path.join(root, "bench.py"), "--gpus", "3", "--method", "bzip2", "--steps", "1", "--warmup", "1", "--mib", "40"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):                     # the plain form: bench.py starts its own ranks (bench.launch_ranks)
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--method", "bzip2", "--steps", "1", "--warmup", "1", "--mib", "40"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

@@ -134,3 +134,20 @@ def test_zip64_promotion_of_the_container_writer():
         got = both(entries)
         assert (b"PK\x06\x06" in got[-200:]) == z64
         assert len(zipfile.ZipFile(io.BytesIO(got)).infolist()) == count
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly():
+    """`python bench.py --gpus N` (no launcher) starts N ranks through torch.distributed.run before touching a GPU and relays
+    their exit code; a launcher whose WORLD_SIZE disagrees with --gpus is refused.  (No GPU here: the ranks stop at "needs a
+    GPU", which is the loud failure the product path promises.)"""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--mib", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("only 0 GPU(s) are visible") >= 2 or r.stderr.count("needs a GPU") >= 2, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started 2 ranks" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "at least 1" in r.stderr

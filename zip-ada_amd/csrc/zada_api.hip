@@ -613,7 +613,19 @@ static int deflate_spans(Ctx *c, int method, const uint8_t *d_src, const uint8_t
       if (rc) return rc;
       cc = R.carry_out;
       const uint64_t nb = (R.co.total_bits + 7) / 8;
-      if (base_bytes + nb >= n) { inefficient = true; base_bytes += nb; break; }             // zip-compress.adb:479-486: the reference stops here as well
+      if (base_bytes + nb >= n) {                       // zip-compress.adb:479-486: the reference stops here as well
+        // ... but the caller Stores the entry with the CRC-32 of ALL its bytes (zip-compress.adb:224-237): this span's
+        // part is known, the bytes behind it go through the CRC kernels alone, a span at a time
+        inefficient = true; base_bytes += nb;
+        crc = crc32_advance(crc, hi - lo) ^ R.crc_raw;
+        for (uint64_t o = hi; o < n && crc_inout; o += span) {
+          const uint64_t k = n - o < span ? n - o : span;
+          const uint8_t *p = d_src ? d_src + o : W.rin_own;
+          if (!d_src) copy_in(c, W.rin_own, h_src + o, k);            // (rin_own holds more than a span)
+          if ((rc = crc_launch(c, p, k)) || (rc = crc_finish(c, k, &crc))) return rc;
+        }
+        break;
+      }
       rc = entropy_emit(c, nullptr);
       if (rc) return rc;
       if (base_bytes + nb > cap) { c->err = "output buffer too small"; return ZADA_E_INVALID; }
@@ -828,6 +840,26 @@ extern "C" {
 
 const char *zada_version(void) { return "zada-hip 0.1 (gfx950)"; }
 
+static void lzma_free(zada::Ctx *c);
+// releases whatever a context holds (also a partly built one: every handle is tested)
+static void ctx_release(zada_ctx *z) {
+  if (z->c.stream) hipStreamSynchronize(z->c.stream);
+  if (z->c.stream2) hipStreamSynchronize(z->c.stream2);
+  bz2_destroy(&z->c);
+  lzma_free(&z->c);
+  free_workspace(&z->c);
+  for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
+  if (z->c.stream2) hipStreamDestroy(z->c.stream2);
+  if (z->c.crc_host) hipHostFree(z->c.crc_host);
+  for (int b = 0; b < 8; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
+  if (z->c.bstage) hipHostFree(z->c.bstage);
+  if (z->c.btab) hipHostFree(z->c.btab);
+  if (z->c.ev_input) hipEventDestroy(z->c.ev_input);
+  if (z->c.ev_out) hipEventDestroy(z->c.ev_out);
+  if (z->c.stream) hipStreamDestroy(z->c.stream);
+  delete z;
+}
+
 zada_ctx *zada_create(int device) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return nullptr;
@@ -835,10 +867,10 @@ zada_ctx *zada_create(int device) {
   zada_ctx *z = new (std::nothrow) zada_ctx();
   if (!z) return nullptr;
   z->c.device = device;
-  if (hipStreamCreate(&z->c.stream) != hipSuccess) { delete z; return nullptr; }
-  if (hipHostMalloc((void **)&z->c.crc_host, (CRC_HOST_TOP + 64) * 4, hipHostMallocDefault) != hipSuccess) { delete z; return nullptr; }
-  if (hipStreamCreate(&z->c.stream2) != hipSuccess || hipEventCreateWithFlags(&z->c.ev_input, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&z->c.ev_out, hipEventDisableTiming) != hipSuccess) { delete z; return nullptr; }
+  if (hipStreamCreate(&z->c.stream) != hipSuccess ||
+      hipHostMalloc((void **)&z->c.crc_host, (CRC_HOST_TOP + 64) * 4, hipHostMallocDefault) != hipSuccess ||
+      hipStreamCreate(&z->c.stream2) != hipSuccess || hipEventCreateWithFlags(&z->c.ev_input, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&z->c.ev_out, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx_release(z); return nullptr; }
   // tuning knobs: read once per context
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
   if (const char *e = getenv("ZADA_INNER_BUDGET")) z->c.knob_inner_budget = atoi(e);
@@ -847,25 +879,10 @@ zada_ctx *zada_create(int device) {
   return z;
 }
 
-static void lzma_free(zada::Ctx *c);
 void zada_destroy(zada_ctx *z) {
   if (!z) return;
   hipSetDevice(z->c.device);
-  hipStreamSynchronize(z->c.stream);
-  hipStreamSynchronize(z->c.stream2);
-  bz2_destroy(&z->c);
-  lzma_free(&z->c);
-  free_workspace(&z->c);
-  for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
-  hipStreamDestroy(z->c.stream2);
-  hipHostFree(z->c.crc_host);
-  for (int b = 0; b < 8; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
-  if (z->c.bstage) hipHostFree(z->c.bstage);
-  if (z->c.btab) hipHostFree(z->c.btab);
-  hipEventDestroy(z->c.ev_input);
-  hipEventDestroy(z->c.ev_out);
-  hipStreamDestroy(z->c.stream);
-  delete z;
+  ctx_release(z);
 }
 
 const char *zada_last_error(const zada_ctx *z) { return z ? z->c.err.c_str() : "no context"; }
@@ -1254,7 +1271,7 @@ static int lzma_batch_core(Ctx *c, int method, const int *idx, uint32_t E, const
   uint64_t total = 0, ototal = 0;
   for (uint32_t e = 0; e < E; e++) {
     start[e] = total; start32[e] = (uint32_t)total; len[e] = (uint32_t)n[idx[e]]; crc_in[e] = crc ? crc[idx[e]] : 0xFFFFFFFFu;
-    total += ((n[idx[e]] ? n[idx[e]] : 1) + 65535) & ~65535ull;                  // (64 KiB slots: a slot is a range of the LZ stage)
+    total += ((n[idx[e]] ? n[idx[e]] : 1) + 63) & ~63ull;                        // (64-byte slots: Level_0 / Level_3 never see the LZ stage)
     ostart[e] = ototal; ototal += (n[idx[e]] + n[idx[e]] / 8 + 128 + 63) & ~63ull;
   }
   if (total >= (1ull << 32)) return ZADA_E_TOO_LARGE;
@@ -1398,7 +1415,8 @@ int zada_lzma_batch(zada_ctx *z, int method, int count, const uint8_t *const *in
   };
   for (int i = 0; i < count; i++) {
     if (n[i] >= (2ull << 30) - 65536) { rc[i] = ZADA_E_TOO_LARGE; worst = rc[i]; continue; }
-    const uint64_t slot = ((n[i] ? n[i] : 1) + 65535) & ~65535ull;
+    const bool iz_slots = method == ZADA_LZMA_1 || method == ZADA_LZMA_2;       // (whole 32 KiB segments of the LZ stage; 64-byte slots otherwise)
+    const uint64_t slot = iz_slots ? ((n[i] ? n[i] : 1) + 32767) & ~32767ull : ((n[i] ? n[i] : 1) + 63) & ~63ull;
     if (gbytes + slot > (1ull << 30)) flush_group();
     group.push_back(i); gbytes += slot;
   }

@@ -2065,10 +2065,12 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
     if (bstart.empty()) { c->err = "bzip2: span shorter than a block"; return ZADA_E_INVALID; }
     if ((rc = bz_blocks_encode(c, option, d_in, bstart, blen, fb, user, 3.0 + 95.0 * (double)pos0 / (double)(n ? n : 1), 3.0 + 95.0 * (double)next / (double)(n ? n : 1)))) return rc;
     pos0 = next;
-    if (B->min_bits_sum + 32 + 80 > cap * 8) {      // cannot fit any more, whatever is chosen: Compression_inefficient (zip-compress.adb:479-486)
-      if (out_len) *out_len = (B->min_bits_sum + 32 + 80 + 7) / 8;
+    if (B->min_bits_sum + 32 + 80 > cap * 8) {      // cannot fit any more, whatever is chosen
+      const uint64_t least = (B->min_bits_sum + 32 + 80 + 7) / 8;
+      if (out_len) *out_len = least;
       bz_reset_call(c);
-      return ZADA_INEFFICIENT;
+      if (least >= n) return ZADA_INEFFICIENT;      // Compression_inefficient (zip-compress.adb:479-486): not smaller than the input
+      c->err = "output buffer too small"; return ZADA_E_INVALID;
     }
   } while (pos0 < n);
   std::vector<uint64_t> tab;
@@ -2079,7 +2081,11 @@ int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64
   bz_set_trace(B, choice.data());
   uint64_t nbytes = (bit_end + 80 + 7) / 8;
   if (out_len) *out_len = nbytes;
-  if (nbytes > cap) { bz_reset_call(c); return ZADA_INEFFICIENT; }
+  if (nbytes > cap) {
+    bz_reset_call(c);
+    if (nbytes >= n) return ZADA_INEFFICIENT;
+    c->err = "output buffer too small"; return ZADA_E_INVALID;
+  }
   rc = bz_assemble_range(c, option, choice.data(), 32, 3, crc, d_out, cap, &nbytes);
   bz_reset_call(c);
   if (rc) return rc;

@@ -58,6 +58,7 @@ def gather_payloads_begin(payload, length, meta, dst=0, group=None):
     far below one xGMI link per peer, so a direct gather to the root is used, not a ring."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    gdst = dst if group is None else dist.get_global_rank(group, dst)      # (dst is a rank of the group; torch takes global ranks)
     dev = payload.device
     hdr = torch.cat([torch.tensor([length], dtype=torch.int64, device=dev), meta.to(dev)])
     hdrs = [torch.empty_like(hdr) for _ in range(world)]
@@ -68,9 +69,9 @@ def gather_payloads_begin(payload, length, meta, dst=0, group=None):
     send = send.contiguous()
     if rank == dst:
         bufs = [torch.empty(maxlen, dtype=torch.uint8, device=dev) for _ in range(world)]
-        work = dist.gather(send, bufs, dst=dst, group=group, async_op=True)
+        work = dist.gather(send, bufs, dst=gdst, group=group, async_op=True)
         return PendingGather(work, bufs, lens, hdrs, send)
-    work = dist.gather(send, None, dst=dst, group=group, async_op=True)
+    work = dist.gather(send, None, dst=gdst, group=group, async_op=True)
     return PendingGather(work, None, lens, hdrs, send)
 
 
@@ -145,6 +146,10 @@ class TorchComm:
         self.group, self.device = group, device
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
+    def _g(self, k):
+        """Rank k of the group as torch.distributed addresses it (src / dst are GLOBAL ranks also when a group is given)."""
+        return k if self.group is None else dist.get_global_rank(self.group, k)
+
     def all_gather_obj(self, obj):
         out = [None] * self.world
         dist.all_gather_object(out, obj, group=self.group)
@@ -152,7 +157,7 @@ class TorchComm:
 
     def bcast_obj(self, obj, src):
         box = [obj]
-        dist.broadcast_object_list(box, src=src, group=self.group)
+        dist.broadcast_object_list(box, src=self._g(src), group=self.group)
         return box[0]
 
     def all_gather_dev(self, t):
@@ -168,11 +173,11 @@ class TorchComm:
 
     def send_bytes(self, b, dst):
         t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(self.device)
-        dist.send(t, dst=dst, group=self.group)
+        dist.send(t, dst=self._g(dst), group=self.group)
 
     def recv_bytes(self, n, src):
         t = torch.empty(n, dtype=torch.uint8, device=self.device)
-        dist.recv(t, src=src, group=self.group)
+        dist.recv(t, src=self._g(src), group=self.group)
         return bytes(t.cpu().numpy())
 
     def gather_payload(self, payload, length, dst=0):
