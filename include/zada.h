@@ -74,7 +74,8 @@ const char *zada_version(void);
  * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of
  * a stream the match finder takes at a time, multiple of 64), "span_mib" (MiB of a stream one pass takes; longer streams go span after
  * span, default 2048), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
- * batching).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's
+ * batching), "lzma_chunk" (positions of an LZMA stream one launch codes between two feedback calls; 0 = by level, -1 = one launch
+ * per stream).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's
  * dictionary_size for LZMA_3 in bytes (0, the default: the entry's size, as Zip.Compress.LZMA_E passes it; lzma_enc.adb uses 32 KiB). */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 
@@ -84,7 +85,8 @@ int zada_set_knob(zada_ctx *ctx, const char *name, int value);
  *               Final after, zip-compress.adb:144, 218).  May be NULL.
  *   cap       : capacity of out; cap >= n + 64 always suffices.
  *   out_len   : output_size.
- * Output bytes are bit-exact with the reference encoder's for the same method. */
+ * Output bytes are bit-exact with the CPU restatement of the reference encoder (oracle/) for the same method; parity with an
+ * Ada build of the reference is unpinned (no GNAT in this image: DESIGN.md 2). */
 int zada_deflate(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n,
                  uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout,
                  zada_feedback_fn fb, void *user);
@@ -201,9 +203,14 @@ int zada_bzip2_batch(zada_ctx *ctx, int method, int count, const uint8_t *const 
  * method = Compression_Method'Pos, crc_inout = the running Zip CRC-32 register, return ZADA_OK / ZADA_INEFFICIENT / < 0.
  * The output is the Zip payload: the four bytes 16, 2, 5, 0 (:155-158), the 5-byte LZMA header, the range-coded stream.
  * A stream is one chain of dependent steps (adaptive probabilities): one workgroup codes it; entries are what runs in
- * parallel -- use zada_lzma_batch for many of them.  Entries below 2 GiB.
+ * parallel -- use zada_lzma_batch for many of them.  A stream runs as a sequence of bounded launches (about half a second each,
+ * "lzma_chunk"), the coder's state waiting in device memory in between: fb (may be NULL) is called with 0, between the launches
+ * and with 100, and a non-zero return ends the call with ZADA_ABORTED (Feedback / User_abort, zip-compress-lzma_e.adb:78-92).
+ * Limits: entries below 2 GiB - 64 KiB (ZADA_E_TOO_LARGE beyond: the shim Stores such an entry or raises); only the
+ * (lc, lp, pb) = (3, 0, 2) methods LZMA_0 .. LZMA_3, not the data-specific LZMA_for_* variants (ZADA_E_INVALID).
  * --------------------------------------------------------------------------------------------------------------- */
-int zada_lzma(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
+int zada_lzma(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout,
+              zada_feedback_fn fb, void *user);
 /* the same with input and output in device memory (d_out: cap bytes) */
 int zada_lzma_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
 /* Many entries, one launch of the coder for all of them.  Arrays as for zada_deflate_batch; rc[i] is zada_lzma's return code

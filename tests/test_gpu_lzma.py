@@ -131,3 +131,38 @@ def test_dictionary_smaller_than_the_entry(encoder):
             assert lzma_decode(z, 4) == d
     finally:
         encoder.set_knob("lzma_dict", 0)
+
+
+def test_stream_in_bounded_launches_feedback_and_abort(encoder):
+    """Zip.Compress.LZMA_E drives `feedback` and raises User_abort (zip-compress-lzma_e.adb:78-92).  A stream is coded as a sequence
+    of bounded launches with the coder's state (model, match sets, range coder, BT4) parked in device memory in between ("lzma_chunk"
+    positions per launch): chunked == one launch == the oracle for every method, whatever the chunk; feedback is monotone 0 .. 100 and
+    called between the launches; an abort returns ZADA_ABORTED (UserAbort) and leaves the context usable."""
+    Z = product()
+    d = bytes(Z.silesia_mix(90000))
+    try:
+        for method in LZMA_METHODS:
+            want = oracle_lzma(d, method)
+            for chunk in (-1, 777, 20000):
+                encoder.set_knob("lzma_chunk", chunk)
+                assert encoder.lzma(d, method) == want, (method, chunk)
+        encoder.set_knob("lzma_chunk", 5000)
+        for method in (15, 16, 18):
+            seen = []
+            got = encoder.lzma(d, method, feedback=lambda pct: seen.append(pct) and False)
+            assert got == oracle_lzma(d, method)
+            assert seen[0] == 0 and seen[-1] == 100 and seen == sorted(seen) and len(seen) >= 90000 // 5000, seen
+            with pytest.raises(Z.UserAbort):
+                encoder.lzma(d, method, feedback=lambda pct: pct >= 40)
+            assert encoder.lzma(d[:30000], method) == oracle_lzma(d[:30000], method)      # usable after an abort
+        # the window-move case (dictionary smaller than the entry) across launch boundaries
+        m = lz_inputs()["mix_256k"]
+        d2 = m + m[:47856]
+        encoder.set_knob("lzma_dict", 10000)
+        encoder.set_knob("lzma_chunk", 30011)
+        rc, z, crc = encoder.lzma(d2, 18)
+        want, _ = oracle_lzma_encode(d2, 3, dictionary_size=10000)
+        assert z == bytes([16, 2, 5, 0]) + want
+    finally:
+        encoder.set_knob("lzma_dict", 0)
+        encoder.set_knob("lzma_chunk", 0)

@@ -99,7 +99,7 @@ def load_library():
     L.zada_bz2_range_assemble.argtypes = [vp, vp, u64, u64, i32, ctypes.c_uint32, vp, u64, u64p]
     L.zada_crc32_device.argtypes = [vp, vp, u64, u32p]
     L.zada_bzip2_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-    L.zada_lzma.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
+    L.zada_lzma.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, vp, vp]
     L.zada_lzma_device.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
     L.zada_lzma_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.zada_bz2_last_blocks.restype = ctypes.c_uint64
@@ -224,15 +224,20 @@ class Encoder:
         mv = memoryview(arena)
         return [(int(rcs[i]), bytes(mv[int(offs[i]):int(offs[i]) + int(ols[i])]) if rcs[i] >= 0 and ols[i] <= caps[i] else None, int(crcs[i])) for i in range(cnt)]
 
-    def lzma(self, data, method=18, crc=0xFFFFFFFF, cap=None):
+    def lzma(self, data, method=18, crc=0xFFFFFFFF, cap=None, feedback=None):
         """Zip.Compress.LZMA_E (method 15 .. 18 = LZMA_0 .. LZMA_3).  Returns (rc, Zip payload, running CRC register); rc 1 = not
-        smaller than the input (the payload is still returned when it fits `cap`, default len(data) * 9 // 8 + 4096)."""
+        smaller than the input (the payload is still returned when it fits `cap`, default len(data) * 9 // 8 + 4096).
+        feedback(percent) is called between the launches of the stream; a true return raises UserAbort."""
         n = len(data)
         cap = int(cap if cap is not None else n + n // 8 + 4096)
         out = ctypes.create_string_buffer(cap)
         ol = ctypes.c_uint64(0)
         c = ctypes.c_uint32(crc)
-        rc = self.lib.zada_lzma(self.ctx, method, _addr(data) if n else None, n, ctypes.addressof(out), cap, ctypes.byref(ol), ctypes.byref(c))
+        cb = FEEDBACK_FN(lambda pct, _u: 1 if feedback(pct) else 0) if feedback else None
+        rc = self.lib.zada_lzma(self.ctx, method, _addr(data) if n else None, n, ctypes.addressof(out), cap, ctypes.byref(ol), ctypes.byref(c),
+                                ctypes.cast(cb, ctypes.c_void_p) if cb else None, None)
+        if rc == 2:
+            raise UserAbort()
         if rc < 0:
             self._err(rc, "zada_lzma")
         return rc, (out.raw[:ol.value] if ol.value <= cap else None), c.value

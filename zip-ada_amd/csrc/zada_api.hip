@@ -899,6 +899,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
   else if (!strcmp(name, "lzma_dict")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_lzma_dict = value; }
+  else if (!strcmp(name, "lzma_chunk")) z->c.knob_lzma_chunk = value;
   else return ZADA_E_INVALID;
   return ZADA_OK;
 }
@@ -1163,11 +1164,15 @@ static int lz_grow(Ctx *c, void **p, size_t *cap, size_t bytes) {
 static void lzma_free(Ctx *c) {
   if (c->lz_tab) hipFree(c->lz_tab);
   if (c->lz_ws) hipFree(c->lz_ws);
-  c->lz_tab = c->lz_ws = nullptr; c->cap_lz_tab = c->cap_lz_ws = 0;
+  if (c->lz_save) hipFree(c->lz_save);
+  c->lz_tab = c->lz_ws = c->lz_save = nullptr; c->cap_lz_tab = c->cap_lz_ws = c->cap_lz_save = 0;
 }
 // jobs: ws_off / sbs / hash4_size are filled here.  res: 2 per job (stream bytes, input bytes coded).
+// budget > 0: launches of `budget` positions per stream (the coder's state waits in HBM in between, zada_lzma.hip "A stream in several
+// launches"), with feedback (pct_lo .. pct_hi by positions coded) and the abort test between them.
 static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, std::vector<uint64_t> &res,
-                    const uint32_t *d_apos = nullptr, uint32_t T = 0, const uint32_t *d_ent_start = nullptr) {
+                    const uint32_t *d_apos = nullptr, uint32_t T = 0, const uint32_t *d_ent_start = nullptr,
+                    uint64_t budget = 0, zada_feedback_fn fb = nullptr, void *user = nullptr, int pct_lo = 0, int pct_hi = 100) {
   const uint32_t E = (uint32_t)jobs.size();
   uint64_t ws_ints = 0;
   for (LzmaJob &j : jobs) {
@@ -1189,10 +1194,30 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, con
   hipMemcpyAsync(d_order, order.data(), 4 * (size_t)E, hipMemcpyHostToDevice, c->stream);
   if (ws_ints) hipMemsetAsync(c->lz_ws, 0, ws_ints * 4, c->stream);
   if (d_apos && (rc = lzma_token_ranges(c, E, d_apos, T, d_ent_start, d_jobs))) return rc;   // token ranges of a batch, found on the device
-  if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res))) return rc;
   res.resize(2 * (size_t)E);
-  hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
-  if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
+  if (budget == 0) {
+    if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res))) return rc;
+    hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
+    if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
+  } else {
+    const size_t save_bytes = (size_t)lzma_save_stride() * E;
+    if ((rc = lz_grow(c, &c->lz_save, &c->cap_lz_save, save_bytes))) return rc;
+    hipMemsetAsync(c->lz_save, 0, save_bytes, c->stream);
+    uint64_t total = 0;
+    for (const LzmaJob &j : jobs) total += j.n;
+    c->lzma_launches = 0;
+    for (;;) {
+      if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res, (uint8_t *)c->lz_save, budget))) return rc;
+      c->lzma_launches++;
+      hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
+      if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
+      bool more = false;
+      uint64_t coded = 0;
+      for (uint32_t e = 0; e < E; e++) { more = more || (res[2 * e + 1] >> 63); res[2 * e + 1] &= ~(1ull << 63); coded += res[2 * e + 1]; }
+      if (!more) break;
+      if (fb && fb(pct_lo + (int)((uint64_t)(pct_hi - pct_lo) * coded / (total ? total : 1)), user)) return ZADA_ABORTED;
+    }
+  }
   for (uint32_t e = 0; e < E; e++) if (res[2 * e + 1] != jobs[e].n) { c->err = "LZMA: the coder did not consume the entry"; return ZADA_E_HIP; }
   return 0;
 }
@@ -1205,11 +1230,21 @@ static int lzma_tokens(Ctx *c, int level, const uint8_t *d_in, uint64_t n, uint6
   c->rg.open = false;
   return 0;
 }
-static int lzma_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout) {
+// Positions a launch codes before the coder's state goes back to HBM and the caller is asked whether to go on ("lzma_chunk" knob;
+// 0 = by level, sized for launches of about half a second: one stream is ONE wave walking a chain).
+static uint64_t lzma_budget(const Ctx *c, int level) {
+  if (c->knob_lzma_chunk > 0) return (uint64_t)c->knob_lzma_chunk;
+  if (c->knob_lzma_chunk < 0) return 0;                               // (one launch per stream, as a batch does it)
+  return level == 0 ? 4ull << 20 : level == 1 ? 1ull << 20 : level == 2 ? 256ull << 10 : 64ull << 10;
+}
+static int lzma_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout,
+                     zada_feedback_fn fb, void *user) {
   if (method < ZADA_LZMA_0 || method > ZADA_LZMA_3) { c->err = "not an LZMA method"; return ZADA_E_INVALID; }
-  if (n >= (2ull << 30) - 65536) { c->err = "LZMA: entries of 2 GiB and more are not taken yet"; return ZADA_E_TOO_LARGE; }
+  // (BT4's positions are Integers that the reference re-bases at Integer'Last, lz77.adb:981-990, 1078-1083; the kernel does not)
+  if (n >= (2ull << 30) - 65536) { c->err = "LZMA: entries of 2 GiB and more are not taken"; return ZADA_E_TOO_LARGE; }
   const int level = method - ZADA_LZMA_0;
   int rc;
+  if (fb && fb(0, user)) return ZADA_ABORTED;                         // zip-compress-lzma_e.adb:78-92
   c->tbegin(); c->tmark("lzma:begin");
   if (crc_inout && n) {
     if ((rc = ensure_crc_workspace(c, n))) return rc;
@@ -1225,9 +1260,12 @@ static int lzma_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint8_
     d_tok = c->ws.ea_atoms + LB_CAP;
   }
   c->tmark("lzma:tokens");
+  const int pct0 = d_tok ? 10 : 1;
+  if (fb && fb(pct0, user)) return ZADA_ABORTED;
   std::vector<uint64_t> res;
-  if ((rc = lzma_run(c, jobs, d_in, d_tok, d_out, res))) return rc;
+  if ((rc = lzma_run(c, jobs, d_in, d_tok, d_out, res, nullptr, 0, nullptr, lzma_budget(c, level), fb, user, pct0, 99))) return rc;
   c->tmark("lzma:end"); c->tend();
+  if (fb && fb(100, user)) return ZADA_ABORTED;
   *out_len = res[0];
   if (res[0] > cap) { if (res[0] >= n) return ZADA_INEFFICIENT; c->err = "output buffer too small"; return ZADA_E_INVALID; }
   return res[0] >= n ? ZADA_INEFFICIENT : ZADA_OK;                   // zip-compress.adb:479-486
@@ -1243,11 +1281,12 @@ int zada_lzma_device(zada_ctx *z, int method, const void *d_in, uint64_t n, void
     src = c->ws.rin_own;
   }
   uint64_t ol = 0;
-  rc = finish_call(c, lzma_core(c, method, src, n, (uint8_t *)d_out, cap, &ol, crc_inout));
+  rc = finish_call(c, lzma_core(c, method, src, n, (uint8_t *)d_out, cap, &ol, crc_inout, nullptr, nullptr));
   if (out_len && rc >= 0) *out_len = ol;
   return rc;
 }
-int zada_lzma(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout) {
+int zada_lzma(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout,
+              zada_feedback_fn fb, void *user) {
   int rc = prepare(z);
   if (rc) return rc;
   Ctx *c = &z->c;
@@ -1255,7 +1294,7 @@ int zada_lzma(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *o
   copy_in(c, c->ws.rin_own, in, n);
   uint8_t *d_out = c->ws.rin_own + ((n + 63) & ~63ull);
   uint64_t ol = 0;
-  rc = finish_call(c, lzma_core(c, method, c->ws.rin_own, n, d_out, cap, &ol, crc_inout));
+  rc = finish_call(c, lzma_core(c, method, c->ws.rin_own, n, d_out, cap, &ol, crc_inout, fb, user));
   if (rc < 0 || rc == ZADA_ABORTED) return rc;
   if (out_len) *out_len = ol;
   if (ol <= cap && copy_out(c, out, d_out, ol)) return ZADA_E_HIP;
@@ -1623,7 +1662,7 @@ int zada_compress_data(zada_ctx *z, int method, const uint8_t *in, uint64_t n, u
   const bool bz = method >= ZADA_BZIP2_1 && method <= ZADA_BZIP2_3;                  // :204-209 (bzip2_code = 12, zip.ads:502)
   const bool lz = method >= ZADA_LZMA_0 && method <= ZADA_LZMA_3;                    // :211-216 (lzma_code = 14, zip.ads:503)
   int rc = bz ? zada_bzip2(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr)
-         : lz ? zada_lzma(z, method, in, n, out, cap, out_len, &crc)
+         : lz ? zada_lzma(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr)
               : zada_deflate(z, method, in, n, out, cap, out_len, &crc, nullptr, nullptr);
   if (rc < 0 || rc == ZADA_ABORTED) return rc;
   *zip_type = bz ? 12 : lz ? 14 : 8;

@@ -245,6 +245,8 @@ struct Ctx {
   void *bz = nullptr;                                // BZip2 state (zada_bz2.hip), made on first use
   void *lz_tab = nullptr; size_t cap_lz_tab = 0;     // LZMA (zada_lzma.hip): job table + results
   void *lz_ws = nullptr; size_t cap_lz_ws = 0;       // ... the BT4 matcher's hash tables and trees (Level_3)
+  void *lz_save = nullptr; size_t cap_lz_save = 0;   // ... the coder's state between the launches of one stream
+  int lzma_launches = 0;                             // launches the last chunked LZMA call took
   // timing
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<const char *, hipEvent_t>> marks;
@@ -264,6 +266,8 @@ struct Ctx {
   int knob_bz_batch_melems = 640;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
   int knob_lzma_dict = 0;           // LZMA_3: dictionary_size in bytes instead of the entry's size (0 = the entry's size, as Zip.Compress.LZMA_E asks;
                                     // lzma_enc.adb's default is 32 KiB) -- this one DOES change the output: it is the reference's parameter
+  int knob_lzma_chunk = 0;          // LZMA: positions one launch codes before the stream's state goes back to HBM and the caller's feedback is
+                                    // called (0 = by level, about half a second per launch; -1 = the whole stream in one launch)
   int knob_shard_kib = 1 << 20;     // ZADA_SHARD_KIB: bytes of a range the LZ stage takes at a time, in KiB (multiple of 64)
   void tmark(const char *name);
   void tbegin();
@@ -295,7 +299,9 @@ uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size);
 uint32_t lzma_hash4_size(uint32_t sbs);
 uint64_t lzma_workspace_ints(int level, uint32_t sbs);
 int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, const uint32_t *d_ent_start, LzmaJob *d_jobs);
-int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result);
+int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result,
+                uint8_t *d_save = nullptr, uint64_t budget = 0);
+uint64_t lzma_save_stride();
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);
 int ensure_crc_workspace(Ctx *c, uint64_t n);

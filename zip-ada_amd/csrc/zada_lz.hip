@@ -983,7 +983,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           const uint32_t dn = lnk[ca];
           uint32_t aa = ca + off;
           asm("" : "+v"(aa));                                     // (keeps the + 1 of the second byte in the instruction's offset field)
-          const lds_bytes pa = (lds_bytes)aa;
+          const lds_bytes pa = (lds_bytes)(uintptr_t)aa;
           const uint32_t c16 = (uint32_t)pa[0] | ((uint32_t)pa[1] << 8);
           cb = ca - dn;
           walk = !(c16 == s_end || (int)cb < lim_pos);
@@ -995,7 +995,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
           const uint32_t dn = lnk[cb];
           uint32_t ab = cb + off;
           asm("" : "+v"(ab));
-          const lds_bytes pb = (lds_bytes)ab;
+          const lds_bytes pb = (lds_bytes)(uintptr_t)ab;
           const uint32_t c16 = (uint32_t)pb[0] | ((uint32_t)pb[1] << 8);
           ca = cb - dn;
           walk = !(c16 == s_end || (int)ca < lim_pos);

@@ -957,7 +957,7 @@ __device__ __noinline__ void lz_next_symbol() {           // Get_Next_Symbol :16
   lz_send_dl(main_dist, main_len);
 }
 
-__device__ void lz_bt4(int sbs, int32_t *ws, uint32_t hash4_size) {
+__device__ bool lz_bt4_begin(int sbs, int32_t *ws, uint32_t hash4_size) {        // LZ77_using_BT4 up to its main loop; False: nothing to code
   s_B.sbs = sbs; s_B.readPos = -1; s_B.readLimit = -1; s_B.writePos = 0; s_B.pendingSize = 0;
   s_B.keepSizeBefore = BT_OPTS + sbs;
   s_B.keepSizeAfter = BT_OPTS + BT_LOOK;
@@ -972,54 +972,101 @@ __device__ void lz_bt4(int sbs, int32_t *ws, uint32_t hash4_size) {
   s_B.best_len_rep = 0; s_B.best_rep_index = 0;
   s_B.cur = 0; s_B.cur_literal = 0;
   s_MM[0].count = 0; s_MM[1].count = 0;
-  int written = bt_fill_window(sbs);
-  if (written > 0) {
-    for (;;) {
-      lz_next_symbol();
-      if (bt_available() == 0) {
-        written = bt_fill_window(sbs);
-        if (written == 0) break;
-      }
-    }
-  }
+  return bt_fill_window(sbs) > 0;
 }
 #undef BUF
 
 // ---------------------------------------------------------------- one stream per workgroup
 
+// A stream in several launches.  Zip.Compress.LZMA_E reports progress and can be aborted between any two bytes it reads
+// (zip-compress-lzma_e.adb:78-92); one launch per stream would be minutes to hours without either.  Everything a stream carries from
+// one step of its main loop to the next lives in the four LDS objects (model, match sets, coder, BT4; the hash tables and the tree are in
+// HBM anyway), so a launch that has coded `budget` more positions writes them to the job's slot and the next launch goes on there.
+struct LzSave {
+  uint32_t phase;                              // 0: not started, 1: under way, 2: finished
+  uint32_t running;                            // Level_3: the main loop has not seen the end of the input yet
+  uint64_t iter;                               // Level_0: next byte; Level_1 / _2: next token
+  LzProbs P; Matches MM[2]; Enc E; BT4 B;
+};
+constexpr uint64_t LZ_SAVE_STRIDE = (sizeof(LzSave) + 63) & ~63ull;
+static_assert(sizeof(LzProbs) % 4 == 0 && sizeof(Matches) % 4 == 0 && sizeof(Enc) % 4 == 0 && sizeof(BT4) % 4 == 0, "word copies");
+
+template <typename T> __device__ inline void words_out(T *dst, const T &src) {
+  const uint32_t *s = (const uint32_t *)&src; uint32_t *d = (uint32_t *)dst;
+  for (uint32_t i = threadIdx.x; i < sizeof(T) / 4; i += 64) d[i] = s[i];
+}
+template <typename T> __device__ inline void words_in(T &dst, const T *src) {
+  const uint32_t *s = (const uint32_t *)src; uint32_t *d = (uint32_t *)&dst;
+  for (uint32_t i = threadIdx.x; i < sizeof(T) / 4; i += 64) d[i] = s[i];
+}
+
 __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint32_t *order, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
-                                                    int32_t *ws_base, uint64_t *result) {
+                                                    int32_t *ws_base, uint64_t *result, uint8_t *save_base, uint64_t budget) {
   LzProbs &P = s_P;
   const uint32_t job = order ? order[blockIdx.x] : blockIdx.x;      // the longest entries first: workgroups start in index order
   const LzmaJob J = jobs[job];
-  {
-    uint16_t *p = (uint16_t *)&P;
-    for (uint32_t i = threadIdx.x; i < sizeof(LzProbs) / 2; i += 64) p[i] = 1024;    // initial_probability
+  LzSave *S = save_base ? (LzSave *)(save_base + job * LZ_SAVE_STRIDE) : nullptr;
+  const uint32_t phase = S ? S->phase : 0u;
+  if (phase == 2) return;                                           // (coded by an earlier launch of this call)
+  uint64_t iter = 0;
+  bool running = false;
+  if (phase == 1) {
+    words_in(s_P, &S->P); words_in(s_MM[0], &S->MM[0]); words_in(s_MM[1], &S->MM[1]); words_in(s_E, &S->E); words_in(s_B, &S->B);
+    iter = S->iter; running = S->running != 0;
+    __syncthreads();
+  } else {
+    {
+      uint16_t *p = (uint16_t *)&P;
+      for (uint32_t i = threadIdx.x; i < sizeof(LzProbs) / 2; i += 64) p[i] = 1024;    // initial_probability
+    }
+    __syncthreads();
   }
-  __syncthreads();
 #ifdef ZADA_LZ_PROF
   const unsigned long long prof_k0 = clock64();
   for (int i = 0; i < 8; i++) g_lzprof[i] = 0;
 #endif
-  s_E.in = in_base + J.in_off; s_E.n = J.n;
-  s_E.cv = J.level <= 1 ? 0 : J.level == 2 ? 1 : 2;
-  s_E.ES.state = 0; s_E.ES.pos_state = 0; s_E.ES.prev_byte = 0; s_E.ES.pos = 0; s_E.ES.tw = 1;
-  s_E.ES.rep[0] = s_E.ES.rep[1] = s_E.ES.rep[2] = s_E.ES.rep[3] = 0;
-  s_E.width = 0xFFFFFFFFu; s_E.low = 0; s_E.cache = 0; s_E.cache_size = 1;
-  s_E.out = out_base + J.out_off; s_E.cap = J.cap; s_E.olen = 0;
-  if (J.zip_prefix) { put_byte(16); put_byte(2); put_byte(5); put_byte(0); }   // zip-compress-lzma_e.adb:155-158
-  put_byte(3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
-  for (int i = 0; i < 4; i++) put_byte((J.sbs >> (8 * i)) & 255);
+  if (phase == 0) {
+    s_E.in = in_base + J.in_off; s_E.n = J.n;
+    s_E.cv = J.level <= 1 ? 0 : J.level == 2 ? 1 : 2;
+    s_E.ES.state = 0; s_E.ES.pos_state = 0; s_E.ES.prev_byte = 0; s_E.ES.pos = 0; s_E.ES.tw = 1;
+    s_E.ES.rep[0] = s_E.ES.rep[1] = s_E.ES.rep[2] = s_E.ES.rep[3] = 0;
+    s_E.width = 0xFFFFFFFFu; s_E.low = 0; s_E.cache = 0; s_E.cache_size = 1;
+    s_E.out = out_base + J.out_off; s_E.cap = J.cap; s_E.olen = 0;
+    if (J.zip_prefix) { put_byte(16); put_byte(2); put_byte(5); put_byte(0); }   // zip-compress-lzma_e.adb:155-158
+    put_byte(3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
+    for (int i = 0; i < 4; i++) put_byte((J.sbs >> (8 * i)) & 255);
+    if (J.level == 3) running = lz_bt4_begin((int)J.sbs, ws_base + J.ws_off, J.hash4_size);
+  }
+  const uint64_t stop = budget ? s_E.ES.pos + budget : ~0ull;      // (every step of the loops below codes at least one position)
+  bool done = true;
   if (J.level == 0) {
-    for (uint64_t i = 0; i < J.n; i++) emit_literal(s_E.in[i]);                     // No_LZ77
+    for (; iter < J.n; iter++) {                                                   // No_LZ77
+      if (s_E.ES.pos >= stop) { done = false; break; }
+      emit_literal(s_E.in[iter]);
+    }
   } else if (J.level <= 2) {
     const uint32_t *tok = tok_base + J.tok_off;
-    for (uint64_t t = 0; t < J.ntok; t++) {
-      const uint32_t tk = tok[t];
+    for (; iter < J.ntok; iter++) {
+      if (s_E.ES.pos >= stop) { done = false; break; }
+      const uint32_t tk = tok[iter];
       if (tk & 0x80000000u) emit_dl(tk & 0xFFFF, (int)((tk >> 16) & 0x7FFF)); else emit_literal(tk & 0xFF);
     }
   } else {
-    lz_bt4((int)J.sbs, ws_base + J.ws_off, J.hash4_size);
+    while (running) {                                                              // the main loop of LZ77_using_BT4 (lz77.adb:1798-1827)
+      if (s_E.ES.pos >= stop) { done = false; break; }
+      lz_next_symbol();
+      if (bt_available() == 0 && bt_fill_window((int)J.sbs) == 0) running = false;
+    }
+  }
+  if (!done) {
+    __syncthreads();
+    words_out(&S->P, s_P); words_out(&S->MM[0], s_MM[0]); words_out(&S->MM[1], s_MM[1]); words_out(&S->E, s_E); words_out(&S->B, s_B);
+    if (threadIdx.x == 0) {
+      S->phase = 1; S->running = running ? 1u : 0u; S->iter = iter;
+      result[2 * job] = s_E.olen;
+      result[2 * job + 1] = s_E.ES.pos | (1ull << 63);                             // bit 63: more to come
+    }
+    return;
   }
   encode_bit(P.match[s_E.ES.state][s_E.ES.pos_state], 1);                             // end marker :1549-1556
   write_simple_match(0xFFFFFFFFu, 2);
@@ -1027,6 +1074,7 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
 #ifdef ZADA_LZ_PROF
   if (blockIdx.x == 0 && threadIdx.x == 0) printf("LZPROF total %llu literal %llu emit_dl %llu estimate %llu bt_get %llu bt_skip %llu split(all levels) %llu\n", clock64() - prof_k0, g_lzprof[1], g_lzprof[2], g_lzprof[3], g_lzprof[4], g_lzprof[5], g_lzprof[6]);
 #endif
+  if (S && threadIdx.x == 0) S->phase = 2;
   result[2 * job] = s_E.olen;
   result[2 * job + 1] = s_E.ES.pos;
 }
@@ -1078,9 +1126,13 @@ int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, co
 }
 
 // jobs[0 .. count): device array; results: 2 x count uint64 (stream bytes, input bytes coded).  Level_3 hash tables must be zero.
-int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result) {
+// d_save / budget: a stream in several launches (count slots of lzma_save_stride() bytes, zero before the first launch; a launch codes
+// `budget` more positions of every unfinished stream and flags bit 63 of its second result while there is more to come); nullptr / 0: one launch.
+uint64_t lzma_save_stride() { return LZ_SAVE_STRIDE; }
+int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result,
+                uint8_t *d_save, uint64_t budget) {
   if (count == 0) return 0;
-  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, d_ws, d_result);
+  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, d_ws, d_result, d_save, d_save ? budget : 0ull);
   return hip_check(c, hipGetLastError(), "k_lzma_encode") ? ZADA_E_HIP : 0;
 }
 
