@@ -41,8 +41,62 @@ import zlib
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_SPEC_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = HBM_SPEC_GBS    # the roofline's peak: min(spec, copy bandwidth measured on this box) once main() has measured it
+HBM_MEASURED = None
 SEED = 0x5A1E51A
+
+
+def host_cpus():
+    """Hardware threads this process may use and, when the container has a CPU quota (cgroup cpu.max), the cores' worth of CPU
+    time it actually gets -- the all-cores baselines scale with the latter, not with the thread count."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = round(int(a) / int(b), 2)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = round(q / per, 2)
+        except Exception:
+            pass
+    return cores, quota
+
+
+def all_cores(fn, parts, one_core_mbs):
+    """fn(part) on every part at once, one thread per part (the oracle is called through ctypes, which releases the GIL; the
+    reference is single-threaded per stream).  Returns the all-cores object of a cpu_baseline."""
+    from concurrent.futures import ThreadPoolExecutor
+    cores, quota = host_cpus()
+    nbytes = sum(len(p) for p in parts)
+    t = time.perf_counter()
+    c0 = time.process_time()
+    with ThreadPoolExecutor(len(parts)) as ex:
+        list(ex.map(fn, parts))
+    dt = time.perf_counter() - t
+    busy = (time.process_time() - c0) / dt if dt > 0 else 0.0
+    v = nbytes / dt / 1e6
+    return {"value": round(v, 2), "unit": "MB/s", "cores": cores, "threads": len(parts), "cpu_quota_cores": quota,
+            "effective_parallelism": round(busy, 1), "speedup_over_one_core": round(v / one_core_mbs, 1) if one_core_mbs else None,
+            "sample": "%d independent streams of %d KiB at once, one per thread, %.1f s (effective_parallelism = CPU seconds per wall second)" % (len(parts), len(parts[0]) >> 10, dt)}
+
+
+def hbm_copy_gbs(torch, dev, mib=1024, reps=5):
+    """Measured HBM bandwidth of this box: a device-to-device copy of `mib` MiB (read + write), best of `reps`, HIP events.
+    SURVEY.md 8d: the roofline's peak is the lower of this and the 8 TB/s of the data sheet."""
+    a = torch.empty(mib << 20, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    a.zero_(); b.copy_(a)
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); b.copy_(a); e1.record(); e1.synchronize()
+        best = max(best, 2.0 * (mib << 20) / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return round(best, 1)
 
 
 def _oracle():
@@ -73,7 +127,6 @@ def _oracle_deflate(O, d):
 def cpu_baseline(za, sample_mib):
     """The CPU restatement of zip-compress-deflate.adb (oracle/, kind "port") timed on the host cores of this box, on the
     first sample_mib MiB of the benchmark stream.  The oracle is used here only as the measured baseline and checker."""
-    from concurrent.futures import ThreadPoolExecutor
     O, P = _oracle()
     n = sample_mib << 20
     d = za.silesia_mix(n, seed=SEED).tobytes()
@@ -81,14 +134,11 @@ def cpu_baseline(za, sample_mib):
     ref = _oracle_deflate(O, d)
     dt = time.perf_counter() - t0
     # all cores: one independent stream per hardware thread (the reference is single-threaded per stream); every thread
-    # takes its own 16 MiB of the stream (ctypes releases the GIL during the call)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # takes its own 8 MiB of the stream
+    cores, _ = host_cpus()
     per = 8 << 20
     parts = [za.silesia_mix(per, seed=SEED, offset=(i + 1) * (64 << 20)).tobytes() for i in range(cores)]
-    t1 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda p: len(_oracle_deflate(O, p)), parts))
-    dta = time.perf_counter() - t1
+    ac = all_cores(lambda p: len(_oracle_deflate(O, p)), parts, n / dt / 1e6)
     # libz with the reference's IZ_10 tuple (lz77.adb:546): the same LZ77 decisions, zlib's own block splitting
     t2 = time.perf_counter()
     zt = P.zp_zlib_tuned_size(d, n, 34, 258, 258, 4096)
@@ -99,8 +149,7 @@ def cpu_baseline(za, sample_mib):
     return {"value": round(n / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
             "sample": "first %d MiB of the same silesia_mix_v1 stream, Deflate_3, oracle/zada_oracle.c single thread, %.1f s" % (sample_mib, dt),
             "ratio": round(len(ref) / n, 4),
-            "all_cores": {"value": round(cores * per / dta / 1e6, 2), "unit": "MB/s", "cores": cores,
-                          "sample": "%d independent streams of 8 MiB, one per hardware thread, %.1f s" % (cores, dta)},
+            "all_cores": ac,
             "zlib_tuned_34_258_258_4096": {"ratio": round(zt / n, 4), "MB/s": round(n / dzt / 1e6, 2)},
             "zlib9": {"ratio": round(z9 / n, 4), "MB/s": round(n / dz9 / 1e6, 2)}}, ref
 
@@ -195,6 +244,10 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
         dtc = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(len(sample) / dtc / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
                                "sample": "first 2 MiB of the workload, oracle/zada_oracle_bz2.c (its BWT is a prefix-doubling sort: faster than the reference's comparison sort)"}
+        cores, _ = host_cpus()
+        per = 1 << 20                                     # (more than one 900 k block each)
+        parts = [host[(i * per) % (n - per):(i * per) % (n - per) + per].tobytes() for i in range(cores)]
+        out["cpu_baseline"]["all_cores"] = all_cores(lambda p: len(oracle_encode(p, 2)[0]), parts, len(sample) / dtc / 1e6)
         if with_checks:
             _, g, _ = enc.bzip2(sample, 14)
             out["sample_stream_equals_cpu_port"] = bool(g == ref)
@@ -247,6 +300,10 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks):
         dtc = time.perf_counter() - t2
         out["cpu_baseline"] = {"value": round(k * size / dtc / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
                                "sample": "the first %d entries, oracle/zada_oracle_lzma.c" % k}
+        cores, _ = host_cpus()
+        per = max(1, (512 << 10) // size)                 # entries per thread: 512 KiB of them
+        groups = [b"".join(datas[(i * per + j) % entries] for j in range(per)) for i in range(cores)]
+        out["cpu_baseline"]["all_cores"] = all_cores(lambda g: [oracle_lzma(g[o:o + size], 18) for o in range(0, len(g), size)] and len(g), groups, k * size / dtc / 1e6)
         if with_checks:
             out["sample_payloads_equal_cpu_port"] = bool(all(res[i] == ref[i] for i in range(k)))
     if with_checks:
@@ -395,6 +452,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    global HBM_PEAK_GBS, HBM_MEASURED
+    HBM_MEASURED = hbm_copy_gbs(torch, dev)
+    HBM_PEAK_GBS = min(HBM_SPEC_GBS, HBM_MEASURED)
     za = importlib.import_module("zip-ada_amd")
     sharding = importlib.import_module("zip-ada_amd.sharding")
     enc = za.Encoder(local_rank)
@@ -511,9 +571,9 @@ def main():
                        "value_is": "device-resident input (host buffers: see host_path)",
                        "phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in phase_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": kernels[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(n, kernels[dom]) if world == 1 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "peak_spec": HBM_SPEC_GBS, "peak_measured_copy": HBM_MEASURED, "traffic": pmc_traffic(n, kernels[dom]) if world == 1 else None,
                          "bound2": second_bound(kernels[dom]),
-                         "note": "algorithmic bytes = N_in + N_out per launch; the LZ kernels are latency / issue bound (radix sort of positions, chain walk), not HBM bound"},
+                         "note": "algorithmic bytes = N_in + N_out per launch; peak = min(data sheet, 1 GiB device-to-device copy measured on this box, read + write); the LZ kernels are latency / issue bound (radix sort of positions, chain walk), not HBM bound"},
         }
         stream = b""
         if world == 1 and args.no_host_path:
@@ -525,9 +585,11 @@ def main():
             hout[:] = 0                                   # (pages touched before the clock starts)
             enc.deflate_into(host, hout, za.Method.Deflate_3)
             t1 = time.perf_counter()
-            _, ol_h, crc_h = enc.deflate_into(host, hout, za.Method.Deflate_3)
-            dth = time.perf_counter() - t1
-            res["host_path"] = {"value": round(n / dth / 1e6, 2), "unit": "MB/s", "entry": "zada_deflate (pageable host buffers in and out, PCIe both ways included)"}
+            for _ in range(args.steps):
+                _, ol_h, crc_h = enc.deflate_into(host, hout, za.Method.Deflate_3)
+            dth = (time.perf_counter() - t1) / args.steps
+            res["host_path"] = {"value": round(n / dth / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dth * 1e3, 3), "steps": args.steps,
+                                "entry": "zada_deflate (pageable host buffers in and out, PCIe both ways included), the same %d steps" % args.steps}
             stream = hout[:ol_h].tobytes()
         else:
             stream = bytes(state["stream"].cpu().numpy()) if state["stream"] is not None else b""
