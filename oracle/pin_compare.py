@@ -9,8 +9,20 @@ import subprocess
 import sys
 
 zipada, work, root = sys.argv[1:4]
+zipada = zipada.split()                                       # ("python3 oracle/zipada_stub.py" for the rehearsal without GNAT)
 sys.path.insert(0, os.path.join(root, "tests"))
 from _common import GOLDEN, edge_inputs  # noqa: E402
+
+LIMIT = int(os.environ.get("PIN_LIMIT", "0"))                 # rehearsals: at most this many inputs per half (0 = all)
+# What the Ada binary's bytes depend on OUTSIDE the zip-ada tree (exactness notes): worth knowing when a difference shows up.
+print("note: BZip2 streams depend on GNAT's Ada.Containers.Generic_Constrained_Array_Sort (a-cgcaso.adb: heap sort, its order of equal keys)")
+print("note: BZip2 segmentation depends on the C library's log() behind Ada.Numerics.Elementary_Functions.Log (data_segmentation.adb)")
+print("note: LZMA estimates are `digits 15` floating point: the oracle assumes IEEE doubles without fused multiply-add")
+
+
+def limited(items):
+    items = sorted(items)
+    return items[:LIMIT] if LIMIT else items
 
 OPT = {6: "-edf", 7: "-ed0", 8: "-ed1", 9: "-ed2", 10: "-ed3"}
 cases = dict(edge_inputs())
@@ -18,7 +30,7 @@ for f in ("sample.xls", "sample.jpg", "sample_pgm_100k.bin"):
     cases[f] = open(os.path.join(GOLDEN, f), "rb").read()
 dig = json.load(open(os.path.join(GOLDEN, "deflate_digests.json")))
 bad = checked = 0
-for name, data in sorted(cases.items()):
+for name, data in limited(cases.items()):
     src = os.path.join(work, "in.bin")
     open(src, "wb").write(data)
     for m, opt in OPT.items():
@@ -26,7 +38,7 @@ for name, data in sorted(cases.items()):
         arc = os.path.join(work, "out.zip")
         if os.path.exists(arc):
             os.remove(arc)
-        subprocess.run([zipada, opt, arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
+        subprocess.run(zipada + [opt, arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
         z = open(arc, "rb").read()
         sig, ver, flag, method, tm, crc, csize, usize, nl, xl = struct.unpack("<4sHHHIIIIHH", z[:30])
         assert sig == b"PK\x03\x04"
@@ -45,7 +57,7 @@ bdig = json.load(open(os.path.join(GOLDEN, "bzip2_digests.json")))
 bcases = bz_inputs()
 for f in ("sample.xls", "sample.jpg", "sample_pgm_100k.bin"):
     bcases[f] = open(os.path.join(GOLDEN, f), "rb").read()
-for key, want in sorted(bdig.items()):
+for key, want in limited(bdig.items()):
     name, m = key.split("|")
     data = bcases[name]
     src = os.path.join(work, "in.bin")
@@ -53,7 +65,7 @@ for key, want in sorted(bdig.items()):
     arc = os.path.join(work, "out.zip")
     if os.path.exists(arc):
         os.remove(arc)
-    subprocess.run([zipada, {"12": "-eb1", "13": "-eb2", "14": "-eb3"}[m], arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
+    subprocess.run(zipada + [{"12": "-eb1", "13": "-eb2", "14": "-eb3"}[m], arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
     z = open(arc, "rb").read()
     sig, ver, flag, method, tm, crc, csize, usize, nl, xl = struct.unpack("<4sHHHIIIIHH", z[:30])
     payload = z[30 + nl + xl:30 + nl + xl + csize]
@@ -71,7 +83,7 @@ ldig = json.load(open(os.path.join(GOLDEN, "lzma_digests.json")))
 lcases = lz_inputs()
 for f in ("sample.xls", "sample.jpg", "sample_pgm_100k.bin"):
     lcases[f] = open(os.path.join(GOLDEN, f), "rb").read()
-for key, want in sorted(ldig.items()):
+for key, want in limited(ldig.items()):
     name, m = key.split("|")
     data = lcases[name]
     src = os.path.join(work, "in.bin")
@@ -79,7 +91,7 @@ for key, want in sorted(ldig.items()):
     arc = os.path.join(work, "out.zip")
     if os.path.exists(arc):
         os.remove(arc)
-    subprocess.run([zipada, {"15": "-el0", "16": "-el1", "17": "-el2", "18": "-el3"}[m], arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
+    subprocess.run(zipada + [{"15": "-el0", "16": "-el1", "17": "-el2", "18": "-el3"}[m], arc, src], check=True, stdout=subprocess.DEVNULL, cwd=work)
     z = open(arc, "rb").read()
     sig, ver, flag, method, tm, crc, csize, usize, nl, xl = struct.unpack("<4sHHHIIIIHH", z[:30])
     payload = z[30 + nl + xl:30 + nl + xl + csize]
@@ -92,5 +104,8 @@ for key, want in sorted(ldig.items()):
         bad += 1
         print("DIFFERENT: %s LZMA method %s: zipada wrote %d bytes (zip method %d), the oracle %s" % (name, m, csize, method, want["size"]))
 print("%d streams compared, %d different" % (checked, bad))
-print("PINNED: the oracle's streams are the Ada binary's" if bad == 0 else "NOT pinned")
+if any("zipada_stub" in a for a in zipada):
+    print("REHEARSAL with oracle/zipada_stub.py: the harness works end to end; nothing is pinned (the oracle was compared with itself)")
+else:
+    print("PINNED: the oracle's streams are the Ada binary's" if bad == 0 else "NOT pinned")
 sys.exit(1 if bad else 0)

@@ -12,7 +12,7 @@ import zlib
 import numpy as np
 import pytest
 
-from _common import (GOLDEN, LEVEL, METHODS, TUNE, edge_inputs, oracle, oracle_deflate, oracle_tokens, oracle_zip,
+from _common import (GOLDEN, LEVEL, METHODS, ROOT, TUNE, edge_inputs, oracle, oracle_deflate, oracle_tokens, oracle_zip,
                      position_tokens, silesia_mix, zlibpin)
 
 FIXTURE_FILES = ("sample.xls", "sample.jpg", "sample_pgm_100k.bin")
@@ -224,3 +224,18 @@ def test_every_block_format_is_byte_compared():
     c9 = [a for a, _ in per_case[("copies_1500k", 9)][1]]
     evens = [131072 * k + 750 for k in range(0, 3)]
     assert all(e in c10 for e in evens) and not any(e in c9 for e in evens), (c10, c9)
+
+
+def test_pin_harness_rehearsal_with_a_stub_zipada(tmp_path):
+    """oracle/pin_with_gnat.sh is what would pin the oracle to the Ada binary on a box with GNAT.  Its second half (pin_compare.py:
+    zipada's option letters, local-header parsing, stored entries, digest comparison) is rehearsed here against oracle/zipada_stub.py,
+    a stand-in with zipada's command line that compresses with the oracle itself -- so that the harness is known to work the day a
+    GNAT box exists.  Nothing is pinned by this (the script says so)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PIN_LIMIT="3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "pin_compare.py"), "%s %s" % (sys.executable, os.path.join(ROOT, "oracle", "zipada_stub.py")),
+                        str(tmp_path), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 different" in r.stdout and "REHEARSAL" in r.stdout and "PINNED" not in r.stdout
+    assert "a-cgcaso.adb" in r.stdout

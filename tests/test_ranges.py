@@ -13,12 +13,11 @@ pytestmark = pytest.mark.gpu
 
 
 def gpu_deflate(enc, d, method):
-    za = product()
-    try:
-        out, crc = enc.deflate(d, method)
-        return 0, out, crc
-    except za.CompressionInefficient:
-        return 1, b"", None
+    """(rc, stream, running CRC register) -- the register is delivered also when the stream is inefficient (the caller Stores
+    the entry with it, zip-compress.adb:224-237)."""
+    out = bytearray(len(d) + 64)
+    rc, ol, crc = enc.deflate_into(d, out, method)
+    return rc, bytes(out[:ol]) if rc == 0 else b"", crc
 
 
 def test_shards_do_not_change_a_byte(encoder):

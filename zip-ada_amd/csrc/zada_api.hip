@@ -856,6 +856,7 @@ static void ctx_release(zada_ctx *z) {
   if (z->c.btab) hipHostFree(z->c.btab);
   if (z->c.ev_input) hipEventDestroy(z->c.ev_input);
   if (z->c.ev_out) hipEventDestroy(z->c.ev_out);
+  if (z->c.ev_dlim) hipEventDestroy(z->c.ev_dlim);
   if (z->c.stream) hipStreamDestroy(z->c.stream);
   delete z;
 }
@@ -870,7 +871,7 @@ zada_ctx *zada_create(int device) {
   if (hipStreamCreate(&z->c.stream) != hipSuccess ||
       hipHostMalloc((void **)&z->c.crc_host, (CRC_HOST_TOP + 64) * 4, hipHostMallocDefault) != hipSuccess ||
       hipStreamCreate(&z->c.stream2) != hipSuccess || hipEventCreateWithFlags(&z->c.ev_input, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&z->c.ev_out, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx_release(z); return nullptr; }
+      hipEventCreateWithFlags(&z->c.ev_out, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&z->c.ev_dlim, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx_release(z); return nullptr; }
   // tuning knobs: read once per context
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
   if (const char *e = getenv("ZADA_INNER_BUDGET")) z->c.knob_inner_budget = atoi(e);

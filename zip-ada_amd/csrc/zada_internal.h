@@ -230,7 +230,7 @@ constexpr uint64_t STAGE_BYTES = 8ull << 20;
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: CRC-32, next to the LZ stage
-  hipEvent_t ev_input = nullptr, ev_out = nullptr;
+  hipEvent_t ev_input = nullptr, ev_out = nullptr, ev_dlim = nullptr;
   CrcPending crc;
   uint32_t *crc_host = nullptr;                     // pinned: [CRC_HOST_TOP] top-level values, then 4 x 16 leftovers
   uint8_t *stage[8] = {};                            // pinned staging buffers of the host-buffer entry points: four copy lanes x two (copy_in / copy_out)

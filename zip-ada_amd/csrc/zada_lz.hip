@@ -92,6 +92,14 @@ __device__ __forceinline__ bool sameL(const uint8_t *__restrict__ in, uint64_t p
   return ((load8(in, p) ^ load8(in, q)) & mask) == 0;
 }
 
+// Eight window bytes at any byte offset from three aligned dwords.  (gfx950 also accepts misaligned
+// ds_read addresses, but measured 35 % slower in k_match than aligned pieces + alignbyte.)
+__device__ __forceinline__ uint64_t lds_u64_at(const uint8_t *b, uint32_t o) {
+  const uint32_t *w = (const uint32_t *)(b + (o & ~3u));
+  const uint32_t x = w[0], y = w[1], z = w[2], s = o & 3u;
+  return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
+}
+
 // --------------------------------------------------------------------------------------------
 // Stable LSD radix sort of a segment's positions by a 16-bit key, entirely in LDS and registers.
 // 16 waves; in every pass wave w owns the elements [w*2048, w*2048+2048) of the pass's input order and
@@ -209,12 +217,17 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint32_t *bsc = bsc3 + seg * 32768ull;          // bucket start | count << 16
   uint16_t *s3 = S3 + seg * 32768ull;
   uint8_t *t3 = T3 + seg * 32768ull;              // top three bits of byte 0: what the 15-bit hash drops
+#ifdef ZADA_OLD_INIT
   for (int l = 0; l < NLEVELS; l++) {
     uint16_t *tail = lv.tails[l] + seg * 65536ull;                  // 65536 buckets per level
     for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tail)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
   }
-  for (int i = tid; i < 32768 / 4; i += 1024) ((uint4 *)bsc)[i] = make_uint4(0, 0, 0, 0);
   for (uint32_t e = tid; e < m; e += 1024) dp.dlim[base + e] = 0xFFFFFFFFu;   // no chain-length limit unless k_bucket_limits finds one
+#endif
+  // (The tails tables -- last position of each of the 65 536 buckets of a level -- are NOT initialised: only occupied buckets are
+  // written below, and k_cross_links tells a stale entry from a tail by hashing the position it names.  "No chain-length limit",
+  // the default of dlim, is a memset on the second stream: lz_shard.)
+  for (int i = tid; i < 32768 / 4; i += 1024) ((uint4 *)bsc)[i] = make_uint4(0, 0, 0, 0);
   const uint8_t *sin = in + base;
   PL_STAMP();   // 8: table init
   uint32_t *F = cnt;                               // level 3: bucket-start bitmask of the sorted order, 1024 words (+1 spill word)
@@ -565,15 +578,32 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
   if (lay_first(L, seg)) return;                                   // an entry's first segment has nothing before it
   const uint32_t m = lay_inserted(L, seg);
   const bool prev_first = lay_first(L, seg - 1);
+#ifndef ZADA_OLD_INIT
+  const uint32_t m_prev = lay_inserted(L, seg - 1);
+#endif
   {
     const uint4 *src = (const uint4 *)(lv.tails[l] + (seg - 1) * 65536ull);
     for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tl)[i] = src[i];
-    if (has_plane) {
+#ifdef ZADA_OLD_INIT
+    if (has_plane)
+#endif
+    {
       const uint4 *bs = (const uint4 *)(in + pbase);
       for (int i = tid; i < 32768 / 16; i += 1024) ((uint4 *)(smem + 131072))[i] = bs[i];
     }
   }
   __syncthreads();
+#ifndef ZADA_OLD_INIT
+  // Only the occupied buckets of the table were written by k_prev_links; the others hold whatever the memory held.  An entry t is
+  // the bucket's tail iff position t of the previous segment was inserted and hashes to the bucket: if any inserted position does,
+  // the bucket is occupied and its entry was written in this call.  (The last bytes of the segment are not all staged: global loads.)
+  auto is_tail = [&](uint32_t t, uint32_t key) -> bool {
+    if (t >= m_prev) return false;
+    uint64_t v;
+    if (t <= 32768u - 12u) v = lds_u64_at(pb, t); else v = load8(in, pbase + t);
+    return hashL_of(v, 4 + l) == key;
+  };
+#endif
   uint16_t *prevl = lv.prev[l] + base;
   uint16_t *plane = has_plane ? dp.d[1 + l] + base : nullptr;
   const uint8_t *sin = in + base;
@@ -591,9 +621,14 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
       const bool cont = (pl[k] & DISTL_CONTINUE) != 0;
       if (pv[k] != 0 && !cont) continue;
       const uint32_t e = e0 + 1024 * k;
-      const uint32_t t = tl[hashL_of(v[k], 4 + l)];
+      const uint32_t key = hashL_of(v[k], 4 + l);
+      const uint32_t t = tl[key];
       const uint64_t q = pbase + t, d = base + e - q;
+#ifdef ZADA_OLD_INIT
       const bool reach = t != 0xFFFFu && d <= (uint64_t)MAX_DIST && !(prev_first && t == 0);    // position 0 is never a match source (:467)
+#else
+      const bool reach = is_tail(t, key) && d <= (uint64_t)MAX_DIST && !(prev_first && t == 0); // position 0 is never a match source (:467)
+#endif
       if (pv[k] == 0 && reach) prevl[e] = (uint16_t)d;
       if (cont) {
         // the search for the nearest position sharing 4 + l bytes goes on at the tail: none in reach -> none at all (older
@@ -788,13 +823,6 @@ constexpr int WLINKS = HALO + MB;                 // 48896
 constexpr int MATCH_LDS = WBYTES + WLINKS * 2 + 16 + 16 * 128 * 8;   // window, links, work counter, one queue of start records per wave
 static_assert(MATCH_LDS <= 160 * 1024, "k_match: one workgroup per CU");
 
-// Eight window bytes at any byte offset from three aligned dwords.  (gfx950 also accepts misaligned
-// ds_read addresses, but measured 35 % slower in this kernel than aligned pieces + alignbyte.)
-__device__ __forceinline__ uint64_t lds_u64_at(const uint8_t *b, uint32_t o) {
-  const uint32_t *w = (const uint32_t *)(b + (o & ~3u));
-  const uint32_t x = w[0], y = w[1], z = w[2], s = o & 3u;
-  return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
-}
 #define LDS_U16(b, o) ((uint32_t)(b)[(o)] | ((uint32_t)(b)[(o) + 1] << 8))
 
 // First pass of the match finder: a BOUNDED search for every position (see lz_stage: "demand driven").
@@ -1675,8 +1703,19 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   dpl.dlim = W.dlim;
   if (nseg > 0) {
     for (int l = 0; l < NLEVELS; l++) { lv.prev[l] = W.lprev[l]; lv.tails[l] = W.ltails[l]; }
+#ifndef ZADA_OLD_INIT
+    // "no chain-length limit" for every position (k_bucket_limits writes the few there are): a memset next to k_prev_links, which
+    // leaves the memory pipes mostly idle (one workgroup per CU, bound by its LDS round trips)
+    hipEventRecord(c->ev_dlim, st);                                  // (the shard before has read the plane)
+    hipStreamWaitEvent(c->stream2, c->ev_dlim, 0);
+    hipMemsetAsync(W.dlim, 0xFF, (size_t)n * 4, c->stream2);
+    hipEventRecord(c->ev_dlim, c->stream2);
+#endif
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
                        W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax);
+#ifndef ZADA_OLD_INIT
+    hipStreamWaitEvent(st, c->ev_dlim, 0);
+#endif
 #ifdef ZADA_PL_STATS
     { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); hipMemset(W.dbg, 0, 256);
       unsigned long long sd[8]; hipMemcpyFromSymbol(sd, HIP_SYMBOL(g_sort_dbg), sizeof sd); fprintf(stderr, "[sort_pass cycles/segment, all six passes] clear %.0f  rank (LDS atomics) %.0f  scan %.0f  scatter %.0f\n", (double)sd[0] / nseg, (double)sd[1] / nseg, (double)sd[2] / nseg, (double)sd[3] / nseg); for (int q = 0; q < 8; q++) sd[q] = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_sort_dbg), sd, sizeof sd); }
