@@ -7,6 +7,9 @@ from _common import product
 Z = product()
 enc = Z.Encoder(0)
 L = Z.load_library()
+for knob in ("bz_lists", "bz_pipeline", "bz_small_wg", "bz_batch_melems"):
+    if os.environ.get(knob.upper()):
+        enc.set_knob(knob, int(os.environ[knob.upper()]))
 for mib in [int(x) for x in os.environ.get("BZ_MIBS", "64,256").split(",")]:
     n = mib << 20
     h = np.zeros(n, np.uint8)
@@ -33,7 +36,7 @@ for mib in [int(x) for x in os.environ.get("BZ_MIBS", "64,256").split(",")]:
         d = _fetch(L, enc, "dbg", np.uint64, 8 * nsb).reshape(-1, 8)
         res = _fetch(L, enc, "res", np.uint32, 8 * nsb).reshape(-1, 8)
         mh = _fetch(L, enc, "bwt_m", np.uint64, 64)
-        print("    BWT rows per round (share of all %d): %s" % (int(mh[0]), " ".join("%.3f" % (x / mh[0]) for x in mh[1:])))
+        print("    BWT rows per round (share of all %d): %s; rounds %d, groups sorted from lists %d" % (int(mh[0]), " ".join("%.3f" % (x / mh[0]) for x in mh[1:]), int(info[1]), int(info[3])))
         st = d[:, 6].astype(np.int64); en = st + d[:, 7].astype(np.int64); t0 = st.min(); span = (en.max() - t0) / 1e5
         grid = np.linspace(t0, en.max(), 41)[:-1]
         conc = [int(((st <= g) & (en > g)).sum()) for g in grid]

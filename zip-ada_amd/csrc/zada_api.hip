@@ -896,6 +896,9 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "bz_batch_mib")) { if (value < 1 || value > 2048) return ZADA_E_INVALID; z->c.knob_bz_batch_mib = value; }
   else if (!strcmp(name, "bz_span_mib")) { if (value < 24 || value > 3072) return ZADA_E_INVALID; z->c.knob_bz_span_mib = value; }
   else if (!strcmp(name, "bz_batch_melems")) { if (value < 1 || value > 1536) return ZADA_E_INVALID; z->c.knob_bz_batch_melems = value; }
+  else if (!strcmp(name, "bz_pipeline")) z->c.knob_bz_pipeline = value;
+  else if (!strcmp(name, "bz_small_wg")) z->c.knob_bz_small_wg = value;
+  else if (!strcmp(name, "bz_lists")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_bz_lists = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }

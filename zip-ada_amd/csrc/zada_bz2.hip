@@ -17,6 +17,7 @@
 #include <string.h>
 #include <math.h>
 #include <algorithm>
+#include <thread>
 #include <vector>
 #include "../../include/zada.h"
 #include "zada_internal.h"
@@ -598,6 +599,215 @@ __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+//  Late rounds: group lists.  The rounds above sweep every row of a sub-block (the rows read in order are what gives the second
+//  halves' order for free), whatever share of them is still unsorted -- and on data with long repeats a few percent of the rows
+//  stay unsorted for ten more doublings, in groups of a handful of rows.  Once every unsorted group of a sub-block has at most
+//  GL_MAX rows the sub-block leaves the sweeps: its groups go on a list (first row, rows, sub-block) and a round sorts each group
+//  by the class of its rows' second halves inside a TEAM of lanes (8 or 64: a bitonic network over cross-lane reads), one launch
+//  over the list, touching nothing but the groups' own rows.  The order among rows that still agree is immaterial (they stay one
+//  group; rotations that are equal to the end have equal last bytes, and the original's row is its group's first: :266-276).
+//  A round reads the classes of the round before: the new classes wait in `nc` until every group has been sorted (k_bz_gl_apply).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t GL_MAX = 64, GL_SMALL = 8;
+struct GlEntry { uint32_t first, rows, sb, pad; };
+struct GlLists { GlEntry *s, *m; uint32_t *cnt; uint32_t cap_s, cap_m; };      // cnt[0] / cnt[1]: entries of s / m; cnt[2]: overflow flag
+
+// largest unsorted group of every sub-block that is still swept: a row is its group's last when the next row's class differs
+__global__ void __launch_bounds__(1024) k_bz_gl_max(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles,
+                                                    const uint8_t *__restrict__ done, uint32_t *__restrict__ submax, uint32_t ntiles_x) {
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
+  if (done[t.sb]) return;
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  uint32_t mx = 0;
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    const uint32_t l = t.lo + i, g = off + l, c = cl[sa[g]];
+    const bool last = l + 1 == n || cl[sa[g + 1]] != c;
+    if (last) mx = max(mx, g - c + 1);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx > 1) atomicMax(&submax[t.sb], mx);
+}
+__global__ void k_bz_gl_decide(SubTab T, const uint8_t *__restrict__ done, const uint32_t *__restrict__ submax, uint8_t *__restrict__ lmode) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < T.nsb) lmode[s] = (!done[s] && submax[s] <= GL_MAX) ? 1 : 0;
+}
+// Appends to the lists, one atomic per WORKGROUP and list (a counter that every wave hits by itself is one address for millions of
+// atomics a round: they queue up at its L2 channel).  Every thread of the workgroup must call it; lds: 2 * waves + 2 words.
+__device__ __forceinline__ void gl_append(GlLists L, bool small, bool medium, uint32_t first, uint32_t rows, uint32_t sb, uint32_t *lds) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const unsigned long long ms = __ballot(small), mm = __ballot(medium), lt = (1ull << lane) - 1ull;
+  __syncthreads();                                                    // (the call before has read its bases)
+  if (lane == 0) { lds[2 * w] = (uint32_t)__popcll(ms); lds[2 * w + 1] = (uint32_t)__popcll(mm); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t ts = 0, tm = 0;
+    for (int k = 0; k < nw; k++) { const uint32_t a = lds[2 * k], b = lds[2 * k + 1]; lds[2 * k] = ts; lds[2 * k + 1] = tm; ts += a; tm += b; }
+    lds[2 * nw] = ts ? atomicAdd(&L.cnt[0], ts) : 0u;
+    lds[2 * nw + 1] = tm ? atomicAdd(&L.cnt[1], tm) : 0u;
+  }
+  __syncthreads();
+  if (small) {
+    const uint32_t i = lds[2 * nw] + lds[2 * w] + (uint32_t)__popcll(ms & lt);
+    if (i < L.cap_s) L.s[i] = GlEntry{first, rows, sb, 0u}; else L.cnt[2] = 1;
+  }
+  if (medium) {
+    const uint32_t i = lds[2 * nw + 1] + lds[2 * w + 1] + (uint32_t)__popcll(mm & lt);
+    if (i < L.cap_m) L.m[i] = GlEntry{first, rows, sb, 0u}; else L.cnt[2] = 1;
+  }
+}
+// the unsorted groups of the sub-blocks that leave the sweeps, listed by their last rows
+__global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles,
+                                                      const uint8_t *__restrict__ lmode, GlLists L, uint32_t ntiles_x) {
+  __shared__ uint32_t lds[34];
+  const uint32_t bx = xcd_tile(ntiles_x);
+  if (bx >= ntiles_x) return;
+  const Tile t = tiles[bx];
+  if (!lmode[t.sb]) return;
+  const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
+  for (uint32_t i0 = 0; i0 < m; i0 += 1024) {
+    const uint32_t i = i0 + threadIdx.x;
+    uint32_t first = 0, rows = 0;
+    if (i < m) {
+      const uint32_t l = t.lo + i, g = off + l, c = cl[sa[g]];
+      if (l + 1 == n || cl[sa[g + 1]] != c) { first = c; rows = g - c + 1; }
+    }
+    gl_append(L, rows > 1 && rows <= GL_SMALL, rows > GL_SMALL, first, rows, t.sb, lds);
+  }
+}
+__global__ void k_bz_gl_leave(SubTab T, const uint8_t *__restrict__ lmode, uint8_t *__restrict__ done) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < T.nsb && lmode[s]) done[s] = 1;
+}
+// One round of the small groups (2 .. 8 rows): a THREAD per group -- most groups of the late rounds are pairs, a team of lanes would
+// idle -- with the group's rows and keys in registers and a sorting network over them.
+__device__ __forceinline__ void gl_cex(uint32_t &ka, uint32_t &va, uint32_t &kb, uint32_t &vb) {
+  const bool sw = kb < ka || (kb == ka && vb < va);
+  const uint32_t k0 = sw ? kb : ka, v0 = sw ? vb : va, k1 = sw ? ka : kb, v1 = sw ? va : vb;
+  ka = k0; va = v0; kb = k1; vb = v1;
+}
+__global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
+                                                          const uint32_t *__restrict__ cl, SubTab T, uint32_t *__restrict__ nc, GlLists next) {
+  __shared__ uint32_t lds[10];
+  const uint32_t count = *cnt_p, gi = blockIdx.x * 256u + threadIdx.x;
+  GlEntry E{0, 0, 0, 0};
+  if (gi < count) E = list[gi];
+  uint32_t n = 1, off = 0;
+  if (E.rows) { n = T.n[E.sb]; off = T.off[E.sb]; }
+  const bool live = E.rows != 0 && h < n;                              // h >= n: the rotations of the group are equal, nothing is left to tell them apart
+  uint32_t k[8], v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { k[j] = 0xFFFFFFFFu; v[j] = 0xFFFFFFFFu; }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) if ((uint32_t)j < E.rows) v[j] = sa[E.first + j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) if ((uint32_t)j < E.rows) { uint32_t l = v[j] - off + h; if (l >= n) l -= n; k[j] = cl[off + l]; }
+    if (E.rows == 2) gl_cex(k[0], v[0], k[1], v[1]);
+    else {
+      // 19 compare-exchanges sort eight (the empty places hold the largest key and stay behind)
+#define CX(a, b) gl_cex(k[a], v[a], k[b], v[b])
+      CX(0, 1); CX(2, 3); CX(4, 5); CX(6, 7); CX(0, 2); CX(1, 3); CX(4, 6); CX(5, 7); CX(1, 2); CX(5, 6); CX(0, 4); CX(3, 7); CX(1, 5); CX(2, 6); CX(1, 4); CX(3, 6); CX(2, 4); CX(3, 5); CX(3, 4);
+#undef CX
+    }
+  }
+  // rows in order; a row starts a new group where its key differs from the row before.  Groups of more than one row go on the next list.
+  uint32_t start = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (live && (uint32_t)j < E.rows) {
+      if (j > 0 && k[j] != k[j - 1]) start = (uint32_t)j;
+      sa[E.first + j] = v[j];
+      nc[E.first + j] = E.first + start;
+    }
+  }
+  // (eight rows make at most four groups of two or more)
+  uint32_t s0 = 0;
+  int found = 0;
+  uint32_t gf[4], gr[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { gf[q] = 0; gr[q] = 0; }
+  if (live) {
+#pragma unroll
+    for (int j = 1; j <= 8; j++) {
+      const bool brk = (uint32_t)j >= E.rows || k[j < 8 ? j : 7] != k[j - 1] || j == 8;
+      if ((uint32_t)j <= E.rows && brk) {
+        if ((uint32_t)j - s0 > 1) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) if (q == found) { gf[q] = E.first + s0; gr[q] = (uint32_t)j - s0; }
+          found++;
+        }
+        s0 = (uint32_t)j;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) gl_append(next, gr[q] > 1, false, gf[q], gr[q], E.sb, lds);
+}
+// one round of the medium groups (9 .. 64 rows): a wave per group, a bitonic network over cross-lane reads
+__global__ void __launch_bounds__(256) k_bz_gl_sort_wave(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
+                                                         const uint32_t *__restrict__ cl, SubTab T, uint32_t *__restrict__ nc, GlLists next) {
+  __shared__ uint32_t lds[10];
+  constexpr int TW = 64;
+  const uint32_t count = *cnt_p;
+  const uint32_t team = (blockIdx.x * 256u + threadIdx.x) / TW;
+  const int tl = threadIdx.x & 63;
+  GlEntry E{0, 0, 0, 0};
+  if (team < count) E = list[team];
+  uint32_t n = 1, off = 0;
+  if (E.rows) { n = T.n[E.sb]; off = T.off[E.sb]; }
+  const bool live = E.rows != 0 && h < n;
+  const bool mine = live && (uint32_t)tl < E.rows;
+  uint32_t k = 0xFFFFFFFFu, v = 0xFFFFFFFFu;
+  if (mine) {
+    v = sa[E.first + tl];
+    uint32_t l = v - off + h;
+    if (l >= n) l -= n;
+    k = cl[off + l];
+  }
+#pragma unroll
+  for (int size = 2; size <= TW; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const uint32_t ok = __shfl_xor(k, stride), ov = __shfl_xor(v, stride);
+      const bool keep_min = ((tl & stride) == 0) == ((tl & size) == 0);
+      const bool other_less = ok < k || (ok == k && ov < v);
+      const bool other_more = ok > k || (ok == k && ov > v);
+      if (keep_min ? other_less : other_more) { k = ok; v = ov; }
+    }
+  }
+  const uint32_t kp = __shfl_up(k, 1);
+  const bool head = mine && (tl == 0 || kp != k);
+  const unsigned long long hm = __ballot(head);
+  uint32_t start = 0, nxt = E.rows;
+  if (mine) {
+    const unsigned long long upto = hm & (tl == 63 ? ~0ull : ((2ull << tl) - 1ull));
+    start = 63u - (uint32_t)__builtin_clzll(upto);
+    const unsigned long long above = tl == 63 ? 0ull : hm & ~((2ull << tl) - 1ull);
+    if (above) nxt = (uint32_t)__builtin_ctzll(above);
+    sa[E.first + tl] = v;
+    nc[E.first + tl] = E.first + start;
+  }
+  const uint32_t rows_new = head ? nxt - (uint32_t)tl : 0u;
+  gl_append(next, rows_new > 1 && rows_new <= GL_SMALL, rows_new > GL_SMALL, E.first + (uint32_t)tl, rows_new, E.sb, lds);
+}
+// the new classes of the groups just sorted (nc) become the classes (cl): TW lanes per group
+template <int TW>
+__global__ void __launch_bounds__(256) k_bz_gl_apply(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, const uint32_t *__restrict__ sa,
+                                                     const uint32_t *__restrict__ nc, SubTab T, uint32_t *__restrict__ cl) {
+  const uint32_t count = *cnt_p;
+  const uint32_t team = (blockIdx.x * 256u + threadIdx.x) / TW;
+  const uint32_t tl = threadIdx.x & (TW - 1);
+  if (team >= count) return;
+  const GlEntry E = list[team];
+  if (TW == 1) {
+    if (h < T.n[E.sb]) for (uint32_t j = 0; j < E.rows; j++) cl[sa[E.first + j]] = nc[E.first + j];
+  } else if (tl < E.rows && h < T.n[E.sb]) cl[sa[E.first + tl]] = nc[E.first + tl];
+}
+
 // rows ordered by `prefix` bytes: a sub-block whose rotations are that short is done (equal rotations stay in one group)
 __global__ void k_bz_done(SubTab T, uint32_t prefix, uint8_t *__restrict__ done) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -865,6 +1075,11 @@ __global__ void __launch_bounds__(64) k_bz_rank(EntTab E, uint32_t first) {
 }
 
 constexpr int EN_THREADS = 512;
+#ifndef ZADA_EN_SMALL_THREADS
+#define ZADA_EN_SMALL_THREADS 256
+#endif
+constexpr int EN_SMALL_THREADS = ZADA_EN_SMALL_THREADS;
+constexpr uint32_t EN_SMALL_SEL = 2040;     // groups a small workgroup takes
 
 // Move-to-front order of the (at most six) coders, and the effect of a stretch of groups on it: the coders chosen in the
 // stretch, most recent first.  Both are lists of nibbles (entry j in bits 4j .. 4j+3) with their length in bits 28 .. 30; the
@@ -881,25 +1096,31 @@ __device__ __forceinline__ uint32_t mtf_compose(uint32_t A, uint32_t B) {
   return list | (k << 28);
 }
 
-__global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t nsb) {
-  __shared__ uint32_t sel4[(BZ_MAX_SEL + 7) / 8 + 2];  // the coder of each group, four bits each (LDS decides how many workgroups a CU holds)
+// THREADS lanes per sub-block, room for MAXSEL groups: the many short sub-blocks (the segments of the splitting tactics) take a
+// smaller workgroup with less LDS, so that twice as many share a CU -- the search is a chain of short dependent phases, the
+// more sub-blocks in flight the better.  `first`: offset in the (largest-first) order of the sub-blocks.
+template <int THREADS, int MAXSEL>
+// (second bound: waves per SIMD that the LDS footprint lets a CU hold -- 3 / 5 / 8 workgroups of 8 / 4 / 2 waves)
+__global__ void __launch_bounds__(THREADS, THREADS >= 512 ? 6 : THREADS >= 256 ? 5 : 4) k_bz_entropy(EntTab E, uint32_t nsb, uint32_t first) {
+  constexpr int NW = THREADS / 64, NLL = NW < 6 ? NW : 6;                // waves, and how many of them make code lengths at a time
+  __shared__ uint32_t sel4[(MAXSEL + 7) / 8 + 2];  // the coder of each group, four bits each (LDS decides how many workgroups a CU holds)
   __shared__ uint32_t freq[6 * BZ_LSTRIDE];          // symbol counts per cluster
   __shared__ uint8_t lens[6 * BZ_LSTRIDE];
   __shared__ unsigned long long lens6[BZ_LSTRIDE];   // the six coders' lengths of a symbol, ten bits apart
-  __shared__ __align__(16) uint8_t scratch[6 * LLHC_WAVE_SCRATCH];
-  __shared__ uint32_t wtot[EN_THREADS / 64];
+  __shared__ __align__(16) uint8_t scratch[NLL * LLHC_WAVE_SCRATCH];
+  __shared__ uint32_t wtot[NW];
   __shared__ uint32_t red[16];
   __shared__ uint32_t dirty;                         // clusters whose counts changed since their code lengths were made
-  const uint32_t s = E.order[blockIdx.x];
+  const uint32_t s = E.order[first + blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t m = E.mtf_n[s], A = E.nsym[s] + 2, ns = 1 + (m - 1) / BZ_GROUP;
   const uint16_t *sym = E.sym + E.soff[s];
   const uint32_t so = E.sel_off[s];
   unsigned long long *gc = (unsigned long long *)E.gcost + so;
-  const uint32_t G = (((ns + EN_THREADS - 1) / EN_THREADS) + 7) & ~7u;             // groups per thread in the chain: whole words of sel4
+  const uint32_t G = (((ns + THREADS - 1) / THREADS) + 7) & ~7u;             // groups per thread in the chain: whole words of sel4
   auto sel_get = [&](uint32_t g) -> uint32_t { return (sel4[g >> 3] >> (4 * (g & 7))) & 15u; };
   const uint32_t g0 = min((uint32_t)tid * G, ns), g1 = min(g0 + G, ns);
-  unsigned long long t_hist = 0, t_llhc = 0, t_cost = 0, t_chain = 0, n_pass = 0, n_round = 0, n_constr = 0;
+  unsigned long long t_hist = 0, t_llhc = 0, t_cost = 0, t_chain = 0, n_pass = 0, n_round = 0;
   const unsigned long long t_begin = wall_clock64();
 
   // counts of one group's symbols go to (sign > 0) or leave (sign < 0) a cluster; the four most frequent symbols (the two
@@ -931,9 +1152,9 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
   };
   auto histogram = [&]() {                                                            // :637-655
     const unsigned long long ta = wall_clock64();
-    for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) freq[i] = 0;
+    for (int i = tid; i < 6 * BZ_LSTRIDE; i += THREADS) freq[i] = 0;
     __syncthreads();
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) count_group(g, 6, sel_get(g) - 1u);
+    for (uint32_t g = tid; g < ns; g += THREADS) count_group(g, 6, sel_get(g) - 1u);
     if (tid == 0) dirty = 63u;
     __syncthreads();
     t_hist += wall_clock64() - ta;
@@ -942,25 +1163,30 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
     const unsigned long long tb = wall_clock64();
     // the counts as the code length procedure reads them (after Avoid_Zeros) sit in that procedure's own scratch, in the part it
     // only uses once the counts have been read
-    for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) ((uint32_t *)(scratch + (i / BZ_LSTRIDE) * LLHC_WAVE_SCRATCH + 1728))[i % BZ_LSTRIDE] = freq[i];
-    __syncthreads();
     const uint32_t todo = dirty;                                                      // same counts, same code lengths: only the clusters that changed
-    if (w < ec && ((todo >> w) & 1u)) {
-      uint32_t *f = (uint32_t *)(scratch + w * LLHC_WAVE_SCRATCH + 1728);
-      int zeroes = 0;
-      for (uint32_t base = 0; base < A; base += 64) { const uint32_t a = base + lane; zeroes += __popcll(__ballot(a < A && f[a] == 0)); }
-      if (zeroes > 0) {                                                               // Avoid_Zeros :436-460
-        for (uint32_t a = lane; a < A; a += 64) { const uint32_t v = f[a]; f[a] = zeroes <= 100 ? (v < 1 ? 1u : v) : (v == 0 ? 1u : v * 2); }
+    if (w < NLL) {
+      for (int k = w; k < ec; k += NLL) {
+        if (!((todo >> k) & 1u)) continue;
+        uint8_t *sc = scratch + w * LLHC_WAVE_SCRATCH;
+        uint32_t *f = (uint32_t *)(sc + 1728);
+        for (uint32_t a = lane; a < (uint32_t)BZ_LSTRIDE; a += 64) f[a] = freq[k * BZ_LSTRIDE + a];
+        wave_sync();
+        int zeroes = 0;
+        for (uint32_t base = 0; base < A; base += 64) { const uint32_t a = base + lane; zeroes += __popcll(__ballot(a < A && f[a] == 0)); }
+        if (zeroes > 0) {                                                               // Avoid_Zeros :436-460
+          for (uint32_t a = lane; a < A; a += 64) { const uint32_t v = f[a]; f[a] = zeroes <= 100 ? (v < 1 ? 1u : v) : (v == 0 ? 1u : v * 2); }
+        }
+        wave_sync();
+        uint8_t *bl = lens + k * BZ_LSTRIDE;
+        if (ml == 15) llhc_wave<15>(f, (int)A, bl, sc, lane);
+        else if (ml == 16) llhc_wave<16>(f, (int)A, bl, sc, lane);
+        else llhc_wave<17>(f, (int)A, bl, sc, lane);
+        wave_sync();
       }
-      wave_sync();
-      uint8_t *bl = lens + w * BZ_LSTRIDE, *sc = scratch + w * LLHC_WAVE_SCRATCH;
-      if (ml == 15) llhc_wave<15>(f, (int)A, bl, sc, lane);
-      else if (ml == 16) llhc_wave<16>(f, (int)A, bl, sc, lane);
-      else llhc_wave<17>(f, (int)A, bl, sc, lane);
     }
     __syncthreads();
     if (tid == 0) dirty = 0;
-    for (uint32_t y = tid; y < A; y += EN_THREADS) {
+    for (uint32_t y = tid; y < A; y += THREADS) {
       unsigned long long v = 0;
       for (int cl = 0; cl < ec; cl++) v |= (unsigned long long)lens[cl * BZ_LSTRIDE + y] << (10 * cl);
       lens6[y] = v;
@@ -970,7 +1196,7 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
   };
   auto compute_costs = [&]() {                                                        // the bit_count of :735-739, all groups at once
     const unsigned long long ta = wall_clock64();
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) {
+    for (uint32_t g = tid; g < ns; g += THREADS) {
       const uint32_t cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
       uint32_t v[25];
       load_group(g, v);
@@ -994,21 +1220,32 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
     auto run = [&]() {
       uint32_t perm = used;
       def = 0; selc = 0; chosen = 0; nw0 = 0; nw1 = 0;
-      for (uint32_t g = g0; g < g1; g++) {
-        const unsigned long long cp = gc[g];
-        const uint32_t old = sel_get(g);
-        uint32_t bestc = 0xFFFFFFFFu, bestcl = old, bestpos = 1;
-        for (int j = 0; j < ec; j++) {
-          const uint32_t cl = (perm >> (4 * j)) & 15u;
-          const uint32_t cost = (uint32_t)((cp >> (10 * (cl - 1))) & 1023u) + (uint32_t)j + 1;
-          if (cost < bestc || (cost == bestc && cl < bestcl)) { bestc = cost; bestcl = cl; bestpos = (uint32_t)j + 1; }
+      // the groups' costs eight at a time: the loads are in flight together (one by one, each was a round trip to L2 in a serial loop)
+      for (uint32_t gb = g0; gb < g1; gb += 8) {
+        unsigned long long cps[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cps[q] = gb + q < g1 ? gc[gb + q] : 0ull;
+        const uint32_t olds = sel4[gb >> 3];                                           // (g0 and the stretch length are multiples of eight)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t g = gb + q;
+          if (g < g1) {
+            const unsigned long long cp = cps[q];
+            const uint32_t old = (olds >> (4 * q)) & 15u;
+            uint32_t bestc = 0xFFFFFFFFu, bestcl = old, bestpos = 1;
+            for (int j = 0; j < ec; j++) {
+              const uint32_t cl = (perm >> (4 * j)) & 15u;
+              const uint32_t cost = (uint32_t)((cp >> (10 * (cl - 1))) & 1023u) + (uint32_t)j + 1;
+              if (cost < bestc || (cost == bestc && cl < bestcl)) { bestc = cost; bestcl = cl; bestpos = (uint32_t)j + 1; }
+            }
+            if (bestcl != old) def++;
+            selc += bestpos;
+            chosen |= 1u << bestcl;
+            const uint32_t lowm = (1u << (4 * (bestpos - 1))) - 1u, upto = (1u << (4 * bestpos)) - 1u;
+            perm = (perm & ~upto) | ((perm & lowm) << 4) | bestcl;
+            { const uint32_t qq = g - g0; if (qq < 21) nw0 |= (unsigned long long)bestcl << (3 * qq); else nw1 |= (unsigned long long)bestcl << (3 * (qq - 21)); }
+          }
         }
-        if (bestcl != old) def++;
-        selc += bestpos;
-        chosen |= 1u << bestcl;
-        const uint32_t lowm = (1u << (4 * (bestpos - 1))) - 1u, upto = (1u << (4 * bestpos)) - 1u;
-        perm = (perm & ~upto) | ((perm & lowm) << 4) | bestcl;
-        { const uint32_t q = g - g0; if (q < 21) nw0 |= (unsigned long long)bestcl << (3 * q); else nw1 |= (unsigned long long)bestcl << (3 * (q - 21)); }
       }
       const uint32_t k = __popc(chosen);
       outv = (perm & ((1u << (4 * k)) - 1u)) | (k << 28);                              // the stretch's effect
@@ -1031,7 +1268,6 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
       used = in;
       if (!__syncthreads_or(need ? 1 : 0)) break;
     }
-    const unsigned long long tu = wall_clock64();
     if (tid < 3) red[tid] = 0;
     __syncthreads();
     if (def) atomicAdd(&red[0], def);
@@ -1048,7 +1284,7 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
     }
     __syncthreads();
     const uint32_t ndef = red[2];
-    for (uint32_t i = tid; i < ndef; i += EN_THREADS) {                                 // ... they take their counts along, all threads sharing the work
+    for (uint32_t i = tid; i < ndef; i += THREADS) {                                 // ... they take their counts along, all threads sharing the work
       const uint32_t v = E.deflist[so + i];
       count_group(v & 0xFFFFu, (v >> 16) & 15u, (v >> 20) & 15u);
       atomicOr(&dirty, (1u << ((v >> 16) & 15u)) | (1u << ((v >> 20) & 15u)));
@@ -1057,12 +1293,11 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
     defectors = red[0]; selbits = red[1];
     __syncthreads();
     t_chain += wall_clock64() - ta;
-    n_constr += wall_clock64() - tu;
   };
   auto cluster_statistics = [&](int ec) -> bool {                                     // :756-779
     if (tid < 8) red[8 + tid] = 0;
     __syncthreads();
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) atomicAdd(&red[8 + sel_get(g)], 1u);
+    for (uint32_t g = tid; g < ns; g += THREADS) atomicAdd(&red[8 + sel_get(g)], 1u);
     __syncthreads();
     const uint32_t uniform_usage = ns / (uint32_t)ec;
     bool low = false;
@@ -1075,9 +1310,9 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
     {                                                                                 // Initial_Clustering_by_Rank :574-591
       const uint32_t attr = ec == 2 ? 0x12u : ec == 3 ? 0x213u : ec == 4 ? 0x3124u : ec == 5 ? 0x42135u : 0x531246u;
       const uint16_t *rk = E.rank_idx + (size_t)widx * E.selcap + so;
-      for (uint32_t i = tid; i < (ns + 7) / 8 + 1; i += EN_THREADS) sel4[i] = 0;
+      for (uint32_t i = tid; i < (ns + 7) / 8 + 1; i += THREADS) sel4[i] = 0;
       __syncthreads();
-      for (uint32_t i = tid; i < ns; i += EN_THREADS) {
+      for (uint32_t i = tid; i < ns; i += THREADS) {
         uint32_t a32 = 1;
         while ((uint32_t)(a32 * ns / (uint32_t)ec) < i + 1) a32++;
         const uint32_t g = rk[i] - 1u;
@@ -1100,11 +1335,11 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
     if (tid < 2) red[tid] = 0;
     __syncthreads();
     uint32_t d = 0;
-    for (uint32_t g = tid; g < ns; g += EN_THREADS) d += (uint32_t)((gc[g] >> (10 * (sel_get(g) - 1))) & 1023u);
+    for (uint32_t g = tid; g < ns; g += THREADS) d += (uint32_t)((gc[g] >> (10 * (sel_get(g) - 1))) & 1023u);
     for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
     if (lane == 0 && d) atomicAdd(&red[0], d);
     uint32_t tb = 0;
-    for (uint32_t q = tid; q < (uint32_t)ec * A; q += EN_THREADS) {
+    for (uint32_t q = tid; q < (uint32_t)ec * A; q += THREADS) {
       const uint32_t cl = q / A, i = q % A;
       const int cur = lens[cl * BZ_LSTRIDE + i], prev = lens[cl * BZ_LSTRIDE + (i ? i - 1 : 0)];
       tb += 1u + 2u * (uint32_t)(cur > prev ? cur - prev : prev - cur) + (i == 0 ? 5u : 0u);
@@ -1137,8 +1372,8 @@ __global__ void __launch_bounds__(EN_THREADS, 6) k_bz_entropy(EntTab E, uint32_t
         const uint32_t cost = k.data + k.selb + k.tree;
         if (cost < best_cost) {      // :926-950; the reference constructs the winner once more at the end (:952-960): same input, same result, so it is kept here
           best_cost = cost; best_ec = ec; best_ml = mcl[a]; best_w = b;
-          for (uint32_t g = tid; g < ns; g += EN_THREADS) { E.sel[so + g] = (uint8_t)sel_get(g); E.gcbest[so + g] = gc[g]; }
-          for (int i = tid; i < 6 * BZ_LSTRIDE; i += EN_THREADS) E.lens[(size_t)s * 6 * BZ_LSTRIDE + i] = (i / BZ_LSTRIDE < ec && (uint32_t)(i % BZ_LSTRIDE) < A) ? lens[i] : 0;
+          for (uint32_t g = tid; g < ns; g += THREADS) { E.sel[so + g] = (uint8_t)sel_get(g); E.gcbest[so + g] = gc[g]; }
+          for (int i = tid; i < 6 * BZ_LSTRIDE; i += THREADS) E.lens[(size_t)s * 6 * BZ_LSTRIDE + i] = (i / BZ_LSTRIDE < ec && (uint32_t)(i % BZ_LSTRIDE) < A) ? lens[i] : 0;
           if (tid == 0) {
             uint32_t *r = E.res + (size_t)s * 8;
             r[0] = (uint32_t)ec; r[1] = (uint32_t)mcl[a]; r[2] = (uint32_t)(E.option == 2 ? 3 + b : 4); r[3] = ns;
@@ -1471,6 +1706,8 @@ struct Bz2State {
   DBuf rtiles, rtile_first, rtile_val, rtile_crc, rtile_rs, etiles, etile_first;
   // element space
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
+  DBuf gl_s[2], gl_m[2], gl_nc, gl_submax, gl_lmode, gl_cnt;   // group lists of the late rounds (k_bz_gl_*)
+  uint64_t gl_rows = 0;             // groups the lists' rounds of the last batch sorted (profiling aid)
   std::vector<uint32_t> h_cm, h_cfirst;
   std::vector<uint64_t> m_hist;     // rows the doubling rounds of the last batch had to sort (profiling aid)
   std::vector<Tile> h_ct;
@@ -1481,6 +1718,9 @@ struct Bz2State {
   // stream level
   DBuf rs1, epre, bstart, blen, etab, seg_off, seg, seg_cnt, extra;
   bool etab_ready = false;
+  Bz2State *slot1 = nullptr;        // the second batch in flight (bz_blocks_encode pipelines the stages of consecutive batches)
+  hipStream_t st_pipe = nullptr;    // ... and the stream its entropy stage runs on
+  hipStream_t st_small = nullptr; hipEvent_t ev_small = nullptr;     // the entropy search of the short sub-blocks runs next to the long ones'
   std::vector<uint64_t> trace;      // per block: raw start, raw length, tactic kept, its number of sub-blocks
   // the call in flight: every unique piece's bits are kept until the tactics are chosen
   struct KeptSub { uint64_t bits, woff; uint32_t crc, buf; };
@@ -1497,7 +1737,8 @@ struct Bz2State {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc, &rtile_rs,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
-            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest};
+            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest,
+            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -1510,13 +1751,20 @@ static Bz2State *bz_state(Ctx *c) {
   if (!c->bz) c->bz = new Bz2State();
   return (Bz2State *)c->bz;
 }
+static void bz_free_state(Bz2State *B);
 void bz2_destroy(Ctx *c) {
   if (!c->bz) return;
-  Bz2State *B = (Bz2State *)c->bz;
+  bz_free_state((Bz2State *)c->bz);
+  c->bz = nullptr;
+}
+static void bz_free_state(Bz2State *B) {
+  if (B->slot1) bz_free_state(B->slot1);
+  if (B->st_pipe) { hipStreamSynchronize(B->st_pipe); hipStreamDestroy(B->st_pipe); }
   for (DBuf *b : B->all()) if (b->p) hipFree(b->p);
   for (DBuf &b : B->kept_bufs) if (b.p) hipFree(b.p);
+  if (B->st_small) { hipStreamSynchronize(B->st_small); hipStreamDestroy(B->st_small); }
+  if (B->ev_small) hipEventDestroy(B->ev_small);
   delete B;
-  c->bz = nullptr;
 }
 
 static void build_tiles(const std::vector<uint32_t> &len, uint32_t tile, std::vector<Tile> &tiles, std::vector<uint32_t> &first) {
@@ -1536,9 +1784,9 @@ static SubTab subtab(Bz2State *B) {
 }
 
 // RLE_1, CRC and BWT of a batch of sub-blocks of d_in.  Leaves rle / bwt / tables in the state.
-static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t> &starts, const std::vector<uint32_t> &lens) {
-  Bz2State *B = bz_state(c);
-  hipStream_t st = c->stream;
+// (B: the state that holds the batch -- the context's own, or its second slot when batches are pipelined; st: the stream of this
+// stage; marks: phase timing marks, main thread only)
+static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const uint8_t *d_in, const std::vector<uint64_t> &starts, const std::vector<uint32_t> &lens) {
   const uint32_t nsb = (uint32_t)starts.size();
   B->nsb = nsb; B->h_raw_start = starts; B->h_raw_len = lens;
   int rc;
@@ -1582,7 +1830,7 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
     hipLaunchKernelGGL(k_bz_crc_tiles, dim3((nrt + 63) / 64), dim3(64), 0, st, d_in, T, B->rtiles.as<Tile>(), nrt, B->rtile_crc.as<uint32_t>());
   }
   hipLaunchKernelGGL(k_bz_crc_fold, dim3((nsb + 63) / 64), dim3(64), 0, st, T, B->rtile_first.as<uint32_t>(), B->rtile_crc.as<uint32_t>());
-  c->tmark("bz:rle1");
+  if (marks) c->tmark("bz:rle1");
   // element tiles
   std::vector<Tile> et; std::vector<uint32_t> efirst;
   build_tiles(B->h_n, BW_TILE, et, efirst);
@@ -1626,46 +1874,94 @@ static int bz_transform(Ctx *c, const uint8_t *d_in, const std::vector<uint64_t>
   C.off = B->coff.as<uint32_t>(); C.n = B->cm.as<uint32_t>();
   std::vector<uint32_t> &h_cm = B->h_cm;
   std::vector<Tile> &ct = B->h_ct; std::vector<uint32_t> &cfirst = B->h_cfirst;
+  // group lists of the late rounds (k_bz_gl_*): two generations, filled by one round and sorted by the next
+  const bool use_lists = c->knob_bz_lists != 0;
+  GlLists GL[2];
+  uint32_t *nc = nullptr, *submax = nullptr, *glcnt = nullptr;
+  uint8_t *lmode = nullptr;
+  if (use_lists) {
+    const uint32_t cap_s = (uint32_t)(tot / 2 + 64), cap_m = (uint32_t)(tot / (GL_SMALL + 1) + 64);
+    if ((rc = dbuf_ensure(c, B->gl_s[0], sizeof(GlEntry) * (size_t)cap_s)) || (rc = dbuf_ensure(c, B->gl_s[1], sizeof(GlEntry) * (size_t)cap_s)) ||
+        (rc = dbuf_ensure(c, B->gl_m[0], sizeof(GlEntry) * (size_t)cap_m)) || (rc = dbuf_ensure(c, B->gl_m[1], sizeof(GlEntry) * (size_t)cap_m)) ||
+        (rc = dbuf_ensure(c, B->gl_nc, 4 * ne)) || (rc = dbuf_ensure(c, B->gl_submax, 4ull * nsb + 64)) || (rc = dbuf_ensure(c, B->gl_lmode, nsb + 64)) ||
+        (rc = dbuf_ensure(c, B->gl_cnt, 64))) return rc;
+    glcnt = B->gl_cnt.as<uint32_t>();
+    for (int k = 0; k < 2; k++) GL[k] = GlLists{B->gl_s[k].as<GlEntry>(), B->gl_m[k].as<GlEntry>(), glcnt + 4 * k, cap_s, cap_m};
+    nc = B->gl_nc.as<uint32_t>(); submax = B->gl_submax.as<uint32_t>(); lmode = B->gl_lmode.as<uint8_t>();
+    BZ_HIP(hipMemsetAsync(glcnt, 0, 64, st));
+  }
+  uint32_t gl_n[2] = {0, 0};                                        // entries (small, medium) of the generation to sort in this round
+  int gcur = 0;
+  bool swept = true;                                                // sub-blocks are still being swept
+  B->gl_rows = 0;
   for (uint32_t h = 4;; h *= 2) {
-    hipLaunchKernelGGL(k_bz_filter_count, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, acte, T, ET, done, h, hv, net);
-    scan_launch<OpSum, false>(st, FArrPad{hv, net}, (uint64_t)net + 1, agg, hr, nullptr);          // hr[t] = filtered rows before tile t
-    hipLaunchKernelGGL(k_bz_counts, dim3((nsb + 255) / 256), dim3(256), 0, st, T, EF, hr, C.off, C.n);
-    h_cm.resize(nsb);
-    BZ_HIP(hipMemcpyAsync(h_cm.data(), C.n, 4ull * nsb, hipMemcpyDeviceToHost, st));
-    BZ_HIP(hipStreamSynchronize(st));
-    build_tiles(h_cm, BW_TILE, ct, cfirst);
-    const uint32_t nct = (uint32_t)ct.size();
-    if (nct == 0) break;
+    uint32_t nct = 0;
+    if (swept) {
+      hipLaunchKernelGGL(k_bz_filter_count, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, acte, T, ET, done, h, hv, net);
+      scan_launch<OpSum, false>(st, FArrPad{hv, net}, (uint64_t)net + 1, agg, hr, nullptr);          // hr[t] = filtered rows before tile t
+      hipLaunchKernelGGL(k_bz_counts, dim3((nsb + 255) / 256), dim3(256), 0, st, T, EF, hr, C.off, C.n);
+      h_cm.resize(nsb);
+      BZ_HIP(hipMemcpyAsync(h_cm.data(), C.n, 4ull * nsb, hipMemcpyDeviceToHost, st));
+      BZ_HIP(hipStreamSynchronize(st));
+      build_tiles(h_cm, BW_TILE, ct, cfirst);
+      nct = (uint32_t)ct.size();
+      if (nct == 0) swept = false;
+    }
+    if (!swept && gl_n[0] + gl_n[1] == 0) break;
     B->bwt_rounds++;
-    if ((rc = dbuf_ensure(c, B->ctiles, sizeof(Tile) * (size_t)nct))) return rc;
-    BZ_HIP(hipMemcpyAsync(B->ctiles.p, ct.data(), sizeof(Tile) * (size_t)nct, hipMemcpyHostToDevice, st));
-    BZ_HIP(hipMemcpyAsync(B->ctile_first.p, cfirst.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
-    const Tile *CT = B->ctiles.as<Tile>();
-    const uint32_t *CF = B->ctile_first.as<uint32_t>();
-    uint64_t M = 0;
-    for (uint32_t s2 = 0; s2 < nsb; s2++) M += h_cm[s2];
-    B->m_hist.push_back(M);
-    hipLaunchKernelGGL(k_bz_filter_emit, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, acte, cl, T, ET, done, h, hr, keyA, cv0, net);
-    radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 0); radix(C, CT, CF, nct, keyB, cv1, keyA, cv0, 8);
-    radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 16);        // first rows are below 2^20 (block capacity 900 000)
-    hipLaunchKernelGGL(k_bz_rf_agg, dim3(xcd_grid(nct)), dim3(1024), 0, st, keyB, C, CT, hv, nct);
-    scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last run start before tile t
-    hipLaunchKernelGGL(k_bz_place, dim3(xcd_grid(nct)), dim3(1024), 0, st, keyB, cv1, hr, T, C, CT, cl, h, valA, keyA, hv, nct);
-    scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last group start before tile t
-    hipLaunchKernelGGL(k_bz_newclass, dim3(xcd_grid(nct)), dim3(1024), 0, st, cv1, keyA, hr, C, CT, cl, acte, nct);
-    hipLaunchKernelGGL(k_bz_done, dim3((nsb + 255) / 256), dim3(256), 0, st, T, 2 * h, done);
+    if (swept) {
+      if ((rc = dbuf_ensure(c, B->ctiles, sizeof(Tile) * (size_t)nct))) return rc;
+      BZ_HIP(hipMemcpyAsync(B->ctiles.p, ct.data(), sizeof(Tile) * (size_t)nct, hipMemcpyHostToDevice, st));
+      BZ_HIP(hipMemcpyAsync(B->ctile_first.p, cfirst.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
+      const Tile *CT = B->ctiles.as<Tile>();
+      const uint32_t *CF = B->ctile_first.as<uint32_t>();
+      uint64_t M = 0;
+      for (uint32_t s2 = 0; s2 < nsb; s2++) M += h_cm[s2];
+      B->m_hist.push_back(M);
+      hipLaunchKernelGGL(k_bz_filter_emit, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, acte, cl, T, ET, done, h, hr, keyA, cv0, net);
+      radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 0); radix(C, CT, CF, nct, keyB, cv1, keyA, cv0, 8);
+      radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 16);        // first rows are below 2^20 (block capacity 900 000)
+      hipLaunchKernelGGL(k_bz_rf_agg, dim3(xcd_grid(nct)), dim3(1024), 0, st, keyB, C, CT, hv, nct);
+      scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last run start before tile t
+      hipLaunchKernelGGL(k_bz_place, dim3(xcd_grid(nct)), dim3(1024), 0, st, keyB, cv1, hr, T, C, CT, cl, h, valA, keyA, hv, nct);
+      scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last group start before tile t
+      hipLaunchKernelGGL(k_bz_newclass, dim3(xcd_grid(nct)), dim3(1024), 0, st, cv1, keyA, hr, C, CT, cl, acte, nct);
+      hipLaunchKernelGGL(k_bz_done, dim3((nsb + 255) / 256), dim3(256), 0, st, T, 2 * h, done);
+    } else B->m_hist.push_back(0);
+    if (use_lists) {
+      const GlLists cur = GL[gcur], nxt = GL[gcur ^ 1];
+      // the listed groups, sorted by 2h bytes now; what is left of them goes on the other generation's lists
+      if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.s, cur.cnt + 0, h, valA, cl, T, nc, nxt);
+      if (gl_n[1]) hipLaunchKernelGGL(k_bz_gl_sort_wave, dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MAX + 255) / 256)), dim3(256), 0, st, cur.m, cur.cnt + 1, h, valA, cl, T, nc, nxt);
+      if (gl_n[0]) hipLaunchKernelGGL((k_bz_gl_apply<1>), dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.s, cur.cnt + 0, h, valA, nc, T, cl);
+      if (gl_n[1]) hipLaunchKernelGGL((k_bz_gl_apply<(int)GL_MAX>), dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MAX + 255) / 256)), dim3(256), 0, st, cur.m, cur.cnt + 1, h, valA, nc, T, cl);
+      // sub-blocks whose unsorted groups have all become small leave the sweeps: their groups (classes of 2h bytes) join the lists
+      if (swept && 2 * h >= (uint32_t)c->knob_bz_lists) {
+        BZ_HIP(hipMemsetAsync(submax, 0, 4ull * nsb, st));
+        hipLaunchKernelGGL(k_bz_gl_max, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, cl, T, ET, done, submax, net);
+        hipLaunchKernelGGL(k_bz_gl_decide, dim3((nsb + 255) / 256), dim3(256), 0, st, T, done, submax, lmode);
+        hipLaunchKernelGGL(k_bz_gl_build, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, cl, T, ET, lmode, nxt, net);
+        hipLaunchKernelGGL(k_bz_gl_leave, dim3((nsb + 255) / 256), dim3(256), 0, st, T, lmode, done);
+      }
+      uint32_t hc[4] = {0, 0, 0, 0};
+      BZ_HIP(hipMemcpyAsync(hc, nxt.cnt, 16, hipMemcpyDeviceToHost, st));
+      BZ_HIP(hipMemsetAsync(cur.cnt, 0, 16, st));                  // (the generation just sorted is the next one to be filled)
+      BZ_HIP(hipStreamSynchronize(st));
+      if (hc[2] || hc[0] > nxt.cap_s || hc[1] > nxt.cap_m) { c->err = "bzip2: group list overflow"; return ZADA_E_HIP; }
+      B->gl_rows += (uint64_t)gl_n[0] + gl_n[1];
+      gl_n[0] = hc[0]; gl_n[1] = hc[1];
+      gcur ^= 1;
+    }
   }
   hipLaunchKernelGGL(k_bz_bwt_out, dim3(xcd_grid(net)), dim3(1024), 0, st, B->rle.as<uint8_t>(), valA, cl, T, ET, B->bwt.as<uint8_t>(), net);
-  c->tmark("bz:bwt");
+  if (marks) c->tmark("bz:bwt");
   BZ_HIP(hipGetLastError());
   return 0;
 }
 
 
 // MTF + RLE_2 of the batch that bz_transform has left in the state: symbols (u16) in B->sym, tables soff / mtf_n / nsym / seq
-static int bz_mtf(Ctx *c) {
-  Bz2State *B = bz_state(c);
-  hipStream_t st = c->stream;
+static int bz_mtf(Ctx *c, Bz2State *B, hipStream_t st, bool marks) {
   const uint32_t nsb = B->nsb, net = B->n_etiles, tot = B->ntot;
   const uint64_t slots = (uint64_t)net * MTF_PER_TILE;
   int rc;
@@ -1693,15 +1989,13 @@ static int bz_mtf(Ctx *c) {
   hipLaunchKernelGGL(k_bz_sym_layout, dim3((nsb + 255) / 256), dim3(256), 0, st, T, P, B->nsym.as<uint32_t>(), B->soff.as<uint32_t>(), B->mtf_n.as<uint32_t>(),
                      B->sym.as<uint16_t>());
   if (net) hipLaunchKernelGGL(k_bz_rle2_emit, dim3(net), dim3(1024), 0, st, idx, hr, P, T, ET, B->soff.as<uint32_t>(), B->sym.as<uint16_t>());
-  c->tmark("bz:mtf");
+  if (marks) c->tmark("bz:mtf");
   BZ_HIP(hipGetLastError());
   return 0;
 }
 
 // entropy coders + bit strings of the batch: words at B->words, sub-block s at word h_woff[s], h_res[8 s + 7] bits
-static int bz_entropy_emit(Ctx *c, int option) {
-  Bz2State *B = bz_state(c);
-  hipStream_t st = c->stream;
+static int bz_entropy_emit(Ctx *c, Bz2State *B, hipStream_t st, bool marks, int option) {
   const uint32_t nsb = B->nsb;
   int rc;
   std::vector<uint32_t> so(nsb + 1);
@@ -1734,10 +2028,27 @@ static int bz_entropy_emit(Ctx *c, int option) {
   const uint32_t nwid = option == 2 ? 2 : 1;
   if (nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nbig, nwid), dim3(64), rank_lds_big, st, E, 0u);
   if (nsb > nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nsb - nbig, nwid), dim3(64), rank_lds_small, st, E, nbig);
-  c->tmark("bz:rank");
-  hipLaunchKernelGGL(k_bz_entropy, dim3(nsb), dim3(EN_THREADS), 0, st, E, nsb);
+  if (marks) c->tmark("bz:rank");
+  {
+    // the sub-blocks of up to 2040 groups (102 000 symbols: most segments of the splitting tactics) go to the small workgroups
+    uint32_t nlarge = 0;
+    while (nlarge < nsb && 1 + B->h_n[order[nlarge]] / BZ_GROUP > EN_SMALL_SEL) nlarge++;       // (an upper bound of the groups: mtf_n <= n + 1)
+    if (c->knob_bz_small_wg == 0) nlarge = nsb;
+    // The two launches share the GPU (the small one on a stream of its own): the long sub-blocks' workgroups run for tens of
+    // milliseconds, and what they leave idle while the last of them finish is taken by the short ones.
+    const bool both = nlarge > 0 && nsb > nlarge;
+    if (both) {
+      if (!B->st_small) { BZ_HIP(hipStreamCreateWithFlags(&B->st_small, hipStreamNonBlocking)); BZ_HIP(hipEventCreateWithFlags(&B->ev_small, hipEventDisableTiming)); }
+      BZ_HIP(hipEventRecord(B->ev_small, st));                                          // (rankings and symbols are in place)
+      BZ_HIP(hipStreamWaitEvent(B->st_small, B->ev_small, 0));
+    }
+    hipStream_t sts = both ? B->st_small : st;
+    if (nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_THREADS, BZ_MAX_SEL>), dim3(nlarge), dim3(EN_THREADS), 0, st, E, nsb, 0u);
+    if (nsb > nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_SMALL_THREADS, (int)EN_SMALL_SEL>), dim3(nsb - nlarge), dim3(EN_SMALL_THREADS), 0, sts, E, nsb, nlarge);
+    if (both) { BZ_HIP(hipEventRecord(B->ev_small, B->st_small)); BZ_HIP(hipStreamWaitEvent(st, B->ev_small, 0)); }
+  }
   hipLaunchKernelGGL(k_bz_block_bits, dim3((nsb + 255) / 256), dim3(256), 0, st, T, B->res.as<uint32_t>());
-  c->tmark("bz:entropy");
+  if (marks) c->tmark("bz:entropy");
   B->h_res.resize(8ull * nsb); B->h_crc.resize(nsb);
   BZ_HIP(hipMemcpyAsync(B->h_res.data(), B->res.p, 32ull * nsb, hipMemcpyDeviceToHost, st));
   BZ_HIP(hipMemcpyAsync(B->h_crc.data(), B->crc.p, 4ull * nsb, hipMemcpyDeviceToHost, st));
@@ -1752,7 +2063,7 @@ static int bz_entropy_emit(Ctx *c, int option) {
   BZ_HIP(hipMemsetAsync(B->words.p, 0, 4 * (w + 16), st));
   hipLaunchKernelGGL(k_bz_emit_head, dim3(nsb), dim3(64), 0, st, T, E, B->woff.as<uint32_t>(), B->words.as<uint32_t>());
   hipLaunchKernelGGL(k_bz_emit_data, dim3(nsb), dim3(EN_THREADS), 0, st, T, E, B->woff.as<uint32_t>(), B->words.as<uint32_t>());
-  c->tmark("bz:emit");
+  if (marks) c->tmark("bz:emit");
   BZ_HIP(hipGetLastError());
   return 0;
 }
@@ -1847,6 +2158,45 @@ static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::
   const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 640) << 20;
   const size_t plan_base = B->plans.size();
   constexpr uint32_t KEPT = 0x80000000u;                                   // piece number that already is a number in B->kept
+  // Two batches in flight ("bz_pipeline", default on): the second one in a state of its own (B->slot1).
+  const bool pipelined = c->knob_bz_pipeline != 0;
+  if (pipelined) {
+    if (!B->slot1) B->slot1 = new Bz2State();
+    if (!B->st_pipe) BZ_HIP(hipStreamCreateWithFlags(&B->st_pipe, hipStreamNonBlocking));
+  }
+  struct Pending { bool active = false; std::thread th; int rc = 0; Bz2State *S = nullptr; uint32_t base = 0; DBuf kb; } pend;
+  struct Joiner { Pending &p; ~Joiner() { if (p.th.joinable()) p.th.join(); } } joiner{pend};      // (no return leaves a worker behind)
+  uint32_t nbatch = 0;
+  // waits for the batch whose stage B is under way and books its bit strings: the plans' piece numbers become numbers in B->kept
+  auto finish = [&]() -> int {
+    if (!pend.active) return 0;
+    if (pend.th.joinable()) pend.th.join();
+    pend.active = false;
+    if (pend.rc) { if (pend.kb.p) hipFree(pend.kb.p); return pend.rc; }
+    Bz2State *S = pend.S;
+    const uint32_t bufno = (uint32_t)B->kept_bufs.size();
+    B->kept_bufs.push_back(pend.kb);
+    for (uint32_t s = 0; s < S->nsb; s++) B->kept[pend.base + s] = {S->h_res[8ull * s + 7], S->h_woff[s], S->h_crc[s], bufno};
+    return 0;
+  };
+  // A batch's pieces get their numbers in B->kept when the batch is launched (what the numbers stand for -- bits, place, CRC -- arrives
+  // with finish): the next batch, also the first of the segments' pass, is planned without waiting for this one's entropy stage.
+  auto book = [&](uint32_t k0, uint32_t k1, int pass, const std::vector<uint64_t> &starts, const std::vector<uint32_t> &lens) -> uint32_t {
+    const uint32_t base = (uint32_t)B->kept.size();
+    B->kept.resize((size_t)base + starts.size());
+    for (uint32_t k = k0; k < k1; k++) {
+      BlkPlan &P = B->plans[plan_base + k];
+      for (int t = 2 * pass; t < 2 * pass + 2; t++)
+        for (uint32_t &sb : P.tac[t]) {
+          if (sb & KEPT) { sb &= ~KEPT; continue; }
+          sb += base;
+          bool known = false;
+          for (const auto &pc : P.pieces) known |= pc.kept == sb;
+          if (!known) P.pieces.push_back({starts[sb - base], lens[sb - base], sb});
+        }
+    }
+    return base;
+  };
   // pass 0: the single block and its four quarters; pass 1: the segments (those that are not one of the former)
   for (int pass = 0; pass < (option == 2 ? 2 : 1); pass++) {
     if (pass == 1) {
@@ -1897,35 +2247,34 @@ static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::
         P.tac[2 * pass] = std::move(t0); P.tac[2 * pass + 1] = std::move(t1);
       }
       if (!starts.empty()) {
-        if ((rc = bz_transform(c, d_in, starts, lens)) || (rc = bz_mtf(c)) || (rc = bz_entropy_emit(c, option))) return rc;
-        // keep the batch's bit strings; the plans' piece numbers become numbers in B->kept
-        const uint32_t base = (uint32_t)B->kept.size(), bufno = (uint32_t)B->kept_bufs.size();
-        DBuf kb;
-        if ((rc = dbuf_ensure(c, kb, 4 * (B->nwords + 16)))) return rc;
-        BZ_HIP(hipMemcpyAsync(kb.p, B->words.p, 4 * B->nwords, hipMemcpyDeviceToDevice, st));
-        B->kept_bufs.push_back(kb);
-        for (uint32_t s = 0; s < B->nsb; s++) B->kept.push_back({B->h_res[8ull * s + 7], B->h_woff[s], B->h_crc[s], bufno});
-        for (uint32_t k = k0; k < k1; k++) {
-          BlkPlan &P = B->plans[plan_base + k];
-          for (int t = 2 * pass; t < 2 * pass + 2; t++)
-            for (uint32_t &sb : P.tac[t]) {
-              if (sb & KEPT) { sb &= ~KEPT; continue; }
-              sb += base;
-              bool known = false;
-              for (const auto &pc : P.pieces) known |= pc.kept == sb;
-              if (!known) P.pieces.push_back({starts[sb - base], lens[sb - base], sb});
-            }
-        }
-        c->tmark("bz:keep");
+        // Stage A of this batch (RLE_1, rotation sort, MTF: bound by memory) on the main stream, next to stage B of the batch
+        // before (rankings, entropy search, bits: chains of short dependent steps, bound by how many sub-blocks are in flight).
+        Bz2State *S = pipelined && (nbatch & 1) ? B->slot1 : B;
+        nbatch++;
+        if ((rc = bz_transform(c, S, st, true, d_in, starts, lens)) || (rc = bz_mtf(c, S, st, true))) { finish(); return rc; }
         BZ_HIP(hipStreamSynchronize(st));
+        if ((rc = finish())) return rc;                                       // the batch before: its worker has had all of stage A to finish
+        pend.S = S; pend.base = book(k0, k1, pass, starts, lens); pend.rc = 0; pend.kb = DBuf();
+        auto stage_b = [c, option, &pend](hipStream_t sb, bool marks) {
+          Bz2State *S2 = pend.S;
+          int r = bz_entropy_emit(c, S2, sb, marks, option);
+          if (!r) r = dbuf_ensure(c, pend.kb, 4 * (S2->nwords + 16));
+          if (!r && hipMemcpyAsync(pend.kb.p, S2->words.p, 4 * S2->nwords, hipMemcpyDeviceToDevice, sb) != hipSuccess) r = ZADA_E_HIP_;
+          if (!r && hipStreamSynchronize(sb) != hipSuccess) r = ZADA_E_HIP_;
+          pend.rc = r;
+        };
+        pend.active = true;
+        if (pipelined) pend.th = std::thread([c, stage_b, B] { hipSetDevice(c->device); stage_b(B->st_pipe, false); });
+        else { stage_b(st, true); c->tmark("bz:keep"); if ((rc = finish())) return rc; }
       } else {
         for (uint32_t k = k0; k < k1; k++) for (int t = 2 * pass; t < 2 * pass + 2; t++) for (uint32_t &sb : B->plans[plan_base + k].tac[t]) sb &= ~KEPT;
       }
       k0 = k1;
       const double done = ((double)pass + (double)k0 / (double)nblk) / (option == 2 ? 2.0 : 1.0);
-      if (fb && fb((int)(prog0 + (prog1 - prog0) * done), user)) { hipStreamSynchronize(st2); return ZADA_ABORTED; }
+      if (fb && fb((int)(prog0 + (prog1 - prog0) * done), user)) { finish(); hipStreamSynchronize(st2); return ZADA_ABORTED; }
     }
   }
+  if ((rc = finish())) return rc;
   for (size_t q = plan_base; q < B->plans.size(); q++) {
     uint64_t mn = ~0ull;
     for (int t = 0; t < 4; t++) {
@@ -2259,9 +2608,10 @@ extern "C" int zada_bz2_run(zada_ctx *z, const uint8_t *in, uint64_t n, uint32_t
   hipMemset(d_in + n, 0, 64);
   std::vector<uint64_t> s(starts, starts + nsb);
   std::vector<uint32_t> l(lens, lens + nsb);
-  int rc = bz_transform(c, d_in, s, l);
-  if (rc == 0 && stages >= 2) rc = bz_mtf(c);
-  if (rc == 0 && stages >= 3) rc = bz_entropy_emit(c, option);
+  Bz2State *B = bz_state(c);
+  int rc = bz_transform(c, B, c->stream, true, d_in, s, l);
+  if (rc == 0 && stages >= 2) rc = bz_mtf(c, B, c->stream, true);
+  if (rc == 0 && stages >= 3) rc = bz_entropy_emit(c, B, c->stream, true, option);
   hipStreamSynchronize(c->stream);
   hipFree(d_in);
   return rc;
@@ -2291,7 +2641,7 @@ extern "C" int zada_bz2_fetch(zada_ctx *z, const char *name, void *dst, uint64_t
   else if (!strcmp(name, "dbg")) { src = B->dbg.p; len = 64ull * nsb; }
   else if (!strcmp(name, "woff")) { src = B->woff.p; len = 4ull * (nsb + 1); }
   else if (!strcmp(name, "words")) { src = B->words.p; len = 4ull * B->nwords; }
-  else if (!strcmp(name, "info")) { tmp[0] = B->ntot; tmp[1] = (uint32_t)B->bwt_rounds; tmp[2] = nsb; tmp[3] = 0; if (cap < 16) return ZADA_E_INVALID; memcpy(dst, tmp, 16); if (nbytes) *nbytes = 16; return 0; }
+  else if (!strcmp(name, "info")) { tmp[0] = B->ntot; tmp[1] = (uint32_t)B->bwt_rounds; tmp[2] = nsb; tmp[3] = (uint32_t)B->gl_rows; if (cap < 16) return ZADA_E_INVALID; memcpy(dst, tmp, 16); if (nbytes) *nbytes = 16; return 0; }
   else return ZADA_E_INVALID;
   if (nbytes) *nbytes = len;
   if (len > cap) return ZADA_E_INVALID;
