@@ -349,59 +349,64 @@ __global__ void k_bz_crc_fold(SubTab T, const uint32_t *__restrict__ first_tile,
 constexpr int BW_TILE = 8192;    // elements per tile, 1024 threads x 8 (wave w owns 512 consecutive elements)
 
 // stable radix pass over (key, val) pairs, segmented by sub-block: digit = (key >> shift) & 255
+// (BITS: width of the digit -- 8 for the first sort's four bytes, 10 for the rounds' classes, which are below 2^20: two passes)
+template <int BITS>
 __global__ void __launch_bounds__(1024) k_bz_radix_hist(const uint32_t *__restrict__ key, SubTab T, const Tile *__restrict__ tiles,
                                                         const uint32_t *__restrict__ first_tile, const uint8_t *__restrict__ done, int shift,
                                                         uint32_t *__restrict__ H, uint32_t ntiles_x) {
-  __shared__ uint32_t cnt[256];
+  constexpr uint32_t NB = 1u << BITS;
+  __shared__ uint32_t cnt[NB];
   const uint32_t bx = xcd_tile(ntiles_x);
   if (bx >= ntiles_x) return;
   const Tile t = tiles[bx];
   const uint32_t n = T.n[t.sb], base = T.off[t.sb] + t.lo, m = done[t.sb] ? 0u : min((uint32_t)BW_TILE, n - t.lo);
-  if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+  if (threadIdx.x < NB) cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) atomicAdd(&cnt[(key[base + i] >> shift) & 255u], 1u);
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) atomicAdd(&cnt[(key[base + i] >> shift) & (NB - 1u)], 1u);
   __syncthreads();
-  if (threadIdx.x < 256) {
+  if (threadIdx.x < NB) {
     const uint32_t t0 = first_tile[t.sb], ts = first_tile[t.sb + 1] - t0;
-    H[(uint64_t)t0 * 256 + (uint64_t)threadIdx.x * ts + (bx - t0)] = cnt[threadIdx.x];
+    H[(uint64_t)t0 * NB + (uint64_t)threadIdx.x * ts + (bx - t0)] = cnt[threadIdx.x];
   }
 }
+template <int BITS>
 __global__ void __launch_bounds__(1024) k_bz_radix_scatter(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, SubTab T,
                                                            const Tile *__restrict__ tiles, const uint32_t *__restrict__ first_tile,
                                                            const uint8_t *__restrict__ done, int shift,
                                                            const uint32_t *__restrict__ H, uint32_t *__restrict__ key_out, uint32_t *__restrict__ val_out, uint32_t ntiles_x) {
-  __shared__ uint32_t cnt[16 * 256];
+  constexpr uint32_t NB = 1u << BITS;
+  __shared__ uint32_t cnt[16 * NB];
   const uint32_t bx = xcd_tile(ntiles_x);
   if (bx >= ntiles_x) return;
   const Tile t = tiles[bx];
   if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], base = T.off[t.sb] + t.lo, m = min((uint32_t)BW_TILE, n - t.lo);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < 16 * 256; i += 1024) cnt[i] = 0;
+  for (int i = tid; i < (int)(16 * NB); i += 1024) cnt[i] = 0;
   __syncthreads();
   uint32_t kx[8], vx[8], rk[8];
-  uint32_t *mycnt = cnt + w * 256;
+  uint32_t *mycnt = cnt + w * NB;
   // rank among the wave's elements with the same digit, in element order (LDS atomics of one instruction are served in lane
   // order; see sort_pass in zada_lz.hip and tests/probes/lds_atomic_order.hip)
 #pragma unroll
   for (int it = 0; it < 8; it++) {
     const uint32_t i = (uint32_t)w * 512 + it * 64 + lane;
     kx[it] = 0; vx[it] = 0; rk[it] = 0;
-    if (i < m) { kx[it] = key[base + i]; vx[it] = val[base + i]; rk[it] = atomicAdd(&mycnt[(kx[it] >> shift) & 255u], 1u); }
+    if (i < m) { kx[it] = key[base + i]; vx[it] = val[base + i]; rk[it] = atomicAdd(&mycnt[(kx[it] >> shift) & (NB - 1u)], 1u); }
   }
   __syncthreads();
   // per digit: exclusive prefix over the waves, plus the tile's base from the scanned histogram
-  if (tid < 256) {
+  if ((uint32_t)tid < NB) {
     const uint32_t t0 = first_tile[t.sb], ts = first_tile[t.sb + 1] - t0;
     // the scan runs over all sub-blocks' histograms; a sub-block's own part starts at its first entry
-    uint32_t run = T.off[t.sb] + H[(uint64_t)t0 * 256 + (uint64_t)tid * ts + (bx - t0)] - H[(uint64_t)t0 * 256];
-    for (int k = 0; k < 16; k++) { const uint32_t x = cnt[k * 256 + tid]; cnt[k * 256 + tid] = run; run += x; }
+    uint32_t run = T.off[t.sb] + H[(uint64_t)t0 * NB + (uint64_t)tid * ts + (bx - t0)] - H[(uint64_t)t0 * NB];
+    for (int k = 0; k < 16; k++) { const uint32_t x = cnt[k * NB + tid]; cnt[k * NB + tid] = run; run += x; }
   }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < 8; it++) {
     const uint32_t i = (uint32_t)w * 512 + it * 64 + lane;
-    if (i < m) { const uint32_t d = mycnt[(kx[it] >> shift) & 255u] + rk[it]; key_out[d] = kx[it]; val_out[d] = vx[it]; }
+    if (i < m) { const uint32_t d = mycnt[(kx[it] >> shift) & (NB - 1u)] + rk[it]; key_out[d] = kx[it]; val_out[d] = vx[it]; }
   }
 }
 
@@ -1646,32 +1651,54 @@ __global__ void __launch_bounds__(64) k_bz_segment(const uint8_t *__restrict__ i
     }
     double mark1 = entropy, mark2 = entropy;
     uint32_t im1 = 1, im2 = 1;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     for (uint32_t i0 = SEG_WINDOW + 1; i0 <= len; i0 += 64) {
       const uint32_t cnt = min(64u, len - i0 + 1), i = i0 + lane;
       const bool valid = (uint32_t)lane < cnt;
       const uint32_t xin = valid ? buf[i - 1] : 0u, xout = valid ? buf[i - SEG_WINDOW - 1] : 0u;
       const uint32_t f0in = freq[xin], f0out = freq[xout];
       wave_sync();
-      uint32_t ii = 0, oi = 0, io = 0, oo = 0;
-      for (int j = 0; j < (int)cnt; j++) {
-        const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)xin, j), bo = (uint32_t)__builtin_amdgcn_readlane((int)xout, j);
-        if (j < lane) { ii += bi == xin; oi += bo == xin; io += bi == xout; oo += bo == xout; }
+      // how often the bytes of this lane's step came in / went out in the steps before it of this stretch: the lanes holding a given
+      // byte are the AND, over its eight bits, of the ballots of that bit (or their complements)
+      unsigned long long m_ii = ~0ull, m_oi = ~0ull, m_io = ~0ull, m_oo = ~0ull;
+#pragma unroll
+      for (int bt = 0; bt < 8; bt++) {
+        const unsigned long long bi = __ballot((xin >> bt) & 1u), bo = __ballot((xout >> bt) & 1u);
+        const bool mi = (xin >> bt) & 1u, mo = (xout >> bt) & 1u;
+        m_ii &= mi ? bi : ~bi; m_oi &= mi ? bo : ~bo;
+        m_io &= mo ? bi : ~bi; m_oo &= mo ? bo : ~bo;
       }
+      const unsigned long long before = lt & (cnt == 64 ? ~0ull : (1ull << cnt) - 1ull);
+      const uint32_t ii = (uint32_t)__popcll(m_ii & before), oi = (uint32_t)__popcll(m_oi & before);
+      const uint32_t io = (uint32_t)__popcll(m_io & before), oo = (uint32_t)__popcll(m_oo & before);
       if (valid) { atomicAdd(&freq[xin], 1u); atomicSub(&freq[xout], 1u); }
       const uint32_t f = f0in + ii - oi + 1, g = f0out + io + (xin == xout ? 1u : 0u) - oo;
       double A = 0.0, Bv = 0.0, C = 0.0, D = 0.0;
       if (valid) { A = etab[f - 1]; Bv = etab[f]; C = etab[g]; D = etab[g - 1]; }       // etab[0] = 0.0
       wave_sync();
+      // the chain of additions, in the reference's order; lane j keeps the value after step j.  The tests against the marks follow for
+      // all steps at once: a mark moves at most once in a stretch (64 steps are fewer than the 4 000 / 8 000 between two marks)
+      double e_mine = 0.0;
       for (int j = 0; j < (int)cnt; j++) {
         entropy = entropy - lane_value(A, j);
         entropy = entropy + lane_value(Bv, j);
         entropy = entropy - lane_value(C, j);
         entropy = entropy + lane_value(D, j);           // 0.0 where the reference adds nothing (the byte has left the window): the same value
-        // the marks move rarely: one uniform test for both profiles, the rest behind it
-        if (__ballot(fabs(entropy - mark1) > thr1 || (t2 && fabs(entropy - mark2) > thr2))) {
-          const uint32_t seg_point = i0 + (uint32_t)j - SEG_WINDOW;
-          if (fabs(entropy - mark1) > thr1 && seg_point > im1 && seg_point - im1 > 4000u) { if (lane == 0) s1[n1] = seg_point; n1++; im1 = seg_point; mark1 = entropy; }
-          if (t2 && fabs(entropy - mark2) > thr2 && seg_point > im2 && seg_point - im2 > 8000u) { if (lane == 0) s2[n2] = seg_point; n2++; im2 = seg_point; mark2 = entropy; }
+        if (lane == j) e_mine = entropy;
+      }
+      const uint32_t sp = i0 + (uint32_t)lane - SEG_WINDOW;
+      const unsigned long long h1 = __ballot(valid && fabs(e_mine - mark1) > thr1 && sp > im1 && sp - im1 > 4000u);
+      if (h1) {
+        const int j = __builtin_ctzll(h1);
+        if (lane == 0) s1[n1] = i0 + (uint32_t)j - SEG_WINDOW;
+        n1++; im1 = i0 + (uint32_t)j - SEG_WINDOW; mark1 = lane_value(e_mine, j);
+      }
+      if (t2) {
+        const unsigned long long h2 = __ballot(valid && fabs(e_mine - mark2) > thr2 && sp > im2 && sp - im2 > 8000u);
+        if (h2) {
+          const int j = __builtin_ctzll(h2);
+          if (lane == 0) s2[n2] = i0 + (uint32_t)j - SEG_WINDOW;
+          n2++; im2 = i0 + (uint32_t)j - SEG_WINDOW; mark2 = lane_value(e_mine, j);
         }
       }
     }
@@ -1706,7 +1733,7 @@ struct Bz2State {
   DBuf rtiles, rtile_first, rtile_val, rtile_crc, rtile_rs, etiles, etile_first;
   // element space
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
-  DBuf gl_s[2], gl_m[2], gl_nc, gl_submax, gl_lmode, gl_cnt;   // group lists of the late rounds (k_bz_gl_*)
+  DBuf gl_s[2], gl_m[2], gl_nc, gl_submax, gl_lmode, gl_cnt, gl_tmp;   // group lists of the late rounds (k_bz_gl_*)
   uint64_t gl_rows = 0;             // groups the lists' rounds of the last batch sorted (profiling aid)
   std::vector<uint32_t> h_cm, h_cfirst;
   std::vector<uint64_t> m_hist;     // rows the doubling rounds of the last batch had to sort (profiling aid)
@@ -1738,7 +1765,7 @@ struct Bz2State {
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
             &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest,
-            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt};
+            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt, &gl_tmp};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -1841,10 +1868,10 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   BZ_HIP(hipMemcpyAsync(B->etile_first.p, efirst.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
   if ((rc = dbuf_ensure(c, B->keyA, 4 * ne)) || (rc = dbuf_ensure(c, B->keyB, 4 * ne)) || (rc = dbuf_ensure(c, B->valA, 4 * ne)) ||
       (rc = dbuf_ensure(c, B->valB, 4 * ne)) || (rc = dbuf_ensure(c, B->cl, 4 * ne)) || (rc = dbuf_ensure(c, B->hv, 4 * ne)) ||
-      (rc = dbuf_ensure(c, B->hr, 4 * ne)) || (rc = dbuf_ensure(c, B->H, 1024ull * (net + nsb) + 1024)) || (rc = dbuf_ensure(c, B->cv0, 4 * ne)) ||
+      (rc = dbuf_ensure(c, B->hr, 4 * ne)) || (rc = dbuf_ensure(c, B->H, 4096ull * (net + nsb) + 4096)) || (rc = dbuf_ensure(c, B->gl_tmp, 4 * ne)) || (rc = dbuf_ensure(c, B->cv0, 4 * ne)) ||
       (rc = dbuf_ensure(c, B->cv1, 4 * ne)) || (rc = dbuf_ensure(c, B->acte, 4 * (ne / 32 + 4))) || (rc = dbuf_ensure(c, B->coff, 4ull * (nsb + 2))) ||
       (rc = dbuf_ensure(c, B->cm, 4ull * (nsb + 2))) || (rc = dbuf_ensure(c, B->ctile_first, 4ull * (nsb + 2))) ||
-      (rc = dbuf_ensure(c, B->agg, 4ull * ((1024ull * net / 4 + ne) / SC_TILE + 16)))) return rc;
+      (rc = dbuf_ensure(c, B->agg, 4ull * ((1024ull * net + ne) / SC_TILE + 16)))) return rc;
   BZ_HIP(hipStreamSynchronize(st));   // rt / et vectors go out of scope
   B->bwt_rounds = 0;
   if (net == 0) return 0;
@@ -1855,9 +1882,14 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   uint32_t *cv0 = B->cv0.as<uint32_t>(), *cv1 = B->cv1.as<uint32_t>(), *acte = B->acte.as<uint32_t>();
   uint32_t *H = B->H.as<uint32_t>(), *agg = B->agg.as<uint32_t>(), *hv = B->hv.as<uint32_t>(), *hr = B->hr.as<uint32_t>(), *cl = B->cl.as<uint32_t>();
   auto radix = [&](const SubTab &S, const Tile *tl, const uint32_t *tf, uint32_t nt, const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int shift) {
-    hipLaunchKernelGGL(k_bz_radix_hist, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, S, tl, tf, done, shift, H, nt);
+    hipLaunchKernelGGL(k_bz_radix_hist<8>, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, S, tl, tf, done, shift, H, nt);
     scan_launch<OpSum, false>(st, FArr{H}, 256ull * nt, agg, H, nullptr);
-    hipLaunchKernelGGL(k_bz_radix_scatter, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, vi, S, tl, tf, done, shift, H, ko, vo, nt);
+    hipLaunchKernelGGL(k_bz_radix_scatter<8>, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, vi, S, tl, tf, done, shift, H, ko, vo, nt);
+  };
+  auto radix10 = [&](const SubTab &S, const Tile *tl, const uint32_t *tf, uint32_t nt, const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int shift) {
+    hipLaunchKernelGGL(k_bz_radix_hist<10>, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, S, tl, tf, done, shift, H, nt);
+    scan_launch<OpSum, false>(st, FArr{H}, 1024ull * nt, agg, H, nullptr);
+    hipLaunchKernelGGL(k_bz_radix_scatter<10>, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, vi, S, tl, tf, done, shift, H, ko, vo, nt);
   };
   B->m_hist.clear();
   B->m_hist.push_back(tot);
@@ -1919,8 +1951,8 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       for (uint32_t s2 = 0; s2 < nsb; s2++) M += h_cm[s2];
       B->m_hist.push_back(M);
       hipLaunchKernelGGL(k_bz_filter_emit, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, acte, cl, T, ET, done, h, hr, keyA, cv0, net);
-      radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 0); radix(C, CT, CF, nct, keyB, cv1, keyA, cv0, 8);
-      radix(C, CT, CF, nct, keyA, cv0, keyB, cv1, 16);        // first rows are below 2^20 (block capacity 900 000)
+      // (first rows are below 2^20 -- the block capacity is 900 000 --: two passes of ten bits, by way of valB / gl_tmp into keyB / cv1)
+      radix10(C, CT, CF, nct, keyA, cv0, valB, B->gl_tmp.as<uint32_t>(), 0); radix10(C, CT, CF, nct, valB, B->gl_tmp.as<uint32_t>(), keyB, cv1, 10);
       hipLaunchKernelGGL(k_bz_rf_agg, dim3(xcd_grid(nct)), dim3(1024), 0, st, keyB, C, CT, hv, nct);
       scan_launch<OpMax, false>(st, FArr{hv}, nct, agg, hr, nullptr);                                   // hr[t] = last run start before tile t
       hipLaunchKernelGGL(k_bz_place, dim3(xcd_grid(nct)), dim3(1024), 0, st, keyB, cv1, hr, T, C, CT, cl, h, valA, keyA, hv, nct);
