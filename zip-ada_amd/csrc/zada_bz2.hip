@@ -2238,11 +2238,27 @@ static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::
       BZ_HIP(hipMemcpy(seg.data(), B->seg.p, 4 * seg_total, hipMemcpyDeviceToHost));
       BZ_HIP(hipMemcpy(seg_cnt.data(), B->seg_cnt.p, 8ull * nblk, hipMemcpyDeviceToHost));
     }
+    // Batches of this pass.  The entropy stage of the LAST batch of a call has nothing to hide behind: when batches are pipelined the
+    // last pass can end with a short batch ("bz_tail_pct" of the pass; measured: no gain, what the tail saves the extra batch costs -- default 0), the rest is cut evenly.
+    std::vector<uint64_t> targets;
+    {
+      uint64_t pass_est = 0;
+      for (uint32_t k = 0; k < nblk; k++) pass_est += 2 * ((uint64_t)blen[k] + blen[k] / 4 + 8) + 24;       // (single + quarters, or the two segmentations)
+      const bool last_pass = pass == (option == 2 ? 1 : 0);
+      const uint64_t tail = pipelined && last_pass && nblk >= 8 ? pass_est * (uint64_t)(c->knob_bz_tail_pct < 0 ? 0 : c->knob_bz_tail_pct > 50 ? 50 : c->knob_bz_tail_pct) / 100 : 0;
+      const uint64_t body = pass_est - tail;
+      const uint64_t nb = (body + batch_elems - 1) / batch_elems;
+      for (uint64_t i = 0; i < nb; i++) targets.push_back(body / nb + body / (64 * nb) + 1);
+      if (tail) targets.push_back(batch_elems);                                                              // (the rest)
+    }
+    size_t bi = 0;
     uint32_t k0 = 0;
     while (k0 < nblk) {
       std::vector<uint64_t> starts; std::vector<uint32_t> lens;
       uint64_t est = 0;
       uint32_t k1 = k0;
+      const uint64_t limit_cur = bi < targets.size() && targets[bi] < batch_elems ? targets[bi] : batch_elems;
+      bi++;
       for (; k1 < nblk; k1++) {
         if (pass == 0) { BlkPlan Pn; Pn.start = bstart[k1]; Pn.len = blen[k1]; B->plans.push_back(std::move(Pn)); }
         BlkPlan &P = B->plans[plan_base + k1];
@@ -2274,7 +2290,7 @@ static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::
           }
         }
         for (size_t i = before; i < starts.size(); i++) e_blk += (uint64_t)lens[i] + lens[i] / 4 + 8;
-        if (k1 > k0 && est + e_blk > batch_elems) { starts.resize(before); lens.resize(before); if (pass == 0) B->plans.pop_back(); break; }
+        if (k1 > k0 && est + e_blk > limit_cur) { starts.resize(before); lens.resize(before); if (pass == 0) B->plans.pop_back(); break; }
         est += e_blk;
         P.tac[2 * pass] = std::move(t0); P.tac[2 * pass + 1] = std::move(t1);
       }

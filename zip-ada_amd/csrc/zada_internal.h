@@ -263,7 +263,8 @@ struct Ctx {
   int knob_batch_mib = 512;         // MiB of LZ buffer one batch of small entries may take (zada_deflate_batch)
   int knob_bz_batch_mib = 256;      // BZip2: MiB of small entries zada_bzip2_batch takes through one launch sequence
   int knob_bz_span_mib = 1024;      // BZip2: MiB of the stream whose block limits are found at a time
-  int knob_bz_batch_melems = 640;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
+  int knob_bz_tail_pct = 0;         // BZip2: share of the last pass that the last (short) batch of a pipelined call takes
+  int knob_bz_batch_melems = 768;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
   int knob_bz_lists = 16;           // BZip2 rotation sort: from this prefix length on, sub-blocks whose unsorted groups have at most 64 rows leave the
                                     // full sweeps for per-group sorts driven by a list (0 = never: every round sweeps)
   int knob_bz_pipeline = 1;         // BZip2: the transforms of a batch of sub-blocks run next to the entropy stage of the batch before (0: one batch at a time)
