@@ -607,16 +607,19 @@ __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict
 
 // ---------------------------------------------------------------------------------------------------------------
 //  Late rounds: group lists.  The rounds above sweep every row of a sub-block (the rows read in order are what gives the second
-//  halves' order for free), whatever share of them is still unsorted -- and on data with long repeats a few percent of the rows
-//  stay unsorted for ten more doublings, in groups of a handful of rows.  Once every unsorted group of a sub-block has at most
-//  GL_MAX rows the sub-block leaves the sweeps: its groups go on a list (first row, rows, sub-block) and a round sorts each group
-//  by the class of its rows' second halves inside a TEAM of lanes (8 or 64: a bitonic network over cross-lane reads), one launch
-//  over the list, touching nothing but the groups' own rows.  The order among rows that still agree is immaterial (they stay one
-//  group; rotations that are equal to the end have equal last bytes, and the original's row is its group's first: :266-276).
-//  A round reads the classes of the round before: the new classes wait in `nc` until every group has been sorted (k_bz_gl_apply).
+//  halves' order for free), whatever share of them is still unsorted -- and on data with long repeats most of what is left after a
+//  few doublings are groups of a handful of rows that take ten more doublings to come apart.  Once every unsorted group of a
+//  sub-block has at most GL_MAX rows the sub-block leaves the sweeps: its groups go on a list (first row, rows, sub-block) and a
+//  round sorts each group by the class of its rows' second halves -- a thread per group of up to 8 rows, a wave per larger one --
+//  touching nothing but the groups' own rows.  The order among rows that still agree is immaterial (they stay one group; rotations
+//  that are equal to the end have equal last bytes, and the original's row is its group's first: :266-276).
+//  A round reads the classes of the round before while it makes the new ones: the listed sub-blocks' classes live in TWO arrays that
+//  take turns (a round reads one and writes the other, every row of every listed group); a row that comes to stand alone stays on the
+//  list for one more round as a group of one, which writes its (final) class into the other array as well.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t GL_MAX = 64, GL_SMALL = 8;
-struct GlEntry { uint32_t first, rows, sb, pad; };
+struct GlEntry { uint32_t first, sb_rows; };           // first row | sub-block << 6 | rows - 1
+__device__ __forceinline__ GlEntry gl_entry(uint32_t first, uint32_t rows, uint32_t sb) { return GlEntry{first, (sb << 6) | (rows - 1u)}; }
 struct GlLists { GlEntry *s, *m; uint32_t *cnt; uint32_t cap_s, cap_m; };      // cnt[0] / cnt[1]: entries of s / m; cnt[2]: overflow flag
 
 // largest unsorted group of every sub-block that is still swept: a row is its group's last when the next row's class differs
@@ -640,13 +643,15 @@ __global__ void k_bz_gl_decide(SubTab T, const uint8_t *__restrict__ done, const
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < T.nsb) lmode[s] = (!done[s] && submax[s] <= GL_MAX) ? 1 : 0;
 }
-// Appends to the lists, one atomic per WORKGROUP and list (a counter that every wave hits by itself is one address for millions of
-// atomics a round: they queue up at its L2 channel).  Every thread of the workgroup must call it; lds: 2 * waves + 2 words.
-__device__ __forceinline__ void gl_append(GlLists L, bool small, bool medium, uint32_t first, uint32_t rows, uint32_t sb, uint32_t *lds) {
+// Room for this thread's `ns` entries of the small list and `nm` of the medium one: one atomic per WORKGROUP and list (a counter that
+// every wave hits by itself is one address for millions of atomics a round: they queue up at its L2 channel).  Every thread of the
+// workgroup must call it; lds: 2 * waves + 2 words.  Returns the thread's first slots (past the capacity: the overflow flag is set).
+__device__ __forceinline__ void gl_reserve(GlLists L, uint32_t ns, uint32_t nm, uint32_t *lds, uint32_t &is, uint32_t &im) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const unsigned long long ms = __ballot(small), mm = __ballot(medium), lt = (1ull << lane) - 1ull;
-  __syncthreads();                                                    // (the call before has read its bases)
-  if (lane == 0) { lds[2 * w] = (uint32_t)__popcll(ms); lds[2 * w + 1] = (uint32_t)__popcll(mm); }
+  uint32_t ss = ns, sm = nm;                           // inclusive scans over the wave
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ss, o), b = __shfl_up(sm, o); if (lane >= o) { ss += a; sm += b; } }
+  __syncthreads();                                     // (the call before has read its bases)
+  if (lane == 63) { lds[2 * w] = ss; lds[2 * w + 1] = sm; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t ts = 0, tm = 0;
@@ -655,18 +660,13 @@ __device__ __forceinline__ void gl_append(GlLists L, bool small, bool medium, ui
     lds[2 * nw + 1] = tm ? atomicAdd(&L.cnt[1], tm) : 0u;
   }
   __syncthreads();
-  if (small) {
-    const uint32_t i = lds[2 * nw] + lds[2 * w] + (uint32_t)__popcll(ms & lt);
-    if (i < L.cap_s) L.s[i] = GlEntry{first, rows, sb, 0u}; else L.cnt[2] = 1;
-  }
-  if (medium) {
-    const uint32_t i = lds[2 * nw + 1] + lds[2 * w + 1] + (uint32_t)__popcll(mm & lt);
-    if (i < L.cap_m) L.m[i] = GlEntry{first, rows, sb, 0u}; else L.cnt[2] = 1;
-  }
+  is = lds[2 * nw] + lds[2 * w] + ss - ns;
+  im = lds[2 * nw + 1] + lds[2 * w + 1] + sm - nm;
+  if ((ns && is + ns > L.cap_s) || (nm && im + nm > L.cap_m)) L.cnt[2] = 1;
 }
-// the unsorted groups of the sub-blocks that leave the sweeps, listed by their last rows
-__global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles,
-                                                      const uint8_t *__restrict__ lmode, GlLists L, uint32_t ntiles_x) {
+// the unsorted groups of the sub-blocks that leave the sweeps, listed by their last rows; the second class array gets the classes
+__global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, uint32_t *__restrict__ cl2, SubTab T,
+                                                      const Tile *__restrict__ tiles, const uint8_t *__restrict__ lmode, GlLists L, uint32_t ntiles_x) {
   __shared__ uint32_t lds[34];
   const uint32_t bx = xcd_tile(ntiles_x);
   if (bx >= ntiles_x) return;
@@ -677,140 +677,134 @@ __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict
     const uint32_t i = i0 + threadIdx.x;
     uint32_t first = 0, rows = 0;
     if (i < m) {
-      const uint32_t l = t.lo + i, g = off + l, c = cl[sa[g]];
+      const uint32_t l = t.lo + i, g = off + l, e = sa[g], c = cl[e];
+      cl2[e] = c;
       if (l + 1 == n || cl[sa[g + 1]] != c) { first = c; rows = g - c + 1; }
     }
-    gl_append(L, rows > 1 && rows <= GL_SMALL, rows > GL_SMALL, first, rows, t.sb, lds);
+    const bool small = rows > 1 && rows <= GL_SMALL, medium = rows > GL_SMALL;
+    uint32_t is, im;
+    gl_reserve(L, small ? 1u : 0u, medium ? 1u : 0u, lds, is, im);
+    if (small && is < L.cap_s) L.s[is] = gl_entry(first, rows, t.sb);
+    if (medium && im < L.cap_m) L.m[im] = gl_entry(first, rows, t.sb);
   }
 }
 __global__ void k_bz_gl_leave(SubTab T, const uint8_t *__restrict__ lmode, uint8_t *__restrict__ done) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < T.nsb && lmode[s]) done[s] = 1;
 }
-// One round of the small groups (2 .. 8 rows): a THREAD per group -- most groups of the late rounds are pairs, a team of lanes would
-// idle -- with the group's rows and keys in registers and a sorting network over them.
+// One round of the small groups (1 .. 8 rows): a THREAD per group -- most groups of the late rounds are pairs, a team of lanes would
+// idle -- with the group's rows and keys in registers and a sorting network over them.  clr: the classes of the round before; clw: the
+// other array, which gets the class of every row of the group.
 __device__ __forceinline__ void gl_cex(uint32_t &ka, uint32_t &va, uint32_t &kb, uint32_t &vb) {
   const bool sw = kb < ka || (kb == ka && vb < va);
   const uint32_t k0 = sw ? kb : ka, v0 = sw ? vb : va, k1 = sw ? ka : kb, v1 = sw ? va : vb;
   ka = k0; va = v0; kb = k1; vb = v1;
 }
 __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
-                                                          const uint32_t *__restrict__ cl, SubTab T, uint32_t *__restrict__ nc, GlLists next) {
+                                                          const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
   __shared__ uint32_t lds[10];
   const uint32_t count = *cnt_p, gi = blockIdx.x * 256u + threadIdx.x;
-  GlEntry E{0, 0, 0, 0};
-  if (gi < count) E = list[gi];
-  uint32_t n = 1, off = 0;
-  if (E.rows) { n = T.n[E.sb]; off = T.off[E.sb]; }
-  const bool live = E.rows != 0 && h < n;                              // h >= n: the rotations of the group are equal, nothing is left to tell them apart
+  uint32_t first = 0, rows = 0, sb = 0;
+  if (gi < count) { const GlEntry E = list[gi]; first = E.first; rows = (E.sb_rows & 63u) + 1u; sb = E.sb_rows >> 6; }
   uint32_t k[8], v[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) { k[j] = 0xFFFFFFFFu; v[j] = 0xFFFFFFFFu; }
-  if (live) {
+  uint32_t nnew = 0;                                   // groups for the next round: bit j set = a group starts at row j ...
+  uint32_t ends = 0;                                   // ... bit j set = a group ends behind row j
+  if (rows == 1) clw[sa[first]] = first;               // a row that came to stand alone in the round before: its class, in the other array as well
+  else if (rows > 1) {
+    const uint32_t n = T.n[sb], off = T.off[sb];
 #pragma unroll
-    for (int j = 0; j < 8; j++) if ((uint32_t)j < E.rows) v[j] = sa[E.first + j];
+    for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) v[j] = sa[first + j];
+    if (h >= n) {                                      // the rotations of the group are equal: nothing is left to tell them apart, the group goes off the lists
 #pragma unroll
-    for (int j = 0; j < 8; j++) if ((uint32_t)j < E.rows) { uint32_t l = v[j] - off + h; if (l >= n) l -= n; k[j] = cl[off + l]; }
-    if (E.rows == 2) gl_cex(k[0], v[0], k[1], v[1]);
-    else {
-      // 19 compare-exchanges sort eight (the empty places hold the largest key and stay behind)
+      for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) clw[v[j]] = first;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) { uint32_t l = v[j] - off + h; if (l >= n) l -= n; k[j] = clr[off + l]; }
+      if (rows == 2) gl_cex(k[0], v[0], k[1], v[1]);
+      else {
+        // 19 compare-exchanges sort eight (the empty places hold the largest key and stay behind)
 #define CX(a, b) gl_cex(k[a], v[a], k[b], v[b])
-      CX(0, 1); CX(2, 3); CX(4, 5); CX(6, 7); CX(0, 2); CX(1, 3); CX(4, 6); CX(5, 7); CX(1, 2); CX(5, 6); CX(0, 4); CX(3, 7); CX(1, 5); CX(2, 6); CX(1, 4); CX(3, 6); CX(2, 4); CX(3, 5); CX(3, 4);
+        CX(0, 1); CX(2, 3); CX(4, 5); CX(6, 7); CX(0, 2); CX(1, 3); CX(4, 6); CX(5, 7); CX(1, 2); CX(5, 6); CX(0, 4); CX(3, 7); CX(1, 5); CX(2, 6); CX(1, 4); CX(3, 6); CX(2, 4); CX(3, 5); CX(3, 4);
 #undef CX
-    }
-  }
-  // rows in order; a row starts a new group where its key differs from the row before.  Groups of more than one row go on the next list.
-  uint32_t start = 0;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    if (live && (uint32_t)j < E.rows) {
-      if (j > 0 && k[j] != k[j - 1]) start = (uint32_t)j;
-      sa[E.first + j] = v[j];
-      nc[E.first + j] = E.first + start;
-    }
-  }
-  // (eight rows make at most four groups of two or more)
-  uint32_t s0 = 0;
-  int found = 0;
-  uint32_t gf[4], gr[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) { gf[q] = 0; gr[q] = 0; }
-  if (live) {
-#pragma unroll
-    for (int j = 1; j <= 8; j++) {
-      const bool brk = (uint32_t)j >= E.rows || k[j < 8 ? j : 7] != k[j - 1] || j == 8;
-      if ((uint32_t)j <= E.rows && brk) {
-        if ((uint32_t)j - s0 > 1) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) if (q == found) { gf[q] = E.first + s0; gr[q] = (uint32_t)j - s0; }
-          found++;
-        }
-        s0 = (uint32_t)j;
       }
+      // rows in order; a row starts a new group where its key differs from the row before
+      uint32_t start = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if ((uint32_t)j < rows) {
+          if (j > 0 && k[j] != k[j - 1]) { start = (uint32_t)j; ends |= 1u << (j - 1); }
+          sa[first + j] = v[j];
+          clw[v[j]] = first + start;
+        }
+      }
+      ends |= 1u << (rows - 1);
+      nnew = (uint32_t)__popc(ends);
     }
   }
-#pragma unroll
-  for (int q = 0; q < 4; q++) gl_append(next, gr[q] > 1, false, gf[q], gr[q], E.sb, lds);
+  uint32_t is, im;
+  gl_reserve(next, nnew, 0u, lds, is, im);
+  uint32_t s0 = 0;
+  while (ends) {
+    const uint32_t e = (uint32_t)__builtin_ctz(ends);
+    ends &= ends - 1u;
+    if (is < next.cap_s) next.s[is] = gl_entry(first + s0, e + 1u - s0, sb);
+    is++;
+    s0 = e + 1u;
+  }
 }
 // one round of the medium groups (9 .. 64 rows): a wave per group, a bitonic network over cross-lane reads
 __global__ void __launch_bounds__(256) k_bz_gl_sort_wave(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
-                                                         const uint32_t *__restrict__ cl, SubTab T, uint32_t *__restrict__ nc, GlLists next) {
+                                                         const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
   __shared__ uint32_t lds[10];
   constexpr int TW = 64;
   const uint32_t count = *cnt_p;
   const uint32_t team = (blockIdx.x * 256u + threadIdx.x) / TW;
   const int tl = threadIdx.x & 63;
-  GlEntry E{0, 0, 0, 0};
-  if (team < count) E = list[team];
+  uint32_t first = 0, rows = 0, sb = 0;
+  if (team < count) { const GlEntry E = list[team]; first = E.first; rows = (E.sb_rows & 63u) + 1u; sb = E.sb_rows >> 6; }
   uint32_t n = 1, off = 0;
-  if (E.rows) { n = T.n[E.sb]; off = T.off[E.sb]; }
-  const bool live = E.rows != 0 && h < n;
-  const bool mine = live && (uint32_t)tl < E.rows;
+  if (rows) { n = T.n[sb]; off = T.off[sb]; }
+  const bool live = rows != 0 && h < n;
+  const bool mine = (uint32_t)tl < rows;
   uint32_t k = 0xFFFFFFFFu, v = 0xFFFFFFFFu;
   if (mine) {
-    v = sa[E.first + tl];
-    uint32_t l = v - off + h;
-    if (l >= n) l -= n;
-    k = cl[off + l];
+    v = sa[first + tl];
+    if (live) { uint32_t l = v - off + h; if (l >= n) l -= n; k = clr[off + l]; }
+    else clw[v] = first;                               // (equal rotations: the group goes off the lists, its class in both arrays)
   }
+  uint32_t rows_new = 0;
+  if (live) {                                          // (uniform over the wave)
 #pragma unroll
-  for (int size = 2; size <= TW; size <<= 1) {
+    for (int size = 2; size <= TW; size <<= 1) {
 #pragma unroll
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const uint32_t ok = __shfl_xor(k, stride), ov = __shfl_xor(v, stride);
-      const bool keep_min = ((tl & stride) == 0) == ((tl & size) == 0);
-      const bool other_less = ok < k || (ok == k && ov < v);
-      const bool other_more = ok > k || (ok == k && ov > v);
-      if (keep_min ? other_less : other_more) { k = ok; v = ov; }
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        const uint32_t ok = __shfl_xor(k, stride), ov = __shfl_xor(v, stride);
+        const bool keep_min = ((tl & stride) == 0) == ((tl & size) == 0);
+        const bool other_less = ok < k || (ok == k && ov < v);
+        const bool other_more = ok > k || (ok == k && ov > v);
+        if (keep_min ? other_less : other_more) { k = ok; v = ov; }
+      }
+    }
+    const uint32_t kp = __shfl_up(k, 1);
+    const bool head = mine && (tl == 0 || kp != k);
+    const unsigned long long hm = __ballot(head);
+    if (mine) {
+      const unsigned long long upto = hm & (tl == 63 ? ~0ull : ((2ull << tl) - 1ull));
+      const uint32_t start = 63u - (uint32_t)__builtin_clzll(upto);
+      const unsigned long long above = tl == 63 ? 0ull : hm & ~((2ull << tl) - 1ull);
+      const uint32_t nxt = above ? (uint32_t)__builtin_ctzll(above) : rows;
+      sa[first + tl] = v;
+      clw[v] = first + start;
+      if (head) rows_new = nxt - (uint32_t)tl;
     }
   }
-  const uint32_t kp = __shfl_up(k, 1);
-  const bool head = mine && (tl == 0 || kp != k);
-  const unsigned long long hm = __ballot(head);
-  uint32_t start = 0, nxt = E.rows;
-  if (mine) {
-    const unsigned long long upto = hm & (tl == 63 ? ~0ull : ((2ull << tl) - 1ull));
-    start = 63u - (uint32_t)__builtin_clzll(upto);
-    const unsigned long long above = tl == 63 ? 0ull : hm & ~((2ull << tl) - 1ull);
-    if (above) nxt = (uint32_t)__builtin_ctzll(above);
-    sa[E.first + tl] = v;
-    nc[E.first + tl] = E.first + start;
-  }
-  const uint32_t rows_new = head ? nxt - (uint32_t)tl : 0u;
-  gl_append(next, rows_new > 1 && rows_new <= GL_SMALL, rows_new > GL_SMALL, E.first + (uint32_t)tl, rows_new, E.sb, lds);
-}
-// the new classes of the groups just sorted (nc) become the classes (cl): TW lanes per group
-template <int TW>
-__global__ void __launch_bounds__(256) k_bz_gl_apply(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, const uint32_t *__restrict__ sa,
-                                                     const uint32_t *__restrict__ nc, SubTab T, uint32_t *__restrict__ cl) {
-  const uint32_t count = *cnt_p;
-  const uint32_t team = (blockIdx.x * 256u + threadIdx.x) / TW;
-  const uint32_t tl = threadIdx.x & (TW - 1);
-  if (team >= count) return;
-  const GlEntry E = list[team];
-  if (TW == 1) {
-    if (h < T.n[E.sb]) for (uint32_t j = 0; j < E.rows; j++) cl[sa[E.first + j]] = nc[E.first + j];
-  } else if (tl < E.rows && h < T.n[E.sb]) cl[sa[E.first + tl]] = nc[E.first + tl];
+  const bool small = rows_new >= 1 && rows_new <= GL_SMALL, medium = rows_new > GL_SMALL;
+  uint32_t is, im;
+  gl_reserve(next, small ? 1u : 0u, medium ? 1u : 0u, lds, is, im);
+  if (small && is < next.cap_s) next.s[is] = gl_entry(first + (uint32_t)tl, rows_new, sb);
+  if (medium && im < next.cap_m) next.m[im] = gl_entry(first + (uint32_t)tl, rows_new, sb);
 }
 
 // rows ordered by `prefix` bytes: a sub-block whose rotations are that short is done (equal rotations stay in one group)
@@ -1912,7 +1906,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   uint32_t *nc = nullptr, *submax = nullptr, *glcnt = nullptr;
   uint8_t *lmode = nullptr;
   if (use_lists) {
-    const uint32_t cap_s = (uint32_t)(tot / 2 + 64), cap_m = (uint32_t)(tot / (GL_SMALL + 1) + 64);
+    const uint32_t cap_s = (uint32_t)(tot + 64), cap_m = (uint32_t)(tot / (GL_SMALL + 1) + 64);          // (groups of one included: a round lists a row at most once)
     if ((rc = dbuf_ensure(c, B->gl_s[0], sizeof(GlEntry) * (size_t)cap_s)) || (rc = dbuf_ensure(c, B->gl_s[1], sizeof(GlEntry) * (size_t)cap_s)) ||
         (rc = dbuf_ensure(c, B->gl_m[0], sizeof(GlEntry) * (size_t)cap_m)) || (rc = dbuf_ensure(c, B->gl_m[1], sizeof(GlEntry) * (size_t)cap_m)) ||
         (rc = dbuf_ensure(c, B->gl_nc, 4 * ne)) || (rc = dbuf_ensure(c, B->gl_submax, 4ull * nsb + 64)) || (rc = dbuf_ensure(c, B->gl_lmode, nsb + 64)) ||
@@ -1963,16 +1957,17 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
     if (use_lists) {
       const GlLists cur = GL[gcur], nxt = GL[gcur ^ 1];
       // the listed groups, sorted by 2h bytes now; what is left of them goes on the other generation's lists
-      if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.s, cur.cnt + 0, h, valA, cl, T, nc, nxt);
-      if (gl_n[1]) hipLaunchKernelGGL(k_bz_gl_sort_wave, dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MAX + 255) / 256)), dim3(256), 0, st, cur.m, cur.cnt + 1, h, valA, cl, T, nc, nxt);
-      if (gl_n[0]) hipLaunchKernelGGL((k_bz_gl_apply<1>), dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.s, cur.cnt + 0, h, valA, nc, T, cl);
-      if (gl_n[1]) hipLaunchKernelGGL((k_bz_gl_apply<(int)GL_MAX>), dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MAX + 255) / 256)), dim3(256), 0, st, cur.m, cur.cnt + 1, h, valA, nc, T, cl);
+      // (the listed sub-blocks' classes: read in one array, written in the other; the swept ones keep to cl)
+      const uint32_t *clr = gcur ? nc : cl;
+      uint32_t *clw = gcur ? cl : nc;
+      if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.s, cur.cnt + 0, h, valA, clr, clw, T, nxt);
+      if (gl_n[1]) hipLaunchKernelGGL(k_bz_gl_sort_wave, dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MAX + 255) / 256)), dim3(256), 0, st, cur.m, cur.cnt + 1, h, valA, clr, clw, T, nxt);
       // sub-blocks whose unsorted groups have all become small leave the sweeps: their groups (classes of 2h bytes) join the lists
       if (swept && 2 * h >= (uint32_t)c->knob_bz_lists) {
         BZ_HIP(hipMemsetAsync(submax, 0, 4ull * nsb, st));
         hipLaunchKernelGGL(k_bz_gl_max, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, cl, T, ET, done, submax, net);
         hipLaunchKernelGGL(k_bz_gl_decide, dim3((nsb + 255) / 256), dim3(256), 0, st, T, done, submax, lmode);
-        hipLaunchKernelGGL(k_bz_gl_build, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, cl, T, ET, lmode, nxt, net);
+        hipLaunchKernelGGL(k_bz_gl_build, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, cl, nc, T, ET, lmode, nxt, net);
         hipLaunchKernelGGL(k_bz_gl_leave, dim3((nsb + 255) / 256), dim3(256), 0, st, T, lmode, done);
       }
       uint32_t hc[4] = {0, 0, 0, 0};
