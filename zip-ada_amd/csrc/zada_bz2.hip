@@ -620,7 +620,10 @@ __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict
 constexpr uint32_t GL_MAX = 64, GL_SMALL = 8;
 struct GlEntry { uint32_t first, sb_rows; };           // first row | sub-block << 6 | rows - 1
 __device__ __forceinline__ GlEntry gl_entry(uint32_t first, uint32_t rows, uint32_t sb) { return GlEntry{first, (sb << 6) | (rows - 1u)}; }
-struct GlLists { GlEntry *s, *m; uint32_t *cnt; uint32_t cap_s, cap_m; };      // cnt[0] / cnt[1]: entries of s / m; cnt[2]: overflow flag
+// three lists by group size: up to 8 rows (a thread sorts the group), 9 .. 16 (sixteen lanes), 17 .. 64 (a wave)
+constexpr uint32_t GL_MID = 16;
+struct GlLists { GlEntry *l[3]; uint32_t *cnt; uint32_t cap[3]; };             // cnt[0 .. 2]: entries of the lists; cnt[3]: overflow flag
+__device__ __forceinline__ int gl_class(uint32_t rows) { return rows <= GL_SMALL ? 0 : rows <= GL_MID ? 1 : 2; }
 
 // largest unsorted group of every sub-block that is still swept: a row is its group's last when the next row's class differs
 __global__ void __launch_bounds__(1024) k_bz_gl_max(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles,
@@ -643,31 +646,36 @@ __global__ void k_bz_gl_decide(SubTab T, const uint8_t *__restrict__ done, const
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < T.nsb) lmode[s] = (!done[s] && submax[s] <= GL_MAX) ? 1 : 0;
 }
-// Room for this thread's `ns` entries of the small list and `nm` of the medium one: one atomic per WORKGROUP and list (a counter that
-// every wave hits by itself is one address for millions of atomics a round: they queue up at its L2 channel).  Every thread of the
-// workgroup must call it; lds: 2 * waves + 2 words.  Returns the thread's first slots (past the capacity: the overflow flag is set).
-__device__ __forceinline__ void gl_reserve(GlLists L, uint32_t ns, uint32_t nm, uint32_t *lds, uint32_t &is, uint32_t &im) {
+// Room for this thread's entries (cnt[k] of list k): one atomic per WORKGROUP and list (a counter that every wave hits by itself is
+// one address for millions of atomics a round: they queue up at its L2 channel).  Every thread of the workgroup must call it;
+// lds: 3 * waves + 3 words.  Returns the thread's first slot of each list (past the capacity: the overflow flag is set).
+__device__ __forceinline__ void gl_reserve(GlLists L, const uint32_t (&cnt)[3], uint32_t *lds, uint32_t (&slot)[3]) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  uint32_t ss = ns, sm = nm;                           // inclusive scans over the wave
-  for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ss, o), b = __shfl_up(sm, o); if (lane >= o) { ss += a; sm += b; } }
+  uint32_t sc[3] = {cnt[0], cnt[1], cnt[2]};           // inclusive scans over the wave
+  for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const uint32_t a = __shfl_up(sc[k], o); if (lane >= o) sc[k] += a; }
+  }
   __syncthreads();                                     // (the call before has read its bases)
-  if (lane == 63) { lds[2 * w] = ss; lds[2 * w + 1] = sm; }
+  if (lane == 63) { lds[3 * w] = sc[0]; lds[3 * w + 1] = sc[1]; lds[3 * w + 2] = sc[2]; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t ts = 0, tm = 0;
-    for (int k = 0; k < nw; k++) { const uint32_t a = lds[2 * k], b = lds[2 * k + 1]; lds[2 * k] = ts; lds[2 * k + 1] = tm; ts += a; tm += b; }
-    lds[2 * nw] = ts ? atomicAdd(&L.cnt[0], ts) : 0u;
-    lds[2 * nw + 1] = tm ? atomicAdd(&L.cnt[1], tm) : 0u;
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    uint32_t t = 0;
+    for (int q = 0; q < nw; q++) { const uint32_t a = lds[3 * q + k]; lds[3 * q + k] = t; t += a; }
+    lds[3 * nw + k] = t ? atomicAdd(&L.cnt[k], t) : 0u;
   }
   __syncthreads();
-  is = lds[2 * nw] + lds[2 * w] + ss - ns;
-  im = lds[2 * nw + 1] + lds[2 * w + 1] + sm - nm;
-  if ((ns && is + ns > L.cap_s) || (nm && im + nm > L.cap_m)) L.cnt[2] = 1;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    slot[k] = lds[3 * nw + k] + lds[3 * w + k] + sc[k] - cnt[k];
+    if (cnt[k] && slot[k] + cnt[k] > L.cap[k]) L.cnt[3] = 1;
+  }
 }
 // the unsorted groups of the sub-blocks that leave the sweeps, listed by their last rows; the second class array gets the classes
 __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, uint32_t *__restrict__ cl2, SubTab T,
                                                       const Tile *__restrict__ tiles, const uint8_t *__restrict__ lmode, GlLists L, uint32_t ntiles_x) {
-  __shared__ uint32_t lds[34];
+  __shared__ uint32_t lds[52];
   const uint32_t bx = xcd_tile(ntiles_x);
   if (bx >= ntiles_x) return;
   const Tile t = tiles[bx];
@@ -681,11 +689,11 @@ __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict
       cl2[e] = c;
       if (l + 1 == n || cl[sa[g + 1]] != c) { first = c; rows = g - c + 1; }
     }
-    const bool small = rows > 1 && rows <= GL_SMALL, medium = rows > GL_SMALL;
-    uint32_t is, im;
-    gl_reserve(L, small ? 1u : 0u, medium ? 1u : 0u, lds, is, im);
-    if (small && is < L.cap_s) L.s[is] = gl_entry(first, rows, t.sb);
-    if (medium && im < L.cap_m) L.m[im] = gl_entry(first, rows, t.sb);
+    const int kc = gl_class(rows);
+    const uint32_t cnt[3] = {rows > 1 && kc == 0 ? 1u : 0u, kc == 1 ? 1u : 0u, kc == 2 ? 1u : 0u};
+    uint32_t slot[3];
+    gl_reserve(L, cnt, lds, slot);
+    if (rows > 1 && slot[kc] < L.cap[kc]) L.l[kc][slot[kc]] = gl_entry(first, rows, t.sb);
   }
 }
 __global__ void k_bz_gl_leave(SubTab T, const uint8_t *__restrict__ lmode, uint8_t *__restrict__ done) {
@@ -702,7 +710,7 @@ __device__ __forceinline__ void gl_cex(uint32_t &ka, uint32_t &va, uint32_t &kb,
 }
 __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
                                                           const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
-  __shared__ uint32_t lds[10];
+  __shared__ uint32_t lds[16];
   const uint32_t count = *cnt_p, gi = blockIdx.x * 256u + threadIdx.x;
   uint32_t first = 0, rows = 0, sb = 0;
   if (gi < count) { const GlEntry E = list[gi]; first = E.first; rows = (E.sb_rows & 63u) + 1u; sb = E.sb_rows >> 6; }
@@ -743,25 +751,26 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restr
       nnew = (uint32_t)__popc(ends);
     }
   }
-  uint32_t is, im;
-  gl_reserve(next, nnew, 0u, lds, is, im);
-  uint32_t s0 = 0;
+  const uint32_t cnt[3] = {nnew, 0u, 0u};
+  uint32_t slot[3];
+  gl_reserve(next, cnt, lds, slot);
+  uint32_t s0 = 0, is = slot[0];
   while (ends) {
     const uint32_t e = (uint32_t)__builtin_ctz(ends);
     ends &= ends - 1u;
-    if (is < next.cap_s) next.s[is] = gl_entry(first + s0, e + 1u - s0, sb);
+    if (is < next.cap[0]) next.l[0][is] = gl_entry(first + s0, e + 1u - s0, sb);
     is++;
     s0 = e + 1u;
   }
 }
-// one round of the medium groups (9 .. 64 rows): a wave per group, a bitonic network over cross-lane reads
-__global__ void __launch_bounds__(256) k_bz_gl_sort_wave(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
+// one round of the larger groups: TW lanes per group (16 for 9 .. 16 rows, 64 for 17 .. 64), a bitonic network over cross-lane reads
+template <int TW>
+__global__ void __launch_bounds__(256) k_bz_gl_sort_team(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
                                                          const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
-  __shared__ uint32_t lds[10];
-  constexpr int TW = 64;
+  __shared__ uint32_t lds[16];
   const uint32_t count = *cnt_p;
   const uint32_t team = (blockIdx.x * 256u + threadIdx.x) / TW;
-  const int tl = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, tl = lane & (TW - 1), tbase = lane - tl;
   uint32_t first = 0, rows = 0, sb = 0;
   if (team < count) { const GlEntry E = list[team]; first = E.first; rows = (E.sb_rows & 63u) + 1u; sb = E.sb_rows >> 6; }
   uint32_t n = 1, off = 0;
@@ -774,37 +783,37 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_wave(const GlEntry *__restri
     if (live) { uint32_t l = v - off + h; if (l >= n) l -= n; k = clr[off + l]; }
     else clw[v] = first;                               // (equal rotations: the group goes off the lists, its class in both arrays)
   }
-  uint32_t rows_new = 0;
-  if (live) {                                          // (uniform over the wave)
 #pragma unroll
-    for (int size = 2; size <= TW; size <<= 1) {
+  for (int size = 2; size <= TW; size <<= 1) {
 #pragma unroll
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        const uint32_t ok = __shfl_xor(k, stride), ov = __shfl_xor(v, stride);
-        const bool keep_min = ((tl & stride) == 0) == ((tl & size) == 0);
-        const bool other_less = ok < k || (ok == k && ov < v);
-        const bool other_more = ok > k || (ok == k && ov > v);
-        if (keep_min ? other_less : other_more) { k = ok; v = ov; }
-      }
-    }
-    const uint32_t kp = __shfl_up(k, 1);
-    const bool head = mine && (tl == 0 || kp != k);
-    const unsigned long long hm = __ballot(head);
-    if (mine) {
-      const unsigned long long upto = hm & (tl == 63 ? ~0ull : ((2ull << tl) - 1ull));
-      const uint32_t start = 63u - (uint32_t)__builtin_clzll(upto);
-      const unsigned long long above = tl == 63 ? 0ull : hm & ~((2ull << tl) - 1ull);
-      const uint32_t nxt = above ? (uint32_t)__builtin_ctzll(above) : rows;
-      sa[first + tl] = v;
-      clw[v] = first + start;
-      if (head) rows_new = nxt - (uint32_t)tl;
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const uint32_t ok = __shfl_xor(k, stride), ov = __shfl_xor(v, stride);
+      const bool keep_min = ((tl & stride) == 0) == ((tl & size) == 0);
+      const bool other_less = ok < k || (ok == k && ov < v);
+      const bool other_more = ok > k || (ok == k && ov > v);
+      if (keep_min ? other_less : other_more) { k = ok; v = ov; }
     }
   }
-  const bool small = rows_new >= 1 && rows_new <= GL_SMALL, medium = rows_new > GL_SMALL;
-  uint32_t is, im;
-  gl_reserve(next, small ? 1u : 0u, medium ? 1u : 0u, lds, is, im);
-  if (small && is < next.cap_s) next.s[is] = gl_entry(first + (uint32_t)tl, rows_new, sb);
-  if (medium && im < next.cap_m) next.m[im] = gl_entry(first + (uint32_t)tl, rows_new, sb);
+  // lanes 0 .. rows-1 of the team hold the group's rows in order; a row starts a new group where its key differs from the row before
+  const uint32_t kp = __shfl_up(k, 1);
+  const bool head = live && mine && (tl == 0 || kp != k);
+  unsigned long long hm = __ballot(head);
+  if (TW < 64) hm = (hm >> tbase) & ((1ull << (TW & 63)) - 1ull);      // the team's own heads, bit j = lane j of the team
+  uint32_t rows_new = 0;
+  if (live && mine) {
+    const unsigned long long upto = hm & (tl == 63 ? ~0ull : ((2ull << tl) - 1ull));
+    const uint32_t start = 63u - (uint32_t)__builtin_clzll(upto);
+    const unsigned long long above = tl == 63 ? 0ull : hm & ~((2ull << tl) - 1ull);
+    const uint32_t nxt = above ? (uint32_t)__builtin_ctzll(above) : rows;
+    sa[first + tl] = v;
+    clw[v] = first + start;
+    if (head) rows_new = nxt - (uint32_t)tl;
+  }
+  const int kc = gl_class(rows_new);
+  const uint32_t cnt[3] = {rows_new >= 1 && kc == 0 ? 1u : 0u, kc == 1 ? 1u : 0u, kc == 2 ? 1u : 0u};
+  uint32_t slot[3];
+  gl_reserve(next, cnt, lds, slot);
+  if (rows_new >= 1 && slot[kc] < next.cap[kc]) next.l[kc][slot[kc]] = gl_entry(first + (uint32_t)tl, rows_new, sb);
 }
 
 // rows ordered by `prefix` bytes: a sub-block whose rotations are that short is done (equal rotations stay in one group)
@@ -1727,7 +1736,7 @@ struct Bz2State {
   DBuf rtiles, rtile_first, rtile_val, rtile_crc, rtile_rs, etiles, etile_first;
   // element space
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
-  DBuf gl_s[2], gl_m[2], gl_nc, gl_submax, gl_lmode, gl_cnt, gl_tmp;   // group lists of the late rounds (k_bz_gl_*)
+  DBuf gl_s[2], gl_m[2], gl_l[2], gl_nc, gl_submax, gl_lmode, gl_cnt, gl_tmp;   // group lists of the late rounds (k_bz_gl_*)
   uint64_t gl_rows = 0;             // groups the lists' rounds of the last batch sorted (profiling aid)
   std::vector<uint32_t> h_cm, h_cfirst;
   std::vector<uint64_t> m_hist;     // rows the doubling rounds of the last batch had to sort (profiling aid)
@@ -1759,7 +1768,7 @@ struct Bz2State {
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
             &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest,
-            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt, &gl_tmp};
+            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_l[0], &gl_l[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt, &gl_tmp};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -1906,17 +1915,18 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   uint32_t *nc = nullptr, *submax = nullptr, *glcnt = nullptr;
   uint8_t *lmode = nullptr;
   if (use_lists) {
-    const uint32_t cap_s = (uint32_t)(tot + 64), cap_m = (uint32_t)(tot / (GL_SMALL + 1) + 64);          // (groups of one included: a round lists a row at most once)
+    const uint32_t cap_s = (uint32_t)(tot + 64), cap_m = (uint32_t)(tot / (GL_SMALL + 1) + 64), cap_l = (uint32_t)(tot / (GL_MID + 1) + 64);   // (groups of one included: a round lists a row at most once)
     if ((rc = dbuf_ensure(c, B->gl_s[0], sizeof(GlEntry) * (size_t)cap_s)) || (rc = dbuf_ensure(c, B->gl_s[1], sizeof(GlEntry) * (size_t)cap_s)) ||
         (rc = dbuf_ensure(c, B->gl_m[0], sizeof(GlEntry) * (size_t)cap_m)) || (rc = dbuf_ensure(c, B->gl_m[1], sizeof(GlEntry) * (size_t)cap_m)) ||
+        (rc = dbuf_ensure(c, B->gl_l[0], sizeof(GlEntry) * (size_t)cap_l)) || (rc = dbuf_ensure(c, B->gl_l[1], sizeof(GlEntry) * (size_t)cap_l)) ||
         (rc = dbuf_ensure(c, B->gl_nc, 4 * ne)) || (rc = dbuf_ensure(c, B->gl_submax, 4ull * nsb + 64)) || (rc = dbuf_ensure(c, B->gl_lmode, nsb + 64)) ||
         (rc = dbuf_ensure(c, B->gl_cnt, 64))) return rc;
     glcnt = B->gl_cnt.as<uint32_t>();
-    for (int k = 0; k < 2; k++) GL[k] = GlLists{B->gl_s[k].as<GlEntry>(), B->gl_m[k].as<GlEntry>(), glcnt + 4 * k, cap_s, cap_m};
+    for (int k = 0; k < 2; k++) GL[k] = GlLists{{B->gl_s[k].as<GlEntry>(), B->gl_m[k].as<GlEntry>(), B->gl_l[k].as<GlEntry>()}, glcnt + 4 * k, {cap_s, cap_m, cap_l}};
     nc = B->gl_nc.as<uint32_t>(); submax = B->gl_submax.as<uint32_t>(); lmode = B->gl_lmode.as<uint8_t>();
     BZ_HIP(hipMemsetAsync(glcnt, 0, 64, st));
   }
-  uint32_t gl_n[2] = {0, 0};                                        // entries (small, medium) of the generation to sort in this round
+  uint32_t gl_n[3] = {0, 0, 0};                                     // entries of the three lists of the generation to sort in this round
   int gcur = 0;
   bool swept = true;                                                // sub-blocks are still being swept
   B->gl_rows = 0;
@@ -1933,7 +1943,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       nct = (uint32_t)ct.size();
       if (nct == 0) swept = false;
     }
-    if (!swept && gl_n[0] + gl_n[1] == 0) break;
+    if (!swept && gl_n[0] + gl_n[1] + gl_n[2] == 0) break;
     B->bwt_rounds++;
     if (swept) {
       if ((rc = dbuf_ensure(c, B->ctiles, sizeof(Tile) * (size_t)nct))) return rc;
@@ -1960,8 +1970,9 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       // (the listed sub-blocks' classes: read in one array, written in the other; the swept ones keep to cl)
       const uint32_t *clr = gcur ? nc : cl;
       uint32_t *clw = gcur ? cl : nc;
-      if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.s, cur.cnt + 0, h, valA, clr, clw, T, nxt);
-      if (gl_n[1]) hipLaunchKernelGGL(k_bz_gl_sort_wave, dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MAX + 255) / 256)), dim3(256), 0, st, cur.m, cur.cnt + 1, h, valA, clr, clw, T, nxt);
+      if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.l[0], cur.cnt + 0, h, valA, clr, clw, T, nxt);
+      if (gl_n[1]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_MID>), dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MID + 255) / 256)), dim3(256), 0, st, cur.l[1], cur.cnt + 1, h, valA, clr, clw, T, nxt);
+      if (gl_n[2]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_MAX>), dim3((uint32_t)(((uint64_t)gl_n[2] * GL_MAX + 255) / 256)), dim3(256), 0, st, cur.l[2], cur.cnt + 2, h, valA, clr, clw, T, nxt);
       // sub-blocks whose unsorted groups have all become small leave the sweeps: their groups (classes of 2h bytes) join the lists
       if (swept && 2 * h >= (uint32_t)c->knob_bz_lists) {
         BZ_HIP(hipMemsetAsync(submax, 0, 4ull * nsb, st));
@@ -1974,9 +1985,9 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       BZ_HIP(hipMemcpyAsync(hc, nxt.cnt, 16, hipMemcpyDeviceToHost, st));
       BZ_HIP(hipMemsetAsync(cur.cnt, 0, 16, st));                  // (the generation just sorted is the next one to be filled)
       BZ_HIP(hipStreamSynchronize(st));
-      if (hc[2] || hc[0] > nxt.cap_s || hc[1] > nxt.cap_m) { c->err = "bzip2: group list overflow"; return ZADA_E_HIP; }
-      B->gl_rows += (uint64_t)gl_n[0] + gl_n[1];
-      gl_n[0] = hc[0]; gl_n[1] = hc[1];
+      if (hc[3] || hc[0] > nxt.cap[0] || hc[1] > nxt.cap[1] || hc[2] > nxt.cap[2]) { c->err = "bzip2: group list overflow"; return ZADA_E_HIP; }
+      B->gl_rows += (uint64_t)gl_n[0] + gl_n[1] + gl_n[2];
+      gl_n[0] = hc[0]; gl_n[1] = hc[1]; gl_n[2] = hc[2];
       gcur ^= 1;
     }
   }
