@@ -19,7 +19,7 @@ for ctr, sub in (("FETCH_SIZE", "_fetch"), ("WRITE_SIZE", "_write")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != ctr:
                 continue
-            name = r["Kernel_Name"].split("(")[0]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             a = acc.setdefault(name, {"sum": 0.0, "dispatches": 0})
             a["sum"] += float(r["Counter_Value"]); a["dispatches"] += 1
     out[ctr] = acc
@@ -31,7 +31,7 @@ json.dump(out, open(os.path.join(P, "pmc_fetch_write_by_kernel.json"), "w"), ind
 sq = {}
 for f in glob.glob(os.path.join(G, tag + "_sq", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("zada::", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("zada::", "")
         a = sq.setdefault(name, {})
         a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 bounds = {}
@@ -53,7 +53,7 @@ if bounds:
     json.dump(bounds, open(os.path.join(P, "sq_bounds_by_kernel.json"), "w"), indent=1)
 rows = list(csv.DictReader(open(os.path.join(P, "bench_1gib_kernel_stats.csv"))))
 for r in rows[:14]:
-    k = r["Name"].split("(")[0]
+    k = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
     f = out["FETCH_SIZE"].get(k); w = out["WRITE_SIZE"].get(k)
     print("%-32s calls %3s avg %9.3f ms %6s%%  fetch(x2) %7.2f GB  write %7.2f GB per launch" % (
         k[:32], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"][:5],
