@@ -193,11 +193,13 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
 // markers in the level-3 plane for k_cross_dist: the search goes on in the previous segment (p has / has no earlier position
 // with its 15-bit hash in its own segment); only the head of the chain at exactly MAX_DIST is left to check
 constexpr uint32_t DIST3_CONTINUE = 0xFFFF, DIST3_HEADCHK = 0xFFFE, DIST3_CONT_FIRST = 0xFFFD, DISTL_CONTINUE = 0x8000;
+constexpr uint32_t HEAVY_STRIDE = 2048, HEAVY_CAP = HEAVY_STRIDE - 1;       // per segment: the list of its heavy 15-bit buckets
 static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, Layout L, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
-                                                     DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg, uint32_t *__restrict__ segmax) {
+                                                     DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg, uint32_t *__restrict__ segmax,
+                                                     uint16_t *__restrict__ heavy) {
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
 #define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
@@ -217,6 +219,8 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint32_t *bsc = bsc3 + seg * 32768ull;          // bucket start | count << 16
   uint16_t *s3 = S3 + seg * 32768ull;
   uint8_t *t3 = T3 + seg * 32768ull;              // top three bits of byte 0: what the 15-bit hash drops
+  uint16_t *hvy = heavy + seg * HEAVY_STRIDE;     // [0]: number of heavy buckets (0xFFFF: too many to list), then their hashes
+  const uint32_t heavy_thr = kquarter / 2 > 0 ? (uint32_t)kquarter / 2 : 1u;
 #ifdef ZADA_OLD_INIT
   for (int l = 0; l < NLEVELS; l++) {
     uint16_t *tail = lv.tails[l] + seg * 65536ull;                  // 65536 buckets per level
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       }
     }
     if (want_runs) {
-      if (tid == 0) cnt[2048] = 0;                   // (free between the sorts: the largest bucket of the segment, level 3)
+      if (tid == 0) { cnt[2048] = 0; cnt[2049] = 0; } // (free between the sorts: the largest bucket of the segment, the number of heavy ones; level 3)
       __syncthreads();
       {
         // LW[wd] = last word index <= wd whose F word is non-zero (word 0 always is: element 0 starts a bucket)
@@ -342,7 +346,14 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 #pragma unroll
         for (int it = 0; it < 32; it++) {
           const uint32_t i = i0 + it * 64;
-          if ((ed[it] >> 15) & 1u) { const uint32_t bs = bucket_start(i); bsc[AB[i] >> 16] = bs | ((i - bs + 1) << 16); mx = mx > i - bs + 1 ? mx : i - bs + 1; }
+          if ((ed[it] >> 15) & 1u) {
+            const uint32_t bs = bucket_start(i), hb = AB[i] >> 16, members = i - bs + 1;
+            bsc[hb] = bs | (members << 16);
+            mx = mx > members ? mx : members;
+            // heavy buckets (half a quarter chain and more): the only ones k_bucket_limits has to look at -- a bucket needs a
+            // quarter chain's worth of members over two segments to get a limit, so it is heavy in one of the two
+            if (members >= heavy_thr) { const uint32_t kh = atomicAdd(&cnt[2049], 1u); if (kh < HEAVY_CAP) hvy[1 + kh] = (uint16_t)hb; }
+          }
         }
         for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(mx, off); mx = mx > o ? mx : o; }
         if (lane == 0 && mx) atomicMax(&cnt[2048], mx);
@@ -372,7 +383,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       }
     }
     __syncthreads();                                 // keys (A) and sorted positions (B) are dead from here
-    if (lvl == 0 && tid == 0) segmax[seg] = cnt[2048];
+    if (lvl == 0 && tid == 0) { segmax[seg] = cnt[2048]; hvy[0] = cnt[2049] <= HEAVY_CAP ? (uint16_t)cnt[2049] : (uint16_t)0xFFFF; }
     for (uint32_t i = tid; i < (m + 16 + 15) / 16; i += 1024) ((uint4 *)A)[i] = ((const uint4 *)sin)[i];   // A := bytes
 #pragma unroll
     for (int it = 0; it < 32; it++) {
@@ -758,7 +769,8 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 // per-position default (no limit) is written by k_prev_links and this kernel touches the few long
 // buckets: one workgroup per segment, long buckets listed in LDS, then processed by all threads.
 __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int kquarter, const uint16_t *__restrict__ S3,
-                                                       const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim, const uint32_t *__restrict__ segmax) {
+                                                       const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim, const uint32_t *__restrict__ segmax,
+                                                       const uint16_t *__restrict__ heavy) {
   __shared__ uint32_t list[2048];
   __shared__ uint32_t nlist;
   const uint64_t seg = blockIdx.x, base = seg * 32768ull;
@@ -772,14 +784,11 @@ __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int 
   }
   const uint32_t *own = bsc3 + base, *prv = has_prev ? bsc3 + base - 32768 : nullptr;
   const uint16_t *s3 = S3 + base, *p3 = has_prev ? S3 + base - 32768 : nullptr;
-  for (uint32_t h0 = 0; h0 < 32768; h0 += 2048) {        // rounds of 2048 buckets: the list cannot overflow
-    if (tid == 0) nlist = 0;
-    __syncthreads();
-    for (uint32_t h = h0 + tid; h < h0 + 2048; h += 256) {
-      const uint32_t c = own[h] >> 16, cp = prv ? prv[h] >> 16 : 0u;
-      if (c > 0 && c - 1 + cp >= (uint32_t)kquarter) { const uint32_t k = atomicAdd(&nlist, 1u); if (k < 2048) list[k] = h; }
-    }
-    __syncthreads();
+  auto qualifies = [&](uint32_t h) -> bool {
+    const uint32_t c = own[h] >> 16, cp = prv ? prv[h] >> 16 : 0u;
+    return c > 0 && c - 1 + cp >= (uint32_t)kquarter;
+  };
+  auto process = [&]() {                             // the limits of the members of the listed buckets, all threads
     const uint32_t nl = nlist < 2048 ? nlist : 2048;
     for (uint32_t li = 0; li < nl; li++) {
       const uint32_t h = list[li];
@@ -800,6 +809,38 @@ __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int 
         dlim[base + e] = lim[0] | (lim[1] << 16);
       }
     }
+  };
+  // Candidates: a bucket with kquarter members over the two segments has half of them in one of the two, i.e. it is on this
+  // segment's list of heavy buckets or on the previous one's (written by k_prev_links) -- a few dozen look-ups instead of a sweep
+  // over the 2 x 32 768 bucket records.  (Lists that overflowed -- short chains, where nearly every bucket is heavy -- : the sweep.)
+  const uint32_t heavy_thr = kquarter / 2 > 0 ? (uint32_t)kquarter / 2 : 1u;
+  const uint16_t *ho = heavy + seg * HEAVY_STRIDE, *hp = has_prev ? heavy + (seg - 1) * HEAVY_STRIDE : nullptr;
+  const uint32_t no = ho[0], np = hp ? hp[0] : 0u;
+  if (no != 0xFFFFu && np != 0xFFFFu) {
+    for (int phase = 0; phase < 2; phase++) {
+      if (tid == 0) nlist = 0;
+      __syncthreads();
+      const uint16_t *hl = phase == 0 ? ho : hp;
+      const uint32_t nh = phase == 0 ? no : np;
+      for (uint32_t i = tid; i < nh; i += 256) {
+        const uint32_t h = hl[1 + i];
+        if (phase == 1 && (own[h] >> 16) >= heavy_thr) continue;          // (on this segment's own list: done in the first phase)
+        if (qualifies(h)) { const uint32_t k = atomicAdd(&nlist, 1u); if (k < 2048) list[k] = h; }
+      }
+      __syncthreads();
+      process();
+      __syncthreads();
+    }
+    return;
+  }
+  for (uint32_t h0 = 0; h0 < 32768; h0 += 2048) {        // rounds of 2048 buckets: the list cannot overflow
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    for (uint32_t h = h0 + tid; h < h0 + 2048; h += 256) {
+      if (qualifies(h)) { const uint32_t k = atomicAdd(&nlist, 1u); if (k < 2048) list[k] = h; }
+    }
+    __syncthreads();
+    process();
     __syncthreads();
   }
 }
@@ -1712,7 +1753,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     hipEventRecord(c->ev_dlim, c->stream2);
 #endif
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
-                       W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax);
+                       W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy);
 #ifndef ZADA_OLD_INIT
     hipStreamWaitEvent(st, c->ev_dlim, 0);
 #endif
@@ -1726,7 +1767,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl);
       hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl);
     }
-    hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax);
+    hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax, W.heavy);
     {
     }
   }
