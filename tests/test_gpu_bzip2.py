@@ -259,3 +259,35 @@ def test_batch_of_small_entries_is_bit_exact(encoder):
     zc = Z.ZipCreate(encoder, 14)
     zc.add_streams([n for n, _ in entries], [d for _, d in entries])
     assert zc.finish() == oracle_zip(entries, 14)
+
+
+def test_group_lists_of_the_rotation_sort(encoder):
+    """Round 3: the late rounds of the rotation sort run from lists of the unsorted groups (a thread per group of up to 8 rows,
+    sixteen lanes up to 16, a wave up to 64; classes in two arrays that take turns, zada_bz2.hip "Late rounds: group lists").  The
+    knob `bz_lists` moves the round from which sub-blocks may leave the sweeps: whatever it is, the stream is the oracle's -- on
+    periodic data whose period straddles the team sizes (rotations equal to the end: groups that never come apart and go off the
+    lists with h >= n), few-symbol data (groups of every size), repeated chunks (long repeats: pairs that take ten more doublings)
+    and the mix; with and without the two-batch pipeline and the small entropy workgroups."""
+    Z = product()
+    rng = np.random.default_rng(303)
+    mix = Z.silesia_mix(2 << 20)
+    cases = []
+    for per in (1, 2, 7, 8, 9, 16, 17, 64, 65, 1000):
+        pat = bytes(rng.integers(0, 256, per, dtype=np.uint8))
+        n = int(rng.integers(3000, 90000))
+        cases.append((pat * (n // per + 1))[:n])
+    cases.append(bytes(rng.integers(0, 3, 400000, dtype=np.uint8)))
+    chunk = bytes(mix[12345:12345 + 41000])
+    cases.append((chunk * 30)[:1100000])
+    parts = [bytes(mix[int(rng.integers(0, 1 << 20)):][:int(rng.integers(100, 30000))]) for _ in range(12)]
+    cases.append(b"".join(parts + parts[::-1] + parts))
+    cases.append(bytes(mix[:1500000]))
+    want = [oracle_encode(d, 2) for d in cases]
+    try:
+        for lists, pipeline, small_wg in ((64, 1, 1), (8, 1, 1), (1024, 0, 1), (0, 0, 0), (16, 1, 0)):
+            encoder.set_knob("bz_lists", lists); encoder.set_knob("bz_pipeline", pipeline); encoder.set_knob("bz_small_wg", small_wg)
+            for d, (o, ev) in zip(cases, want):
+                rc, p, crc = encoder.bzip2(d, 14, cap=len(d) * 2 + 4096)
+                assert p == o and encoder.bz2_last_blocks() == ev and (crc ^ 0xFFFFFFFF) == zlib.crc32(d), (lists, pipeline, small_wg, len(d))
+    finally:
+        encoder.set_knob("bz_lists", 64); encoder.set_knob("bz_pipeline", 1); encoder.set_knob("bz_small_wg", 1)
