@@ -1,0 +1,41 @@
+"""GPU script (run by tests/test_ranges.py::test_rccl_backend_with_a_world_of_one): the exchanges of the multi-GPU path on torch.distributed's
+"nccl" backend -- RCCL -- with a world of ONE rank, which is all a one-GPU box can hold.  It proves little about xGMI, but it does prove that
+every call the protocol makes (all_gather_object, all_gather of device tensors, the asynchronous gather of the payloads, broadcast_object_list,
+all_reduce, barrier) is accepted by the RCCL backend with the dtypes and devices used, and that one range through TorchComm gives the oracle's stream."""
+import importlib, os, sys, zlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import torch.distributed as dist
+from _common import oracle_deflate
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29611")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+za = importlib.import_module("zip-ada_amd")
+sh = importlib.import_module("zip-ada_amd.sharding")
+enc = za.Encoder(0)
+comm = sh.TorchComm(dev)
+assert comm.all_gather_obj({"atoms": 5, "exit": (1, 2)}) == [{"atoms": 5, "exit": (1, 2)}]
+assert comm.bcast_obj("x", 0) == "x"
+t = torch.arange(1000, dtype=torch.int32, device=dev)
+g = comm.all_gather_dev(t)
+assert len(g) == 1 and bool((g[0] == t).all())
+n = (3 << 20) + 777
+d = za.silesia_mix(n)
+d_in = torch.from_numpy(d).to(dev)
+ranges = sh.stream_ranges(n, 1)
+res = sh.deflate_stream_rank(enc, comm, torch, n, ranges, d_in.data_ptr(), 10,
+                             lambda k: torch.empty(k, dtype=torch.int32, device=dev), lambda k: torch.empty(k, dtype=torch.uint8, device=dev))
+h = sh.gather_payloads_begin(res["payload"], res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
+payloads, _ = h.finish()
+stream = bytes(sh.stitch_stream(torch, payloads, res["spans"], res["total_bits"], dev).cpu().numpy())
+rc, ref, crc = oracle_deflate(d.tobytes(), 10)
+assert rc == 0 and stream == ref and zlib.decompress(stream, -15) == d.tobytes()
+assert sh.stream_crc(enc.crc32_combine, res["infos"]) == crc
+x = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(x, op=dist.ReduceOp.MAX)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl world-of-one ok", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")

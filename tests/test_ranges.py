@@ -253,3 +253,17 @@ def test_spans_on_one_context(encoder):
         assert zf.testzip() is None and zf.read("rnd.bin") == rnd and zf.getinfo("rnd.bin").compress_type == 0
     finally:
         encoder.set_knob("span_mib", 2048)
+
+
+def test_rccl_backend_with_a_world_of_one():
+    """The multi-GPU protocol's calls on torch.distributed's "nccl" backend (= RCCL) with a world of one rank: tests/rccl_world1.py.
+    (Two ranks cannot share a GPU under RCCL, so this is as far as a one-GPU box goes; the protocol with 2 and 3 ranks runs over gloo
+    in tests/test_distributed.py and test_bench_multi_rank_path_on_one_gpu.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_world1.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl world-of-one ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
