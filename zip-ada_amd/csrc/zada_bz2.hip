@@ -2064,27 +2064,25 @@ static int bz_entropy_emit(Ctx *c, Bz2State *B, hipStream_t st, bool marks, int 
   uint32_t nbig = 0;
   while (nbig < nsb && 1 + B->h_n[order[nbig]] / BZ_GROUP > RANK_SMALL_NS) nbig++;       // order: largest first
   const uint32_t nwid = option == 2 ? 2 : 1;
-  if (nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nbig, nwid), dim3(64), rank_lds_big, st, E, 0u);
-  if (nsb > nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nsb - nbig, nwid), dim3(64), rank_lds_small, st, E, nbig);
-  if (marks) c->tmark("bz:rank");
-  {
-    // the sub-blocks of up to 2040 groups (102 000 symbols: most segments of the splitting tactics) go to the small workgroups
-    uint32_t nlarge = 0;
-    while (nlarge < nsb && 1 + B->h_n[order[nlarge]] / BZ_GROUP > EN_SMALL_SEL) nlarge++;       // (an upper bound of the groups: mtf_n <= n + 1)
-    if (c->knob_bz_small_wg == 0) nlarge = nsb;
-    // The two launches share the GPU (the small one on a stream of its own): the long sub-blocks' workgroups run for tens of
-    // milliseconds, and what they leave idle while the last of them finish is taken by the short ones.
-    const bool both = nlarge > 0 && nsb > nlarge;
-    if (both) {
-      if (!B->st_small) { BZ_HIP(hipStreamCreateWithFlags(&B->st_small, hipStreamNonBlocking)); BZ_HIP(hipEventCreateWithFlags(&B->ev_small, hipEventDisableTiming)); }
-      BZ_HIP(hipEventRecord(B->ev_small, st));                                          // (rankings and symbols are in place)
-      BZ_HIP(hipStreamWaitEvent(B->st_small, B->ev_small, 0));
-    }
-    hipStream_t sts = both ? B->st_small : st;
-    if (nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_THREADS, BZ_MAX_SEL>), dim3(nlarge), dim3(EN_THREADS), 0, st, E, nsb, 0u);
-    if (nsb > nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_SMALL_THREADS, (int)EN_SMALL_SEL>), dim3(nsb - nlarge), dim3(EN_SMALL_THREADS), 0, sts, E, nsb, nlarge);
-    if (both) { BZ_HIP(hipEventRecord(B->ev_small, B->st_small)); BZ_HIP(hipStreamWaitEvent(st, B->ev_small, 0)); }
+  // The long sub-blocks (more than 2 040 groups) and the short ones go their own ways from here, each its rankings and then its
+  // entropy search, on two streams: the long ones' rankings are a few hundred single waves of pure latency (a lane replays a heap
+  // sort of up to 18 000 keys), their search workgroups run for tens of milliseconds -- what they leave idle is taken by the short
+  // ones (256-thread workgroups, 30 KB of LDS: five per CU).
+  static_assert(RANK_SMALL_NS == EN_SMALL_SEL, "one split of the sub-blocks for the rankings and the search");
+  const uint32_t nlarge = c->knob_bz_small_wg == 0 ? nsb : nbig;
+  const bool both = nbig > 0 && nsb > nbig && c->knob_bz_small_wg != 0;
+  if (both) {
+    if (!B->st_small) { BZ_HIP(hipStreamCreateWithFlags(&B->st_small, hipStreamNonBlocking)); BZ_HIP(hipEventCreateWithFlags(&B->ev_small, hipEventDisableTiming)); }
+    BZ_HIP(hipEventRecord(B->ev_small, st));                                          // (the symbols are in place)
+    BZ_HIP(hipStreamWaitEvent(B->st_small, B->ev_small, 0));
   }
+  hipStream_t sts = both ? B->st_small : st;
+  if (nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nbig, nwid), dim3(64), rank_lds_big, st, E, 0u);
+  if (nsb > nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nsb - nbig, nwid), dim3(64), rank_lds_small, sts, E, nbig);
+  if (marks) c->tmark("bz:rank");
+  if (nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_THREADS, BZ_MAX_SEL>), dim3(nlarge), dim3(EN_THREADS), 0, st, E, nsb, 0u);
+  if (nsb > nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_SMALL_THREADS, (int)EN_SMALL_SEL>), dim3(nsb - nlarge), dim3(EN_SMALL_THREADS), 0, sts, E, nsb, nlarge);
+  if (both) { BZ_HIP(hipEventRecord(B->ev_small, B->st_small)); BZ_HIP(hipStreamWaitEvent(st, B->ev_small, 0)); }
   hipLaunchKernelGGL(k_bz_block_bits, dim3((nsb + 255) / 256), dim3(256), 0, st, T, B->res.as<uint32_t>());
   if (marks) c->tmark("bz:entropy");
   B->h_res.resize(8ull * nsb); B->h_crc.resize(nsb);
