@@ -685,8 +685,8 @@ __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict
     const uint32_t i = i0 + threadIdx.x;
     uint32_t first = 0, rows = 0;
     if (i < m) {
-      const uint32_t l = t.lo + i, g = off + l, e = sa[g], c = cl[e];
-      cl2[e] = c;
+      const uint32_t l = t.lo + i, g = off + l, c = cl[sa[g]];
+      cl2[g] = cl[g];                                  // (the sub-block's elements are the same index range as its rows: a straight copy)
       if (l + 1 == n || cl[sa[g + 1]] != c) { first = c; rows = g - c + 1; }
     }
     const int kc = gl_class(rows);
@@ -1028,6 +1028,8 @@ struct EntTab {
   uint32_t *res;               // [nsb][8]: coders, max code length, sample width, groups, data bits, selector bits, tree bits, block bits
   uint32_t *deflist;           // [selcap]: the groups that change coder in a round
   const uint32_t *order;       // sub-blocks, largest first: workgroup b takes sub-block order[b] (the long ones must not start last)
+  // the long sub-blocks' search is cut into its four independent chains (max code length x sample width): a workgroup each, results in slots of their own
+  uint8_t *csel; unsigned long long *cgcbest; uint8_t *clens; uint32_t *cres;   // [4][selcap], [4][selcap], [nsb][4][6][260], [nsb][4][8]
   unsigned long long *dbg;     // [nsb][8] clock counts (profiling aid): histogram, code lengths, costs, chain, passes, rounds, constructs, total
   int option;                  // 0 / 1 / 2 = block_100k / 400k / 900k
 };
@@ -1107,7 +1109,7 @@ __device__ __forceinline__ uint32_t mtf_compose(uint32_t A, uint32_t B) {
 // THREADS lanes per sub-block, room for MAXSEL groups: the many short sub-blocks (the segments of the splitting tactics) take a
 // smaller workgroup with less LDS, so that twice as many share a CU -- the search is a chain of short dependent phases, the
 // more sub-blocks in flight the better.  `first`: offset in the (largest-first) order of the sub-blocks.
-template <int THREADS, int MAXSEL>
+template <int THREADS, int MAXSEL, bool SPLIT>
 // (second bound: waves per SIMD that the LDS footprint lets a CU hold -- 3 / 5 / 8 workgroups of 8 / 4 / 2 waves)
 __global__ void __launch_bounds__(THREADS, THREADS >= 512 ? 6 : THREADS >= 256 ? 5 : 4) k_bz_entropy(EntTab E, uint32_t nsb, uint32_t first) {
   constexpr int NW = THREADS / 64, NLL = NW < 6 ? NW : 6;                // waves, and how many of them make code lengths at a time
@@ -1124,7 +1126,17 @@ __global__ void __launch_bounds__(THREADS, THREADS >= 512 ? 6 : THREADS >= 256 ?
   const uint32_t m = E.mtf_n[s], A = E.nsym[s] + 2, ns = 1 + (m - 1) / BZ_GROUP;
   const uint16_t *sym = E.sym + E.soff[s];
   const uint32_t so = E.sel_off[s];
-  unsigned long long *gc = (unsigned long long *)E.gcost + so;
+  // SPLIT: this workgroup runs ONE of the four chains (max code length, sample width) = blockIdx.y of the search, in scratch and result
+  // slots of its own.  The chains do not depend on each other: what a construct hands the next one is `low`, and the first construct of a
+  // chain (six coders) is on every list (:900-925), so it runs whatever `low` says.  k_bz_pick keeps the best chain, the first in the
+  // reference's order among equals (:926-950 compares with "<").
+  const uint32_t chn = SPLIT ? blockIdx.y : 0u;
+  unsigned long long *gc = (unsigned long long *)E.gcost + (size_t)chn * E.selcap + so;
+  uint32_t *deflist = E.deflist + (size_t)chn * E.selcap + so;
+  uint8_t *sel_out = SPLIT ? E.csel + (size_t)chn * E.selcap + so : E.sel + so;
+  unsigned long long *gcbest_out = SPLIT ? E.cgcbest + (size_t)chn * E.selcap + so : E.gcbest + so;
+  uint8_t *lens_out = SPLIT ? E.clens + ((size_t)s * 4 + chn) * 6 * BZ_LSTRIDE : E.lens + (size_t)s * 6 * BZ_LSTRIDE;
+  uint32_t *res_out = SPLIT ? E.cres + ((size_t)s * 4 + chn) * 8 : E.res + (size_t)s * 8;
   const uint32_t G = (((ns + THREADS - 1) / THREADS) + 7) & ~7u;             // groups per thread in the chain: whole words of sel4
   auto sel_get = [&](uint32_t g) -> uint32_t { return (sel4[g >> 3] >> (4 * (g & 7))) & 15u; };
   const uint32_t g0 = min((uint32_t)tid * G, ns), g1 = min(g0 + G, ns);
@@ -1285,7 +1297,7 @@ __global__ void __launch_bounds__(THREADS, THREADS >= 512 ? 6 : THREADS >= 256 ?
       for (uint32_t g = gw; g < gw + 8 && g < g1; g++) {
         const uint32_t q = g - g0, old = sel_get(g);
         const uint32_t nw = (uint32_t)((q < 21 ? nw0 >> (3 * q) : nw1 >> (3 * (q - 21))) & 7u);
-        if (nw != old) E.deflist[so + atomicAdd(&red[2], 1u)] = g | ((old - 1) << 16) | ((nw - 1) << 20);
+        if (nw != old) deflist[atomicAdd(&red[2], 1u)] = g | ((old - 1) << 16) | ((nw - 1) << 20);
         word |= nw << (4 * (g & 7));
       }
       sel4[gw >> 3] = word;
@@ -1293,7 +1305,7 @@ __global__ void __launch_bounds__(THREADS, THREADS >= 512 ? 6 : THREADS >= 256 ?
     __syncthreads();
     const uint32_t ndef = red[2];
     for (uint32_t i = tid; i < ndef; i += THREADS) {                                 // ... they take their counts along, all threads sharing the work
-      const uint32_t v = E.deflist[so + i];
+      const uint32_t v = deflist[i];
       count_group(v & 0xFFFFu, (v >> 16) & 15u, (v >> 20) & 15u);
       atomicOr(&dirty, (1u << ((v >> 16) & 15u)) | (1u << ((v >> 20) & 15u)));
     }
@@ -1370,8 +1382,9 @@ __global__ void __launch_bounds__(THREADS, THREADS >= 512 ? 6 : THREADS >= 256 ?
   bool low = false;
   uint32_t best_cost = 0x7FFFFFFFu;
   int best_ec = 2, best_ml = mcl[0], best_w = 0;
-  for (int a = 0; a < nmcl; a++)
-    for (int b = 0; b < nsw; b++)
+  if (SPLIT && tid == 0) { res_out[4] = 0x7FFFFFFFu; res_out[5] = 0; res_out[6] = 0; }      // (a chain that constructs nothing: never the best)
+  for (int a = SPLIT ? (int)(chn >> 1) : 0; a < (SPLIT ? (int)(chn >> 1) + 1 : nmcl); a++)
+    for (int b = SPLIT ? (int)(chn & 1u) : 0; b < (SPLIT ? (int)(chn & 1u) + 1 : nsw); b++)
       for (int ec = 6; ec >= 2; ec--) {
         bool listed = false;
         for (int q = 0; q < ncc; q++) listed |= cc[q] == ec;
@@ -1380,10 +1393,10 @@ __global__ void __launch_bounds__(THREADS, THREADS >= 512 ? 6 : THREADS >= 256 ?
         const uint32_t cost = k.data + k.selb + k.tree;
         if (cost < best_cost) {      // :926-950; the reference constructs the winner once more at the end (:952-960): same input, same result, so it is kept here
           best_cost = cost; best_ec = ec; best_ml = mcl[a]; best_w = b;
-          for (uint32_t g = tid; g < ns; g += THREADS) { E.sel[so + g] = (uint8_t)sel_get(g); E.gcbest[so + g] = gc[g]; }
-          for (int i = tid; i < 6 * BZ_LSTRIDE; i += THREADS) E.lens[(size_t)s * 6 * BZ_LSTRIDE + i] = (i / BZ_LSTRIDE < ec && (uint32_t)(i % BZ_LSTRIDE) < A) ? lens[i] : 0;
+          for (uint32_t g = tid; g < ns; g += THREADS) { sel_out[g] = (uint8_t)sel_get(g); gcbest_out[g] = gc[g]; }
+          for (int i = tid; i < 6 * BZ_LSTRIDE; i += THREADS) lens_out[i] = (i / BZ_LSTRIDE < ec && (uint32_t)(i % BZ_LSTRIDE) < A) ? lens[i] : 0;
           if (tid == 0) {
-            uint32_t *r = E.res + (size_t)s * 8;
+            uint32_t *r = res_out;
             r[0] = (uint32_t)ec; r[1] = (uint32_t)mcl[a]; r[2] = (uint32_t)(E.option == 2 ? 3 + b : 4); r[3] = ns;
             r[4] = k.data; r[5] = k.selb; r[6] = k.tree; r[7] = 0;
           }
@@ -1391,10 +1404,30 @@ __global__ void __launch_bounds__(THREADS, THREADS >= 512 ? 6 : THREADS >= 256 ?
         }
       }
   (void)best_ec; (void)best_ml; (void)best_w;
-  if (tid == 0) {
+  if (tid == 0 && chn == 0) {
     unsigned long long *d = E.dbg + (size_t)s * 8;
     d[0] = t_hist; d[1] = t_llhc; d[2] = t_cost; d[3] = t_chain; d[4] = n_pass; d[5] = n_round; d[6] = t_begin; d[7] = wall_clock64() - t_begin;
   }
+}
+
+// the best of a long sub-block's four chains (k_bz_entropy<.., true>) becomes its result: the first in the reference's order among equals
+__global__ void __launch_bounds__(256) k_bz_pick(EntTab E) {
+  const uint32_t s = E.order[blockIdx.x];
+  const uint32_t so = E.sel_off[s];
+  const uint32_t *cr = E.cres + (size_t)s * 4 * 8;
+  uint32_t best = 0;
+  unsigned long long bc = ~0ull;
+  for (uint32_t q = 0; q < 4; q++) {
+    const unsigned long long cost = (unsigned long long)cr[q * 8 + 4] + cr[q * 8 + 5] + cr[q * 8 + 6];
+    if (cost < bc) { bc = cost; best = q; }
+  }
+  const uint32_t ns = cr[best * 8 + 3];
+  const uint8_t *cs = E.csel + (size_t)best * E.selcap + so;
+  const unsigned long long *cg = E.cgcbest + (size_t)best * E.selcap + so;
+  for (uint32_t g = threadIdx.x; g < ns; g += 256) { E.sel[so + g] = cs[g]; E.gcbest[so + g] = cg[g]; }
+  const uint8_t *cl = E.clens + ((size_t)s * 4 + best) * 6 * BZ_LSTRIDE;
+  for (int i = threadIdx.x; i < 6 * BZ_LSTRIDE; i += 256) E.lens[(size_t)s * 6 * BZ_LSTRIDE + i] = cl[i];
+  if (threadIdx.x < 8) E.res[(size_t)s * 8 + threadIdx.x] = cr[best * 8 + threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1744,7 +1777,7 @@ struct Bz2State {
   // MTF / symbol space
   DBuf seq, nsym, rec, recbm, reccnt, lists, sym, soff, mtf_n;
   // entropy coders and output
-  DBuf sel_off, rank_idx, gcost, gcbest, sel, lens, res, woff, words, jobs, job_first, outw, dbg, deflist, order;
+  DBuf sel_off, rank_idx, gcost, gcbest, sel, lens, res, woff, words, jobs, job_first, outw, dbg, deflist, order, csel, cgcbest, clens, cres;
   // stream level
   DBuf rs1, epre, bstart, blen, etab, seg_off, seg, seg_cnt, extra;
   bool etab_ready = false;
@@ -1767,7 +1800,7 @@ struct Bz2State {
     return {&raw_start, &raw_len, &off, &n, &inuse, &crc, &bwt_index, &done, &scal, &rtiles, &rtile_first, &rtile_val, &rtile_crc, &rtile_rs,
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
-            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest,
+            &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest, &csel, &cgcbest, &clens, &cres,
             &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_l[0], &gl_l[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt, &gl_tmp};
   }
   // host mirrors of the batch in flight
@@ -2040,9 +2073,10 @@ static int bz_entropy_emit(Ctx *c, Bz2State *B, hipStream_t st, bool marks, int 
   for (uint32_t s = 0; s <= nsb; s++) so[s] = B->h_off[s] / BZ_GROUP + 2 * s;
   const uint32_t selcap = so[nsb] + 8;
   B->selcap = selcap;
-  if ((rc = dbuf_ensure(c, B->sel_off, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->rank_idx, 4ull * selcap)) || (rc = dbuf_ensure(c, B->gcost, 8ull * selcap)) || (rc = dbuf_ensure(c, B->gcbest, 8ull * selcap)) ||
+  if ((rc = dbuf_ensure(c, B->sel_off, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->rank_idx, 4ull * selcap)) || (rc = dbuf_ensure(c, B->gcost, 4 * 8ull * selcap)) || (rc = dbuf_ensure(c, B->gcbest, 8ull * selcap)) ||
+      (rc = dbuf_ensure(c, B->csel, 4ull * selcap)) || (rc = dbuf_ensure(c, B->cgcbest, 4 * 8ull * selcap)) || (rc = dbuf_ensure(c, B->clens, 4ull * 6 * BZ_LSTRIDE * nsb)) || (rc = dbuf_ensure(c, B->cres, 4 * 32ull * nsb)) ||
       (rc = dbuf_ensure(c, B->sel, selcap)) || (rc = dbuf_ensure(c, B->lens, 6ull * BZ_LSTRIDE * nsb)) || (rc = dbuf_ensure(c, B->res, 32ull * nsb)) ||
-      (rc = dbuf_ensure(c, B->woff, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->dbg, 64ull * nsb)) || (rc = dbuf_ensure(c, B->deflist, 4ull * selcap))) return rc;
+      (rc = dbuf_ensure(c, B->woff, 4ull * (nsb + 1))) || (rc = dbuf_ensure(c, B->dbg, 64ull * nsb)) || (rc = dbuf_ensure(c, B->deflist, 4 * 4ull * selcap))) return rc;
   BZ_HIP(hipMemcpyAsync(B->sel_off.p, so.data(), 4ull * (nsb + 1), hipMemcpyHostToDevice, st));
   std::vector<uint32_t> order(nsb);
   for (uint32_t s = 0; s < nsb; s++) order[s] = s;
@@ -2053,6 +2087,7 @@ static int bz_entropy_emit(Ctx *c, Bz2State *B, hipStream_t st, bool marks, int 
   E.sym = B->sym.as<uint16_t>(); E.soff = B->soff.as<uint32_t>(); E.mtf_n = B->mtf_n.as<uint32_t>(); E.nsym = B->nsym.as<uint32_t>();
   E.sel_off = B->sel_off.as<uint32_t>(); E.rank_idx = B->rank_idx.as<uint16_t>(); E.selcap = selcap; E.gcost = B->gcost.as<unsigned long long>(); E.gcbest = B->gcbest.as<unsigned long long>();
   E.sel = B->sel.as<uint8_t>(); E.lens = B->lens.as<uint8_t>(); E.res = B->res.as<uint32_t>(); E.option = option; E.dbg = B->dbg.as<unsigned long long>(); E.deflist = B->deflist.as<uint32_t>(); E.order = B->order.as<uint32_t>();
+  E.csel = B->csel.as<uint8_t>(); E.cgcbest = B->cgcbest.as<unsigned long long>(); E.clens = B->clens.as<uint8_t>(); E.cres = B->cres.as<uint32_t>();
   SubTab T = subtab(B);
   // the rankings are replayed by single lanes: the small ones (most of them) take little LDS, so that many share a CU
   constexpr uint32_t RANK_SMALL_NS = 2040;
@@ -2072,7 +2107,13 @@ static int bz_entropy_emit(Ctx *c, Bz2State *B, hipStream_t st, bool marks, int 
   const uint32_t nlarge = c->knob_bz_small_wg == 0 ? nsb : nbig;
   const bool both = nbig > 0 && nsb > nbig && c->knob_bz_small_wg != 0;
   if (both) {
-    if (!B->st_small) { BZ_HIP(hipStreamCreateWithFlags(&B->st_small, hipStreamNonBlocking)); BZ_HIP(hipEventCreateWithFlags(&B->ev_small, hipEventDisableTiming)); }
+    if (!B->st_small) {
+      // (lowest priority: the short sub-blocks fill what the long ones leave, not the other way round)
+      int least = 0, greatest = 0;
+      BZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      BZ_HIP(hipStreamCreateWithPriority(&B->st_small, hipStreamNonBlocking, least));
+      BZ_HIP(hipEventCreateWithFlags(&B->ev_small, hipEventDisableTiming));
+    }
     BZ_HIP(hipEventRecord(B->ev_small, st));                                          // (the symbols are in place)
     BZ_HIP(hipStreamWaitEvent(B->st_small, B->ev_small, 0));
   }
@@ -2080,8 +2121,14 @@ static int bz_entropy_emit(Ctx *c, Bz2State *B, hipStream_t st, bool marks, int 
   if (nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nbig, nwid), dim3(64), rank_lds_big, st, E, 0u);
   if (nsb > nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nsb - nbig, nwid), dim3(64), rank_lds_small, sts, E, nbig);
   if (marks) c->tmark("bz:rank");
-  if (nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_THREADS, BZ_MAX_SEL>), dim3(nlarge), dim3(EN_THREADS), 0, st, E, nsb, 0u);
-  if (nsb > nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_SMALL_THREADS, (int)EN_SMALL_SEL>), dim3(nsb - nlarge), dim3(EN_SMALL_THREADS), 0, sts, E, nsb, nlarge);
+  // (the long sub-blocks' search as four workgroups, one per chain, when there are four: a 900 k block's search takes 55 ms as one workgroup,
+  // and the launch is not over before the last of them is)
+  const bool split = option == 2 && c->knob_bz_split != 0 && nlarge > 0;
+  if (split) {
+    hipLaunchKernelGGL((k_bz_entropy<EN_THREADS, BZ_MAX_SEL, true>), dim3(nlarge, 4), dim3(EN_THREADS), 0, st, E, nsb, 0u);
+    hipLaunchKernelGGL(k_bz_pick, dim3(nlarge), dim3(256), 0, st, E);
+  } else if (nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_THREADS, BZ_MAX_SEL, false>), dim3(nlarge), dim3(EN_THREADS), 0, st, E, nsb, 0u);
+  if (nsb > nlarge) hipLaunchKernelGGL((k_bz_entropy<EN_SMALL_THREADS, (int)EN_SMALL_SEL, false>), dim3(nsb - nlarge), dim3(EN_SMALL_THREADS), 0, sts, E, nsb, nlarge);
   if (both) { BZ_HIP(hipEventRecord(B->ev_small, B->st_small)); BZ_HIP(hipStreamWaitEvent(st, B->ev_small, 0)); }
   hipLaunchKernelGGL(k_bz_block_bits, dim3((nsb + 255) / 256), dim3(256), 0, st, T, B->res.as<uint32_t>());
   if (marks) c->tmark("bz:entropy");
