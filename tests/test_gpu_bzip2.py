@@ -286,8 +286,9 @@ def test_group_lists_of_the_rotation_sort(encoder):
     try:
         for lists, pipeline, small_wg in ((64, 1, 1), (8, 1, 1), (1024, 0, 1), (0, 0, 0), (16, 1, 0)):
             encoder.set_knob("bz_lists", lists); encoder.set_knob("bz_pipeline", pipeline); encoder.set_knob("bz_small_wg", small_wg)
+            encoder.set_knob("bz_split", small_wg)                        # (the long sub-blocks' search as four workgroups, or as one)
             for d, (o, ev) in zip(cases, want):
                 rc, p, crc = encoder.bzip2(d, 14, cap=len(d) * 2 + 4096)
                 assert p == o and encoder.bz2_last_blocks() == ev and (crc ^ 0xFFFFFFFF) == zlib.crc32(d), (lists, pipeline, small_wg, len(d))
     finally:
-        encoder.set_knob("bz_lists", 64); encoder.set_knob("bz_pipeline", 1); encoder.set_knob("bz_small_wg", 1)
+        encoder.set_knob("bz_lists", 64); encoder.set_knob("bz_pipeline", 1); encoder.set_knob("bz_small_wg", 1); encoder.set_knob("bz_split", 1)
