@@ -1783,7 +1783,7 @@ struct Bz2State {
   bool etab_ready = false;
   Bz2State *slot1 = nullptr;        // the second batch in flight (bz_blocks_encode pipelines the stages of consecutive batches)
   hipStream_t st_pipe = nullptr;    // ... and the stream its entropy stage runs on
-  hipStream_t st_small = nullptr; hipEvent_t ev_small = nullptr;     // the entropy search of the short sub-blocks runs next to the long ones'
+  hipStream_t st_small = nullptr; hipEvent_t ev_small = nullptr, ev_rank = nullptr;     // the entropy search of the short sub-blocks runs next to the long ones'
   std::vector<uint64_t> trace;      // per block: raw start, raw length, tactic kept, its number of sub-blocks
   // the call in flight: every unique piece's bits are kept until the tactics are chosen
   struct KeptSub { uint64_t bits, woff; uint32_t crc, buf; };
@@ -1827,6 +1827,7 @@ static void bz_free_state(Bz2State *B) {
   for (DBuf &b : B->kept_bufs) if (b.p) hipFree(b.p);
   if (B->st_small) { hipStreamSynchronize(B->st_small); hipStreamDestroy(B->st_small); }
   if (B->ev_small) hipEventDestroy(B->ev_small);
+  if (B->ev_rank) hipEventDestroy(B->ev_rank);
   delete B;
 }
 
@@ -2120,6 +2121,13 @@ static int bz_entropy_emit(Ctx *c, Bz2State *B, hipStream_t st, bool marks, int 
   hipStream_t sts = both ? B->st_small : st;
   if (nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nbig, nwid), dim3(64), rank_lds_big, st, E, 0u);
   if (nsb > nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nsb - nbig, nwid), dim3(64), rank_lds_small, sts, E, nbig);
+  if (both) {
+    // (the short sub-blocks' search waits for the long ones' rankings: its workgroups would fill every CU's LDS, and the rankings'
+    // single waves -- 72 KB of LDS each -- would trickle in behind them: 69 ms instead of 20)
+    if (!B->ev_rank) BZ_HIP(hipEventCreateWithFlags(&B->ev_rank, hipEventDisableTiming));
+    BZ_HIP(hipEventRecord(B->ev_rank, st));
+    BZ_HIP(hipStreamWaitEvent(B->st_small, B->ev_rank, 0));
+  }
   if (marks) c->tmark("bz:rank");
   // (the long sub-blocks' search as four workgroups, one per chain, when there are four: a 900 k block's search takes 55 ms as one workgroup,
   // and the launch is not over before the last of them is)
