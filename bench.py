@@ -395,6 +395,12 @@ def launch_ranks(n):
     output (rank 0 prints the JSON line) and returns its exit code."""
     import socket
     import subprocess
+    if os.environ.get("BENCH_EMULATE") != "1":
+        import torch                                  # (counting devices does not initialise the GPU: nothing is forked or replaced afterwards anyway)
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
+            return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
