@@ -1255,7 +1255,14 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       const MatchPair og = M[p];
       const uint32_t idx1 = rp.idx[p], c1 = rp.cnt[p];
       uint32_t t = 0xFFFFu;
-      if (!seg_first) t = tailsK[(seg - 1) * 65536ull + hashL_of(lds_u64_at(win8, wi), 3 + NLEVELS)];
+      if (!seg_first) {
+        // (only the occupied buckets of a tails table are written: an entry is the bucket's tail iff it names an inserted position of
+        // the previous segment that hashes to the bucket -- see k_cross_links; a tail out of reach leaves nothing to scan there)
+        const uint32_t key = hashL_of(lds_u64_at(win8, wi), 3 + NLEVELS);
+        const uint32_t tt = tailsK[(seg - 1) * 65536ull + key];
+        const uint64_t q = pbase + tt;
+        if (tt < lay_inserted(L, seg - 1) && p - q <= (uint64_t)MAX_DIST && hashL_of(lds_u64_at(win8, (uint32_t)(q - WB)), 3 + NLEVELS) == key) t = tt;
+      }
       uint32_t idx2 = 0, c2 = 0;
       if (t != 0xFFFFu) { idx2 = rp.idx[pbase + t]; c2 = (uint32_t)rp.cnt[pbase + t] + 1u; }
       const uint32_t df = dlimv & 0xFFFF, dq = dlimv >> 16;
