@@ -341,3 +341,20 @@ def test_full_size_properties(encoder):
     rc, ref, _ = oracle_deflate(head, 10)
     got, _ = encoder.deflate(head, 10)
     assert rc == 0 and got == ref
+
+
+def test_stale_workspace_between_calls(encoder):
+    """The tails tables of the link stage are not initialised (round 3): only occupied buckets are written, and their consumers
+    (k_cross_links, k_match_demand) tell a tail from what an earlier call left behind by hashing the position an entry names.
+    Different inputs one after the other on ONE context -- every bucket of the second finds the first one's entries where it has
+    none of its own -- each the oracle's stream, for the methods with long and short chains."""
+    rng = np.random.default_rng(77)
+    a = silesia_mix(3 << 20)
+    b = silesia_mix(3 << 20, seed=12345, class_mask=0x1B)
+    cth = bytes((rng.integers(0, 3, 2 << 20) + 65).astype(np.uint8))
+    d = bytes(rng.integers(0, 256, 100000, dtype=np.uint8)) + a[:1 << 20]
+    for method in (10, 8):
+        for x in (a, b, cth, a, d, b[: (1 << 20) + 5], a):
+            rc, ref, crc = oracle_deflate(x, method)
+            rc2, out, crc2 = gpu_deflate(encoder, x, method)
+            assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), (len(x), method)
