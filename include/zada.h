@@ -74,7 +74,7 @@ const char *zada_version(void);
  * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of
  * a stream the match finder takes at a time, multiple of 64), "span_mib" (MiB of a stream one pass takes; longer streams go span after
  * span, default 2048), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
- * batching), "lzma_chunk" (positions of an LZMA stream one launch codes between two feedback calls; 0 = by level, -1 = one launch
+ * batching; "bz_lists", "bz_pipeline", "bz_small_wg", "bz_split", "bz_tail_pct": scheduling of the BZip2 stages), "lzma_chunk" (positions of an LZMA stream one launch codes between two feedback calls; 0 = by level, -1 = one launch
  * per stream).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's
  * dictionary_size for LZMA_3 in bytes (0, the default: the entry's size, as Zip.Compress.LZMA_E passes it; lzma_enc.adb uses 32 KiB). */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
@@ -182,6 +182,8 @@ void zada_silesia_mix(uint64_t seed, unsigned class_mask, uint64_t offset, uint6
  * register, return ZADA_OK / ZADA_INEFFICIENT (stream not smaller than the input: compression_ok := False) / ZADA_ABORTED / < 0.
  * The stream is the complete BZip2 stream ("BZh9" ... footer).  Unlike zada_deflate it is also delivered with
  * ZADA_INEFFICIENT when it fits `cap` (*out_len <= cap), so the entry points serve a stand-alone .bz2 writer (bzip2_enc.adb) too.
+ * A stream that is SMALLER than the input but does not fit `cap` is an error (ZADA_E_INVALID, "output buffer too small"), not
+ * ZADA_INEFFICIENT: cap >= n is always enough for the Zip use (a stream of n bytes or more is inefficient whatever cap is).
  * Streams of any length: the block limits are found a span of the stream at a time (knob "bz_span_mib", default 1024).
  * --------------------------------------------------------------------------------------------------------------- */
 int zada_bzip2(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len,
