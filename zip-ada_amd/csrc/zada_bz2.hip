@@ -617,13 +617,15 @@ __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict
 //  take turns (a round reads one and writes the other, every row of every listed group); a row that comes to stand alone stays on the
 //  list for one more round as a group of one, which writes its (final) class into the other array as well.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr uint32_t GL_MAX = 64, GL_SMALL = 8;
-struct GlEntry { uint32_t first, sb_rows; };           // first row | sub-block << 6 | rows - 1
-__device__ __forceinline__ GlEntry gl_entry(uint32_t first, uint32_t rows, uint32_t sb) { return GlEntry{first, (sb << 6) | (rows - 1u)}; }
-// three lists by group size: up to 8 rows (a thread sorts the group), 9 .. 16 (sixteen lanes), 17 .. 64 (a wave)
+constexpr uint32_t GL_SMALL = 8, GL_WAVE = 64, GL_MAX = 8192;
+constexpr int GL_NCL = 4;                              // lists by group size
+struct GlEntry { uint32_t first, sb_rows; };           // first row | sub-block << 13 | rows - 1
+__device__ __forceinline__ GlEntry gl_entry(uint32_t first, uint32_t rows, uint32_t sb) { return GlEntry{first, (sb << 13) | (rows - 1u)}; }
+__device__ __forceinline__ void gl_unpack(const GlEntry E, uint32_t &first, uint32_t &rows, uint32_t &sb) { first = E.first; rows = (E.sb_rows & 8191u) + 1u; sb = E.sb_rows >> 13; }
+// four lists by group size: up to 8 rows (a thread sorts the group), 9 .. 16 (sixteen lanes), 17 .. 64 (a wave), 65 .. 8 192 (a workgroup, in LDS)
 constexpr uint32_t GL_MID = 16;
-struct GlLists { GlEntry *l[3]; uint32_t *cnt; uint32_t cap[3]; };             // cnt[0 .. 2]: entries of the lists; cnt[3]: overflow flag
-__device__ __forceinline__ int gl_class(uint32_t rows) { return rows <= GL_SMALL ? 0 : rows <= GL_MID ? 1 : 2; }
+struct GlLists { GlEntry *l[GL_NCL]; uint32_t *cnt; uint32_t cap[GL_NCL]; };   // cnt[0 .. 3]: entries of the lists; cnt[4]: overflow flag
+__device__ __forceinline__ int gl_class(uint32_t rows) { return rows <= GL_SMALL ? 0 : rows <= GL_MID ? 1 : rows <= GL_WAVE ? 2 : 3; }
 
 // largest unsorted group of every sub-block that is still swept: a row is its group's last when the next row's class differs
 __global__ void __launch_bounds__(1024) k_bz_gl_max(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles,
@@ -642,40 +644,45 @@ __global__ void __launch_bounds__(1024) k_bz_gl_max(const uint32_t *__restrict__
   for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
   if ((threadIdx.x & 63) == 0 && mx > 1) atomicMax(&submax[t.sb], mx);
 }
-__global__ void k_bz_gl_decide(SubTab T, const uint8_t *__restrict__ done, const uint32_t *__restrict__ submax, uint8_t *__restrict__ lmode) {
+__global__ void k_bz_gl_decide(SubTab T, const uint8_t *__restrict__ done, const uint32_t *__restrict__ submax, uint8_t *__restrict__ lmode, uint32_t gl_max) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < T.nsb) lmode[s] = (!done[s] && submax[s] <= GL_MAX) ? 1 : 0;
+  if (s < T.nsb) lmode[s] = (!done[s] && submax[s] <= gl_max) ? 1 : 0;
 }
 // Room for this thread's entries (cnt[k] of list k): one atomic per WORKGROUP and list (a counter that every wave hits by itself is
 // one address for millions of atomics a round: they queue up at its L2 channel).  Every thread of the workgroup must call it;
-// lds: 3 * waves + 3 words.  Returns the thread's first slot of each list (past the capacity: the overflow flag is set).
-__device__ __forceinline__ void gl_reserve(GlLists L, const uint32_t (&cnt)[3], uint32_t *lds, uint32_t (&slot)[3]) {
+// lds: 4 * waves + 4 words.  Returns the thread's first slot of each list (past the capacity: the overflow flag is set).
+__device__ __forceinline__ void gl_reserve(GlLists L, const uint32_t (&cnt)[GL_NCL], uint32_t *lds, uint32_t (&slot)[GL_NCL]) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  uint32_t sc[3] = {cnt[0], cnt[1], cnt[2]};           // inclusive scans over the wave
+  uint32_t sc[GL_NCL];                                 // inclusive scans over the wave
+#pragma unroll
+  for (int k = 0; k < GL_NCL; k++) sc[k] = cnt[k];
   for (int o = 1; o < 64; o <<= 1) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) { const uint32_t a = __shfl_up(sc[k], o); if (lane >= o) sc[k] += a; }
+    for (int k = 0; k < GL_NCL; k++) { const uint32_t a = __shfl_up(sc[k], o); if (lane >= o) sc[k] += a; }
   }
   __syncthreads();                                     // (the call before has read its bases)
-  if (lane == 63) { lds[3 * w] = sc[0]; lds[3 * w + 1] = sc[1]; lds[3 * w + 2] = sc[2]; }
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < GL_NCL; k++) lds[GL_NCL * w + k] = sc[k];
+  }
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if (threadIdx.x < GL_NCL) {
     const int k = threadIdx.x;
     uint32_t t = 0;
-    for (int q = 0; q < nw; q++) { const uint32_t a = lds[3 * q + k]; lds[3 * q + k] = t; t += a; }
-    lds[3 * nw + k] = t ? atomicAdd(&L.cnt[k], t) : 0u;
+    for (int q = 0; q < nw; q++) { const uint32_t a = lds[GL_NCL * q + k]; lds[GL_NCL * q + k] = t; t += a; }
+    lds[GL_NCL * nw + k] = t ? atomicAdd(&L.cnt[k], t) : 0u;
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    slot[k] = lds[3 * nw + k] + lds[3 * w + k] + sc[k] - cnt[k];
-    if (cnt[k] && slot[k] + cnt[k] > L.cap[k]) L.cnt[3] = 1;
+  for (int k = 0; k < GL_NCL; k++) {
+    slot[k] = lds[GL_NCL * nw + k] + lds[GL_NCL * w + k] + sc[k] - cnt[k];
+    if (cnt[k] && slot[k] + cnt[k] > L.cap[k]) L.cnt[GL_NCL] = 1;
   }
 }
 // the unsorted groups of the sub-blocks that leave the sweeps, listed by their last rows; the second class array gets the classes
 __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, uint32_t *__restrict__ cl2, SubTab T,
                                                       const Tile *__restrict__ tiles, const uint8_t *__restrict__ lmode, GlLists L, uint32_t ntiles_x) {
-  __shared__ uint32_t lds[52];
+  __shared__ uint32_t lds[GL_NCL * 17];
   const uint32_t bx = xcd_tile(ntiles_x);
   if (bx >= ntiles_x) return;
   const Tile t = tiles[bx];
@@ -690,8 +697,8 @@ __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict
       if (l + 1 == n || cl[sa[g + 1]] != c) { first = c; rows = g - c + 1; }
     }
     const int kc = gl_class(rows);
-    const uint32_t cnt[3] = {rows > 1 && kc == 0 ? 1u : 0u, kc == 1 ? 1u : 0u, kc == 2 ? 1u : 0u};
-    uint32_t slot[3];
+    const uint32_t cnt[GL_NCL] = {rows > 1 && kc == 0 ? 1u : 0u, kc == 1 ? 1u : 0u, kc == 2 ? 1u : 0u, kc == 3 ? 1u : 0u};
+    uint32_t slot[GL_NCL];
     gl_reserve(L, cnt, lds, slot);
     if (rows > 1 && slot[kc] < L.cap[kc]) L.l[kc][slot[kc]] = gl_entry(first, rows, t.sb);
   }
@@ -710,10 +717,10 @@ __device__ __forceinline__ void gl_cex(uint32_t &ka, uint32_t &va, uint32_t &kb,
 }
 __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
                                                           const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
-  __shared__ uint32_t lds[16];
+  __shared__ uint32_t lds[GL_NCL * 5];
   const uint32_t count = *cnt_p, gi = blockIdx.x * 256u + threadIdx.x;
   uint32_t first = 0, rows = 0, sb = 0;
-  if (gi < count) { const GlEntry E = list[gi]; first = E.first; rows = (E.sb_rows & 63u) + 1u; sb = E.sb_rows >> 6; }
+  if (gi < count) gl_unpack(list[gi], first, rows, sb);
   uint32_t k[8], v[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) { k[j] = 0xFFFFFFFFu; v[j] = 0xFFFFFFFFu; }
@@ -751,8 +758,8 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restr
       nnew = (uint32_t)__popc(ends);
     }
   }
-  const uint32_t cnt[3] = {nnew, 0u, 0u};
-  uint32_t slot[3];
+  const uint32_t cnt[GL_NCL] = {nnew, 0u, 0u, 0u};
+  uint32_t slot[GL_NCL];
   gl_reserve(next, cnt, lds, slot);
   uint32_t s0 = 0, is = slot[0];
   while (ends) {
@@ -767,12 +774,12 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restr
 template <int TW>
 __global__ void __launch_bounds__(256) k_bz_gl_sort_team(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
                                                          const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
-  __shared__ uint32_t lds[16];
+  __shared__ uint32_t lds[GL_NCL * 5];
   const uint32_t count = *cnt_p;
   const uint32_t team = (blockIdx.x * 256u + threadIdx.x) / TW;
   const int lane = threadIdx.x & 63, tl = lane & (TW - 1), tbase = lane - tl;
   uint32_t first = 0, rows = 0, sb = 0;
-  if (team < count) { const GlEntry E = list[team]; first = E.first; rows = (E.sb_rows & 63u) + 1u; sb = E.sb_rows >> 6; }
+  if (team < count) gl_unpack(list[team], first, rows, sb);
   uint32_t n = 1, off = 0;
   if (rows) { n = T.n[sb]; off = T.off[sb]; }
   const bool live = rows != 0 && h < n;
@@ -810,10 +817,76 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_team(const GlEntry *__restri
     if (head) rows_new = nxt - (uint32_t)tl;
   }
   const int kc = gl_class(rows_new);
-  const uint32_t cnt[3] = {rows_new >= 1 && kc == 0 ? 1u : 0u, kc == 1 ? 1u : 0u, kc == 2 ? 1u : 0u};
-  uint32_t slot[3];
+  const uint32_t cnt[GL_NCL] = {rows_new >= 1 && kc == 0 ? 1u : 0u, kc == 1 ? 1u : 0u, kc == 2 ? 1u : 0u, 0u};
+  uint32_t slot[GL_NCL];
   gl_reserve(next, cnt, lds, slot);
   if (rows_new >= 1 && slot[kc] < next.cap[kc]) next.l[kc][slot[kc]] = gl_entry(first + (uint32_t)tl, rows_new, sb);
+}
+
+// one round of the large groups (65 .. 8 192 rows): a workgroup per group, keys and rows in LDS, a bitonic network over them
+__global__ void __launch_bounds__(256) k_bz_gl_sort_wg(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
+                                                       const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
+  __shared__ uint32_t K[GL_MAX], V[GL_MAX];
+  __shared__ uint32_t lds[GL_NCL * 5];
+  __shared__ uint32_t l17[17];
+  if (blockIdx.x >= *cnt_p) return;
+  uint32_t first, rows, sb;
+  gl_unpack(list[blockIdx.x], first, rows, sb);
+  const uint32_t n = T.n[sb], off = T.off[sb];
+  const int tid = threadIdx.x;
+  if (h >= n) {                                        // (equal rotations: the group goes off the lists, its class in both arrays)
+    for (uint32_t i = tid; i < rows; i += 256) clw[sa[first + i]] = first;
+    return;
+  }
+  uint32_t P = 128;
+  while (P < rows) P <<= 1;
+  for (uint32_t i = tid; i < P; i += 256) {
+    uint32_t k = 0xFFFFFFFFu, v = 0xFFFFFFFFu;
+    if (i < rows) { v = sa[first + i]; uint32_t l = v - off + h; if (l >= n) l -= n; k = clr[off + l]; }
+    K[i] = k; V[i] = v;
+  }
+  __syncthreads();
+  for (uint32_t size = 2; size <= P; size <<= 1)
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t idx = tid; idx < P / 2; idx += 256) {
+        const uint32_t a = 2 * idx - (idx & (stride - 1)), b = a + stride;
+        const uint32_t ka = K[a], kb = K[b], va = V[a], vb = V[b];
+        const bool b_less = kb < ka || (kb == ka && vb < va);
+        if (((a & size) == 0) == b_less) { K[a] = kb; K[b] = ka; V[a] = vb; V[b] = va; }   // ascending stretches keep the smaller one in front, descending ones the larger
+      }
+      __syncthreads();
+    }
+  // the rows in order; a thread takes a stretch of them: where its stretch's first group starts comes from a max-scan over the threads
+  const uint32_t per = (rows + 255) / 256, lo = min((uint32_t)tid * per, rows), hi = min(lo + per, rows);
+  uint32_t last_head = 0;                              // (index + 1 of the last row of the stretch that starts a group, 0: none)
+  for (uint32_t i = lo; i < hi; i++) if (i == 0 || K[i] != K[i - 1]) last_head = i + 1;
+  OpMax mx;
+  const uint32_t incl = wg_scan_incl(last_head, l17, mx, nullptr);
+  uint32_t before = __shfl_up(incl, 1);
+  if ((tid & 63) == 0) { before = 0; for (int q = 0; q < (tid >> 6); q++) before = mx(before, l17[q]); }
+  uint32_t start = before ? before - 1 : 0u;           // the group the stretch's first row belongs to starts here (row 0 starts one)
+  uint32_t cnt[GL_NCL] = {0u, 0u, 0u, 0u};
+  {
+    uint32_t s0 = start;
+    for (uint32_t i = lo; i < hi; i++) {
+      if (i > 0 && K[i] != K[i - 1]) s0 = i;
+      if (i + 1 == rows || K[i + 1] != K[i]) cnt[gl_class(i + 1 - s0)]++;        // a group ends behind row i: listed by the thread that holds its last row
+    }
+  }
+  uint32_t slot[GL_NCL];
+  gl_reserve(next, cnt, lds, slot);
+  for (uint32_t i = lo; i < hi; i++) {
+    if (i > 0 && K[i] != K[i - 1]) start = i;
+    const uint32_t v = V[i];
+    sa[first + i] = v;
+    clw[v] = first + start;
+    if (i + 1 == rows || K[i + 1] != K[i]) {
+      const uint32_t rn = i + 1 - start;
+      const int kc = gl_class(rn);
+      if (slot[kc] < next.cap[kc]) next.l[kc][slot[kc]] = gl_entry(first + start, rn, sb);
+      slot[kc]++;
+    }
+  }
 }
 
 // rows ordered by `prefix` bytes: a sub-block whose rotations are that short is done (equal rotations stay in one group)
@@ -1769,7 +1842,7 @@ struct Bz2State {
   DBuf rtiles, rtile_first, rtile_val, rtile_crc, rtile_rs, etiles, etile_first;
   // element space
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
-  DBuf gl_s[2], gl_m[2], gl_l[2], gl_nc, gl_submax, gl_lmode, gl_cnt, gl_tmp;   // group lists of the late rounds (k_bz_gl_*)
+  DBuf gl_s[2], gl_m[2], gl_l[2], gl_w[2], gl_nc, gl_submax, gl_lmode, gl_cnt, gl_tmp;   // group lists of the late rounds (k_bz_gl_*)
   uint64_t gl_rows = 0;             // groups the lists' rounds of the last batch sorted (profiling aid)
   std::vector<uint32_t> h_cm, h_cfirst;
   std::vector<uint64_t> m_hist;     // rows the doubling rounds of the last batch had to sort (profiling aid)
@@ -1801,7 +1874,7 @@ struct Bz2State {
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
             &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest, &csel, &cgcbest, &clens, &cres,
-            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_l[0], &gl_l[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt, &gl_tmp};
+            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_l[0], &gl_l[1], &gl_w[0], &gl_w[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt, &gl_tmp};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -1949,18 +2022,19 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   uint32_t *nc = nullptr, *submax = nullptr, *glcnt = nullptr;
   uint8_t *lmode = nullptr;
   if (use_lists) {
-    const uint32_t cap_s = (uint32_t)(tot + 64), cap_m = (uint32_t)(tot / (GL_SMALL + 1) + 64), cap_l = (uint32_t)(tot / (GL_MID + 1) + 64);   // (groups of one included: a round lists a row at most once)
+    const uint32_t cap_s = (uint32_t)(tot + 64), cap_m = (uint32_t)(tot / (GL_SMALL + 1) + 64), cap_l = (uint32_t)(tot / (GL_MID + 1) + 64), cap_w = (uint32_t)(tot / (GL_WAVE + 1) + 64);   // (groups of one included: a round lists a row at most once)
     if ((rc = dbuf_ensure(c, B->gl_s[0], sizeof(GlEntry) * (size_t)cap_s)) || (rc = dbuf_ensure(c, B->gl_s[1], sizeof(GlEntry) * (size_t)cap_s)) ||
         (rc = dbuf_ensure(c, B->gl_m[0], sizeof(GlEntry) * (size_t)cap_m)) || (rc = dbuf_ensure(c, B->gl_m[1], sizeof(GlEntry) * (size_t)cap_m)) ||
         (rc = dbuf_ensure(c, B->gl_l[0], sizeof(GlEntry) * (size_t)cap_l)) || (rc = dbuf_ensure(c, B->gl_l[1], sizeof(GlEntry) * (size_t)cap_l)) ||
+        (rc = dbuf_ensure(c, B->gl_w[0], sizeof(GlEntry) * (size_t)cap_w)) || (rc = dbuf_ensure(c, B->gl_w[1], sizeof(GlEntry) * (size_t)cap_w)) ||
         (rc = dbuf_ensure(c, B->gl_nc, 4 * ne)) || (rc = dbuf_ensure(c, B->gl_submax, 4ull * nsb + 64)) || (rc = dbuf_ensure(c, B->gl_lmode, nsb + 64)) ||
         (rc = dbuf_ensure(c, B->gl_cnt, 64))) return rc;
     glcnt = B->gl_cnt.as<uint32_t>();
-    for (int k = 0; k < 2; k++) GL[k] = GlLists{{B->gl_s[k].as<GlEntry>(), B->gl_m[k].as<GlEntry>(), B->gl_l[k].as<GlEntry>()}, glcnt + 4 * k, {cap_s, cap_m, cap_l}};
+    for (int k = 0; k < 2; k++) GL[k] = GlLists{{B->gl_s[k].as<GlEntry>(), B->gl_m[k].as<GlEntry>(), B->gl_l[k].as<GlEntry>(), B->gl_w[k].as<GlEntry>()}, glcnt + 8 * k, {cap_s, cap_m, cap_l, cap_w}};
     nc = B->gl_nc.as<uint32_t>(); submax = B->gl_submax.as<uint32_t>(); lmode = B->gl_lmode.as<uint8_t>();
     BZ_HIP(hipMemsetAsync(glcnt, 0, 64, st));
   }
-  uint32_t gl_n[3] = {0, 0, 0};                                     // entries of the three lists of the generation to sort in this round
+  uint32_t gl_n[GL_NCL] = {0, 0, 0, 0};                             // entries of the lists of the generation to sort in this round
   int gcur = 0;
   bool swept = true;                                                // sub-blocks are still being swept
   B->gl_rows = 0;
@@ -1977,7 +2051,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       nct = (uint32_t)ct.size();
       if (nct == 0) swept = false;
     }
-    if (!swept && gl_n[0] + gl_n[1] + gl_n[2] == 0) break;
+    if (!swept && gl_n[0] + gl_n[1] + gl_n[2] + gl_n[3] == 0) break;
     B->bwt_rounds++;
     if (swept) {
       if ((rc = dbuf_ensure(c, B->ctiles, sizeof(Tile) * (size_t)nct))) return rc;
@@ -2006,22 +2080,23 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       uint32_t *clw = gcur ? cl : nc;
       if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.l[0], cur.cnt + 0, h, valA, clr, clw, T, nxt);
       if (gl_n[1]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_MID>), dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MID + 255) / 256)), dim3(256), 0, st, cur.l[1], cur.cnt + 1, h, valA, clr, clw, T, nxt);
-      if (gl_n[2]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_MAX>), dim3((uint32_t)(((uint64_t)gl_n[2] * GL_MAX + 255) / 256)), dim3(256), 0, st, cur.l[2], cur.cnt + 2, h, valA, clr, clw, T, nxt);
+      if (gl_n[2]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_WAVE>), dim3((uint32_t)(((uint64_t)gl_n[2] * GL_WAVE + 255) / 256)), dim3(256), 0, st, cur.l[2], cur.cnt + 2, h, valA, clr, clw, T, nxt);
+      if (gl_n[3]) hipLaunchKernelGGL(k_bz_gl_sort_wg, dim3(gl_n[3]), dim3(256), 0, st, cur.l[3], cur.cnt + 3, h, valA, clr, clw, T, nxt);
       // sub-blocks whose unsorted groups have all become small leave the sweeps: their groups (classes of 2h bytes) join the lists
       if (swept && 2 * h >= (uint32_t)c->knob_bz_lists) {
         BZ_HIP(hipMemsetAsync(submax, 0, 4ull * nsb, st));
         hipLaunchKernelGGL(k_bz_gl_max, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, cl, T, ET, done, submax, net);
-        hipLaunchKernelGGL(k_bz_gl_decide, dim3((nsb + 255) / 256), dim3(256), 0, st, T, done, submax, lmode);
+        hipLaunchKernelGGL(k_bz_gl_decide, dim3((nsb + 255) / 256), dim3(256), 0, st, T, done, submax, lmode, (uint32_t)(c->knob_bz_list_rows > 0 && c->knob_bz_list_rows <= (int)GL_MAX ? c->knob_bz_list_rows : (int)GL_MAX));
         hipLaunchKernelGGL(k_bz_gl_build, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, cl, nc, T, ET, lmode, nxt, net);
         hipLaunchKernelGGL(k_bz_gl_leave, dim3((nsb + 255) / 256), dim3(256), 0, st, T, lmode, done);
       }
-      uint32_t hc[4] = {0, 0, 0, 0};
-      BZ_HIP(hipMemcpyAsync(hc, nxt.cnt, 16, hipMemcpyDeviceToHost, st));
-      BZ_HIP(hipMemsetAsync(cur.cnt, 0, 16, st));                  // (the generation just sorted is the next one to be filled)
+      uint32_t hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      BZ_HIP(hipMemcpyAsync(hc, nxt.cnt, 32, hipMemcpyDeviceToHost, st));
+      BZ_HIP(hipMemsetAsync(cur.cnt, 0, 32, st));                  // (the generation just sorted is the next one to be filled)
       BZ_HIP(hipStreamSynchronize(st));
-      if (hc[3] || hc[0] > nxt.cap[0] || hc[1] > nxt.cap[1] || hc[2] > nxt.cap[2]) { c->err = "bzip2: group list overflow"; return ZADA_E_HIP; }
-      B->gl_rows += (uint64_t)gl_n[0] + gl_n[1] + gl_n[2];
-      gl_n[0] = hc[0]; gl_n[1] = hc[1]; gl_n[2] = hc[2];
+      if (hc[GL_NCL] || hc[0] > nxt.cap[0] || hc[1] > nxt.cap[1] || hc[2] > nxt.cap[2] || hc[3] > nxt.cap[3]) { c->err = "bzip2: group list overflow"; return ZADA_E_HIP; }
+      B->gl_rows += (uint64_t)gl_n[0] + gl_n[1] + gl_n[2] + gl_n[3];
+      for (int k = 0; k < GL_NCL; k++) gl_n[k] = hc[k];
       gcur ^= 1;
     }
   }

@@ -269,6 +269,7 @@ struct Ctx {
   int knob_bz_lists = 64;           // BZip2 rotation sort: from this prefix length on, sub-blocks whose unsorted groups have at most 64 rows leave the
                                     // full sweeps for per-group sorts driven by a list (0 = never: every round sweeps)
   int knob_bz_pipeline = 1;         // BZip2: the transforms of a batch of sub-blocks run next to the entropy stage of the batch before (0: one batch at a time)
+  int knob_bz_list_rows = 0;        // BZip2: a sub-block leaves the sweeps when its unsorted groups have at most this many rows (0 = 8 192, the most a workgroup sorts)
   int knob_bz_split = 1;            // BZip2 entropy search: the long sub-blocks' four chains on four workgroups (0: one workgroup per sub-block)
   int knob_bz_small_wg = 1;         // BZip2 entropy search: short sub-blocks on small workgroups (0: every sub-block on the large ones)
   int knob_lzma_dict = 0;           // LZMA_3: dictionary_size in bytes instead of the entry's size (0 = the entry's size, as Zip.Compress.LZMA_E asks;
