@@ -263,7 +263,7 @@ def test_batch_of_small_entries_is_bit_exact(encoder):
 
 def test_group_lists_of_the_rotation_sort(encoder):
     """Round 3: the late rounds of the rotation sort run from lists of the unsorted groups (a thread per group of up to 8 rows,
-    sixteen lanes up to 16, a wave up to 64; classes in two arrays that take turns, zada_bz2.hip "Late rounds: group lists").  The
+    sixteen lanes up to 16, a wave up to 64, a workgroup up to 8 192; classes in two arrays that take turns, zada_bz2.hip "Late rounds: group lists").  The
     knob `bz_lists` moves the round from which sub-blocks may leave the sweeps: whatever it is, the stream is the oracle's -- on
     periodic data whose period straddles the team sizes (rotations equal to the end: groups that never come apart and go off the
     lists with h >= n), few-symbol data (groups of every size), repeated chunks (long repeats: pairs that take ten more doublings)
@@ -284,11 +284,13 @@ def test_group_lists_of_the_rotation_sort(encoder):
     cases.append(bytes(mix[:1500000]))
     want = [oracle_encode(d, 2) for d in cases]
     try:
-        for lists, pipeline, small_wg in ((64, 1, 1), (8, 1, 1), (1024, 0, 1), (0, 0, 0), (16, 1, 0)):
+        for lists, pipeline, small_wg, list_rows in ((16, 1, 1, 0), (8, 1, 1, 0), (1024, 0, 1, 0), (0, 0, 0, 0), (16, 1, 0, 64), (8, 0, 1, 300), (64, 1, 1, 8)):
             encoder.set_knob("bz_lists", lists); encoder.set_knob("bz_pipeline", pipeline); encoder.set_knob("bz_small_wg", small_wg)
+            encoder.set_knob("bz_list_rows", list_rows)                   # (largest group a listed sub-block may have: 0 = 8 192, a workgroup's sort)
             encoder.set_knob("bz_split", small_wg)                        # (the long sub-blocks' search as four workgroups, or as one)
             for d, (o, ev) in zip(cases, want):
                 rc, p, crc = encoder.bzip2(d, 14, cap=len(d) * 2 + 4096)
-                assert p == o and encoder.bz2_last_blocks() == ev and (crc ^ 0xFFFFFFFF) == zlib.crc32(d), (lists, pipeline, small_wg, len(d))
+                assert p == o and encoder.bz2_last_blocks() == ev and (crc ^ 0xFFFFFFFF) == zlib.crc32(d), (lists, pipeline, small_wg, list_rows, len(d))
     finally:
-        encoder.set_knob("bz_lists", 64); encoder.set_knob("bz_pipeline", 1); encoder.set_knob("bz_small_wg", 1); encoder.set_knob("bz_split", 1)
+        encoder.set_knob("bz_lists", 16); encoder.set_knob("bz_pipeline", 1); encoder.set_knob("bz_small_wg", 1); encoder.set_knob("bz_split", 1)
+        encoder.set_knob("bz_list_rows", 0)
