@@ -493,6 +493,10 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       for (int cur = 0;; cur ^= 1) {
         const uint32_t nq = qn[cur] < QCAP ? qn[cur] : QCAP;
         if (nq == 0) break;
+#ifdef ZADA_PL_STATS
+        if (tid == 0 && lvl == 1) { atomicAdd(&dbg[24], 1ull); atomicAdd(&dbg[25], (unsigned long long)nq); if (nq <= 1024) atomicAdd(&dbg[26], (unsigned long long)nq); if (cur == 0 && qn[0] > QCAP) atomicAdd(&dbg[30], (unsigned long long)(qn[0] - QCAP)); }
+        unsigned long long tq0 = clock64();
+#endif
         __syncthreads();
         if (tid == 0) qn[cur ^ 1] = 0;
         __syncthreads();
@@ -548,11 +552,20 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           if (idx < nq) {
             const uint32_t ent = (cur ? Qb : Qa)[idx];
             e = ent & 0x7FFFu; q = ent >> 16;
+#ifdef ZADA_PL_STATS
+            const uint32_t q_in = q; uint32_t hops = 0;
+            if (lvl == 1) { uint32_t qq = q, stp = P[qq]; while (stp != 0 && e - (qq - stp) <= (uint32_t)MAX_DIST) { qq -= stp; hops++; if ((lb8(qq) & lmask) == (lb8(e) & lmask)) break; stp = P[qq]; } atomicAdd(&dbg[27], (unsigned long long)hops); atomicMax(&dbg[28], (unsigned long long)hops); if (hops > 64) atomicAdd(&dbg[29], 1ull); }
+            (void)q_in;
+#endif
             pend = !walk(e, q, lb8(e) & lmask, maxs, dl);
             if (!pend) plane[e] = (uint16_t)dl;
           }
           push(pend, e | (q << 16), cur ? Qa : Qb, &qn[cur ^ 1]);
         }
+#ifdef ZADA_PL_STATS
+        __syncthreads();
+        if (tid == 0 && lvl == 1) atomicAdd(&dbg[31], clock64() - tq0);
+#endif
         }
         __syncthreads();
       }
@@ -1765,7 +1778,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     hipStreamWaitEvent(st, c->ev_dlim, 0);
 #endif
 #ifdef ZADA_PL_STATS
-    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); hipMemset(W.dbg, 0, 256);
+    { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); fprintf(stderr, "[level 4 walks per segment] rounds %.2f  entries %.1f  entries of the last round %.1f  hops there %.1f (max %llu over all segments; walks over 64 hops %.3f)  first-queue overflow %.1f  cycles of the last round %.0f\n", (double)h[24] / nseg, (double)h[25] / nseg, (double)h[26] / nseg, (double)h[27] / nseg, h[28], (double)h[29] / nseg, (double)h[30] / nseg, (double)h[31] / nseg); hipMemset(W.dbg, 0, 256);
       unsigned long long sd[8]; hipMemcpyFromSymbol(sd, HIP_SYMBOL(g_sort_dbg), sizeof sd); fprintf(stderr, "[sort_pass cycles/segment, all six passes] clear %.0f  rank (LDS atomics) %.0f  scan %.0f  scatter %.0f\n", (double)sd[0] / nseg, (double)sd[1] / nseg, (double)sd[2] / nseg, (double)sd[3] / nseg); for (int q = 0; q < 8; q++) sd[q] = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_sort_dbg), sd, sizeof sd); }
 #endif
     c->tmark("prev_links");
