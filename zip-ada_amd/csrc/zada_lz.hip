@@ -193,6 +193,13 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
 // markers in the level-3 plane for k_cross_dist: the search goes on in the previous segment (p has / has no earlier position
 // with its 15-bit hash in its own segment); only the head of the chain at exactly MAX_DIST is left to check
 constexpr uint32_t DIST3_CONTINUE = 0xFFFF, DIST3_HEADCHK = 0xFFFE, DIST3_CONT_FIRST = 0xFFFD, DISTL_CONTINUE = 0x8000;
+// levels >= 4: the walk inside the segment was given up after WALK_CAP candidates (a position whose bucket is full of another
+// string: one or two per segment, and the whole workgroup waited for them); k_cross_dist walks it, next to thousands of others
+#ifndef ZADA_WALK_CAP
+#define ZADA_WALK_CAP 16
+#endif
+constexpr uint32_t DISTL_GAVEUP = 0x7FFF, WALK_CAP = ZADA_WALK_CAP;
+static_assert(MAX_DIST < 0x7FFF, "the give-up marker is no distance");
 constexpr uint32_t HEAVY_STRIDE = 2048, HEAVY_CAP = HEAVY_STRIDE - 1;       // per segment: the list of its heavy 15-bit buckets
 static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, Layout L, int kfull, int kquarter,
@@ -456,6 +463,10 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         if (pend && idx < QCAP) { dstq[idx] = entry; return true; }
         return !pend;
       };
+      // a walk is followed to its end -- or, where k_cross_dist comes by afterwards (levels >= 4, not an entry's first segment), as far
+      // as WALK_CAP candidates beyond the rounds of eight below
+      const bool capped = lvl > 0 && !first_seg && WALK_CAP > 0;
+      const uint32_t maxs_last = capped ? WALK_CAP : 1u << 30;
       for (uint32_t e0 = 0; e0 < m; e0 += 4096) {                   // first candidate of every position, four positions per lane at a time
         uint32_t ee[4], st[4];
         uint64_t mn[4], th[4];
@@ -484,7 +495,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
               else pend = true;
             }
           }
-          if (!push(pend, e | (q << 16), Qa, &qn[0])) { walk(e, q, mn[j], 1u << 30, dl); pend = false; }
+          if (!push(pend, e | (q << 16), Qa, &qn[0])) { if (!walk(e, q, mn[j], maxs_last, dl)) dl = DISTL_GAVEUP; pend = false; }   // (queue full)
           if (ex[j] && !pend) plane[e] = (uint16_t)dl;
         }
       }
@@ -544,7 +555,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
             push(val[j] && act[j], e4[j] | (q4[j] << 16), cur ? Qa : Qb, &qn[cur ^ 1]);
           }
         } else {
-        const uint32_t maxs = 1u << 30;
+        const uint32_t maxs = maxs_last;                             // the last round
         for (uint32_t i0q = 0; i0q < nq; i0q += 1024) {
           const uint32_t idx = i0q + tid;
           bool pend = false;
@@ -558,6 +569,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
             (void)q_in;
 #endif
             pend = !walk(e, q, lb8(e) & lmask, maxs, dl);
+            if (pend && capped) { dl = DISTL_GAVEUP; pend = false; }
             if (!pend) plane[e] = (uint16_t)dl;
           }
           push(pend, e | (q << 16), cur ? Qa : Qb, &qn[cur ^ 1]);
@@ -695,7 +707,7 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
   const uint32_t far24 = (d3_stored == DIST3_HEADCHK || d3_stored == DIST3_CONT_FIRST) ? *(const u32u *)(in + p - (uint64_t)MAX_DIST) & 0xFFFFFFu : 0xFFFFFFFFu;
   bool need = d3_stored >= DIST3_CONT_FIRST;
 #pragma unroll
-  for (int l = 0; l + 1 < NLEVELS; l++) need = need || (dl_first[l] & DISTL_CONTINUE);
+  for (int l = 0; l + 1 < NLEVELS; l++) need = need || (dl_first[l] & DISTL_CONTINUE) || dl_first[l] == DISTL_GAVEUP;
   if (!need) return;
   // level 3 first: the previous segment's bucket of the 15-bit hash, newest first, as far back as TOO_FAR (see k_prev_links)
   uint32_t dprev = d3_stored >= DIST3_CONT_FIRST ? 0u : d3_stored;
@@ -753,9 +765,10 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 #pragma unroll
   for (int l = 0; l + 1 < NLEVELS; l++) {
     uint32_t dl = dl_first[l];
-    if (dl & DISTL_CONTINUE) {
+    if ((dl & DISTL_CONTINUE) || dl == DISTL_GAVEUP) {
       // the chain of p's bucket ended, inside p's segment, at q0 (the bucket's first member there): go on from its link
-      uint64_t q = p - (dl & 0x7FFFu);
+      // (a walk k_prev_links gave up: from p itself)
+      uint64_t q = dl == DISTL_GAVEUP ? p : p - (dl & 0x7FFFu);
       dl = 0;
       {
         const uint64_t mask = (1ull << (8 * (4 + l))) - 1ull;
