@@ -1123,33 +1123,51 @@ __global__ void __launch_bounds__(64) k_bz_rank(EntTab E, uint32_t first) {
     P[g + 1] = (key << 16) | (g + 1);
   }
   wave_sync();
-  if (lane == 0) {
+  {
+    // GNAT's heap sort (a-cgcaso.adb: the hole sinks to a leaf along the larger sons -- the left one on a tie --, then the saved
+    // element rises from there), replayed by the WAVE: the sort is one chain of dependent reads, ~14 levels deep per sift with
+    // one lane at work; here 63 lanes read the son pairs of the six levels under the hole at once, the path through them is a
+    // scalar walk over two ballots, the lanes on the path move their chosen son up with one write, and the rise reads all the
+    // fathers at once: three round trips per sift instead of fourteen and more.  Same moves, same array after every sift.
     int Max = (int)ns;
-    uint32_t t;
-    auto sift = [&](int S) {
+    const int rel = lane + 1, dl = 31 - __clz(rel), jl = rel - (1 << dl);      // this lane's node of the subtree under the hole
+    auto sift = [&](const int S, const uint32_t t) {
       int C = S;
       for (;;) {
-        int Son = 2 * C;
-        if (Son > Max) break;
-        const uint2 two = *(const uint2 *)&P[Son];
-        uint32_t v = two.x;
-        if (Son < Max && (two.x >> 16) < (two.y >> 16)) { Son++; v = two.y; }
-        P[C] = v;
-        C = Son;
+        const int node = (C << dl) + jl, son = 2 * node;
+        const bool has = lane < 63 && son <= Max;
+        uint2 two = make_uint2(0u, 0u);
+        if (has) two = *(const uint2 *)&P[son];
+        const bool right = has && son < Max && (two.x >> 16) < (two.y >> 16);
+        const unsigned long long hm = __ballot(has), rm = __ballot(right);
+        int r = 1;
+        unsigned long long pm = 0;
+        for (int k = 0; k < 6; k++) {
+          if (!((hm >> (r - 1)) & 1ull)) break;
+          pm |= 1ull << (r - 1);
+          r = 2 * r + (int)((rm >> (r - 1)) & 1ull);
+        }
+        if ((pm >> lane) & 1ull) P[node] = right ? two.y : two.x;
+        const int dr = 31 - __clz(r);
+        C = (C << dr) + (r - (1 << dr));
+        if (dr < 6) break;
       }
-      while (C != S) {
-        const int F = C / 2;
-        const uint32_t f = P[F];
-        if ((f >> 16) < (t >> 16)) { P[C] = f; C = F; } else break;
-      }
-      P[C] = t;
+      // the rise: the fathers of C up to S, all at once
+      const int nf = __clz(S) - __clz(C);
+      uint32_t f = 0;
+      if (lane < nf) f = P[C >> (lane + 1)];
+      const unsigned long long um = __ballot(lane < nf && (f >> 16) < (t >> 16));
+      const int u = (int)__builtin_ctzll(~um);
+      if (lane < u) P[C >> lane] = f;
+      if (lane == 0) P[C >> u] = t;
     };
-    for (int J = Max / 2; J >= 1; J--) { t = P[J]; sift(J); }
+    for (int J = Max / 2; J >= 1; J--) { const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)P[J]); sift(J, t); }
     while (Max > 1) {
-      t = P[Max];
-      P[Max] = P[1];
+      const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)P[Max]);
+      const uint32_t top = P[1];
+      if (lane == 0) P[Max] = top;
       Max--;
-      sift(1);
+      sift(1, t);
     }
   }
   wave_sync();
