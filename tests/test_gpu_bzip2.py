@@ -284,13 +284,15 @@ def test_group_lists_of_the_rotation_sort(encoder):
     cases.append(bytes(mix[:1500000]))
     want = [oracle_encode(d, 2) for d in cases]
     try:
-        for lists, pipeline, small_wg, list_rows in ((16, 1, 1, 0), (8, 1, 1, 0), (1024, 0, 1, 0), (0, 0, 0, 0), (16, 1, 0, 64), (8, 0, 1, 300), (64, 1, 1, 8)):
+        for lists, pipeline, small_wg, list_rows, text_order in ((16, 1, 1, 0, 1), (8, 1, 1, 0, 0), (1024, 0, 1, 0, 1), (0, 0, 0, 0, 1), (16, 1, 0, 64, 1), (8, 0, 1, 300, 1),
+                                                                  (64, 1, 1, 8, 0), (16, 0, 1, 0, 0)):
             encoder.set_knob("bz_lists", lists); encoder.set_knob("bz_pipeline", pipeline); encoder.set_knob("bz_small_wg", small_wg)
             encoder.set_knob("bz_list_rows", list_rows)                   # (largest group a listed sub-block may have: 0 = 8 192, a workgroup's sort)
+            encoder.set_knob("bz_text_order", text_order)                 # (the thread-per-group list in the order of the text, or of the sorted rows)
             encoder.set_knob("bz_split", small_wg)                        # (the long sub-blocks' search as four workgroups, or as one)
             for d, (o, ev) in zip(cases, want):
                 rc, p, crc = encoder.bzip2(d, 14, cap=len(d) * 2 + 4096)
-                assert p == o and encoder.bz2_last_blocks() == ev and (crc ^ 0xFFFFFFFF) == zlib.crc32(d), (lists, pipeline, small_wg, list_rows, len(d))
+                assert p == o and encoder.bz2_last_blocks() == ev and (crc ^ 0xFFFFFFFF) == zlib.crc32(d), (lists, pipeline, small_wg, list_rows, text_order, len(d))
     finally:
         encoder.set_knob("bz_lists", 16); encoder.set_knob("bz_pipeline", 1); encoder.set_knob("bz_small_wg", 1); encoder.set_knob("bz_split", 1)
-        encoder.set_knob("bz_list_rows", 0)
+        encoder.set_knob("bz_list_rows", 0); encoder.set_knob("bz_text_order", 1)

@@ -897,6 +897,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "bz_span_mib")) { if (value < 24 || value > 3072) return ZADA_E_INVALID; z->c.knob_bz_span_mib = value; }
   else if (!strcmp(name, "bz_batch_melems")) { if (value < 1 || value > 1536) return ZADA_E_INVALID; z->c.knob_bz_batch_melems = value; }
   else if (!strcmp(name, "bz_tail_pct")) z->c.knob_bz_tail_pct = value;
+  else if (!strcmp(name, "bz_text_order")) z->c.knob_bz_text_order = value;
   else if (!strcmp(name, "bz_pipeline")) z->c.knob_bz_pipeline = value;
   else if (!strcmp(name, "bz_list_rows")) { if (value < 0 || value > 8192) return ZADA_E_INVALID; z->c.knob_bz_list_rows = value; }
   else if (!strcmp(name, "bz_split")) z->c.knob_bz_split = value;

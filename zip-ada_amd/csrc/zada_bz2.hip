@@ -624,9 +624,22 @@ __device__ __forceinline__ GlEntry gl_entry(uint32_t first, uint32_t rows, uint3
 __device__ __forceinline__ void gl_unpack(const GlEntry E, uint32_t &first, uint32_t &rows, uint32_t &sb) { first = E.first; rows = (E.sb_rows & 8191u) + 1u; sb = E.sb_rows >> 13; }
 // four lists by group size: up to 8 rows (a thread sorts the group), 9 .. 16 (sixteen lanes), 17 .. 64 (a wave), 65 .. 8 192 (a workgroup, in LDS)
 constexpr uint32_t GL_MID = 16;
-struct GlLists { GlEntry *l[GL_NCL]; uint32_t *cnt; uint32_t cap[GL_NCL]; };   // cnt[0 .. 3]: entries of the lists; cnt[4]: overflow flag
+struct GlLists { GlEntry *l[GL_NCL]; uint32_t *cnt; uint32_t cap[GL_NCL]; };
+int gl_sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
+                  const unsigned long long *vals_in, unsigned long long *vals_out, size_t n, unsigned begin_bit, unsigned end_bit);   // zada_glsort.hip   // cnt[0 .. 3]: entries of the lists; cnt[4]: overflow flag
 __device__ __forceinline__ int gl_class(uint32_t rows) { return rows <= GL_SMALL ? 0 : rows <= GL_MID ? 1 : rows <= GL_WAVE ? 2 : 3; }
 
+// Text order.  k_bz_gl_build lists the groups in the order of the sorted rotations, where the rows of neighbouring groups lie side by side
+// and everything else a round touches -- the classes of the rows' second halves, the classes it writes -- is scattered: four or five 64-byte
+// sectors for the 16 bytes a pair needs.  Data with long repeats (what is left for the lists: the same two, three stretches of text, row
+// by row) has the opposite order to offer: the groups {a+j, b+j}, j = 0, 1, 2 ... read classes at a+j+h and b+j+h and write them at a+j and
+// b+j.  Listed by the position of their first row, neighbouring threads share those sectors and only the group's rows themselves are a
+// gather.  The key is that position; one stable radix sort of the (key, entry) pairs when a list has been built (gl_sort_pairs,
+// zada_glsort.hip); the rounds keep the order workgroup by workgroup.
+__global__ void k_bz_gl_keys(const GlEntry *__restrict__ list, uint32_t n, const uint32_t *__restrict__ sa, uint32_t *__restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = sa[list[i].first];
+}
 // largest unsorted group of every sub-block that is still swept: a row is its group's last when the next row's class differs
 __global__ void __launch_bounds__(1024) k_bz_gl_max(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles,
                                                     const uint8_t *__restrict__ done, uint32_t *__restrict__ submax, uint32_t ntiles_x) {
@@ -710,10 +723,11 @@ __global__ void k_bz_gl_leave(SubTab T, const uint8_t *__restrict__ lmode, uint8
 // One round of the small groups (1 .. 8 rows): a THREAD per group -- most groups of the late rounds are pairs, a team of lanes would
 // idle -- with the group's rows and keys in registers and a sorting network over them.  clr: the classes of the round before; clw: the
 // other array, which gets the class of every row of the group.
-__device__ __forceinline__ void gl_cex(uint32_t &ka, uint32_t &va, uint32_t &kb, uint32_t &vb) {
+__device__ __forceinline__ bool gl_cex(uint32_t &ka, uint32_t &va, uint32_t &kb, uint32_t &vb) {
   const bool sw = kb < ka || (kb == ka && vb < va);
   const uint32_t k0 = sw ? kb : ka, v0 = sw ? vb : va, k1 = sw ? ka : kb, v1 = sw ? va : vb;
   ka = k0; va = v0; kb = k1; vb = v1;
+  return sw;
 }
 __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
                                                           const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
@@ -737,10 +751,11 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restr
     } else {
 #pragma unroll
       for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) { uint32_t l = v[j] - off + h; if (l >= n) l -= n; k[j] = clr[off + l]; }
-      if (rows == 2) gl_cex(k[0], v[0], k[1], v[1]);
+      bool moved = false;                              // (rows that stay where they are are not written back: in text order that write is the gather)
+      if (rows == 2) moved = gl_cex(k[0], v[0], k[1], v[1]);
       else {
         // 19 compare-exchanges sort eight (the empty places hold the largest key and stay behind)
-#define CX(a, b) gl_cex(k[a], v[a], k[b], v[b])
+#define CX(a, b) moved |= gl_cex(k[a], v[a], k[b], v[b])
         CX(0, 1); CX(2, 3); CX(4, 5); CX(6, 7); CX(0, 2); CX(1, 3); CX(4, 6); CX(5, 7); CX(1, 2); CX(5, 6); CX(0, 4); CX(3, 7); CX(1, 5); CX(2, 6); CX(1, 4); CX(3, 6); CX(2, 4); CX(3, 5); CX(3, 4);
 #undef CX
       }
@@ -750,7 +765,7 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restr
       for (int j = 0; j < 8; j++) {
         if ((uint32_t)j < rows) {
           if (j > 0 && k[j] != k[j - 1]) { start = (uint32_t)j; ends |= 1u << (j - 1); }
-          sa[first + j] = v[j];
+          if (moved) sa[first + j] = v[j];
           clw[v[j]] = first + start;
         }
       }
@@ -1860,8 +1875,9 @@ struct Bz2State {
   DBuf rtiles, rtile_first, rtile_val, rtile_crc, rtile_rs, etiles, etile_first;
   // element space
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
-  DBuf gl_s[2], gl_m[2], gl_l[2], gl_w[2], gl_nc, gl_submax, gl_lmode, gl_cnt, gl_tmp;   // group lists of the late rounds (k_bz_gl_*)
+  DBuf gl_s[2], gl_m[2], gl_l[2], gl_w[2], gl_nc, gl_submax, gl_lmode, gl_cnt, gl_tmp, gl_k0, gl_k1, gl_v, gl_st;   // group lists of the late rounds (k_bz_gl_*)
   uint64_t gl_rows = 0;             // groups the lists' rounds of the last batch sorted (profiling aid)
+  size_t gl_st_bytes = 0;            // temporary storage of gl_sort_pairs
   std::vector<uint32_t> h_cm, h_cfirst;
   std::vector<uint64_t> m_hist;     // rows the doubling rounds of the last batch had to sort (profiling aid)
   std::vector<Tile> h_ct;
@@ -1892,7 +1908,7 @@ struct Bz2State {
             &etiles, &etile_first, &rle, &bwt, &keyA, &keyB, &valA, &valB, &cl, &hv, &hr, &H, &agg, &cv0, &cv1, &acte, &coff, &cm, &ctiles, &ctile_first, &seq, &nsym, &rec, &recbm, &reccnt, &lists,
             &sym, &soff, &mtf_n, &sel_off, &rank_idx, &gcost, &sel, &lens, &res, &woff, &words, &jobs, &job_first, &outw,
             &rs1, &epre, &bstart, &blen, &etab, &seg_off, &seg, &seg_cnt, &extra, &dbg, &deflist, &order, &gcbest, &csel, &cgcbest, &clens, &cres,
-            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_l[0], &gl_l[1], &gl_w[0], &gl_w[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt, &gl_tmp};
+            &gl_s[0], &gl_s[1], &gl_m[0], &gl_m[1], &gl_l[0], &gl_l[1], &gl_w[0], &gl_w[1], &gl_nc, &gl_submax, &gl_lmode, &gl_cnt, &gl_tmp, &gl_k0, &gl_k1, &gl_v, &gl_st};
   }
   // host mirrors of the batch in flight
   std::vector<uint64_t> h_raw_start;
@@ -2047,6 +2063,13 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
         (rc = dbuf_ensure(c, B->gl_w[0], sizeof(GlEntry) * (size_t)cap_w)) || (rc = dbuf_ensure(c, B->gl_w[1], sizeof(GlEntry) * (size_t)cap_w)) ||
         (rc = dbuf_ensure(c, B->gl_nc, 4 * ne)) || (rc = dbuf_ensure(c, B->gl_submax, 4ull * nsb + 64)) || (rc = dbuf_ensure(c, B->gl_lmode, nsb + 64)) ||
         (rc = dbuf_ensure(c, B->gl_cnt, 64))) return rc;
+    if (c->knob_bz_text_order) {
+      size_t tb = 0;
+      if (gl_sort_pairs(st, nullptr, tb, nullptr, nullptr, nullptr, nullptr, cap_s, 8, 30)) { c->err = "bzip2: list sort (size query)"; return ZADA_E_HIP; }
+      if ((rc = dbuf_ensure(c, B->gl_k0, 4ull * cap_s)) || (rc = dbuf_ensure(c, B->gl_k1, 4ull * cap_s)) || (rc = dbuf_ensure(c, B->gl_v, sizeof(GlEntry) * (size_t)cap_s)) ||
+          (rc = dbuf_ensure(c, B->gl_st, tb + 256))) return rc;
+      B->gl_st_bytes = tb;
+    }
     glcnt = B->gl_cnt.as<uint32_t>();
     for (int k = 0; k < 2; k++) GL[k] = GlLists{{B->gl_s[k].as<GlEntry>(), B->gl_m[k].as<GlEntry>(), B->gl_l[k].as<GlEntry>(), B->gl_w[k].as<GlEntry>()}, glcnt + 8 * k, {cap_s, cap_m, cap_l, cap_w}};
     nc = B->gl_nc.as<uint32_t>(); submax = B->gl_submax.as<uint32_t>(); lmode = B->gl_lmode.as<uint8_t>();
@@ -2115,6 +2138,15 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       if (hc[GL_NCL] || hc[0] > nxt.cap[0] || hc[1] > nxt.cap[1] || hc[2] > nxt.cap[2] || hc[3] > nxt.cap[3]) { c->err = "bzip2: group list overflow"; return ZADA_E_HIP; }
       B->gl_rows += (uint64_t)gl_n[0] + gl_n[1] + gl_n[2] + gl_n[3];
       for (int k = 0; k < GL_NCL; k++) gl_n[k] = hc[k];
+      // a list that has just been built (or added to): into text order (see k_bz_gl_keys; the key is an element index below 2^30, and the
+      // order inside 256 positions does not matter: they share their sectors anyway)
+      if (c->knob_bz_text_order && swept && 2 * h >= (uint32_t)c->knob_bz_lists && hc[0] > 1) {
+        hipLaunchKernelGGL(k_bz_gl_keys, dim3((hc[0] + 255) / 256), dim3(256), 0, st, nxt.l[0], hc[0], valA, B->gl_k0.as<uint32_t>());
+        size_t tb = B->gl_st_bytes;
+        if (gl_sort_pairs(st, B->gl_st.p, tb, B->gl_k0.as<uint32_t>(), B->gl_k1.as<uint32_t>(), (const unsigned long long *)nxt.l[0],
+                          (unsigned long long *)B->gl_v.p, (size_t)hc[0], 8, 30)) { c->err = "bzip2: list sort"; return ZADA_E_HIP; }
+        BZ_HIP(hipMemcpyAsync(nxt.l[0], B->gl_v.p, sizeof(GlEntry) * (size_t)hc[0], hipMemcpyDeviceToDevice, st));
+      }
       gcur ^= 1;
     }
   }

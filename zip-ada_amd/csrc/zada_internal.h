@@ -264,6 +264,7 @@ struct Ctx {
   int knob_batch_mib = 512;         // MiB of LZ buffer one batch of small entries may take (zada_deflate_batch)
   int knob_bz_batch_mib = 256;      // BZip2: MiB of small entries zada_bzip2_batch takes through one launch sequence
   int knob_bz_span_mib = 1024;      // BZip2: MiB of the stream whose block limits are found at a time
+  int knob_bz_text_order = 1;       // BZip2: the group lists of the late sort rounds in text order (one library radix sort per build)
   int knob_bz_tail_pct = 0;         // BZip2: share of the last pass that the last (short) batch of a pipelined call takes
   int knob_bz_batch_melems = 768;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
   int knob_bz_lists = 16;           // BZip2 rotation sort: from this prefix length on, sub-blocks whose unsorted groups have at most 8 192 rows ("bz_list_rows") leave the
