@@ -624,9 +624,12 @@ __device__ __forceinline__ GlEntry gl_entry(uint32_t first, uint32_t rows, uint3
 __device__ __forceinline__ void gl_unpack(const GlEntry E, uint32_t &first, uint32_t &rows, uint32_t &sb) { first = E.first; rows = (E.sb_rows & 8191u) + 1u; sb = E.sb_rows >> 13; }
 // four lists by group size: up to 8 rows (a thread sorts the group), 9 .. 16 (sixteen lanes), 17 .. 64 (a wave), 65 .. 8 192 (a workgroup, in LDS)
 constexpr uint32_t GL_MID = 16;
-struct GlLists { GlEntry *l[GL_NCL]; uint32_t *cnt; uint32_t cap[GL_NCL]; };
+// the thread-per-group list (groups of up to 8 rows) has records of its own: the group's first two rows travel with the entry -- most
+// groups are pairs, and in text order (k_bz_gl_keys) fetching a pair's rows from the sorted order would be the one gather left
+struct GlSmall { uint32_t first, sb_rows, v0, v1; };
+struct GlLists { GlEntry *l[GL_NCL]; GlSmall *s; uint32_t *cnt; uint32_t cap[GL_NCL]; };   // (l[0] is not used: list 0 is s)
 int gl_sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-                  const unsigned long long *vals_in, unsigned long long *vals_out, size_t n, unsigned begin_bit, unsigned end_bit);   // zada_glsort.hip   // cnt[0 .. 3]: entries of the lists; cnt[4]: overflow flag
+                  const void *vals_in, void *vals_out, size_t n, unsigned begin_bit, unsigned end_bit);   // zada_glsort.hip: 16-byte values   // cnt[0 .. 3]: entries of the lists; cnt[4]: overflow flag
 __device__ __forceinline__ int gl_class(uint32_t rows) { return rows <= GL_SMALL ? 0 : rows <= GL_MID ? 1 : rows <= GL_WAVE ? 2 : 3; }
 
 // Text order.  k_bz_gl_build lists the groups in the order of the sorted rotations, where the rows of neighbouring groups lie side by side
@@ -636,9 +639,9 @@ __device__ __forceinline__ int gl_class(uint32_t rows) { return rows <= GL_SMALL
 // b+j.  Listed by the position of their first row, neighbouring threads share those sectors and only the group's rows themselves are a
 // gather.  The key is that position; one stable radix sort of the (key, entry) pairs when a list has been built (gl_sort_pairs,
 // zada_glsort.hip); the rounds keep the order workgroup by workgroup.
-__global__ void k_bz_gl_keys(const GlEntry *__restrict__ list, uint32_t n, const uint32_t *__restrict__ sa, uint32_t *__restrict__ keys) {
+__global__ void k_bz_gl_keys(const GlSmall *__restrict__ list, uint32_t n, uint32_t *__restrict__ keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keys[i] = sa[list[i].first];
+  if (i < n) keys[i] = list[i].v0;
 }
 // largest unsorted group of every sub-block that is still swept: a row is its group's last when the next row's class differs
 __global__ void __launch_bounds__(1024) k_bz_gl_max(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ cl, SubTab T, const Tile *__restrict__ tiles,
@@ -701,19 +704,36 @@ __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict
   const Tile t = tiles[bx];
   if (!lmode[t.sb]) return;
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i0 = 0; i0 < m; i0 += 1024) {
-    const uint32_t i = i0 + threadIdx.x;
+  // (the tile's groups are found first, eight rows per thread, and listed after ONE reservation: gl_reserve)
+  constexpr int PER = BW_TILE / 1024;
+  uint32_t firstA[PER], rowsA[PER];
+  uint32_t cnt[GL_NCL] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x;
     uint32_t first = 0, rows = 0;
     if (i < m) {
       const uint32_t l = t.lo + i, g = off + l, c = cl[sa[g]];
       cl2[g] = cl[g];                                  // (the sub-block's elements are the same index range as its rows: a straight copy)
       if (l + 1 == n || cl[sa[g + 1]] != c) { first = c; rows = g - c + 1; }
     }
-    const int kc = gl_class(rows);
-    const uint32_t cnt[GL_NCL] = {rows > 1 && kc == 0 ? 1u : 0u, kc == 1 ? 1u : 0u, kc == 2 ? 1u : 0u, kc == 3 ? 1u : 0u};
-    uint32_t slot[GL_NCL];
-    gl_reserve(L, cnt, lds, slot);
-    if (rows > 1 && slot[kc] < L.cap[kc]) L.l[kc][slot[kc]] = gl_entry(first, rows, t.sb);
+    firstA[q] = first; rowsA[q] = rows;
+    if (rows > 1) cnt[gl_class(rows)]++;
+  }
+  uint32_t slot[GL_NCL];
+  gl_reserve(L, cnt, lds, slot);
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t first = firstA[q], rows = rowsA[q];
+    if (rows > 1) {
+      const int kc = gl_class(rows);
+      if (slot[kc] < L.cap[kc]) {
+        const GlEntry e = gl_entry(first, rows, t.sb);
+        if (kc == 0) L.s[slot[0]] = GlSmall{e.first, e.sb_rows, sa[first], sa[first + 1]};
+        else L.l[kc][slot[kc]] = e;
+      }
+      slot[kc]++;
+    }
   }
 }
 __global__ void k_bz_gl_leave(SubTab T, const uint8_t *__restrict__ lmode, uint8_t *__restrict__ done) {
@@ -729,69 +749,100 @@ __device__ __forceinline__ bool gl_cex(uint32_t &ka, uint32_t &va, uint32_t &kb,
   ka = k0; va = v0; kb = k1; vb = v1;
   return sw;
 }
-__global__ void __launch_bounds__(256) k_bz_gl_sort_small(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
+#ifndef ZADA_GLS_THREADS
+#define ZADA_GLS_THREADS 1024
+#endif
+#ifndef ZADA_GLS_PER
+#define ZADA_GLS_PER 2
+#endif
+// One reservation on the lists' counters per workgroup and round: the atomics of all workgroups go to one address and are served one
+// after the other (≈ 13 ns each: with 256 entries per workgroup the rounds' 430 000 reservations WERE the round, 5.5 ms).  So few, large
+// workgroups (1 024 threads), every thread with GLS_PER consecutive entries whose results wait in registers for the one reservation.
+constexpr int GLS_THREADS = ZADA_GLS_THREADS, GLS_PER = ZADA_GLS_PER;
+__global__ void __launch_bounds__(GLS_THREADS) k_bz_gl_sort_small(const GlSmall *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
                                                           const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
-  __shared__ uint32_t lds[GL_NCL * 5];
-  const uint32_t count = *cnt_p, gi = blockIdx.x * 256u + threadIdx.x;
-  uint32_t first = 0, rows = 0, sb = 0;
-  if (gi < count) gl_unpack(list[gi], first, rows, sb);
-  uint32_t k[8], v[8];
+  __shared__ uint32_t lds[GL_NCL * (GLS_THREADS / 64 + 1)];
+  const uint32_t count = *cnt_p, g0 = (blockIdx.x * (uint32_t)GLS_THREADS + threadIdx.x) * (uint32_t)GLS_PER;
+  uint32_t firstA[GLS_PER], packA[GLS_PER], endsA[GLS_PER], vA[GLS_PER][9];
+  GlSmall EA[GLS_PER];
 #pragma unroll
-  for (int j = 0; j < 8; j++) { k[j] = 0xFFFFFFFFu; v[j] = 0xFFFFFFFFu; }
-  uint32_t nnew = 0;                                   // groups for the next round: bit j set = a group starts at row j ...
-  uint32_t ends = 0;                                   // ... bit j set = a group ends behind row j
-  if (rows == 1) clw[sa[first]] = first;               // a row that came to stand alone in the round before: its class, in the other array as well
-  else if (rows > 1) {
-    const uint32_t n = T.n[sb], off = T.off[sb];
+  for (int q = 0; q < GLS_PER; q++) { EA[q] = GlSmall{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu}; if (g0 + q < count) EA[q] = list[g0 + q]; }
+  uint32_t total = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) v[j] = sa[first + j];
-    if (h >= n) {                                      // the rotations of the group are equal: nothing is left to tell them apart, the group goes off the lists
+  for (int q = 0; q < GLS_PER; q++) {
+    const GlSmall E = EA[q];
+    uint32_t first = 0, rows = 0, sb = 0;
+    if (g0 + q < count) gl_unpack(GlEntry{E.first, E.sb_rows}, first, rows, sb);
+    uint32_t k[8], v[9];
 #pragma unroll
-      for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) clw[v[j]] = first;
-    } else {
+    for (int j = 0; j < 8; j++) { k[j] = 0xFFFFFFFFu; v[j] = 0xFFFFFFFFu; }
+    v[8] = 0xFFFFFFFFu;
+    uint32_t ends = 0;                                 // groups for the next round: bit j set = a group ends behind row j
+    if (rows == 1) clw[E.v0] = first;                  // a row that came to stand alone in the round before: its class, in the other array as well
+    else if (rows > 1) {
+      const uint32_t n = T.n[sb], off = T.off[sb];
+      v[0] = E.v0; v[1] = E.v1;
 #pragma unroll
-      for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) { uint32_t l = v[j] - off + h; if (l >= n) l -= n; k[j] = clr[off + l]; }
-      bool moved = false;                              // (rows that stay where they are are not written back: in text order that write is the gather)
-      if (rows == 2) moved = gl_cex(k[0], v[0], k[1], v[1]);
-      else {
-        // 19 compare-exchanges sort eight (the empty places hold the largest key and stay behind)
+      for (int j = 2; j < 8; j++) if ((uint32_t)j < rows) v[j] = sa[first + j];
+      if (h >= n) {                                    // the rotations of the group are equal: nothing is left to tell them apart, the group goes off the lists
+#pragma unroll
+        for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) clw[v[j]] = first;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) if ((uint32_t)j < rows) { uint32_t l = v[j] - off + h; if (l >= n) l -= n; k[j] = clr[off + l]; }
+        bool moved = false;                            // (rows that stay where they are are not written back: in text order that write is a gather)
+        if (rows == 2) moved = gl_cex(k[0], v[0], k[1], v[1]);
+        else {
+          // 19 compare-exchanges sort eight (the empty places hold the largest key and stay behind)
 #define CX(a, b) moved |= gl_cex(k[a], v[a], k[b], v[b])
-        CX(0, 1); CX(2, 3); CX(4, 5); CX(6, 7); CX(0, 2); CX(1, 3); CX(4, 6); CX(5, 7); CX(1, 2); CX(5, 6); CX(0, 4); CX(3, 7); CX(1, 5); CX(2, 6); CX(1, 4); CX(3, 6); CX(2, 4); CX(3, 5); CX(3, 4);
+          CX(0, 1); CX(2, 3); CX(4, 5); CX(6, 7); CX(0, 2); CX(1, 3); CX(4, 6); CX(5, 7); CX(1, 2); CX(5, 6); CX(0, 4); CX(3, 7); CX(1, 5); CX(2, 6); CX(1, 4); CX(3, 6); CX(2, 4); CX(3, 5); CX(3, 4);
 #undef CX
-      }
-      // rows in order; a row starts a new group where its key differs from the row before
-      uint32_t start = 0;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        if ((uint32_t)j < rows) {
-          if (j > 0 && k[j] != k[j - 1]) { start = (uint32_t)j; ends |= 1u << (j - 1); }
-          if (moved) sa[first + j] = v[j];
-          clw[v[j]] = first + start;
         }
+        // rows in order; a row starts a new group where its key differs from the row before
+        uint32_t start = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if ((uint32_t)j < rows) {
+            if (j > 0 && k[j] != k[j - 1]) { start = (uint32_t)j; ends |= 1u << (j - 1); }
+            if (moved) sa[first + j] = v[j];
+            clw[v[j]] = first + start;
+          }
+        }
+        ends |= 1u << (rows - 1);
       }
-      ends |= 1u << (rows - 1);
-      nnew = (uint32_t)__popc(ends);
     }
+    firstA[q] = first; packA[q] = E.sb_rows; endsA[q] = ends;
+#pragma unroll
+    for (int j = 0; j < 9; j++) vA[q][j] = v[j];
+    total += (uint32_t)__popc(ends);
   }
-  const uint32_t cnt[GL_NCL] = {nnew, 0u, 0u, 0u};
+  const uint32_t cnt[GL_NCL] = {total, 0u, 0u, 0u};
   uint32_t slot[GL_NCL];
   gl_reserve(next, cnt, lds, slot);
-  uint32_t s0 = 0, is = slot[0];
-  while (ends) {
-    const uint32_t e = (uint32_t)__builtin_ctz(ends);
-    ends &= ends - 1u;
-    if (is < next.cap[0]) next.l[0][is] = gl_entry(first + s0, e + 1u - s0, sb);
-    is++;
-    s0 = e + 1u;
+  uint32_t is = slot[0];
+#pragma unroll
+  for (int q = 0; q < GLS_PER; q++) {
+    // a group starts at row 0 and behind every group's end (static row numbers: the rows stay in registers)
+    const uint32_t ends = endsA[q], rows = (packA[q] & 8191u) + 1u, sb = packA[q] >> 13;
+    const uint32_t starts = ends ? ((ends << 1) | 1u) & ((1u << rows) - 1u) : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if ((starts >> j) & 1u) {
+        const uint32_t e = (uint32_t)__builtin_ctz(ends >> j) + (uint32_t)j;
+        const GlEntry ge = gl_entry(firstA[q] + (uint32_t)j, e + 1u - (uint32_t)j, sb);
+        if (is < next.cap[0]) next.s[is] = GlSmall{ge.first, ge.sb_rows, vA[q][j], vA[q][j + 1]};
+        is++;
+      }
+    }
   }
 }
 // one round of the larger groups: TW lanes per group (16 for 9 .. 16 rows, 64 for 17 .. 64), a bitonic network over cross-lane reads
 template <int TW>
-__global__ void __launch_bounds__(256) k_bz_gl_sort_team(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
+__global__ void __launch_bounds__(GLS_THREADS) k_bz_gl_sort_team(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
                                                          const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
-  __shared__ uint32_t lds[GL_NCL * 5];
+  __shared__ uint32_t lds[GL_NCL * (GLS_THREADS / 64 + 1)];
   const uint32_t count = *cnt_p;
-  const uint32_t team = (blockIdx.x * 256u + threadIdx.x) / TW;
+  const uint32_t team = (blockIdx.x * (uint32_t)GLS_THREADS + threadIdx.x) / TW;
   const int lane = threadIdx.x & 63, tl = lane & (TW - 1), tbase = lane - tl;
   uint32_t first = 0, rows = 0, sb = 0;
   if (team < count) gl_unpack(list[team], first, rows, sb);
@@ -835,7 +886,12 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_team(const GlEntry *__restri
   const uint32_t cnt[GL_NCL] = {rows_new >= 1 && kc == 0 ? 1u : 0u, kc == 1 ? 1u : 0u, kc == 2 ? 1u : 0u, 0u};
   uint32_t slot[GL_NCL];
   gl_reserve(next, cnt, lds, slot);
-  if (rows_new >= 1 && slot[kc] < next.cap[kc]) next.l[kc][slot[kc]] = gl_entry(first + (uint32_t)tl, rows_new, sb);
+  const uint32_t v1 = __shfl_down(v, 1);               // (the row behind: the second of a group that this lane's row starts)
+  if (rows_new >= 1 && slot[kc] < next.cap[kc]) {
+    const GlEntry e = gl_entry(first + (uint32_t)tl, rows_new, sb);
+    if (kc == 0) next.s[slot[0]] = GlSmall{e.first, e.sb_rows, v, v1};
+    else next.l[kc][slot[kc]] = e;
+  }
 }
 
 // one round of the large groups (65 .. 8 192 rows): a workgroup per group, keys and rows in LDS, a bitonic network over them
@@ -898,7 +954,11 @@ __global__ void __launch_bounds__(256) k_bz_gl_sort_wg(const GlEntry *__restrict
     if (i + 1 == rows || K[i + 1] != K[i]) {
       const uint32_t rn = i + 1 - start;
       const int kc = gl_class(rn);
-      if (slot[kc] < next.cap[kc]) next.l[kc][slot[kc]] = gl_entry(first + start, rn, sb);
+      if (slot[kc] < next.cap[kc]) {
+        const GlEntry e = gl_entry(first + start, rn, sb);
+        if (kc == 0) next.s[slot[0]] = GlSmall{e.first, e.sb_rows, V[start], rn > 1 ? V[start + 1] : 0u};
+        else next.l[kc][slot[kc]] = e;
+      }
       slot[kc]++;
     }
   }
@@ -2057,7 +2117,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   uint8_t *lmode = nullptr;
   if (use_lists) {
     const uint32_t cap_s = (uint32_t)(tot + 64), cap_m = (uint32_t)(tot / (GL_SMALL + 1) + 64), cap_l = (uint32_t)(tot / (GL_MID + 1) + 64), cap_w = (uint32_t)(tot / (GL_WAVE + 1) + 64);   // (groups of one included: a round lists a row at most once)
-    if ((rc = dbuf_ensure(c, B->gl_s[0], sizeof(GlEntry) * (size_t)cap_s)) || (rc = dbuf_ensure(c, B->gl_s[1], sizeof(GlEntry) * (size_t)cap_s)) ||
+    if ((rc = dbuf_ensure(c, B->gl_s[0], sizeof(GlSmall) * (size_t)cap_s)) || (rc = dbuf_ensure(c, B->gl_s[1], sizeof(GlSmall) * (size_t)cap_s)) ||
         (rc = dbuf_ensure(c, B->gl_m[0], sizeof(GlEntry) * (size_t)cap_m)) || (rc = dbuf_ensure(c, B->gl_m[1], sizeof(GlEntry) * (size_t)cap_m)) ||
         (rc = dbuf_ensure(c, B->gl_l[0], sizeof(GlEntry) * (size_t)cap_l)) || (rc = dbuf_ensure(c, B->gl_l[1], sizeof(GlEntry) * (size_t)cap_l)) ||
         (rc = dbuf_ensure(c, B->gl_w[0], sizeof(GlEntry) * (size_t)cap_w)) || (rc = dbuf_ensure(c, B->gl_w[1], sizeof(GlEntry) * (size_t)cap_w)) ||
@@ -2066,12 +2126,12 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
     if (c->knob_bz_text_order) {
       size_t tb = 0;
       if (gl_sort_pairs(st, nullptr, tb, nullptr, nullptr, nullptr, nullptr, cap_s, 8, 30)) { c->err = "bzip2: list sort (size query)"; return ZADA_E_HIP; }
-      if ((rc = dbuf_ensure(c, B->gl_k0, 4ull * cap_s)) || (rc = dbuf_ensure(c, B->gl_k1, 4ull * cap_s)) || (rc = dbuf_ensure(c, B->gl_v, sizeof(GlEntry) * (size_t)cap_s)) ||
+      if ((rc = dbuf_ensure(c, B->gl_k0, 4ull * cap_s)) || (rc = dbuf_ensure(c, B->gl_k1, 4ull * cap_s)) || (rc = dbuf_ensure(c, B->gl_v, sizeof(GlSmall) * (size_t)cap_s)) ||
           (rc = dbuf_ensure(c, B->gl_st, tb + 256))) return rc;
       B->gl_st_bytes = tb;
     }
     glcnt = B->gl_cnt.as<uint32_t>();
-    for (int k = 0; k < 2; k++) GL[k] = GlLists{{B->gl_s[k].as<GlEntry>(), B->gl_m[k].as<GlEntry>(), B->gl_l[k].as<GlEntry>(), B->gl_w[k].as<GlEntry>()}, glcnt + 8 * k, {cap_s, cap_m, cap_l, cap_w}};
+    for (int k = 0; k < 2; k++) GL[k] = GlLists{{nullptr, B->gl_m[k].as<GlEntry>(), B->gl_l[k].as<GlEntry>(), B->gl_w[k].as<GlEntry>()}, B->gl_s[k].as<GlSmall>(), glcnt + 8 * k, {cap_s, cap_m, cap_l, cap_w}};
     nc = B->gl_nc.as<uint32_t>(); submax = B->gl_submax.as<uint32_t>(); lmode = B->gl_lmode.as<uint8_t>();
     BZ_HIP(hipMemsetAsync(glcnt, 0, 64, st));
   }
@@ -2119,9 +2179,9 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       // (the listed sub-blocks' classes: read in one array, written in the other; the swept ones keep to cl)
       const uint32_t *clr = gcur ? nc : cl;
       uint32_t *clw = gcur ? cl : nc;
-      if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + 255) / 256), dim3(256), 0, st, cur.l[0], cur.cnt + 0, h, valA, clr, clw, T, nxt);
-      if (gl_n[1]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_MID>), dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MID + 255) / 256)), dim3(256), 0, st, cur.l[1], cur.cnt + 1, h, valA, clr, clw, T, nxt);
-      if (gl_n[2]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_WAVE>), dim3((uint32_t)(((uint64_t)gl_n[2] * GL_WAVE + 255) / 256)), dim3(256), 0, st, cur.l[2], cur.cnt + 2, h, valA, clr, clw, T, nxt);
+      if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + GLS_THREADS * GLS_PER - 1) / (GLS_THREADS * GLS_PER)), dim3(GLS_THREADS), 0, st, cur.s, cur.cnt + 0, h, valA, clr, clw, T, nxt);
+      if (gl_n[1]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_MID>), dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MID + GLS_THREADS - 1) / GLS_THREADS)), dim3(GLS_THREADS), 0, st, cur.l[1], cur.cnt + 1, h, valA, clr, clw, T, nxt);
+      if (gl_n[2]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_WAVE>), dim3((uint32_t)(((uint64_t)gl_n[2] * GL_WAVE + GLS_THREADS - 1) / GLS_THREADS)), dim3(GLS_THREADS), 0, st, cur.l[2], cur.cnt + 2, h, valA, clr, clw, T, nxt);
       if (gl_n[3]) hipLaunchKernelGGL(k_bz_gl_sort_wg, dim3(gl_n[3]), dim3(256), 0, st, cur.l[3], cur.cnt + 3, h, valA, clr, clw, T, nxt);
       // sub-blocks whose unsorted groups have all become small leave the sweeps: their groups (classes of 2h bytes) join the lists
       if (swept && 2 * h >= (uint32_t)c->knob_bz_lists) {
@@ -2141,11 +2201,10 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       // a list that has just been built (or added to): into text order (see k_bz_gl_keys; the key is an element index below 2^30, and the
       // order inside 256 positions does not matter: they share their sectors anyway)
       if (c->knob_bz_text_order && swept && 2 * h >= (uint32_t)c->knob_bz_lists && hc[0] > 1) {
-        hipLaunchKernelGGL(k_bz_gl_keys, dim3((hc[0] + 255) / 256), dim3(256), 0, st, nxt.l[0], hc[0], valA, B->gl_k0.as<uint32_t>());
+        hipLaunchKernelGGL(k_bz_gl_keys, dim3((hc[0] + 255) / 256), dim3(256), 0, st, nxt.s, hc[0], B->gl_k0.as<uint32_t>());
         size_t tb = B->gl_st_bytes;
-        if (gl_sort_pairs(st, B->gl_st.p, tb, B->gl_k0.as<uint32_t>(), B->gl_k1.as<uint32_t>(), (const unsigned long long *)nxt.l[0],
-                          (unsigned long long *)B->gl_v.p, (size_t)hc[0], 8, 30)) { c->err = "bzip2: list sort"; return ZADA_E_HIP; }
-        BZ_HIP(hipMemcpyAsync(nxt.l[0], B->gl_v.p, sizeof(GlEntry) * (size_t)hc[0], hipMemcpyDeviceToDevice, st));
+        if (gl_sort_pairs(st, B->gl_st.p, tb, B->gl_k0.as<uint32_t>(), B->gl_k1.as<uint32_t>(), nxt.s, B->gl_v.p, (size_t)hc[0], 8, 30)) { c->err = "bzip2: list sort"; return ZADA_E_HIP; }
+        BZ_HIP(hipMemcpyAsync(nxt.s, B->gl_v.p, sizeof(GlSmall) * (size_t)hc[0], hipMemcpyDeviceToDevice, st));
       }
       gcur ^= 1;
     }
