@@ -388,11 +388,18 @@ __global__ void __launch_bounds__(1024) k_bz_radix_scatter(const uint32_t *__res
   uint32_t *mycnt = cnt + w * NB;
   // rank among the wave's elements with the same digit, in element order (LDS atomics of one instruction are served in lane
   // order; see sort_pass in zada_lz.hip and tests/probes/lds_atomic_order.hip)
+  // (the sixteen loads first, without conditions -- an element beyond the tile's end reads the tile's first --, then the atomics: under
+  // `if (i < m) { load; load; atomic }` every element was a global round trip of its own, eight in a row per lane)
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const uint32_t i = (uint32_t)w * 512 + it * 64 + lane, j = i < m ? i : 0u;
+    kx[it] = key[base + j]; vx[it] = val[base + j];
+  }
 #pragma unroll
   for (int it = 0; it < 8; it++) {
     const uint32_t i = (uint32_t)w * 512 + it * 64 + lane;
-    kx[it] = 0; vx[it] = 0; rk[it] = 0;
-    if (i < m) { kx[it] = key[base + i]; vx[it] = val[base + i]; rk[it] = atomicAdd(&mycnt[(kx[it] >> shift) & (NB - 1u)], 1u); }
+    rk[it] = 0;
+    if (i < m) rk[it] = atomicAdd(&mycnt[(kx[it] >> shift) & (NB - 1u)], 1u);
   }
   __syncthreads();
   // per digit: exclusive prefix over the waves, plus the tile's base from the scanned histogram
@@ -446,11 +453,23 @@ __global__ void __launch_bounds__(1024) k_bz_set_class(const uint32_t *__restric
   if (bx >= ntiles_x) return;
   const Tile t = tiles[bx];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, g = off + l, e = sa[g];
-    cl[e] = hr[g] - 1;
-    const bool single = hv[g] != 0 && (l + 1 == n || hv[g + 1] != 0);
-    if (!single) atomicOr(&acte[e >> 5], 1u << (e & 31));
+  // (a tile is eight rows per thread: all their loads first, then the scattered stores and atomics -- stores count in the same counter as
+  // loads, so a loop of load / store / load waits for every scattered store before it goes on)
+  constexpr int PER = BW_TILE / 1024;
+  uint32_t e8[PER], c8[PER];
+  bool act8[PER];
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, j = i < m ? i : 0u, l = t.lo + j, g = off + l;
+    e8[q] = sa[g]; c8[q] = hr[g] - 1;
+    const uint32_t h0 = hv[g], h1 = l + 1 == n ? 1u : hv[g + 1];
+    act8[q] = i < m && !(h0 != 0 && h1 != 0);
+  }
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x;
+    if (i < m) cl[e8[q]] = c8[q];
+    if (act8[q]) atomicOr(&acte[e8[q] >> 5], 1u << (e8[q] & 31));
   }
 }
 // A doubling round only moves the rows of groups that still have more than one row.  The rows, read in order and shifted
@@ -467,6 +486,25 @@ __device__ __forceinline__ uint32_t bz_shifted_active(const uint32_t *__restrict
   *e_out = e;
   return (acte[e >> 5] >> (e & 31)) & 1u;
 }
+// the same for a thread's eight consecutive rows r0 .. r0+7 of the tile (those below m): the rows first, then the marks -- two round trips,
+// not sixteen.  Bit k of the result: row r0+k exists and its shifted element is marked; ev[k] = that element.
+__device__ __forceinline__ uint32_t bz_shifted_active8(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, uint32_t g0, uint32_t r0, uint32_t m,
+                                                        uint32_t off, uint32_t n, uint32_t h, uint32_t (&ev)[8]) {
+  uint32_t r[8], a[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) r[k] = sa[g0 + (r0 + k < m ? r0 + k : 0u)];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint32_t l = r[k] - off;
+    l = l >= h ? l - h : l + n - h;             // h < n for a sub-block that is not done
+    ev[k] = off + l;
+    a[k] = acte[ev[k] >> 5];
+  }
+  uint32_t fl = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) if (r0 + k < m && ((a[k] >> (ev[k] & 31)) & 1u)) fl |= 1u << k;
+  return fl;
+}
 __global__ void __launch_bounds__(1024) k_bz_filter_count(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, SubTab T, const Tile *__restrict__ tiles,
                                                           const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ tile_cnt, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
@@ -476,8 +514,8 @@ __global__ void __launch_bounds__(1024) k_bz_filter_count(const uint32_t *__rest
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   uint32_t c = 0;
   if (!done[t.sb]) {
-    const uint32_t r0 = threadIdx.x * 8;
-    for (uint32_t k = 0; k < 8; k++) if (r0 + k < m) { uint32_t e; c += bz_shifted_active(sa, acte, off + t.lo + r0 + k, off, n, h, &e); }
+    uint32_t ev[8];
+    c = (uint32_t)__popc(bz_shifted_active8(sa, acte, off + t.lo, threadIdx.x * 8, m, off, n, h, ev));
   }
   OpSum sm;
   uint32_t tot;
@@ -502,15 +540,15 @@ __global__ void __launch_bounds__(1024) k_bz_filter_emit(const uint32_t *__restr
   if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   const uint32_t r0 = threadIdx.x * 8;
-  uint32_t ev[8], fl = 0, c = 0;
-  for (uint32_t k = 0; k < 8; k++) {
-    ev[k] = 0;
-    if (r0 + k < m && bz_shifted_active(sa, acte, off + t.lo + r0 + k, off, n, h, &ev[k])) { fl |= 1u << k; c++; }
-  }
+  uint32_t ev[8], ck[8];
+  const uint32_t fl = bz_shifted_active8(sa, acte, off + t.lo, r0, m, off, n, h, ev), c = (uint32_t)__popc(fl);
+#pragma unroll
+  for (int k = 0; k < 8; k++) ck[k] = cl[((fl >> k) & 1u) ? ev[k] : off];          // (the survivors' classes, all in flight)
   OpSum sm;
   const uint32_t incl = wg_scan_incl(c, l17, sm, nullptr);
   uint32_t j = tscan[bx] + incl - c;
-  for (uint32_t k = 0; k < 8; k++) if ((fl >> k) & 1u) { ckey[j] = cl[ev[k]] - off; cval[j] = ev[k]; j++; }
+#pragma unroll
+  for (int k = 0; k < 8; k++) if ((fl >> k) & 1u) { ckey[j] = ck[k] - off; cval[j] = ev[k]; j++; }
 }
 // C = the filtered rows' space (sub-block s owns [coff[s], coff[s] + cm[s])), its tiles in `tiles`.  After the sort the rows of a
 // group are together (equal keys).  Three kernels, a thread taking eight consecutive slots, scans inside the tile and a carry
@@ -543,28 +581,39 @@ __global__ void __launch_bounds__(1024) k_bz_place(const uint32_t *__restrict__ 
   uint32_t key[8], val[8], flags = 0, last = 0;
   auto second = [&](uint32_t e) -> uint32_t { uint32_t l = e - off + h; if (l >= n) l -= n; return cl[off + l]; };
   uint32_t sec_prev = 0;
-  for (uint32_t k = 0; k < 8; k++) {
-    key[k] = 0; val[k] = 0;
+  // (loads first: the eight slots' keys and elements and the slot in front, then the classes of their second halves -- the loop below
+  // stores to scattered rows, and a load behind a store waits for it)
+  uint32_t pk0 = 0, pv0 = 0, sec[8];
+  {
+    const uint32_t jm = coff + t.lo + (r0 < m ? r0 : 0u);
+    if (t.lo + r0 > 0 && r0 < m) { pk0 = ckey[jm - 1]; pv0 = cval[jm - 1]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t j = coff + t.lo + (r0 + k < m ? r0 + k : 0u); key[k] = ckey[j]; val[k] = cval[j]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) sec[k] = second(r0 + k < m ? val[k] : off);
+  if (r0 < m && t.lo + r0 > 0) sec_prev = second(pv0);                              // the slot in front of this thread's first
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
     if (r0 + k < m) {
       const uint32_t l = t.lo + r0 + k, j = coff + l;
-      key[k] = ckey[j]; val[k] = cval[j];
-      const uint32_t pk = k ? key[k - 1] : (l ? ckey[j - 1] : 0u);
+      const uint32_t pk = k ? key[k - 1] : pk0;
       if (l == 0 || key[k] != pk) { flags |= 1u << k; last = j + 1; }
-    }
+    } else { key[k] = 0; val[k] = 0; }
   }
-  if (r0 < m && t.lo + r0 > 0) sec_prev = second(cval[coff + t.lo + r0 - 1]);       // the slot in front of this thread's first
   OpMax mx;
   const uint32_t incl = wg_scan_incl(last, l17, mx, nullptr);
   uint32_t before = __shfl_up(incl, 1);
   if ((threadIdx.x & 63) == 0) { before = 0; for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before = mx(before, l17[k]); }
   uint32_t run = mx(carry_rf[bx], before), hmax = 0;
-  for (uint32_t k = 0; k < 8; k++) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
     if (r0 + k < m) {
       const uint32_t j = coff + t.lo + r0 + k, e = val[k];
       if ((flags >> k) & 1u) run = j + 1;
       const uint32_t row = off + key[k] + (j - (run - 1));
       sa[row] = e;
-      const uint32_t sc = second(e);
+      const uint32_t sc = sec[k];
       const uint32_t hv = (((flags >> k) & 1u) || sc != sec_prev) ? row + 1 : 0u;
       hd[j] = hv;
       hmax = mx(hmax, hv);
@@ -595,9 +644,13 @@ __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict
   uint32_t before = __shfl_up(incl, 1);
   if ((threadIdx.x & 63) == 0) { before = 0; for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before = mx(before, l17[k]); }
   uint32_t run = mx(carry_hd[bx], before);
-  for (uint32_t k = 0; k < 8; k++) {
+  uint32_t ee[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) ee[k] = cval[coff + t.lo + (r0 + k < m ? r0 + k : 0u)];   // (loads before the scattered stores)
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
     if (r0 + k < m) {
-      const uint32_t j = coff + t.lo + r0 + k, e = cval[j];
+      const uint32_t e = ee[k];
       if (hv[k]) run = hv[k];
       cl[e] = run - 1;
       if (hv[k] != 0 && hv[k + 1] != 0) atomicAnd(&acte[e >> 5], ~(1u << (e & 31)));
@@ -652,10 +705,20 @@ __global__ void __launch_bounds__(1024) k_bz_gl_max(const uint32_t *__restrict__
   if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   uint32_t mx = 0;
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, g = off + l, c = cl[sa[g]];
-    const bool last = l + 1 == n || cl[sa[g + 1]] != c;
-    if (last) mx = max(mx, g - c + 1);
+  // (eight rows per thread: their rows first, then their classes -- two round trips instead of sixteen)
+  constexpr int PER = BW_TILE / 1024;
+  uint32_t r0[PER], r1[PER], c0[PER], c1[PER];
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, j = i < m ? i : 0u, l = t.lo + j, g = off + l;
+    r0[q] = sa[g]; r1[q] = sa[l + 1 == n ? g : g + 1];
+  }
+#pragma unroll
+  for (int q = 0; q < PER; q++) { c0[q] = cl[r0[q]]; c1[q] = cl[r1[q]]; }
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, l = t.lo + i, g = off + l;
+    if (i < m && (l + 1 == n || c1[q] != c0[q])) mx = max(mx, g - c0[q] + 1);
   }
   for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
   if ((threadIdx.x & 63) == 0 && mx > 1) atomicMax(&submax[t.sb], mx);
@@ -708,17 +771,26 @@ __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict
   constexpr int PER = BW_TILE / 1024;
   uint32_t firstA[PER], rowsA[PER];
   uint32_t cnt[GL_NCL] = {0u, 0u, 0u, 0u};
+  {
+    uint32_t r0[PER], r1[PER], c0[PER], c1[PER], cg[PER];
 #pragma unroll
-  for (int q = 0; q < PER; q++) {
-    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x;
-    uint32_t first = 0, rows = 0;
-    if (i < m) {
-      const uint32_t l = t.lo + i, g = off + l, c = cl[sa[g]];
-      cl2[g] = cl[g];                                  // (the sub-block's elements are the same index range as its rows: a straight copy)
-      if (l + 1 == n || cl[sa[g + 1]] != c) { first = c; rows = g - c + 1; }
+    for (int q = 0; q < PER; q++) {
+      const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, j = i < m ? i : 0u, l = t.lo + j, g = off + l;
+      r0[q] = sa[g]; r1[q] = sa[l + 1 == n ? g : g + 1]; cg[q] = cl[g];
     }
-    firstA[q] = first; rowsA[q] = rows;
-    if (rows > 1) cnt[gl_class(rows)]++;
+#pragma unroll
+    for (int q = 0; q < PER; q++) { c0[q] = cl[r0[q]]; c1[q] = cl[r1[q]]; }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, l = t.lo + i, g = off + l;
+      uint32_t first = 0, rows = 0;
+      if (i < m) {
+        cl2[g] = cg[q];                                // (the sub-block's elements are the same index range as its rows: a straight copy)
+        if (l + 1 == n || c1[q] != c0[q]) { first = c0[q]; rows = g - c0[q] + 1; }
+      }
+      firstA[q] = first; rowsA[q] = rows;
+      if (rows > 1) cnt[gl_class(rows)]++;
+    }
   }
   uint32_t slot[GL_NCL];
   gl_reserve(L, cnt, lds, slot);
