@@ -1096,13 +1096,28 @@ __global__ void __launch_bounds__(64) k_bz_mtf_recency(const uint8_t *__restrict
   const uint32_t m = min((uint32_t)MTF_CHUNK, n - lo);
   const uint8_t *src = bwt + T.off[t.sb] + lo, *sq = seq + t.sb * 256;
   for (int w = 0; w < 8; w++) seen[w * 64 + lane] = 0;
-  uint32_t c = 0;
-  uint8_t *out = rec + (uint64_t)slot * 256;
-  for (int i = (int)m - 1; i >= 0; i--) {
-    const uint32_t y = sq[src[i]];
-    const uint32_t w = seen[(y >> 5) * 64 + lane];
-    if (!((w >> (y & 31)) & 1u)) { seen[(y >> 5) * 64 + lane] = w | (1u << (y & 31)); out[c++] = (uint8_t)y; }
+  uint32_t c = 0, acc = 0;
+  uint32_t *out = (uint32_t *)(rec + (uint64_t)slot * 256);
+  // (the chunk sixteen bytes per load, the distinct symbols four per store: a lane's chunk is 512 bytes of its own, and as one byte load and one
+  // byte store per step every step was a memory round trip that also waited for the store before it.  The last piece may read a few bytes
+  // past the chunk: they lie inside the buffer and are not looked at.)
+  for (int i0 = (int)((m - 1) & ~15u); i0 >= 0; i0 -= 16) {
+    uint32_t in[4];
+    __builtin_memcpy(in, src + i0, 16);
+#pragma unroll
+    for (int q = 15; q >= 0; q--) {
+      if ((uint32_t)(i0 + q) < m) {
+        const uint32_t y = sq[(in[q >> 2] >> (8 * (q & 3))) & 0xFFu];
+        const uint32_t w = seen[(y >> 5) * 64 + lane];
+        if (!((w >> (y & 31)) & 1u)) {
+          seen[(y >> 5) * 64 + lane] = w | (1u << (y & 31));
+          acc |= y << (8 * (c & 3u));
+          if ((++c & 3u) == 0) { out[(c >> 2) - 1] = acc; acc = 0; }
+        }
+      }
+    }
   }
+  if (c & 3u) out[c >> 2] = acc;
   for (int w = 0; w < 8; w++) bm[(uint64_t)slot * 8 + w] = seen[w * 64 + lane];
   cnt[slot] = c;
 }
@@ -1156,22 +1171,32 @@ __global__ void __launch_bounds__(64) k_bz_mtf_apply(const uint8_t *__restrict__
   uint8_t *dst = idx_out + T.off[t.sb] + lo;
   uint32_t *my = L + lane * 65;                                   // entry p = byte p & 3 of word p >> 2
   for (int i = 0; i < 64; i++) my[i] = l0[i];
-  for (uint32_t i = 0; i < m; i++) {
-    const uint32_t y = sq[src[i]], yy = y * 0x01010101u;
-    uint32_t wi = 0, wv = my[0], x = wv ^ yy;
-    while (!((x - 0x01010101u) & ~x & 0x80808080u)) { wi++; wv = my[wi]; x = wv ^ yy; }       // no zero byte: y is not among these four
-    const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;      // lowest set bit marks the first zero byte (no borrow can reach below it)
-    const uint32_t b = (uint32_t)(__ffs((int)z) - 1) >> 3;        // its byte
-    const uint32_t idx = wi * 4 + b;
-    if (idx) {
-      // entries 0 .. idx - 1 move up by one, y goes to the front: whole words below wi, part of word wi
-      const uint32_t keep = b == 3 ? 0u : (wv & (0xFFFFFFFFu << (8 * (b + 1))));
-      uint32_t carry = y;
-      for (uint32_t k = 0; k < wi; k++) { const uint32_t w = my[k]; my[k] = (w << 8) | carry; carry = w >> 24; }
-      const uint32_t lowmask = (1u << (8 * b)) - 1u;               // the bytes of word wi in front of y
-      my[wi] = keep | ((((wv & lowmask) << 8) | carry) & ((b == 3) ? 0xFFFFFFFFu : ((1u << (8 * (b + 1))) - 1u)));
+  // (sixteen bytes per load and per store: see k_bz_mtf_recency)
+  for (uint32_t i0 = 0; i0 < m; i0 += 16) {
+    uint32_t in[4], outw[4] = {0u, 0u, 0u, 0u};
+    __builtin_memcpy(in, src + i0, 16);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      if (i0 + (uint32_t)q < m) {
+        const uint32_t y = sq[(in[q >> 2] >> (8 * (q & 3))) & 0xFFu], yy = y * 0x01010101u;
+        uint32_t wi = 0, wv = my[0], x = wv ^ yy;
+        while (!((x - 0x01010101u) & ~x & 0x80808080u)) { wi++; wv = my[wi]; x = wv ^ yy; }       // no zero byte: y is not among these four
+        const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;      // lowest set bit marks the first zero byte (no borrow can reach below it)
+        const uint32_t b = (uint32_t)(__ffs((int)z) - 1) >> 3;        // its byte
+        const uint32_t idx = wi * 4 + b;
+        if (idx) {
+          // entries 0 .. idx - 1 move up by one, y goes to the front: whole words below wi, part of word wi
+          const uint32_t keep = b == 3 ? 0u : (wv & (0xFFFFFFFFu << (8 * (b + 1))));
+          uint32_t carry = y;
+          for (uint32_t k = 0; k < wi; k++) { const uint32_t w = my[k]; my[k] = (w << 8) | carry; carry = w >> 24; }
+          const uint32_t lowmask = (1u << (8 * b)) - 1u;               // the bytes of word wi in front of y
+          my[wi] = keep | ((((wv & lowmask) << 8) | carry) & ((b == 3) ? 0xFFFFFFFFu : ((1u << (8 * (b + 1))) - 1u)));
+        }
+        outw[q >> 2] |= idx << (8 * (q & 3));
+      }
     }
-    dst[i] = (uint8_t)idx;
+    if (i0 + 16 <= m) __builtin_memcpy(dst + i0, outw, 16);
+    else for (uint32_t q = 0; i0 + q < m; q++) dst[i0 + q] = (uint8_t)(outw[q >> 2] >> (8 * (q & 3)));
   }
 }
 
