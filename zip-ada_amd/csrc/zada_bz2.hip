@@ -1288,11 +1288,26 @@ __global__ void __launch_bounds__(64) k_bz_rank(EntTab E, uint32_t first) {
   const uint16_t *sym = E.sym + E.soff[s];
   const int eob = (int)E.nsym[s] + 1;
   const int last_sampled = eob - 1 < width - 1 ? eob - 1 : width - 1;          // :595
-  for (uint32_t g = lane; g < ns; g += 64) {
-    const uint32_t cnt = min((uint32_t)BZ_GROUP, m - g * BZ_GROUP);
-    uint32_t key = 0;
-    for (uint32_t k = 0; k < cnt; k++) key += (int)sym[g * BZ_GROUP + k] <= last_sampled ? 1u : 0u;
-    P[g + 1] = (key << 16) | (g + 1);
+  // keys (:586-600): how many of a group's symbols are among the sampled ones.  The wave reads the symbols as words, neighbouring lanes
+  // neighbouring words (a lane per group was fifty 2-byte loads 100 bytes apart per group), and adds a word's count to its group's entry.
+  for (uint32_t g = lane; g < ns; g += 64) P[g + 1] = g + 1;
+  wave_sync();
+  {
+    const uint32_t *sw = (const uint32_t *)sym;                   // (a sub-block's symbols start at an even offset: k_bz_sym_layout)
+    const uint32_t nw = (m + 1) / 2;
+    for (uint32_t w0 = 0; w0 < nw; w0 += 64 * 8) {
+      uint32_t x[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const uint32_t w = w0 + (uint32_t)q * 64 + lane; x[q] = sw[w < nw ? w : 0u]; }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t w = w0 + (uint32_t)q * 64 + lane;
+        if (w < nw) {
+          const uint32_t a = (int)(x[q] & 0xFFFFu) <= last_sampled ? 1u : 0u, b = (2 * w + 1 < m && (int)(x[q] >> 16) <= last_sampled) ? 1u : 0u;
+          if (a + b) atomicAdd(&P[w / (BZ_GROUP / 2) + 1], (a + b) << 16);        // (a word lies inside one group: fifty is even)
+        }
+      }
+    }
   }
   wave_sync();
   {
@@ -2400,7 +2415,12 @@ static int bz_entropy_emit(Ctx *c, Bz2State *B, hipStream_t st, bool marks, int 
     BZ_HIP(hipStreamWaitEvent(B->st_small, B->ev_small, 0));
   }
   hipStream_t sts = both ? B->st_small : st;
-  if (nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nbig, nwid), dim3(64), rank_lds_big, st, E, 0u);
+  // (the long ones in two launches: a quarter of a block has 4 500 groups and should not hold the 72 KB of LDS a whole block's ranking needs)
+  constexpr uint32_t RANK_MID_NS = 6000;
+  uint32_t nfull = 0;
+  while (nfull < nbig && 1 + B->h_n[order[nfull]] / BZ_GROUP > RANK_MID_NS) nfull++;
+  if (nfull) hipLaunchKernelGGL(k_bz_rank, dim3(nfull, nwid), dim3(64), rank_lds_big, st, E, 0u);
+  if (nbig > nfull) hipLaunchKernelGGL(k_bz_rank, dim3(nbig - nfull, nwid), dim3(64), 4 * (size_t)(RANK_MID_NS + 8), st, E, nfull);
   if (nsb > nbig) hipLaunchKernelGGL(k_bz_rank, dim3(nsb - nbig, nwid), dim3(64), rank_lds_small, sts, E, nbig);
   if (both) {
     // (the short sub-blocks' search waits for the long ones' rankings: its workgroups would fill every CU's LDS, and the rankings'
