@@ -267,24 +267,28 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         uint32_t key[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) key[k] = 0;
-        const uint32_t *wp = (const uint32_t *)(sin + (i0 & ~3u));
         const uint32_t sh = i0 & 3u;
         // the loads are not guarded (the buffer is padded past its end), so that eight elements' words are in flight together
-        // instead of one global round trip per element; what lies beyond the segment's elements gets key 0 and is not sorted
+        // instead of one global round trip per element; what lies beyond the segment's elements gets key 0 and is not sorted.
+        // From the second level on the segment's bytes are still in LDS (A, staged for the level before: nothing has written there since).
+        auto build = [&](auto wp) {
 #pragma unroll
-        for (int g8 = 0; g8 < 4; g8++) {
-          uint32_t wa[8], wb[8], wc[8];
+          for (int g8 = 0; g8 < 4; g8++) {
+            uint32_t wa[8], wb[8], wc[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) { const int it = g8 * 8 + q; wa[q] = wp[it * 16]; wb[q] = wp[it * 16 + 1]; wc[q] = wp[it * 16 + 2]; }
+            for (int q = 0; q < 8; q++) { const int it = g8 * 8 + q; wa[q] = wp[it * 16]; wb[q] = wp[it * 16 + 1]; wc[q] = wp[it * 16 + 2]; }
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const int it = g8 * 8 + q;
-            const uint64_t v = (uint64_t)__builtin_amdgcn_alignbyte(wb[q], wa[q], sh) | ((uint64_t)__builtin_amdgcn_alignbyte(wc[q], wb[q], sh) << 32);
-            uint32_t k = (lvl == 0) ? hash3_of(v) : hashL_of(v, L);
-            if (!(it * 64 < rem)) k = 0;
-            key[it >> 1] |= k << (16 * (it & 1));
+            for (int q = 0; q < 8; q++) {
+              const int it = g8 * 8 + q;
+              const uint64_t v = (uint64_t)__builtin_amdgcn_alignbyte(wb[q], wa[q], sh) | ((uint64_t)__builtin_amdgcn_alignbyte(wc[q], wb[q], sh) << 32);
+              uint32_t k = (lvl == 0) ? hash3_of(v) : hashL_of(v, L);
+              if (!(it * 64 < rem)) k = 0;
+              key[it >> 1] |= k << (16 * (it & 1));
+            }
           }
-        }
+        };
+        if (lvl == 0) build((const uint32_t *)(sin + (i0 & ~3u)));
+        else build((const uint32_t *)(sb + (i0 & ~3u)));
         sort_pass<256, 0, true>(key, AB, cnt, wsum, i0, rem);
       }
       uint32_t pr[32];
