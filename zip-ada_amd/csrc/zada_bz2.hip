@@ -967,14 +967,18 @@ __global__ void __launch_bounds__(GLS_THREADS) k_bz_gl_sort_team(const GlEntry *
 }
 
 // one round of the large groups (65 .. 8 192 rows): a workgroup per group, keys and rows in LDS, a bitonic network over them
+// (two instances over the same list: groups of up to 1 024 rows with 8 KB of LDS, many to a CU, and the few larger ones with 64 KB; a
+// workgroup whose entry belongs to the other instance leaves at once)
+template <uint32_t LO, uint32_t CAP>
 __global__ void __launch_bounds__(256) k_bz_gl_sort_wg(const GlEntry *__restrict__ list, const uint32_t *__restrict__ cnt_p, uint32_t h, uint32_t *__restrict__ sa,
                                                        const uint32_t *__restrict__ clr, uint32_t *__restrict__ clw, SubTab T, GlLists next) {
-  __shared__ uint32_t K[GL_MAX], V[GL_MAX];
+  __shared__ uint32_t K[CAP], V[CAP];
   __shared__ uint32_t lds[GL_NCL * 5];
   __shared__ uint32_t l17[17];
   if (blockIdx.x >= *cnt_p) return;
   uint32_t first, rows, sb;
   gl_unpack(list[blockIdx.x], first, rows, sb);
+  if (rows <= LO || rows > CAP) return;
   const uint32_t n = T.n[sb], off = T.off[sb];
   const int tid = threadIdx.x;
   if (h >= n) {                                        // (equal rotations: the group goes off the lists, its class in both arrays)
@@ -2294,7 +2298,10 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       if (gl_n[0]) hipLaunchKernelGGL(k_bz_gl_sort_small, dim3((gl_n[0] + GLS_THREADS * GLS_PER - 1) / (GLS_THREADS * GLS_PER)), dim3(GLS_THREADS), 0, st, cur.s, cur.cnt + 0, h, valA, clr, clw, T, nxt);
       if (gl_n[1]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_MID>), dim3((uint32_t)(((uint64_t)gl_n[1] * GL_MID + GLS_THREADS - 1) / GLS_THREADS)), dim3(GLS_THREADS), 0, st, cur.l[1], cur.cnt + 1, h, valA, clr, clw, T, nxt);
       if (gl_n[2]) hipLaunchKernelGGL((k_bz_gl_sort_team<(int)GL_WAVE>), dim3((uint32_t)(((uint64_t)gl_n[2] * GL_WAVE + GLS_THREADS - 1) / GLS_THREADS)), dim3(GLS_THREADS), 0, st, cur.l[2], cur.cnt + 2, h, valA, clr, clw, T, nxt);
-      if (gl_n[3]) hipLaunchKernelGGL(k_bz_gl_sort_wg, dim3(gl_n[3]), dim3(256), 0, st, cur.l[3], cur.cnt + 3, h, valA, clr, clw, T, nxt);
+      if (gl_n[3]) {
+        hipLaunchKernelGGL((k_bz_gl_sort_wg<0u, 1024u>), dim3(gl_n[3]), dim3(256), 0, st, cur.l[3], cur.cnt + 3, h, valA, clr, clw, T, nxt);
+        hipLaunchKernelGGL((k_bz_gl_sort_wg<1024u, GL_MAX>), dim3(gl_n[3]), dim3(256), 0, st, cur.l[3], cur.cnt + 3, h, valA, clr, clw, T, nxt);
+      }
       // sub-blocks whose unsorted groups have all become small leave the sweeps: their groups (classes of 2h bytes) join the lists
       if (swept && 2 * h >= (uint32_t)c->knob_bz_lists) {
         BZ_HIP(hipMemsetAsync(submax, 0, 4ull * nsb, st));
