@@ -679,7 +679,10 @@ __device__ __forceinline__ void gl_unpack(const GlEntry E, uint32_t &first, uint
 constexpr uint32_t GL_MID = 16;
 // the thread-per-group list (groups of up to 8 rows) has records of its own: the group's first two rows travel with the entry -- most
 // groups are pairs, and in text order (k_bz_gl_keys) fetching a pair's rows from the sorted order would be the one gather left
+// Bit 31 of v1 (element indices stay below 2^30): BOTH class arrays hold the group's class -- it was listed when the arrays were equal
+// (k_bz_gl_build) or has been through a round without coming apart; such a group has nothing to write while it stays whole.
 struct GlSmall { uint32_t first, sb_rows, v0, v1; };
+constexpr uint32_t GLS_BOTH = 0x80000000u;
 struct GlLists { GlEntry *l[GL_NCL]; GlSmall *s; uint32_t *cnt; uint32_t cap[GL_NCL]; };   // (l[0] is not used: list 0 is s)
 int gl_sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                   const void *vals_in, void *vals_out, size_t n, unsigned begin_bit, unsigned end_bit);   // zada_glsort.hip: 16-byte values   // cnt[0 .. 3]: entries of the lists; cnt[4]: overflow flag
@@ -801,7 +804,7 @@ __global__ void __launch_bounds__(1024) k_bz_gl_build(const uint32_t *__restrict
       const int kc = gl_class(rows);
       if (slot[kc] < L.cap[kc]) {
         const GlEntry e = gl_entry(first, rows, t.sb);
-        if (kc == 0) L.s[slot[0]] = GlSmall{e.first, e.sb_rows, sa[first], sa[first + 1]};
+        if (kc == 0) L.s[slot[0]] = GlSmall{e.first, e.sb_rows, sa[first], sa[first + 1] | GLS_BOTH};   // (cl2 := cl above: the arrays agree)
         else L.l[kc][slot[kc]] = e;
       }
       slot[kc]++;
@@ -836,6 +839,7 @@ __global__ void __launch_bounds__(GLS_THREADS) k_bz_gl_sort_small(const GlSmall 
   __shared__ uint32_t lds[GL_NCL * (GLS_THREADS / 64 + 1)];
   const uint32_t count = *cnt_p, g0 = (blockIdx.x * (uint32_t)GLS_THREADS + threadIdx.x) * (uint32_t)GLS_PER;
   uint32_t firstA[GLS_PER], packA[GLS_PER], endsA[GLS_PER], vA[GLS_PER][9];
+  bool wholeA[GLS_PER];
   GlSmall EA[GLS_PER];
 #pragma unroll
   for (int q = 0; q < GLS_PER; q++) { EA[q] = GlSmall{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu}; if (g0 + q < count) EA[q] = list[g0 + q]; }
@@ -850,10 +854,12 @@ __global__ void __launch_bounds__(GLS_THREADS) k_bz_gl_sort_small(const GlSmall 
     for (int j = 0; j < 8; j++) { k[j] = 0xFFFFFFFFu; v[j] = 0xFFFFFFFFu; }
     v[8] = 0xFFFFFFFFu;
     uint32_t ends = 0;                                 // groups for the next round: bit j set = a group ends behind row j
+    bool whole = false;
     if (rows == 1) clw[E.v0] = first;                  // a row that came to stand alone in the round before: its class, in the other array as well
     else if (rows > 1) {
       const uint32_t n = T.n[sb], off = T.off[sb];
-      v[0] = E.v0; v[1] = E.v1;
+      const bool both = (E.v1 & GLS_BOTH) != 0;
+      v[0] = E.v0; v[1] = E.v1 & ~GLS_BOTH;
 #pragma unroll
       for (int j = 2; j < 8; j++) if ((uint32_t)j < rows) v[j] = sa[first + j];
       if (h >= n) {                                    // the rotations of the group are equal: nothing is left to tell them apart, the group goes off the lists
@@ -871,19 +877,22 @@ __global__ void __launch_bounds__(GLS_THREADS) k_bz_gl_sort_small(const GlSmall 
 #undef CX
         }
         // rows in order; a row starts a new group where its key differs from the row before
+#pragma unroll
+        for (int j = 1; j < 8; j++) if ((uint32_t)j < rows && k[j] != k[j - 1]) ends |= 1u << (j - 1);
+        whole = ends == 0;                             // the group has not come apart: its class stays `first`
         uint32_t start = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           if ((uint32_t)j < rows) {
-            if (j > 0 && k[j] != k[j - 1]) { start = (uint32_t)j; ends |= 1u << (j - 1); }
+            if (j > 0 && ((ends >> (j - 1)) & 1u)) start = (uint32_t)j;
             if (moved) sa[first + j] = v[j];
-            clw[v[j]] = first + start;
+            if (!(whole && both)) clw[v[j]] = first + start;
           }
         }
         ends |= 1u << (rows - 1);
       }
     }
-    firstA[q] = first; packA[q] = E.sb_rows; endsA[q] = ends;
+    firstA[q] = first; packA[q] = E.sb_rows; endsA[q] = ends; wholeA[q] = whole;
 #pragma unroll
     for (int j = 0; j < 9; j++) vA[q][j] = v[j];
     total += (uint32_t)__popc(ends);
@@ -902,7 +911,8 @@ __global__ void __launch_bounds__(GLS_THREADS) k_bz_gl_sort_small(const GlSmall 
       if ((starts >> j) & 1u) {
         const uint32_t e = (uint32_t)__builtin_ctz(ends >> j) + (uint32_t)j;
         const GlEntry ge = gl_entry(firstA[q] + (uint32_t)j, e + 1u - (uint32_t)j, sb);
-        if (is < next.cap[0]) next.s[is] = GlSmall{ge.first, ge.sb_rows, vA[q][j], vA[q][j + 1]};
+        // (a group that is still whole has its class in both arrays after this round, whether it was written just now or before)
+        if (is < next.cap[0]) next.s[is] = GlSmall{ge.first, ge.sb_rows, vA[q][j], (vA[q][j + 1] & ~GLS_BOTH) | (wholeA[q] ? GLS_BOTH : 0u)};
         is++;
       }
     }
