@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(1024) k_bz_heads0(const uint32_t *__restrict__
 }
 // classes from the scanned head values of the first sort; the elements of groups of more than one row are marked (acte)
 __global__ void __launch_bounds__(1024) k_bz_set_class(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ hv, const uint32_t *__restrict__ hr,
-                                                       SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte, uint32_t ntiles_x) {
+                                                       SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint8_t *__restrict__ acte, uint32_t ntiles_x) {
   const uint32_t bx = xcd_tile(ntiles_x);
   if (bx >= ntiles_x) return;
   const Tile t = tiles[bx];
@@ -468,8 +468,8 @@ __global__ void __launch_bounds__(1024) k_bz_set_class(const uint32_t *__restric
 #pragma unroll
   for (int q = 0; q < PER; q++) {
     const uint32_t i = (uint32_t)q * 1024u + threadIdx.x;
-    if (i < m) cl[e8[q]] = c8[q];
-    if (act8[q]) atomicOr(&acte[e8[q] >> 5], 1u << (e8[q] & 31));
+    // (the marks are bytes: every element gets its own, a plain store -- as bits they were 535 M scattered atomics and a memset)
+    if (i < m) { cl[e8[q]] = c8[q]; acte[e8[q]] = act8[q] ? 1 : 0; }
   }
 }
 // A doubling round only moves the rows of groups that still have more than one row.  The rows, read in order and shifted
@@ -478,17 +478,17 @@ __global__ void __launch_bounds__(1024) k_bz_set_class(const uint32_t *__restric
 // written back to the group's rows.
 // pass 1: per tile of rows, how many survive the filter; pass 2 (after a scan of the tile counts) writes them in order.  Both
 // read the rows and the mark of the shifted element; nothing per row is stored in between.
-__device__ __forceinline__ uint32_t bz_shifted_active(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, uint32_t g, uint32_t off, uint32_t n,
+__device__ __forceinline__ uint32_t bz_shifted_active(const uint32_t *__restrict__ sa, const uint8_t *__restrict__ acte, uint32_t g, uint32_t off, uint32_t n,
                                                        uint32_t h, uint32_t *e_out) {
   uint32_t l = sa[g] - off;
   l = l >= h ? l - h : l + n - h;               // h < n for a sub-block that is not done
   const uint32_t e = off + l;
   *e_out = e;
-  return (acte[e >> 5] >> (e & 31)) & 1u;
+  return acte[e];
 }
 // the same for a thread's eight consecutive rows r0 .. r0+7 of the tile (those below m): the rows first, then the marks -- two round trips,
 // not sixteen.  Bit k of the result: row r0+k exists and its shifted element is marked; ev[k] = that element.
-__device__ __forceinline__ uint32_t bz_shifted_active8(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, uint32_t g0, uint32_t r0, uint32_t m,
+__device__ __forceinline__ uint32_t bz_shifted_active8(const uint32_t *__restrict__ sa, const uint8_t *__restrict__ acte, uint32_t g0, uint32_t r0, uint32_t m,
                                                         uint32_t off, uint32_t n, uint32_t h, uint32_t (&ev)[8]) {
   uint32_t r[8], a[8];
 #pragma unroll
@@ -498,14 +498,14 @@ __device__ __forceinline__ uint32_t bz_shifted_active8(const uint32_t *__restric
     uint32_t l = r[k] - off;
     l = l >= h ? l - h : l + n - h;             // h < n for a sub-block that is not done
     ev[k] = off + l;
-    a[k] = acte[ev[k] >> 5];
+    a[k] = acte[ev[k]];
   }
   uint32_t fl = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) if (r0 + k < m && ((a[k] >> (ev[k] & 31)) & 1u)) fl |= 1u << k;
+  for (int k = 0; k < 8; k++) if (r0 + k < m && a[k]) fl |= 1u << k;
   return fl;
 }
-__global__ void __launch_bounds__(1024) k_bz_filter_count(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, SubTab T, const Tile *__restrict__ tiles,
+__global__ void __launch_bounds__(1024) k_bz_filter_count(const uint32_t *__restrict__ sa, const uint8_t *__restrict__ acte, SubTab T, const Tile *__restrict__ tiles,
                                                           const uint8_t *__restrict__ done, uint32_t h, uint32_t *__restrict__ tile_cnt, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
   const uint32_t bx = xcd_tile(ntiles_x);
@@ -530,7 +530,7 @@ __global__ void k_bz_counts(SubTab T, const uint32_t *__restrict__ first_tile, c
   coff[s] = a; cm[s] = b - a;
   if (s + 1 == T.nsb) coff[s + 1] = b;
 }
-__global__ void __launch_bounds__(1024) k_bz_filter_emit(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ acte, const uint32_t *__restrict__ cl, SubTab T,
+__global__ void __launch_bounds__(1024) k_bz_filter_emit(const uint32_t *__restrict__ sa, const uint8_t *__restrict__ acte, const uint32_t *__restrict__ cl, SubTab T,
                                                          const Tile *__restrict__ tiles, const uint8_t *__restrict__ done, uint32_t h,
                                                          const uint32_t *__restrict__ tscan, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(1024) k_bz_place(const uint32_t *__restrict__ 
   if (threadIdx.x == 0) agg_out[bx] = tot;
 }
 __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict__ cval, const uint32_t *__restrict__ hd, const uint32_t *__restrict__ carry_hd, SubTab C,
-                                                      const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint32_t *__restrict__ acte, uint32_t ntiles_x) {
+                                                      const Tile *__restrict__ tiles, uint32_t *__restrict__ cl, uint8_t *__restrict__ acte, uint32_t ntiles_x) {
   __shared__ uint32_t l17[17];
   const uint32_t bx = xcd_tile(ntiles_x);
   if (bx >= ntiles_x) return;
@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict
       const uint32_t e = ee[k];
       if (hv[k]) run = hv[k];
       cl[e] = run - 1;
-      if (hv[k] != 0 && hv[k + 1] != 0) atomicAnd(&acte[e >> 5], ~(1u << (e & 31)));
+      if (hv[k] != 0 && hv[k + 1] != 0) acte[e] = 0;
     }
   }
 }
@@ -2199,7 +2199,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   if ((rc = dbuf_ensure(c, B->keyA, 4 * ne)) || (rc = dbuf_ensure(c, B->keyB, 4 * ne)) || (rc = dbuf_ensure(c, B->valA, 4 * ne)) ||
       (rc = dbuf_ensure(c, B->valB, 4 * ne)) || (rc = dbuf_ensure(c, B->cl, 4 * ne)) || (rc = dbuf_ensure(c, B->hv, 4 * ne)) ||
       (rc = dbuf_ensure(c, B->hr, 4 * ne)) || (rc = dbuf_ensure(c, B->H, 4096ull * (net + nsb) + 4096)) || (rc = dbuf_ensure(c, B->gl_tmp, 4 * ne)) || (rc = dbuf_ensure(c, B->cv0, 4 * ne)) ||
-      (rc = dbuf_ensure(c, B->cv1, 4 * ne)) || (rc = dbuf_ensure(c, B->acte, 4 * (ne / 32 + 4))) || (rc = dbuf_ensure(c, B->coff, 4ull * (nsb + 2))) ||
+      (rc = dbuf_ensure(c, B->cv1, 4 * ne)) || (rc = dbuf_ensure(c, B->acte, ne + 64)) || (rc = dbuf_ensure(c, B->coff, 4ull * (nsb + 2))) ||
       (rc = dbuf_ensure(c, B->cm, 4ull * (nsb + 2))) || (rc = dbuf_ensure(c, B->ctile_first, 4ull * (nsb + 2))) ||
       (rc = dbuf_ensure(c, B->agg, 4ull * ((1024ull * net + ne) / SC_TILE + 16)))) return rc;
   BZ_HIP(hipStreamSynchronize(st));   // rt / et vectors go out of scope
@@ -2209,7 +2209,8 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   const uint32_t *EF = B->etile_first.as<uint32_t>();
   uint8_t *done = B->done.as<uint8_t>();
   uint32_t *keyA = B->keyA.as<uint32_t>(), *keyB = B->keyB.as<uint32_t>(), *valA = B->valA.as<uint32_t>(), *valB = B->valB.as<uint32_t>();
-  uint32_t *cv0 = B->cv0.as<uint32_t>(), *cv1 = B->cv1.as<uint32_t>(), *acte = B->acte.as<uint32_t>();
+  uint32_t *cv0 = B->cv0.as<uint32_t>(), *cv1 = B->cv1.as<uint32_t>();
+  uint8_t *acte = B->acte.as<uint8_t>();                 // one byte per element: it belongs to a group of more than one row
   uint32_t *H = B->H.as<uint32_t>(), *agg = B->agg.as<uint32_t>(), *hv = B->hv.as<uint32_t>(), *hr = B->hr.as<uint32_t>(), *cl = B->cl.as<uint32_t>();
   auto radix = [&](const SubTab &S, const Tile *tl, const uint32_t *tf, uint32_t nt, const uint32_t *ki, const uint32_t *vi, uint32_t *ko, uint32_t *vo, int shift) {
     hipLaunchKernelGGL(k_bz_radix_hist<8>, dim3(xcd_grid(nt)), dim3(1024), 0, st, ki, S, tl, tf, done, shift, H, nt);
@@ -2224,7 +2225,6 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   B->m_hist.clear();
   B->m_hist.push_back(tot);
   // first sort: four bytes
-  BZ_HIP(hipMemsetAsync(acte, 0, 4 * ((size_t)tot / 32 + 2), st));
   hipLaunchKernelGGL(k_bz_bwt_init, dim3(xcd_grid(net)), dim3(1024), 0, st, B->rle.as<uint8_t>(), T, ET, keyA, valA, net);
   radix(T, ET, EF, net, keyA, valA, keyB, valB, 0); radix(T, ET, EF, net, keyB, valB, keyA, valA, 8);
   radix(T, ET, EF, net, keyA, valA, keyB, valB, 16); radix(T, ET, EF, net, keyB, valB, keyA, valA, 24);
