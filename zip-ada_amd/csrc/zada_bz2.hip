@@ -362,7 +362,13 @@ __global__ void __launch_bounds__(1024) k_bz_radix_hist(const uint32_t *__restri
   const uint32_t n = T.n[t.sb], base = T.off[t.sb] + t.lo, m = done[t.sb] ? 0u : min((uint32_t)BW_TILE, n - t.lo);
   if (threadIdx.x < NB) cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) atomicAdd(&cnt[(key[base + i] >> shift) & (NB - 1u)], 1u);
+  {
+    uint32_t kx[BW_TILE / 1024];                       // (the eight loads together, then the counts)
+#pragma unroll
+    for (int q = 0; q < BW_TILE / 1024; q++) { const uint32_t i = (uint32_t)q * 1024u + threadIdx.x; kx[q] = key[base + (i < m ? i : 0u)]; }
+#pragma unroll
+    for (int q = 0; q < BW_TILE / 1024; q++) if ((uint32_t)q * 1024u + threadIdx.x < m) atomicAdd(&cnt[(kx[q] >> shift) & (NB - 1u)], 1u);
+  }
   __syncthreads();
   if (threadIdx.x < NB) {
     const uint32_t t0 = first_tile[t.sb], ts = first_tile[t.sb + 1] - t0;
@@ -441,9 +447,16 @@ __global__ void __launch_bounds__(1024) k_bz_heads0(const uint32_t *__restrict__
   const Tile t = tiles[bx];
   if (done[t.sb]) return;
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, g = off + l;
-    hv[g] = (l == 0 || key[g] != key[g - 1]) ? g + 1 : 0u;
+  uint32_t k0[BW_TILE / 1024], k1[BW_TILE / 1024];   // (loads before stores)
+#pragma unroll
+  for (int q = 0; q < BW_TILE / 1024; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, l = t.lo + (i < m ? i : 0u), g = off + l;
+    k0[q] = key[g]; k1[q] = key[l ? g - 1 : g];
+  }
+#pragma unroll
+  for (int q = 0; q < BW_TILE / 1024; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, l = t.lo + i, g = off + l;
+    if (i < m) hv[g] = (l == 0 || k0[q] != k1[q]) ? g + 1 : 0u;
   }
 }
 // classes from the scanned head values of the first sort; the elements of groups of more than one row are marked (acte)
@@ -1062,10 +1075,15 @@ __global__ void __launch_bounds__(1024) k_bz_bwt_out(const uint8_t *__restrict__
   if (bx >= ntiles_x) return;
   const Tile t = tiles[bx];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t g = off + t.lo + i, l = sa[g] - off;
-    bwt[g] = rle[off + (l == 0 ? n - 1 : l - 1)];
-  }
+  constexpr int PER = BW_TILE / 1024;                  // (rows, then bytes, then stores)
+  uint32_t r[PER];
+  uint8_t b[PER];
+#pragma unroll
+  for (int q = 0; q < PER; q++) { const uint32_t i = (uint32_t)q * 1024u + threadIdx.x; r[q] = sa[off + t.lo + (i < m ? i : 0u)] - off; }
+#pragma unroll
+  for (int q = 0; q < PER; q++) b[q] = rle[off + (r[q] == 0 ? n - 1 : r[q] - 1)];
+#pragma unroll
+  for (int q = 0; q < PER; q++) { const uint32_t i = (uint32_t)q * 1024u + threadIdx.x; if (i < m) bwt[off + t.lo + i] = b[q]; }
   if (t.lo == 0 && threadIdx.x == 0) T.bwt_index[t.sb] = cl[off] - off;
 }
 
@@ -1218,9 +1236,13 @@ __global__ void __launch_bounds__(64) k_bz_mtf_apply(const uint8_t *__restrict__
 __global__ void __launch_bounds__(1024) k_bz_rle2_val(const uint8_t *__restrict__ idx, SubTab T, const Tile *__restrict__ tiles, uint32_t *__restrict__ v) {
   const Tile t = tiles[blockIdx.x];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, g = off + l;
-    v[g] = idx[g] != 0 ? g + 1 : (l == 0 ? g : 0u);
+  uint8_t x[BW_TILE / 1024];                           // (loads before stores)
+#pragma unroll
+  for (int q = 0; q < BW_TILE / 1024; q++) { const uint32_t i = (uint32_t)q * 1024u + threadIdx.x; x[q] = idx[off + t.lo + (i < m ? i : 0u)]; }
+#pragma unroll
+  for (int q = 0; q < BW_TILE / 1024; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, l = t.lo + i, g = off + l;
+    if (i < m) v[g] = x[q] != 0 ? g + 1 : (l == 0 ? g : 0u);
   }
 }
 // symbols produced at element g: 1 for a non-zero index, the run's binary digits at the end of a zero run (:363-379)
@@ -1228,14 +1250,23 @@ __global__ void __launch_bounds__(1024) k_bz_rle2_cnt(const uint8_t *__restrict_
                                                       uint32_t *__restrict__ cnt) {
   const Tile t = tiles[blockIdx.x];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, g = off + l;
+  constexpr int PER = BW_TILE / 1024;                  // (loads before stores)
+  uint8_t x0[PER], x1[PER];
+  uint32_t r[PER];
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, l = t.lo + (i < m ? i : 0u), g = off + l;
+    x0[q] = idx[g]; x1[q] = l + 1 == n ? 1 : idx[g + 1]; r[q] = rs[g];
+  }
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, g = off + t.lo + i;
     uint32_t c = 1;
-    if (idx[g] == 0) {
+    if (x0[q] == 0) {
       c = 0;
-      if (l + 1 == n || idx[g + 1] != 0) { const uint32_t run = g - rs[g] + 1; c = 31 - __clz(run + 1); }
+      if (x1[q] != 0) { const uint32_t run = g - r[q] + 1; c = 31 - __clz(run + 1); }
     }
-    cnt[g] = c;
+    if (i < m) cnt[g] = c;
   }
 }
 // symbol space: sub-block s owns [soff[s], soff[s] + mtf_n[s]); the sub-blocks follow each other with at most two symbols between them
@@ -1254,13 +1285,24 @@ __global__ void __launch_bounds__(1024) k_bz_rle2_emit(const uint8_t *__restrict
   const Tile t = tiles[blockIdx.x];
   const uint32_t n = T.n[t.sb], off = T.off[t.sb], m = min((uint32_t)BW_TILE, n - t.lo);
   const uint32_t base = soff[t.sb] - P[off];
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    const uint32_t l = t.lo + i, g = off + l;
-    const uint32_t x = idx[g];
-    if (x != 0) sym[base + P[g]] = (uint16_t)(x + 1);
-    else if (l + 1 == n || idx[g + 1] != 0) {
-      uint32_t rc = g - rs[g] + 2, o = base + P[g];
-      do { sym[o++] = (uint16_t)(rc & 1u); rc >>= 1; } while (rc >= 2);
+  constexpr int PER = BW_TILE / 1024;                  // (loads before stores)
+  uint8_t x0[PER], x1[PER];
+  uint32_t r[PER], pp[PER];
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, l = t.lo + (i < m ? i : 0u), g = off + l;
+    x0[q] = idx[g]; x1[q] = l + 1 == n ? 1 : idx[g + 1]; r[q] = rs[g]; pp[q] = P[g];
+  }
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const uint32_t i = (uint32_t)q * 1024u + threadIdx.x, g = off + t.lo + i;
+    if (i < m) {
+      const uint32_t x = x0[q];
+      if (x != 0) sym[base + pp[q]] = (uint16_t)(x + 1);
+      else if (x1[q] != 0) {
+        uint32_t rc = g - r[q] + 2, o = base + pp[q];
+        do { sym[o++] = (uint16_t)(rc & 1u); rc >>= 1; } while (rc >= 2);
+      }
     }
   }
 }
