@@ -171,12 +171,20 @@ struct RleThread {
 // `dst` is non-null also writes them at dst[prefix ...] (prefix = exclusive scan of the emit counts, computed inside).
 template <bool EMIT>
 __device__ __forceinline__ uint32_t rle1_tile(const uint8_t *__restrict__ raw, uint32_t len, uint32_t lo, uint32_t carry_rs1, uint32_t *l17,
-                                              uint8_t *__restrict__ dst, uint32_t dst_base, uint32_t *inuse8) {
+                                              uint8_t *__restrict__ dst, uint32_t dst_base, uint8_t *seen /* [256], LDS: byte values that occur */) {
   const int tid = threadIdx.x;
   const uint32_t p0 = lo + (uint32_t)tid * 32;
   uint8_t b[34];   // b[0] = byte before the thread's first, b[1..32] = the thread's bytes, b[33] = byte after
+  if (p0 >= 4 && (uint64_t)p0 + 36 <= (uint64_t)len) {
+    // (inside the sub-block: ten words instead of 34 byte loads)
+    uint32_t w[10];
+    __builtin_memcpy(w, raw + p0 - 4, 40);
 #pragma unroll
-  for (int k = 0; k < 34; k++) { const int64_t p = (int64_t)p0 + k - 1; b[k] = (p >= 0 && p < (int64_t)len) ? raw[p] : 0; }
+    for (int k = 0; k < 34; k++) b[k] = (uint8_t)(w[(k + 3) >> 2] >> (8 * ((k + 3) & 3)));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 34; k++) { const int64_t p = (int64_t)p0 + k - 1; b[k] = (p >= 0 && p < (int64_t)len) ? raw[p] : 0; }
+  }
   // last run start (sub-block offset + 1, 0 = none) among the thread's bytes
   uint32_t last = 0;
 #pragma unroll
@@ -209,7 +217,7 @@ __device__ __forceinline__ uint32_t rle1_tile(const uint8_t *__restrict__ raw, u
   if ((tid & 63) == 0) { pre = 0; for (int k = 0; k < (tid >> 6); k++) pre += l17[k]; }
   for (uint32_t k = 0; k < emits; k++) {
     dst[dst_base + pre + k] = outb[k];
-    atomicOr(&inuse8[outb[k] >> 5], 1u << (outb[k] & 31));
+    seen[outb[k]] = 1;                                 // (plain stores of the same value: as atomics on eight words every byte queued behind its neighbours)
   }
   return emits;
 }
@@ -279,14 +287,19 @@ __global__ void __launch_bounds__(64) k_bz_tile_scan(const uint32_t *__restrict_
 __global__ void __launch_bounds__(256) k_bz_rle_emit(const uint8_t *__restrict__ in, SubTab T, const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_rs,
                                                      const uint32_t *__restrict__ tile_off, uint8_t *__restrict__ rle) {
   __shared__ uint32_t l17[17];
-  __shared__ uint32_t use8[8];
+  __shared__ uint8_t seen[256];
   const Tile t = tiles[blockIdx.x];
-  if (threadIdx.x < 8) use8[threadIdx.x] = 0;
+  seen[threadIdx.x] = 0;                               // (256 threads)
   __syncthreads();
   const uint8_t *raw = in + T.raw_start[t.sb];
-  rle1_tile<true>(raw, T.raw_len[t.sb], t.lo, tile_rs[blockIdx.x], l17, rle, T.off[t.sb] + tile_off[blockIdx.x], use8);
+  rle1_tile<true>(raw, T.raw_len[t.sb], t.lo, tile_rs[blockIdx.x], l17, rle, T.off[t.sb] + tile_off[blockIdx.x], seen);
   __syncthreads();
-  if (threadIdx.x < 8 && use8[threadIdx.x]) atomicOr(&T.inuse[t.sb * 8 + threadIdx.x], use8[threadIdx.x]);
+  {
+    const unsigned long long mk = __ballot(seen[threadIdx.x] != 0);               // wave w holds the byte values 64 w .. 64 w + 63
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0 && (uint32_t)mk) atomicOr(&T.inuse[t.sb * 8 + 2 * w], (uint32_t)mk);
+    if (lane == 1 && (uint32_t)(mk >> 32)) atomicOr(&T.inuse[t.sb * 8 + 2 * w + 1], (uint32_t)(mk >> 32));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
