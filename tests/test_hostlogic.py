@@ -153,3 +153,15 @@ def test_bench_starts_its_own_ranks_and_fails_loudly():
     assert r.returncode != 0 and "--gpus 4 but the launcher started 2 ranks" in r.stderr
     r = subprocess.run([sys.executable, bench, "--gpus", "0"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "at least 1" in r.stderr
+
+
+def test_every_knob_is_documented_in_the_header():
+    """zada_set_knob's names (zada_api.hip) all appear in include/zada.h, where an integrator looks for them."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "zip-ada_amd", "csrc", "zada_api.hip")).read()
+    hdr = open(os.path.join(root, "include", "zada.h")).read()
+    names = set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', api))
+    assert len(names) >= 15
+    missing = sorted(n for n in names if '"%s"' % n not in hdr)
+    assert not missing, missing
