@@ -153,6 +153,10 @@ int zo_lzma_encode(const uint8_t *in, uint64_t n, int level, int lc, int lp, int
  * LZMA header, stream with end marker).  Return codes as zo_deflate. */
 int zo_lzma(const uint8_t *in, uint64_t n, int method, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
 
+/* Stage export: the match sets of BT4_Algo.Read_One_and_Get_Matches (lz77.adb:1234-1361) at every position of the input, the window
+ * filled as LZ77_using_BT4 fills it; cnt [n], len / dist [n * stride] (stride >= 50: two hash matches + Depth_Limit tree matches). */
+int zo_bt4_match_sets(const uint8_t *in, uint64_t n, int64_t dictionary_size, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride);
+
 #ifdef __cplusplus
 }
 #endif

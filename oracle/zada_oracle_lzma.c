@@ -1119,10 +1119,10 @@ static void Get_Next_Symbol(BT4 *B) {   /* :1605-1796 */
   Send_DL_code(B, main.distance, main.length);
 }
 
-static int LZ77_using_BT4(Lz *L, int String_buffer_size, int Look_Ahead, int Threshold) {
+/* The set-up of LZ77_using_BT4 (lz77.adb:953-1126, 1798-1810): window sizes, hash tables, tree. */
+static BT4 *bt4_open(Lz *L, int String_buffer_size, int Look_Ahead, int Threshold) {
   BT4 *B = (BT4 *)calloc(1, sizeof(BT4));
-  int actual_written, rc = ZO_OK;
-  if (!B) return ZO_ENOMEM;
+  if (!B) return NULL;
   B->L = L; B->String_buffer_size = String_buffer_size; B->Look_Ahead = Look_Ahead; B->Threshold = Threshold;
   B->MATCH_LEN_MIN = Threshold + 1;
   B->readPos = -1; B->readLimit = -1; B->writePos = 0; B->pendingSize = 0;
@@ -1151,11 +1151,23 @@ static int LZ77_using_BT4(Lz *L, int String_buffer_size, int Look_Ahead, int Thr
   B->max_dist = B->cyclicSize - (Look_Ahead + 2);
   B->buf = (uint8_t *)calloc((size_t)B->buf_len + 8, 1);
   B->tree = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)B->cyclicSize);
-  if (!B->hash2Table || !B->hash3Table || !B->hash4Table || !B->buf || !B->tree) { rc = ZO_ENOMEM; goto done; }
+  if (!B->hash2Table || !B->hash3Table || !B->hash4Table || !B->buf || !B->tree) return B;   /* (the caller tests the tables) */
   for (int64_t i = 0; i < 2 * (int64_t)B->cyclicSize; i++) B->tree[i] = Null_position;
   B->readAhead = -1;
   for (int i = 0; i < 4; i++) { B->rep_dist[i] = 1; B->len_rep_dist[i] = 0; }
   B->current_match_index = 0;
+  return B;
+}
+static int bt4_ready(const BT4 *B) { return B && B->hash2Table && B->hash3Table && B->hash4Table && B->buf && B->tree; }
+static void bt4_close(BT4 *B) {
+  if (!B) return;
+  free(B->hash2Table); free(B->hash3Table); free(B->hash4Table); free(B->buf); free(B->tree); free(B);
+}
+
+static int LZ77_using_BT4(Lz *L, int String_buffer_size, int Look_Ahead, int Threshold) {
+  BT4 *B = bt4_open(L, String_buffer_size, Look_Ahead, Threshold);
+  int actual_written, rc = ZO_OK;
+  if (!bt4_ready(B)) { rc = ZO_ENOMEM; goto done; }
   actual_written = Fill_Window(B, String_buffer_size);
   if (actual_written > 0) {
     for (;;) {
@@ -1167,7 +1179,43 @@ static int LZ77_using_BT4(Lz *L, int String_buffer_size, int Look_Ahead, int Thr
     }
   }
 done:
-  free(B->hash2Table); free(B->hash3Table); free(B->hash4Table); free(B->buf); free(B->tree); free(B);
+  bt4_close(B);
+  return rc;
+}
+
+/* Stage export for the tests: the match set BT4_Algo.Read_One_and_Get_Matches (lz77.adb:1234-1361) returns at EVERY position of the
+   input when every position is read (none skipped), with the window filled as LZ77_using_BT4's main loop fills it (:1798-1827) --
+   Skip (:1208-1232) and Read_One share the tree update (:1154-1206), so the tree after position p, hence every set, does not depend
+   on which positions the coder reads and which it skips.  cnt [p] = number of matches at p; len / dist [p * stride + i], i < cnt [p].
+   sbs = the String_buffer_size of Level_3 for this dictionary_size (lzma-encoding.adb:137-149). */
+int zo_bt4_match_sets(const uint8_t *in, uint64_t n, int64_t dictionary_size, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride) {
+  Lz *L = (Lz *)calloc(1, sizeof(Lz));
+  BT4 *B;
+  int64_t sbs;
+  uint64_t p = 0;
+  int rc = ZO_OK;
+  Matches_Type *m = (Matches_Type *)malloc(sizeof(Matches_Type));
+  if (!L || !m) { free(L); free(m); return ZO_ENOMEM; }
+  sbs = Ceiling_power_of_2(dictionary_size + 273 + 1 + 64);
+  if (sbs > (1 << 28)) sbs = 1 << 28;
+  if (sbs < Min_dictionary_size) sbs = Min_dictionary_size;
+  L->in = in; L->n = n;
+  B = bt4_open(L, (int)sbs, 273, 1);
+  if (!bt4_ready(B)) { rc = ZO_ENOMEM; goto done; }
+  memset(cnt, 0, (size_t)n);
+  if (Fill_Window(B, (int)sbs) > 0) {
+    for (;;) {
+      BT4_Read_One_and_Get_Matches(B, m);
+      if (p >= n || m->count > stride) { rc = ZO_EINVAL; goto done; }
+      cnt[p] = (uint8_t)m->count;
+      for (int i = 1; i <= m->count; i++) { len[p * (uint64_t)stride + (i - 1)] = (uint16_t)m->dl[i].length; dist[p * (uint64_t)stride + (i - 1)] = (uint32_t)m->dl[i].distance; }
+      p++;
+      if (Get_Available(B) == 0 && Fill_Window(B, (int)sbs) == 0) break;
+    }
+  }
+  if (p != n) rc = ZO_EINVAL;
+done:
+  bt4_close(B); free(m); free(L);
   return rc;
 }
 

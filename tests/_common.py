@@ -75,12 +75,14 @@ def hostcheck():
         src = os.path.join(d, "hostcheck.cpp")
         hdr = os.path.join(ROOT, "zip-ada_amd", "csrc", "zada_logic.h")
         hdr2 = os.path.join(d, "hostcheck_logic.h")
-        if not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
+        hdr3 = os.path.join(ROOT, "zip-ada_amd", "csrc", "zada_bt4.h")
+        if not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(f) for f in (src, hdr, hdr2, hdr3)):
             subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", p, src], check=True)
         H = ctypes.CDLL(p)
         H.hc_chunked_tokens.restype = ctypes.c_uint64
         H.hc_chunked_tokens.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int)]
         H.hc_header_bits.restype = ctypes.c_uint32
+        H.hc_bt4_sets.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]
         _cache["h"] = H
     return _cache["h"]
 

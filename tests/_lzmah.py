@@ -27,6 +27,7 @@ def lz_oracle():
         O.zo_lzma_encode.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int64, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), vp]
         O.zo_lzma.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+        O.zo_bt4_match_sets.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int64, vp, vp, vp, ctypes.c_int]
         O._lz_ready = True
     return O
 
@@ -67,3 +68,25 @@ def lzma_decode(stream, skip=0):
     out = d.decompress(s[5:])
     assert d.eof, "no end-of-stream marker met"
     return out
+
+
+BT4_SET = 50                             # most matches of one position (zada_bt4.h): two hash matches + Depth_Limit tree matches
+
+
+def oracle_bt4_sets(data, dictionary_size=None):
+    """The match sets of BT4_Algo.Read_One_and_Get_Matches at every position (oracle stage export) -> cnt [n], len [n, 50], dist [n, 50]."""
+    O = lz_oracle()
+    data = bytes(data)
+    n = len(data)
+    cnt = np.zeros(n, np.uint8); ln = np.zeros((n, BT4_SET), np.uint16); ds = np.zeros((n, BT4_SET), np.uint32)
+    rc = O.zo_bt4_match_sets(data, n, n if dictionary_size is None else dictionary_size, cnt.ctypes.data, ln.ctypes.data, ds.ctypes.data, BT4_SET)
+    assert rc == 0, rc
+    return cnt, ln, ds
+
+
+def sets_equal(a, b):
+    """Two (cnt, len, dist) triples hold the same sets (slots beyond cnt are not compared)."""
+    if not np.array_equal(a[0], b[0]):
+        return False
+    live = np.arange(BT4_SET)[None, :] < a[0][:, None]
+    return bool(np.array_equal(a[1][live], b[1][live]) and np.array_equal(a[2][live], b[2][live]))

@@ -5,6 +5,9 @@
 #include <string.h>
 #include <vector>
 #include "hostcheck_logic.h"
+#include "../../zip-ada_amd/csrc/zada_bt4.h"
+#include <algorithm>
+#include <numeric>
 using namespace zada;
 
 extern "C" {
@@ -153,4 +156,58 @@ extern "C" void hc_llhc_pm(const uint32_t *freq, int n, int max_bits, uint8_t *b
     x = 2 * (x - a);
   }
   for (int r = 0; r < ns; r++) { int len = 0; for (int l = 1; l <= max_bits; l++) if (acnt[l] > r) len++; bl[s[r]] = (uint8_t)len; }
+}
+
+// The producer form of BT4 (zada_bt4.h) on the CPU, the way the kernels of zada_bt4.hip run it: hashes of the inserted positions,
+// three stable sorts (hash2 / hash3 predecessors, hash-4 buckets), then every bucket on its own -- in a SHUFFLED order of the buckets
+// (seed), to show that the buckets do not depend on each other.  Same outputs as the oracle's zo_bt4_match_sets.  Returns 0, or -1 when
+// the schedule is refused.
+extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride, uint32_t seed) {
+  const uint32_t sbs = bt4_string_buffer_size((uint64_t)dict), mask = bt4_hash4_size(sbs) - 1;
+  const int32_t max_dist = (int32_t)sbs - (BT4_LOOK + 2);
+  std::vector<Bt4Run> runs;
+  if (!bt4_schedule(n, sbs, runs)) return -1;
+  memset(cnt, 0, n);
+  std::vector<uint32_t> pos, h2, h3, h4;
+  for (uint64_t q = 0; q < n; q++) {
+    const Bt4Run *r = bt4_run_of(runs.data(), (uint32_t)runs.size(), (uint32_t)q);
+    if (r->cls == 2) continue;
+    uint32_t a, b, c;
+    bt4_hashes(bt4_crc(in[q]), in[q + 1], in[q + 2], bt4_crc(in[q + 3]), mask, a, b, c);
+    pos.push_back((uint32_t)q); h2.push_back(a); h3.push_back(b); h4.push_back(c);
+  }
+  const size_t m = pos.size();
+  auto ord_of = [&](uint32_t q) { return (int32_t)(q - bt4_run_of(runs.data(), (uint32_t)runs.size(), q)->gap); };
+  std::vector<int32_t> o2(n, BT4_NONE), o3(n, BT4_NONE);
+  std::vector<uint32_t> idx(m);
+  auto preds = [&](const std::vector<uint32_t> &h, std::vector<int32_t> &o) {
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return h[x] < h[y]; });
+    for (size_t i = 1; i < m; i++) if (h[idx[i]] == h[idx[i - 1]]) o[pos[idx[i]]] = ord_of(pos[idx[i - 1]]);
+  };
+  preds(h2, o2); preds(h3, o3);
+  std::iota(idx.begin(), idx.end(), 0u);
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return h4[x] < h4[y]; });
+  std::vector<std::pair<size_t, size_t>> buckets;
+  for (size_t i = 0; i < m;) { size_t j = i + 1; while (j < m && h4[idx[j]] == h4[idx[i]]) j++; buckets.push_back({i, j}); i = j; }
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+  for (size_t i = buckets.size(); i > 1; i--) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(buckets[i - 1], buckets[x % i]); }
+  std::vector<int32_t> tree(2 * n + 2, 12345);       // (never read before written: a walk only reaches nodes of its own bucket)
+  uint16_t ml[BT4_SET]; uint32_t md[BT4_SET];
+  auto ext = [](const uint8_t *b, int64_t a, int64_t c, int l, int lim) { return bt4_extend(b, a, c, l, lim); };
+  for (auto &bk : buckets) {
+    int32_t root = BT4_NONE;
+    for (size_t i = bk.first; i < bk.second; i++) {
+      const uint32_t q = pos[idx[i]];
+      const Bt4Run *r = bt4_run_of(runs.data(), (uint32_t)runs.size(), q);
+      const int32_t ordp = (int32_t)(q - r->gap);
+      const int avail = (int)(r->W - q - 1), limit = avail < BT4_LOOK ? avail : BT4_LOOK;
+      const int c = bt4_visit(in, q, ordp, r->cls == 0, limit, max_dist, tree.data(), root, o2[q], o3[q], ml, md, ext);
+      if (c > stride) return -2;
+      cnt[q] = (uint8_t)c;
+      for (int k = 0; k < c; k++) { len[(uint64_t)q * stride + k] = ml[k]; dist[(uint64_t)q * stride + k] = md[k]; }
+      root = ordp;
+    }
+  }
+  return 0;
 }

@@ -1,0 +1,40 @@
+"""BT4 as a producer of match sets (zip-ada_amd/csrc/zada_bt4.h, compiled for the host by tests/hostcheck -- a TEST library): one lane
+per hash-4 bucket, the hash-2 / hash-3 heads as predecessors in a stable sort, the window fills replayed by the host -- against the
+oracle's sequential BT4 (lz77.adb:953-1827, every position read: zo_bt4_match_sets).  The buckets are walked in a shuffled order."""
+import numpy as np
+import pytest
+
+from _common import hostcheck
+from _lzmah import BT4_SET, lz_inputs, oracle_bt4_sets, sets_equal
+
+
+def producer_sets(data, dictionary_size=None, seed=1):
+    H = hostcheck()
+    n = len(data)
+    cnt = np.zeros(n, np.uint8); ln = np.zeros((n, BT4_SET), np.uint16); ds = np.zeros((n, BT4_SET), np.uint32)
+    rc = H.hc_bt4_sets(bytes(data), n, n if dictionary_size is None else dictionary_size, cnt.ctypes.data, ln.ctypes.data, ds.ctypes.data, BT4_SET, seed)
+    assert rc == 0, rc
+    return cnt, ln, ds
+
+
+# dictionary_size None = the entry's size (what Zip.Compress.LZMA_E asks, zip-compress-lzma_e.adb:165); 3000 -> String_buffer_size 4096
+# (the pending bytes never catch up: gaps in the ordinals), 5000 -> 8192, 20 000 / 100 000: several fills, window moves.
+@pytest.mark.parametrize("dictionary_size", [None, 3000, 5000, 20000, 100000])
+def test_producer_sets_equal_the_sequential_matcher(dictionary_size):
+    seen = 0
+    for name, d in lz_inputs().items():
+        if dictionary_size and dictionary_size >= len(d) and dictionary_size != 3000:
+            continue
+        a = oracle_bt4_sets(d, dictionary_size)
+        b = producer_sets(d, dictionary_size, seed=len(d) + (dictionary_size or 0))
+        assert sets_equal(a, b), (name, len(d), dictionary_size)
+        seen += 1
+    assert seen >= 5
+
+
+def test_sets_are_bounded_and_increasing():
+    d = lz_inputs()["mix_256k"]
+    cnt, ln, ds = oracle_bt4_sets(d)
+    assert cnt.max() <= BT4_SET and cnt[-162:].max() == 0            # Move_Pos with finishing = False (lz77.adb:959, 1000-1017)
+    for p in np.nonzero(cnt > 1)[0][:2000]:
+        assert np.all(np.diff(ln[p, :cnt[p]].astype(int)) > 0)
