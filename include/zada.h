@@ -248,6 +248,10 @@ uint64_t zada_bz2_range_table(zada_ctx *ctx, uint64_t *tab, uint64_t cap_blocks)
 void zada_bz2_select(uint64_t nblk, const uint64_t *tab, uint64_t bitpos_in, uint32_t crc_in, uint8_t *choice, uint64_t *bitpos_out, uint32_t *crc_out);
 int zada_bz2_range_assemble(zada_ctx *ctx, const uint8_t *choice, uint64_t nblk, uint64_t bit_begin, int flags, uint32_t footer_crc,
                             void *d_out, uint64_t cap, uint64_t *nbytes);
+/* Test hook: the match sets LZMA_3's BT4 matcher (lz77.adb:1234-1361, BT4_Algo.Read_One_and_Get_Matches) finds at every position of
+ * ONE entry, as the producer kernels leave them for the coder (zip-ada_amd/csrc/zada_bt4.hip): cnt [n] matches per position, lengths and
+ * distances in len / dist [n * stride], stride >= 50.  Dictionary = the entry's size, or the "lzma_dict" knob. */
+int zada_lzma_match_sets(zada_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride);
 /* Test hooks: sub-blocks (Encode_Block jobs) of a host buffer through the stages, and the tables they leave. */
 int zada_bz2_run(zada_ctx *ctx, const uint8_t *in, uint64_t n, uint32_t nsb, const uint64_t *starts, const uint32_t *lens, int option, int stages);
 int zada_bz2_fetch(zada_ctx *ctx, const char *name, void *dst, uint64_t cap, uint64_t *nbytes);

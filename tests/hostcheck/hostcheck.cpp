@@ -202,7 +202,11 @@ extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t 
       const Bt4Run *r = bt4_run_of(runs.data(), (uint32_t)runs.size(), q);
       const int32_t ordp = (int32_t)(q - r->gap);
       const int avail = (int)(r->W - q - 1), limit = avail < BT4_LOOK ? avail : BT4_LOOK;
-      const int c = bt4_visit(in, q, ordp, r->cls == 0, limit, max_dist, tree.data(), root, o2[q], o3[q], ml, md, ext);
+      auto put = [&](int i, int l, uint32_t dd) { ml[i] = (uint16_t)l; md[i] = dd; };
+      Bt4Walk wk;
+      bt4_begin(wk, in, q, ordp, r->cls == 0, limit, max_dist, root, o2[q], o3[q], ext, put);
+      while (!bt4_step(wk, tree.data(), ext, put)) {}
+      const int c = wk.count;
       if (c > stride) return -2;
       cnt[q] = (uint8_t)c;
       for (int k = 0; k < c; k++) { len[(uint64_t)q * stride + k] = ml[k]; dist[(uint64_t)q * stride + k] = md[k]; }

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from _common import GOLDEN, product, oracle_zip
-from _lzmah import lz_inputs, oracle_lzma, oracle_lzma_encode, lzma_decode, LZMA_METHODS
+from _lzmah import lz_inputs, oracle_lzma, oracle_lzma_encode, lzma_decode, LZMA_METHODS, oracle_bt4_sets, sets_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,27 @@ def test_streams_bit_exact_vs_oracle_and_digests(encoder, method):
         want = dig["%s|%d" % (name, method)]
         assert (want["rc"], want["size"], want["sha256"]) == (rc, len(z), hashlib.sha256(z).hexdigest()), name
         assert crc ^ 0xFFFFFFFF == zlib.crc32(d)
+
+
+def test_match_sets_of_the_bt4_producer_equal_the_sequential_matchers(encoder):
+    """The stage between the BT4 producer (zada_bt4.hip: one lane per hash-4 bucket, sorted hash-2 / hash-3 predecessors, replayed
+    window fills) and the coder: the match set of EVERY position == what the oracle's sequential BT4 (lz77.adb:1234-1361, every position
+    read) returns there -- with the entry's size as the dictionary and with smaller ones (several fills, window moves, the pending
+    bytes that String_buffer_size 4096 never catches up with)."""
+    cases = lz_inputs()
+    try:
+        for name in sorted(cases):
+            d = cases[name]
+            if len(d) < 5 or len(d) > 300000:
+                continue
+            for ds in (0, 3000, 5000, 20000):
+                if ds and (ds >= len(d) or len(d) > 120000) and ds != 3000:
+                    continue
+                encoder.set_knob("lzma_dict", ds)
+                got = encoder.lzma_match_sets(d)
+                assert sets_equal(oracle_bt4_sets(d, ds or None), got), (name, len(d), ds)
+    finally:
+        encoder.set_knob("lzma_dict", 0)
 
 
 def test_single_calls_host_and_device_entry(encoder):

@@ -102,6 +102,7 @@ def load_library():
     L.zada_lzma.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, vp, vp]
     L.zada_lzma_device.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
     L.zada_lzma_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.zada_lzma_match_sets.argtypes = [vp, vp, u64, vp, vp, vp, i32]
     L.zada_bz2_last_blocks.restype = ctypes.c_uint64
     L.zada_bz2_last_blocks.argtypes = [vp, vp, u64]
     L.zada_crc32_combine.restype = ctypes.c_uint32
@@ -265,6 +266,17 @@ class Encoder:
             self._err(worst, "zada_lzma_batch")
         mv = memoryview(arena)
         return [(int(rcs[i]), bytes(mv[int(offs[i]):int(offs[i]) + int(ols[i])]) if rcs[i] >= 0 and ols[i] <= caps[i] else None, int(crcs[i])) for i in range(cnt)]
+
+    def lzma_match_sets(self, data, stride=50):
+        """Test hook: the match sets of LZMA_3's BT4 matcher at every position of `data`, as the producer kernels leave them for the coder
+        (lz77.adb:1234-1361).  Returns (cnt [n] u8, len [n, stride] u16, dist [n, stride] u32)."""
+        import numpy as np
+        n = len(data)
+        cnt = np.zeros(n, np.uint8); ln = np.zeros((n, stride), np.uint16); ds = np.zeros((n, stride), np.uint32)
+        rc = self.lib.zada_lzma_match_sets(self.ctx, _addr(data) if n else None, n, cnt.ctypes.data, ln.ctypes.data, ds.ctypes.data, stride)
+        if rc < 0:
+            self._err(rc, "zada_lzma_match_sets")
+        return cnt, ln, ds
 
     def lzma_device(self, d_in, n, d_out, cap, method=18, crc=0xFFFFFFFF):
         """LZMA payload of n bytes at device address d_in into d_out (cap bytes).  Returns (rc, length, running CRC register)."""

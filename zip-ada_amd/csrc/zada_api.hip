@@ -12,6 +12,7 @@
 #include <thread>
 #include "../../include/zada.h"
 #include "zada_internal.h"
+#include "zada_bt4.h"
 
 struct zada_ctx { zada::Ctx c; };
 
@@ -1171,27 +1172,32 @@ static int lz_grow(Ctx *c, void **p, size_t *cap, size_t bytes) {
 }
 static void lzma_free(Ctx *c) {
   if (c->lz_tab) hipFree(c->lz_tab);
-  if (c->lz_ws) hipFree(c->lz_ws);
   if (c->lz_save) hipFree(c->lz_save);
-  c->lz_tab = c->lz_ws = c->lz_save = nullptr; c->cap_lz_tab = c->cap_lz_ws = c->cap_lz_save = 0;
+  c->lz_tab = c->lz_save = nullptr; c->cap_lz_tab = c->cap_lz_save = 0;
+  bt4_destroy(c);
 }
-// jobs: ws_off / sbs / hash4_size are filled here.  res: 2 per job (stream bytes, input bytes coded).
+// jobs: sbs / hash4_size are filled here.  res: 2 per job (stream bytes, input bytes coded).  arena_bytes: the bytes at d_in that hold
+// the entries (Level_3: the BT4 producer of zada_bt4.hip writes the match sets of all entries before the coder starts).
 // budget > 0: launches of `budget` positions per stream (the coder's state waits in HBM in between, zada_lzma.hip "A stream in several
 // launches"), with feedback (pct_lo .. pct_hi by positions coded) and the abort test between them.
-static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, std::vector<uint64_t> &res,
+static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uint64_t arena_bytes, const uint32_t *d_tok, uint8_t *d_out, std::vector<uint64_t> &res,
                     const uint32_t *d_apos = nullptr, uint32_t T = 0, const uint32_t *d_ent_start = nullptr,
                     uint64_t budget = 0, zada_feedback_fn fb = nullptr, void *user = nullptr, int pct_lo = 0, int pct_hi = 100) {
   const uint32_t E = (uint32_t)jobs.size();
-  uint64_t ws_ints = 0;
+  bool bt4 = false;
   for (LzmaJob &j : jobs) {
     j.sbs = lzma_string_buffer_size(j.level, c->knob_lzma_dict > 0 ? (uint64_t)c->knob_lzma_dict : j.n);   // dictionary_size = the entry's size, zip-compress-lzma_e.adb:165
     j.hash4_size = j.level == 3 ? lzma_hash4_size(j.sbs) : 0;
-    j.ws_off = ws_ints;
-    ws_ints += (lzma_workspace_ints(j.level, j.sbs) + 15) & ~15ull;
+    j.ws_off = 0;
+    bt4 = bt4 || (j.level == 3 && j.n > 0);
   }
   int rc = lz_grow(c, &c->lz_tab, &c->cap_lz_tab, (sizeof(LzmaJob) + 16 + 4) * (size_t)E + 192);
-  if (!rc && ws_ints) rc = lz_grow(c, &c->lz_ws, &c->cap_lz_ws, ws_ints * 4);
   if (rc) return rc;
+  Bt4Sets sets{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (bt4) {
+    if ((rc = bt4_produce(c, jobs, d_in, arena_bytes, &sets))) return rc;
+    c->tmark("lzma:bt4");
+  }
   LzmaJob *d_jobs = (LzmaJob *)c->lz_tab;
   uint64_t *d_res = (uint64_t *)((uint8_t *)c->lz_tab + ((sizeof(LzmaJob) * (size_t)E + 63) & ~63ull));
   uint32_t *d_order = (uint32_t *)((uint8_t *)d_res + ((16 * (size_t)E + 63) & ~63ull));
@@ -1200,11 +1206,10 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, con
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n > jobs[b].n; });
   hipMemcpyAsync(d_jobs, jobs.data(), sizeof(LzmaJob) * (size_t)E, hipMemcpyHostToDevice, c->stream);
   hipMemcpyAsync(d_order, order.data(), 4 * (size_t)E, hipMemcpyHostToDevice, c->stream);
-  if (ws_ints) hipMemsetAsync(c->lz_ws, 0, ws_ints * 4, c->stream);
   if (d_apos && (rc = lzma_token_ranges(c, E, d_apos, T, d_ent_start, d_jobs))) return rc;   // token ranges of a batch, found on the device
   res.resize(2 * (size_t)E);
   if (budget == 0) {
-    if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res))) return rc;
+    if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, sets, d_res))) return rc;
     hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
     if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
   } else {
@@ -1215,7 +1220,7 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, con
     for (const LzmaJob &j : jobs) total += j.n;
     c->lzma_launches = 0;
     for (;;) {
-      if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, (int32_t *)c->lz_ws, d_res, (uint8_t *)c->lz_save, budget))) return rc;
+      if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, sets, d_res, (uint8_t *)c->lz_save, budget))) return rc;
       c->lzma_launches++;
       hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
       if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
@@ -1271,7 +1276,7 @@ static int lzma_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint8_
   const int pct0 = d_tok ? 10 : 1;
   if (fb && fb(pct0, user)) return ZADA_ABORTED;
   std::vector<uint64_t> res;
-  if ((rc = lzma_run(c, jobs, d_in, d_tok, d_out, res, nullptr, 0, nullptr, lzma_budget(c, level), fb, user, pct0, 99))) return rc;
+  if ((rc = lzma_run(c, jobs, d_in, n, d_tok, d_out, res, nullptr, 0, nullptr, lzma_budget(c, level), fb, user, pct0, 99))) return rc;
   c->tmark("lzma:end"); c->tend();
   if (fb && fb(100, user)) return ZADA_ABORTED;
   *out_len = res[0];
@@ -1307,6 +1312,43 @@ int zada_lzma(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *o
   if (out_len) *out_len = ol;
   if (ol <= cap && copy_out(c, out, d_out, ol)) return ZADA_E_HIP;
   return rc;
+}
+// Test hook: the match sets the BT4 producer leaves for ONE entry (the stage the coder reads; compare zo_bt4_match_sets of the
+// oracle): cnt [n], len / dist [n * stride] (stride >= 50).  The dictionary is the entry's size or the "lzma_dict" knob.
+int zada_lzma_match_sets(zada_ctx *z, const uint8_t *in, uint64_t n, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride) {
+  if (!z || stride < BT4_SET || n >= (2ull << 30) - 65536) return ZADA_E_INVALID;
+  int rc = prepare(z);
+  if (rc) return rc;
+  Ctx *c = &z->c;
+  if (n == 0) return 0;
+  if ((rc = ensure_rin(c, n + 64))) return rc;
+  copy_in(c, c->ws.rin_own, in, n);
+  std::vector<LzmaJob> jobs(1);
+  LzmaJob &J = jobs[0];
+  memset(&J, 0, sizeof J);
+  J.n = n; J.level = 3;
+  J.sbs = lzma_string_buffer_size(3, c->knob_lzma_dict > 0 ? (uint64_t)c->knob_lzma_dict : n);
+  J.hash4_size = lzma_hash4_size(J.sbs);
+  Bt4Sets S;
+  if ((rc = finish_call(c, bt4_produce(c, jobs, c->ws.rin_own, n, &S)))) return rc;
+  std::vector<uint16_t> sl(n * BT4_INLINE); std::vector<uint32_t> sd(n * BT4_INLINE);
+  const uint64_t nov = c->bt4_overflow;
+  std::vector<uint16_t> ol(nov * BT4_OVF + 1); std::vector<uint32_t> od(nov * BT4_OVF + 1);
+  hipMemcpy(cnt, S.cnt, n, hipMemcpyDeviceToHost);
+  hipMemcpy(sl.data(), S.sl, 2 * n * BT4_INLINE, hipMemcpyDeviceToHost);
+  hipMemcpy(sd.data(), S.sd, 4 * n * BT4_INLINE, hipMemcpyDeviceToHost);
+  if (nov) { hipMemcpy(ol.data(), S.ol, 2 * nov * BT4_OVF, hipMemcpyDeviceToHost); hipMemcpy(od.data(), S.od, 4 * nov * BT4_OVF, hipMemcpyDeviceToHost); }
+  if (hip_check(c, hipGetLastError(), "match sets")) return ZADA_E_HIP;
+  for (uint64_t p = 0; p < n; p++)
+    for (int i = 0; i < cnt[p]; i++) {
+      if (i < BT4_INLINE - 1) { len[p * stride + i] = sl[p * BT4_INLINE + i]; dist[p * stride + i] = sd[p * BT4_INLINE + i]; }
+      else {
+        const uint64_t o = (uint64_t)sd[p * BT4_INLINE + BT4_INLINE - 1] * BT4_OVF + (uint32_t)(i - (BT4_INLINE - 1));
+        if (o >= ol.size()) { c->err = "match sets: overflow block out of range"; return ZADA_E_HIP; }
+        len[p * stride + i] = ol[o]; dist[p * stride + i] = od[o];
+      }
+    }
+  return 0;
 }
 // Many entries in one call: every entry is a stream of ONE launch of k_lzma_encode -- the only parallelism LZMA's chain of
 // adaptive probabilities leaves (see zada_lzma.hip).  This one: Level_0 and Level_3 (no tokens from the LZ stage).
@@ -1344,7 +1386,7 @@ static int lzma_batch_core(Ctx *c, int method, const int *idx, uint32_t E, const
   }
   c->tmark("lzma:tokens");
   std::vector<uint64_t> res;
-  if ((rc = lzma_run(c, jobs, d_arena, nullptr, d_out, res))) return rc;
+  if ((rc = lzma_run(c, jobs, d_arena, total, nullptr, d_out, res))) return rc;
   hipMemcpyAsync(c->bstage, d_out, ototal, hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "LZMA batch out")) return ZADA_E_HIP;
   c->tmark("lzma:end"); c->tend();
@@ -1424,7 +1466,7 @@ static int lzma_batch_iz(Ctx *c, int method, const int *idx, uint32_t E, const u
   }
   std::vector<uint64_t> res;
   uint8_t *d_out = c->ws.rin_own;
-  if ((rc = lzma_run(c, jobs, W.in, W.ea_atoms + LB_CAP, d_out, res, W.ea_apos + LB_CAP, sres.ntok, W.ent_start))) return rc;
+  if ((rc = lzma_run(c, jobs, W.in, total, W.ea_atoms + LB_CAP, d_out, res, W.ea_apos + LB_CAP, sres.ntok, W.ent_start))) return rc;
   hipMemcpyAsync(crc_in.data(), W.ent_crc, 4ull * E, hipMemcpyDeviceToHost, st);
   hipMemcpyAsync(c->bstage, d_out, ototal, hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "LZMA batch out")) return ZADA_E_HIP;

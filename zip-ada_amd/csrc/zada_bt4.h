@@ -40,6 +40,9 @@ namespace zada {
 constexpr int BT4_LOOK = 273, BT4_NICE = 162, BT4_DEPTH = 48, BT4_OPTS = 4096;
 constexpr int BT4_SET = 50;                         // most matches of one position: one per hash (2, 3 bytes) + one per tree step (Depth_Limit)
 constexpr int32_t BT4_NONE = -1;
+// Match sets in HBM: BT4_INLINE slots per position -- BT4_INLINE - 1 matches and, for a longer set, the number of its block in the overflow
+// pool (in the last slot's distance), BT4_OVF more matches there.
+constexpr int BT4_INLINE = 8, BT4_OVF = BT4_SET - (BT4_INLINE - 1);
 
 struct Bt4Run { uint32_t start, end, W, gap, cls, pad; };   // positions [start, end) of the entry; ord = q - gap; available at the first visit = W - q - 1
 
@@ -101,53 +104,67 @@ ZADA_BT_HD int bt4_extend(const uint8_t *in, int64_t a, int64_t b, int len, int 
 // (hash4Table [h4]), o2 / o3 = ordinals of the previous inserted positions with the same hash2 / hash3; BT4_NONE where there is none.
 // tree: the entry's nodes, two ints per ordinal (left / right child as ordinals).  A candidate of ordinal c is met at distance
 // delta = ordp - c and its bytes are those at q - delta (the reference addresses buf [readPos - delta], :1285, 1318).
-// Returns the number of matches (lengths strictly increasing) written to mlen / mdist (record only).
-template <typename Ext>
-ZADA_BT_HD int bt4_visit(const uint8_t *in, uint32_t q, int32_t ordp, bool record, int matchLenLimit, int32_t max_dist, int32_t *tree, int32_t root, int32_t o2,
-                         int32_t o3, uint16_t *mlen, uint32_t *mdist, Ext extend) {
+// In two parts, so that a lane can take its next position while its neighbours are still on their way down: bt4_begin (the two hash
+// matches, :1263-1305) and bt4_step (one level of the tree, :1309-1360 / :1164-1205; true = the visit is over).  `put (i, len, dist)`
+// receives match i (lengths strictly increasing); `extend (in, a, b, len, limit)` is bt4_extend or a faster form of it.
+struct Bt4Walk {
+  const uint8_t *in; int64_t qq;
+  int32_t ordp, max_dist, cur;
+  uint32_t ptr0, ptr1;                               // (2 * ordinal + 1 needs all 32 bits for an entry of 1 GiB)
+  int limit, depth, len0, len1, lenBest, count;
+  bool record;
+};
+template <typename Ext, typename Put>
+ZADA_BT_HD void bt4_begin(Bt4Walk &w, const uint8_t *in, uint32_t q, int32_t ordp, bool record, int matchLenLimit, int32_t max_dist, int32_t root, int32_t o2, int32_t o3,
+                          Ext extend, Put put) {
+  constexpr int32_t FAR = 0x7FFFFFFF;
+  w.in = in; w.qq = (int64_t)q; w.ordp = ordp; w.max_dist = max_dist; w.cur = root; w.limit = matchLenLimit; w.record = record;
+  w.count = 0; w.lenBest = 0;
+  if (record) {
+    const int32_t delta2 = o2 >= 0 ? ordp - o2 : FAR, delta3 = o3 >= 0 ? ordp - o3 : FAR;
+    const bool m2 = delta2 < max_dist && in[w.qq - delta2] == in[w.qq];                                       // :1263-1270
+    const bool m3 = delta2 != delta3 && delta3 < max_dist && in[w.qq - delta3] == in[w.qq];                   // :1275-1282
+    if (m2 || m3) {
+      const int32_t d = m3 ? delta3 : delta2;
+      w.lenBest = extend(in, w.qq - d, w.qq, m3 ? 3 : 2, matchLenLimit);                                       // :1285-1292
+      if (m2 && m3) put(0, 2, (uint32_t)delta2);
+      put(m2 && m3 ? 1 : 0, w.lenBest, (uint32_t)d);
+      w.count = m2 && m3 ? 2 : 1;
+      if (w.lenBest >= BT4_NICE) w.record = false;   // :1294-1299: the tree is updated as Skip does it, no more matches
+    }
+    if (w.lenBest < 3) w.lenBest = 3;                // :1303-1305
+  }
+  w.depth = BT4_DEPTH; w.ptr0 = 2u * (uint32_t)ordp + 1u; w.ptr1 = 2u * (uint32_t)ordp; w.len0 = 0; w.len1 = 0;
+}
+template <typename Ext, typename Put>
+ZADA_BT_HD bool bt4_step(Bt4Walk &w, int32_t *tree, Ext extend, Put put) {
   constexpr int32_t FAR = 0x7FFFFFFF;
   const int nice = BT4_NICE;                         // niceLenLimit = min (Nice_Length, avail) = 162 for every inserted position
-  const int64_t qq = (int64_t)q;
-  int count = 0, lenBest = 0;
-  int32_t cur = root;
-  if (record) {
-    int32_t delta2 = o2 >= 0 ? ordp - o2 : FAR;
-    const int32_t delta3 = o3 >= 0 ? ordp - o3 : FAR;
-    if (delta2 < max_dist && in[qq - delta2] == in[qq]) { lenBest = 2; count = 1; mlen[0] = 2; mdist[0] = (uint32_t)delta2; }          // :1263-1270
-    if (delta2 != delta3 && delta3 < max_dist && in[qq - delta3] == in[qq]) { lenBest = 3; mdist[count] = (uint32_t)delta3; count++; delta2 = delta3; }   // :1275-1282
-    if (count > 0) {
-      lenBest = extend(in, qq - delta2, qq, lenBest, matchLenLimit);                                                                     // :1285-1292
-      mlen[count - 1] = (uint16_t)lenBest;
-      if (lenBest >= nice) record = false;           // :1294-1299: the tree is updated as Skip does it, no more matches
-    }
-    if (lenBest < 3) lenBest = 3;                    // :1303-1305
-  }
-  int depth = BT4_DEPTH, ptr0 = 2 * ordp + 1, ptr1 = 2 * ordp, len0 = 0, len1 = 0;
-  for (;;) {
-    const int32_t delta0 = cur >= 0 ? ordp - cur : FAR;
-    if (depth == 0 || delta0 >= max_dist) { tree[ptr0] = BT4_NONE; tree[ptr1] = BT4_NONE; return count; }                             // :1166-1170, 1311-1315
-    depth--;
-    const int pair = 2 * cur;
-    int len = len0 < len1 ? len0 : len1;
-    if (record) {
-      if (in[qq + len - delta0] == in[qq + len]) {
-        len = extend(in, qq - delta0, qq, len + 1, matchLenLimit);
-        if (len > lenBest) {
-          lenBest = len;
-          mlen[count] = (uint16_t)len; mdist[count] = (uint32_t)delta0; count++;
-          if (len >= nice) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return count; }                                      // :1340-1345
-        }
+  const int32_t cur = w.cur, delta0 = cur >= 0 ? w.ordp - cur : FAR;
+  if (w.depth == 0 || delta0 >= w.max_dist) { tree[w.ptr0] = BT4_NONE; tree[w.ptr1] = BT4_NONE; return true; }                          // :1166-1170, 1311-1315
+  w.depth--;
+  const uint32_t pair = 2u * (uint32_t)cur;
+  const uint8_t *in = w.in;
+  const int64_t qq = w.qq;
+  int len = w.len0 < w.len1 ? w.len0 : w.len1;
+  if (w.record) {
+    if (in[qq + len - delta0] == in[qq + len]) {
+      len = extend(in, qq - delta0, qq, len + 1, w.limit);
+      if (len > w.lenBest) {
+        w.lenBest = len;
+        put(w.count, len, (uint32_t)delta0); w.count++;
+        if (len >= nice) { tree[w.ptr1] = tree[pair]; tree[w.ptr0] = tree[pair + 1]; return true; }                                       // :1340-1345
       }
-    } else {
-      len = extend(in, qq - delta0, qq, len, nice);
-      if (len == nice) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return count; }                                          // :1185-1189
     }
-    if (in[qq + len - delta0] < in[qq + len]) { tree[ptr1] = cur; ptr1 = pair + 1; cur = tree[ptr1]; len1 = len; }                      // :1195-1205, 1349-1359
-    else { tree[ptr0] = cur; ptr0 = pair; cur = tree[ptr0]; len0 = len; }
+  } else {
+    len = extend(in, qq - delta0, qq, len, nice);
+    if (len == nice) { tree[w.ptr1] = tree[pair]; tree[w.ptr0] = tree[pair + 1]; return true; }                                           // :1185-1189
   }
+  if (in[qq + len - delta0] < in[qq + len]) { tree[w.ptr1] = cur; w.ptr1 = pair + 1; w.cur = tree[w.ptr1]; w.len1 = len; }              // :1195-1205, 1349-1359
+  else { tree[w.ptr0] = cur; w.ptr0 = pair; w.cur = tree[w.ptr0]; w.len0 = len; }
+  return false;
 }
 
-#if !defined(__HIPCC__) || !defined(__HIP_DEVICE_COMPILE__)
 // The fills of LZ77_using_BT4's main loop (:1798-1827) replayed for an entry of n bytes: Fill_Window (:1389-1440) with Move_Window
 // (:1375-1386) and processPendingBytes (:1397-1406).  Writes the entry's runs (see the head of the file); returns false when a fill
 // would re-insert positions that are in the tree already (pending bytes left over by an earlier fill AND taken up by a later one:
@@ -196,6 +213,5 @@ template <typename Vec> inline bool bt4_schedule(uint64_t n, uint32_t sbs, Vec &
   }
   return true;
 }
-#endif
 
 }  // namespace zada

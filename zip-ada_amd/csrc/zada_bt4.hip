@@ -1,0 +1,298 @@
+// zada_bt4.hip -- the BT4 match finder of LZMA Level_3 (zip_lib/lz77.adb:953-1827) as a PRODUCER that runs ahead of the coder: the match
+// set Read_One_and_Get_Matches (:1234-1361) returns at every position of every entry of a call, written to HBM before k_lzma_encode
+// starts.  zada_bt4.h says why the sets are a function of the input alone and holds the tree walk itself (host + device text, checked on
+// the CPU against the oracle's sequential matcher by tests/test_bt4_producer.py).  Here: the data-parallel frame around it.
+//
+//   k_bt4_keys     one lane per position of the arena (all entries of the call side by side): its three hashes (calcHashes :1061-1069),
+//                  or "not inserted" (padding; positions the window schedule never inserts: the last 162 of a stream, Move_Pos :1000-1017);
+//   radix sort     (zada_sort.hip) of the positions by hash 2, by hash 3, by hash 4 -- stable, so a hash's positions stay in text order
+//                  and, the arena being entry after entry, in entry order;
+//   k_bt4_pred     hash 2 / hash 3: the previous position of the same hash AND entry = what hash2Table / hash3Table hold when the position
+//                  is reached (:1247-1251);
+//   k_bt4_flags, k_bt4_heads, k_bt4_split
+//                  hash 4: the runs of equal (hash, entry) = the buckets, each one binary tree; long buckets and short ones apart;
+//   k_bt4_walk     one LANE per bucket walks its positions in increasing order (bt4_begin / bt4_step): persistent lanes, a lane that
+//                  finishes a position takes its bucket's next one -- or the next bucket -- while its neighbours are still on their way
+//                  down; long buckets are handed out one by one through a counter, the short ones by stride.
+//
+// Match sets in HBM: 8 slots per position (7 matches; most positions have one to three), the rest of a longer set (up to 50 matches: one
+// per hash + one per tree level, Depth_Limit = 48) in a 43-slot block of an overflow pool booked through an atomic counter.  When the pool
+// is too small the walk still counts what it would have needed, and the host runs it again with a pool of that size.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "../../include/zada.h"
+#include "zada_internal.h"
+#include "zada_bt4.h"
+
+namespace zada {
+namespace {
+
+constexpr uint32_t NOJOB = 0xFFFFFFFFu;
+constexpr uint32_t BT_LONG = 32;                    // a bucket of this many positions or more is handed out on its own
+
+struct Tables { const uint32_t *tile_job; const Bt4Job *jobs; const Bt4Run *runs; };
+
+__device__ __forceinline__ int32_t ord_of(const Tables &T, uint32_t j, uint32_t p) {
+  const Bt4Job &J = T.jobs[j];
+  const uint32_t q = p - (uint32_t)J.in_off;
+  return (int32_t)(q - bt4_run_of(T.runs + J.run_off, J.run_cnt, q)->gap);
+}
+
+__global__ void __launch_bounds__(256) k_bt4_keys(const uint8_t *__restrict__ in, uint32_t P, Tables T, uint32_t hb4, uint32_t *__restrict__ k2, uint32_t *__restrict__ k3,
+                                                  uint32_t *__restrict__ k4, uint32_t *__restrict__ val) {
+  __shared__ uint32_t crc[256];
+  crc[threadIdx.x] = bt4_crc(threadIdx.x);
+  __syncthreads();
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  uint32_t a = 1u << 10, b = 1u << 16, c = 1u << hb4;              // "not inserted": one bit above the hash, sorts behind everything
+  const uint32_t j = T.tile_job[p >> 6];
+  if (j != NOJOB) {
+    const Bt4Job &J = T.jobs[j];
+    const uint32_t q = p - (uint32_t)J.in_off;
+    if (q < J.n && bt4_run_of(T.runs + J.run_off, J.run_cnt, q)->cls != 2)
+      bt4_hashes(crc[in[p]], in[p + 1], in[p + 2], crc[in[p + 3]], J.hash4_mask, a, b, c);      // (an inserted position has 162 bytes after it)
+  }
+  k2[p] = a; k3[p] = b; k4[p] = c; val[p] = p;
+}
+
+// pred [p] = ordinal (inside its entry) of the previous inserted position with p's hash, BT4_NONE when p is the first one
+__global__ void __launch_bounds__(256) k_bt4_pred(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T, int32_t *__restrict__ pred) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t k = keys[i];
+  if (k & flag) return;
+  const uint32_t p = vals[i];
+  int32_t o = BT4_NONE;
+  if (i > 0 && keys[i - 1] == k) {
+    const uint32_t pp = vals[i - 1], j = T.tile_job[p >> 6];
+    if (T.tile_job[pp >> 6] == j) o = ord_of(T, j, pp);
+  }
+  pred[p] = o;
+}
+
+// cnts: [0] long buckets, [1] short buckets, [2] next long bucket to hand out, [3] overflow blocks booked, [4] first "not inserted" index
+__global__ void __launch_bounds__(256) k_bt4_flags(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T,
+                                                   uint32_t *__restrict__ flags, uint32_t *__restrict__ cnts) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t k = keys[i];
+  uint32_t f = 0;
+  if (k & flag) { if (i == 0 || !(keys[i - 1] & flag)) cnts[4] = i; }
+  else f = (i == 0 || keys[i - 1] != k || T.tile_job[vals[i - 1] >> 6] != T.tile_job[vals[i] >> 6]) ? 1u : 0u;
+  flags[i] = f;
+}
+__global__ void __launch_bounds__(256) k_bt4_heads(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T,
+                                                   const uint32_t *__restrict__ rank, uint32_t *__restrict__ heads) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t k = keys[i];
+  if (k & flag) return;
+  if (i == 0 || keys[i - 1] != k || T.tile_job[vals[i - 1] >> 6] != T.tile_job[vals[i] >> 6]) heads[rank[i]] = i;
+}
+__global__ void __launch_bounds__(256) k_bt4_split(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ nruns, uint32_t *__restrict__ cnts,
+                                                   uint2 *__restrict__ longs, uint2 *__restrict__ shorts) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x, R = *nruns;
+  const bool live = r < R;
+  uint32_t s = 0, len = 0;
+  if (live) { s = heads[r]; len = (r + 1 < R ? heads[r + 1] : cnts[4]) - s; }
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (1ull << lane) - 1;
+  for (int cls = 0; cls < 2; cls++) {                               // one atomic per wave and list
+    const bool mine = live && (cls == 0 ? len >= BT_LONG : len < BT_LONG);
+    const uint64_t m = __ballot(mine);
+    if (m == 0) continue;
+    uint32_t base = 0;
+    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cnts[cls], (uint32_t)__popcll(m));
+    base = __shfl(base, (int)__builtin_ctzll(m));
+    if (mine) (cls == 0 ? longs : shorts)[base + (uint32_t)__popcll(m & lt)] = make_uint2(s, len);
+  }
+}
+
+struct Sets { uint8_t *cnt; uint16_t *sl; uint32_t *sd; uint16_t *ol; uint32_t *od; uint32_t ovf_cap; };
+
+// eight bytes at a time while eight remain below the limit (nothing at or beyond a + limit / b + limit is read)
+__device__ __forceinline__ int extend8(const uint8_t *in, int64_t a, int64_t b, int len, int limit) {
+  while (len + 8 <= limit) {
+    unsigned long long x, y;
+    __builtin_memcpy(&x, in + a + len, 8);
+    __builtin_memcpy(&y, in + b + len, 8);
+    x ^= y;
+    if (x) return len + (__builtin_ctzll(x) >> 3);
+    len += 8;
+  }
+  while (len < limit && in[a + len] == in[b + len]) len++;
+  return len;
+}
+
+__global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ vals, const uint2 *__restrict__ longs, const uint2 *__restrict__ shorts,
+                                                  uint32_t *__restrict__ cnts, Tables T, const int32_t *__restrict__ d2, const int32_t *__restrict__ d3, int32_t *__restrict__ tree, Sets S) {
+  const uint32_t nlong = cnts[0], nshort = cnts[1], nthreads = gridDim.x * 256;
+  uint32_t next_short = blockIdx.x * 256 + threadIdx.x;
+  bool more_long = nlong > 0, walking = false;
+  uint32_t i = 0, e = 0, p = 0, blk = 0, job = NOJOB;
+  int32_t prev_ord = BT4_NONE;
+  // the bucket's entry (a bucket never leaves its entry)
+  const uint8_t *jin = nullptr; int32_t *jtree = nullptr; const Bt4Run *jruns = nullptr;
+  uint32_t jrun_cnt = 0, joff = 0; int32_t jmax = 0;
+  Bt4Walk w;
+  bool rec0 = false;
+  auto ext = [](const uint8_t *b, int64_t x, int64_t y, int l, int lim) { return extend8(b, x, y, l, lim); };
+  auto put = [&](int k, int len, uint32_t dist) {
+    const size_t base = (size_t)p * BT4_INLINE;
+    if (k < BT4_INLINE - 1) { S.sl[base + k] = (uint16_t)len; S.sd[base + k] = dist; return; }
+    if (k == BT4_INLINE - 1) { blk = atomicAdd(&cnts[3], 1u); S.sd[base + BT4_INLINE - 1] = blk; }
+    if (blk < S.ovf_cap) { const size_t o = (size_t)blk * BT4_OVF + (uint32_t)(k - (BT4_INLINE - 1)); S.ol[o] = (uint16_t)len; S.od[o] = dist; }
+  };
+  for (;;) {
+    if (!walking) {
+      if (i >= e) {                                                  // the next bucket
+        bool got = false;
+        uint2 d = make_uint2(0, 0);
+        if (more_long) {
+          const uint32_t r = atomicAdd(&cnts[2], 1u);
+          if (r < nlong) { d = longs[r]; got = true; } else more_long = false;
+        }
+        if (!got && next_short < nshort) { d = shorts[next_short]; next_short += nthreads; got = true; }
+        if (!got) break;
+        i = d.x; e = d.x + d.y; prev_ord = BT4_NONE;
+        job = T.tile_job[vals[i] >> 6];
+        const Bt4Job &J = T.jobs[job];
+        joff = (uint32_t)J.in_off; jin = arena + J.in_off; jtree = tree + 2 * (size_t)J.in_off;
+        jruns = T.runs + J.run_off; jrun_cnt = J.run_cnt; jmax = (int32_t)J.max_dist;
+      }
+      p = vals[i];
+      const uint32_t q = p - joff;
+      const Bt4Run *r = bt4_run_of(jruns, jrun_cnt, q);
+      const int avail = (int)(r->W - q - 1);
+      rec0 = r->cls == 0;
+      bt4_begin(w, jin, q, (int32_t)(q - r->gap), rec0, avail < BT4_LOOK ? avail : BT4_LOOK, jmax, prev_ord, rec0 ? d2[p] : BT4_NONE, rec0 ? d3[p] : BT4_NONE, ext, put);
+      walking = true;
+    }
+    if (bt4_step(w, jtree, ext, put)) {
+      if (rec0) S.cnt[p] = (uint8_t)w.count;
+      prev_ord = w.ordp;
+      i++;
+      walking = false;
+    }
+  }
+}
+
+struct Buf {
+  void *p = nullptr; size_t cap = 0;
+  template <typename T> T *as() const { return (T *)p; }
+};
+struct State {
+  Buf tile_job, jobs, runs, k2, k3, k4, val, ks, vs, tmp, d2, d3, tree, cnt, sl, sd, ol, od, flags, heads, longs, shorts, cnts, scan;
+  Buf *all[24] = {&tile_job, &jobs, &runs, &k2, &k3, &k4, &val, &ks, &vs, &tmp, &d2, &d3, &tree, &cnt, &sl, &sd, &ol, &od, &flags, &heads, &longs, &shorts, &cnts, &scan};
+  uint32_t ovf_cap = 0;
+};
+int grow(Ctx *c, Buf &b, size_t bytes) {
+  if (b.p && b.cap >= bytes) return 0;
+  hipStreamSynchronize(c->stream);
+  if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  const size_t want = bytes + bytes / 16 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { (void)hipGetLastError(); hip_check(c, e, "hipMalloc (BT4 producer)"); b.p = nullptr; return ZADA_E_NOMEM; }
+  b.cap = want;
+  return 0;
+}
+
+}  // namespace
+
+void bt4_destroy(Ctx *c) {
+  State *B = (State *)c->bt4;
+  if (!B) return;
+  for (Buf *b : B->all) if (b->p) hipFree(b->p);
+  delete B;
+  c->bt4 = nullptr;
+}
+
+// The match sets of all Level_3 entries among `jobs` (arena: the device buffer the entries' in_off count from; P = bytes of it that
+// hold entries, every entry at a multiple of 64).  On return `out` points at the sets (device memory owned by the context, valid until
+// the next call).  Returns 0, ZADA_E_NOMEM, ZADA_E_INVALID (a window schedule the producer does not take) or ZADA_E_HIP.
+int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out) {
+  if (!c->bt4) c->bt4 = new State();
+  State *B = (State *)c->bt4;
+  hipStream_t st = c->stream;
+  const uint64_t P64 = (arena_bytes + 63) & ~63ull;
+  if (P64 >= (1ull << 32)) { c->err = "LZMA: a batch of 4 GiB and more is not taken at once"; return ZADA_E_TOO_LARGE; }
+  const uint32_t P = (uint32_t)P64;
+  std::vector<Bt4Job> hj(jobs.size());
+  std::vector<Bt4Run> hr, one;
+  std::vector<uint32_t> tj(P / 64, NOJOB);
+  uint32_t hmax = 1u << 16;
+  for (size_t e = 0; e < jobs.size(); e++) {
+    const LzmaJob &J = jobs[e];
+    Bt4Job &b = hj[e];
+    memset(&b, 0, sizeof b);
+    b.in_off = J.in_off; b.n = J.level == 3 ? (uint32_t)J.n : 0; b.sbs = J.sbs; b.hash4_mask = J.hash4_size - 1; b.max_dist = J.sbs - (BT4_LOOK + 2);
+    b.run_off = (uint32_t)hr.size();
+    if (J.level != 3 || J.n == 0) continue;
+    if ((J.in_off & 63) || J.in_off + J.n > arena_bytes) { c->err = "LZMA: entry outside the arena"; return ZADA_E_INVALID; }
+    if (!bt4_schedule(J.n, J.sbs, one)) { c->err = "LZMA: window schedule not taken by the match producer"; return ZADA_E_INVALID; }
+    hr.insert(hr.end(), one.begin(), one.end());
+    b.run_cnt = (uint32_t)one.size();
+    if (J.hash4_size > hmax) hmax = J.hash4_size;
+    for (uint64_t t = J.in_off >> 6; t < (J.in_off + J.n + 63) >> 6; t++) tj[t] = (uint32_t)e;
+  }
+  if (hr.empty()) hr.push_back(Bt4Run{0, 0, 0, 0, 2, 0});
+  uint32_t hb4 = 16;
+  while ((1u << hb4) < hmax) hb4++;
+  const size_t tmp_bytes = radix_sort_tmp_bytes(P, 4);
+  if (B->ovf_cap < P / 16 + 1024) B->ovf_cap = P / 16 + 1024;
+  int rc;
+  if ((rc = grow(c, B->tile_job, 4ull * (P / 64) + 64)) || (rc = grow(c, B->jobs, sizeof(Bt4Job) * hj.size() + 64)) || (rc = grow(c, B->runs, sizeof(Bt4Run) * hr.size())) ||
+      (rc = grow(c, B->k2, 4ull * P)) || (rc = grow(c, B->k3, 4ull * P)) || (rc = grow(c, B->k4, 4ull * P)) || (rc = grow(c, B->val, 4ull * P)) || (rc = grow(c, B->ks, 4ull * P)) ||
+      (rc = grow(c, B->vs, 4ull * P)) || (rc = grow(c, B->tmp, tmp_bytes)) || (rc = grow(c, B->d2, 4ull * P)) || (rc = grow(c, B->d3, 4ull * P)) || (rc = grow(c, B->tree, 8ull * P)) ||
+      (rc = grow(c, B->cnt, P)) || (rc = grow(c, B->sl, 2ull * BT4_INLINE * P)) || (rc = grow(c, B->sd, 4ull * BT4_INLINE * P)) || (rc = grow(c, B->flags, 4ull * P)) ||
+      (rc = grow(c, B->heads, 4ull * P)) || (rc = grow(c, B->longs, 8ull * (P / BT_LONG + 64))) || (rc = grow(c, B->shorts, 8ull * P)) || (rc = grow(c, B->cnts, 256)) ||
+      (rc = grow(c, B->scan, 4ull * (P / 1024 + 64))))
+    return rc;
+  if (hipMemcpyAsync(B->tile_job.p, tj.data(), 4ull * tj.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(B->jobs.p, hj.data(), sizeof(Bt4Job) * hj.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(B->runs.p, hr.data(), sizeof(Bt4Run) * hr.size(), hipMemcpyHostToDevice, st) != hipSuccess) { hip_check(c, hipGetLastError(), "BT4 tables"); return ZADA_E_HIP; }
+  hipStreamSynchronize(st);                                         // (the host vectors go out of scope)
+  uint32_t *cnts = B->cnts.as<uint32_t>();
+  const uint32_t cnts0[8] = {0, 0, 0, 0, P, 0, 0, 0};
+  hipMemcpyAsync(cnts, cnts0, sizeof cnts0, hipMemcpyHostToDevice, st);
+  hipMemsetAsync(B->cnt.p, 0, P, st);
+  const Tables T{B->tile_job.as<uint32_t>(), B->jobs.as<Bt4Job>(), B->runs.as<Bt4Run>()};
+  const dim3 gp((P + 255) / 256), b256(256);
+  uint32_t *ks = B->ks.as<uint32_t>(), *vs = B->vs.as<uint32_t>(), *val = B->val.as<uint32_t>();
+  hipLaunchKernelGGL(k_bt4_keys, gp, b256, 0, st, d_arena, P, T, hb4, B->k2.as<uint32_t>(), B->k3.as<uint32_t>(), B->k4.as<uint32_t>(), val);
+  if ((rc = radix_sort_pairs(c, st, B->tmp.p, B->tmp.cap, B->k2.as<uint32_t>(), ks, val, vs, 4, P, 0, 11))) return rc;
+  hipLaunchKernelGGL(k_bt4_pred, gp, b256, 0, st, ks, vs, P, 1u << 10, T, B->d2.as<int32_t>());
+  if ((rc = radix_sort_pairs(c, st, B->tmp.p, B->tmp.cap, B->k3.as<uint32_t>(), ks, val, vs, 4, P, 0, 17))) return rc;
+  hipLaunchKernelGGL(k_bt4_pred, gp, b256, 0, st, ks, vs, P, 1u << 16, T, B->d3.as<int32_t>());
+  if ((rc = radix_sort_pairs(c, st, B->tmp.p, B->tmp.cap, B->k4.as<uint32_t>(), ks, val, vs, 4, P, 0, hb4 + 1))) return rc;
+  uint32_t *flags = B->flags.as<uint32_t>(), *heads = B->heads.as<uint32_t>();
+  hipLaunchKernelGGL(k_bt4_flags, gp, b256, 0, st, ks, vs, P, 1u << hb4, T, flags, cnts);
+  exclusive_scan_u32(st, flags, flags, B->scan.as<uint32_t>(), cnts + 5, P);                 // cnts [5] = number of buckets
+  hipLaunchKernelGGL(k_bt4_heads, gp, b256, 0, st, ks, vs, P, 1u << hb4, T, flags, heads);
+  hipLaunchKernelGGL(k_bt4_split, gp, b256, 0, st, heads, cnts + 5, cnts, B->longs.as<uint2>(), B->shorts.as<uint2>());
+  if (hip_check(c, hipGetLastError(), "BT4 producer (sorts)")) return ZADA_E_HIP;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if ((rc = grow(c, B->ol, 2ull * BT4_OVF * B->ovf_cap)) || (rc = grow(c, B->od, 4ull * BT4_OVF * B->ovf_cap))) return rc;
+    const Sets S{B->cnt.as<uint8_t>(), B->sl.as<uint16_t>(), B->sd.as<uint32_t>(), B->ol.as<uint16_t>(), B->od.as<uint32_t>(), B->ovf_cap};
+    const uint32_t nblk = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
+    hipLaunchKernelGGL(k_bt4_walk, dim3(nblk), b256, 0, st, d_arena, vs, B->longs.as<uint2>(), B->shorts.as<uint2>(), cnts, T, B->d2.as<int32_t>(), B->d3.as<int32_t>(),
+                       B->tree.as<int32_t>(), S);
+    uint32_t h[8];
+    hipMemcpyAsync(h, cnts, sizeof h, hipMemcpyDeviceToHost, st);
+    if (hip_check(c, hipStreamSynchronize(st), "k_bt4_walk")) return ZADA_E_HIP;
+    c->bt4_buckets = h[5]; c->bt4_long = h[0]; c->bt4_overflow = h[3];
+    if (h[3] <= B->ovf_cap) break;
+    if (attempt == 1) { c->err = "LZMA: overflow pool of the match sets"; return ZADA_E_HIP; }
+    B->ovf_cap = h[3] + 1024;                                        // (the trees are rebuilt from nothing: every walk writes its nodes before anyone reads them)
+    const uint32_t again[4] = {h[0], h[1], 0, 0};
+    hipMemcpyAsync(cnts, again, sizeof again, hipMemcpyHostToDevice, st);
+    hipMemsetAsync(B->cnt.p, 0, P, st);
+  }
+  out->cnt = B->cnt.as<uint8_t>(); out->sl = B->sl.as<uint16_t>(); out->sd = B->sd.as<uint32_t>(); out->ol = B->ol.as<uint16_t>(); out->od = B->od.as<uint32_t>();
+  return 0;
+}
+
+}  // namespace zada

@@ -726,6 +726,8 @@ __global__ void __launch_bounds__(1024) k_bz_newclass(const uint32_t *__restrict
 constexpr uint32_t GL_SMALL = 8, GL_WAVE = 64, GL_MAX = 8192;
 constexpr int GL_NCL = 4;                              // lists by group size
 struct GlEntry { uint32_t first, sb_rows; };           // first row | sub-block << 13 | rows - 1
+constexpr int GL_SB_BITS = 19;                         // sub-block numbers a list entry can hold (32 - 13 bits): bz_transform leaves the lists off beyond
+static_assert(GL_SB_BITS + 13 == 32, "GlEntry::sb_rows: 13 bits of rows - 1, the rest is the sub-block");
 __device__ __forceinline__ GlEntry gl_entry(uint32_t first, uint32_t rows, uint32_t sb) { return GlEntry{first, (sb << 13) | (rows - 1u)}; }
 __device__ __forceinline__ void gl_unpack(const GlEntry E, uint32_t &first, uint32_t &rows, uint32_t &sb) { first = E.first; rows = (E.sb_rows & 8191u) + 1u; sb = E.sb_rows >> 13; }
 // four lists by group size: up to 8 rows (a thread sorts the group), 9 .. 16 (sixteen lanes), 17 .. 64 (a wave), 65 .. 8 192 (a workgroup, in LDS)
@@ -737,8 +739,7 @@ constexpr uint32_t GL_MID = 16;
 struct GlSmall { uint32_t first, sb_rows, v0, v1; };
 constexpr uint32_t GLS_BOTH = 0x80000000u;
 struct GlLists { GlEntry *l[GL_NCL]; GlSmall *s; uint32_t *cnt; uint32_t cap[GL_NCL]; };   // (l[0] is not used: list 0 is s)
-int gl_sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-                  const void *vals_in, void *vals_out, size_t n, unsigned begin_bit, unsigned end_bit);   // zada_glsort.hip: 16-byte values   // cnt[0 .. 3]: entries of the lists; cnt[4]: overflow flag
+static_assert(sizeof(GlSmall) == 16, "the list sort moves 16-byte values (radix_sort_pairs, zada_sort.hip)");   // cnt[0 .. 3]: entries of the lists; cnt[4]: overflow flag
 __device__ __forceinline__ int gl_class(uint32_t rows) { return rows <= GL_SMALL ? 0 : rows <= GL_MID ? 1 : rows <= GL_WAVE ? 2 : 3; }
 
 // Text order.  k_bz_gl_build lists the groups in the order of the sorted rotations, where the rows of neighbouring groups lie side by side
@@ -746,8 +747,8 @@ __device__ __forceinline__ int gl_class(uint32_t rows) { return rows <= GL_SMALL
 // sectors for the 16 bytes a pair needs.  Data with long repeats (what is left for the lists: the same two, three stretches of text, row
 // by row) has the opposite order to offer: the groups {a+j, b+j}, j = 0, 1, 2 ... read classes at a+j+h and b+j+h and write them at a+j and
 // b+j.  Listed by the position of their first row, neighbouring threads share those sectors and only the group's rows themselves are a
-// gather.  The key is that position; one stable radix sort of the (key, entry) pairs when a list has been built (gl_sort_pairs,
-// zada_glsort.hip); the rounds keep the order workgroup by workgroup.
+// gather.  The key is that position; one stable radix sort of the (key, entry) pairs when a list has been built (radix_sort_pairs,
+// zada_sort.hip); the rounds keep the order workgroup by workgroup.
 __global__ void k_bz_gl_keys(const GlSmall *__restrict__ list, uint32_t n, uint32_t *__restrict__ keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) keys[i] = list[i].v0;
@@ -2145,7 +2146,7 @@ struct Bz2State {
   DBuf rle, bwt, keyA, keyB, valA, valB, cl, hv, hr, H, agg, cv0, cv1, acte, coff, cm, ctiles, ctile_first;
   DBuf gl_s[2], gl_m[2], gl_l[2], gl_w[2], gl_nc, gl_submax, gl_lmode, gl_cnt, gl_tmp, gl_k0, gl_k1, gl_v, gl_st;   // group lists of the late rounds (k_bz_gl_*)
   uint64_t gl_rows = 0;             // groups the lists' rounds of the last batch sorted (profiling aid)
-  size_t gl_st_bytes = 0;            // temporary storage of gl_sort_pairs
+  size_t gl_st_bytes = 0;            // temporary storage of the list sort
   std::vector<uint32_t> h_cm, h_cfirst;
   std::vector<uint64_t> m_hist;     // rows the doubling rounds of the last batch had to sort (profiling aid)
   std::vector<Tile> h_ct;
@@ -2319,7 +2320,8 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   std::vector<uint32_t> &h_cm = B->h_cm;
   std::vector<Tile> &ct = B->h_ct; std::vector<uint32_t> &cfirst = B->h_cfirst;
   // group lists of the late rounds (k_bz_gl_*): two generations, filled by one round and sorted by the next
-  const bool use_lists = c->knob_bz_lists != 0;
+  // (a list entry packs its sub-block into GL_SB_BITS bits -- gl_entry: a batch of more sub-blocks than that keeps sweeping)
+  const bool use_lists = c->knob_bz_lists != 0 && nsb <= (1u << GL_SB_BITS);
   GlLists GL[2];
   uint32_t *nc = nullptr, *submax = nullptr, *glcnt = nullptr;
   uint8_t *lmode = nullptr;
@@ -2332,8 +2334,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
         (rc = dbuf_ensure(c, B->gl_nc, 4 * ne)) || (rc = dbuf_ensure(c, B->gl_submax, 4ull * nsb + 64)) || (rc = dbuf_ensure(c, B->gl_lmode, nsb + 64)) ||
         (rc = dbuf_ensure(c, B->gl_cnt, 64))) return rc;
     if (c->knob_bz_text_order) {
-      size_t tb = 0;
-      if (gl_sort_pairs(st, nullptr, tb, nullptr, nullptr, nullptr, nullptr, cap_s, 8, 30)) { c->err = "bzip2: list sort (size query)"; return ZADA_E_HIP; }
+      const size_t tb = radix_sort_tmp_bytes(cap_s, sizeof(GlSmall));
       if ((rc = dbuf_ensure(c, B->gl_k0, 4ull * cap_s)) || (rc = dbuf_ensure(c, B->gl_k1, 4ull * cap_s)) || (rc = dbuf_ensure(c, B->gl_v, sizeof(GlSmall) * (size_t)cap_s)) ||
           (rc = dbuf_ensure(c, B->gl_st, tb + 256))) return rc;
       B->gl_st_bytes = tb;
@@ -2413,8 +2414,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       // order inside 256 positions does not matter: they share their sectors anyway)
       if (c->knob_bz_text_order && swept && 2 * h >= (uint32_t)c->knob_bz_lists && hc[0] > 1) {
         hipLaunchKernelGGL(k_bz_gl_keys, dim3((hc[0] + 255) / 256), dim3(256), 0, st, nxt.s, hc[0], B->gl_k0.as<uint32_t>());
-        size_t tb = B->gl_st_bytes;
-        if (gl_sort_pairs(st, B->gl_st.p, tb, B->gl_k0.as<uint32_t>(), B->gl_k1.as<uint32_t>(), nxt.s, B->gl_v.p, (size_t)hc[0], 8, 30)) { c->err = "bzip2: list sort"; return ZADA_E_HIP; }
+        if (radix_sort_pairs(c, st, B->gl_st.p, B->gl_st_bytes, B->gl_k0.as<uint32_t>(), B->gl_k1.as<uint32_t>(), nxt.s, B->gl_v.p, sizeof(GlSmall), (size_t)hc[0], 8, 30)) return ZADA_E_HIP;
         BZ_HIP(hipMemcpyAsync(nxt.s, B->gl_v.p, sizeof(GlSmall) * (size_t)hc[0], hipMemcpyDeviceToDevice, st));
       }
       gcur ^= 1;

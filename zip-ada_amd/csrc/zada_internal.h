@@ -245,9 +245,10 @@ struct Ctx {
   bool lz_attrs_set = false;
   void *bz = nullptr;                                // BZip2 state (zada_bz2.hip), made on first use
   void *lz_tab = nullptr; size_t cap_lz_tab = 0;     // LZMA (zada_lzma.hip): job table + results
-  void *lz_ws = nullptr; size_t cap_lz_ws = 0;       // ... the BT4 matcher's hash tables and trees (Level_3)
   void *lz_save = nullptr; size_t cap_lz_save = 0;   // ... the coder's state between the launches of one stream
   int lzma_launches = 0;                             // launches the last chunked LZMA call took
+  void *bt4 = nullptr;                               // ... the BT4 match producer's buffers (zada_bt4.hip), made on first use
+  uint32_t bt4_buckets = 0, bt4_long = 0, bt4_overflow = 0;   // last producer run: hash-4 buckets, long ones among them, overflow blocks booked
   // timing
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<const char *, hipEvent_t>> marks;
@@ -300,15 +301,19 @@ struct LzmaJob {
   uint64_t in_off, n;               // the entry
   uint64_t tok_off, ntok;           // its LZ77 tokens (Level_1 / Level_2)
   uint64_t out_off, cap;            // where the stream goes (the bytes beyond cap are counted, not written)
-  uint64_t ws_off;                  // Level_3: hash2 (1024) | hash3 (65536) | hash4 | tree (2 x sbs), all zero
+  uint64_t ws_off;                  // (unused: BT4's tables live with the producer, zada_bt4.hip)
   uint32_t sbs, hash4_size;         // String_buffer_size (lzma-encoding.adb:137-149), BT4's hash4 size (lz77.adb:1019-1032)
   int32_t level, zip_prefix;        // 0 .. 3; 1: the four bytes of zip-compress-lzma_e.adb:155-158 go first
 };
+// The match sets the BT4 producer leaves in HBM (zada_bt4.hip), indexed by arena position p: cnt [p] matches; match i < 7 at slot
+// p * 8 + i of sl (length) / sd (distance); match i >= 7 at slot sd [p * 8 + 7] * 43 + (i - 7) of ol / od.
+struct Bt4Sets { const uint8_t *cnt; const uint16_t *sl; const uint32_t *sd; const uint16_t *ol; const uint32_t *od; };
+int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out);
+void bt4_destroy(Ctx *c);
 uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size);
 uint32_t lzma_hash4_size(uint32_t sbs);
-uint64_t lzma_workspace_ints(int level, uint32_t sbs);
 int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, const uint32_t *d_ent_start, LzmaJob *d_jobs);
-int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result,
+int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
                 uint8_t *d_save = nullptr, uint64_t budget = 0);
 uint64_t lzma_save_stride();
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
@@ -339,6 +344,10 @@ int entropy_choose(Ctx *c);
 int entropy_emit(Ctx *c, uint8_t *d_out);
 int crc_launch(Ctx *c, const uint8_t *d_in, uint64_t n);
 int crc_finish(Ctx *c, uint64_t n, uint32_t *crc_inout);
+// zada_sort.hip: stable radix sort of n (key, value) pairs by the key bits [begin_bit, end_bit); values of 4 or 16 bytes
+size_t radix_sort_tmp_bytes(size_t n, size_t value_bytes);
+int radix_sort_pairs(Ctx *c, hipStream_t st, void *tmp, size_t tmp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const void *vals_in, void *vals_out, size_t value_bytes,
+                     size_t n, unsigned begin_bit, unsigned end_bit);
 void exclusive_scan_u32(hipStream_t st, const uint32_t *d_in, uint32_t *d_out, uint32_t *d_sums, uint32_t *d_total, uint32_t n);
 
 }  // namespace zada

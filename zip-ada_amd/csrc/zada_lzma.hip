@@ -8,8 +8,10 @@
 // the chain in step (same data, same branches: the cost of one lane) and part where the reference compares INDEPENDENT
 // simulations of what to write next -- a team of lanes per simulation, one lane per cut inside it (decide, scoring_top) -- to
 // compare the results in the reference's order.  Level_1 / Level_2 take their LZ77 tokens from the Info-Zip matcher kernels of the
-// Deflate path (IZ_6 / IZ_10, :118-122; zada_lz.hip) -- that part IS data parallel; Level_3 runs the BT4 binary-tree matcher
-// (lz77.adb:953-1827, insertion order matters) inside the chain, with its hash tables and tree in HBM.  The floating-point
+// Deflate path (IZ_6 / IZ_10, :118-122; zada_lz.hip) -- that part IS data parallel; Level_3's BT4 binary-tree matcher
+// (lz77.adb:953-1827) runs AHEAD of the chain as well: its match sets are a function of the input alone, one tree per hash-4 bucket,
+// and the producer of zada_bt4.hip leaves them in HBM before this kernel starts; what stays in the chain of LZ77_using_BT4 is the part
+// that reads the coder's state (repeat distances, the look-ahead of one position scored by the estimates, :1605-1796).  The floating-point
 // estimates are IEEE doubles multiplied in the reference's order, without contraction, so they are the values the Ada code computes.
 //
 // The sliding text buffer of the reference (Text_Buf, a ring of String_buffer_size bytes) only ever holds bytes of the input at
@@ -21,13 +23,14 @@
 #include <stdio.h>
 #include "../../include/zada.h"
 #include "zada_internal.h"
+#include "zada_bt4.h"
 
 namespace zada {
 namespace {
 
 constexpr int LZ_LIT = 0x300 << 3;             // lc = 3, lp = 0
 constexpr uint32_t LZ_PBM = 3;                 // pb = 2
-constexpr int LZ_MAXM = 276;                   // matches of one position: lengths strictly increase from 2 to 273 (272 of them), + 1 repeat match, (1 .. count)
+constexpr int LZ_MAXM = BT4_SET + 2;           // matches of one position: BT4 finds at most 50 (zada_bt4.h), + 1 repeat match, (1 .. count)
 
 struct LenProbs { uint16_t c1, c2, low[16][8], mid[16][8], high[256]; };
 struct LzProbs {                               // lzma.ads:137-201
@@ -253,6 +256,22 @@ __device__ inline double fmax0(double x) { return x > 0.0 ? x : 0.0; }
 // largest power of two t with n * t <= 64 (n >= 1): the lanes a task gets when n tasks share the wave
 __device__ inline int team_width(int n) { return n <= 1 ? 64 : n <= 2 ? 32 : n <= 4 ? 16 : n <= 8 ? 8 : n <= 16 ? 4 : n <= 32 ? 2 : 1; }
 
+// The cuts Test_Split_DL tries for a length (:899, 924-943): cut in 2 .. length - 2 with cut or length - cut in 4 .. 9 -- at most two
+// runs of consecutive values (12 cuts), listed in increasing order; nothing is kept in an array (a lane-indexed one lives in scratch).
+struct Cuts { int lo1, n1, lo2, n2; };
+__device__ inline Cuts cuts_of(int length) {
+  Cuts c{0, 0, 0, 0};
+  if (length < 6) return c;
+  const int a0 = 4, a1 = length - 2 < 9 ? length - 2 : 9;                      // cut in 4 .. 9
+  const int b0 = length - 9 > 2 ? length - 9 : 2, b1 = length - 4;             // length - cut in 4 .. 9
+  const bool a_first = a0 <= b0;
+  const int x0 = a_first ? a0 : b0, x1 = a_first ? a1 : b1, y0 = a_first ? b0 : a0, y1 = a_first ? b1 : a1;
+  if (y0 <= x1 + 1) { c.lo1 = x0; c.n1 = (x1 > y1 ? x1 : y1) - x0 + 1; }
+  else { c.lo1 = x0; c.n1 = x1 - x0 + 1; c.lo2 = y0; c.n2 = y1 - y0 + 1; }
+  return c;
+}
+__device__ inline int cut_at(const Cuts &c, int k) { return k < c.n1 ? c.lo1 + k : c.lo2 + (k - c.n1); }
+
 enum { W_STRICT = 0, W_LIT_DL = 1, W_DL_LIT = 2, W_EXPAND = 3, W_SPLIT = 4 };
 
 template <int R> __device__ void sim_any(uint32_t distance, int length, MS &sim, double &prob);   // Simulate_any_DL_Code, recursion_limit = R
@@ -308,15 +327,12 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t dist
     best_cut = 2;
     if (!(malus < soe)) {
       if constexpr (PAR) {
-        int cuts[12], nc = 0;                                                      // cut or length - cut in 4 .. 9 (:899, 925)
-        for (int cut = 2; cut <= length - 2; cut++) {
-          const int rest = length - cut;
-          if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) cuts[nc++] = cut;
-        }
+        const Cuts cuts = cuts_of(length);                                         // cut or length - cut in 4 .. 9 (:899, 925)
+        const int nc = cuts.n1 + cuts.n2;
         const int tw = team_width(nc), task = lane / tw;                           // one cut per team of tw lanes
         double pm = 0.0, pf = 0.0;
         if (task < nc) {
-          const int cut = cuts[task];
+          const int cut = cut_at(cuts, task);
           double p = malus;
           MS v = sim;
           v.tw = tw;
@@ -326,22 +342,19 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t dist
         }
         for (int k = 0; k < nc; k++) {
           const double pmk = __shfl(pm, k * tw), pfk = __shfl(pf, k * tw);
-          if (!(pmk <= soe)) { if (pfk > best_prob) { best_prob = pfk; best_cut = cuts[k]; } }
+          if (!(pmk <= soe)) { if (pfk > best_prob) { best_prob = pfk; best_cut = cut_at(cuts, k); } }
         }
       } else if (sim.tw > 1) {
         // A team of sim.tw lanes runs this simulation in step (same state, same branches).  Its cuts are independent simulations
         // again: a lane each, tw at a time; the results go round the team by cross-lane reads and are taken in cut order.
         const int tw = sim.tw, tl = lane & (tw - 1), tb = lane & ~(tw - 1);
-        int cuts[12], nc = 0;
-        for (int cut = 2; cut <= length - 2; cut++) {
-          const int rest = length - cut;
-          if ((cut >= 4 && cut <= 9) || (rest >= 4 && rest <= 9)) cuts[nc++] = cut;
-        }
+        const Cuts cuts = cuts_of(length);
+        const int nc = cuts.n1 + cuts.n2;
         for (int r = 0; r * tw < nc; r++) {
           const int k = r * tw + tl;
           double pm = 0.0, pf = 0.0;
           if (k < nc) {
-            const int cut = cuts[k];
+            const int cut = cut_at(cuts, k);
             double p = malus;
             MS v = sim;
             v.tw = 1;
@@ -351,7 +364,7 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t dist
           }
           for (int j = 0; j < tw && r * tw + j < nc; j++) {
             const double pmk = __shfl(pm, tb + j), pfk = __shfl(pf, tb + j);
-            if (!(pmk <= soe)) { if (pfk > best_prob) { best_prob = pfk; best_cut = cuts[r * tw + j]; } }
+            if (!(pmk <= soe)) { if (pfk > best_prob) { best_prob = pfk; best_cut = cut_at(cuts, r * tw + j); } }
           }
         }
       } else {
@@ -554,10 +567,11 @@ __device__ __noinline__ void write_strict(uint32_t distance, int length) {   // 
 // LZ77_emits_DL_code :1355-1361 = Write_any_DL_code (..., ES, max_recursion): the writing instance of Generic_any_DL_Code does not
 // lower its limit (:756-760), so its own recursion can go a match length deep; it is a work list here.  An item is a length
 // still to be written at `distance`, or the literal that follows a shortened match (:797-805).
+__shared__ uint16_t s_work[2 * 280];                                   // (every lane pushes and pops the same items: one copy in LDS, not 64 in scratch)
 __device__ __noinline__ void emit_dl(uint32_t distance, int length0) {
   PROF_T0;
   constexpr uint16_t POST_LIT = 0xFFFF;
-  uint16_t stack[2 * 280];
+  uint16_t *stack = s_work;
   int sp = 0;
   stack[sp++] = (uint16_t)length0;
   while (sp > 0) {
@@ -674,31 +688,26 @@ __device__ void estimate_dl_codes(int old_index, uint32_t prefix1, int &best_ind
 
 // ---------------------------------------------------------------- LZ77_using_BT4 (lz77.adb:953-1827)
 
+// What the chain keeps of BT4: the window bookkeeping (read / write positions, pending bytes: they decide how far matches and
+// repeat matches may reach and when the window is filled) and the state of Get_Next_Symbol.  The hash tables and the trees are the
+// producer's (zada_bt4.hip): Read_One_and_Get_Matches fetches the position's set from HBM, Skip only moves on.
 struct BT4 {
   int sbs, readPos, readLimit, writePos, pendingSize;
   int keepSizeBefore, keepSizeAfter, buf_len;
   int64_t moved;                                   // sum of the window moves: buf (i) = in [i + moved]
   uint64_t in_pos;
-  uint32_t hash_4_mask, h2, h3, h4;
-  int32_t *hash2, *hash3, *hash4, *tree;
-  int cyclicPos, lzPos, max_dist;
+  uint64_t base;                                   // arena position of the entry's first byte: the match sets are indexed by arena position
+  Bt4Sets sets;
   int readAhead, rep_dist[4], len_rep[4], best_len_rep, best_rep_index;
   int cur;                                         // current_match_index
   uint32_t cur_literal;
 };
 __shared__ BT4 s_B;
-constexpr int BT_LOOK = 273, BT_NICE = 162, BT_MIN = 2, BT_DEPTH = 48, BT_OPTS = 4096;
-
-__device__ inline uint32_t crc_tab(uint32_t i) {                                  // Hash234.crcTable :1091-1101
-  uint32_t r = i;
-#pragma unroll
-  for (int j = 0; j < 8; j++) r = (r & 1) ? (r >> 1) ^ 0xEDB88320u : r >> 1;
-  return r;
-}
+constexpr int BT_LOOK = BT4_LOOK, BT_NICE = BT4_NICE, BT_MIN = 2, BT_OPTS = BT4_OPTS;
 #define BUF(i) ((uint32_t)s_E.in[(int64_t)(i) + s_B.moved])
 
-// First index k in [len, limit) at which buf [a + k] /= buf [b + k], or limit: the byte loops of lz77.adb:1183-1191, 1287-1291,
-// 1331-1335, 1456-1458, eight bytes at a time while eight remain below the limit (nothing beyond a + limit / b + limit is read).
+// First index k in [len, limit) at which buf [a + k] /= buf [b + k], or limit: the byte loop of lz77.adb:1456-1458, eight bytes at
+// a time while eight remain below the limit (nothing beyond a + limit / b + limit is read).
 __device__ inline int bt_extend(const uint8_t *buf, int64_t a, int64_t b, int len, int limit) {
   while (len + 8 <= limit) {
     unsigned long long x, y;
@@ -714,102 +723,36 @@ __device__ inline int bt_extend(const uint8_t *buf, int64_t a, int64_t b, int le
 
 __device__ inline int bt_available() { return s_B.writePos - s_B.readPos - 1; }
 
-__device__ inline int bt_move_pos() {                                       // Move_Pos_in_BT4 :1127-1150 (finishing = False, :959)
+// Move_Pos_in_BT4 :1127-1150 (finishing = False, :959) without lzPos / cyclicPos: the producer counts the inserted positions itself
+__device__ inline int bt_move_pos() {
   s_B.readPos++;
   int avail = bt_available();
   if (avail < BT_NICE) { s_B.pendingSize++; avail = 0; }
-  if (avail != 0) {
-    s_B.lzPos++;                                     // (normalisation at Integer'Last cannot be reached below 2 GiB of input)
-    s_B.cyclicPos++;
-    if (s_B.cyclicPos == s_B.sbs) s_B.cyclicPos = 0;
-  }
   return avail;
 }
 
-__device__ inline void bt_hashes() {                           // calcHashes :1061-1069
-  const int off = s_B.readPos;
-  uint32_t t = crc_tab(BUF(off)) ^ BUF(off + 1);
-  s_B.h2 = t & 1023;
-  t ^= BUF(off + 2) << 8;
-  s_B.h3 = t & 65535;
-  t ^= crc_tab(BUF(off + 3)) << 5;
-  s_B.h4 = t & s_B.hash_4_mask;
+__device__ void bt_skip(int len) {                           // BT4_Algo.Skip :1208-1232: the tree update is the producer's
+  for (int count = len; count >= 1; count--) bt_move_pos();
 }
 
-__device__ __noinline__ void bt_skip_update(int niceLenLimit, int currentMatch) {   // Skip_and_Update_Tree :1154-1206
-  int32_t *tree = s_B.tree;
-  int depth = BT_DEPTH, ptr0 = s_B.cyclicPos * 2 + 1, ptr1 = s_B.cyclicPos * 2, len0 = 0, len1 = 0;
-  const int rp = s_B.readPos;
-  for (;;) {
-    const int delta0 = s_B.lzPos - currentMatch;
-    if (depth == 0 || delta0 >= s_B.max_dist) { tree[ptr0] = -1; tree[ptr1] = -1; return; }
-    depth--;
-    const int pair = (s_B.cyclicPos - delta0 + (s_B.cyclicPos - delta0 < 0 ? s_B.sbs : 0)) * 2;
-    int len = len0 < len1 ? len0 : len1;
-    len = bt_extend(s_E.in + s_B.moved, (int64_t)rp - delta0, rp, len, niceLenLimit);
-    if (len == niceLenLimit) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return; }
-    if (BUF(rp + len - delta0) < BUF(rp + len)) { tree[ptr1] = currentMatch; ptr1 = pair + 1; currentMatch = tree[ptr1]; len1 = len; }
-    else { tree[ptr0] = currentMatch; ptr0 = pair; currentMatch = tree[ptr0]; len0 = len; }
-  }
-}
-
-__device__ void bt_skip(int len) {                           // BT4_Algo.Skip :1208-1232
-  for (int count = len; count >= 1; count--) {
-    int nice = BT_NICE;
-    const int avail = bt_move_pos();
-    if (avail < nice) { if (avail == 0) continue; nice = avail; }
-    bt_hashes();
-    const int currentMatch = s_B.hash4[s_B.h4];
-    s_B.hash2[s_B.h2] = s_B.lzPos; s_B.hash3[s_B.h3] = s_B.lzPos; s_B.hash4[s_B.h4] = s_B.lzPos;
-    bt_skip_update(nice, currentMatch);
-  }
-}
-
+// BT4_Algo.Read_One_and_Get_Matches :1234-1361: the set the producer found for this position (none for a pending position: the
+// producer's schedule says so as well, cnt = 0), one match per lane
 __device__ __noinline__ void bt_get_matches(int set) {
-  Matches &M = s_MM[set];     // BT4_Algo.Read_One_and_Get_Matches :1234-1361
-  int32_t *tree = s_B.tree;
-  int matchLenLimit = BT_LOOK, nice = BT_NICE;
+  Matches &M = s_MM[set];
   M.count = 0;
   const int avail = bt_move_pos();
-  if (avail < matchLenLimit) {
-    if (avail == 0) return;
-    matchLenLimit = avail;
-    if (nice > avail) nice = avail;
-  }
-  const int rp = s_B.readPos;
-  bt_hashes();
-  int delta2 = s_B.lzPos - s_B.hash2[s_B.h2];
-  const int delta3 = s_B.lzPos - s_B.hash3[s_B.h3];
-  int currentMatch = s_B.hash4[s_B.h4];
-  s_B.hash2[s_B.h2] = s_B.lzPos; s_B.hash3[s_B.h3] = s_B.lzPos; s_B.hash4[s_B.h4] = s_B.lzPos;
-  int lenBest = 0;
-  if (delta2 < s_B.max_dist && BUF(rp - delta2) == BUF(rp)) { lenBest = 2; M.count = 1; M.len[1] = 2; M.dist[1] = delta2; }
-  if (delta2 != delta3 && delta3 < s_B.max_dist && BUF(rp - delta3) == BUF(rp)) { lenBest = 3; M.count++; M.dist[M.count] = delta3; delta2 = delta3; }
-  if (M.count > 0) {
-    lenBest = bt_extend(s_E.in + s_B.moved, (int64_t)rp - delta2, rp, lenBest, matchLenLimit);
-    M.len[M.count] = (uint16_t)lenBest;
-    if (lenBest >= nice) { bt_skip_update(nice, currentMatch); return; }
-  }
-  if (lenBest < 3) lenBest = 3;
-  int depth = BT_DEPTH, ptr0 = s_B.cyclicPos * 2 + 1, ptr1 = s_B.cyclicPos * 2, len0 = 0, len1 = 0;
-  for (;;) {
-    const int delta0 = s_B.lzPos - currentMatch;
-    if (depth == 0 || delta0 >= s_B.max_dist) { tree[ptr0] = -1; tree[ptr1] = -1; return; }
-    depth--;
-    const int pair = (s_B.cyclicPos - delta0 + (s_B.cyclicPos - delta0 < 0 ? s_B.sbs : 0)) * 2;
-    int len = len0 < len1 ? len0 : len1;
-    if (BUF(rp + len - delta0) == BUF(rp + len)) {
-      len = bt_extend(s_E.in + s_B.moved, (int64_t)rp - delta0, rp, len + 1, matchLenLimit);
-      if (len > lenBest) {
-        lenBest = len;
-        M.count++;
-        M.len[M.count] = (uint16_t)len; M.dist[M.count] = delta0;
-        if (len >= nice) { tree[ptr1] = tree[pair]; tree[ptr0] = tree[pair + 1]; return; }
-      }
+  if (avail == 0) return;
+  const uint64_t p = s_B.base + (uint64_t)((int64_t)s_B.readPos + s_B.moved);
+  const int cnt = s_B.sets.cnt[p], i = (int)threadIdx.x;
+  if (i < cnt) {
+    if (i < BT4_INLINE - 1) { M.len[i + 1] = s_B.sets.sl[p * BT4_INLINE + i]; M.dist[i + 1] = (int)s_B.sets.sd[p * BT4_INLINE + i]; }
+    else {
+      const uint64_t o = (uint64_t)s_B.sets.sd[p * BT4_INLINE + (BT4_INLINE - 1)] * BT4_OVF + (uint32_t)(i - (BT4_INLINE - 1));
+      M.len[i + 1] = s_B.sets.ol[o]; M.dist[i + 1] = (int)s_B.sets.od[o];
     }
-    if (BUF(rp + len - delta0) < BUF(rp + len)) { tree[ptr1] = currentMatch; ptr1 = pair + 1; currentMatch = tree[ptr1]; len1 = len; }
-    else { tree[ptr0] = currentMatch; ptr0 = pair; currentMatch = tree[ptr0]; len0 = len; }
   }
+  M.count = cnt;
+  __syncthreads();
 }
 
 __device__ int bt_fill_window(int len_initial) {             // Fill_Window :1389-1440, Move_Window :1375-1386
@@ -957,16 +900,14 @@ __device__ __noinline__ void lz_next_symbol() {           // Get_Next_Symbol :16
   lz_send_dl(main_dist, main_len);
 }
 
-__device__ bool lz_bt4_begin(int sbs, int32_t *ws, uint32_t hash4_size) {        // LZ77_using_BT4 up to its main loop; False: nothing to code
+__device__ bool lz_bt4_begin(int sbs, uint64_t base, const Bt4Sets &sets) {        // LZ77_using_BT4 up to its main loop; False: nothing to code
   s_B.sbs = sbs; s_B.readPos = -1; s_B.readLimit = -1; s_B.writePos = 0; s_B.pendingSize = 0;
   s_B.keepSizeBefore = BT_OPTS + sbs;
   s_B.keepSizeAfter = BT_OPTS + BT_LOOK;
   const int64_t r = (int64_t)sbs / 2 + 256 * 1024, rmax = 512ll << 20;
   s_B.buf_len = s_B.keepSizeBefore + s_B.keepSizeAfter + (int)(r < rmax ? r : rmax) + 1;
   s_B.moved = 0; s_B.in_pos = 0;
-  s_B.hash_4_mask = hash4_size - 1;
-  s_B.hash2 = ws; s_B.hash3 = ws + 1024; s_B.hash4 = ws + 1024 + 65536; s_B.tree = ws + 1024 + 65536 + hash4_size;
-  s_B.cyclicPos = -1; s_B.lzPos = sbs; s_B.max_dist = sbs - (BT_LOOK + 2);
+  s_B.base = base; s_B.sets = sets;
   s_B.readAhead = -1;
   for (int i = 0; i < 4; i++) { s_B.rep_dist[i] = 1; s_B.len_rep[i] = 0; }
   s_B.best_len_rep = 0; s_B.best_rep_index = 0;
@@ -1001,7 +942,7 @@ template <typename T> __device__ inline void words_in(T &dst, const T *src) {
 }
 
 __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint32_t *order, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
-                                                    int32_t *ws_base, uint64_t *result, uint8_t *save_base, uint64_t budget) {
+                                                    Bt4Sets sets, uint64_t *result, uint8_t *save_base, uint64_t budget) {
   LzProbs &P = s_P;
   const uint32_t job = order ? order[blockIdx.x] : blockIdx.x;      // the longest entries first: workgroups start in index order
   const LzmaJob J = jobs[job];
@@ -1013,6 +954,8 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   if (phase == 1) {
     words_in(s_P, &S->P); words_in(s_MM[0], &S->MM[0]); words_in(s_MM[1], &S->MM[1]); words_in(s_E, &S->E); words_in(s_B, &S->B);
     iter = S->iter; running = S->running != 0;
+    __syncthreads();
+    if (threadIdx.x == 0) s_B.sets = sets;                          // (the producer's buffers of THIS call)
     __syncthreads();
   } else {
     {
@@ -1035,7 +978,7 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
     if (J.zip_prefix) { put_byte(16); put_byte(2); put_byte(5); put_byte(0); }   // zip-compress-lzma_e.adb:155-158
     put_byte(3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
     for (int i = 0; i < 4; i++) put_byte((J.sbs >> (8 * i)) & 255);
-    if (J.level == 3) running = lz_bt4_begin((int)J.sbs, ws_base + J.ws_off, J.hash4_size);
+    if (J.level == 3) running = lz_bt4_begin((int)J.sbs, J.in_off, sets);
   }
   const uint64_t stop = budget ? s_E.ES.pos + budget : ~0ull;      // (every step of the loops below codes at least one position)
   bool done = true;
@@ -1085,22 +1028,9 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
 uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size) {
   if (level == 0) return 16;
   if (level <= 2) return 1u << 15;
-  uint64_t x = dictionary_size + 273 + 1 + 64, p = 1;
-  while (p < 0x7FFFFFFFull / 2 && p < x) p *= 2;
-  if (p < x) p = x;
-  if (p > (1ull << 28)) p = 1ull << 28;
-  if (p < 4096) p = 4096;
-  return (uint32_t)p;
+  return bt4_string_buffer_size(dictionary_size);
 }
-uint32_t lzma_hash4_size(uint32_t sbs) {
-  uint32_t h = sbs - 1;
-  h |= h >> 1; h |= h >> 2; h |= h >> 4; h |= h >> 8;
-  h >>= 1;
-  h |= 0xFFFF;
-  if (h > (1u << 24)) h >>= 1;
-  return h + 1;
-}
-uint64_t lzma_workspace_ints(int level, uint32_t sbs) { return level == 3 ? 1024ull + 65536 + lzma_hash4_size(sbs) + 2ull * sbs : 0; }
+uint32_t lzma_hash4_size(uint32_t sbs) { return bt4_hash4_size(sbs); }
 
 // A batch whose tokens came from ONE pass of the LZ stage over all entries (zada_api.hip, lzma_batch_iz): entry e's tokens are
 // those whose positions lie in its slot [ent_start[e], ent_start[e + 1]) of the packed buffer.
@@ -1125,14 +1055,14 @@ int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, co
   return hip_check(c, hipGetLastError(), "k_lzma_token_ranges") ? ZADA_E_HIP : 0;
 }
 
-// jobs[0 .. count): device array; results: 2 x count uint64 (stream bytes, input bytes coded).  Level_3 hash tables must be zero.
+// jobs[0 .. count): device array; results: 2 x count uint64 (stream bytes, input bytes coded).  sets: the BT4 producer's match sets (Level_3).
 // d_save / budget: a stream in several launches (count slots of lzma_save_stride() bytes, zero before the first launch; a launch codes
 // `budget` more positions of every unfinished stream and flags bit 63 of its second result while there is more to come); nullptr / 0: one launch.
 uint64_t lzma_save_stride() { return LZ_SAVE_STRIDE; }
-int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, int32_t *d_ws, uint64_t *d_result,
+int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
                 uint8_t *d_save, uint64_t budget) {
   if (count == 0) return 0;
-  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, d_ws, d_result, d_save, d_save ? budget : 0ull);
+  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, sets, d_result, d_save, d_save ? budget : 0ull);
   return hip_check(c, hipGetLastError(), "k_lzma_encode") ? ZADA_E_HIP : 0;
 }
 
