@@ -215,3 +215,53 @@ extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t 
   }
   return 0;
 }
+
+// Analysis helper (not a test): steps of bt4_step per hash-4 bucket -- the longest sum is the producer's critical path.
+extern "C" int hc_bt4_bucket_steps(const uint8_t *in, uint64_t n, int64_t dict, uint64_t *out /* [0] buckets, [1] positions, [2] total steps, [3] max steps of a bucket, [4] its positions, [5] max positions of a bucket */) {
+  const uint32_t sbs = bt4_string_buffer_size((uint64_t)dict), mask = bt4_hash4_size(sbs) - 1;
+  const int32_t max_dist = (int32_t)sbs - (BT4_LOOK + 2);
+  std::vector<Bt4Run> runs;
+  if (!bt4_schedule(n, sbs, runs)) return -1;
+  std::vector<uint32_t> pos, h2, h3, h4;
+  for (uint64_t q = 0; q < n; q++) {
+    const Bt4Run *r = bt4_run_of(runs.data(), (uint32_t)runs.size(), (uint32_t)q);
+    if (r->cls == 2) continue;
+    uint32_t a, b, c;
+    bt4_hashes(bt4_crc(in[q]), in[q + 1], in[q + 2], bt4_crc(in[q + 3]), mask, a, b, c);
+    pos.push_back((uint32_t)q); h2.push_back(a); h3.push_back(b); h4.push_back(c);
+  }
+  const size_t m = pos.size();
+  std::vector<int32_t> o2(n, BT4_NONE), o3(n, BT4_NONE);
+  std::vector<uint32_t> idx(m);
+  auto preds = [&](const std::vector<uint32_t> &h, std::vector<int32_t> &o) {
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return h[x] < h[y]; });
+    for (size_t i = 1; i < m; i++) if (h[idx[i]] == h[idx[i - 1]]) o[pos[idx[i]]] = (int32_t)pos[idx[i - 1]];
+  };
+  preds(h2, o2); preds(h3, o3);
+  std::iota(idx.begin(), idx.end(), 0u);
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return h4[x] < h4[y]; });
+  std::vector<int32_t> tree(2 * n + 2, 12345);
+  auto ext = [](const uint8_t *b, int64_t a, int64_t c, int l, int lim) { return bt4_extend(b, a, c, l, lim); };
+  auto put = [&](int, int, uint32_t) {};
+  memset(out, 0, 6 * sizeof(uint64_t));
+  for (size_t i = 0; i < m;) {
+    size_t j = i + 1; while (j < m && h4[idx[j]] == h4[idx[i]]) j++;
+    int32_t root = BT4_NONE; uint64_t steps = 0;
+    for (size_t k = i; k < j; k++) {
+      const uint32_t q = pos[idx[k]];
+      const Bt4Run *r = bt4_run_of(runs.data(), (uint32_t)runs.size(), q);
+      const int avail = (int)(r->W - q - 1);
+      Bt4Walk wk;
+      bt4_begin(wk, in, q, (int32_t)q, r->cls == 0, avail < BT4_LOOK ? avail : BT4_LOOK, max_dist, root, o2[q], o3[q], ext, put);
+      steps++;
+      while (!bt4_step(wk, tree.data(), ext, put)) steps++;
+      root = (int32_t)q;
+    }
+    out[0]++; out[1] += j - i; out[2] += steps;
+    if (steps > out[3]) { out[3] = steps; out[4] = j - i; }
+    if (j - i > out[5]) out[5] = j - i;
+    i = j;
+  }
+  return 0;
+}

@@ -210,15 +210,18 @@ __device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &si
   int found = -1;
   const double dlc = tbe(s_P.match[sim.state][sim.pos_state], 1);
   const double sma = test_simple_match(dist_ip, (uint32_t)length, sim);
-  for (int i = 0; i < 4; i++) if (dist_ip == sim.rep[i]) { found = i; break; }
+  // (no run-time index into sim.rep: one would put the whole state in scratch memory)
+  found = dist_ip == sim.rep[0] ? 0 : dist_ip == sim.rep[1] ? 1 : dist_ip == sim.rep[2] ? 2 : dist_ip == sim.rep[3] ? 3 : -1;
   bool rep = false;
   if (found >= 0) {
     const double rma = test_repeat_match(found, (uint32_t)length, sim);
     if (rma >= sma * 0.55) {                                                       // Malus_simple_match_vs_rep :301
       prob = prob * dlc * rma;
-      const uint32_t aux = sim.rep[found];
-      for (int i = found; i >= 1; i--) sim.rep[i] = sim.rep[i - 1];
-      sim.rep[0] = aux;
+      const uint32_t r0 = sim.rep[0], r1 = sim.rep[1], r2 = sim.rep[2];           // rep (found) to the front, the ones before it one down
+      sim.rep[0] = dist_ip;
+      if (found >= 1) sim.rep[1] = r0;
+      if (found >= 2) sim.rep[2] = r1;
+      if (found >= 3) sim.rep[3] = r2;
       sim.state = T_REP[sim.state];
       rep = true;
     }
