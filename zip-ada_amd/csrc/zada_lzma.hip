@@ -607,61 +607,79 @@ __device__ __noinline__ void emit_dl(uint32_t distance, int length0) {
 
 // ---------------------------------------------------------------- Estimate_DL_Codes_for_LZ77 :1363-1498
 
+// What Scoring shares between its levels (:1370-1384): the same for every lane, so in LDS once (as a local passed by reference it
+// lived in every lane's scratch memory).
 struct ScoreCtx { int old_index, last_pos_any; MS sim_new; double head_lit_prob; };
+__shared__ ScoreCtx s_S;
+
+__device__ double scoring2(MS state, int start);
 
 // One candidate of Scoring (:1404-1468): the probability of the message that starts with match i of set m.
-template <int LEVEL> __device__ void scoring(const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set);
-template <int LEVEL> __device__ inline double score_candidate(const ScoreCtx &S, const MS &state, int start, int m, int i) {
+template <int LEVEL> __device__ __forceinline__ double score_candidate(const MS &state, int start, int m, int i) {
   const Matches &M = s_MM[m];
-  const int last_pos_i = M.len[i] + (m != S.old_index ? 1 : 0);
+  const int old_index = s_S.old_index;
+  const int mlen = M.len[i], last_pos_i = mlen + (m != old_index ? 1 : 0);
   MS t; double p;
-  if (m != S.old_index && start == 1) { t = S.sim_new; p = S.head_lit_prob; } else { t = state; p = 1.0; }
+  if (m != old_index && start == 1) { t = s_S.sim_new; p = s_S.head_lit_prob; } else { t = state; p = 1.0; }
   t.tw = state.tw;
   int trunc;
-  if (m == S.old_index) trunc = M.len[i] - start + 1;
-  else if (start == 1) trunc = M.len[i];
-  else trunc = M.len[i] - start + 2;
+  if (m == old_index) trunc = mlen - start + 1;
+  else if (start == 1) trunc = mlen;
+  else trunc = mlen - start + 2;
   if (trunc == 1) sim_literal(TB((int64_t)state.pos), t, p);
   else sim_any<1>((uint32_t)M.dist[i], trunc, t, p);
   if constexpr (LEVEL < 2) {
-    if (last_pos_i < S.last_pos_any) {
-      double tail; int si = 1, sm = 0;
-      scoring<LEVEL + 1>(S, t, last_pos_i + 1, tail, si, sm);
-      p = p * tail;
-    }
+    if (last_pos_i < s_S.last_pos_any) p = p * scoring2(t, last_pos_i + 1);
   }
   return p;
 }
 
-template <int LEVEL> __device__ __noinline__ void scoring_impl(const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {   // :1385-1469
-  prob = 0.0;
-  for (int m = 0; m <= 1; m++) {
-    const Matches &M = s_MM[m];
-    for (int i = 1; i <= M.count; i++) {
-      const int last_pos_i = M.len[i] + (m != S.old_index ? 1 : 0);
-      if (last_pos_i < start) continue;
-      if (last_pos_i < S.last_pos_any && LEVEL >= 2) continue;
-      const double p = score_candidate<LEVEL>(S, state, start, m, i);
-      if (p > prob) { prob = p; index = i; match_set = m; }
-    }
-  }
+// Scoring at recursion level 2 (:1385-1469; only the probability of its best candidate is used, :1459-1464).  It runs on the team of
+// state.tw lanes that scores one candidate of level 1, in step.  Its own candidates -- the matches that reach last_pos_any (:1421-1424)
+// -- are independent simulations again: the team parts into sub-teams, one candidate each, as many at a time as there are sub-teams,
+// and the results are reduced over the team (a maximum: Scoring keeps the first strict maximum, and nothing but its value is used).
+__device__ inline bool score2_takes(int m, int i, int start) {
+  const int last_pos_i = s_MM[m].len[i] + (m != s_S.old_index ? 1 : 0);
+  return last_pos_i >= start && last_pos_i >= s_S.last_pos_any;
 }
-template <int LEVEL> __device__ void scoring(const ScoreCtx &S, const MS &state, int start, double &prob, int &index, int &match_set) {
-  scoring_impl<LEVEL>(S, state, start, prob, index, match_set);
+__device__ __noinline__ double scoring2(MS state, int start) {
+  const int tw = state.tw, lane = (int)threadIdx.x, tl = lane & (tw - 1);
+  const int c0 = s_MM[0].count, total = c0 + s_MM[1].count;
+  int nq = 0;
+  for (int k = 0; k < total; k++) nq += score2_takes(k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1, start) ? 1 : 0;
+  int stw = tw;                                                      // sub-team width: the largest power of two with nq * stw <= tw, at least 1
+  while (stw > 1 && nq * stw > tw) stw >>= 1;
+  const int groups = tw / stw, g = tl / stw;
+  double best = 0.0;
+  for (int r = 0; r * groups < nq; r++) {
+    const int mine = r * groups + g;
+    double p = 0.0;
+    if (mine < nq) {
+      int seen = 0, km = 0;
+      for (int k = 0; k < total; k++)
+        if (score2_takes(k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1, start)) { if (seen == mine) km = k; seen++; }
+      MS st = state;
+      st.tw = stw;
+      p = score_candidate<2>(st, start, km < c0 ? 0 : 1, (km < c0 ? km : km - c0) + 1);
+    }
+    for (int off = stw; off < tw; off <<= 1) { const double o = __shfl_xor(p, off); p = o > p ? o : p; }     // (the lanes of a sub-team hold the same p)
+    if (p > best) best = p;
+  }
+  return best;
 }
 
 // Scoring at level 1, start 1, called from the chain (all lanes in step): every match of both sets is a candidate (their
-// last positions are >= 1), one lane each; the best is then picked by all lanes in the reference's order (first strict maximum).
-__device__ __noinline__ void scoring_top(const ScoreCtx &S, const MS &state, double &prob, int &index, int &match_set) {
+// last positions are >= 1), a team of lanes each; the best is then picked by all lanes in the reference's order (first strict maximum).
+__device__ __forceinline__ void scoring_top(const MS &state, int &index, int &match_set) {
   const int lane = (int)threadIdx.x, c0 = s_MM[0].count, total = c0 + s_MM[1].count;
   const int tw = team_width(total), per_round = 64 / tw;                           // a team of tw lanes per candidate
   MS st = state;
   st.tw = tw;
-  prob = 0.0;
+  double prob = 0.0;
   for (int base = 0; base < total; base += per_round) {
     const int k = base + lane / tw;
     double p = 0.0;
-    if (k < total) p = score_candidate<1>(S, st, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
+    if (k < total) p = score_candidate<1>(st, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
     const int cnt = total - base < per_round ? total - base : per_round;
     for (int j = 0; j < cnt; j++) {
       const double pj = __shfl(p, j * tw);
@@ -673,19 +691,20 @@ __device__ __noinline__ void scoring_top(const ScoreCtx &S, const MS &state, dou
 
 __device__ void estimate_dl_codes(int old_index, uint32_t prefix1, int &best_index, int &best_set) {
   PROF_T0;
-  ScoreCtx S;
-  S.old_index = old_index; S.last_pos_any = 0; S.sim_new = s_E.ES;
+  int last_pos_any = 0;
   for (int m = 0; m <= 1; m++)
     for (int i = 1; i <= s_MM[m].count; i++) {
       const int lp = s_MM[m].len[i] + (m != old_index ? 1 : 0);
-      if (lp > S.last_pos_any) S.last_pos_any = lp;
+      if (lp > last_pos_any) last_pos_any = lp;
     }
-  S.head_lit_prob = 1.0;
-  sim_literal(prefix1, S.sim_new, S.head_lit_prob);
+  MS sim_new = s_E.ES;
+  double head_lit_prob = 1.0;
+  sim_literal(prefix1, sim_new, head_lit_prob);
+  s_S.old_index = old_index; s_S.last_pos_any = last_pos_any; s_S.sim_new = sim_new; s_S.head_lit_prob = head_lit_prob;
+  __syncthreads();
   best_index = 1; best_set = old_index;
-  double best;
   const MS sim_old = s_E.ES;
-  scoring_top(S, sim_old, best, best_index, best_set);
+  scoring_top(sim_old, best_index, best_set);
   PROF_ADD(3);
 }
 
@@ -933,7 +952,7 @@ struct LzSave {
   LzProbs P; Matches MM[2]; Enc E; BT4 B;
 };
 constexpr uint64_t LZ_SAVE_STRIDE = (sizeof(LzSave) + 63) & ~63ull;
-static_assert(sizeof(LzProbs) % 4 == 0 && sizeof(Matches) % 4 == 0 && sizeof(Enc) % 4 == 0 && sizeof(BT4) % 4 == 0, "word copies");
+static_assert(sizeof(ScoreCtx) % 4 == 0 && sizeof(LzProbs) % 4 == 0 && sizeof(Matches) % 4 == 0 && sizeof(Enc) % 4 == 0 && sizeof(BT4) % 4 == 0, "word copies");
 
 template <typename T> __device__ inline void words_out(T *dst, const T &src) {
   const uint32_t *s = (const uint32_t *)&src; uint32_t *d = (uint32_t *)dst;
