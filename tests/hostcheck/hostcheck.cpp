@@ -193,6 +193,8 @@ extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t 
   uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
   for (size_t i = buckets.size(); i > 1; i--) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(buckets[i - 1], buckets[x % i]); }
   std::vector<int32_t> tree(2 * n + 2, 12345);       // (never read before written: a walk only reaches nodes of its own bucket)
+  std::vector<uint16_t> tree16(2 * n + 2, 12345);    // the LDS form of the nodes (k_bt4_walk_lds) for entries it would take
+  const bool small = n <= BT4_LDS_N && runs.size() <= 2;
   uint16_t ml[BT4_SET]; uint32_t md[BT4_SET];
   auto ext = [](const uint8_t *b, int64_t a, int64_t c, int l, int lim) { return bt4_extend(b, a, c, l, lim); };
   for (auto &bk : buckets) {
@@ -205,7 +207,8 @@ extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t 
       auto put = [&](int i, int l, uint32_t dd) { ml[i] = (uint16_t)l; md[i] = dd; };
       Bt4Walk wk;
       bt4_begin(wk, in, q, ordp, r->cls == 0, limit, max_dist, root, o2[q], o3[q], ext, put);
-      while (!bt4_step(wk, tree.data(), ext, put)) {}
+      if (small) { while (!bt4_step(wk, Bt4TreeU16{tree16.data()}, ext, put)) {} }
+      else { while (!bt4_step(wk, Bt4TreeI32{tree.data()}, ext, put)) {} }
       const int c = wk.count;
       if (c > stride) return -2;
       cnt[q] = (uint8_t)c;
@@ -255,7 +258,7 @@ extern "C" int hc_bt4_bucket_steps(const uint8_t *in, uint64_t n, int64_t dict, 
       Bt4Walk wk;
       bt4_begin(wk, in, q, (int32_t)q, r->cls == 0, avail < BT4_LOOK ? avail : BT4_LOOK, max_dist, root, o2[q], o3[q], ext, put);
       steps++;
-      while (!bt4_step(wk, tree.data(), ext, put)) steps++;
+      while (!bt4_step(wk, Bt4TreeI32{tree.data()}, ext, put)) steps++;
       root = (int32_t)q;
     }
     out[0]++; out[1] += j - i; out[2] += steps;

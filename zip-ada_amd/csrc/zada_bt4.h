@@ -51,7 +51,10 @@ struct Bt4Job {
   uint64_t in_off;                                   // arena position of the entry's first byte (a multiple of 64)
   uint32_t n, sbs, hash4_mask, max_dist;
   uint32_t run_off, run_cnt;                         // its runs in the run table
+  uint32_t sorted_off;                               // its inserted positions in the (entry, hash 4) order start here
+  uint32_t small;                                    // 1: one window fill and at most BT4_LDS_N bytes -- its trees are built in LDS
 };
+constexpr uint32_t BT4_LDS_N = 16384;                // tree (2 x 2 bytes per inserted position; the last 162 never are) + text = 80 KB: two entries per CU
 
 // String_buffer_size of Level_3 (lzma-encoding.adb:137-149) and BT4's hash-4 table size (lz77.adb:1019-1032)
 ZADA_BT_HD uint32_t bt4_string_buffer_size(uint64_t dictionary_size) {
@@ -107,6 +110,19 @@ ZADA_BT_HD int bt4_extend(const uint8_t *in, int64_t a, int64_t b, int len, int 
 // In two parts, so that a lane can take its next position while its neighbours are still on their way down: bt4_begin (the two hash
 // matches, :1263-1305) and bt4_step (one level of the tree, :1309-1360 / :1164-1205; true = the visit is over).  `put (i, len, dist)`
 // receives match i (lengths strictly increasing); `extend (in, a, b, len, limit)` is bt4_extend or a faster form of it.
+// The nodes of an entry's trees: two children per inserted position, as ordinals (BT4_NONE = no child).  In HBM they are ints; an
+// entry small enough for LDS (zada_bt4.hip, k_bt4_walk_lds) keeps them as 16-bit values there.
+struct Bt4TreeI32 {
+  int32_t *t;
+  ZADA_BT_HD int32_t get(uint32_t i) const { return t[i]; }
+  ZADA_BT_HD void set(uint32_t i, int32_t v) const { t[i] = v; }
+};
+struct Bt4TreeU16 {
+  uint16_t *t;
+  ZADA_BT_HD int32_t get(uint32_t i) const { const uint16_t v = t[i]; return v == 0xFFFFu ? BT4_NONE : (int32_t)v; }
+  ZADA_BT_HD void set(uint32_t i, int32_t v) const { t[i] = (uint16_t)v; }          // (BT4_NONE = -1 -> 0xFFFF)
+};
+
 struct Bt4Walk {
   const uint8_t *in; int64_t qq;
   int32_t ordp, max_dist, cur;
@@ -136,14 +152,17 @@ ZADA_BT_HD void bt4_begin(Bt4Walk &w, const uint8_t *in, uint32_t q, int32_t ord
   }
   w.depth = BT4_DEPTH; w.ptr0 = 2u * (uint32_t)ordp + 1u; w.ptr1 = 2u * (uint32_t)ordp; w.len0 = 0; w.len1 = 0;
 }
-template <typename Ext, typename Put>
-ZADA_BT_HD bool bt4_step(Bt4Walk &w, int32_t *tree, Ext extend, Put put) {
+template <typename Tree, typename Ext, typename Put>
+ZADA_BT_HD bool bt4_step(Bt4Walk &w, const Tree tree, Ext extend, Put put) {
   constexpr int32_t FAR = 0x7FFFFFFF;
   const int nice = BT4_NICE;                         // niceLenLimit = min (Nice_Length, avail) = 162 for every inserted position
   const int32_t cur = w.cur, delta0 = cur >= 0 ? w.ordp - cur : FAR;
-  if (w.depth == 0 || delta0 >= w.max_dist) { tree[w.ptr0] = BT4_NONE; tree[w.ptr1] = BT4_NONE; return true; }                          // :1166-1170, 1311-1315
+  if (w.depth == 0 || delta0 >= w.max_dist) { tree.set(w.ptr0, BT4_NONE); tree.set(w.ptr1, BT4_NONE); return true; }                          // :1166-1170, 1311-1315
   w.depth--;
   const uint32_t pair = 2u * (uint32_t)cur;
+  // the candidate's two children now, next to its bytes: nothing below writes them (the stores go to slots of nodes met EARLIER on the
+  // way down, or of the position itself), and loaded here they do not wait for the byte comparison
+  const int32_t child0 = tree.get(pair), child1 = tree.get(pair + 1);
   const uint8_t *in = w.in;
   const int64_t qq = w.qq;
   int len = w.len0 < w.len1 ? w.len0 : w.len1;
@@ -153,15 +172,15 @@ ZADA_BT_HD bool bt4_step(Bt4Walk &w, int32_t *tree, Ext extend, Put put) {
       if (len > w.lenBest) {
         w.lenBest = len;
         put(w.count, len, (uint32_t)delta0); w.count++;
-        if (len >= nice) { tree[w.ptr1] = tree[pair]; tree[w.ptr0] = tree[pair + 1]; return true; }                                       // :1340-1345
+        if (len >= nice) { tree.set(w.ptr1, child0); tree.set(w.ptr0, child1); return true; }                                                   // :1340-1345
       }
     }
   } else {
     len = extend(in, qq - delta0, qq, len, nice);
-    if (len == nice) { tree[w.ptr1] = tree[pair]; tree[w.ptr0] = tree[pair + 1]; return true; }                                           // :1185-1189
+    if (len == nice) { tree.set(w.ptr1, child0); tree.set(w.ptr0, child1); return true; }                                                       // :1185-1189
   }
-  if (in[qq + len - delta0] < in[qq + len]) { tree[w.ptr1] = cur; w.ptr1 = pair + 1; w.cur = tree[w.ptr1]; w.len1 = len; }              // :1195-1205, 1349-1359
-  else { tree[w.ptr0] = cur; w.ptr0 = pair; w.cur = tree[w.ptr0]; w.len0 = len; }
+  if (in[qq + len - delta0] < in[qq + len]) { tree.set(w.ptr1, cur); w.ptr1 = pair + 1; w.cur = child1; w.len1 = len; }                     // :1195-1205, 1349-1359
+  else { tree.set(w.ptr0, cur); w.ptr0 = pair; w.cur = child0; w.len0 = len; }
   return false;
 }
 

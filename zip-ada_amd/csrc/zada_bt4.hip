@@ -9,11 +9,14 @@
 //                  and, the arena being entry after entry, in entry order;
 //   k_bt4_pred     hash 2 / hash 3: the previous position of the same hash AND entry = what hash2Table / hash3Table hold when the position
 //                  is reached (:1247-1251);
+//   k_bt4_jobkeys  + one more stable sort, by entry: the hash-4 order becomes (entry, hash 4, position) -- an entry's buckets side by side;
 //   k_bt4_flags, k_bt4_heads, k_bt4_split
-//                  hash 4: the runs of equal (hash, entry) = the buckets, each one binary tree; long buckets and short ones apart;
-//   k_bt4_walk     one LANE per bucket walks its positions in increasing order (bt4_begin / bt4_step): persistent lanes, a lane that
-//                  finishes a position takes its bucket's next one -- or the next bucket -- while its neighbours are still on their way
-//                  down; long buckets are handed out one by one through a counter, the short ones by stride.
+//                  the runs of equal (entry, hash 4) = the buckets, each one binary tree; long buckets and short ones apart;
+//   k_bt4_walk_lds an entry of up to 16 KiB (one window fill) per workgroup: its text and its trees (16-bit nodes) in LDS, one LANE per
+//                  bucket -- a walk is a chain of dependent reads (node, then the candidate's bytes), in LDS a tenth of what it is in HBM;
+//   k_bt4_walk     the buckets of all other entries, one LANE per bucket (bt4_begin / bt4_step) with the nodes in HBM: persistent
+//                  lanes, a lane that finishes a position takes its bucket's next one -- or the next bucket -- while its neighbours are
+//                  still on their way down; long buckets are handed out one by one through a counter, the short ones by stride.
 //
 // Match sets in HBM: 8 slots per position (7 matches; most positions have one to three), the rest of a longer set (up to 50 matches: one
 // per hash + one per tree level, Depth_Limit = 48) in a 43-slot block of an overflow pool booked through an atomic counter.  When the pool
@@ -73,31 +76,57 @@ __global__ void __launch_bounds__(256) k_bt4_pred(const uint32_t *__restrict__ k
   pred[p] = o;
 }
 
-// cnts: [0] long buckets, [1] short buckets, [2] next long bucket to hand out, [3] overflow blocks booked, [4] first "not inserted" index
-__global__ void __launch_bounds__(256) k_bt4_flags(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T,
-                                                   uint32_t *__restrict__ flags, uint32_t *__restrict__ cnts) {
+// after the hash-4 sort: the key of the second sort = the position's entry ("not inserted" behind all entries)
+__global__ void __launch_bounds__(256) k_bt4_jobkeys(uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T, uint32_t E) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
-  const uint32_t k = keys[i];
-  uint32_t f = 0;
-  if (k & flag) { if (i == 0 || !(keys[i - 1] & flag)) cnts[4] = i; }
-  else f = (i == 0 || keys[i - 1] != k || T.tile_job[vals[i - 1] >> 6] != T.tile_job[vals[i] >> 6]) ? 1u : 0u;
-  flags[i] = f;
+  keys[i] = (keys[i] & flag) ? E : T.tile_job[vals[i] >> 6];
 }
-__global__ void __launch_bounds__(256) k_bt4_heads(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T,
+
+// cnts: [0] long buckets, [1] short buckets, [2] next long bucket to hand out, [3] overflow blocks booked, [4] first "not inserted" index
+// vals: the positions in (entry, hash 4, position) order, the ones that are not inserted behind; k4: their hash-4 keys BY POSITION
+__device__ __forceinline__ bool bt4_is_head(const uint32_t *__restrict__ k4, const uint32_t *__restrict__ vals, uint32_t i, const Tables &T) {
+  if (i == 0) return true;
+  const uint32_t p = vals[i], pp = vals[i - 1];
+  return k4[p] != k4[pp] || T.tile_job[p >> 6] != T.tile_job[pp >> 6];
+}
+__global__ void __launch_bounds__(256) k_bt4_flags(const uint32_t *__restrict__ k4, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T,
+                                                   uint32_t *__restrict__ flags, uint32_t *__restrict__ cnts) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i > P) return;
+  uint32_t f = 0;
+  if (i < P) {
+    if (k4[vals[i]] & flag) { if (i == 0 || !(k4[vals[i - 1]] & flag)) cnts[4] = i; }
+    else f = bt4_is_head(k4, vals, i, T) ? 1u : 0u;
+  }
+  flags[i] = f;                                                      // (P + 1 entries: the scan's value at P is the number of buckets)
+}
+__global__ void __launch_bounds__(256) k_bt4_heads(const uint32_t *__restrict__ k4, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T,
                                                    const uint32_t *__restrict__ rank, uint32_t *__restrict__ heads) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
-  const uint32_t k = keys[i];
-  if (k & flag) return;
-  if (i == 0 || keys[i - 1] != k || T.tile_job[vals[i - 1] >> 6] != T.tile_job[vals[i] >> 6]) heads[rank[i]] = i;
+  if (k4[vals[i]] & flag) return;
+  if (bt4_is_head(k4, vals, i, T)) heads[rank[i]] = i;
 }
-__global__ void __launch_bounds__(256) k_bt4_split(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ nruns, uint32_t *__restrict__ cnts,
-                                                   uint2 *__restrict__ longs, uint2 *__restrict__ shorts) {
+// what a walk needs to start on a position, side by side in the order the walks take the positions in: (position, hash-2 predecessor,
+// hash-3 predecessor) -- one 16-byte load, the next position's issued while the current one is on its way down the tree
+__global__ void __launch_bounds__(256) k_bt4_records(const uint32_t *__restrict__ k4, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, const int32_t *__restrict__ d2,
+                                                     const int32_t *__restrict__ d3, uint4 *__restrict__ rec) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t p = vals[i];
+  if (k4[p] & flag) return;
+  rec[i] = make_uint4(p, (uint32_t)d2[p], (uint32_t)d3[p], 0u);
+}
+__global__ void __launch_bounds__(256) k_bt4_split(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ vals, Tables T, const uint32_t *__restrict__ nruns,
+                                                   uint32_t *__restrict__ cnts, uint2 *__restrict__ longs, uint2 *__restrict__ shorts) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x, R = *nruns;
-  const bool live = r < R;
+  bool live = r < R;
   uint32_t s = 0, len = 0;
-  if (live) { s = heads[r]; len = (r + 1 < R ? heads[r + 1] : cnts[4]) - s; }
+  if (live) {
+    s = heads[r]; len = (r + 1 < R ? heads[r + 1] : cnts[4]) - s;
+    if (len < BT_LONG && T.jobs[T.tile_job[vals[s] >> 6]].small) live = false;       // (k_bt4_walk_lds takes the short buckets of such an entry)
+  }
   const int lane = threadIdx.x & 63;
   const uint64_t lt = (1ull << lane) - 1;
   for (int cls = 0; cls < 2; cls++) {                               // one atomic per wave and list
@@ -127,13 +156,14 @@ __device__ __forceinline__ int extend8(const uint8_t *in, int64_t a, int64_t b, 
   return len;
 }
 
-__global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ vals, const uint2 *__restrict__ longs, const uint2 *__restrict__ shorts,
-                                                  uint32_t *__restrict__ cnts, Tables T, const int32_t *__restrict__ d2, const int32_t *__restrict__ d3, int32_t *__restrict__ tree, Sets S) {
+__global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ arena, const uint4 *__restrict__ rec, const uint2 *__restrict__ longs, const uint2 *__restrict__ shorts,
+                                                  uint32_t *__restrict__ cnts, Tables T, int32_t *__restrict__ tree, Sets S) {
   const uint32_t nlong = cnts[0], nshort = cnts[1], nthreads = gridDim.x * 256;
   uint32_t next_short = blockIdx.x * 256 + threadIdx.x;
   bool more_long = nlong > 0, walking = false;
   uint32_t i = 0, e = 0, p = 0, blk = 0, job = NOJOB;
   int32_t prev_ord = BT4_NONE;
+  uint4 nxt = make_uint4(0, 0, 0, 0);                                // the record of position i (loaded while position i - 1 was walked)
   // the bucket's entry (a bucket never leaves its entry)
   const uint8_t *jin = nullptr; int32_t *jtree = nullptr; const Bt4Run *jruns = nullptr;
   uint32_t jrun_cnt = 0, joff = 0; int32_t jmax = 0;
@@ -158,24 +188,95 @@ __global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ ar
         if (!got && next_short < nshort) { d = shorts[next_short]; next_short += nthreads; got = true; }
         if (!got) break;
         i = d.x; e = d.x + d.y; prev_ord = BT4_NONE;
-        job = T.tile_job[vals[i] >> 6];
+        nxt = rec[i];
+        job = T.tile_job[nxt.x >> 6];
         const Bt4Job &J = T.jobs[job];
         joff = (uint32_t)J.in_off; jin = arena + J.in_off; jtree = tree + 2 * (size_t)J.in_off;
         jruns = T.runs + J.run_off; jrun_cnt = J.run_cnt; jmax = (int32_t)J.max_dist;
       }
-      p = vals[i];
+      const uint4 rc = nxt;
+      if (i + 1 < e) nxt = rec[i + 1];
+      p = rc.x;
       const uint32_t q = p - joff;
       const Bt4Run *r = bt4_run_of(jruns, jrun_cnt, q);
       const int avail = (int)(r->W - q - 1);
       rec0 = r->cls == 0;
-      bt4_begin(w, jin, q, (int32_t)(q - r->gap), rec0, avail < BT4_LOOK ? avail : BT4_LOOK, jmax, prev_ord, rec0 ? d2[p] : BT4_NONE, rec0 ? d3[p] : BT4_NONE, ext, put);
+      bt4_begin(w, jin, q, (int32_t)(q - r->gap), rec0, avail < BT4_LOOK ? avail : BT4_LOOK, jmax, prev_ord, rec0 ? (int32_t)rc.y : BT4_NONE, rec0 ? (int32_t)rc.z : BT4_NONE, ext, put);
       walking = true;
     }
-    if (bt4_step(w, jtree, ext, put)) {
+    if (bt4_step(w, Bt4TreeI32{jtree}, ext, put)) {
       if (rec0) S.cnt[p] = (uint8_t)w.count;
       prev_ord = w.ordp;
       i++;
       walking = false;
+    }
+  }
+}
+
+// An entry of up to BT4_LDS_N bytes with one window fill (positions 0 .. n - 163 are read and inserted with n - q - 1 bytes available,
+// the last 162 never: bt4_schedule gives two runs): one workgroup, the entry's text and the nodes of its trees in LDS.  Its buckets are
+// the entries rank [sorted_off] .. rank [sorted_end] of `heads`; the lanes take them through an LDS counter.  Only the SHORT buckets
+// (fewer than BT_LONG positions): a long bucket is one lane's chain of thousands of dependent steps, during which the workgroup would
+// keep its 80 KB of LDS to itself -- those go to k_bt4_walk, with their nodes in HBM (a bucket's nodes are nobody else's), where the long
+// buckets of ALL entries of the call walk side by side.
+constexpr int BT4_LDS_THREADS = 512;
+constexpr uint32_t BT4_LDS_BYTES = 4 * (BT4_LDS_N - BT4_NICE) + BT4_LDS_N + 16;
+__global__ void __launch_bounds__(BT4_LDS_THREADS) k_bt4_walk_lds(const uint8_t *__restrict__ arena, const uint4 *__restrict__ rec, const uint32_t *__restrict__ heads,
+                                                                  const uint32_t *__restrict__ rank, const uint32_t *__restrict__ small_jobs, uint32_t *__restrict__ cnts, Tables T, Sets S) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t job = small_jobs[blockIdx.x];
+  const Bt4Job J = T.jobs[job];
+  const uint32_t n = J.n, nins = n - BT4_NICE;                       // inserted positions (n > 162: the host lists no other entries)
+  uint16_t *tree = (uint16_t *)lds;
+  uint8_t *text = lds + 4 * (size_t)(BT4_LDS_N - BT4_NICE);
+  uint32_t *next = (uint32_t *)(text + BT4_LDS_N);
+  const uint8_t *src = arena + J.in_off;
+  for (uint32_t i = threadIdx.x * 16; i < n; i += BT4_LDS_THREADS * 16) {                 // (entries start at multiples of 64)
+    if (i + 16 <= n) *(uint4 *)(text + i) = *(const uint4 *)(src + i);
+    else for (uint32_t k = i; k < n; k++) text[k] = src[k];          // (nothing is read behind the entry: the caller's buffer may end there)
+  }
+  if (threadIdx.x < 2) next[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t s0 = J.sorted_off, s1 = s0 + nins, h0 = rank[s0], h1 = rank[s1], joff = (uint32_t)J.in_off;
+  const int32_t jmax = (int32_t)J.max_dist;
+  const Bt4TreeU16 TR{tree};
+  auto ext = [](const uint8_t *b, int64_t x, int64_t y, int l, int lim) { return bt4_extend(b, x, y, l, lim); };
+  {
+    constexpr int round = 0;
+    bool walking = false;
+    uint32_t i = 0, e = 0, p = 0, blk = 0;
+    int32_t prev_ord = BT4_NONE;
+    uint4 nxt = make_uint4(0, 0, 0, 0);                              // the record of position i (loaded while position i - 1 was walked)
+    Bt4Walk w;
+    auto put = [&](int k, int len, uint32_t dist) {
+      const size_t base = (size_t)p * BT4_INLINE;
+      if (k < BT4_INLINE - 1) { S.sl[base + k] = (uint16_t)len; S.sd[base + k] = dist; return; }
+      if (k == BT4_INLINE - 1) { blk = atomicAdd(&cnts[3], 1u); S.sd[base + BT4_INLINE - 1] = blk; }
+      if (blk < S.ovf_cap) { const size_t o = (size_t)blk * BT4_OVF + (uint32_t)(k - (BT4_INLINE - 1)); S.ol[o] = (uint16_t)len; S.od[o] = dist; }
+    };
+    for (;;) {
+      if (!walking) {
+        while (i >= e) {                                              // the next bucket of this round
+          const uint32_t b = h0 + atomicAdd(&next[round], 1u);
+          if (b >= h1) { i = 1; e = 0; break; }
+          const uint32_t hs = heads[b], he = b + 1 < h1 ? heads[b + 1] : s1;
+          if (he - hs < BT_LONG) { i = hs; e = he; prev_ord = BT4_NONE; nxt = rec[i]; }
+        }
+        if (i >= e) break;
+        const uint4 r = nxt;
+        if (i + 1 < e) nxt = rec[i + 1];
+        p = r.x;
+        const uint32_t q = p - joff;
+        const int avail = (int)(n - q - 1);
+        bt4_begin(w, text, q, (int32_t)q, true, avail < BT4_LOOK ? avail : BT4_LOOK, jmax, prev_ord, (int32_t)r.y, (int32_t)r.z, ext, put);
+        walking = true;
+      }
+      if (bt4_step(w, TR, ext, put)) {
+        S.cnt[p] = (uint8_t)w.count;
+        prev_ord = w.ordp;
+        i++;
+        walking = false;
+      }
     }
   }
 }
@@ -185,8 +286,9 @@ struct Buf {
   template <typename T> T *as() const { return (T *)p; }
 };
 struct State {
-  Buf tile_job, jobs, runs, k2, k3, k4, val, ks, vs, tmp, d2, d3, tree, cnt, sl, sd, ol, od, flags, heads, longs, shorts, cnts, scan;
-  Buf *all[24] = {&tile_job, &jobs, &runs, &k2, &k3, &k4, &val, &ks, &vs, &tmp, &d2, &d3, &tree, &cnt, &sl, &sd, &ol, &od, &flags, &heads, &longs, &shorts, &cnts, &scan};
+  Buf tile_job, jobs, runs, k2, k3, k4, val, ks, vs, tmp, d2, d3, tree, cnt, sl, sd, ol, od, flags, heads, longs, shorts, cnts, scan, small, rec;
+  Buf *all[26] = {&tile_job, &jobs, &runs, &k2, &k3, &k4, &val, &ks, &vs, &tmp, &d2, &d3, &tree, &cnt, &sl, &sd, &ol, &od, &flags, &heads, &longs, &shorts, &cnts, &scan, &small, &rec};
+  bool lds_attr = false;
   uint32_t ovf_cap = 0;
 };
 int grow(Ctx *c, Buf &b, size_t bytes) {
@@ -223,18 +325,23 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   std::vector<Bt4Job> hj(jobs.size());
   std::vector<Bt4Run> hr, one;
   std::vector<uint32_t> tj(P / 64, NOJOB);
-  uint32_t hmax = 1u << 16;
+  uint32_t hmax = 1u << 16, sorted = 0;
+  std::vector<uint32_t> small_jobs;
   for (size_t e = 0; e < jobs.size(); e++) {
     const LzmaJob &J = jobs[e];
     Bt4Job &b = hj[e];
     memset(&b, 0, sizeof b);
     b.in_off = J.in_off; b.n = J.level == 3 ? (uint32_t)J.n : 0; b.sbs = J.sbs; b.hash4_mask = J.hash4_size - 1; b.max_dist = J.sbs - (BT4_LOOK + 2);
-    b.run_off = (uint32_t)hr.size();
+    b.run_off = (uint32_t)hr.size(); b.sorted_off = sorted;
     if (J.level != 3 || J.n == 0) continue;
     if ((J.in_off & 63) || J.in_off + J.n > arena_bytes) { c->err = "LZMA: entry outside the arena"; return ZADA_E_INVALID; }
     if (!bt4_schedule(J.n, J.sbs, one)) { c->err = "LZMA: window schedule not taken by the match producer"; return ZADA_E_INVALID; }
     hr.insert(hr.end(), one.begin(), one.end());
     b.run_cnt = (uint32_t)one.size();
+    for (const Bt4Run &r : one) if (r.cls != 2) sorted += r.end - r.start;
+    if (J.n <= BT4_LDS_N && J.n > (uint64_t)BT4_NICE && one.size() == 2 && one[0].cls == 0 && one[1].cls == 2 && one[0].end == J.n - BT4_NICE) {
+      b.small = 1; small_jobs.push_back((uint32_t)e);
+    }
     if (J.hash4_size > hmax) hmax = J.hash4_size;
     for (uint64_t t = J.in_off >> 6; t < (J.in_off + J.n + 63) >> 6; t++) tj[t] = (uint32_t)e;
   }
@@ -247,13 +354,14 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   if ((rc = grow(c, B->tile_job, 4ull * (P / 64) + 64)) || (rc = grow(c, B->jobs, sizeof(Bt4Job) * hj.size() + 64)) || (rc = grow(c, B->runs, sizeof(Bt4Run) * hr.size())) ||
       (rc = grow(c, B->k2, 4ull * P)) || (rc = grow(c, B->k3, 4ull * P)) || (rc = grow(c, B->k4, 4ull * P)) || (rc = grow(c, B->val, 4ull * P)) || (rc = grow(c, B->ks, 4ull * P)) ||
       (rc = grow(c, B->vs, 4ull * P)) || (rc = grow(c, B->tmp, tmp_bytes)) || (rc = grow(c, B->d2, 4ull * P)) || (rc = grow(c, B->d3, 4ull * P)) || (rc = grow(c, B->tree, 8ull * P)) ||
-      (rc = grow(c, B->cnt, P)) || (rc = grow(c, B->sl, 2ull * BT4_INLINE * P)) || (rc = grow(c, B->sd, 4ull * BT4_INLINE * P)) || (rc = grow(c, B->flags, 4ull * P)) ||
+      (rc = grow(c, B->cnt, P)) || (rc = grow(c, B->sl, 2ull * BT4_INLINE * P)) || (rc = grow(c, B->sd, 4ull * BT4_INLINE * P)) || (rc = grow(c, B->flags, 4ull * P + 64)) || (rc = grow(c, B->small, 4ull * small_jobs.size() + 64)) || (rc = grow(c, B->rec, 16ull * P)) ||
       (rc = grow(c, B->heads, 4ull * P)) || (rc = grow(c, B->longs, 8ull * (P / BT_LONG + 64))) || (rc = grow(c, B->shorts, 8ull * P)) || (rc = grow(c, B->cnts, 256)) ||
-      (rc = grow(c, B->scan, 4ull * (P / 1024 + 64))))
+      (rc = grow(c, B->scan, 4ull * ((P + 1) / 1024 + 64))))
     return rc;
   if (hipMemcpyAsync(B->tile_job.p, tj.data(), 4ull * tj.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(B->jobs.p, hj.data(), sizeof(Bt4Job) * hj.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(B->runs.p, hr.data(), sizeof(Bt4Run) * hr.size(), hipMemcpyHostToDevice, st) != hipSuccess) { hip_check(c, hipGetLastError(), "BT4 tables"); return ZADA_E_HIP; }
+      hipMemcpyAsync(B->runs.p, hr.data(), sizeof(Bt4Run) * hr.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+      (!small_jobs.empty() && hipMemcpyAsync(B->small.p, small_jobs.data(), 4ull * small_jobs.size(), hipMemcpyHostToDevice, st) != hipSuccess)) { hip_check(c, hipGetLastError(), "BT4 tables"); return ZADA_E_HIP; }
   hipStreamSynchronize(st);                                         // (the host vectors go out of scope)
   uint32_t *cnts = B->cnts.as<uint32_t>();
   const uint32_t cnts0[8] = {0, 0, 0, 0, P, 0, 0, 0};
@@ -268,18 +376,34 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   if ((rc = radix_sort_pairs(c, st, B->tmp.p, B->tmp.cap, B->k3.as<uint32_t>(), ks, val, vs, 4, P, 0, 17))) return rc;
   hipLaunchKernelGGL(k_bt4_pred, gp, b256, 0, st, ks, vs, P, 1u << 16, T, B->d3.as<int32_t>());
   if ((rc = radix_sort_pairs(c, st, B->tmp.p, B->tmp.cap, B->k4.as<uint32_t>(), ks, val, vs, 4, P, 0, hb4 + 1))) return rc;
+  const uint32_t E = (uint32_t)jobs.size();
+  const uint32_t *order = vs;                                        // positions in (entry, hash 4, position) order
+  if (E > 1) {
+    uint32_t eb = 1;
+    while ((1u << eb) <= E) eb++;
+    hipLaunchKernelGGL(k_bt4_jobkeys, gp, b256, 0, st, ks, vs, P, 1u << hb4, T, E);
+    if ((rc = radix_sort_pairs(c, st, B->tmp.p, B->tmp.cap, ks, B->k2.as<uint32_t>(), vs, val, 4, P, 0, eb))) return rc;   // (k2 and the identity are free by now)
+    order = val;
+  }
   uint32_t *flags = B->flags.as<uint32_t>(), *heads = B->heads.as<uint32_t>();
-  hipLaunchKernelGGL(k_bt4_flags, gp, b256, 0, st, ks, vs, P, 1u << hb4, T, flags, cnts);
-  exclusive_scan_u32(st, flags, flags, B->scan.as<uint32_t>(), cnts + 5, P);                 // cnts [5] = number of buckets
-  hipLaunchKernelGGL(k_bt4_heads, gp, b256, 0, st, ks, vs, P, 1u << hb4, T, flags, heads);
-  hipLaunchKernelGGL(k_bt4_split, gp, b256, 0, st, heads, cnts + 5, cnts, B->longs.as<uint2>(), B->shorts.as<uint2>());
+  const uint32_t *k4 = B->k4.as<uint32_t>();
+  hipLaunchKernelGGL(k_bt4_flags, dim3(P / 256 + 1), b256, 0, st, k4, order, P, 1u << hb4, T, flags, cnts);
+  exclusive_scan_u32(st, flags, flags, B->scan.as<uint32_t>(), cnts + 5, P + 1);             // cnts [5] = number of buckets
+  hipLaunchKernelGGL(k_bt4_heads, gp, b256, 0, st, k4, order, P, 1u << hb4, T, flags, heads);
+  hipLaunchKernelGGL(k_bt4_records, gp, b256, 0, st, k4, order, P, 1u << hb4, B->d2.as<int32_t>(), B->d3.as<int32_t>(), B->rec.as<uint4>());
+  hipLaunchKernelGGL(k_bt4_split, gp, b256, 0, st, heads, order, T, cnts + 5, cnts, B->longs.as<uint2>(), B->shorts.as<uint2>());
   if (hip_check(c, hipGetLastError(), "BT4 producer (sorts)")) return ZADA_E_HIP;
+  if (!small_jobs.empty() && !B->lds_attr) {
+    if (hip_check(c, hipFuncSetAttribute((const void *)k_bt4_walk_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BT4_LDS_BYTES), "k_bt4_walk_lds (LDS size)")) return ZADA_E_HIP;
+    B->lds_attr = true;
+  }
   for (int attempt = 0; attempt < 2; attempt++) {
     if ((rc = grow(c, B->ol, 2ull * BT4_OVF * B->ovf_cap)) || (rc = grow(c, B->od, 4ull * BT4_OVF * B->ovf_cap))) return rc;
     const Sets S{B->cnt.as<uint8_t>(), B->sl.as<uint16_t>(), B->sd.as<uint32_t>(), B->ol.as<uint16_t>(), B->od.as<uint32_t>(), B->ovf_cap};
     const uint32_t nblk = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
-    hipLaunchKernelGGL(k_bt4_walk, dim3(nblk), b256, 0, st, d_arena, vs, B->longs.as<uint2>(), B->shorts.as<uint2>(), cnts, T, B->d2.as<int32_t>(), B->d3.as<int32_t>(),
-                       B->tree.as<int32_t>(), S);
+    if (!small_jobs.empty())
+      hipLaunchKernelGGL(k_bt4_walk_lds, dim3((uint32_t)small_jobs.size()), dim3(BT4_LDS_THREADS), BT4_LDS_BYTES, st, d_arena, B->rec.as<uint4>(), heads, flags, B->small.as<uint32_t>(), cnts, T, S);
+    hipLaunchKernelGGL(k_bt4_walk, dim3(nblk), b256, 0, st, d_arena, B->rec.as<uint4>(), B->longs.as<uint2>(), B->shorts.as<uint2>(), cnts, T, B->tree.as<int32_t>(), S);
     uint32_t h[8];
     hipMemcpyAsync(h, cnts, sizeof h, hipMemcpyDeviceToHost, st);
     if (hip_check(c, hipStreamSynchronize(st), "k_bt4_walk")) return ZADA_E_HIP;
