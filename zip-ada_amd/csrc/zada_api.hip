@@ -18,11 +18,14 @@ struct zada_ctx { zada::Ctx c; };
 
 namespace zada {
 
+// A worker thread of a call (the BZip2 path's second batch in flight) sets tls_err: its error text goes there, and the main thread
+// copies it to the context when it joins the worker -- two threads never write the same string.
+thread_local std::string *tls_err = nullptr;
 int hip_check(Ctx *c, hipError_t e, const char *what) {
   if (e == hipSuccess) return 0;
   char buf[256];
   snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-  c->err = buf;
+  if (tls_err) *tls_err = buf; else c->err = buf;
   return ZADA_E_HIP_;
 }
 
@@ -897,18 +900,20 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "bz_batch_mib")) { if (value < 1 || value > 2048) return ZADA_E_INVALID; z->c.knob_bz_batch_mib = value; }
   else if (!strcmp(name, "bz_span_mib")) { if (value < 24 || value > 3072) return ZADA_E_INVALID; z->c.knob_bz_span_mib = value; }
   else if (!strcmp(name, "bz_batch_melems")) { if (value < 1 || value > 1536) return ZADA_E_INVALID; z->c.knob_bz_batch_melems = value; }
-  else if (!strcmp(name, "bz_tail_pct")) z->c.knob_bz_tail_pct = value;
-  else if (!strcmp(name, "bz_text_order")) z->c.knob_bz_text_order = value;
-  else if (!strcmp(name, "bz_pipeline")) z->c.knob_bz_pipeline = value;
+  else if (!strcmp(name, "bz_tail_pct")) { if (value < 0 || value > 50) return ZADA_E_INVALID; z->c.knob_bz_tail_pct = value; }
+  else if (!strcmp(name, "bz_text_order")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_text_order = value; }
+  else if (!strcmp(name, "bz_pipeline")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_pipeline = value; }
   else if (!strcmp(name, "bz_list_rows")) { if (value < 0 || value > 8192) return ZADA_E_INVALID; z->c.knob_bz_list_rows = value; }
-  else if (!strcmp(name, "bz_split")) z->c.knob_bz_split = value;
-  else if (!strcmp(name, "bz_small_wg")) z->c.knob_bz_small_wg = value;
+  else if (!strcmp(name, "bz_split")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_split = value; }
+  else if (!strcmp(name, "bz_small_wg")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_small_wg = value; }
   else if (!strcmp(name, "bz_lists")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_bz_lists = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
   else if (!strcmp(name, "lzma_dict")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_lzma_dict = value; }
-  else if (!strcmp(name, "lzma_chunk")) z->c.knob_lzma_chunk = value;
+  // (positions per launch: -1 = the whole stream in one launch, 0 = by level; a launch of fewer than 256 positions is a host round trip
+  // per handful of bytes -- the tests go down to 777)
+  else if (!strcmp(name, "lzma_chunk")) { if (value < -1 || (value > 0 && value < 256)) return ZADA_E_INVALID; z->c.knob_lzma_chunk = value; }
   else return ZADA_E_INVALID;
   return ZADA_OK;
 }

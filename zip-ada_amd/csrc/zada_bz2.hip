@@ -2158,6 +2158,7 @@ struct Bz2State {
   DBuf rs1, epre, bstart, blen, etab, seg_off, seg, seg_cnt, extra;
   bool etab_ready = false;
   Bz2State *slot1 = nullptr;        // the second batch in flight (bz_blocks_encode pipelines the stages of consecutive batches)
+  bool no_pipeline = false;         // the device ran out of memory with two batches in flight: one at a time from then on
   hipStream_t st_pipe = nullptr;    // ... and the stream its entropy stage runs on
   hipStream_t st_small = nullptr; hipEvent_t ev_small = nullptr, ev_rank = nullptr;     // the entropy search of the short sub-blocks runs next to the long ones'
   std::vector<uint64_t> trace;      // per block: raw start, raw length, tactic kept, its number of sub-blocks
@@ -2612,8 +2613,8 @@ static int bz_span_blocks(Ctx *c, int option, const uint8_t *d_in, uint64_t pos0
 }
 
 // Segmentation and every stage of Encode_Block for the given blocks: appends to B->plans / B->kept.
-static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::vector<uint64_t> &bstart, const std::vector<uint32_t> &blen,
-                            zada_feedback_fn fb, void *user, double prog0, double prog1) {
+static int bz_blocks_encode_once(Ctx *c, int option, const uint8_t *d_in, const std::vector<uint64_t> &bstart, const std::vector<uint32_t> &blen,
+                                 zada_feedback_fn fb, void *user, double prog0, double prog1, bool pipelined, uint64_t batch_elems) {
   Bz2State *B = bz_state(c);
   hipStream_t st = c->stream, st2 = c->stream2;
   int rc;
@@ -2646,24 +2647,25 @@ static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::
     hipLaunchKernelGGL(k_bz_segment, dim3(nblk), dim3(64), 0, st2, d_in, B->bstart.as<uint64_t>(), B->blen.as<uint32_t>(), nblk, B->etab.as<double>(),
                        (double)0.6f, (double)0.4f, B->seg_off.as<uint32_t>(), B->seg.as<uint32_t>(), B->seg_cnt.as<uint32_t>());
   }
-  const uint64_t batch_elems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 640) << 20;
   const size_t plan_base = B->plans.size();
   constexpr uint32_t KEPT = 0x80000000u;                                   // piece number that already is a number in B->kept
   // Two batches in flight ("bz_pipeline", default on): the second one in a state of its own (B->slot1).
-  const bool pipelined = c->knob_bz_pipeline != 0;
   if (pipelined) {
     if (!B->slot1) B->slot1 = new Bz2State();
     if (!B->st_pipe) BZ_HIP(hipStreamCreateWithFlags(&B->st_pipe, hipStreamNonBlocking));
   }
-  struct Pending { bool active = false; std::thread th; int rc = 0; Bz2State *S = nullptr; uint32_t base = 0; DBuf kb; } pend;
-  struct Joiner { Pending &p; ~Joiner() { if (p.th.joinable()) p.th.join(); } } joiner{pend};      // (no return leaves a worker behind)
+  // (err: the worker's error text -- hip_check writes it there through tls_err while the main thread may be writing c->err -- is copied to
+  // c->err by finish, on the main thread)
+  struct Pending { bool active = false; std::thread th; int rc = 0; Bz2State *S = nullptr; uint32_t base = 0; DBuf kb; std::string err; } pend;
+  // (no return leaves a worker behind, nor the device buffer of a batch that was never booked)
+  struct Joiner { Pending &p; ~Joiner() { if (p.th.joinable()) p.th.join(); if (p.active && p.kb.p) { hipFree(p.kb.p); p.kb.p = nullptr; } } } joiner{pend};
   uint32_t nbatch = 0;
   // waits for the batch whose stage B is under way and books its bit strings: the plans' piece numbers become numbers in B->kept
   auto finish = [&]() -> int {
     if (!pend.active) return 0;
     if (pend.th.joinable()) pend.th.join();
     pend.active = false;
-    if (pend.rc) { if (pend.kb.p) hipFree(pend.kb.p); return pend.rc; }
+    if (pend.rc) { if (pend.kb.p) { hipFree(pend.kb.p); pend.kb.p = nullptr; } if (!pend.err.empty()) c->err = pend.err; return pend.rc; }
     Bz2State *S = pend.S;
     const uint32_t bufno = (uint32_t)B->kept_bufs.size();
     B->kept_bufs.push_back(pend.kb);
@@ -2771,7 +2773,7 @@ static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::
           pend.rc = r;
         };
         pend.active = true;
-        if (pipelined) pend.th = std::thread([c, stage_b, B] { hipSetDevice(c->device); stage_b(B->st_pipe, false); });
+        if (pipelined) pend.th = std::thread([c, stage_b, B, &pend] { hipSetDevice(c->device); tls_err = &pend.err; stage_b(B->st_pipe, false); tls_err = nullptr; });
         else { stage_b(st, true); c->tmark("bz:keep"); if ((rc = finish())) return rc; }
       } else {
         for (uint32_t k = k0; k < k1; k++) for (int t = 2 * pass; t < 2 * pass + 2; t++) for (uint32_t &sb : B->plans[plan_base + k].tac[t]) sb &= ~KEPT;
@@ -2792,6 +2794,29 @@ static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::
     B->min_bits_sum += mn;
   }
   return 0;
+}
+// Encode_Block for every piece of every tactic of the blocks.  Out of device memory (two batches in flight hold two full states, sized for
+// "bz_batch_melems" elements each): what the failed attempt booked is dropped, and the call goes again -- first without the second batch
+// in flight (its state is freed; the context stays unpipelined), then with batches half the size, down to 32 Mi elements.
+static int bz_blocks_encode(Ctx *c, int option, const uint8_t *d_in, const std::vector<uint64_t> &bstart, const std::vector<uint32_t> &blen,
+                            zada_feedback_fn fb, void *user, double prog0, double prog1) {
+  Bz2State *B = bz_state(c);
+  const size_t plans0 = B->plans.size(), kept0 = B->kept.size(), bufs0 = B->kept_bufs.size(), trace0 = B->trace.size();
+  const uint64_t bits0 = B->min_bits_sum;
+  bool pipelined = c->knob_bz_pipeline != 0 && !B->no_pipeline;
+  uint64_t melems = (uint64_t)(c->knob_bz_batch_melems > 0 ? c->knob_bz_batch_melems : 640);
+  for (;;) {
+    const int rc = bz_blocks_encode_once(c, option, d_in, bstart, blen, fb, user, prog0, prog1, pipelined, melems << 20);
+    if (rc != ZADA_E_NOMEM) return rc;
+    hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
+    for (size_t i = bufs0; i < B->kept_bufs.size(); i++) if (B->kept_bufs[i].p) hipFree(B->kept_bufs[i].p);
+    B->kept_bufs.resize(bufs0); B->kept.resize(kept0); B->plans.resize(plans0); B->trace.resize(trace0); B->min_bits_sum = bits0;
+    if (pipelined) {
+      if (B->slot1) { bz_free_state(B->slot1); B->slot1 = nullptr; }
+      pipelined = false; B->no_pipeline = true;
+    } else if (melems > 32) melems /= 2;
+    else return rc;
+  }
 }
 
 // per block and tactic: bits, number of pieces, and the pieces' CRCs folded from zero (the combined CRC after the block is

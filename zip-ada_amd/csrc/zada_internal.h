@@ -284,6 +284,7 @@ struct Ctx {
   void tend();
 };
 
+extern thread_local std::string *tls_err;          // error text of a worker thread (see hip_check)
 int hip_check(Ctx *c, hipError_t e, const char *what);
 void bz2_destroy(Ctx *c);
 int bz2_encode_device(Ctx *c, int option, const uint8_t *d_in, uint64_t n, int64_t size_hint, uint8_t *d_out, uint64_t cap, uint64_t *out_len,

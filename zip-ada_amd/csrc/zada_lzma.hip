@@ -571,7 +571,8 @@ __device__ __noinline__ void write_strict(uint32_t distance, int length) {   // 
 // lower its limit (:756-760), so its own recursion can go a match length deep; it is a work list here.  An item is a length
 // still to be written at `distance`, or the literal that follows a shortened match (:797-805).
 __shared__ uint16_t s_work[2 * 280];                                   // (every lane pushes and pops the same items: one copy in LDS, not 64 in scratch)
-__device__ __noinline__ void emit_dl(uint32_t distance, int length0) {
+// (inlined at its one call site, the kernel's main loop: as a function of its own it saved and restored 42 registers per call)
+__device__ __forceinline__ void emit_dl(uint32_t distance, int length0) {
   PROF_T0;
   constexpr uint16_t POST_LIT = 0xFFFF;
   uint16_t *stack = s_work;
@@ -850,8 +851,11 @@ __device__ inline void lz_reduce(int set) {
   while (m.count > 1 && m.len[m.count] == m.len[m.count - 1] + 1 && much_smaller(m.dist[m.count - 1], m.dist[m.count])) m.count--;
 }
 
-__device__ void lz_send_dl(int distance, int length) {               // Send_DL_code :1627-1659
-  emit_dl((uint32_t)distance, length);
+// What Get_Next_Symbol decided for the next symbol.  The emission itself (LZ77_emits_DL_code / LZ77_emits_literal_byte, the calls of
+// Send_DL_code :1629 and Send_first_literal_of_match :1622) happens in the kernel's main loop, at ONE inlined site; nothing that
+// Send_DL_code does after the emission reads the coder's state, so the matcher's bookkeeping is done here, before.
+struct Symbol { int length; uint32_t distance; uint32_t literal; };  // length 0: a literal
+__device__ __forceinline__ Symbol lz_send_dl(int distance, int length) {               // Send_DL_code :1627-1659
   s_B.readAhead -= length;
   int found = -1;
   for (int i = 0; i < 4; i++) if (distance == s_B.rep_dist[i]) { found = i; break; }
@@ -862,27 +866,27 @@ __device__ void lz_send_dl(int distance, int length) {               // Send_DL_
   } else {
     s_B.rep_dist[3] = s_B.rep_dist[2]; s_B.rep_dist[2] = s_B.rep_dist[1]; s_B.rep_dist[1] = s_B.rep_dist[0]; s_B.rep_dist[0] = distance;
   }
+  return Symbol{length, (uint32_t)distance, 0u};
 }
-__device__ inline void lz_send_literal() { emit_literal(s_B.cur_literal); s_B.readAhead--; }
+__device__ __forceinline__ Symbol lz_send_literal() { s_B.readAhead--; return Symbol{0, 0u, s_B.cur_literal}; }
 __device__ inline void lz_skip(int len) { PROF_T0; s_B.readAhead += len; bt_skip(len); PROF_ADD(5); }
 
-__device__ __noinline__ void lz_next_symbol() {           // Get_Next_Symbol :1605-1796
+__device__ __forceinline__ Symbol lz_next_symbol() {       // Get_Next_Symbol :1605-1796
   constexpr int hurdle = 40;
   if (s_B.readAhead == -1) lz_read_one(s_B.cur);
   s_B.cur_literal = BUF(s_B.readPos);
   const int a = bt_available(), avail = a < BT_LOOK ? a : BT_LOOK;
-  if (avail < BT_MIN) { lz_send_literal(); return; }
+  if (avail < BT_MIN) return lz_send_literal();
   if (s_B.best_len_rep >= BT_NICE) {
     lz_skip(s_B.best_len_rep - 1);
-    lz_send_dl(s_B.rep_dist[s_B.best_rep_index], s_B.best_len_rep);
-    return;
+    return lz_send_dl(s_B.rep_dist[s_B.best_rep_index], s_B.best_len_rep);
   }
   int main_len = 1, main_dist = 1;
   {
     Matches &C = s_MM[s_B.cur];
     if (C.count > 0) {
       main_len = C.len[C.count]; main_dist = C.dist[C.count];
-      if (main_len >= BT_NICE) { lz_skip(main_len - 1); lz_send_dl(main_dist, main_len); return; }
+      if (main_len >= BT_NICE) { lz_skip(main_len - 1); return lz_send_dl(main_dist, main_len); }
       lz_reduce(s_B.cur);
       lz_supplement(s_B.cur);
       main_len = C.len[C.count]; main_dist = C.dist[C.count];
@@ -892,10 +896,9 @@ __device__ __noinline__ void lz_next_symbol() {           // Get_Next_Symbol :16
   if (s_B.best_len_rep > BT_MIN &&
       (s_B.best_len_rep >= main_len || (s_B.best_len_rep >= main_len - 2 && main_dist > (1 << 9)) || (s_B.best_len_rep >= main_len - 3 && main_dist > (1 << 15)))) {
     lz_skip(s_B.best_len_rep - 1);
-    lz_send_dl(s_B.rep_dist[s_B.best_rep_index], s_B.best_len_rep);
-    return;
+    return lz_send_dl(s_B.rep_dist[s_B.best_rep_index], s_B.best_len_rep);
   }
-  if (main_len < BT_MIN || avail <= BT_MIN) { lz_send_literal(); return; }
+  if (main_len < BT_MIN || avail <= BT_MIN) return lz_send_literal();
   s_B.cur = 1 - s_B.cur;
   lz_read_one(s_B.cur);
   {
@@ -904,22 +907,21 @@ __device__ __noinline__ void lz_next_symbol() {           // Get_Next_Symbol :16
       const int nl = C.len[C.count], nd = C.dist[C.count];
       if ((nl >= main_len + hurdle && nd < main_dist) || (nl == main_len + hurdle + 1 && !much_smaller(main_dist, nd)) || nl > main_len + hurdle + 1 ||
           (nl >= main_len + hurdle - 1 && main_len >= BT_MIN + 1 && much_smaller(nd, main_dist))) {
-        lz_send_literal();
-        return;
+        return lz_send_literal();
       }
       lz_reduce(s_B.cur);
       lz_supplement(s_B.cur);
       int idx = 1, set = 1 - s_B.cur;
       estimate_dl_codes(1 - s_B.cur, s_B.cur_literal, idx, set);
       if (set == 1 - s_B.cur) { main_len = s_MM[set].len[idx]; main_dist = s_MM[set].dist[idx]; }
-      else { lz_send_literal(); return; }
+      else return lz_send_literal();
     }
   }
   const int limit = main_len - 1 > BT_MIN ? main_len - 1 : BT_MIN;
   for (int rep = 0; rep < 4; rep++)
-    if (bt_match_len(s_B.rep_dist[rep], limit) == limit) { lz_send_literal(); return; }
+    if (bt_match_len(s_B.rep_dist[rep], limit) == limit) return lz_send_literal();
   lz_skip(main_len - 2);
-  lz_send_dl(main_dist, main_len);
+  return lz_send_dl(main_dist, main_len);
 }
 
 __device__ bool lz_bt4_begin(int sbs, uint64_t base, const Bt4Sets &sets) {        // LZ77_using_BT4 up to its main loop; False: nothing to code
@@ -1004,24 +1006,27 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   }
   const uint64_t stop = budget ? s_E.ES.pos + budget : ~0ull;      // (every step of the loops below codes at least one position)
   bool done = true;
-  if (J.level == 0) {
-    for (; iter < J.n; iter++) {                                                   // No_LZ77
-      if (s_E.ES.pos >= stop) { done = false; break; }
-      emit_literal(s_E.in[iter]);
-    }
-  } else if (J.level <= 2) {
-    const uint32_t *tok = tok_base + J.tok_off;
-    for (; iter < J.ntok; iter++) {
-      if (s_E.ES.pos >= stop) { done = false; break; }
+  const uint32_t *tok = tok_base + J.tok_off;
+  // One loop for the three sources of symbols -- No_LZ77 (level 0: every byte a literal), the tokens of the Info-Zip matcher (levels 1, 2)
+  // and Get_Next_Symbol of LZ77_using_BT4 (lz77.adb:1798-1827) -- so that the emission is inlined once.
+  for (;;) {
+    if (s_E.ES.pos >= stop) { done = false; break; }
+    Symbol sy;
+    if (J.level == 0) {
+      if (iter >= J.n) break;
+      sy = Symbol{0, 0u, (uint32_t)s_E.in[iter]};
+      iter++;
+    } else if (J.level <= 2) {
+      if (iter >= J.ntok) break;
       const uint32_t tk = tok[iter];
-      if (tk & 0x80000000u) emit_dl(tk & 0xFFFF, (int)((tk >> 16) & 0x7FFF)); else emit_literal(tk & 0xFF);
+      sy = (tk & 0x80000000u) ? Symbol{(int)((tk >> 16) & 0x7FFF), tk & 0xFFFF, 0u} : Symbol{0, 0u, tk & 0xFF};
+      iter++;
+    } else {
+      if (!running) break;
+      sy = lz_next_symbol();
+      if (bt_available() == 0 && bt_fill_window((int)J.sbs) == 0) running = false;    // (the window's bookkeeping: nothing the emission reads)
     }
-  } else {
-    while (running) {                                                              // the main loop of LZ77_using_BT4 (lz77.adb:1798-1827)
-      if (s_E.ES.pos >= stop) { done = false; break; }
-      lz_next_symbol();
-      if (bt_available() == 0 && bt_fill_window((int)J.sbs) == 0) running = false;
-    }
+    if (sy.length) emit_dl(sy.distance, sy.length); else emit_literal(sy.literal);
   }
   if (!done) {
     __syncthreads();
