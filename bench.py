@@ -180,6 +180,19 @@ def pmc_traffic(n, kernel):
         return None
 
 
+def leg_traffic(key):
+    """HBM bytes per launch / per run of a secondary leg's dominant kernel from the committed PMC passes of that leg's script
+    (profiles/<round>/pmc_secondary_legs.json: {key: {"fetch_kb", "write_kb", "launches", "workload"}}, FETCH_SIZE doubled)."""
+    best = _latest_profile("pmc_secondary_legs.json")
+    if not best:
+        return None, None
+    try:
+        d = json.load(open(best))[key]
+        return int((2 * d["fetch_kb"] + d["write_kb"]) * 1024 / d["launches"]), d["workload"] + " (" + os.path.relpath(best, ROOT) + ")"
+    except Exception:
+        return None, None
+
+
 def second_bound(kernel):
     """What really bounds the dominant kernel (VALU issue slots / LDS / waiting), from the committed SQ counter pass."""
     best = _latest_profile("sq_bounds_by_kernel.json")
@@ -218,23 +231,35 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
     d_out = torch.zeros(n + 4096, dtype=torch.uint8, device="cuda")
     enc.bzip2_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 14)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rc, ol, crc = enc.bzip2_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 14)
-    dt = time.perf_counter() - t0
+    runs = []
+    for _ in range(3):                                   # three timed runs; the value is their median
+        t0 = time.perf_counter()
+        rc, ol, crc = enc.bzip2_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 14)
+        runs.append(time.perf_counter() - t0)
+    dt = sorted(runs)[1]
+    blocks = enc.bz2_last_blocks()
+    # the phases one by one (one batch in flight at a time, "bz_pipeline" = 0: with two in flight the entropy stage runs on a worker's
+    # stream and has no marks): one extra run, not part of the value
+    enc.set_knob("bz_pipeline", 0)
+    enc.bzip2_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 14)
+    enc.set_knob("bz_pipeline", 1)
     tim = {}
     for k, v in enc.last_timing():
         if not k.startswith("#") and k != "bz:end":
             tim[k] = round(tim.get(k, 0.0) + v, 1)
-    blocks = enc.bz2_last_blocks()
     out = {"metric": "BZip2_3 encode MB/s (stream bit-exact with the CPU restatement of the reference, Ada parity unpinned)", "value": round(n / dt / 1e6, 2),
-           "unit": "MB/s", "workload": "%d MiB silesia_mix_v1, one stream, input and output resident in HBM" % mib, "ms": round(dt * 1e3, 1), "rc": rc,
+           "unit": "MB/s", "workload": "%d MiB silesia_mix_v1, one stream, input and output resident in HBM" % mib, "ms": round(dt * 1e3, 1), "runs_ms": [round(r * 1e3, 1) for r in runs], "rc": rc,
            "compression_ratio": round(ol / n, 4), "blocks": len(blocks), "tactics_kept": [sum(1 for b in blocks if b[2] == t) for t in range(4)], "phase_ms": tim}
-    dom = max((k for k in tim if k in ("bz:bwt", "bz:entropy", "bz:mtf", "bz:rank")), key=lambda k: tim[k])
-    ach = (n + ol) / (tim[dom] * 1e-3) / 1e9
-    out["roofline"] = {"bound": "hbm", "kernel": {"bz:bwt": "rotation sort (k_bz_radix_* / k_bz_filter_* / k_bz_place / k_bz_newclass, %d rounds)" % 14,
-                                                  "bz:entropy": "k_bz_entropy", "bz:mtf": "k_bz_mtf_*", "bz:rank": "k_bz_rank"}[dom],
-                       "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-                       "note": "algorithmic bytes = N_in + N_out over the longest phase; the path is bound by LDS round trips (package-merge, heap replay) and random class look-ups, not by HBM (DESIGN.md 9)"}
+    # dominant KERNEL (by kernel time, profiles/<round>/bzip2_256mib_kernel_stats.csv): k_bz_entropy, the search for the tables and selectors --
+    # the "bz:entropy" phase is its launches alone (the longest PHASE, bz:bwt, is some 400 launches of a dozen kernels, none of them as long)
+    dom = "bz:entropy"
+    ach = (n + ol) / (tim[dom] * 1e-3) / 1e9 if tim.get(dom) else 0.0
+    traffic, tsrc = leg_traffic("k_bz_entropy") if mib == 256 else (None, None)
+    out["phases_are_of"] = "one extra run with one batch in flight at a time (bz_pipeline = 0), not part of the value"
+    out["roofline"] = {"bound": "hbm", "kernel": "k_bz_entropy", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                       "traffic": traffic, "traffic_source": tsrc, "launch_ms": tim.get(dom),
+                       "note": "algorithmic bytes = N_in + N_out over the kernel's launches of one run (HIP events of the context's stream); the kernel is bound by LDS round trips "
+                               "(cost sums, package-merge) and by how many sub-blocks are in flight, not by HBM (DESIGN.md 9)"}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _bzip2 import oracle_encode
@@ -264,7 +289,7 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
     return out
 
 
-def lzma_leg(za, enc, entries, kib, with_cpu, with_checks):
+def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
     """Secondary measurement (BASELINE config 4's method): LZMA_3 of `entries` Zip entries of `kib` KiB
     (slices of the same synthetic stream) through ONE launch of the coder -- a stream is a chain of dependent steps, so entries
     are what runs in parallel -- and ONE stream alone beside it (config 4's shape).  Host buffers in, host buffers out."""
@@ -283,14 +308,21 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks):
            "ms": round(dt * 1e3, 1), "compression_ratio": round(out_bytes / (entries * size), 4), "phase_ms": tim}
     kms = tim.get("lzma:end", dt * 1e3)
     ach = (entries * size + out_bytes) / (kms * 1e-3) / 1e9
-    out["roofline"] = {"bound": "hbm", "kernel": "k_lzma_encode", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 7), "traffic": None,
-                       "note": "algorithmic bytes = N_in + N_out over the coder's launch; the bound is neither HBM nor MFMA but the latency of one dependent instruction stream per entry (adaptive probabilities), 2 048 entries in flight (DESIGN.md 10)"}
-    one = datas[0] * max(1, 64 // kib)
+    traffic, tsrc = leg_traffic("k_lzma_encode") if (entries, kib) == (4096, 16) else (None, None)
+    out["roofline"] = {"bound": "hbm", "kernel": "k_lzma_encode", "achieved": round(ach, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 7),
+                       "traffic": traffic, "traffic_source": tsrc, "launch_ms": kms, "producer_ms": tim.get("lzma:bt4"),
+                       "note": "algorithmic bytes = N_in + N_out over the coder's launch (lzma:end; the BT4 match producer's kernels run before it: lzma:bt4); the bound is neither HBM nor MFMA "
+                               "but the latency of one dependent instruction stream per entry (adaptive probabilities), 2 048 entries in flight (DESIGN.md 10)"}
+    # BASELINE config 4's shape: ONE stream, `one_mib` MiB of the stream itself (not a repeated slice)
+    one = host[:one_mib << 20].tobytes() if (one_mib << 20) <= len(host) else za.silesia_mix(one_mib << 20, seed=SEED).tobytes()
     t1 = time.perf_counter()
     rc1, z1, _ = enc.lzma(one, 18)
     d1 = time.perf_counter() - t1
-    out["one_stream"] = {"value": round(len(one) / d1 / 1e6, 4), "unit": "MB/s", "bytes": len(one),
-                         "note": "config 4 is ONE 1 GiB stream: it runs at this rate (one wave walks the chain of adaptive probabilities; the independent simulations of a step run one per lane)"}
+    tim1 = {k: round(v, 1) for k, v in enc.last_timing() if not k.startswith("#")}
+    out["one_stream"] = {"value": round(len(one) / d1 / 1e6, 4), "unit": "MB/s", "bytes": len(one), "compression_ratio": round(len(z1) / len(one), 4), "phase_ms": tim1,
+                         "seconds_for_config_4": round((1 << 30) / (len(one) / d1), 0),
+                         "note": "config 4 is ONE 1 GiB stream: it runs at this rate -- the match sets come from the producer's parallel kernels (lzma:bt4), the coder is one wave walking "
+                                 "the chain of adaptive probabilities (the independent simulations of a step run on teams of its lanes)"}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _lzmah import oracle_lzma
@@ -304,6 +336,17 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks):
         per = max(1, (512 << 10) // size)                 # entries per thread: 512 KiB of them
         groups = [b"".join(datas[(i * per + j) % entries] for j in range(per)) for i in range(cores)]
         out["cpu_baseline"]["all_cores"] = all_cores(lambda g: [oracle_lzma(g[o:o + size], 18) for o in range(0, len(g), size)] and len(g), groups, k * size / dtc / 1e6)
+        # what an unthrottled host of this box would do: the one-core rate times its hardware threads (the quota above is the container's)
+        ht = os.cpu_count() or cores
+        one_core = k * size / dtc / 1e6
+        out["cpu_baseline"]["extrapolated_all_hardware_threads"] = {"value": round(one_core * ht, 1), "unit": "MB/s", "threads": ht,
+                                                                    "gpu_batch_over_it": round(out["value"] / (one_core * ht), 2) if one_core else None,
+                                                                    "note": "one-core rate x os.cpu_count(): an upper bound for the host (no memory or SMT contention counted)"}
+        if with_checks:
+            t3 = time.perf_counter()
+            ref1 = oracle_lzma(one[:1 << 20], 18)
+            out["one_stream"]["cpu_one_core_MBs"] = round((1 << 20) / (time.perf_counter() - t3) / 1e6, 3)
+            out["one_stream"]["first_MiB_alone_equals_cpu_port"] = bool(enc.lzma(one[:1 << 20], 18) == ref1)
         if with_checks:
             out["sample_payloads_equal_cpu_port"] = bool(all(res[i] == ref[i] for i in range(k)))
     if with_checks:
@@ -390,14 +433,33 @@ def bzip2_main(args, za, sharding, enc, torch, dist, rank, world, dev, emulate):
     print(json.dumps(out))
 
 
+def visible_gpus():
+    """GPUs this process' children would see, counted WITHOUT loading torch or the HIP runtime: the KFD topology nodes that have
+    SIMDs (CPUs have none), cut down by a *_VISIBLE_DEVICES list when one is set."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except OSError:
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n):
     """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <the same arguments>` as a child process, relays its
     output (rank 0 prints the JSON line) and returns its exit code."""
     import socket
     import subprocess
     if os.environ.get("BENCH_EMULATE") != "1":
-        import torch                                  # (counting devices does not initialise the GPU: nothing is forked or replaced afterwards anyway)
-        have = torch.cuda.device_count()
+        have = visible_gpus()                         # (read from sysfs: this process never loads the HIP runtime)
         if have < n:
             print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
             return 2
@@ -426,6 +488,7 @@ def main():
     ap.add_argument("--bzip2-mib", type=int, default=256, help="input MiB of the secondary BZip2_3 measurement at one GPU (0 = skip)")
     ap.add_argument("--lzma-entries", type=int, default=4096, help="entries of the secondary LZMA_3 batch measurement at one GPU (0 = skip)")
     ap.add_argument("--lzma-kib", type=int, default=16, help="KiB per entry of the LZMA_3 batch")
+    ap.add_argument("--lzma-one-mib", type=int, default=4, help="MiB of the ONE LZMA_3 stream measured beside the batch (BASELINE config 4's shape)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -504,16 +567,20 @@ def main():
         last = {}
         state = {"pending": None, "stream": None}
 
+        xt = {}                                        # wall-clock seconds this rank spent in the exchange steps (all timed steps)
+
         def finish_pending():
             p = state["pending"]
             if p is None:
                 return
             h, res = p
+            tg = time.perf_counter()
             got = h.finish()
             if got is not None:                       # rank 0: OR the ranges' bytes into one stream
                 payloads, _ = got
                 state["stream"] = sharding.stitch_stream(torch, payloads, res["spans"], res["total_bits"], dev)
             state["pending"] = None
+            xt["gather_stitch"] = xt.get("gather_stitch", 0.0) + time.perf_counter() - tg
 
         def step():
             res = sharding.deflate_stream_rank(enc, comm, torch, total, ranges, d_in.data_ptr(), za.Method.Deflate_3,
@@ -524,6 +591,8 @@ def main():
                 torch.cuda.synchronize()
                 payload = payload.cpu()
             # the payload of this step travels to rank 0 while the next step is compressed
+            for k, v in res.get("exchange_s", {}).items():
+                xt[k] = xt.get(k, 0.0) + v
             h = sharding.gather_payloads_begin(payload, res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
             finish_pending()
             state["pending"] = (h, res)
@@ -537,6 +606,7 @@ def main():
         step()
     drain()
     if world > 1:
+        xt.clear()                                        # (the warm-up's exchange times are not the timed region's)
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -548,10 +618,24 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    multi = None
     if world > 1:
+        # what the N > 1 line says about itself: the backend that really carried the exchange, the ranks the process group saw, every rank's
+        # own time for the K steps and where it spent its exchange time (so that a scaling loss can be attributed)
+        mine = {"rank": rank, "s": dt, "exchange_s": dict(xt)}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
         t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if emulate else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        keys = sorted({k for e in every for k in e["exchange_s"]})
+        multi = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                 "rank_ms_per_step": {"min": round(min(e["s"] for e in every) * 1e3 / args.steps, 3), "max": round(max(e["s"] for e in every) * 1e3 / args.steps, 3)},
+                 "exchange_ms_per_step": {k: {"rank0": round(every[0]["exchange_s"].get(k, 0.0) * 1e3 / args.steps, 3),
+                                              "max": round(max(e["exchange_s"].get(k, 0.0) for e in every) * 1e3 / args.steps, 3)} for k in keys},
+                 "exchange_note": "wall clock a rank spends inside each exchange step of sharding.deflate_stream_rank (waiting for its neighbours included): "
+                                  "all_gather_state = parser states and atom counts (a), boundary_atoms = edge atoms by all_gather (c), carry_chain = the 352-byte chooser state "
+                                  "from rank to rank (d), spans = bit positions by all_gather (d), gather_stitch = payloads to rank 0 and the OR (e)"}
 
     if rank == 0:
         rc, out_len, crc = last["rc"], last["out_len"], last["crc"]
@@ -573,6 +657,7 @@ def main():
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
+            "backend": multi["backend"] if multi else "none (one process, no process group)", "ranks_seen": multi["ranks_seen"] if multi else 1,
             "config": {"workload": wl, "bytes_per_gpu": n, "stream_bytes": total, "compression_ratio": round(out_len / total, 4), "rc": rc,
                        "value_is": "device-resident input (host buffers: see host_path)",
                        "phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in phase_ms.items()}},
@@ -581,6 +666,10 @@ def main():
                          "bound2": second_bound(kernels[dom]),
                          "note": "algorithmic bytes = N_in + N_out per launch; peak = min(data sheet, 1 GiB device-to-device copy measured on this box, read + write); the LZ kernels are latency / issue bound (radix sort of positions, chain walk), not HBM bound"},
         }
+        if multi:
+            res["rank_ms_per_step"] = multi["rank_ms_per_step"]
+            res["exchange_ms_per_step"] = multi["exchange_ms_per_step"]
+            res["exchange_note"] = multi["exchange_note"]
         stream = b""
         if world == 1 and args.no_host_path:
             args.no_checks = True
@@ -645,7 +734,7 @@ def main():
         if world == 1 and args.bzip2_mib > 0:
             res["bzip2"] = bzip2_leg(za, enc, args.bzip2_mib, not args.no_cpu_baseline, not args.no_checks)
         if world == 1 and args.lzma_entries > 0:
-            res["lzma"] = lzma_leg(za, enc, args.lzma_entries, args.lzma_kib, not args.no_cpu_baseline, not args.no_checks)
+            res["lzma"] = lzma_leg(za, enc, args.lzma_entries, args.lzma_kib, not args.no_cpu_baseline, not args.no_checks, args.lzma_one_mib)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

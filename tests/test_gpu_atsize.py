@@ -112,6 +112,67 @@ def test_bzip2_stream_across_a_span_boundary(encoder):
     assert tot == n and dec.eof and c == zlib.crc32(host)
 
 
+def test_c3_rank_shape_two_gib_range_between_its_neighbours(encoder):
+    """BASELINE config 3 gives each of 8 GPUs a 2 GiB range of ONE 16 GiB Deflate_3 stream (bench.py --gpus 8: sharding.stream_ranges,
+    32 KiB in front of the range and 1 MiB behind it resident as well).  No 8-GPU node has run it yet, so ONE rank's share runs here at
+    its size, on the one GPU there is: a 2 GiB range cut from the middle of a longer stream, the boundary state it needs (parser
+    states, edge atoms, the 352-byte chooser state) produced by contexts on the 64 MiB ranges on either side of it, all through
+    sharding.deflate_stream_rank -- the code a rank of bench.py runs.  The stitched stream == the stream of ONE call on the whole input
+    (another cut of the sequential encoder's state) == the input after zlib's inflate, with the combined CRC-32."""
+    import torch
+    za = product()
+    side, mid = 64 << 20, 2 << 30
+    n = side + mid + side
+    host = za.silesia_mix(n)
+    want_crc = zlib.crc32(host)
+    t_in = torch.from_numpy(host).cuda()
+    t_out = torch.empty(n // 2 + (64 << 20), dtype=torch.uint8, device="cuda")
+    rc, ol, crc = encoder.deflate_device(t_in.data_ptr(), n, t_out.data_ptr(), t_out.numel(), 10)
+    assert rc == 0 and (crc ^ 0xFFFFFFFF) == want_crc
+    one = bytes(t_out[:ol].cpu().numpy())
+    del t_in, t_out
+    encoder.close()                                  # (its workspace goes back before the three range contexts take theirs)
+    torch.cuda.empty_cache()
+    ranges = [(0, side), (side, mid), (side + mid, side)]
+    rc2, three, crc2, res = deflate_over_contexts(host, 3, 10, ranges=ranges)
+    assert rc2 == 0 and crc2 == crc and three == one, (len(three), len(one))
+    assert res[1]["infos"][1]["n"] == mid and res[1]["bit_begin"] == res[0]["bit_end"] and res[2]["bit_begin"] == res[1]["bit_end"]
+    c, tot, eof = _inflate_crc(three)
+    assert tot == n and c == want_crc and eof
+
+
+def test_c5_rank_shape_one_gib_bzip2_range_between_its_neighbours(encoder):
+    """BASELINE config 5 gives each of 8 GPUs a 1 GiB range of ONE 8 GiB BZip2_3 stream plus the 9 MB behind it that its last block
+    may reach into (sharding.bzip2_window).  One rank's share at its size on the one GPU there is: a 1 GiB range between two 64 MiB
+    ranges, through sharding.bzip2_stream_rank (block chain handed on, tables gathered, tactics replayed, bytes assembled and OR-ed) ==
+    the stream of ONE call on the whole input; libbz2 decodes it to the input."""
+    import torch
+    from test_gpu_bzip2 import _bzip2_over_contexts
+    za = product()
+    side, mid = 64 << 20, 1 << 30
+    n = side + mid + side
+    host = za.silesia_mix(n)
+    t_in = torch.from_numpy(host).cuda()
+    t_out = torch.zeros(n // 2 + (64 << 20), dtype=torch.uint8, device="cuda")
+    rc, ol, crc = encoder.bzip2_device(t_in.data_ptr(), n, t_out.data_ptr(), t_out.numel(), 14)
+    assert rc == 0 and (crc ^ 0xFFFFFFFF) == zlib.crc32(host)
+    one = bytes(t_out[:ol].cpu().numpy())
+    one_blocks = [tuple(int(x) for x in b) for b in encoder.bz2_last_blocks()]
+    del t_in, t_out
+    encoder.close()
+    torch.cuda.empty_cache()
+    stream, blocks, nr = _bzip2_over_contexts(host, 3, 14, ranges=[(0, side), (side, mid), (side + mid, side)])
+    assert nr == 3 and stream == one, (len(stream), len(one))
+    assert [tuple(int(x) for x in b) for b in blocks] == one_blocks
+    dec = bz2.BZ2Decompressor()
+    c, tot, off = 0, 0, 0
+    while off < len(stream):
+        ch = dec.decompress(stream[off:off + (8 << 20)])
+        off += 8 << 20
+        c = zlib.crc32(ch, c); tot += len(ch)
+    assert tot == n and dec.eof and c == zlib.crc32(host)
+
+
 # ---- soak seeds (tests/gpu_soak2.py, gpu_bz2_soak.py, gpu_lzma_soak.py ran thousands of such cases in round 2; one seed each here) ----
 
 def _soak_input(za, rng, n):

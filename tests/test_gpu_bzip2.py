@@ -149,8 +149,9 @@ def test_zip_archive_with_bzip2_entries(encoder):
     assert [i.compress_type for i in zf.infolist()] == [12, 0, 0, 0, 12]
 
 
-def _bzip2_over_contexts(data, world, method=14):
-    """The stream compressed by `world` contexts on cuda:0, one thread each, through sharding.bzip2_stream_rank."""
+def _bzip2_over_contexts(data, world, method=14, ranges=None):
+    """The stream compressed by `world` contexts on cuda:0, one thread each, through sharding.bzip2_stream_rank
+    (ranges: [(lo, n)] instead of the even cut of sharding.bzip2_ranges)."""
     import importlib
     import threading
     import torch
@@ -158,10 +159,10 @@ def _bzip2_over_contexts(data, world, method=14):
     Z = product()
     sh = importlib.import_module("zip-ada_amd.sharding")
     n = len(data)
-    ranges = sh.bzip2_ranges(n, world)
+    ranges = ranges or sh.bzip2_ranges(n, world)
     shared = ThreadComm.Shared(world)
     dev = torch.device("cuda", 0)
-    whole = torch.frombuffer(bytearray(data) if n else bytearray(1), dtype=torch.uint8).to(dev)
+    whole = (torch.from_numpy(data) if isinstance(data, np.ndarray) else torch.frombuffer(bytearray(data) if n else bytearray(1), dtype=torch.uint8)).to(dev)
     results, errors = [None] * world, []
 
     def run(r):

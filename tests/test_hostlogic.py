@@ -144,10 +144,16 @@ def test_bench_starts_its_own_ranks_and_fails_loudly():
     import sys
     bench = os.path.join(ROOT, "bench.py")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--mib", "1"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and "--gpus 2 but only 0 GPU(s) are visible" in r.stderr            # (the parent counts the devices before it starts anything)
+    # the parent counts the devices before it starts anything -- from sysfs, without loading torch or HIP; with every GPU hidden
+    # from it the answer is 0 on any box
+    import re
+    hidden = dict(env, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--mib", "1"], env=hidden, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and re.search(r"--gpus 2 but only 0 GPU\(s\) are visible", r.stderr), r.stderr[-2000:]
+    src = open(bench).read()
+    assert "import torch" not in src[src.index("def launch_ranks"):src.index("def main")], "the launching parent must not load torch / HIP"
     # BENCH_EMULATE=1 (every rank on GPU 0) skips that count: the two ranks are started and stop at "needs a GPU"
-    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--mib", "1"], env=dict(env, BENCH_EMULATE="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--mib", "1"], env=dict(hidden, BENCH_EMULATE="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and r.stderr.count("needs a GPU") >= 2, r.stderr[-2000:]
     r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "--gpus 4 but the launcher started 2 ranks" in r.stderr

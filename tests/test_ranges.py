@@ -97,16 +97,17 @@ class ThreadComm:
             return self.s.mail.pop((src, self.rank))
 
 
-def deflate_over_contexts(data, world, method, shard_kib=None):
-    """The stream `data` compressed by `world` contexts on cuda:0, one thread each, through sharding.deflate_stream_rank."""
+def deflate_over_contexts(data, world, method, shard_kib=None, ranges=None):
+    """The stream `data` compressed by `world` contexts on cuda:0, one thread each, through sharding.deflate_stream_rank
+    (ranges: [(lo, n)] instead of the even cut of sharding.stream_ranges)."""
     import torch
     za = product()
     sh = importlib.import_module("zip-ada_amd.sharding")
     n = len(data)
-    ranges = sh.stream_ranges(n, world)
+    ranges = ranges or sh.stream_ranges(n, world)
     shared = ThreadComm.Shared(world)
     dev = torch.device("cuda", 0)
-    whole = torch.frombuffer(bytearray(data) if n else bytearray(1), dtype=torch.uint8).to(dev)
+    whole = (torch.from_numpy(data) if isinstance(data, np.ndarray) else torch.frombuffer(bytearray(data) if n else bytearray(1), dtype=torch.uint8)).to(dev)
     results, errors = [None] * world, []
 
     def run(r):
@@ -206,6 +207,11 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     assert res["n_gpus"] == 3 and res["config"]["rc"] == 0
     assert res["checks"]["stream_inflates_to_input_crc"] is True and res["checks"]["sample_stream_equals_cpu_port"] is True, res["checks"]
     assert res["checks"]["inflated_bytes"] == 3 * (48 << 20)
+    # the line says what carried the exchange and where the ranks spent their time (what must be exchanged, zip-create.adb:194-297)
+    assert res["backend"] == "gloo" and res["ranks_seen"] == 3
+    assert 0 < res["rank_ms_per_step"]["min"] <= res["rank_ms_per_step"]["max"] <= res["ms_per_step"] * 1.05
+    assert set(res["exchange_ms_per_step"]) == {"all_gather_state", "boundary_atoms", "carry_chain", "spans", "gather_stitch"}
+    assert all(v["max"] >= v["rank0"] >= 0 for v in res["exchange_ms_per_step"].values())
 
 
 def test_spans_on_one_context(encoder):

@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ ar
   // the bucket's entry (a bucket never leaves its entry)
   const uint8_t *jin = nullptr; int32_t *jtree = nullptr; const Bt4Run *jruns = nullptr;
   uint32_t jrun_cnt = 0, joff = 0; int32_t jmax = 0;
+  Bt4Run cr{0, 0, 0, 0, 2, 0};                                       // the run of the last position (a bucket's positions mostly share it: no look-up in HBM per position)
   Bt4Walk w;
   bool rec0 = false;
   auto ext = [](const uint8_t *b, int64_t x, int64_t y, int l, int lim) { return extend8(b, x, y, l, lim); };
@@ -193,12 +194,14 @@ __global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ ar
         const Bt4Job &J = T.jobs[job];
         joff = (uint32_t)J.in_off; jin = arena + J.in_off; jtree = tree + 2 * (size_t)J.in_off;
         jruns = T.runs + J.run_off; jrun_cnt = J.run_cnt; jmax = (int32_t)J.max_dist;
+        cr.start = cr.end = 0;
       }
       const uint4 rc = nxt;
       if (i + 1 < e) nxt = rec[i + 1];
       p = rc.x;
       const uint32_t q = p - joff;
-      const Bt4Run *r = bt4_run_of(jruns, jrun_cnt, q);
+      if (q < cr.start || q >= cr.end) cr = *bt4_run_of(jruns, jrun_cnt, q);
+      const Bt4Run *r = &cr;
       const int avail = (int)(r->W - q - 1);
       rec0 = r->cls == 0;
       bt4_begin(w, jin, q, (int32_t)(q - r->gap), rec0, avail < BT4_LOOK ? avail : BT4_LOOK, jmax, prev_ord, rec0 ? (int32_t)rc.y : BT4_NONE, rec0 ? (int32_t)rc.z : BT4_NONE, ext, put);

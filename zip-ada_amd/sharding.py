@@ -196,11 +196,13 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
     tensors    module with the tensor ops the protocol needs (torch)
     Returns dict(bit_begin, bit_end, total_bits, payload (uint8 tensor holding stream bytes [bit_begin // 8,
     ceil(bit_end / 8))), nbytes, crc_raw, n, infos, inefficient)."""
+    import time
     r, W = comm.rank, comm.world
     nr = len(ranges)
     active = r < nr
     fixed_only = method == 6
     info = None
+    xs = {"all_gather_state": 0.0, "boundary_atoms": 0.0, "carry_chain": 0.0, "spans": 0.0}     # seconds inside the exchange steps (waiting included)
     if active:
         lo, n = ranges[r]
         _, pre, post = range_window(stream_size, lo, n)
@@ -208,6 +210,7 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
         info = enc.range_lz(None)
         info["n"] = n
     # ---- a. parser states at the boundaries
+    t_x = time.perf_counter()
     infos = comm.all_gather_obj(info)
     for k in range(1, nr):
         if tuple(infos[k]["warm"]) != tuple(infos[k - 1]["exit"]):
@@ -216,6 +219,7 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
                 info = enc.range_lz(tuple(infos[k - 1]["exit"]))
                 info["n"] = ranges[k][1]
             infos[k] = comm.bcast_obj(info if r == k else None, src=k)
+    xs["all_gather_state"] += time.perf_counter() - t_x
     # ---- b. the ranges on the flush grid
     counts = [infos[k]["atoms"] for k in range(nr)]
     total = sum(counts)
@@ -228,8 +232,10 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
     lb_a = lb_p = la_a = la_p = None
     n_lb = n_la = 0
     if not fixed_only and any(a or b for a, b in need):
+        t_x = time.perf_counter()
         heads_a, heads_p = comm.all_gather_dev(head_a), comm.all_gather_dev(head_p)
         tails_a, tails_p = comm.all_gather_dev(tail_a), comm.all_gather_dev(tail_p)
+        xs["boundary_atoms"] += time.perf_counter() - t_x
         if active:
             n_lb, n_la = need[r]
             if n_lb:                                  # the last n_lb (<= 2 048) atoms before this range: tails of r-1, r-2, ...
@@ -258,11 +264,17 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
     # ---- d. the block decisions: the one sequential step, 352 bytes from rank to rank
     bit_begin = bit_end = 0
     if active:
+        t_x = time.perf_counter()
         carry = comm.recv_bytes(352, r - 1) if r > 0 else None
+        xs["carry_chain"] += time.perf_counter() - t_x
         carry_out, bit_begin, bit_end = enc.range_choose(carry)
         if r + 1 < nr:
+            t_x = time.perf_counter()
             comm.send_bytes(carry_out, r + 1)
+            xs["carry_chain"] += time.perf_counter() - t_x
+    t_x = time.perf_counter()
     spans = comm.all_gather_obj((bit_begin, bit_end) if active else None)
+    xs["spans"] += time.perf_counter() - t_x
     total_bits = spans[nr - 1][1]
     inefficient = (total_bits + 7) // 8 >= stream_size            # Compression_inefficient, zip-compress.adb:479-486
     # ---- e. this rank's bytes of the stream
@@ -272,7 +284,7 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
         payload = alloc_out(cap)
         nbytes = enc.range_emit(payload.data_ptr(), cap)
     return dict(bit_begin=bit_begin, bit_end=bit_end, total_bits=total_bits, payload=payload, nbytes=nbytes, spans=spans,
-                infos=infos, inefficient=inefficient, crc_raw=info["crc_raw"] if active else 0)
+                infos=infos, inefficient=inefficient, crc_raw=info["crc_raw"] if active else 0, exchange_s=xs)
 
 
 def stitch_stream(tensors, payloads, spans, total_bits, device):
