@@ -54,7 +54,8 @@ enum {
   ZADA_E_INVALID = -1,      /* bad argument / unsupported method */
   ZADA_E_NOMEM = -2,        /* host or device allocation failed */
   ZADA_E_HIP = -3,          /* HIP runtime error; see zada_last_error() */
-  ZADA_E_TOO_LARGE = -4,    /* zada_range_open: a range is < 4 GiB - 64 MiB (zada_deflate* take streams of any length, span after span) */
+  ZADA_E_TOO_LARGE = -4,    /* the input is larger than the call takes: zada_range_open takes ranges below 4 GiB - 64 MiB (zada_deflate* take streams of any
+                             * length, span after span), zada_lzma* entries below 2 GiB - 64 KiB and batches below 4 GiB */
   ZADA_E_NO_DEVICE = -5     /* no gfx950 device / HIP extension unusable */
 };
 
