@@ -297,7 +297,7 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
     size = kib << 10
     host = za.silesia_mix(entries * size, seed=SEED)
     datas = [host[i * size:(i + 1) * size].tobytes() for i in range(entries)]
-    enc.lzma_batch(datas[:8], 18)
+    enc.lzma_batch(datas, 18)                            # warm-up at full size (the producer's and the coder's buffers are allocated here)
     t0 = time.perf_counter()
     res = enc.lzma_batch(datas, 18)
     dt = time.perf_counter() - t0

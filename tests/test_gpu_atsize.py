@@ -173,6 +173,47 @@ def test_c5_rank_shape_one_gib_bzip2_range_between_its_neighbours(encoder):
     assert tot == n and dec.eof and c == zlib.crc32(host)
 
 
+def test_two_contexts_at_config_2_size_on_one_gpu():
+    """Two contexts, each compressing a 1 GiB entry (BASELINE config 2's size) at the same time on one GPU: a context's workspace for
+    such an entry is about 75 GiB with the default 1 GiB shards of the match finder (60 bytes per byte of shard + 15 per atom slot), 45 GiB with
+    512 MiB shards ("shard_kib": 3.5 % slower) -- both fit 288 GB twice.  One context of each kind here; both streams == the stream
+    of a context alone, and inflate to the input."""
+    import threading
+    import torch
+    za = product()
+    n = 1 << 30
+    host = za.silesia_mix(n)
+    want_crc = zlib.crc32(host)
+    t_in = torch.from_numpy(host).cuda()
+    outs = [torch.empty(n // 2 + (64 << 20), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    got, errors = [None, None], []
+
+    def run(k):
+        try:
+            torch.cuda.set_device(0)
+            enc = za.Encoder(0)
+            if k == 1:
+                enc.set_knob("shard_kib", 512 << 10)
+            for _ in range(2):
+                got[k] = enc.deflate_device(t_in.data_ptr(), n, outs[k].data_ptr(), outs[k].numel(), 10)
+            free, total = torch.cuda.mem_get_info()
+            got[k] = got[k] + (total - free,)
+            enc.close()
+        except BaseException as e:          # noqa: BLE001
+            errors.append((k, repr(e)))
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    (rc0, ol0, crc0, used0), (rc1, ol1, crc1, used1) = got
+    assert rc0 == rc1 == 0 and ol0 == ol1 and crc0 == crc1 and (crc0 ^ 0xFFFFFFFF) == want_crc
+    a = bytes(outs[0][:ol0].cpu().numpy())
+    assert a == bytes(outs[1][:ol1].cpu().numpy())
+    c, tot, eof = _inflate_crc(a)
+    assert tot == n and c == want_crc and eof
+    assert max(used0, used1) < (200 << 30), (used0, used1)        # both workspaces, the input and the two outputs together
+
+
 # ---- soak seeds (tests/gpu_soak2.py, gpu_bz2_soak.py, gpu_lzma_soak.py ran thousands of such cases in round 2; one seed each here) ----
 
 def _soak_input(za, rng, n):

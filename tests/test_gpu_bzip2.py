@@ -262,6 +262,26 @@ def test_batch_of_small_entries_is_bit_exact(encoder):
     assert zc.finish() == oracle_zip(entries, 14)
 
 
+def test_batch_with_more_sub_blocks_than_a_list_entry_can_name(encoder):
+    """A list entry of the rotation sort's late rounds packs its sub-block into 19 bits (GlEntry::sb_rows, zada_bz2.hip): 120 000 small
+    entries in ONE launch sequence make 600 000 sub-blocks (BZip2_3: the single block and its four quarters each, bzip2-encoding.adb:
+    1237-1253) -- beyond that, the batch keeps sweeping instead of listing (bz_transform).  Every stream is decoded by libbz2, a sample is
+    compared with the oracle byte for byte."""
+    Z = product()
+    rng = np.random.default_rng(524288)
+    mix = Z.silesia_mix(4 << 20, class_mask=1)
+    offs = rng.integers(0, len(mix) - 400, 120000)
+    lens = rng.integers(250, 351, 120000)
+    datas = [bytes(mix[int(o):int(o) + int(n)]) for o, n in zip(offs, lens)]
+    res = encoder.bzip2_batch(datas, 14)
+    assert len(res) == len(datas)
+    for k in range(0, len(datas), 500):
+        o, _ = oracle_encode(datas[k], 2)
+        assert res[k][1] == o, k
+    for d, (rc, p, crc) in zip(datas, res):
+        assert bz2.decompress(p) == d and (crc ^ 0xFFFFFFFF) == zlib.crc32(d)
+
+
 def test_group_lists_of_the_rotation_sort(encoder):
     """Round 3: the late rounds of the rotation sort run from lists of the unsorted groups (a thread per group of up to 8 rows,
     sixteen lanes up to 16, a wave up to 64, a workgroup up to 8 192; classes in two arrays that take turns, zada_bz2.hip "Late rounds: group lists").  The
