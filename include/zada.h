@@ -205,8 +205,10 @@ int zada_bzip2_batch(zada_ctx *ctx, int method, int count, const uint8_t *const 
  * marker and dictionary_size = the input's size (zip-compress-lzma_e.adb:121-126, 160-165).  Conventions as zada_deflate:
  * method = Compression_Method'Pos, crc_inout = the running Zip CRC-32 register, return ZADA_OK / ZADA_INEFFICIENT / < 0.
  * The output is the Zip payload: the four bytes 16, 2, 5, 0 (:155-158), the 5-byte LZMA header, the range-coded stream.
- * A stream is one chain of dependent steps (adaptive probabilities): one workgroup codes it; entries are what runs in
- * parallel -- use zada_lzma_batch for many of them.  A stream runs as a sequence of bounded launches (about half a second each,
+ * The coder of a stream is one chain of dependent steps (adaptive probabilities): one workgroup codes it; entries are what runs in
+ * parallel -- use zada_lzma_batch for many of them.  LZMA_3's BT4 matcher (lz77.adb:953-1827) is NOT part of that chain: its match sets are
+ * a function of the input alone and are produced by data-parallel kernels before the coder starts (about 140 bytes of device memory per
+ * input byte of the call, kept by the context).  A stream runs as a sequence of bounded launches (about half a second each,
  * "lzma_chunk"), the coder's state waiting in device memory in between: fb (may be NULL) is called with 0, between the launches
  * and with 100, and a non-zero return ends the call with ZADA_ABORTED (Feedback / User_abort, zip-compress-lzma_e.adb:78-92).
  * Limits: entries below 2 GiB - 64 KiB (ZADA_E_TOO_LARGE beyond: the shim Stores such an entry or raises); only the

@@ -8,7 +8,8 @@ E = int(os.environ.get("LZ_ENTRIES", "4096")); size = 16 << 10
 one_kib = int(os.environ.get("LZ_ONE_KIB", "1024"))
 mix = Z.silesia_mix(max(E * size, one_kib << 10))
 datas = [bytes(mix[i * size:(i + 1) * size]) for i in range(E)]
-enc.lzma_batch(datas[:8], 18)
+if os.environ.get("LZ_WARM", "1") != "0":
+    enc.lzma_batch(datas[:8], 18)
 if E:
     for rep in range(2):
         t = time.time(); res = enc.lzma_batch(datas, 18); dt = time.time() - t
