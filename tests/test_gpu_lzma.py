@@ -57,6 +57,18 @@ def test_match_sets_of_the_bt4_producer_equal_the_sequential_matchers(encoder):
         encoder.set_knob("lzma_dict", 0)
 
 
+def test_one_stream_of_four_mib_and_more(encoder):
+    """BASELINE config 4's shape at a size the oracle finishes in seconds: ONE LZMA_3 stream of 4 MiB + 12 345 bytes of the benchmark stream
+    (not a repeated slice) through zada_lzma -- the producer's kernels on one big entry (its long buckets, nodes in HBM), the coder in bounded
+    launches of 64 Ki positions with feedback -- == the oracle's payload; liblzma decodes it."""
+    Z = product()
+    d = bytes(Z.silesia_mix((4 << 20) + 12345, seed=0x5A1E51A))
+    seen = []
+    rc, z, crc = encoder.lzma(d, 18, feedback=lambda pct: seen.append(pct) and False)
+    assert (rc, z, crc) == oracle_lzma(d, 18)
+    assert lzma_decode(z, 4) == d and seen[0] == 0 and seen[-1] == 100 and len(seen) > 60
+
+
 def test_single_calls_host_and_device_entry(encoder):
     """zada_lzma and zada_lzma_device on the mixed corpus (every variant of a DL code is taken there), all four methods;
     liblzma decodes what the product wrote."""
