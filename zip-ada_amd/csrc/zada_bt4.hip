@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_bt4_split(const uint32_t *__restrict__ 
   uint32_t s = 0, len = 0;
   if (live) {
     s = heads[r]; len = (r + 1 < R ? heads[r + 1] : cnts[4]) - s;
-    if (len < BT_LONG && T.jobs[T.tile_job[vals[s] >> 6]].small) live = false;       // (k_bt4_walk_lds takes the short buckets of such an entry)
+    if (T.jobs[T.tile_job[vals[s] >> 6]].small) live = false;       // (k_bt4_walk_lds takes such an entry: short buckets and long ones)
   }
   const int lane = threadIdx.x & 63;
   const uint64_t lt = (1ull << lane) - 1;
@@ -217,69 +217,75 @@ __global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ ar
 }
 
 // An entry of up to BT4_LDS_N bytes with one window fill (positions 0 .. n - 163 are read and inserted with n - q - 1 bytes available,
-// the last 162 never: bt4_schedule gives two runs): one workgroup, the entry's text and the nodes of its trees in LDS.  Its buckets are
-// the entries rank [sorted_off] .. rank [sorted_end] of `heads`; the lanes take them through an LDS counter.  Only the SHORT buckets
-// (fewer than BT_LONG positions): a long bucket is one lane's chain of thousands of dependent steps, during which the workgroup would
-// keep its 80 KB of LDS to itself -- those go to k_bt4_walk, with their nodes in HBM (a bucket's nodes are nobody else's), where the long
-// buckets of ALL entries of the call walk side by side.
+// the last 162 never: bt4_schedule gives two runs): one workgroup, the entry's text in LDS.  Its buckets are the entries
+// rank [sorted_off] .. rank [sorted_end] of `heads`; the lanes take them through an LDS counter.  Two launches:
+//   LONGS = false  512 lanes, the SHORT buckets (fewer than BT_LONG positions) with the nodes of their trees in LDS as well (16-bit
+//                  nodes: 80 KB with the text, two entries per CU) -- a walk is a chain of dependent reads, in LDS a tenth of what it is in HBM;
+//   LONGS = true   64 lanes, the LONG buckets with their nodes in HBM (a bucket's nodes are nobody else's): a long bucket is one lane's
+//                  chain of thousands of dependent steps, during which a workgroup of the first kind would keep its 80 KB to itself; with
+//                  the text alone (16 KB) ten entries share a CU, the long buckets of 2 560 entries walk side by side, and what a step
+//                  waits for is one node from HBM -- the byte comparisons stay in LDS.
 constexpr int BT4_LDS_THREADS = 512;
-constexpr uint32_t BT4_LDS_BYTES = 4 * (BT4_LDS_N - BT4_NICE) + BT4_LDS_N + 16;
-__global__ void __launch_bounds__(BT4_LDS_THREADS) k_bt4_walk_lds(const uint8_t *__restrict__ arena, const uint4 *__restrict__ rec, const uint32_t *__restrict__ heads,
-                                                                  const uint32_t *__restrict__ rank, const uint32_t *__restrict__ small_jobs, uint32_t *__restrict__ cnts, Tables T, Sets S) {
+constexpr uint32_t BT4_LDS_BYTES = 4 * (BT4_LDS_N - BT4_NICE) + BT4_LDS_N + 16, BT4_TEXT_BYTES = BT4_LDS_N + 16;
+template <bool LONGS>
+__global__ void __launch_bounds__(LONGS ? 64 : BT4_LDS_THREADS) k_bt4_walk_lds(const uint8_t *__restrict__ arena, const uint4 *__restrict__ rec, const uint32_t *__restrict__ heads,
+                                                                           const uint32_t *__restrict__ rank, const uint32_t *__restrict__ small_jobs, uint32_t *__restrict__ cnts, Tables T,
+                                                                           int32_t *__restrict__ gtree, Sets S) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int NT = LONGS ? 64 : BT4_LDS_THREADS;
   const uint32_t job = small_jobs[blockIdx.x];
   const Bt4Job J = T.jobs[job];
   const uint32_t n = J.n, nins = n - BT4_NICE;                       // inserted positions (n > 162: the host lists no other entries)
   uint16_t *tree = (uint16_t *)lds;
-  uint8_t *text = lds + 4 * (size_t)(BT4_LDS_N - BT4_NICE);
+  uint8_t *text = lds + (LONGS ? 0 : 4 * (size_t)(BT4_LDS_N - BT4_NICE));
   uint32_t *next = (uint32_t *)(text + BT4_LDS_N);
   const uint8_t *src = arena + J.in_off;
-  for (uint32_t i = threadIdx.x * 16; i < n; i += BT4_LDS_THREADS * 16) {                 // (entries start at multiples of 64)
+  for (uint32_t i = threadIdx.x * 16; i < n; i += NT * 16) {         // (entries start at multiples of 64)
     if (i + 16 <= n) *(uint4 *)(text + i) = *(const uint4 *)(src + i);
     else for (uint32_t k = i; k < n; k++) text[k] = src[k];          // (nothing is read behind the entry: the caller's buffer may end there)
   }
-  if (threadIdx.x < 2) next[threadIdx.x] = 0;
+  if (threadIdx.x == 0) next[0] = 0;
   __syncthreads();
   const uint32_t s0 = J.sorted_off, s1 = s0 + nins, h0 = rank[s0], h1 = rank[s1], joff = (uint32_t)J.in_off;
   const int32_t jmax = (int32_t)J.max_dist;
-  const Bt4TreeU16 TR{tree};
+  int32_t *jtree = gtree + 2 * (size_t)J.in_off;
   auto ext = [](const uint8_t *b, int64_t x, int64_t y, int l, int lim) { return bt4_extend(b, x, y, l, lim); };
-  {
-    constexpr int round = 0;
-    bool walking = false;
-    uint32_t i = 0, e = 0, p = 0, blk = 0;
-    int32_t prev_ord = BT4_NONE;
-    uint4 nxt = make_uint4(0, 0, 0, 0);                              // the record of position i (loaded while position i - 1 was walked)
-    Bt4Walk w;
-    auto put = [&](int k, int len, uint32_t dist) {
-      const size_t base = (size_t)p * BT4_INLINE;
-      if (k < BT4_INLINE - 1) { S.sl[base + k] = (uint16_t)len; S.sd[base + k] = dist; return; }
-      if (k == BT4_INLINE - 1) { blk = atomicAdd(&cnts[3], 1u); S.sd[base + BT4_INLINE - 1] = blk; }
-      if (blk < S.ovf_cap) { const size_t o = (size_t)blk * BT4_OVF + (uint32_t)(k - (BT4_INLINE - 1)); S.ol[o] = (uint16_t)len; S.od[o] = dist; }
-    };
-    for (;;) {
-      if (!walking) {
-        while (i >= e) {                                              // the next bucket of this round
-          const uint32_t b = h0 + atomicAdd(&next[round], 1u);
-          if (b >= h1) { i = 1; e = 0; break; }
-          const uint32_t hs = heads[b], he = b + 1 < h1 ? heads[b + 1] : s1;
-          if (he - hs < BT_LONG) { i = hs; e = he; prev_ord = BT4_NONE; nxt = rec[i]; }
-        }
-        if (i >= e) break;
-        const uint4 r = nxt;
-        if (i + 1 < e) nxt = rec[i + 1];
-        p = r.x;
-        const uint32_t q = p - joff;
-        const int avail = (int)(n - q - 1);
-        bt4_begin(w, text, q, (int32_t)q, true, avail < BT4_LOOK ? avail : BT4_LOOK, jmax, prev_ord, (int32_t)r.y, (int32_t)r.z, ext, put);
-        walking = true;
+  bool walking = false;
+  uint32_t i = 0, e = 0, p = 0, blk = 0;
+  int32_t prev_ord = BT4_NONE;
+  uint4 nxt = make_uint4(0, 0, 0, 0);                                // the record of position i (loaded while position i - 1 was walked)
+  Bt4Walk w;
+  auto put = [&](int k, int len, uint32_t dist) {
+    const size_t base = (size_t)p * BT4_INLINE;
+    if (k < BT4_INLINE - 1) { S.sl[base + k] = (uint16_t)len; S.sd[base + k] = dist; return; }
+    if (k == BT4_INLINE - 1) { blk = atomicAdd(&cnts[3], 1u); S.sd[base + BT4_INLINE - 1] = blk; }
+    if (blk < S.ovf_cap) { const size_t o = (size_t)blk * BT4_OVF + (uint32_t)(k - (BT4_INLINE - 1)); S.ol[o] = (uint16_t)len; S.od[o] = dist; }
+  };
+  for (;;) {
+    if (!walking) {
+      while (i >= e) {                                                // the next bucket of this kind
+        const uint32_t b = h0 + atomicAdd(&next[0], 1u);
+        if (b >= h1) { i = 1; e = 0; break; }
+        const uint32_t hs = heads[b], he = b + 1 < h1 ? heads[b + 1] : s1;
+        if ((he - hs >= BT_LONG) == LONGS) { i = hs; e = he; prev_ord = BT4_NONE; nxt = rec[i]; }
       }
-      if (bt4_step(w, TR, ext, put)) {
-        S.cnt[p] = (uint8_t)w.count;
-        prev_ord = w.ordp;
-        i++;
-        walking = false;
-      }
+      if (i >= e) break;
+      const uint4 r = nxt;
+      if (i + 1 < e) nxt = rec[i + 1];
+      p = r.x;
+      const uint32_t q = p - joff;
+      const int avail = (int)(n - q - 1);
+      bt4_begin(w, text, q, (int32_t)q, true, avail < BT4_LOOK ? avail : BT4_LOOK, jmax, prev_ord, (int32_t)r.y, (int32_t)r.z, ext, put);
+      walking = true;
+    }
+    bool done;
+    if constexpr (LONGS) done = bt4_step(w, Bt4TreeI32{jtree}, ext, put);
+    else done = bt4_step(w, Bt4TreeU16{tree}, ext, put);
+    if (done) {
+      S.cnt[p] = (uint8_t)w.count;
+      prev_ord = w.ordp;
+      i++;
+      walking = false;
     }
   }
 }
@@ -397,15 +403,19 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   hipLaunchKernelGGL(k_bt4_split, gp, b256, 0, st, heads, order, T, cnts + 5, cnts, B->longs.as<uint2>(), B->shorts.as<uint2>());
   if (hip_check(c, hipGetLastError(), "BT4 producer (sorts)")) return ZADA_E_HIP;
   if (!small_jobs.empty() && !B->lds_attr) {
-    if (hip_check(c, hipFuncSetAttribute((const void *)k_bt4_walk_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BT4_LDS_BYTES), "k_bt4_walk_lds (LDS size)")) return ZADA_E_HIP;
+    if (hip_check(c, hipFuncSetAttribute((const void *)k_bt4_walk_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BT4_LDS_BYTES), "k_bt4_walk_lds (LDS size)")) return ZADA_E_HIP;
     B->lds_attr = true;
   }
   for (int attempt = 0; attempt < 2; attempt++) {
     if ((rc = grow(c, B->ol, 2ull * BT4_OVF * B->ovf_cap)) || (rc = grow(c, B->od, 4ull * BT4_OVF * B->ovf_cap))) return rc;
     const Sets S{B->cnt.as<uint8_t>(), B->sl.as<uint16_t>(), B->sd.as<uint32_t>(), B->ol.as<uint16_t>(), B->od.as<uint32_t>(), B->ovf_cap};
     const uint32_t nblk = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
-    if (!small_jobs.empty())
-      hipLaunchKernelGGL(k_bt4_walk_lds, dim3((uint32_t)small_jobs.size()), dim3(BT4_LDS_THREADS), BT4_LDS_BYTES, st, d_arena, B->rec.as<uint4>(), heads, flags, B->small.as<uint32_t>(), cnts, T, S);
+    if (!small_jobs.empty()) {                                         // (the long buckets first: their chains are the critical path)
+      hipLaunchKernelGGL(k_bt4_walk_lds<true>, dim3((uint32_t)small_jobs.size()), dim3(64), BT4_TEXT_BYTES, st, d_arena, B->rec.as<uint4>(), heads, flags, B->small.as<uint32_t>(), cnts, T,
+                         B->tree.as<int32_t>(), S);
+      hipLaunchKernelGGL(k_bt4_walk_lds<false>, dim3((uint32_t)small_jobs.size()), dim3(BT4_LDS_THREADS), BT4_LDS_BYTES, st, d_arena, B->rec.as<uint4>(), heads, flags, B->small.as<uint32_t>(), cnts, T,
+                         B->tree.as<int32_t>(), S);
+    }
     hipLaunchKernelGGL(k_bt4_walk, dim3(nblk), b256, 0, st, d_arena, B->rec.as<uint4>(), B->longs.as<uint2>(), B->shorts.as<uint2>(), cnts, T, B->tree.as<int32_t>(), S);
     uint32_t h[8];
     hipMemcpyAsync(h, cnts, sizeof h, hipMemcpyDeviceToHost, st);
