@@ -12,11 +12,13 @@
 //   k_bt4_jobkeys  + one more stable sort, by entry: the hash-4 order becomes (entry, hash 4, position) -- an entry's buckets side by side;
 //   k_bt4_flags, k_bt4_heads, k_bt4_split
 //                  the runs of equal (entry, hash 4) = the buckets, each one binary tree; long buckets and short ones apart;
-//   k_bt4_walk_lds an entry of up to 16 KiB (one window fill) per workgroup: its text and its trees (16-bit nodes) in LDS, one LANE per
-//                  bucket -- a walk is a chain of dependent reads (node, then the candidate's bytes), in LDS a tenth of what it is in HBM;
-//   k_bt4_walk     the buckets of all other entries, one LANE per bucket (bt4_begin / bt4_step) with the nodes in HBM: persistent
-//                  lanes, a lane that finishes a position takes its bucket's next one -- or the next bucket -- while its neighbours are
-//                  still on their way down; long buckets are handed out one by one through a counter, the short ones by stride.
+//   k_bt4_walk_lds an entry of up to 16 KiB (one window fill) per workgroup, its text in LDS, one LANE per bucket (bt4_begin / bt4_step) -- a
+//                  walk is a chain of dependent reads (node, then the candidate's bytes).  Two launches: the short buckets with their trees
+//                  in LDS as well (16-bit nodes; a step is a tenth of what it is in HBM), the long buckets with their nodes in HBM and only
+//                  the text in LDS (ten entries per CU: the long chains of thousands of entries side by side);
+//   k_bt4_walk     the buckets of all other entries, one LANE per bucket with the nodes in HBM: persistent lanes, a lane that finishes a
+//                  position takes its bucket's next one -- or the next bucket -- while its neighbours are still on their way down; long
+//                  buckets are handed out one by one through a counter, the short ones by stride.
 //
 // Match sets in HBM: 8 slots per position (7 matches; most positions have one to three), the rest of a longer set (up to 50 matches: one
 // per hash + one per tree level, Depth_Limit = 48) in a 43-slot block of an overflow pool booked through an atomic counter.  When the pool

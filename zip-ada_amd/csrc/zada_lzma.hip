@@ -73,10 +73,13 @@ __device__ unsigned long long g_lzprof[8];
 #define PROF_ADD(i)
 #endif
 
-__device__ const uint8_t T_LIT[12]  = {0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 4, 5};          // lzma.ads:86-89
-__device__ const uint8_t T_MATCH[12] = {7, 7, 7, 7, 7, 7, 7, 10, 10, 10, 10, 10};
-__device__ const uint8_t T_REP[12]  = {8, 8, 8, 8, 8, 8, 8, 11, 11, 11, 11, 11};
-__device__ const uint8_t T_SREP[12] = {9, 9, 9, 9, 9, 9, 9, 11, 11, 11, 11, 11};
+// The state transitions of lzma.ads:86-89 (Update_State_Literal = 0 0 0 0 1 2 3 4 5 6 4 5, _Match = 7 x 7, 10 x 5, _Rep = 8 x 7, 11 x 5,
+// _ShortRep = 9 x 7, 11 x 5) as arithmetic: as tables in device memory every simulated symbol waited for a load before the next
+// symbol's probabilities could even be addressed.
+__device__ __forceinline__ uint32_t t_lit(uint32_t s) { return s < 4 ? 0u : s < 10 ? s - 3u : s - 6u; }
+__device__ __forceinline__ uint32_t t_match(uint32_t s) { return s < 7 ? 7u : 10u; }
+__device__ __forceinline__ uint32_t t_rep(uint32_t s) { return s < 7 ? 8u : 11u; }
+__device__ __forceinline__ uint32_t t_srep(uint32_t s) { return s < 7 ? 9u : 11u; }
 
 __device__ inline uint32_t TB(int64_t p) { return p < 0 ? 0u : (uint32_t)s_E.in[p]; }
 
@@ -95,10 +98,19 @@ __device__ inline double tbe(uint16_t p, uint32_t sym) {
   const uint32_t q = sym ? 2048u - (uint32_t)p : (uint32_t)p;
   return (double)q * (1.0 / 2048.0);
 }
+// The same without the scaling.  A product of such factors, multiplied in the reference's order and scaled ONCE at the end by 2 ** (-11 n), is
+// the reference's product bit for bit: a scaling by a power of two commutes with every rounding as long as nothing leaves the normal range,
+// and the unscaled partial products here stay between 31 ** 10 and 2048 ** 10 (probabilities are kept within 31 .. 2017 by their update
+// rule; a function multiplies at most ten of them before it scales).  One multiplication per factor instead of two.
+__device__ inline double tq(uint16_t p, uint32_t sym) {
+  const uint32_t q = sym ? 2048u - (uint32_t)p : (uint32_t)p;
+  return (double)q;
+}
+__device__ inline double scale11(double x, int factors) { return __builtin_ldexp(x, -11 * factors); }
 
 __device__ double test_simple_literal(uint32_t b, uint32_t b_match, int idx, const MS &sim) {   // :372-419
   const uint16_t *prob = s_P.lit + idx;
-  double pl = tbe(s_P.match[sim.state][sim.pos_state], 0);
+  double pl = tq(s_P.match[sim.state][sim.pos_state], 0);
   uint32_t symb = b | 0x100;
   uint16_t pr[8];                                 // the eight probabilities first (their addresses do not depend on each other), then the products in order
   if (sim.state < 7) {
@@ -115,31 +127,34 @@ __device__ double test_simple_literal(uint32_t b, uint32_t b_match, int idx, con
     }
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++) pl = pl * tbe(pr[k], (symb >> (7 - k)) & 1);
-  return pl;
+  for (int k = 0; k < 8; k++) pl = pl * tq(pr[k], (symb >> (7 - k)) & 1);
+  return scale11(pl, 9);
 }
 
 __device__ inline double test_short_rep(const MS &sim) {           // :421-428
   const LzProbs &P = s_P;
-  return tbe(P.match[sim.state][sim.pos_state], 1) * tbe(P.rep[sim.state], 1) * tbe(P.g0[sim.state], 0) * tbe(P.rep0_long[sim.state][sim.pos_state], 0);
+  return scale11(tq(P.match[sim.state][sim.pos_state], 1) * tq(P.rep[sim.state], 1) * tq(P.g0[sim.state], 0) * tq(P.rep0_long[sim.state][sim.pos_state], 0), 4);
 }
 
 __device__ inline int lit_idx(uint32_t prev_byte) { return 0x300 * (int)(prev_byte >> 5); }    // Idx_for_Literal_prob :193-201
 
-__device__ __forceinline__ void sim_literal(uint32_t b, MS &sim, double &prob) {    // Simulate_Literal_Byte :431-458
+// Simulate_Literal_Byte :431-458; b_match = the byte at the last distance, Text_Buf ((R - rep_dist (0) - 1) and mask)
+__device__ __forceinline__ void sim_literal_bm(uint32_t b, uint32_t b_match, MS &sim, double &prob) {
   const int idx = lit_idx(sim.prev_byte);
-  const uint32_t b_match = TB((int64_t)sim.pos - (int64_t)sim.rep[0] - 1);
   sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
   const double ltr = test_simple_literal(b, b_match, idx, sim);
   bool srep = false;
   if (b == b_match && sim.pos > (uint64_t)(uint32_t)(sim.rep[0] + 1)) {
     const double srm = test_short_rep(sim);
-    if (srm > ltr) { sim.state = T_SREP[sim.state]; prob = prob * srm; srep = true; }
+    if (srm > ltr) { sim.state = t_srep(sim.state); prob = prob * srm; srep = true; }
   }
-  if (!srep) { sim.state = T_LIT[sim.state]; prob = prob * ltr; }
+  if (!srep) { sim.state = t_lit(sim.state); prob = prob * ltr; }
   sim.pos += 1;
   sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
   sim.prev_byte = b;
+}
+__device__ __forceinline__ void sim_literal(uint32_t b, MS &sim, double &prob) {
+  sim_literal_bm(b, TB((int64_t)sim.pos - (int64_t)sim.rep[0] - 1), sim, prob);
 }
 
 __device__ inline double test_literal_byte(uint32_t b, const MS &sim) {          // :460-468
@@ -148,61 +163,69 @@ __device__ inline double test_literal_byte(uint32_t b, const MS &sim) {         
   return prob;
 }
 
-template <int NB> __device__ inline double sim_bit_tree(const uint16_t *prob, uint32_t symbol) {   // Simulate_Bit_Tree :470-481
+// (the `_u` functions return UNSCALED products -- see tq -- and say how many factors they hold; their callers scale)
+template <int NB> __device__ inline double sim_bit_tree_u(const uint16_t *prob, uint32_t symbol) {   // Simulate_Bit_Tree :470-481, NB factors
   uint16_t pr[NB];
   uint32_t m = 1;
 #pragma unroll
   for (int k = 0; k < NB; k++) { pr[k] = prob[m]; m = 2 * m + ((symbol >> (NB - 1 - k)) & 1); }
   double res = 1.0;
 #pragma unroll
-  for (int k = 0; k < NB; k++) res = res * tbe(pr[k], (symbol >> (NB - 1 - k)) & 1);
+  for (int k = 0; k < NB; k++) res = res * tq(pr[k], (symbol >> (NB - 1 - k)) & 1);
   return res;
 }
-__device__ inline double sim_bit_tree_rev(const uint16_t *prob, int num_bits, uint32_t symbol) {   // :548-563
+__device__ inline double sim_bit_tree_rev_u(const uint16_t *prob, int num_bits, uint32_t symbol) {   // :548-563, num_bits factors (at most 5)
   double res = 1.0; uint32_t m = 1;
-  for (int c = num_bits; c >= 1; c--) { const uint32_t bit = symbol & 1; res = res * tbe(prob[m], bit); m = 2 * m + bit; symbol >>= 1; }
+  for (int c = num_bits; c >= 1; c--) { const uint32_t bit = symbol & 1; res = res * tq(prob[m], bit); m = 2 * m + bit; symbol >>= 1; }
   return res;
 }
 
-__device__ double test_length(bool rep, uint32_t length, uint32_t ps) {              // :483-509
+__device__ double test_length_u(bool rep, uint32_t length, uint32_t ps, int &factors) {              // :483-509
   const LenProbs &pl = rep ? s_P.rep_len : s_P.len;
   uint32_t len = length - 2; double res;
-  if (len < 8) res = tbe(pl.c1, 0) * sim_bit_tree<3>(pl.low[ps], len);
+  if (len < 8) { res = tq(pl.c1, 0) * sim_bit_tree_u<3>(pl.low[ps], len); factors = 4; }
   else {
-    res = tbe(pl.c1, 1); len -= 8;
-    if (len < 8) res = res * tbe(pl.c2, 0) * sim_bit_tree<3>(pl.mid[ps], len);
-    else { res = res * tbe(pl.c2, 1); len -= 8; res = res * sim_bit_tree<8>(pl.high, len); }
+    res = tq(pl.c1, 1); len -= 8;
+    if (len < 8) { res = res * tq(pl.c2, 0) * sim_bit_tree_u<3>(pl.mid[ps], len); factors = 5; }
+    else { res = res * tq(pl.c2, 1); len -= 8; res = res * sim_bit_tree_u<8>(pl.high, len); factors = 10; }
   }
   return res;
 }
 
 __device__ double test_repeat_match(int index_rm, uint32_t length, const MS &sim) {   // :511-538
   const LzProbs &P = s_P;
-  double res = tbe(P.rep[sim.state], 1);
+  // (the switches' and the length's partial products are scaled separately, as the reference forms them: two products, then their product)
+  double res = tq(P.rep[sim.state], 1);
+  int nsw;
   switch (index_rm) {
-    case 0: res = res * tbe(P.g0[sim.state], 0) * tbe(P.rep0_long[sim.state][sim.pos_state], 1); break;
-    case 1: res = res * tbe(P.g0[sim.state], 1) * tbe(P.g1[sim.state], 0); break;
-    case 2: res = res * tbe(P.g0[sim.state], 1) * tbe(P.g1[sim.state], 1) * tbe(P.g2[sim.state], 0); break;
-    default: res = res * tbe(P.g0[sim.state], 1) * tbe(P.g1[sim.state], 1) * tbe(P.g2[sim.state], 1); break;
+    case 0: res = res * tq(P.g0[sim.state], 0) * tq(P.rep0_long[sim.state][sim.pos_state], 1); nsw = 3; break;
+    case 1: res = res * tq(P.g0[sim.state], 1) * tq(P.g1[sim.state], 0); nsw = 3; break;
+    case 2: res = res * tq(P.g0[sim.state], 1) * tq(P.g1[sim.state], 1) * tq(P.g2[sim.state], 0); nsw = 4; break;
+    default: res = res * tq(P.g0[sim.state], 1) * tq(P.g1[sim.state], 1) * tq(P.g2[sim.state], 1); nsw = 4; break;
   }
-  return res * test_length(true, length, sim.pos_state);
+  int nlen;
+  const double tl = test_length_u(true, length, sim.pos_state, nlen);
+  return scale11(res * tl, nsw + nlen);
 }
 
 __device__ double test_simple_match(uint32_t distance, uint32_t length, const MS &sim) {   // :540-601
   const LzProbs &P = s_P;
   const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(distance);
-  double td = sim_bit_tree<6>(P.slot[len_state], ds);
+  double td = sim_bit_tree_u<6>(P.slot[len_state], ds);
+  int ntd = 6;
   if (ds >= 4) {
     const int footer = (int)(ds >> 1) - 1;
     const uint32_t base = (2 | (ds & 1)) << footer, red = distance - base;
-    if (ds < 14) td = td * sim_bit_tree_rev(P.pos + ((int)base - (int)ds - 1) + 1, footer, red);
+    if (ds < 14) { td = td * sim_bit_tree_rev_u(P.pos + ((int)base - (int)ds - 1) + 1, footer, red); ntd += footer; }
     else {
       double h = 1.0;
       for (int i = 0; i < footer - 4; i++) h = h * 0.5;                          // 0.5 ** (footerBits - align_bits), exact
-      td = td * h * sim_bit_tree_rev(P.align, 4, red & 15);
+      td = td * h * sim_bit_tree_rev_u(P.align, 4, red & 15); ntd += 4;
     }
   }
-  return tbe(P.rep[sim.state], 0) * test_length(false, length, sim.pos_state) * td;
+  int nlen;
+  const double tl = test_length_u(false, length, sim.pos_state, nlen);
+  return scale11(tq(P.rep[sim.state], 0) * tl * td, 1 + nlen + ntd);
 }
 
 __device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &sim, double &prob) {   // Simulate_Strict_DL_Code :605-659
@@ -222,14 +245,14 @@ __device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &si
       if (found >= 1) sim.rep[1] = r0;
       if (found >= 2) sim.rep[2] = r1;
       if (found >= 3) sim.rep[3] = r2;
-      sim.state = T_REP[sim.state];
+      sim.state = t_rep(sim.state);
       rep = true;
     }
   }
   if (!rep) {
     prob = prob * dlc * sma;
     sim.rep[3] = sim.rep[2]; sim.rep[2] = sim.rep[1]; sim.rep[1] = sim.rep[0]; sim.rep[0] = dist_ip;
-    sim.state = T_MATCH[sim.state];
+    sim.state = t_match(sim.state);
   }
   sim.pos += (uint64_t)length;
   sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
@@ -245,9 +268,24 @@ __device__ inline double test_strict(uint32_t distance, int length, const MS &si
 __device__ double test_expanded(uint32_t distance, int length, double give_up, const MS &sim) {   // :680-726
   MS v = sim; double p = 1.0;
   const int64_t copy_start = (int64_t)sim.pos - (int64_t)distance;
+  // The copied bytes and the bytes at the last distance (a literal does not change it) are two runs of consecutive bytes: eight of each
+  // per load instead of two dependent byte loads per literal (where eight lie inside the entry; byte by byte at its edges).
+  const int64_t match_start = (int64_t)sim.pos - (int64_t)sim.rep[0] - 1;
+  const uint8_t *in = s_E.in;
+  const int64_t n = (int64_t)s_E.n;
+  unsigned long long wb = 0, wm = 0;
   for (int x = 1; x <= length; x++) {
-    const uint32_t b = TB(copy_start + (x - 1));
-    sim_literal(b, v, p);
+    const int k = (x - 1) & 7;
+    if (k == 0) {
+      const int64_t pb = copy_start + (x - 1), pm = match_start + (x - 1);
+      if (pm >= 0 && pb + 8 <= n && pm + 8 <= n) { __builtin_memcpy(&wb, in + pb, 8); __builtin_memcpy(&wm, in + pm, 8); }
+      else {
+        wb = 0; wm = 0;
+        for (int j = 0; j < 8 && x + j <= length; j++) { wb |= (unsigned long long)TB(pb + j) << (8 * j); wm |= (unsigned long long)TB(pm + j) << (8 * j); }
+      }
+    }
+    const uint32_t b = (uint32_t)(wb >> (8 * k)) & 255u;
+    sim_literal_bm(b, (uint32_t)(wm >> (8 * k)) & 255u, v, p);
     if (p < give_up) break;
     v.prev_byte = b;
   }
@@ -298,7 +336,7 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t dist
       const double head_lit = test_literal_byte(b_head, sim);
       if (head_lit >= 0.875) return W_LIT_DL;                                      // Lit_then_DL_threshold :306
       MS after = sim;
-      after.state = T_LIT[sim.state]; after.pos = sim.pos + 1; after.pos_state = (uint32_t)after.pos & LZ_PBM; after.prev_byte = b_head;
+      after.state = t_lit(sim.state); after.pos = sim.pos + 1; after.pos_state = (uint32_t)after.pos & LZ_PBM; after.prev_byte = b_head;
       const double malus_dtl = fmax0(0.135 - (double)distance * 1.0e-8 - (double)length * 1.0e-4);     // DL_code_then_Literal :869-889
       double dal, dtl;
       if constexpr (PAR) {
@@ -474,7 +512,7 @@ __device__ __noinline__ void emit_literal(uint32_t b) {                   // LZ7
     encode_bit(P.rep[S.state], 1);
     encode_bit(P.g0[S.state], 0);
     encode_bit(P.rep0_long[S.state][S.pos_state], 0);
-    S.state = T_SREP[S.state];
+    S.state = t_srep(S.state);
   } else {
     encode_bit(P.match[S.state][S.pos_state], 0);
     uint16_t *prob = P.lit + idx;
@@ -490,7 +528,7 @@ __device__ __noinline__ void emit_literal(uint32_t b) {                   // LZ7
         offs &= ~(match ^ symb);
       } while (symb < 0x10000);
     }
-    S.state = T_LIT[S.state];
+    S.state = t_lit(S.state);
   }
   S.pos += 1;
   S.pos_state = (uint32_t)S.pos & LZ_PBM;
@@ -514,7 +552,7 @@ __device__ __noinline__ void write_simple_match(uint32_t dist_ip, uint32_t lengt
   LzProbs &P = s_P;
   MS &S = s_E.ES;
   encode_bit(P.rep[S.state], 0);
-  S.state = T_MATCH[S.state];
+  S.state = t_match(S.state);
   encode_length(false, length);
   const uint32_t len_state = length - 2 < 3 ? length - 2 : 3, ds = dist_slot(dist_ip);
   bit_tree_encode(P.slot[len_state], 6, ds);
@@ -549,7 +587,7 @@ __device__ __noinline__ void write_repeat_match(int index_rm, uint32_t length) {
   for (int i = index_rm; i >= 1; i--) S.rep[i] = S.rep[i - 1];
   S.rep[0] = aux;
   encode_length(true, length);
-  S.state = T_REP[S.state];
+  S.state = t_rep(S.state);
 }
 
 __device__ __noinline__ void write_strict(uint32_t distance, int length) {   // Write_Strict_DL_Code :1288-1328
