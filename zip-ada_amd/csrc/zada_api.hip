@@ -1199,16 +1199,18 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
   int rc = lz_grow(c, &c->lz_tab, &c->cap_lz_tab, (sizeof(LzmaJob) + 16 + 4) * (size_t)E + 192);
   if (rc) return rc;
   Bt4Sets sets{nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<uint32_t> weight;                                    // Level_3: what the producer found in each entry
   if (bt4) {
-    if ((rc = bt4_produce(c, jobs, d_in, arena_bytes, &sets))) return rc;
+    if ((rc = bt4_produce(c, jobs, d_in, arena_bytes, &sets, &weight))) return rc;
     c->tmark("lzma:bt4");
   }
   LzmaJob *d_jobs = (LzmaJob *)c->lz_tab;
   uint64_t *d_res = (uint64_t *)((uint8_t *)c->lz_tab + ((sizeof(LzmaJob) * (size_t)E + 63) & ~63ull));
   uint32_t *d_order = (uint32_t *)((uint8_t *)d_res + ((16 * (size_t)E + 63) & ~63ull));
-  std::vector<uint32_t> order(E);                                  // a stream's time goes with its length: the longest first
+  std::vector<uint32_t> order(E);                                  // a stream's time goes with its length -- and, at Level_3, with the matches in it: the heaviest first
   for (uint32_t e = 0; e < E; e++) order[e] = e;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n > jobs[b].n; });
+  if (weight.size() == E) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+  else std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n > jobs[b].n; });
   hipMemcpyAsync(d_jobs, jobs.data(), sizeof(LzmaJob) * (size_t)E, hipMemcpyHostToDevice, c->stream);
   hipMemcpyAsync(d_order, order.data(), 4 * (size_t)E, hipMemcpyHostToDevice, c->stream);
   if (d_apos && (rc = lzma_token_ranges(c, E, d_apos, T, d_ent_start, d_jobs))) return rc;   // token ranges of a batch, found on the device

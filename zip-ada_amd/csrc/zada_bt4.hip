@@ -292,13 +292,26 @@ __global__ void __launch_bounds__(LONGS ? 64 : BT4_LDS_THREADS) k_bt4_walk_lds(c
   }
 }
 
+// How much the coder will have to do for an entry, roughly: the matches the producer found in it (every one is a candidate that
+// Get_Next_Symbol and the estimates look at) on top of its length.  The coder starts the heaviest entries first.
+__global__ void __launch_bounds__(64) k_bt4_weight(const Bt4Job *__restrict__ jobs, const uint8_t *__restrict__ cnt, uint32_t *__restrict__ weight) {
+  const Bt4Job J = jobs[blockIdx.x];
+  uint32_t s = 0;
+  for (uint32_t q = threadIdx.x * 4; q + 4 <= J.n; q += 256) {
+    const uint32_t w = *(const uint32_t *)(cnt + J.in_off + q);       // (entries start at multiples of 64)
+    s += (w & 255u) + ((w >> 8) & 255u) + ((w >> 16) & 255u) + (w >> 24);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (threadIdx.x == 0) weight[blockIdx.x] = s + J.n / 4;
+}
+
 struct Buf {
   void *p = nullptr; size_t cap = 0;
   template <typename T> T *as() const { return (T *)p; }
 };
 struct State {
-  Buf tile_job, jobs, runs, k2, k3, k4, val, ks, vs, tmp, d2, d3, tree, cnt, sl, sd, ol, od, flags, heads, longs, shorts, cnts, scan, small, rec;
-  Buf *all[26] = {&tile_job, &jobs, &runs, &k2, &k3, &k4, &val, &ks, &vs, &tmp, &d2, &d3, &tree, &cnt, &sl, &sd, &ol, &od, &flags, &heads, &longs, &shorts, &cnts, &scan, &small, &rec};
+  Buf tile_job, jobs, runs, k2, k3, k4, val, ks, vs, tmp, d2, d3, tree, cnt, sl, sd, ol, od, flags, heads, longs, shorts, cnts, scan, small, rec, weight;
+  Buf *all[27] = {&tile_job, &jobs, &runs, &k2, &k3, &k4, &val, &ks, &vs, &tmp, &d2, &d3, &tree, &cnt, &sl, &sd, &ol, &od, &flags, &heads, &longs, &shorts, &cnts, &scan, &small, &rec, &weight};
   bool lds_attr = false;
   uint32_t ovf_cap = 0;
 };
@@ -326,7 +339,7 @@ void bt4_destroy(Ctx *c) {
 // The match sets of all Level_3 entries among `jobs` (arena: the device buffer the entries' in_off count from; P = bytes of it that
 // hold entries, every entry at a multiple of 64).  On return `out` points at the sets (device memory owned by the context, valid until
 // the next call).  Returns 0, ZADA_E_NOMEM, ZADA_E_INVALID (a window schedule the producer does not take) or ZADA_E_HIP.
-int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out) {
+int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out, std::vector<uint32_t> *weights) {
   if (!c->bt4) c->bt4 = new State();
   State *B = (State *)c->bt4;
   hipStream_t st = c->stream;
@@ -429,6 +442,13 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
     const uint32_t again[4] = {h[0], h[1], 0, 0};
     hipMemcpyAsync(cnts, again, sizeof again, hipMemcpyHostToDevice, st);
     hipMemsetAsync(B->cnt.p, 0, P, st);
+  }
+  if (weights && jobs.size() > 1) {                                  // (one entry: nothing to order)
+    if ((rc = grow(c, B->weight, 4ull * jobs.size() + 64))) return rc;
+    weights->resize(jobs.size());
+    hipLaunchKernelGGL(k_bt4_weight, dim3((uint32_t)jobs.size()), dim3(64), 0, st, B->jobs.as<Bt4Job>(), B->cnt.as<uint8_t>(), B->weight.as<uint32_t>());
+    hipMemcpyAsync(weights->data(), B->weight.p, 4ull * jobs.size(), hipMemcpyDeviceToHost, st);
+    if (hip_check(c, hipStreamSynchronize(st), "k_bt4_weight")) return ZADA_E_HIP;
   }
   out->cnt = B->cnt.as<uint8_t>(); out->sl = B->sl.as<uint16_t>(); out->sd = B->sd.as<uint32_t>(); out->ol = B->ol.as<uint16_t>(); out->od = B->od.as<uint32_t>();
   return 0;

@@ -309,7 +309,7 @@ struct LzmaJob {
 // The match sets the BT4 producer leaves in HBM (zada_bt4.hip), indexed by arena position p: cnt [p] matches; match i < 7 at slot
 // p * 8 + i of sl (length) / sd (distance); match i >= 7 at slot sd [p * 8 + 7] * 43 + (i - 7) of ol / od.
 struct Bt4Sets { const uint8_t *cnt; const uint16_t *sl; const uint32_t *sd; const uint16_t *ol; const uint32_t *od; };
-int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out);
+int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out, std::vector<uint32_t> *weights = nullptr);
 void bt4_destroy(Ctx *c);
 uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size);
 uint32_t lzma_hash4_size(uint32_t sbs);
