@@ -309,8 +309,9 @@ def test_soak_seed_lzma(encoder, seed):
     za = product()
     rng = np.random.default_rng(seed)
     datas = []
-    for i in range(60):
-        n = int(rng.choice([0, 1, 2, 3, 161, 162, 163, 273, 274, 4096, int(rng.integers(0, 24576)), int(rng.integers(0, 24576)), int(rng.integers(0, 2000))]))
+    for i in range(90):
+        # (16 222 / 16 384 / 16 385: the producer keeps an entry's trees in LDS up to 16 KiB, zada_bt4.hip; 162 / 163: nothing / one position inserted)
+        n = int(rng.choice([0, 1, 2, 3, 161, 162, 163, 164, 273, 274, 4096, 16222, 16383, 16384, 16385, 33000, int(rng.integers(0, 24576)), int(rng.integers(0, 24576)), int(rng.integers(0, 2000))]))
         kind = int(rng.integers(0, 6))
         if kind == 0:
             d = bytes(rng.integers(0, 256, n, dtype=np.uint8))
