@@ -76,7 +76,8 @@ const char *zada_version(void);
  * a stream the match finder takes at a time, multiple of 64), "span_mib" (MiB of a stream one pass takes; longer streams go span after
  * span, default 2048), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
  * batching; "bz_lists", "bz_list_rows", "bz_text_order", "bz_pipeline", "bz_small_wg", "bz_split", "bz_tail_pct": scheduling of the BZip2 stages), "lzma_chunk" (positions of an LZMA stream one launch codes between two feedback calls; 0 = by level, -1 = one launch
- * per stream).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's
+ * per stream), "lzma_pool" (test knob: blocks of the LZMA_3 match sets' overflow pool to start with, 0 = by size; a pool that is too small is
+ * counted and the match producer's walk runs again).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's
  * dictionary_size for LZMA_3 in bytes (0, the default: the entry's size, as Zip.Compress.LZMA_E passes it; lzma_enc.adb uses 32 KiB). */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 

@@ -69,6 +69,28 @@ def test_one_stream_of_four_mib_and_more(encoder):
     assert lzma_decode(z, 4) == d and seen[0] == 0 and seen[-1] == 100 and len(seen) > 60
 
 
+def test_overflow_pool_of_the_match_sets_too_small(encoder):
+    """The producer keeps seven matches of a position next to it and longer sets in blocks of an overflow pool sized by a guess; a pool that
+    is too small is counted, not overrun, and the walk runs again with a pool of the counted size (the trees are rebuilt from nothing).
+    Forced here with a pool of ONE block ("lzma_pool"): same sets, same payloads."""
+    cases = lz_inputs()
+    d = cases["mix_256k"][:150000]
+    small = [cases["mix_256k"][i * 9000:i * 9000 + 8000 + 37 * i] for i in range(20)]
+    want_sets = oracle_bt4_sets(d)
+    assert int((want_sets[0] > 7).sum()) > 50                  # (sets of more than seven matches exist: the pool is needed)
+    before = dict(encoder.last_timing()).get("#bt4_reruns", 0)
+    try:
+        encoder.set_knob("lzma_pool", 1)
+        assert sets_equal(want_sets, encoder.lzma_match_sets(d))
+        assert encoder.lzma(d, 18) == oracle_lzma(d, 18)
+        for e, got in zip(small, encoder.lzma_batch(small, 18)):
+            assert got == oracle_lzma(e, 18)
+    finally:
+        encoder.set_knob("lzma_pool", 0)
+    encoder.lzma(d[:1000], 18)
+    assert dict(encoder.last_timing()).get("#bt4_reruns", 0) >= before + 2     # (the sets and the stream of d; the small entries may have no long set)
+
+
 def test_single_calls_host_and_device_entry(encoder):
     """zada_lzma and zada_lzma_device on the mixed corpus (every variant of a DL code is taken there), all four methods;
     liblzma decodes what the product wrote."""

@@ -51,6 +51,7 @@ void Ctx::tend() {
   // counters (names start with '#'): rounds of the demand loop and of the parse splice
   timing.push_back({"#demand_rounds", (float)demand_rounds});
   timing.push_back({"#splice_rounds", (float)parse_rounds});
+  timing.push_back({"#bt4_reruns", (float)bt4_reruns});
 }
 
 template <typename T>
@@ -914,6 +915,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   // (positions per launch: -1 = the whole stream in one launch, 0 = by level; a launch of fewer than 256 positions is a host round trip
   // per handful of bytes -- the tests go down to 777)
   else if (!strcmp(name, "lzma_chunk")) { if (value < -1 || (value > 0 && value < 256)) return ZADA_E_INVALID; z->c.knob_lzma_chunk = value; }
+  else if (!strcmp(name, "lzma_pool")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_lzma_pool = value; }
   else return ZADA_E_INVALID;
   return ZADA_OK;
 }

@@ -373,7 +373,8 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   uint32_t hb4 = 16;
   while ((1u << hb4) < hmax) hb4++;
   const size_t tmp_bytes = radix_sort_tmp_bytes(P, 4);
-  if (B->ovf_cap < P / 16 + 1024) B->ovf_cap = P / 16 + 1024;
+  if (c->knob_lzma_pool > 0) B->ovf_cap = (uint32_t)c->knob_lzma_pool;        // (test knob: a pool that is too small, to walk twice)
+  else if (B->ovf_cap < P / 16 + 1024) B->ovf_cap = P / 16 + 1024;
   int rc;
   if ((rc = grow(c, B->tile_job, 4ull * (P / 64) + 64)) || (rc = grow(c, B->jobs, sizeof(Bt4Job) * hj.size() + 64)) || (rc = grow(c, B->runs, sizeof(Bt4Run) * hr.size())) ||
       (rc = grow(c, B->k2, 4ull * P)) || (rc = grow(c, B->k3, 4ull * P)) || (rc = grow(c, B->k4, 4ull * P)) || (rc = grow(c, B->val, 4ull * P)) || (rc = grow(c, B->ks, 4ull * P)) ||
@@ -439,6 +440,7 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
     if (h[3] <= B->ovf_cap) break;
     if (attempt == 1) { c->err = "LZMA: overflow pool of the match sets"; return ZADA_E_HIP; }
     B->ovf_cap = h[3] + 1024;                                        // (the trees are rebuilt from nothing: every walk writes its nodes before anyone reads them)
+    c->bt4_reruns++;
     const uint32_t again[4] = {h[0], h[1], 0, 0};
     hipMemcpyAsync(cnts, again, sizeof again, hipMemcpyHostToDevice, st);
     hipMemsetAsync(B->cnt.p, 0, P, st);

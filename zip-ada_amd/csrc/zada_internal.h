@@ -249,6 +249,8 @@ struct Ctx {
   int lzma_launches = 0;                             // launches the last chunked LZMA call took
   void *bt4 = nullptr;                               // ... the BT4 match producer's buffers (zada_bt4.hip), made on first use
   uint32_t bt4_buckets = 0, bt4_long = 0, bt4_overflow = 0;   // last producer run: hash-4 buckets, long ones among them, overflow blocks booked
+  uint32_t bt4_reruns = 0;                           // walks repeated with a larger overflow pool (since the context was made)
+  int knob_lzma_pool = 0;                            // LZMA_3 test knob: blocks of the match sets' overflow pool to start with (0 = by size)
   // timing
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<const char *, hipEvent_t>> marks;
