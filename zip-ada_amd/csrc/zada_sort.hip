@@ -39,12 +39,15 @@ template <typename V>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const uint32_t *__restrict__ keys, const V *__restrict__ vals, uint32_t n, uint32_t shift, uint32_t bits, uint32_t ntiles,
                                                            const uint32_t *__restrict__ starts, uint32_t *__restrict__ keys_out, V *__restrict__ vals_out) {
   __shared__ uint32_t wh[RS_WAVES][RS_MAXRADIX];                    // per wave: keys of each digit seen so far (then: before this wave)
-  __shared__ uint32_t gbase[RS_MAXRADIX];
+  __shared__ uint32_t gbase[RS_MAXRADIX];                           // where the tile's keys of a digit go in the output, minus where they lie in the sorted tile
+  __shared__ uint32_t lbase[RS_MAXRADIX];                           // where they lie in the sorted tile
+  __shared__ uint32_t wsum[RS_WAVES];
+  __shared__ uint16_t perm[RS_TILE];                                // sorted tile: the element's place in the tile as it was read
   const uint32_t radix = 1u << bits, mask = radix - 1;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (uint32_t i = threadIdx.x; i < RS_WAVES * RS_MAXRADIX; i += RS_THREADS) (&wh[0][0])[i] = 0;
   __syncthreads();
-  const uint32_t wbase = blockIdx.x * RS_TILE + w * (RS_ITEMS * 64);
+  const uint32_t tbase = blockIdx.x * RS_TILE, wbase = tbase + w * (RS_ITEMS * 64);
   const uint64_t lt = (1ull << lane) - 1;
   uint32_t key[RS_ITEMS], rank[RS_ITEMS];
 #pragma unroll
@@ -63,22 +66,53 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const uint32_t *__res
     if (valid && (m & lt) == 0) wh[w][d] = before + (uint32_t)__popcll(m);
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) {
-    uint32_t tot = 0;
+  // per digit: the waves' counts become "before this wave"; the tile's count per digit, scanned over the digits = the sorted tile's layout
+  {
+    constexpr int PER = RS_MAXRADIX / RS_THREADS;                    // digits per thread, consecutive
+    uint32_t tot[PER], s = 0;
 #pragma unroll
-    for (int k = 0; k < RS_WAVES; k++) { const uint32_t t = wh[k][d]; wh[k][d] = tot; tot += t; }
-    gbase[d] = starts[(size_t)d * ntiles + blockIdx.x];
+    for (int q = 0; q < PER; q++) {
+      const uint32_t d = threadIdx.x * PER + q;
+      uint32_t t = 0;
+      if (d < radix) {
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) { const uint32_t c = wh[k][d]; wh[k][d] = t; t += c; }
+      }
+      tot[q] = t; s += t;
+    }
+    uint32_t incl = s;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t run = incl - s;
+    for (int k = 0; k < w; k++) run += wsum[k];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const uint32_t d = threadIdx.x * PER + q;
+      if (d < radix) { lbase[d] = run; gbase[d] = starts[(size_t)d * ntiles + blockIdx.x] - run; }
+      run += tot[q];
+    }
   }
   __syncthreads();
+  // the sorted tile in LDS (who goes where), ...
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const uint32_t i = wbase + r * 64 + lane;
     if (i < n) {
       const uint32_t d = (key[r] >> shift) & mask;
-      const uint32_t dst = gbase[d] + wh[w][d] + rank[r];
-      keys_out[dst] = key[r];
-      vals_out[dst] = vals[i];
+      perm[lbase[d] + wh[w][d] + rank[r]] = (uint16_t)(i - tbase);
     }
+  }
+  __syncthreads();
+  // ... then written out in sorted order: the keys of a digit go to consecutive places, so neighbouring lanes store side by side (as
+  // each element went straight from its register to its place, every store was a sector of its own: 14 GB written for 4 GB of pairs)
+  const uint32_t cnt = n - tbase < (uint32_t)RS_TILE ? n - tbase : (uint32_t)RS_TILE;
+  for (uint32_t j = threadIdx.x; j < cnt; j += RS_THREADS) {
+    const uint32_t src = tbase + perm[j];
+    const uint32_t k = keys[src];                                    // (the tile was read a moment ago: L1 / L2)
+    const uint32_t dst = gbase[(k >> shift) & mask] + j;
+    keys_out[dst] = k;
+    vals_out[dst] = vals[src];
   }
 }
 
