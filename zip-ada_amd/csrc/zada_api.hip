@@ -9,6 +9,8 @@
 #include <new>
 #include <atomic>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <thread>
 #include "../../include/zada.h"
 #include "zada_internal.h"
@@ -53,6 +55,65 @@ void Ctx::tend() {
   timing.push_back({"#splice_rounds", (float)parse_rounds});
   timing.push_back({"#bt4_reruns", (float)bt4_reruns});
 }
+
+constexpr int ARR_LANES = 4;                      // copy lanes (= COPY_LANES below: the same staging buffers)
+// An input that arrives while the LZ stage has begun (zada_deflate on host buffers).  The copy lanes of copy_in run in the background,
+// each on a stream of its own; range_lz / lz_shard ask for the bytes they are about to read (arrival_order): the caller waits until
+// the lanes have SENT them, and the stream that will read them waits for the lanes' events.  The first kernel of the LZ stage
+// (k_prev_links, a fifth of the step) works segment by segment, so it runs on what has come while the rest is on the link.
+struct Arrival {
+  Ctx *c; const uint8_t *src; uint8_t *dst; uint64_t n; int T;
+  std::vector<std::thread> th;
+  std::mutex m; std::condition_variable cv;
+  uint64_t sent[ARR_LANES] = {0, 0, 0, 0};                       // pieces a lane has put on its stream
+  bool failed = false;
+  void lane(int t) {
+    hipSetDevice(c->device);
+    uint64_t i = 0;
+    for (uint64_t o = (uint64_t)t * STAGE_BYTES; o < n; o += (uint64_t)T * STAGE_BYTES, i++) {
+      const int b = 2 * t + (int)(i & 1);
+      if (i >= 2) hipEventSynchronize(c->ev_stage[b]);             // the copy that last used this buffer has left it
+      const uint64_t k = n - o < STAGE_BYTES ? n - o : STAGE_BYTES;
+      memcpy(c->stage[b], src + o, k);
+      const bool ok = hipMemcpyAsync(dst + o, c->stage[b], k, hipMemcpyHostToDevice, c->stream_in[t]) == hipSuccess &&
+                      hipEventRecord(c->ev_stage[b], c->stream_in[t]) == hipSuccess;
+      std::lock_guard<std::mutex> g(m);
+      if (!ok || hipEventRecord(c->ev_in[t], c->stream_in[t]) != hipSuccess) failed = true;
+      sent[t]++;
+      cv.notify_all();
+    }
+  }
+  void start() { for (int t = 0; t < T; t++) th.emplace_back([this, t] { lane(t); }); }
+  void join() { for (auto &x : th) if (x.joinable()) x.join(); th.clear(); }
+  ~Arrival() { join(); }
+};
+static bool ensure_arrival_streams(Ctx *c) {
+  for (int t = 0; t < ARR_LANES; t++) {
+    if (c->stream_in[t]) continue;
+    if (hipStreamCreateWithFlags(&c->stream_in[t], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_in[t], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+  }
+  return true;
+}
+// the first `upto` bytes of the arriving input: sent (the caller waits for that) and waited for by `st` (in stream order)
+static int arrival_order(Ctx *c, hipStream_t st, uint64_t upto) {
+  Arrival *A = (Arrival *)c->arrival;
+  if (!A) return 0;
+  if (upto > A->n) upto = A->n;
+  const uint64_t P = (upto + STAGE_BYTES - 1) / STAGE_BYTES;      // pieces that hold them
+  std::unique_lock<std::mutex> g(A->m);
+  for (int t = 0; t < A->T; t++) {
+    const uint64_t want = P > (uint64_t)t ? (P - 1 - t) / A->T + 1 : 0;
+    if (want == 0) continue;
+    A->cv.wait(g, [&] { return A->sent[t] >= want || A->failed; });
+    if (A->failed) { c->err = "host to device copy of the input"; return ZADA_E_HIP; }
+    if (hipStreamWaitEvent(st, c->ev_in[t], 0) != hipSuccess) { c->err = "hipStreamWaitEvent (input arrival)"; return ZADA_E_HIP; }
+  }
+  return 0;
+}
+
 
 template <typename T>
 static int dalloc(Ctx *c, std::vector<void *> &group, T **p, uint64_t count) {
@@ -436,11 +497,15 @@ int range_lz(Ctx *c, const GlobalState *entry, zada_feedback_fn fb, void *user) 
   if (!R.first && entry) cur = *entry;
   R.warm = cur;
   bool known = R.entry_known;
-  // CRC-32 of the range's own bytes, on the second stream (register started from 0: the linear part)
-  hipEventRecord(c->ev_input, st);
-  hipStreamWaitEvent(c->stream2, c->ev_input, 0);
-  int rc = crc_launch(c, R.rin + R.pre, R.n);
-  if (rc) return rc;
+  // CRC-32 of the range's own bytes, on the second stream (register started from 0: the linear part) -- at once when the input is
+  // resident, behind the LZ stage's first kernel when it is still arriving (Arrival: that kernel starts on what has come)
+  Arrival *arr = (Arrival *)c->arrival;
+  int rc = 0;
+  if (!arr) {
+    hipEventRecord(c->ev_input, st);
+    hipStreamWaitEvent(c->stream2, c->ev_input, 0);
+    if ((rc = crc_launch(c, R.rin + R.pre, R.n))) return rc;
+  }
   for (uint64_t s_lo = 0; s_lo < R.n; s_lo += shard) {
     const uint64_t s_hi = s_lo + shard < R.n ? s_lo + shard : R.n;
     const uint32_t H = (R.pre + s_lo > 0) ? SHARD_HALO : 0u;
@@ -451,15 +516,15 @@ int range_lz(Ctx *c, const GlobalState *entry, zada_feedback_fn fb, void *user) 
     const uint64_t gbuf = R.lo + s_lo - H;                      // ... and in the stream
     // (boff is a multiple of 32 KiB and rin 16-byte aligned; the last 16-byte piece may read up to 15 bytes of the resident
     // tail / allocation slack behind the buffer, which the pad kernel below overwrites with zeros)
-    if (nbuf >= (1u << 20) && (R.pre + R.n + R.post) - boff >= ((nbuf + 15) & ~15ull))
+    uint64_t copied = 0;                                        // bytes of the buffer that are in W.in (or on their way, in stream order)
+    if (arr) {}                                                 // (piece by piece, as lz_shard asks for them: job.need below)
+    else if (nbuf >= (1u << 20) && (R.pre + R.n + R.post) - boff >= ((nbuf + 15) & ~15ull))
       hipLaunchKernelGGL(k_copy16, dim3(4096), dim3(256), 0, st, (const uint4 *)(R.rin + boff), (uint4 *)W.in, (nbuf + 15) / 16);
     else hipMemcpyAsync(W.in, R.rin + boff, nbuf, hipMemcpyDeviceToDevice, st);
-    {
-      // zero pad behind the buffer and behind the link planes: one small launch
-      PadArgs pa; pa.in_end = W.in + nbuf; pa.n_in = IN_PAD;
-      for (int l = 0; l < NLEVELS; l++) pa.link_end[l] = W.lprev[l] + (nbuf >= 2 ? nbuf - 2 : 0);
-      hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);
-    }
+    // zero pad behind the buffer and behind the link planes: one small launch
+    PadArgs pa; pa.in_end = W.in + nbuf; pa.n_in = IN_PAD;
+    for (int l = 0; l < NLEVELS; l++) pa.link_end[l] = W.lprev[l] + (nbuf >= 2 ? nbuf - 2 : 0);
+    hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);
     ShardJob job;
     job.nbuf = nbuf; job.tok_lo = H; job.tok_hi = (uint32_t)(H + (s_hi - s_lo));
     job.final = R.last && s_hi == R.n;
@@ -468,6 +533,16 @@ int range_lz(Ctx *c, const GlobalState *entry, zada_feedback_fn fb, void *user) 
     job.dst_atoms = W.ea_atoms + LB_CAP + R.T; job.dst_apos = W.ea_apos + LB_CAP + R.T;
     job.apos_bias = (uint32_t)boff;
     job.cap_atoms = W.cap_atoms - R.T;
+    if (arr) job.need = [&, boff, nbuf, pa](uint64_t upto) -> int {
+      if (upto > nbuf) upto = nbuf;
+      if (upto <= copied) return 0;
+      if (int ra = arrival_order(c, st, boff + upto)) return ra;       // the bytes have been sent and `st` waits for them
+      const uint64_t a = copied & ~15ull, b = upto == nbuf ? nbuf : upto & ~15ull;      // (whole 16-byte pieces; the last one as above)
+      if (b > a) hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(256), 0, st, (const uint4 *)(R.rin + boff + a), (uint4 *)(W.in + a), (b - a + 15) / 16);
+      if (b == nbuf && (nbuf & 15)) hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);      // (the last 16-byte piece wrote up to 15 bytes behind the buffer: zeros again)
+      copied = b;
+      return 0;
+    };
     ShardResult res;
     rc = lz_shard(c, R.level, job, &res);
     if (rc) return rc == -2 ? ZADA_E_NOMEM : rc;
@@ -478,6 +553,9 @@ int range_lz(Ctx *c, const GlobalState *entry, zada_feedback_fn fb, void *user) 
     if (fb && fb(5 + (int)(65 * s_hi / R.n), user)) return ZADA_ABORTED;
   }
   R.exit = cur;
+  if (arr) {                                                    // (every byte has been asked for by now: the shards' last need)
+    if ((rc = arrival_order(c, c->stream2, R.pre + R.n)) || (rc = crc_launch(c, R.rin + R.pre, R.n))) return rc;
+  }
   uint32_t raw = 0;
   rc = crc_finish(c, R.n, &raw);
   if (rc) return rc;
@@ -857,6 +935,7 @@ static void ctx_release(zada_ctx *z) {
   if (z->c.stream2) hipStreamDestroy(z->c.stream2);
   if (z->c.crc_host) hipHostFree(z->c.crc_host);
   for (int b = 0; b < 8; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
+  for (int t = 0; t < 4; t++) { if (z->c.stream_in[t]) hipStreamDestroy(z->c.stream_in[t]); if (z->c.ev_in[t]) hipEventDestroy(z->c.ev_in[t]); }
   if (z->c.bstage) hipHostFree(z->c.bstage);
   if (z->c.btab) hipHostFree(z->c.btab);
   if (z->c.ev_input) hipEventDestroy(z->c.ev_input);
@@ -927,6 +1006,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
 // takes 55 GB/s: large copies go over COPY_LANES lanes, a host thread and two staging buffers each, taking every fourth piece
 // (the pieces go to their own places, so their order on the stream does not matter).
 constexpr int COPY_LANES = 4;
+static_assert(COPY_LANES == ARR_LANES, "the arriving input's lanes use the staging buffers of copy_in's");
 constexpr uint64_t COPY_MT_MIN = 64ull << 20;
 static bool ensure_staging(Ctx *c, int lanes) {
   for (int b = 0; b < 2 * lanes; b++) {
@@ -1023,9 +1103,21 @@ int zada_deflate(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t
   }
   rc = ensure_rin(c, n);
   if (rc) return rc;
-  copy_in(c, c->ws.rin_own, in, n);
   uint64_t ol = 0;
-  rc = finish_call(c, deflate_core(c, method, c->ws.rin_own, n, &ol, crc_inout, fb, user));
+  if (n >= COPY_MT_MIN && method != ZADA_DEFLATE_0 && ensure_staging(c, COPY_LANES) && ensure_arrival_streams(c)) {
+    // the input goes to the device while the LZ stage's first kernel already works on what has come
+    hipStreamSynchronize(c->stream);                                 // (the staging buffers and rin_own: nothing of an earlier call is in flight)
+    Arrival A; A.c = c; A.src = in; A.dst = c->ws.rin_own; A.n = n; A.T = ARR_LANES;
+    c->arrival = &A;
+    A.start();
+    rc = finish_call(c, deflate_core(c, method, c->ws.rin_own, n, &ol, crc_inout, fb, user));
+    A.join();
+    c->arrival = nullptr;
+    for (int t = 0; t < ARR_LANES; t++) hipStreamSynchronize(c->stream_in[t]);
+  } else {
+    copy_in(c, c->ws.rin_own, in, n);
+    rc = finish_call(c, deflate_core(c, method, c->ws.rin_own, n, &ol, crc_inout, fb, user));
+  }
   if (rc < 0 || rc == ZADA_ABORTED) return rc;
   if (out_len) *out_len = ol;
   if (rc == ZADA_OK) {

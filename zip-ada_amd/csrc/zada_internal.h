@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <functional>
 #include <vector>
 #include "zada_logic.h"
 
@@ -231,6 +232,9 @@ constexpr uint64_t STAGE_BYTES = 8ull << 20;
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: CRC-32, next to the LZ stage
+  hipStream_t stream_in[4] = {};                     // the copy lanes of an input that arrives while the LZ stage has begun (zada_deflate)
+  hipEvent_t ev_in[4] = {};                          // ... how far each lane has come
+  void *arrival = nullptr;                           // ... the copy in flight (Arrival, zada_api.hip), null when the input is resident
   hipEvent_t ev_input = nullptr, ev_out = nullptr, ev_dlim = nullptr;
   CrcPending crc;
   uint32_t *crc_host = nullptr;                     // pinned: [CRC_HOST_TOP] top-level values, then 4 x 16 leftovers
@@ -336,6 +340,9 @@ struct ShardJob {
   uint32_t apos_bias = 0;             // added to buffer positions: offset of the buffer in the range's input
   uint64_t cap_atoms = 0;             // room at dst
   const uint32_t *segend = nullptr;   // a batch of entries in the buffer (Layout); then tok_lo = 0, final, entry at 0
+  // need (x): the first x bytes of W.in are to be valid before whatever is enqueued next on the context's stream runs (null: all of
+  // them are).  The host-buffer entry point's input arrives piece by piece while the first kernel already works on what has come.
+  std::function<int(uint64_t)> need;
 };
 struct ShardResult { uint32_t ntok = 0; ExitState exit{0, SYNC_F}, warm{0, SYNC_F}; };
 int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res);

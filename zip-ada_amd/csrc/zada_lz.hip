@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
                                                      DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg, uint32_t *__restrict__ segmax,
-                                                     uint16_t *__restrict__ heavy) {
+                                                     uint16_t *__restrict__ heavy, uint32_t seg0) {
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
 #define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint32_t *AB = (uint32_t *)smem;                // A and B as one array of 32 768 words (the sorts)
   uint32_t *cnt = (uint32_t *)(B + 32768);        // 16 KiB
   uint32_t *wsum = cnt + 4096;                    // 64 B
-  const uint64_t seg = blockIdx.x, base = seg * 32768ull;
+  const uint64_t seg = (uint64_t)blockIdx.x + seg0, base = seg * 32768ull;      // (seg0: the launch covers the segments of one piece of the input)
   const uint32_t m = lay_inserted(L, seg);
   const bool first_seg = lay_first(L, seg);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1741,6 +1741,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   const uint64_t n = job.nbuf;
   res->ntok = 0; res->exit = ExitState{(uint32_t)n, SYNC_F}; res->warm = ExitState{job.tok_lo, SYNC_F};
   if (n == 0) return 0;
+  if (job.need && (level == 0 || n < 32768 + 2)) { if (int rn = job.need(n)) return rn; }      // (no segments to go by: everything first)
   if (level == 0 && job.segend) {                  // a batch: the chunks' byte counts stand for their token counts (zada_api.hip, batch_core)
     const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
     const Layout L{job.segend, n};
@@ -1789,8 +1790,22 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     hipMemsetAsync(W.dlim, 0xFF, (size_t)n * 4, c->stream2);
     hipEventRecord(c->ev_dlim, c->stream2);
 #endif
+    if (job.need) {
+      // the input is still arriving (host buffers): the segments of what has come, 64 MiB at a time -- a segment's workgroup reads
+      // its 32 KiB and at most 31 bytes behind them, so a piece holds back its last segment until the next piece is there
+      constexpr uint32_t PIECE = 2048;
+      for (uint32_t s0 = 0; s0 < nseg;) {
+        const uint32_t s1 = s0 + PIECE < nseg ? s0 + PIECE : nseg;
+        const uint64_t upto = (uint64_t)s1 * 32768 + 64 < n ? (uint64_t)s1 * 32768 + 64 : n;
+        if (int rn = job.need(upto)) return rn;
+        hipLaunchKernelGGL(k_prev_links, dim3(s1 - s0), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
+                           W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0);
+        s0 = s1;
+      }
+      if (int rn = job.need(n)) return rn;
+    } else
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
-                       W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy);
+                       W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, 0u);
 #ifndef ZADA_OLD_INIT
     hipStreamWaitEvent(st, c->ev_dlim, 0);
 #endif
