@@ -56,7 +56,10 @@ void Ctx::tend() {
   timing.push_back({"#bt4_reruns", (float)bt4_reruns});
 }
 
-constexpr int ARR_LANES = 4;                      // copy lanes (= COPY_LANES below: the same staging buffers)
+#ifndef ZADA_COPY_LANES
+#define ZADA_COPY_LANES 4
+#endif
+constexpr int ARR_LANES = ZADA_COPY_LANES;                      // copy lanes (= COPY_LANES below: the same staging buffers)
 // An input that arrives while the LZ stage has begun (zada_deflate on host buffers).  The copy lanes of copy_in run in the background,
 // each on a stream of its own; range_lz / lz_shard ask for the bytes they are about to read (arrival_order): the caller waits until
 // the lanes have SENT them, and the stream that will read them waits for the lanes' events.  The first kernel of the LZ stage
@@ -65,7 +68,7 @@ struct Arrival {
   Ctx *c; const uint8_t *src; uint8_t *dst; uint64_t n; int T;
   std::vector<std::thread> th;
   std::mutex m; std::condition_variable cv;
-  uint64_t sent[ARR_LANES] = {0, 0, 0, 0};                       // pieces a lane has put on its stream
+  uint64_t sent[ARR_LANES] = {};                       // pieces a lane has put on its stream
   bool failed = false;
   void lane(int t) {
     hipSetDevice(c->device);
@@ -934,8 +937,8 @@ static void ctx_release(zada_ctx *z) {
   for (hipEvent_t e : z->c.ev_pool) hipEventDestroy(e);
   if (z->c.stream2) hipStreamDestroy(z->c.stream2);
   if (z->c.crc_host) hipHostFree(z->c.crc_host);
-  for (int b = 0; b < 8; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
-  for (int t = 0; t < 4; t++) { if (z->c.stream_in[t]) hipStreamDestroy(z->c.stream_in[t]); if (z->c.ev_in[t]) hipEventDestroy(z->c.ev_in[t]); }
+  for (int b = 0; b < 2 * MAX_COPY_LANES; b++) { if (z->c.stage[b]) hipHostFree(z->c.stage[b]); if (z->c.ev_stage[b]) hipEventDestroy(z->c.ev_stage[b]); }
+  for (int t = 0; t < MAX_COPY_LANES; t++) { if (z->c.stream_in[t]) hipStreamDestroy(z->c.stream_in[t]); if (z->c.ev_in[t]) hipEventDestroy(z->c.ev_in[t]); }
   if (z->c.bstage) hipHostFree(z->c.bstage);
   if (z->c.btab) hipHostFree(z->c.btab);
   if (z->c.ev_input) hipEventDestroy(z->c.ev_input);
@@ -1005,7 +1008,8 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
 // Host buffers travel through pinned staging buffers, 8 MiB at a time.  One thread moves ~12-25 GB/s through memcpy, the link
 // takes 55 GB/s: large copies go over COPY_LANES lanes, a host thread and two staging buffers each, taking every fourth piece
 // (the pieces go to their own places, so their order on the stream does not matter).
-constexpr int COPY_LANES = 4;
+constexpr int COPY_LANES = ZADA_COPY_LANES;
+static_assert(COPY_LANES <= MAX_COPY_LANES, "staging buffers");
 static_assert(COPY_LANES == ARR_LANES, "the arriving input's lanes use the staging buffers of copy_in's");
 constexpr uint64_t COPY_MT_MIN = 64ull << 20;
 static bool ensure_staging(Ctx *c, int lanes) {
@@ -1069,7 +1073,7 @@ static int copy_out(Ctx *c, uint8_t *dst, const void *d_src, uint64_t n) {
     return hip_check(c, hipStreamSynchronize(c->stream), "copy out");
   }
   // (the staging buffers are free: every copy_in of this call was consumed before the kernels ran)
-  int rcs[COPY_LANES] = {0, 0, 0, 0};
+  int rcs[COPY_LANES] = {};
   std::vector<std::thread> th;
   for (int t = 1; t < T; t++) th.emplace_back([=, &rcs] { hipSetDevice(c->device); rcs[t] = copy_out_lane(c, dst, d_src, n, t, T); });
   rcs[0] = copy_out_lane(c, dst, d_src, n, 0, T);

@@ -229,19 +229,20 @@ constexpr uint32_t CRC_HOST_TOP = 4096;           // top-level CRC values per ca
 struct CrcPending { uint32_t nsub = 0, nfull0 = 0, cnt[4] = {0, 0, 0, 0}, nrest[4] = {0, 0, 0, 0}; };
 
 constexpr uint64_t STAGE_BYTES = 8ull << 20;
+constexpr int MAX_COPY_LANES = 8;
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: CRC-32, next to the LZ stage
-  hipStream_t stream_in[4] = {};                     // the copy lanes of an input that arrives while the LZ stage has begun (zada_deflate)
-  hipEvent_t ev_in[4] = {};                          // ... how far each lane has come
+  hipStream_t stream_in[MAX_COPY_LANES] = {};                     // the copy lanes of an input that arrives while the LZ stage has begun (zada_deflate)
+  hipEvent_t ev_in[MAX_COPY_LANES] = {};                          // ... how far each lane has come
   void *arrival = nullptr;                           // ... the copy in flight (Arrival, zada_api.hip), null when the input is resident
   hipEvent_t ev_input = nullptr, ev_out = nullptr, ev_dlim = nullptr;
   CrcPending crc;
   uint32_t *crc_host = nullptr;                     // pinned: [CRC_HOST_TOP] top-level values, then 4 x 16 leftovers
-  uint8_t *stage[8] = {};                            // pinned staging buffers of the host-buffer entry points: four copy lanes x two (copy_in / copy_out)
+  uint8_t *stage[2 * MAX_COPY_LANES] = {};           // pinned staging buffers of the host-buffer entry points: two per copy lane (copy_in / copy_out)
   uint8_t *bstage = nullptr; uint64_t cap_bstage = 0; // pinned: a batch's packed input, then its output
   uint32_t *btab = nullptr; uint64_t cap_btab = 0;    // pinned: a batch's tables on their way to / from the device
-  hipEvent_t ev_stage[8] = {};
+  hipEvent_t ev_stage[2 * MAX_COPY_LANES] = {};
   Workspace ws;
   Range rg;                                          // the range in flight
   std::string err;
