@@ -162,7 +162,9 @@ extern "C" void hc_llhc_pm(const uint32_t *freq, int n, int max_bits, uint8_t *b
 // three stable sorts (hash2 / hash3 predecessors, hash-4 buckets), then every bucket on its own -- in a SHUFFLED order of the buckets
 // (seed), to show that the buckets do not depend on each other.  Same outputs as the oracle's zo_bt4_match_sets.  Returns 0, or -1 when
 // the schedule is refused.
-extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride, uint32_t seed) {
+// seg_shift < 32: the stream in segments of 2 ** seg_shift positions, as one stream coded in launches takes it (bt4_walk_segment): the buckets
+// of a segment in a shuffled order, the segments one after the other, a bucket's root handed on through a table indexed by the hash-4 key.
+static int bt4_sets_impl(const uint8_t *in, uint64_t n, int64_t dict, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride, uint32_t seed, uint32_t seg_shift) {
   const uint32_t sbs = bt4_string_buffer_size((uint64_t)dict), mask = bt4_hash4_size(sbs) - 1;
   const int32_t max_dist = (int32_t)sbs - (BT4_LOOK + 2);
   std::vector<Bt4Run> runs;
@@ -188,17 +190,25 @@ extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t 
   preds(h2, o2); preds(h3, o3);
   std::iota(idx.begin(), idx.end(), 0u);
   std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return h4[x] < h4[y]; });
+  auto seg_of = [&](uint32_t k) { return seg_shift < 32 ? pos[k] >> seg_shift : 0u; };
+  if (seg_shift < 32) std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return seg_of(x) < seg_of(y); });
   std::vector<std::pair<size_t, size_t>> buckets;
-  for (size_t i = 0; i < m;) { size_t j = i + 1; while (j < m && h4[idx[j]] == h4[idx[i]]) j++; buckets.push_back({i, j}); i = j; }
+  for (size_t i = 0; i < m;) { size_t j = i + 1; while (j < m && h4[idx[j]] == h4[idx[i]] && seg_of(idx[j]) == seg_of(idx[i])) j++; buckets.push_back({i, j}); i = j; }
   uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
-  for (size_t i = buckets.size(); i > 1; i--) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(buckets[i - 1], buckets[x % i]); }
+  for (size_t s0 = 0; s0 < buckets.size();) {                          // shuffled within a segment
+    size_t s1 = s0 + 1;
+    while (s1 < buckets.size() && seg_of(idx[buckets[s1].first]) == seg_of(idx[buckets[s0].first])) s1++;
+    for (size_t i = s1 - s0; i > 1; i--) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(buckets[s0 + i - 1], buckets[s0 + x % i]); }
+    s0 = s1;
+  }
+  std::vector<int32_t> htab(seg_shift < 32 ? (size_t)mask + 1 : 0, BT4_NONE);
   std::vector<int32_t> tree(2 * n + 2, 12345);       // (never read before written: a walk only reaches nodes of its own bucket)
   std::vector<uint16_t> tree16(2 * n + 2, 12345);    // the LDS form of the nodes (k_bt4_walk_lds) for entries it would take
   const bool small = n <= BT4_LDS_N && runs.size() <= 2;
   uint16_t ml[BT4_SET]; uint32_t md[BT4_SET];
   auto ext = [](const uint8_t *b, int64_t a, int64_t c, int l, int lim) { return bt4_extend(b, a, c, l, lim); };
   for (auto &bk : buckets) {
-    int32_t root = BT4_NONE;
+    int32_t root = htab.empty() ? BT4_NONE : htab[h4[idx[bk.first]]];
     for (size_t i = bk.first; i < bk.second; i++) {
       const uint32_t q = pos[idx[i]];
       const Bt4Run *r = bt4_run_of(runs.data(), (uint32_t)runs.size(), q);
@@ -215,8 +225,15 @@ extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t 
       for (int k = 0; k < c; k++) { len[(uint64_t)q * stride + k] = ml[k]; dist[(uint64_t)q * stride + k] = md[k]; }
       root = ordp;
     }
+    if (!htab.empty()) htab[h4[idx[bk.first]]] = root;
   }
   return 0;
+}
+extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride, uint32_t seed) {
+  return bt4_sets_impl(in, n, dict, cnt, len, dist, stride, seed, 32);
+}
+extern "C" int hc_bt4_sets_segments(const uint8_t *in, uint64_t n, int64_t dict, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride, uint32_t seed, uint32_t seg_shift) {
+  return bt4_sets_impl(in, n, dict, cnt, len, dist, stride, seed, seg_shift);
 }
 
 // Analysis helper (not a test): steps of bt4_step per hash-4 bucket -- the longest sum is the producer's critical path.

@@ -8,11 +8,12 @@ from _common import hostcheck
 from _lzmah import BT4_SET, lz_inputs, oracle_bt4_sets, sets_equal
 
 
-def producer_sets(data, dictionary_size=None, seed=1):
+def producer_sets(data, dictionary_size=None, seed=1, seg_shift=None):
     H = hostcheck()
     n = len(data)
     cnt = np.zeros(n, np.uint8); ln = np.zeros((n, BT4_SET), np.uint16); ds = np.zeros((n, BT4_SET), np.uint32)
-    rc = H.hc_bt4_sets(bytes(data), n, n if dictionary_size is None else dictionary_size, cnt.ctypes.data, ln.ctypes.data, ds.ctypes.data, BT4_SET, seed)
+    args = (bytes(data), n, n if dictionary_size is None else dictionary_size, cnt.ctypes.data, ln.ctypes.data, ds.ctypes.data, BT4_SET, seed)
+    rc = H.hc_bt4_sets(*args) if seg_shift is None else H.hc_bt4_sets_segments(*args, seg_shift)
     assert rc == 0, rc
     return cnt, ln, ds
 
@@ -30,6 +31,19 @@ def test_producer_sets_equal_the_sequential_matcher(dictionary_size):
         assert sets_equal(a, b), (name, len(d), dictionary_size)
         seen += 1
     assert seen >= 5
+
+
+@pytest.mark.parametrize("seg_shift", [10, 13, 16])
+def test_producer_in_segments(seg_shift):
+    """One stream coded in launches takes the producer segment by segment (zada_api.hip lzma_run; k_bt4_walk's `htab`): the buckets of a
+    segment do not depend on each other, a bucket's root comes from the segments before through a table by hash-4 key."""
+    for name, d in lz_inputs().items():
+        for dictionary_size in (None, 5000):
+            if dictionary_size and dictionary_size >= len(d):
+                continue
+            a = oracle_bt4_sets(d, dictionary_size)
+            b = producer_sets(d, dictionary_size, seed=7 + len(d), seg_shift=seg_shift)
+            assert sets_equal(a, b), (name, len(d), dictionary_size)
 
 
 def test_sets_are_bounded_and_increasing():

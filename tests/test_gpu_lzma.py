@@ -69,6 +69,54 @@ def test_one_stream_of_four_mib_and_more(encoder):
     assert lzma_decode(z, 4) == d and seen[0] == 0 and seen[-1] == 100 and len(seen) > 60
 
 
+def test_one_stream_with_the_producer_in_segments(encoder):
+    """ONE LZMA_3 stream coded in launches takes its match sets segment by segment ("lzma_segment": 2 ** k positions; by default 2 ** 20 for
+    streams of two segments and more): the walks of segment k + 1 run beside the coder of segment k, a bucket's root travelling from segment to
+    segment through a table like the reference's hash4Table (lz77.adb:1247-1251).  The stage: the sets of every position == the sequential
+    matcher's, for segments of 8 Ki .. 64 Ki positions, the entry's size as the dictionary and smaller ones (window moves inside segments).
+    The stream: payload == the oracle's with segments smaller than, equal to and larger than a launch; an abort leaves the context usable; a pool
+    that is too small for the segments sends the stream back to the unsegmented way (same payload, one more rerun counted)."""
+    Z = product()
+    cases = lz_inputs()
+    d = cases["mix_256k"][:200000]
+    rep = (cases["mix_256k"][:30000] * 6)[:170001]                # long buckets that span segments
+    try:
+        for data, ds in ((d, 0), (d, 20000), (rep, 0), (rep, 5000), (d[:70000], 3000)):
+            encoder.set_knob("lzma_dict", ds)
+            want = oracle_bt4_sets(data, ds or None)
+            for seg in (13, 16):
+                encoder.set_knob("lzma_segment", seg)
+                assert sets_equal(want, encoder.lzma_match_sets(data)), (len(data), ds, seg)
+        encoder.set_knob("lzma_dict", 0)
+        want = oracle_lzma(d, 18)
+        for seg, chunk in ((13, 20000), (14, 16384), (15, 5000), (16, 0)):
+            encoder.set_knob("lzma_segment", seg)
+            encoder.set_knob("lzma_chunk", chunk)
+            assert encoder.lzma(d, 18) == want, (seg, chunk)
+        assert dict(encoder.last_timing()).get("#lzma_launches", 0) >= 4
+        encoder.set_knob("lzma_dict", 10000)
+        encoder.set_knob("lzma_segment", 14)
+        z, _ = oracle_lzma_encode(rep, 3, dictionary_size=10000)
+        assert encoder.lzma(rep, 18)[1] == bytes([16, 2, 5, 0]) + z
+        encoder.set_knob("lzma_dict", 0)
+        with pytest.raises(Z.UserAbort):
+            encoder.lzma(d, 18, feedback=lambda pct: pct >= 30)
+        assert encoder.lzma(d[:50000], 18) == oracle_lzma(d[:50000], 18)
+        before = dict(encoder.last_timing()).get("#bt4_reruns", 0)
+        encoder.set_knob("lzma_pool", 1)
+        assert encoder.lzma(d, 18) == want
+        assert dict(encoder.last_timing()).get("#bt4_reruns", 0) >= before + 2    # (out of the segments, then the unsegmented producer's own)
+    finally:
+        for k in ("lzma_dict", "lzma_chunk", "lzma_segment", "lzma_pool"):
+            encoder.set_knob(k, 0)
+    # without segments: the same stream
+    try:
+        encoder.set_knob("lzma_segment", -1)
+        assert encoder.lzma(d, 18) == want
+    finally:
+        encoder.set_knob("lzma_segment", 0)
+
+
 def test_overflow_pool_of_the_match_sets_too_small(encoder):
     """The producer keeps seven matches of a position next to it and longer sets in blocks of an overflow pool sized by a guess; a pool that
     is too small is counted, not overrun, and the walk runs again with a pool of the counted size (the trees are rebuilt from nothing).

@@ -54,6 +54,7 @@ void Ctx::tend() {
   timing.push_back({"#demand_rounds", (float)demand_rounds});
   timing.push_back({"#splice_rounds", (float)parse_rounds});
   timing.push_back({"#bt4_reruns", (float)bt4_reruns});
+  timing.push_back({"#lzma_launches", (float)lzma_launches});
 }
 
 #ifndef ZADA_COPY_LANES
@@ -998,6 +999,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   // per handful of bytes -- the tests go down to 777)
   else if (!strcmp(name, "lzma_chunk")) { if (value < -1 || (value > 0 && value < 256)) return ZADA_E_INVALID; z->c.knob_lzma_chunk = value; }
   else if (!strcmp(name, "lzma_pool")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_lzma_pool = value; }
+  else if (!strcmp(name, "lzma_segment")) { if (value < -1 || (value > 0 && (value < 13 || value > 30))) return ZADA_E_INVALID; z->c.knob_lzma_segment = value; }
   else return ZADA_E_INVALID;
   return ZADA_OK;
 }
@@ -1279,6 +1281,13 @@ static void lzma_free(Ctx *c) {
   c->lz_tab = c->lz_save = nullptr; c->cap_lz_tab = c->cap_lz_save = 0;
   bt4_destroy(c);
 }
+// One LZMA_3 stream in launches (budget > 0): log2 of the positions per segment of the BT4 producer, 32 = no segments.  The match sets of
+// segment k + 1 are found (stream2) while the coder -- one wave -- codes segment k: of all the producer's time, only segment 0's is waited for.
+static uint32_t lzma_segment_shift(const Ctx *c, uint64_t n) {
+  if (c->knob_lzma_segment < 0) return 32;
+  const uint32_t sh = c->knob_lzma_segment > 0 ? (uint32_t)c->knob_lzma_segment : 20;
+  return n >= (2ull << sh) ? sh : 32;                                // (fewer than two segments: nothing to overlap)
+}
 // jobs: sbs / hash4_size are filled here.  res: 2 per job (stream bytes, input bytes coded).  arena_bytes: the bytes at d_in that hold
 // the entries (Level_3: the BT4 producer of zada_bt4.hip writes the match sets of all entries before the coder starts).
 // budget > 0: launches of `budget` positions per stream (the coder's state waits in HBM in between, zada_lzma.hip "A stream in several
@@ -1298,8 +1307,9 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
   if (rc) return rc;
   Bt4Sets sets{nullptr, nullptr, nullptr, nullptr, nullptr};
   std::vector<uint32_t> weight;                                    // Level_3: what the producer found in each entry
+  uint32_t seg_shift = bt4 && E == 1 && budget > 0 && jobs[0].in_off == 0 ? lzma_segment_shift(c, jobs[0].n) : 32, nseg = 0;
   if (bt4) {
-    if ((rc = bt4_produce(c, jobs, d_in, arena_bytes, &sets, &weight))) return rc;
+    if ((rc = bt4_produce(c, jobs, d_in, arena_bytes, &sets, &weight, seg_shift, &nseg))) return rc;
     c->tmark("lzma:bt4");
   }
   LzmaJob *d_jobs = (LzmaJob *)c->lz_tab;
@@ -1324,16 +1334,47 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
     uint64_t total = 0;
     for (const LzmaJob &j : jobs) total += j.n;
     c->lzma_launches = 0;
+    // (segments: the coder stops LZ_SEG_MARGIN positions short of a segment whose sets are still being written -- a step of its loop looks at
+    // the sets of fewer than 2 x 273 positions beyond the one it codes)
+    constexpr uint64_t LZ_SEG_MARGIN = 4096;
+    uint32_t k = 0;                                                  // segments whose sets are there
+    uint64_t cap = ~0ull;
+    if (seg_shift < 32 && (rc = bt4_walk_segment(c, 0, c->stream2))) return rc;
     for (;;) {
-      if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, sets, d_res, (uint8_t *)c->lz_save, budget))) return rc;
-      c->lzma_launches++;
-      hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
-      if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
-      bool more = false;
-      uint64_t coded = 0;
-      for (uint32_t e = 0; e < E; e++) { more = more || (res[2 * e + 1] >> 63); res[2 * e + 1] &= ~(1ull << 63); coded += res[2 * e + 1]; }
-      if (!more) break;
-      if (fb && fb(pct_lo + (int)((uint64_t)(pct_hi - pct_lo) * coded / (total ? total : 1)), user)) return ZADA_ABORTED;
+      if (seg_shift < 32 && k < nseg && (k == 0 || cap != ~0ull)) {
+        // segment k's sets are complete when stream2 is idle; the next segment's walks start before the coder goes on
+        const int ov = bt4_segments_overflowed(c, c->stream2);
+        if (ov < 0) return ov;
+        if (ov) {                                                    // the pool was too small: the whole stream again, the producer first (it grows the pool itself)
+          hipStreamSynchronize(c->stream);
+          c->bt4_reruns++;
+          seg_shift = 32; cap = ~0ull;
+          if ((rc = bt4_produce(c, jobs, d_in, arena_bytes, &sets, nullptr))) return rc;
+          hipMemsetAsync(c->lz_save, 0, save_bytes, c->stream);
+        } else {
+          k++;
+          if (k < nseg && (rc = bt4_walk_segment(c, k, c->stream2))) return rc;
+          cap = k < nseg ? ((uint64_t)k << seg_shift) - LZ_SEG_MARGIN : ~0ull;
+        }
+      }
+      uint64_t pos = 0;
+      for (;;) {                                                     // the launches up to `cap`
+        if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, sets, d_res, (uint8_t *)c->lz_save, budget, cap))) return rc;
+        c->lzma_launches++;
+        hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
+        if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
+        bool more = false;
+        uint64_t coded = 0;
+        for (uint32_t e = 0; e < E; e++) { more = more || (res[2 * e + 1] >> 63); res[2 * e + 1] &= ~(1ull << 63); coded += res[2 * e + 1]; }
+        pos = more ? coded : ~0ull;
+        if (!more) break;
+        if (fb && fb(pct_lo + (int)((uint64_t)(pct_hi - pct_lo) * coded / (total ? total : 1)), user)) {
+          if (seg_shift < 32) hipStreamSynchronize(c->stream2);      // (walks under way write into the context's buffers)
+          return ZADA_ABORTED;
+        }
+        if (coded >= cap) break;
+      }
+      if (pos == ~0ull) break;
     }
   }
   for (uint32_t e = 0; e < E; e++) if (res[2 * e + 1] != jobs[e].n) { c->err = "LZMA: the coder did not consume the entry"; return ZADA_E_HIP; }
@@ -1435,7 +1476,12 @@ int zada_lzma_match_sets(zada_ctx *z, const uint8_t *in, uint64_t n, uint8_t *cn
   J.sbs = lzma_string_buffer_size(3, c->knob_lzma_dict > 0 ? (uint64_t)c->knob_lzma_dict : n);
   J.hash4_size = lzma_hash4_size(J.sbs);
   Bt4Sets S;
-  if ((rc = finish_call(c, bt4_produce(c, jobs, c->ws.rin_own, n, &S)))) return rc;
+  const uint32_t seg_shift = lzma_segment_shift(c, n);                // (segments as a stream in launches takes them, one after the other)
+  uint32_t nseg = 0;
+  rc = bt4_produce(c, jobs, c->ws.rin_own, n, &S, nullptr, seg_shift, &nseg);
+  for (uint32_t k = 0; !rc && k < nseg; k++) rc = bt4_walk_segment(c, k, c->stream);
+  if (!rc && nseg) { const int ov = bt4_segments_overflowed(c, c->stream); if (ov) { if (ov > 0) c->err = "match sets: the overflow pool is too small for segments"; rc = ov < 0 ? ov : ZADA_E_NOMEM; } }
+  if ((rc = finish_call(c, rc))) return rc;
   std::vector<uint16_t> sl(n * BT4_INLINE); std::vector<uint32_t> sd(n * BT4_INLINE);
   const uint64_t nov = c->bt4_overflow;
   std::vector<uint16_t> ol(nov * BT4_OVF + 1); std::vector<uint32_t> od(nov * BT4_OVF + 1);

@@ -79,36 +79,37 @@ __global__ void __launch_bounds__(256) k_bt4_pred(const uint32_t *__restrict__ k
 }
 
 // after the hash-4 sort: the key of the second sort = the position's entry ("not inserted" behind all entries)
-__global__ void __launch_bounds__(256) k_bt4_jobkeys(uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T, uint32_t E) {
+// (seg_shift < 32: ONE entry at the start of the arena, walked in segments of 2 ** seg_shift positions -- the key is the segment)
+__global__ void __launch_bounds__(256) k_bt4_jobkeys(uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T, uint32_t E, uint32_t seg_shift) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
-  keys[i] = (keys[i] & flag) ? E : T.tile_job[vals[i] >> 6];
+  keys[i] = (keys[i] & flag) ? E : seg_shift < 32 ? vals[i] >> seg_shift : T.tile_job[vals[i] >> 6];
 }
 
 // cnts: [0] long buckets, [1] short buckets, [2] next long bucket to hand out, [3] overflow blocks booked, [4] first "not inserted" index
 // vals: the positions in (entry, hash 4, position) order, the ones that are not inserted behind; k4: their hash-4 keys BY POSITION
-__device__ __forceinline__ bool bt4_is_head(const uint32_t *__restrict__ k4, const uint32_t *__restrict__ vals, uint32_t i, const Tables &T) {
+__device__ __forceinline__ bool bt4_is_head(const uint32_t *__restrict__ k4, const uint32_t *__restrict__ vals, uint32_t i, const Tables &T, uint32_t seg_shift) {
   if (i == 0) return true;
   const uint32_t p = vals[i], pp = vals[i - 1];
-  return k4[p] != k4[pp] || T.tile_job[p >> 6] != T.tile_job[pp >> 6];
+  return k4[p] != k4[pp] || T.tile_job[p >> 6] != T.tile_job[pp >> 6] || (seg_shift < 32 && (p >> seg_shift) != (pp >> seg_shift));
 }
 __global__ void __launch_bounds__(256) k_bt4_flags(const uint32_t *__restrict__ k4, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T,
-                                                   uint32_t *__restrict__ flags, uint32_t *__restrict__ cnts) {
+                                                   uint32_t *__restrict__ flags, uint32_t *__restrict__ cnts, uint32_t seg_shift) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i > P) return;
   uint32_t f = 0;
   if (i < P) {
     if (k4[vals[i]] & flag) { if (i == 0 || !(k4[vals[i - 1]] & flag)) cnts[4] = i; }
-    else f = bt4_is_head(k4, vals, i, T) ? 1u : 0u;
+    else f = bt4_is_head(k4, vals, i, T, seg_shift) ? 1u : 0u;
   }
   flags[i] = f;                                                      // (P + 1 entries: the scan's value at P is the number of buckets)
 }
 __global__ void __launch_bounds__(256) k_bt4_heads(const uint32_t *__restrict__ k4, const uint32_t *__restrict__ vals, uint32_t P, uint32_t flag, Tables T,
-                                                   const uint32_t *__restrict__ rank, uint32_t *__restrict__ heads) {
+                                                   const uint32_t *__restrict__ rank, uint32_t *__restrict__ heads, uint32_t seg_shift) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   if (k4[vals[i]] & flag) return;
-  if (bt4_is_head(k4, vals, i, T)) heads[rank[i]] = i;
+  if (bt4_is_head(k4, vals, i, T, seg_shift)) heads[rank[i]] = i;
 }
 // what a walk needs to start on a position, side by side in the order the walks take the positions in: (position, hash-2 predecessor,
 // hash-3 predecessor) -- one 16-byte load, the next position's issued while the current one is on its way down the tree
@@ -120,10 +121,12 @@ __global__ void __launch_bounds__(256) k_bt4_records(const uint32_t *__restrict_
   if (k4[p] & flag) return;
   rec[i] = make_uint4(p, (uint32_t)d2[p], (uint32_t)d3[p], 0u);
 }
+// (i0, i1: the sorted indices the launch takes the buckets of -- everything, or one segment of a stream walked in segments; rank [i] = buckets before index i)
 __global__ void __launch_bounds__(256) k_bt4_split(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ vals, Tables T, const uint32_t *__restrict__ nruns,
-                                                   uint32_t *__restrict__ cnts, uint2 *__restrict__ longs, uint2 *__restrict__ shorts) {
-  const uint32_t r = blockIdx.x * 256 + threadIdx.x, R = *nruns;
-  bool live = r < R;
+                                                   uint32_t *__restrict__ cnts, uint2 *__restrict__ longs, uint2 *__restrict__ shorts, const uint32_t *__restrict__ rank, uint32_t i0, uint32_t i1) {
+  const uint32_t R = *nruns, r0 = rank[i0], r1 = rank[i1];
+  const uint32_t r = r0 + blockIdx.x * 256 + threadIdx.x;
+  bool live = r < r1;
   uint32_t s = 0, len = 0;
   if (live) {
     s = heads[r]; len = (r + 1 < R ? heads[r + 1] : cnts[4]) - s;
@@ -158,12 +161,14 @@ __device__ __forceinline__ int extend8(const uint8_t *in, int64_t a, int64_t b, 
   return len;
 }
 
+// htab (a stream walked in segments, else null): the ordinal of a bucket's last position in the segments before = the root its first position
+// of this segment starts from, the reference's hash4Table (lz77.adb:1247-1251); k4: the positions' hash-4 keys.
 __global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ arena, const uint4 *__restrict__ rec, const uint2 *__restrict__ longs, const uint2 *__restrict__ shorts,
-                                                  uint32_t *__restrict__ cnts, Tables T, int32_t *__restrict__ tree, Sets S) {
+                                                  uint32_t *__restrict__ cnts, Tables T, int32_t *__restrict__ tree, Sets S, int32_t *__restrict__ htab, const uint32_t *__restrict__ k4) {
   const uint32_t nlong = cnts[0], nshort = cnts[1], nthreads = gridDim.x * 256;
   uint32_t next_short = blockIdx.x * 256 + threadIdx.x;
   bool more_long = nlong > 0, walking = false;
-  uint32_t i = 0, e = 0, p = 0, blk = 0, job = NOJOB;
+  uint32_t i = 0, e = 0, p = 0, blk = 0, job = NOJOB, hcur = 0;
   int32_t prev_ord = BT4_NONE;
   uint4 nxt = make_uint4(0, 0, 0, 0);                                // the record of position i (loaded while position i - 1 was walked)
   // the bucket's entry (a bucket never leaves its entry)
@@ -197,6 +202,7 @@ __global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ ar
         joff = (uint32_t)J.in_off; jin = arena + J.in_off; jtree = tree + 2 * (size_t)J.in_off;
         jruns = T.runs + J.run_off; jrun_cnt = J.run_cnt; jmax = (int32_t)J.max_dist;
         cr.start = cr.end = 0;
+        if (htab) { hcur = k4[nxt.x] & J.hash4_mask; prev_ord = htab[hcur]; }
       }
       const uint4 rc = nxt;
       if (i + 1 < e) nxt = rec[i + 1];
@@ -214,6 +220,7 @@ __global__ void __launch_bounds__(256) k_bt4_walk(const uint8_t *__restrict__ ar
       prev_ord = w.ordp;
       i++;
       walking = false;
+      if (htab && i >= e) htab[hcur] = prev_ord;                      // (the bucket's last position of this segment)
     }
   }
 }
@@ -313,6 +320,12 @@ struct State {
   Buf tile_job, jobs, runs, k2, k3, k4, val, ks, vs, tmp, d2, d3, tree, cnt, sl, sd, ol, od, flags, heads, longs, shorts, cnts, scan, small, rec, weight;
   Buf *all[27] = {&tile_job, &jobs, &runs, &k2, &k3, &k4, &val, &ks, &vs, &tmp, &d2, &d3, &tree, &cnt, &sl, &sd, &ol, &od, &flags, &heads, &longs, &shorts, &cnts, &scan, &small, &rec, &weight};
   bool lds_attr = false;
+  // a stream walked in segments (bt4_produce with `seg`, then bt4_walk_segment per segment)
+  Buf htab;
+  uint32_t seg_shift = 32, P = 0, hb4 = 16;
+  std::vector<uint32_t> seg_start;                                   // sorted index at which segment k begins (+ the end)
+  const uint32_t *order = nullptr;
+  const uint8_t *arena = nullptr;
   uint32_t ovf_cap = 0;
 };
 int grow(Ctx *c, Buf &b, size_t bytes) {
@@ -332,6 +345,7 @@ void bt4_destroy(Ctx *c) {
   State *B = (State *)c->bt4;
   if (!B) return;
   for (Buf *b : B->all) if (b->p) hipFree(b->p);
+  if (B->htab.p) hipFree(B->htab.p);
   delete B;
   c->bt4 = nullptr;
 }
@@ -339,7 +353,9 @@ void bt4_destroy(Ctx *c) {
 // The match sets of all Level_3 entries among `jobs` (arena: the device buffer the entries' in_off count from; P = bytes of it that
 // hold entries, every entry at a multiple of 64).  On return `out` points at the sets (device memory owned by the context, valid until
 // the next call).  Returns 0, ZADA_E_NOMEM, ZADA_E_INVALID (a window schedule the producer does not take) or ZADA_E_HIP.
-int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out, std::vector<uint32_t> *weights) {
+// seg_shift < 32 (ONE entry at the start of the arena): everything but the walks -- the entry is then walked segment by segment (2 ** seg_shift
+// positions each, bt4_walk_segment), so that the coder of a segment runs next to the walks of the segment after it; *nseg receives their number.
+int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out, std::vector<uint32_t> *weights, uint32_t seg_shift, uint32_t *nseg) {
   if (!c->bt4) c->bt4 = new State();
   State *B = (State *)c->bt4;
   hipStream_t st = c->stream;
@@ -373,8 +389,22 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   uint32_t hb4 = 16;
   while ((1u << hb4) < hmax) hb4++;
   const size_t tmp_bytes = radix_sort_tmp_bytes(P, 4);
+  const bool segmented = seg_shift < 32;
+  if (segmented && (jobs.size() != 1 || jobs[0].in_off != 0 || jobs[0].level != 3)) { c->err = "LZMA: segments are for one entry"; return ZADA_E_INVALID; }
   if (c->knob_lzma_pool > 0) B->ovf_cap = (uint32_t)c->knob_lzma_pool;        // (test knob: a pool that is too small, to walk twice)
-  else if (B->ovf_cap < P / 16 + 1024) B->ovf_cap = P / 16 + 1024;
+  else if (B->ovf_cap < P / (segmented ? 8 : 16) + 1024) B->ovf_cap = P / (segmented ? 8 : 16) + 1024;
+  B->seg_shift = seg_shift; B->P = P; B->arena = d_arena;
+  if (segmented) {                                                   // where every segment begins in the (segment, hash 4, position) order: the inserted positions before it
+    const uint32_t ns = (uint32_t)((jobs[0].n + (1ull << seg_shift) - 1) >> seg_shift);
+    B->seg_start.assign(ns + 1, 0);
+    for (uint32_t k = 0; k <= ns; k++) {
+      const uint64_t x = (uint64_t)k << seg_shift;
+      uint64_t ins = 0;
+      for (const Bt4Run &r : hr) if (r.cls != 2 && x > r.start) ins += (x < r.end ? x : r.end) - r.start;
+      B->seg_start[k] = (uint32_t)ins;
+    }
+    if (nseg) *nseg = ns;
+  }
   int rc;
   if ((rc = grow(c, B->tile_job, 4ull * (P / 64) + 64)) || (rc = grow(c, B->jobs, sizeof(Bt4Job) * hj.size() + 64)) || (rc = grow(c, B->runs, sizeof(Bt4Run) * hr.size())) ||
       (rc = grow(c, B->k2, 4ull * P)) || (rc = grow(c, B->k3, 4ull * P)) || (rc = grow(c, B->k4, 4ull * P)) || (rc = grow(c, B->val, 4ull * P)) || (rc = grow(c, B->ks, 4ull * P)) ||
@@ -403,20 +433,30 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   if ((rc = radix_sort_pairs(c, st, B->tmp.p, B->tmp.cap, B->k4.as<uint32_t>(), ks, val, vs, 4, P, 0, hb4 + 1))) return rc;
   const uint32_t E = (uint32_t)jobs.size();
   const uint32_t *order = vs;                                        // positions in (entry, hash 4, position) order
-  if (E > 1) {
+  const uint32_t nkeys = segmented ? (uint32_t)B->seg_start.size() - 1 : E;      // entries, or segments of the one entry
+  if (nkeys > 1) {
     uint32_t eb = 1;
-    while ((1u << eb) <= E) eb++;
-    hipLaunchKernelGGL(k_bt4_jobkeys, gp, b256, 0, st, ks, vs, P, 1u << hb4, T, E);
+    while ((1u << eb) <= nkeys) eb++;
+    hipLaunchKernelGGL(k_bt4_jobkeys, gp, b256, 0, st, ks, vs, P, 1u << hb4, T, nkeys, seg_shift);
     if ((rc = radix_sort_pairs(c, st, B->tmp.p, B->tmp.cap, ks, B->k2.as<uint32_t>(), vs, val, 4, P, 0, eb))) return rc;   // (k2 and the identity are free by now)
     order = val;
   }
   uint32_t *flags = B->flags.as<uint32_t>(), *heads = B->heads.as<uint32_t>();
   const uint32_t *k4 = B->k4.as<uint32_t>();
-  hipLaunchKernelGGL(k_bt4_flags, dim3(P / 256 + 1), b256, 0, st, k4, order, P, 1u << hb4, T, flags, cnts);
+  hipLaunchKernelGGL(k_bt4_flags, dim3(P / 256 + 1), b256, 0, st, k4, order, P, 1u << hb4, T, flags, cnts, seg_shift);
   exclusive_scan_u32(st, flags, flags, B->scan.as<uint32_t>(), cnts + 5, P + 1);             // cnts [5] = number of buckets
-  hipLaunchKernelGGL(k_bt4_heads, gp, b256, 0, st, k4, order, P, 1u << hb4, T, flags, heads);
+  hipLaunchKernelGGL(k_bt4_heads, gp, b256, 0, st, k4, order, P, 1u << hb4, T, flags, heads, seg_shift);
   hipLaunchKernelGGL(k_bt4_records, gp, b256, 0, st, k4, order, P, 1u << hb4, B->d2.as<int32_t>(), B->d3.as<int32_t>(), B->rec.as<uint4>());
-  hipLaunchKernelGGL(k_bt4_split, gp, b256, 0, st, heads, order, T, cnts + 5, cnts, B->longs.as<uint2>(), B->shorts.as<uint2>());
+  B->order = order; B->hb4 = hb4;
+  if (segmented) {
+    // the walks come segment by segment (bt4_walk_segment); the buckets' roots travel from segment to segment in a table like the reference's
+    if ((rc = grow(c, B->htab, 4ull * jobs[0].hash4_size)) || (rc = grow(c, B->ol, 2ull * BT4_OVF * B->ovf_cap)) || (rc = grow(c, B->od, 4ull * BT4_OVF * B->ovf_cap))) return rc;
+    hipMemsetAsync(B->htab.p, 0xFF, 4ull * jobs[0].hash4_size, st);
+    if (hip_check(c, hipStreamSynchronize(st), "BT4 producer (sorts)")) return ZADA_E_HIP;
+    out->cnt = B->cnt.as<uint8_t>(); out->sl = B->sl.as<uint16_t>(); out->sd = B->sd.as<uint32_t>(); out->ol = B->ol.as<uint16_t>(); out->od = B->od.as<uint32_t>();
+    return 0;
+  }
+  hipLaunchKernelGGL(k_bt4_split, gp, b256, 0, st, heads, order, T, cnts + 5, cnts, B->longs.as<uint2>(), B->shorts.as<uint2>(), flags, 0u, P);
   if (hip_check(c, hipGetLastError(), "BT4 producer (sorts)")) return ZADA_E_HIP;
   if (!small_jobs.empty() && !B->lds_attr) {
     if (hip_check(c, hipFuncSetAttribute((const void *)k_bt4_walk_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BT4_LDS_BYTES), "k_bt4_walk_lds (LDS size)")) return ZADA_E_HIP;
@@ -432,7 +472,7 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
       hipLaunchKernelGGL(k_bt4_walk_lds<false>, dim3((uint32_t)small_jobs.size()), dim3(BT4_LDS_THREADS), BT4_LDS_BYTES, st, d_arena, B->rec.as<uint4>(), heads, flags, B->small.as<uint32_t>(), cnts, T,
                          B->tree.as<int32_t>(), S);
     }
-    hipLaunchKernelGGL(k_bt4_walk, dim3(nblk), b256, 0, st, d_arena, B->rec.as<uint4>(), B->longs.as<uint2>(), B->shorts.as<uint2>(), cnts, T, B->tree.as<int32_t>(), S);
+    hipLaunchKernelGGL(k_bt4_walk, dim3(nblk), b256, 0, st, d_arena, B->rec.as<uint4>(), B->longs.as<uint2>(), B->shorts.as<uint2>(), cnts, T, B->tree.as<int32_t>(), S, (int32_t *)nullptr, k4);
     uint32_t h[8];
     hipMemcpyAsync(h, cnts, sizeof h, hipMemcpyDeviceToHost, st);
     if (hip_check(c, hipStreamSynchronize(st), "k_bt4_walk")) return ZADA_E_HIP;
@@ -454,6 +494,34 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   }
   out->cnt = B->cnt.as<uint8_t>(); out->sl = B->sl.as<uint16_t>(); out->sd = B->sd.as<uint32_t>(); out->ol = B->ol.as<uint16_t>(); out->od = B->od.as<uint32_t>();
   return 0;
+}
+
+// The walks of segment k of the stream bt4_produce prepared in segments, on `st` (no wait: the caller orders the coder behind them).
+int bt4_walk_segment(Ctx *c, uint32_t k, hipStream_t st) {
+  State *B = (State *)c->bt4;
+  if (!B || B->seg_shift >= 32 || k + 1 >= B->seg_start.size()) { c->err = "LZMA: no such segment"; return ZADA_E_INVALID; }
+  const uint32_t i0 = B->seg_start[k], i1 = B->seg_start[k + 1];
+  if (i1 <= i0) return 0;
+  uint32_t *cnts = B->cnts.as<uint32_t>();
+  hipMemsetAsync(cnts, 0, 12, st);                                   // long / short buckets and the long ones' hand-out counter: this segment's
+  const Tables T{B->tile_job.as<uint32_t>(), B->jobs.as<Bt4Job>(), B->runs.as<Bt4Run>()};
+  hipLaunchKernelGGL(k_bt4_split, dim3((i1 - i0 + 255) / 256), dim3(256), 0, st, B->heads.as<uint32_t>(), B->order, T, cnts + 5, cnts, B->longs.as<uint2>(), B->shorts.as<uint2>(),
+                     B->flags.as<uint32_t>(), i0, i1);
+  const Sets S{B->cnt.as<uint8_t>(), B->sl.as<uint16_t>(), B->sd.as<uint32_t>(), B->ol.as<uint16_t>(), B->od.as<uint32_t>(), B->ovf_cap};
+  const uint32_t nblk = (i1 - i0 + 255) / 256 < 2048 ? (i1 - i0 + 255) / 256 : 2048;
+  hipLaunchKernelGGL(k_bt4_walk, dim3(nblk), dim3(256), 0, st, B->arena, B->rec.as<uint4>(), B->longs.as<uint2>(), B->shorts.as<uint2>(), cnts, T, B->tree.as<int32_t>(), S,
+                     B->htab.as<int32_t>(), B->k4.as<uint32_t>());
+  return hip_check(c, hipGetLastError(), "k_bt4_walk (segment)") ? ZADA_E_HIP : 0;
+}
+// After the walks enqueued on `st` so far: 1 when the overflow pool of the match sets was too small for them (the sets of the last
+// segment are not all there: the caller goes back to the unsegmented way), 0 when all is well.
+int bt4_segments_overflowed(Ctx *c, hipStream_t st) {
+  State *B = (State *)c->bt4;
+  uint32_t h = 0;
+  hipMemcpyAsync(&h, B->cnts.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost, st);
+  if (hip_check(c, hipStreamSynchronize(st), "k_bt4_walk (segment)")) return ZADA_E_HIP;
+  c->bt4_overflow = h;
+  return h > B->ovf_cap ? 1 : 0;
 }
 
 }  // namespace zada

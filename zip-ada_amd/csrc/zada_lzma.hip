@@ -1004,7 +1004,7 @@ template <typename T> __device__ inline void words_in(T &dst, const T *src) {
 }
 
 __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint32_t *order, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
-                                                    Bt4Sets sets, uint64_t *result, uint8_t *save_base, uint64_t budget) {
+                                                    Bt4Sets sets, uint64_t *result, uint8_t *save_base, uint64_t budget, uint64_t pos_cap) {
   LzProbs &P = s_P;
   const uint32_t job = order ? order[blockIdx.x] : blockIdx.x;      // the longest entries first: workgroups start in index order
   const LzmaJob J = jobs[job];
@@ -1042,7 +1042,8 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
     for (int i = 0; i < 4; i++) put_byte((J.sbs >> (8 * i)) & 255);
     if (J.level == 3) running = lz_bt4_begin((int)J.sbs, J.in_off, sets);
   }
-  const uint64_t stop = budget ? s_E.ES.pos + budget : ~0ull;      // (every step of the loops below codes at least one position)
+  // (every step of the loops below codes at least one position; pos_cap: the match sets beyond are still being written, lzma_run "segments")
+  const uint64_t stop = budget ? (s_E.ES.pos + budget < pos_cap ? s_E.ES.pos + budget : pos_cap) : ~0ull;
   bool done = true;
   const uint32_t *tok = tok_base + J.tok_off;
   // One loop for the three sources of symbols -- No_LZ77 (level 0: every byte a literal), the tokens of the Info-Zip matcher (levels 1, 2)
@@ -1122,12 +1123,13 @@ int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, co
 
 // jobs[0 .. count): device array; results: 2 x count uint64 (stream bytes, input bytes coded).  sets: the BT4 producer's match sets (Level_3).
 // d_save / budget: a stream in several launches (count slots of lzma_save_stride() bytes, zero before the first launch; a launch codes
-// `budget` more positions of every unfinished stream and flags bit 63 of its second result while there is more to come); nullptr / 0: one launch.
+// `budget` more positions of every unfinished stream -- up to position pos_cap at most -- and flags bit 63 of its second result while there
+// is more to come); nullptr / 0: one launch.
 uint64_t lzma_save_stride() { return LZ_SAVE_STRIDE; }
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
-                uint8_t *d_save, uint64_t budget) {
+                uint8_t *d_save, uint64_t budget, uint64_t pos_cap) {
   if (count == 0) return 0;
-  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, sets, d_result, d_save, d_save ? budget : 0ull);
+  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, sets, d_result, d_save, d_save ? budget : 0ull, pos_cap);
   return hip_check(c, hipGetLastError(), "k_lzma_encode") ? ZADA_E_HIP : 0;
 }
 
