@@ -392,7 +392,7 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   const bool segmented = seg_shift < 32;
   if (segmented && (jobs.size() != 1 || jobs[0].in_off != 0 || jobs[0].level != 3)) { c->err = "LZMA: segments are for one entry"; return ZADA_E_INVALID; }
   if (c->knob_lzma_pool > 0) B->ovf_cap = (uint32_t)c->knob_lzma_pool;        // (test knob: a pool that is too small, to walk twice)
-  else if (B->ovf_cap < P / (segmented ? 8 : 16) + 1024) B->ovf_cap = P / (segmented ? 8 : 16) + 1024;
+  else if (B->ovf_cap < P / 16 + 1024) B->ovf_cap = P / 16 + 1024;
   B->seg_shift = seg_shift; B->P = P; B->arena = d_arena;
   if (segmented) {                                                   // where every segment begins in the (segment, hash 4, position) order: the inserted positions before it
     const uint32_t ns = (uint32_t)((jobs[0].n + (1ull << seg_shift) - 1) >> seg_shift);

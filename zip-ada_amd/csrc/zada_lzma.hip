@@ -328,9 +328,15 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t dist
   double strict_dlc = 0.0, expanded_dlc = 0.0, soe = 0.0;
   [[maybe_unused]] const int lane = (int)threadIdx.x;
   if (s_E.cv >= 1) {
+#ifdef ZADA_LZ_PROF
+    const unsigned long long prof_a = clock64();
+#endif
     strict_dlc = test_strict(distance, length, sim);
     expanded_dlc = test_expanded(distance, length, strict_dlc, sim);
     soe = strict_dlc > expanded_dlc ? strict_dlc : expanded_dlc;
+#ifdef ZADA_LZ_PROF
+    if constexpr (PAR) { g_lzprof[7] += clock64() - prof_a; g_lzprof[0] += 1; }
+#endif
     if (length > 2) {
       const uint32_t b_head = TB((int64_t)sim.pos - (int64_t)distance);
       const double head_lit = test_literal_byte(b_head, sim);
@@ -423,7 +429,9 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t dist
         }
       }
     }
-    PROF_ADD(6);
+#ifdef ZADA_LZ_PROF
+    if constexpr (PAR) g_lzprof[6] += clock64() - prof_t0;
+#endif
     if (best_prob > soe) return W_SPLIT;
   }
   return W_STRICT;
@@ -804,13 +812,17 @@ __device__ __noinline__ void bt_get_matches(int set) {
   const int avail = bt_move_pos();
   if (avail == 0) return;
   const uint64_t p = s_B.base + (uint64_t)((int64_t)s_B.readPos + s_B.moved);
-  const int cnt = s_B.sets.cnt[p], i = (int)threadIdx.x;
+  // the count and the eight slots next to the position in ONE round trip (slots beyond the count hold nothing, and are not used); only a set of
+  // more than seven matches takes a second one, to its overflow block
+  const int i = (int)threadIdx.x;
+  const Bt4Sets &S = s_B.sets;
+  uint32_t l = 0, d = 0;
+  if (i < BT4_INLINE) { l = S.sl[p * BT4_INLINE + i]; d = S.sd[p * BT4_INLINE + i]; }
+  const int cnt = S.cnt[p];
+  const uint32_t blk = __shfl(d, BT4_INLINE - 1);
   if (i < cnt) {
-    if (i < BT4_INLINE - 1) { M.len[i + 1] = s_B.sets.sl[p * BT4_INLINE + i]; M.dist[i + 1] = (int)s_B.sets.sd[p * BT4_INLINE + i]; }
-    else {
-      const uint64_t o = (uint64_t)s_B.sets.sd[p * BT4_INLINE + (BT4_INLINE - 1)] * BT4_OVF + (uint32_t)(i - (BT4_INLINE - 1));
-      M.len[i + 1] = s_B.sets.ol[o]; M.dist[i + 1] = (int)s_B.sets.od[o];
-    }
+    if (i >= BT4_INLINE - 1) { const uint64_t o = (uint64_t)blk * BT4_OVF + (uint32_t)(i - (BT4_INLINE - 1)); l = S.ol[o]; d = S.od[o]; }
+    M.len[i + 1] = (uint16_t)l; M.dist[i + 1] = (int)d;
   }
   M.count = cnt;
   __syncthreads();
@@ -850,8 +862,10 @@ __device__ void lz_read_one(int set) {                     // Read_One_and_Get_M
   s_B.best_len_rep = 0;
   const int a = bt_available(), avail = a < BT_LOOK ? a : BT_LOOK;
   if (avail >= BT_MIN) {
+    // (the four repeat distances on four lanes: their byte loads are in flight together instead of one after the other)
+    const int mine = bt_match_len(s_B.rep_dist[threadIdx.x & 3], avail);
     for (int rep = 0; rep < 4; rep++) {
-      const int len = bt_match_len(s_B.rep_dist[rep], avail);
+      const int len = __shfl(mine, rep);
       s_B.len_rep[rep] = len;
       if (len > s_B.best_len_rep) { s_B.best_rep_index = rep; s_B.best_len_rep = len; }
     }
@@ -956,8 +970,7 @@ __device__ __forceinline__ Symbol lz_next_symbol() {       // Get_Next_Symbol :1
     }
   }
   const int limit = main_len - 1 > BT_MIN ? main_len - 1 : BT_MIN;
-  for (int rep = 0; rep < 4; rep++)
-    if (bt_match_len(s_B.rep_dist[rep], limit) == limit) return lz_send_literal();
+  if (__any(bt_match_len(s_B.rep_dist[threadIdx.x & 3], limit) == limit)) return lz_send_literal();
   lz_skip(main_len - 2);
   return lz_send_dl(main_dist, main_len);
 }
@@ -1081,7 +1094,7 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   write_simple_match(0xFFFFFFFFu, 2);
   for (int i = 0; i < 5; i++) shift_low();                                          // Flush_range_encoder
 #ifdef ZADA_LZ_PROF
-  if (blockIdx.x == 0 && threadIdx.x == 0) printf("LZPROF total %llu literal %llu emit_dl %llu estimate %llu bt_get %llu bt_skip %llu split(all levels) %llu\n", clock64() - prof_k0, g_lzprof[1], g_lzprof[2], g_lzprof[3], g_lzprof[4], g_lzprof[5], g_lzprof[6]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) printf("LZPROF total %llu literal %llu emit_dl %llu (decisions %llu: strict + expanded %llu, cuts %llu) estimate %llu bt_get %llu bt_skip %llu\n", clock64() - prof_k0, g_lzprof[1], g_lzprof[2], g_lzprof[0], g_lzprof[7], g_lzprof[6], g_lzprof[3], g_lzprof[4], g_lzprof[5]);
 #endif
   if (S && threadIdx.x == 0) S->phase = 2;
   result[2 * job] = s_E.olen;
