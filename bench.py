@@ -322,10 +322,12 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
     rc1, z1, _ = enc.lzma(one, 18)
     d1 = time.perf_counter() - t1
     tim1 = {k: round(v, 1) for k, v in enc.last_timing() if not k.startswith("#")}
+    cnt1 = {k: v for k, v in enc.last_timing() if k.startswith("#")}
     out["one_stream"] = {"value": round(len(one) / d1 / 1e6, 4), "unit": "MB/s", "bytes": len(one), "compression_ratio": round(len(z1) / len(one), 4), "phase_ms": tim1,
+                         "launches": int(cnt1.get("#lzma_launches", 0)), "producer": "in segments of 2**20 positions on a second stream, beside the coder (knob lzma_segment)",
                          "seconds_for_config_4": round((1 << 30) / (len(one) / d1), 0),
-                         "note": "config 4 is ONE 1 GiB stream: it runs at this rate -- the match sets come from the producer's parallel kernels (lzma:bt4), the coder is one wave walking "
-                                 "the chain of adaptive probabilities (the independent simulations of a step run on teams of its lanes)"}
+                         "note": "config 4 is ONE 1 GiB stream: it runs at this rate -- the match sets come from the producer's parallel kernels, segment k + 1 while the coder -- one "
+                                 "wave walking the chain of adaptive probabilities, the independent simulations of a step on teams of its lanes -- codes segment k"}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _lzmah import oracle_lzma
