@@ -1,9 +1,13 @@
-"""GPU script: where one LZMA stream's time goes (variant build with -DZADA_LZ_PROF prints clock counters of entry 0)."""
-import sys, os, time
+"""GPU script: where one LZMA_3 stream's time goes -- run with the variant build `make -C zip-ada_amd/csrc variant NAME=lzprof DEFS=-DZADA_LZ_PROF`
+(ZADA_LIB=zip-ada_amd/variants/lzprof.so), which prints the clock counters of entry 0 of every launch: entries of 16 KiB (fresh data at two
+places of the benchmark stream), 64 KiB and 1 MiB (mostly long repeats), each as a batch of one = one launch."""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _common import product
-from _lzmah import lz_inputs
 Z = product(); enc = Z.Encoder(0)
-d = lz_inputs()["mix_256k"][:65536]
-for m in (17, 18):
-    t = time.time(); rc, z, crc = enc.lzma(d, m); print("method", m, len(z), "%.3f s" % (time.time() - t), flush=True)
+mix = Z.silesia_mix(4 << 20)
+for off, kib in ((0, 16), (1 << 20, 16), (0, 64), (0, 1024)):
+    d = bytes(mix[off:off + (kib << 10)])
+    print("== offset", off, "KiB", kib, flush=True)
+    r = enc.lzma_batch([d], 18)
+    print("ratio %.3f" % (len(r[0][1]) / len(d)), flush=True)
