@@ -353,6 +353,15 @@ template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t dist
         sim_any<NEW>(distance, length - 1, v, p);
         if (task == 1) sim_literal(TB((int64_t)v.pos - (int64_t)distance), v, p);
         dal = __shfl(p, 0); dtl = __shfl(p, 32);
+      } else if (sim.tw >= 2) {
+        // the team that runs this simulation parts in two for the same pair (the halves run sim_any<NEW> in step, as the wave's halves do above)
+        const int tw = sim.tw, half = tw >> 1, task = (lane & (tw - 1)) >= half ? 1 : 0, tb = lane & ~(tw - 1);
+        MS v = task == 0 ? after : sim;
+        v.tw = half;
+        double p = task == 0 ? 1.0 : malus_dtl;
+        sim_any<NEW>(distance, length - 1, v, p);
+        if (task == 1) sim_literal(TB((int64_t)v.pos - (int64_t)distance), v, p);
+        dal = __shfl(p, tb); dtl = __shfl(p, tb + half);
       } else {
         dal = 1.0;
         sim_any<NEW>(distance, length - 1, after, dal);
