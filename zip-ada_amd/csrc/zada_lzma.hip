@@ -228,10 +228,17 @@ __device__ double test_simple_match(uint32_t distance, uint32_t length, const MS
   return scale11(tq(P.rep[sim.state], 0) * tl * td, 1 + nlen + ntd);
 }
 
-__device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &sim, double &prob) {   // Simulate_Strict_DL_Code :605-659
+// Simulate_Strict_DL_Code :605-659 as the state it leaves and the two factors it multiplies the probability by (prob := prob * f1 * f2, in that
+// order): Generic_any_DL_Code tests the strict code first (:661-677, from probability 1.0: 1.0 * f1 is f1) and, when nothing beats it, simulates
+// it again on the same state (:826-830) -- the second time the factors are the first time's.
+struct StrictRes { MS after; double f1, f2; };
+__device__ __forceinline__ StrictRes strict_factors(uint32_t distance, int length, const MS &sim0) {
+  StrictRes r;
+  MS &sim = r.after;
+  sim = sim0;
   const uint32_t dist_ip = distance - 1;
   int found = -1;
-  const double dlc = tbe(s_P.match[sim.state][sim.pos_state], 1);
+  r.f1 = tbe(s_P.match[sim.state][sim.pos_state], 1);
   const double sma = test_simple_match(dist_ip, (uint32_t)length, sim);
   // (no run-time index into sim.rep: one would put the whole state in scratch memory)
   found = dist_ip == sim.rep[0] ? 0 : dist_ip == sim.rep[1] ? 1 : dist_ip == sim.rep[2] ? 2 : dist_ip == sim.rep[3] ? 3 : -1;
@@ -239,7 +246,7 @@ __device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &si
   if (found >= 0) {
     const double rma = test_repeat_match(found, (uint32_t)length, sim);
     if (rma >= sma * 0.55) {                                                       // Malus_simple_match_vs_rep :301
-      prob = prob * dlc * rma;
+      r.f2 = rma;
       const uint32_t r0 = sim.rep[0], r1 = sim.rep[1], r2 = sim.rep[2];           // rep (found) to the front, the ones before it one down
       sim.rep[0] = dist_ip;
       if (found >= 1) sim.rep[1] = r0;
@@ -250,19 +257,19 @@ __device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &si
     }
   }
   if (!rep) {
-    prob = prob * dlc * sma;
+    r.f2 = sma;
     sim.rep[3] = sim.rep[2]; sim.rep[2] = sim.rep[1]; sim.rep[1] = sim.rep[0]; sim.rep[0] = dist_ip;
     sim.state = t_match(sim.state);
   }
   sim.pos += (uint64_t)length;
   sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
   sim.prev_byte = TB((int64_t)sim.pos - 1);
+  return r;
 }
-
-__device__ inline double test_strict(uint32_t distance, int length, const MS &sim) {   // :661-677
-  MS v = sim; double prob = 1.0;
-  sim_strict(distance, length, v, prob);
-  return prob;
+__device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &sim, double &prob) {
+  const StrictRes r = strict_factors(distance, length, sim);
+  prob = prob * r.f1 * r.f2;
+  sim = r.after;
 }
 
 __device__ double test_expanded(uint32_t distance, int length, double give_up, const MS &sim) {   // :680-726
@@ -324,14 +331,15 @@ template <int R> __device__ void sim_any(uint32_t distance, int length, MS &sim,
 // Where the reference compares INDEPENDENT simulations -- literal + code against code + literal (:783-805), the cuts of
 // Test_Split_DL (:924-943) -- the lanes part: one simulation each, from their own copy of the state, nothing written but the
 // result; the results are then compared by all lanes in the reference's order.  Same doubles, a shorter critical path.
-template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t distance, int length, const MS &sim, int &best_cut) {
+template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t distance, int length, const MS &sim, int &best_cut, StrictRes &strict) {
   double strict_dlc = 0.0, expanded_dlc = 0.0, soe = 0.0;
   [[maybe_unused]] const int lane = (int)threadIdx.x;
   if (s_E.cv >= 1) {
 #ifdef ZADA_LZ_PROF
     const unsigned long long prof_a = clock64();
 #endif
-    strict_dlc = test_strict(distance, length, sim);
+    strict = strict_factors(distance, length, sim);
+    strict_dlc = strict.f1 * strict.f2;                                              // (Test_Strict_DL_Code starts from 1.0: 1.0 * f1 * f2)
     expanded_dlc = test_expanded(distance, length, strict_dlc, sim);
     soe = strict_dlc > expanded_dlc ? strict_dlc : expanded_dlc;
 #ifdef ZADA_LZ_PROF
@@ -454,7 +462,9 @@ template <int R> __device__ __noinline__ SimRes sim_any_impl(uint32_t distance, 
   } else {
     constexpr int NEW = R - 1;
     int cut = 2;
-    switch (decide<NEW, false>(distance, length, sim, cut)) {
+    StrictRes strict;
+    const bool tested = s_E.cv >= 1;                                               // (Level_0 / Level_1 never come here: their codes are written strictly)
+    switch (decide<NEW, false>(distance, length, sim, cut, strict)) {
       case W_LIT_DL:
         sim_literal(TB((int64_t)sim.pos - (int64_t)distance), sim, prob);
         sim_any<NEW>(distance, length - 1, sim, prob);
@@ -471,7 +481,8 @@ template <int R> __device__ __noinline__ SimRes sim_any_impl(uint32_t distance, 
         sim_any<NEW>(distance, length - cut, sim, prob);
         break;
       default:
-        sim_strict(distance, length, sim, prob);
+        if (tested) { const int tw = sim.tw; prob = prob * strict.f1 * strict.f2; sim = strict.after; sim.tw = tw; }
+        else sim_strict(distance, length, sim, prob);
     }
   }
   return SimRes{sim, prob};
@@ -638,7 +649,8 @@ __device__ __forceinline__ void emit_dl(uint32_t distance, int length0) {
     if (it == POST_LIT) { emit_literal(TB((int64_t)s_E.ES.pos - (int64_t)distance)); continue; }
     const int length = it;
     int cut = 2;
-    switch (decide<2, true>(distance, length, s_E.ES, cut)) {
+    StrictRes strict;
+    switch (decide<2, true>(distance, length, s_E.ES, cut, strict)) {
       case W_LIT_DL:
         emit_literal(TB((int64_t)s_E.ES.pos - (int64_t)distance));
         stack[sp++] = (uint16_t)(length - 1);
