@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include "zada_logic.h"
 #include "zada_internal.h"
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -608,11 +609,12 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 // third of all positions).  (A/B, ZADA_CL_SPLIT: the table in 2 / 4 parts with as many workgroups per CU is 6 % / 45 %
 // slower: every part re-reads the positions.)
 constexpr int CL_LDS_PLANE = 131072 + 32768;
-__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv, DistPlanes dp) {
+// (seg0: the launch takes the segments seg0 + 1 ..: one piece of an input that is still arriving, lz_shard)
+__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv, DistPlanes dp, uint32_t seg0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *tl = (uint16_t *)smem;                                 // 128 KiB
   const uint8_t *pb = smem + 131072;                               // the previous segment's bytes (levels with a plane)
-  const uint64_t seg = blockIdx.x + 1, base = seg * 32768ull, pbase = base - 32768ull;
+  const uint64_t seg = (uint64_t)blockIdx.x + 1 + seg0, base = seg * 32768ull, pbase = base - 32768ull;
   const int l = blockIdx.y, tid = threadIdx.x;
   const bool has_plane = l + 1 < NLEVELS;
   if (lay_first(L, seg)) return;                                   // an entry's first segment has nothing before it
@@ -693,9 +695,9 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
 constexpr int CD_THREADS = ZADA_CD_THREADS;
 __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv,
                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
-                                                    DistPlanes dp) {
-  const uint64_t p = 32768ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= L.n) return;
+                                                    DistPlanes dp, uint64_t p0, uint64_t p1) {
+  const uint64_t p = p0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (the positions [p0, p1): all from 32 768 on, or one piece's)
+  if (p >= p1 || p >= L.n) return;
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
   if (lay_first(L, seg) || (uint32_t)(p & 32767u) >= lay_inserted(L, seg)) return;
   const bool prev_first = lay_first(L, seg - 1);
@@ -800,10 +802,10 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 // buckets: one workgroup per segment, long buckets listed in LDS, then processed by all threads.
 __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int kquarter, const uint16_t *__restrict__ S3,
                                                        const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim, const uint32_t *__restrict__ segmax,
-                                                       const uint16_t *__restrict__ heavy) {
+                                                       const uint16_t *__restrict__ heavy, uint32_t seg0) {
   __shared__ uint32_t list[2048];
   __shared__ uint32_t nlist;
-  const uint64_t seg = blockIdx.x, base = seg * 32768ull;
+  const uint64_t seg = (uint64_t)blockIdx.x + seg0, base = seg * 32768ull;
   const int tid = threadIdx.x;
   const bool has_prev = !lay_first(L, seg);
   // a bucket matters only with at least kquarter members in this segment and the previous one together (see above): none
@@ -1791,36 +1793,60 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     hipEventRecord(c->ev_dlim, c->stream2);
 #endif
     if (job.need) {
-      // the input is still arriving (host buffers): the segments of what has come, 64 MiB at a time -- a segment's workgroup reads
-      // its 32 KiB and at most 31 bytes behind them, so a piece holds back its last segment until the next piece is there
+      // The input is still arriving (host buffers): k_prev_links and k_bucket_limits on the segments of what has come, 64 MiB at a time --
+      // a segment's workgroups read its 32 KiB and at most 31 bytes behind them, so a piece ends 64 bytes short of what is there.
+      // k_cross_links (it only looks one segment back, which the piece before has finished on the same stream) joins them when the
+      // pieces come slower than the chip takes them -- a piece of k_prev_links is 1.5 ms, with k_cross_links 2.2: on a host that
+      // delivers 64 MiB every 1.7 ms it would only make the chip the slower side (measured on two boxes: 49.7 against 48.6 ms for the
+      // link stage on a fast host, ten milliseconds the other way on a slow one), so it is launched over everything that is still open
+      // whenever a piece took 2 ms and more to come, and at the end.  k_cross_dist always waits for the end: piece by piece it takes twice its
+      // time (1.2 - 1.5 ms per 64 MiB against 0.68: the few long walks at the end of every launch, sixteen times instead of once --
+      // tests/prof_trace_hostpath.sh).
       constexpr uint32_t PIECE = 2048;
+      constexpr double SLOW_PIECE_S = 2.0e-3;
+      uint32_t cl_from = 1;                                              // first segment whose cross links are still to be made (segment 0 has nothing before it)
+      auto cross_links_upto = [&](uint32_t s1) {
+        if (s1 > cl_from) hipLaunchKernelGGL(k_cross_links, dim3(s1 - cl_from, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl, cl_from - 1);
+        if (s1 > cl_from) cl_from = s1;
+      };
+      auto t_prev = std::chrono::steady_clock::now();
       for (uint32_t s0 = 0; s0 < nseg;) {
         const uint32_t s1 = s0 + PIECE < nseg ? s0 + PIECE : nseg;
         const uint64_t upto = (uint64_t)s1 * 32768 + 64 < n ? (uint64_t)s1 * 32768 + 64 : n;
         if (int rn = job.need(upto)) return rn;
+        const auto t_now = std::chrono::steady_clock::now();
+        const bool slow = s0 > 0 && std::chrono::duration<double>(t_now - t_prev).count() >= SLOW_PIECE_S;
+        t_prev = t_now;
         hipLaunchKernelGGL(k_prev_links, dim3(s1 - s0), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
                            W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0);
+#ifndef ZADA_OLD_INIT
+        if (s0 == 0) hipStreamWaitEvent(st, c->ev_dlim, 0);              // (k_bucket_limits writes into the plane the second stream has preset)
+#endif
+        if (slow) cross_links_upto(s1);
+        hipLaunchKernelGGL(k_bucket_limits, dim3(s1 - s0), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax, W.heavy, s0);
         s0 = s1;
       }
       if (int rn = job.need(n)) return rn;
+      cross_links_upto(nseg);
+      if (nseg > 1) hipLaunchKernelGGL(k_cross_dist, dim3((uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS)), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n);
     } else
     hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
                        W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, 0u);
 #ifndef ZADA_OLD_INIT
-    hipStreamWaitEvent(st, c->ev_dlim, 0);
+    if (!job.need) hipStreamWaitEvent(st, c->ev_dlim, 0);
 #endif
 #ifdef ZADA_PL_STATS
     { unsigned long long h[32]; hipMemcpy(h, W.dbg, sizeof h, hipMemcpyDeviceToHost); fprintf(stderr, "[prev_links cycles/segment] init %.0f |", (double)h[8] / nseg); for (int q = 9; q < 9 + 4 * (NLEVELS + 1) - 1; q++) fprintf(stderr, " %.0f", (double)h[q] / nseg); fprintf(stderr, "  (per level 3..: sort, links, first candidates, queue rounds)\n"); fprintf(stderr, "[level 4 walks per segment] rounds %.2f  entries %.1f  entries of the last round %.1f  hops there %.1f (max %llu over all segments; walks over 64 hops %.3f)  first-queue overflow %.1f  cycles of the last round %.0f\n", (double)h[24] / nseg, (double)h[25] / nseg, (double)h[26] / nseg, (double)h[27] / nseg, h[28], (double)h[29] / nseg, (double)h[30] / nseg, (double)h[31] / nseg); hipMemset(W.dbg, 0, 256);
       unsigned long long sd[8]; hipMemcpyFromSymbol(sd, HIP_SYMBOL(g_sort_dbg), sizeof sd); fprintf(stderr, "[sort_pass cycles/segment, all six passes] clear %.0f  rank (LDS atomics) %.0f  scan %.0f  scatter %.0f\n", (double)sd[0] / nseg, (double)sd[1] / nseg, (double)sd[2] / nseg, (double)sd[3] / nseg); for (int q = 0; q < 8; q++) sd[q] = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_sort_dbg), sd, sizeof sd); }
 #endif
     c->tmark("prev_links");
-    if (nseg > 1) {
-      const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
-      hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl);
-      hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl);
-    }
-    hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax, W.heavy);
-    {
+    if (!job.need) {
+      if (nseg > 1) {
+        const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
+        hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl, 0u);
+        hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n);
+      }
+      hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax, W.heavy, 0u);
     }
   }
   c->tmark("cross_links");
