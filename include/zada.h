@@ -56,7 +56,11 @@ enum {
   ZADA_E_HIP = -3,          /* HIP runtime error; see zada_last_error() */
   ZADA_E_TOO_LARGE = -4,    /* the input is larger than the call takes: zada_range_open takes ranges below 4 GiB - 64 MiB (zada_deflate* take streams of any
                              * length, span after span), zada_lzma* entries below 2 GiB - 64 KiB and batches below 4 GiB */
-  ZADA_E_NO_DEVICE = -5     /* no gfx950 device / HIP extension unusable */
+  ZADA_E_NO_DEVICE = -5,    /* no gfx950 device / HIP extension unusable */
+  ZADA_E_REFERENCE = -6     /* LZMA_3 only: on this entry the reference's BT4 matcher reports a match that is none (lz77.adb:1262-1290 read behind pending
+                             * bytes that no window fill took up, :1000-1017, 1397-1406: lzPos lags behind readPos) and the reference's own stream does not
+                             * decode to the input.  Cannot happen with the dictionary Zip.Compress.LZMA_E asks for unless the entry is beyond 256 MiB and its
+                             * last window fill brings 163 .. 4 368 bytes; the shim Stores such an entry or takes another method.  Nothing was written. */
 };
 
 typedef struct zada_ctx zada_ctx;

@@ -84,6 +84,7 @@ def hostcheck():
         H.hc_header_bits.restype = ctypes.c_uint32
         H.hc_bt4_sets.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]
         H.hc_bt4_sets_segments.argtypes = H.hc_bt4_sets.argtypes + [ctypes.c_uint32]
+        H.hc_bt4_reads_behind_a_gap.argtypes = [ctypes.c_uint64, ctypes.c_int64]
         _cache["h"] = H
     return _cache["h"]
 

@@ -90,3 +90,114 @@ def sets_equal(a, b):
         return False
     live = np.arange(BT4_SET)[None, :] < a[0][:, None]
     return bool(np.array_equal(a[1][live], b[1][live]) and np.array_equal(a[2][live], b[2][live]))
+
+
+def lzma_symbols(stream):
+    """A plain LZMA decoder that keeps the symbols: (decoded bytes, [(position, kind, distance, length)]) of a stream as the oracle / the
+    product write it (5-byte header, end marker); kind 'L' literal (distance = the byte), 'S' short repeat, 'R' repeat match, 'M' match,
+    'E' end marker.  Test tool: it says WHICH symbol of a stream is wrong, liblzma only says that one is."""
+    buf = bytes(stream)
+    props = buf[0]; lc = props % 9; lp = (props // 9) % 5; pb = props // 45
+    st = {"rng": 0xFFFFFFFF, "code": int.from_bytes(buf[6:10], "big"), "pos": 10}
+
+    def norm():
+        if st["rng"] < (1 << 24):
+            st["rng"] = (st["rng"] << 8) & 0xFFFFFFFF
+            st["code"] = ((st["code"] << 8) | (buf[st["pos"]] if st["pos"] < len(buf) else 0)) & 0xFFFFFFFF
+            st["pos"] += 1
+
+    def bit(probs, i):
+        p = probs[i]; bound = (st["rng"] >> 11) * p
+        if st["code"] < bound:
+            st["rng"] = bound; probs[i] = p + ((2048 - p) >> 5); norm(); return 0
+        st["rng"] -= bound; st["code"] -= bound; probs[i] = p - (p >> 5); norm(); return 1
+
+    def direct(n):
+        r = 0
+        for _ in range(n):
+            st["rng"] >>= 1
+            st["code"] = (st["code"] - st["rng"]) & 0xFFFFFFFF
+            t = (0 - (st["code"] >> 31)) & 0xFFFFFFFF
+            st["code"] = (st["code"] + (st["rng"] & t)) & 0xFFFFFFFF
+            norm(); r = (r << 1) + ((t + 1) & 1)
+        return r
+
+    def tree(probs, off, nb):
+        m = 1
+        for _ in range(nb):
+            m = (m << 1) + bit(probs, off + m)
+        return m - (1 << nb)
+
+    def rtree(probs, off, nb):
+        m, v = 1, 0
+        for i in range(nb):
+            b = bit(probs, off + m); m = (m << 1) + b; v |= b << i
+        return v
+
+    P = lambda n: [1024] * n
+    is_match, is_rep, g0, g1, g2, rep0long = P(12 * 16), P(12), P(12), P(12), P(12), P(12 * 16)
+    slot, spec, align, lit = P(4 * 64), P(115), P(16), P(0x300 << (lc + lp))
+    lens = [{"c": P(2), "low": P(16 * 8), "mid": P(16 * 8), "high": P(256)} for _ in range(2)]
+
+    def dlen(L, ps):
+        if bit(L["c"], 0) == 0:
+            return tree(L["low"], ps * 8, 3)
+        if bit(L["c"], 1) == 0:
+            return 8 + tree(L["mid"], ps * 8, 3)
+        return 16 + tree(L["high"], 0, 8)
+
+    out, state, reps, syms = bytearray(), 0, [0, 0, 0, 0], []
+    while True:
+        ps = len(out) & ((1 << pb) - 1)
+        if bit(is_match, state * 16 + ps) == 0:
+            prev = out[-1] if out else 0
+            off = 0x300 * (((len(out) & ((1 << lp) - 1)) << lc) + (prev >> (8 - lc)))
+            sym = 1
+            if state >= 7:
+                mb = out[len(out) - reps[0] - 1]
+                while sym < 0x100:
+                    mbit = (mb >> 7) & 1; mb = (mb << 1) & 0xFF
+                    b = bit(lit, off + ((1 + mbit) << 8) + sym); sym = (sym << 1) | b
+                    if mbit != b:
+                        break
+            while sym < 0x100:
+                sym = (sym << 1) | bit(lit, off + sym)
+            syms.append((len(out), "L", sym & 0xFF, 1)); out.append(sym & 0xFF)
+            state = 0 if state < 4 else state - 3 if state < 10 else state - 6
+            continue
+        if bit(is_rep, state):
+            if bit(g0, state) == 0:
+                if bit(rep0long, state * 16 + ps) == 0:
+                    state = 9 if state < 7 else 11
+                    syms.append((len(out), "S", reps[0] + 1, 1)); out.append(out[len(out) - reps[0] - 1])
+                    continue
+                d = reps[0]
+            else:
+                if bit(g1, state) == 0:
+                    d = reps[1]; reps[1] = reps[0]
+                else:
+                    if bit(g2, state) == 0:
+                        d = reps[2]
+                    else:
+                        d = reps[3]; reps[3] = reps[2]
+                    reps[2] = reps[1]; reps[1] = reps[0]
+                reps[0] = d
+            ln = dlen(lens[1], ps) + 2; state = 8 if state < 7 else 11; kind = "R"
+        else:
+            ln = dlen(lens[0], ps) + 2; state = 7 if state < 7 else 10
+            s = tree(slot, (ln - 2 if ln - 2 < 3 else 3) * 64, 6)
+            if s < 4:
+                d = s
+            else:
+                nb = (s >> 1) - 1; d = (2 | (s & 1)) << nb
+                d += rtree(spec, d - s - 1, nb) if s < 14 else (direct(nb - 4) << 4) + rtree(align, 0, 4)
+            if d == 0xFFFFFFFF:
+                syms.append((len(out), "E", 0, 0))
+                break
+            reps[3] = reps[2]; reps[2] = reps[1]; reps[1] = reps[0]; reps[0] = d; kind = "M"
+        if reps[0] + 1 > len(out):
+            raise ValueError("distance %d at position %d" % (reps[0] + 1, len(out)))
+        syms.append((len(out), kind, reps[0] + 1, ln))
+        for _ in range(ln):
+            out.append(out[len(out) - reps[0] - 1])
+    return bytes(out), syms

@@ -232,6 +232,13 @@ static int bt4_sets_impl(const uint8_t *in, uint64_t n, int64_t dict, uint8_t *c
 extern "C" int hc_bt4_sets(const uint8_t *in, uint64_t n, int64_t dict, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride, uint32_t seed) {
   return bt4_sets_impl(in, n, dict, cnt, len, dist, stride, seed, 32);
 }
+// 1: an entry of n bytes coded with this dictionary has positions read behind pending bytes that no window fill took up (zada_bt4.h
+// bt4_reads_behind_a_gap: zada_lzma then verifies the match sets it reads); 0: not; -1: the schedule is refused
+extern "C" int hc_bt4_reads_behind_a_gap(uint64_t n, int64_t dict) {
+  std::vector<Bt4Run> runs;
+  if (!bt4_schedule(n, bt4_string_buffer_size((uint64_t)dict), runs)) return -1;
+  return bt4_reads_behind_a_gap(runs) ? 1 : 0;
+}
 extern "C" int hc_bt4_sets_segments(const uint8_t *in, uint64_t n, int64_t dict, uint8_t *cnt, uint16_t *len, uint32_t *dist, int stride, uint32_t seed, uint32_t seg_shift) {
   return bt4_sets_impl(in, n, dict, cnt, len, dist, stride, seed, seg_shift);
 }

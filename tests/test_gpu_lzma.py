@@ -236,6 +236,40 @@ def test_dictionary_smaller_than_the_entry(encoder):
         encoder.set_knob("lzma_dict", 0)
 
 
+def test_reference_defect_is_refused_not_written(encoder):
+    """Where the reference's own matcher reports matches that are none (positions read behind pending bytes no window fill took up:
+    test_lzma_oracle.py::test_reference_defect_behind_pending_bytes_no_fill_took_up) its stream decodes to something else than the input, and the
+    product -- whose coder reads the text itself, not a buffer such matches have been copied into -- could only write a third thing.  It verifies
+    the match sets it reads on such entries (bt4_reads_behind_a_gap) and refuses at the first match that is none: ZADA_E_REFERENCE, nothing written,
+    per entry in a batch, the context usable afterwards.  An entry in the same regime whose sets are all true is coded, == the oracle, and decodes."""
+    Z = product()
+    m = lz_inputs()["mix_256k"]
+    x = bytes(m[:12000])
+    try:
+        encoder.set_knob("lzma_dict", 5000)
+        with pytest.raises(Z.ReferenceDefect):
+            encoder.lzma(x, 18)
+        with pytest.raises(Z.ReferenceDefect):
+            encoder.lzma(bytes(m[50000:70000]), 18, feedback=lambda pct: False)
+        # (the sets themselves are the sequential matcher's, matches that are none included)
+        assert sets_equal(oracle_bt4_sets(x, 5000), encoder.lzma_match_sets(x))
+        # levels below 3 have no BT4: coded as ever
+        assert encoder.lzma(x, 17) == oracle_lzma(x, 17)
+        # in the regime, but nothing wrong among the sets read: no byte behind the gap (positions 8 030 .. 8 191 are never inserted) occurs in
+        # front of it, so no distance goes across it -- 3 275 positions behind it have matches, all of them true
+        r = bytes(np.concatenate([np.frombuffer(m[:8030], np.uint8) & 0x7F, np.frombuffer(m[20000:23970], np.uint8) | 0x80]).astype(np.uint8))
+        rc, z, crc = encoder.lzma(r, 18)
+        want, _ = oracle_lzma_encode(r, 3, dictionary_size=5000)
+        assert z == bytes([16, 2, 5, 0]) + want and lzma_decode(z, 4) == r
+        # a batch: the refused entries say so, the others are coded
+        res = encoder.lzma_batch([x, r, x[:5000], bytes(m[50000:70000])], 18)
+        assert [t[0] for t in res] == [Z.E_REFERENCE, 0, 0, Z.E_REFERENCE] and res[0][1] is None and res[3][1] is None
+        assert res[1][1] == z and res[2] == encoder.lzma(x[:5000], 18)
+    finally:
+        encoder.set_knob("lzma_dict", 0)
+    assert encoder.lzma(x, 18) == oracle_lzma(x, 18)
+
+
 def test_stream_in_bounded_launches_feedback_and_abort(encoder):
     """Zip.Compress.LZMA_E drives `feedback` and raises User_abort (zip-compress-lzma_e.adb:78-92).  A stream is coded as a sequence
     of bounded launches with the coder's state (model, match sets, range coder, BT4) parked in device memory in between ("lzma_chunk"

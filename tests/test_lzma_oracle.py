@@ -11,7 +11,7 @@ import zipfile
 import zlib
 
 from _common import oracle_zip
-from _lzmah import lz_inputs, oracle_lzma, oracle_lzma_encode, lzma_decode, LZMA_METHODS
+from _lzmah import oracle_bt4_sets, lz_inputs, oracle_lzma, oracle_lzma_encode, lzma_decode, LZMA_METHODS
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -71,6 +71,38 @@ def test_bt4_tail_quirk_and_windows():
     for ds in (20000, 70000, 300000):
         z, st = oracle_lzma_encode(big, 3, dictionary_size=ds)
         assert lzma_decode(z) == big
+
+
+def test_reference_defect_behind_pending_bytes_no_fill_took_up():
+    """A defect of the reference that the oracle keeps (and the product refuses with ZADA_E_REFERENCE).  Move_Pos leaves lzPos behind readPos for
+    pending bytes (lz77.adb:1000-1017, "GdM: This causes cyclicPos and lzpos not being in sync with readPos"); Fill_Window catches up only if the
+    fill brought more than keepSizeAfter = 4 369 bytes (:1397-1406, 1431-1437).  After a shorter fill -- the last one of a stream, or every one at
+    String_buffer_size 4096 -- the positions that follow are inserted with lzPos short by the gap, a distance into the text before the gap is short
+    by as much, and the hash-2 / hash-3 matches compare only one byte at it (:1262-1290): matches that are none get coded (or expanded into the
+    encoder's text buffer ahead of the coder), and the stream -- self-consistent, right length -- decodes to something else than the input.
+    Zip.Compress.LZMA_E asks for a dictionary of the entry's size (zip-compress-lzma_e.adb:165): the whole entry arrives in the first fill, nothing
+    is read behind a gap -- unless the entry is beyond 256 MiB (String_buffer_size is capped at 2 ** 28) and its last fill brings 163 .. 4 368 bytes."""
+    from _common import hostcheck
+    from _lzmah import lzma_symbols
+    H = hostcheck()
+    x = bytes(lz_inputs()["mix_256k"][:12000])         # dictionary 5000 -> String_buffer_size 8192: fills of 8 192 and 3 808 bytes
+    z, _ = oracle_lzma_encode(x, 3, dictionary_size=5000)
+    out, syms = lzma_symbols(z)
+    assert len(out) == len(x) and out != x and syms[-1][1] == "E"
+    p = next(i for i in range(len(x)) if out[i] != x[i])
+    assert p >= 8192                                                                              # behind the gap (the first fill's last 162 positions)
+    # the root: the sequential matcher's own sets hold matches that are none there (and nowhere else)
+    cnt, ln, ds = oracle_bt4_sets(x, 5000)
+    none = [q for q in range(len(x)) for k in range(cnt[q]) if x[q - ds[q, k]:q - ds[q, k] + ln[q, k]] != x[q:q + ln[q, k]]]
+    assert none and min(none) >= 8192 and min(none) <= p
+    assert H.hc_bt4_reads_behind_a_gap(len(x), 5000) == 1
+    # the entry's size as the dictionary, or fills that all bring more than keepSizeAfter bytes: fine, and the schedule says so
+    assert lzma_symbols(oracle_lzma_encode(x, 3)[0])[0] == x and H.hc_bt4_reads_behind_a_gap(len(x), len(x)) == 0
+    big = bytes(lz_inputs()["mix_256k"]) * 3
+    for dsz in (20000, 70000, 300000):
+        assert H.hc_bt4_reads_behind_a_gap(len(big), dsz) == 0
+    assert H.hc_bt4_reads_behind_a_gap(1 << 30, 1 << 30) == 0                                       # BASELINE config 4: no fill is short
+    assert H.hc_bt4_reads_behind_a_gap((1 << 30) + 1605632, (1 << 30) + 1605632) == 1               # an entry beyond 256 MiB whose last fill is
 
 
 def test_every_variant_is_taken():

@@ -32,8 +32,16 @@ class Method:
     LZMA_0, LZMA_1, LZMA_2, LZMA_3 = 15, 16, 17, 18
 
 
+E_REFERENCE = -6     # zada.h ZADA_E_REFERENCE: LZMA_3, the reference's own matcher reports a match that is none on this entry
+
+
 class ZadaError(RuntimeError):
     pass
+
+
+class ReferenceDefect(ZadaError):
+    """ZADA_E_REFERENCE: on this LZMA_3 entry the reference's BT4 matcher reports a match that is none (include/zada.h); the reference's own
+    stream would not decode to the input, nothing was written."""
 
 
 class CompressionInefficient(Exception):
@@ -163,6 +171,8 @@ class Encoder:
             raise ZadaError("unknown knob %r" % name)
 
     def _err(self, rc, what):
+        if rc == E_REFERENCE:
+            raise ReferenceDefect("%s: rc=%d (%s)" % (what, rc, self.lib.zada_last_error(self.ctx).decode()))
         raise ZadaError("%s failed: rc=%d (%s)" % (what, rc, self.lib.zada_last_error(self.ctx).decode()))
 
     def deflate(self, data, method=Method.Deflate_3, crc=0xFFFFFFFF, feedback=None):
@@ -262,7 +272,7 @@ class Encoder:
         rcs = np.zeros(cnt, dtype=np.int32)
         worst = self.lib.zada_lzma_batch(self.ctx, method, cnt, ins.ctypes.data, lens.ctypes.data, outp.ctypes.data, caps.ctypes.data,
                                          ols.ctypes.data, crcs.ctypes.data, rcs.ctypes.data)
-        if worst < 0:
+        if worst < 0 and not (worst == E_REFERENCE and all(r >= 0 or r == E_REFERENCE for r in rcs)):     # (refused entries: rc -6, no payload)
             self._err(worst, "zada_lzma_batch")
         mv = memoryview(arena)
         return [(int(rcs[i]), bytes(mv[int(offs[i]):int(offs[i]) + int(ols[i])]) if rcs[i] >= 0 and ols[i] <= caps[i] else None, int(crcs[i])) for i in range(cnt)]

@@ -1300,7 +1300,11 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
   for (LzmaJob &j : jobs) {
     j.sbs = lzma_string_buffer_size(j.level, c->knob_lzma_dict > 0 ? (uint64_t)c->knob_lzma_dict : j.n);   // dictionary_size = the entry's size, zip-compress-lzma_e.adb:165
     j.hash4_size = j.level == 3 ? lzma_hash4_size(j.sbs) : 0;
-    j.ws_off = 0;
+    j.verify = 0;
+    if (j.level == 3 && j.n > j.sbs) {                                 // (n <= String_buffer_size: the whole entry in the first fill, nothing is read behind a gap)
+      std::vector<Bt4Run> runs;
+      if (bt4_schedule(j.n, j.sbs, runs) && bt4_reads_behind_a_gap(runs)) j.verify = 1;
+    }
     bt4 = bt4 || (j.level == 3 && j.n > 0);
   }
   int rc = lz_grow(c, &c->lz_tab, &c->cap_lz_tab, (sizeof(LzmaJob) + 16 + 4) * (size_t)E + 192);
@@ -1365,7 +1369,7 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
         if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;
         bool more = false;
         uint64_t coded = 0;
-        for (uint32_t e = 0; e < E; e++) { more = more || (res[2 * e + 1] >> 63); res[2 * e + 1] &= ~(1ull << 63); coded += res[2 * e + 1]; }
+        for (uint32_t e = 0; e < E; e++) { more = more || (res[2 * e + 1] >> 63); res[2 * e + 1] &= ~(1ull << 63); coded += res[2 * e + 1] & ~(1ull << 62); }
         pos = more ? coded : ~0ull;
         if (!more) break;
         if (fb && fb(pct_lo + (int)((uint64_t)(pct_hi - pct_lo) * coded / (total ? total : 1)), user)) {
@@ -1377,8 +1381,15 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
       if (pos == ~0ull) break;
     }
   }
-  for (uint32_t e = 0; e < E; e++) if (res[2 * e + 1] != jobs[e].n) { c->err = "LZMA: the coder did not consume the entry"; return ZADA_E_HIP; }
+  // bit 62 of an entry's second result: ZADA_E_REFERENCE (the callers look at it: lzma_refused)
+  for (uint32_t e = 0; e < E; e++) if (!(res[2 * e + 1] >> 62 & 1) && res[2 * e + 1] != jobs[e].n) { c->err = "LZMA: the coder did not consume the entry"; return ZADA_E_HIP; }
   return 0;
+}
+static bool lzma_refused(Ctx *c, const std::vector<uint64_t> &res, uint32_t e) {
+  if (!(res[2 * (size_t)e + 1] >> 62 & 1)) return false;
+  c->err = "LZMA_3: the reference's matcher reports a match that is none on this entry (positions read behind pending bytes no window fill took up, "
+           "lz77.adb:1000-1017, 1262-1290): its own stream does not decode to the input";
+  return true;
 }
 static int lzma_tokens(Ctx *c, int level, const uint8_t *d_in, uint64_t n, uint64_t *ntok) {     // IZ_6 / IZ_10, lzma-encoding.adb:118-122
   int rc = range_open(c, level == 1 ? ZADA_DEFLATE_1 : ZADA_DEFLATE_3, d_in, n, 0, n, 0, 0);
@@ -1424,6 +1435,7 @@ static int lzma_core(Ctx *c, int method, const uint8_t *d_in, uint64_t n, uint8_
   std::vector<uint64_t> res;
   if ((rc = lzma_run(c, jobs, d_in, n, d_tok, d_out, res, nullptr, 0, nullptr, lzma_budget(c, level), fb, user, pct0, 99))) return rc;
   c->tmark("lzma:end"); c->tend();
+  if (lzma_refused(c, res, 0)) { *out_len = 0; return ZADA_E_REFERENCE; }
   if (fb && fb(100, user)) return ZADA_ABORTED;
   *out_len = res[0];
   if (res[0] > cap) { if (res[0] >= n) return ZADA_INEFFICIENT; c->err = "output buffer too small"; return ZADA_E_INVALID; }
@@ -1542,16 +1554,19 @@ static int lzma_batch_core(Ctx *c, int method, const int *idx, uint32_t E, const
   if (hip_check(c, hipStreamSynchronize(st), "LZMA batch out")) return ZADA_E_HIP;
   c->tmark("lzma:end"); c->tend();
   std::atomic<int> bad(0);
+  std::atomic<int> refused(0);
   parallel_entries(E, ototal, [&](uint32_t e) {
     const int i = idx[e];
     const uint64_t bytes = res[2 * e];
     out_len[i] = bytes;
     if (crc) crc[i] = crc_in[e];
+    if (res[2 * (size_t)e + 1] >> 62 & 1) { rc_out[i] = ZADA_E_REFERENCE; out_len[i] = 0; refused = 1; return; }
     rc_out[i] = bytes >= n[i] ? ZADA_INEFFICIENT : ZADA_OK;
     if (bytes <= cap[i] && bytes <= jobs[e].cap) memcpy(out[i], c->bstage + ostart[e], bytes);
     else if (rc_out[i] == ZADA_OK) { rc_out[i] = ZADA_E_INVALID; bad = 1; }
   });
   if (bad) c->err = "output buffer too small";
+  if (refused) for (uint32_t e = 0; e < E; e++) if (lzma_refused(c, res, e)) break;     // (the error text)
   return 0;
 }
 // Level_1 / Level_2 batches: the tokens of ALL entries from one pass of the LZ stage (the batch layout of batch_core above:

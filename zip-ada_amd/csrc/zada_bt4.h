@@ -233,4 +233,18 @@ template <typename Vec> inline bool bt4_schedule(uint64_t n, uint32_t sbs, Vec &
   return true;
 }
 
+// True when positions are read and inserted while lzPos lags behind readPos -- after pending bytes that no fill took up (a fill of at most
+// keepSizeAfter - 1 = 4 368 bytes, i.e. the last one of a stream, or every one at String_buffer_size 4096; the reference notes the lag at
+// lz77.adb:1010-1012).  From there on a distance taken from the hash tables or the tree into the positions before the gap is short by the gap:
+// the reference compares the bytes at THAT distance, and its hash-2 / hash-3 matches compare only the first byte (:1262-1290, "the hashing
+// algorithm guarantees ...": not across a gap) -- it can report, and code, matches that are none, and its stream then decodes to something
+// else than the input.  With the dictionary Zip.Compress.LZMA_E asks for (the entry's size) the whole entry arrives in the first fill and
+// nothing is read behind a gap; an entry beyond 256 MiB whose last fill brings 163 .. 4 368 bytes is (LZMA.Encoding's default of 32 KiB on
+// longer data as well).  zada_lzma verifies the match sets of such an entry as it reads them and refuses it (ZADA_E_REFERENCE) on the first
+// match that is none.
+template <typename Vec> inline bool bt4_reads_behind_a_gap(const Vec &runs) {
+  for (const Bt4Run &r : runs) if (r.cls == 0 && r.gap > 0 && r.end > r.start) return true;
+  return false;
+}
+
 }  // namespace zada

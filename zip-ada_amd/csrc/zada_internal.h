@@ -310,7 +310,7 @@ struct LzmaJob {
   uint64_t in_off, n;               // the entry
   uint64_t tok_off, ntok;           // its LZ77 tokens (Level_1 / Level_2)
   uint64_t out_off, cap;            // where the stream goes (the bytes beyond cap are counted, not written)
-  uint64_t ws_off;                  // (unused: BT4's tables live with the producer, zada_bt4.hip)
+  uint64_t verify;                  // Level_3: 1 = the coder checks every match of the sets it reads against the text (bt4_reads_behind_a_gap, zada_bt4.h)
   uint32_t sbs, hash4_size;         // String_buffer_size (lzma-encoding.adb:137-149), BT4's hash4 size (lz77.adb:1019-1032)
   int32_t level, zip_prefix;        // 0 .. 3; 1: the four bytes of zip-compress-lzma_e.adb:155-158 go first
 };

@@ -59,6 +59,7 @@ struct Enc {
   MS ES;
   uint32_t width; uint64_t low; uint32_t cache; uint64_t cache_size;      // Range_Encoder :952-957
   uint8_t *out; uint64_t cap, olen;
+  uint32_t verify, defect;                     // Level_3: check the match sets against the text (LzmaJob::verify) / a match that is none was found
 };
 // The encoder's state as well: every lane holds the same values outside the forks, the simulations only read it.  (As a local of
 // the kernel it was reached through a pointer into scratch: a flat load, 100+ cycles and both wait counters, per field read.)
@@ -846,6 +847,13 @@ __device__ __noinline__ void bt_get_matches(int set) {
     M.len[i + 1] = (uint16_t)l; M.dist[i + 1] = (int)d;
   }
   M.count = cnt;
+  if (s_E.verify) {
+    // (a stream that reads positions behind a gap of never-inserted ones: the reference's distances into the text before the gap are short by
+    // the gap and its hash-2 / hash-3 matches are not compared beyond their first byte -- a match that is none ends the stream, zada_bt4.h)
+    bool bad = false;
+    if (i < cnt) bad = bt_extend(s_E.in + s_B.moved, (int64_t)s_B.readPos - (int64_t)d, s_B.readPos, 0, (int)l) < (int)l;
+    if (__any(bad)) s_E.defect = 1;
+  }
   __syncthreads();
 }
 
@@ -1071,6 +1079,7 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
     s_E.ES.rep[0] = s_E.ES.rep[1] = s_E.ES.rep[2] = s_E.ES.rep[3] = 0;
     s_E.width = 0xFFFFFFFFu; s_E.low = 0; s_E.cache = 0; s_E.cache_size = 1;
     s_E.out = out_base + J.out_off; s_E.cap = J.cap; s_E.olen = 0;
+    s_E.verify = J.level == 3 ? (uint32_t)J.verify : 0u; s_E.defect = 0;
     if (J.zip_prefix) { put_byte(16); put_byte(2); put_byte(5); put_byte(0); }   // zip-compress-lzma_e.adb:155-158
     put_byte(3 + 9 * 0 + 45 * 2);                                                   // Write_LZMA_header :1513-1536
     for (int i = 0; i < 4; i++) put_byte((J.sbs >> (8 * i)) & 255);
@@ -1083,6 +1092,11 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   // One loop for the three sources of symbols -- No_LZ77 (level 0: every byte a literal), the tokens of the Info-Zip matcher (levels 1, 2)
   // and Get_Next_Symbol of LZ77_using_BT4 (lz77.adb:1798-1827) -- so that the emission is inlined once.
   for (;;) {
+    if (s_E.defect) {                                                 // (ZADA_E_REFERENCE: nothing more is coded)
+      if (S && threadIdx.x == 0) S->phase = 2;
+      if (threadIdx.x == 0) { result[2 * job] = 0; result[2 * job + 1] = s_E.ES.pos | (1ull << 62); }
+      return;
+    }
     if (s_E.ES.pos >= stop) { done = false; break; }
     Symbol sy;
     if (J.level == 0) {
