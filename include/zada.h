@@ -218,6 +218,8 @@ int zada_bzip2_batch(zada_ctx *ctx, int method, int count, const uint8_t *const 
  * input byte of the call, kept by the context).  A stream runs as a sequence of bounded launches (about half a second each,
  * "lzma_chunk"), the coder's state waiting in device memory in between: fb (may be NULL) is called with 0, between the launches
  * and with 100, and a non-zero return ends the call with ZADA_ABORTED (Feedback / User_abort, zip-compress-lzma_e.adb:78-92).
+ * LZMA_3 can also return ZADA_E_REFERENCE (see the enum: an entry on which the reference's own matcher leaves the format -- not with the dictionary
+ * Zip.Compress.LZMA_E asks for unless the entry is beyond 256 MiB; per entry in zada_lzma_batch's rc array).
  * Limits: entries below 2 GiB - 64 KiB (ZADA_E_TOO_LARGE beyond: the shim Stores such an entry or raises); only the
  * (lc, lp, pb) = (3, 0, 2) methods LZMA_0 .. LZMA_3, not the data-specific LZMA_for_* variants (ZADA_E_INVALID).
  * --------------------------------------------------------------------------------------------------------------- */
