@@ -326,3 +326,48 @@ def test_soak_seed_lzma(encoder, seed):
         for i, (d, got) in enumerate(zip(datas, encoder.lzma_batch(datas, m))):
             assert got == oracle_lzma(d, m), (m, i, len(d))
             assert lzma_decode(got[1], 4) == d
+
+
+@pytest.mark.parametrize("seed", (4242,))
+def test_soak_seed_lzma_stream(encoder, seed):
+    """ONE LZMA_3 stream per case, coded in launches with the match producer in segments: random sizes, segment sizes ("lzma_segment"), launch
+    budgets ("lzma_chunk") and dictionaries below the stream's size (window fills, moves; knob "lzma_dict") on corpus, periodic, few-symbol and
+    random data -- the first ten cases of tests/gpu_lzma_soak_stream.py (the script that found the reference's defect behind unprocessed pending
+    bytes).  Every payload == the oracle's and decodes; an entry the product refuses (ZADA_E_REFERENCE) is one whose reference
+    stream does not decode to the input, or that the sequential matcher's own sets show a match that is none for."""
+    from _lzmah import oracle_lzma_encode, lzma_decode, lzma_symbols
+    za = product()
+    mix = za.silesia_mix(32 << 20)
+    rng = np.random.default_rng(seed)
+    coded = 0
+    try:
+        for k in range(10):
+            n = int(rng.integers(20000, 2_500_000))
+            kind = int(rng.integers(0, 7))
+            if kind <= 3:
+                o = int(rng.integers(0, len(mix) - n - 1)); d = bytes(mix[o:o + n])
+            elif kind == 4:
+                per = bytes(rng.integers(0, 256, int(rng.integers(1, 70000)), dtype=np.uint8)); d = (per * (n // len(per) + 1))[:n]
+            elif kind == 5:
+                d = bytes((rng.integers(0, int(rng.integers(2, 6)), n) + 65).astype(np.uint8))
+            else:
+                n = min(n, 400000); d = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+            seg = int(rng.choice([-1, 0, 13, 14, 15, 16, 17, 18, 19, 20]))
+            chunk = int(rng.choice([0, 0, 4096, 10000, 65536, 200000]))
+            ds = int(rng.choice([0, 0, 0, 5000, 70000, 300000]))
+            if ds >= n:
+                ds = 0
+            encoder.set_knob("lzma_segment", seg); encoder.set_knob("lzma_chunk", chunk); encoder.set_knob("lzma_dict", ds)
+            want, _ = oracle_lzma_encode(d, 3, dictionary_size=ds or None)
+            try:
+                rc, z, crc = encoder.lzma(d, 18)
+            except za.ReferenceDefect:
+                assert ds and lzma_symbols(want)[0] != d, (k, n, ds)
+                continue
+            assert z == bytes([16, 2, 5, 0]) + want, (k, n, kind, seg, chunk, ds)
+            assert lzma_decode(z, 4) == d
+            coded += 1
+    finally:
+        for kn in ("lzma_segment", "lzma_chunk", "lzma_dict"):
+            encoder.set_knob(kn, 0)
+    assert coded >= 8
