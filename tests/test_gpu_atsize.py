@@ -371,3 +371,28 @@ def test_soak_seed_lzma_stream(encoder, seed):
         for kn in ("lzma_segment", "lzma_chunk", "lzma_dict"):
             encoder.set_knob(kn, 0)
     assert coded >= 8
+
+
+def test_host_path_with_the_input_still_arriving_equals_the_device_path(encoder):
+    """zada_deflate on host buffers of 64 MiB and more copies the input in on background lanes while the link stage already runs on what has
+    come, 64 MiB at a time (zada_api.hip Arrival, zada_lz.hip lz_shard `job.need`: k_prev_links and k_bucket_limits piece by piece,
+    k_cross_links too when the pieces come slowly): sizes around the pieces' edges, Deflate_1 and Deflate_3 -- the stream == the
+    device-resident entry point's on the same bytes and inflates to the input (tests/gpu_hostpath_soak.py has more sizes)."""
+    import torch
+    za = product()
+    M = 1 << 20
+    sizes = [64 * M + 1, 64 * M + 32768 + 63, 96 * M - 5, 128 * M + 65]
+    base = za.silesia_mix(max(sizes) + 64, seed=77)
+    for n in sizes:
+        for method in (8, 10):
+            host = base[7:7 + n].copy()
+            hout = np.zeros(n + 64, dtype=np.uint8)
+            got = encoder.deflate_into(host, hout, method)
+            t_in = torch.from_numpy(host).cuda()
+            t_out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+            dev = encoder.deflate_device(t_in.data_ptr(), n, t_out.data_ptr(), t_out.numel(), method)
+            assert got == dev and got[0] == 0, (n, method, got, dev)
+            assert np.array_equal(hout[:got[1]], t_out[:dev[1]].cpu().numpy()), (n, method)
+            c, tot, eof = _inflate_crc(bytes(hout[:got[1]]))
+            assert tot == n and eof and c == zlib.crc32(host) == (got[2] ^ 0xFFFFFFFF)
+            del t_in, t_out
