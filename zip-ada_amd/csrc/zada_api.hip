@@ -1285,7 +1285,8 @@ static void lzma_free(Ctx *c) {
 // segment k + 1 are found (stream2) while the coder -- one wave -- codes segment k: of all the producer's time, only segment 0's is waited for.
 static uint32_t lzma_segment_shift(const Ctx *c, uint64_t n) {
   if (c->knob_lzma_segment < 0) return 32;
-  const uint32_t sh = c->knob_lzma_segment > 0 ? (uint32_t)c->knob_lzma_segment : 20;
+  // (by size: 2 ** 20 positions from 2 MiB on, 2 ** 18 from 512 KiB on -- the walks of a small segment are launch overhead and short buckets' tails)
+  const uint32_t sh = c->knob_lzma_segment > 0 ? (uint32_t)c->knob_lzma_segment : n >= (2ull << 20) ? 20 : 18;
   return n >= (2ull << sh) ? sh : 32;                                // (fewer than two segments: nothing to overlap)
 }
 // jobs: sbs / hash4_size are filled here.  res: 2 per job (stream bytes, input bytes coded).  arena_bytes: the bytes at d_in that hold
