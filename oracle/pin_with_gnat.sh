@@ -35,4 +35,15 @@ cp -r "$REF" "$WORK/ref"
 ( cd "$WORK/ref" && if command -v gprbuild >/dev/null 2>&1; then gprbuild -q -p -P zipada.gpr -XZip_Build_Mode=Fast zipada.adb; else gnatmake -q -O2 -Izip_lib -Itools tools/zipada.adb; fi )
 ZIPADA=$(find "$WORK/ref" -type f -name 'zipada*' -perm -u+x | head -1)
 [ -n "$ZIPADA" ] || { echo "zipada was not built"; exit 2; }
+# The reference's defect behind unprocessed pending bytes: its own encoder on tests/golden/lzma_defect_input_12000.bin with a
+# 5 000-byte dictionary must write the stream the oracle writes (tests/golden/lzma_defect.json) -- which does not decode to the input.
+( cd "$WORK/ref" && cp "$HERE/pin_lzma_defect.adb" . && gnatmake -q -O2 -Izip_lib pin_lzma_defect.adb 2>/dev/null ) && {
+  "$WORK/ref/pin_lzma_defect" "$ROOT/tests/golden/lzma_defect_input_12000.bin" "$WORK/defect.lzma" 5000
+  python3 - "$WORK/defect.lzma" "$ROOT/tests/golden/lzma_defect.json" <<'PY'
+import hashlib, json, sys
+z = open(sys.argv[1], "rb").read(); want = json.load(open(sys.argv[2]))
+same = hashlib.sha256(z).hexdigest() == want["stream_sha256"]
+print("LZMA_3, dictionary 5000 on 12 000 bytes: the Ada encoder's stream %s the oracle's (%d bytes; the oracle's does not decode to the input)" % ("EQUALS" if same else "DIFFERS FROM", len(z)))
+PY
+} || echo "pin_lzma_defect.adb was not built (the defect check is skipped)"
 exec python3 "$HERE/pin_compare.py" "$ZIPADA" "$WORK" "$ROOT"

@@ -88,6 +88,10 @@ def test_reference_defect_behind_pending_bytes_no_fill_took_up():
     x = bytes(lz_inputs()["mix_256k"][:12000])         # dictionary 5000 -> String_buffer_size 8192: fills of 8 192 and 3 808 bytes
     z, _ = oracle_lzma_encode(x, 3, dictionary_size=5000)
     out, syms = lzma_symbols(z)
+    # (the committed vector oracle/pin_with_gnat.sh holds against the Ada encoder itself: oracle/pin_lzma_defect.adb)
+    gold = json.load(open(os.path.join(GOLDEN, "lzma_defect.json")))
+    assert open(os.path.join(GOLDEN, "lzma_defect_input_12000.bin"), "rb").read() == x and hashlib.sha256(x).hexdigest() == gold["input_sha256"]
+    assert (len(z), hashlib.sha256(z).hexdigest(), out == x, hashlib.sha256(out).hexdigest()) == (gold["stream_bytes"], gold["stream_sha256"], gold["decodes_to_input"], gold["decoded_sha256"])
     assert len(out) == len(x) and out != x and syms[-1][1] == "E"
     p = next(i for i in range(len(x)) if out[i] != x[i])
     assert p >= 8192                                                                              # behind the gap (the first fill's last 162 positions)
