@@ -11,11 +11,18 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
 shutil.copy(os.path.join(G, tag + "_bench.json"), os.path.join(P, "bench_1gib.json"))
-shutil.copy(glob.glob(os.path.join(G, tag + "_stats", "*", "*_kernel_stats.csv"))[0], os.path.join(P, "bench_1gib_kernel_stats.csv"))
+def newest(pattern):
+    """The files of the LAST run of a pass only: gpurun merges a call's output into gpurun_out/ next to what earlier calls left there, and two
+    runs' counters must not be added up."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
+shutil.copy(newest(os.path.join(G, tag + "_stats", "*", "*_kernel_stats.csv"))[0], os.path.join(P, "bench_1gib_kernel_stats.csv"))
 out = {}
 for ctr, sub in (("FETCH_SIZE", "_fetch"), ("WRITE_SIZE", "_write")):
     acc = {}
-    for f in glob.glob(os.path.join(G, tag + sub, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(G, tag + sub, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != ctr:
                 continue
@@ -29,7 +36,7 @@ out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes 
 json.dump(out, open(os.path.join(P, "pmc_fetch_write_by_kernel.json"), "w"), indent=1)
 # SQ counters: what the kernels that are nowhere near the HBM roofline are bound by
 sq = {}
-for f in glob.glob(os.path.join(G, tag + "_sq", "*", "*_counter_collection.csv")):
+for f in newest(os.path.join(G, tag + "_sq", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("zada::", "")
         a = sq.setdefault(name, {})
