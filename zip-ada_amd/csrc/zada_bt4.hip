@@ -496,6 +496,9 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   return 0;
 }
 
+#ifndef ZADA_SEG_NBLK
+#define ZADA_SEG_NBLK 2048
+#endif
 // The walks of segment k of the stream bt4_produce prepared in segments, on `st` (no wait: the caller orders the coder behind them).
 int bt4_walk_segment(Ctx *c, uint32_t k, hipStream_t st) {
   State *B = (State *)c->bt4;
@@ -508,7 +511,7 @@ int bt4_walk_segment(Ctx *c, uint32_t k, hipStream_t st) {
   hipLaunchKernelGGL(k_bt4_split, dim3((i1 - i0 + 255) / 256), dim3(256), 0, st, B->heads.as<uint32_t>(), B->order, T, cnts + 5, cnts, B->longs.as<uint2>(), B->shorts.as<uint2>(),
                      B->flags.as<uint32_t>(), i0, i1);
   const Sets S{B->cnt.as<uint8_t>(), B->sl.as<uint16_t>(), B->sd.as<uint32_t>(), B->ol.as<uint16_t>(), B->od.as<uint32_t>(), B->ovf_cap};
-  const uint32_t nblk = (i1 - i0 + 255) / 256 < 2048 ? (i1 - i0 + 255) / 256 : 2048;
+  const uint32_t nblk = (i1 - i0 + 255) / 256 < ZADA_SEG_NBLK ? (i1 - i0 + 255) / 256 : ZADA_SEG_NBLK;
   hipLaunchKernelGGL(k_bt4_walk, dim3(nblk), dim3(256), 0, st, B->arena, B->rec.as<uint4>(), B->longs.as<uint2>(), B->shorts.as<uint2>(), cnts, T, B->tree.as<int32_t>(), S,
                      B->htab.as<int32_t>(), B->k4.as<uint32_t>());
   return hip_check(c, hipGetLastError(), "k_bt4_walk (segment)") ? ZADA_E_HIP : 0;
