@@ -261,12 +261,27 @@ def test_reference_defect_is_refused_not_written(encoder):
         rc, z, crc = encoder.lzma(r, 18)
         want, _ = oracle_lzma_encode(r, 3, dictionary_size=5000)
         assert z == bytes([16, 2, 5, 0]) + want and lzma_decode(z, 4) == r
+        # refused in the middle of a stream whose producer works in segments (the walks of the next segment are under way when the coder gives
+        # up): the call after it finds the context's buffers its own
+        big = bytes(m[:250000])
+        encoder.set_knob("lzma_dict", 70000)                  # String_buffer_size 131 072: the second (last) fill brings 118 928 bytes -- no gap
+        encoder.set_knob("lzma_segment", 13)
+        want_big, _ = oracle_lzma_encode(big, 3, dictionary_size=70000)
+        assert encoder.lzma(big, 18)[1] == bytes([16, 2, 5, 0]) + want_big
+        tail = bytes(m[:135000])                              # ... 3 928 bytes: read behind a gap, in the 17th segment
+        encoder.set_knob("lzma_dict", 70000)
+        with pytest.raises(Z.ReferenceDefect):                # (the oracle's stream for it does not decode to the input)
+            encoder.lzma(tail, 18)
+        assert encoder.lzma(big, 18)[1] == bytes([16, 2, 5, 0]) + want_big
+        encoder.set_knob("lzma_segment", 0)
+        encoder.set_knob("lzma_dict", 5000)
         # a batch: the refused entries say so, the others are coded
         res = encoder.lzma_batch([x, r, x[:5000], bytes(m[50000:70000])], 18)
         assert [t[0] for t in res] == [Z.E_REFERENCE, 0, 0, Z.E_REFERENCE] and res[0][1] is None and res[3][1] is None
         assert res[1][1] == z and res[2] == encoder.lzma(x[:5000], 18)
     finally:
         encoder.set_knob("lzma_dict", 0)
+        encoder.set_knob("lzma_segment", 0)
     assert encoder.lzma(x, 18) == oracle_lzma(x, 18)
 
 

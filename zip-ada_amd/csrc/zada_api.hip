@@ -1381,6 +1381,9 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
       }
       if (pos == ~0ull) break;
     }
+    // (a stream that ended before its last segment -- refused, ZADA_E_REFERENCE -- leaves the walks of the next segment under way: they write into
+    // the context's buffers, which the next call fills again)
+    if (nseg && hip_check(c, hipStreamSynchronize(c->stream2), "k_bt4_walk (segment)")) return ZADA_E_HIP;
   }
   // bit 62 of an entry's second result: ZADA_E_REFERENCE (the callers look at it: lzma_refused)
   for (uint32_t e = 0; e < E; e++) if (!(res[2 * e + 1] >> 62 & 1) && res[2 * e + 1] != jobs[e].n) { c->err = "LZMA: the coder did not consume the entry"; return ZADA_E_HIP; }
