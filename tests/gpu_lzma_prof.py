@@ -11,3 +11,11 @@ for off, kib in ((0, 16), (1 << 20, 16), (0, 64), (0, 1024)):
     print("== offset", off, "KiB", kib, flush=True)
     r = enc.lzma_batch([d], 18)
     print("ratio %.3f" % (len(r[0][1]) / len(d)), flush=True)
+# the same entries as ONE stream each through zada_lzma (launches of 64 Ki positions: one line per launch): the chain's wave alone, and with three helpers
+for waves in (1, 4):
+    enc.set_knob("lzma_waves", waves)
+    for off, kib in ((0, 16), (0, 64)):
+        d = bytes(mix[off:off + (kib << 10)])
+        print("== zada_lzma, waves", waves, "KiB", kib, flush=True)
+        enc.lzma(d, 18)
+enc.set_knob("lzma_waves", 0)

@@ -999,6 +999,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   // per handful of bytes -- the tests go down to 777)
   else if (!strcmp(name, "lzma_chunk")) { if (value < -1 || (value > 0 && value < 256)) return ZADA_E_INVALID; z->c.knob_lzma_chunk = value; }
   else if (!strcmp(name, "lzma_pool")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_lzma_pool = value; }
+  else if (!strcmp(name, "lzma_waves")) { if (value != 0 && value != 1 && value != 4) return ZADA_E_INVALID; z->c.knob_lzma_waves = value; }
   else if (!strcmp(name, "lzma_segment")) { if (value < -1 || (value > 0 && (value < 13 || value > 30))) return ZADA_E_INVALID; z->c.knob_lzma_segment = value; }
   else return ZADA_E_INVALID;
   return ZADA_OK;
@@ -1342,6 +1343,8 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
     // (segments: the coder stops LZ_SEG_MARGIN positions short of a segment whose sets are still being written -- a step of its loop looks at
     // the sets of fewer than 2 x 273 positions beyond the one it codes)
     constexpr uint64_t LZ_SEG_MARGIN = 4096;
+    // one LZMA_3 stream alone: its workgroup gets four waves, the chain's and three helpers for its forks (zada_lzma.hip "one stream on four waves")
+    const int waves = E == 1 && bt4 && (c->knob_lzma_waves == 0 || c->knob_lzma_waves == 4) ? 4 : 1;
     uint32_t k = 0;                                                  // segments whose sets are there
     uint64_t cap = ~0ull;
     if (seg_shift < 32 && (rc = bt4_walk_segment(c, 0, c->stream2))) return rc;
@@ -1364,7 +1367,7 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
       }
       uint64_t pos = 0;
       for (;;) {                                                     // the launches up to `cap`
-        if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, sets, d_res, (uint8_t *)c->lz_save, budget, cap))) return rc;
+        if ((rc = lzma_launch(c, d_jobs, d_order, E, d_in, d_tok, d_out, sets, d_res, (uint8_t *)c->lz_save, budget, cap, waves))) return rc;
         c->lzma_launches++;
         hipMemcpyAsync(res.data(), d_res, 16 * (size_t)E, hipMemcpyDeviceToHost, c->stream);
         if (hip_check(c, hipStreamSynchronize(c->stream), "k_lzma_encode")) return ZADA_E_HIP;

@@ -255,6 +255,7 @@ struct Ctx {
   void *bt4 = nullptr;                               // ... the BT4 match producer's buffers (zada_bt4.hip), made on first use
   uint32_t bt4_buckets = 0, bt4_long = 0, bt4_overflow = 0;   // last producer run: hash-4 buckets, long ones among them, overflow blocks booked
   uint32_t bt4_reruns = 0;                           // walks repeated with a larger overflow pool (since the context was made)
+  int knob_lzma_waves = 0;                           // LZMA_3, one stream: waves of its workgroup (0 = by the call: 4 for zada_lzma, 1 = the chain's wave alone)
   int knob_lzma_segment = 0;                         // LZMA_3, one stream: log2 of the positions per producer segment (0 = 20, -1 = no segments)
   int knob_lzma_pool = 0;                            // LZMA_3 test knob: blocks of the match sets' overflow pool to start with (0 = by size)
   // timing
@@ -326,7 +327,7 @@ uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size);
 uint32_t lzma_hash4_size(uint32_t sbs);
 int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, const uint32_t *d_ent_start, LzmaJob *d_jobs);
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
-                uint8_t *d_save = nullptr, uint64_t budget = 0, uint64_t pos_cap = ~0ull);
+                uint8_t *d_save = nullptr, uint64_t budget = 0, uint64_t pos_cap = ~0ull, int waves = 1);
 uint64_t lzma_save_stride();
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);

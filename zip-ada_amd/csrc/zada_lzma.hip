@@ -65,6 +65,15 @@ struct Enc {
 // the kernel it was reached through a pointer into scratch: a flat load, 100+ cycles and both wait counters, per field read.)
 __shared__ Enc s_E;
 
+// A stream's workgroup is one wave -- or four ("helpers", one stream alone on the chip: k_lzma_encode): the chain is walked by wave 0 only,
+// the other waves run shares of its forks.  lane_id: the lane within the wave; chain_sync: between the lanes of the wave that walks the chain.
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// (HW: the kernel's template parameter -- the one-wave kernel of the batches holds none of the helpers' code)
+template <bool HW> __device__ __forceinline__ void chain_sync() {
+  if constexpr (!HW) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+}
+
 #ifdef ZADA_LZ_PROF
 __device__ unsigned long long g_lzprof[8];
 #define PROF_T0 const unsigned long long prof_t0 = clock64()
@@ -332,9 +341,11 @@ template <int R> __device__ void sim_any(uint32_t distance, int length, MS &sim,
 // Where the reference compares INDEPENDENT simulations -- literal + code against code + literal (:783-805), the cuts of
 // Test_Split_DL (:924-943) -- the lanes part: one simulation each, from their own copy of the state, nothing written but the
 // result; the results are then compared by all lanes in the reference's order.  Same doubles, a shorter critical path.
-template <int NEW, bool PAR> __device__ __forceinline__ int decide(uint32_t distance, int length, const MS &sim, int &best_cut, StrictRes &strict) {
+__device__ int decide_with_helpers(uint32_t distance, int length, const MS &sim, int &best_cut);
+template <int NEW, bool PAR, bool HW = false> __device__ __forceinline__ int decide(uint32_t distance, int length, const MS &sim, int &best_cut, StrictRes &strict) {
+  if constexpr (PAR && HW) return decide_with_helpers(distance, length, sim, best_cut);
   double strict_dlc = 0.0, expanded_dlc = 0.0, soe = 0.0;
-  [[maybe_unused]] const int lane = (int)threadIdx.x;
+  [[maybe_unused]] const int lane = lane_id();
   if (s_E.cv >= 1) {
 #ifdef ZADA_LZ_PROF
     const unsigned long long prof_a = clock64();
@@ -639,7 +650,7 @@ __device__ __noinline__ void write_strict(uint32_t distance, int length) {   // 
 // still to be written at `distance`, or the literal that follows a shortened match (:797-805).
 __shared__ uint16_t s_work[2 * 280];                                   // (every lane pushes and pops the same items: one copy in LDS, not 64 in scratch)
 // (inlined at its one call site, the kernel's main loop: as a function of its own it saved and restored 42 registers per call)
-__device__ __forceinline__ void emit_dl(uint32_t distance, int length0) {
+template <bool HW> __device__ __forceinline__ void emit_dl(uint32_t distance, int length0) {
   PROF_T0;
   constexpr uint16_t POST_LIT = 0xFFFF;
   uint16_t *stack = s_work;
@@ -651,7 +662,7 @@ __device__ __forceinline__ void emit_dl(uint32_t distance, int length0) {
     const int length = it;
     int cut = 2;
     StrictRes strict;
-    switch (decide<2, true>(distance, length, s_E.ES, cut, strict)) {
+    switch (decide<2, true, HW>(distance, length, s_E.ES, cut, strict)) {
       case W_LIT_DL:
         emit_literal(TB((int64_t)s_E.ES.pos - (int64_t)distance));
         stack[sp++] = (uint16_t)(length - 1);
@@ -712,7 +723,7 @@ __device__ inline bool score2_takes(int m, int i, int start) {
   return last_pos_i >= start && last_pos_i >= s_S.last_pos_any;
 }
 __device__ __noinline__ double scoring2(MS state, int start) {
-  const int tw = state.tw, lane = (int)threadIdx.x, tl = lane & (tw - 1);
+  const int tw = state.tw, lane = lane_id(), tl = lane & (tw - 1);
   const int c0 = s_MM[0].count, total = c0 + s_MM[1].count;
   int nq = 0;
   for (int k = 0; k < total; k++) nq += score2_takes(k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1, start) ? 1 : 0;
@@ -737,10 +748,159 @@ __device__ __noinline__ double scoring2(MS state, int start) {
   return best;
 }
 
+
+// ---------------------------------------------------------------- one stream on four waves ("helpers")
+//
+// A stream alone on the chip (zada_lzma: config 4's shape) leaves 255 CUs and three of its own CU's SIMDs idle while ONE wave walks the
+// chain.  Teams of lanes shorten the chain only where the simulations they run take the same path -- a wave executes the union of its
+// lanes' paths; DIFFERENT simulations side by side need different waves.  With blockDim.x = 256 wave 0 walks the chain as ever and posts
+// its two forks -- the ways of writing a code (decide: the literal / shortened-code pair and the cuts, :783-805, 924-943) and Scoring's
+// candidates (:1404-1468) -- in LDS; waves 1 .. 3 wait at a barrier, take their shares (a whole wave per simulation of the pair, the cuts
+// and the candidates dealt over the waves: wider teams inside them as well), leave the results in LDS and wait again.  The model, the match
+// sets and the coder's state are LDS objects of the workgroup already; the helpers only read them.  Same doubles, compared by wave 0 in the
+// reference's order.
+struct HelpArgs {
+  int cmd;                                       // 0: the stream is over (or parked), 1: decide, 2: Scoring
+  uint32_t distance; int length, pair, nc;
+  Cuts cuts;
+  MS sim, after;
+  double malus_dtl, malus, soe;
+  int total;
+};
+__shared__ HelpArgs s_H;
+__shared__ double s_Hp[2 * LZ_MAXM + 2][2];      // decide: [0] / [1] the pair, [2 + k] cut k (after its first part, at its end); Scoring: [k] candidate k
+constexpr int HELP_WAVES = 4;
+
+// the cuts [k0, k1) of the posted decision, a team each
+__device__ void help_cuts(int k0, int k1) {
+  const int n = k1 - k0, lane = lane_id();
+  if (n <= 0) return;
+  const int tw = team_width(n), task = lane / tw;
+  if (task < n) {
+    const int cut = cut_at(s_H.cuts, k0 + task);
+    double p = s_H.malus;
+    MS v = s_H.sim;
+    v.tw = tw;
+    sim_any<1>(s_H.distance, cut, v, p);
+    const double pm = p;
+    if (!(p <= s_H.soe)) sim_any<1>(s_H.distance, s_H.length - cut, v, p);
+    if ((lane & (tw - 1)) == 0) { s_Hp[2 + k0 + task][0] = pm; s_Hp[2 + k0 + task][1] = p; }
+  }
+}
+// wave w's share of the posted decision: with a pair, waves 1 and 2 take its two simulations and waves 0 and 3 the cuts; without, all four the cuts
+__device__ void help_decide(int w) {
+  const int nc = s_H.nc;
+  if (s_H.pair) {
+    if (w == 1 || w == 2) {
+      const int t = w - 1;
+      MS v = t == 0 ? s_H.after : s_H.sim;
+      v.tw = 64;
+      double p = t == 0 ? 1.0 : s_H.malus_dtl;
+      sim_any<2>(s_H.distance, s_H.length - 1, v, p);
+      if (t == 1) sim_literal(TB((int64_t)v.pos - (int64_t)s_H.distance), v, p);
+      if (lane_id() == 0) s_Hp[t][0] = p;
+    } else {
+      const int j = w == 0 ? 0 : 1;
+      help_cuts(nc * j / 2, nc * (j + 1) / 2);
+    }
+  } else help_cuts(nc * w / HELP_WAVES, nc * (w + 1) / HELP_WAVES);
+}
+// wave w's share of Scoring's candidates: w, w + 4, ...
+__device__ void help_score(int w) {
+  const int lane = lane_id(), c0 = s_MM[0].count, total = s_H.total;
+  const int mine = total > w ? (total - w + HELP_WAVES - 1) / HELP_WAVES : 0;
+  if (mine == 0) return;
+  const int tw = team_width(mine), per_round = 64 / tw;
+  MS st = s_H.sim;
+  st.tw = tw;
+  for (int base = 0; base < mine; base += per_round) {
+    const int idx = base + lane / tw;
+    if (idx < mine) {
+      const int k = w + HELP_WAVES * idx;
+      const double p = score_candidate<1>(st, 1, k < c0 ? 0 : 1, (k < c0 ? k : k - c0) + 1);
+      if ((lane & (tw - 1)) == 0) s_Hp[k][0] = p;
+    }
+  }
+}
+__device__ void helper_loop(int w) {
+  for (;;) {
+    __syncthreads();                                                   // (A) a fork is posted
+    const int cmd = s_H.cmd;
+    if (cmd == 0) return;
+    if (cmd == 1) help_decide(w); else help_score(w);
+    __syncthreads();                                                   // (B) the shares are done
+  }
+}
+template <bool HW> __device__ __forceinline__ void helpers_release() {                  // wave 0, before it leaves the kernel
+  if constexpr (HW) {
+    if (lane_id() == 0) s_H.cmd = 0;
+    __syncthreads();
+  }
+}
+
+// decide <2, true> of the wave that walks the chain, its independent simulations on the helpers
+__device__ int decide_with_helpers(uint32_t distance, int length, const MS &sim, int &best_cut) {
+  const StrictRes strict = strict_factors(distance, length, sim);
+  const double strict_dlc = strict.f1 * strict.f2;
+  const double expanded_dlc = test_expanded(distance, length, strict_dlc, sim);
+  const double soe = strict_dlc > expanded_dlc ? strict_dlc : expanded_dlc;
+  const bool pair = length > 2;
+  double head_lit = 0.0, malus_dtl = 0.0;
+  MS after = sim;
+  if (pair) {
+    const uint32_t b_head = TB((int64_t)sim.pos - (int64_t)distance);
+    head_lit = test_literal_byte(b_head, sim);
+    if (head_lit >= 0.875) return W_LIT_DL;                                          // Lit_then_DL_threshold :306
+    after.state = t_lit(sim.state); after.pos = sim.pos + 1; after.pos_state = (uint32_t)after.pos & LZ_PBM; after.prev_byte = b_head;
+    malus_dtl = fmax0(0.135 - (double)distance * 1.0e-8 - (double)length * 1.0e-4);  // DL_code_then_Literal :869-889
+  }
+  const double malus = fmax0(0.27 - (double)distance * 2.0e-6);                      // Test_Split_DL :901-944
+  const bool split = s_E.cv >= 2 && !(malus < soe);
+  const Cuts cuts = cuts_of(length);
+  const int nc = split ? cuts.n1 + cuts.n2 : 0;
+  if (!pair && nc == 0) return expanded_dlc > strict_dlc ? W_EXPAND : W_STRICT;
+  if (lane_id() == 0) {
+    s_H.cmd = 1; s_H.distance = distance; s_H.length = length; s_H.pair = pair ? 1 : 0; s_H.nc = nc; s_H.cuts = cuts;
+    s_H.sim = sim; s_H.after = after; s_H.malus_dtl = malus_dtl; s_H.malus = malus; s_H.soe = soe;
+  }
+  __syncthreads();                                                     // (A)
+  help_decide(0);
+  __syncthreads();                                                     // (B)
+  if (pair) {
+    const double dal = s_Hp[0][0], dtl = s_Hp[1][0];
+    if (head_lit * dal * fmax0(0.064 - (double)distance * 1.0e-9 - (double)length * 3.0e-5) > soe) return W_LIT_DL;
+    if (dtl > soe) return W_DL_LIT;
+  }
+  if (expanded_dlc > strict_dlc) return W_EXPAND;
+  double best_prob = 0.0;
+  best_cut = 2;
+  for (int k = 0; k < nc; k++) {
+    const double pmk = s_Hp[2 + k][0], pfk = s_Hp[2 + k][1];
+    if (!(pmk <= soe)) { if (pfk > best_prob) { best_prob = pfk; best_cut = cut_at(cuts, k); } }
+  }
+  if (best_prob > soe) return W_SPLIT;
+  return W_STRICT;
+}
+
+// scoring_top of the wave that walks the chain, the candidates dealt over the four waves
+__device__ void scoring_with_helpers(const MS &state, int &index, int &match_set) {
+  const int c0 = s_MM[0].count, total = c0 + s_MM[1].count;
+  if (lane_id() == 0) { s_H.cmd = 2; s_H.sim = state; s_H.total = total; }
+  __syncthreads();                                                     // (A)
+  help_score(0);
+  __syncthreads();                                                     // (B)
+  double prob = 0.0;
+  for (int kk = 0; kk < total; kk++) {
+    const double pj = s_Hp[kk][0];
+    if (pj > prob) { prob = pj; index = (kk < c0 ? kk : kk - c0) + 1; match_set = kk < c0 ? 0 : 1; }
+  }
+}
+
 // Scoring at level 1, start 1, called from the chain (all lanes in step): every match of both sets is a candidate (their
 // last positions are >= 1), a team of lanes each; the best is then picked by all lanes in the reference's order (first strict maximum).
-__device__ __forceinline__ void scoring_top(const MS &state, int &index, int &match_set) {
-  const int lane = (int)threadIdx.x, c0 = s_MM[0].count, total = c0 + s_MM[1].count;
+template <bool HW> __device__ __forceinline__ void scoring_top(const MS &state, int &index, int &match_set) {
+  if constexpr (HW) { scoring_with_helpers(state, index, match_set); return; }
+  const int lane = lane_id(), c0 = s_MM[0].count, total = c0 + s_MM[1].count;
   const int tw = team_width(total), per_round = 64 / tw;                           // a team of tw lanes per candidate
   MS st = state;
   st.tw = tw;
@@ -758,7 +918,7 @@ __device__ __forceinline__ void scoring_top(const MS &state, int &index, int &ma
   }
 }
 
-__device__ void estimate_dl_codes(int old_index, uint32_t prefix1, int &best_index, int &best_set) {
+template <bool HW> __device__ void estimate_dl_codes(int old_index, uint32_t prefix1, int &best_index, int &best_set) {
   PROF_T0;
   int last_pos_any = 0;
   for (int m = 0; m <= 1; m++)
@@ -770,10 +930,10 @@ __device__ void estimate_dl_codes(int old_index, uint32_t prefix1, int &best_ind
   double head_lit_prob = 1.0;
   sim_literal(prefix1, sim_new, head_lit_prob);
   s_S.old_index = old_index; s_S.last_pos_any = last_pos_any; s_S.sim_new = sim_new; s_S.head_lit_prob = head_lit_prob;
-  __syncthreads();
+  chain_sync<HW>();
   best_index = 1; best_set = old_index;
   const MS sim_old = s_E.ES;
-  scoring_top(sim_old, best_index, best_set);
+  scoring_top<HW>(sim_old, best_index, best_set);
   PROF_ADD(3);
 }
 
@@ -828,7 +988,7 @@ __device__ void bt_skip(int len) {                           // BT4_Algo.Skip :1
 
 // BT4_Algo.Read_One_and_Get_Matches :1234-1361: the set the producer found for this position (none for a pending position: the
 // producer's schedule says so as well, cnt = 0), one match per lane
-__device__ __noinline__ void bt_get_matches(int set) {
+template <bool HW> __device__ __noinline__ void bt_get_matches(int set) {
   Matches &M = s_MM[set];
   M.count = 0;
   const int avail = bt_move_pos();
@@ -836,7 +996,7 @@ __device__ __noinline__ void bt_get_matches(int set) {
   const uint64_t p = s_B.base + (uint64_t)((int64_t)s_B.readPos + s_B.moved);
   // the count and the eight slots next to the position in ONE round trip (slots beyond the count hold nothing, and are not used); only a set of
   // more than seven matches takes a second one, to its overflow block
-  const int i = (int)threadIdx.x;
+  const int i = lane_id();
   const Bt4Sets &S = s_B.sets;
   uint32_t l = 0, d = 0;
   if (i < BT4_INLINE) { l = S.sl[p * BT4_INLINE + i]; d = S.sd[p * BT4_INLINE + i]; }
@@ -854,7 +1014,7 @@ __device__ __noinline__ void bt_get_matches(int set) {
     if (i < cnt) bad = bt_extend(s_E.in + s_B.moved, (int64_t)s_B.readPos - (int64_t)d, s_B.readPos, 0, (int)l) < (int)l;
     if (__any(bad)) s_E.defect = 1;
   }
-  __syncthreads();
+  chain_sync<HW>();
 }
 
 __device__ int bt_fill_window(int len_initial) {             // Fill_Window :1389-1440, Move_Window :1375-1386
@@ -884,10 +1044,10 @@ __device__ inline int bt_match_len(int distance, int limit) {   // Compute_Match
 }
 __device__ inline bool much_smaller(int smallDist, int bigDist) { return (smallDist - 1) < (bigDist - 1) / 128; }   // :1469-1473
 
-__device__ void lz_read_one(int set) {                     // Read_One_and_Get_Matches :1477-1503
+template <bool HW> __device__ void lz_read_one(int set) {                     // Read_One_and_Get_Matches :1477-1503
   PROF_T0;
   s_B.readAhead++;
-  bt_get_matches(set);
+  bt_get_matches<HW>(set);
   s_B.best_len_rep = 0;
   const int a = bt_available(), avail = a < BT_LOOK ? a : BT_LOOK;
   if (avail >= BT_MIN) {
@@ -952,9 +1112,9 @@ __device__ __forceinline__ Symbol lz_send_dl(int distance, int length) {        
 __device__ __forceinline__ Symbol lz_send_literal() { s_B.readAhead--; return Symbol{0, 0u, s_B.cur_literal}; }
 __device__ inline void lz_skip(int len) { PROF_T0; s_B.readAhead += len; bt_skip(len); PROF_ADD(5); }
 
-__device__ __forceinline__ Symbol lz_next_symbol() {       // Get_Next_Symbol :1605-1796
+template <bool HW> __device__ __forceinline__ Symbol lz_next_symbol() {       // Get_Next_Symbol :1605-1796
   constexpr int hurdle = 40;
-  if (s_B.readAhead == -1) lz_read_one(s_B.cur);
+  if (s_B.readAhead == -1) lz_read_one<HW>(s_B.cur);
   s_B.cur_literal = BUF(s_B.readPos);
   const int a = bt_available(), avail = a < BT_LOOK ? a : BT_LOOK;
   if (avail < BT_MIN) return lz_send_literal();
@@ -981,7 +1141,7 @@ __device__ __forceinline__ Symbol lz_next_symbol() {       // Get_Next_Symbol :1
   }
   if (main_len < BT_MIN || avail <= BT_MIN) return lz_send_literal();
   s_B.cur = 1 - s_B.cur;
-  lz_read_one(s_B.cur);
+  lz_read_one<HW>(s_B.cur);
   {
     Matches &C = s_MM[s_B.cur];
     if (C.count > 0) {
@@ -993,7 +1153,7 @@ __device__ __forceinline__ Symbol lz_next_symbol() {       // Get_Next_Symbol :1
       lz_reduce(s_B.cur);
       lz_supplement(s_B.cur);
       int idx = 1, set = 1 - s_B.cur;
-      estimate_dl_codes(1 - s_B.cur, s_B.cur_literal, idx, set);
+      estimate_dl_codes<HW>(1 - s_B.cur, s_B.cur_literal, idx, set);
       if (set == 1 - s_B.cur) { main_len = s_MM[set].len[idx]; main_dist = s_MM[set].dist[idx]; }
       else return lz_send_literal();
     }
@@ -1045,7 +1205,7 @@ template <typename T> __device__ inline void words_in(T &dst, const T *src) {
   for (uint32_t i = threadIdx.x; i < sizeof(T) / 4; i += 64) d[i] = s[i];
 }
 
-__global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, const uint32_t *order, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
+template <bool HW> __global__ void __launch_bounds__(HW ? 64 * HELP_WAVES : 64, 2) k_lzma_encode(const LzmaJob *jobs, const uint32_t *order, const uint8_t *in_base, const uint32_t *tok_base, uint8_t *out_base,
                                                     Bt4Sets sets, uint64_t *result, uint8_t *save_base, uint64_t budget, uint64_t pos_cap) {
   LzProbs &P = s_P;
   const uint32_t job = order ? order[blockIdx.x] : blockIdx.x;      // the longest entries first: workgroups start in index order
@@ -1068,6 +1228,8 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
     }
     __syncthreads();
   }
+  // (the kernel of a stream alone, 256 threads: the waves behind the first are its helpers from here on -- "one stream on four waves")
+  if constexpr (HW) { if (threadIdx.x >= 64u) { helper_loop((int)(threadIdx.x >> 6)); return; } }
 #ifdef ZADA_LZ_PROF
   const unsigned long long prof_k0 = clock64();
   for (int i = 0; i < 8; i++) g_lzprof[i] = 0;
@@ -1095,6 +1257,7 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
     if (s_E.defect) {                                                 // (ZADA_E_REFERENCE: nothing more is coded)
       if (S && threadIdx.x == 0) S->phase = 2;
       if (threadIdx.x == 0) { result[2 * job] = 0; result[2 * job + 1] = s_E.ES.pos | (1ull << 62); }
+      helpers_release<HW>();
       return;
     }
     if (s_E.ES.pos >= stop) { done = false; break; }
@@ -1110,19 +1273,20 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
       iter++;
     } else {
       if (!running) break;
-      sy = lz_next_symbol();
+      sy = lz_next_symbol<HW>();
       if (bt_available() == 0 && bt_fill_window((int)J.sbs) == 0) running = false;    // (the window's bookkeeping: nothing the emission reads)
     }
-    if (sy.length) emit_dl(sy.distance, sy.length); else emit_literal(sy.literal);
+    if (sy.length) emit_dl<HW>(sy.distance, sy.length); else emit_literal(sy.literal);
   }
   if (!done) {
-    __syncthreads();
+    chain_sync<HW>();
     words_out(&S->P, s_P); words_out(&S->MM[0], s_MM[0]); words_out(&S->MM[1], s_MM[1]); words_out(&S->E, s_E); words_out(&S->B, s_B);
     if (threadIdx.x == 0) {
       S->phase = 1; S->running = running ? 1u : 0u; S->iter = iter;
       result[2 * job] = s_E.olen;
       result[2 * job + 1] = s_E.ES.pos | (1ull << 63);                             // bit 63: more to come
     }
+    helpers_release<HW>();
     return;
   }
   encode_bit(P.match[s_E.ES.state][s_E.ES.pos_state], 1);                             // end marker :1549-1556
@@ -1134,6 +1298,7 @@ __global__ void __launch_bounds__(64, 2) k_lzma_encode(const LzmaJob *jobs, cons
   if (S && threadIdx.x == 0) S->phase = 2;
   result[2 * job] = s_E.olen;
   result[2 * job + 1] = s_E.ES.pos;
+  helpers_release<HW>();
 }
 
 }  // namespace
@@ -1175,9 +1340,12 @@ int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, co
 // is more to come); nullptr / 0: one launch.
 uint64_t lzma_save_stride() { return LZ_SAVE_STRIDE; }
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
-                uint8_t *d_save, uint64_t budget, uint64_t pos_cap) {
+                uint8_t *d_save, uint64_t budget, uint64_t pos_cap, int waves) {
   if (count == 0) return 0;
-  hipLaunchKernelGGL(k_lzma_encode, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, sets, d_result, d_save, d_save ? budget : 0ull, pos_cap);
+  if (waves == HELP_WAVES)
+    hipLaunchKernelGGL(k_lzma_encode<true>, dim3(count), dim3(64 * HELP_WAVES), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, sets, d_result, d_save, d_save ? budget : 0ull, pos_cap);
+  else
+  hipLaunchKernelGGL(k_lzma_encode<false>, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, sets, d_result, d_save, d_save ? budget : 0ull, pos_cap);
   return hip_check(c, hipGetLastError(), "k_lzma_encode") ? ZADA_E_HIP : 0;
 }
 
