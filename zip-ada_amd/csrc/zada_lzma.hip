@@ -783,7 +783,9 @@ __device__ void help_cuts(int k0, int k1) {
     v.tw = tw;
     sim_any<1>(s_H.distance, cut, v, p);
     const double pm = p;
-    if (!(p <= s_H.soe)) sim_any<1>(s_H.distance, s_H.length - cut, v, p);
+    // (the reference goes on only if pm > the strict / expanded probability, :933: that one is still being worked out by wave 0 -- both parts
+    // here, the test when wave 0 collects)
+    sim_any<1>(s_H.distance, s_H.length - cut, v, p);
     if ((lane & (tw - 1)) == 0) { s_Hp[2 + k0 + task][0] = pm; s_Hp[2 + k0 + task][1] = p; }
   }
 }
@@ -840,10 +842,6 @@ template <bool HW> __device__ __forceinline__ void helpers_release() {          
 
 // decide <2, true> of the wave that walks the chain, its independent simulations on the helpers
 __device__ int decide_with_helpers(uint32_t distance, int length, const MS &sim, int &best_cut) {
-  const StrictRes strict = strict_factors(distance, length, sim);
-  const double strict_dlc = strict.f1 * strict.f2;
-  const double expanded_dlc = test_expanded(distance, length, strict_dlc, sim);
-  const double soe = strict_dlc > expanded_dlc ? strict_dlc : expanded_dlc;
   const bool pair = length > 2;
   double head_lit = 0.0, malus_dtl = 0.0;
   MS after = sim;
@@ -855,17 +853,26 @@ __device__ int decide_with_helpers(uint32_t distance, int length, const MS &sim,
     malus_dtl = fmax0(0.135 - (double)distance * 1.0e-8 - (double)length * 1.0e-4);  // DL_code_then_Literal :869-889
   }
   const double malus = fmax0(0.27 - (double)distance * 2.0e-6);                      // Test_Split_DL :901-944
-  const bool split = s_E.cv >= 2 && !(malus < soe);
   const Cuts cuts = cuts_of(length);
-  const int nc = split ? cuts.n1 + cuts.n2 : 0;
-  if (!pair && nc == 0) return expanded_dlc > strict_dlc ? W_EXPAND : W_STRICT;
-  if (lane_id() == 0) {
-    s_H.cmd = 1; s_H.distance = distance; s_H.length = length; s_H.pair = pair ? 1 : 0; s_H.nc = nc; s_H.cuts = cuts;
-    s_H.sim = sim; s_H.after = after; s_H.malus_dtl = malus_dtl; s_H.malus = malus; s_H.soe = soe;
+  const int nc = s_E.cv >= 2 && malus > 0.0 ? cuts.n1 + cuts.n2 : 0;                 // (malus = 0: no cut can beat anything)
+  const bool fork = pair || nc > 0;
+  if (fork) {
+    if (lane_id() == 0) {
+      s_H.cmd = 1; s_H.distance = distance; s_H.length = length; s_H.pair = pair ? 1 : 0; s_H.nc = nc; s_H.cuts = cuts;
+      s_H.sim = sim; s_H.after = after; s_H.malus_dtl = malus_dtl; s_H.malus = malus; s_H.soe = 0.0;
+    }
+    __syncthreads();                                                   // (A)
   }
-  __syncthreads();                                                     // (A)
-  help_decide(0);
-  __syncthreads();                                                     // (B)
+  // the strict and the expanded code (:661-726) on this wave while the helpers are at the pair
+  const StrictRes strict = strict_factors(distance, length, sim);
+  const double strict_dlc = strict.f1 * strict.f2;
+  const double expanded_dlc = test_expanded(distance, length, strict_dlc, sim);
+  const double soe = strict_dlc > expanded_dlc ? strict_dlc : expanded_dlc;
+  if (fork) {
+    help_decide(0);
+    __syncthreads();                                                   // (B)
+  }
+  const bool split = !(malus < soe);
   if (pair) {
     const double dal = s_Hp[0][0], dtl = s_Hp[1][0];
     if (head_lit * dal * fmax0(0.064 - (double)distance * 1.0e-9 - (double)length * 3.0e-5) > soe) return W_LIT_DL;
@@ -874,7 +881,7 @@ __device__ int decide_with_helpers(uint32_t distance, int length, const MS &sim,
   if (expanded_dlc > strict_dlc) return W_EXPAND;
   double best_prob = 0.0;
   best_cut = 2;
-  for (int k = 0; k < nc; k++) {
+  for (int k = 0; split && k < nc; k++) {
     const double pmk = s_Hp[2 + k][0], pfk = s_Hp[2 + k][1];
     if (!(pmk <= soe)) { if (pfk > best_prob) { best_prob = pfk; best_cut = cut_at(cuts, k); } }
   }
