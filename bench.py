@@ -325,6 +325,7 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
     cnt1 = {k: v for k, v in enc.last_timing() if k.startswith("#")}
     out["one_stream"] = {"value": round(len(one) / d1 / 1e6, 4), "unit": "MB/s", "bytes": len(one), "compression_ratio": round(len(z1) / len(one), 4), "phase_ms": tim1,
                          "launches": int(cnt1.get("#lzma_launches", 0)), "producer": "in segments of 2**20 positions on a second stream, beside the coder (knob lzma_segment)",
+                         "coder": "one workgroup of four waves: the chain's and three helpers for its forks (knob lzma_waves)",
                          "seconds_for_config_4": round((1 << 30) / (len(one) / d1), 0),
                          "config_4_measured": {"seconds": 888.1, "MB/s": 1.209, "equals_cpu_port": True,
                                                "source": "profiles/r4/config4_lzma3_1gib_final.log: config 4 itself (ONE 1 GiB stream), one run on one MI355X -- not part of this run"},

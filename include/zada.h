@@ -83,7 +83,8 @@ const char *zada_version(void);
  * per stream), "lzma_pool" (test knob: blocks of the LZMA_3 match sets' overflow pool to start with, 0 = by size; a pool that is too small is
  * counted and the match producer's walk runs again), "lzma_segment" (one LZMA_3 stream coded in launches: log2 of the positions per segment of
  * the match producer, whose walks of segment k + 1 run beside the coder of segment k; 13 .. 30, 0 = by size: 2 ** 20 positions for streams from 2 MiB on, 2 ** 18 from 512 KiB on, none below,
- * -1 = all match sets before the coder starts).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's
+ * -1 = all match sets before the coder starts), "lzma_waves" (one LZMA_3 stream alone: waves of its workgroup -- 0 or 4 = the wave that walks the stream's
+ * chain and three helpers that take shares of its forks, 1 = that wave alone, as every entry of a batch has it).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's
  * dictionary_size for LZMA_3 in bytes (0, the default: the entry's size, as Zip.Compress.LZMA_E passes it; lzma_enc.adb uses 32 KiB). */
 int zada_set_knob(zada_ctx *ctx, const char *name, int value);
 

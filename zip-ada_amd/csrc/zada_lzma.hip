@@ -769,7 +769,10 @@ struct HelpArgs {
 };
 __shared__ HelpArgs s_H;
 __shared__ double s_Hp[2 * LZ_MAXM + 2][2];      // decide: [0] / [1] the pair, [2 + k] cut k (after its first part, at its end); Scoring: [k] candidate k
-constexpr int HELP_WAVES = 4;
+#ifndef ZADA_HELP_WAVES
+#define ZADA_HELP_WAVES 4
+#endif
+constexpr int HELP_WAVES = ZADA_HELP_WAVES;
 
 // the cuts [k0, k1) of the posted decision, a team each
 __device__ void help_cuts(int k0, int k1) {
@@ -802,8 +805,8 @@ __device__ void help_decide(int w) {
       if (t == 1) sim_literal(TB((int64_t)v.pos - (int64_t)s_H.distance), v, p);
       if (lane_id() == 0) s_Hp[t][0] = p;
     } else {
-      const int j = w == 0 ? 0 : 1;
-      help_cuts(nc * j / 2, nc * (j + 1) / 2);
+      const int j = w == 0 ? 0 : w - 2, m = HELP_WAVES - 2;            // (the waves that are not at the pair)
+      help_cuts(nc * j / m, nc * (j + 1) / m);
     }
   } else help_cuts(nc * w / HELP_WAVES, nc * (w + 1) / HELP_WAVES);
 }
@@ -1349,7 +1352,7 @@ uint64_t lzma_save_stride() { return LZ_SAVE_STRIDE; }
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
                 uint8_t *d_save, uint64_t budget, uint64_t pos_cap, int waves) {
   if (count == 0) return 0;
-  if (waves == HELP_WAVES)
+  if (waves > 1)                                                     // (the chain's wave and HELP_WAVES - 1 helpers)
     hipLaunchKernelGGL(k_lzma_encode<true>, dim3(count), dim3(64 * HELP_WAVES), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, sets, d_result, d_save, d_save ? budget : 0ull, pos_cap);
   else
   hipLaunchKernelGGL(k_lzma_encode<false>, dim3(count), dim3(64), 0, c->stream, d_jobs, d_order, d_in, d_tok, d_out, sets, d_result, d_save, d_save ? budget : 0ull, pos_cap);
