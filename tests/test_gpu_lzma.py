@@ -117,6 +117,31 @@ def test_one_stream_with_the_producer_in_segments(encoder):
         encoder.set_knob("lzma_segment", 0)
 
 
+def test_one_stream_alone_on_four_waves(encoder):
+    """A stream coded by zada_lzma has a workgroup of four waves: the one that walks the chain and three helpers that take shares of its forks (the
+    literal / shortened-code pair and the cuts of a code to write, Scoring's candidates; zada_lzma.hip "one stream on four waves", knob "lzma_waves").
+    Every input of the parity matrix up to 100 KB as a single LZMA_3 stream on four waves and on one: both == the oracle (which the batches' one-wave
+    kernel is held against as well); launches of a few thousand positions in between (the helpers are released and taken up again at every launch)."""
+    cases = lz_inputs()
+    try:
+        for name in sorted(cases):
+            d = cases[name]
+            if len(d) > 100000:
+                continue
+            want = oracle_lzma(d, 18)
+            for waves, chunk in ((4, 0), (1, 0), (4, 3000)):
+                encoder.set_knob("lzma_waves", waves)
+                encoder.set_knob("lzma_chunk", chunk)
+                assert encoder.lzma(d, 18) == want, (name, len(d), waves, chunk)
+        # LZMA_2 (no BT4, no helpers) is untouched by the knob
+        encoder.set_knob("lzma_waves", 4)
+        d = cases["mix_256k"][:60000]
+        assert encoder.lzma(d, 17) == oracle_lzma(d, 17)
+    finally:
+        encoder.set_knob("lzma_waves", 0)
+        encoder.set_knob("lzma_chunk", 0)
+
+
 def test_overflow_pool_of_the_match_sets_too_small(encoder):
     """The producer keeps seven matches of a position next to it and longer sets in blocks of an overflow pool sized by a guess; a pool that
     is too small is counted, not overrun, and the walk runs again with a pool of the counted size (the trees are rebuilt from nothing).
