@@ -327,7 +327,7 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
                          "launches": int(cnt1.get("#lzma_launches", 0)), "producer": "in segments of 2**20 positions on a second stream, beside the coder (knob lzma_segment)",
                          "coder": "one workgroup of four waves: the chain's and three helpers for its forks (knob lzma_waves)",
                          "seconds_for_config_4": round((1 << 30) / (len(one) / d1), 0),
-                         "config_4_measured": {"seconds": 888.1, "MB/s": 1.209, "equals_cpu_port": True,
+                         "config_4_measured": {"seconds": 788.6, "MB/s": 1.362, "equals_cpu_port": True,
                                                "source": "profiles/r4/config4_lzma3_1gib_final.log: config 4 itself (ONE 1 GiB stream), one run on one MI355X -- not part of this run"},
                          "note": "config 4 is ONE 1 GiB stream: it runs at this rate -- the match sets come from the producer's parallel kernels, segment k + 1 while the coder -- one "
                                  "wave walking the chain of adaptive probabilities, the independent simulations of a step on teams of its lanes -- codes segment k"}
