@@ -241,45 +241,45 @@ __device__ double test_simple_match(uint32_t distance, uint32_t length, const MS
 // Simulate_Strict_DL_Code :605-659 as the state it leaves and the two factors it multiplies the probability by (prob := prob * f1 * f2, in that
 // order): Generic_any_DL_Code tests the strict code first (:661-677, from probability 1.0: 1.0 * f1 is f1) and, when nothing beats it, simulates
 // it again on the same state (:826-830) -- the second time the factors are the first time's.
-struct StrictRes { MS after; double f1, f2; };
-__device__ __forceinline__ StrictRes strict_factors(uint32_t distance, int length, const MS &sim0) {
+// (what is kept is small -- the two factors and WHICH code it was: the state it leaves is worked out again from that, a few integer operations and
+// one byte of the text; kept whole, the state cost sim_any_impl<2> twenty spilled registers across its nested simulations)
+struct StrictRes { double f1, f2; int found; };      // found: the repeat distance taken (0 .. 3), -1: a simple match
+__device__ __forceinline__ StrictRes strict_factors(uint32_t distance, int length, const MS &sim) {
   StrictRes r;
-  MS &sim = r.after;
-  sim = sim0;
   const uint32_t dist_ip = distance - 1;
-  int found = -1;
   r.f1 = tbe(s_P.match[sim.state][sim.pos_state], 1);
   const double sma = test_simple_match(dist_ip, (uint32_t)length, sim);
   // (no run-time index into sim.rep: one would put the whole state in scratch memory)
-  found = dist_ip == sim.rep[0] ? 0 : dist_ip == sim.rep[1] ? 1 : dist_ip == sim.rep[2] ? 2 : dist_ip == sim.rep[3] ? 3 : -1;
-  bool rep = false;
+  const int found = dist_ip == sim.rep[0] ? 0 : dist_ip == sim.rep[1] ? 1 : dist_ip == sim.rep[2] ? 2 : dist_ip == sim.rep[3] ? 3 : -1;
+  r.f2 = sma; r.found = -1;
   if (found >= 0) {
     const double rma = test_repeat_match(found, (uint32_t)length, sim);
-    if (rma >= sma * 0.55) {                                                       // Malus_simple_match_vs_rep :301
-      r.f2 = rma;
-      const uint32_t r0 = sim.rep[0], r1 = sim.rep[1], r2 = sim.rep[2];           // rep (found) to the front, the ones before it one down
-      sim.rep[0] = dist_ip;
-      if (found >= 1) sim.rep[1] = r0;
-      if (found >= 2) sim.rep[2] = r1;
-      if (found >= 3) sim.rep[3] = r2;
-      sim.state = t_rep(sim.state);
-      rep = true;
-    }
+    if (rma >= sma * 0.55) { r.f2 = rma; r.found = found; }                        // Malus_simple_match_vs_rep :301
   }
-  if (!rep) {
-    r.f2 = sma;
+  return r;
+}
+// the state behind the strict code whose factors are r
+__device__ __forceinline__ void strict_apply(uint32_t distance, int length, const StrictRes &r, MS &sim) {
+  const uint32_t dist_ip = distance - 1;
+  if (r.found >= 0) {
+    const uint32_t r0 = sim.rep[0], r1 = sim.rep[1], r2 = sim.rep[2];             // rep (found) to the front, the ones before it one down
+    sim.rep[0] = dist_ip;
+    if (r.found >= 1) sim.rep[1] = r0;
+    if (r.found >= 2) sim.rep[2] = r1;
+    if (r.found >= 3) sim.rep[3] = r2;
+    sim.state = t_rep(sim.state);
+  } else {
     sim.rep[3] = sim.rep[2]; sim.rep[2] = sim.rep[1]; sim.rep[1] = sim.rep[0]; sim.rep[0] = dist_ip;
     sim.state = t_match(sim.state);
   }
   sim.pos += (uint64_t)length;
   sim.pos_state = (uint32_t)sim.pos & LZ_PBM;
   sim.prev_byte = TB((int64_t)sim.pos - 1);
-  return r;
 }
 __device__ __forceinline__ void sim_strict(uint32_t distance, int length, MS &sim, double &prob) {
   const StrictRes r = strict_factors(distance, length, sim);
   prob = prob * r.f1 * r.f2;
-  sim = r.after;
+  strict_apply(distance, length, r, sim);
 }
 
 __device__ double test_expanded(uint32_t distance, int length, double give_up, const MS &sim) {   // :680-726
@@ -493,7 +493,7 @@ template <int R> __device__ __noinline__ SimRes sim_any_impl(uint32_t distance, 
         sim_any<NEW>(distance, length - cut, sim, prob);
         break;
       default:
-        if (tested) { const int tw = sim.tw; prob = prob * strict.f1 * strict.f2; sim = strict.after; sim.tw = tw; }
+        if (tested) { prob = prob * strict.f1 * strict.f2; strict_apply(distance, length, strict, sim); }
         else sim_strict(distance, length, sim, prob);
     }
   }
