@@ -7,6 +7,11 @@
  * What is checked: every stream decodes with liblzma (Python's lzma module, raw LZMA1 filter) to the input,
  * and oracle/pin_with_gnat.sh compares `zipada -el1..3` payloads with tests/golden/lzma_digests.json
  * wherever a GNAT toolchain exists.  Valid-but-different choices would pass the first check.
+ * "Every stream decodes": with the dictionary Zip.Compress.LZMA_E asks for (the entry's size).  With a dictionary SMALLER than the data the
+ * reference's BT4 reads positions behind pending bytes that no window fill took up (lz77.adb:1000-1017, 1397-1406), lzPos lags behind readPos,
+ * and its matcher reports matches that are none (:1262-1290): this file keeps that, it is the reference's behaviour -- such streams do NOT decode
+ * to the input (tests/test_lzma_oracle.py::test_reference_defect_behind_pending_bytes_no_fill_took_up, tests/golden/lzma_defect.json, and
+ * oracle/pin_lzma_defect.adb for a GNAT box); the product refuses those entries (ZADA_E_REFERENCE).
  *
  * Follows, function by function:
  *   zip_lib/lzma.ads:81-268            constants, probability model layout
