@@ -171,3 +171,17 @@ def test_every_knob_is_documented_in_the_header():
     assert len(names) >= 15
     missing = sorted(n for n in names if '"%s"' % n not in hdr)
     assert not missing, missing
+
+
+def test_return_codes_of_the_header_and_of_the_python_mirror_agree():
+    """The negative codes of include/zada.h are distinct, and the one the Python mirror names (E_REFERENCE: an LZMA_3 entry on which the
+    reference's own matcher leaves the format) has the header's value; INTEGRATION.md tells the shim what to do with it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "zada.h")).read()
+    codes = {k: int(v) for k, v in re.findall(r"\b(ZADA_[A-Z_]+)\s*=\s*(-?\d+)", hdr)}
+    assert codes["ZADA_OK"] == 0 and codes["ZADA_INEFFICIENT"] == 1 and codes["ZADA_ABORTED"] == 2
+    neg = [v for k, v in codes.items() if k.startswith("ZADA_E_")]
+    assert len(neg) == len(set(neg)) >= 6 and all(v < 0 for v in neg)
+    src = open(os.path.join(root, "zip-ada_amd", "__init__.py")).read()
+    assert int(re.search(r"^E_REFERENCE\s*=\s*(-?\d+)", src, re.M).group(1)) == codes["ZADA_E_REFERENCE"] == -6
+    assert "ZADA_E_REFERENCE" in open(os.path.join(root, "INTEGRATION.md")).read()
