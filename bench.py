@@ -6,7 +6,7 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Workloads (BASELINE.json configs):
-  N = 1   C2: Deflate_3 on 1 GiB of the synthetic "silesia_mix_v1" stream, one entry, input resident in HBM.
+  N = 1   C2: Deflate_3 on 1 GiB of the synthetic "silesia_mix_v2" stream, one entry, input resident in HBM.
   N > 1   C3: Deflate_3 on ONE logical stream of N x 2 GiB (16 GiB at N = 8), cut into N ranges, one per GPU
           (SURVEY.md 8e primary mode).  The ranks exchange the sequential encoder's state at the range boundaries over
           RCCL / xGMI (zip-ada_amd/sharding.py: parser states and atom counts by all_gather, boundary atoms by all_gather,
@@ -42,9 +42,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_SPEC_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-HBM_PEAK_GBS = HBM_SPEC_GBS    # the roofline's peak: min(spec, copy bandwidth measured on this box) once main() has measured it
+HBM_PEAK_GBS = HBM_SPEC_GBS    # the roofline's peak (every "frac" divides by it); the copy bandwidth measured on the box is carried beside it
 HBM_MEASURED = None
 SEED = 0x5A1E51A
+CORPUS = 2                     # silesia_mix_v2 (segments seeded independently; v1's were shifted copies of one stream of draws -- csrc/silesia_mix.c)
+CORPUS_NAME = "silesia_mix_v2"
+
+
+def mix(za, nbytes, offset=0, version=None):
+    return za.silesia_mix(nbytes, seed=SEED, offset=offset, version=CORPUS if version is None else version)
 
 
 def host_cpus():
@@ -129,7 +135,7 @@ def cpu_baseline(za, sample_mib):
     first sample_mib MiB of the benchmark stream.  The oracle is used here only as the measured baseline and checker."""
     O, P = _oracle()
     n = sample_mib << 20
-    d = za.silesia_mix(n, seed=SEED).tobytes()
+    d = mix(za, n).tobytes()
     t0 = time.perf_counter()
     ref = _oracle_deflate(O, d)
     dt = time.perf_counter() - t0
@@ -137,7 +143,7 @@ def cpu_baseline(za, sample_mib):
     # takes its own 8 MiB of the stream
     cores, _ = host_cpus()
     per = 8 << 20
-    parts = [za.silesia_mix(per, seed=SEED, offset=(i + 1) * (64 << 20)).tobytes() for i in range(cores)]
+    parts = [mix(za, per, (i + 1) * (64 << 20)).tobytes() for i in range(cores)]
     ac = all_cores(lambda p: len(_oracle_deflate(O, p)), parts, n / dt / 1e6)
     # libz with the reference's IZ_10 tuple (lz77.adb:546): the same LZ77 decisions, zlib's own block splitting
     t2 = time.perf_counter()
@@ -147,7 +153,7 @@ def cpu_baseline(za, sample_mib):
     z9 = len(zlib.compress(d, 9)) - 6
     dz9 = time.perf_counter() - t3
     return {"value": round(n / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": "first %d MiB of the same silesia_mix_v1 stream, Deflate_3, oracle/zada_oracle.c single thread, %.1f s" % (sample_mib, dt),
+            "sample": "first %d MiB of the same %s stream, Deflate_3, oracle/zada_oracle.c single thread, %.1f s" % (sample_mib, CORPUS_NAME, dt),
             "ratio": round(len(ref) / n, 4),
             "all_cores": ac,
             "zlib_tuned_34_258_258_4096": {"ratio": round(zt / n, 4), "MB/s": round(n / dzt / 1e6, 2)},
@@ -171,11 +177,26 @@ def pmc_traffic(n, kernel):
     the profile was taken on; null otherwise."""
     best = _latest_profile("pmc_fetch_write_by_kernel.json")
     if n != (1 << 30) or not best:
-        return None
+        return None, None
     d = json.load(open(best))
     try:
         f = d["FETCH_SIZE"]["zada::" + kernel]; w = d["WRITE_SIZE"]["zada::" + kernel]
-        return int((2 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024)
+        src = {"file": os.path.relpath(best, ROOT), "taken_at_commit": d.get("_commit"), "corpus": d.get("_corpus"),
+               "note": "NOT measured in this run: rocprofv3 --pmc passes of this same command, committed under profiles/"}
+        return int((2 * f["sum"] / f["dispatches"] + w["sum"] / w["dispatches"]) * 1024), src
+    except Exception:
+        return None, None
+
+
+def pipeline_traffic(n):
+    """HBM bytes of one whole step (all kernels) from the same committed PMC passes: sum over kernels of (2 x FETCH + WRITE), for a
+    --steps 1 --warmup 0 run of the 1 GiB workload."""
+    best = _latest_profile("pmc_fetch_write_by_kernel.json")
+    if n != (1 << 30) or not best:
+        return None
+    try:
+        d = json.load(open(best))
+        return int((2 * sum(v["sum"] for v in d["FETCH_SIZE"].values()) + sum(v["sum"] for v in d["WRITE_SIZE"].values())) * 1024)
     except Exception:
         return None
 
@@ -188,7 +209,9 @@ def leg_traffic(key):
         return None, None
     try:
         d = json.load(open(best))[key]
-        return int((2 * d["fetch_kb"] + d["write_kb"]) * 1024 / d["launches"]), d["workload"] + " (" + os.path.relpath(best, ROOT) + ")"
+        whole = json.load(open(best))
+        return (int((2 * d["fetch_kb"] + d["write_kb"]) * 1024 / d["launches"]),
+                d["workload"] + " (" + os.path.relpath(best, ROOT) + (", taken at commit %s" % whole["_commit"] if whole.get("_commit") else "") + "; not measured in this run)")
     except Exception:
         return None, None
 
@@ -200,7 +223,7 @@ def second_bound(kernel):
         return None
     try:
         d = json.load(open(best))[kernel]
-        d["source"] = os.path.relpath(best, ROOT)
+        d["source"] = os.path.relpath(best, ROOT) + " (committed SQ counter pass, not measured in this run)"
         return d
     except Exception:
         return None
@@ -226,7 +249,7 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
     import numpy as np
     import torch
     n = mib << 20
-    host = za.silesia_mix(n, seed=SEED)
+    host = mix(za, n)
     d_in = torch.from_numpy(host).cuda()
     d_out = torch.zeros(n + 4096, dtype=torch.uint8, device="cuda")
     enc.bzip2_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 14)
@@ -248,7 +271,7 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
         if not k.startswith("#") and k != "bz:end":
             tim[k] = round(tim.get(k, 0.0) + v, 1)
     out = {"metric": "BZip2_3 encode MB/s (stream bit-exact with the CPU restatement of the reference, Ada parity unpinned)", "value": round(n / dt / 1e6, 2),
-           "unit": "MB/s", "workload": "%d MiB silesia_mix_v1, one stream, input and output resident in HBM" % mib, "ms": round(dt * 1e3, 1), "runs_ms": [round(r * 1e3, 1) for r in runs], "rc": rc,
+           "unit": "MB/s", "workload": "%d MiB %s, one stream, input and output resident in HBM" % (mib, CORPUS_NAME), "ms": round(dt * 1e3, 1), "runs_ms": [round(r * 1e3, 1) for r in runs], "rc": rc,
            "compression_ratio": round(ol / n, 4), "blocks": len(blocks), "tactics_kept": [sum(1 for b in blocks if b[2] == t) for t in range(4)], "phase_ms": tim}
     # dominant KERNEL (by kernel time, profiles/<round>/bzip2_256mib_kernel_stats.csv): k_bz_entropy, the search for the tables and selectors --
     # the "bz:entropy" phase is its launches alone (the longest PHASE, bz:bwt, is some 400 launches of a dozen kernels, none of them as long)
@@ -289,13 +312,27 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
     return out
 
 
+def config_4_log():
+    """BASELINE config 4 itself (ONE LZMA_3 stream of 1 GiB) is a run of many minutes and not part of this command: what
+    tests/gpu_lzma_c4.py printed when it was last run on this round's corpus, read from the committed log -- or nothing."""
+    p = _latest_profile("config4_lzma3_1024mib_%s.json" % CORPUS_NAME)
+    if not p:
+        return None
+    try:
+        d = json.load(open(p))
+        d["source"] = os.path.relpath(p, ROOT) + ": config 4 itself, one run on one MI355X -- NOT part of this run"
+        return d
+    except Exception:
+        return None
+
+
 def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
     """Secondary measurement (BASELINE config 4's method): LZMA_3 of `entries` Zip entries of `kib` KiB
     (slices of the same synthetic stream) through ONE launch of the coder -- a stream is a chain of dependent steps, so entries
     are what runs in parallel -- and ONE stream alone beside it (config 4's shape).  Host buffers in, host buffers out."""
     import lzma
     size = kib << 10
-    host = za.silesia_mix(entries * size, seed=SEED)
+    host = mix(za, entries * size)
     datas = [host[i * size:(i + 1) * size].tobytes() for i in range(entries)]
     enc.lzma_batch(datas, 18)                            # warm-up at full size (the producer's and the coder's buffers are allocated here)
     runs = []
@@ -307,7 +344,7 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
     tim = {k: round(v, 1) for k, v in enc.last_timing() if not k.startswith("#")}
     out_bytes = sum(len(z) for _, z, _ in res)
     out = {"metric": "LZMA_3 encode MB/s over a batch of Zip entries (payloads bit-exact with the CPU restatement of the reference, Ada parity unpinned)",
-           "value": round(entries * size / dt / 1e6, 3), "unit": "MB/s", "workload": "%d entries of %d KiB, silesia_mix_v1, one launch" % (entries, kib),
+           "value": round(entries * size / dt / 1e6, 3), "unit": "MB/s", "workload": "%d entries of %d KiB, %s, one launch" % (entries, kib, CORPUS_NAME),
            "ms": round(dt * 1e3, 1), "runs_ms": [round(r * 1e3, 1) for r in runs], "compression_ratio": round(out_bytes / (entries * size), 4), "phase_ms": tim}
     kms = tim.get("lzma:end", dt * 1e3)
     ach = (entries * size + out_bytes) / (kms * 1e-3) / 1e9
@@ -317,7 +354,7 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
                        "note": "algorithmic bytes = N_in + N_out over the coder's launch (lzma:end; the BT4 match producer's kernels run before it: lzma:bt4); the bound is neither HBM nor MFMA "
                                "but the latency of one dependent instruction stream per entry (adaptive probabilities), 2 048 entries in flight (DESIGN.md 10)"}
     # BASELINE config 4's shape: ONE stream, `one_mib` MiB of the stream itself (not a repeated slice)
-    one = host[:one_mib << 20].tobytes() if (one_mib << 20) <= len(host) else za.silesia_mix(one_mib << 20, seed=SEED).tobytes()
+    one = host[:one_mib << 20].tobytes() if (one_mib << 20) <= len(host) else mix(za, one_mib << 20).tobytes()
     t1 = time.perf_counter()
     rc1, z1, _ = enc.lzma(one, 18)
     d1 = time.perf_counter() - t1
@@ -326,11 +363,12 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
     out["one_stream"] = {"value": round(len(one) / d1 / 1e6, 4), "unit": "MB/s", "bytes": len(one), "compression_ratio": round(len(z1) / len(one), 4), "phase_ms": tim1,
                          "launches": int(cnt1.get("#lzma_launches", 0)), "producer": "in segments of 2**20 positions on a second stream, beside the coder (knob lzma_segment)",
                          "coder": "one workgroup of four waves: the chain's and three helpers for its forks (knob lzma_waves)",
-                         "seconds_for_config_4": round((1 << 30) / (len(one) / d1), 0),
-                         "config_4_measured": {"seconds": 788.6, "MB/s": 1.362, "equals_cpu_port": True,
-                                               "source": "profiles/r4/config4_lzma3_1gib_final.log: config 4 itself (ONE 1 GiB stream), one run on one MI355X -- not part of this run"},
+                         "seconds_for_config_4_extrapolated": round((1 << 30) / (len(one) / d1), 0),
                          "note": "config 4 is ONE 1 GiB stream: it runs at this rate -- the match sets come from the producer's parallel kernels, segment k + 1 while the coder -- one "
                                  "wave walking the chain of adaptive probabilities, the independent simulations of a step on teams of its lanes -- codes segment k"}
+    c4 = config_4_log()
+    if c4:
+        out["one_stream"]["config_4_measured"] = c4
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _lzmah import oracle_lzma
@@ -353,7 +391,9 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
         if with_checks:
             t3 = time.perf_counter()
             ref1 = oracle_lzma(one[:1 << 20], 18)
-            out["one_stream"]["cpu_one_core_MBs"] = round((1 << 20) / (time.perf_counter() - t3) / 1e6, 3)
+            c1 = (1 << 20) / (time.perf_counter() - t3) / 1e6
+            out["one_stream"]["cpu_one_core"] = {"value": round(c1, 3), "unit": "MB/s", "sample": "the first MiB of the same stream, oracle/zada_oracle_lzma.c, one thread"}
+            out["one_stream"]["gpu_over_cpu_one_core"] = round(out["one_stream"]["value"] / c1, 3) if c1 else None
             out["one_stream"]["first_MiB_alone_equals_cpu_port"] = bool(enc.lzma(one[:1 << 20], 18) == ref1)
         if with_checks:
             out["sample_payloads_equal_cpu_port"] = bool(all(res[i] == ref[i] for i in range(k)))
@@ -377,7 +417,7 @@ def bzip2_main(args, za, sharding, enc, torch, dist, rank, world, dev, emulate):
     ranges = sharding.bzip2_ranges(total, world)
     active = rank < len(ranges)
     off, blen = sharding.bzip2_window(total, *ranges[rank]) if active else (0, 1)
-    host = za.silesia_mix(blen, seed=SEED, offset=off)
+    host = mix(za, blen, off)
     d_buf = torch.from_numpy(host).to(dev)
 
     class Solo:                                       # one GPU: the same protocol without a process group
@@ -425,7 +465,7 @@ def bzip2_main(args, za, sharding, enc, torch, dist, rank, world, dev, emulate):
     out = {"metric": "BZip2_3 encode MB/s (one stream, blocks sharded over the GPUs; bit-exact with the CPU restatement of the reference, Ada parity unpinned)",
            "value": round(total * args.steps / dt / 1e6, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "C5: BZip2_3, one stream of %d x %d MiB synthetic silesia_mix_v1, %d block ranges, input resident in HBM" % (world, mib, len(ranges)),
+           "config": {"workload": "C5: BZip2_3, one stream of %d x %d MiB synthetic %s, %d block ranges, input resident in HBM" % (world, mib, CORPUS_NAME, len(ranges)),
                       "bytes_per_gpu": n, "stream_bytes": total, "compression_ratio": round(nbytes / total, 4), "blocks_rank0": len(res["blocks"])}}
     if not args.no_checks and total <= (3 << 30):
         stream = bytes(state["stream"].cpu().numpy())
@@ -492,6 +532,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-checks", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--no-v1", action="store_true", help="skip the extra Deflate measurement on silesia_mix_v1")
     ap.add_argument("--method", choices=("deflate", "bzip2"), default="deflate", help="bzip2: BASELINE config 5 -- ONE BZip2_3 stream of N x --mib (default 1024) MiB over N GPUs")
     ap.add_argument("--bzip2-mib", type=int, default=256, help="input MiB of the secondary BZip2_3 measurement at one GPU (0 = skip)")
     ap.add_argument("--lzma-entries", type=int, default=4096, help="entries of the secondary LZMA_3 batch measurement at one GPU (0 = skip)")
@@ -531,7 +572,6 @@ def main():
 
     global HBM_PEAK_GBS, HBM_MEASURED
     HBM_MEASURED = hbm_copy_gbs(torch, dev)
-    HBM_PEAK_GBS = min(HBM_SPEC_GBS, HBM_MEASURED)
     za = importlib.import_module("zip-ada_amd")
     sharding = importlib.import_module("zip-ada_amd.sharding")
     enc = za.Encoder(local_rank)
@@ -551,7 +591,7 @@ def main():
             phase_ms[k] = phase_ms.get(k, 0.0) + v    # (names starting with '#' are counters, e.g. rounds of the demand loop)
 
     if world == 1:
-        host = za.silesia_mix(n, seed=SEED)
+        host = mix(za, n)
         d_in = torch.from_numpy(host).to(dev)
         d_out = torch.empty(n + 4096, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
@@ -568,7 +608,7 @@ def main():
         ranges = sharding.stream_ranges(total, world)
         lo, ln = ranges[rank]
         first, pre, post = sharding.range_window(total, lo, ln)
-        host = za.silesia_mix(pre + ln + post, seed=SEED, offset=first)
+        host = mix(za, pre + ln + post, first)
         d_in = torch.from_numpy(host).to(dev)
         comm = sharding.TorchComm(torch.device("cpu") if emulate else dev)
         torch.cuda.synchronize()
@@ -655,11 +695,13 @@ def main():
         t_dom = phase_ms.get(dom, 0.0) / args.steps * 1e-3
         alg_bytes = n + out_len / world                  # N_in + N_out of what this GPU's launches process
         achieved = alg_bytes / t_dom / 1e9 if t_dom > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(n, kernels[dom]) if world == 1 else (None, None)
+        ptraffic = pipeline_traffic(n) if world == 1 else None
         if world == 1:
-            wl = "C2: Deflate_3, %d MiB synthetic silesia_mix_v1, one entry on one GPU, input resident in HBM" % mib
+            wl = "C2: Deflate_3, %d MiB synthetic %s, one entry on one GPU, input resident in HBM" % (mib, CORPUS_NAME)
         else:
-            wl = ("C3: Deflate_3, ONE logical stream of %d MiB synthetic silesia_mix_v1 cut into %d ranges of %d MiB, one per GPU; "
-                  "boundary state over RCCL, payloads gathered and stitched on rank 0" % (total >> 20, world, mib))
+            wl = ("C3: Deflate_3, ONE logical stream of %d MiB synthetic %s cut into %d ranges of %d MiB, one per GPU; "
+                  "boundary state over RCCL, payloads gathered and stitched on rank 0" % (total >> 20, CORPUS_NAME, world, mib))
         res = {
             "metric": "Deflate encode MB/s (Deflate_3; stream bit-exact with the CPU restatement of the reference, Ada parity unpinned)",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -669,10 +711,18 @@ def main():
             "config": {"workload": wl, "bytes_per_gpu": n, "stream_bytes": total, "compression_ratio": round(out_len / total, 4), "rc": rc,
                        "value_is": "device-resident input (host buffers: see host_path)",
                        "phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in phase_ms.items()}},
+            "value_kind": "device_resident: input and output in HBM when the clock starts (the measurement contract's `value`); value_host_buffers on this line is "
+                          "SURVEY 8d's end-to-end figure through zada_deflate on pageable host buffers, H2D and D2H included",
             "roofline": {"bound": "hbm", "kernel": kernels[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "peak_spec": HBM_SPEC_GBS, "peak_measured_copy": HBM_MEASURED, "traffic": pmc_traffic(n, kernels[dom]) if world == 1 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "peak_measured_copy": HBM_MEASURED, "frac_of_measured_copy": round(achieved / HBM_MEASURED, 6) if HBM_MEASURED else None,
+                         "launch_ms": round(t_dom * 1e3, 3), "traffic": traffic, "traffic_source": traffic_src,
                          "bound2": second_bound(kernels[dom]),
-                         "note": "algorithmic bytes = N_in + N_out per launch; peak = min(data sheet, 1 GiB device-to-device copy measured on this box, read + write); the LZ kernels are latency / issue bound (radix sort of positions, chain walk), not HBM bound"},
+                         "note": "algorithmic bytes = N_in + N_out per launch / the kernel's duration (HIP events on the encoder's stream, this run); peak = the data sheet's 8 TB/s (a 1 GiB device-to-device "
+                                 "copy measured on this box, read + write, is peak_measured_copy); the LZ kernels are latency / issue bound (radix sort of positions, chain walk), not HBM bound"},
+            "roofline_pipeline": {"bound": "hbm", "achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": ptraffic,
+                                  "traffic_over_algorithmic": round(ptraffic / alg_bytes, 1) if ptraffic else None,
+                                  "note": "the whole step priced like one kernel: (N_in + N_out) / ms_per_step / peak; traffic = HBM bytes of all kernels of one step from the same committed PMC passes as roofline.traffic"},
         }
         if multi:
             res["rank_ms_per_step"] = multi["rank_ms_per_step"]
@@ -693,6 +743,7 @@ def main():
             dth = (time.perf_counter() - t1) / args.steps
             res["host_path"] = {"value": round(n / dth / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dth * 1e3, 3), "steps": args.steps,
                                 "entry": "zada_deflate (pageable host buffers in and out, PCIe both ways included), the same %d steps" % args.steps}
+            res["value_host_buffers"] = res["host_path"]["value"]
             stream = hout[:ol_h].tobytes()
         else:
             stream = bytes(state["stream"].cpu().numpy()) if state["stream"] is not None else b""
@@ -729,10 +780,25 @@ def main():
                 checks["stream_inflates_to_input_crc"] = bool(ok)
                 checks["inflated_bytes"] = int(tot)
             if ref is not None:
-                head = za.silesia_mix(args.cpu_sample_mib << 20, seed=SEED).tobytes()
+                head = mix(za, args.cpu_sample_mib << 20).tobytes()
                 g, _ = enc.deflate(head, za.Method.Deflate_3)
                 checks["sample_stream_equals_cpu_port"] = bool(g == ref)
             res["checks"] = checks
+        if world == 1 and not args.no_v1:
+            # round 5: the same workload on silesia_mix_v1 (the stream of rounds 1-4) beside it, so that the change of corpus is visible
+            # on one line; Deflate's 32 KiB window cannot see what was wrong with v1
+            h1 = mix(za, n, version=1)
+            d_in.copy_(torch.from_numpy(h1).to(dev))
+            rc1, ol1, _ = enc.deflate_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, za.Method.Deflate_3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                enc.deflate_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, za.Method.Deflate_3)
+            torch.cuda.synchronize()
+            d1 = (time.perf_counter() - t1) / args.steps
+            res["deflate_on_silesia_mix_v1"] = {"value": round(n / d1 / 1e6, 2), "unit": "MB/s", "ms_per_step": round(d1 * 1e3, 3), "steps": args.steps, "rc": rc1,
+                                                "compression_ratio": round(ol1 / n, 4), "note": "the workload of rounds 1-4, device-resident, same steps"}
+            del h1
         if world == 1 and (args.bzip2_mib > 0 or args.lzma_entries > 0):
             # the secondary legs get a context of their own: the Deflate context's workspace (80 GiB for the 1 GiB entry) goes back first
             del d_in, d_out

@@ -55,7 +55,8 @@ enum {
   ZADA_E_NOMEM = -2,        /* host or device allocation failed */
   ZADA_E_HIP = -3,          /* HIP runtime error; see zada_last_error() */
   ZADA_E_TOO_LARGE = -4,    /* the input is larger than the call takes: zada_range_open takes ranges below 4 GiB - 64 MiB (zada_deflate* take streams of any
-                             * length, span after span), zada_lzma* entries below 2 GiB - 64 KiB and batches below 4 GiB */
+                             * length, span after span), zada_lzma* entries below 2 GiB - 64 KiB and batches below 4 GiB; LZMA_3 also what the match producer's 156 bytes of
+                             * device memory per input byte allow */
   ZADA_E_NO_DEVICE = -5,    /* no gfx950 device / HIP extension unusable */
   ZADA_E_REFERENCE = -6     /* LZMA_3 only: on this entry the reference's BT4 matcher reports a match that is none (lz77.adb:1262-1290 read behind pending
                              * bytes that no window fill took up, :1000-1017, 1397-1406: lzPos lags behind readPos) and the reference's own stream does not
@@ -78,7 +79,8 @@ const char *zada_version(void);
  * "budget" (ZADA_BUDGET: rounds of chain steps per position in the first match pass; 0 = unbounded, -1 = default),
  * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of
  * a stream the match finder takes at a time, multiple of 64), "span_mib" (MiB of a stream one pass takes; longer streams go span after
- * span, default 2048), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
+ * span, default 2048), "link_run" (segments of 32 KiB one workgroup of the link stage takes one after the other, making their cross links itself:
+ * 1 .. 64, 0 = by size), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
  * batching; "bz_lists", "bz_list_rows", "bz_text_order", "bz_pipeline", "bz_small_wg", "bz_split", "bz_tail_pct": scheduling of the BZip2 stages), "lzma_chunk" (positions of an LZMA stream one launch codes between two feedback calls; 0 = by level, -1 = one launch
  * per stream), "lzma_pool" (test knob: blocks of the LZMA_3 match sets' overflow pool to start with, 0 = by size; a pool that is too small is
  * counted and the match producer's walk runs again), "lzma_segment" (one LZMA_3 stream coded in launches: log2 of the positions per segment of
@@ -215,13 +217,15 @@ int zada_bzip2_batch(zada_ctx *ctx, int method, int count, const uint8_t *const 
  * The output is the Zip payload: the four bytes 16, 2, 5, 0 (:155-158), the 5-byte LZMA header, the range-coded stream.
  * The coder of a stream is one chain of dependent steps (adaptive probabilities): one workgroup codes it; entries are what runs in
  * parallel -- use zada_lzma_batch for many of them.  LZMA_3's BT4 matcher (lz77.adb:953-1827) is NOT part of that chain: its match sets are
- * a function of the input alone and are produced by data-parallel kernels before the coder starts (about 140 bytes of device memory per
- * input byte of the call, kept by the context).  A stream runs as a sequence of bounded launches (about half a second each,
+ * a function of the input alone and are produced by data-parallel kernels before the coder starts (about 156 bytes of device memory per
+ * input byte of the call, kept by the context: an LZMA_3 entry or batch of more than free device memory / 156 -- about 1.6 GiB on a
+ * 288 GB device with nothing else on it -- is refused with ZADA_E_TOO_LARGE and the limit in zada_last_error).  A stream runs as a sequence of bounded launches (about half a second each,
  * "lzma_chunk"), the coder's state waiting in device memory in between: fb (may be NULL) is called with 0, between the launches
  * and with 100, and a non-zero return ends the call with ZADA_ABORTED (Feedback / User_abort, zip-compress-lzma_e.adb:78-92).
  * LZMA_3 can also return ZADA_E_REFERENCE (see the enum: an entry on which the reference's own matcher leaves the format -- not with the dictionary
  * Zip.Compress.LZMA_E asks for unless the entry is beyond 256 MiB; per entry in zada_lzma_batch's rc array).
- * Limits: entries below 2 GiB - 64 KiB (ZADA_E_TOO_LARGE beyond: the shim Stores such an entry or raises); only the
+ * Limits: entries below 2 GiB - 64 KiB, and for LZMA_3 below what the producer's memory allows (see above) (ZADA_E_TOO_LARGE beyond: the shim
+ * Stores such an entry or raises); only the
  * (lc, lp, pb) = (3, 0, 2) methods LZMA_0 .. LZMA_3, not the data-specific LZMA_for_* variants (ZADA_E_INVALID).
  * --------------------------------------------------------------------------------------------------------------- */
 int zada_lzma(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout,

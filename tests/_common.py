@@ -99,6 +99,7 @@ def mixlib():
             subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-o", p, src, "-lm"], check=True)
         M = ctypes.CDLL(p)
         M.zada_silesia_mix.argtypes = [ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        M.zada_silesia_mix_v2.argtypes = M.zada_silesia_mix.argtypes
         _cache["m"] = M
     return _cache["m"]
 
@@ -109,10 +110,12 @@ def product():
     return _cache["z"]
 
 
-def silesia_mix(n, class_mask=0x1F, offset=0, seed=0x5A1E51A):
+def silesia_mix(n, class_mask=0x1F, offset=0, seed=0x5A1E51A, version=1):
+    """version 1: what the golden digests were taken on; version 2: segments seeded independently (the benchmark stream since round 5)."""
     b = np.zeros(n, dtype=np.uint8)
     if n:
-        mixlib().zada_silesia_mix(seed, class_mask, offset, n, b.ctypes.data)
+        M = mixlib()
+        (M.zada_silesia_mix_v2 if version >= 2 else M.zada_silesia_mix)(seed, class_mask, offset, n, b.ctypes.data)
     return b.tobytes()
 
 

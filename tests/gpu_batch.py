@@ -8,7 +8,7 @@ za = importlib.import_module("zip-ada_amd")
 enc = za.Encoder(0)
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
-mix = za.silesia_mix(count * size).tobytes()
+mix = za.silesia_mix(count * size, version=2).tobytes()
 datas = [mix[i * size:(i + 1) * size] for i in range(count)]
 enc.deflate_batch(datas[:64], 10)
 t0 = time.time(); res = enc.deflate_batch(datas, 10); dt = time.time() - t0

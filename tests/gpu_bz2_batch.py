@@ -6,7 +6,7 @@ from _common import product
 from _bzip2 import oracle_encode
 Z = product(); enc = Z.Encoder(0)
 for count, size in ((10000, 16 << 10), (2000, 256 << 10)):
-    mix = Z.silesia_mix(count * size)
+    mix = Z.silesia_mix(count * size, version=2)
     datas = [bytes(mix[i * size:(i + 1) * size]) for i in range(count)]
     enc.bzip2_batch(datas[:50], 14)
     t0 = time.time(); res = enc.bzip2_batch(datas, 14); dt = time.time() - t0

@@ -12,7 +12,7 @@ for knob in ("bz_lists", "bz_pipeline", "bz_small_wg", "bz_batch_melems", "bz_ta
         enc.set_knob(knob, int(os.environ[knob.upper()]))
 for mib in [int(x) for x in os.environ.get("BZ_MIBS", "64,256").split(",")]:
     n = mib << 20
-    h = Z.silesia_mix(n)                      # the benchmark stream (seed 0x5A1E51A, all five classes), as bench.py's BZip2 leg takes it
+    h = Z.silesia_mix(n, version=2)                      # the benchmark stream (seed 0x5A1E51A, all five classes), as bench.py's BZip2 leg takes it
     d_in = torch.from_numpy(h).cuda()
     d_out = torch.zeros(n + 4096, dtype=torch.uint8, device="cuda")
     for it in range(2):

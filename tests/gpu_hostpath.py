@@ -4,7 +4,7 @@ import importlib, numpy as np
 za = importlib.import_module("zip-ada_amd")
 enc = za.Encoder(0)
 n = 1 << 30
-host = za.silesia_mix(n, seed=0x5A1E51A)
+host = za.silesia_mix(n, seed=0x5A1E51A, version=2)
 hout = np.zeros(n + 64, dtype=np.uint8)
 for i in range(4):
     t = time.perf_counter(); rc, ol, crc = enc.deflate_into(host, hout, 10); dt = time.perf_counter() - t

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _common import product
 Z = product(); enc = Z.Encoder(0)
 E = int(os.environ.get("LZ_ENTRIES", "4096")); size = 16 << 10
-mix = Z.silesia_mix(E * size)
+mix = Z.silesia_mix(E * size, version=2)
 datas = [bytes(mix[i * size:(i + 1) * size]) for i in range(E)]
 enc.lzma_batch(datas[:8], 18)
 for m in (18, 17, 16):

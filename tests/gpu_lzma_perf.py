@@ -6,7 +6,7 @@ from _common import product
 Z = product(); enc = Z.Encoder(0)
 E = int(os.environ.get("LZ_ENTRIES", "4096")); size = 16 << 10
 one_kib = int(os.environ.get("LZ_ONE_KIB", "1024"))
-mix = Z.silesia_mix(max(E * size, one_kib << 10))
+mix = Z.silesia_mix(max(E * size, one_kib << 10), version=2)
 datas = [bytes(mix[i * size:(i + 1) * size]) for i in range(E)]
 if os.environ.get("LZ_WARM", "1") != "0":
     enc.lzma_batch(datas[:8], 18)

@@ -6,7 +6,7 @@ za = importlib.import_module("zip-ada_amd")
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 enc = za.Encoder(0)
-d = za.silesia_mix(mib << 20).tobytes()
+d = za.silesia_mix(mib << 20, version=int(os.environ.get("CORPUS", "2"))).tobytes()
 for _ in range(reps):
     t0 = time.time(); out, _c = enc.deflate(d, 10); dt = time.time() - t0
     tm = enc.last_timing()

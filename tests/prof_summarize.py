@@ -33,6 +33,18 @@ for ctr, sub in (("FETCH_SIZE", "_fetch"), ("WRITE_SIZE", "_write")):
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline` "
                 "(1 GiB Deflate_3); values in KB summed over the dispatches of each kernel; FETCH_SIZE is to be doubled on gfx950 "
                 "(MI355X_MICROARCH.md, HBM section)")
+import subprocess
+try:
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "zip-ada_amd", "bench.py"], capture_output=True, text=True).stdout.strip())
+    commit = commit + ("+uncommitted changes" if dirty else "")
+except Exception:
+    commit = None
+out["_commit"] = commit          # the tree the passes were taken on (bench.py prints it beside the traffic figures it reads from here)
+try:
+    out["_corpus"] = json.load(open(os.path.join(P, "bench_1gib.json")))["config"]["workload"]
+except Exception:
+    out["_corpus"] = None
 json.dump(out, open(os.path.join(P, "pmc_fetch_write_by_kernel.json"), "w"), indent=1)
 # SQ counters: what the kernels that are nowhere near the HBM roofline are bound by
 sq = {}

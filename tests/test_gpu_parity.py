@@ -321,10 +321,10 @@ def test_archive_of_many_small_files_equals_the_oracles(encoder):
 def test_full_size_properties(encoder):
     """BASELINE config C2 size (1 GiB, Deflate_3): properties that do not need the oracle at full size --
     the stream inflates back to the input (independent inflater), CRC equals zlib's, and the first
-    64 MiB entry compressed alone equals the oracle's stream (the encoder is a pure function)."""
+    16 MiB compressed alone equal the oracle's stream (the encoder is a pure function).  The benchmark stream (silesia_mix_v2)."""
     za = product()
     n = 1 << 30
-    d = za.silesia_mix(n)
+    d = za.silesia_mix(n, version=2)
     out, crc = encoder.deflate(d, 10)
     dec = zlib.decompressobj(-15)
     h = hashlib.sha256()
@@ -341,6 +341,47 @@ def test_full_size_properties(encoder):
     rc, ref, _ = oracle_deflate(head, 10)
     got, _ = encoder.deflate(head, 10)
     assert rc == 0 and got == ref
+
+
+def test_link_stage_in_runs_of_segments(encoder):
+    """Round 5: a workgroup of k_prev_links takes a RUN of segments one after the other and makes the cross links of all but the run's first
+    segment itself (tails read in key order while the sorted order is in LDS, occupancy bit maps instead of initialised tables, the searches that
+    end at a cross link settled against the previous segment's bytes); k_cross_links is left with the runs' first segments.  By default only from
+    64 MiB on ("link_run" 0): here forced to 2, 4 and 16 segments on small inputs -- tokens of every edge input, streams of several MiB of every
+    class of both corpus versions, different inputs one after the other on one context (stale tables under fresh bit maps), batches (entries'
+    first segments inside runs) and an input in shards -- all equal to the oracle / to the run-less path."""
+    rng = np.random.default_rng(5)
+    a = silesia_mix(3 << 20)
+    b = silesia_mix((5 << 20) + 4321, version=2)
+    cth = bytes((rng.integers(0, 3, 1 << 20) + 65).astype(np.uint8))
+    streams = [a, b, cth, silesia_mix(2 << 20, class_mask=16, version=2), a[:1 << 20], bytes(300000) + b[:1 << 20], silesia_mix(1 << 20, class_mask=8, version=2), b"abcdefgh" * 40000 + a[:200000]]
+    refs = {(i, m): oracle_deflate(x, m) for i, x in enumerate(streams) for m in (10, 8)}
+    mix = silesia_mix(3 << 20, version=2)
+    datas = [b"", b"a", bytes(mix[:40000]), bytes(mix[40000:240000]), bytes(mix[:(1 << 20) + 17]), bytes(mix[100000:100000 + 70000]), bytes(mix[1 << 20:(1 << 20) + 32768]), bytes(mix[:65536])]
+    encoder.set_knob("link_run", 1)
+    batch_ref = encoder.deflate_batch(datas, 10)
+    try:
+        for run in (2, 4, 16):
+            encoder.set_knob("link_run", run)
+            for method in (10, 8):
+                for name, d in edge_inputs().items():
+                    if len(d) >= 32768:
+                        ta = oracle_tokens(d, method)
+                        tb = encoder.lz77_tokens(d, method)
+                        assert len(ta) == len(tb) and (ta == tb).all(), (run, method, name)
+                for i, x in enumerate(streams):
+                    rc, ref, crc = refs[(i, method)]
+                    rc2, out, crc2 = gpu_deflate(encoder, x, method)
+                    assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), (run, method, i)
+            assert encoder.deflate_batch(datas, 10) == batch_ref, run
+            encoder.set_knob("shard_kib", 1024)
+            rc, ref, crc = refs[(1, 10)]
+            rc2, out, crc2 = gpu_deflate(encoder, streams[1], 10)
+            encoder.set_knob("shard_kib", 1 << 20)
+            assert rc == rc2 and out == ref and crc == crc2, run
+    finally:
+        encoder.set_knob("link_run", 0)
+        encoder.set_knob("shard_kib", 1 << 20)
 
 
 def test_stale_workspace_between_calls(encoder):

@@ -88,6 +88,7 @@ def load_library():
     L.zada_last_timing.argtypes = [vp, vp, vp, i32]
     L.zada_last_trace.argtypes = [vp, vp, u64, u64p]
     L.zada_silesia_mix.argtypes = [u64, ctypes.c_uint, u64, u64, vp]
+    L.zada_silesia_mix_v2.argtypes = [u64, ctypes.c_uint, u64, u64, vp]
     L.zada_set_knob.argtypes = [vp, ctypes.c_char_p, i32]
     L.zada_range_open.argtypes = [vp, i32, vp, u64, u64, u64, u64, u64]
     L.zada_range_lz.argtypes = [vp, vp, vp]
@@ -517,13 +518,15 @@ class Encoder:
         return [(names[i].decode(), ms[i]) for i in range(k)]
 
 
-def silesia_mix(nbytes, seed=0x5A1E51A, class_mask=0x1F, offset=0):
-    """Deterministic synthetic corpus (csrc/silesia_mix.c), as a numpy uint8 array."""
+def silesia_mix(nbytes, seed=0x5A1E51A, class_mask=0x1F, offset=0, version=1):
+    """Deterministic synthetic corpus (csrc/silesia_mix.c), as a numpy uint8 array.  version 1 = "silesia_mix_v1" (what the committed
+    golden digests were taken on; its 64 KiB segments are shifted copies of one stream of draws, which only encoders that look
+    further back than 32 KiB can see), version 2 = "silesia_mix_v2" (segments seeded independently: the benchmark stream)."""
     import numpy as np
     L = load_library()
     b = np.zeros(nbytes, dtype=np.uint8)
     if nbytes:
-        L.zada_silesia_mix(seed, class_mask, offset, nbytes, b.ctypes.data)
+        (L.zada_silesia_mix_v2 if version >= 2 else L.zada_silesia_mix)(seed, class_mask, offset, nbytes, b.ctypes.data)
     return b
 
 

@@ -151,6 +151,7 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   A(in, cap + IN_PAD + 64);
   for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); A(ltails[l], nseg32 * 65536); }
   A(S3, nseg32 * 32768); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768); A(segmax, nseg32 + 16); A(heavy, nseg32 * 2048);
+  A(occ, (uint64_t)NLEVELS * nseg32 * 2048); W.occ_level_stride = nseg32 * 2048;
   for (int l = 0; l < NLEVELS; l++) A(dplane[l], cap + 64);
   A(dlim, cap + 64);
   A(M, cap + 64);
@@ -963,6 +964,7 @@ zada_ctx *zada_create(int device) {
   // tuning knobs: read once per context
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
   if (const char *e = getenv("ZADA_INNER_BUDGET")) z->c.knob_inner_budget = atoi(e);
+  if (const char *e = getenv("ZADA_LINK_RUN")) { const int v = atoi(e); if (v >= 0 && v <= 64 && !(v & (v - 1))) z->c.knob_link_run = v; }
   if (const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS")) { if (atoi(e) > 0) z->c.knob_max_demand_rounds = atoi(e); }
   if (const char *e = getenv("ZADA_SHARD_KIB")) { if (atoi(e) >= 64 && atoi(e) % 64 == 0) z->c.knob_shard_kib = atoi(e); }
   return z;
@@ -980,6 +982,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   if (!z || !name) return ZADA_E_INVALID;
   if (!strcmp(name, "budget")) z->c.knob_budget = value;
   else if (!strcmp(name, "inner_budget")) z->c.knob_inner_budget = value;
+  else if (!strcmp(name, "link_run")) { if (value < 0 || value > 64 || (value & (value - 1))) return ZADA_E_INVALID; z->c.knob_link_run = value; }
   else if (!strcmp(name, "span_mib")) { if (value < 1 || value > 3968) return ZADA_E_INVALID; z->c.knob_span_mib = value; }
   else if (!strcmp(name, "bz_batch_mib")) { if (value < 1 || value > 2048) return ZADA_E_INVALID; z->c.knob_bz_batch_mib = value; }
   else if (!strcmp(name, "bz_span_mib")) { if (value < 24 || value > 3072) return ZADA_E_INVALID; z->c.knob_bz_span_mib = value; }

@@ -316,6 +316,9 @@ struct Buf {
   void *p = nullptr; size_t cap = 0;
   template <typename T> T *as() const { return (T *)p; }
 };
+// what bt4_produce books per position of the arena, grow()'s slack of 1/16 included: six key / value planes of the sorts (24) and their scratch (8), the two
+// predecessor planes (8), the tree (8), the inline match sets (1 + 16 + 32), flags / heads / shorts (16), the 16-byte records, the overflow pool (16)
+constexpr unsigned BT4_BYTES_PER_POSITION = 156;
 struct State {
   Buf tile_job, jobs, runs, k2, k3, k4, val, ks, vs, tmp, d2, d3, tree, cnt, sl, sd, ol, od, flags, heads, longs, shorts, cnts, scan, small, rec, weight;
   Buf *all[27] = {&tile_job, &jobs, &runs, &k2, &k3, &k4, &val, &ks, &vs, &tmp, &d2, &d3, &tree, &cnt, &sl, &sd, &ol, &od, &flags, &heads, &longs, &shorts, &cnts, &scan, &small, &rec, &weight};
@@ -362,6 +365,23 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   const uint64_t P64 = (arena_bytes + 63) & ~63ull;
   if (P64 >= (1ull << 32)) { c->err = "LZMA: a batch of 4 GiB and more is not taken at once"; return ZADA_E_TOO_LARGE; }
   const uint32_t P = (uint32_t)P64;
+  {
+    // The producer books everything for the whole arena at once -- BT4_BYTES_PER_POSITION per position with grow()'s slack -- and keeps it in the
+    // context: an arena that cannot fit the device's free memory is refused with the limit in the message instead of failing half way with NOMEM.
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      size_t held = 0;
+      for (Buf *b : B->all) held += b->cap;
+      const double need = (double)BT4_BYTES_PER_POSITION * (double)P;
+      if (need > (double)fr + (double)held) {
+        static thread_local char msg[200];
+        snprintf(msg, sizeof msg, "LZMA_3: the match producer needs about %u bytes per input byte; %.1f GiB of entries do not fit the %.1f GiB that are free on this device (limit here: %.2f GiB per call)",
+                 BT4_BYTES_PER_POSITION, P / 1073741824.0, ((double)fr + (double)held) / 1073741824.0, ((double)fr + (double)held) / BT4_BYTES_PER_POSITION / 1073741824.0);
+        c->err = msg;
+        return ZADA_E_TOO_LARGE;
+      }
+    }
+  }
   std::vector<Bt4Job> hj(jobs.size());
   std::vector<Bt4Run> hr, one;
   std::vector<uint32_t> tj(P / 64, NOJOB);
@@ -379,7 +399,9 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
     hr.insert(hr.end(), one.begin(), one.end());
     b.run_cnt = (uint32_t)one.size();
     for (const Bt4Run &r : one) if (r.cls != 2) sorted += r.end - r.start;
-    if (J.n <= BT4_LDS_N && J.n > (uint64_t)BT4_NICE && one.size() == 2 && one[0].cls == 0 && one[1].cls == 2 && one[0].end == J.n - BT4_NICE) {
+    // (an entry walked in LDS belongs to the unsegmented walks: the segmented path returns before they are launched and its split drops
+    // the buckets of small entries -- a 16 384-byte stream coded with lzma_segment = 13 got no match sets that way)
+    if (seg_shift >= 32 && J.n <= BT4_LDS_N && J.n > (uint64_t)BT4_NICE && one.size() == 2 && one[0].cls == 0 && one[1].cls == 2 && one[0].end == J.n - BT4_NICE) {
       b.small = 1; small_jobs.push_back((uint32_t)e);
     }
     if (J.hash4_size > hmax) hmax = J.hash4_size;

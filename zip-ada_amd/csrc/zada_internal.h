@@ -140,6 +140,7 @@ struct Workspace {
   uint16_t *S3 = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
   uint32_t *segmax = nullptr;                // largest 15-bit bucket of every segment
   uint16_t *heavy = nullptr;                 // per segment 2048 x u16: the number of its heavy 15-bit buckets, then their hashes (zada_lz.hip)
+  uint32_t *occ = nullptr; uint64_t occ_level_stride = 0;   // per level and segment 2 048 words: which buckets of the segment's tails table are occupied (k_prev_links in runs)
   uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr;  // DistPlanes
   uint16_t *SK = nullptr, *idxK = nullptr, *cntK = nullptr;   // RunPtrs
   MatchPair *M = nullptr;                    // match tables
@@ -269,6 +270,7 @@ struct Ctx {
   // zada_set_knob)
   int knob_budget = -1;             // ZADA_BUDGET: rounds of chain steps per position in the first match pass (0 = unbounded, -1 = default)
   int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
+  int knob_link_run = 0;            // ZADA_LINK_RUN: segments per workgroup of k_prev_links (0 = by size: lz_shard)
   int knob_inner_budget = 0;        // ZADA_INNER_BUDGET: rounds for positions deep inside a match (0 = as every other position; A/B: 1 round saves 4.7 ms in k_match and costs 8.9 ms of demand searches, 2 rounds: -3.2 / +3.7)
   int knob_span_mib = 2048;         // MiB of a stream one pass takes (longer streams: spans one after the other, deflate_spans)
   int knob_batch_mib = 512;         // MiB of LZ buffer one batch of small entries may take (zada_deflate_batch)

@@ -203,11 +203,23 @@ constexpr uint32_t DISTL_GAVEUP = 0x7FFF, WALK_CAP = ZADA_WALK_CAP;
 static_assert(MAX_DIST < 0x7FFF, "the give-up marker is no distance");
 constexpr uint32_t HEAVY_STRIDE = 2048, HEAVY_CAP = HEAVY_STRIDE - 1;       // per segment: the list of its heavy 15-bit buckets
 static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
+// LDS of k_prev_links: the sort's two halves (128 KiB), its counters (16 KiB + 64 B); with runs of segments per workgroup 8 KiB more for the bit map of
+// occupied buckets; the previous segment's bytes are staged over counters and bit map (131 072 ..) when both are dead.
+constexpr int PL_LDS = 144 * 1024 + 64, PL_OCC_OFF = PL_LDS, PL_LDS_RUNS = 160 * 1024, PL_PREV_OFF = 131072;
+static_assert(PL_OCC_OFF + 8192 <= PL_LDS_RUNS && PL_PREV_OFF + 32768 <= PL_LDS_RUNS, "k_prev_links: LDS map of the fused cross links");
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, Layout L, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
                                                      DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg, uint32_t *__restrict__ segmax,
-                                                     uint16_t *__restrict__ heavy, uint32_t seg0) {
+                                                     uint16_t *__restrict__ heavy, uint32_t seg0, uint32_t run_len, uint32_t seg_end,
+                                                     uint32_t *__restrict__ occ, uint64_t occ_level_stride) {
+  // run_len consecutive segments per workgroup, one after the other (seg0 + blockIdx.x * run_len ...; up to seg_end).  From the second segment of
+  // a run on the workgroup makes the CROSS LINKS itself ("fused"): the first member of each of a level's buckets is linked to the last member
+  // of that bucket in the segment before -- whose tails table this very workgroup wrote a moment ago -- while the sorted order is still in LDS
+  // (neighbouring lanes hold neighbouring keys: the table is read in ascending order, sector by sector, instead of being staged as 128 KB per
+  // segment and level by k_cross_links), and the searches for the nearest four-byte match that end at such a link are settled against the
+  // previous segment's bytes (staged behind the segment's own once the walks are over).  k_cross_links is left with the first segment of every run.
+  // Which buckets of a table are occupied (the tables are not initialised) is kept as a bit map per segment and level (occ: 2 048 words each).
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
 #define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
@@ -220,10 +232,20 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint32_t *AB = (uint32_t *)smem;                // A and B as one array of 32 768 words (the sorts)
   uint32_t *cnt = (uint32_t *)(B + 32768);        // 16 KiB
   uint32_t *wsum = cnt + 4096;                    // 64 B
-  const uint64_t seg = (uint64_t)blockIdx.x + seg0, base = seg * 32768ull;      // (seg0: the launch covers the segments of one piece of the input)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool runs = run_len > 1;
+  uint32_t *occL = (uint32_t *)(smem + PL_OCC_OFF);                              // runs: the bit map of the level's occupied buckets, this segment
+#pragma unroll 1
+  for (uint32_t jrun = 0; jrun < run_len; jrun++) {
+  const uint64_t seg = (uint64_t)blockIdx.x * run_len + jrun + seg0, base = seg * 32768ull;      // (seg0: the launch covers the segments of one piece of the input)
+  if (seg >= seg_end) break;
   const uint32_t m = lay_inserted(L, seg);
   const bool first_seg = lay_first(L, seg);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool fused = jrun > 0 && !first_seg;                                    // cross links from this workgroup (it has just finished segment seg - 1)
+  const bool prev_first = fused && lay_first(L, seg - 1);
+#ifdef ZADA_PL_STATS
+  tph = 8;
+#endif
   uint32_t *bsc = bsc3 + seg * 32768ull;          // bucket start | count << 16
   uint16_t *s3 = S3 + seg * 32768ull;
   uint8_t *t3 = T3 + seg * 32768ull;              // top three bits of byte 0: what the 15-bit hash drops
@@ -262,6 +284,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     uint32_t i0 = (uint32_t)w * 2048 + lane;
     asm volatile("" : "+v"(i0));
     const int rem = (int)m - (int)i0;
+    if (runs && lvl > 0) { occL[tid] = 0; occL[tid + 1024] = 0; }   // (the barriers of the sort lie between this and its use)
     // ---- sort: AB[i] := element | key << 16 in (key, position) order (A and B as one array of 32-bit words) ----
     {
       {
@@ -309,6 +332,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     {
       const uint32_t *pp = AB + i0;
       uint32_t *pf = F + (i0 >> 5);
+      uint32_t firstmask = 0;                                          // bit `it`: the element starts a bucket
 #pragma unroll
       for (int it = 0; it < 32; it++) {
         uint32_t x = 0;
@@ -322,12 +346,44 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           uint32_t d = 0;
           if (!first) { const uint32_t e0 = pm & 0xFFFFu; if (!(first_seg && e0 == 0)) d = e - e0; }     // NIL = position 0, lz77.adb:467
           x = e | ((uint32_t)last << 15) | (d << 16);
-          if (lvl > 0 && last) tail[k] = (uint16_t)e;
         }
         ed[it] = x;
+        firstmask |= (uint32_t)first << it;
         if (want_runs) {
           const unsigned long long mk = __ballot(first);
           if (lane == 0) { pf[it * 2] = (uint32_t)mk; pf[it * 2 + 1] = (uint32_t)(mk >> 32); }
+        }
+      }
+      if (lvl > 0) {
+        // tails of the level's buckets; with runs: the bit map of occupied buckets and, fused, the cross links of the buckets' first members.
+        // Eight elements at a time, the table look-ups of all eight in front of everything that depends on them and of the stores.
+        const uint16_t *tprev = tail - 65536;                                       // the table of the segment before (fused)
+        const uint32_t *oprev = occ + (uint64_t)(lvl - 1) * occ_level_stride + (seg - 1) * 2048ull;
+#pragma unroll
+        for (int g8 = 0; g8 < 4; g8++) {
+          uint32_t kk[8], tt[8], oo[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) { const int it = g8 * 8 + q; kk[q] = (it * 64 < rem) ? pp[it * 64] >> 16 : 0u; }
+          if (fused) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) { tt[q] = tprev[kk[q]]; oo[q] = oprev[kk[q] >> 5]; }
+          }
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const int it = g8 * 8 + q;
+            if (it * 64 < rem) {
+              const uint32_t e = ed[it] & 0x7FFFu;
+              if ((firstmask >> it) & 1u) {
+                if (runs) atomicOr(&occL[kk[q] >> 5], 1u << (kk[q] & 31u));
+                if (fused) {
+                  // the bucket's tail in the previous segment, if the bucket has members there, within MAX_DIST, and not position 0 of an entry (:467)
+                  const uint32_t t = tt[q], d = e + 32768u - t;
+                  if (((oo[q] >> (kk[q] & 31u)) & 1u) && d <= (uint32_t)MAX_DIST && !(prev_first && t == 0)) ed[it] |= d << 16;
+                }
+              }
+              if ((ed[it] >> 15) & 1u) tail[kk[q]] = (uint16_t)e;
+            }
+          }
         }
       }
     }
@@ -395,6 +451,10 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       }
     }
     __syncthreads();                                 // keys (A) and sorted positions (B) are dead from here
+    if (runs && lvl > 0) {                           // this segment's bit map of occupied buckets, for the next segment of the run
+      uint32_t *ocur = occ + (uint64_t)(lvl - 1) * occ_level_stride + seg * 2048ull;
+      ocur[tid] = occL[tid]; ocur[tid + 1024] = occL[tid + 1024];
+    }
     if (lvl == 0 && tid == 0) { segmax[seg] = cnt[2048]; hvy[0] = cnt[2049] <= HEAVY_CAP ? (uint16_t)cnt[2049] : (uint16_t)0xFFFF; }
     for (uint32_t i = tid; i < (m + 16 + 15) / 16; i += 1024) ((uint4 *)A)[i] = ((const uint4 *)sin)[i];   // A := bytes
 #pragma unroll
@@ -431,9 +491,12 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       // the reference accepts at exactly that distance (the head of the 15-bit chain, :850 vs :820; k_cross_dist).
       // Levels >= 4 say where to continue: the chain ended at q, the first member of the bucket in this segment, whose link
       // k_cross_links will point into the previous segment (0x8000 | e - q; distances proper stay below 0x8000).
+      // Fused (levels >= 4): q's link already points into the previous segment -- or is none, when its bucket has no member in reach there, and then
+      // nothing has (older members lie farther back still); the searches that end at a link are settled below, once the walks are over.
       auto dflt_of = [&](uint32_t e, uint32_t q) -> uint32_t {
         if (first_seg) return 0u;
         if (lvl == 0) return e < (uint32_t)TOO_FAR ? (q == e ? DIST3_CONT_FIRST : DIST3_CONTINUE) : (q == e ? DIST3_HEADCHK : 0u);
+        if (fused && P[q] == 0) return 0u;
         return DISTL_CONTINUE | (e - q);
       };
       constexpr uint32_t QCAP = 4000;
@@ -446,7 +509,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       auto walk = [&](uint32_t e, uint32_t &q, uint64_t mine, uint32_t maxs, uint32_t &dl) -> bool {
         uint32_t step = P[q];
         for (uint32_t sidx = 0; sidx < maxs; sidx++) {
-          if (step == 0) { dl = dflt_of(e, q); return true; }
+          if (step - 1u >= q) { dl = dflt_of(e, q); return true; }      // no link, or (fused) one that leaves the segment: step > q
           q -= step;
           const uint32_t dist = e - q;
           step = P[q];                                              // next link and this candidate's bytes in one LDS round trip
@@ -481,13 +544,13 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 #pragma unroll
         for (int j = 0; j < 4; j++) { mn[j] = lb8(ee[j]) & lmask; st[j] = P[ee[j]]; }          // (no conditions: the LDS reads overlap)
 #pragma unroll
-        for (int j = 0; j < 4; j++) th[j] = lb8(ee[j] - st[j]) & lmask;                        // (no link: its own bytes)
+        for (int j = 0; j < 4; j++) th[j] = lb8(st[j] <= ee[j] ? ee[j] - st[j] : ee[j]) & lmask;   // (no link, or one that leaves the segment: its own bytes)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const uint32_t e = ee[j], step = st[j];
           uint32_t dl = dflt_of(e, e), q = e;
           bool pend = false;
-          if (ex[j] && step != 0) {
+          if (ex[j] && step - 1u < e) {
             q = e - step;
             if (lvl == 0) {
               // the head of the 15-bit chain: accepted up to exactly MAX_DIST (:850); the walk behind it only to TOO_FAR
@@ -538,7 +601,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
             uint64_t th[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              if (act[j] && st4[j] == 0) { dl4[j] = dflt_of(e4[j], q4[j]); act[j] = false; }    // the chain ends inside the segment
+              if (act[j] && st4[j] - 1u >= q4[j]) { dl4[j] = dflt_of(e4[j], q4[j]); act[j] = false; }    // the chain ends inside the segment
               qx[j] = act[j] ? q4[j] - st4[j] : q4[j];
             }
 #pragma unroll
@@ -586,10 +649,39 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         }
         __syncthreads();
       }
+      if (fused && lvl > 0) {
+        // The searches that ended at a link into the previous segment: that link leads to the most recent position there with the same hash, which
+        // usually IS the nearest match; a hash collision leaves the search to k_cross_dist (marker unchanged), as k_cross_links does.  The previous
+        // segment's bytes are staged over the sort's counters and the bit map (both dead); the plane is read back as it was written above.
+        static_assert(NLEVELS <= 2, "the candidate compare of the fused cross links takes four bytes");
+        uint8_t *pbL = smem + PL_PREV_OFF;
+        {
+          const uint4 *bs = (const uint4 *)(in + base - 32768ull);
+          for (int i = tid; i < 32768 / 16; i += 1024) ((uint4 *)pbL)[i] = bs[i];
+        }
+        __syncthreads();
+        for (uint32_t e0 = tid; e0 < m; e0 += 8192) {
+          uint32_t pl[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) { const uint32_t e = e0 + 1024u * k; pl[k] = e < m ? (uint32_t)plane[e] : 0u; }
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            if (!(pl[k] & DISTL_CONTINUE)) continue;
+            const uint32_t e = e0 + 1024u * k, q = e - (pl[k] & 0x7FFFu), t = q + 32768u - P[q], d = e + 32768u - t;
+            if (d > (uint32_t)MAX_DIST) plane[e] = 0;
+            else if (t <= 32768u - 4u) {
+              const uint32_t *wp = (const uint32_t *)(pbL + (t & ~3u));
+              const uint32_t theirs = __builtin_amdgcn_alignbyte(wp[1], wp[0], t & 3u);   // (t <= 32764: both words inside the staged bytes)
+              if (theirs == (uint32_t)lb8(e)) plane[e] = (uint16_t)d;
+            }
+          }
+        }
+      }
     }
     __syncthreads();
     PL_STAMP();
   }
+  }   // the run's segments
 }
 
 // Cross-segment links: grid = (segments - 1, levels), block = 1024.  The workgroup of (segment s, level l) stages
@@ -610,11 +702,12 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 // slower: every part re-reads the positions.)
 constexpr int CL_LDS_PLANE = 131072 + 32768;
 // (seg0: the launch takes the segments seg0 + 1 ..: one piece of an input that is still arriving, lz_shard)
-__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv, DistPlanes dp, uint32_t seg0) {
+__global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv, DistPlanes dp, uint32_t seg_first, uint32_t seg_stride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *tl = (uint16_t *)smem;                                 // 128 KiB
   const uint8_t *pb = smem + 131072;                               // the previous segment's bytes (levels with a plane)
-  const uint64_t seg = (uint64_t)blockIdx.x + 1 + seg0, base = seg * 32768ull, pbase = base - 32768ull;
+  // (the segments seg_first, seg_first + seg_stride, ...: with runs of segments per workgroup in k_prev_links, the first segment of every run)
+  const uint64_t seg = (uint64_t)blockIdx.x * seg_stride + seg_first, base = seg * 32768ull, pbase = base - 32768ull;
   const int l = blockIdx.y, tid = threadIdx.x;
   const bool has_plane = l + 1 < NLEVELS;
   if (lay_first(L, seg)) return;                                   // an entry's first segment has nothing before it
@@ -1771,7 +1864,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   const uint32_t nseg = (uint32_t)((n_ins + 32767) / 32768);
   c->tmark("lz:begin");
   if (!c->lz_attrs_set) {                            // per context: the attribute belongs to the function object of the current device
-    hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
+    hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS_RUNS);
     hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS_PLANE);
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS);
     hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
@@ -1792,6 +1885,21 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     hipMemsetAsync(W.dlim, 0xFF, (size_t)n * 4, c->stream2);
     hipEventRecord(c->ev_dlim, c->stream2);
 #endif
+    // Runs of R segments per workgroup of k_prev_links (it then makes the cross links of all but a run's first segment itself; k_cross_links takes
+    // those): as long as the launch still fills the chip several times over -- R = 16 from 512 MiB on, 1 (no runs) below 64 MiB; a piece of an
+    // input that is still arriving (2 048 segments) goes as 256 workgroups of 8.  Knob "link_run" (0 = this rule).
+    uint32_t R = 1;
+    if (c->knob_link_run > 0) R = (uint32_t)c->knob_link_run;
+    else if (job.need) R = 8;
+    else while (R < 16 && nseg / (2 * R) >= 1024) R *= 2;
+    auto prev_links = [&](uint32_t s0, uint32_t s1) {                     // segments [s0, s1), s0 a multiple of R
+      hipLaunchKernelGGL(k_prev_links, dim3((s1 - s0 + R - 1) / R), dim3(1024), R > 1 ? PL_LDS_RUNS : PL_LDS, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
+                         W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0, R, s1, W.occ, (uint64_t)W.occ_level_stride);
+    };
+    auto cross_links = [&](uint32_t from, uint32_t to) {                  // the segments of [from, to) that k_prev_links did not link itself
+      const uint32_t first = (from + R - 1) / R * R;
+      if (first < to) hipLaunchKernelGGL(k_cross_links, dim3((to - first + R - 1) / R, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl, first, R);
+    };
     if (job.need) {
       // The input is still arriving (host buffers): k_prev_links and k_bucket_limits on the segments of what has come, 64 MiB at a time --
       // a segment's workgroups read its 32 KiB and at most 31 bytes behind them, so a piece ends 64 bytes short of what is there.
@@ -1806,7 +1914,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       constexpr double SLOW_PIECE_S = 2.0e-3;
       uint32_t cl_from = 1;                                              // first segment whose cross links are still to be made (segment 0 has nothing before it)
       auto cross_links_upto = [&](uint32_t s1) {
-        if (s1 > cl_from) hipLaunchKernelGGL(k_cross_links, dim3(s1 - cl_from, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl, cl_from - 1);
+        if (s1 > cl_from) cross_links(cl_from, s1);
         if (s1 > cl_from) cl_from = s1;
       };
       auto t_prev = std::chrono::steady_clock::now();
@@ -1817,8 +1925,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
         const auto t_now = std::chrono::steady_clock::now();
         const bool slow = s0 > 0 && std::chrono::duration<double>(t_now - t_prev).count() >= SLOW_PIECE_S;
         t_prev = t_now;
-        hipLaunchKernelGGL(k_prev_links, dim3(s1 - s0), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
-                           W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0);
+        prev_links(s0, s1);
 #ifndef ZADA_OLD_INIT
         if (s0 == 0) hipStreamWaitEvent(st, c->ev_dlim, 0);              // (k_bucket_limits writes into the plane the second stream has preset)
 #endif
@@ -1830,8 +1937,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       cross_links_upto(nseg);
       if (nseg > 1) hipLaunchKernelGGL(k_cross_dist, dim3((uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS)), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n);
     } else
-    hipLaunchKernelGGL(k_prev_links, dim3(nseg), dim3(1024), 144 * 1024 + 64, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
-                       W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, 0u);
+    prev_links(0, nseg);
 #ifndef ZADA_OLD_INIT
     if (!job.need) hipStreamWaitEvent(st, c->ev_dlim, 0);
 #endif
@@ -1843,7 +1949,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     if (!job.need) {
       if (nseg > 1) {
         const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
-        hipLaunchKernelGGL(k_cross_links, dim3((uint32_t)nseg - 1, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl, 0u);
+        cross_links(1, nseg);
         hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n);
       }
       hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax, W.heavy, 0u);
