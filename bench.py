@@ -670,20 +670,22 @@ def main():
     if world > 1:
         # what the N > 1 line says about itself: the backend that really carried the exchange, the ranks the process group saw, every rank's
         # own time for the K steps and where it spent its exchange time (so that a scaling loss can be attributed)
-        mine = {"rank": rank, "s": dt, "exchange_s": dict(xt)}
-        every = [None] * world
-        dist.all_gather_object(every, mine)
+        keys = ["all_gather_state", "boundary_atoms", "carry_chain", "spans", "gather_stitch"]
+        mine = torch.tensor([dt] + [xt.get(k, 0.0) for k in keys], dtype=torch.float64, device=torch.device("cpu") if emulate else dev)
+        allr = torch.empty(world * mine.numel(), dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(allr, mine)                # (one fixed-size tensor collective, as in the timed region: no object collectives anywhere)
+        allr = allr.cpu().view(world, -1).tolist()
+        every = [{"s": v[0], "exchange_s": dict(zip(keys, v[1:]))} for v in allr]
         t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if emulate else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        keys = sorted({k for e in every for k in e["exchange_s"]})
         multi = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
                  "rank_ms_per_step": {"min": round(min(e["s"] for e in every) * 1e3 / args.steps, 3), "max": round(max(e["s"] for e in every) * 1e3 / args.steps, 3)},
                  "exchange_ms_per_step": {k: {"rank0": round(every[0]["exchange_s"].get(k, 0.0) * 1e3 / args.steps, 3),
                                               "max": round(max(e["exchange_s"].get(k, 0.0) for e in every) * 1e3 / args.steps, 3)} for k in keys},
                  "exchange_note": "wall clock a rank spends inside each exchange step of sharding.deflate_stream_rank (waiting for its neighbours included): "
-                                  "all_gather_state = parser states and atom counts (a), boundary_atoms = edge atoms by all_gather (c), carry_chain = the 352-byte chooser state "
-                                  "from rank to rank (d), spans = bit positions by all_gather (d), gather_stitch = payloads to rank 0 and the OR (e)"}
+                                  "all_gather_state = parser states and atom counts, one 64-byte-per-rank tensor all_gather (a), boundary_atoms = edge atoms by all_gather (c), carry_chain = the 352-byte chooser state "
+                                  "from rank to rank, its receive posted before the range's analysis (d), spans = bit positions, one 24-byte-per-rank tensor all_gather (d), gather_stitch = payloads to rank 0 and the OR (e)"}
 
     if rank == 0:
         rc, out_len, crc = last["rc"], last["out_len"], last["crc"]

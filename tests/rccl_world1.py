@@ -1,7 +1,8 @@
 """GPU script (run by tests/test_ranges.py::test_rccl_backend_with_a_world_of_one): the exchanges of the multi-GPU path on torch.distributed's
 "nccl" backend -- RCCL -- with a world of ONE rank, which is all a one-GPU box can hold.  It proves little about xGMI, but it does prove that
-every call the protocol makes (all_gather_object, all_gather of device tensors, the asynchronous gather of the payloads, broadcast_object_list,
-all_reduce, barrier) is accepted by the RCCL backend with the dtypes and devices used, and that one range through TorchComm gives the oracle's stream."""
+every call the protocol makes (the fixed-size int64 tensor all_gathers of the parser states and bit positions, the padded one of the BZip2 tables,
+all_gather of device tensors, the posted receive / send pair of the chooser chain -- to itself, the only peer there is --, the asynchronous gather
+of the payloads, all_reduce, barrier) is accepted by the RCCL backend with the dtypes and devices used, and that one range through TorchComm gives the oracle's stream."""
 import importlib, os, sys, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,8 +18,10 @@ za = importlib.import_module("zip-ada_amd")
 sh = importlib.import_module("zip-ada_amd.sharding")
 enc = za.Encoder(0)
 comm = sh.TorchComm(dev)
-assert comm.all_gather_obj({"atoms": 5, "exit": (1, 2)}) == [{"atoms": 5, "exit": (1, 2)}]
-assert comm.bcast_obj("x", 0) == "x"
+import numpy as np
+assert comm.all_gather_i64([1, 5, 1 << 40, 2]) == [[1, 5, 1 << 40, 2]]
+tabs = comm.all_gather_i64_var(np.array([7, 0xFFFFFFFFFFFFFFFF, 3], dtype=np.uint64))
+assert len(tabs) == 1 and tabs[0].tolist() == [7, 0xFFFFFFFFFFFFFFFF, 3] and comm.all_gather_i64_var(np.zeros(0, np.uint64))[0].size == 0
 t = torch.arange(1000, dtype=torch.int32, device=dev)
 g = comm.all_gather_dev(t)
 assert len(g) == 1 and bool((g[0] == t).all())

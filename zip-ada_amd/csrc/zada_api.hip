@@ -151,7 +151,6 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   A(in, cap + IN_PAD + 64);
   for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); A(ltails[l], nseg32 * 65536); }
   A(S3, nseg32 * 32768); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768); A(segmax, nseg32 + 16); A(heavy, nseg32 * 2048);
-  A(occ, (uint64_t)NLEVELS * nseg32 * 2048); W.occ_level_stride = nseg32 * 2048;
   for (int l = 0; l < NLEVELS; l++) A(dplane[l], cap + 64);
   A(dlim, cap + 64);
   A(M, cap + 64);

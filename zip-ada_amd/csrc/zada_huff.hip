@@ -94,7 +94,11 @@ __global__ void __launch_bounds__(64) k_window_descr(EntropyView v, uint32_t kst
   const int lane = threadIdx.x;
   for (int i = lane; i < 320; i += 64) hist[i] = (i == 256) ? 1u : 0u;     // empty_lit_len_stat :946
   __syncthreads();
+#ifdef ZADA_WD_NOHIST   /* timing experiment only (wrong results): the window's first 64 * 8 atoms stand for all of them */
+  for (int64_t a0 = lo + lane; a0 <= hi && a0 < lo + 512; a0 += 64 * 8) {
+#else
   for (int64_t a0 = lo + lane; a0 <= hi; a0 += 64 * 8) {              // eight loads in flight, then their counts
+#endif
     uint32_t at[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) { const int64_t a = a0 + 64 * u; at[u] = atoms[a <= hi ? a : hi]; }

@@ -140,7 +140,6 @@ struct Workspace {
   uint16_t *S3 = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
   uint32_t *segmax = nullptr;                // largest 15-bit bucket of every segment
   uint16_t *heavy = nullptr;                 // per segment 2048 x u16: the number of its heavy 15-bit buckets, then their hashes (zada_lz.hip)
-  uint32_t *occ = nullptr; uint64_t occ_level_stride = 0;   // per level and segment 2 048 words: which buckets of the segment's tails table are occupied (k_prev_links in runs)
   uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr;  // DistPlanes
   uint16_t *SK = nullptr, *idxK = nullptr, *cntK = nullptr;   // RunPtrs
   MatchPair *M = nullptr;                    // match tables

@@ -113,6 +113,14 @@ __device__ unsigned long long g_sort_dbg[8];
 #else
 #define SP_STAMP(k) do {} while (0)
 #endif
+// Barrier for LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0): stores and loads share the
+// counter on gfx9), and k_prev_links has scattered stores in flight in front of nearly every barrier -- tables, planes, sorted orders -- that nobody in
+// the workgroup reads back: this one waits for the LDS operations (lgkmcnt) only and leaves the stores draining behind the next phase.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 template <int NDIG, int SHIFT, bool LINEAR, int NPR>
 __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *dst,
                                           uint32_t *cnt /*[16][NDIG]*/, uint32_t *wsum /*[16]*/, uint32_t i0, int rem) {
@@ -128,7 +136,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
   unsigned long long tsp = clock64();
 #endif
   for (int i = tid; i < NDIG * 16; i += 1024) cnt[i] = 0;
-  __syncthreads();
+  lds_barrier();
   SP_STAMP(0);
   uint32_t *mycnt = cnt + w * NDIG;
   // phase A: per (wave, digit) histogram; the value an element gets back is its rank among the wave's elements with
@@ -145,7 +153,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
     if (it * 64 < rem) r = atomicAdd(&mycnt[d], 1u);
     rk[it >> 1] |= r << (16 * (it & 1));
   }
-  __syncthreads();
+  lds_barrier();
   SP_STAMP(1);
   // phase B: exclusive scan over (digit major, wave minor)
   {
@@ -155,13 +163,13 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
     uint32_t incl = s;
     for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
     if (lane == 63) wsum[w] = incl;
-    __syncthreads();
+    lds_barrier();
     uint32_t base = 0;
     for (int k = 0; k < w; k++) base += wsum[k];
     uint32_t run = base + incl - s;
     for (int k = 0; k < PER; k++) { const int idx = tid * PER + k; cnt[(idx & 15) * NDIG + (idx >> 4)] = run; run += v[k]; }
   }
-  __syncthreads();
+  lds_barrier();
   SP_STAMP(2);
   // phase C: stable scatter
 #pragma unroll
@@ -171,7 +179,7 @@ __device__ __forceinline__ void sort_pass(const uint32_t (&pr)[NPR], uint32_t *d
       dst[mycnt[d] + ((rk[it >> 1] >> (16 * (it & 1))) & 0xFFFFu)] = wd;
     }
   }
-  __syncthreads();
+  lds_barrier();
   SP_STAMP(3);
 }
 
@@ -203,26 +211,28 @@ constexpr uint32_t DISTL_GAVEUP = 0x7FFF, WALK_CAP = ZADA_WALK_CAP;
 static_assert(MAX_DIST < 0x7FFF, "the give-up marker is no distance");
 constexpr uint32_t HEAVY_STRIDE = 2048, HEAVY_CAP = HEAVY_STRIDE - 1;       // per segment: the list of its heavy 15-bit buckets
 static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
-// LDS of k_prev_links: the sort's two halves (128 KiB), its counters (16 KiB + 64 B); with runs of segments per workgroup 8 KiB more for the bit map of
-// occupied buckets; the previous segment's bytes are staged over counters and bit map (131 072 ..) when both are dead.
-constexpr int PL_LDS = 144 * 1024 + 64, PL_OCC_OFF = PL_LDS, PL_LDS_RUNS = 160 * 1024, PL_PREV_OFF = 131072;
-static_assert(PL_OCC_OFF + 8192 <= PL_LDS_RUNS && PL_PREV_OFF + 32768 <= PL_LDS_RUNS, "k_prev_links: LDS map of the fused cross links");
+// LDS of k_prev_links: the sort's two halves (128 KiB), its counters (16 KiB + 64 B); with runs of segments per workgroup the previous segment's bytes
+// are staged from 131 072 on (32 KiB: over the counters, which are dead during the walks of the one level that needs them).
+constexpr int PL_LDS = 144 * 1024 + 64, PL_LDS_RUNS = 160 * 1024, PL_PREV_OFF = 131072;
+constexpr int PL_XOFF = 32784, PL_XENT = (65536 - PL_XOFF) / 2;          // behind the segment's staged bytes: room for 16 376 table entries
+static_assert(PL_PREV_OFF + 32768 <= PL_LDS_RUNS, "k_prev_links: LDS map of the fused cross links");
+template <bool RUNS>
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, Layout L, int kfull, int kquarter,
                                                      LevelPtrs lv,
                                                      uint16_t *__restrict__ S3, uint8_t *__restrict__ T3, uint32_t *__restrict__ bsc3,
                                                      DistPlanes dp, RunPtrs rp, unsigned long long *__restrict__ dbg, uint32_t *__restrict__ segmax,
-                                                     uint16_t *__restrict__ heavy, uint32_t seg0, uint32_t run_len, uint32_t seg_end,
-                                                     uint32_t *__restrict__ occ, uint64_t occ_level_stride) {
+                                                     uint16_t *__restrict__ heavy, uint32_t seg0, uint32_t run_len, uint32_t seg_end) {
   // run_len consecutive segments per workgroup, one after the other (seg0 + blockIdx.x * run_len ...; up to seg_end).  From the second segment of
   // a run on the workgroup makes the CROSS LINKS itself ("fused"): the first member of each of a level's buckets is linked to the last member
   // of that bucket in the segment before -- whose tails table this very workgroup wrote a moment ago -- while the sorted order is still in LDS
   // (neighbouring lanes hold neighbouring keys: the table is read in ascending order, sector by sector, instead of being staged as 128 KB per
   // segment and level by k_cross_links), and the searches for the nearest four-byte match that end at such a link are settled against the
-  // previous segment's bytes (staged behind the segment's own once the walks are over).  k_cross_links is left with the first segment of every run.
-  // Which buckets of a table are occupied (the tables are not initialised) is kept as a bit map per segment and level (occ: 2 048 words each).
+  // previous segment's bytes (staged next to the segment's own, where the sort's counters were).  k_cross_links is left with the first segment of every run.
+  // With runs (RUNS) a workgroup initialises the tails tables of its segments ("no member": 0xFFFF), so that the next segment can take an entry as it
+  // stands; without them the kernel is what it was (tables not initialised, their readers check an entry by hashing the position it names).
 #ifdef ZADA_PL_STATS
   unsigned long long tprev = clock64(); int tph = 8;
-#define PL_STAMP() do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
+#define PL_STAMP() do { lds_barrier(); if (threadIdx.x == 0) { unsigned long long t = clock64(); atomicAdd(&dbg[tph], t - tprev); tprev = t; } tph++; } while (0)
 #else
 #define PL_STAMP() do {} while (0)
 #endif
@@ -233,16 +243,16 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   uint32_t *cnt = (uint32_t *)(B + 32768);        // 16 KiB
   uint32_t *wsum = cnt + 4096;                    // 64 B
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const bool runs = run_len > 1;
-  uint32_t *occL = (uint32_t *)(smem + PL_OCC_OFF);                              // runs: the bit map of the level's occupied buckets, this segment
+  const uint8_t *pbL = smem + PL_PREV_OFF;                                       // fused: the previous segment's bytes (over the sort's counters, when they are dead)
 #pragma unroll 1
-  for (uint32_t jrun = 0; jrun < run_len; jrun++) {
+  for (uint32_t jrun = 0; jrun < (RUNS ? run_len : 1u); jrun++) {
   const uint64_t seg = (uint64_t)blockIdx.x * run_len + jrun + seg0, base = seg * 32768ull;      // (seg0: the launch covers the segments of one piece of the input)
   if (seg >= seg_end) break;
   const uint32_t m = lay_inserted(L, seg);
   const bool first_seg = lay_first(L, seg);
-  const bool fused = jrun > 0 && !first_seg;                                    // cross links from this workgroup (it has just finished segment seg - 1)
+  const bool fused = RUNS && jrun > 0 && !first_seg;                            // cross links from this workgroup (it has just finished segment seg - 1)
   const bool prev_first = fused && lay_first(L, seg - 1);
+
 #ifdef ZADA_PL_STATS
   tph = 8;
 #endif
@@ -261,7 +271,6 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
   // (The tails tables -- last position of each of the 65 536 buckets of a level -- are NOT initialised: only occupied buckets are
   // written below, and k_cross_links tells a stale entry from a tail by hashing the position it names.  "No chain-length limit",
   // the default of dlim, is a memset on the second stream: lz_shard.)
-  for (int i = tid; i < 32768 / 4; i += 1024) ((uint4 *)bsc)[i] = make_uint4(0, 0, 0, 0);
   const uint8_t *sin = in + base;
   PL_STAMP();   // 8: table init
   uint32_t *F = cnt;                               // level 3: bucket-start bitmask of the sorted order, 1024 words (+1 spill word)
@@ -284,7 +293,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     uint32_t i0 = (uint32_t)w * 2048 + lane;
     asm volatile("" : "+v"(i0));
     const int rem = (int)m - (int)i0;
-    if (runs && lvl > 0) { occL[tid] = 0; occL[tid + 1024] = 0; }   // (the barriers of the sort lie between this and its use)
+
     // ---- sort: AB[i] := element | key << 16 in (key, position) order (A and B as one array of 32-bit words) ----
     {
       {
@@ -311,8 +320,18 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
             }
           }
         };
-        if (lvl == 0) build((const uint32_t *)(sin + (i0 & ~3u)));
-        else build((const uint32_t *)(sb + (i0 & ~3u)));
+        if (lvl == 0) {
+          build((const uint32_t *)(sin + (i0 & ~3u)));
+          // The segment's tables are initialised HERE, behind the key loads and in front of the sorts: loads wait for the stores issued before them
+          // (one counter), and the two sort passes that follow need no global memory -- the stores drain behind them.
+          for (int i = tid; i < 32768 / 4; i += 1024) ((uint4 *)bsc)[i] = make_uint4(0, 0, 0, 0);
+          if (RUNS) {
+            for (int l = 0; l < NLEVELS; l++) {
+              uint16_t *tl = lv.tails[l] + seg * 65536ull;                       // 65536 buckets per level: "no member"
+              for (int i = tid; i < 65536 / 8; i += 1024) ((uint4 *)tl)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            }
+          }
+        } else build((const uint32_t *)(sb + (i0 & ~3u)));
         sort_pass<256, 0, true>(key, AB, cnt, wsum, i0, rem);
       }
       uint32_t pr[32];
@@ -324,6 +343,9 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       if (lvl == 0) sort_pass<128, 8, false>(pr, AB, cnt, wsum, i0, rem);
       else sort_pass<256, 8, false>(pr, AB, cnt, wsum, i0, rem);
     }
+    // (the one place where stores of different lanes to the same address follow each other -- a bucket's record over the table's zero --
+    // gets a full barrier; the zeros have had two sort passes to arrive)
+    if (lvl == 0) __syncthreads();
     PL_STAMP();
     // ---- links: element | last-of-bucket << 15 | distance to the bucket's previous element << 16, in registers ----
     uint16_t *tail = lvl > 0 ? lv.tails[lvl - 1] + seg * 65536ull : nullptr;
@@ -332,7 +354,6 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     {
       const uint32_t *pp = AB + i0;
       uint32_t *pf = F + (i0 >> 5);
-      uint32_t firstmask = 0;                                          // bit `it`: the element starts a bucket
 #pragma unroll
       for (int it = 0; it < 32; it++) {
         uint32_t x = 0;
@@ -346,61 +367,29 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           uint32_t d = 0;
           if (!first) { const uint32_t e0 = pm & 0xFFFFu; if (!(first_seg && e0 == 0)) d = e - e0; }     // NIL = position 0, lz77.adb:467
           x = e | ((uint32_t)last << 15) | (d << 16);
+          if (lvl > 0 && last) tail[k] = (uint16_t)e;
         }
         ed[it] = x;
-        firstmask |= (uint32_t)first << it;
         if (want_runs) {
           const unsigned long long mk = __ballot(first);
           if (lane == 0) { pf[it * 2] = (uint32_t)mk; pf[it * 2 + 1] = (uint32_t)(mk >> 32); }
         }
       }
-      if (lvl > 0) {
-        // tails of the level's buckets; with runs: the bit map of occupied buckets and, fused, the cross links of the buckets' first members.
-        // Eight elements at a time, the table look-ups of all eight in front of everything that depends on them and of the stores.
-        const uint16_t *tprev = tail - 65536;                                       // the table of the segment before (fused)
-        const uint32_t *oprev = occ + (uint64_t)(lvl - 1) * occ_level_stride + (seg - 1) * 2048ull;
-#pragma unroll
-        for (int g8 = 0; g8 < 4; g8++) {
-          uint32_t kk[8], tt[8], oo[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) { const int it = g8 * 8 + q; kk[q] = (it * 64 < rem) ? pp[it * 64] >> 16 : 0u; }
-          if (fused) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) { tt[q] = tprev[kk[q]]; oo[q] = oprev[kk[q] >> 5]; }
-          }
-#pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const int it = g8 * 8 + q;
-            if (it * 64 < rem) {
-              const uint32_t e = ed[it] & 0x7FFFu;
-              if ((firstmask >> it) & 1u) {
-                if (runs) atomicOr(&occL[kk[q] >> 5], 1u << (kk[q] & 31u));
-                if (fused) {
-                  // the bucket's tail in the previous segment, if the bucket has members there, within MAX_DIST, and not position 0 of an entry (:467)
-                  const uint32_t t = tt[q], d = e + 32768u - t;
-                  if (((oo[q] >> (kk[q] & 31u)) & 1u) && d <= (uint32_t)MAX_DIST && !(prev_first && t == 0)) ed[it] |= d << 16;
-                }
-              }
-              if ((ed[it] >> 15) & 1u) tail[kk[q]] = (uint16_t)e;
-            }
-          }
-        }
-      }
     }
     if (want_runs) {
       if (tid == 0) { cnt[2048] = 0; cnt[2049] = 0; } // (free between the sorts: the largest bucket of the segment, the number of heavy ones; level 3)
-      __syncthreads();
+      lds_barrier();
       {
         // LW[wd] = last word index <= wd whose F word is non-zero (word 0 always is: element 0 starts a bucket)
         uint32_t v = F[tid] != 0 ? (uint32_t)tid : 0u;
         for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if (lane >= off) v = v > t ? v : t; }
         if (lane == 63) wsum[w] = v;
-        __syncthreads();
+        lds_barrier();
         uint32_t before = 0;
         for (int k = 0; k < w; k++) before = before > wsum[k] ? before : wsum[k];
         LW[tid] = (uint16_t)(v > before ? v : before);
       }
-      __syncthreads();
+      lds_barrier();
       // start of i's bucket = highest set bit of F at or below i
       auto bucket_start = [&](uint32_t i) -> uint32_t {
         const uint32_t wd = i >> 5;
@@ -429,7 +418,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         // last level: the bucket of a position is a contiguous run of the sorted order, which the demand pass
         // of the match kernel scans instead of chasing links.  Written out: the sorted order S, and per
         // position its index in S and the number of bucket members before it (planes, staged as one word per position in AB).
-        __syncthreads();                             // keys (A) and sorted positions (B) are dead from here
+        lds_barrier();                             // keys (A) and sorted positions (B) are dead from here
         uint16_t *sK = rp.S + seg * 32768ull;
 #pragma unroll
         for (int it = 0; it < 32; it++) {
@@ -439,7 +428,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
             AB[e] = i | ((i - bucket_start(i)) << 16);       // (one scatter for both planes)
           }
         }
-        __syncthreads();
+        lds_barrier();
         for (uint32_t i = tid; i < (m + 7) / 8; i += 1024) {
           const uint4 p = ((const uint4 *)AB)[2 * i], q = ((const uint4 *)AB)[2 * i + 1];
           uint4 lo, hi;
@@ -450,11 +439,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         }
       }
     }
-    __syncthreads();                                 // keys (A) and sorted positions (B) are dead from here
-    if (runs && lvl > 0) {                           // this segment's bit map of occupied buckets, for the next segment of the run
-      uint32_t *ocur = occ + (uint64_t)(lvl - 1) * occ_level_stride + seg * 2048ull;
-      ocur[tid] = occL[tid]; ocur[tid + 1024] = occL[tid + 1024];
-    }
+    lds_barrier();                                 // keys (A) and sorted positions (B) are dead from here
     if (lvl == 0 && tid == 0) { segmax[seg] = cnt[2048]; hvy[0] = cnt[2049] <= HEAVY_CAP ? (uint16_t)cnt[2049] : (uint16_t)0xFFFF; }
     for (uint32_t i = tid; i < (m + 16 + 15) / 16; i += 1024) ((uint4 *)A)[i] = ((const uint4 *)sin)[i];   // A := bytes
 #pragma unroll
@@ -465,7 +450,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         if (lvl == 0) s3[i0 + it * 64] = (uint16_t)e;
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (lvl == 0) {
 #pragma unroll
       for (int it = 0; it < 32; it++) {              // T3: tags for the cross-segment continuation (k_cross_dist)
@@ -475,6 +460,53 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         }
       }
     } else {
+      if (RUNS && fused) {
+        // Cross links, fused: the first member of each of the level's buckets (no link so far) is linked to the bucket's last member in the segment
+        // before -- what k_cross_links does, but with the links and the bytes where they are, in LDS, and the previous segment's tails table (which
+        // this workgroup wrote itself, initialised) staged half at a time, coalesced.  (Looked up
+        // straight from memory -- two-byte gathers, 64 addresses an instruction -- the same entries cost 47 000 cycles per level: 90 cycles an
+        // instruction in the memory pipeline.)  The keys are hashed again from the bytes, in every round (registers are what this kernel has none of).
+        // Two rounds of half a table: 16 384 entries where the counters were, 16 376 behind the segment's bytes (the queues' place, not in use yet);
+        // the eight entries per half that have no room are read from memory by whoever needs one (one bucket head in 4 000).
+        uint16_t *tqY = (uint16_t *)(smem + PL_PREV_OFF), *tqX = (uint16_t *)(smem + PL_XOFF);
+        const uint16_t *tprev = lv.tails[lvl - 1] + (seg - 1) * 65536ull;
+#pragma unroll 1
+        for (uint32_t r = 0; r < 2; r++) {
+          lds_barrier();                             // (the half before this one has been read)
+          {
+            const uint4 *src = (const uint4 *)(tprev + r * 32768u);
+            const uint4 y0 = src[tid], y1 = src[tid + 1024], x0 = src[tid + 2048], x1 = src[tid + 3072];
+            ((uint4 *)tqY)[tid] = y0; ((uint4 *)tqY)[tid + 1024] = y1;
+            ((uint4 *)tqX)[tid] = x0;
+            if (tid + 1024 < PL_XENT / 8) ((uint4 *)tqX)[tid + 1024] = x1;
+          }
+          lds_barrier();
+#pragma unroll 1
+          for (uint32_t e0 = tid; e0 < m; e0 += 8192) {               // eight positions per lane at a time, nothing conditional: their LDS reads overlap
+            uint32_t pe[8], kk[8], tt[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const uint32_t e = e0 + 1024u * q; pe[q] = P[e < m ? e : 0u]; if (e >= m) pe[q] = 1u; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const uint32_t e = e0 + 1024u * q; kk[q] = hashL_of(lb8(e < m ? e : 0u), L); }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const uint32_t kr = kk[q] & 32767u;
+              tt[q] = kr < 16384u ? (uint32_t)tqY[kr] : (uint32_t)tqX[kr - 16384u < PL_XENT ? kr - 16384u : 0u];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              if (pe[q] != 0 || (kk[q] >> 15) != r) continue;
+              const uint32_t e = e0 + 1024u * q;
+              uint32_t t = tt[q];
+              if ((kk[q] & 32767u) >= 16384u + PL_XENT) t = tprev[kk[q]];
+              // the bucket's last member in the previous segment, if it has one there, within MAX_DIST, and not position 0 of an entry (:467)
+              const uint32_t dx = e + 32768u - t;
+              if (t != 0xFFFFu && dx <= (uint32_t)MAX_DIST && !(prev_first && t == 0)) P[e] = (uint16_t)dx;
+            }
+          }
+        }
+        lds_barrier();
+      }
       uint16_t *prevl = lv.prev[lvl - 1];
       for (uint32_t i = tid; i < (m + 7) / 8; i += 1024) ((uint4 *)(prevl + base))[i] = ((const uint4 *)P)[i];
     }
@@ -492,19 +524,36 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
       // Levels >= 4 say where to continue: the chain ended at q, the first member of the bucket in this segment, whose link
       // k_cross_links will point into the previous segment (0x8000 | e - q; distances proper stay below 0x8000).
       // Fused (levels >= 4): q's link already points into the previous segment -- or is none, when its bucket has no member in reach there, and then
-      // nothing has (older members lie farther back still); the searches that end at a link are settled below, once the walks are over.
+      // nothing has (older members lie farther back still).  The link leads to the most recent position there with the same hash, which usually IS the
+      // nearest match: its bytes are compared here (the previous segment's are staged in LDS); a hash collision leaves the search to k_cross_dist.
       auto dflt_of = [&](uint32_t e, uint32_t q) -> uint32_t {
         if (first_seg) return 0u;
         if (lvl == 0) return e < (uint32_t)TOO_FAR ? (q == e ? DIST3_CONT_FIRST : DIST3_CONTINUE) : (q == e ? DIST3_HEADCHK : 0u);
-        if (fused && P[q] == 0) return 0u;
+        if (RUNS && fused) {
+          const uint32_t step = P[q];
+          if (step == 0) return 0u;
+          const uint32_t t = q + 32768u - step, d = e + 32768u - t;
+          if (d > (uint32_t)MAX_DIST) return 0u;
+          if (t <= 32768u - 4u) {
+            const uint32_t *wp = (const uint32_t *)(pbL + (t & ~3u));
+            const uint32_t theirs = __builtin_amdgcn_alignbyte(wp[1], wp[0], t & 3u);   // (t <= 32764: both words inside the staged bytes)
+            if (theirs == (uint32_t)lb8(e)) return d;
+          }
+        }
         return DISTL_CONTINUE | (e - q);
       };
+      static_assert(NLEVELS <= 2, "the candidate compare of the fused cross links takes four bytes");
       constexpr uint32_t QCAP = 4000;
       uint32_t *Qa = (uint32_t *)(smem + 32800), *Qb = Qa + QCAP;   // behind the 32 784 staged bytes
-      uint32_t *qn = wsum;
+      uint32_t *qn = RUNS ? (uint32_t *)(smem + 32800 + 8 * QCAP) : wsum;     // (RUNS: the counters' place may hold the previous segment's bytes)
+      static_assert(32800 + 8 * QCAP + 8 <= 65536, "queues and their counters behind the staged bytes");
       const unsigned long long ltm = (1ull << lane) - 1ull;
       if (tid < 2) qn[tid] = 0;
-      __syncthreads();
+      if (RUNS && fused && lvl > 0) {
+        const uint4 *bs = (const uint4 *)(in + base - 32768ull);
+        for (int i = tid; i < 32768 / 16; i += 1024) ((uint4 *)(smem + PL_PREV_OFF))[i] = bs[i];
+      }
+      lds_barrier();
       // up to `maxs` further candidates of position e, starting behind q; true = settled (dl valid)
       auto walk = [&](uint32_t e, uint32_t &q, uint64_t mine, uint32_t maxs, uint32_t &dl) -> bool {
         uint32_t step = P[q];
@@ -567,7 +616,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           if (ex[j] && !pend) plane[e] = (uint16_t)dl;
         }
       }
-      __syncthreads();
+      lds_barrier();
       PL_STAMP();
       for (int cur = 0;; cur ^= 1) {
         const uint32_t nq = qn[cur] < QCAP ? qn[cur] : QCAP;
@@ -576,9 +625,9 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         if (tid == 0 && lvl == 1) { atomicAdd(&dbg[24], 1ull); atomicAdd(&dbg[25], (unsigned long long)nq); if (nq <= 1024) atomicAdd(&dbg[26], (unsigned long long)nq); if (cur == 0 && qn[0] > QCAP) atomicAdd(&dbg[30], (unsigned long long)(qn[0] - QCAP)); }
         unsigned long long tq0 = clock64();
 #endif
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) qn[cur ^ 1] = 0;
-        __syncthreads();
+        lds_barrier();
         if (nq > 1024) {
           // Up to four entries per lane, eight candidates each, in step with each other: the LDS reads of the four walks
           // overlap (a walk is one dependent LDS round trip per candidate).
@@ -643,41 +692,14 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           push(pend, e | (q << 16), cur ? Qa : Qb, &qn[cur ^ 1]);
         }
 #ifdef ZADA_PL_STATS
-        __syncthreads();
+        lds_barrier();
         if (tid == 0 && lvl == 1) atomicAdd(&dbg[31], clock64() - tq0);
 #endif
         }
-        __syncthreads();
-      }
-      if (fused && lvl > 0) {
-        // The searches that ended at a link into the previous segment: that link leads to the most recent position there with the same hash, which
-        // usually IS the nearest match; a hash collision leaves the search to k_cross_dist (marker unchanged), as k_cross_links does.  The previous
-        // segment's bytes are staged over the sort's counters and the bit map (both dead); the plane is read back as it was written above.
-        static_assert(NLEVELS <= 2, "the candidate compare of the fused cross links takes four bytes");
-        uint8_t *pbL = smem + PL_PREV_OFF;
-        {
-          const uint4 *bs = (const uint4 *)(in + base - 32768ull);
-          for (int i = tid; i < 32768 / 16; i += 1024) ((uint4 *)pbL)[i] = bs[i];
-        }
-        __syncthreads();
-        for (uint32_t e0 = tid; e0 < m; e0 += 8192) {
-          uint32_t pl[8];
-#pragma unroll
-          for (int k = 0; k < 8; k++) { const uint32_t e = e0 + 1024u * k; pl[k] = e < m ? (uint32_t)plane[e] : 0u; }
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            if (!(pl[k] & DISTL_CONTINUE)) continue;
-            const uint32_t e = e0 + 1024u * k, q = e - (pl[k] & 0x7FFFu), t = q + 32768u - P[q], d = e + 32768u - t;
-            if (d > (uint32_t)MAX_DIST) plane[e] = 0;
-            else if (t <= 32768u - 4u) {
-              const uint32_t *wp = (const uint32_t *)(pbL + (t & ~3u));
-              const uint32_t theirs = __builtin_amdgcn_alignbyte(wp[1], wp[0], t & 3u);   // (t <= 32764: both words inside the staged bytes)
-              if (theirs == (uint32_t)lb8(e)) plane[e] = (uint16_t)d;
-            }
-          }
-        }
+        lds_barrier();
       }
     }
+    // (a full barrier, global memory included: the next segment of the run reads the tails tables this one has written)
     __syncthreads();
     PL_STAMP();
   }
@@ -1618,12 +1640,34 @@ struct TokSink {
   __device__ void flush() { for (uint32_t i = n & ~7u; i < n; i++) dst[i] = buf[(i & 7u) * 64]; }
 };
 
+// The chunks a demand pass has flagged (chg), as a list: the speculative parse of a later round is launched over the list, every lane with a
+// chunk to parse -- flagged chunks are a few per cent, spread evenly, so that a launch over all chunks had nearly every wave run one or two lanes
+// for the whole length of a parse (four such rounds cost as much as the first parse of everything).  One counter reservation per workgroup.
+__global__ void __launch_bounds__(1024) k_list_flagged(const uint8_t *__restrict__ flag, uint32_t n, uint32_t *__restrict__ list, uint32_t *__restrict__ count) {
+  __shared__ uint32_t wcnt[16], wbase;
+  const uint32_t i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool f = i < n && flag[i];
+  const unsigned long long mk = __ballot(f);
+  if (lane == 0) wcnt[w] = (uint32_t)__popcll(mk);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int k = 0; k < 16; k++) { const uint32_t c = wcnt[k]; wcnt[k] = t; t += c; }
+    wbase = t ? atomicAdd(count, t) : 0u;
+  }
+  __syncthreads();
+  if (f) list[wbase + wcnt[w] + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = i;
+}
+
 __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict__ spec_tok, uint32_t *__restrict__ spec_cnt,
                              uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits,
-                             DemandMarker dm, const uint8_t *__restrict__ redo /* null: every chunk */) {
+                             DemandMarker dm, const uint32_t *__restrict__ list /* null: every chunk */, const uint32_t *__restrict__ list_n) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (list) {                                         // the flagged chunks only (the grid is sized for all of them; what lies beyond the list ends here)
+    if (k >= *list_n) return;
+    k = list[k];
+  }
   if (k >= nchunks) return;
-  if (redo && !redo[k]) return;
   if (io.segend) io.n = io.segend[((uint64_t)k * PCHUNK) >> 15] & 0x7FFFFFFFu;     // a batch: the input ends where the chunk's entry ends
   uint32_t ntok = 0;
   ExitState ex;
@@ -1864,7 +1908,8 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   const uint32_t nseg = (uint32_t)((n_ins + 32767) / 32768);
   c->tmark("lz:begin");
   if (!c->lz_attrs_set) {                            // per context: the attribute belongs to the function object of the current device
-    hipFuncSetAttribute((const void *)k_prev_links, hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS_RUNS);
+    hipFuncSetAttribute((const void *)k_prev_links<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS_RUNS);
+    hipFuncSetAttribute((const void *)k_prev_links<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS);
     hipFuncSetAttribute((const void *)k_cross_links, hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS_PLANE);
     hipFuncSetAttribute((const void *)k_match, hipFuncAttributeMaxDynamicSharedMemorySize, MATCH_LDS);
     hipFuncSetAttribute((const void *)k_match_demand, hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS);
@@ -1893,8 +1938,10 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     else if (job.need) R = 8;
     else while (R < 16 && nseg / (2 * R) >= 1024) R *= 2;
     auto prev_links = [&](uint32_t s0, uint32_t s1) {                     // segments [s0, s1), s0 a multiple of R
-      hipLaunchKernelGGL(k_prev_links, dim3((s1 - s0 + R - 1) / R), dim3(1024), R > 1 ? PL_LDS_RUNS : PL_LDS, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
-                         W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0, R, s1, W.occ, (uint64_t)W.occ_level_stride);
+      if (R > 1) hipLaunchKernelGGL(k_prev_links<true>, dim3((s1 - s0 + R - 1) / R), dim3(1024), PL_LDS_RUNS, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
+                                    W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0, R, s1);
+      else hipLaunchKernelGGL(k_prev_links<false>, dim3(s1 - s0), dim3(1024), PL_LDS, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
+                              W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0, 1u, s1);
     };
     auto cross_links = [&](uint32_t from, uint32_t to) {                  // the segments of [from, to) that k_prev_links did not link itself
       const uint32_t first = (from + R - 1) / R * R;
@@ -1986,8 +2033,16 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   const uint32_t kE = job.entry_known ? (entry0.pos / PCHUNK < nch ? entry0.pos / PCHUNK : nch) : 0u;
   for (bool first = true;; first = false) {
     // speculative parse: every chunk the first time, afterwards the chunks flagged by the demand pass
-    hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
-                       W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, first ? (const uint8_t *)nullptr : (const uint8_t *)W.chg);
+    if (first) hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
+                                  W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    else {
+      // (the list's length stays on the device: the grid covers the most there can be -- the host knows how many chunks the last demand pass flagged
+      // at most only after a round trip it does not need -- and the waves beyond the list end at once)
+      hipMemsetAsync(W.n_changed + 2, 0, 4, st);
+      hipLaunchKernelGGL(k_list_flagged, dim3((nch + 1023) / 1024), dim3(1024), 0, st, W.chg, nch, W.offsets, W.n_changed + 2);
+      hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
+                         W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)W.offsets, (const uint32_t *)(W.n_changed + 2));
+    }
     // fixpoint of the splice, from scratch: round 0 handles every chunk with the speculative exits as entries
     hipMemcpyAsync(W.true_exits, W.spec_exits, (size_t)nch * sizeof(ExitState), hipMemcpyDeviceToDevice, st);
     if (kE > 0) hipLaunchKernelGGL(k_seed_entry, dim3((kE + 255) / 256), dim3(256), 0, st, W.true_exits, kE, entry0);

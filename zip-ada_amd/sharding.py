@@ -85,7 +85,7 @@ def gather_payloads(payload, length, meta, dst=0, group=None):
 # compresses range r with the zada_range_* calls of libzada_hip.so and the ranks exchange exactly the state the
 # reference's sequential encoder carries through the stream (include/zada.h "One stream over several contexts"):
 #
-#   a. parser state at the range boundaries   all_gather of (atoms, exit, warm) -- 40 bytes per rank.  A range whose
+#   a. parser state at the range boundaries   ONE all_gather of a fixed-size int64 tensor (atoms, exit, warm, CRC, bytes) -- 64 bytes per rank.  A range whose
 #                                             warm-up parse did not meet its neighbour's exit state re-runs its LZ stage
 #                                             from that state (degenerate data only, e.g. one long run)
 #   b. atom counts -> position of every range on the stream's 65 536-atom flush grid (zip-compress-deflate.adb:1424-1432)
@@ -150,15 +150,29 @@ class TorchComm:
         """Rank k of the group as torch.distributed addresses it (src / dst are GLOBAL ranks also when a group is given)."""
         return k if self.group is None else dist.get_global_rank(self.group, k)
 
-    def all_gather_obj(self, obj):
-        out = [None] * self.world
-        dist.all_gather_object(out, obj, group=self.group)
-        return out
+    def all_gather_i64(self, values):
+        """Every rank's vector of `len(values)` integers (the same length on every rank), as a list of lists: ONE all_gather of a fixed-size
+        int64 tensor (64 bytes per rank for the parser states, 24 for the bit positions) -- no pickling, no object collectives, one
+        device-to-host copy of world x len(values) numbers on the nccl backend."""
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self.device)
+        out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.cpu().view(self.world, t.numel()).tolist()
 
-    def bcast_obj(self, obj, src):
-        box = [obj]
-        dist.broadcast_object_list(box, src=self._g(src), group=self.group)
-        return box[0]
+    def all_gather_i64_var(self, arr):
+        """Every rank's 1-D array of unsigned 64-bit numbers, lengths differing (the BZip2 block tables): the lengths by all_gather_i64, then ONE
+        all_gather of the arrays padded to the longest.  Returns a list of numpy uint64 arrays."""
+        import numpy as np
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+        lens = [v[0] for v in self.all_gather_i64([a.size])]
+        width = max(max(lens), 1)
+        pad = np.zeros(width, dtype=np.int64)
+        pad[:a.size] = a.view(np.int64)
+        t = torch.from_numpy(pad).to(self.device)
+        out = torch.empty(self.world * width, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        h = out.cpu().numpy().reshape(self.world, width)
+        return [h[k, :lens[k]].view(np.uint64).copy() for k in range(self.world)]
 
     def all_gather_dev(self, t):
         if t.is_cuda and dist.get_backend(self.group) == "gloo":     # CPU-only transport (tests, BENCH_EMULATE): stage through the host
@@ -176,13 +190,48 @@ class TorchComm:
         dist.send(t, dst=self._g(dst), group=self.group)
 
     def recv_bytes(self, n, src):
+        return self.recv_bytes_begin(n, src)()
+
+    def recv_bytes_begin(self, n, src):
+        """Posts the receive now and returns a function that waits for it and returns the bytes: the 352-byte chooser state is asked for BEFORE
+        the range's analysis, so that the hop from the rank before costs its own latency only if that rank is late.  (Posted after the last
+        collective in front of it: operations of one communicator run in the order they were issued on every rank.)"""
         t = torch.empty(n, dtype=torch.uint8, device=self.device)
-        dist.recv(t, src=self._g(src), group=self.group)
-        return bytes(t.cpu().numpy())
+        work = dist.irecv(t, src=self._g(src), group=self.group)
+
+        def wait():
+            work.wait()
+            return bytes(t.cpu().numpy())
+        return wait
 
     def gather_payload(self, payload, length, dst=0):
         res = gather_payloads(payload, length, torch.zeros(1, dtype=torch.int64), dst=dst, group=self.group)
         return None if res is None else res[0]
+
+
+def _gather_i64(comm, values):
+    """comm.all_gather_i64, or the same through a comm double that only gathers Python objects (threads inside one process)."""
+    if hasattr(comm, "all_gather_i64"):
+        return comm.all_gather_i64(values)
+    return [list(v) for v in comm.all_gather_obj([int(x) for x in values])]
+
+
+def _gather_i64_var(comm, arr):
+    import numpy as np
+    if hasattr(comm, "all_gather_i64_var"):
+        return comm.all_gather_i64_var(arr)
+    return [np.frombuffer(b, np.uint64) for b in comm.all_gather_obj(np.ascontiguousarray(arr, np.uint64).tobytes())]
+
+
+def _info_vec(info):
+    """A range's parser state as eight integers (the all_gather of step a): active, atoms, exit, warm-up state, raw CRC register, bytes."""
+    if info is None:
+        return [0] * 8
+    return [1, info["atoms"], info["exit"][0], info["exit"][1], info["warm"][0], info["warm"][1], info["crc_raw"], info["n"]]
+
+
+def _info_of(v):
+    return None if not v[0] else dict(atoms=v[1], exit=(v[2], v[3]), warm=(v[4], v[5]), crc_raw=v[6], n=v[7])
 
 
 def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, method, alloc_u32, alloc_out):
@@ -211,14 +260,15 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
         info["n"] = n
     # ---- a. parser states at the boundaries
     t_x = time.perf_counter()
-    infos = comm.all_gather_obj(info)
+    infos = [_info_of(v) for v in _gather_i64(comm, _info_vec(info))]
     for k in range(1, nr):
         if tuple(infos[k]["warm"]) != tuple(infos[k - 1]["exit"]):
-            # the warm-up parse of range k did not meet the true one: run it again from the true state (rare)
+            # the warm-up parse of range k did not meet the true one: run it again from the true state, and everybody hears the new one (rare:
+            # data like one long run; every rank sees the same states, so every rank comes here)
             if r == k:
                 info = enc.range_lz(tuple(infos[k - 1]["exit"]))
                 info["n"] = ranges[k][1]
-            infos[k] = comm.bcast_obj(info if r == k else None, src=k)
+            infos = [_info_of(v) for v in _gather_i64(comm, _info_vec(info))]
     xs["all_gather_state"] += time.perf_counter() - t_x
     # ---- b. the ranges on the flush grid
     counts = [infos[k]["atoms"] for k in range(nr)]
@@ -255,6 +305,10 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
                     left -= take
                     k += 1
                 la_a, la_p = tensors.cat(parts_a).contiguous(), tensors.cat(parts_p).contiguous()
+    # ---- d. (first half) the receive of the chooser's state from the rank before is posted before this range is analysed
+    carry_wait = None
+    if active and r > 0:
+        carry_wait = comm.recv_bytes_begin(352, r - 1) if hasattr(comm, "recv_bytes_begin") else (lambda: comm.recv_bytes(352, r - 1))
     if active:
         if (n_lb or n_la) and hasattr(tensors, "cuda") and (lb_a if n_lb else la_a).is_cuda:
             tensors.cuda.current_stream().synchronize()      # the slices were put together on torch's stream, the encoder reads them on its own
@@ -265,7 +319,7 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
     bit_begin = bit_end = 0
     if active:
         t_x = time.perf_counter()
-        carry = comm.recv_bytes(352, r - 1) if r > 0 else None
+        carry = carry_wait() if carry_wait is not None else None
         xs["carry_chain"] += time.perf_counter() - t_x
         carry_out, bit_begin, bit_end = enc.range_choose(carry)
         if r + 1 < nr:
@@ -273,7 +327,7 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
             comm.send_bytes(carry_out, r + 1)
             xs["carry_chain"] += time.perf_counter() - t_x
     t_x = time.perf_counter()
-    spans = comm.all_gather_obj((bit_begin, bit_end) if active else None)
+    spans = [(v[1], v[2]) if v[0] else None for v in _gather_i64(comm, [1 if active else 0, bit_begin, bit_end])]
     xs["spans"] += time.perf_counter() - t_x
     total_bits = spans[nr - 1][1]
     inefficient = (total_bits + 7) // 8 >= stream_size            # Compression_inefficient, zip-compress.adb:479-486
@@ -355,11 +409,11 @@ def bzip2_stream_rank(enc, comm, stream_size, ranges, d_buf_ptr, method, alloc_o
         tab = enc.bz2_range_table()
         if hasattr(enc, "crc32_device") and n and d_buf_ptr % 16 == 0:      # the rank's piece of the Zip CRC-32 (its own range, not the halo)
             crc_raw = enc.crc32_device(d_buf_ptr, n)
-    tabs = comm.all_gather_obj(tab.tobytes() if active else None)
+    tabs = _gather_i64_var(comm, tab if active else np.zeros(0, np.uint64))
     bp, crc = 32, 0
     spans, mine = [], None
     for k in range(nr):
-        tk = np.frombuffer(tabs[k], np.uint64).reshape(-1, 4, 3)
+        tk = tabs[k].reshape(-1, 4, 3)
         ch, bp2, crc2 = enc.bz2_select(tk, bp, crc)
         b0 = 0 if k == 0 else bp
         b1 = bp2 + (80 if k == nr - 1 else 0)
