@@ -102,6 +102,15 @@ def test_one_stream_with_the_producer_in_segments(encoder):
         with pytest.raises(Z.UserAbort):
             encoder.lzma(d, 18, feedback=lambda pct: pct >= 30)
         assert encoder.lzma(d[:50000], 18) == oracle_lzma(d[:50000], 18)
+        # an entry small enough for the LDS walks (up to 16 384 bytes) with segments forced on it -- the segmented path returns
+        # before those walks are launched and drops the buckets of "small" entries, so the stream was coded without a single tree match; such an
+        # entry is no longer marked small when segments are asked for
+        for nsmall in (16384, 16383, 9000):
+            encoder.set_knob("lzma_segment", 13)
+            small = d[777:777 + nsmall]
+            assert sets_equal(oracle_bt4_sets(small, None), encoder.lzma_match_sets(small)), nsmall
+            assert encoder.lzma(small, 18) == oracle_lzma(small, 18), nsmall
+        encoder.set_knob("lzma_segment", 0)
         before = dict(encoder.last_timing()).get("#bt4_reruns", 0)
         encoder.set_knob("lzma_pool", 1)
         assert encoder.lzma(d, 18) == want
