@@ -11,6 +11,14 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
 shutil.copy(os.path.join(G, tag + "_bench.json"), os.path.join(P, "bench_1gib.json"))
+def norm(kernel_name):
+    """zada::k_name -- without return type, anonymous namespace, template arguments and parameter list (k_prev_links<true> is k_prev_links)."""
+    n = kernel_name.replace("(anonymous namespace)::", "").split("(")[0]
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
+
+
 def newest(pattern):
     """The files of the LAST run of a pass only: gpurun merges a call's output into gpurun_out/ next to what earlier calls left there, and two
     runs' counters must not be added up."""
@@ -26,7 +34,7 @@ for ctr, sub in (("FETCH_SIZE", "_fetch"), ("WRITE_SIZE", "_write")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != ctr:
                 continue
-            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+            name = norm(r["Kernel_Name"])
             a = acc.setdefault(name, {"sum": 0.0, "dispatches": 0})
             a["sum"] += float(r["Counter_Value"]); a["dispatches"] += 1
     out[ctr] = acc
@@ -50,7 +58,7 @@ json.dump(out, open(os.path.join(P, "pmc_fetch_write_by_kernel.json"), "w"), ind
 sq = {}
 for f in newest(os.path.join(G, tag + "_sq", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("zada::", "")
+        name = norm(r["Kernel_Name"]).replace("zada::", "")
         a = sq.setdefault(name, {})
         a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 bounds = {}
@@ -72,7 +80,7 @@ if bounds:
     json.dump(bounds, open(os.path.join(P, "sq_bounds_by_kernel.json"), "w"), indent=1)
 rows = list(csv.DictReader(open(os.path.join(P, "bench_1gib_kernel_stats.csv"))))
 for r in rows[:14]:
-    k = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
+    k = norm(r["Name"])
     f = out["FETCH_SIZE"].get(k); w = out["WRITE_SIZE"].get(k)
     print("%-32s calls %3s avg %9.3f ms %6s%%  fetch(x2) %7.2f GB  write %7.2f GB per launch" % (
         k[:32], r["Calls"], float(r["AverageNs"]) / 1e6, r["Percentage"][:5],

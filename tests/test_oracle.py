@@ -40,7 +40,9 @@ def test_lz77_tokens_equal_committed_zlib_tokens(fname, level):
 def test_lz77_tokens_equal_live_zlib(level):
     """Same pin, run live against the libz of this image on generated data (crosses the 32 KiB slide)."""
     P = zlibpin()
-    for d in (silesia_mix(200000), silesia_mix(70000, class_mask=4), silesia_mix(66000, class_mask=2, offset=65536 * 7), b"ab" * 50000, bytes(70000)):
+    # (the last three: the benchmark stream since round 5, silesia_mix_v2 -- every class, across segment boundaries)
+    for d in (silesia_mix(200000), silesia_mix(70000, class_mask=4), silesia_mix(66000, class_mask=2, offset=65536 * 7), b"ab" * 50000, bytes(70000),
+              silesia_mix(300000, version=2), silesia_mix(140000, class_mask=0x19, offset=65536 * 3 - 7000, version=2), silesia_mix(100000, class_mask=6, offset=65536 * 11, version=2)):
         z = np.zeros(len(d), dtype=np.uint32)
         assert P.zp_zlib_position_tokens(d, len(d), *TUNE[level], z.ctypes.data) == 0
         t = np.zeros(len(d) + 8, dtype=np.uint32)
