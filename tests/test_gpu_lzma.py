@@ -110,7 +110,7 @@ def test_one_stream_with_the_producer_in_segments(encoder):
             small = d[777:777 + nsmall]
             assert sets_equal(oracle_bt4_sets(small, None), encoder.lzma_match_sets(small)), nsmall
             assert encoder.lzma(small, 18) == oracle_lzma(small, 18), nsmall
-        encoder.set_knob("lzma_segment", 0)
+        encoder.set_knob("lzma_segment", 14)
         before = dict(encoder.last_timing()).get("#bt4_reruns", 0)
         encoder.set_knob("lzma_pool", 1)
         assert encoder.lzma(d, 18) == want

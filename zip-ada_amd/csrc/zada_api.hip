@@ -135,7 +135,7 @@ static void free_group(std::vector<void *> &group) {
 }
 
 // LZ stage: per byte of shard buffer 2 x 2 (links) + 8/32768 x 65536 x 2 (tails) + 2 + 1 + 4 (15-bit order) + 2 x 2 + 4 (planes) +
-// 8 (match records) + 2 + 2 + 2 (last-level order) + 2 x 9 (tokens) + ... = about 55 bytes; the buffer is one shard of a range
+// 8 (match records) + 2 + 2 + 2 (last-level order) + 9 (fix-up tokens; the speculative ones share the link stage's tables' block) + ... = about 46 bytes; the buffer is one shard of a range
 // (ZADA_SHARD_KIB, default 1 GiB) with its halo and tail.
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   Workspace &W = c->ws;
@@ -148,14 +148,32 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   const uint64_t nch = cap / PCHUNK + 2, nseg32 = cap / 32768 + 2;
   int rc = 0;
 #define A(ptr, cnt) if (!rc) rc = dalloc(c, W.allocs, &W.ptr, (cnt))
+#define A2(ptr, cnt) if (!rc) rc = dalloc(c, W.allocs, &ptr, (cnt))
   A(in, cap + IN_PAD + 64);
-  for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); A(ltails[l], nseg32 * 65536); }
-  A(S3, nseg32 * 32768); A(T3, nseg32 * 32768); A(bsc3, nseg32 * 32768); A(segmax, nseg32 + 16); A(heavy, nseg32 * 2048);
+  // What only the LINK stage reads -- the tails tables of the first hashed level (k_cross_links and the runs of k_prev_links; the last level's are read
+  // by the demand pass), the 15-bit hash's sorted order, tags and bucket records (k_cross_dist, k_bucket_limits) -- is dead when the first parse starts,
+  // and the speculative tokens are born there and dead again when the shard's tokens have been compacted: the two share ONE block (11 against 9 bytes
+  // per input byte).  The tables' readers take whatever the block holds (uninitialised tables are checked entry by entry, the others are written whole).
+  {
+    const uint64_t b_tails0 = nseg32 * 65536 * 2, b_s3 = nseg32 * 32768 * 2, b_t3 = nseg32 * 32768, b_bsc = nseg32 * 32768 * 4, b_spec = nch * (uint64_t)PTOK_STRIDE * 4;
+    const uint64_t links = b_tails0 + b_s3 + b_t3 + b_bsc + 1024, bytes = links > b_spec ? links : b_spec;
+    uint8_t *blk = nullptr;
+    A2(blk, bytes);
+    if (!rc) {
+      uint8_t *q = blk;
+      W.ltails[0] = (uint16_t *)q; q += b_tails0 + 256;
+      W.S3 = (uint16_t *)q; q += b_s3 + 256;
+      W.bsc3 = (uint32_t *)q; q += b_bsc + 256;
+      W.T3 = q;
+      W.spec_tok = (uint32_t *)blk;
+    }
+  }
+  for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); if (l > 0) A(ltails[l], nseg32 * 65536); }
+  A(segmax, nseg32 + 16); A(heavy, nseg32 * 2048);
   for (int l = 0; l < NLEVELS; l++) A(dplane[l], cap + 64);
-  A(dlim, cap + 64);
+  A(dlim, cap + 64); A(dlim_bits, cap / 32 + 64);
   A(M, cap + 64);
   A(SK, nseg32 * 32768); A(idxK, cap + 64); A(cntK, cap + 64);
-  A(spec_tok, nch * PTOK_STRIDE);
   A(fix_tok, nch * PTOK_STRIDE);
   A(spec_cnt, nch); A(fix_cnt, nch); A(take_from, nch); A(start_pos, nch); A(counts, nch); A(offsets, nch);
   A(scan_sums, nch / 1024 + 1024);
@@ -166,6 +184,7 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   A(blk_demand, cap / 4096 + 64); A(dbits, cap / 32 + 4096); A(n_demand, 16); A(chg, nch + 64);
   A(dbg, 128);
 #undef A
+#undef A2
   if (rc) { free_group(W.allocs); return rc; }
   W.cap_n = cap;
   hipMemsetAsync(W.dbg, 0, 128 * 8, c->stream);
@@ -271,19 +290,40 @@ static void free_workspace(Ctx *c) {
 // One lane per CRC_SUB bytes (raw register started at 0: the linear part), then the 16 sub-results of
 // each CRC_CHUNK are folded on the device with the fixed "advance by CRC_SUB zero bytes" operator
 // (mat, 32 words), leaving one value per CRC_CHUNK for the host to chain.
-__global__ void __launch_bounds__(256) k_crc_chunks(const uint8_t *__restrict__ in, uint64_t n, uint32_t nsub, uint32_t *__restrict__ sub) {   // in: 16-byte aligned
+// Round 5: the workgroup's 16 KiB of input are staged in LDS with coalesced 16-byte loads and every lane then reads its own 256 bytes from there
+// (rows padded to 272 bytes: lanes 68 words apart, no bank conflicts beyond the four a 16-byte read has anyway).  With every lane loading its own
+// 256-byte stretch from memory, 16 bytes at a time and 256 bytes apart from its neighbours', the kernel fetched 3.5 times the input (PMC FETCH_SIZE).
+constexpr int CRC_WG = 64, CRC_ROW = CRC_SUB + 16;
+__global__ void __launch_bounds__(CRC_WG) k_crc_chunks(const uint8_t *__restrict__ in, uint64_t n, uint32_t nsub, uint32_t *__restrict__ sub) {   // in: 16-byte aligned
   __shared__ uint32_t tab[256];
-  {
-    uint32_t l = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t rows[CRC_WG * CRC_ROW];
+  for (uint32_t t = threadIdx.x; t < 256; t += CRC_WG) {
+    uint32_t l = t;
     for (int b = 0; b < 8; b++) l = (l & 1) ? (l >> 1) ^ 0xEDB88320u : l >> 1;      // Prepare_table :31-47
-    tab[threadIdx.x] = l;
+    tab[t] = l;
+  }
+  const uint64_t tile0 = (uint64_t)blockIdx.x * CRC_WG * CRC_SUB;
+  {
+    // (whole 16-byte words inside the input only -- a caller's device buffer ends at n --, the last few bytes one by one)
+    const uint4 *src = (const uint4 *)(in + tile0);
+    const uint64_t left = tile0 < n ? n - tile0 : 0, words = left / 16;
+#pragma unroll
+    for (int j = 0; j < CRC_SUB / 16; j++) {
+      const uint32_t wq = j * CRC_WG + threadIdx.x;                               // word of the tile: row wq / 16, word wq % 16 of the row
+      if (wq < words) *(uint4 *)(rows + (wq >> 4) * CRC_ROW + (wq & 15) * 16) = src[wq];
+    }
+    if (words < (uint64_t)CRC_WG * CRC_SUB / 16 && threadIdx.x < (left & 15)) {
+      const uint64_t o = words * 16 + threadIdx.x;                                // byte of the tile
+      rows[(o / CRC_SUB) * CRC_ROW + (o % CRC_SUB)] = in[tile0 + o];
+    }
   }
   __syncthreads();
-  uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  uint32_t k = blockIdx.x * CRC_WG + threadIdx.x;
   if (k >= nsub) return;
   uint64_t p0 = (uint64_t)k * CRC_SUB, p1 = p0 + CRC_SUB < n ? p0 + CRC_SUB : n;
   uint32_t r = 0;
-  const uint4 *w = (const uint4 *)(in + p0);
+  const uint8_t *row = rows + threadIdx.x * CRC_ROW;
+  const uint4 *w = (const uint4 *)row;
   uint64_t len = p1 - p0, i = 0;
   for (; i + 16 <= len; i += 16) {
     const uint4 v = w[i >> 4];
@@ -297,7 +337,7 @@ __global__ void __launch_bounds__(256) k_crc_chunks(const uint8_t *__restrict__ 
       r = tab[(r ^ x) & 0xFF] ^ (r >> 8);
     }
   }
-  for (; i < len; i++) r = tab[(r ^ in[p0 + i]) & 0xFF] ^ (r >> 8);
+  for (; i < len; i++) r = tab[(r ^ row[i]) & 0xFF] ^ (r >> 8);
   sub[k] = r;
 }
 
@@ -359,7 +399,7 @@ int crc_launch(Ctx *c, const uint8_t *d_in, uint64_t n) {
   P.cnt[0] = P.nfull0;
   for (int l = 1; l < CRC_NLEV; l++) P.cnt[l] = P.cnt[l - 1] / 16;
   if (!W.crc_mat_ready) { hipMemcpyAsync(W.crc_mat, crc_M, sizeof(uint32_t) * 32 * (CRC_NLEV - 1), hipMemcpyHostToDevice, s2); W.crc_mat_ready = true; }
-  hipLaunchKernelGGL(k_crc_chunks, dim3((P.nsub + 255) / 256), dim3(256), 0, s2, d_in, n, P.nsub, W.crc_lvl[0]);
+  hipLaunchKernelGGL(k_crc_chunks, dim3((P.nsub + CRC_WG - 1) / CRC_WG), dim3(CRC_WG), 0, s2, d_in, n, P.nsub, W.crc_lvl[0]);
   for (int l = 1; l < CRC_NLEV; l++)
     if (P.cnt[l]) hipLaunchKernelGGL(k_crc_fold, dim3((P.cnt[l] + 255) / 256), dim3(256), 0, s2, W.crc_lvl[l - 1], P.cnt[l], W.crc_mat + 32 * (l - 1), W.crc_lvl[l]);
   // values the host needs: all of the top level, and per lower level the < 16 values after the last full group

@@ -30,7 +30,12 @@ struct LevelPtrs { uint16_t *prev[NLEVELS]; uint16_t *tails[NLEVELS]; };
 // Last level of the nested chains: sorted order of every segment, and per position its index in it and the number
 // of members of its bucket before it (inside the segment).
 struct RunPtrs { uint16_t *S, *idx, *cnt; };
-struct DistPlanes { uint16_t *d[NLEVELS]; uint32_t *dlim; };
+// dlim is sparse: only the members of the few buckets with a quarter chain's worth of members have a limit (k_bucket_limits); one bit per position
+// (dlim_bits) says whether dlim [p] holds one -- "no limit" is the absence of the bit, not 4 bytes per position written by a memset and read back.
+struct DistPlanes {
+  uint16_t *d[NLEVELS]; uint32_t *dlim; uint32_t *dlim_bits;
+  __device__ __forceinline__ uint32_t limits(uint64_t p) const { return ((dlim_bits[p >> 5] >> (p & 31)) & 1u) ? dlim[p] : 0xFFFFFFFFu; }
+};
 
 // ---- entropy stage geometry (zip-compress-deflate.adb:942, 1294, 1313) ----
 constexpr uint32_t FLUSH = 65536;                 // atoms per Flush_half_buffer
@@ -140,7 +145,7 @@ struct Workspace {
   uint16_t *S3 = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
   uint32_t *segmax = nullptr;                // largest 15-bit bucket of every segment
   uint16_t *heavy = nullptr;                 // per segment 2048 x u16: the number of its heavy 15-bit buckets, then their hashes (zada_lz.hip)
-  uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr;  // DistPlanes
+  uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr, *dlim_bits = nullptr;  // DistPlanes
   uint16_t *SK = nullptr, *idxK = nullptr, *cntK = nullptr;   // RunPtrs
   MatchPair *M = nullptr;                    // match tables
   uint32_t *spec_tok = nullptr, *fix_tok = nullptr;

@@ -214,7 +214,7 @@ static_assert(MAX_DIST < 0x8000, "continue markers of the planes");
 // LDS of k_prev_links: the sort's two halves (128 KiB), its counters (16 KiB + 64 B); with runs of segments per workgroup the previous segment's bytes
 // are staged from 131 072 on (32 KiB: over the counters, which are dead during the walks of the one level that needs them).
 constexpr int PL_LDS = 144 * 1024 + 64, PL_LDS_RUNS = 160 * 1024, PL_PREV_OFF = 131072;
-constexpr int PL_XOFF = 32784, PL_XENT = (65536 - PL_XOFF) / 2;          // behind the segment's staged bytes: room for 16 376 table entries
+constexpr int PL_HB_OFF = PL_PREV_OFF + 12288;                          // the bit map of bucket heads (4 KiB), clear of the level's bucket-start masks
 static_assert(PL_PREV_OFF + 32768 <= PL_LDS_RUNS, "k_prev_links: LDS map of the fused cross links");
 template <bool RUNS>
 __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__ in, Layout L, int kfull, int kquarter,
@@ -351,6 +351,12 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     uint16_t *tail = lvl > 0 ? lv.tails[lvl - 1] + seg * 65536ull : nullptr;
     const bool want_runs = lvl == 0 || lvl == NLEVELS;   // bucket boundaries of the sorted order are needed
     uint32_t ed[32];
+    // keyed (fused cross links): a bucket's first member has no link yet -- its key travels in the link's place (and from there into the link array P) and a bit
+    // map of such heads, HB, says which entries of P are keys: the cross-link phase below then needs neither the bytes nor a hash
+    const bool keyed = RUNS && fused && lvl > 0;
+    uint32_t *HB = (uint32_t *)(smem + PL_HB_OFF);
+    uint32_t firstmask = 0;                                            // bit `it`: the lane's element `it` starts a bucket
+    if (keyed) HB[tid] = 0;                                            // (the sort's counters are dead; the barrier in front of the scatter lies between this and its use)
     {
       const uint32_t *pp = AB + i0;
       uint32_t *pf = F + (i0 >> 5);
@@ -366,6 +372,8 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           const bool last = (it * 64 + 1 == rem) || ((pp[it * 64 + 1] >> 16) != k);
           uint32_t d = 0;
           if (!first) { const uint32_t e0 = pm & 0xFFFFu; if (!(first_seg && e0 == 0)) d = e - e0; }     // NIL = position 0, lz77.adb:467
+          else if (keyed) d = k;
+          firstmask |= (uint32_t)first << it;
           x = e | ((uint32_t)last << 15) | (d << 16);
           if (lvl > 0 && last) tail[k] = (uint16_t)e;
         }
@@ -441,12 +449,13 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
     }
     lds_barrier();                                 // keys (A) and sorted positions (B) are dead from here
     if (lvl == 0 && tid == 0) { segmax[seg] = cnt[2048]; hvy[0] = cnt[2049] <= HEAVY_CAP ? (uint16_t)cnt[2049] : (uint16_t)0xFFFF; }
-    for (uint32_t i = tid; i < (m + 16 + 15) / 16; i += 1024) ((uint4 *)A)[i] = ((const uint4 *)sin)[i];   // A := bytes
+    if (!keyed) { for (uint32_t i = tid; i < (m + 16 + 15) / 16; i += 1024) ((uint4 *)A)[i] = ((const uint4 *)sin)[i]; }   // A := bytes (keyed: after the cross links, A holds the table first)
 #pragma unroll
     for (int it = 0; it < 32; it++) {
       if (it * 64 < rem) {
         const uint32_t e = ed[it] & 0x7FFFu;
         P[e] = (uint16_t)(ed[it] >> 16);
+        if (keyed && ((firstmask >> it) & 1u)) atomicOr(&HB[e >> 5], 1u << (e & 31u));
         if (lvl == 0) s3[i0 + it * 64] = (uint16_t)e;
       }
     }
@@ -460,52 +469,47 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         }
       }
     } else {
-      if (RUNS && fused) {
-        // Cross links, fused: the first member of each of the level's buckets (no link so far) is linked to the bucket's last member in the segment
-        // before -- what k_cross_links does, but with the links and the bytes where they are, in LDS, and the previous segment's tails table (which
-        // this workgroup wrote itself, initialised) staged half at a time, coalesced.  (Looked up
+      if (keyed) {
+        // Cross links, fused: the first member of each of the level's buckets is linked to the bucket's last member in the segment before -- what
+        // k_cross_links does, but with the links where they are, in LDS, and the previous segment's tails table (which this workgroup wrote itself,
+        // initialised) staged half at a time, coalesced, in the sort's first half (the segment's bytes are staged there afterwards).  (Looked up
         // straight from memory -- two-byte gathers, 64 addresses an instruction -- the same entries cost 47 000 cycles per level: 90 cycles an
-        // instruction in the memory pipeline.)  The keys are hashed again from the bytes, in every round (registers are what this kernel has none of).
-        // Two rounds of half a table: 16 384 entries where the counters were, 16 376 behind the segment's bytes (the queues' place, not in use yet);
-        // the eight entries per half that have no room are read from memory by whoever needs one (one bucket head in 4 000).
-        uint16_t *tqY = (uint16_t *)(smem + PL_PREV_OFF), *tqX = (uint16_t *)(smem + PL_XOFF);
+        // instruction in the memory pipeline; with the keys hashed again from the bytes, position by position, 50 000: LDS instructions.)  A lane
+        // takes the heads among its 32 positions from the bit map, four at a time.  Round r takes the keys with bit 15 = r: a head that has been
+        // linked holds a distance (<= MAX_DIST < 2^15) or 0 and is never taken for a key of round 1.
+        const uint16_t *tab = (const uint16_t *)A;
         const uint16_t *tprev = lv.tails[lvl - 1] + (seg - 1) * 65536ull;
+        const uint32_t hb = HB[tid], e00 = (uint32_t)tid * 32u;
 #pragma unroll 1
         for (uint32_t r = 0; r < 2; r++) {
-          lds_barrier();                             // (the half before this one has been read)
+          if (r) lds_barrier();                      // (the half before this one has been read)
           {
             const uint4 *src = (const uint4 *)(tprev + r * 32768u);
-            const uint4 y0 = src[tid], y1 = src[tid + 1024], x0 = src[tid + 2048], x1 = src[tid + 3072];
-            ((uint4 *)tqY)[tid] = y0; ((uint4 *)tqY)[tid + 1024] = y1;
-            ((uint4 *)tqX)[tid] = x0;
-            if (tid + 1024 < PL_XENT / 8) ((uint4 *)tqX)[tid + 1024] = x1;
+            const uint4 v0 = src[tid], v1 = src[tid + 1024], v2 = src[tid + 2048], v3 = src[tid + 3072];
+            ((uint4 *)A)[tid] = v0; ((uint4 *)A)[tid + 1024] = v1; ((uint4 *)A)[tid + 2048] = v2; ((uint4 *)A)[tid + 3072] = v3;
           }
           lds_barrier();
-#pragma unroll 1
-          for (uint32_t e0 = tid; e0 < m; e0 += 8192) {               // eight positions per lane at a time, nothing conditional: their LDS reads overlap
-            uint32_t pe[8], kk[8], tt[8];
+          uint32_t w = hb;
+          while (w) {
+            uint32_t eb[4], kk[4], tt[4];
+            bool vv[4];
 #pragma unroll
-            for (int q = 0; q < 8; q++) { const uint32_t e = e0 + 1024u * q; pe[q] = P[e < m ? e : 0u]; if (e >= m) pe[q] = 1u; }
+            for (int q = 0; q < 4; q++) { vv[q] = w != 0; eb[q] = e00 + (vv[q] ? (uint32_t)__ffs((int)w) - 1u : 0u); w &= w - 1u; }
 #pragma unroll
-            for (int q = 0; q < 8; q++) { const uint32_t e = e0 + 1024u * q; kk[q] = hashL_of(lb8(e < m ? e : 0u), L); }
+            for (int q = 0; q < 4; q++) kk[q] = P[eb[q]];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-              const uint32_t kr = kk[q] & 32767u;
-              tt[q] = kr < 16384u ? (uint32_t)tqY[kr] : (uint32_t)tqX[kr - 16384u < PL_XENT ? kr - 16384u : 0u];
-            }
+            for (int q = 0; q < 4; q++) tt[q] = tab[kk[q] & 32767u];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-              if (pe[q] != 0 || (kk[q] >> 15) != r) continue;
-              const uint32_t e = e0 + 1024u * q;
-              uint32_t t = tt[q];
-              if ((kk[q] & 32767u) >= 16384u + PL_XENT) t = tprev[kk[q]];
+            for (int q = 0; q < 4; q++) {
+              if (!vv[q] || (kk[q] >> 15) != r) continue;
               // the bucket's last member in the previous segment, if it has one there, within MAX_DIST, and not position 0 of an entry (:467)
-              const uint32_t dx = e + 32768u - t;
-              if (t != 0xFFFFu && dx <= (uint32_t)MAX_DIST && !(prev_first && t == 0)) P[e] = (uint16_t)dx;
+              const uint32_t t = tt[q], dx = eb[q] + 32768u - t;
+              P[eb[q]] = (t != 0xFFFFu && dx <= (uint32_t)MAX_DIST && !(prev_first && t == 0)) ? (uint16_t)dx : (uint16_t)0;
             }
           }
         }
         lds_barrier();
+        if (lvl < NLEVELS) { for (uint32_t i = tid; i < (m + 16 + 15) / 16; i += 1024) ((uint4 *)A)[i] = ((const uint4 *)sin)[i]; }   // A := bytes, for the walks and the next level's keys
       }
       uint16_t *prevl = lv.prev[lvl - 1];
       for (uint32_t i = tid; i < (m + 7) / 8; i += 1024) ((uint4 *)(prevl + base))[i] = ((const uint4 *)P)[i];
@@ -916,7 +920,7 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 // per-position default (no limit) is written by k_prev_links and this kernel touches the few long
 // buckets: one workgroup per segment, long buckets listed in LDS, then processed by all threads.
 __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int kquarter, const uint16_t *__restrict__ S3,
-                                                       const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim, const uint32_t *__restrict__ segmax,
+                                                       const uint32_t *__restrict__ bsc3, uint32_t *__restrict__ dlim, uint32_t *__restrict__ dlim_bits, const uint32_t *__restrict__ segmax,
                                                        const uint16_t *__restrict__ heavy, uint32_t seg0) {
   __shared__ uint32_t list[2048];
   __shared__ uint32_t nlist;
@@ -954,6 +958,7 @@ __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int 
           lim[t] = d < 0xFFFF ? (uint32_t)d : 0xFFFFu;
         }
         dlim[base + e] = lim[0] | (lim[1] << 16);
+        atomicOr(&dlim_bits[(base + e) >> 5], 1u << ((base + e) & 31u));
       }
     }
   };
@@ -1097,7 +1102,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
             const int la_ = rem < 258 ? (int)rem : 258;            // Longest_Match never returns more
             const int nice_ = nice_cfg < la_ ? nice_cfg : la_;     // lz77.adb:858-860
             // limits of this position's walk, as distances, and the nearest 3 .. K-1 byte matches (k_prev_links)
-            const uint32_t dlimv = dp.dlim[B + k];
+            const uint32_t dlimv = dp.limits(B + k);
             const uint32_t df = dlimv & 0xFFFF, dq = dlimv >> 16;
             uint32_t dl[NLEVELS];
 #pragma unroll
@@ -1395,7 +1400,7 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       const int la = rem < 258 ? (int)rem : 258;                   // Longest_Match never returns more
       const int nice = nice_cfg < la ? nice_cfg : la;              // lz77.adb:858-860
       const uint64_t seg = p >> 15, pbase = (seg << 15) - 32768;
-      const uint32_t dlimv = dp.dlim[p];
+      const uint32_t dlimv = dp.limits(p);
       uint32_t dl[NLEVELS];
 #pragma unroll
       for (int l = 0; l < NLEVELS; l++) dl[l] = dp.d[l][p];
@@ -1588,6 +1593,14 @@ struct DemandMarker {
 // The parser's look-ups walk forward through the 8-byte match records, landing on every third or so: fetching each
 // record on its own pulls the same 64-byte line from HBM several times (PMC: 27 GB per parse of 1 GiB, three times
 // the table).  Each lane keeps the line of its last look-up in LDS (lane-interleaved, so lanes never share a bank).
+#ifndef ZADA_PS_BWORDS
+#define ZADA_PS_BWORDS 16
+#endif
+#ifndef ZADA_PS_TOKS
+#define ZADA_PS_TOKS 8
+#endif
+constexpr uint32_t PS_BWORDS = ZADA_PS_BWORDS, PS_TOKS = ZADA_PS_TOKS;
+static_assert((PS_BWORDS == 8 || PS_BWORDS == 16) && (PS_TOKS == 4 || PS_TOKS == 8), "line sizes of the parser's LDS caches");
 struct LineFetch {
   const MatchPair *M; uint64_t *slot;              // slot[r * 64] = record r of the cached line, for this lane
   uint32_t tag;
@@ -1606,20 +1619,26 @@ struct LineFetch {
     MatchPair r; r.full = (uint32_t)v; r.quarter = (uint32_t)(v >> 32);
     return r;
   }
-  // the literal byte in front of a position: 64 input bytes per lane are kept the same way
+  // the literal byte in front of a position: PS_BWORDS * 4 input bytes per lane are kept the same way (64; round 5 measured 32 with the token
+  // buffer halved as well -- 7 KB of LDS per wave instead of 10, 22 waves per CU instead of 16 --: the parse phase 27.1 -> 28.0 ms, the refills
+  // cost more than the waves bring; -DZADA_PS_BWORDS=8 -DZADA_PS_TOKS=4)
   const uint8_t *in; uint32_t *bslot; uint32_t btag;
   __device__ uint32_t byte(uint32_t p) {
-    const uint32_t t = p >> 6;
+    constexpr uint32_t SH = PS_BWORDS == 16 ? 6 : 5;
+    const uint32_t t = p >> SH;
     if (t != btag) {
-      const uint4 *src = (const uint4 *)(in + ((uint64_t)t << 6));
-      const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+      const uint4 *src = (const uint4 *)(in + ((uint64_t)t << SH));
+      const uint4 a = src[0], b = src[1];
       bslot[0 * 64] = a.x; bslot[1 * 64] = a.y; bslot[2 * 64] = a.z; bslot[3 * 64] = a.w;
       bslot[4 * 64] = b.x; bslot[5 * 64] = b.y; bslot[6 * 64] = b.z; bslot[7 * 64] = b.w;
-      bslot[8 * 64] = c.x; bslot[9 * 64] = c.y; bslot[10 * 64] = c.z; bslot[11 * 64] = c.w;
-      bslot[12 * 64] = d.x; bslot[13 * 64] = d.y; bslot[14 * 64] = d.z; bslot[15 * 64] = d.w;
+      if (PS_BWORDS == 16) {
+        const uint4 c = src[2], d = src[3];
+        bslot[8 * 64] = c.x; bslot[9 * 64] = c.y; bslot[10 * 64] = c.z; bslot[11 * 64] = c.w;
+        bslot[12 * 64] = d.x; bslot[13 * 64] = d.y; bslot[14 * 64] = d.z; bslot[15 * 64] = d.w;
+      }
       btag = t;
     }
-    return (bslot[((p >> 2) & 15u) * 64] >> (8 * (p & 3u))) & 0xFFu;
+    return (bslot[((p >> 2) & (PS_BWORDS - 1u)) * 64] >> (8 * (p & 3u))) & 0xFFu;
   }
 };
 
@@ -1628,16 +1647,17 @@ struct LineFetch {
 struct TokSink {
   uint32_t *dst; uint32_t *buf; uint32_t n;
   __device__ void push(uint32_t t) {
-    buf[(n & 7u) * 64] = t;
+    buf[(n & (PS_TOKS - 1u)) * 64] = t;
     n++;
-    if ((n & 7u) == 0) {
-      uint4 a, b;
-      a.x = buf[0]; a.y = buf[64]; a.z = buf[128]; a.w = buf[192]; b.x = buf[256]; b.y = buf[320]; b.z = buf[384]; b.w = buf[448];
-      uint4 *o = (uint4 *)(dst + n - 8);
-      o[0] = a; o[1] = b;
+    if ((n & (PS_TOKS - 1u)) == 0) {
+      uint4 a;
+      a.x = buf[0]; a.y = buf[64]; a.z = buf[128]; a.w = buf[192];
+      uint4 *o = (uint4 *)(dst + n - PS_TOKS);
+      o[0] = a;
+      if (PS_TOKS == 8) { uint4 b; b.x = buf[256]; b.y = buf[320]; b.z = buf[384]; b.w = buf[448]; o[1] = b; }
     }
   }
-  __device__ void flush() { for (uint32_t i = n & ~7u; i < n; i++) dst[i] = buf[(i & 7u) * 64]; }
+  __device__ void flush() { for (uint32_t i = n & ~(PS_TOKS - 1u); i < n; i++) dst[i] = buf[(i & (PS_TOKS - 1u)) * 64]; }
 };
 
 // The chunks a demand pass has flagged (chg), as a list: the speculative parse of a later round is launched over the list, every lane with a
@@ -1672,8 +1692,8 @@ __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict_
   uint32_t ntok = 0;
   ExitState ex;
   __shared__ uint64_t lines[8 * 64];
-  __shared__ uint32_t tbuf[8 * 64];
-  __shared__ uint32_t blines[16 * 64];
+  __shared__ uint32_t tbuf[PS_TOKS * 64];
+  __shared__ uint32_t blines[PS_BWORDS * 64];
   LineFetch lf; lf.M = io.M; lf.slot = lines + threadIdx.x; lf.tag = 0xFFFFFFFFu; lf.in = io.in; lf.bslot = blines + threadIdx.x; lf.btag = 0xFFFFFFFFu;
   TokSink ts; ts.dst = spec_tok + (uint64_t)k * PTOK_STRIDE; ts.buf = tbuf + threadIdx.x; ts.n = 0;
   parse_spec_chunk_to(io, k, PCHUNK, ts, Fbits, Lbits, ex, dm, lf);
@@ -1919,15 +1939,15 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   DistPlanes dpl;
   RunPtrs rpt; rpt.S = W.SK; rpt.idx = W.idxK; rpt.cnt = W.cntK;
   for (int l = 0; l < NLEVELS; l++) dpl.d[l] = W.dplane[l];
-  dpl.dlim = W.dlim;
+  dpl.dlim = W.dlim; dpl.dlim_bits = W.dlim_bits;
   if (nseg > 0) {
     for (int l = 0; l < NLEVELS; l++) { lv.prev[l] = W.lprev[l]; lv.tails[l] = W.ltails[l]; }
 #ifndef ZADA_OLD_INIT
-    // "no chain-length limit" for every position (k_bucket_limits writes the few there are): a memset next to k_prev_links, which
-    // leaves the memory pipes mostly idle (one workgroup per CU, bound by its LDS round trips)
+    // "no chain-length limit" for every position (k_bucket_limits writes the few there are, and sets their bits): the bit map is cleared next to
+    // k_prev_links (round 5: a bit per position instead of the 4-byte plane itself -- 4 bytes per input byte less written, and as many less read)
     hipEventRecord(c->ev_dlim, st);                                  // (the shard before has read the plane)
     hipStreamWaitEvent(c->stream2, c->ev_dlim, 0);
-    hipMemsetAsync(W.dlim, 0xFF, (size_t)n * 4, c->stream2);
+    hipMemsetAsync(W.dlim_bits, 0, (size_t)(n / 32 + 2) * 4, c->stream2);
     hipEventRecord(c->ev_dlim, c->stream2);
 #endif
     // Runs of R segments per workgroup of k_prev_links (it then makes the cross links of all but a run's first segment itself; k_cross_links takes
@@ -1977,7 +1997,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
         if (s0 == 0) hipStreamWaitEvent(st, c->ev_dlim, 0);              // (k_bucket_limits writes into the plane the second stream has preset)
 #endif
         if (slow) cross_links_upto(s1);
-        hipLaunchKernelGGL(k_bucket_limits, dim3(s1 - s0), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax, W.heavy, s0);
+        hipLaunchKernelGGL(k_bucket_limits, dim3(s1 - s0), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.dlim_bits, W.segmax, W.heavy, s0);
         s0 = s1;
       }
       if (int rn = job.need(n)) return rn;
@@ -1999,7 +2019,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
         cross_links(1, nseg);
         hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n);
       }
-      hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.segmax, W.heavy, 0u);
+      hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.dlim_bits, W.segmax, W.heavy, 0u);
     }
   }
   c->tmark("cross_links");
