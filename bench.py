@@ -533,6 +533,7 @@ def main():
     ap.add_argument("--no-checks", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-v1", action="store_true", help="skip the extra Deflate measurement on silesia_mix_v1")
+    ap.add_argument("--no-copy-probe", action="store_true", help="skip the device-to-device copy that measures the box's HBM bandwidth (the PMC passes: their counters then hold the step alone)")
     ap.add_argument("--method", choices=("deflate", "bzip2"), default="deflate", help="bzip2: BASELINE config 5 -- ONE BZip2_3 stream of N x --mib (default 1024) MiB over N GPUs")
     ap.add_argument("--bzip2-mib", type=int, default=256, help="input MiB of the secondary BZip2_3 measurement at one GPU (0 = skip)")
     ap.add_argument("--lzma-entries", type=int, default=4096, help="entries of the secondary LZMA_3 batch measurement at one GPU (0 = skip)")
@@ -571,7 +572,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     global HBM_PEAK_GBS, HBM_MEASURED
-    HBM_MEASURED = hbm_copy_gbs(torch, dev)
+    HBM_MEASURED = None if args.no_copy_probe else hbm_copy_gbs(torch, dev)
     za = importlib.import_module("zip-ada_amd")
     sharding = importlib.import_module("zip-ada_amd.sharding")
     enc = za.Encoder(local_rank)

@@ -598,11 +598,28 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
         for (int j = 0; j < 4; j++) { mn[j] = lb8(ee[j]) & lmask; st[j] = P[ee[j]]; }          // (no conditions: the LDS reads overlap)
 #pragma unroll
         for (int j = 0; j < 4; j++) th[j] = lb8(st[j] <= ee[j] ? ee[j] - st[j] : ee[j]) & lmask;   // (no link, or one that leaves the segment: its own bytes)
+        // fused: a position whose own link leaves the segment (a bucket's first member -- every other position or so) has its candidate in the previous
+        // segment, at the distance the link says; its four bytes are fetched with everything else, without a condition
+        uint32_t pw[4] = {0, 0, 0, 0};
+        if (RUNS && fused && lvl > 0) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t t = st[j] > ee[j] ? ee[j] + 32768u - st[j] : 0u, tr = t <= 32768u - 4u ? t : 0u;
+            const uint32_t *wp = (const uint32_t *)(pbL + (tr & ~3u));
+            pw[j] = __builtin_amdgcn_alignbyte(wp[1], wp[0], tr & 3u);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const uint32_t e = ee[j], step = st[j];
-          uint32_t dl = dflt_of(e, e), q = e;
+          uint32_t dl = 0, q = e;
           bool pend = false;
+          if (!(ex[j] && step - 1u < e)) {
+            if (RUNS && fused && lvl > 0) {
+              // no link: nothing in reach in the previous segment either; a link into it: the candidate there, compared (dflt_of (e, e) without its branches)
+              if (step != 0) dl = (e + 32768u - step <= 32768u - 4u && pw[j] == (uint32_t)mn[j]) ? step : DISTL_CONTINUE;
+            } else dl = dflt_of(e, e);
+          }
           if (ex[j] && step - 1u < e) {
             q = e - step;
             if (lvl == 0) {
