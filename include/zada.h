@@ -83,7 +83,8 @@ const char *zada_version(void);
  * 1 .. 64, 0 = by size), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
  * batching; "bz_lists", "bz_list_rows", "bz_text_order", "bz_pipeline", "bz_small_wg", "bz_split", "bz_tail_pct": scheduling of the BZip2 stages), "lzma_chunk" (positions of an LZMA stream one launch codes between two feedback calls; 0 = by level, -1 = one launch
  * per stream), "lzma_pool" (test knob: blocks of the LZMA_3 match sets' overflow pool to start with, 0 = by size; a pool that is too small is
- * counted and the match producer's walk runs again), "lzma_segment" (one LZMA_3 stream coded in launches: log2 of the positions per segment of
+ * counted and the match producer's walk runs again; for a stream whose producer works in segments the pool grows between the segments), "lzma_pool_fixed" (test knob: 1 = it
+ * does not), "lzma_segment" (one LZMA_3 stream coded in launches: log2 of the positions per segment of
  * the match producer, whose walks of segment k + 1 run beside the coder of segment k; 13 .. 30, 0 = by size: 2 ** 20 positions for streams from 2 MiB on, 2 ** 18 from 512 KiB on, none below,
  * -1 = all match sets before the coder starts), "lzma_waves" (one LZMA_3 stream alone: waves of its workgroup -- 0 or 4 = the wave that walks the stream's
  * chain and three helpers that take shares of its forks, 1 = that wave alone, as every entry of a batch has it).  None of them changes a byte.  One knob is a parameter of the reference instead: "lzma_dict" = LZMA.Encoding.Encode's

@@ -12,7 +12,7 @@ import zlib
 import numpy as np
 import pytest
 
-from _common import GOLDEN, product, oracle_zip
+from _common import GOLDEN, product, oracle_zip, silesia_mix
 from _lzmah import lz_inputs, oracle_lzma, oracle_lzma_encode, lzma_decode, LZMA_METHODS, oracle_bt4_sets, sets_equal
 
 pytestmark = pytest.mark.gpu
@@ -110,13 +110,31 @@ def test_one_stream_with_the_producer_in_segments(encoder):
             small = d[777:777 + nsmall]
             assert sets_equal(oracle_bt4_sets(small, None), encoder.lzma_match_sets(small)), nsmall
             assert encoder.lzma(small, 18) == oracle_lzma(small, 18), nsmall
+        # Round 5: the overflow pool of the match sets GROWS between the segments (a 512 MiB stream of the benchmark corpus ran out of the pool it
+        # started with at 70 % and was coded a second time, all match sets first).  A pool that holds the first segments' long sets (those of more
+        # than seven matches book a block each) but not the stream's: no rerun, the pool enlarged at least once, the oracle's payload.
+        code = silesia_mix(600000, class_mask=6, version=2)     # (tagged records and source-like lines: one position in a hundred has a long set)
+        longsets = oracle_bt4_sets(code, None)[0] > 7
+        pool = int(longsets[:3 << 13].sum()) + 1200
+        assert int(longsets.sum()) > 2 * pool, "the stream must need more blocks than the pool it starts with"
+        want_code = oracle_lzma(code, 18)
+        encoder.set_knob("lzma_segment", 13)
+        encoder.set_knob("lzma_pool", pool)
+        r0, g0 = (dict(encoder.last_timing()).get(k, 0) for k in ("#bt4_reruns", "#bt4_pool_grown"))
+        assert encoder.lzma(code, 18) == want_code
+        r1, g1 = (dict(encoder.last_timing()).get(k, 0) for k in ("#bt4_reruns", "#bt4_pool_grown"))
+        assert r1 == r0 and g1 > g0, (r0, r1, g0, g1)
+        encoder.set_knob("lzma_pool_fixed", 1)                 # the round-4 behaviour: run out, start again -- the same payload
+        assert encoder.lzma(code, 18) == want_code
+        assert dict(encoder.last_timing()).get("#bt4_reruns", 0) > r1
+        encoder.set_knob("lzma_pool", 0)
         encoder.set_knob("lzma_segment", 14)
         before = dict(encoder.last_timing()).get("#bt4_reruns", 0)
-        encoder.set_knob("lzma_pool", 1)
+        encoder.set_knob("lzma_pool", 1)                       # (still with a pool that may not grow)
         assert encoder.lzma(d, 18) == want
         assert dict(encoder.last_timing()).get("#bt4_reruns", 0) >= before + 2    # (out of the segments, then the unsegmented producer's own)
     finally:
-        for k in ("lzma_dict", "lzma_chunk", "lzma_segment", "lzma_pool"):
+        for k in ("lzma_dict", "lzma_chunk", "lzma_segment", "lzma_pool", "lzma_pool_fixed"):
             encoder.set_knob(k, 0)
     # without segments: the same stream
     try:

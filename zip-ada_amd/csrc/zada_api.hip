@@ -55,6 +55,7 @@ void Ctx::tend() {
   timing.push_back({"#splice_rounds", (float)parse_rounds});
   timing.push_back({"#bt4_reruns", (float)bt4_reruns});
   timing.push_back({"#lzma_launches", (float)lzma_launches});
+  timing.push_back({"#bt4_pool_grown", (float)bt4_pool_grown});
 }
 
 #ifndef ZADA_COPY_LANES
@@ -1041,6 +1042,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   // per handful of bytes -- the tests go down to 777)
   else if (!strcmp(name, "lzma_chunk")) { if (value < -1 || (value > 0 && value < 256)) return ZADA_E_INVALID; z->c.knob_lzma_chunk = value; }
   else if (!strcmp(name, "lzma_pool")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_lzma_pool = value; }
+  else if (!strcmp(name, "lzma_pool_fixed")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_lzma_pool_fixed = value; }
   else if (!strcmp(name, "lzma_waves")) { if (value != 0 && value != 1 && value != 4) return ZADA_E_INVALID; z->c.knob_lzma_waves = value; }
   else if (!strcmp(name, "lzma_segment")) { if (value < -1 || (value > 0 && (value < 13 || value > 30))) return ZADA_E_INVALID; z->c.knob_lzma_segment = value; }
   else return ZADA_E_INVALID;
@@ -1393,7 +1395,7 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
     for (;;) {
       if (seg_shift < 32 && k < nseg && (k == 0 || cap != ~0ull)) {
         // segment k's sets are complete when stream2 is idle; the next segment's walks start before the coder goes on
-        const int ov = bt4_segments_overflowed(c, c->stream2);
+        const int ov = bt4_segments_overflowed(c, c->stream2, &sets);     // (may move the overflow pool to a larger one: nothing of this stream is running)
         if (ov < 0) return ov;
         if (ov) {                                                    // the pool was too small: the whole stream again, the producer first (it grows the pool itself)
           hipStreamSynchronize(c->stream);

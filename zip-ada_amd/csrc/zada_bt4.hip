@@ -330,6 +330,7 @@ struct State {
   const uint32_t *order = nullptr;
   const uint8_t *arena = nullptr;
   uint32_t ovf_cap = 0;
+  uint32_t seg_blocks_max = 0;                                       // the most overflow blocks one segment's walks have booked (this stream)
 };
 int grow(Ctx *c, Buf &b, size_t bytes) {
   if (b.p && b.cap >= bytes) return 0;
@@ -413,9 +414,9 @@ int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena
   const size_t tmp_bytes = radix_sort_tmp_bytes(P, 4);
   const bool segmented = seg_shift < 32;
   if (segmented && (jobs.size() != 1 || jobs[0].in_off != 0 || jobs[0].level != 3)) { c->err = "LZMA: segments are for one entry"; return ZADA_E_INVALID; }
-  if (c->knob_lzma_pool > 0) B->ovf_cap = (uint32_t)c->knob_lzma_pool;        // (test knob: a pool that is too small, to walk twice)
+  if (c->knob_lzma_pool > 0) B->ovf_cap = (uint32_t)c->knob_lzma_pool;        // (test knob: a pool that is too small, to walk twice -- or, segmented, to grow)
   else if (B->ovf_cap < P / 16 + 1024) B->ovf_cap = P / 16 + 1024;
-  B->seg_shift = seg_shift; B->P = P; B->arena = d_arena;
+  B->seg_shift = seg_shift; B->P = P; B->arena = d_arena; B->seg_blocks_max = 0; c->bt4_overflow = 0;
   if (segmented) {                                                   // where every segment begins in the (segment, hash 4, position) order: the inserted positions before it
     const uint32_t ns = (uint32_t)((jobs[0].n + (1ull << seg_shift) - 1) >> seg_shift);
     B->seg_start.assign(ns + 1, 0);
@@ -540,13 +541,44 @@ int bt4_walk_segment(Ctx *c, uint32_t k, hipStream_t st) {
 }
 // After the walks enqueued on `st` so far: 1 when the overflow pool of the match sets was too small for them (the sets of the last
 // segment are not all there: the caller goes back to the unsegmented way), 0 when all is well.
-int bt4_segments_overflowed(Ctx *c, hipStream_t st) {
+// Round 5: the pool GROWS between the segments.  The segments book their blocks one after the other, so what the walks so far have used says what
+// the next ones will (P / 16 blocks to start with was enough for the whole of a stream on silesia_mix_v1, whose long repeats have short match sets;
+// on v2 a 512 MiB stream ran out at 70 % and was coded a second time from its first byte, all match sets first).  The caller comes here with no
+// kernel of the stream under way on either of the context's streams (the walks of `st` are waited for here, the coder's launches are bounded and
+// waited for): when less than three segments' worth of room is left, a pool of twice the size takes the blocks over; *out is pointed at it.
+int bt4_segments_overflowed(Ctx *c, hipStream_t st, Bt4Sets *out) {
   State *B = (State *)c->bt4;
   uint32_t h = 0;
   hipMemcpyAsync(&h, B->cnts.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "k_bt4_walk (segment)")) return ZADA_E_HIP;
+  const uint32_t used_before = c->bt4_overflow;
   c->bt4_overflow = h;
-  return h > B->ovf_cap ? 1 : 0;
+  if (h > B->ovf_cap) return 1;
+  const uint32_t this_seg = h >= used_before ? h - used_before : h;
+  if (this_seg > B->seg_blocks_max) B->seg_blocks_max = this_seg;
+  const uint64_t room = (uint64_t)B->ovf_cap - h, want = 3ull * B->seg_blocks_max + 1024;
+  if (out && room < want && c->knob_lzma_pool_fixed == 0) {
+    uint64_t cap2 = 2ull * B->ovf_cap > (uint64_t)h + 2 * want ? 2ull * B->ovf_cap : (uint64_t)h + 2 * want;
+    if (cap2 > B->P) cap2 = B->P;                                    // (a position books at most one block)
+    if (cap2 > B->ovf_cap) {
+      hipStreamSynchronize(c->stream);
+      void *nl = nullptr, *nd = nullptr;
+      const size_t bl = 2ull * BT4_OVF * cap2 + 4096, bd = 4ull * BT4_OVF * cap2 + 4096;
+      if (hipMalloc(&nl, bl) == hipSuccess && hipMalloc(&nd, bd) == hipSuccess) {
+        hipMemcpy(nl, B->ol.p, 2ull * BT4_OVF * (size_t)(h < B->ovf_cap ? h : B->ovf_cap), hipMemcpyDeviceToDevice);
+        hipMemcpy(nd, B->od.p, 4ull * BT4_OVF * (size_t)(h < B->ovf_cap ? h : B->ovf_cap), hipMemcpyDeviceToDevice);
+        hipFree(B->ol.p); hipFree(B->od.p);
+        B->ol.p = nl; B->ol.cap = bl; B->od.p = nd; B->od.cap = bd;
+        B->ovf_cap = (uint32_t)cap2;
+        out->ol = B->ol.as<uint16_t>(); out->od = B->od.as<uint32_t>();
+        c->bt4_pool_grown++;
+      } else {                                                       // no memory for a larger pool: go on with the one there is (it may still do)
+        (void)hipGetLastError();
+        if (nl) hipFree(nl);
+      }
+    }
+  }
+  return 0;
 }
 
 }  // namespace zada

@@ -259,6 +259,8 @@ struct Ctx {
   int lzma_launches = 0;                             // launches the last chunked LZMA call took
   void *bt4 = nullptr;                               // ... the BT4 match producer's buffers (zada_bt4.hip), made on first use
   uint32_t bt4_buckets = 0, bt4_long = 0, bt4_overflow = 0;   // last producer run: hash-4 buckets, long ones among them, overflow blocks booked
+  uint32_t bt4_pool_grown = 0;                       // the overflow pool of a stream's match sets was enlarged between two segments (since the context was made)
+  int knob_lzma_pool_fixed = 0;                      // test knob "lzma_pool_fixed": 1 = the pool never grows between segments (the round-4 behaviour: run out, start again)
   uint32_t bt4_reruns = 0;                           // walks repeated with a larger overflow pool (since the context was made)
   int knob_lzma_waves = 0;                           // LZMA_3, one stream: waves of its workgroup (0 = by the call: 4 for zada_lzma, 1 = the chain's wave alone)
   int knob_lzma_segment = 0;                         // LZMA_3, one stream: log2 of the positions per producer segment (0 = 20, -1 = no segments)
@@ -327,7 +329,7 @@ struct Bt4Sets { const uint8_t *cnt; const uint16_t *sl; const uint32_t *sd; con
 int bt4_produce(Ctx *c, const std::vector<LzmaJob> &jobs, const uint8_t *d_arena, uint64_t arena_bytes, Bt4Sets *out, std::vector<uint32_t> *weights = nullptr,
                 uint32_t seg_shift = 32, uint32_t *nseg = nullptr);
 int bt4_walk_segment(Ctx *c, uint32_t k, hipStream_t st);
-int bt4_segments_overflowed(Ctx *c, hipStream_t st);
+int bt4_segments_overflowed(Ctx *c, hipStream_t st, Bt4Sets *out = nullptr);
 void bt4_destroy(Ctx *c);
 uint32_t lzma_string_buffer_size(int level, uint64_t dictionary_size);
 uint32_t lzma_hash4_size(uint32_t sbs);

@@ -848,8 +848,14 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
   // (only where the head of the chain may lie exactly MAX_DIST back; p >= 32 768 > MAX_DIST)
   const uint32_t far24 = (d3_stored == DIST3_HEADCHK || d3_stored == DIST3_CONT_FIRST) ? *(const u32u *)(in + p - (uint64_t)MAX_DIST) & 0xFFFFFFu : 0xFFFFFFFFu;
   bool need = d3_stored >= DIST3_CONT_FIRST;
+#ifdef ZADA_CD_SKIP3      /* timing experiments only (wrong results): the kernel without its level-3 / level >= 4 part */
+  need = false;
+#endif
 #pragma unroll
   for (int l = 0; l + 1 < NLEVELS; l++) need = need || (dl_first[l] & DISTL_CONTINUE) || dl_first[l] == DISTL_GAVEUP;
+#ifdef ZADA_CD_SKIP4
+  need = d3_stored >= DIST3_CONT_FIRST;
+#endif
   if (!need) return;
   // level 3 first: the previous segment's bucket of the 15-bit hash, newest first, as far back as TOO_FAR (see k_prev_links)
   uint32_t dprev = d3_stored >= DIST3_CONT_FIRST ? 0u : d3_stored;
