@@ -313,14 +313,22 @@ def bzip2_leg(za, enc, mib, with_cpu, with_checks):
 
 
 def config_4_log():
-    """BASELINE config 4 itself (ONE LZMA_3 stream of 1 GiB) is a run of many minutes and not part of this command: what
-    tests/gpu_lzma_c4.py printed when it was last run on this round's corpus, read from the committed log -- or nothing."""
-    p = _latest_profile("config4_lzma3_1024mib_%s.json" % CORPUS_NAME)
-    if not p:
+    """BASELINE config 4 (ONE LZMA_3 stream of 1 GiB) is a run of an hour and more and not part of this command: what tests/gpu_lzma_c4.py
+    wrote when it was last run on this round's corpus -- the largest such run whose record is committed under profiles/ (the full size does
+    not fit the pool's one-hour limit per GPU call at 0.25 MB/s; its size is in the record) -- or nothing."""
+    import glob
+    import re
+    best, best_mib = None, 0
+    for p in glob.glob(os.path.join(ROOT, "profiles", "*", "config4_lzma3_*mib_%s.json" % CORPUS_NAME)):
+        m = re.search(r"config4_lzma3_(\d+)mib_", os.path.basename(p))
+        if m and (int(m.group(1)), p) > (best_mib, best or ""):
+            best, best_mib = p, int(m.group(1))
+    if not best:
         return None
     try:
-        d = json.load(open(p))
-        d["source"] = os.path.relpath(p, ROOT) + ": config 4 itself, one run on one MI355X -- NOT part of this run"
+        d = json.load(open(best))
+        d["source"] = os.path.relpath(best, ROOT) + ": tests/gpu_lzma_c4.py, one run on one MI355X -- NOT part of this run"
+        d["is_config_4_itself"] = bool(best_mib == 1024)
         return d
     except Exception:
         return None
@@ -368,7 +376,7 @@ def lzma_leg(za, enc, entries, kib, with_cpu, with_checks, one_mib=4):
                                  "wave walking the chain of adaptive probabilities, the independent simulations of a step on teams of its lanes -- codes segment k"}
     c4 = config_4_log()
     if c4:
-        out["one_stream"]["config_4_measured"] = c4
+        out["one_stream"]["config_4_shape_measured"] = c4
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _lzmah import oracle_lzma

@@ -947,6 +947,7 @@ __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int 
                                                        const uint16_t *__restrict__ heavy, uint32_t seg0) {
   __shared__ uint32_t list[2048];
   __shared__ uint32_t nlist;
+  __shared__ uint32_t lbits[1024];                   // the segment's share of dlim_bits (its 32 768 positions are its own 1 024 words), put together here
   const uint64_t seg = (uint64_t)blockIdx.x + seg0, base = seg * 32768ull;
   const int tid = threadIdx.x;
   const bool has_prev = !lay_first(L, seg);
@@ -954,8 +955,12 @@ __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int 
   // can have that many if the largest buckets of the two segments do not add up to it -- the usual case
   {
     const uint32_t mo = segmax[seg], mp = has_prev ? segmax[seg - 1] : 0u;
-    if (mo == 0 || mo - 1 + mp < (uint32_t)kquarter) return;
+    if (mo == 0 || mo - 1 + mp < (uint32_t)kquarter) return;          // (the segment's words of dlim_bits stay as the memset left them: no limits)
   }
+  for (int i = tid; i < 1024; i += 256) lbits[i] = 0;
+  // (plain stores at the end: the words are this workgroup's alone, and 50 M scattered global atomics -- every twentieth position of the benchmark
+  // stream has a limit -- cost the kernel 0.8 ms)
+  auto flush_bits = [&]() { __syncthreads(); for (int i = tid; i < 1024; i += 256) { const uint32_t w = lbits[i]; if (w) dlim_bits[(base >> 5) + i] = w; } };
   const uint32_t *own = bsc3 + base, *prv = has_prev ? bsc3 + base - 32768 : nullptr;
   const uint16_t *s3 = S3 + base, *p3 = has_prev ? S3 + base - 32768 : nullptr;
   auto qualifies = [&](uint32_t h) -> bool {
@@ -981,7 +986,7 @@ __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int 
           lim[t] = d < 0xFFFF ? (uint32_t)d : 0xFFFFu;
         }
         dlim[base + e] = lim[0] | (lim[1] << 16);
-        atomicOr(&dlim_bits[(base + e) >> 5], 1u << ((base + e) & 31u));
+        atomicOr(&lbits[e >> 5], 1u << (e & 31u));
       }
     }
   };
@@ -1006,6 +1011,7 @@ __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int 
       process();
       __syncthreads();
     }
+    flush_bits();
     return;
   }
   for (uint32_t h0 = 0; h0 < 32768; h0 += 2048) {        // rounds of 2048 buckets: the list cannot overflow
@@ -1018,6 +1024,7 @@ __global__ void __launch_bounds__(256) k_bucket_limits(Layout L, int kfull, int 
     process();
     __syncthreads();
   }
+  flush_bits();
 }
 
 // --------------------------------------------------------------------------------------------
