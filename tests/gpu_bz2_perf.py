@@ -7,7 +7,7 @@ from _common import product
 Z = product()
 enc = Z.Encoder(0)
 L = Z.load_library()
-for knob in ("bz_lists", "bz_pipeline", "bz_small_wg", "bz_batch_melems", "bz_tail_pct", "bz_split", "bz_list_rows", "bz_text_order"):
+for knob in ("bz_lists", "bz_pipeline", "bz_small_wg", "bz_batch_melems", "bz_tail_pct", "bz_split", "bz_list_rows", "bz_text_order", "bz_pipe_prio"):
     if os.environ.get(knob.upper()):
         enc.set_knob(knob, int(os.environ[knob.upper()]))
 for mib in [int(x) for x in os.environ.get("BZ_MIBS", "64,256").split(",")]:

@@ -1030,6 +1030,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "bz_tail_pct")) { if (value < 0 || value > 50) return ZADA_E_INVALID; z->c.knob_bz_tail_pct = value; }
   else if (!strcmp(name, "bz_text_order")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_text_order = value; }
   else if (!strcmp(name, "bz_pipeline")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_pipeline = value; }
+  else if (!strcmp(name, "bz_pipe_prio")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_pipe_prio = value; }
   else if (!strcmp(name, "bz_list_rows")) { if (value < 0 || value > 8192) return ZADA_E_INVALID; z->c.knob_bz_list_rows = value; }
   else if (!strcmp(name, "bz_split")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_split = value; }
   else if (!strcmp(name, "bz_small_wg")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_small_wg = value; }

@@ -2652,7 +2652,15 @@ static int bz_blocks_encode_once(Ctx *c, int option, const uint8_t *d_in, const 
   // Two batches in flight ("bz_pipeline", default on): the second one in a state of its own (B->slot1).
   if (pipelined) {
     if (!B->slot1) B->slot1 = new Bz2State();
-    if (!B->st_pipe) BZ_HIP(hipStreamCreateWithFlags(&B->st_pipe, hipStreamNonBlocking));
+    if (!B->st_pipe) {
+      // (round 5, knob "bz_pipe_prio": the kernel timeline (tests/prof_trace_bz2.sh) shows the next batch's transform kernels -- 1 024-thread
+      // workgroups -- waiting for the whole of the entropy search of the batch before, whose 512-thread workgroups hold every CU for tens of
+      // milliseconds: one launch of k_bz_filter_emit takes 78 ms beside a 79 ms k_bz_entropy.  With the worker's stream at the LOWEST priority a slot
+      // that comes free should go to the transforms first -- measured 467 / 460 ms against 453 without: no gain, the default stays 0)
+      int least = 0, greatest = 0;
+      BZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      BZ_HIP(hipStreamCreateWithPriority(&B->st_pipe, hipStreamNonBlocking, c->knob_bz_pipe_prio ? least : 0));
+    }
   }
   // (err: the worker's error text -- hip_check writes it there through tls_err while the main thread may be writing c->err -- is copied to
   // c->err by finish, on the main thread)
