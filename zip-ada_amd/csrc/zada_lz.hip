@@ -1985,8 +1985,10 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     // input that is still arriving (2 048 segments) goes as 256 workgroups of 8.  Knob "link_run" (0 = this rule).
     uint32_t R = 1;
     if (c->knob_link_run > 0) R = (uint32_t)c->knob_link_run;
-    else if (job.need) R = 8;
-    else while (R < 16 && nseg / (2 * R) >= 1024) R *= 2;
+    else {
+      while (R < 16 && nseg / (2 * R) >= 1024) R *= 2;
+      if (job.need && R > 8) R = 8;                                       // (a piece of 2 048 segments: one workgroup per CU)
+    }
     auto prev_links = [&](uint32_t s0, uint32_t s1) {                     // segments [s0, s1), s0 a multiple of R
       if (R > 1) hipLaunchKernelGGL(k_prev_links<true>, dim3((s1 - s0 + R - 1) / R), dim3(1024), PL_LDS_RUNS, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
                                     W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0, R, s1);
