@@ -185,3 +185,24 @@ def test_return_codes_of_the_header_and_of_the_python_mirror_agree():
     src = open(os.path.join(root, "zip-ada_amd", "__init__.py")).read()
     assert int(re.search(r"^E_REFERENCE\s*=\s*(-?\d+)", src, re.M).group(1)) == codes["ZADA_E_REFERENCE"] == -6
     assert "ZADA_E_REFERENCE" in open(os.path.join(root, "INTEGRATION.md")).read()
+
+
+def test_bench_reads_committed_records_and_carries_no_constants():
+    """every figure on the bench line that the run did not measure itself comes from a committed file under profiles/ and is
+    named with that file (and the commit it was taken at); config 4's shape is the record of the largest committed run on the round's corpus."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    c4 = b.config_4_log()
+    assert c4 is not None and c4["workload"].endswith(b.CORPUS_NAME) and c4["equals_cpu_port"] is True and c4["source"].startswith("profiles/")
+    assert c4["is_config_4_itself"] == ("1024 MiB" in c4["workload"])
+    t, src = b.pmc_traffic(1 << 30, "k_match")
+    assert isinstance(t, int) and t > (1 << 30) and src["file"].startswith("profiles/") and src["taken_at_commit"]
+    assert b.pmc_traffic(1 << 20, "k_match") == (None, None)                  # (only valid for the workload the passes were taken on)
+    pt = b.pipeline_traffic(1 << 30)
+    assert isinstance(pt, int) and pt > t
+    tr, tsrc = b.leg_traffic("k_bz_entropy")
+    assert tr > 0 and "profiles/" in tsrc and "commit" in tsrc
+    src_text = open(os.path.join(ROOT, "bench.py")).read()
+    assert "788.6" not in src_text and "1.362" not in src_text                 # (round 4's hard-coded config-4 result)

@@ -6,13 +6,14 @@
 //   k_prev_links     per 32 KiB segment, for the reference's 15-bit hash (UPDATE_HASH, :553-557) and for 16-bit
 //                    hashes of the first 4 .. 3+NLEVELS bytes: stable LDS radix sort of the positions; links to
 //                    the previous position of the same bucket (what INSERT_STRING's prev[] holds, :566-573),
-//                    nearest true 3 .. 2+NLEVELS byte match of every position, sorted orders, tail tables
-//   k_cross_links    links the first position of each bucket to the previous segment's tail
+//                    nearest true 3 .. 2+NLEVELS byte match of every position, sorted orders, tail tables.  From 64 MiB on
+//                    a workgroup takes a RUN of segments and makes the cross links of all but the run's first itself
+//   k_cross_links    links the first position of each bucket to the previous segment's tail (with runs: a run's first segment)
 //   k_cross_dist     continues the nearest-match searches that did not end inside their own segment
 //   k_bucket_limits  the chain-length limits (max_chain_length, and a quarter of it: :733-735) as distances
 //   k_match          Longest_Match (:715-825), BOUNDED, for every position; window + links staged in LDS;
 //                    full-chain and quarter-chain results, or a guess when the budget ran out
-//   k_parse_spec     lazy-evaluation parser (:827-933), one lane per 1 KiB chunk, speculatively
+//   k_parse_spec     lazy-evaluation parser (:827-933), one lane per 512-byte chunk, speculatively
 //                    started in the fresh state at each chunk boundary; marks the guesses it lands on
 //   k_parse_fix      re-parses from the previous chunk's true exit state until it meets a
 //                    history-free state of the speculative parse (splice); iterated to a fixpoint
