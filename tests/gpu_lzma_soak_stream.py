@@ -26,7 +26,8 @@ try:
         chunk = int(rng.choice([0, 0, 4096, 10000, 65536, 200000]))
         ds = int(rng.choice([0, 0, 0, 5000, 70000, 300000]))
         if ds >= n: ds = 0
-        enc.set_knob("lzma_segment", seg); enc.set_knob("lzma_chunk", chunk); enc.set_knob("lzma_dict", ds)
+        pool = int(rng.choice([0, 0, 0, 40, 300, 2000]))     # (round 5: a pool of the match sets' overflow blocks that has to grow between the segments, or to be run out of)
+        enc.set_knob("lzma_segment", seg); enc.set_knob("lzma_chunk", chunk); enc.set_knob("lzma_dict", ds); enc.set_knob("lzma_pool", pool)
         want, _ = oracle_lzma_encode(d, 3, dictionary_size=ds or None)
         try:
             rc, z, crc = enc.lzma(d, 18)
