@@ -206,3 +206,57 @@ def test_bench_reads_committed_records_and_carries_no_constants():
     assert tr > 0 and "profiles/" in tsrc and "commit" in tsrc
     src_text = open(os.path.join(ROOT, "bench.py")).read()
     assert "788.6" not in src_text and "1.362" not in src_text                 # (round 4's hard-coded config-4 result)
+
+
+def test_fused_cross_links_model():
+    """The scheme of k_prev_links' fused cross links (round 5) in numpy, against the plain definition "distance to the nearest earlier
+    position with the same key, if within MAX_DIST": per segment the links inside the segment from a stable sort; a bucket's first member carries
+    its KEY in the link array, a bit map says which entries are keys; the previous segment's tails table is consulted in two rounds, round r taking
+    the keys with bit 15 = r -- a head linked in round 0 holds a distance <= MAX_DIST < 2^15 (or 0) and is never mistaken for a key of round 1."""
+    MAX_DIST, SEG = 32506, 32768
+    rng = np.random.default_rng(9)
+    for trial in range(6):
+        nkeys = [40, 3000, 65536, 65536, 20000, 7][trial]
+        keys = rng.integers(0, nkeys, 3 * SEG).astype(np.int64)
+        if trial >= 2:
+            keys = (keys * 40503 + 12345) % 65536                  # spread over all 16 bits, bit 15 included
+        n = len(keys)
+        # the plain definition
+        want = np.zeros(n, np.int64)
+        last = {}
+        for p in range(n):
+            q = last.get(int(keys[p]))
+            if q is not None and p - q <= MAX_DIST:
+                want[p] = p - q
+            last[int(keys[p])] = p
+        prev_tails = None
+        for s in range(3):
+            k = keys[s * SEG:(s + 1) * SEG]
+            order = np.argsort(k, kind="stable")                    # the segment's sorted order: (key, position)
+            P = np.zeros(SEG, np.int64)
+            head = np.zeros(SEG, bool)
+            ks, es = k[order], order
+            first = np.ones(SEG, bool); first[1:] = ks[1:] != ks[:-1]
+            lastm = np.ones(SEG, bool); lastm[:-1] = ks[1:] != ks[:-1]
+            P[es[~first]] = (es[1:] - es[:-1])[~first[1:]]          # links inside the segment
+            P[es[first]] = ks[first]; head[es[first]] = True        # heads: the key in the link's place
+            tails = np.full(65536, 0xFFFF, np.int64); tails[ks[lastm]] = es[lastm]
+            if prev_tails is None:
+                P[head] = 0                                         # (a stream's first segment: nothing before it)
+            else:
+                for r in (0, 1):
+                    for e in np.nonzero(head)[0]:
+                        v = P[e]
+                        if (v >> 15) != r:
+                            continue                                # a key of the other round -- or, in round 1, a head that round 0 has linked
+                        if r == 1:
+                            assert v >= 32768
+                        t = prev_tails[v]
+                        d = e + SEG - t
+                        P[e] = d if (t != 0xFFFF and d <= MAX_DIST) else 0
+                        assert P[e] < 32768
+            got = P.copy()
+            got[got > MAX_DIST] = 0                                 # (inside a segment a link is at most 32 767; the match kernels bound it)
+            w = want[s * SEG:(s + 1) * SEG]
+            assert np.array_equal(got, w), (trial, s, int(np.argmax(got != w)))
+            prev_tails = tails
