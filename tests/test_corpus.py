@@ -75,3 +75,24 @@ def test_class_shares_of_v2_follow_the_recipe():
 
 V1_FIRST_MIB = "3a9a10298dcc1e56b911223de7f4c69590bc5618a18d736e2ccfa784f010eb86"
 V1_TEXT_SLICE = "85852e8660c00f455134909e597f7091505cb744b601c5b26c922e3e7af42296"
+
+
+def test_oracles_round_trip_on_the_benchmark_stream():
+    """The three CPU oracles on silesia_mix_v2 itself (their golden digests were taken on v1 inputs): every stream goes back to its input through an
+    independent decoder -- zlib (raw inflate), libbz2, liblzma -- and the BZip2 oracle keeps more than one splitting tactic on it."""
+    import bz2
+    import lzma as _lzma
+    import zlib as _zlib
+    from _common import oracle_deflate
+    from _bzip2 import oracle_encode
+    from _lzmah import oracle_lzma, lzma_decode
+    d = silesia_mix((1 << 20) + 4321, offset=65536 * 5 - 1000, version=2)
+    for method in (10, 8):
+        rc, z, crc = oracle_deflate(d, method)
+        assert rc == 0 and _zlib.decompress(z, -15) == d and crc ^ 0xFFFFFFFF == _zlib.crc32(d)
+    z, blocks = oracle_encode(d[:1 << 20], 2)
+    assert bz2.decompress(z) == d[:1 << 20] and len(blocks) >= 1
+    small = d[:300000]
+    for method in (15, 16, 17, 18):
+        rc, z, crc = oracle_lzma(small, method)
+        assert rc == 0 and lzma_decode(z, 4) == small and crc ^ 0xFFFFFFFF == _zlib.crc32(small)
