@@ -443,9 +443,9 @@ def bzip2_main(args, za, sharding, enc, torch, dist, rank, world, dev, emulate):
             if emulate:
                 torch.cuda.synchronize()
                 payload = payload.cpu()
-            got = sharding.gather_payloads(payload, res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
+            got = sharding.gather_stream(payload, res["spans"], res["total_bits"], dst=0)     # every range straight to its byte offset on rank 0
             if got is not None:
-                state["stream"] = sharding.stitch_stream(torch, got[0], res["spans"], res["total_bits"], dev)
+                state["stream"] = got
         else:
             state["stream"] = res["payload"][:res["nbytes"]]
         state["res"] = res
@@ -632,10 +632,9 @@ def main():
                 return
             h, res = p
             tg = time.perf_counter()
-            got = h.finish()
-            if got is not None:                       # rank 0: OR the ranges' bytes into one stream
-                payloads, _ = got
-                state["stream"] = sharding.stitch_stream(torch, payloads, res["spans"], res["total_bits"], dev)
+            got = h.finish() if h is not None else None
+            if got is not None:                       # rank 0: the stream, every range received at its byte offset, shared edge bytes OR-ed
+                state["stream"] = got
             state["pending"] = None
             xt["gather_stitch"] = xt.get("gather_stitch", 0.0) + time.perf_counter() - tg
 
@@ -650,7 +649,7 @@ def main():
             # the payload of this step travels to rank 0 while the next step is compressed
             for k, v in res.get("exchange_s", {}).items():
                 xt[k] = xt.get(k, 0.0) + v
-            h = sharding.gather_payloads_begin(payload, res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
+            h = None if res["inefficient"] else sharding.gather_stream_begin(payload, res["spans"], res["total_bits"], dst=0)
             finish_pending()
             state["pending"] = (h, res)
             last.update(rc=1 if res["inefficient"] else 0, out_len=(res["total_bits"] + 7) // 8,
@@ -694,7 +693,7 @@ def main():
                                               "max": round(max(e["exchange_s"].get(k, 0.0) for e in every) * 1e3 / args.steps, 3)} for k in keys},
                  "exchange_note": "wall clock a rank spends inside each exchange step of sharding.deflate_stream_rank (waiting for its neighbours included): "
                                   "all_gather_state = parser states and atom counts, one 64-byte-per-rank tensor all_gather (a), boundary_atoms = edge atoms by all_gather (c), carry_chain = the 352-byte chooser state "
-                                  "from rank to rank, its receive posted before the range's analysis (d), spans = bit positions, one 24-byte-per-rank tensor all_gather (d), gather_stitch = payloads to rank 0 and the OR (e)"}
+                                  "from rank to rank, its receive posted before the range's analysis (d), spans = bit positions, one 24-byte-per-rank tensor all_gather (d), gather_stitch = payloads to rank 0, each received at its byte offset in the stream, shared edge bytes OR-ed (e)"}
 
     if rank == 0:
         rc, out_len, crc = last["rc"], last["out_len"], last["crc"]

@@ -212,9 +212,8 @@ def _stream_worker(rank, world, port, q, n, method, lie):
     res = sharding.deflate_stream_rank(enc, comm, torch, n, ranges, 0, method,
                                        lambda k: torch.zeros(k, dtype=torch.int32), lambda k: torch.zeros(k, dtype=torch.uint8))
     payload = res["payload"] if res["payload"] is not None else torch.zeros(1, dtype=torch.uint8)
-    got = sharding.gather_payloads(payload, res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
+    out = sharding.gather_stream(payload, res["spans"], res["total_bits"], dst=0)
     if rank == 0:
-        out = sharding.stitch_stream(torch, got[0], res["spans"], res["total_bits"], torch.device("cpu"))
         lib = za.load_library()
         crc = sharding.stream_crc(lib.zada_crc32_combine, res["infos"])
         q.put((bytes(out.numpy()), crc, [i["atoms"] for i in res["infos"] if i is not None]))
@@ -396,11 +395,10 @@ def _bz_stream_worker(rank, world, port, q, n, method):
     comm = sharding.TorchComm(torch.device("cpu"))
     res = sharding.bzip2_stream_rank(enc, comm, n, ranges, 0, method, lambda k: torch.zeros(k, dtype=torch.uint8))
     payload = res["payload"] if res["payload"] is not None else torch.zeros(1, dtype=torch.uint8)
-    got = sharding.gather_payloads(payload, res["nbytes"], torch.zeros(1, dtype=torch.int64), dst=0)
+    out = sharding.gather_stream(payload, res["spans"], res["total_bits"], dst=0)
     blocks = [None] * world
     dist.all_gather_object(blocks, res["blocks"])
     if rank == 0:
-        out = sharding.stitch_stream(torch, got[0], res["spans"], res["total_bits"], torch.device("cpu"))
         q.put((bytes(out.numpy()), [b for bl in blocks for b in bl], len(ranges), enc.ref, enc.trace))
     dist.barrier()
     dist.destroy_process_group()
@@ -424,3 +422,55 @@ def test_one_bzip2_stream_over_two_and_three_ranks_protocol():
         assert nr == (world if method == 12 else 1)
         assert out == ref and blocks == trace, (world, n, method)
         assert bz2.decompress(out) == bytes(silesia_mix(n))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# gather_stream_begin: every range received at its byte offset, shared edge bytes OR-ed
+# ----------------------------------------------------------------------------------------------------------------------
+def _gather_worker(rank, world, port, q, spans, seed):
+    sys.path.insert(0, ROOT)
+    import importlib
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding = importlib.import_module("zip-ada_amd.sharding")
+    total_bits = max(s[1] for s in spans if s is not None)
+    bits = np.random.RandomState(seed).randint(0, 2, total_bits).astype(np.uint8)
+    sp = spans[rank] if rank < len(spans) else None
+    payload = torch.zeros(1, dtype=torch.uint8)
+    if sp is not None:
+        own = np.zeros((total_bits + 7) // 8 * 8, np.uint8)
+        own[sp[0]:sp[1]] = bits[sp[0]:sp[1]]                        # this range's bits only, at their place in the stream
+        by = np.packbits(own, bitorder="little")
+        off, ln = sp[0] // 8, max(0, (sp[1] + 7) // 8 - sp[0] // 8)
+        payload = torch.from_numpy(np.concatenate([by[off:off + ln], np.full(5, 0xAA, np.uint8)]))   # bytes behind ln are not the range's
+    h = sharding.gather_stream_begin(payload, spans, total_bits, dst=0)
+    out = h.finish()
+    if rank == 0:
+        full = np.zeros((total_bits + 7) // 8 * 8, np.uint8)
+        full[:total_bits] = bits
+        q.put(bytes(out.numpy()) == bytes(np.packbits(full, bitorder="little")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("spans", [
+    [(0, 100003), (100003, 250001), (250001, 250002), (250002, 250009), (250009, 400000)],      # ranges of 1 and 7 bits inside one byte shared by three
+    [(0, 64), (64, 72), (72, 80), (80, 1000)],                                                  # byte-aligned joints, one-byte ranges
+    [(0, 5), (5, 11), None, None],                                                               # tiny stream, two ranks without a range
+    [(0, 3 * 8 * 1000 + 1), (3 * 8 * 1000 + 1, 3 * 8 * 1000 + 17), (3 * 8 * 1000 + 17, 50000)],  # a range of exactly two (shared) bytes
+])
+def test_stream_gather_puts_every_range_at_its_offset(spans):
+    world = len(spans)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() + world * 13 + spans[0][1]) % 2000
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q, spans, 5)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok

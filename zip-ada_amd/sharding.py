@@ -80,6 +80,109 @@ def gather_payloads(payload, length, meta, dst=0, group=None):
     return gather_payloads_begin(payload, length, meta, dst=dst, group=group).finish()
 
 
+class PendingStream:
+    """A gather of the ranges' bytes of ONE stream in flight (gather_stream_begin).  finish() waits for it and returns, on dst, the
+    stream as a 1-D uint8 tensor of ceil(total_bits / 8) bytes; None elsewhere.  The payload handed to gather_stream_begin must not be
+    overwritten before finish()."""
+
+    def __init__(self, works, out, edges, layout, keep):
+        self.works, self.out, self.edges, self.layout, self.keep = works, out, edges, layout, keep
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        if self.works and self.keep is not None and self.keep.is_cuda:
+            # NCCL's wait() only orders the current stream behind the transfer; the caller is about to reuse the payload from another stream
+            torch.cuda.current_stream(self.keep.device).synchronize()
+        self.works = []
+        if self.out is None:
+            return None
+        if self.edges is not None:
+            # the only bytes two ranges can share are a range's first and last: OR them together on the host (2 bytes per range) and
+            # write them with one indexed store; every other byte of the stream was received (or copied) straight into its place
+            e = torch.stack(self.edges).cpu().tolist()
+            merged = {}
+            for (off, ln), (first, last) in zip(self.layout, (x[:2] for x in e)):
+                if ln >= 1:
+                    merged[off] = merged.get(off, 0) | first
+                if ln >= 2:
+                    merged[off + ln - 1] = merged.get(off + ln - 1, 0) | last
+            if merged:
+                idx = torch.tensor(sorted(merged), dtype=torch.int64, device=self.out.device)
+                val = torch.tensor([merged[k] for k in sorted(merged)], dtype=torch.uint8, device=self.out.device)
+                self.out[idx] = val
+            self.edges = None
+        return self.out
+
+
+def stream_layout(spans, world):
+    """Byte offset and byte count of every rank's payload inside the stream, from the bit spans every rank knows: [(off, ln), ...]
+    ((0, 0) for a rank without a range)."""
+    out = []
+    for k in range(world):
+        sp = spans[k] if k < len(spans) else None
+        if sp is None:
+            out.append((0, 0))
+        else:
+            b0, b1 = sp
+            out.append((b0 // 8, max(0, (b1 + 7) // 8 - b0 // 8)))
+    return out
+
+
+def gather_stream_begin(payload, spans, total_bits, dst=0, group=None):
+    """Starts gathering the ranges' bytes of ONE stream onto `dst`, every range straight into its place ("Gather-v of
+    bit-strings to rank 0 ... then a shift-merge"; here the ranges are emitted at their final bit phase, so there is nothing to shift):
+
+      * every rank knows every range's bit span (the `spans` all_gather of deflate_stream_rank / the replayed choice of bzip2_stream_rank),
+        hence every payload's byte offset and length: no length exchange, no padding to the longest payload;
+      * `dst` allocates the stream ONCE and posts one receive per peer for the peer's INTERIOR bytes (all but its first and last byte),
+        directly at stream[off + 1 : off + ln - 1] -- a byte strictly inside a range's span holds that range's bits only;
+      * the first and last byte of a range may be shared with its neighbours: they travel as one small fixed-size gather (8 bytes per
+        rank) and are OR-ed together on the host in finish() -- at most 2 x world bytes.
+
+    payload : this rank's 1-D uint8 tensor, valid in [0, ln) with (off, ln) = stream_layout(spans)[rank]; bits outside its span zero.
+    Peak memory on dst: the stream plus its own payload (the padded gather held world x longest + the stream)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+
+    def g(k):
+        return k if group is None else dist.get_global_rank(group, k)
+    layout = stream_layout(spans, world)
+    off, ln = layout[rank]
+    dev = payload.device
+    edge = torch.zeros(8, dtype=torch.uint8, device=dev)
+    if ln >= 1:
+        edge[0] = payload[0]
+        edge[1] = payload[ln - 1]
+    works = []
+    if rank == dst:
+        out = torch.empty((total_bits + 7) // 8, dtype=torch.uint8, device=dev)
+        edges = [torch.empty(8, dtype=torch.uint8, device=dev) for _ in range(world)]
+        works.append(dist.gather(edge, edges, dst=g(dst), group=group, async_op=True))
+        ops = []
+        for k in range(world):
+            ko, kl = layout[k]
+            if kl <= 2:
+                continue
+            if k == rank:
+                out[ko + 1:ko + kl - 1].copy_(payload[1:kl - 1])
+            else:
+                ops.append(dist.P2POp(dist.irecv, out[ko + 1:ko + kl - 1], g(k), group))
+        if ops:
+            works.extend(dist.batch_isend_irecv(ops))
+        return PendingStream(works, out, edges, layout, payload)
+    works.append(dist.gather(edge, None, dst=g(dst), group=group, async_op=True))
+    if ln > 2:
+        body = payload[1:ln - 1]
+        works.extend(dist.batch_isend_irecv([dist.P2POp(dist.isend, body, g(dst), group)]))
+    return PendingStream(works, None, None, layout, payload)
+
+
+def gather_stream(payload, spans, total_bits, dst=0, group=None):
+    """gather_stream_begin(...).finish(): the blocking form."""
+    return gather_stream_begin(payload, spans, total_bits, dst=dst, group=group).finish()
+
+
 # ======================================================================================================================
 # ONE stream over several GPUs (SURVEY.md 8e, primary mode): the stream is cut into ranges at multiples of 64 KiB, rank r
 # compresses range r with the zada_range_* calls of libzada_hip.so and the ranks exchange exactly the state the
@@ -93,7 +196,8 @@ def gather_payloads(payload, length, meta, dst=0, group=None):
 #                                             rank): a range completes its last flush with its successors' atoms and
 #                                             reads 2 048 atoms back into its predecessors' (:1338-1360, 1372)
 #   d. Send_as_block's state                  352 bytes handed from rank to rank (send / recv), the one sequential step
-#   e. payloads                               gathered onto rank 0 (gather_payloads), OR-ed together at the shared bytes
+#   e. payloads                               received by rank 0 straight at their byte offsets in the stream (gather_stream_begin); only a
+#                                             range's first and last byte can be shared with a neighbour: those are OR-ed (2 bytes per rank)
 #
 # With torch.distributed's "nccl" backend these are RCCL collectives over xGMI; TorchComm runs the same code on "gloo"
 # (CPU tests), ThreadComm inside one process (several contexts on one GPU: tests/test_ranges.py).
@@ -204,9 +308,8 @@ class TorchComm:
             return bytes(t.cpu().numpy())
         return wait
 
-    def gather_payload(self, payload, length, dst=0):
-        res = gather_payloads(payload, length, torch.zeros(1, dtype=torch.int64), dst=dst, group=self.group)
-        return None if res is None else res[0]
+    def gather_stream(self, payload, spans, total_bits, dst=0):
+        return gather_stream(payload, spans, total_bits, dst=dst, group=self.group)
 
 
 def _gather_i64(comm, values):
@@ -342,7 +445,8 @@ def deflate_stream_rank(enc, comm, tensors, stream_size, ranges, d_in_ptr, metho
 
 
 def stitch_stream(tensors, payloads, spans, total_bits, device):
-    """Rank 0: the ranges' bytes OR-ed into one stream (a byte shared by two ranges holds bits of both)."""
+    """The ranges' bytes OR-ed into one stream (a byte shared by two ranges holds bits of both) -- for payloads that are already in one
+    process (several contexts on one GPU: tests/test_ranges.py).  Between ranks gather_stream_begin puts every range in its place."""
     out = tensors.zeros((total_bits + 7) // 8, dtype=tensors.uint8, device=device)
     for p, span in zip(payloads, spans):
         if span is None or p is None:
