@@ -80,7 +80,7 @@ const char *zada_version(void);
  * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of
  * a stream the match finder takes at a time, multiple of 64), "span_mib" (MiB of a stream one pass takes; longer streams go span after
  * span, default 2048), "link_run" (segments of 32 KiB one workgroup of the link stage takes one after the other, making their cross links itself:
- * 1 .. 64, 0 = by size), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
+ * a power of two from 1 to 64, 0 = by size; anything else is ZADA_E_INVALID), "batch_mib" (MiB one batch of small entries may take), "bz_batch_mib" / "bz_span_mib" / "bz_batch_melems" (BZip2
  * batching; "bz_lists", "bz_list_rows", "bz_text_order", "bz_pipeline", "bz_pipe_prio", "bz_small_wg", "bz_split", "bz_tail_pct": scheduling of the BZip2 stages), "lzma_chunk" (positions of an LZMA stream one launch codes between two feedback calls; 0 = by level, -1 = one launch
  * per stream), "lzma_pool" (test knob: blocks of the LZMA_3 match sets' overflow pool to start with, 0 = by size; a pool that is too small is
  * counted and the match producer's walk runs again; for a stream whose producer works in segments the pool grows between the segments), "lzma_pool_fixed" (test knob: 1 = it

@@ -27,7 +27,9 @@ while time.time() - t0 < budget:
     method = int(rng.choice([10, 10, 9, 8, 7]))
     run = int(rng.choice([0, 1, 2, 4, 8, 16, 32]))
     shard = int(rng.choice([1 << 20, 1 << 20, 512, 1024, 4096]))
-    enc.set_knob("link_run", run); enc.set_knob("shard_kib", shard)
+    budget_k = int(rng.choice([-1, -1, 1, 2, 3, 8]))              # round 6: small first-pass budgets (many guesses, many demand rounds) and both ways of parsing the flagged chunks again
+    exact = int(rng.choice([32768, 32768, 1 << 30, 64, 0]))   # (lists up to this many chunks: one wave per chunk with the exact search inside)
+    enc.set_knob("link_run", run); enc.set_knob("shard_kib", shard); enc.set_knob("budget", budget_k); enc.set_knob("exact_respec", exact)
     rc, ref, crc = oracle_deflate(d, method)
     try:
         out, crc2 = enc.deflate(d, method); rc2 = 0
@@ -37,6 +39,6 @@ while time.time() - t0 < budget:
     cases += 1
     if not ok:
         bad += 1
-        print("MISMATCH seed %d case %d: n %d method %d link_run %d shard_kib %d" % (seed, cases, n, method, run, shard), flush=True)
+        print("MISMATCH seed %d case %d: n %d method %d link_run %d shard_kib %d budget %d exact_respec %d" % (seed, cases, n, method, run, shard, budget_k, exact), flush=True)
 print("link-run soak seed %d: %d cases in %.0f s, %d mismatches" % (seed, cases, time.time() - t0, bad), flush=True)
 sys.exit(1 if bad else 0)

@@ -155,6 +155,10 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   // by the demand pass), the 15-bit hash's sorted order, tags and bucket records (k_cross_dist, k_bucket_limits) -- is dead when the first parse starts,
   // and the speculative tokens are born there and dead again when the shard's tokens have been compacted: the two share ONE block (11 against 9 bytes
   // per input byte).  The tables' readers take whatever the block holds (uninitialised tables are checked entry by entry, the others are written whole).
+  // (Who may touch the link tables: k_prev_links, k_cross_links, k_cross_dist, k_bucket_limits -- everything in front of tmark("cross_links") in lz_shard.
+  // From k_match on the block holds speculative tokens; deflate_spans also uses it as scratch between spans.  With one hashed level ltails[0] would be
+  // the table k_match_demand reads: the aliasing needs two.)
+  static_assert(NLEVELS >= 2, "spec_tok shares the block of ltails[0], S3, T3, bsc3: the first level's tails table must be dead when the first parse starts");
   {
     const uint64_t b_tails0 = nseg32 * 65536 * 2, b_s3 = nseg32 * 32768 * 2, b_t3 = nseg32 * 32768, b_bsc = nseg32 * 32768 * 4, b_spec = nch * (uint64_t)PTOK_STRIDE * 4;
     const uint64_t links = b_tails0 + b_s3 + b_t3 + b_bsc + 1024, bytes = links > b_spec ? links : b_spec;
@@ -1005,6 +1009,7 @@ zada_ctx *zada_create(int device) {
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
   if (const char *e = getenv("ZADA_INNER_BUDGET")) z->c.knob_inner_budget = atoi(e);
   if (const char *e = getenv("ZADA_LINK_RUN")) { const int v = atoi(e); if (v >= 0 && v <= 64 && !(v & (v - 1))) z->c.knob_link_run = v; }
+  if (const char *e = getenv("ZADA_EXACT_RESPEC")) { if (atoi(e) >= 0) z->c.knob_exact_respec = atoi(e); }
   if (const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS")) { if (atoi(e) > 0) z->c.knob_max_demand_rounds = atoi(e); }
   if (const char *e = getenv("ZADA_SHARD_KIB")) { if (atoi(e) >= 64 && atoi(e) % 64 == 0) z->c.knob_shard_kib = atoi(e); }
   return z;
@@ -1036,6 +1041,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "bz_small_wg")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_small_wg = value; }
   else if (!strcmp(name, "bz_lists")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_bz_lists = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
+  else if (!strcmp(name, "exact_respec")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_exact_respec = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }
   else if (!strcmp(name, "lzma_dict")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_lzma_dict = value; }

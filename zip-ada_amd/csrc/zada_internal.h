@@ -276,6 +276,7 @@ struct Ctx {
   // zada_set_knob)
   int knob_budget = -1;             // ZADA_BUDGET: rounds of chain steps per position in the first match pass (0 = unbounded, -1 = default)
   int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
+  int knob_exact_respec = 32768;    // "exact_respec" / ZADA_EXACT_RESPEC: lists of up to this many flagged chunks are parsed again by one wave per chunk with the exact search inside the parse (0: never -- the lane-per-chunk parse with guesses in every round, as in rounds 1-5)
   int knob_bz_pipe_prio = 0;        // "bz_pipe_prio": 1 = the worker stream of the BZip2 pipeline (entropy stage of the batch before) has the lowest priority (measured: no gain)
   int knob_link_run = 0;            // ZADA_LINK_RUN: segments per workgroup of k_prev_links (0 = by size: lz_shard)
   int knob_inner_budget = 0;        // ZADA_INNER_BUDGET: rounds for positions deep inside a match (0 = as every other position; A/B: 1 round saves 4.7 ms in k_match and costs 8.9 ms of demand searches, 2 rounds: -3.2 / +3.7)

@@ -30,6 +30,7 @@
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace zada {
 
@@ -100,6 +101,15 @@ __device__ __forceinline__ uint64_t lds_u64_at(const uint8_t *b, uint32_t o) {
   const uint32_t *w = (const uint32_t *)(b + (o & ~3u));
   const uint32_t x = w[0], y = w[1], z = w[2], s = o & 3u;
   return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
+}
+
+// Four bytes at byte offset t of an LDS array whose last aligned word starts at t & ~3 (t <= size - 4): the second word is only read when
+// the offset is not aligned, so that t = size - 4 does not touch the word behind the array (the staged 32 KiB end where the
+// kernels' LDS allocation ends).
+__device__ __forceinline__ uint32_t lds_u32_tail(const uint8_t *b, uint32_t t) {
+  const uint32_t *wp = (const uint32_t *)(b + (t & ~3u));
+  const uint32_t sh = t & 3u;
+  return __builtin_amdgcn_alignbyte(wp[sh ? 1 : 0], wp[0], sh);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -540,8 +550,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
           const uint32_t t = q + 32768u - step, d = e + 32768u - t;
           if (d > (uint32_t)MAX_DIST) return 0u;
           if (t <= 32768u - 4u) {
-            const uint32_t *wp = (const uint32_t *)(pbL + (t & ~3u));
-            const uint32_t theirs = __builtin_amdgcn_alignbyte(wp[1], wp[0], t & 3u);   // (t <= 32764: both words inside the staged bytes)
+            const uint32_t theirs = lds_u32_tail(pbL, t);                               // (t <= 32764: nothing behind the staged bytes is read)
             if (theirs == (uint32_t)lb8(e)) return d;
           }
         }
@@ -606,8 +615,7 @@ __global__ void __launch_bounds__(1024) k_prev_links(const uint8_t *__restrict__
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const uint32_t t = st[j] > ee[j] ? ee[j] + 32768u - st[j] : 0u, tr = t <= 32768u - 4u ? t : 0u;
-            const uint32_t *wp = (const uint32_t *)(pbL + (tr & ~3u));
-            pw[j] = __builtin_amdgcn_alignbyte(wp[1], wp[0], tr & 3u);
+            pw[j] = lds_u32_tail(pbL, tr);
           }
         }
 #pragma unroll
@@ -814,8 +822,7 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
         // members of the bucket are farther still); a true match -> settled; a hash collision -> left to k_cross_dist
         if (!reach) plane[e] = 0;
         else if (t <= 32768u - 4u) {
-          const uint32_t *wp = (const uint32_t *)(pb + (t & ~3u));
-          const uint32_t theirs = __builtin_amdgcn_alignbyte(wp[1], wp[0], t & 3u);   // (t <= 32764: both words inside the staged bytes)
+          const uint32_t theirs = lds_u32_tail(pb, t);                                // (t <= 32764: nothing behind the staged bytes is read)
           if (((theirs ^ (uint32_t)v[k]) & cmask) == 0) plane[e] = (uint16_t)d;
         }
       }
@@ -830,6 +837,10 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
 #define ZADA_CD_THREADS 64
 #endif
 constexpr int CD_THREADS = ZADA_CD_THREADS;
+// (Round 6, measured and dropped: the level-3 look-up and the level-4 walk of a position as two state machines side by side in the lane, their loads
+// issued together in every turn, a batch's eight sorted-order entries fetched with its tags -- three round trips instead of four for the look-up,
+// the longer of the two chains instead of their sum.  Bit-exact, and SLOWER: 16.0 against 12.7 ms for the phase at 1 GiB.  The kernel moves 64-byte
+// sectors for two to eight useful bytes at 3.4 TB/s; what the entries' 16 bytes per batch add in sectors costs more than the shorter chain saves.)
 __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv,
                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
                                                     DistPlanes dp, uint64_t p0, uint64_t p1) {
@@ -1624,6 +1635,10 @@ struct DemandMarker {
 // The parser's look-ups walk forward through the 8-byte match records, landing on every third or so: fetching each
 // record on its own pulls the same 64-byte line from HBM several times (PMC: 27 GB per parse of 1 GiB, three times
 // the table).  Each lane keeps the line of its last look-up in LDS (lane-interleaved, so lanes never share a bank).
+// (Round 6, measured and dropped: the refills as WAVE-WIDE events -- every lane looks at the top of a turn of the parser's loop whether the turn's record is in
+// its window of one / two / four lines, and if any lane's is not, all lanes that have left their window's first line fetch a new one together: one latency
+// for the wave instead of one per lane and crossing.  The parse phase at 1 GiB: 28.1 / 29.9 / 30.1 ms against 27.6 -- the turns are not waiting for the
+// refills' memory latency as much as for their own chain of LDS reads and branches, and the larger windows cost waves per CU.)
 #ifndef ZADA_PS_BWORDS
 #define ZADA_PS_BWORDS 16
 #endif
@@ -1712,10 +1727,12 @@ __global__ void __launch_bounds__(1024) k_list_flagged(const uint8_t *__restrict
 
 __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict__ spec_tok, uint32_t *__restrict__ spec_cnt,
                              uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits,
-                             DemandMarker dm, const uint32_t *__restrict__ list /* null: every chunk */, const uint32_t *__restrict__ list_n) {
+                             DemandMarker dm, const uint32_t *__restrict__ list /* null: every chunk */, const uint32_t *__restrict__ list_n,
+                             uint32_t exact_max /* lists of up to this many chunks are left to k_parse_spec_exact */) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (list) {                                         // the flagged chunks only (the grid is sized for all of them; what lies beyond the list ends here)
-    if (k >= *list_n) return;
+    const uint32_t nl = *list_n;
+    if (nl <= exact_max || k >= nl) return;
     k = list[k];
   }
   if (k >= nchunks) return;
@@ -1732,6 +1749,174 @@ __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict_
   ntok = ts.n;
   spec_cnt[k] = ntok;
   exits[k] = ex;
+}
+
+// --------------------------------------------------------------------------------------------
+// Round 6: the speculative parse of the chunks a demand pass has flagged, with the EXACT search inside the parse.
+// One wave per flagged chunk.  All 64 lanes run the chunk's parse in step with each other (one state, uniform control flow); where the
+// parse lands on a guess the wave searches that position to the end there and then -- the demand pass's scan (64 candidates of the
+// bucket's run in the sorted order per batch, four filter bytes, whole-wave compares, the quarter-chain snapshot where the batch
+// crosses the quarter distance), resumed where k_match stopped, with the candidates' bytes read from memory instead of a staged
+// window -- writes the exact record and parses on with it.  Such a parse has used exact values only: the chunk is never flagged again,
+// and the rounds "parse the flagged chunks with guesses, search the guesses they landed on, flag, parse again" (four of them on the
+// benchmark stream, each a handful of launches that last as long as one lane's parse whatever the number of chunks) become one launch.
+// The chunk's match records are fetched into LDS by the whole wave first (the parse is a chain of dependent look-ups).
+// --------------------------------------------------------------------------------------------
+struct WaveExact {
+  const uint8_t *in; Layout L; DistPlanes dp; RunPtrs rp; const uint16_t *tailsK; MatchPair *M; int nice_cfg; const uint16_t *resume;
+  __device__ __forceinline__ uint32_t g32(uint64_t o) const { return *(const u32u *)(in + o); }
+  // Longest_Match of position p over the full chain and its quarter-chain snapshot, started from the guess `og` (wave uniform)
+  __device__ MatchPair search(uint64_t p, MatchPair og) const {
+    const int lane = threadIdx.x & 63;
+    const uint64_t seg = p >> 15, n = lay_end(L, seg);
+    const bool seg_first = lay_first(L, seg), prev_first = seg > 0 && lay_first(L, seg - 1);
+    const uint64_t rem = n - p;
+    const int la = rem < 258 ? (int)rem : 258;                   // Longest_Match never returns more
+    const int nice = nice_cfg < la ? nice_cfg : la;              // lz77.adb:858-860
+    const uint64_t pbase = (seg << 15) - 32768;
+    const uint32_t dlimv = dp.limits(p);
+    uint32_t dl[NLEVELS];
+#pragma unroll
+    for (int l = 0; l < NLEVELS; l++) dl[l] = dp.d[l][p];
+    const uint32_t idx1 = rp.idx[p], c1 = rp.cnt[p];
+    uint32_t t = 0xFFFFu;
+    if (!seg_first) {
+      // (only the occupied buckets of a tails table are written: an entry is the bucket's tail iff it names an inserted position of
+      // the previous segment that hashes to the bucket -- see k_cross_links; a tail out of reach leaves nothing to scan there)
+      const uint32_t key = hashL_of(*(const u64u *)(in + p), 3 + NLEVELS);
+      const uint32_t tt = tailsK[(seg - 1) * 65536ull + key];
+      const uint64_t q = pbase + tt;
+      if (tt < lay_inserted(L, seg - 1) && p - q <= (uint64_t)MAX_DIST && hashL_of(*(const u64u *)(in + q), 3 + NLEVELS) == key) t = tt;
+    }
+    uint32_t idx2 = 0, c2 = 0;
+    if (t != 0xFFFFu) { idx2 = rp.idx[pbase + t]; c2 = (uint32_t)rp.cnt[pbase + t] + 1u; }
+    const uint32_t df = dlimv & 0xFFFF, dq = dlimv >> 16;
+    const uint32_t LF = dl[0] == (uint32_t)MAX_DIST ? (uint32_t)MAX_DIST : (df < (uint32_t)(MAX_DIST - 1) ? df : (uint32_t)(MAX_DIST - 1));   // :850 / :820-822
+    const uint32_t LQ = dq < LF ? dq : LF;                                                                                                       // :733-735
+    int bst = 2;
+    uint32_t bd = 0, rqq = 0;
+    bool chain_ok = true;
+#pragma unroll
+    for (int l = 0; l < NLEVELS; l++) {                            // (levels on their own: see k_match)
+      const bool v = la >= 3 + l && dl[l] != 0 && dl[l] <= LF;
+      if (v) { bst = 3 + l; bd = dl[l]; if (dl[l] <= LQ) rqq = ((uint32_t)(3 + l) << 16) | dl[l]; }
+      chain_ok = v;
+    }
+    bool hq = chain_ok && bd > LQ;
+    // The search was begun by k_match: its best so far is the guess, and `resume` the candidate it had come to.
+    // The candidates before that one (nearer) are dropped from the two runs.
+    uint32_t i1 = idx1, n1 = c1, i2 = idx2, n2 = c2;
+    if (chain_ok) {
+      const uint32_t gl = (og.full & M_VALUE) >> 16;
+      if (gl >= 3) { bst = (int)gl; bd = og.full & 0xFFFFu; }
+      hq = (og.full & M_HAVEQ) != 0;
+      if (hq) rqq = og.quarter;
+      const uint64_t q = p - resume[p];
+      const uint32_t iq = rp.idx[q];
+      const uint32_t skip = q >= (seg << 15) ? idx1 - 1 - iq : c1 + (idx2 - iq);   // candidates nearer than q
+      if (skip < c1) { i1 = idx1 - skip; n1 = c1 - skip; }
+      else { const uint32_t s2 = skip - c1 < c2 ? skip - c1 : c2; n1 = 0; i2 = idx2 - s2; n2 = c2 - s2; }
+    }
+    MatchPair r;
+    if (!(chain_ok && bst < nice && n1 + n2 > 0)) {
+      const uint32_t packed = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u;
+      r.full = packed; r.quarter = !chain_ok ? rqq : (hq ? rqq : packed);
+      if (lane == 0) M[p] = r;
+      return r;
+    }
+    // ---- the scan: candidate c of the position (nearest first) as a distance; 0 = no such candidate.  Position 0 is never a match source (:467)
+    const uint16_t *sprev = rp.S + ((seg << 15) - 32768);          // (32-bit offsets from the start of the previous segment in the sorted order)
+    const uint32_t TT = n1 + n2, po = (uint32_t)p & 32767u;
+    auto cand = [&](uint32_t c) -> uint32_t {
+      const bool in1 = c < n1, in2 = !in1 && c - n1 < n2;
+      const uint32_t a = in1 ? 32768u + i1 - 1u - c : (in2 ? i2 - (c - n1) : 32768u);
+      const uint32_t raw = sprev[a];
+      const bool q0 = raw == 0 && ((in1 && seg_first) || (in2 && prev_first));   // the candidate is position 0 of the stream
+      return q0 ? 0u : (in1 ? po - raw : (in2 ? po + 32768u - raw : 0u));
+    };
+    uint32_t s_end = g32(p + (uint32_t)bst - 3);
+    bool over = false;
+    uint32_t dnext = cand((uint32_t)lane);
+    for (uint32_t c0 = 0; c0 < TT && !over; c0 += 64) {
+      const uint32_t d = dnext;
+      if (c0 + 64 < TT) dnext = cand(c0 + 64 + (uint32_t)lane);
+      const bool valid = d != 0;
+      const bool inr = valid && d <= LF;
+      bool pass = false;
+      if (inr) pass = g32(p - d + (uint32_t)bst - 3) == s_end;    // (:754-757, four bytes bst-3 .. bst instead of two)
+      unsigned long long pm = __ballot(pass);
+      while (pm) {
+        const int j = __ffsll((long long)pm) - 1;
+        const uint32_t dj = RL(d, j);
+        if (!hq && dj > LQ) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }     // the walk crosses the quarter limit (:733-735)
+        const uint32_t o = 4u * (uint32_t)lane;
+        const uint32_t x = g32(p - dj + o) ^ g32(p + o);
+        const unsigned long long mm = __ballot(x != 0);
+        int len;
+        if (mm) { const int l0 = __ffsll((long long)mm) - 1; len = 4 * l0 + (int)(__builtin_ctz(RL(x, l0)) >> 3); }
+        else { const uint32_t y = (g32(p - dj + 256) ^ g32(p + 256)) & 0xFFFFu; len = 256 + (y == 0 ? 2 : ((y & 0xFF) == 0 ? 1 : 0)); }
+        len = len < la ? len : la;
+        if (len > bst) {
+          bst = len; bd = dj;
+          if (len >= nice) { over = true; break; }                                               // :815
+          s_end = g32(p + (uint32_t)bst - 3);
+          pass = pass && lane > j && g32(p - d + (uint32_t)bst - 3) == s_end;
+        } else pass = pass && lane > j;
+        pm = __ballot(pass);
+      }
+      if (!over && !hq && __any(valid && d > LQ)) { hq = true; rqq = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u; }
+      // beyond the limit, or position 0, or no more candidates: the chain ends (:819-822)
+      if (__any(!inr)) over = true;
+    }
+    const uint32_t packed = bst >= 3 ? ((uint32_t)bst << 16) | bd : 0u;
+    r.full = packed; r.quarter = hq ? rqq : packed;
+    if (lane == 0) M[p] = r;
+    return r;
+  }
+};
+
+constexpr uint32_t PX_RECS = PCHUNK + 320;          // match records of a chunk kept in LDS (a parse runs over its chunk's end by a match or two; beyond: memory)
+struct WaveFetch {
+  const uint64_t *recs; uint32_t c0; const MatchPair *Mg; const WaveExact *wx;
+  __device__ MatchPair operator()(uint32_t p) const {
+    MatchPair r;
+    if (p - c0 < PX_RECS) { const uint64_t v = recs[p - c0]; r.full = (uint32_t)v; r.quarter = (uint32_t)(v >> 32); }
+    else r = Mg[p];
+    if (r.full & M_GUESS) r = wx->search(p, r);
+    return r;
+  }
+};
+struct WaveSink {                                   // every lane counts, lane 0 writes
+  uint32_t *dst; uint32_t n;
+  __device__ void push(uint32_t t) { if ((threadIdx.x & 63) == 0) dst[n] = t; n++; }
+};
+constexpr int PX_WAVES = 4;
+__global__ void __launch_bounds__(64 * PX_WAVES) k_parse_spec_exact(ParseIO io, uint32_t nchunks, uint32_t *__restrict__ spec_tok, uint32_t *__restrict__ spec_cnt,
+                                                                     uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits,
+                                                                     WaveExact wx, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n, uint32_t exact_max) {
+  __shared__ uint64_t recs[PX_WAVES][PX_RECS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t nl = *list_n, stride = gridDim.x * PX_WAVES;
+  if (nl > exact_max) return;                         // (a long list: the lane-per-chunk parse takes it)
+  for (uint32_t i = blockIdx.x * PX_WAVES + w; i < nl; i += stride) {      // (a wave's loop: no workgroup barrier inside)
+    const uint32_t k = list[i];
+    if (k >= nchunks) continue;
+    ParseIO cio = io;
+    if (io.segend) cio.n = io.segend[((uint64_t)k * PCHUNK) >> 15] & 0x7FFFFFFFu;     // a batch: the input ends where the chunk's entry ends
+    const uint32_t c0 = k * PCHUNK;
+    {
+      const uint64_t *src = (const uint64_t *)(io.M + c0);
+      const uint32_t have = (uint64_t)c0 + PX_RECS <= io.n ? PX_RECS : (uint32_t)(io.n - c0);      // (the parse never looks beyond the input)
+      for (uint32_t j = lane; j < have; j += 64) recs[w][j] = src[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    WaveFetch wf; wf.recs = recs[w]; wf.c0 = c0; wf.Mg = io.M; wf.wx = &wx;
+    WaveSink ts; ts.dst = spec_tok + (uint64_t)k * PTOK_STRIDE; ts.n = 0;
+    ExitState ex;
+    parse_spec_chunk_to(cio, k, PCHUNK, ts, Fbits, Lbits, ex, NoGuess(), wf);
+    if (lane == 0) { spec_cnt[k] = ts.n; exits[k] = ex; }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // Fix-up: chunk k re-parses from the true exit of chunk k-1 until it meets the speculative parse.
@@ -1990,6 +2175,8 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       while (R < 16 && nseg / (2 * R) >= 1024) R *= 2;
       if (job.need && R > 8) R = 8;                                       // (a piece of 2 048 segments: one workgroup per CU)
     }
+    // (zada_set_knob keeps R a power of two up to 64; the pieces below start at multiples of 2 048 segments, so every piece starts at a run)
+    if ((R & (R - 1)) || R > 64) { c->err = "link_run is not a power of two up to 64"; return -1; }
     auto prev_links = [&](uint32_t s0, uint32_t s1) {                     // segments [s0, s1), s0 a multiple of R
       if (R > 1) hipLaunchKernelGGL(k_prev_links<true>, dim3((s1 - s0 + R - 1) / R), dim3(1024), PL_LDS_RUNS, st, W.in, L, cfg.chain, cfg.chain >> 2, lv,
                                     W.S3, W.T3, W.bsc3, dpl, rpt, (unsigned long long *)W.dbg, W.segmax, W.heavy, s0, R, s1);
@@ -2011,6 +2198,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       // time (1.2 - 1.5 ms per 64 MiB against 0.68: the few long walks at the end of every launch, sixteen times instead of once --
       // tests/prof_trace_hostpath.sh).
       constexpr uint32_t PIECE = 2048;
+      static_assert(PIECE % 64 == 0, "pieces start at multiples of every run length (a power of two up to 64)");
       constexpr double SLOW_PIECE_S = 2.0e-3;
       uint32_t cl_from = 1;                                              // first segment whose cross links are still to be made (segment 0 has nothing before it)
       auto cross_links_upto = [&](uint32_t s1) {
@@ -2080,6 +2268,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   DemandMarker dmf = dm; dmf.by = 0;
   int rounds = 0, demand_rounds = 0;
   bool valve_used = false;
+  static const bool round_stats = getenv("ZADA_ROUND_STATS") != nullptr;
   // where the parse enters the buffer: at its first byte in the fresh state (the stream starts here, or a warm-up parse
   // through the halo), or in the state the shard before ended in
   const ExitState entry0 = job.entry_known ? job.entry : ExitState{0, SYNC_F};
@@ -2087,14 +2276,25 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   for (bool first = true;; first = false) {
     // speculative parse: every chunk the first time, afterwards the chunks flagged by the demand pass
     if (first) hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
-                                  W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                                  W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
     else {
       // (the list's length stays on the device: the grid covers the most there can be -- the host knows how many chunks the last demand pass flagged
       // at most only after a round trip it does not need -- and the waves beyond the list end at once)
       hipMemsetAsync(W.n_changed + 2, 0, 4, st);
       hipLaunchKernelGGL(k_list_flagged, dim3((nch + 1023) / 1024), dim3(1024), 0, st, W.chg, nch, W.offsets, W.n_changed + 2);
+      // Short lists (the last rounds: thousands of chunks, then a hundred, then one) go to k_parse_spec_exact -- one wave per chunk, the exact search inside
+      // the parse, so that the chunk is never flagged again and the loop's tail of rounds, each as long as one lane's parse whatever the number of chunks,
+      // is one launch.  Long lists (round 2 re-parses two thirds of all chunks on the benchmark stream: nearly every chunk has used one guess that turned out
+      // different) stay with the lane-per-chunk parse: a wave per chunk for 1.4 M chunks took 28 ms.  The list's length stays on the device: both kernels
+      // are launched, and the one the length is not for ends at once.
+      const uint32_t exact_max = c->knob_exact_respec > 0 ? (uint32_t)c->knob_exact_respec : 0u;
+      if (exact_max) {
+        WaveExact wx; wx.in = W.in; wx.L = L; wx.dp = dpl; wx.rp = rpt; wx.tailsK = W.ltails[NLEVELS - 1]; wx.M = W.M; wx.nice_cfg = cfg.nice; wx.resume = W.lprev[0];
+        hipLaunchKernelGGL(k_parse_spec_exact, dim3(256 * 5), dim3(64 * PX_WAVES), 0, st, io, nch, W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits,
+                           wx, (const uint32_t *)W.offsets, (const uint32_t *)(W.n_changed + 2), exact_max);
+      }
       hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
-                         W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)W.offsets, (const uint32_t *)(W.n_changed + 2));
+                         W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)W.offsets, (const uint32_t *)(W.n_changed + 2), exact_max);
     }
     // fixpoint of the splice, from scratch: round 0 handles every chunk with the speculative exits as entries
     hipMemcpyAsync(W.true_exits, W.spec_exits, (size_t)nch * sizeof(ExitState), hipMemcpyDeviceToDevice, st);
@@ -2121,6 +2321,13 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       // never meet the true one; k_fix_forward would carry it through if it were not stopped by guesses.
       if (++it >= 32 && !valve_used) { slow = true; break; }
       cur ^= 1;
+    }
+    if (round_stats) {                                             // ZADA_ROUND_STATS=1: what every round of the loop did (stderr; costs a round trip per round)
+      uint32_t nl = 0, nmark = 0;
+      if (!first) hipMemcpy(&nl, W.n_changed + 2, 4, hipMemcpyDeviceToHost);
+      { std::vector<uint32_t> hb(nbd); hipMemcpy(hb.data(), W.blk_demand, (size_t)nbd * 4, hipMemcpyDeviceToHost); for (uint32_t v : hb) nmark += v != 0; }
+      fprintf(stderr, "[lz round %d] %s parse of %u chunks, splice iterations so far %d, blocks with demanded positions %u of %u, demand %u%s\n", demand_rounds, first || nl > (uint32_t)(c->knob_exact_respec > 0 ? c->knob_exact_respec : 0) ? "speculative" : "exact",
+              first ? nch : nl, rounds, nmark, nbd, ndem, slow ? " (slow splice)" : "");
     }
     if (ndem == 0 && !slow) break;
     demand_rounds++;
