@@ -29,7 +29,8 @@ while time.time() - t0 < budget:
     shard = int(rng.choice([1 << 20, 1 << 20, 512, 1024, 4096]))
     budget_k = int(rng.choice([-1, -1, 1, 2, 3, 8]))              # round 6: small first-pass budgets (many guesses, many demand rounds) and both ways of parsing the flagged chunks again
     exact = int(rng.choice([32768, 32768, 1 << 30, 64, 0]))   # (lists up to this many chunks: one wave per chunk with the exact search inside)
-    enc.set_knob("link_run", run); enc.set_knob("shard_kib", shard); enc.set_knob("budget", budget_k); enc.set_knob("exact_respec", exact)
+    cdf = int(rng.choice([1, 1, 1, 0]))                           # (the cross-segment continuation with the Bloom filter and its second / third pass, or in one pass)
+    enc.set_knob("link_run", run); enc.set_knob("shard_kib", shard); enc.set_knob("budget", budget_k); enc.set_knob("exact_respec", exact); enc.set_knob("cd_filter", cdf)
     rc, ref, crc = oracle_deflate(d, method)
     try:
         out, crc2 = enc.deflate(d, method); rc2 = 0
@@ -39,6 +40,6 @@ while time.time() - t0 < budget:
     cases += 1
     if not ok:
         bad += 1
-        print("MISMATCH seed %d case %d: n %d method %d link_run %d shard_kib %d budget %d exact_respec %d" % (seed, cases, n, method, run, shard, budget_k, exact), flush=True)
+        print("MISMATCH seed %d case %d: n %d method %d link_run %d shard_kib %d budget %d exact_respec %d cd_filter %d" % (seed, cases, n, method, run, shard, budget_k, exact, cdf), flush=True)
 print("link-run soak seed %d: %d cases in %.0f s, %d mismatches" % (seed, cases, time.time() - t0, bad), flush=True)
 sys.exit(1 if bad else 0)

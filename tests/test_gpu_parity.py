@@ -343,23 +343,23 @@ def test_full_size_properties(encoder):
     assert rc == 0 and got == ref
     # The size-dependent defaults, bit for bit at this size (an inflate round trip cannot see a missed cross link): the host path's
     # pieces of 2 048 segments with runs of 8, the device path's runs of 16, no runs at all, and the flagged chunks parsed again with guesses in
-    # every round (rounds 1-5) or by the exact parse in every round instead of for short lists only (round 6) -- five ways through the link stage
-    # and the demand loop, one stream.
+    # every round (rounds 1-5) or by the exact parse in every round instead of for short lists only (round 6), the cross-segment continuation in
+    # one pass without its Bloom filter -- six ways through the link stage and the demand loop, one stream.
     import torch
     want = hashlib.sha256(out).digest()
     d_in = torch.from_numpy(d).cuda()
     d_out = torch.empty(n + 4096, dtype=torch.uint8, device="cuda")
     try:
-        for knobs in ({}, {"link_run": 1}, {"exact_respec": 0}, {"exact_respec": 1 << 30}):
+        for knobs in ({}, {"link_run": 1}, {"exact_respec": 0}, {"exact_respec": 1 << 30}, {"cd_filter": 0}):
             for k, v in knobs.items():
                 encoder.set_knob(k, v)
             rc2, ol, crc2 = encoder.deflate_device(d_in.data_ptr(), n, d_out.data_ptr(), n + 4096, 10)
             assert rc2 == 0 and crc2 == crc and ol == len(out), knobs
             assert hashlib.sha256(d_out[:ol].cpu().numpy().tobytes()).digest() == want, knobs
             for k in knobs:
-                encoder.set_knob(k, 0 if k == "link_run" else 32768)
+                encoder.set_knob(k, {"link_run": 0, "exact_respec": 32768, "cd_filter": 1}[k])
     finally:
-        encoder.set_knob("link_run", 0); encoder.set_knob("exact_respec", 32768)
+        encoder.set_knob("link_run", 0); encoder.set_knob("exact_respec", 32768); encoder.set_knob("cd_filter", 1)
 
 
 def test_link_stage_in_runs_of_segments(encoder):

@@ -175,6 +175,8 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   }
   for (int l = 0; l < NLEVELS; l++) { A(lprev[l], cap + IN_PAD); if (l > 0) A(ltails[l], nseg32 * 65536); }
   A(segmax, nseg32 + 16); A(heavy, nseg32 * 2048);
+  A(bloom4, nseg32 * 4096);                                   // (BLOOM_WORDS of zada_lz.hip: 2^17 bits per segment)
+  W.cd_cap = cap / 256 + 4096; A(cd_list, W.cd_cap + W.cd_cap / 4);    // (the list of the sweep, and behind it the list of its second pass)
   for (int l = 0; l < NLEVELS; l++) A(dplane[l], cap + 64);
   A(dlim, cap + 64); A(dlim_bits, cap / 32 + 64);
   A(M, cap + 64);
@@ -1009,6 +1011,7 @@ zada_ctx *zada_create(int device) {
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
   if (const char *e = getenv("ZADA_INNER_BUDGET")) z->c.knob_inner_budget = atoi(e);
   if (const char *e = getenv("ZADA_LINK_RUN")) { const int v = atoi(e); if (v >= 0 && v <= 64 && !(v & (v - 1))) z->c.knob_link_run = v; }
+  if (const char *e = getenv("ZADA_CD_FILTER")) z->c.knob_cd_filter = atoi(e) != 0;
   if (const char *e = getenv("ZADA_EXACT_RESPEC")) { if (atoi(e) >= 0) z->c.knob_exact_respec = atoi(e); }
   if (const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS")) { if (atoi(e) > 0) z->c.knob_max_demand_rounds = atoi(e); }
   if (const char *e = getenv("ZADA_SHARD_KIB")) { if (atoi(e) >= 64 && atoi(e) % 64 == 0) z->c.knob_shard_kib = atoi(e); }
@@ -1041,6 +1044,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "bz_small_wg")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_small_wg = value; }
   else if (!strcmp(name, "bz_lists")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_bz_lists = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
+  else if (!strcmp(name, "cd_filter")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_cd_filter = value; }
   else if (!strcmp(name, "exact_respec")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_exact_respec = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;
   else if (!strcmp(name, "shard_kib")) { if (value < 64 || value % 64) return ZADA_E_INVALID; z->c.knob_shard_kib = value; }

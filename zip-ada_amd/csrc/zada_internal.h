@@ -145,6 +145,8 @@ struct Workspace {
   uint16_t *S3 = nullptr; uint8_t *T3 = nullptr; uint32_t *bsc3 = nullptr;   // 15-bit hash order of every segment (positions, tags, buckets)
   uint32_t *segmax = nullptr;                // largest 15-bit bucket of every segment
   uint16_t *heavy = nullptr;                 // per segment 2048 x u16: the number of its heavy 15-bit buckets, then their hashes (zada_lz.hip)
+  uint32_t *bloom4 = nullptr;                // per segment 2^17 bits: which four-byte values it holds (k_bloom4, asked by k_cross_dist)
+  uint32_t *cd_list = nullptr; uint64_t cd_cap = 0;   // positions whose level-4 walk k_cross_dist's sweep left open (its second pass takes them)
   uint16_t *dplane[NLEVELS] = {}; uint32_t *dlim = nullptr, *dlim_bits = nullptr;  // DistPlanes
   uint16_t *SK = nullptr, *idxK = nullptr, *cntK = nullptr;   // RunPtrs
   MatchPair *M = nullptr;                    // match tables
@@ -276,6 +278,7 @@ struct Ctx {
   // zada_set_knob)
   int knob_budget = -1;             // ZADA_BUDGET: rounds of chain steps per position in the first match pass (0 = unbounded, -1 = default)
   int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
+  int knob_cd_filter = 1;           // "cd_filter" / ZADA_CD_FILTER: k_cross_dist asks a Bloom filter of the previous segment's four-byte values before a level-4 walk, walks at most six steps in its sweep and leaves longer walks to a second, packed pass (0: one pass, no filter, no limit -- rounds 1-5)
   int knob_exact_respec = 32768;    // "exact_respec" / ZADA_EXACT_RESPEC: lists of up to this many flagged chunks are parsed again by one wave per chunk with the exact search inside the parse (0: never -- the lane-per-chunk parse with guesses in every round, as in rounds 1-5)
   int knob_bz_pipe_prio = 0;        // "bz_pipe_prio": 1 = the worker stream of the BZip2 pipeline (entropy stage of the batch before) has the lowest priority (measured: no gain)
   int knob_link_run = 0;            // ZADA_LINK_RUN: segments per workgroup of k_prev_links (0 = by size: lz_shard)

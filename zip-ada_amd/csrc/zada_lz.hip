@@ -37,6 +37,9 @@ namespace zada {
 // global memory accepts any byte address: one load instead of aligned pieces
 typedef uint32_t __attribute__((aligned(1))) u32u;
 typedef uint64_t __attribute__((aligned(1))) u64u;
+// value of lane j (j wave uniform) of a vector register, as a scalar
+#define RL(v, j) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (j)))
+#define RL64(v, j) ((uint64_t)RL((uint32_t)(v), (j)) | ((uint64_t)RL((uint32_t)((v) >> 32), (j)) << 32))
 
 // --------------------------------------------------------------------------------------------
 // Layout of the LZ buffer: ONE stream [0, n), or a BATCH of independent streams (Zip entries), each starting at a multiple
@@ -837,14 +840,65 @@ __global__ void __launch_bounds__(1024) k_cross_links(const uint8_t *__restrict_
 #define ZADA_CD_THREADS 64
 #endif
 constexpr int CD_THREADS = ZADA_CD_THREADS;
+#ifdef ZADA_CD_STATS
+__device__ unsigned long long g_cd_dbg[16];
+#endif
+// Round 6: which four-byte values a segment holds, as a Bloom filter (2^17 bits = 16 KiB per segment, 0.5 byte per input byte; one bit per value).
+// Nine in ten of k_cross_dist's level-4 walks find nothing (measured at 256 MiB: 8.7 M walks, 2.75 steps each, 8.6 % find a match): the value
+// of a bucket's first member does not occur in the previous segment, but the bucket there is not empty -- a hash collision, and if it is with a
+// frequent string the walk goes through all its occurrences, two 64-byte sectors a step, with the wave's other 63 lanes waiting.  A walk now
+// asks the previous segment's filter first: a clear bit means the value is not there, and that IS the answer (no four-byte match).
+constexpr uint32_t BLOOM_BITS = 1u << 17, BLOOM_WORDS = BLOOM_BITS / 32;
+// (Two bits per value in one 64-byte block of the filter, measured: 9 % instead of 18 % of the absent values pass, the sweep 6.80 instead of 6.88 ms, the filters'
+// build 0.62 instead of 0.46 ms -- the same sum; one bit it is.  Another multiplier than hashL_of's: a bucket's collisions spread over the filter.)
+__device__ __forceinline__ uint32_t bloom4_of(uint32_t x) { return (x * 0x85EBCA6Bu) >> 15; }
+__global__ void __launch_bounds__(256) k_bloom4(const uint8_t *__restrict__ in, Layout L, uint32_t *__restrict__ bloom, uint32_t seg0) {
+  __shared__ uint32_t bits[BLOOM_WORDS];
+  const uint64_t seg = (uint64_t)blockIdx.x + seg0, base = seg * 32768ull;
+  const uint32_t m = lay_inserted(L, seg);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (int)BLOOM_WORDS; i += 256) bits[i] = 0;
+  __syncthreads();
+  const uint32_t *w = (const uint32_t *)(in + base);               // (the buffer is padded behind the input)
+  for (uint32_t i = tid; i < 32768u / 4u; i += 256) {
+    const uint32_t a = w[i], b = w[i + 1], e = 4u * i;
+    const uint32_t x[4] = {a, __builtin_amdgcn_alignbyte(b, a, 1), __builtin_amdgcn_alignbyte(b, a, 2), __builtin_amdgcn_alignbyte(b, a, 3)};
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (e + (uint32_t)j < m) { const uint32_t h = bloom4_of(x[j]); atomicOr(&bits[h >> 5], 1u << (h & 31u)); }
+  }
+  __syncthreads();
+  uint4 *dst = (uint4 *)(bloom + seg * BLOOM_WORDS);
+  for (int i = tid; i < (int)BLOOM_WORDS / 4; i += 256) dst[i] = ((const uint4 *)bits)[i];
+}
+
 // (Round 6, measured and dropped: the level-3 look-up and the level-4 walk of a position as two state machines side by side in the lane, their loads
 // issued together in every turn, a batch's eight sorted-order entries fetched with its tags -- three round trips instead of four for the look-up,
 // the longer of the two chains instead of their sum.  Bit-exact, and SLOWER: 16.0 against 12.7 ms for the phase at 1 GiB.  The kernel moves 64-byte
 // sectors for two to eight useful bytes at 3.4 TB/s; what the entries' 16 bytes per batch add in sectors costs more than the shorter chain saves.)
+// Round 6, the level-4 walks in two passes: the SWEEP (CD_SWEEP, a lane per position as before) asks the Bloom filter and walks at most CD_CAP steps;
+// a walk that is still open then -- and a walk that k_prev_links gave up, which starts again from the position itself -- goes on a list (its plane keeps
+// the marker), and CD_LIST takes the list with every lane busy and no limit: the long walks are a few per thousand, but in the sweep each of them held a
+// wave of 64 positions for its whole length.  CD_ALL is the kernel as it was (no filter, no limit, no list): it follows the other two and does something
+// only if the list has overflowed (the count stays on the device).
+struct CdTail { const uint32_t *bloom; uint32_t *list; uint32_t *count; uint32_t cap; uint32_t *list2; uint32_t *count2; uint32_t cap2; };
+enum { CD_SWEEP = 0, CD_LIST = 1, CD_ALL = 2 };
+#ifndef ZADA_CD_CAP
+#define ZADA_CD_CAP 16
+#endif
+#ifndef ZADA_CD_CAP2
+#define ZADA_CD_CAP2 256
+#endif
+constexpr uint32_t CD_CAP = ZADA_CD_CAP, CD_CAP2 = ZADA_CD_CAP2;
+template <int MODE>
 __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv,
                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
-                                                    DistPlanes dp, uint64_t p0, uint64_t p1) {
-  const uint64_t p = p0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (the positions [p0, p1): all from 32 768 on, or one piece's)
+                                                    DistPlanes dp, uint64_t p0, uint64_t p1, CdTail tl) {
+  uint64_t p = p0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;            // (the positions [p0, p1): all from 32 768 on, or one piece's)
+  if (MODE == CD_LIST) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, nc = *tl.count, nl = nc < tl.cap ? nc : tl.cap;    // (what did not fit was walked in the sweep)
+    if (i >= nl) return;
+    p = tl.list[i];
+  }
   if (p >= p1 || p >= L.n) return;
   const uint64_t seg = p >> 15, pbase = (seg - 1) * 32768ull;
   if (lay_first(L, seg) || (uint32_t)(p & 32767u) >= lay_inserted(L, seg)) return;
@@ -869,12 +923,22 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
   need = d3_stored >= DIST3_CONT_FIRST;
 #endif
   if (!need) return;
+  // (the filter's bit is asked for here, so that it arrives while level 3 is looked up)
+  uint32_t bloom_bit = 1u;
+  if (MODE == CD_SWEEP && tl.bloom && NLEVELS > 1 && (dl_first[0] & DISTL_CONTINUE)) {
+    const uint32_t hb = bloom4_of((uint32_t)mine);
+    bloom_bit = (tl.bloom[(seg - 1) * BLOOM_WORDS + (hb >> 5)] >> (hb & 31u)) & 1u;
+  }
   // level 3 first: the previous segment's bucket of the 15-bit hash, newest first, as far back as TOO_FAR (see k_prev_links)
   uint32_t dprev = d3_stored >= DIST3_CONT_FIRST ? 0u : d3_stored;
   const uint32_t my24 = (uint32_t)mine & 0xFFFFFFu;
   const uint32_t b0 = my24 & 0xFF, b1 = (my24 >> 8) & 0xFF;
   const uint32_t h = ((b0 << 10) ^ (b1 << 5) ^ (my24 >> 16)) & 0x7FFFu;
+#ifdef ZADA_CD_NOL3   /* timing experiment only (wrong results): the kernel without its level-3 look-ups */
+  if (false) {
+#else
   if (d3_stored == DIST3_CONTINUE || d3_stored == DIST3_CONT_FIRST) {
+#endif
     const uint32_t bsc = bsc3[pbase + h];
     const uint32_t pst = bsc & 0xFFFF, pct = bsc >> 16;
     const uint16_t *ps = S3 + pbase;
@@ -925,27 +989,105 @@ __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__rest
 #pragma unroll
   for (int l = 0; l + 1 < NLEVELS; l++) {
     uint32_t dl = dl_first[l];
+#ifdef ZADA_CD_NOL4   /* timing experiment only (wrong results): the kernel without its level-4 walks */
+    if (false) {
+#else
     if ((dl & DISTL_CONTINUE) || dl == DISTL_GAVEUP) {
+#endif
       // the chain of p's bucket ended, inside p's segment, at q0 (the bucket's first member there): go on from its link
       // (a walk k_prev_links gave up: from p itself)
-      uint64_t q = dl == DISTL_GAVEUP ? p : p - (dl & 0x7FFFu);
+      const bool gaveup = dl == DISTL_GAVEUP;
+      uint64_t q = gaveup ? p : p - (dl & 0x7FFFu);
       dl = 0;
-      {
+      // (the plane of a listed position keeps its marker: CD_LIST starts the walk again; a full list: the walk goes on here)
+      bool may_list = (MODE == CD_SWEEP && tl.list != nullptr) || (MODE == CD_LIST && tl.list2 != nullptr);
+      uint32_t *const o_list = MODE == CD_LIST ? tl.list2 : tl.list, *const o_count = MODE == CD_LIST ? tl.count2 : tl.count;
+      const uint32_t o_cap = MODE == CD_LIST ? tl.cap2 : tl.cap, step_cap = MODE == CD_LIST ? CD_CAP2 : CD_CAP;
+      // (one reservation for all lanes that come here in the same turn: atomics on one address are served one after the other, chip-wide)
+      auto to_list = [&]() -> bool {
+        const unsigned long long act = __ballot(1);
+        const int leader = __ffsll((long long)act) - 1, lane_ = (int)(threadIdx.x & 63);
+        uint32_t base = 0;
+        if (lane_ == leader) base = atomicAdd(o_count, (uint32_t)__popcll(act));
+        base = (uint32_t)__shfl((int)base, leader);
+        const uint32_t k = base + (uint32_t)__popcll(act & ((1ull << lane_) - 1ull));
+        if (k < o_cap) { o_list[k] = (uint32_t)p; return true; }
+        may_list = false; return false;
+      };
+      if (MODE == CD_SWEEP && may_list && gaveup && to_list()) return;   // (a walk through the position's own segment first: the filter says nothing about that)
+      if (MODE == CD_SWEEP && l == 0 && !bloom_bit) { }                  // the value is not in the previous segment: no four-byte match
+      else {
         const uint64_t mask = (1ull << (8 * (4 + l))) - 1ull;
         uint32_t d = q == p ? link_first[l] : (uint32_t)lv.prev[l][q];
+        uint32_t nsteps = 0;
         for (;;) {
           if (d == 0) break;
           q -= d;
           if (p - q > (uint64_t)MAX_DIST) break;
+          if (may_list && nsteps == step_cap && to_list()) return;
           const uint32_t dn = lv.prev[l][q];                            // the next link and this candidate's bytes in one round trip
           const uint64_t theirs = *(const u64u *)(in + q);
+          nsteps++;
           if (p - q >= (uint64_t)dprev && ((theirs ^ mine) & mask) == 0) { dl = (uint32_t)(p - q); break; }
           d = dn;
         }
+#ifdef ZADA_CD_STATS
+        atomicAdd(&g_cd_dbg[0], 1ull); atomicAdd(&g_cd_dbg[1], (unsigned long long)nsteps); if (dl) atomicAdd(&g_cd_dbg[2], 1ull);
+        if (nsteps == 0) atomicAdd(&g_cd_dbg[3], 1ull); if (nsteps > 8) atomicAdd(&g_cd_dbg[4], 1ull); if (nsteps > 64) atomicAdd(&g_cd_dbg[5], 1ull);
+        if (dl == 0) atomicAdd(&g_cd_dbg[6], (unsigned long long)nsteps);
+        if (dl_first[l] == DISTL_GAVEUP) atomicAdd(&g_cd_dbg[7], 1ull);
+        if (nsteps > 32) atomicAdd(&g_cd_dbg[8], 1ull); if (nsteps > 128) atomicAdd(&g_cd_dbg[9], 1ull); if (nsteps > 256) atomicAdd(&g_cd_dbg[10], 1ull);
+        if (nsteps > 512) atomicAdd(&g_cd_dbg[11], 1ull); if (nsteps > 1024) atomicAdd(&g_cd_dbg[12], 1ull); atomicMax(&g_cd_dbg[13], (unsigned long long)nsteps);
+#endif
       }
       dp.d[1 + l][p] = (uint16_t)dl;
     }
     dprev = dl;
+  }
+}
+
+// The longest level-4 walks (CD_LIST gave them up after CD_CAP2 steps: a bucket shared with a frequent string, walked one dependent load after the
+// other -- the longest of a GiB, some two thousand steps, WAS the list pass: 2 ms for one lane).  What such a walk looks for is the nearest earlier
+// position with the same four bytes, not farther than MAX_DIST: every such position is on the chain (same bytes, same bucket), and the first one the walk
+// meets is the nearest.  So one WAVE reads the text backwards from the position, 64 positions at a time, eight loads in flight: at most 508 steps whose
+// loads do not depend on each other (a lane takes four neighbouring candidates from one 8-byte load: sixteen turns for the whole window), instead of a chain of any length.  (The position's own segment is read too: for a walk that left it there is no
+// match in it, and a walk k_prev_links gave up starts there anyway.)
+__global__ void __launch_bounds__(256) k_cross_scan(const uint8_t *__restrict__ in, Layout L, DistPlanes dp, CdTail tl) {
+  const uint32_t lane = threadIdx.x & 63, nc = *tl.count2, nl = nc < tl.cap2 ? nc : tl.cap2;
+  for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < nl; i += (gridDim.x * blockDim.x) >> 6) {
+    const uint64_t p = tl.list2[i], seg = p >> 15;
+    // the oldest candidate: MAX_DIST back, not in front of the entry, and never the entry's first position (:467)
+    uint64_t first = (seg - 1) << 15;                                       // (a listed position is not in an entry's first segment)
+    if (lay_first(L, seg - 1)) first += 1;
+    const uint64_t lo = p - (uint64_t)MAX_DIST > first ? p - (uint64_t)MAX_DIST : first;
+    const uint32_t mine = *(const u32u *)(in + p);
+    uint32_t found = 0;
+    // a turn: the 2 048 candidates [hi - 2 048, hi), newest first, in eight groups of 256 -- a lane takes four neighbouring candidates from one 8-byte load
+    for (uint64_t hi = p; hi > lo && !found; hi = hi - lo > 2048 ? hi - 2048 : lo) {
+      uint64_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint64_t q0 = hi - 256ull * (uint64_t)(u + 1) + 4ull * lane;         // (may wrap below zero: then it is not < hi)
+        v[u] = (q0 < hi && q0 + 3 >= lo) ? *(const u64u *)(in + q0) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint64_t q0 = hi - 256ull * (uint64_t)(u + 1) + 4ull * lane;
+        uint32_t mk = 0;
+        if (q0 < hi && q0 + 3 >= lo) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) if ((uint32_t)(v[u] >> (8 * j)) == mine && q0 + (uint64_t)j >= lo && q0 + (uint64_t)j < hi) mk |= 1u << j;
+        }
+        const unsigned long long m = __ballot(mk != 0);
+        if (m && !found) {
+          const int top = 63 - __builtin_clzll(m);                                  // the newest candidates are the highest lane's
+          const uint32_t tm = RL(mk, top);
+          const uint64_t q = hi - 256ull * (uint64_t)(u + 1) + 4ull * (uint64_t)top + (uint64_t)(31 - __builtin_clz(tm));
+          found = (uint32_t)(p - q);
+        }
+      }
+    }
+    if (lane == 0) dp.d[1][p] = (uint16_t)found;
   }
 }
 
@@ -1353,9 +1495,6 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
 // becomes, per batch of 64: the maximum length, at its nearest occurrence, or the nearest one reaching
 // nice_match.  The quarter-chain snapshot (:733-735) is taken when the batch crosses the quarter distance.
 // --------------------------------------------------------------------------------------------
-// value of lane j (j wave uniform) of a vector register, as a scalar
-#define RL(v, j) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (j)))
-#define RL64(v, j) ((uint64_t)RL((uint32_t)(v), (j)) | ((uint64_t)RL((uint32_t)((v) >> 32), (j)) << 32))
 #ifndef ZADA_DM_THREADS
 #define ZADA_DM_THREADS 512
 #endif
@@ -2187,6 +2326,22 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       const uint32_t first = (from + R - 1) / R * R;
       if (first < to) hipLaunchKernelGGL(k_cross_links, dim3((to - first + R - 1) / R, NLEVELS), dim3(1024), CL_LDS_PLANE, st, W.in, L, lv, dpl, first, R);
     };
+    static_assert(BLOOM_WORDS == 4096, "Workspace::bloom4 is sized in zada_api.hip");
+    auto cross_dist = [&]() {                                             // the positions from 32 768 on (everything is there: the last piece has come)
+      const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
+      if (!c->knob_cd_filter) {
+        hipLaunchKernelGGL(k_cross_dist<CD_ALL>, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n, CdTail{nullptr, nullptr, W.n_changed + 4, 0u, nullptr, W.n_changed + 5, 0u});
+        return;
+      }
+      // the filters of the segments that are somebody's previous one; the sweep; the list of the walks it left open
+      hipMemsetAsync(W.n_changed + 4, 0, 4, st);
+      hipLaunchKernelGGL(k_bloom4, dim3(nseg - 1), dim3(256), 0, st, W.in, L, W.bloom4, 0u);
+      hipMemsetAsync(W.n_changed + 5, 0, 4, st);
+      const CdTail tl{W.bloom4, W.cd_list, W.n_changed + 4, (uint32_t)W.cd_cap, W.cd_list + W.cd_cap, W.n_changed + 5, (uint32_t)(W.cd_cap / 4)};
+      hipLaunchKernelGGL(k_cross_dist<CD_SWEEP>, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n, tl);
+      hipLaunchKernelGGL(k_cross_dist<CD_LIST>, dim3((uint32_t)((W.cd_cap + CD_THREADS - 1) / CD_THREADS)), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)0, (uint64_t)n, tl);
+      hipLaunchKernelGGL(k_cross_scan, dim3(2048), dim3(256), 0, st, W.in, L, dpl, tl);
+    };
     if (job.need) {
       // The input is still arriving (host buffers): k_prev_links and k_bucket_limits on the segments of what has come, 64 MiB at a time --
       // a segment's workgroups read its 32 KiB and at most 31 bytes behind them, so a piece ends 64 bytes short of what is there.
@@ -2223,7 +2378,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       }
       if (int rn = job.need(n)) return rn;
       cross_links_upto(nseg);
-      if (nseg > 1) hipLaunchKernelGGL(k_cross_dist, dim3((uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS)), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n);
+      if (nseg > 1) cross_dist();
     } else
     prev_links(0, nseg);
 #ifndef ZADA_OLD_INIT
@@ -2236,13 +2391,19 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     c->tmark("prev_links");
     if (!job.need) {
       if (nseg > 1) {
-        const uint32_t nb = (uint32_t)((n_ins - 32768 + CD_THREADS - 1) / CD_THREADS);
         cross_links(1, nseg);
-        hipLaunchKernelGGL(k_cross_dist, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n);
+        cross_dist();
       }
       hipLaunchKernelGGL(k_bucket_limits, dim3(nseg), dim3(256), 0, st, L, cfg.chain, cfg.chain >> 2, W.S3, W.bsc3, W.dlim, W.dlim_bits, W.segmax, W.heavy, 0u);
     }
   }
+#ifdef ZADA_CD_STATS
+  { unsigned long long h[16]; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cd_dbg), sizeof h);
+    fprintf(stderr, "[k_cross_dist level-4 walks] %llu walks (%.1f %% of the positions), %llu steps (%.2f per walk), found %llu (%.1f %%), no step %llu, > 8 steps %llu, > 64 steps %llu, steps of the walks that found nothing %llu, gave-up restarts %llu\n",
+            h[0], 100.0 * h[0] / n, h[1], (double)h[1] / (h[0] ? h[0] : 1), h[2], 100.0 * h[2] / (h[0] ? h[0] : 1), h[3], h[4], h[5], h[6], h[7]);
+    fprintf(stderr, "[k_cross_dist level-4 walks] > 32 steps %llu, > 128 %llu, > 256 %llu, > 512 %llu, > 1024 %llu, longest %llu\n", h[8], h[9], h[10], h[11], h[12], h[13]);
+    for (int q = 0; q < 16; q++) h[q] = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_cd_dbg), h, sizeof h); }
+#endif
   c->tmark("cross_links");
   // ---- matches and parse, demand driven ----
   // The parser only ever looks at about a third of the positions, and hardly ever at the ones with the longest
