@@ -418,3 +418,28 @@ def test_stale_workspace_between_calls(encoder):
             rc, ref, crc = oracle_deflate(x, method)
             rc2, out, crc2 = gpu_deflate(encoder, x, method)
             assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), (len(x), method)
+
+
+def test_workspace_guesses_that_turn_out_too_small(encoder):
+    """Round 6 sizes two arrays by what streams usually need instead of by the worst case: the atom arrays (room for 0.5 atoms per input byte, "atoms_pct";
+    one per byte is the worst case) and the parse splice's token slots (128 per 512-byte chunk, "fix_stride"; 1152 is the worst case).  Both grow when a
+    call needs more -- the atoms of the shards before are kept, the parse starts again --, and the stream is the oracle's either way: forced here with a
+    1 % guess and slots of two tokens, on inputs in several shards, and without forcing on random bytes (one atom per byte)."""
+    rng = np.random.default_rng(21)
+    inputs = [silesia_mix((3 << 20) + 123, version=2), bytes(rng.integers(0, 256, 5 << 20, dtype=np.uint8)), silesia_mix(5 << 20, class_mask=1) + bytes(rng.integers(0, 256, 1 << 20, dtype=np.uint8))]
+    refs = [oracle_deflate(d, 10) for d in inputs]
+    try:
+        for pct, stride, shard in ((50, 0, 1 << 20), (1, 2, 1 << 20), (1, 2, 1024), (3, 7, 2048)):
+            encoder.set_knob("atoms_pct", pct); encoder.set_knob("fix_stride", stride); encoder.set_knob("shard_kib", shard)
+            grown = [0, 0]
+            for d, (rc, ref, crc) in zip(inputs, refs):
+                rc2, out, crc2 = gpu_deflate(encoder, d, 10)
+                assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), (pct, stride, shard, len(d))
+                t = dict(encoder.last_timing())
+                grown[0] += t.get("#atoms_grown", 0); grown[1] += t.get("#fix_grown", 0)
+            if pct == 1:
+                assert grown[0] >= 1 and grown[1] >= 1, grown            # both fall-backs really ran
+            else:
+                assert grown[1] == 0 or stride, grown
+    finally:
+        encoder.set_knob("atoms_pct", 50); encoder.set_knob("fix_stride", 0); encoder.set_knob("shard_kib", 1 << 20)

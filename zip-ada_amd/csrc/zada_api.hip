@@ -56,6 +56,8 @@ void Ctx::tend() {
   timing.push_back({"#bt4_reruns", (float)bt4_reruns});
   timing.push_back({"#lzma_launches", (float)lzma_launches});
   timing.push_back({"#bt4_pool_grown", (float)bt4_pool_grown});
+  timing.push_back({"#atoms_grown", (float)atoms_grown});
+  timing.push_back({"#fix_grown", (float)fix_grown});
 }
 
 #ifndef ZADA_COPY_LANES
@@ -181,7 +183,9 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
   A(dlim, cap + 64); A(dlim_bits, cap / 32 + 64);
   A(M, cap + 64);
   A(SK, nseg32 * 32768); A(idxK, cap + 64); A(cntK, cap + 64);
-  A(fix_tok, nch * PTOK_STRIDE);
+  W.fix_stride = c->knob_fix_stride > 0 ? (uint32_t)c->knob_fix_stride : FIX_STRIDE_SMALL;
+  if (W.fix_stride > PTOK_STRIDE) W.fix_stride = PTOK_STRIDE;
+  A(fix_tok, nch * W.fix_stride);
   A(spec_cnt, nch); A(fix_cnt, nch); A(take_from, nch); A(start_pos, nch); A(counts, nch); A(offsets, nch);
   A(scan_sums, nch / 1024 + 1024);
   A(Fbits, cap / 32 + 64); A(Lbits, cap / 32 + 64);
@@ -199,9 +203,11 @@ int ensure_lz_workspace(Ctx *c, uint64_t nbuf) {
 }
 
 // Entropy stage: sized for the atoms of one range (worst case one atom per byte) and its output.
-int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes) {
+int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes, uint64_t out_bytes) {
   Workspace &W = c->ws;
-  if (W.cap_atoms >= atoms && W.cap_flush >= flushes && W.cap_atoms > 0) return 0;
+  if (out_bytes < atoms) out_bytes = atoms;
+  const uint64_t out_need = out_bytes + out_bytes / 8 + (1u << 20);
+  if (W.cap_atoms >= atoms && W.cap_flush >= flushes && W.cap_atoms > 0 && W.cap_out >= out_need) return 0;
   hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
   free_group(W.en_allocs);
   W.cap_atoms = 0; W.cap_flush = 0;
@@ -230,10 +236,13 @@ int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes) {
   A(chooser, 1); A(carry, 2);
   A(scan2, nflush / 1024 + 1024); A(total2, 16);
   // the largest stream the encoder can produce for `cap` bytes: every literal in nine bits (fixed code) + block overheads
-  W.cap_out = cap + cap / 8 + (1u << 20);
+  {
+    const uint64_t ob = ((out_bytes < (1u << 20) ? (1u << 20) : out_bytes) + 65535) & ~65535ull;
+    W.cap_out = ob + ob / 8 + (1u << 20);
+  }
   A(out, W.cap_out);
 #undef A
-  if (!rc) rc = ensure_crc_workspace(c, cap);
+  if (!rc) rc = ensure_crc_workspace(c, out_bytes > cap ? out_bytes : cap);
   if (rc) { free_group(W.en_allocs); return rc; }
   W.cap_atoms = cap; W.cap_flush = nflush - 3;
   return 0;
@@ -516,7 +525,12 @@ int range_open(Ctx *c, int method, const uint8_t *rin, uint64_t stream_size, uin
   if (pre + n + post >= (1ull << 32) - (1ull << 26)) { c->err = "range too large for one context (4 GiB - 64 MiB): split the stream into ranges"; return ZADA_E_TOO_LARGE; }
   if (((uintptr_t)rin & 15) != 0) { c->err = "range: input must be 16-byte aligned"; return ZADA_E_INVALID; }
   const uint64_t shard = (uint64_t)c->knob_shard_kib << 10;
-  int rc = ensure_entropy_workspace(c, n + carry_atoms, 0);
+  // The atom arrays start with room for "atoms_pct" atoms per 100 bytes (one atom per byte is the worst case, the benchmark stream has 0.3) and grow
+  // when a shard has more (range_lz: grow_atoms); everything the entropy stage sizes by atoms is the smaller for it.  A workspace that is large enough
+  // already (an earlier, larger call) stays as it is.
+  const uint64_t pct = c->knob_atoms_pct < 1 ? 1 : c->knob_atoms_pct > 100 ? 100 : (uint64_t)c->knob_atoms_pct;
+  const uint64_t guess = n < (4u << 20) ? n : n / 100 * pct + (1u << 20);
+  int rc = ensure_entropy_workspace(c, (guess < n ? guess : n) + carry_atoms, 0, n);
   if (!rc) rc = ensure_lz_workspace(c, (n < shard ? n : shard) + SHARD_HALO + SHARD_TAIL);
   if (rc) return rc;
   Range &R = c->rg;
@@ -525,7 +539,7 @@ int range_open(Ctx *c, int method, const uint8_t *rin, uint64_t stream_size, uin
   R.open = true; R.rin = rin; R.lo = lo; R.pre = pre; R.n = n; R.post = post;
   R.first = lo == 0; R.last = behind == 0; R.method = method; R.level = level;
   c->last_nblocks = 0;
-  c->demand_rounds = 0; c->parse_rounds = 0;
+  c->demand_rounds = 0; c->parse_rounds = 0; c->atoms_grown = 0; c->fix_grown = 0;
   // the output bit stream is OR-ed together: zero it meanwhile, on the second stream
   Workspace &W = c->ws;
   const uint64_t zbytes = n + n / 8 + (1u << 20) < W.cap_out ? n + n / 8 + (1u << 20) : W.cap_out;
@@ -592,6 +606,33 @@ int range_lz(Ctx *c, const GlobalState *entry, zada_feedback_fn fb, void *user) 
       if (b > a) hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(256), 0, st, (const uint4 *)(R.rin + boff + a), (uint4 *)(W.in + a), (b - a + 15) / 16);
       if (b == nbuf && (nbuf & 15)) hipLaunchKernelGGL(k_pad_init, dim3(1), dim3(256), 0, st, pa);      // (the last 16-byte piece wrote up to 15 bytes behind the buffer: zeros again)
       copied = b;
+      return 0;
+    };
+    job.grow_atoms = [&, s_hi](uint64_t total, uint32_t **da, uint32_t **dp) -> int {
+      // room for what is there, this shard's atoms and one atom per byte of what follows: it grows once
+      const uint64_t keep = LB_CAP + R.T, want = R.T + total + (R.n - s_hi) + 4096;
+      uint32_t *sa = nullptr, *sp = nullptr;
+      if (keep) {
+        if (hipMalloc(&sa, keep * 4) != hipSuccess || hipMalloc(&sp, keep * 4) != hipSuccess) { (void)hipGetLastError(); if (sa) hipFree(sa); c->err = "out of device memory (atom arrays)"; return ZADA_E_NOMEM; }
+        hipMemcpyAsync(sa, W.ea_atoms, keep * 4, hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(sp, W.ea_apos, keep * 4, hipMemcpyDeviceToDevice, st);
+      }
+      int rg = ensure_entropy_workspace(c, want, 0, R.n + R.T_carried);      // (waits for both streams, frees, books anew)
+      if (!rg && keep) {
+        hipMemcpyAsync(W.ea_atoms, sa, keep * 4, hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(W.ea_apos, sp, keep * 4, hipMemcpyDeviceToDevice, st);
+      }
+      if (!rg) {                                                          // the new output buffer: zeros again, as range_open left the old one
+        const uint64_t zb = R.n + R.n / 8 + (1u << 20) < W.cap_out ? R.n + R.n / 8 + (1u << 20) : W.cap_out;
+        hipMemsetAsync(W.out, 0, zb, c->stream2);
+        hipEventRecord(c->ev_out, c->stream2);
+      }
+      hipStreamSynchronize(st);
+      if (sa) hipFree(sa);
+      if (sp) hipFree(sp);
+      if (rg) return rg;
+      c->atoms_grown++;
+      *da = W.ea_atoms + LB_CAP + R.T; *dp = W.ea_apos + LB_CAP + R.T;
       return 0;
     };
     ShardResult res;
@@ -1011,6 +1052,7 @@ zada_ctx *zada_create(int device) {
   if (const char *e = getenv("ZADA_BUDGET")) z->c.knob_budget = atoi(e);
   if (const char *e = getenv("ZADA_INNER_BUDGET")) z->c.knob_inner_budget = atoi(e);
   if (const char *e = getenv("ZADA_LINK_RUN")) { const int v = atoi(e); if (v >= 0 && v <= 64 && !(v & (v - 1))) z->c.knob_link_run = v; }
+  if (const char *e = getenv("ZADA_ATOMS_PCT")) { if (atoi(e) >= 1 && atoi(e) <= 100) z->c.knob_atoms_pct = atoi(e); }
   if (const char *e = getenv("ZADA_CD_FILTER")) z->c.knob_cd_filter = atoi(e) != 0;
   if (const char *e = getenv("ZADA_EXACT_RESPEC")) { if (atoi(e) >= 0) z->c.knob_exact_respec = atoi(e); }
   if (const char *e = getenv("ZADA_MAX_DEMAND_ROUNDS")) { if (atoi(e) > 0) z->c.knob_max_demand_rounds = atoi(e); }
@@ -1044,6 +1086,8 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "bz_small_wg")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_small_wg = value; }
   else if (!strcmp(name, "bz_lists")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_bz_lists = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
+  else if (!strcmp(name, "atoms_pct")) { if (value < 1 || value > 100) return ZADA_E_INVALID; z->c.knob_atoms_pct = value; z->c.ws.cap_atoms = 0; }   // (the next call books the entropy workspace anew)
+  else if (!strcmp(name, "fix_stride")) { if (value < 0 || value > (int)PTOK_STRIDE) return ZADA_E_INVALID; z->c.knob_fix_stride = value; z->c.ws.cap_n = 0; }
   else if (!strcmp(name, "cd_filter")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_cd_filter = value; }
   else if (!strcmp(name, "exact_respec")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_exact_respec = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;

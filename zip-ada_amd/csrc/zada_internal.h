@@ -21,6 +21,7 @@ constexpr int ZADA_E_HIP_ = -3;
 constexpr uint32_t PCHUNK = ZADA_PCHUNK;
 static_assert(PCHUNK > 258, "k_fix_forward: a 258-byte step crosses at most one chunk boundary");                 // bytes parsed per lane (speculative chunk)
 constexpr uint32_t PTOK_STRIDE = PCHUNK + 640;    // token slots per chunk (a parse may overrun its chunk by < 600 B)
+constexpr uint32_t FIX_STRIDE_SMALL = 128;        // ... of the splice's tokens to start with (1 instead of 9 bytes per input byte): a splice meets the speculative parse after a few tokens
 constexpr uint32_t CRC_CHUNK = 4096, CRC_SUB = 256;   // CRC: one lane per 256 B, folded to one value per 4 KiB on the device
 constexpr uint64_t IN_PAD = 1024;                 // zero bytes kept after the input
 
@@ -151,6 +152,7 @@ struct Workspace {
   uint16_t *SK = nullptr, *idxK = nullptr, *cntK = nullptr;   // RunPtrs
   MatchPair *M = nullptr;                    // match tables
   uint32_t *spec_tok = nullptr, *fix_tok = nullptr;
+  uint32_t fix_stride = 0;                   // token slots per chunk in fix_tok: FIX_STRIDE_SMALL, or PTOK_STRIDE once a splice has needed more (lz_shard)
   uint32_t *spec_cnt = nullptr, *fix_cnt = nullptr, *take_from = nullptr, *start_pos = nullptr;
   uint32_t *counts = nullptr, *offsets = nullptr, *scan_sums = nullptr;
   uint32_t *Fbits = nullptr, *Lbits = nullptr;
@@ -254,6 +256,7 @@ struct Ctx {
   Range rg;                                          // the range in flight
   std::string err;
   int parse_rounds = 0, demand_rounds = 0;
+  int atoms_grown = 0, fix_grown = 0;                // how often a call had to enlarge the atom arrays / the splice's token slots (last_timing: #atoms_grown, #fix_grown)
   bool lz_attrs_set = false;
   void *bz = nullptr;                                // BZip2 state (zada_bz2.hip), made on first use
   void *lz_tab = nullptr; size_t cap_lz_tab = 0;     // LZMA (zada_lzma.hip): job table + results
@@ -278,6 +281,8 @@ struct Ctx {
   // zada_set_knob)
   int knob_budget = -1;             // ZADA_BUDGET: rounds of chain steps per position in the first match pass (0 = unbounded, -1 = default)
   int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
+  int knob_atoms_pct = 50;          // "atoms_pct": the atom arrays of a stream start with room for this many atoms per 100 input bytes (they grow when a shard has more: one atom per byte is the worst case, the benchmark stream has 0.3)
+  int knob_fix_stride = 0;          // "fix_stride" (test knob): token slots per chunk the splice starts with (0 = FIX_STRIDE_SMALL)
   int knob_cd_filter = 1;           // "cd_filter" / ZADA_CD_FILTER: k_cross_dist asks a Bloom filter of the previous segment's four-byte values before a level-4 walk, walks at most six steps in its sweep and leaves longer walks to a second, packed pass (0: one pass, no filter, no limit -- rounds 1-5)
   int knob_exact_respec = 32768;    // "exact_respec" / ZADA_EXACT_RESPEC: lists of up to this many flagged chunks are parsed again by one wave per chunk with the exact search inside the parse (0: never -- the lane-per-chunk parse with guesses in every round, as in rounds 1-5)
   int knob_bz_pipe_prio = 0;        // "bz_pipe_prio": 1 = the worker stream of the BZip2 pipeline (entropy stage of the batch before) has the lowest priority (measured: no gain)
@@ -343,7 +348,7 @@ int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t
                 uint8_t *d_save = nullptr, uint64_t budget = 0, uint64_t pos_cap = ~0ull, int waves = 1);
 uint64_t lzma_save_stride();
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
-int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes);
+int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes, uint64_t out_bytes = 0);   // out_bytes: the input the stream is made of (0: as many bytes as atoms)
 int ensure_crc_workspace(Ctx *c, uint64_t n);
 
 // One shard of a range through the LZ stage.  W.in holds `nbuf` bytes (zero pad behind): a 32 KiB halo in front of the
@@ -358,6 +363,9 @@ struct ShardJob {
   uint32_t *dst_atoms = nullptr, *dst_apos = nullptr;
   uint32_t apos_bias = 0;             // added to buffer positions: offset of the buffer in the range's input
   uint64_t cap_atoms = 0;             // room at dst
+  // grow_atoms (total): the shard has `total` atoms and dst has room for fewer -- the caller makes room (keeping what the shards before have written)
+  // and says where the shard's atoms go now; null, or a non-zero return: ZADA_E_NOMEM ("atom array overflow")
+  std::function<int(uint64_t, uint32_t **, uint32_t **)> grow_atoms;
   const uint32_t *segend = nullptr;   // a batch of entries in the buffer (Layout); then tok_lo = 0, final, entry at 0
   // need (x): the first x bytes of W.in are to be valid before whatever is enqueued next on the context's stream runs (null: all of
   // them are).  The host-buffer entry point's input arrives piece by piece while the first kernel already works on what has come.

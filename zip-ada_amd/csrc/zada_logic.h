@@ -153,6 +153,9 @@ template <typename F> ZADA_HD typename std::enable_if<has_byte<typename std::rem
 template <typename F> ZADA_HD typename std::enable_if<!has_byte<typename std::remove_reference<F>::type>::value, uint32_t>::type fetch_byte(F &, const uint8_t *in, uint32_t p) { return in[p]; }
 // Sink: where the tokens go (the GPU's speculative parse collects eight of them in LDS before it writes).
 struct DirectSink { uint32_t *tok; uint32_t &ntok; ZADA_HD void push(uint32_t t) { tok[ntok++] = t; } };
+// ... with room for `cap` tokens: what does not fit is counted, not written, and *overflow says so (the splice's tokens get a small slot per chunk --
+// a splice meets the speculative parse after a few tokens -- and the whole slot only when one ever does not: csrc/zada_lz.hip, lz_shard)
+struct CappedSink { uint32_t *tok; uint32_t &ntok; uint32_t cap; uint32_t *overflow; ZADA_HD void push(uint32_t t) { if (ntok < cap) tok[ntok] = t; else if (overflow) *overflow = 1u; ntok++; } };
 template <typename Sink, typename OnTop, typename OnGuess, typename Fetch>
 ZADA_HD void run_parser(ParseState &s, const ParseIO &io, Sink &&sink, OnTop &&on_top, OnGuess &&on_guess, Fetch &&fetch) {
   for (;;) {
@@ -215,7 +218,7 @@ template <typename OnGuess, typename Fetch>
 ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, ExitState entry,
                              const uint32_t *spec_tok, uint32_t spec_cnt, const uint32_t *Fbits, const uint32_t *Lbits,
                              ExitState spec_exit, uint32_t *tok, uint32_t &ntok, uint32_t &take, uint32_t &u0, ExitState &new_exit,
-                             OnGuess on_guess, Fetch &&fetch) {
+                             OnGuess on_guess, Fetch &&fetch, uint32_t tok_cap = 0xFFFFFFFFu, uint32_t *tok_overflow = nullptr) {
   const uint64_t c0 = (uint64_t)k * chunk, c1 = (c0 + chunk < io.n) ? c0 + chunk : io.n;
   u0 = entry.kind == SYNC_L ? entry.pos - 1 : entry.pos;      // first byte not yet emitted at entry
   ntok = 0;
@@ -228,7 +231,7 @@ ZADA_HD void parse_fix_chunk(const ParseIO &io, uint32_t k, uint32_t chunk, Exit
   ParseState s{entry.pos, entry.kind == SYNC_L ? 1u : 0u, 2, 0};
   bool synced = false;
   ExitState e; e.pos = (uint32_t)io.n; e.kind = SYNC_F;
-  run_parser(s, io, DirectSink{tok, ntok}, [&](const ParseState &st) {
+  run_parser(s, io, CappedSink{tok, ntok, tok_cap, tok_overflow}, [&](const ParseState &st) {
     int kind = sync_kind(st);
     if (kind == SYNC_NONE) return false;
     if ((uint64_t)st.p >= c1) { e.pos = st.p; e.kind = (uint32_t)kind; return true; }

@@ -2066,7 +2066,7 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
                             uint32_t *__restrict__ fix_tok, uint32_t *__restrict__ fix_cnt,
                             uint32_t *__restrict__ take_from, uint32_t *__restrict__ start_pos,
                             const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
-                            uint32_t *__restrict__ n_changed, DemandMarker dm, ExitState entry0) {
+                            uint32_t *__restrict__ n_changed, DemandMarker dm, ExitState entry0, uint32_t fix_stride, uint32_t *__restrict__ fix_overflow) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nchunks) return;
   if (!dirty_in[k]) return;
@@ -2081,7 +2081,7 @@ __global__ void k_parse_fix(ParseIO io, uint32_t nchunks, const uint32_t *__rest
   ExitState new_exit;
   uint32_t ntok = 0, take = 0, u0 = 0;
   parse_fix_chunk(io, k, PCHUNK, entry, spec_tok + (uint64_t)k * PTOK_STRIDE, spec_cnt[k], Fbits, Lbits, spec_exits[k],
-                  fix_tok + (uint64_t)k * PTOK_STRIDE, ntok, take, u0, new_exit, dm, DirectFetch{io.M});
+                  fix_tok + (uint64_t)k * fix_stride, ntok, take, u0, new_exit, dm, DirectFetch{io.M}, fix_stride, fix_overflow);
   fix_cnt[k] = ntok;
   take_from[k] = take;
   start_pos[k] = u0;
@@ -2153,14 +2153,14 @@ __global__ void __launch_bounds__(256) k_tok_compact(uint32_t nchunks, const uin
                                                      const uint32_t *__restrict__ spec_cnt, const uint32_t *__restrict__ fix_tok,
                                                      const uint32_t *__restrict__ fix_cnt, const uint32_t *__restrict__ take_from,
                                                      const uint32_t *__restrict__ start_pos, const uint32_t *__restrict__ offsets,
-                                                     uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos, uint32_t k0, uint32_t apos_bias) {
+                                                     uint32_t *__restrict__ atoms, uint32_t *__restrict__ apos, uint32_t k0, uint32_t apos_bias, uint32_t fix_stride) {
   // chunks [k0, k0 + nchunks); offsets[] is the exclusive scan over exactly these chunks
   const uint32_t kk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (kk >= nchunks) return;
   const uint32_t k = k0 + kk;
   const uint32_t nf = fix_cnt[k], tf = take_from[k], ns = spec_cnt[k] - tf;
-  const uint32_t *ft = fix_tok + (uint64_t)k * PTOK_STRIDE;
+  const uint32_t *ft = fix_tok + (uint64_t)k * fix_stride;
   const uint32_t *st = spec_tok + (uint64_t)k * PTOK_STRIDE + tf;
   uint32_t out = offsets[kk];
   uint32_t pos = start_pos[k] + apos_bias;
@@ -2271,8 +2271,12 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   }
   if (level == 0) {
     const uint64_t hi = job.final ? n : job.tok_hi, cnt = hi - job.tok_lo;
-    if (cnt > job.cap_atoms) { c->err = "atom array overflow"; return -2; }
-    if (cnt) hipLaunchKernelGGL(k_literal_atoms, dim3(2048), dim3(256), 0, st, W.in + job.tok_lo, cnt, job.dst_atoms, job.dst_apos, job.apos_bias + job.tok_lo);
+    uint32_t *dst_atoms = job.dst_atoms, *dst_apos = job.dst_apos;
+    if (cnt > job.cap_atoms) {                                       // (one atom per byte: more than the caller guessed -- it makes room, or it is an error)
+      if (!job.grow_atoms) { c->err = "atom array overflow"; return -2; }
+      if (int rg = job.grow_atoms(cnt, &dst_atoms, &dst_apos)) return rg;
+    }
+    if (cnt) hipLaunchKernelGGL(k_literal_atoms, dim3(2048), dim3(256), 0, st, W.in + job.tok_lo, cnt, dst_atoms, dst_apos, job.apos_bias + job.tok_lo);
     res->ntok = (uint32_t)cnt;
     res->exit = ExitState{(uint32_t)hi, SYNC_F};
     return hip_check(c, hipGetLastError(), "k_literal_atoms");
@@ -2434,7 +2438,10 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   // through the halo), or in the state the shard before ended in
   const ExitState entry0 = job.entry_known ? job.entry : ExitState{0, SYNC_F};
   const uint32_t kE = job.entry_known ? (entry0.pos / PCHUNK < nch ? entry0.pos / PCHUNK : nch) : 0u;
+  hipMemsetAsync(W.n_changed + 6, 0, 4, st);
+  bool restart = false, first_again = false;
   for (bool first = true;; first = false) {
+    if (first_again) { first = true; first_again = false; }
     // speculative parse: every chunk the first time, afterwards the chunks flagged by the demand pass
     if (first) hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
                                   W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
@@ -2470,13 +2477,27 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       hipMemsetAsync(W.n_changed + 1, 0xFF, 4, st);
       hipLaunchKernelGGL(k_parse_fix, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
                          W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, W.true_exits, W.fix_tok, W.fix_cnt,
-                         W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed, dmf, entry0);
+                         W.take_from, W.start_pos, W.dirty[cur], W.dirty[cur ^ 1], W.n_changed, dmf, entry0, W.fix_stride, W.n_changed + 6);
       hipLaunchKernelGGL(k_fix_forward, dim3(1), dim3(64), 0, st, io, nch, W.true_exits, W.dirty[cur ^ 1], W.n_changed);
-      uint32_t changed = 0;
+      uint32_t changed = 0, fix_ovf = 0;
       hipMemcpyAsync(&changed, W.n_changed, 4, hipMemcpyDeviceToHost, st);
       hipMemcpyAsync(&ndem, W.n_demand, 4, hipMemcpyDeviceToHost, st);     // (with the same round trip; the last one read counts)
+      if (W.fix_stride < PTOK_STRIDE) hipMemcpyAsync(&fix_ovf, W.n_changed + 6, 4, hipMemcpyDeviceToHost, st);
       if (hip_check(c, hipStreamSynchronize(st), "parse_fix")) return ZADA_E_HIP_;
       rounds++;
+      if (fix_ovf) {
+        // A splice wrote more tokens than its chunk's small slot holds (it ran FIX_STRIDE_SMALL tokens without meeting the speculative parse): the
+        // slots get their full size -- for the rest of the workspace's life -- and the parse starts again (what the rounds so far have made exact stays).
+        uint32_t *bigger = nullptr;
+        const uint64_t nch_cap = W.cap_n / PCHUNK + 2;
+        if (hipMalloc(&bigger, nch_cap * (uint64_t)PTOK_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); c->err = "out of device memory (splice tokens)"; return -2; }
+        W.allocs.push_back(bigger);                                  // (the small array stays booked until the workspace is rebuilt)
+        W.fix_tok = bigger; W.fix_stride = PTOK_STRIDE;
+        c->fix_grown++;
+        hipMemsetAsync(W.n_changed + 6, 0, 4, st);
+        restart = true;
+        break;
+      }
       if (changed == 0) break;
       // A splice that needs this many rounds is advancing chunk by chunk through data in which the speculative parses
       // never meet the true one; k_fix_forward would carry it through if it were not stopped by guesses.
@@ -2490,6 +2511,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       fprintf(stderr, "[lz round %d] %s parse of %u chunks, splice iterations so far %d, blocks with demanded positions %u of %u, demand %u%s\n", demand_rounds, first || nl > (uint32_t)(c->knob_exact_respec > 0 ? c->knob_exact_respec : 0) ? "speculative" : "exact",
               first ? nch : nl, rounds, nmark, nbd, ndem, slow ? " (slow splice)" : "");
     }
+    if (restart) { restart = false; first_again = true; continue; }
     if (ndem == 0 && !slow) break;
     demand_rounds++;
     if (demand_rounds > 1000) { c->err = "demand loop did not converge"; return ZADA_E_HIP_; }
@@ -2517,9 +2539,13 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   if (!job.final) hipMemcpyAsync(&h.ex, W.true_exits + (k1 - 1), sizeof(ExitState), hipMemcpyDeviceToHost, st);
   if (k0 > 0) hipMemcpyAsync(&h.warm, W.true_exits + (k0 - 1), sizeof(ExitState), hipMemcpyDeviceToHost, st);
   if (hip_check(c, hipStreamSynchronize(st), "tok_scan")) return ZADA_E_HIP_;
-  if (h.total > job.cap_atoms) { c->err = "atom array overflow"; return -2; }
+  uint32_t *dst_atoms = job.dst_atoms, *dst_apos = job.dst_apos;
+  if (h.total > job.cap_atoms) {                                     // more atoms than the caller guessed: it makes room, or it is an error
+    if (!job.grow_atoms) { c->err = "atom array overflow"; return -2; }
+    if (int rg = job.grow_atoms(h.total, &dst_atoms, &dst_apos)) return rg;
+  }
   hipLaunchKernelGGL(k_tok_compact, dim3((nk + 3) / 4), dim3(256), 0, st, nk, W.spec_tok, W.spec_cnt, W.fix_tok, W.fix_cnt,
-                     W.take_from, W.start_pos, W.offsets, job.dst_atoms, job.dst_apos, k0, job.apos_bias);
+                     W.take_from, W.start_pos, W.offsets, dst_atoms, dst_apos, k0, job.apos_bias, W.fix_stride);
   c->tmark("compact");
   res->ntok = h.total; res->exit = h.ex; res->warm = h.warm;
   return hip_check(c, hipGetLastError(), "lz_shard");
