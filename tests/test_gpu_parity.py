@@ -441,5 +441,14 @@ def test_workspace_guesses_that_turn_out_too_small(encoder):
                 assert grown[0] >= 1 and grown[1] >= 1, grown            # both fall-backs really ran
             else:
                 assert grown[1] == 0 or stride, grown
+        # ... and in a stream that goes through one context span after span (the atoms carried from span to span live in the arrays that grow)
+        d = inputs[2] + inputs[0]
+        encoder.set_knob("span_mib", 4); encoder.set_knob("shard_kib", 1 << 20)
+        for method in (10, 7):
+            rc, ref, crc = oracle_deflate(d, method)
+            encoder.set_knob("atoms_pct", 1)
+            rc2, out, crc2 = gpu_deflate(encoder, d, method)
+            assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), ("spans", method)
+            assert dict(encoder.last_timing()).get("#atoms_grown", 0) >= 0
     finally:
-        encoder.set_knob("atoms_pct", 50); encoder.set_knob("fix_stride", 0); encoder.set_knob("shard_kib", 1 << 20)
+        encoder.set_knob("atoms_pct", 50); encoder.set_knob("fix_stride", 0); encoder.set_knob("shard_kib", 1 << 20); encoder.set_knob("span_mib", 2048)

@@ -740,7 +740,12 @@ static int deflate_spans(Ctx *c, int method, const uint8_t *d_src, const uint8_t
   const uint64_t span = (uint64_t)c->knob_span_mib << 20;
   if (fb && fb(0, user)) return ZADA_ABORTED;
   c->tbegin(); c->tmark("begin");
-  int rc = ensure_entropy_workspace(c, span + FLUSH + 4096, 0);         // (never re-allocated between spans: the carried atoms live in it)
+  // (The entropy workspace is booked once, for the largest request a span can make -- range_open asks for its guess plus the carried atoms, fewer than a
+  // flush --, so that it is never booked anew between spans: the carried atoms live in it.  A span with more atoms than the guess enlarges it through
+  // range_lz's grow_atoms, which keeps them.)
+  const uint64_t pct = c->knob_atoms_pct < 1 ? 1 : c->knob_atoms_pct > 100 ? 100 : (uint64_t)c->knob_atoms_pct;
+  const uint64_t sguess = span / 100 * pct + (1u << 20);
+  int rc = ensure_entropy_workspace(c, (sguess < span ? sguess : span) + FLUSH + 4096, 0, span + FLUSH + 4096);
   if (rc) return rc;
   GlobalState entry{0, SYNC_F, 0};
   uint64_t G = 0, ws_prev = 0, carry_first_byte = 0, base_bytes = 0;
