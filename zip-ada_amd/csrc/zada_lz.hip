@@ -1864,6 +1864,9 @@ __global__ void __launch_bounds__(1024) k_list_flagged(const uint8_t *__restrict
   if (f) list[wbase + wcnt[w] + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = i;
 }
 
+#ifdef ZADA_RESPEC_STATS
+__device__ unsigned long long g_respec_dbg[4];
+#endif
 __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict__ spec_tok, uint32_t *__restrict__ spec_cnt,
                              uint32_t *__restrict__ Fbits, uint32_t *__restrict__ Lbits, ExitState *__restrict__ exits,
                              DemandMarker dm, const uint32_t *__restrict__ list /* null: every chunk */, const uint32_t *__restrict__ list_n,
@@ -1878,6 +1881,10 @@ __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict_
   if (io.segend) io.n = io.segend[((uint64_t)k * PCHUNK) >> 15] & 0x7FFFFFFFu;     // a batch: the input ends where the chunk's entry ends
   uint32_t ntok = 0;
   ExitState ex;
+#ifdef ZADA_RESPEC_STATS   /* how many of a later round's parses change anything: the chunk's old tokens and exit against the new ones */
+  uint32_t old_h = 0, old_n = 0; ExitState old_ex{0, 0};
+  if (list) { old_n = spec_cnt[k]; old_ex = exits[k]; const uint32_t *ot = spec_tok + (uint64_t)k * PTOK_STRIDE; for (uint32_t i = 0; i < old_n; i++) old_h = old_h * 0x9E3779B1u + ot[i]; }
+#endif
   __shared__ uint64_t lines[8 * 64];
   __shared__ uint32_t tbuf[PS_TOKS * 64];
   __shared__ uint32_t blines[PS_BWORDS * 64];
@@ -1888,6 +1895,14 @@ __global__ void k_parse_spec(ParseIO io, uint32_t nchunks, uint32_t *__restrict_
   ntok = ts.n;
   spec_cnt[k] = ntok;
   exits[k] = ex;
+#ifdef ZADA_RESPEC_STATS
+  if (list) {
+    __threadfence();
+    uint32_t new_h = 0; const uint32_t *nt = spec_tok + (uint64_t)k * PTOK_STRIDE; for (uint32_t i = 0; i < ntok; i++) new_h = new_h * 0x9E3779B1u + nt[i];
+    atomicAdd(&g_respec_dbg[0], 1ull);
+    if (new_h == old_h && ntok == old_n && ex.pos == old_ex.pos && ex.kind == old_ex.kind) atomicAdd(&g_respec_dbg[1], 1ull);
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2511,6 +2526,9 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       fprintf(stderr, "[lz round %d] %s parse of %u chunks, splice iterations so far %d, blocks with demanded positions %u of %u, demand %u%s\n", demand_rounds, first || nl > (uint32_t)(c->knob_exact_respec > 0 ? c->knob_exact_respec : 0) ? "speculative" : "exact",
               first ? nch : nl, rounds, nmark, nbd, ndem, slow ? " (slow splice)" : "");
     }
+#ifdef ZADA_RESPEC_STATS
+    if (!first) { unsigned long long h[4]; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_respec_dbg), sizeof h); fprintf(stderr, "[respec round %d] %llu chunks parsed again, %llu of them with the same tokens and exit as before\n", demand_rounds, h[0], h[1]); h[0] = h[1] = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_respec_dbg), h, sizeof h); }
+#endif
     if (restart) { restart = false; first_again = true; continue; }
     if (ndem == 0 && !slow) break;
     demand_rounds++;
