@@ -9,7 +9,10 @@
 //                    nearest true 3 .. 2+NLEVELS byte match of every position, sorted orders, tail tables.  From 64 MiB on
 //                    a workgroup takes a RUN of segments and makes the cross links of all but the run's first itself
 //   k_cross_links    links the first position of each bucket to the previous segment's tail (with runs: a run's first segment)
-//   k_cross_dist     continues the nearest-match searches that did not end inside their own segment
+//   k_bloom4         per segment a Bloom filter of its four-byte values (round 6)
+//   k_cross_dist     continues the nearest-match searches that did not end inside their own segment: a sweep over all positions that asks the
+//                    previous segment's filter before a level-4 walk and walks at most 16 steps, a second pass over the list of the walks still open
+//   k_cross_scan     the longest of those walks, by reading the text backwards with a whole wave
 //   k_bucket_limits  the chain-length limits (max_chain_length, and a quarter of it: :733-735) as distances
 //   k_match          Longest_Match (:715-825), BOUNDED, for every position; window + links staged in LDS;
 //                    full-chain and quarter-chain results, or a guess when the budget ran out
@@ -18,6 +21,7 @@
 //   k_parse_fix      re-parses from the previous chunk's true exit state until it meets a
 //                    history-free state of the speculative parse (splice); iterated to a fixpoint
 //   k_match_demand   exact Longest_Match of the marked guesses, one wave per position over the sorted order
+//   k_parse_spec_exact   (round 6) short lists of flagged chunks: one wave per chunk, the exact search inside the parse
 //   k_tok_count / k_tok_compact   gather the true tokens into one global atom array
 //   lz_stage         host driver: first pass, then parse / demand rounds until a parse has used exact values only
 //
