@@ -123,7 +123,10 @@ struct MatchPair { uint32_t full, quarter; };
 // it and marks it DEMANDed; demanded positions are then searched to the end, the parses that used a value which
 // changed are redone, and so on until a parse has used exact values only (zada_lz.hip, lz_stage).
 constexpr uint32_t M_GUESS = 0x80000000u, M_DEMAND = 0x40000000u, M_BYSPEC = 0x20000000u, M_HAVEQ = 0x10000000u, M_VALUE = 0x01FFFFFFu;   // M_BYSPEC: demanded by a speculative parse
-struct NoGuess { ZADA_HD void operator()(uint32_t, uint32_t) const {} };
+// A guess record carries, in the seven bits above its quarter value, the smallest "length to beat" any speculative parse had when it landed on it
+// (parse_step only asks whether the record's length exceeds the state's match length; 127 stands for "127 or more"; zada_lz.hip, DemandMarker / store_result).
+constexpr uint32_t M_BEAT_SHIFT = 25, M_BEAT_MAX = 127;
+struct NoGuess { ZADA_HD void operator()(uint32_t, uint32_t, uint32_t, uint32_t) const {} };
 struct ParseIO { const uint8_t *in; uint64_t n; const MatchPair *M; LzConfig cfg; const uint32_t *segend; };   // segend: see Layout
 // Where the entries of a batch lie in the LZ buffer (csrc/zada_lz.hip "Layout of the LZ buffer"); segend = nullptr: one stream [0, n)
 struct Layout { const uint32_t *segend; uint64_t n; };
@@ -169,7 +172,7 @@ ZADA_HD void run_parser(ParseState &s, const ParseIO &io, Sink &&sink, OnTop &&o
     uint32_t m = 0;
     if (srch) {
       const MatchPair mm = fetch(s.p);
-      if (mm.full & M_GUESS) on_guess(s.p, mm.full);
+      if (mm.full & M_GUESS) on_guess(s.p, mm.full, mm.quarter, s.mlen);
       m = (parse_need_quarter(s, io.cfg) ? mm.quarter : mm.full) & M_VALUE;
     }
     const uint32_t bb = s.avail ? fetch_byte(fetch, io.in, s.p - 1) : 0;

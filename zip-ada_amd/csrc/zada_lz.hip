@@ -1471,7 +1471,7 @@ __global__ void __launch_bounds__(1024) k_match(const uint8_t *__restrict__ in, 
     if (state == 1 && ++age >= mybudget) {
       const uint32_t packed = best >= 3 ? ((uint32_t)best << 16) | bdist : 0u;
       // (k_match_demand takes the search up where it stops here: the next candidate, as a distance, goes with the guess)
-      MatchPair r; r.full = packed | M_GUESS | (have_q ? M_HAVEQ : 0u); r.quarter = have_q ? rq : packed;
+      MatchPair r; r.full = packed | M_GUESS | (have_q ? M_HAVEQ : 0u); r.quarter = (have_q ? rq : packed) | (M_BEAT_MAX << M_BEAT_SHIFT);   // (length to beat: none asked yet)
       M[B + kpos] = r;
       resume[B + kpos] = (uint16_t)(wi - cur);
       state = 0;
@@ -1522,7 +1522,7 @@ static_assert(MB % DMB == 0 && DM_WBYTES % 16 == 0 && sizeof(ScanDesc) == 32, "d
 __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *__restrict__ in, Layout L, DistPlanes dp, RunPtrs rp,
                                                              const uint16_t *__restrict__ tailsK, MatchPair *__restrict__ M, int nice_cfg,
                                                              const uint32_t *__restrict__ blk_demand, uint32_t *__restrict__ dbits, uint8_t *__restrict__ chg,
-                                                             const ExitState *__restrict__ spec_exits, const uint16_t *__restrict__ resume) {
+                                                             const ExitState *__restrict__ spec_exits, const uint16_t *__restrict__ resume, bool use_beat) {
   if (blk_demand[xcd_block()] == 0) return;
   const uint64_t B = (uint64_t)xcd_block() * DMB;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1550,7 +1550,8 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
   auto store_result = [&](uint64_t p, uint32_t full, uint32_t quarter, uint32_t og_full, uint32_t og_quarter, bool reach) {
     MatchPair r; r.full = full; r.quarter = quarter;
     M[p] = r;
-    if ((og_full & M_BYSPEC) && (full != (og_full & M_VALUE) || quarter != og_quarter)) {
+    const uint32_t beat = use_beat ? og_quarter >> M_BEAT_SHIFT : 0u, ogq = og_quarter & M_VALUE;      // (the first parse leaves no length to beat: every change counts)
+    if ((og_full & M_BYSPEC) && ((full != (og_full & M_VALUE) && (full >> 16) > beat) || (quarter != ogq && (quarter >> 16) > beat))) {
       const uint64_t ch = p / PCHUNK;
       chg[ch] = 1;
       if (reach) chg[ch - 1] = 1;
@@ -1622,7 +1623,7 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
         const uint32_t gl = (og.full & M_VALUE) >> 16;
         if (gl >= 3) { best = (int)gl; bdist = og.full & 0xFFFFu; }
         have_q = (og.full & M_HAVEQ) != 0;
-        if (have_q) qbest = og.quarter;
+        if (have_q) qbest = og.quarter & M_VALUE;
         const uint64_t q = p - resume[p];
         const uint32_t iq = rp.idx[q];
         const uint32_t skip = q >= (seg << 15) ? idx1 - 1 - iq : c1 + (idx2 - iq);   // candidates nearer than q
@@ -1763,8 +1764,17 @@ __global__ void k_demand_all(Layout L, MatchPair *__restrict__ M, uint32_t *__re
 // flag per k_match_demand block (so that the demand pass skips blocks without work) and a grand total for the host.
 struct DemandMarker {
   MatchPair *M; uint32_t *blk_demand; uint32_t *n_demand; uint32_t by;   // by = M_BYSPEC for the speculative parse, 0 for the splice
+  bool track = false;                                                    // the speculative parses from the second round on leave their length to beat (below)
   uint32_t *dbits;                                                       // one bit per position: to be searched in the next demand pass
-  __device__ void operator()(uint32_t p, uint32_t full) const {
+  __device__ void operator()(uint32_t p, uint32_t full, uint32_t quarter, uint32_t beat) const {
+    // Round 6: a speculative parse leaves the length its state has to beat with the guess (the smallest over the parses that land there: the chunk's own
+    // and the chunk before's, if it ran over): the exact value changes the parse only if its length exceeds that -- a lazy look-up that was "not longer"
+    // with the guess and still is with the exact value decides the same (85 - 93 % of the chunks the third and fourth demand pass flagged, measured).
+    // Not in the FIRST parse: one more atomic per landed guess, 21 M of them, cost its 2 M lanes 2 ms for a list 12 % shorter; a guess that a later parse
+    // lands on has never been landed on before (the first demand pass made every one of those exact), so every parse that uses it has left its length.
+    // (`quarter` is the word as the parse read it: an atomic only where it lowers what stands there, and nothing is waited for)
+    if (track && (beat < M_BEAT_MAX ? beat : M_BEAT_MAX) < (quarter >> M_BEAT_SHIFT))
+      __hip_atomic_fetch_min(&M[p].quarter, (quarter & M_VALUE) | ((beat < M_BEAT_MAX ? beat : M_BEAT_MAX) << M_BEAT_SHIFT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t want = M_DEMAND | by;
     if ((full & want) == want) return;
     // plain stores: every concurrent writer of these words writes a value that only adds flags
@@ -1968,7 +1978,7 @@ struct WaveExact {
       const uint32_t gl = (og.full & M_VALUE) >> 16;
       if (gl >= 3) { bst = (int)gl; bd = og.full & 0xFFFFu; }
       hq = (og.full & M_HAVEQ) != 0;
-      if (hq) rqq = og.quarter;
+      if (hq) rqq = og.quarter & M_VALUE;
       const uint64_t q = p - resume[p];
       const uint32_t iq = rp.idx[q];
       const uint32_t skip = q >= (seg << 15) ? idx1 - 1 - iq : c1 + (idx2 - iq);   // candidates nearer than q
@@ -2461,6 +2471,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   bool restart = false, first_again = false;
   for (bool first = true;; first = false) {
     if (first_again) { first = true; first_again = false; }
+    const bool beat_valid = !first;                                  // the guesses this round's speculative parse lands on carry their length to beat (list parses only)
     // speculative parse: every chunk the first time, afterwards the chunks flagged by the demand pass
     if (first) hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
                                   W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
@@ -2480,8 +2491,9 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
         hipLaunchKernelGGL(k_parse_spec_exact, dim3(256 * 5), dim3(64 * PX_WAVES), 0, st, io, nch, W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits,
                            wx, (const uint32_t *)W.offsets, (const uint32_t *)(W.n_changed + 2), exact_max);
       }
+      DemandMarker dmt = dm; dmt.track = true;
       hipLaunchKernelGGL(k_parse_spec, dim3((nch + 63) / 64), dim3(64), 0, st, io, nch,
-                         W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dm, (const uint32_t *)W.offsets, (const uint32_t *)(W.n_changed + 2), exact_max);
+                         W.spec_tok, W.spec_cnt, W.Fbits, W.Lbits, W.spec_exits, dmt, (const uint32_t *)W.offsets, (const uint32_t *)(W.n_changed + 2), exact_max);
     }
     // fixpoint of the splice, from scratch: round 0 handles every chunk with the speculative exits as entries
     hipMemcpyAsync(W.true_exits, W.spec_exits, (size_t)nch * sizeof(ExitState), hipMemcpyDeviceToDevice, st);
@@ -2544,7 +2556,7 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       hipLaunchKernelGGL(k_demand_all, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, L, W.M, W.blk_demand, W.dbits);
     }
     hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, L, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
-                       W.blk_demand, W.dbits, W.chg, W.spec_exits, W.lprev[0]);
+                       W.blk_demand, W.dbits, W.chg, W.spec_exits, W.lprev[0], beat_valid);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
   }
   c->demand_rounds += demand_rounds;
