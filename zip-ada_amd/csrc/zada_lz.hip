@@ -2448,7 +2448,9 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
   const uint32_t nch = (uint32_t)((n + PCHUNK - 1) / PCHUNK);
   const int max_rounds = c->knob_max_demand_rounds;     // demand rounds before everything that is still a guess is searched
   // (below 2 MiB the rounds cost more launches than the bounded search saves)
-  int budget_env = c->knob_budget >= 0 ? c->knob_budget : (n < (2u << 20) ? 0 : 8);
+  // (round 6: six rounds from 512 MiB on -- the later demand rounds got cheaper, the flat optimum of 6 - 8 moved: 5 / 6 / 7 / 8 / 10 rounds give
+  // 115.5 / 115.2 / 115.4 / 115.9 / 116.0 ms per GiB, k_match 27.6 ... 37.1 against parse 32.6 ... 23.7; at 256 MiB 31.7 against 31.5 ms for 6 / 8)
+  int budget_env = c->knob_budget >= 0 ? c->knob_budget : (n < (2u << 20) ? 0 : n < (512u << 20) ? 8 : 6);
   if (budget_env < 1) budget_env = 1 << 20;
   const uint32_t nbd = (uint32_t)((n + DMB - 1) / DMB);
   hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
