@@ -80,6 +80,7 @@ const char *zada_version(void);
  * "max_demand_rounds" (ZADA_MAX_DEMAND_ROUNDS), "exact_respec" (ZADA_EXACT_RESPEC: lists of up to this many flagged 512-byte chunks are parsed again by
  * one wave per chunk with the exact match search inside the parse, default 32768; 0 = never), "cd_filter" (ZADA_CD_FILTER: 1 = the cross-segment
  * continuation of the four-byte searches asks a Bloom filter of the previous segment first and leaves long walks to a second pass, 0 = one pass as in rounds 1-5),
+ * "cd_list_cap" (test knob: entries of that pass's list of open walks, 0 = by size; a full list leaves the walks where they are),
  * "atoms_pct" (ZADA_ATOMS_PCT: the atom arrays of a stream start with room for this many atoms per 100 input bytes, default 50, and grow when the match finder
  * writes more -- one atom per byte is the worst case), "fix_stride" (test knob: token slots per 512-byte chunk the parse splice starts with, 0 = 128; a splice that
  * needs more gets the full 1152 and the parse starts again), "inner_budget" (ZADA_INNER_BUDGET), "shard_kib" (ZADA_SHARD_KIB: KiB of

@@ -452,3 +452,20 @@ def test_workspace_guesses_that_turn_out_too_small(encoder):
             assert dict(encoder.last_timing()).get("#atoms_grown", 0) >= 0
     finally:
         encoder.set_knob("atoms_pct", 50); encoder.set_knob("fix_stride", 0); encoder.set_knob("shard_kib", 1 << 20); encoder.set_knob("span_mib", 2048)
+
+
+def test_cross_segment_walks_with_lists_that_overflow(encoder):
+    """k_cross_dist (round 6) puts the level-4 walks its sweep leaves open on a list for a second pass, and the longest of those on a second list for a
+    wave that reads the text backwards; a list that is full leaves the walk where it is.  With lists of 1, 7 and 300 entries ("cd_list_cap") nearly every
+    open walk takes that path -- streams of every kind still the oracle's; the few-symbol inputs are where walks are long."""
+    rng = np.random.default_rng(31)
+    inputs = [silesia_mix((5 << 20) + 77, version=2), bytes((rng.integers(0, 3, 3 << 20) + 65).astype(np.uint8)), silesia_mix(3 << 20, class_mask=16, version=2) + bytes(100000) + silesia_mix(1 << 20, class_mask=2)]
+    refs = [oracle_deflate(d, 10) for d in inputs]
+    try:
+        for cap in (1, 7, 300, 0):
+            encoder.set_knob("cd_list_cap", cap)
+            for d, (rc, ref, crc) in zip(inputs, refs):
+                rc2, out, crc2 = gpu_deflate(encoder, d, 10)
+                assert rc == rc2 and (rc != 0 or (out == ref and crc == crc2)), (cap, len(d))
+    finally:
+        encoder.set_knob("cd_list_cap", 0)

@@ -1093,6 +1093,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "atoms_pct")) { if (value < 1 || value > 100) return ZADA_E_INVALID; z->c.knob_atoms_pct = value; z->c.ws.cap_atoms = 0; }   // (the next call books the entropy workspace anew)
   else if (!strcmp(name, "fix_stride")) { if (value < 0 || value > (int)PTOK_STRIDE) return ZADA_E_INVALID; z->c.knob_fix_stride = value; z->c.ws.cap_n = 0; }
+  else if (!strcmp(name, "cd_list_cap")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_cd_list_cap = value; }
   else if (!strcmp(name, "cd_filter")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_cd_filter = value; }
   else if (!strcmp(name, "exact_respec")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_exact_respec = value; }
   else if (!strcmp(name, "max_demand_rounds")) z->c.knob_max_demand_rounds = value > 0 ? value : 12;

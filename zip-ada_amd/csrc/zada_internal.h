@@ -283,6 +283,7 @@ struct Ctx {
   int knob_max_demand_rounds = 12;  // ZADA_MAX_DEMAND_ROUNDS
   int knob_atoms_pct = 50;          // "atoms_pct": the atom arrays of a stream start with room for this many atoms per 100 input bytes (they grow when a shard has more: one atom per byte is the worst case, the benchmark stream has 0.3)
   int knob_fix_stride = 0;          // "fix_stride" (test knob): token slots per chunk the splice starts with (0 = FIX_STRIDE_SMALL)
+  int knob_cd_list_cap = 0;         // "cd_list_cap" (test knob): entries of k_cross_dist's list of open walks (0 = by size; its second list a quarter of it) -- a full list leaves the walks in the sweep
   int knob_cd_filter = 1;           // "cd_filter" / ZADA_CD_FILTER: k_cross_dist asks a Bloom filter of the previous segment's four-byte values before a level-4 walk, walks at most six steps in its sweep and leaves longer walks to a second, packed pass (0: one pass, no filter, no limit -- rounds 1-5)
   int knob_exact_respec = 32768;    // "exact_respec" / ZADA_EXACT_RESPEC: lists of up to this many flagged chunks are parsed again by one wave per chunk with the exact search inside the parse (0: never -- the lane-per-chunk parse with guesses in every round, as in rounds 1-5)
   int knob_bz_pipe_prio = 0;        // "bz_pipe_prio": 1 = the worker stream of the BZip2 pipeline (entropy stage of the batch before) has the lowest priority (measured: no gain)

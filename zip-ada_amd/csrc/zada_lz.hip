@@ -2370,7 +2370,8 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
       hipMemsetAsync(W.n_changed + 4, 0, 4, st);
       hipLaunchKernelGGL(k_bloom4, dim3(nseg - 1), dim3(256), 0, st, W.in, L, W.bloom4, 0u);
       hipMemsetAsync(W.n_changed + 5, 0, 4, st);
-      const CdTail tl{W.bloom4, W.cd_list, W.n_changed + 4, (uint32_t)W.cd_cap, W.cd_list + W.cd_cap, W.n_changed + 5, (uint32_t)(W.cd_cap / 4)};
+      const uint32_t lcap = c->knob_cd_list_cap > 0 && (uint64_t)c->knob_cd_list_cap < W.cd_cap ? (uint32_t)c->knob_cd_list_cap : (uint32_t)W.cd_cap;
+      const CdTail tl{W.bloom4, W.cd_list, W.n_changed + 4, lcap, W.cd_list + W.cd_cap, W.n_changed + 5, lcap / 4};
       hipLaunchKernelGGL(k_cross_dist<CD_SWEEP>, dim3(nb), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)32768, (uint64_t)n, tl);
       hipLaunchKernelGGL(k_cross_dist<CD_LIST>, dim3((uint32_t)((W.cd_cap + CD_THREADS - 1) / CD_THREADS)), dim3(CD_THREADS), 0, st, W.in, L, lv, W.S3, W.T3, W.bsc3, dpl, (uint64_t)0, (uint64_t)n, tl);
       hipLaunchKernelGGL(k_cross_scan, dim3(2048), dim3(256), 0, st, W.in, L, dpl, tl);
