@@ -70,55 +70,75 @@ __device__ __forceinline__ bool flush_geom(const EntropyView &v, uint32_t j, uin
 }
 
 // --------------------------------------------------------------------------------------------
-// k_window_descr : one wave per (flush segment, slot)
+// k_window_descr : one wave per flush segment and GROUP of WD_GROUP neighbouring slots
+// Round 6: neighbouring sliding windows (750 atoms apart, 4 097 atoms each) share 82 % of their atoms: a wave takes WD_GROUP slots one after the other and
+// moves the histogram from one window to the next -- the 750 atoms that leave are taken off, the 750 that come are added (1 500 visits instead of
+// 4 097) -- instead of counting every window from nothing.  The distance patch works in place: the raw distance counts wait in registers.  (Slot 0 -- the flush's initial window --, the empty windows of the null-slice quirk and the first window of a group are counted whole.)
 // --------------------------------------------------------------------------------------------
+#ifndef ZADA_WD_GROUP
+#define ZADA_WD_GROUP 4
+#endif
+constexpr uint32_t WD_GROUP = ZADA_WD_GROUP, WD_NGROUPS = (SLOTS + WD_GROUP - 1) / WD_GROUP;
 __global__ void __launch_bounds__(64) k_window_descr(EntropyView v, uint32_t kstep, uint8_t *__restrict__ descr) {
   __shared__ uint32_t hist[320];
   __shared__ uint8_t bl[320];
   __shared__ __attribute__((aligned(16))) uint8_t S[LLHC_WAVE_SCRATCH];
   const uint32_t *__restrict__ atoms = v.atoms;
-  const uint32_t slot = blockIdx.x % SLOTS, j = blockIdx.x / SLOTS;       // j: owned flush (local number)
+  const uint32_t grp = blockIdx.x % WD_NGROUPS, j = blockIdx.x / WD_NGROUPS;   // j: owned flush (local number)
   uint64_t gj; uint32_t F, to, fl;                                          // its number in the stream, its first and last atom
   if (!flush_geom(v, j, F, to, gj, fl)) return;
   if (to - F < SLIDER - 1) return;                                  // :1333-1336 short flush: no scanning
-  int64_t lo, hi;
-  if (slot == 0) { lo = (gj == 0) ? (int64_t)F : (int64_t)F - HALF_SLIDER; hi = lo + SLIDER - 1; }   // :1338-1360
-  else {
-    const uint32_t m = F + MIN_STEP * slot;
-    if (!((uint64_t)m + HALF_SLIDER < to)) return;                  // :1364
-    if (slot % kstep) return;
-    lo = (int64_t)m - HALF_SLIDER; hi = (int64_t)m + HALF_SLIDER;
-    // ring-index wrap => Ada null slice (:1372): first-half flushes only
-    if ((gj & 1) == 0 && MIN_STEP * slot < HALF_SLIDER) { lo = 0; hi = -1; }
-  }
   const int lane = threadIdx.x;
-  for (int i = lane; i < 320; i += 64) hist[i] = (i == 256) ? 1u : 0u;     // empty_lit_len_stat :946
-  __syncthreads();
-#ifdef ZADA_WD_NOHIST   /* timing experiment only (wrong results): the window's first 64 * 8 atoms stand for all of them */
-  for (int64_t a0 = lo + lane; a0 <= hi && a0 < lo + 512; a0 += 64 * 8) {
-#else
-  for (int64_t a0 = lo + lane; a0 <= hi; a0 += 64 * 8) {              // eight loads in flight, then their counts
-#endif
-    uint32_t at[8];
+  // counts of the atoms [a, b] go to (add) or leave (!add) the histogram, eight loads in flight, then their counts
+  auto count = [&](int64_t a, int64_t b, bool add) {
+    for (int64_t a0 = a + lane; a0 <= b; a0 += 64 * 8) {
+      uint32_t at[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { const int64_t a = a0 + 64 * u; at[u] = atoms[a <= hi ? a : hi]; }
+      for (int u = 0; u < 8; u++) { const int64_t x = a0 + 64 * u; at[u] = atoms[x <= b ? x : b]; }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if (a0 + 64 * u <= hi) {
-        int ls, ds; atom_symbols(at[u], ls, ds);
-        atomicAdd(&hist[ls], 1u);
-        if (ds >= 0) atomicAdd(&hist[288 + ds], 1u);
+      for (int u = 0; u < 8; u++) {
+        if (a0 + 64 * u <= b) {
+          int ls, ds; atom_symbols(at[u], ls, ds);
+          if (add) { atomicAdd(&hist[ls], 1u); if (ds >= 0) atomicAdd(&hist[288 + ds], 1u); }
+          else { atomicSub(&hist[ls], 1u); if (ds >= 0) atomicSub(&hist[288 + ds], 1u); }
+        }
       }
     }
-  }
-  __syncthreads();
-  if (lane == 0) patch_dist_stats(hist + 288);
-  __syncthreads();
+  };
+  bool have = false;                                                 // `hist` holds the counts of the window [plo, phi]
+  int64_t plo = 0, phi = -1;
+  for (uint32_t slot = grp * WD_GROUP; slot < (grp + 1) * WD_GROUP && slot < SLOTS; slot++) {
+    int64_t lo, hi;
+    if (slot == 0) { lo = (gj == 0) ? (int64_t)F : (int64_t)F - HALF_SLIDER; hi = lo + SLIDER - 1; }   // :1338-1360
+    else {
+      const uint32_t m = F + MIN_STEP * slot;
+      if (!((uint64_t)m + HALF_SLIDER < to)) break;                   // :1364 (nor any later slot)
+      if (slot % kstep) continue;
+      lo = (int64_t)m - HALF_SLIDER; hi = (int64_t)m + HALF_SLIDER;
+      // ring-index wrap => Ada null slice (:1372): first-half flushes only
+      if ((gj & 1) == 0 && MIN_STEP * slot < HALF_SLIDER) { lo = 0; hi = -1; }
+    }
+    __syncthreads();
+    const bool slide = have && slot != 0 && hi >= lo && lo > plo && lo <= phi && hi > phi;      // the window before overlaps this one
+    if (slide) { count(plo, lo - 1, false); count(phi + 1, hi, true); }
+    else {
+      for (int i = lane; i < 320; i += 64) hist[i] = (i == 256) ? 1u : 0u;     // empty_lit_len_stat :946
+      __syncthreads();
+      count(lo, hi, true);
+    }
+    have = hi >= lo && slot != 0; plo = lo; phi = hi;
+    __syncthreads();
+    const uint32_t raw_dist = lane < 32 ? hist[288 + lane] : 0u;      // (the patch changes the distance counts in place: the raw ones go on to the next window)
+    __syncthreads();
+    if (lane == 0) patch_dist_stats(hist + 288);
+    __syncthreads();
 #pragma unroll 1
-  for (int t = 0; t < 2; t++) llhc_wave<15>(hist + 288 * t, t ? 32 : 288, bl + 288 * t, S, lane);
-  __syncthreads();
-  uint8_t *dst = descr + ((uint64_t)j * SLOTS + slot) * 320;
-  for (int i = lane; i < 320; i += 64) dst[i] = bl[i];
+    for (int t = 0; t < 2; t++) llhc_wave<15>(hist + 288 * t, t ? 32 : 288, bl + 288 * t, S, lane);
+    __syncthreads();
+    if (lane < 32) hist[288 + lane] = raw_dist;
+    uint8_t *dst = descr + ((uint64_t)j * SLOTS + slot) * 320;
+    for (int i = lane; i < 320; i += 64) dst[i] = bl[i];
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1065,7 +1085,7 @@ int entropy_analyze(Ctx *c) {
       hipLaunchKernelGGL(k_fill_blocks_fixed, dim3((nblocks + 255) / 256), dim3(256), 0, st, v.foff, v.lvalid - v.foff, nblocks, W.blocks);
     } else {
       const uint32_t kstep = fixed_only ? (1u << 30) : R.method == 8 ? 8 : R.method == 9 ? 4 : 1;   // max_choice :1310-1311 (Deflate_Fixed in a batch: no scanning, one block per flush)
-      if (!fixed_only) hipLaunchKernelGGL(k_window_descr, dim3(v.nflush * SLOTS), dim3(64), 0, st, v, kstep, W.descr);
+      if (!fixed_only) hipLaunchKernelGGL(k_window_descr, dim3(v.nflush * WD_NGROUPS), dim3(64), 0, st, v, kstep, W.descr);
       c->tmark("window_descr");
       hipLaunchKernelGGL(k_cut_scan, dim3(v.nflush), dim3(64), 0, st, v, kstep, W.descr, W.seg_nblk, W.seg_cut, W.cut_trace);
       exclusive_scan_u32(st, W.seg_nblk, W.seg_blk_off, W.scan2, W.total2, v.nflush);
