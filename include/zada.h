@@ -239,6 +239,16 @@ int zada_lzma(zada_ctx *ctx, int method, const uint8_t *in, uint64_t n, uint8_t 
               zada_feedback_fn fb, void *user);
 /* the same with input and output in device memory (d_out: cap bytes) */
 int zada_lzma_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len, uint32_t *crc_inout);
+/* A stream that stopped between two launches (its feedback returned non-zero: ZADA_ABORTED) can be taken up again -- by this context, another one or
+ * another process: zada_lzma_export_state copies out the coder's state (*state_len bytes: the probability model, the range coder, the window
+ * bookkeeping; state_cap must hold them -- call with state = NULL to learn the length) and the stream bytes written so far (*out_bytes of them into
+ * `out`, NULL to skip; *positions = input positions coded); zada_lzma_import_state hands a state to a context, whose NEXT zada_lzma call -- same
+ * input, same method -- goes on from there and returns the whole stream's length, with its output buffer valid from byte *out_bytes of the export on
+ * (the bytes before are the export's).  The match sets of LZMA_3 are a function of the input alone: the resumed call makes them again.  This is
+ * Feedback / User_abort (zip-compress-lzma_e.adb:78-92) turned into a checkpoint: a stream that takes longer than one call may run is coded in two. */
+int zada_lzma_export_state(zada_ctx *ctx, uint8_t *state, uint64_t state_cap, uint64_t *state_len, uint8_t *out, uint64_t out_cap, uint64_t *out_bytes,
+                           uint64_t *positions);
+int zada_lzma_import_state(zada_ctx *ctx, const uint8_t *state, uint64_t state_len);
 /* Many entries, one launch of the coder for all of them.  Arrays as for zada_deflate_batch; rc[i] is zada_lzma's return code
  * for entry i.  Returns the worst rc. */
 int zada_lzma_batch(zada_ctx *ctx, int method, int count, const uint8_t *const *in, const uint64_t *n, uint8_t *const *out,

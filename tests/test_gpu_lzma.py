@@ -370,3 +370,34 @@ def test_stream_in_bounded_launches_feedback_and_abort(encoder):
     finally:
         encoder.set_knob("lzma_dict", 0)
         encoder.set_knob("lzma_chunk", 0)
+
+
+def test_a_stream_stopped_by_its_feedback_goes_on_in_another_context():
+    """zada_lzma_export_state / zada_lzma_import_state (round 6): a stream that its feedback stops between two launches (User_abort,
+    zip-compress-lzma_e.adb:78-92) is taken up by ANOTHER context from the exported state -- same input, same method; the match sets are made
+    again, the launches up to the state's position code nothing -- and the exported stream bytes followed by the resumed call's bytes from that length on
+    are the oracle's payload.  LZMA_3 (BT4 producer in segments, helper waves) and LZMA_2 (tokens of the Info-Zip matcher), stops at two places, and a
+    state handed to the wrong input is refused by the coder's own end check or gives a different stream -- never silently the right one."""
+    from _common import product, silesia_mix
+    from _lzmah import oracle_lzma
+    Z = product()
+    d = silesia_mix((1 << 20) + 4321, version=2)
+    for method, chunk in ((18, 20000), (17, 60000)):
+        want = oracle_lzma(d, method)
+        for stop_pct in (30, 80):
+            a = Z.Encoder(0)
+            a.set_knob("lzma_chunk", chunk)
+            seen = []
+            with pytest.raises(Z.UserAbort):
+                a.lzma(d, method, feedback=lambda pct: seen.append(pct) or pct >= stop_pct)
+            state, head, pos = a.lzma_export_state(len(d) + 4096)
+            a.close()
+            assert 0 < pos < len(d) and seen[-1] >= stop_pct
+            b = Z.Encoder(0)                                            # another context: nothing of the first one's device memory is there
+            b.set_knob("lzma_chunk", chunk)
+            b.lzma_import_state(state)
+            rc, z, crc = b.lzma(d, method)
+            assert (rc, head + z[len(head):], crc) == want, (method, stop_pct, pos, len(head))
+            rc2, z2, crc2 = b.lzma(d, method)                           # (the state was for one call: the next one starts at the first byte)
+            assert (rc2, z2, crc2) == want
+            b.close()

@@ -110,6 +110,8 @@ def load_library():
     L.zada_bzip2_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.zada_lzma.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p, vp, vp]
     L.zada_lzma_device.argtypes = [vp, i32, vp, u64, vp, u64, u64p, u32p]
+    L.zada_lzma_export_state.argtypes = [vp, vp, u64, u64p, vp, u64, u64p, u64p]
+    L.zada_lzma_import_state.argtypes = [vp, vp, u64]
     L.zada_lzma_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.zada_lzma_match_sets.argtypes = [vp, vp, u64, vp, vp, vp, i32]
     L.zada_bz2_last_blocks.restype = ctypes.c_uint64
@@ -253,6 +255,26 @@ class Encoder:
         if rc < 0:
             self._err(rc, "zada_lzma")
         return rc, (out.raw[:ol.value] if ol.value <= cap else None), c.value
+
+    def lzma_export_state(self, out_cap):
+        """After lzma() raised UserAbort (its feedback stopped the stream between two launches): (state bytes, the stream bytes written so far,
+        input positions coded).  zada_lzma_export_state."""
+        sl = ctypes.c_uint64(0)
+        self.lib.zada_lzma_export_state(self.ctx, None, 0, ctypes.byref(sl), None, 0, None, None)
+        state = ctypes.create_string_buffer(sl.value)
+        out = ctypes.create_string_buffer(int(out_cap))
+        ob, pos = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = self.lib.zada_lzma_export_state(self.ctx, ctypes.addressof(state), sl.value, ctypes.byref(sl), ctypes.addressof(out), int(out_cap), ctypes.byref(ob), ctypes.byref(pos))
+        if rc != 0:
+            self._err(rc, "zada_lzma_export_state")
+        return state.raw[:sl.value], out.raw[:ob.value], pos.value
+
+    def lzma_import_state(self, state):
+        """The NEXT lzma() call of this encoder -- same input, same method -- goes on from `state` (lzma_export_state of any context or process); its
+        payload is valid from the exported stream bytes' length on."""
+        rc = self.lib.zada_lzma_import_state(self.ctx, _addr(state), len(state))
+        if rc != 0:
+            self._err(rc, "zada_lzma_import_state")
 
     def lzma_batch(self, datas, method=18, crc=0xFFFFFFFF):
         """Independent LZMA payloads (one per Zip entry) in one call: every entry is a workgroup of ONE launch of the coder.

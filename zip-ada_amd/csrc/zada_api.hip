@@ -1441,7 +1441,14 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
   } else {
     const size_t save_bytes = (size_t)lzma_save_stride() * E;
     if ((rc = lz_grow(c, &c->lz_save, &c->cap_lz_save, save_bytes))) return rc;
-    hipMemsetAsync(c->lz_save, 0, save_bytes, c->stream);
+    // (a state from zada_lzma_import_state: ONE stream goes on from where an earlier call -- of another context, of another process -- stopped; the match
+    // sets are a function of the input alone, so the producer simply makes them again, and the launches up to the state's position code nothing)
+    const bool resume = E == 1 && c->lz_resume.size() == save_bytes;
+    auto fresh_state = [&]() {
+      if (resume) hipMemcpyAsync(c->lz_save, c->lz_resume.data(), save_bytes, hipMemcpyHostToDevice, c->stream);
+      else hipMemsetAsync(c->lz_save, 0, save_bytes, c->stream);
+    };
+    fresh_state();
     uint64_t total = 0;
     for (const LzmaJob &j : jobs) total += j.n;
     c->lzma_launches = 0;
@@ -1463,7 +1470,7 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
           c->bt4_reruns++;
           seg_shift = 32; cap = ~0ull;
           if ((rc = bt4_produce(c, jobs, d_in, arena_bytes, &sets, nullptr))) return rc;
-          hipMemsetAsync(c->lz_save, 0, save_bytes, c->stream);
+          fresh_state();
         } else {
           k++;
           if (k < nseg && (rc = bt4_walk_segment(c, k, c->stream2))) return rc;
@@ -1577,11 +1584,45 @@ int zada_lzma(zada_ctx *z, int method, const uint8_t *in, uint64_t n, uint8_t *o
   copy_in(c, c->ws.rin_own, in, n);
   uint8_t *d_out = c->ws.rin_own + ((n + 63) & ~63ull);
   uint64_t ol = 0;
+  c->lz_last_n = n; c->lz_last_out_off = (n + 63) & ~63ull;
   rc = finish_call(c, lzma_core(c, method, c->ws.rin_own, n, d_out, cap, &ol, crc_inout, fb, user));
+  c->lz_resume.clear();                                           // (an imported state is for one call)
   if (rc < 0 || rc == ZADA_ABORTED) return rc;
   if (out_len) *out_len = ol;
   if (ol <= cap && copy_out(c, out, d_out, ol)) return ZADA_E_HIP;
   return rc;
+}
+// A stream that stopped between two launches (its feedback said so: ZADA_ABORTED) can be taken up again -- by this context, another one, or another
+// process: export the coder's state and the stream bytes written so far, import the state into a context and call zada_lzma with the SAME input and
+// method again.  The second call's output buffer holds the whole stream's length with the bytes from *out_bytes of the export on; the bytes before are
+// the export's.  (The match producer's sets are a function of the input alone and are made again.)  This is how a stream that takes longer than a
+// machine lets one call run is coded in two (tests/gpu_lzma_c4.py: BASELINE config 4 on a pool that ends a call after an hour).
+int zada_lzma_export_state(zada_ctx *z, uint8_t *state, uint64_t state_cap, uint64_t *state_len, uint8_t *out, uint64_t out_cap, uint64_t *out_bytes, uint64_t *positions) {
+  if (!z) return ZADA_E_INVALID;
+  Ctx *c = &z->c;
+  const uint64_t sb = lzma_save_stride();
+  if (state_len) *state_len = sb;
+  if (!state) return ZADA_OK;                                      // (the length only)
+  if (!c->lz_save || c->cap_lz_save < sb || state_cap < sb) { c->err = "zada_lzma_export_state: no stopped stream, or the state buffer is too small"; return ZADA_E_INVALID; }
+  if (hipSetDevice(c->device) != hipSuccess) return ZADA_E_HIP;
+  if (hipMemcpy(state, c->lz_save, sb, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return ZADA_E_HIP; }
+  uint64_t pos = 0, olen = 0, n = 0;
+  if (!lzma_save_info(state, &pos, &olen, &n) || n != c->lz_last_n) { c->err = "zada_lzma_export_state: the last zada_lzma call did not stop between two launches of ONE stream"; return ZADA_E_INVALID; }
+  if (out_bytes) *out_bytes = olen;
+  if (positions) *positions = pos;
+  if (out) {
+    if (olen > out_cap) { c->err = "zada_lzma_export_state: output buffer too small"; return ZADA_E_INVALID; }
+    if (olen && copy_out(c, out, c->ws.rin_own + c->lz_last_out_off, olen)) return ZADA_E_HIP;
+  }
+  return ZADA_OK;
+}
+int zada_lzma_import_state(zada_ctx *z, const uint8_t *state, uint64_t state_len) {
+  if (!z) return ZADA_E_INVALID;
+  Ctx *c = &z->c;
+  uint64_t pos = 0, olen = 0, n = 0;
+  if (!state || state_len != lzma_save_stride() || !lzma_save_info(state, &pos, &olen, &n)) { c->err = "zada_lzma_import_state: not the state of a stopped stream"; return ZADA_E_INVALID; }
+  c->lz_resume.assign(state, state + state_len);
+  return ZADA_OK;
 }
 // Test hook: the match sets the BT4 producer leaves for ONE entry (the stage the coder reads; compare zo_bt4_match_sets of the
 // oracle): cnt [n], len / dist [n * stride] (stride >= 50).  The dictionary is the entry's size or the "lzma_dict" knob.

@@ -262,6 +262,8 @@ struct Ctx {
   void *lz_tab = nullptr; size_t cap_lz_tab = 0;     // LZMA (zada_lzma.hip): job table + results
   void *lz_save = nullptr; size_t cap_lz_save = 0;   // ... the coder's state between the launches of one stream
   int lzma_launches = 0;                             // launches the last chunked LZMA call took
+  std::vector<uint8_t> lz_resume;                    // zada_lzma_import_state: the coder's state the next zada_lzma call goes on from (one stream)
+  uint64_t lz_last_n = 0, lz_last_out_off = 0;       // the last zada_lzma call: its input length and where its stream lies in the context's buffer (zada_lzma_export_state)
   void *bt4 = nullptr;                               // ... the BT4 match producer's buffers (zada_bt4.hip), made on first use
   uint32_t bt4_buckets = 0, bt4_long = 0, bt4_overflow = 0;   // last producer run: hash-4 buckets, long ones among them, overflow blocks booked
   uint32_t bt4_pool_grown = 0;                       // the overflow pool of a stream's match sets was enlarged between two segments (since the context was made)
@@ -348,6 +350,7 @@ int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, co
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
                 uint8_t *d_save = nullptr, uint64_t budget = 0, uint64_t pos_cap = ~0ull, int waves = 1);
 uint64_t lzma_save_stride();
+int lzma_save_info(const uint8_t *blob, uint64_t *pos, uint64_t *olen, uint64_t *n);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes, uint64_t out_bytes = 0);   // out_bytes: the input the stream is made of (0: as many bytes as atoms)
 int ensure_crc_workspace(Ctx *c, uint64_t n);

@@ -1229,7 +1229,9 @@ template <bool HW> __global__ void __launch_bounds__(HW ? 64 * HELP_WAVES : 64, 
     words_in(s_P, &S->P); words_in(s_MM[0], &S->MM[0]); words_in(s_MM[1], &S->MM[1]); words_in(s_E, &S->E); words_in(s_B, &S->B);
     iter = S->iter; running = S->running != 0;
     __syncthreads();
-    if (threadIdx.x == 0) s_B.sets = sets;                          // (the producer's buffers of THIS call)
+    // (the producer's buffers of THIS call -- and the entry's and the stream's addresses: a state that zada_lzma_export_state took out of another context,
+    // or another process, goes on from where it stopped)
+    if (threadIdx.x == 0) { s_B.sets = sets; s_E.in = in_base + J.in_off; s_E.out = out_base + J.out_off; s_E.cap = J.cap; }
     __syncthreads();
   } else {
     {
@@ -1349,6 +1351,13 @@ int lzma_token_ranges(Ctx *c, uint32_t E, const uint32_t *d_apos, uint32_t T, co
 // `budget` more positions of every unfinished stream -- up to position pos_cap at most -- and flags bit 63 of its second result while there
 // is more to come); nullptr / 0: one launch.
 uint64_t lzma_save_stride() { return LZ_SAVE_STRIDE; }
+// what a saved state (host copy of one slot) says about itself: 1 = a stream under way, with the positions it has coded and the stream bytes it has written
+int lzma_save_info(const uint8_t *blob, uint64_t *pos, uint64_t *olen, uint64_t *n) {
+  const LzSave *S = (const LzSave *)blob;
+  if (S->phase != 1) return 0;
+  *pos = S->E.ES.pos; *olen = S->E.olen; *n = S->E.n;
+  return 1;
+}
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
                 uint8_t *d_save, uint64_t budget, uint64_t pos_cap, int waves) {
   if (count == 0) return 0;
