@@ -327,7 +327,9 @@ def config_4_log():
         return None
     try:
         d = json.load(open(best))
-        d["source"] = os.path.relpath(best, ROOT) + ": tests/gpu_lzma_c4.py, one run on one MI355X -- NOT part of this run"
+        d["source"] = os.path.relpath(best, ROOT) + (": tests/gpu_lzma_c4.py, ONE stream coded in TWO GPU calls on one MI355X each (the first stopped by its feedback, its state exported "
+                                                      "and imported: the pool ends a call after an hour) -- NOT part of this run" if "first_call" in d else
+                                                      ": tests/gpu_lzma_c4.py, one run on one MI355X -- NOT part of this run")
         d["is_config_4_itself"] = bool(best_mib == 1024)
         return d
     except Exception:
