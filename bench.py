@@ -538,7 +538,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mib", type=int, default=0, help="input MiB per GPU (default: 1024 at one GPU = BASELINE C2, 2048 otherwise = C3 at 8 GPUs)")
-    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--cpu-sample-mib", type=int, default=128, help="MiB of the workload the one-core CPU baseline (the oracle) is timed on: about 12 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-checks", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
