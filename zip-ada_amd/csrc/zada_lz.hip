@@ -1511,6 +1511,9 @@ static_assert(NLEVELS >= 2, "the links of level 0 are dead after k_cross_dist: t
 #endif
 constexpr int DM_THREADS = ZADA_DM_THREADS, DMB = ZADA_DMB, DM_SLICE = 256, DM_AHEAD = ZADA_DM_AHEAD;
 constexpr int DM_WBYTES = HALO + DMB + 272;
+#ifdef ZADA_DM_STATS
+__device__ unsigned long long g_dm_dbg[8];
+#endif
 struct ScanDesc {                                  // a position whose candidates have to be scanned (32 bytes, in LDS)
   uint16_t k, la, idx1, c1, idx2, c2, lim_full, lim_q;
   uint16_t bdist, best_hq;                         // best | reach << 14 | have_q << 15
@@ -1524,6 +1527,12 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
                                                              const uint32_t *__restrict__ blk_demand, uint32_t *__restrict__ dbits, uint8_t *__restrict__ chg,
                                                              const ExitState *__restrict__ spec_exits, const uint16_t *__restrict__ resume, bool use_beat) {
   if (blk_demand[xcd_block()] == 0) return;
+#ifdef ZADA_DM_STATS   /* cycles of a block's phases (thread 0's clock at the barriers that are there anyway): staging, list, phase A, phase B */
+  unsigned long long dm_t = clock64();
+#define DM_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_dm_dbg[k], t_ - dm_t); dm_t = t_; } } while (0)
+#else
+#define DM_STAMP(k) do {} while (0)
+#endif
   const uint64_t B = (uint64_t)xcd_block() * DMB;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t *win = (uint32_t *)smem;                               // DM_WBYTES bytes
@@ -1559,6 +1568,7 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
   };
   if (tid == 0) ctr[0] = 0;
   __syncthreads();
+  DM_STAMP(0);
   // the marked positions of the block, from the bit map the parsers keep (one bit per position: 512 bytes instead of the
   // block's 32 KB of match records); the block's bits are cleared for the next round
   if (tid < DMB / 32) {
@@ -1571,9 +1581,13 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
     }
   }
   __syncthreads();
+  DM_STAMP(1);
   const uint32_t nl = ctr[0];
+#ifdef ZADA_DM_STATS
+  if (tid == 0) { atomicAdd(&g_dm_dbg[4], 1ull); atomicAdd(&g_dm_dbg[5], (unsigned long long)nl); }
+#endif
   for (uint32_t l0 = 0; l0 < nl; l0 += DM_SLICE) {
-    if (tid == 0) ctr[1] = 0;
+    if (tid == 0) { ctr[1] = 0; ctr[2] = DM_THREADS / 64; }
     __syncthreads();
     // ---- phase A, one lane per marked position: everything that is known about the position (limits, nearest
     //      3..K-1 byte matches, where its bucket lies in the sorted orders) and the start of the search.  Positions
@@ -1644,6 +1658,10 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       }
     }
     __syncthreads();
+    DM_STAMP(2);
+#ifdef ZADA_DM_STATS
+    if (tid == 0) atomicAdd(&g_dm_dbg[6], (unsigned long long)ctr[1]);
+#endif
     // ---- phase B, one wave per descriptor: scan the candidates, 64 per batch.  The members of the bucket are a
     //      contiguous run of the sorted order, nearest first when read backwards, in the position's own segment
     //      and then in the previous one.  The first batch of the wave's next descriptor is fetched meanwhile. ----
@@ -1667,11 +1685,23 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       const bool q0 = raw == 0 && ((in1 && seg_first) || (in2 && prev_first));   // the candidate is position 0 of the stream
       return q0 ? 0u : (in1 ? po - raw : (in2 ? po + 32768u - raw : 0u));
     };
+#ifdef ZADA_DM_DYNAMIC
+    // the descriptors are handed out through a counter instead of wave by wave in turn: a scan is one batch or sixty, and a wave that drew the long ones
+    // kept the other seven waiting at the slice's barrier
+    auto take = [&]() -> uint32_t { uint32_t t = 0; if (lane == 0) t = atomicAdd(&ctr[2], 1u); return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); };
+    uint32_t si = (uint32_t)wave, nxt = si < ns ? take() : ns;
+    uint32_t rnext = si < ns ? cand_load(desc[si], (uint32_t)lane) : 0u;
+    for (; si < ns; si = nxt, nxt = si < ns ? take() : ns) {
+      const ScanDesc ds = desc[si];
+      const uint32_t r0 = rnext;
+      if (nxt < ns) rnext = cand_load(desc[nxt], (uint32_t)lane);
+#else
     uint32_t rnext = (uint32_t)wave < ns ? cand_load(desc[wave], (uint32_t)lane) : 0u;
     for (uint32_t si = (uint32_t)wave; si < ns; si += DM_THREADS / 64) {
       const ScanDesc ds = desc[si];
       const uint32_t r0 = rnext;
       if (si + DM_THREADS / 64 < ns) rnext = cand_load(desc[si + DM_THREADS / 64], (uint32_t)lane);
+#endif
       const uint32_t WI = woff + ds.k, LF = ds.lim_full, LQ = ds.lim_q, TT = (uint32_t)ds.c1 + ds.c2;
       const int LA = ds.la, NICE = nice_cfg < LA ? nice_cfg : LA;
       int bst = ds.best_hq & 0x3FFF;
@@ -1740,6 +1770,7 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       }
     }
     __syncthreads();
+    DM_STAMP(3);
   }
 }
 
@@ -2561,6 +2592,12 @@ int lz_shard(Ctx *c, int level, const ShardJob &job, ShardResult *res) {
     hipLaunchKernelGGL(k_match_demand, dim3(nbd), dim3(DM_THREADS), DM_LDS, st, W.in, L, dpl, rpt, W.ltails[NLEVELS - 1], W.M, cfg.nice,
                        W.blk_demand, W.dbits, W.chg, W.spec_exits, W.lprev[0], beat_valid);
     hipMemsetAsync(W.blk_demand, 0, (size_t)nbd * 4, st);
+#ifdef ZADA_DM_STATS
+    { unsigned long long h[8]; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dm_dbg), sizeof h);
+      fprintf(stderr, "[k_match_demand round %d] %llu blocks, %.1f marked positions and %.1f scans per block; cycles per block: staging %.0f, list %.0f, phase A %.0f, phase B %.0f\n", demand_rounds, h[4],
+              (double)h[5] / (h[4] ? h[4] : 1), (double)h[6] / (h[4] ? h[4] : 1), (double)h[0] / (h[4] ? h[4] : 1), (double)h[1] / (h[4] ? h[4] : 1), (double)h[2] / (h[4] ? h[4] : 1), (double)h[3] / (h[4] ? h[4] : 1));
+      for (int q = 0; q < 8; q++) h[q] = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_dm_dbg), h, sizeof h); }
+#endif
   }
   c->demand_rounds += demand_rounds;
   c->parse_rounds += rounds;
