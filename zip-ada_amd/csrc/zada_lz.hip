@@ -1685,9 +1685,10 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       const bool q0 = raw == 0 && ((in1 && seg_first) || (in2 && prev_first));   // the candidate is position 0 of the stream
       return q0 ? 0u : (in1 ? po - raw : (in2 ? po + 32768u - raw : 0u));
     };
-#ifdef ZADA_DM_DYNAMIC
-    // the descriptors are handed out through a counter instead of wave by wave in turn: a scan is one batch or sixty, and a wave that drew the long ones
-    // kept the other seven waiting at the slice's barrier
+#ifndef ZADA_DM_STATIC
+    // (round 6) the descriptors are handed out through a counter instead of wave by wave in turn: a scan is one batch or sixty, and a wave that drew the long ones
+    // kept the other seven waiting at the slice's barrier (parse phase 30.75 -> 30.08 ms per GiB; per block of the first demand pass -- 120 scans --
+    // staging 5 k, list 7 k, phase A 11 k, phase B 78 k cycles: -DZADA_DM_STATS)
     auto take = [&]() -> uint32_t { uint32_t t = 0; if (lane == 0) t = atomicAdd(&ctr[2], 1u); return (uint32_t)__builtin_amdgcn_readfirstlane((int)t); };
     uint32_t si = (uint32_t)wave, nxt = si < ns ? take() : ns;
     uint32_t rnext = si < ns ? cand_load(desc[si], (uint32_t)lane) : 0u;
