@@ -60,7 +60,8 @@ if stopped:
     sys.exit(0)
 if resume:
     tail = z[head_len:]
-    rec = {"workload": "ONE LZMA_3 stream of %d MiB silesia_mix_v%d, second call: from the exported state" % (mib, ver), "seconds": round(dt, 1), "rc": rc, "stream_bytes_total": len(z),
+    rec = {"workload": "ONE LZMA_3 stream of %d MiB silesia_mix_v%d" % (mib, ver), "calls": "two GPU calls: this record is the second call's, from the state the first exported (first_call)",
+           "seconds": round(dt, 1), "rc": rc, "stream_bytes_total": len(z),
            "tail_bytes": len(tail), "tail_sha256": hashlib.sha256(tail).hexdigest(), "compression_ratio": round(len(z) / n, 4), "first_call": meta}
     print("second call: %.1f s, rc %d, stream of %d bytes (%d of them from this call), ratio %.4f" % (dt, rc, len(z), len(tail), len(z) / n), flush=True)
     if os.environ.get("C4_ORACLE") == "1":
