@@ -1545,12 +1545,21 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
   const uint32_t cnt = n > B ? (uint32_t)((n - B) < (uint64_t)DMB ? (n - B) : (uint64_t)DMB) : 0u;
   const bool seg_first = lay_first(L, B >> 15), prev_first = (B >> 15) > 0 && lay_first(L, (B >> 15) - 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {
+  // Round 6: the window is staged BESIDE phase A of the first slice, by the threads phase A does not use (it has one lane per marked position, 256 at
+  // most, and is a chain of dependent loads of its own; the two hashes it took from the window come from memory there).  -DZADA_DM_STAGE_FIRST: all
+  // threads stage first, as before.
+#ifdef ZADA_DM_STAGE_FIRST
+  constexpr bool STAGE_BESIDE = false;
+#else
+  constexpr bool STAGE_BESIDE = DM_THREADS > DM_SLICE;
+#endif
+  auto stage = [&](uint32_t t0, uint32_t stride) {
     const uint32_t nb = woff + cnt + 272;
     const uint4 *src = (const uint4 *)(in + WB);
     uint4 *dst = (uint4 *)win;
-    for (uint32_t i = tid; i < (nb + 15) / 16; i += DM_THREADS) dst[i] = src[i];
-  }
+    for (uint32_t i = t0; i < (nb + 15) / 16; i += stride) dst[i] = src[i];
+  };
+  if (!STAGE_BESIDE) stage((uint32_t)tid, DM_THREADS);
   const uint8_t *win8 = (const uint8_t *)win;
   // a changed value: the speculative parses that used the guess have to be redone (the chunk's own, and the previous
   // chunk's if it ran over into this position)
@@ -1592,6 +1601,8 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
     // ---- phase A, one lane per marked position: everything that is known about the position (limits, nearest
     //      3..K-1 byte matches, where its bucket lies in the sorted orders) and the start of the search.  Positions
     //      with nothing to scan are finished here; the others leave a descriptor in LDS. ----
+    if (STAGE_BESIDE && l0 == 0 && tid >= DM_SLICE) stage((uint32_t)(tid - DM_SLICE), DM_THREADS - DM_SLICE);
+    const bool win_ready = !(STAGE_BESIDE && l0 == 0);               // (the first slice's phase A runs while the window is on its way)
     if ((uint32_t)tid < (uint32_t)DM_SLICE && l0 + tid < nl) {
       const uint32_t k = list[l0 + tid];
       const uint64_t p = B + k;
@@ -1610,10 +1621,11 @@ __global__ void __launch_bounds__(DM_THREADS, 6) k_match_demand(const uint8_t *_
       if (!seg_first) {
         // (only the occupied buckets of a tails table are written: an entry is the bucket's tail iff it names an inserted position of
         // the previous segment that hashes to the bucket -- see k_cross_links; a tail out of reach leaves nothing to scan there)
-        const uint32_t key = hashL_of(lds_u64_at(win8, wi), 3 + NLEVELS);
+        const uint32_t key = hashL_of(win_ready ? lds_u64_at(win8, wi) : *(const u64u *)(in + p), 3 + NLEVELS);
         const uint32_t tt = tailsK[(seg - 1) * 65536ull + key];
         const uint64_t q = pbase + tt;
-        if (tt < lay_inserted(L, seg - 1) && p - q <= (uint64_t)MAX_DIST && hashL_of(lds_u64_at(win8, (uint32_t)(q - WB)), 3 + NLEVELS) == key) t = tt;
+        if (tt < lay_inserted(L, seg - 1) && p - q <= (uint64_t)MAX_DIST &&
+            hashL_of(win_ready ? lds_u64_at(win8, (uint32_t)(q - WB)) : *(const u64u *)(in + q), 3 + NLEVELS) == key) t = tt;
       }
       uint32_t idx2 = 0, c2 = 0;
       if (t != 0xFFFFu) { idx2 = rp.idx[pbase + t]; c2 = (uint32_t)rp.cnt[pbase + t] + 1u; }
