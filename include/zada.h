@@ -245,7 +245,10 @@ int zada_lzma_device(zada_ctx *ctx, int method, const void *d_in, uint64_t n, vo
  * `out`, NULL to skip; *positions = input positions coded); zada_lzma_import_state hands a state to a context, whose NEXT zada_lzma call -- same
  * input, same method -- goes on from there and returns the whole stream's length, with its output buffer valid from byte *out_bytes of the export on
  * (the bytes before are the export's).  The match sets of LZMA_3 are a function of the input alone: the resumed call makes them again.  This is
- * Feedback / User_abort (zip-compress-lzma_e.adb:78-92) turned into a checkpoint: a stream that takes longer than one call may run is coded in two. */
+ * Feedback / User_abort (zip-compress-lzma_e.adb:78-92) turned into a checkpoint: a stream that takes longer than one call may run is coded in two.
+ * A state is spent by the next zada_lzma / zada_lzma_device call whatever comes of it, and it is checked before the coder takes it: a blob that is not
+ * a stopped stream's (length, phase) is refused by zada_lzma_import_state, one whose stream length, method level, dictionary or counters do not fit the
+ * call it meets by that call (ZADA_E_INVALID both times).  What cannot be checked is the input's CONTENT: the same bytes are the caller's to hand over. */
 int zada_lzma_export_state(zada_ctx *ctx, uint8_t *state, uint64_t state_cap, uint64_t *state_len, uint8_t *out, uint64_t out_cap, uint64_t *out_bytes,
                            uint64_t *positions);
 int zada_lzma_import_state(zada_ctx *ctx, const uint8_t *state, uint64_t state_len);

@@ -1,7 +1,7 @@
 """GPU script: step time of 256 MiB degenerate inputs (zeros, random, three symbols, a period longer than the window, text only) under the
 round-6 defaults and under the round-5 settings of the same knobs -- a check that the filter, the lists and the exact re-parse have no cliff.  Prints one line per input."""
 import importlib, os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 za = importlib.import_module("zip-ada_amd")
 n = 256 << 20

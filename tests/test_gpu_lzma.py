@@ -400,4 +400,14 @@ def test_a_stream_stopped_by_its_feedback_goes_on_in_another_context():
             assert (rc, head + z[len(head):], crc) == want, (method, stop_pct, pos, len(head))
             rc2, z2, crc2 = b.lzma(d, method)                           # (the state was for one call: the next one starts at the first byte)
             assert (rc2, z2, crc2) == want
+            # a state is checked against the stream it is handed to before the kernel takes its counters as they are: another length, another method's kind
+            # of state, a damaged blob -- refused (ZADA_E_INVALID), the state is spent, and the context codes the next stream as ever
+            for wrong_input, wrong_method in ((d[:-1], method), (d, 35 - method)):
+                b.lzma_import_state(state)
+                with pytest.raises(Z.ZadaError, match="imported state"):
+                    b.lzma(wrong_input, wrong_method)
+            for damage in (lambda s: b"\x02" + s[1:], lambda s: s[:-1], lambda s: b""):
+                with pytest.raises(Z.ZadaError, match="not the state of a stopped stream"):
+                    b.lzma_import_state(damage(state))
+            assert b.lzma(d, method) == want
             b.close()

@@ -1414,6 +1414,14 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
     }
     bt4 = bt4 || (j.level == 3 && j.n > 0);
   }
+  // (a state from zada_lzma_import_state is for the next stream coded, whatever comes of it: it has to be the state of THIS stream -- one LZMA_3 stream in
+  // launches, same length, dictionary and place -- or the call is refused; the kernel would take its counters as they are)
+  std::vector<uint8_t> resume_blob;
+  resume_blob.swap(c->lz_resume);
+  if (!resume_blob.empty() && !(E == 1 && budget > 0 && resume_blob.size() == lzma_save_stride() && lzma_save_fits(resume_blob.data(), jobs[0]))) {
+    c->err = "LZMA: the imported state is not one of this stream (ONE LZMA_3 stream in launches, of the same length and dictionary)";
+    return ZADA_E_INVALID;
+  }
   int rc = lz_grow(c, &c->lz_tab, &c->cap_lz_tab, (sizeof(LzmaJob) + 16 + 4) * (size_t)E + 192);
   if (rc) return rc;
   Bt4Sets sets{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1443,9 +1451,9 @@ static int lzma_run(Ctx *c, std::vector<LzmaJob> &jobs, const uint8_t *d_in, uin
     if ((rc = lz_grow(c, &c->lz_save, &c->cap_lz_save, save_bytes))) return rc;
     // (a state from zada_lzma_import_state: ONE stream goes on from where an earlier call -- of another context, of another process -- stopped; the match
     // sets are a function of the input alone, so the producer simply makes them again, and the launches up to the state's position code nothing)
-    const bool resume = E == 1 && c->lz_resume.size() == save_bytes;
+    const bool resume = !resume_blob.empty();
     auto fresh_state = [&]() {
-      if (resume) hipMemcpyAsync(c->lz_save, c->lz_resume.data(), save_bytes, hipMemcpyHostToDevice, c->stream);
+      if (resume) hipMemcpyAsync(c->lz_save, resume_blob.data(), save_bytes, hipMemcpyHostToDevice, c->stream);
       else hipMemsetAsync(c->lz_save, 0, save_bytes, c->stream);
     };
     fresh_state();

@@ -351,6 +351,7 @@ int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t
                 uint8_t *d_save = nullptr, uint64_t budget = 0, uint64_t pos_cap = ~0ull, int waves = 1);
 uint64_t lzma_save_stride();
 int lzma_save_info(const uint8_t *blob, uint64_t *pos, uint64_t *olen, uint64_t *n);
+int lzma_save_fits(const uint8_t *blob, const LzmaJob &J);
 int ensure_lz_workspace(Ctx *c, uint64_t nbuf);
 int ensure_entropy_workspace(Ctx *c, uint64_t atoms, uint64_t flushes, uint64_t out_bytes = 0);   // out_bytes: the input the stream is made of (0: as many bytes as atoms)
 int ensure_crc_workspace(Ctx *c, uint64_t n);

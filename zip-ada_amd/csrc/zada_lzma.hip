@@ -1199,7 +1199,7 @@ __device__ bool lz_bt4_begin(int sbs, uint64_t base, const Bt4Sets &sets) {     
 // HBM anyway), so a launch that has coded `budget` more positions writes them to the job's slot and the next launch goes on there.
 struct LzSave {
   uint32_t phase;                              // 0: not started, 1: under way, 2: finished
-  uint32_t running;                            // Level_3: the main loop has not seen the end of the input yet
+  uint32_t running;                            // bit 0, Level_3: the main loop has not seen the end of the input yet; bits 8 .. 9: the level the state is of
   uint64_t iter;                               // Level_0: next byte; Level_1 / _2: next token
   LzProbs P; Matches MM[2]; Enc E; BT4 B;
 };
@@ -1227,7 +1227,7 @@ template <bool HW> __global__ void __launch_bounds__(HW ? 64 * HELP_WAVES : 64, 
   bool running = false;
   if (phase == 1) {
     words_in(s_P, &S->P); words_in(s_MM[0], &S->MM[0]); words_in(s_MM[1], &S->MM[1]); words_in(s_E, &S->E); words_in(s_B, &S->B);
-    iter = S->iter; running = S->running != 0;
+    iter = S->iter; running = (S->running & 1u) != 0;
     __syncthreads();
     // (the producer's buffers of THIS call -- and the entry's and the stream's addresses: a state that zada_lzma_export_state took out of another context,
     // or another process, goes on from where it stopped)
@@ -1294,7 +1294,7 @@ template <bool HW> __global__ void __launch_bounds__(HW ? 64 * HELP_WAVES : 64, 
     chain_sync<HW>();
     words_out(&S->P, s_P); words_out(&S->MM[0], s_MM[0]); words_out(&S->MM[1], s_MM[1]); words_out(&S->E, s_E); words_out(&S->B, s_B);
     if (threadIdx.x == 0) {
-      S->phase = 1; S->running = running ? 1u : 0u; S->iter = iter;
+      S->phase = 1; S->running = (running ? 1u : 0u) | ((uint32_t)J.level << 8); S->iter = iter;      // (the level: lzma_save_fits)
       result[2 * job] = s_E.olen;
       result[2 * job + 1] = s_E.ES.pos | (1ull << 63);                             // bit 63: more to come
     }
@@ -1356,6 +1356,17 @@ int lzma_save_info(const uint8_t *blob, uint64_t *pos, uint64_t *olen, uint64_t 
   const LzSave *S = (const LzSave *)blob;
   if (S->phase != 1) return 0;
   *pos = S->E.ES.pos; *olen = S->E.olen; *n = S->E.n;
+  return 1;
+}
+// does an imported state belong to THIS stream?  (length, dictionary, place in the arena; its counters are inside the stream and the window: the kernel
+// takes them as they are)
+int lzma_save_fits(const uint8_t *blob, const LzmaJob &J) {
+  const LzSave *S = (const LzSave *)blob;
+  if (S->phase != 1 || S->E.n != J.n || S->E.ES.pos > J.n) return 0;   // (olen beyond the caller's room is the coder's ordinary "counted, not written")
+  if ((int32_t)(S->running >> 8) != J.level || (S->running & 0xFEu)) return 0;
+  if (J.level < 3) return S->iter <= (J.level == 0 ? J.n : J.ntok);   // (next byte / next token)
+  if ((uint64_t)(uint32_t)S->B.sbs != J.sbs || S->B.base != J.in_off || S->B.in_pos > J.n) return 0;
+  if (S->B.buf_len < 0 || S->B.readPos < -1 || S->B.readPos > S->B.buf_len || S->B.writePos < 0 || S->B.writePos > S->B.buf_len || S->B.readLimit > S->B.buf_len) return 0;
   return 1;
 }
 int lzma_launch(Ctx *c, const LzmaJob *d_jobs, const uint32_t *d_order, uint32_t count, const uint8_t *d_in, const uint32_t *d_tok, uint8_t *d_out, const Bt4Sets &sets, uint64_t *d_result,
