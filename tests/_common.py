@@ -82,6 +82,9 @@ def hostcheck():
         H.hc_chunked_tokens.restype = ctypes.c_uint64
         H.hc_chunked_tokens.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int)]
         H.hc_header_bits.restype = ctypes.c_uint32
+        H.hc_demand_loop_tokens.restype = ctypes.c_uint64
+        H.hc_demand_loop_tokens.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
+                                            ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         H.hc_bt4_sets.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]
         H.hc_bt4_sets_segments.argtypes = H.hc_bt4_sets.argtypes + [ctypes.c_uint32]
         H.hc_bt4_reads_behind_a_gap.argtypes = [ctypes.c_uint64, ctypes.c_int64]

@@ -106,6 +106,149 @@ uint64_t hc_chunked_tokens(const uint8_t *in, uint64_t n, int level, uint32_t ch
   return T;
 }
 
+
+// ---- Model of the demand loop (zada_lz.hip, lz_shard "parse / demand rounds") with the chunk logic of zada_logic.h: a first pass that gives every
+// position `budget` chain steps and leaves its best-so-far as a GUESS where the chain goes on; parses that land on guesses use them and demand them;
+// demanded positions become exact; the chunks whose speculative parse used a value that changed are parsed again -- from the second round on only if
+// the new length exceeds the smallest "length to beat" a parse left with the guess (round 6) --; short lists are parsed with the exact value looked
+// up inside the parse (k_parse_spec_exact); a splice that needs more token slots than the small stride holds starts the parse again with full slots.
+// Sequential, one chunk after the other; the rules (who marks what, what a changed value flags, what a round re-parses) are restated here from the
+// kernels' text.  Must give the oracle's tokens whatever the budget, the list threshold, the slots and with or without the lengths to beat.
+// stats: [0] demand rounds, [1] chunks parsed again over all rounds, [2] changed values that flagged nothing thanks to their length to beat,
+//        [3] restarts for splice slots, [4] guesses of the first pass, [5] chunks parsed with the exact look-up.
+struct ModelMarker {
+  MatchPair *M; uint8_t *demand; uint32_t *ndem; uint32_t by; bool track;
+  void operator()(uint32_t p, uint32_t full, uint32_t quarter, uint32_t beat) const {
+    const uint32_t b = beat < M_BEAT_MAX ? beat : M_BEAT_MAX;
+    if (track && b < (quarter >> M_BEAT_SHIFT)) {
+      const uint32_t v = (quarter & M_VALUE) | (b << M_BEAT_SHIFT);
+      if (v < M[p].quarter) M[p].quarter = v;
+    }
+    const uint32_t want = M_DEMAND | by;
+    if ((full & want) == want) return;
+    M[p].full = full | want; demand[p] = 1; *ndem = 1;
+  }
+};
+struct ExactFetch {                                   // the parse of a listed chunk that looks the exact value up itself: the record is exact when the parse reads it
+  MatchPair *M; const uint32_t *XF, *XQ;
+  MatchPair operator()(uint64_t p) const { if (M[p].full & M_GUESS) { M[p].full = XF[p]; M[p].quarter = XQ[p]; } return M[p]; }
+};
+uint64_t hc_demand_loop_tokens(const uint8_t *in, uint64_t n, int level, uint32_t chunk, int budget, int use_beat, uint32_t exact_max, uint32_t fix_cap,
+                               uint32_t *tokens, uint64_t cap, uint64_t *stats) {
+  for (int i = 0; i < 6; i++) stats[i] = 0;
+  if (n == 0) return 0;
+  LzConfig cfg = lz_config(level);
+  // exact tables and the first pass's records in one walk (the model of match_tables above, with a snapshot after `budget` steps)
+  std::vector<uint32_t> XF(n, 0), XQ(n, 0);
+  std::vector<MatchPair> M(n);
+  {
+    std::vector<int64_t> prev(n, -1), head(32768, -1);
+    for (uint64_t p = 0; p < n; p++) { M[p].full = 0; M[p].quarter = 0; }
+    for (uint64_t p = 0; p + 2 < n; p++) {
+      uint32_t h = (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFF;
+      prev[p] = head[h]; head[h] = (int64_t)p;
+      int la = (n - p) < 258 ? (int)(n - p) : 258;
+      int nice = cfg.nice < la ? cfg.nice : la;
+      int best = 2; uint32_t bd = 0; int steps = 0; bool haveq = false; uint32_t rq = 0;
+      bool snap = false; uint32_t gf = 0, gq = 0;
+      int64_t c = prev[p];
+      while (c > 0) {
+        uint64_t dist = p - (uint64_t)c;
+        if (dist > (uint64_t)(steps == 0 ? MAX_DIST : MAX_DIST - 1)) break;
+        if (steps == budget && !snap) { snap = true; gf = best >= 3 ? ((uint32_t)best << 16) | bd : 0; gq = haveq ? rq : gf; }   // the chain goes on: a guess
+        steps++;
+        int len = 0;
+        while (len < la && in[c + len] == in[p + len]) len++;
+        if (len > best) { best = len; bd = (uint32_t)dist; if (len >= nice) break; }
+        if (steps == cfg.chain / 4) { haveq = true; rq = best >= 3 ? ((uint32_t)best << 16) | bd : 0; }
+        if (steps == cfg.chain) break;
+        c = prev[c];
+      }
+      XF[p] = best >= 3 ? ((uint32_t)best << 16) | bd : 0;
+      XQ[p] = haveq ? rq : XF[p];
+      if (snap) { M[p].full = gf | M_GUESS; M[p].quarter = gq | (M_BEAT_MAX << M_BEAT_SHIFT); stats[4]++; }
+      else { M[p].full = XF[p]; M[p].quarter = XQ[p]; }
+    }
+  }
+  ParseIO io{in, n, M.data(), cfg};
+  const uint32_t nch = (uint32_t)((n + chunk - 1) / chunk), stride = chunk + 1024;
+  std::vector<uint32_t> spec((size_t)nch * stride), fix((size_t)nch * stride), scnt(nch), fcnt(nch), take(nch), u0(nch);
+  std::vector<uint32_t> Fb(n / 32 + 2, 0xDEADBEEF), Lb(n / 32 + 2, 0xDEADBEEF);
+  std::vector<ExitState> sex(nch), tex(nch);
+  std::vector<uint8_t> demand(n, 0), chg(nch, 0);
+  uint32_t ndem = 0;
+  bool first = true;
+  for (int guard = 0; guard < 100000; guard++) {
+    const bool beat_valid = !first;
+    if (first) {
+      ModelMarker dm{M.data(), demand.data(), &ndem, M_BYSPEC, false};
+      for (uint32_t k = 0; k < nch; k++) { uint32_t nt = 0; parse_spec_chunk(io, k, chunk, &spec[(size_t)k * stride], nt, Fb.data(), Lb.data(), sex[k], dm, DirectFetch{io.M}); scnt[k] = nt; }
+    } else {
+      uint32_t nl = 0;
+      for (uint32_t k = 0; k < nch; k++) nl += chg[k];
+      const bool exact = exact_max && nl <= exact_max;
+      ModelMarker dm{M.data(), demand.data(), &ndem, M_BYSPEC, true};
+      for (uint32_t k = 0; k < nch; k++) {
+        if (!chg[k]) continue;
+        uint32_t nt = 0; stats[1]++;
+        if (exact) { stats[5]++; parse_spec_chunk(io, k, chunk, &spec[(size_t)k * stride], nt, Fb.data(), Lb.data(), sex[k], NoGuess(), ExactFetch{M.data(), XF.data(), XQ.data()}); }
+        else parse_spec_chunk(io, k, chunk, &spec[(size_t)k * stride], nt, Fb.data(), Lb.data(), sex[k], dm, DirectFetch{io.M});
+        scnt[k] = nt;
+      }
+    }
+    // the splice, from scratch, to its fixpoint
+    tex = sex;
+    std::vector<uint8_t> dirty(nch, 1), nd(nch, 0);
+    uint32_t overflow = 0;
+    ModelMarker dmf{M.data(), demand.data(), &ndem, 0, false};
+    for (;;) {
+      std::fill(nd.begin(), nd.end(), 0);
+      uint32_t changed = 0;
+      std::vector<ExitState> snapshot = tex;
+      for (uint32_t k = 0; k < nch; k++) {
+        if (!dirty[k]) continue;
+        ExitState entry{0, SYNC_F};
+        if (k > 0) entry = snapshot[k - 1];
+        ExitState ne; uint32_t nt = 0, tk = 0, uu = 0;
+        parse_fix_chunk(io, k, chunk, entry, &spec[(size_t)k * stride], scnt[k], Fb.data(), Lb.data(), sex[k], &fix[(size_t)k * stride], nt, tk, uu, ne, dmf, DirectFetch{io.M},
+                        fix_cap, &overflow);
+        fcnt[k] = nt; take[k] = tk; u0[k] = uu;
+        ExitState old = tex[k];
+        tex[k] = ne;
+        if (k + 1 < nch && (ne.pos != old.pos || ne.kind != old.kind)) { nd[k + 1] = 1; changed++; }
+      }
+      if (overflow || !changed) break;
+      dirty = nd;
+    }
+    if (overflow) { fix_cap = 0xFFFFFFFFu; stats[3]++; first = true; continue; }      // full slots, and the parse starts again (what is exact stays exact)
+    if (!ndem) break;
+    // the demand pass: every marked position searched to the end
+    stats[0]++;
+    ndem = 0;
+    std::fill(chg.begin(), chg.end(), 0);
+    for (uint64_t p = 0; p < n; p++) {
+      if (!demand[p]) continue;
+      demand[p] = 0;
+      const MatchPair og = M[p];
+      M[p].full = XF[p]; M[p].quarter = XQ[p];
+      if (!(og.full & M_BYSPEC)) continue;
+      const uint32_t beat = (use_beat && beat_valid) ? og.quarter >> M_BEAT_SHIFT : 0u, ogq = og.quarter & M_VALUE;
+      const bool df = XF[p] != (og.full & M_VALUE), dq = XQ[p] != ogq;
+      if ((df && (XF[p] >> 16) > beat) || (dq && (XQ[p] >> 16) > beat)) {
+        const uint64_t ch = p / chunk;
+        chg[ch] = 1;
+        if (ch > 0 && (uint64_t)sex[ch - 1].pos > p) chg[ch - 1] = 1;                     // the chunk before ran over into this position
+      } else if (df || dq) stats[2]++;
+    }
+    first = false;
+  }
+  uint64_t T = 0;
+  for (uint32_t k = 0; k < nch; k++) {
+    for (uint32_t i = 0; i < fcnt[k]; i++) { if (T < cap) tokens[T] = fix[(size_t)k * stride + i]; T++; }
+    for (uint32_t i = take[k]; i < scnt[k]; i++) { if (T < cap) tokens[T] = spec[(size_t)k * stride + i]; T++; }
+  }
+  return T;
+}
 }  // extern "C"
 
 // ---- reference of the wave-parallel LLHC algorithm's MATH (classic package-merge with the

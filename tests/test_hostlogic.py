@@ -49,6 +49,38 @@ def test_symbol_tables_equal_rfc1951():
         assert H.hc_dist_symbol(D) == s and H.hc_dist_extra_bits(D) == dext[s] and H.hc_dist_extra_val(D) == D - dbase[s]
 
 
+def test_demand_loop_model_with_lengths_to_beat():
+    """Round 6's rules of the demand loop (zada_lz.hip, lz_shard) as a sequential model over the product's own chunk logic (zada_logic.h: run_parser's
+    on_guess with the state's match length, parse_fix_chunk's capped sink): a first pass of `budget` chain steps leaves guesses; the parses that land on
+    them demand them; a changed value flags its chunk -- from the second round on only if its length exceeds the smallest length to beat a parse left --;
+    short lists are parsed with the exact look-up inside; a splice that overflows its small slot starts the parse again.  Whatever the budget, the list
+    threshold, the slots, and with or without the lengths to beat: the oracle's tokens (lz77.adb:460-943 run sequentially).  And the rule is worth having:
+    over the matrix it leaves changed values unflagged, and never parses more chunks again than the plain rule."""
+    H = hostcheck()
+    cases = {k: v for k, v in edge_inputs().items() if 3000 < len(v) <= 120000}
+    rs = np.random.RandomState(5)
+    cases["runs_and_noise"] = b"".join(bytes([rs.randint(97, 101)]) * int(rs.randint(1, 400)) if rs.rand() < 0.5 else bytes(rs.randint(97, 103, int(rs.randint(1, 300))).astype(np.uint8)) for _ in range(500))
+    saved = respec = 0
+    for name, d in cases.items():
+        for method, level in ((10, 10), (8, 6)):
+            a = oracle_tokens(d, method)
+            got = {}
+            for budget, use_beat, exact_max, fix_cap, chunk in ((1, 1, 0, 0xFFFFFFFF, 512), (1, 0, 0, 0xFFFFFFFF, 512), (4, 1, 8, 128, 512), (4, 0, 8, 128, 512),
+                                                                (16, 1, 1 << 30, 2, 1024), (2, 1, 0, 3, 4096), (64, 1, 4, 128, 512)):
+                t = np.zeros(len(d) + 8, dtype=np.uint32)
+                st = np.zeros(6, dtype=np.uint64)
+                k = H.hc_demand_loop_tokens(d, len(d), level, chunk, budget, use_beat, exact_max, fix_cap, t.ctypes.data, len(t), st.ctypes.data)
+                assert k == len(a) and (t[:k] == a).all(), (name, method, budget, use_beat, exact_max, fix_cap, chunk, st.tolist())
+                got[(budget, use_beat, exact_max, fix_cap, chunk)] = st.tolist()
+            for budget, ex, cap, chunk in ((1, 0, 0xFFFFFFFF, 512), (4, 8, 128, 512)):
+                with_beat, plain = got[(budget, 1, ex, cap, chunk)], got[(budget, 0, ex, cap, chunk)]
+                assert with_beat[4] == plain[4] and plain[2] == 0
+                assert with_beat[1] <= plain[1], (name, method, with_beat, plain)
+                saved += with_beat[2]; respec += plain[1] - with_beat[1]
+            assert got[(16, 1, 1 << 30, 2, 1024)][3] <= 1                      # (slots of two tokens: at most one restart, and only where a splice needs a third)
+    assert saved > 0 and respec > 0, (saved, respec)
+
+
 @pytest.mark.parametrize("method", (6, 8, 9, 10))
 def test_chunked_speculative_parse_equals_sequential_reference(method):
     """The GPU's parse = per-chunk speculative parse + splice to a fixpoint (parse_spec_chunk /
