@@ -138,36 +138,48 @@ uint64_t hc_demand_loop_tokens(const uint8_t *in, uint64_t n, int level, uint32_
   for (int i = 0; i < 6; i++) stats[i] = 0;
   if (n == 0) return 0;
   LzConfig cfg = lz_config(level);
-  // exact tables and the first pass's records in one walk (the model of match_tables above, with a snapshot after `budget` steps)
-  std::vector<uint32_t> XF(n, 0), XQ(n, 0);
-  std::vector<MatchPair> M(n);
-  {
-    std::vector<int64_t> prev(n, -1), head(32768, -1);
-    for (uint64_t p = 0; p < n; p++) { M[p].full = 0; M[p].quarter = 0; }
+  // exact tables (the model of match_tables above; kept between calls on the same input and level: the test asks for several budgets) and the first
+  // pass's records: where the walk takes more than `budget` steps, its state after `budget` steps
+  static std::vector<uint8_t> c_in; static int c_level = -1;
+  static std::vector<uint32_t> XF, XQ, nsteps; static std::vector<int64_t> prev;
+  auto walk = [&](uint64_t p, int stop_after, uint32_t &f, uint32_t &q) -> int {      // stop_after < 0: to the end
+    int la = (n - p) < 258 ? (int)(n - p) : 258;
+    int nice = cfg.nice < la ? cfg.nice : la;
+    int best = 2; uint32_t bd = 0; int steps = 0; bool haveq = false; uint32_t rq = 0;
+    int64_t c = prev[p];
+    while (c > 0) {
+      uint64_t dist = p - (uint64_t)c;
+      if (dist > (uint64_t)(steps == 0 ? MAX_DIST : MAX_DIST - 1)) break;
+      if (steps == stop_after) break;
+      steps++;
+      int len = 0;
+      while (len < la && in[c + len] == in[p + len]) len++;
+      if (len > best) { best = len; bd = (uint32_t)dist; if (len >= nice) break; }
+      if (steps == cfg.chain / 4) { haveq = true; rq = best >= 3 ? ((uint32_t)best << 16) | bd : 0; }
+      if (steps == cfg.chain) break;
+      c = prev[c];
+    }
+    f = best >= 3 ? ((uint32_t)best << 16) | bd : 0;
+    q = haveq ? rq : f;
+    return steps;
+  };
+  if (c_level != level || c_in.size() != n || memcmp(c_in.data(), in, n) != 0) {
+    c_in.assign(in, in + n); c_level = level;
+    XF.assign(n, 0); XQ.assign(n, 0); nsteps.assign(n, 0); prev.assign(n, -1);
+    std::vector<int64_t> head(32768, -1);
     for (uint64_t p = 0; p + 2 < n; p++) {
       uint32_t h = (((uint32_t)in[p] << 10) ^ ((uint32_t)in[p + 1] << 5) ^ in[p + 2]) & 0x7FFF;
       prev[p] = head[h]; head[h] = (int64_t)p;
-      int la = (n - p) < 258 ? (int)(n - p) : 258;
-      int nice = cfg.nice < la ? cfg.nice : la;
-      int best = 2; uint32_t bd = 0; int steps = 0; bool haveq = false; uint32_t rq = 0;
-      bool snap = false; uint32_t gf = 0, gq = 0;
-      int64_t c = prev[p];
-      while (c > 0) {
-        uint64_t dist = p - (uint64_t)c;
-        if (dist > (uint64_t)(steps == 0 ? MAX_DIST : MAX_DIST - 1)) break;
-        if (steps == budget && !snap) { snap = true; gf = best >= 3 ? ((uint32_t)best << 16) | bd : 0; gq = haveq ? rq : gf; }   // the chain goes on: a guess
-        steps++;
-        int len = 0;
-        while (len < la && in[c + len] == in[p + len]) len++;
-        if (len > best) { best = len; bd = (uint32_t)dist; if (len >= nice) break; }
-        if (steps == cfg.chain / 4) { haveq = true; rq = best >= 3 ? ((uint32_t)best << 16) | bd : 0; }
-        if (steps == cfg.chain) break;
-        c = prev[c];
-      }
-      XF[p] = best >= 3 ? ((uint32_t)best << 16) | bd : 0;
-      XQ[p] = haveq ? rq : XF[p];
-      if (snap) { M[p].full = gf | M_GUESS; M[p].quarter = gq | (M_BEAT_MAX << M_BEAT_SHIFT); stats[4]++; }
-      else { M[p].full = XF[p]; M[p].quarter = XQ[p]; }
+      nsteps[p] = (uint32_t)walk(p, -1, XF[p], XQ[p]);
+    }
+  }
+  std::vector<MatchPair> M(n);
+  for (uint64_t p = 0; p < n; p++) {
+    M[p].full = XF[p]; M[p].quarter = XQ[p];
+    if (p + 2 < n && nsteps[p] > (uint32_t)budget) {                               // the chain goes on behind the budget: a guess
+      uint32_t gf, gq;
+      walk(p, budget, gf, gq);
+      M[p].full = gf | M_GUESS; M[p].quarter = gq | (M_BEAT_MAX << M_BEAT_SHIFT); stats[4]++;
     }
   }
   ParseIO io{in, n, M.data(), cfg};

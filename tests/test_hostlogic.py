@@ -57,7 +57,7 @@ def test_demand_loop_model_with_lengths_to_beat():
     threshold, the slots, and with or without the lengths to beat: the oracle's tokens (lz77.adb:460-943 run sequentially).  And the rule is worth having:
     over the matrix it leaves changed values unflagged, and never parses more chunks again than the plain rule."""
     H = hostcheck()
-    cases = {k: v for k, v in edge_inputs().items() if 3000 < len(v) <= 120000}
+    cases = {k: v for k, v in edge_inputs().items() if 3000 < len(v) <= 310000}
     rs = np.random.RandomState(5)
     cases["runs_and_noise"] = b"".join(bytes([rs.randint(97, 101)]) * int(rs.randint(1, 400)) if rs.rand() < 0.5 else bytes(rs.randint(97, 103, int(rs.randint(1, 300))).astype(np.uint8)) for _ in range(500))
     saved = respec = 0
