@@ -897,6 +897,8 @@ template <int MODE>
 __global__ void __launch_bounds__(CD_THREADS) k_cross_dist(const uint8_t *__restrict__ in, Layout L, LevelPtrs lv,
                                                     const uint16_t *__restrict__ S3, const uint8_t *__restrict__ T3, const uint32_t *__restrict__ bsc3,
                                                     DistPlanes dp, uint64_t p0, uint64_t p1, CdTail tl) {
+  // (the sweep's waves in XCD order -- xcd_block(), every XCD a contiguous eighth of the stream, so that a previous segment's tables sit in one L2 -- measured: cross
+  // phase 9.93 / 9.74 against 9.89 / 9.86 ms, nothing)
   uint64_t p = p0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;            // (the positions [p0, p1): all from 32 768 on, or one piece's)
   if (MODE == CD_LIST) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, nc = *tl.count, nl = nc < tl.cap ? nc : tl.cap;    // (what did not fit was walked in the sweep)
