@@ -5,10 +5,13 @@ import numpy as np
 from _common import product
 from _bzip2 import oracle_encode
 Z = product(); enc = Z.Encoder(0)
+if os.environ.get("BZ_LISTS"):
+    enc.set_knob("bz_lists", int(os.environ["BZ_LISTS"]))                     # (A/B of the default, round 6)
 for count, size in ((10000, 16 << 10), (2000, 256 << 10)):
     mix = Z.silesia_mix(count * size, version=2)
     datas = [bytes(mix[i * size:(i + 1) * size]) for i in range(count)]
     enc.bzip2_batch(datas[:50], 14)
+    enc.bzip2_batch(datas, 14)                                             # (books the workspaces)
     t0 = time.time(); res = enc.bzip2_batch(datas, 14); dt = time.time() - t0
     k = 20
     t1 = time.time(); one = [enc.bzip2(d, 14) for d in datas[:k]]; d1 = (time.time() - t1) / k

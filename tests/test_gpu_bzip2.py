@@ -315,5 +315,5 @@ def test_group_lists_of_the_rotation_sort(encoder):
                 rc, p, crc = encoder.bzip2(d, 14, cap=len(d) * 2 + 4096)
                 assert p == o and encoder.bz2_last_blocks() == ev and (crc ^ 0xFFFFFFFF) == zlib.crc32(d), (lists, pipeline, small_wg, list_rows, text_order, len(d))
     finally:
-        encoder.set_knob("bz_lists", 8); encoder.set_knob("bz_pipeline", 1); encoder.set_knob("bz_small_wg", 1); encoder.set_knob("bz_split", 1)
+        encoder.set_knob("bz_lists", -1); encoder.set_knob("bz_pipeline", 1); encoder.set_knob("bz_small_wg", 1); encoder.set_knob("bz_split", 1)
         encoder.set_knob("bz_list_rows", 0); encoder.set_knob("bz_text_order", 1)

@@ -1089,7 +1089,7 @@ int zada_set_knob(zada_ctx *z, const char *name, int value) {
   else if (!strcmp(name, "bz_list_rows")) { if (value < 0 || value > 8192) return ZADA_E_INVALID; z->c.knob_bz_list_rows = value; }
   else if (!strcmp(name, "bz_split")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_split = value; }
   else if (!strcmp(name, "bz_small_wg")) { if (value < 0 || value > 1) return ZADA_E_INVALID; z->c.knob_bz_small_wg = value; }
-  else if (!strcmp(name, "bz_lists")) { if (value < 0) return ZADA_E_INVALID; z->c.knob_bz_lists = value; }
+  else if (!strcmp(name, "bz_lists")) { if (value < -1) return ZADA_E_INVALID; z->c.knob_bz_lists = value; }
   else if (!strcmp(name, "batch_mib")) { if (value < 1 || value > 1024) return ZADA_E_INVALID; z->c.knob_batch_mib = value; }
   else if (!strcmp(name, "atoms_pct")) { if (value < 1 || value > 100) return ZADA_E_INVALID; z->c.knob_atoms_pct = value; z->c.ws.cap_atoms = 0; }   // (the next call books the entropy workspace anew)
   else if (!strcmp(name, "fix_stride")) { if (value < 0 || value > (int)PTOK_STRIDE) return ZADA_E_INVALID; z->c.knob_fix_stride = value; z->c.ws.cap_n = 0; }

@@ -2323,6 +2323,13 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
   // group lists of the late rounds (k_bz_gl_*): two generations, filled by one round and sorted by the next
   // (a list entry packs its sub-block into GL_SB_BITS bits -- gl_entry: a batch of more sub-blocks than that keeps sweeping)
   const bool use_lists = c->knob_bz_lists != 0 && nsb <= (1u << GL_SB_BITS);
+  // from which prefix length on sub-blocks may leave the sweeps ("bz_lists"; < 0: by the batch's longest sub-block -- a batch with the blocks of a stream
+  // after the round for 16 bytes, the sub-blocks of small entries after the round for 8.  Round 6, on silesia_mix_v2: a stream of 256 MiB 437 against 457 ms
+  // with 16 instead of 8 -- most rows are still in groups after eight bytes, distinct content rather than copies, and sorting that many groups one by one costs more
+  // than one more sweep; 10 000 entries of 16 KiB 0.39 against 0.40 s, 2 000 of 256 KiB 0.80 against 0.81 s with 8)
+  uint32_t longest_sb = 0;
+  for (uint32_t v : B->h_n) longest_sb = v > longest_sb ? v : longest_sb;
+  const uint32_t lists_from = c->knob_bz_lists > 0 ? (uint32_t)c->knob_bz_lists : (longest_sb >= 300000u ? 16u : 8u);      // (the blocks of a BZip2_2 / _3 stream: 400 k / 900 k)
   GlLists GL[2];
   uint32_t *nc = nullptr, *submax = nullptr, *glcnt = nullptr;
   uint8_t *lmode = nullptr;
@@ -2397,7 +2404,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
         hipLaunchKernelGGL((k_bz_gl_sort_wg<1024u, GL_MAX>), dim3(gl_n[3]), dim3(256), 0, st, cur.l[3], cur.cnt + 3, h, valA, clr, clw, T, nxt);
       }
       // sub-blocks whose unsorted groups have all become small leave the sweeps: their groups (classes of 2h bytes) join the lists
-      if (swept && 2 * h >= (uint32_t)c->knob_bz_lists) {
+      if (swept && 2 * h >= lists_from) {
         BZ_HIP(hipMemsetAsync(submax, 0, 4ull * nsb, st));
         hipLaunchKernelGGL(k_bz_gl_max, dim3(xcd_grid(net)), dim3(1024), 0, st, valA, cl, T, ET, done, submax, net);
         hipLaunchKernelGGL(k_bz_gl_decide, dim3((nsb + 255) / 256), dim3(256), 0, st, T, done, submax, lmode, (uint32_t)(c->knob_bz_list_rows > 0 && c->knob_bz_list_rows <= (int)GL_MAX ? c->knob_bz_list_rows : (int)GL_MAX));
@@ -2413,7 +2420,7 @@ static int bz_transform(Ctx *c, Bz2State *B, hipStream_t st, bool marks, const u
       for (int k = 0; k < GL_NCL; k++) gl_n[k] = hc[k];
       // a list that has just been built (or added to): into text order (see k_bz_gl_keys; the key is an element index below 2^30, and the
       // order inside 256 positions does not matter: they share their sectors anyway)
-      if (c->knob_bz_text_order && swept && 2 * h >= (uint32_t)c->knob_bz_lists && hc[0] > 1) {
+      if (c->knob_bz_text_order && swept && 2 * h >= lists_from && hc[0] > 1) {
         hipLaunchKernelGGL(k_bz_gl_keys, dim3((hc[0] + 255) / 256), dim3(256), 0, st, nxt.s, hc[0], B->gl_k0.as<uint32_t>());
         if (radix_sort_pairs(c, st, B->gl_st.p, B->gl_st_bytes, B->gl_k0.as<uint32_t>(), B->gl_k1.as<uint32_t>(), nxt.s, B->gl_v.p, sizeof(GlSmall), (size_t)hc[0], 8, 30)) return ZADA_E_HIP;
         BZ_HIP(hipMemcpyAsync(nxt.s, B->gl_v.p, sizeof(GlSmall) * (size_t)hc[0], hipMemcpyDeviceToDevice, st));

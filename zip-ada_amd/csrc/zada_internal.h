@@ -298,8 +298,9 @@ struct Ctx {
   int knob_bz_text_order = 1;       // BZip2: the group lists of the late sort rounds in text order (one library radix sort per build)
   int knob_bz_tail_pct = 0;         // BZip2: share of the last pass that the last (short) batch of a pipelined call takes
   int knob_bz_batch_melems = 768;   // BZip2: Mi RLE_1 bytes (summed over the sub-blocks) one batch of blocks may hold
-  int knob_bz_lists = 8;            // BZip2 rotation sort: from this prefix length on, sub-blocks whose unsorted groups have at most 8 192 rows ("bz_list_rows") leave the
-                                    // full sweeps for per-group sorts driven by a list (0 = never: every round sweeps)
+  int knob_bz_lists = -1;           // BZip2 rotation sort: from this prefix length on, sub-blocks whose unsorted groups have at most 8 192 rows ("bz_list_rows") leave the
+                                    // full sweeps for per-group sorts driven by a list (0 = never: every round sweeps; -1 = 16 for a batch that holds a stream's blocks -- a sub-block of 300 000 bytes and more --,
+                                    // 8 for small entries' sub-blocks)
   int knob_bz_pipeline = 1;         // BZip2: the transforms of a batch of sub-blocks run next to the entropy stage of the batch before (0: one batch at a time)
   int knob_bz_list_rows = 0;        // BZip2: a sub-block leaves the sweeps when its unsorted groups have at most this many rows (0 = 8 192, the most a workgroup sorts)
   int knob_bz_split = 1;            // BZip2 entropy search: the long sub-blocks' four chains on four workgroups (0: one workgroup per sub-block)
